@@ -1,0 +1,114 @@
+"""Pins the CPU oracle (oracle/pws_oracle.c) against golden vectors produced by the reference itself
+(tests/golden/make_golden.py imports /root/reference on CPU; the reference has no tests of its own).
+fp32 tolerances: the oracle sums in a different order than ATen/oneDNN, so element errors are
+a few ulp of the accumulated magnitude; bounds below are absolute and stated per check.
+"""
+import numpy as np
+import pytest
+
+from pwstablenet_amd import synth
+
+
+def _csum(a):
+    a = np.asarray(a, dtype=np.float64)
+    return np.array([a.sum(), np.abs(a).sum(), np.abs(a).max()])
+
+
+CONV_CASES = [("c5s1", "conv", 1, 2, "lrelu"), ("c3s2", "conv", 2, 1, "lrelu"), ("c3s1", "conv", 1, 1, "lrelu"),
+              ("c2s1", "conv", 1, 0, "lrelu"), ("c1s1", "conv", 1, 0, "lrelu"), ("c3s1t", "conv", 1, 1, "tanh"),
+              ("t4s2", "convT", 2, 1, "relu"), ("t3s1", "convT", 1, 1, "relu")]
+
+
+@pytest.mark.parametrize("tag,kind,s,p,act", CONV_CASES)
+def test_conv_cases(oracle, ops_golden, tag, kind, s, p, act):
+    g = ops_golden
+    a = {"lrelu": oracle.ACT_LRELU, "relu": oracle.ACT_RELU, "tanh": oracle.ACT_TANH}[act]
+    fn = oracle.conv2d if kind == "conv" else oracle.conv_transpose2d
+    y = fn(g["conv_%s_x" % tag], g["conv_%s_w" % tag], g["conv_%s_b" % tag], s, p, a)
+    ref = g["conv_%s_y" % tag]
+    assert y.shape == ref.shape
+    np.testing.assert_allclose(y, ref, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("tag", ["gs_small", "gs_mid", "gs_gray"])
+@pytest.mark.parametrize("ac", [0, 1])
+def test_grid_sample_fwd_bwd(oracle, ops_golden, tag, ac):
+    g = ops_golden
+    img, grid, gout = g[tag + "_img"], g[tag + "_grid"], g[tag + "_gout"]
+    out = oracle.grid_sample_fwd(img, grid, bool(ac))
+    # conditioning: the pixel coordinate (g+1)*W/2 carries ~W/2 * 2^-24 px of rounding whatever the
+    # operation order (3.9e-6 px at W=65), times |d image/d px| (white noise here, up to ~4) => 2e-5
+    np.testing.assert_allclose(out, g["%s_out_ac%d" % (tag, ac)], rtol=0, atol=2e-5)
+    gi, gg = oracle.grid_sample_bwd(gout, img, grid, bool(ac))
+    np.testing.assert_allclose(gi, g["%s_ginput_ac%d" % (tag, ac)], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(gg, g["%s_ggrid_ac%d" % (tag, ac)], rtol=0, atol=1e-3)  # terms are O(C*W/2*|v|) ~ 1e2
+
+
+def test_grid_sample_empty(oracle):
+    out = oracle.grid_sample_fwd(np.zeros((0, 3, 4, 4), np.float32), np.zeros((0, 4, 4, 2), np.float32))
+    assert out.shape == (0, 3, 4, 4)
+
+
+def test_affine_grid(oracle, ops_golden):
+    g = ops_golden
+    for ac in (0, 1):
+        out = oracle.affine_grid(g["ag_theta"], 12, 20, bool(ac))
+        np.testing.assert_allclose(out, g["ag_out_ac%d" % ac], rtol=0, atol=1e-6)
+    out = oracle.affine_grid(g["ag_theta"], 256, 256, False)
+    np.testing.assert_allclose(out[:, ::16, ::16], g["ag_out256_ac0_sub"], rtol=0, atol=2e-6)
+
+
+def test_upsample_then_warp_720p(oracle, ops_golden):
+    """main_new.py:706-716: field 256x256 -> UpsamplingBilinear2d(720,1280) -> grid_sample of the frame."""
+    g = ops_golden
+    field = g["up_field"]  # 1,256,256,2
+    up = oracle.upsample_bilinear_ac(np.ascontiguousarray(field.transpose(0, 3, 1, 2)), 720, 1280)
+    up = np.ascontiguousarray(up.transpose(0, 2, 3, 1))
+    np.testing.assert_allclose(up[:, ::9, ::16], g["up_out_sub"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(_csum(up)[:2], g["up_out_csum"][:2], rtol=1e-6)
+    frame = synth.make_frames(1, 3, 720, 1280, seed=99)
+    warped = oracle.grid_sample_fwd(frame, up, False)
+    # frames are 0..255 and the coordinate at W=1280 carries ~8e-5 px of rounding: 1e-2 abs here is
+    # 8e-5 on frames scaled to [-1,1] (north_star's bound is 1e-3 on that scale)
+    np.testing.assert_allclose(warped[:, :, ::9, ::16], g["up_warp_sub"], rtol=0, atol=1e-2)
+    np.testing.assert_allclose(_csum(warped)[1], g["up_warp_csum"][1], rtol=1e-6)
+
+
+def test_adam(oracle, ops_golden):
+    g = ops_golden
+    p = g["adam_p0"].copy()
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    for step in range(3):
+        oracle.adam_step(p, np.ascontiguousarray(g["adam_grads"][step]), m, v, 1e-2, 0.5, 0.999, 1e-8, step + 1)
+        np.testing.assert_allclose(p, g["adam_p%d" % (step + 1)], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("tag,kind,ngf,n", [("W1_g16", "W1", 16, 2), ("W2_g16", "W2", 16, 1),
+                                            ("W1_g64", "W1", 64, 2), ("W2_g64", "W2", 64, 2)])
+def test_netg_forward(oracle, netg_golden, tag, kind, ngf, n):
+    """Whole generator (lib/networks_cascading.py:152-237), training-mode outputs of all three stages
+    plus inference-mode equality, against the reference's outputs."""
+    g = netg_golden
+    params = [v for _, v in synth.make_weights(kind, seed=123, ngf=ngf)]
+    x = synth.make_window(n, 31, 256, seed=123)
+    r = oracle.netg_forward(params, x, is_training=True, ngf=ngf, probes=True)
+    np.testing.assert_allclose(r["thetas"][0], g[tag + "_theta1"], rtol=0, atol=2e-5)
+    frames = synth.make_frames(n, 3, 256, 256, seed=321)
+    for k in range(3):
+        grid = r["grids"][k]
+        # warp-field max-abs error (normalised coordinates): bound 2e-5 (measured 5e-7 W1, 4.5e-6 W2)
+        np.testing.assert_allclose(grid[:, ::4, ::4], g["%s_grid%d_sub" % (tag, k)], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(_csum(grid)[1], g["%s_grid%d_csum" % (tag, k)][1], rtol=2e-6)
+        np.testing.assert_allclose(_csum(r["resid"][k])[1], g["%s_resid%d_csum" % (tag, k)][1], rtol=2e-5)
+        warped = oracle.grid_sample_fwd(frames, grid, False)
+        # warped frames, 0..255 scale: north_star's 1e-3 is on frames scaled to [-1,1] => 0.1275 here
+        np.testing.assert_allclose(warped[:, :, ::4, ::4], g["%s_warp%d_sub" % (tag, k)], rtol=0, atol=0.05)
+    if ngf <= 16:
+        np.testing.assert_allclose(r["grids"][2], g[tag + "_grid2_full"], rtol=0, atol=2e-5)
+    for name in ("x11", "x14", "x18"):
+        want = g["%s_act_%s_csum" % (tag, name)]
+        got = r["probes"][name]
+        np.testing.assert_allclose(got[1], want[1], rtol=2e-6)
+    # inference mode returns exactly the stage-3 field (reference :237)
+    ri = oracle.netg_forward(params, x, is_training=False, ngf=ngf)
+    assert np.array_equal(ri["grids"][0], r["grids"][2])
