@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: stabilized frames/s = frames for which ``field = netG(window, False)`` AND
+``warped = grid_sample(frame, field)`` completed (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W            # N=1 directly; N>1 under torch.distributed.run
+
+Workload at every N: BASELINE.json configs[1] per GPU -- batch=8 windows of 31x256x256 (fp32) through the HIP
+generator + HIP grid_sample of 8 RGB 256x256 frames; inputs are synthetic and resident in HBM before the timed
+region.  Frames are independent units, so ranks shard them with NO collective (weak scaling: 8 frames per GPU
+per step); the only collectives are the timing barrier and the MAX over ranks of the elapsed time.
+
+One JSON line on rank 0.  Besides the driver's contract it carries
+  roofline      -- the dominant kernel (most GPU time in the timed region), from hipEvents recorded around every
+                   launch of the K timed steps on the launch stream (pws_prof_* hooks of the C ABI);
+  roofline_grid_sample -- same for grid_sample_fwd_kernel (HBM-bound, north_star's 40 % target), measured on a
+                   larger batch so that the launch is not latency-bound;
+  cpu_baseline  -- the hot path on this box's host cores (PyTorch-CPU restatement of the reference graph, i.e. the
+                   ops the reference executes; oracle/torch_ref.py), bounded sample, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak (no TF32 on gfx950)
+PEAK_HBM_GBS = 8000.0      # HBM3E spec peak
+GFLOP_PER_FRAME_INFER = 94.48  # de-duplicated inference forward
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step (configs[1]: 8)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket launches with hipEvents in the timed region")
+    ap.add_argument("--gs-batch", type=int, default=256, help="frames in the grid_sample roofline launch")
+    return ap.parse_args()
+
+
+def cpu_baseline(batch_unused):
+    """Hot path on the host cores: netG(window, False) + grid_sample, N=1, min over a bounded number of runs."""
+    import torch
+    from oracle import torch_ref
+    from pwstablenet_amd import synth
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    params = [torch.from_numpy(v) for _, v in synth.make_weights("W1", seed=123, ngf=64)]
+    x = torch.from_numpy(synth.noise_window(1, 31, 256, seed=123))
+    fr = torch.from_numpy(synth.make_frames(1, 3, 256, 256, seed=321))
+    torch_ref.stabilize_step(params, x, fr)  # warm-up
+    best, runs, t_all = 1e9, 0, time.time()
+    while runs < 10 and (time.time() - t_all) < 20.0:
+        t0 = time.time()
+        torch_ref.stabilize_step(params, x, fr)
+        best = min(best, time.time() - t0)
+        runs += 1
+    return {"value": round(1.0 / best, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "N=1 frame: PyTorch-CPU restatement of netG(x,False)+grid_sample (oracle/torch_ref.py), "
+                      "min of %d runs after 1 warm-up, %d torch threads" % (runs, torch.get_num_threads())}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    if world != a.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from pwstablenet_amd import functional as PF
+    from pwstablenet_amd import hipabi as A
+    from pwstablenet_amd import synth
+    from pwstablenet_amd.lib.networks_cascading import define_G
+
+    B = a.batch
+    net = define_G(31, 2, 64, "normal", 0.02)
+    net.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in synth.make_weights("W1", seed=123, ngf=64)})
+    net = net.to(dev)
+    x = torch.from_numpy(synth.noise_window(B, 31, 256, seed=123 + rank)).to(dev)
+    frames = torch.from_numpy(synth.make_frames(B, 3, 256, 256, seed=321 + rank)).to(dev)
+
+    def step():
+        with torch.no_grad():
+            grid = net(x, False)
+            return PF.grid_sample(frames, grid)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    prof = not a.no_prof
+    A.lib().pws_prof_enable(1 if prof else 0)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    A.lib().pws_prof_enable(0)
+    recs = A.prof_collect(1 << 16) if prof else []
+    barrier()
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        fps = world * B * a.steps / elapsed
+        line = {
+            "metric": "stabilized frames/sec at 256x256 (netG fp32 + grid_sample), whole job",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: batch=8 256x256 inference per GPU, fp32 HIP conv + grid_sample; "
+                                   "frame-sharded, no collective", "frames_per_gpu_per_step": B,
+                       "window": "31x256x256", "frame": "3x256x256", "weights": "synthetic W1 (pwstablenet_amd.synth)"},
+            "netg_tflops_per_gpu": round(fps / world * GFLOP_PER_FRAME_INFER / 1e3, 2),
+            "netg_frac_fp32_peak": round(fps / world * GFLOP_PER_FRAME_INFER / 1e3 / PEAK_FP32_TFLOPS, 4),
+        }
+        if recs:
+            agg = {}
+            for name, tag, fl, by, ms in recs:
+                e = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+                e[0] += 1; e[1] += fl; e[2] += by; e[3] += ms  # noqa: E702
+            dom = max(agg.items(), key=lambda kv: kv[1][3])
+            name, (cnt, fl, by, ms) = dom
+            ach = fl / (ms * 1e-3) / 1e12
+            line["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS,
+                                "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                                "launches": cnt, "avg_launch_us": round(1e3 * ms / cnt, 2),
+                                "flops_per_launch": fl / cnt}
+            tot_ms = sum(v[3] for v in agg.values())
+            line["kernel_time_share"] = {k: round(v[3] / tot_ms, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][3])}
+            line["kernel_tflops"] = {k: round(v[1] / (v[3] * 1e-3) / 1e12, 2) for k, v in agg.items() if v[3] > 0 and "conv" in k}
+            line["gpu_busy_frac"] = round(tot_ms * 1e-3 / elapsed, 4)
+        # grid_sample roofline on a batch large enough not to be launch-latency-bound
+        GB = a.gs_batch
+        big = torch.rand((GB, 3, 256, 256), device=dev) * 255
+        theta = torch.tensor([1, 0, 0, 0, 1, 0], device=dev, dtype=torch.float32).repeat(GB, 1)
+        theta = theta + 0.05 * torch.randn_like(theta)
+        grid = PF.affine_grid(theta, (GB, 3, 256, 256)) + 0.02 * torch.randn((GB, 256, 256, 2), device=dev)
+        with torch.no_grad():
+            for _ in range(3):
+                PF.grid_sample(big, grid)
+            torch.cuda.synchronize()
+            A.lib().pws_prof_enable(1)
+            for _ in range(10):
+                PF.grid_sample(big, grid)
+            A.lib().pws_prof_enable(0)
+        r = [x_ for x_ in A.prof_collect() if x_[0] == "grid_sample_fwd_kernel"]
+        ms = sum(x_[4] for x_ in r) / len(r)
+        gbs = r[0][3] / (ms * 1e-3) / 1e9
+        line["roofline_grid_sample"] = {"kernel": "grid_sample_fwd_kernel", "bound": "hbm", "achieved": round(gbs, 1),
+                                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                        "traffic": None, "avg_launch_us": round(1e3 * ms, 2),
+                                        "bytes_per_launch": r[0][3], "frames_per_launch": GB}
+        del big, grid
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(B)
+            line["gpu_over_cpu"] = round(fps / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,168 @@
+/*
+ * pwstable.h -- C ABI of libpwstable_hip.so: the MI355X (gfx950) implementation of PWStableNet's hot path.
+ *
+ * This is the drop-in boundary.  Plain pointers and sizes only (no torch types); every pointer is a
+ * DEVICE pointer unless stated otherwise; every launch goes to the caller's HIP stream (`stream` is a
+ * hipStream_t passed as void*, NULL = the default stream); nothing here allocates, frees or
+ * synchronises -- scratch comes from the caller (`ws`), sized by the matching *_workspace_bytes().
+ * Return value: 0 on success, negative errno-style code otherwise (pws_last_error() has the text).
+ * Re-entrant per stream; thread-safe (no global mutable state besides the thread-local error string).
+ *
+ * Reference interfaces replaced (paths relative to the mindazhao/PWStableNet checkout; the reference has
+ * no native code -- each entry point replaces the PyTorch/ATen op the reference dispatches at that line):
+ *   pws_netg_forward              UnetGenerator.forward            lib/networks_cascading.py:152-237
+ *   pws_conv2d_fwd                down / down_bottom / up / up_bottom blocks        :245-350
+ *                                 (nn.Conv2d :248,269,274,285 ; nn.ConvTranspose2d :306,330,339 ;
+ *                                  LeakyReLU :250,271 ; ReLU :305,328 ; torch.cat :296,321,346-350)
+ *   pws_theta_head_fwd            flatten + linear -> theta        :148-149,162-163,186-187,208-209
+ *   pws_field_head_fwd            out conv + tanh + tanh, permute, + F.affine_grid  :128,164,174,235-237
+ *   pws_affine_grid               F.affine_grid                    :164,188,210 ; main_new.py:195
+ *   pws_grid_sample_fwd / _bwd    F.grid_sample (+ autograd)       main_new.py:106,109,116,118,197,214,716
+ *   pws_upsample_bilinear_ac      UpsamplingBilinear2d(size=...)   main_new.py:706-710
+ *   pws_upsample_grid_sample_fwd  the two above fused (720p path)  main_new.py:706-716
+ *   pws_adam_step                 optim.Adam(...).step()           main_new.py:63,216
+ *   pws_pack_* / pws_netg_pack_weights   state_dict (OIHW / IOHW) -> kernel layout; main_new.py:60,471
+ *
+ * Layouts.  Frames / images: NCHW fp32 as in the reference.  Warp fields: N,H,W,2 fp32 (x then y,
+ * normalised to [-1,1]) as in the reference.  Activations inside the generator: NHWC fp32 with an
+ * explicit pixel stride `ld` (floats), so a torch.cat of feature maps is a list of sources, never a copy.
+ */
+#ifndef PWSTABLE_H
+#define PWSTABLE_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PWS_VERSION 1
+
+#define PWS_OK 0
+#define PWS_EINVAL (-22) /* bad argument / unsupported shape */
+#define PWS_ENOMEM (-12) /* caller's workspace too small */
+#define PWS_EHIP (-5)    /* HIP runtime reported an error at launch */
+
+typedef void *pws_stream_t; /* hipStream_t */
+
+int pws_version(void);
+const char *pws_last_error(void); /* thread-local, never NULL */
+/* Number of compute units / XCDs the library sees on the current device (diagnostics). */
+int pws_device_info(int *compute_units, int *arch_is_gfx950);
+
+/* ---------------------------------------------------------------- activations fused into conv epilogues */
+#define PWS_ACT_NONE 0
+#define PWS_ACT_LRELU 1 /* LeakyReLU(0.2) */
+#define PWS_ACT_RELU 2
+
+/* ---------------------------------------------------------------- conv kinds (what the generator uses) */
+#define PWS_CONV_K3S1 0  /* Conv2d k3 s1 p1            (down_bottom*.conv_same)                 */
+#define PWS_CONV_K3S2 1  /* Conv2d k3 s2 p1            (down*, down_bottom*.mpconv)             */
+#define PWS_CONV_K5S1 2  /* Conv2d k5 s1 p2            (transfer)                               */
+#define PWS_CONVT_K3S1 3 /* ConvTranspose2d k3 s1 p1   (up_bottom*.conv_same) == flipped conv   */
+#define PWS_CONVT_K4S2 4 /* ConvTranspose2d k4 s2 p1   (up*, up_bottom*.mpconv), 4 sub-pixel 2x2 convs */
+#define PWS_CONV_K2S1P0 5 /* Conv2d k2 s1 p0 (flatten) -- packing only; run by pws_theta_head_fwd */
+#define PWS_CONV_K1 6     /* Conv2d k1 (linear)        -- packing only                           */
+#define PWS_CONV_K3S1_OUT 7 /* Conv2d k3 s1 p1, Cout=2 (out) -- packing only; run by pws_field_head_fwd */
+
+/* Packed size (floats) of one layer's weight for the kernels: [class][tap][cin padded to 16][cout]. */
+size_t pws_packed_weight_floats(int kind, int cin, int cout);
+/* w_torch: OIHW (conv kinds) or IOHW (convT kinds), dense.  w_packed: pws_packed_weight_floats() floats. */
+int pws_pack_conv_weight(const float *w_torch, float *w_packed, int kind, int cin, int cout,
+                         pws_stream_t stream);
+
+/* One NHWC source of a (virtually concatenated) conv input: `channels` channels starting at `ptr`,
+ * consecutive pixels `ld` floats apart.  ptr 16-byte aligned, ld % 4 == 0, channels % 16 == 0. */
+typedef struct pws_src {
+    const float *ptr;
+    int channels;
+    int ld;
+} pws_src;
+
+typedef struct pws_conv_args {
+    int kind;         /* PWS_CONV_K3S1 | K3S2 | K5S1 | CONVT_K3S1 | CONVT_K4S2 */
+    int n, h, w;      /* batch and INPUT height/width */
+    int nsrc;         /* 1..4 sources, concatenated along channels in this order */
+    pws_src src[4];
+    int src_nchw;     /* 1: src[0] is a dense NCHW tensor with `channels` channels (any count); nsrc==1 */
+    int cout;         /* multiple of 4 */
+    const float *w_packed;
+    const float *bias; /* cout floats or NULL */
+    int act;          /* PWS_ACT_* */
+    float *out;       /* NHWC, output height/width implied by kind */
+    int out_ld;       /* pixel stride of out in floats (>= cout) */
+} pws_conv_args;
+
+int pws_conv2d_fwd(const pws_conv_args *args, pws_stream_t stream);
+
+/* theta = LReLU(W2 . LReLU(W1 . vec(x) + b1) + b2)   x: NHWC [n,2,2,c] (ld == c), theta: [n,6].
+ * w_flat packed as PWS_CONV_K2S1P0 (c -> hidden), w_lin packed as PWS_CONV_K1 (hidden -> 6).
+ * ws: n*hidden floats of scratch. */
+int pws_theta_head_fwd(const float *x, int n, int c, int hidden, const float *w_flat, const float *b_flat,
+                       const float *w_lin, const float *b_lin, float *ws, float *theta, pws_stream_t stream);
+
+/* field = tanh(tanh(conv3x3(x; 2 outputs) + b)) as N,H,W,2, plus affine_grid(theta) when theta != NULL.
+ * x: NHWC [n,h,w,c] pixel stride ld.  w_out packed as PWS_CONV_K3S1_OUT.  resid (nullable) receives the
+ * field without the affine part; grid (nullable) receives resid + affine. */
+int pws_field_head_fwd(const float *x, int ld, int n, int h, int w, int c, const float *w_out,
+                       const float *b_out, const float *theta, int align_corners, float *resid, float *grid,
+                       pws_stream_t stream);
+
+/* F.affine_grid(theta[n,2,3], (n,*,h,w)) -> grid[n,h,w,2] */
+int pws_affine_grid(const float *theta, float *grid, int n, int h, int w, int align_corners,
+                    pws_stream_t stream);
+
+/* F.grid_sample(input[n,c,h,w], grid[n,ho,wo,2]) -> out[n,c,ho,wo]; bilinear, zeros padding. */
+int pws_grid_sample_fwd(const float *input, const float *grid, float *out, int n, int c, int h, int w, int ho,
+                        int wo, int align_corners, pws_stream_t stream);
+/* Backward.  ginput (nullable): [n,c,h,w], OVERWRITTEN (zeroed then scatter-added with atomics);
+ * ggrid (nullable): [n,ho,wo,2], overwritten. */
+int pws_grid_sample_bwd(const float *gout, const float *input, const float *grid, float *ginput, float *ggrid,
+                        int n, int c, int h, int w, int ho, int wo, int align_corners, pws_stream_t stream);
+
+/* Bilinear resize with align_corners=True of an NCHW tensor (reference resizes the field as NCHW). */
+int pws_upsample_bilinear_ac(const float *in, float *out, int n, int c, int h, int w, int ho, int wo,
+                             pws_stream_t stream);
+/* Fused 720p path: field[n,fh,fw,2] is resized on the fly (align_corners=True) to (h,w) and applied to
+ * input[n,c,h,w] -> out[n,c,h,w]; the resized field is never materialised. */
+int pws_upsample_grid_sample_fwd(const float *input, const float *field, float *out, int n, int c, int h,
+                                 int w, int fh, int fw, int align_corners, pws_stream_t stream);
+
+/* Adam (no weight decay / amsgrad) on a flat fp32 buffer, in place; step counts from 1. */
+int pws_adam_step(float *p, const float *g, float *m, float *v, size_t count, float lr, float beta1,
+                  float beta2, float eps, int step, pws_stream_t stream);
+
+/* ---------------------------------------------------------------- whole generator */
+/* Floats needed for all 46 packed layer weights + 46 biases of a generator (input_nc, ngf). */
+size_t pws_netg_packed_floats(int input_nc, int ngf);
+/* params: HOST array of 92 DEVICE pointers in state-dict order (weight, bias per layer; torch layouts). */
+int pws_netg_pack_weights(const float *const *params, float *packed, int input_nc, int ngf,
+                          pws_stream_t stream);
+size_t pws_netg_workspace_bytes(int n, int input_nc, int ngf, int is_training);
+/* x: [n,input_nc,256,256] NCHW.  grids: is_training ? [3][n,256,256,2] : [n,256,256,2] (stage 3).
+ * resid: is_training ? [3][n,256,256,2] : ignored (may be NULL).  thetas (nullable): [3][n,6]. */
+int pws_netg_forward(const float *packed, const float *x, int n, int input_nc, int ngf, int is_training,
+                     int align_corners, void *ws, size_t ws_bytes, float *grids, float *resid, float *thetas,
+                     pws_stream_t stream);
+
+/* ---------------------------------------------------------------- measurement hooks (bench / tests only)
+ * When enabled, every kernel launch of this library is bracketed by two hipEvents on the launch stream and
+ * tagged with its algorithmic work.  Process-global and not thread-safe: a measurement facility, off by
+ * default, never enabled by the product path. */
+typedef struct pws_prof_record {
+    int kernel_id;  /* index for pws_prof_kernel_name() */
+    int tag;        /* caller-defined (the generator executor passes the layer index) */
+    double flops;   /* algorithmic floating-point operations of this launch */
+    double bytes;   /* algorithmic HBM bytes of this launch (each tensor touched once) */
+    float ms;       /* hipEventElapsedTime between the two events */
+} pws_prof_record;
+int pws_prof_enable(int on);
+/* Synchronises the recorded events, copies up to max_records records (launch order), clears the log,
+ * returns the number of records that were pending (may exceed max_records) or a negative error. */
+int pws_prof_collect(pws_prof_record *out, int max_records);
+const char *pws_prof_kernel_name(int kernel_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PWSTABLE_H */

@@ -1,0 +1,72 @@
+// Internal helpers shared by the HIP translation units of libpwstable_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/pwstable.h"
+
+namespace pws {
+
+void set_error(const char *fmt, ...);  // abi.cpp (thread-local buffer)
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return PWS_EHIP;
+    }
+    return PWS_OK;
+}
+
+#define PWS_REQUIRE(cond, ...)          \
+    do {                                \
+        if (!(cond)) {                  \
+            pws::set_error(__VA_ARGS__); \
+            return PWS_EINVAL;          \
+        }                               \
+    } while (0)
+
+inline hipStream_t as_stream(pws_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int kWave = 64;   // CDNA wavefront
+constexpr int kXcds = 8;    // MI355X: 8 XCDs, block b is dispatched to XCD b % 8
+
+// Bijective XCD-aware remap of a 1-D block id: consecutive logical ids [k*chunk, (k+1)*chunk) run on the
+// same XCD (same private L2), so neighbouring tiles share halo lines / gather footprints in one L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
+    const unsigned q = nblocks / kXcds, r = nblocks % kXcds;
+    const unsigned xcd = bid % kXcds, slot = bid / kXcds;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+// Kernel ids for the measurement hooks (pws_prof_*).
+enum KernelId {
+    KID_CONV_K3S1_BIG = 0, KID_CONV_K3S1_SMALL, KID_CONV_K3S2_BIG, KID_CONV_K3S2_SMALL, KID_CONV_K5S1, KID_CONVT4_BIG,
+    KID_CONVT4_SMALL, KID_THETA_HEAD, KID_FIELD_HEAD, KID_GRID_SAMPLE_FWD, KID_GRID_SAMPLE_BWD, KID_UPSAMPLE_GRID_SAMPLE_FWD,
+    KID_UPSAMPLE, KID_AFFINE_GRID, KID_ADAM, KID_PACK, KID_COUNT
+};
+extern bool g_prof_on;
+extern int g_prof_tag;
+void prof_begin(int kernel_id, double flops, double bytes, hipStream_t st);
+void prof_end(hipStream_t st);
+struct ProfScope {  // brackets one launch with events when profiling is enabled; free otherwise
+    hipStream_t st;
+    bool on;
+    ProfScope(int kernel_id, double flops, double bytes, hipStream_t s) : st(s), on(g_prof_on) {
+        if (on) prof_begin(kernel_id, flops, bytes, st);
+    }
+    ~ProfScope() {
+        if (on) prof_end(st);
+    }
+};
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == PWS_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
+    if (act == PWS_ACT_RELU) return v > 0.f ? v : 0.f;
+    return v;
+}
+
+}  // namespace pws

@@ -1,0 +1,306 @@
+// Bilinear warp kernels (HBM-bound): F.grid_sample forward / backward (bilinear, zeros padding), F.affine_grid,
+// UpsamplingBilinear2d (align_corners=True) and the fused "resize the 256x256 field to the frame size and
+// apply it" path of the reference's video loop (reference main_new.py:106-118,197,706-716).
+//
+// Layout: frames NCHW fp32, fields N,H,W,2 fp32 -- both exactly as the reference hands them over.
+// Mapping: one lane owns PPT consecutive output pixels of a row, so the field read (8*PPT B/lane) and each
+// channel-plane store (4*PPT B/lane) are fully coalesced; the 4*C taps per pixel are gathers that hit L1/L2
+// because neighbouring lanes sample neighbouring source pixels when the field is smooth.  Workgroup ids are
+// remapped so that one XCD (one private L2) walks a contiguous range of rows of the same image.
+// Algorithmic traffic (C=3): fwd 8 (field) + 12 (frame) + 12 (out) = 32 B/pixel.
+#include "common.h"
+
+namespace pws {
+
+struct Taps {
+    int o00, o01, o10, o11;  // clamped linear offsets inside one channel plane
+    float w00, w01, w10, w11;  // bilinear weights, zeroed for out-of-range taps
+    float wx0, wx1, wy0, wy1;
+    bool v00, v01, v10, v11;
+};
+
+__device__ __forceinline__ float unnormalize(float g, int size, bool align_corners) {
+    // align_corners=False: ((g+1)*size-1)/2 ; True: (g+1)/2*(size-1) -- evaluated with one rounding
+    return align_corners ? fmaf(g, 0.5f * (float)(size - 1), 0.5f * (float)(size - 1))
+                         : fmaf(g, 0.5f * (float)size, 0.5f * (float)(size - 1));
+}
+
+__device__ __forceinline__ Taps make_taps(float gx, float gy, int H, int W, bool ac) {
+    Taps t;
+    const float ix = unnormalize(gx, W, ac), iy = unnormalize(gy, H, ac);
+    const float fx = floorf(ix), fy = floorf(iy);
+    // NaN / huge coordinates: the float->int conversion saturates, every tap is then out of range -> 0
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    t.wx1 = ix - fx, t.wx0 = 1.f - t.wx1, t.wy1 = iy - fy, t.wy0 = 1.f - t.wy1;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    t.v00 = vy0 && vx0, t.v01 = vy0 && vx1, t.v10 = vy1 && vx0, t.v11 = vy1 && vx1;
+    const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+    const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+    t.o00 = cy0 * W + cx0, t.o01 = cy0 * W + cx1, t.o10 = cy1 * W + cx0, t.o11 = cy1 * W + cx1;
+    t.w00 = t.v00 ? t.wx0 * t.wy0 : 0.f;
+    t.w01 = t.v01 ? t.wx1 * t.wy0 : 0.f;
+    t.w10 = t.v10 ? t.wx0 * t.wy1 : 0.f;
+    t.w11 = t.v11 ? t.wx1 * t.wy1 : 0.f;
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------- forward
+template <int PPT>
+__global__ void __launch_bounds__(256) grid_sample_fwd_kernel(const float *__restrict__ input,
+                                                              const float *__restrict__ grid, float *__restrict__ out,
+                                                              int C, int H, int W, int HoWo, size_t total_groups,
+                                                              unsigned nblocks, int ac) {
+    const unsigned blk = xcd_remap(blockIdx.x, nblocks);
+    const size_t gidx = (size_t)blk * 256 + threadIdx.x;  // group of PPT consecutive output pixels
+    if (gidx >= total_groups) return;
+    const size_t p0 = gidx * PPT;  // HoWo % PPT == 0, so a group never straddles two images
+    const int n = (int)(p0 / HoWo);
+    const int hw = (int)(p0 % HoWo);
+    float g[2 * PPT];
+    if constexpr (PPT == 4) {
+        const float4 a = *reinterpret_cast<const float4 *>(grid + p0 * 2);
+        const float4 b = *reinterpret_cast<const float4 *>(grid + p0 * 2 + 4);
+        g[0] = a.x, g[1] = a.y, g[2] = a.z, g[3] = a.w, g[4] = b.x, g[5] = b.y, g[6] = b.z, g[7] = b.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2 * PPT; ++i) g[i] = grid[p0 * 2 + i];
+    }
+    Taps t[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) t[i] = make_taps(g[2 * i], g[2 * i + 1], H, W, ac != 0);
+    const size_t plane = (size_t)H * W;
+    for (int c = 0; c < C; ++c) {
+        const float *ip = input + ((size_t)n * C + c) * plane;
+        float r[PPT];
+#pragma unroll
+        for (int i = 0; i < PPT; ++i)
+            r[i] = ip[t[i].o00] * t[i].w00 + ip[t[i].o01] * t[i].w01 + ip[t[i].o10] * t[i].w10 + ip[t[i].o11] * t[i].w11;
+        float *op = out + ((size_t)n * C + c) * HoWo + hw;
+        if constexpr (PPT == 4) {
+            *reinterpret_cast<float4 *>(op) = make_float4(r[0], r[1], r[2], r[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) op[i] = r[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- backward
+// One lane per output pixel.  grad wrt the field is a per-pixel reduction over channels (no atomics);
+// grad wrt the frame is a 4*C-tap scatter-add (fp32 atomics in L2; order-dependent in the last ulps).
+__global__ void __launch_bounds__(256) grid_sample_bwd_kernel(const float *__restrict__ gout,
+                                                              const float *__restrict__ input,
+                                                              const float *__restrict__ grid, float *__restrict__ ginput,
+                                                              float *__restrict__ ggrid, int C, int H, int W, int HoWo,
+                                                              size_t total, unsigned nblocks, int ac) {
+    const unsigned blk = xcd_remap(blockIdx.x, nblocks);
+    const size_t p = (size_t)blk * 256 + threadIdx.x;
+    if (p >= total) return;
+    const int n = (int)(p / HoWo);
+    const int hw = (int)(p % HoWo);
+    const float2 g = *reinterpret_cast<const float2 *>(grid + p * 2);
+    const Taps t = make_taps(g.x, g.y, H, W, ac != 0);
+    const size_t plane = (size_t)H * W;
+    float gix = 0.f, giy = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float go = gout[((size_t)n * C + c) * HoWo + hw];
+        const float *ip = input + ((size_t)n * C + c) * plane;
+        const float v00 = t.v00 ? ip[t.o00] : 0.f, v01 = t.v01 ? ip[t.o01] : 0.f;
+        const float v10 = t.v10 ? ip[t.o10] : 0.f, v11 = t.v11 ? ip[t.o11] : 0.f;
+        gix += go * ((v01 - v00) * t.wy0 + (v11 - v10) * t.wy1);
+        giy += go * ((v10 - v00) * t.wx0 + (v11 - v01) * t.wx1);
+        if (ginput) {
+            float *gp = ginput + ((size_t)n * C + c) * plane;
+            if (t.v00) atomicAdd(gp + t.o00, go * t.w00);
+            if (t.v01) atomicAdd(gp + t.o01, go * t.w01);
+            if (t.v10) atomicAdd(gp + t.o10, go * t.w10);
+            if (t.v11) atomicAdd(gp + t.o11, go * t.w11);
+        }
+    }
+    if (ggrid) {
+        const float sx = ac ? 0.5f * (float)(W - 1) : 0.5f * (float)W;
+        const float sy = ac ? 0.5f * (float)(H - 1) : 0.5f * (float)H;
+        *reinterpret_cast<float2 *>(ggrid + p * 2) = make_float2(gix * sx, giy * sy);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- affine_grid
+__device__ __forceinline__ float base_coord(int j, int size, bool ac) {
+    if (ac) return size > 1 ? (2.f * j) / (float)(size - 1) - 1.f : 0.f;
+    return (2.f * j + 1.f) / (float)size - 1.f;
+}
+
+__global__ void affine_grid_kernel(const float *__restrict__ theta, float *__restrict__ grid, int H, int W, size_t total,
+                                   int ac) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    const int x_ = (int)(p % W), y_ = (int)((p / W) % H), n = (int)(p / ((size_t)W * H));
+    const float *t = theta + (size_t)n * 6;
+    const float x = base_coord(x_, W, ac != 0), y = base_coord(y_, H, ac != 0);
+    *reinterpret_cast<float2 *>(grid + p * 2) = make_float2(t[0] * x + t[1] * y + t[2], t[3] * x + t[4] * y + t[5]);
+}
+
+// ---------------------------------------------------------------------------------------------- upsample (ac=True)
+__global__ void upsample_bilinear_ac_kernel(const float *__restrict__ in, float *__restrict__ out, int H, int W, int Ho,
+                                            int Wo, float ry, float rx, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ox = (int)(i % Wo), oy = (int)((i / Wo) % Ho);
+    const size_t nc = i / ((size_t)Wo * Ho);
+    const float sy = ry * oy, sx = rx * ox;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = sy - y0, hy = 1.f - ly, lx = sx - x0, hx = 1.f - lx;
+    const float *ip = in + nc * (size_t)H * W;
+    out[i] = hy * (hx * ip[y0 * W + x0] + lx * ip[y0 * W + x1]) + ly * (hx * ip[y1 * W + x0] + lx * ip[y1 * W + x1]);
+}
+
+// ---------------------------------------------------------------------------------------------- fused 720p path
+// field [n,fh,fw,2] --(bilinear, align_corners=True, never materialised)--> per-pixel (gx,gy) --> 4-tap gather.
+template <int PPT>
+__global__ void __launch_bounds__(256) upsample_grid_sample_fwd_kernel(const float *__restrict__ input,
+                                                                       const float *__restrict__ field,
+                                                                       float *__restrict__ out, int C, int H, int W, int fh,
+                                                                       int fw, float ry, float rx, size_t total_groups,
+                                                                       unsigned nblocks, int ac) {
+    const unsigned blk = xcd_remap(blockIdx.x, nblocks);
+    const size_t gidx = (size_t)blk * 256 + threadIdx.x;
+    if (gidx >= total_groups) return;
+    const int HW = H * W;
+    const size_t p0 = gidx * PPT;
+    const int n = (int)(p0 / HW);
+    const int hw = (int)(p0 % HW);
+    const int oy = hw / W, ox0 = hw % W;  // W % PPT == 0: the group stays inside one row
+    const float sy = ry * oy;
+    const int y0 = (int)sy, y1 = y0 + (y0 < fh - 1 ? 1 : 0);
+    const float ly = sy - y0, hy = 1.f - ly;
+    const float2 *f0 = reinterpret_cast<const float2 *>(field) + ((size_t)n * fh + y0) * fw;
+    const float2 *f1 = reinterpret_cast<const float2 *>(field) + ((size_t)n * fh + y1) * fw;
+    Taps t[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const float sx = rx * (ox0 + i);
+        const int x0 = (int)sx, x1 = x0 + (x0 < fw - 1 ? 1 : 0);
+        const float lx = sx - x0, hx = 1.f - lx;
+        const float2 a = f0[x0], b = f0[x1], c = f1[x0], d = f1[x1];
+        const float gx = hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * d.x);
+        const float gy = hy * (hx * a.y + lx * b.y) + ly * (hx * c.y + lx * d.y);
+        t[i] = make_taps(gx, gy, H, W, ac != 0);
+    }
+    for (int c = 0; c < C; ++c) {
+        const float *ip = input + ((size_t)n * C + c) * HW;
+        float r[PPT];
+#pragma unroll
+        for (int i = 0; i < PPT; ++i)
+            r[i] = ip[t[i].o00] * t[i].w00 + ip[t[i].o01] * t[i].w01 + ip[t[i].o10] * t[i].w10 + ip[t[i].o11] * t[i].w11;
+        float *op = out + ((size_t)n * C + c) * HW + hw;
+        if constexpr (PPT == 4) {
+            *reinterpret_cast<float4 *>(op) = make_float4(r[0], r[1], r[2], r[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) op[i] = r[i];
+        }
+    }
+}
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
+
+}  // namespace pws
+
+using namespace pws;
+
+extern "C" int pws_grid_sample_fwd(const float *input, const float *grid, float *out, int n, int c, int h, int w, int ho,
+                                   int wo, int align_corners, pws_stream_t stream) {
+    PWS_REQUIRE(n >= 0 && c > 0 && h > 0 && w > 0 && ho > 0 && wo > 0, "pws_grid_sample_fwd: bad shape");
+    if (n == 0) return PWS_OK;
+    PWS_REQUIRE(input && grid && out, "pws_grid_sample_fwd: NULL pointer");
+    PWS_REQUIRE((size_t)h * w < (1u << 31) && (size_t)ho * wo < (1u << 31), "pws_grid_sample_fwd: plane too large");
+    const size_t total = (size_t)n * ho * wo;
+    const int howo = ho * wo;
+    // algorithmic traffic: field 8 B + out 4*C B per output pixel, frame 4*C B per input pixel; ~30 flop/px/channel
+    ProfScope prof(KID_GRID_SAMPLE_FWD, (double)total * (14.0 + 8.0 * c),
+                   (double)total * (8.0 + 4.0 * c) + 4.0 * c * (double)n * h * w, as_stream(stream));
+    if (howo % 4 == 0 && aligned16(grid) && aligned16(out)) {
+        const size_t groups = total / 4;
+        const unsigned nb = (unsigned)((groups + 255) / 256);
+        hipLaunchKernelGGL(grid_sample_fwd_kernel<4>, dim3(nb), dim3(256), 0, as_stream(stream), input, grid, out, c, h, w,
+                           howo, groups, nb, align_corners);
+    } else {
+        const unsigned nb = (unsigned)((total + 255) / 256);
+        hipLaunchKernelGGL(grid_sample_fwd_kernel<1>, dim3(nb), dim3(256), 0, as_stream(stream), input, grid, out, c, h, w,
+                           howo, total, nb, align_corners);
+    }
+    return check_launch("grid_sample_fwd_kernel");
+}
+
+extern "C" int pws_grid_sample_bwd(const float *gout, const float *input, const float *grid, float *ginput, float *ggrid,
+                                   int n, int c, int h, int w, int ho, int wo, int align_corners, pws_stream_t stream) {
+    PWS_REQUIRE(n >= 0 && c > 0 && h > 0 && w > 0 && ho > 0 && wo > 0, "pws_grid_sample_bwd: bad shape");
+    if (n == 0 || (!ginput && !ggrid)) return PWS_OK;
+    PWS_REQUIRE(gout && input && grid, "pws_grid_sample_bwd: NULL pointer");
+    PWS_REQUIRE((size_t)h * w < (1u << 31) && (size_t)ho * wo < (1u << 31), "pws_grid_sample_bwd: plane too large");
+    if (ginput) {
+        hipError_t e = hipMemsetAsync(ginput, 0, sizeof(float) * (size_t)n * c * h * w, as_stream(stream));
+        if (e != hipSuccess) {
+            set_error("pws_grid_sample_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
+            return PWS_EHIP;
+        }
+    }
+    const size_t total = (size_t)n * ho * wo;
+    const unsigned nb = (unsigned)((total + 255) / 256);
+    ProfScope prof(KID_GRID_SAMPLE_BWD, (double)total * (20.0 + 16.0 * c),
+                   (double)total * (8.0 + 4.0 * c + (ggrid ? 8.0 : 0.0)) + (ginput ? 8.0 : 4.0) * c * (double)n * h * w,
+                   as_stream(stream));
+    hipLaunchKernelGGL(grid_sample_bwd_kernel, dim3(nb), dim3(256), 0, as_stream(stream), gout, input, grid, ginput, ggrid, c,
+                       h, w, ho * wo, total, nb, align_corners);
+    return check_launch("grid_sample_bwd_kernel");
+}
+
+extern "C" int pws_affine_grid(const float *theta, float *grid, int n, int h, int w, int align_corners,
+                               pws_stream_t stream) {
+    PWS_REQUIRE(n >= 0 && h > 0 && w > 0, "pws_affine_grid: bad shape");
+    if (n == 0) return PWS_OK;
+    PWS_REQUIRE(theta && grid, "pws_affine_grid: NULL pointer");
+    const size_t total = (size_t)n * h * w;
+    hipLaunchKernelGGL(affine_grid_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), theta, grid,
+                       h, w, total, align_corners);
+    return check_launch("affine_grid_kernel");
+}
+
+extern "C" int pws_upsample_bilinear_ac(const float *in, float *out, int n, int c, int h, int w, int ho, int wo,
+                                        pws_stream_t stream) {
+    PWS_REQUIRE(n >= 0 && c > 0 && h > 0 && w > 0 && ho > 0 && wo > 0, "pws_upsample_bilinear_ac: bad shape");
+    if (n == 0) return PWS_OK;
+    PWS_REQUIRE(in && out, "pws_upsample_bilinear_ac: NULL pointer");
+    const float ry = ho > 1 ? (float)(h - 1) / (float)(ho - 1) : 0.f;
+    const float rx = wo > 1 ? (float)(w - 1) / (float)(wo - 1) : 0.f;
+    const size_t total = (size_t)n * c * ho * wo;
+    hipLaunchKernelGGL(upsample_bilinear_ac_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), in,
+                       out, h, w, ho, wo, ry, rx, total);
+    return check_launch("upsample_bilinear_ac_kernel");
+}
+
+extern "C" int pws_upsample_grid_sample_fwd(const float *input, const float *field, float *out, int n, int c, int h, int w,
+                                            int fh, int fw, int align_corners, pws_stream_t stream) {
+    PWS_REQUIRE(n >= 0 && c > 0 && h > 0 && w > 0 && fh > 0 && fw > 0, "pws_upsample_grid_sample_fwd: bad shape");
+    if (n == 0) return PWS_OK;
+    PWS_REQUIRE(input && field && out, "pws_upsample_grid_sample_fwd: NULL pointer");
+    PWS_REQUIRE((size_t)h * w < (1u << 31), "pws_upsample_grid_sample_fwd: plane too large");
+    const float ry = h > 1 ? (float)(fh - 1) / (float)(h - 1) : 0.f;
+    const float rx = w > 1 ? (float)(fw - 1) / (float)(w - 1) : 0.f;
+    const size_t total = (size_t)n * h * w;
+    // fused 720p path: field read once (fh*fw*8 B), frame in + out 4*C B per pixel each
+    ProfScope prof(KID_UPSAMPLE_GRID_SAMPLE_FWD, (double)total * (40.0 + 8.0 * c),
+                   (double)total * 8.0 * c + 8.0 * (double)n * fh * fw, as_stream(stream));
+    if (w % 4 == 0 && aligned16(out)) {
+        const size_t groups = total / 4;
+        const unsigned nb = (unsigned)((groups + 255) / 256);
+        hipLaunchKernelGGL(upsample_grid_sample_fwd_kernel<4>, dim3(nb), dim3(256), 0, as_stream(stream), input, field, out, c,
+                           h, w, fh, fw, ry, rx, groups, nb, align_corners);
+    } else {
+        const unsigned nb = (unsigned)((total + 255) / 256);
+        hipLaunchKernelGGL(upsample_grid_sample_fwd_kernel<1>, dim3(nb), dim3(256), 0, as_stream(stream), input, field, out, c,
+                           h, w, fh, fw, ry, rx, total, nb, align_corners);
+    }
+    return check_launch("upsample_grid_sample_fwd_kernel");
+}

@@ -1,0 +1,144 @@
+// The two regression heads of the generator (fp32 VALU kernels; neither is GEMM-shaped enough for MFMA):
+//
+//  * theta head  (reference lib/networks_cascading.py:148-149,162-163): theta = LReLU(W2 LReLU(W1 vec(x)+b1)+b2),
+//    a 4C->hidden GEMV and a hidden->6 GEMV per sample (`flatten` is a 2x2 conv on a 2x2 map, `linear` a 1x1 conv;
+//    both are `down` blocks, so theta itself passes through LeakyReLU(0.2)).
+//  * field head  (reference :128,174,198,219,235-237): conv3x3 (C->2) + bias, tanh, tanh again, NCHW->NHWC
+//    permute, + F.affine_grid(theta) -- fused into one pass that reads the C-channel feature map once
+//    (HBM-bound: C*4 B/pixel in, 8-16 B/pixel out) and writes the final N,H,W,2 field.
+#include "common.h"
+
+namespace pws {
+
+__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : 0.2f * v; }
+
+// one workgroup per sample
+__global__ void __launch_bounds__(256) theta_head_kernel(const float *__restrict__ x, int k1, int hidden,
+                                                         const float *__restrict__ w_flat, const float *__restrict__ b_flat,
+                                                         const float *__restrict__ w_lin, const float *__restrict__ b_lin,
+                                                         float *__restrict__ theta) {
+    extern __shared__ float sm[];
+    float *sx = sm;        // k1 floats: vec(x) in (ky,kx,ci) order == NHWC memory order
+    float *sh = sm + k1;   // hidden floats
+    const int n = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < k1; i += 256) sx[i] = x[(size_t)n * k1 + i];
+    __syncthreads();
+    for (int j = tid; j < hidden; j += 256) {
+        float acc = b_flat ? b_flat[j] : 0.f;
+        for (int k = 0; k < k1; ++k) acc = fmaf(sx[k], w_flat[(size_t)k * hidden + j], acc);
+        sh[j] = lrelu(acc);
+    }
+    __syncthreads();
+    const int wv = tid >> 6, lane = tid & 63;
+    for (int o = wv; o < 6; o += 4) {
+        float acc = 0.f;
+        for (int j = lane; j < hidden; j += 64) acc = fmaf(sh[j], w_lin[(size_t)j * 6 + o], acc);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) theta[(size_t)n * 6 + o] = lrelu(acc + (b_lin ? b_lin[o] : 0.f));
+    }
+}
+
+// 16x16 output pixels per workgroup, one lane per pixel, channels staged through LDS CH at a time.
+constexpr int FH_T = 16, FH_I = FH_T + 2, FH_CH = 32, FH_LDP = FH_CH + 4;
+
+__global__ void __launch_bounds__(256) field_head_kernel(const float *__restrict__ x, int ld, int N, int H, int W, int C,
+                                                         const float *__restrict__ w_out, const float *__restrict__ b_out,
+                                                         const float *__restrict__ theta, int ac, float *__restrict__ resid,
+                                                         float *__restrict__ grid, int tiles_x, int tiles_y, unsigned ntiles) {
+    __shared__ float s_in[FH_I * FH_I * FH_LDP];
+    __shared__ float s_w[9 * FH_CH * 2];
+    const int tid = threadIdx.x;
+    const unsigned tile = xcd_remap(blockIdx.x, ntiles);
+    const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const int x0 = tx_i * FH_T, y0 = ty_i * FH_T;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int ch = C < FH_CH ? C : FH_CH;  // channels per stage (C % ch == 0 checked on the host)
+    const int c4n = ch / 4;
+    float acc0 = b_out ? b_out[0] : 0.f, acc1 = b_out ? b_out[1] : 0.f;
+    for (int c0 = 0; c0 < C; c0 += ch) {
+        __syncthreads();
+        for (int item = tid; item < FH_I * FH_I * c4n; item += 256) {
+            const int pix = item / c4n, c4 = item % c4n;
+            const int ly = pix / FH_I, lx = pix % FH_I;
+            const int iy = y0 - 1 + ly, ix = x0 - 1 + lx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+                v = *reinterpret_cast<const float4 *>(x + ((size_t)(n * H + iy) * W + ix) * ld + c0 + c4 * 4);
+            *reinterpret_cast<float4 *>(s_in + pix * FH_LDP + c4 * 4) = v;
+        }
+        for (int item = tid; item < 9 * ch * 2; item += 256) {
+            const int tap = item / (ch * 2), r = item % (ch * 2);
+            s_w[item] = w_out[((size_t)tap * C + c0) * 2 + r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float *ip = s_in + ((ty + tap / 3) * FH_I + tx + tap % 3) * FH_LDP;
+            const float *wp = s_w + tap * ch * 2;
+            for (int c4 = 0; c4 < c4n; ++c4) {
+                const float4 v = *reinterpret_cast<const float4 *>(ip + c4 * 4);
+                const float4 wa = *reinterpret_cast<const float4 *>(wp + c4 * 8);      // (c,0),(c,1),(c+1,0),(c+1,1)
+                const float4 wb = *reinterpret_cast<const float4 *>(wp + c4 * 8 + 4);  // (c+2,*),(c+3,*)
+                acc0 = fmaf(v.x, wa.x, acc0), acc1 = fmaf(v.x, wa.y, acc1);
+                acc0 = fmaf(v.y, wa.z, acc0), acc1 = fmaf(v.y, wa.w, acc1);
+                acc0 = fmaf(v.z, wb.x, acc0), acc1 = fmaf(v.z, wb.y, acc1);
+                acc0 = fmaf(v.w, wb.z, acc0), acc1 = fmaf(v.w, wb.w, acc1);
+            }
+        }
+    }
+    const int y = y0 + ty, xq = x0 + tx;
+    if (y < H && xq < W) {
+        const float r0 = tanhf(tanhf(acc0)), r1 = tanhf(tanhf(acc1));
+        const size_t p = ((size_t)n * H + y) * W + xq;
+        if (resid) *reinterpret_cast<float2 *>(resid + p * 2) = make_float2(r0, r1);
+        if (grid) {
+            float a0 = 0.f, a1 = 0.f;
+            if (theta) {
+                const float *t = theta + (size_t)n * 6;
+                const float bx = ac ? (W > 1 ? (2.f * xq) / (float)(W - 1) - 1.f : 0.f) : (2.f * xq + 1.f) / (float)W - 1.f;
+                const float by = ac ? (H > 1 ? (2.f * y) / (float)(H - 1) - 1.f : 0.f) : (2.f * y + 1.f) / (float)H - 1.f;
+                a0 = t[0] * bx + t[1] * by + t[2];
+                a1 = t[3] * bx + t[4] * by + t[5];
+            }
+            *reinterpret_cast<float2 *>(grid + p * 2) = make_float2(r0 + a0, r1 + a1);
+        }
+    }
+}
+
+}  // namespace pws
+
+using namespace pws;
+
+extern "C" int pws_theta_head_fwd(const float *x, int n, int c, int hidden, const float *w_flat, const float *b_flat,
+                                  const float *w_lin, const float *b_lin, float *ws, float *theta, pws_stream_t stream) {
+    (void)ws;
+    PWS_REQUIRE(n >= 0 && c > 0 && hidden > 0, "pws_theta_head_fwd: bad shape");
+    if (n == 0) return PWS_OK;
+    PWS_REQUIRE(x && w_flat && w_lin && theta, "pws_theta_head_fwd: NULL pointer");
+    const int k1 = 4 * c;
+    const size_t lds = sizeof(float) * (size_t)(k1 + hidden);
+    PWS_REQUIRE(lds <= 64 * 1024, "pws_theta_head_fwd: 4*c + hidden = %d floats exceed 64 KB of LDS", k1 + hidden);
+    ProfScope prof(KID_THETA_HEAD, 2.0 * n * ((double)k1 * hidden + 6.0 * hidden), 4.0 * ((double)k1 * hidden + n * k1),
+                   as_stream(stream));
+    hipLaunchKernelGGL(theta_head_kernel, dim3(n), dim3(256), lds, as_stream(stream), x, k1, hidden, w_flat, b_flat, w_lin,
+                       b_lin, theta);
+    return check_launch("theta_head_kernel");
+}
+
+extern "C" int pws_field_head_fwd(const float *x, int ld, int n, int h, int w, int c, const float *w_out, const float *b_out,
+                                  const float *theta, int align_corners, float *resid, float *grid, pws_stream_t stream) {
+    PWS_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0, "pws_field_head_fwd: bad shape");
+    if (n == 0) return PWS_OK;
+    PWS_REQUIRE(x && w_out && (resid || grid), "pws_field_head_fwd: NULL pointer");
+    const int ch = c < FH_CH ? c : FH_CH;
+    PWS_REQUIRE(c % 4 == 0 && c % ch == 0 && ld % 4 == 0 && ld >= c && (reinterpret_cast<size_t>(x) & 15) == 0,
+                "pws_field_head_fwd: c=%d must be a multiple of 4 (and of 32 when > 32), ld %% 4 == 0, x 16-B aligned", c);
+    const int tiles_x = (w + FH_T - 1) / FH_T, tiles_y = (h + FH_T - 1) / FH_T;
+    const unsigned ntiles = (unsigned)tiles_x * tiles_y * n;
+    ProfScope prof(KID_FIELD_HEAD, 2.0 * n * h * w * 18.0 * c,
+                   (double)n * h * w * (4.0 * c + (resid ? 8.0 : 0.0) + (grid ? 8.0 : 0.0)), as_stream(stream));
+    hipLaunchKernelGGL(field_head_kernel, dim3(ntiles), dim3(256), 0, as_stream(stream), x, ld, n, h, w, c, w_out, b_out, theta,
+                       align_corners, resid, grid, tiles_x, tiles_y, ntiles);
+    return check_launch("field_head_kernel");
+}

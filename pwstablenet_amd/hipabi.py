@@ -1,0 +1,119 @@
+"""ctypes binding of the C ABI in include/pwstable.h (libpwstable_hip.so, gfx950).
+
+This is the ONLY way the Python host reaches the kernels, and it passes raw device pointers, sizes and
+the current HIP stream -- exactly what any other host language would pass.  There is no CPU fallback:
+if the library is missing or the call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpwstable_hip.so")
+
+c_f32p = ctypes.c_void_p  # device pointers are passed as integers
+c_stream = ctypes.c_void_p
+
+ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
+CONV_K3S1, CONV_K3S2, CONV_K5S1, CONVT_K3S1, CONVT_K4S2, CONV_K2S1P0, CONV_K1, CONV_K3S1_OUT = range(8)
+
+
+class PwsSrc(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("channels", ctypes.c_int), ("ld", ctypes.c_int)]
+
+
+class PwsConvArgs(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int), ("n", ctypes.c_int), ("h", ctypes.c_int), ("w", ctypes.c_int),
+                ("nsrc", ctypes.c_int), ("src", PwsSrc * 4), ("src_nchw", ctypes.c_int), ("cout", ctypes.c_int),
+                ("w_packed", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("act", ctypes.c_int),
+                ("out", ctypes.c_void_p), ("out_ld", ctypes.c_int)]
+
+
+class PwsProfRecord(ctypes.Structure):
+    _fields_ = [("kernel_id", ctypes.c_int), ("tag", ctypes.c_int), ("flops", ctypes.c_double),
+                ("bytes", ctypes.c_double), ("ms", ctypes.c_float)]
+
+
+_I, _S, _P = ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p
+_F = ctypes.c_float
+# name -> (restype, argtypes); must list every symbol declared in include/pwstable.h
+SIGNATURES = {
+    "pws_version": (_I, []),
+    "pws_last_error": (ctypes.c_char_p, []),
+    "pws_device_info": (_I, [ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "pws_packed_weight_floats": (_S, [_I, _I, _I]),
+    "pws_pack_conv_weight": (_I, [_P, _P, _I, _I, _I, _P]),
+    "pws_conv2d_fwd": (_I, [ctypes.POINTER(PwsConvArgs), _P]),
+    "pws_theta_head_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "pws_field_head_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
+    "pws_affine_grid": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "pws_grid_sample_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "pws_grid_sample_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "pws_upsample_bilinear_ac": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "pws_upsample_grid_sample_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "pws_adam_step": (_I, [_P, _P, _P, _P, _S, _F, _F, _F, _F, _I, _P]),
+    "pws_netg_packed_floats": (_S, [_I, _I]),
+    "pws_netg_pack_weights": (_I, [ctypes.POINTER(_P), _P, _I, _I, _P]),
+    "pws_netg_workspace_bytes": (_S, [_I, _I, _I, _I]),
+    "pws_netg_forward": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _S, _P, _P, _P, _P]),
+    "pws_prof_enable": (_I, [_I]),
+    "pws_prof_collect": (_I, [ctypes.POINTER(PwsProfRecord), _I]),
+    "pws_prof_kernel_name": (ctypes.c_char_p, [_I]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads libpwstable_hip.so (built by ``python -m pwstablenet_amd.build``).  Raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "pwstablenet_amd: %s is missing -- build it with `python -m pwstablenet_amd.build` "
+                "(there is no CPU fallback for the HIP hot path)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        if L.pws_version() != 1:
+            raise RuntimeError("pwstablenet_amd: ABI version mismatch (%d)" % L.pws_version())
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError("pwstable HIP call %s failed (rc=%d): %s" % (what, rc, lib().pws_last_error().decode()))
+
+
+def current_stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    """The hot path runs on the GPU only; refuse anything else loudly."""
+    import torch
+    for t in tensors:
+        if t is None:
+            continue
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise RuntimeError("pwstablenet_amd: the HIP hot path needs CUDA/HIP tensors (got %s); there is no CPU "
+                               "fallback -- move the model and inputs to the GPU" %
+                               (t.device if isinstance(t, torch.Tensor) else type(t)))
+        if t.dtype != torch.float32:
+            raise RuntimeError("pwstablenet_amd: fp32 tensors expected, got %s" % t.dtype)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def prof_collect(max_records=4096):
+    """Returns [(kernel_name, tag, flops, bytes, ms)] of the launches recorded since pws_prof_enable(1)."""
+    buf = (PwsProfRecord * max_records)()
+    n = lib().pws_prof_collect(buf, max_records)
+    if n < 0:
+        check(n, "pws_prof_collect")
+    L = lib()
+    return [(L.pws_prof_kernel_name(r.kernel_id).decode(), r.tag, r.flops, r.bytes, r.ms) for r in buf[:min(n, max_records)]]

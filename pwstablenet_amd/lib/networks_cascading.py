@@ -1,0 +1,214 @@
+"""Host-side mirror of the reference's generator interface (reference lib/networks_cascading.py).
+
+What is kept identical (the drop-in boundary):
+  * ``define_G(input_nc, output_nc, ngf, init_type='normal', init_gain=0.02)`` (an optional trailing
+    ``gpu_ids`` of the older driver is accepted and ignored), ``init_weights`` rules, ``NotImplementedError``
+    for unknown init types (reference :25-60);
+  * ``netG(x)`` -> ``([g1,g2,g3], [r1,r2,r3])`` and ``netG(x, False)`` -> ``g3`` with N,256,256,2 fields
+    (reference :152-237); ``is_training`` is a call argument, independent of ``.train()/.eval()``;
+  * ``state_dict()`` keys, order, shapes and layouts, including the ``module.`` prefix of the reference's
+    DataParallel wrapper (reference :51-52; checkpoints are saved through it, main_new.py:438).
+
+What is different: the module tree only *holds* the parameters (torch = plumbing); the arithmetic is the
+HIP executor behind the C ABI (``pws_netg_forward``).  There is no CPU fallback: calling the generator
+without a GPU or without libpwstable_hip.so raises.  Data parallelism is one process per GPU (RCCL through
+``torch.distributed``), so the wrapper returned by ``define_G`` never scatters over devices.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+from torch.nn import init
+
+from .. import hipabi as A
+from ..spec import layer_specs
+from .cfg import opt
+
+
+# ------------------------------------------------------------------------------------------------ init
+def init_weights(net, init_type='normal', gain=0.02):
+    """Same rules as the reference (:25-46): conv / transposed-conv weights by ``init_type``, biases 0,
+    BatchNorm weight ~ N(1, gain), bias 0."""
+    fillers = {
+        'normal': lambda w: init.normal_(w, 0.0, gain),
+        'xavier': lambda w: init.xavier_normal_(w, gain=gain),
+        'kaiming': lambda w: init.kaiming_normal_(w, a=0, mode='fan_in'),
+        'orthogonal': lambda w: init.orthogonal_(w, gain=gain),
+    }
+    if init_type not in fillers:
+        raise NotImplementedError('initialization method [%s] is not implemented' % init_type)
+    for m in net.modules():
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d, nn.Linear)):
+            fillers[init_type](m.weight.data)
+            if m.bias is not None:
+                init.constant_(m.bias.data, 0.0)
+        elif isinstance(m, nn.BatchNorm2d):
+            init.normal_(m.weight.data, 1.0, gain)
+            init.constant_(m.bias.data, 0.0)
+    print('initialize network with %s' % init_type)
+
+
+class SingleDeviceParallel(nn.Module):
+    """Stands where the reference has ``torch.nn.DataParallel`` (:51-52): same ``.module`` attribute and the
+    same ``module.``-prefixed state-dict keys, but never scatters -- this build runs one process per GPU and
+    all-reduces gradients over RCCL (pwstablenet_amd.distributed)."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+
+def init_net(net, init_type='normal', init_gain=0.02, parallel=False):
+    if parallel:
+        net = SingleDeviceParallel(net)
+    init_weights(net, init_type, gain=init_gain)
+    return net
+
+
+def define_G(input_nc, output_nc, ngf, init_type='normal', init_gain=0.02, gpu_ids=None):
+    return init_net(UnetGenerator(input_nc, output_nc, ngf), init_type, init_gain, parallel=True)
+
+
+def define_D(*args, **kwargs):
+    raise NotImplementedError("define_D: the GAN discriminators are outside the accelerated hot path "
+                              "(off by default in the reference, lib/cfg.py:25)")
+
+
+class GANLoss(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError("GANLoss: the GAN branch is outside the accelerated hot path")
+
+
+# ------------------------------------------------------------------------------------------------ model
+class _Block(nn.Module):
+    """Parameter container for one reference block (down / down_bottom / up / up_bottom)."""
+
+
+class down(_Block):
+    pass
+
+
+class down_bottom(_Block):
+    pass
+
+
+class up(_Block):
+    pass
+
+
+class up_bottom(_Block):
+    pass
+
+
+def _block_class(name):
+    for prefix, cls in (("down_bottom", down_bottom), ("up_bottom", up_bottom), ("up", up)):
+        if name.startswith(prefix):
+            return cls
+    return down
+
+
+class UnetGenerator(nn.Module):
+    """3-stage cascading encoder/decoder regressing an H x W x 2 warp field from ``input_nc`` gray frames."""
+
+    def __init__(self, input_nc, output_nc, ngf=64, use_BN=opt.use_BN):
+        super().__init__()
+        if output_nc != 2:
+            raise ValueError("UnetGenerator: the warp field has 2 components (output_nc=%r)" % (output_nc,))
+        if ngf % 16 != 0:
+            raise ValueError("UnetGenerator: ngf must be a multiple of 16 for the gfx950 kernels (got %r)" % (ngf,))
+        self.input_nc, self.output_nc, self.ngf, self.use_BN = input_nc, output_nc, ngf, bool(use_BN)
+        self._specs = layer_specs(input_nc, output_nc, ngf)
+        for ls in self._specs:
+            block_name, seq_name, _ = ls.name.split(".")
+            if not hasattr(self, block_name):
+                setattr(self, block_name, _block_class(block_name)())
+            if ls.kind == "conv":
+                conv = nn.Conv2d(ls.cin, ls.cout, kernel_size=ls.k, stride=ls.s, padding=ls.p, bias=True)
+            else:
+                conv = nn.ConvTranspose2d(ls.cin, ls.cout, kernel_size=ls.k, stride=ls.s, padding=ls.p, bias=True)
+            if block_name == "out":
+                act = nn.Tanh()
+            elif ls.kind == "conv":
+                act = nn.LeakyReLU(0.2, True)
+            else:
+                act = nn.ReLU(True)
+            mods = [conv] + ([nn.BatchNorm2d(ls.cout)] if self.use_BN else []) + [act]
+            setattr(getattr(self, block_name), seq_name, nn.Sequential(*mods))
+        self._packed = None
+        self._packed_key = None
+        self._ws = {}
+
+    # -- parameters in state-dict order: (weight, bias) per layer
+    def _ordered_params(self):
+        out = []
+        for ls in self._specs:
+            block_name, seq_name, _ = ls.name.split(".")
+            conv = getattr(getattr(self, block_name), seq_name)[0]
+            out += [conv.weight, conv.bias]
+        return out
+
+    def packed_weights(self):
+        """Device buffer with every layer in the kernels' layout; re-packed when a parameter changed."""
+        params = self._ordered_params()
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._packed is None or key != self._packed_key:
+            A.require_cuda(*params)
+            dev = params[0].device
+            nfl = A.lib().pws_netg_packed_floats(self.input_nc, self.ngf)
+            if self._packed is None or self._packed.numel() != nfl or self._packed.device != dev:
+                self._packed = torch.empty(nfl, device=dev, dtype=torch.float32)
+            ptrs = (ctypes.c_void_p * len(params))(*[p.data_ptr() for p in params])
+            A.check(A.lib().pws_netg_pack_weights(ptrs, A.ptr(self._packed), self.input_nc, self.ngf, A.current_stream()),
+                    "pws_netg_pack_weights")
+            self._packed_key = key
+        return self._packed
+
+    def _workspace(self, n, is_training, device):
+        k = (n, bool(is_training), device)
+        if k not in self._ws:
+            nbytes = A.lib().pws_netg_workspace_bytes(n, self.input_nc, self.ngf, int(is_training))
+            self._ws = {k: torch.empty(nbytes + 256, device=device, dtype=torch.uint8)}  # keep one arena only
+        return self._ws[k]
+
+    def forward(self, input1, is_training=True):
+        if self.use_BN:
+            raise NotImplementedError("UnetGenerator: the use_BN variant has no HIP path yet (reference default is False)")
+        A.require_cuda(input1)
+        if input1.dim() != 4 or input1.shape[1] != self.input_nc or input1.shape[2] != 256 or input1.shape[3] != 256:
+            raise RuntimeError("UnetGenerator: expected input (N, %d, 256, 256) -- 7 stride-2 levels and the 2x2 flatten "
+                               "conv fix the size -- got %s" % (self.input_nc, tuple(input1.shape)))
+        needs_grad = torch.is_grad_enabled() and (input1.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if needs_grad:
+            return _netg_autograd(self, input1, is_training)
+        return self._run(input1, is_training)
+
+    def _run(self, input1, is_training):
+        x = input1.contiguous()
+        n = x.shape[0]
+        S = 256
+        packed = self.packed_weights()
+        ws = self._workspace(n, is_training, x.device)
+        ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+        ws_bytes = ws.numel() - (ws_ptr - ws.data_ptr())
+        ng = 3 if is_training else 1
+        grids = torch.empty((ng, n, S, S, 2), device=x.device, dtype=torch.float32)
+        resid = torch.empty((3, n, S, S, 2), device=x.device, dtype=torch.float32) if is_training else None
+        thetas = torch.empty((3, n, 6), device=x.device, dtype=torch.float32)
+        A.check(A.lib().pws_netg_forward(A.ptr(packed), A.ptr(x), n, self.input_nc, self.ngf, int(bool(is_training)),
+                                         0, ctypes.c_void_p(ws_ptr), ws_bytes, A.ptr(grids), A.ptr(resid), A.ptr(thetas),
+                                         A.current_stream()), "pws_netg_forward")
+        self.last_thetas = thetas
+        if is_training:
+            return [grids[0], grids[1], grids[2]], [resid[0], resid[1], resid[2]]
+        return grids[0]
+
+
+def _netg_autograd(net, input1, is_training):
+    """Training entry: forward through the HIP executor with the activations kept in the arena, backward through
+    the HIP backward kernels (pwstablenet_amd.autograd)."""
+    from ..autograd import netg_apply
+    return netg_apply(net, input1, is_training)

@@ -1,0 +1,297 @@
+"""GPU parity tests: every HIP entry point, called through the C ABI (include/pwstable.h), against the CPU
+oracle on the same seeded inputs and against the golden vectors generated from the reference.
+
+Tolerances (fp32): convolutions accumulate K = taps*cin products in a different order than the oracle, so the
+bound scales with sum|a*b|: 2e-5 * sqrt(K)-ish absolute at O(1) activations; stated per test.
+"""
+import ctypes
+import zlib
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from pwstablenet_amd import synth  # noqa: E402
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def nhwc(a):
+    return np.ascontiguousarray(a.transpose(0, 2, 3, 1))
+
+
+def nchw(a):
+    return np.ascontiguousarray(a.transpose(0, 3, 1, 2))
+
+
+def run_conv(A, kind, srcs_nhwc, w_torch, bias, act, cout, nchw_src=None):
+    """srcs_nhwc: list of numpy NHWC arrays (virtual concat) or nchw_src: one NCHW array."""
+    L = A.lib()
+    st = A.current_stream()
+    cin = w_torch.shape[1] if kind in (A.CONV_K3S1, A.CONV_K3S2, A.CONV_K5S1) else w_torch.shape[0]
+    wt = dev(w_torch)
+    wp = torch.empty(L.pws_packed_weight_floats(kind, cin, cout), device="cuda", dtype=torch.float32)
+    A.check(L.pws_pack_conv_weight(A.ptr(wt), A.ptr(wp), kind, cin, cout, st), "pack")
+    args = A.PwsConvArgs()
+    args.kind = kind
+    keep = []
+    if nchw_src is not None:
+        t = dev(nchw_src)
+        keep.append(t)
+        n, _, h, w = nchw_src.shape
+        args.nsrc, args.src_nchw = 1, 1
+        args.src[0].ptr, args.src[0].channels, args.src[0].ld = t.data_ptr(), nchw_src.shape[1], 0
+    else:
+        n, h, w, _ = srcs_nhwc[0].shape
+        args.nsrc = len(srcs_nhwc)
+        for i, s in enumerate(srcs_nhwc):
+            t = dev(s)
+            keep.append(t)
+            args.src[i].ptr, args.src[i].channels, args.src[i].ld = t.data_ptr(), s.shape[3], s.shape[3]
+    args.n, args.h, args.w = n, h, w
+    oh, ow = h, w
+    if kind == A.CONV_K3S2:
+        oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    if kind == A.CONVT_K4S2:
+        oh, ow = 2 * h, 2 * w
+    out = torch.full((n, oh, ow, cout), float("nan"), device="cuda", dtype=torch.float32)
+    b = dev(bias) if bias is not None else None
+    args.cout, args.w_packed, args.bias, args.act = cout, wp.data_ptr(), (b.data_ptr() if b is not None else None), act
+    args.out, args.out_ld = out.data_ptr(), cout
+    A.check(L.pws_conv2d_fwd(ctypes.byref(args), st), "pws_conv2d_fwd")
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+CONV_CASES = [
+    # kind name, (n,h,w), source channel list, cout
+    ("CONV_K3S1", (2, 20, 37), [16], 64),
+    ("CONV_K3S1", (1, 33, 16), [32, 16], 96),       # 2 sources, cout not a multiple of 64
+    ("CONV_K3S1", (3, 8, 8), [16], 16),             # small-tile configs
+    ("CONV_K3S1", (5, 4, 4), [32], 32),
+    ("CONV_K3S1", (18, 2, 2), [16], 64),
+    ("CONV_K3S2", (2, 40, 34), [16, 16], 64),
+    ("CONV_K3S2", (2, 16, 16), [32], 32),
+    ("CONV_K3S2", (3, 8, 8), [16], 32),
+    ("CONV_K3S2", (17, 4, 4), [16, 16, 16], 16),
+    ("CONV_K5S1", (1, 23, 40), [16], 64),
+    ("CONVT_K3S1", (2, 18, 21), [16, 32], 48),
+    ("CONVT_K3S1", (2, 4, 4), [16], 16),
+    ("CONVT_K4S2", (2, 17, 19), [32, 16, 16], 64),
+    ("CONVT_K4S2", (2, 8, 8), [16], 32),
+    ("CONVT_K4S2", (3, 4, 4), [16, 16], 16),
+    ("CONVT_K4S2", (20, 2, 2), [32], 64),
+]
+
+
+@pytest.mark.parametrize("kname,shape,src_c,cout", CONV_CASES)
+@pytest.mark.parametrize("act", [1, 2])
+def test_conv_kinds_vs_oracle(hip, oracle, kname, shape, src_c, cout, act):
+    A = hip
+    kind = getattr(A, kname)
+    n, h, w = shape
+    rs = np.random.RandomState(zlib.crc32(repr((kname, shape, cout)).encode()))
+    cin = sum(src_c)
+    x = rs.standard_normal((n, cin, h, w)).astype(np.float32)
+    k = {"CONV_K3S1": 3, "CONV_K3S2": 3, "CONV_K5S1": 5, "CONVT_K3S1": 3, "CONVT_K4S2": 4}[kname]
+    is_t = kname.startswith("CONVT")
+    wshape = (cin, cout, k, k) if is_t else (cout, cin, k, k)
+    wt = (rs.standard_normal(wshape) / np.sqrt(cin * k * k / (4 if kname == "CONVT_K4S2" else 1))).astype(np.float32)
+    b = rs.standard_normal((cout,)).astype(np.float32)
+    s, p = {"CONV_K3S1": (1, 1), "CONV_K3S2": (2, 1), "CONV_K5S1": (1, 2), "CONVT_K3S1": (1, 1), "CONVT_K4S2": (2, 1)}[kname]
+    oact = {1: oracle.ACT_LRELU, 2: oracle.ACT_RELU}[act]
+    ref = (oracle.conv_transpose2d if is_t else oracle.conv2d)(x, wt, b, s, p, oact)
+    xs = nhwc(x)
+    srcs, c0 = [], 0
+    for c in src_c:
+        srcs.append(np.ascontiguousarray(xs[..., c0:c0 + c]))
+        c0 += c
+    got = run_conv(A, kind, srcs, wt, b, act, cout)
+    assert not np.isnan(got).any(), "kernel left output elements unwritten"
+    # outputs are O(1); K <= 1000 products of N(0,1)*N(0,1/K): 5e-5 abs covers the reordered fp32 sum
+    np.testing.assert_allclose(nchw(got), ref, rtol=0, atol=5e-5)
+
+
+def test_conv_first_layer_nchw_31ch(hip, oracle):
+    """transfer: k5 s1 p2 on the reference's NCHW 31-channel window (lib/networks_cascading.py:112,153)."""
+    A = hip
+    rs = np.random.RandomState(5)
+    x = rs.standard_normal((2, 31, 37, 50)).astype(np.float32)
+    wt = (rs.standard_normal((64, 31, 5, 5)) / 28).astype(np.float32)
+    b = rs.standard_normal((64,)).astype(np.float32)
+    ref = oracle.conv2d(x, wt, b, 1, 2, oracle.ACT_LRELU)
+    got = run_conv(A, A.CONV_K5S1, None, wt, b, 1, 64, nchw_src=x)
+    np.testing.assert_allclose(nchw(got), ref, rtol=0, atol=5e-5)
+
+
+def test_conv_empty_batch_and_bad_args(hip):
+    A = hip
+    args = A.PwsConvArgs()
+    args.kind, args.n, args.h, args.w, args.nsrc, args.cout, args.out_ld = A.CONV_K3S1, 1, 4, 4, 0, 16, 16
+    assert A.lib().pws_conv2d_fwd(ctypes.byref(args), None) == -22  # PWS_EINVAL
+    assert b"nsrc" in A.lib().pws_last_error()
+
+
+@pytest.mark.parametrize("tag", ["gs_small", "gs_mid", "gs_gray"])
+@pytest.mark.parametrize("ac", [0, 1])
+def test_grid_sample_golden(hip, ops_golden, tag, ac):
+    """F.grid_sample fwd + bwd known-answer vectors from torch (OOB, exact-integer, half-integer coordinates)."""
+    A, g = hip, ops_golden
+    L, st = A.lib(), A.current_stream()
+    img, grid, gout = dev(g[tag + "_img"]), dev(g[tag + "_grid"]), dev(g[tag + "_gout"])
+    n, c, h, w = img.shape
+    ho, wo = grid.shape[1], grid.shape[2]
+    out = torch.empty((n, c, ho, wo), device="cuda")
+    A.check(L.pws_grid_sample_fwd(A.ptr(img), A.ptr(grid), A.ptr(out), n, c, h, w, ho, wo, ac, st), "fwd")
+    gi, gg = torch.empty_like(img), torch.empty_like(grid)
+    A.check(L.pws_grid_sample_bwd(A.ptr(gout), A.ptr(img), A.ptr(grid), A.ptr(gi), A.ptr(gg), n, c, h, w, ho, wo, ac, st), "bwd")
+    torch.cuda.synchronize()
+    # coordinate conditioning, see tests/test_oracle_golden.py::test_grid_sample_fwd_bwd
+    np.testing.assert_allclose(out.cpu().numpy(), g["%s_out_ac%d" % (tag, ac)], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(gi.cpu().numpy(), g["%s_ginput_ac%d" % (tag, ac)], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(gg.cpu().numpy(), g["%s_ggrid_ac%d" % (tag, ac)], rtol=0, atol=1e-3)
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 256, 256), (2, 1, 64, 100), (1, 3, 37, 53)])
+def test_grid_sample_vs_oracle(hip, oracle, shape):
+    A = hip
+    n, c, h, w = shape
+    img = synth.make_frames(n, c, h, w, seed=3)
+    rs = np.random.RandomState(4)
+    theta = (np.array([1, 0, 0, 0, 1, 0], np.float32) + 0.1 * rs.standard_normal((n, 6))).astype(np.float32)
+    grid = oracle.affine_grid(theta, h, w) + 0.02 * rs.standard_normal((n, h, w, 2)).astype(np.float32)
+    gout = rs.standard_normal((n, c, h, w)).astype(np.float32)
+    ref = oracle.grid_sample_fwd(img, grid)
+    rgi, rgg = oracle.grid_sample_bwd(gout, img, grid)
+    L, st = A.lib(), A.current_stream()
+    d_img, d_grid, d_gout = dev(img), dev(grid), dev(gout)
+    out, gi, gg = torch.empty_like(d_img), torch.empty_like(d_img), torch.empty_like(d_grid)
+    A.check(L.pws_grid_sample_fwd(A.ptr(d_img), A.ptr(d_grid), A.ptr(out), n, c, h, w, h, w, 0, st), "fwd")
+    A.check(L.pws_grid_sample_bwd(A.ptr(d_gout), A.ptr(d_img), A.ptr(d_grid), A.ptr(gi), A.ptr(gg), n, c, h, w, h, w, 0, st), "bwd")
+    torch.cuda.synchronize()
+    # frames are 0..255 and smooth (|grad| <~ 3/px); coordinate rounding ~1.5e-5 px at W=256
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=2e-3)
+    np.testing.assert_allclose(gi.cpu().numpy(), rgi, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(gg.cpu().numpy(), rgg, rtol=1e-4, atol=0.5)  # terms O(C*W/2*255)
+    # grad-only variants
+    gg2 = torch.empty_like(d_grid)
+    A.check(L.pws_grid_sample_bwd(A.ptr(d_gout), A.ptr(d_img), A.ptr(d_grid), None, A.ptr(gg2), n, c, h, w, h, w, 0, st), "bwd")
+    torch.cuda.synchronize()
+    assert torch.equal(gg, gg2)
+
+
+def test_grid_sample_linearity_full_size(hip):
+    """Size-independent property at the bench size: the warp is linear in the frame and, for the identity field
+    at pixel centres, the identity map."""
+    A = hip
+    L, st = A.lib(), A.current_stream()
+    n, c, h, w = 8, 3, 256, 256
+    a, b = torch.rand((n, c, h, w), device="cuda"), torch.rand((n, c, h, w), device="cuda")
+    theta = torch.tensor([1, 0, 0, 0, 1, 0], device="cuda", dtype=torch.float32).repeat(n, 1)
+    grid = torch.empty((n, h, w, 2), device="cuda")
+    A.check(L.pws_affine_grid(A.ptr(theta), A.ptr(grid), n, h, w, 0, st), "affine")
+    oa, ob, oab = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+    A.check(L.pws_grid_sample_fwd(A.ptr(a), A.ptr(grid), A.ptr(oa), n, c, h, w, h, w, 0, st), "fwd")
+    assert (oa - a).abs().max().item() < 1e-4  # identity field reproduces the frame
+    g2 = grid + 0.05 * torch.randn_like(grid)
+    ab = (2 * a + 3 * b).contiguous()
+    for src, dst in ((a, oa), (b, ob), (ab, oab)):
+        A.check(L.pws_grid_sample_fwd(A.ptr(src), A.ptr(g2), A.ptr(dst), n, c, h, w, h, w, 0, st), "fwd")
+    assert (oab - (2 * oa + 3 * ob)).abs().max().item() < 1e-5
+
+
+def test_affine_grid_golden(hip, ops_golden):
+    A, g = hip, ops_golden
+    theta = dev(g["ag_theta"])
+    for ac in (0, 1):
+        out = torch.empty((3, 12, 20, 2), device="cuda")
+        A.check(A.lib().pws_affine_grid(A.ptr(theta), A.ptr(out), 3, 12, 20, ac, A.current_stream()), "affine")
+        np.testing.assert_allclose(out.cpu().numpy(), g["ag_out_ac%d" % ac], rtol=0, atol=1e-6)
+
+
+def test_upsample_and_fused_720p_golden(hip, ops_golden):
+    """main_new.py:706-716: UpsamplingBilinear2d(720,1280) of the field, then grid_sample; separate and fused."""
+    A, g = hip, ops_golden
+    L, st = A.lib(), A.current_stream()
+    field = dev(g["up_field"])  # 1,256,256,2
+    f_nchw = field.permute(0, 3, 1, 2).contiguous()
+    up = torch.empty((1, 2, 720, 1280), device="cuda")
+    A.check(L.pws_upsample_bilinear_ac(A.ptr(f_nchw), A.ptr(up), 1, 2, 256, 256, 720, 1280, st), "upsample")
+    up_nhwc = up.permute(0, 2, 3, 1).contiguous()
+    np.testing.assert_allclose(up_nhwc.cpu().numpy()[:, ::9, ::16], g["up_out_sub"], rtol=0, atol=2e-6)
+    frame = dev(synth.make_frames(1, 3, 720, 1280, seed=99))
+    w1, w2 = torch.empty_like(frame), torch.empty_like(frame)
+    A.check(L.pws_grid_sample_fwd(A.ptr(frame), A.ptr(up_nhwc), A.ptr(w1), 1, 3, 720, 1280, 720, 1280, 0, st), "fwd")
+    A.check(L.pws_upsample_grid_sample_fwd(A.ptr(frame), A.ptr(field), A.ptr(w2), 1, 3, 720, 1280, 256, 256, 0, st), "fused")
+    torch.cuda.synchronize()
+    # 0..255 frames; 1e-2 abs == 8e-5 on the [-1,1] scale (bound 1e-3)
+    np.testing.assert_allclose(w1.cpu().numpy()[:, :, ::9, ::16], g["up_warp_sub"], rtol=0, atol=1e-2)
+    np.testing.assert_allclose(w2.cpu().numpy()[:, :, ::9, ::16], g["up_warp_sub"], rtol=0, atol=1e-2)
+    assert (w1 - w2).abs().max().item() < 1e-2
+
+
+def test_adam_golden_and_ragged(hip, oracle, ops_golden):
+    A, g = hip, ops_golden
+    p = dev(g["adam_p0"].copy())
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(3):
+        gr = dev(g["adam_grads"][step])
+        A.check(A.lib().pws_adam_step(A.ptr(p), A.ptr(gr), A.ptr(m), A.ptr(v), p.numel(), 1e-2, 0.5, 0.999, 1e-8, step + 1,
+                                      A.current_stream()), "adam")
+        np.testing.assert_allclose(p.cpu().numpy(), g["adam_p%d" % (step + 1)], rtol=0, atol=2e-6)
+    # large ragged buffer vs the oracle
+    rs = np.random.RandomState(0)
+    n = 1_000_003
+    hp, hg = rs.standard_normal(n).astype(np.float32), rs.standard_normal(n).astype(np.float32)
+    hm, hv = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    dp, dg, dm, dv = dev(hp), dev(hg), dev(hm), dev(hv)
+    for step in (1, 2):
+        oracle.adam_step(hp, hg, hm, hv, 1e-3, 0.5, 0.999, 1e-8, step)
+        A.check(A.lib().pws_adam_step(A.ptr(dp), A.ptr(dg), A.ptr(dm), A.ptr(dv), n, 1e-3, 0.5, 0.999, 1e-8, step,
+                                      A.current_stream()), "adam")
+    np.testing.assert_allclose(dp.cpu().numpy(), hp, rtol=0, atol=2e-6)
+
+
+def test_heads_vs_oracle(hip, oracle):
+    """theta head (flatten+linear, LeakyReLU on theta) and field head (out conv, tanh, tanh, + affine)."""
+    A = hip
+    L, st = A.lib(), A.current_stream()
+    rs = np.random.RandomState(9)
+    n, c, hidden = 3, 64, 128
+    x = rs.standard_normal((n, c, 2, 2)).astype(np.float32)
+    wf = (rs.standard_normal((hidden, c, 2, 2)) / 16).astype(np.float32)
+    bf = rs.standard_normal(hidden).astype(np.float32)
+    wl = (rs.standard_normal((6, hidden, 1, 1)) / 11).astype(np.float32)
+    bl = rs.standard_normal(6).astype(np.float32)
+    f = oracle.conv2d(x, wf, bf, 1, 0, oracle.ACT_LRELU)
+    ref_theta = oracle.conv2d(f, wl, bl, 1, 0, oracle.ACT_LRELU).reshape(n, 6)
+    pf = torch.empty(L.pws_packed_weight_floats(A.CONV_K2S1P0, c, hidden), device="cuda")
+    pl = torch.empty(L.pws_packed_weight_floats(A.CONV_K1, hidden, 6), device="cuda")
+    d_wf, d_wl = dev(wf), dev(wl)
+    A.check(L.pws_pack_conv_weight(A.ptr(d_wf), A.ptr(pf), A.CONV_K2S1P0, c, hidden, st), "pack")
+    A.check(L.pws_pack_conv_weight(A.ptr(d_wl), A.ptr(pl), A.CONV_K1, hidden, 6, st), "pack")
+    d_x, d_bf, d_bl = dev(nhwc(x)), dev(bf), dev(bl)
+    theta = torch.empty((n, 6), device="cuda")
+    A.check(L.pws_theta_head_fwd(A.ptr(d_x), n, c, hidden, A.ptr(pf), A.ptr(d_bf), A.ptr(pl), A.ptr(d_bl), None, A.ptr(theta),
+                                 st), "theta")
+    np.testing.assert_allclose(theta.cpu().numpy(), ref_theta, rtol=0, atol=2e-5)
+
+    h, w, c = 37, 45, 64
+    x = rs.standard_normal((n, c, h, w)).astype(np.float32)
+    wo = (rs.standard_normal((2, c, 3, 3)) / 12).astype(np.float32)
+    bo = rs.standard_normal(2).astype(np.float32)
+    r = np.tanh(oracle.conv2d(x, wo, bo, 1, 1, oracle.ACT_TANH))
+    ref_res = nhwc(r)
+    ref_grid = ref_res + oracle.affine_grid(ref_theta, h, w)
+    po = torch.empty(L.pws_packed_weight_floats(A.CONV_K3S1_OUT, c, 2), device="cuda")
+    d_wo, d_bo, d_x = dev(wo), dev(bo), dev(nhwc(x))
+    A.check(L.pws_pack_conv_weight(A.ptr(d_wo), A.ptr(po), A.CONV_K3S1_OUT, c, 2, st), "pack")
+    res, grid = torch.empty((n, h, w, 2), device="cuda"), torch.empty((n, h, w, 2), device="cuda")
+    A.check(L.pws_field_head_fwd(A.ptr(d_x), c, n, h, w, c, A.ptr(po), A.ptr(d_bo), A.ptr(theta), 0, A.ptr(res), A.ptr(grid),
+                                 st), "field")
+    np.testing.assert_allclose(res.cpu().numpy(), ref_res, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(grid.cpu().numpy(), ref_grid, rtol=0, atol=5e-5)
