@@ -43,16 +43,35 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, int(q / int(f.read()))))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(batch_unused):
     """Hot path on the host cores: netG(window, False) + grid_sample, N=1, min over a bounded number of runs."""
     import torch
     from oracle import torch_ref
     from pwstablenet_amd import synth
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = min(usable_cores(), 64)  # oneDNN convs of one 256x256 frame stop scaling long before 64 threads
     torch.set_num_threads(cores)
     params = [torch.from_numpy(v) for _, v in synth.make_weights("W1", seed=123, ngf=64)]
     x = torch.from_numpy(synth.noise_window(1, 31, 256, seed=123))

@@ -91,13 +91,16 @@ typedef struct pws_conv_args {
     int act;          /* PWS_ACT_* */
     float *out;       /* NHWC, output height/width implied by kind */
     int out_ld;       /* pixel stride of out in floats (>= cout) */
+    void *ws;         /* optional scratch for split-K partial tiles (16-B aligned) or NULL: small-spatial layers */
+    size_t ws_bytes;  /* then run un-split.  Any size works; 32 x n*oh*ow*cout*4 bytes never limits the split. */
 } pws_conv_args;
 
 int pws_conv2d_fwd(const pws_conv_args *args, pws_stream_t stream);
 
 /* theta = LReLU(W2 . LReLU(W1 . vec(x) + b1) + b2)   x: NHWC [n,2,2,c] (ld == c), theta: [n,6].
  * w_flat packed as PWS_CONV_K2S1P0 (c -> hidden), w_lin packed as PWS_CONV_K1 (hidden -> 6).
- * ws: n*hidden floats of scratch. */
+ * ws: pws_theta_head_ws_floats(n, c, hidden) floats of scratch (K-split partial sums). */
+size_t pws_theta_head_ws_floats(int n, int c, int hidden);
 int pws_theta_head_fwd(const float *x, int n, int c, int hidden, const float *w_flat, const float *b_flat,
                        const float *w_lin, const float *b_lin, float *ws, float *theta, pws_stream_t stream);
 

@@ -12,20 +12,49 @@ namespace pws {
 
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : 0.2f * v; }
 
-// one workgroup per sample
-__global__ void __launch_bounds__(256) theta_head_kernel(const float *__restrict__ x, int k1, int hidden,
-                                                         const float *__restrict__ w_flat, const float *__restrict__ b_flat,
-                                                         const float *__restrict__ w_lin, const float *__restrict__ b_lin,
-                                                         float *__restrict__ theta) {
-    extern __shared__ float sm[];
-    float *sx = sm;        // k1 floats: vec(x) in (ky,kx,ci) order == NHWC memory order
-    float *sh = sm + k1;   // hidden floats
-    const int n = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < k1; i += 256) sx[i] = x[(size_t)n * k1 + i];
-    __syncthreads();
+// Phase 1: hidden pre-activations, K split over workgroups so that the 4C x hidden weight matrix (2 MB at ngf=64) is
+// streamed by many CUs at once.  One wave per (64 hidden units, K slice); lane = hidden unit, so the weight read
+// w_flat[k][j0..j0+63] is one coalesced 256-B row per k; up to TH_NB samples share each weight.
+// partial[slice][n][hidden] is summed (in slice order: deterministic) by phase 2.
+constexpr int TH_NB = 8;
+
+__global__ void __launch_bounds__(64) theta_hidden_kernel(const float *__restrict__ x, int n, int k1, int hidden, int kchunk,
+                                                          const float *__restrict__ w_flat, float *__restrict__ partial) {
+    extern __shared__ float sx[];  // [TH_NB][kchunk]
+    const int lane = threadIdx.x;
+    const int j = blockIdx.x * 64 + lane;
+    const int slice = blockIdx.y;
+    const int k0 = slice * kchunk, kn = min(kchunk, k1 - k0);
+    for (int n0 = 0; n0 < n; n0 += TH_NB) {
+        const int nb = min(TH_NB, n - n0);
+        __syncthreads();
+        for (int i = lane; i < nb * kn; i += 64) sx[(i / kn) * kchunk + i % kn] = x[(size_t)(n0 + i / kn) * k1 + k0 + i % kn];
+        __syncthreads();
+        float acc[TH_NB];
+#pragma unroll
+        for (int s = 0; s < TH_NB; ++s) acc[s] = 0.f;
+        if (j < hidden) {
+            for (int k = 0; k < kn; ++k) {
+                const float w = w_flat[(size_t)(k0 + k) * hidden + j];
+#pragma unroll
+                for (int s = 0; s < TH_NB; ++s) acc[s] = fmaf(s < nb ? sx[s * kchunk + k] : 0.f, w, acc[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < TH_NB; ++s)
+                if (s < nb) partial[((size_t)slice * n + n0 + s) * hidden + j] = acc[s];
+        }
+    }
+}
+
+// Phase 2: one workgroup per sample: h = LReLU(sum_slices + b1); theta = LReLU(W2 h + b2).
+__global__ void __launch_bounds__(256) theta_final_kernel(const float *__restrict__ partial, int nslices, int n, int hidden,
+                                                          const float *__restrict__ b_flat, const float *__restrict__ w_lin,
+                                                          const float *__restrict__ b_lin, float *__restrict__ theta) {
+    extern __shared__ float sh[];  // hidden floats
+    const int s = blockIdx.x, tid = threadIdx.x;
     for (int j = tid; j < hidden; j += 256) {
         float acc = b_flat ? b_flat[j] : 0.f;
-        for (int k = 0; k < k1; ++k) acc = fmaf(sx[k], w_flat[(size_t)k * hidden + j], acc);
+        for (int sl = 0; sl < nslices; ++sl) acc += partial[((size_t)sl * n + s) * hidden + j];
         sh[j] = lrelu(acc);
     }
     __syncthreads();
@@ -35,7 +64,7 @@ __global__ void __launch_bounds__(256) theta_head_kernel(const float *__restrict
         for (int j = lane; j < hidden; j += 64) acc = fmaf(sh[j], w_lin[(size_t)j * 6 + o], acc);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-        if (lane == 0) theta[(size_t)n * 6 + o] = lrelu(acc + (b_lin ? b_lin[o] : 0.f));
+        if (lane == 0) theta[(size_t)s * 6 + o] = lrelu(acc + (b_lin ? b_lin[o] : 0.f));
     }
 }
 
@@ -110,20 +139,30 @@ __global__ void __launch_bounds__(256) field_head_kernel(const float *__restrict
 
 using namespace pws;
 
+static int theta_slices(int k1) {
+    int kchunk = 64;
+    return (k1 + kchunk - 1) / kchunk;
+}
+
+extern "C" size_t pws_theta_head_ws_floats(int n, int c, int hidden) {
+    if (n <= 0 || c <= 0 || hidden <= 0) return 0;
+    return (size_t)theta_slices(4 * c) * n * hidden;
+}
+
 extern "C" int pws_theta_head_fwd(const float *x, int n, int c, int hidden, const float *w_flat, const float *b_flat,
                                   const float *w_lin, const float *b_lin, float *ws, float *theta, pws_stream_t stream) {
-    (void)ws;
     PWS_REQUIRE(n >= 0 && c > 0 && hidden > 0, "pws_theta_head_fwd: bad shape");
     if (n == 0) return PWS_OK;
-    PWS_REQUIRE(x && w_flat && w_lin && theta, "pws_theta_head_fwd: NULL pointer");
-    const int k1 = 4 * c;
-    const size_t lds = sizeof(float) * (size_t)(k1 + hidden);
-    PWS_REQUIRE(lds <= 64 * 1024, "pws_theta_head_fwd: 4*c + hidden = %d floats exceed 64 KB of LDS", k1 + hidden);
+    PWS_REQUIRE(x && w_flat && w_lin && theta && ws, "pws_theta_head_fwd: NULL pointer (ws needs pws_theta_head_ws_floats())");
+    const int k1 = 4 * c, kchunk = 64, nslices = theta_slices(k1);
+    PWS_REQUIRE(hidden * sizeof(float) <= 64 * 1024, "pws_theta_head_fwd: hidden = %d exceeds 64 KB of LDS", hidden);
     ProfScope prof(KID_THETA_HEAD, 2.0 * n * ((double)k1 * hidden + 6.0 * hidden), 4.0 * ((double)k1 * hidden + n * k1),
                    as_stream(stream));
-    hipLaunchKernelGGL(theta_head_kernel, dim3(n), dim3(256), lds, as_stream(stream), x, k1, hidden, w_flat, b_flat, w_lin,
-                       b_lin, theta);
-    return check_launch("theta_head_kernel");
+    hipLaunchKernelGGL(theta_hidden_kernel, dim3((hidden + 63) / 64, nslices), dim3(64), sizeof(float) * TH_NB * kchunk,
+                       as_stream(stream), x, n, k1, hidden, kchunk, w_flat, ws);
+    hipLaunchKernelGGL(theta_final_kernel, dim3(n), dim3(256), sizeof(float) * hidden, as_stream(stream), ws, nslices, n, hidden,
+                       b_flat, w_lin, b_lin, theta);
+    return check_launch("theta_head kernels");
 }
 
 extern "C" int pws_field_head_fwd(const float *x, int ld, int n, int h, int w, int c, const float *w_out, const float *b_out,

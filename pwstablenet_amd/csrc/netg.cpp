@@ -131,6 +131,7 @@ class Exec {
         }
         a.cout = l.cout, a.w_packed = packed_ + l.w_off, a.bias = packed_ + l.b_off, a.act = act;
         a.out = o.seg[0].ptr, a.out_ld = l.cout;
+        a.ws = splitk_ws_, a.ws_bytes = splitk_bytes_;
         g_prof_tag = layer;
         rc_ = pws_conv2d_fwd(&a, st_);
         g_prof_tag = -1;
@@ -160,7 +161,7 @@ class Exec {
         if (dry_ || rc_ != PWS_OK) return;
         const Layer &f = L_[L_FLATTEN], &l = L_[L_LINEAR];
         rc_ = pws_theta_head_fwd(x_s8.seg[0].ptr, n_, x_s8.seg[0].c, f.cout, packed_ + f.w_off, packed_ + f.b_off,
-                                 packed_ + l.w_off, packed_ + l.b_off, nullptr, theta_out, st_);
+                                 packed_ + l.w_off, packed_ + l.b_off, theta_ws_, theta_out, st_);
     }
     // tanh(out(x)).permute(0,2,3,1) [+ affine_grid(theta)] (reference :174,235-237)
     void field(const Tn &x, const float *theta_k, int ac, float *resid, float *grid) {
@@ -170,7 +171,17 @@ class Exec {
                                  theta_k, ac, resid, grid, st_);
     }
 
+    // scratch shared by all layers (launches are stream-ordered): split-K partial tiles and the theta head's partials
+    void reserve_scratch(int ngf) {
+        splitk_bytes_ = (size_t)(n_ > 8 ? n_ : 8) * (2u << 20);
+        splitk_ws_ = alloc(splitk_bytes_ / sizeof(float));
+        theta_ws_ = alloc(pws_theta_head_ws_floats(n_, 4 * ngf, 8 * ngf));
+        if (!splitk_ws_) splitk_bytes_ = 0;
+    }
+
   private:
+    float *splitk_ws_ = nullptr, *theta_ws_ = nullptr;
+    size_t splitk_bytes_ = 0;
     const float *packed_;
     const std::vector<Layer> &L_;
     int n_;
@@ -187,6 +198,7 @@ static int run_forward(const float *packed, const float *x, int n, int input_nc,
     size_t total = 0;
     const std::vector<Layer> layers = build_layers(input_nc, g, &total);
     Exec E(packed, layers, n, ws, ws_bytes, st, dry);
+    E.reserve_scratch(g);
     const size_t gsz = (size_t)n * S * S * 2;
     float *th = thetas ? thetas : E.alloc((size_t)3 * n * 6);
     if (thetas == nullptr && !dry && E.rc() != PWS_OK) return E.rc();

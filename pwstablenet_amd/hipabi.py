@@ -25,7 +25,7 @@ class PwsConvArgs(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("n", ctypes.c_int), ("h", ctypes.c_int), ("w", ctypes.c_int),
                 ("nsrc", ctypes.c_int), ("src", PwsSrc * 4), ("src_nchw", ctypes.c_int), ("cout", ctypes.c_int),
                 ("w_packed", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("act", ctypes.c_int),
-                ("out", ctypes.c_void_p), ("out_ld", ctypes.c_int)]
+                ("out", ctypes.c_void_p), ("out_ld", ctypes.c_int), ("ws", ctypes.c_void_p), ("ws_bytes", ctypes.c_size_t)]
 
 
 class PwsProfRecord(ctypes.Structure):
@@ -43,6 +43,7 @@ SIGNATURES = {
     "pws_packed_weight_floats": (_S, [_I, _I, _I]),
     "pws_pack_conv_weight": (_I, [_P, _P, _I, _I, _I, _P]),
     "pws_conv2d_fwd": (_I, [ctypes.POINTER(PwsConvArgs), _P]),
+    "pws_theta_head_ws_floats": (_S, [_I, _I, _I]),
     "pws_theta_head_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "pws_field_head_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
     "pws_affine_grid": (_I, [_P, _P, _I, _I, _I, _I, _P]),
@@ -71,6 +72,10 @@ def lib():
             raise RuntimeError(
                 "pwstablenet_amd: %s is missing -- build it with `python -m pwstablenet_amd.build` "
                 "(there is no CPU fallback for the HIP hot path)" % LIB_PATH)
+        # torch bundles its own HIP runtime (libamdhip64.so.7); it must be in the process BEFORE this library is
+        # opened so that both share ONE runtime -- two runtimes in one process cannot both own the device
+        # ("no ROCm-capable device is detected" from whichever comes second).
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

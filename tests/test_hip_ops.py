@@ -28,7 +28,7 @@ def nchw(a):
     return np.ascontiguousarray(a.transpose(0, 3, 1, 2))
 
 
-def run_conv(A, kind, srcs_nhwc, w_torch, bias, act, cout, nchw_src=None):
+def run_conv(A, kind, srcs_nhwc, w_torch, bias, act, cout, nchw_src=None, ws_mb=0):
     """srcs_nhwc: list of numpy NHWC arrays (virtual concat) or nchw_src: one NCHW array."""
     L = A.lib()
     st = A.current_stream()
@@ -62,6 +62,9 @@ def run_conv(A, kind, srcs_nhwc, w_torch, bias, act, cout, nchw_src=None):
     b = dev(bias) if bias is not None else None
     args.cout, args.w_packed, args.bias, args.act = cout, wp.data_ptr(), (b.data_ptr() if b is not None else None), act
     args.out, args.out_ld = out.data_ptr(), cout
+    if ws_mb:
+        ws = torch.empty(ws_mb << 20, device="cuda", dtype=torch.uint8)
+        args.ws, args.ws_bytes = ws.data_ptr(), ws.numel()
     A.check(L.pws_conv2d_fwd(ctypes.byref(args), st), "pws_conv2d_fwd")
     torch.cuda.synchronize()
     return out.cpu().numpy()
@@ -85,6 +88,14 @@ CONV_CASES = [
     ("CONVT_K4S2", (2, 8, 8), [16], 32),
     ("CONVT_K4S2", (3, 4, 4), [16, 16], 16),
     ("CONVT_K4S2", (20, 2, 2), [32], 64),
+    # deep-layer shapes: K large, M tiny -> split-K path when a workspace is given
+    ("CONV_K3S1", (2, 16, 16), [64, 64], 64),
+    ("CONV_K3S1", (3, 4, 4), [128], 64),
+    ("CONV_K3S2", (2, 16, 16), [64, 48], 128),
+    ("CONV_K3S2", (4, 4, 4), [256], 64),
+    ("CONVT_K3S1", (2, 2, 2), [256], 256),
+    ("CONVT_K4S2", (2, 8, 8), [128, 64, 64], 64),
+    ("CONVT_K4S2", (3, 2, 2), [256], 128),
 ]
 
 
@@ -110,10 +121,11 @@ def test_conv_kinds_vs_oracle(hip, oracle, kname, shape, src_c, cout, act):
     for c in src_c:
         srcs.append(np.ascontiguousarray(xs[..., c0:c0 + c]))
         c0 += c
-    got = run_conv(A, kind, srcs, wt, b, act, cout)
-    assert not np.isnan(got).any(), "kernel left output elements unwritten"
-    # outputs are O(1); K <= 1000 products of N(0,1)*N(0,1/K): 5e-5 abs covers the reordered fp32 sum
-    np.testing.assert_allclose(nchw(got), ref, rtol=0, atol=5e-5)
+    for ws_mb in (0, 64):  # without and with split-K scratch
+        got = run_conv(A, kind, srcs, wt, b, act, cout, ws_mb=ws_mb)
+        assert not np.isnan(got).any(), "kernel left output elements unwritten"
+        # outputs are O(1); K <= 2304 products of N(0,1)*N(0,1/K): 5e-5 abs covers the reordered fp32 sum
+        np.testing.assert_allclose(nchw(got), ref, rtol=0, atol=5e-5)
 
 
 def test_conv_first_layer_nchw_31ch(hip, oracle):
@@ -173,8 +185,9 @@ def test_grid_sample_vs_oracle(hip, oracle, shape):
     A.check(L.pws_grid_sample_fwd(A.ptr(d_img), A.ptr(d_grid), A.ptr(out), n, c, h, w, h, w, 0, st), "fwd")
     A.check(L.pws_grid_sample_bwd(A.ptr(d_gout), A.ptr(d_img), A.ptr(d_grid), A.ptr(gi), A.ptr(gg), n, c, h, w, h, w, 0, st), "bwd")
     torch.cuda.synchronize()
-    # frames are 0..255 and smooth (|grad| <~ 3/px); coordinate rounding ~1.5e-5 px at W=256
-    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=2e-3)
+    # frames are 0..255; coordinate rounding is ~3e-5 px at W=256 and the zero padding makes a 0 -> ~200 step at the
+    # image border, so border pixels differ by up to 255 * 3e-5 ~ 8e-3 (6e-5 on the [-1,1] scale; bound there 1e-3)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=1e-2)
     np.testing.assert_allclose(gi.cpu().numpy(), rgi, rtol=0, atol=1e-4)
     np.testing.assert_allclose(gg.cpu().numpy(), rgg, rtol=1e-4, atol=0.5)  # terms O(C*W/2*255)
     # grad-only variants
@@ -276,7 +289,8 @@ def test_heads_vs_oracle(hip, oracle):
     A.check(L.pws_pack_conv_weight(A.ptr(d_wl), A.ptr(pl), A.CONV_K1, hidden, 6, st), "pack")
     d_x, d_bf, d_bl = dev(nhwc(x)), dev(bf), dev(bl)
     theta = torch.empty((n, 6), device="cuda")
-    A.check(L.pws_theta_head_fwd(A.ptr(d_x), n, c, hidden, A.ptr(pf), A.ptr(d_bf), A.ptr(pl), A.ptr(d_bl), None, A.ptr(theta),
+    tws = torch.empty(L.pws_theta_head_ws_floats(n, c, hidden), device="cuda")
+    A.check(L.pws_theta_head_fwd(A.ptr(d_x), n, c, hidden, A.ptr(pf), A.ptr(d_bf), A.ptr(pl), A.ptr(d_bl), A.ptr(tws), A.ptr(theta),
                                  st), "theta")
     np.testing.assert_allclose(theta.cpu().numpy(), ref_theta, rtol=0, atol=2e-5)
 
