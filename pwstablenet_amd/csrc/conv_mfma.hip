@@ -304,7 +304,6 @@ static int launch_cfg(ConvKParams &kp, hipStream_t st, const ProfInfo &pi) {
         attr_set = true;
     }
     dim3 grid(kp.ntiles, (kp.cout + C::BN - 1) / C::BN, kp.nclasses * kp.ksplit);
-    ProfScope prof(KID, pi.flops, pi.bytes, st);
     hipLaunchKernelGGL(conv_mfma_kernel<C>, grid, dim3(C::THREADS), C::LDS_BYTES, st, kp);
     return check_launch("conv_mfma_kernel");
 }
@@ -353,7 +352,7 @@ constexpr long kFillBlocks = 512;  // 256 CUs x 2 resident workgroups
 // Pick the tile and the K split for one launch.
 //  1. drop tiles that are mostly padding for this extent (a 16x16 tile on an 8x8 map);
 //  2. take the largest remaining tile whose grid has >= kFillBlocks workgroups, else the one with the most workgroups;
-//  3. if the grid is still < kFillBlocks/2 and a workspace was given, split K (>= 2 chunks per split, <= 32 splits).
+//  3. if the grid is still < kFillBlocks and a workspace was given, split K (>= 2 chunks per split, <= 32 splits).
 static int select_and_launch(const TileChoice *cands, int ncand, ConvKParams &kp, int cin_total, float *final_out,
                              float *ws, size_t ws_floats, hipStream_t st, const ProfInfo &pi) {
     const TileChoice *best = nullptr;
@@ -377,7 +376,7 @@ static int select_and_launch(const TileChoice *cands, int ncand, ConvKParams &kp
     const int total_chunks = cin_total / c.ck;
     int ksplit = 1;
     const size_t out_floats = (size_t)kp.N * kp.OH * kp.OW * kp.cout;
-    if (best_blocks < kFillBlocks / 2 && ws && kp.out_ld == kp.cout && kp.cout % 4 == 0 && total_chunks >= 4) {
+    if (best_blocks < kFillBlocks && ws && kp.out_ld == kp.cout && kp.cout % 4 == 0 && total_chunks >= 4) {
         long want = cdiv(kFillBlocks, best_blocks);
         if (want > 32) want = 32;
         if (want > total_chunks / 2) want = total_chunks / 2;
@@ -389,6 +388,7 @@ static int select_and_launch(const TileChoice *cands, int ncand, ConvKParams &kp
     kp.ksplit = (int)cdiv(total_chunks, kp.chunks_per_split);  // no empty splits
     kp.split_stride = out_floats;
     kp.out = kp.ksplit > 1 ? ws : final_out;
+    ProfScope prof(c.kid, pi.flops, pi.bytes, st);  // covers the split-K reduce as well
     int rc = c.launch(kp, st, pi);
     if (rc != PWS_OK || kp.ksplit == 1) return rc;
     const size_t total4 = out_floats / 4;

@@ -8,6 +8,8 @@
 // because neighbouring lanes sample neighbouring source pixels when the field is smooth.  Workgroup ids are
 // remapped so that one XCD (one private L2) walks a contiguous range of rows of the same image.
 // Algorithmic traffic (C=3): fwd 8 (field) + 12 (frame) + 12 (out) = 32 B/pixel.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace pws {
@@ -75,6 +77,77 @@ __global__ void __launch_bounds__(256) grid_sample_fwd_kernel(const float *__res
 #pragma unroll
         for (int i = 0; i < PPT; ++i)
             r[i] = ip[t[i].o00] * t[i].w00 + ip[t[i].o01] * t[i].w01 + ip[t[i].o10] * t[i].w10 + ip[t[i].o11] * t[i].w11;
+        float *op = out + ((size_t)n * C + c) * HoWo + hw;
+        if constexpr (PPT == 4) {
+            *reinterpret_cast<float4 *>(op) = make_float4(r[0], r[1], r[2], r[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) op[i] = r[i];
+        }
+    }
+}
+
+// Paired taps: the two taps of one source row are adjacent in memory, so they are fetched with ONE 8-byte load
+// (global_load_dwordx2 needs only 4-byte alignment) -- half the gather instructions of the 4-scalar-tap form.
+// xs = clamp(x0, 0, W-2) is the pair start; at the left/right image border the valid tap moves to the other half.
+struct __attribute__((packed, aligned(4))) F2U {
+    float x, y;
+};
+struct Taps2 {
+    int o0, o1;          // offsets of the two row pairs inside a channel plane
+    float a0, b0, a1, b1;  // weights of (pair.x, pair.y) for row 0 and row 1
+};
+
+__device__ __forceinline__ Taps2 make_taps2(float gx, float gy, int H, int W, bool ac) {
+    const float ix = unnormalize(gx, W, ac), iy = unnormalize(gy, H, ac);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx, wx0 = 1.f - wx1, wy1 = iy - fy, wy0 = 1.f - wy1;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    const int xs = min(max(x0, 0), W - 2);
+    const int sel = x0 - xs;
+    const float wl = sel == 0 ? (vx0 ? wx0 : 0.f) : (sel == -1 ? (vx1 ? wx1 : 0.f) : 0.f);
+    const float wr = sel == 0 ? (vx1 ? wx1 : 0.f) : (sel == 1 ? (vx0 ? wx0 : 0.f) : 0.f);
+    const float r0 = vy0 ? wy0 : 0.f, r1 = vy1 ? wy1 : 0.f;
+    Taps2 t;
+    t.o0 = min(max(y0, 0), H - 1) * W + xs, t.o1 = min(max(y1, 0), H - 1) * W + xs;
+    t.a0 = wl * r0, t.b0 = wr * r0, t.a1 = wl * r1, t.b1 = wr * r1;
+    return t;
+}
+
+template <int PPT, bool REMAP>
+__global__ void __launch_bounds__(256) grid_sample_fwd2_kernel(const float *__restrict__ input,
+                                                               const float *__restrict__ grid, float *__restrict__ out,
+                                                               int C, int H, int W, int HoWo, size_t total_groups,
+                                                               unsigned nblocks, int ac) {
+    const unsigned blk = REMAP ? xcd_remap(blockIdx.x, nblocks) : blockIdx.x;
+    const size_t gidx = (size_t)blk * 256 + threadIdx.x;
+    if (gidx >= total_groups) return;
+    const size_t p0 = gidx * PPT;
+    const int n = (int)(p0 / HoWo);
+    const int hw = (int)(p0 % HoWo);
+    float g[2 * PPT];
+    if constexpr (PPT == 4) {
+        const float4 a = *reinterpret_cast<const float4 *>(grid + p0 * 2);
+        const float4 b = *reinterpret_cast<const float4 *>(grid + p0 * 2 + 4);
+        g[0] = a.x, g[1] = a.y, g[2] = a.z, g[3] = a.w, g[4] = b.x, g[5] = b.y, g[6] = b.z, g[7] = b.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2 * PPT; ++i) g[i] = grid[p0 * 2 + i];
+    }
+    Taps2 t[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) t[i] = make_taps2(g[2 * i], g[2 * i + 1], H, W, ac != 0);
+    const size_t plane = (size_t)H * W;
+    for (int c = 0; c < C; ++c) {
+        const float *ip = input + ((size_t)n * C + c) * plane;
+        float r[PPT];
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const F2U u = *reinterpret_cast<const F2U *>(ip + t[i].o0);
+            const F2U v = *reinterpret_cast<const F2U *>(ip + t[i].o1);
+            r[i] = u.x * t[i].a0 + u.y * t[i].b0 + v.x * t[i].a1 + v.y * t[i].b1;
+        }
         float *op = out + ((size_t)n * C + c) * HoWo + hw;
         if constexpr (PPT == 4) {
             *reinterpret_cast<float4 *>(op) = make_float4(r[0], r[1], r[2], r[3]);
@@ -220,7 +293,23 @@ extern "C" int pws_grid_sample_fwd(const float *input, const float *grid, float 
     // algorithmic traffic: field 8 B + out 4*C B per output pixel, frame 4*C B per input pixel; ~30 flop/px/channel
     ProfScope prof(KID_GRID_SAMPLE_FWD, (double)total * (14.0 + 8.0 * c),
                    (double)total * (8.0 + 4.0 * c) + 4.0 * c * (double)n * h * w, as_stream(stream));
-    if (howo % 4 == 0 && aligned16(grid) && aligned16(out)) {
+    static const int variant = getenv("PWS_GS_VARIANT") ? atoi(getenv("PWS_GS_VARIANT")) : 1;  // experiment knob
+    if (howo % 4 == 0 && aligned16(grid) && aligned16(out) && w >= 2 && variant >= 1) {
+        const size_t groups = total / 4;
+        const unsigned nb = (unsigned)((groups + 255) / 256);
+        if (variant == 1)
+            hipLaunchKernelGGL((grid_sample_fwd2_kernel<4, true>), dim3(nb), dim3(256), 0, as_stream(stream), input, grid, out, c,
+                               h, w, howo, groups, nb, align_corners);
+        else if (variant == 2)
+            hipLaunchKernelGGL((grid_sample_fwd2_kernel<4, false>), dim3(nb), dim3(256), 0, as_stream(stream), input, grid, out,
+                               c, h, w, howo, groups, nb, align_corners);
+        else {
+            const size_t groups2 = total / 2;
+            const unsigned nb2 = (unsigned)((groups2 + 255) / 256);
+            hipLaunchKernelGGL((grid_sample_fwd2_kernel<2, true>), dim3(nb2), dim3(256), 0, as_stream(stream), input, grid, out,
+                               c, h, w, howo, groups2, nb2, align_corners);
+        }
+    } else if (howo % 4 == 0 && aligned16(grid) && aligned16(out)) {
         const size_t groups = total / 4;
         const unsigned nb = (unsigned)((groups + 255) / 256);
         hipLaunchKernelGGL(grid_sample_fwd_kernel<4>, dim3(nb), dim3(256), 0, as_stream(stream), input, grid, out, c, h, w,

@@ -71,14 +71,16 @@ def test_netg_vs_oracle_on_box(hip, oracle):
 
 
 def test_netg_batch_invariance_and_repack(hip):
-    """Frames are independent units: a batch of 5 equals five batches of 1 bit-for-bit (no cross-sample op),
-    and an in-place weight update is picked up (re-pack on parameter version change)."""
+    """Frames are independent units (no cross-sample op): a batch of 5 equals five batches of 1 up to the fp32
+    summation order (tile shape and K split are chosen per batch size), and repeated calls are bit-identical
+    (no atomics on the forward path).  An in-place weight update is picked up (re-pack on version change)."""
     net = make_net("W1", 16)
     x = torch.from_numpy(synth.make_window(5, 31, 256, seed=11)).cuda()
     with torch.no_grad():
         full = net(x, False)
+        assert torch.equal(net(x, False), full), "forward must be deterministic run to run"
         for i in range(5):
-            assert torch.equal(net(x[i:i + 1], False)[0], full[i])
+            assert (net(x[i:i + 1], False)[0] - full[i]).abs().max().item() < 2e-5
         before = full.clone()
         net.module.out.mpconv[0].bias.add_(0.25)
         after = net(x, False)
