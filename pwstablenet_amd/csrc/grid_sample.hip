@@ -8,8 +8,6 @@
 // because neighbouring lanes sample neighbouring source pixels when the field is smooth.  Workgroup ids are
 // remapped so that one XCD (one private L2) walks a contiguous range of rows of the same image.
 // Algorithmic traffic (C=3): fwd 8 (field) + 12 (frame) + 12 (out) = 32 B/pixel.
-#include <cstdlib>
-
 #include "common.h"
 
 namespace pws {
@@ -115,12 +113,12 @@ __device__ __forceinline__ Taps2 make_taps2(float gx, float gy, int H, int W, bo
     return t;
 }
 
-template <int PPT, bool REMAP>
+template <int PPT>
 __global__ void __launch_bounds__(256) grid_sample_fwd2_kernel(const float *__restrict__ input,
                                                                const float *__restrict__ grid, float *__restrict__ out,
                                                                int C, int H, int W, int HoWo, size_t total_groups,
                                                                unsigned nblocks, int ac) {
-    const unsigned blk = REMAP ? xcd_remap(blockIdx.x, nblocks) : blockIdx.x;
+    const unsigned blk = xcd_remap(blockIdx.x, nblocks);
     const size_t gidx = (size_t)blk * 256 + threadIdx.x;
     if (gidx >= total_groups) return;
     const size_t p0 = gidx * PPT;
@@ -249,7 +247,7 @@ __global__ void __launch_bounds__(256) upsample_grid_sample_fwd_kernel(const flo
     const float ly = sy - y0, hy = 1.f - ly;
     const float2 *f0 = reinterpret_cast<const float2 *>(field) + ((size_t)n * fh + y0) * fw;
     const float2 *f1 = reinterpret_cast<const float2 *>(field) + ((size_t)n * fh + y1) * fw;
-    Taps t[PPT];
+    Taps2 t[PPT];
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
         const float sx = rx * (ox0 + i);
@@ -258,14 +256,17 @@ __global__ void __launch_bounds__(256) upsample_grid_sample_fwd_kernel(const flo
         const float2 a = f0[x0], b = f0[x1], c = f1[x0], d = f1[x1];
         const float gx = hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * d.x);
         const float gy = hy * (hx * a.y + lx * b.y) + ly * (hx * c.y + lx * d.y);
-        t[i] = make_taps(gx, gy, H, W, ac != 0);
+        t[i] = make_taps2(gx, gy, H, W, ac != 0);
     }
     for (int c = 0; c < C; ++c) {
         const float *ip = input + ((size_t)n * C + c) * HW;
         float r[PPT];
 #pragma unroll
-        for (int i = 0; i < PPT; ++i)
-            r[i] = ip[t[i].o00] * t[i].w00 + ip[t[i].o01] * t[i].w01 + ip[t[i].o10] * t[i].w10 + ip[t[i].o11] * t[i].w11;
+        for (int i = 0; i < PPT; ++i) {
+            const F2U u = *reinterpret_cast<const F2U *>(ip + t[i].o0);
+            const F2U v = *reinterpret_cast<const F2U *>(ip + t[i].o1);
+            r[i] = u.x * t[i].a0 + u.y * t[i].b0 + v.x * t[i].a1 + v.y * t[i].b1;
+        }
         float *op = out + ((size_t)n * C + c) * HW + hw;
         if constexpr (PPT == 4) {
             *reinterpret_cast<float4 *>(op) = make_float4(r[0], r[1], r[2], r[3]);
@@ -293,22 +294,15 @@ extern "C" int pws_grid_sample_fwd(const float *input, const float *grid, float 
     // algorithmic traffic: field 8 B + out 4*C B per output pixel, frame 4*C B per input pixel; ~30 flop/px/channel
     ProfScope prof(KID_GRID_SAMPLE_FWD, (double)total * (14.0 + 8.0 * c),
                    (double)total * (8.0 + 4.0 * c) + 4.0 * c * (double)n * h * w, as_stream(stream));
-    static const int variant = getenv("PWS_GS_VARIANT") ? atoi(getenv("PWS_GS_VARIANT")) : 1;  // experiment knob
-    if (howo % 4 == 0 && aligned16(grid) && aligned16(out) && w >= 2 && variant >= 1) {
+    if (howo % 4 == 0 && aligned16(grid) && aligned16(out) && w >= 2) {
         const size_t groups = total / 4;
         const unsigned nb = (unsigned)((groups + 255) / 256);
-        if (variant == 1)
-            hipLaunchKernelGGL((grid_sample_fwd2_kernel<4, true>), dim3(nb), dim3(256), 0, as_stream(stream), input, grid, out, c,
-                               h, w, howo, groups, nb, align_corners);
-        else if (variant == 2)
-            hipLaunchKernelGGL((grid_sample_fwd2_kernel<4, false>), dim3(nb), dim3(256), 0, as_stream(stream), input, grid, out,
-                               c, h, w, howo, groups, nb, align_corners);
-        else {
-            const size_t groups2 = total / 2;
-            const unsigned nb2 = (unsigned)((groups2 + 255) / 256);
-            hipLaunchKernelGGL((grid_sample_fwd2_kernel<2, true>), dim3(nb2), dim3(256), 0, as_stream(stream), input, grid, out,
-                               c, h, w, howo, groups2, nb2, align_corners);
-        }
+        hipLaunchKernelGGL(grid_sample_fwd2_kernel<4>, dim3(nb), dim3(256), 0, as_stream(stream), input, grid, out, c, h, w,
+                           howo, groups, nb, align_corners);
+    } else if (w >= 2) {
+        const unsigned nb = (unsigned)((total + 255) / 256);
+        hipLaunchKernelGGL(grid_sample_fwd2_kernel<1>, dim3(nb), dim3(256), 0, as_stream(stream), input, grid, out, c, h, w,
+                           howo, total, nb, align_corners);
     } else if (howo % 4 == 0 && aligned16(grid) && aligned16(out)) {
         const size_t groups = total / 4;
         const unsigned nb = (unsigned)((groups + 255) / 256);
@@ -374,7 +368,7 @@ extern "C" int pws_upsample_grid_sample_fwd(const float *input, const float *fie
     PWS_REQUIRE(n >= 0 && c > 0 && h > 0 && w > 0 && fh > 0 && fw > 0, "pws_upsample_grid_sample_fwd: bad shape");
     if (n == 0) return PWS_OK;
     PWS_REQUIRE(input && field && out, "pws_upsample_grid_sample_fwd: NULL pointer");
-    PWS_REQUIRE((size_t)h * w < (1u << 31), "pws_upsample_grid_sample_fwd: plane too large");
+    PWS_REQUIRE((size_t)h * w < (1u << 31) && w >= 2, "pws_upsample_grid_sample_fwd: plane too large or w < 2");
     const float ry = h > 1 ? (float)(fh - 1) / (float)(h - 1) : 0.f;
     const float rx = w > 1 ? (float)(fw - 1) / (float)(w - 1) : 0.f;
     const size_t total = (size_t)n * h * w;

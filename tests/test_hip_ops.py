@@ -241,10 +241,15 @@ def test_upsample_and_fused_720p_golden(hip, ops_golden):
     A.check(L.pws_grid_sample_fwd(A.ptr(frame), A.ptr(up_nhwc), A.ptr(w1), 1, 3, 720, 1280, 720, 1280, 0, st), "fwd")
     A.check(L.pws_upsample_grid_sample_fwd(A.ptr(frame), A.ptr(field), A.ptr(w2), 1, 3, 720, 1280, 256, 256, 0, st), "fused")
     torch.cuda.synchronize()
-    # 0..255 frames; 1e-2 abs == 8e-5 on the [-1,1] scale (bound 1e-3)
-    np.testing.assert_allclose(w1.cpu().numpy()[:, :, ::9, ::16], g["up_warp_sub"], rtol=0, atol=1e-2)
-    np.testing.assert_allclose(w2.cpu().numpy()[:, :, ::9, ::16], g["up_warp_sub"], rtol=0, atol=1e-2)
-    assert (w1 - w2).abs().max().item() < 1e-2
+    # 0..255 frames.  One ulp of the field at |g|~1 is 1.2e-7 = 7.6e-5 px at W=1280; interior pixels (smooth image,
+    # |grad| <~ 3/px) therefore agree to ~1e-3, but a pixel whose taps straddle the zero padding sees a 0 -> ~200 step
+    # and moves by 200 * (a few ulp) ~ 0.05.  Bound: north_star's 1e-3 on the [-1,1] scale (0.1275 here) everywhere,
+    # and 1e-2 (8e-5 scaled) for all but a handful of border samples.
+    for wgot in (w1, w2):
+        d = np.abs(wgot.cpu().numpy()[:, :, ::9, ::16] - g["up_warp_sub"])
+        assert d.max() < 0.1275, d.max()
+        assert (d > 1e-2).mean() < 2e-3
+    assert (w1 - w2).abs().max().item() < 0.1275
 
 
 def test_adam_golden_and_ragged(hip, oracle, ops_golden):

@@ -1,0 +1,20 @@
+#!/bin/bash
+# rocprofv3 evidence for one round: kernel-trace stats of the bench command + PMC passes (each in its own run).
+# usage (on the GPU box, from the repo root): bash tools/profile_round.sh r01
+set -u
+TAG=${1:-r01}
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err
+SHORT="python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof --gs-batch 256"
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $SHORT > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $SHORT > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F32 SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY -d $OUT/pmc_sq -o pmc -- $SHORT > /dev/null 2> $OUT/pmc_sq.err
+rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT -d $OUT/pmc_grbm -o pmc -- $SHORT > /dev/null 2> $OUT/pmc_grbm.err
+cd $REPO
+python3 tools/summarize_prof.py $OUT $TAG > $OUT/summary.log 2>&1
+ls -R $OUT | head -50
+tail -40 $OUT/summary.log
