@@ -363,6 +363,8 @@ static int select_and_launch(const TileChoice *cands, int ncand, ConvKParams &kp
         const long tiles = cdiv(kp.LW, c.tw) * cdiv(kp.LH, c.th) * cdiv(kp.N, c.tn);
         const double useful = (double)kp.N * kp.LH * kp.LW / ((double)tiles * c.th * c.tw * c.tn);
         if (useful < 0.45 && i + 1 < ncand) continue;
+        // sub-8 spatial tiles exist for maps that are themselves tiny; on a larger map their halo re-reads dominate
+        if (c.th < 8 && c.th < kp.LH && i > 0 && best) continue;
         const long blocks = tiles * cdiv(kp.cout, c.bn) * kp.nclasses;
         if (blocks >= kFillBlocks) {
             best = &c, best_blocks = blocks;

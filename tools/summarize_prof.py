@@ -1,15 +1,23 @@
 #!/usr/bin/env python3
-"""Condenses rocprofv3 output (kernel stats + per-dispatch PMC csv) into small per-kernel summaries.
-usage: summarize_prof.py <prof_dir> <tag>   -> writes <prof_dir>/<tag>_kernel_stats.csv, <tag>_pmc.json"""
+"""Condenses rocprofv3 (rocpd sqlite) output into small per-kernel summaries that can be committed under profiles/.
+
+usage: summarize_prof.py <prof_dir> <tag> [<dest_dir>]
+  <prof_dir>/trace/*.db            from  rocprofv3 --kernel-trace --stats
+  <prof_dir>/pmc_*/*.db            from  rocprofv3 --pmc ...   (one run per counter group)
+writes <dest>/<tag>_kernel_stats.csv and <dest>/<tag>_pmc.json
+"""
 import csv
 import glob
 import json
 import os
 import re
+import sqlite3
 import sys
 from collections import defaultdict
 
 d, tag = sys.argv[1], sys.argv[2]
+dest = sys.argv[3] if len(sys.argv) > 3 else d
+os.makedirs(dest, exist_ok=True)
 
 
 def short(name):
@@ -17,46 +25,60 @@ def short(name):
     m = re.match(r"pws::conv_mfma_kernel<pws::ConvCfg<([^>]*)>\s*>", name)
     if m:
         a = [x.strip() for x in m.group(1).split(",")]
-        return "conv_mfma_kernel<KS%s,S%s,convT=%s,tile%sx%sx%s,CK%s%s>" % (a[0], a[1], a[3][0], a[6], a[4], a[5], a[7],
-                                                                           ",NCHW" if len(a) > 12 and a[12].startswith("t") else "")
-    return re.sub(r"\(.*", "", name).replace("pws::", "")[:90]
+        return "conv_mfma_kernel<k%ss%s%s,tile %sx%sx%s,CK%s%s>" % (
+            a[0], a[1], ",convT" if a[3].startswith("t") else "", a[6], a[4], a[5], a[7],
+            ",NCHW" if len(a) > 12 and a[12].startswith("t") else "")
+    return re.sub(r"\(.*", "", name).replace("pws::", "")[:100]
 
 
-# ---- kernel stats
-stats = glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True)
-rows = []
-if stats:
-    with open(stats[0]) as f:
-        for r in csv.DictReader(f):
-            rows.append(r)
-    out = os.path.join(d, "%s_kernel_stats.csv" % tag)
+def db(sub):
+    f = glob.glob(os.path.join(d, sub, "**", "*.db"), recursive=True)
+    return sqlite3.connect(f[0]) if f else None
+
+
+c = db("trace")
+if c:
+    agg = defaultdict(list)
+    for name, dur in c.execute("select name, duration from kernels"):
+        agg[short(name)].append(dur)
+    tot = sum(sum(v) for v in agg.values())
+    out = os.path.join(dest, "%s_kernel_stats.csv" % tag)
     with open(out, "w") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns"])
-        for r in rows:
-            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+        for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([k, len(v), sum(v), round(sum(v) / len(v), 1), round(100.0 * sum(v) / tot, 3), min(v), max(v)])
     print("kernel stats ->", out)
-    for r in rows[:14]:
-        print("%6s calls  avg %10.1f us  %5s%%  %s" % (r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"], short(r["Name"])))
-else:
-    print("no kernel_stats csv found under", d)
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:16]:
+        print("%6d calls  avg %10.1f us  %6.2f%%  %s" % (len(v), sum(v) / len(v) / 1e3, 100.0 * sum(v) / tot, k))
 
-# ---- PMC: aggregate per kernel name: mean counter value per dispatch
-pmc = defaultdict(lambda: defaultdict(list))
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_grbm"):
-    for fn in glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True):
-        with open(fn) as f:
-            for r in csv.DictReader(f):
-                pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-summ = {}
-for k, cs in pmc.items():
-    summ[k] = {c: {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)} for c, v in cs.items()}
-out = os.path.join(d, "%s_pmc.json" % tag)
+summ = defaultdict(dict)
+for sub in sorted(glob.glob(os.path.join(d, "pmc_*"))):
+    if not os.path.isdir(sub):
+        continue
+    c = db(os.path.basename(sub))
+    if not c:
+        continue
+    per = defaultdict(lambda: defaultdict(float))  # (kernel, dispatch) -> counter -> summed over instances
+    durs = {}
+    for name, disp, cn, val, dur in c.execute(
+            "select kernel_name, dispatch_id, counter_name, value, duration from counters_collection"):
+        per[(short(name), disp)][cn] += val
+        durs[(short(name), disp)] = dur
+    bykernel = defaultdict(lambda: defaultdict(list))
+    for (k, disp), cs in per.items():
+        for cn, val in cs.items():
+            bykernel[k][cn].append(val)
+        bykernel[k]["_duration_ns_under_pmc"].append(durs[(k, disp)])
+    for k, cs in bykernel.items():
+        for cn, vals in cs.items():
+            summ[k][cn] = {"mean_per_dispatch": sum(vals) / len(vals), "dispatches": len(vals)}
+out = os.path.join(dest, "%s_pmc.json" % tag)
 with open(out, "w") as f:
     json.dump(summ, f, indent=1, sort_keys=True)
 print("pmc ->", out)
 for k, cs in sorted(summ.items()):
     if "conv_mfma" in k or "grid_sample" in k or "field_head" in k:
         print(k)
-        for c, v in sorted(cs.items()):
-            print("    %-28s %16.1f  (n=%d)" % (c, v["mean_per_dispatch"], v["dispatches"]))
+        for cn, v in sorted(cs.items()):
+            print("    %-28s %18.1f  (n=%d)" % (cn, v["mean_per_dispatch"], v["dispatches"]))
