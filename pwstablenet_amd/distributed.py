@@ -1,0 +1,87 @@
+"""One process per GPU over torch.distributed (backend "nccl" == RCCL over xGMI on ROCm; "gloo" for CPU tests).
+
+Replaces the reference's single-process ``nn.DataParallel`` (reference lib/networks_cascading.py:51-52):
+  * inference: frames are independent units -> contiguous chunk per rank, NO data-path collective; the streaming
+    loop needs the 15 frames before and after each frame (31-frame window, reference main_new.py:622-673), so a
+    chunk carries a halo of ``period//2`` frames on both sides;
+  * training: replicated weights + ONE gradient all-reduce per step, issued as a few large flat buckets
+    (xGMI is point-to-point, 7 links x ~153 GB/s per GPU: large messages, few of them), sum then divide by world.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialises the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun). Returns (rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            local = int(os.environ.get("LOCAL_RANK", "0"))
+            torch.cuda.set_device(local)
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend, **kw)
+    return rank, world
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def shard_frames(num_frames, rank, world, halo=15):
+    """Contiguous chunk of frame indices for ``rank`` plus the window halo it must also read.
+
+    Returns (start, stop, read_start, read_stop): the rank stabilises frames [start, stop) and needs source frames
+    [read_start, read_stop) (clamped to the video; the reference repeats the first/last frame at the ends,
+    main_new.py:627-633,653-660).  Chunks differ by at most one frame and cover every frame exactly once.
+    """
+    if world < 1 or not (0 <= rank < world) or num_frames < 0:
+        raise ValueError("bad shard request")
+    base, rem = divmod(num_frames, world)
+    start = rank * base + min(rank, rem)
+    stop = start + base + (1 if rank < rem else 0)
+    return start, stop, max(0, start - halo), min(num_frames, stop + halo)
+
+
+def max_over_ranks(value, device=None):
+    """MAX-reduce of a Python float (bench timing: the slowest rank defines the step time)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def allreduce_gradients(params, bucket_bytes=64 << 20):
+    """Averages ``p.grad`` over ranks in place, in flat buckets of ~bucket_bytes.
+
+    Shared-weight gradients (stages 2 and 3 use the same modules) are already accumulated locally by backward before
+    this is called.  Returns the number of collectives issued.
+    """
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    world = dist.get_world_size()
+    grads = [p.grad for p in params if p.grad is not None]
+    n_coll, i = 0, 0
+    while i < len(grads):
+        j, size = i, 0
+        while j < len(grads) and (size == 0 or size + grads[j].numel() * 4 <= bucket_bytes):
+            size += grads[j].numel() * 4
+            j += 1
+        flat = torch.cat([g.reshape(-1) for g in grads[i:j]])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(world)
+        off = 0
+        for g in grads[i:j]:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+        n_coll += 1
+        i = j
+    return n_coll

@@ -1,0 +1,126 @@
+"""CPU tests of the drop-in boundary: config surface, state-dict keys, C-ABI symbols, loud failure without a GPU."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+META = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_meta.json")))
+
+
+def test_cfg_matches_reference_defaults():
+    """Every flag of the reference's lib/cfg.py:7-39 with the same type and default; constants too."""
+    from pwstablenet_amd.lib import cfg
+    for name, (typ, default) in META["cfg_defaults"].items():
+        assert hasattr(cfg.opt, name), name
+        v = getattr(cfg.opt, name)
+        assert type(v).__name__ == typ, (name, type(v).__name__, typ)
+        assert v == default, (name, v, default)
+    assert cfg.REFERENCE_FLAGS and set(cfg.REFERENCE_FLAGS) == set(META["cfg_defaults"])
+    c = META["cfg_constants"]
+    assert cfg.period == c["period"]
+    assert cfg.index_sample.tolist() == c["index_sample"]
+    assert cfg.index_sample_discriminator.tolist() == c["index_sample_discriminator"]
+    assert (cfg.train_files, cfg.val_files, cfg.test_files) == (c["train_files"], c["val_files"], c["test_files"])
+    for name in ("opt", "period", "index_sample", "index_sample_discriminator", "train_files", "val_files", "test_files",
+                 "np", "cudnn", "parser", "argparse"):
+        assert hasattr(cfg, name)
+    # legacy main.py flags accepted
+    for name in ("gpu_ids", "dataset", "dir_logs", "train", "testBatchSize", "start_loss_affine", "affine_weight"):
+        assert hasattr(cfg.opt, name)
+
+
+def test_cfg_survives_foreign_argv_and_parses_flags():
+    code = ("import sys; sys.argv=['prog','--ngf','32','--mode','train','--unknown-flag','7'];"
+            "from pwstablenet_amd.lib.cfg import opt; print(opt.ngf, opt.mode, opt.batchSize)")
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT).decode().split()
+    assert out == ["32", "train", "16"]
+
+
+def test_state_dict_keys_shapes_order_match_reference():
+    import torch
+    from pwstablenet_amd.lib.networks_cascading import define_G
+    net = define_G(31, 2, 64, "normal", 0.02)
+    got = [[k, list(v.shape)] for k, v in net.state_dict().items()]
+    assert got == META["state_dict"]
+    assert sum(p.numel() for p in net.parameters()) == META["num_params"] == 48535944
+    # legacy 6th positional argument of main.py:28
+    net2 = define_G(31, 2, 16, "xavier", 0.02, [0])
+    assert len(net2.state_dict()) == 92
+    with pytest.raises(NotImplementedError):
+        define_G(31, 2, 16, "nope", 0.02)
+    # init rule 'normal': weights ~ N(0, 0.02), biases 0 (reference :29-40)
+    w = net.module.down4.mpconv[0].weight
+    assert abs(float(w.std()) - 0.02) < 1e-3 and float(net.module.down4.mpconv[0].bias.abs().max()) == 0.0
+    assert isinstance(net.module.down4.mpconv[1], torch.nn.LeakyReLU)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    from pwstablenet_amd import functional as PF
+    from pwstablenet_amd.lib.networks_cascading import define_G
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    net = define_G(31, 2, 16, "normal", 0.02)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(1, 31, 256, 256), False)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        PF.grid_sample(torch.zeros(1, 3, 8, 8), torch.zeros(1, 8, 8, 2))
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under pwstablenet_amd/ may import, load or execute it."""
+    for dp, _, files in os.walk(os.path.join(ROOT, "pwstablenet_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), os.path.join(dp, f)
+                assert "pws_oracle" not in txt and "libpws_oracle" not in txt, os.path.join(dp, f)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """libpwstable_hip.so loads (no GPU needed) and exports every function include/pwstable.h declares."""
+    from pwstablenet_amd import build, hipabi
+    build.build(force=False, verbose=False)
+    hdr = open(os.path.join(ROOT, "include", "pwstable.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pws_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    L = hipabi.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), "missing export " + name
+    assert declared == set(hipabi.SIGNATURES), declared ^ set(hipabi.SIGNATURES)
+    assert L.pws_version() == 1
+    assert L.pws_netg_packed_floats(31, 64) >= 48535944
+    assert L.pws_netg_workspace_bytes(8, 31, 64, 0) > 10 ** 9
+    assert L.pws_packed_weight_floats(hipabi.CONVT_K4S2, 1024, 256) == 16 * 1024 * 256
+    assert L.pws_conv2d_fwd(None, None) == -22 and b"NULL" in L.pws_last_error()
+
+
+def test_dropin_shims_resolve():
+    code = ("import sys; sys.argv=['x']; sys.path[:0]=[%r, %r];"
+            "from lib.networks_cascading import define_G, define_D, GANLoss; from lib.cfg import opt, period, index_sample;"
+            "import lib.networks_cascading as m; print(m.define_G.__module__, opt.input_nc, period)") % (
+        ROOT, os.path.join(ROOT, "dropin"))
+    out = subprocess.check_output([sys.executable, "-c", code], cwd="/tmp").decode().split()
+    assert out[-3:] == ["pwstablenet_amd.lib.networks_cascading", "31", "30"]
+
+
+def test_torch_ref_matches_reference_golden(netg_golden):
+    """The PyTorch-CPU restatement used as the host-CPU baseline reproduces the reference's outputs."""
+    import torch
+    from oracle import torch_ref
+    from pwstablenet_amd import synth
+    torch.set_num_threads(8)
+    params = [torch.from_numpy(v) for _, v in synth.make_weights("W2", seed=123, ngf=16)]
+    x = torch.from_numpy(synth.make_window(1, 31, 256, seed=123))
+    with torch.no_grad():
+        grids, resid = torch_ref.netg_forward(params, x, True)
+        g_inf = torch_ref.netg_forward(params, x, False)
+    assert torch.equal(g_inf, grids[2])
+    np.testing.assert_allclose(g_inf.numpy(), netg_golden["W2_g16_grid2_full"], rtol=0, atol=1e-6)
