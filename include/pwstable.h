@@ -97,12 +97,76 @@ typedef struct pws_conv_args {
 
 int pws_conv2d_fwd(const pws_conv_args *args, pws_stream_t stream);
 
+/* ---------------------------------------------------------------- backward of the conv blocks
+ * (autograd of the reference's loss_g.backward(), main_new.py:214, through nn.Conv2d / nn.ConvTranspose2d /
+ *  LeakyReLU / ReLU / torch.cat of lib/networks_cascading.py:245-350)
+ *
+ * Order per layer:  1. pws_act_bwd_bias   dy <- dy * act'(y) in place, db += sum_pixels dy
+ *                   2. pws_conv2d_bwd_weight   dW_packed += x (*) dy
+ *                   3. pws_conv2d_bwd_data     dx (scattered over the layer's concat sources) = dy (*) W
+ * `kind` is always the FORWARD kind of the layer; n,h,w the forward INPUT extent; cout the forward cout. */
+
+/* dy[i] *= act'(y[i]) (LeakyReLU(0.2): y>0 ? 1 : 0.2 ; ReLU: y>0 ? 1 : 0 ; NONE: 1); dbias[c] += sum over pixels.
+ * dy, y: dense NHWC [pixels][c]; dbias (nullable): c floats, ACCUMULATED (fp32 atomics, one per workgroup and channel). */
+int pws_act_bwd_bias(float *dy, const float *y, size_t pixels, int c, int act, float *dbias, pws_stream_t stream);
+
+/* Weights re-laid-out for the data-gradient convolution of a layer.  kind in {K3S1, K3S2, CONVT_K3S1, CONVT_K4S2}. */
+size_t pws_packed_dgrad_floats(int kind, int cin, int cout);
+int pws_pack_conv_weight_dgrad(const float *w_torch, float *w_packed, int kind, int cin, int cout, pws_stream_t stream);
+
+typedef struct pws_dst {
+    float *ptr;      /* NHWC gradient buffer of one forward source */
+    int channels;
+    int ld;
+    int accumulate;  /* 0: overwrite, 1: add to what is there (a tensor consumed by several layers) */
+} pws_dst;
+
+typedef struct pws_conv_bwd_data_args {
+    int kind;
+    int n, h, w;       /* forward input extent */
+    int cout;          /* forward output channels (multiple of 16) */
+    const float *gout; /* dy, NHWC [n, oh, ow, cout], pixel stride gout_ld */
+    int gout_ld;
+    const float *w_dgrad; /* from pws_pack_conv_weight_dgrad */
+    int ndst;          /* 1..4 destinations = the forward sources, in concat order */
+    pws_dst dst[4];
+    void *ws;          /* optional split-K scratch, as in pws_conv_args */
+    size_t ws_bytes;
+} pws_conv_bwd_data_args;
+int pws_conv2d_bwd_data(const pws_conv_bwd_data_args *args, pws_stream_t stream);
+
+typedef struct pws_conv_bwd_weight_args {
+    int kind;          /* K3S1 | K3S2 | K5S1 | CONVT_K3S1 | CONVT_K4S2 */
+    int n, h, w;       /* forward input extent */
+    int nsrc;          /* forward sources (x), as in pws_conv_args */
+    pws_src src[4];
+    int src_nchw;      /* first layer: x is the dense NCHW window */
+    int cout;
+    const float *gout; /* dy (already multiplied by act'), NHWC dense, pixel stride gout_ld */
+    int gout_ld;
+    float *dw_packed;  /* gradient in the FORWARD packed layout (pws_packed_weight_floats), ACCUMULATED into
+                          (fp32 atomics: several pixel ranges, and stages 2/3 share weights) */
+} pws_conv_bwd_weight_args;
+int pws_conv2d_bwd_weight(const pws_conv_bwd_weight_args *args, pws_stream_t stream);
+
+/* Inverse of pws_pack_conv_weight: packed gradient -> torch layout (OIHW / IOHW), overwriting dw_torch. */
+int pws_unpack_conv_weight(const float *w_packed, float *w_torch, int kind, int cin, int cout, pws_stream_t stream);
+
 /* theta = LReLU(W2 . LReLU(W1 . vec(x) + b1) + b2)   x: NHWC [n,2,2,c] (ld == c), theta: [n,6].
  * w_flat packed as PWS_CONV_K2S1P0 (c -> hidden), w_lin packed as PWS_CONV_K1 (hidden -> 6).
  * ws: pws_theta_head_ws_floats(n, c, hidden) floats of scratch (K-split partial sums). */
 size_t pws_theta_head_ws_floats(int n, int c, int hidden);
 int pws_theta_head_fwd(const float *x, int n, int c, int hidden, const float *w_flat, const float *b_flat,
                        const float *w_lin, const float *b_lin, float *ws, float *theta, pws_stream_t stream);
+/* Same, additionally saving the hidden activations h[n,hidden] (post-LeakyReLU) for pws_theta_head_bwd. */
+int pws_theta_head_fwd_save(const float *x, int n, int c, int hidden, const float *w_flat, const float *b_flat,
+                            const float *w_lin, const float *b_lin, float *ws, float *theta, float *h_saved,
+                            pws_stream_t stream);
+/* Backward of the theta head.  dtheta[n,6] in; dw_flat (packed K2S1P0 layout [4c][hidden]), db_flat, dw_lin
+ * ([hidden][6]), db_lin ACCUMULATED; dx (nullable) [n,2,2,c] overwritten or accumulated; ws: n*hidden floats. */
+int pws_theta_head_bwd(const float *x, int n, int c, int hidden, const float *w_flat, const float *w_lin,
+                       const float *h_saved, const float *theta, const float *dtheta, float *dw_flat, float *db_flat,
+                       float *dw_lin, float *db_lin, float *dx, int dx_accumulate, float *ws, pws_stream_t stream);
 
 /* field = tanh(tanh(conv3x3(x; 2 outputs) + b)) as N,H,W,2, plus affine_grid(theta) when theta != NULL.
  * x: NHWC [n,h,w,c] pixel stride ld.  w_out packed as PWS_CONV_K3S1_OUT.  resid (nullable) receives the
@@ -110,6 +174,13 @@ int pws_theta_head_fwd(const float *x, int n, int c, int hidden, const float *w_
 int pws_field_head_fwd(const float *x, int ld, int n, int h, int w, int c, const float *w_out,
                        const float *b_out, const float *theta, int align_corners, float *resid, float *grid,
                        pws_stream_t stream);
+
+/* Backward of pws_field_head_fwd.  resid: the forward's residual output; g_grid / g_resid (either nullable): gradients
+ * wrt the two outputs.  dx (nullable) [n,h,w,c] overwritten or accumulated; dw_out (packed [9][c][2]) and db_out[2]
+ * ACCUMULATED (atomics); dtheta (nullable) [n,6] overwritten; ws: n*h*w*2 floats. */
+int pws_field_head_bwd(const float *x, int ld, int n, int h, int w, int c, const float *w_out, const float *resid,
+                       const float *g_grid, const float *g_resid, int align_corners, float *dx, int dx_ld,
+                       int dx_accumulate, float *dw_out, float *db_out, float *dtheta, float *ws, pws_stream_t stream);
 
 /* F.affine_grid(theta[n,2,3], (n,*,h,w)) -> grid[n,h,w,2] */
 int pws_affine_grid(const float *theta, float *grid, int n, int h, int w, int align_corners,
@@ -147,6 +218,22 @@ size_t pws_netg_workspace_bytes(int n, int input_nc, int ngf, int is_training);
 int pws_netg_forward(const float *packed, const float *x, int n, int input_nc, int ngf, int is_training,
                      int align_corners, void *ws, size_t ws_bytes, float *grids, float *resid, float *thetas,
                      pws_stream_t stream);
+
+/* ---- training: backward of the whole generator (is_training=1 forward must have run on the SAME ws, untouched since).
+ * Data-gradient weights: a second packed buffer (pws_netg_packed_dgrad_floats) filled by pws_netg_pack_weights_dgrad.
+ * g_grids / g_resid: [3][n,256,256,2] each, or NULL as a whole (no gradient wrt that output list).
+ * dpacked: gradient of every weight and bias in the layout of `packed` (pws_netg_packed_floats floats), overwritten;
+ * pws_netg_unpack_grads converts it to 92 torch-layout tensors.  dx (nullable): gradient wrt the input window is not
+ * needed by the reference (the window is data) and is not computed. */
+size_t pws_netg_packed_dgrad_floats(int input_nc, int ngf);
+int pws_netg_pack_weights_dgrad(const float *const *params, float *packed_dgrad, int input_nc, int ngf,
+                                pws_stream_t stream);
+size_t pws_netg_train_workspace_bytes(int n, int input_nc, int ngf);
+int pws_netg_backward(const float *packed, const float *packed_dgrad, const float *x, int n, int input_nc, int ngf,
+                      int align_corners, void *ws, size_t ws_bytes, const float *resid, const float *thetas,
+                      const float *g_grids, const float *g_resid, float *dpacked, pws_stream_t stream);
+/* grads: HOST array of 92 DEVICE pointers (torch layouts, state-dict order), overwritten. */
+int pws_netg_unpack_grads(const float *dpacked, float *const *grads, int input_nc, int ngf, pws_stream_t stream);
 
 /* ---------------------------------------------------------------- measurement hooks (bench / tests only)
  * When enabled, every kernel launch of this library is bracketed by two hipEvents on the launch stream and

@@ -46,7 +46,8 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
 enum KernelId {
     KID_CONV_K3S1_BIG = 0, KID_CONV_K3S1_SMALL, KID_CONV_K3S2_BIG, KID_CONV_K3S2_SMALL, KID_CONV_K5S1, KID_CONVT4_BIG,
     KID_CONVT4_SMALL, KID_THETA_HEAD, KID_FIELD_HEAD, KID_GRID_SAMPLE_FWD, KID_GRID_SAMPLE_BWD, KID_UPSAMPLE_GRID_SAMPLE_FWD,
-    KID_UPSAMPLE, KID_AFFINE_GRID, KID_ADAM, KID_PACK, KID_COUNT
+    KID_UPSAMPLE, KID_AFFINE_GRID, KID_ADAM, KID_PACK, KID_DGRAD_K4S2, KID_DGRAD_SP3, KID_WGRAD, KID_ACT_BWD, KID_FIELD_HEAD_BWD,
+    KID_THETA_HEAD_BWD, KID_COUNT
 };
 extern bool g_prof_on;
 extern int g_prof_tag;

@@ -45,17 +45,41 @@ struct ConvKParams {
     int act;
     int tiles_x, tiles_y;
     unsigned ntiles;
-    int nclasses;   // 4 for convT k4s2, else 1
+    int nclasses;   // 4 for the sub-pixel modes, else 1
     int ksplit;     // >= 1
     int chunks_per_split;
     size_t split_stride;  // floats between consecutive partial buffers
+    // data-gradient mode: the output channels are scattered over up to 4 NHWC destinations (the sources of the
+    // forward layer's virtual concat), each either overwritten or accumulated into.  ndst == 0: plain `out`.
+    int ndst;
+    float *dst_ptr[4];
+    int dst_c0[4], dst_c1[4], dst_ld[4], dst_acc[4];
 };
 
-template <int KS_, int STRIDE_, int PAD_, bool CONVT_, int TH_, int TW_, int TN_, int CK_, int WM_, int WN_, int MT_,
+// final store of one output element (pixel index `pix` in the output tensor, channel `co`)
+__device__ __forceinline__ void epi_store(const ConvKParams &p, size_t pix, int co, float v) {
+    if (p.ndst == 0) {
+        p.out[pix * p.out_ld + co] = act_apply(v + (p.bias ? p.bias[co] : 0.f), p.act);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s < p.ndst && co >= p.dst_c0[s] && co < p.dst_c1[s]) {
+                float *d = p.dst_ptr[s] + pix * p.dst_ld[s] + (co - p.dst_c0[s]);
+                *d = p.dst_acc[s] ? *d + v : v;
+            }
+        }
+    }
+}
+
+// SUBPIX: 0 = ordinary convolution; 1 = ConvTranspose2d k4 s2 p1 forward (output parity class (py,px) is a 2x2
+// convolution whose window starts at (y+py-1, x+px-1)); 2 = data gradient of Conv2d k3 s2 p1 (class (py,px) is a 2x2
+// window starting at (y, x) of which the even parity uses only the first tap).
+template <int KS_, int STRIDE_, int PAD_, int SUBPIX_, int TH_, int TW_, int TN_, int CK_, int WM_, int WN_, int MT_,
           int NT_, bool NCHW_ = false>
 struct ConvCfg {
     static constexpr int KS = KS_, STRIDE = STRIDE_, PAD = PAD_, TH = TH_, TW = TW_, TN = TN_, CK = CK_;
-    static constexpr bool CONVT = CONVT_, NCHW = NCHW_;
+    static constexpr int SUBPIX = SUBPIX_;
+    static constexpr bool CONVT = SUBPIX_ != 0, NCHW = NCHW_;
     static constexpr int WM = WM_, WN = WN_, MT = MT_, NT = NT_;
     static constexpr int THREADS = 64 * WM * WN;
     static constexpr int BM = TH * TW * TN, BN = 32 * NT * WN;
@@ -94,8 +118,8 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_mfma_kernel(const ConvKPar
     const int cls = C::CONVT ? (int)(blockIdx.z & 3) : 0;
     const int split = C::CONVT ? (int)(blockIdx.z >> 2) : (int)blockIdx.z;
     const int py = cls >> 1, px = cls & 1;
-    const int pad_y = C::CONVT ? 1 - py : C::PAD;
-    const int pad_x = C::CONVT ? 1 - px : C::PAD;
+    const int pad_y = C::SUBPIX == 1 ? 1 - py : (C::SUBPIX == 2 ? 0 : C::PAD);
+    const int pad_x = C::SUBPIX == 1 ? 1 - px : (C::SUBPIX == 2 ? 0 : C::PAD);
     const int iy0 = y0 * C::STRIDE - pad_y, ix0 = x0 * C::STRIDE - pad_x;
 
     // ---- hoisted per-thread staging descriptors (pixel decode is chunk independent)
@@ -217,6 +241,7 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_mfma_kernel(const ConvKPar
 
 #pragma unroll
         for (int tap = 0; tap < C::TAPS; ++tap) {
+            if (C::SUBPIX == 2 && ((!py && tap / C::KS) || (!px && tap % C::KS))) continue;  // block-uniform
             const int toff = ((tap / C::KS) * C::IW + (tap % C::KS)) * C::CKP;
 #pragma unroll
             for (int kk = 0; kk < C::CK / 2; ++kk) {
@@ -234,15 +259,14 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_mfma_kernel(const ConvKPar
         }
     }
 
-    // ---- epilogue: bias + activation (or raw partial sums when K is split), NHWC store
+    // ---- epilogue: bias + activation / gradient scatter (or raw partial sums when K is split), NHWC store
     //      (32 lanes = 32 consecutive channels = 128 B per pixel)
     const bool partial = p.ksplit > 1;
-    float *outp = p.out + (partial ? (size_t)split * p.split_stride : 0);
+    float *part = p.out + (size_t)split * p.split_stride;
 #pragma unroll
     for (int nt = 0; nt < C::NT; ++nt) {
         const int co = co0 + (wn * C::NT + nt) * 32 + l31;
         const bool co_ok = co < p.cout;
-        const float bias = (co_ok && p.bias && !partial) ? p.bias[co] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt) {
 #pragma unroll
@@ -250,34 +274,33 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_mfma_kernel(const ConvKPar
                 const int m = (wm * C::MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
                 const int n = n0 + tn, y = y0 + ty, x = x0 + tx;
-                if (co_ok && n < p.N && y < p.LH && x < p.LW) {
-                    const int oy = C::CONVT ? 2 * y + py : y, ox = C::CONVT ? 2 * x + px : x;
-                    const float v = partial ? acc[mt][nt][r] : act_apply(acc[mt][nt][r] + bias, p.act);
-                    outp[((size_t)(n * p.OH + oy) * p.OW + ox) * p.out_ld + co] = v;
+                const int oy = C::CONVT ? 2 * y + py : y, ox = C::CONVT ? 2 * x + px : x;
+                if (co_ok && n < p.N && y < p.LH && x < p.LW && oy < p.OH && ox < p.OW) {
+                    const size_t pix = (size_t)(n * p.OH + oy) * p.OW + ox;
+                    if (partial)
+                        part[pix * p.cout + co] = acc[mt][nt][r];
+                    else
+                        epi_store(p, pix, co, acc[mt][nt][r]);
                 }
             }
         }
     }
 }
 
-// out[i] = act(sum_s partial[s][i] + bias[i % cout]); `total` floats, dense (out_ld == cout), float4 per lane
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float *__restrict__ partial, int ksplit, size_t stride,
-                                                            const float *__restrict__ bias, int cout, int act,
-                                                            float *__restrict__ out, size_t total4) {
+// Split-K reduce: sum the partial tiles (in split order: deterministic) and run the ordinary epilogue.
+// partial[s] is dense [pixels][cout]; 4 consecutive channels per lane.
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvKParams p, const float *__restrict__ partial,
+                                                            size_t total4) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total4) return;
     float4 a = reinterpret_cast<const float4 *>(partial)[i];
-    for (int s = 1; s < ksplit; ++s) {
-        const float4 b = reinterpret_cast<const float4 *>(partial + (size_t)s * stride)[i];
+    for (int s = 1; s < p.ksplit; ++s) {
+        const float4 b = reinterpret_cast<const float4 *>(partial + (size_t)s * p.split_stride)[i];
         a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
     }
-    const int co = (int)((i * 4) % cout);
-    if (bias) {
-        const float4 b = *reinterpret_cast<const float4 *>(bias + co);
-        a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
-    }
-    a.x = act_apply(a.x, act), a.y = act_apply(a.y, act), a.z = act_apply(a.z, act), a.w = act_apply(a.w, act);
-    reinterpret_cast<float4 *>(out)[i] = a;
+    const size_t pix = (i * 4) / p.cout;
+    const int co = (int)((i * 4) % p.cout);
+    epi_store(p, pix, co, a.x), epi_store(p, pix, co + 1, a.y), epi_store(p, pix, co + 2, a.z), epi_store(p, pix, co + 3, a.w);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -313,24 +336,36 @@ static constexpr TileChoice choice() {
     return TileChoice{C::TH, C::TW, C::TN, C::CK, C::BN, KID, &launch_cfg<C, KID>};
 }
 
-//                        KS S  P  convT  TH  TW  TN  CK WM WN MT NT
-using K3S1_T256 = ConvCfg<3, 1, 1, false, 16, 16, 1, 16, 4, 1, 2, 2>;
-using K3S1_T128 = ConvCfg<3, 1, 1, false, 8, 16, 1, 16, 4, 1, 1, 2>;
-using K3S1_T64 = ConvCfg<3, 1, 1, false, 8, 8, 1, 16, 2, 2, 1, 1>;
-using K3S1_T64N4 = ConvCfg<3, 1, 1, false, 4, 4, 4, 16, 2, 2, 1, 1>;
-using K3S1_T64N16 = ConvCfg<3, 1, 1, false, 2, 2, 16, 16, 2, 2, 1, 1>;
-using K3S2_T256 = ConvCfg<3, 2, 1, false, 16, 16, 1, 8, 4, 1, 2, 2>;
-using K3S2_T128 = ConvCfg<3, 2, 1, false, 8, 16, 1, 16, 4, 1, 1, 2>;
-using K3S2_T64 = ConvCfg<3, 2, 1, false, 8, 8, 1, 16, 2, 2, 1, 1>;
-using K3S2_T64N4 = ConvCfg<3, 2, 1, false, 4, 4, 4, 16, 2, 2, 1, 1>;
-using K3S2_T64N16 = ConvCfg<3, 2, 1, false, 2, 2, 16, 16, 2, 2, 1, 1>;
-using K5S1_T256 = ConvCfg<5, 1, 2, false, 16, 16, 1, 8, 4, 1, 2, 2>;
-using K5S1_T256_NCHW = ConvCfg<5, 1, 2, false, 16, 16, 1, 8, 4, 1, 2, 2, true>;
-using CT4_T256 = ConvCfg<2, 1, 0, true, 16, 16, 1, 16, 4, 1, 2, 2>;
-using CT4_T128 = ConvCfg<2, 1, 0, true, 8, 16, 1, 16, 4, 1, 1, 2>;
-using CT4_T64 = ConvCfg<2, 1, 0, true, 8, 8, 1, 16, 2, 2, 1, 1>;
-using CT4_T64N4 = ConvCfg<2, 1, 0, true, 4, 4, 4, 16, 2, 2, 1, 1>;
-using CT4_T64N16 = ConvCfg<2, 1, 0, true, 2, 2, 16, 16, 2, 2, 1, 1>;
+//                        KS S  P  subpix TH  TW  TN  CK WM WN MT NT
+using K3S1_T256 = ConvCfg<3, 1, 1, 0, 16, 16, 1, 16, 4, 1, 2, 2>;
+using K3S1_T128 = ConvCfg<3, 1, 1, 0, 8, 16, 1, 16, 4, 1, 1, 2>;
+using K3S1_T64 = ConvCfg<3, 1, 1, 0, 8, 8, 1, 16, 2, 2, 1, 1>;
+using K3S1_T64N4 = ConvCfg<3, 1, 1, 0, 4, 4, 4, 16, 2, 2, 1, 1>;
+using K3S1_T64N16 = ConvCfg<3, 1, 1, 0, 2, 2, 16, 16, 2, 2, 1, 1>;
+using K3S2_T256 = ConvCfg<3, 2, 1, 0, 16, 16, 1, 8, 4, 1, 2, 2>;
+using K3S2_T128 = ConvCfg<3, 2, 1, 0, 8, 16, 1, 16, 4, 1, 1, 2>;
+using K3S2_T64 = ConvCfg<3, 2, 1, 0, 8, 8, 1, 16, 2, 2, 1, 1>;
+using K3S2_T64N4 = ConvCfg<3, 2, 1, 0, 4, 4, 4, 16, 2, 2, 1, 1>;
+using K3S2_T64N16 = ConvCfg<3, 2, 1, 0, 2, 2, 16, 16, 2, 2, 1, 1>;
+using K5S1_T256 = ConvCfg<5, 1, 2, 0, 16, 16, 1, 8, 4, 1, 2, 2>;
+using K5S1_T256_NCHW = ConvCfg<5, 1, 2, 0, 16, 16, 1, 8, 4, 1, 2, 2, true>;
+using CT4_T256 = ConvCfg<2, 1, 0, 1, 16, 16, 1, 16, 4, 1, 2, 2>;
+using CT4_T128 = ConvCfg<2, 1, 0, 1, 8, 16, 1, 16, 4, 1, 1, 2>;
+using CT4_T64 = ConvCfg<2, 1, 0, 1, 8, 8, 1, 16, 2, 2, 1, 1>;
+using CT4_T64N4 = ConvCfg<2, 1, 0, 1, 4, 4, 4, 16, 2, 2, 1, 1>;
+using CT4_T64N16 = ConvCfg<2, 1, 0, 1, 2, 2, 16, 16, 2, 2, 1, 1>;
+
+// data-gradient kernels: conv k4 s2 p1 (gradient of ConvTranspose2d k4 s2 p1) and the sub-pixel gradient of conv k3 s2 p1
+using K4S2_T256 = ConvCfg<4, 2, 1, 0, 16, 16, 1, 8, 4, 1, 2, 2>;
+using K4S2_T128 = ConvCfg<4, 2, 1, 0, 8, 16, 1, 8, 4, 1, 1, 2>;
+using K4S2_T64 = ConvCfg<4, 2, 1, 0, 8, 8, 1, 8, 2, 2, 1, 1>;
+using K4S2_T64N4 = ConvCfg<4, 2, 1, 0, 4, 4, 4, 8, 2, 2, 1, 1>;
+using K4S2_T64N16 = ConvCfg<4, 2, 1, 0, 2, 2, 16, 8, 2, 2, 1, 1>;
+using SP3_T256 = ConvCfg<2, 1, 0, 2, 16, 16, 1, 16, 4, 1, 2, 2>;
+using SP3_T128 = ConvCfg<2, 1, 0, 2, 8, 16, 1, 16, 4, 1, 1, 2>;
+using SP3_T64 = ConvCfg<2, 1, 0, 2, 8, 8, 1, 16, 2, 2, 1, 1>;
+using SP3_T64N4 = ConvCfg<2, 1, 0, 2, 4, 4, 4, 16, 2, 2, 1, 1>;
+using SP3_T64N16 = ConvCfg<2, 1, 0, 2, 2, 2, 16, 16, 2, 2, 1, 1>;
 
 // candidates ordered from the largest tile (best operand reuse) to the smallest
 static const TileChoice kK3S1[] = {choice<K3S1_T256, KID_CONV_K3S1_BIG>(), choice<K3S1_T128, KID_CONV_K3S1_BIG>(),
@@ -342,6 +377,12 @@ static const TileChoice kK3S2[] = {choice<K3S2_T256, KID_CONV_K3S2_BIG>(), choic
 static const TileChoice kCT4[] = {choice<CT4_T256, KID_CONVT4_BIG>(), choice<CT4_T128, KID_CONVT4_BIG>(),
                                   choice<CT4_T64, KID_CONVT4_SMALL>(), choice<CT4_T64N4, KID_CONVT4_SMALL>(),
                                   choice<CT4_T64N16, KID_CONVT4_SMALL>()};
+static const TileChoice kK4S2[] = {choice<K4S2_T256, KID_DGRAD_K4S2>(), choice<K4S2_T128, KID_DGRAD_K4S2>(),
+                                   choice<K4S2_T64, KID_DGRAD_K4S2>(), choice<K4S2_T64N4, KID_DGRAD_K4S2>(),
+                                   choice<K4S2_T64N16, KID_DGRAD_K4S2>()};
+static const TileChoice kSP3[] = {choice<SP3_T256, KID_DGRAD_SP3>(), choice<SP3_T128, KID_DGRAD_SP3>(),
+                                  choice<SP3_T64, KID_DGRAD_SP3>(), choice<SP3_T64N4, KID_DGRAD_SP3>(),
+                                  choice<SP3_T64N16, KID_DGRAD_SP3>()};
 static const TileChoice kK5[] = {choice<K5S1_T256, KID_CONV_K5S1>()};
 static const TileChoice kK5N[] = {choice<K5S1_T256_NCHW, KID_CONV_K5S1>()};
 
@@ -378,7 +419,7 @@ static int select_and_launch(const TileChoice *cands, int ncand, ConvKParams &kp
     const int total_chunks = cin_total / c.ck;
     int ksplit = 1;
     const size_t out_floats = (size_t)kp.N * kp.OH * kp.OW * kp.cout;
-    if (best_blocks < kFillBlocks && ws && kp.out_ld == kp.cout && kp.cout % 4 == 0 && total_chunks >= 4) {
+    if (best_blocks < kFillBlocks && ws && kp.cout % 4 == 0 && total_chunks >= 4) {
         long want = cdiv(kFillBlocks, best_blocks);
         if (want > 32) want = 32;
         if (want > total_chunks / 2) want = total_chunks / 2;
@@ -394,8 +435,8 @@ static int select_and_launch(const TileChoice *cands, int ncand, ConvKParams &kp
     int rc = c.launch(kp, st, pi);
     if (rc != PWS_OK || kp.ksplit == 1) return rc;
     const size_t total4 = out_floats / 4;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv((long)total4, 256)), dim3(256), 0, st, ws, kp.ksplit, out_floats,
-                       kp.bias, kp.cout, kp.act, final_out, total4);
+    kp.out = final_out;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv((long)total4, 256)), dim3(256), 0, st, kp, ws, total4);
     return check_launch("splitk_reduce_kernel");
 }
 
@@ -469,8 +510,63 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
     }
 }
 
+// Data gradient of one forward layer: dx (scattered over the forward layer's sources) from dy.
+// Every case is again a convolution of dy, run by the same kernel with re-packed weights (pack.hip, dgrad layouts).
+int conv2d_bwd_data_impl(const pws_conv_bwd_data_args *a, hipStream_t st) {
+    PWS_REQUIRE(a != nullptr, "pws_conv2d_bwd_data: args is NULL");
+    PWS_REQUIRE(a->n >= 0 && a->h > 0 && a->w > 0 && a->cout > 0 && a->cout % 16 == 0, "pws_conv2d_bwd_data: bad shape");
+    PWS_REQUIRE(a->gout && a->w_dgrad && a->gout_ld >= a->cout && a->gout_ld % 4 == 0, "pws_conv2d_bwd_data: bad gout / weights");
+    PWS_REQUIRE(a->ndst >= 1 && a->ndst <= 4, "pws_conv2d_bwd_data: ndst %d not in 1..4", a->ndst);
+    if (a->n == 0) return PWS_OK;
+    ConvKParams kp{};
+    int oh = a->h, ow = a->w;  // forward OUTPUT extent = extent of gout
+    if (a->kind == PWS_CONV_K3S2) oh = (a->h - 1) / 2 + 1, ow = (a->w - 1) / 2 + 1;
+    if (a->kind == PWS_CONVT_K4S2) oh = 2 * a->h, ow = 2 * a->w;
+    kp.nsrc = 1, kp.src_ptr[0] = a->gout, kp.src_c[0] = a->cout, kp.src_ld[0] = a->gout_ld;
+    kp.N = a->n, kp.H = oh, kp.W = ow;
+    kp.OH = a->h, kp.OW = a->w;  // dx has the forward INPUT extent
+    kp.cin_pad = a->cout;
+    int cin_f = 0;
+    kp.ndst = a->ndst;
+    for (int s = 0; s < a->ndst; ++s) {
+        const pws_dst &d = a->dst[s];
+        PWS_REQUIRE(d.ptr && d.channels > 0 && d.ld >= d.channels, "pws_conv2d_bwd_data: bad destination %d", s);
+        kp.dst_ptr[s] = d.ptr, kp.dst_c0[s] = cin_f, kp.dst_c1[s] = cin_f + d.channels, kp.dst_ld[s] = d.ld;
+        kp.dst_acc[s] = d.accumulate ? 1 : 0;
+        cin_f += d.channels;
+    }
+    PWS_REQUIRE(cin_f % 4 == 0, "pws_conv2d_bwd_data: total destination channels %d must be a multiple of 4", cin_f);
+    kp.cout = cin_f, kp.w = a->w_dgrad, kp.bias = nullptr, kp.act = PWS_ACT_NONE, kp.out_ld = cin_f, kp.nclasses = 1;
+    PWS_REQUIRE((size_t)a->n * oh * ow < (1u << 31) && (size_t)a->n * a->h * a->w < (1u << 31), "pws_conv2d_bwd_data: too large");
+    float *ws = static_cast<float *>(a->ws);
+    const size_t ws_floats = a->ws_bytes / sizeof(float);
+    ProfInfo pi;
+    const double k2 = a->kind == PWS_CONVT_K4S2 ? 4.0 : 9.0;  // taps per forward OUTPUT pixel
+    pi.flops = 2.0 * a->n * oh * ow * (double)a->cout * cin_f * k2;
+    pi.bytes = 4.0 * ((double)a->n * oh * ow * a->cout + (double)a->n * a->h * a->w * cin_f);
+    switch (a->kind) {
+    case PWS_CONV_K3S1:
+    case PWS_CONVT_K3S1:
+        kp.LH = a->h, kp.LW = a->w;
+        return select_and_launch(kK3S1, 5, kp, a->cout, nullptr, ws, ws_floats, st, pi);
+    case PWS_CONV_K3S2:
+        kp.LH = oh, kp.LW = ow, kp.nclasses = 4;
+        return select_and_launch(kSP3, 5, kp, a->cout, nullptr, ws, ws_floats, st, pi);
+    case PWS_CONVT_K4S2:
+        kp.LH = a->h, kp.LW = a->w;
+        return select_and_launch(kK4S2, 5, kp, a->cout, nullptr, ws, ws_floats, st, pi);
+    default:
+        set_error("pws_conv2d_bwd_data: kind %d has no data gradient here", a->kind);
+        return PWS_EINVAL;
+    }
+}
+
 }  // namespace pws
 
 extern "C" int pws_conv2d_fwd(const pws_conv_args *args, pws_stream_t stream) {
     return pws::conv2d_fwd_impl(args, pws::as_stream(stream));
+}
+
+extern "C" int pws_conv2d_bwd_data(const pws_conv_bwd_data_args *args, pws_stream_t stream) {
+    return pws::conv2d_bwd_data_impl(args, pws::as_stream(stream));
 }

@@ -1,0 +1,342 @@
+// Weight gradient of the conv / transposed-conv layers on the fp32 matrix cores (gfx950, v_mfma_f32_32x32x2_f32).
+//
+// Computed directly in the FORWARD kernel's packed layout, where every layer is a correlation
+//     y[m][co] = sum_{tap,ci} x[m*S + tap - pad][ci] * P[class][tap][ci][co]           (conv_mfma.hip)
+// so   dP[class][tap][ci][co] = sum_m x[m*S + tap - pad][ci] * dy[m][co]   -- a GEMM with K = pixels.
+//
+// GEMM view per tap:  M = 32 input channels, N = 32 output channels, K = pixels of a spatial tile.
+//   * A workgroup owns one (ci block, co block, parity class, tap group) and a strided subset of the spatial tiles
+//     (the K dimension is split over workgroups: "pixel split").  Per tile it stages the halo'd x tile [pix][32+1]
+//     and the dy tile [pix][32+1] in LDS; both MFMA operands are then conflict-free row reads (lane = channel).
+//   * The 4 waves split the tile's pixels; each keeps one 32x32 accumulator per tap (9 taps = 144 VGPRs), the dy
+//     fragment is shared by all taps.  After the last tile the 4 partial sums are added through LDS and the result
+//     is added to global memory with fp32 atomics (pixel splits, and stages 2/3 sharing weights, accumulate there).
+//   * k5 (first layer, 25 taps) runs as 5 tap groups of one kernel row each (blockIdx.z).
+// Numerics: fp32, atomics => the sum order over workgroups varies run to run (last-ulp differences in dW).
+#include "common.h"
+
+namespace pws {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgradParams {
+    const float *src_ptr[4];
+    int src_c[4];
+    int src_ld[4];
+    int nsrc;
+    int cin, cin_pad, cout;
+    int N, H, W;     // forward input extent
+    int LH, LW;      // logical extent walked by tiles
+    int OH, OW;      // forward output extent (extent of dy)
+    const float *gout;
+    int gout_ld;
+    float *dw;
+    int tiles_x, tiles_y, tiles_n;
+    int ntiles;
+    int ci_blocks, co_blocks;
+};
+
+template <int KS_, int STRIDE_, int PAD_, int SUBPIX_, int TH_, int TW_, int TN_, int TG_, bool NCHW_ = false>
+struct WgCfg {
+    static constexpr int KS = KS_, STRIDE = STRIDE_, PAD = PAD_, SUBPIX = SUBPIX_, TH = TH_, TW = TW_, TN = TN_;
+    static constexpr int TG = TG_;              // taps per workgroup (tap group); TAPS % TG == 0
+    static constexpr bool NCHW = NCHW_;
+    static constexpr int TAPS = KS * KS, NGROUPS = TAPS / TG;
+    static constexpr int BM = TH * TW * TN, QP = BM / 4;  // pixels per wave
+    static_assert(QP % TW == 0 && QP % 2 == 0, "a wave's share must be whole rows");
+    static constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
+    static constexpr int PIX = TN * IH * IW;
+    static constexpr int CP = 33;
+    static constexpr int LDS_X = PIX * CP, LDS_G = BM * CP;
+    static constexpr int LDS_RED = 4 * 32 * CP;  // cross-wave reduction of one tap
+    static constexpr int LDS_FLOATS = (LDS_X + LDS_G) > LDS_RED ? (LDS_X + LDS_G) : LDS_RED;
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+};
+
+// offset (in pixels of the LDS x tile) of tile-local output pixel p
+template <class C>
+__host__ __device__ constexpr int xoff(int p) {
+    return ((p / (C::TH * C::TW)) * C::IH + ((p % (C::TH * C::TW)) / C::TW) * C::STRIDE) * C::IW + (p % C::TW) * C::STRIDE;
+}
+
+template <class C>
+__global__ void __launch_bounds__(256, 2) wgrad_mfma_kernel(const WgradParams p) {
+    extern __shared__ float lds[];
+    float *xs = lds;
+    float *gs = lds + C::LDS_X;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+
+    const int cb = blockIdx.y;
+    const int ci0 = (cb / p.co_blocks) * 32, co0 = (cb % p.co_blocks) * 32;
+    const int cls = C::SUBPIX ? (int)(blockIdx.z & 3) : 0;
+    const int tg = C::SUBPIX ? (int)(blockIdx.z >> 2) : (int)blockIdx.z;
+    const int py = cls >> 1, px = cls & 1;
+    const int pad_y = C::SUBPIX ? 1 - py : C::PAD, pad_x = C::SUBPIX ? 1 - px : C::PAD;
+
+    f32x16 acc[C::TG];
+#pragma unroll
+    for (int t = 0; t < C::TG; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int a_base = (xoff<C>(wv * C::QP) + hi * C::STRIDE) * C::CP + l31;
+    const int b_base = (wv * C::QP + hi) * C::CP + l31;
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int tx_i = tile % p.tiles_x, ty_i = (tile / p.tiles_x) % p.tiles_y, tn_i = tile / (p.tiles_x * p.tiles_y);
+        const int n0 = tn_i * C::TN, y0 = ty_i * C::TH, x0 = tx_i * C::TW;
+        const int iy0 = y0 * C::STRIDE - pad_y, ix0 = x0 * C::STRIDE - pad_x;
+        __syncthreads();  // previous tile fully consumed
+        // ---- x halo tile: channels ci0..ci0+31 of (virtually concatenated) sources
+        if constexpr (C::NCHW) {
+            for (int item = tid; item < C::PIX * 32; item += 256) {
+                const int c = item / C::PIX, pix = item % C::PIX;
+                const int lx = pix % C::IW, ly = (pix / C::IW) % C::IH, tn = pix / (C::IW * C::IH);
+                const int n = n0 + tn, iy = iy0 + ly, ix = ix0 + lx, ch = ci0 + c;
+                const bool ok = ch < p.cin && n < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                xs[pix * C::CP + c] = ok ? p.src_ptr[0][((size_t)(n * p.cin + ch) * p.H + iy) * p.W + ix] : 0.f;
+            }
+        } else {
+            for (int item = tid; item < C::PIX * 8; item += 256) {
+                const int pix = item >> 3, c4 = (item & 7) * 4;
+                const int lx = pix % C::IW, ly = (pix / C::IW) % C::IH, tn = pix / (C::IW * C::IH);
+                const int n = n0 + tn, iy = iy0 + ly, ix = ix0 + lx;
+                int ch = ci0 + c4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ch < p.cin && n < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                    int s = 0;
+                    while (s < p.nsrc - 1 && ch >= p.src_c[s]) ch -= p.src_c[s], ++s;
+                    v = *reinterpret_cast<const float4 *>(p.src_ptr[s] + ((size_t)(n * p.H + iy) * p.W + ix) * p.src_ld[s] + ch);
+                }
+                float *d = xs + pix * C::CP + c4;
+                d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+            }
+        }
+        // ---- dy tile: channels co0..co0+31 at the tile's output pixels
+        for (int item = tid; item < C::BM * 8; item += 256) {
+            const int m = item >> 3, c4 = (item & 7) * 4;
+            const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
+            const int n = n0 + tn, y = y0 + ty, x = x0 + tx;
+            const int oy = C::SUBPIX ? 2 * y + py : y, ox = C::SUBPIX ? 2 * x + px : x;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co0 + c4 < p.cout && n < p.N && y < p.LH && x < p.LW && oy < p.OH && ox < p.OW)
+                v = *reinterpret_cast<const float4 *>(p.gout + ((size_t)(n * p.OH + oy) * p.OW + ox) * p.gout_ld + co0 + c4);
+            float *d = gs + m * C::CP + c4;
+            d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+        }
+        __syncthreads();
+        // ---- this wave's QP pixels: K steps of 2 pixels
+#pragma unroll
+        for (int j = 0; j < C::QP / 2; ++j) {
+            const float b = gs[b_base + 2 * j * C::CP];
+#pragma unroll
+            for (int t = 0; t < C::TG; ++t) {
+                // tap inside the kernel window; tg is block-uniform and only the k5 kernel has NGROUPS > 1
+                const int tap = (C::NGROUPS == 1 ? 0 : tg * C::TG) + t;
+                const int toff = ((tap / C::KS) * C::IW + (tap % C::KS)) * C::CP;
+                const float a = xs[a_base + xoff<C>(2 * j) * C::CP + toff];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- cross-wave reduction through LDS, then one atomic per element
+    float *red = lds;
+#pragma unroll
+    for (int t = 0; t < C::TG; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;  // row = input channel
+            red[(wv * 32 + i) * C::CP + l31] = acc[t][r];
+        }
+        __syncthreads();
+        const int tap = tg * C::TG + t;
+        for (int e = tid; e < 32 * 32; e += 256) {
+            const int i = e >> 5, jn = e & 31;
+            const float v = red[i * C::CP + jn] + red[(32 + i) * C::CP + jn] + red[(64 + i) * C::CP + jn] +
+                            red[(96 + i) * C::CP + jn];
+            if (ci0 + i < p.cin_pad && co0 + jn < p.cout)
+                atomicAdd(p.dw + ((size_t)(cls * C::TAPS + tap) * p.cin_pad + ci0 + i) * p.cout + co0 + jn, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct WgChoice {
+    int th, tw, tn;
+    int (*launch)(WgradParams &, int nclasses, hipStream_t);
+};
+
+template <class C>
+static int launch_wg(WgradParams &p, int nclasses, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_mfma_kernel<C>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(wgrad_mfma_kernel, %d B LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
+            return PWS_EHIP;
+        }
+        attr_set = true;
+    }
+    p.tiles_x = (p.LW + C::TW - 1) / C::TW, p.tiles_y = (p.LH + C::TH - 1) / C::TH, p.tiles_n = (p.N + C::TN - 1) / C::TN;
+    p.ntiles = p.tiles_x * p.tiles_y * p.tiles_n;
+    p.ci_blocks = (p.cin_pad + 31) / 32, p.co_blocks = (p.cout + 31) / 32;
+    const long other = (long)p.ci_blocks * p.co_blocks * nclasses * C::NGROUPS;
+    long ps = (1024 + other - 1) / other;  // ~4 workgroups per CU overall
+    if (ps > p.ntiles) ps = p.ntiles;
+    if (ps < 1) ps = 1;
+    dim3 grid((unsigned)ps, (unsigned)(p.ci_blocks * p.co_blocks), (unsigned)(nclasses * C::NGROUPS));
+    hipLaunchKernelGGL(wgrad_mfma_kernel<C>, grid, dim3(256), C::LDS_BYTES, st, p);
+    return check_launch("wgrad_mfma_kernel");
+}
+
+template <class C>
+static constexpr WgChoice wchoice() {
+    return WgChoice{C::TH, C::TW, C::TN, &launch_wg<C>};
+}
+
+//                      KS S  P  subpix TH  TW  TN  TG
+using WG_K3S1_T256 = WgCfg<3, 1, 1, 0, 16, 16, 1, 9>;
+using WG_K3S1_T64 = WgCfg<3, 1, 1, 0, 8, 8, 1, 9>;
+using WG_K3S1_T64N4 = WgCfg<3, 1, 1, 0, 4, 4, 4, 9>;
+using WG_K3S1_T64N16 = WgCfg<3, 1, 1, 0, 2, 2, 16, 9>;
+using WG_K3S2_T64 = WgCfg<3, 2, 1, 0, 8, 8, 1, 9>;
+using WG_K3S2_T64N4 = WgCfg<3, 2, 1, 0, 4, 4, 4, 9>;
+using WG_K3S2_T64N16 = WgCfg<3, 2, 1, 0, 2, 2, 16, 9>;
+using WG_K5S1_T128 = WgCfg<5, 1, 2, 0, 8, 16, 1, 5>;
+using WG_K5S1_T128_NCHW = WgCfg<5, 1, 2, 0, 8, 16, 1, 5, true>;
+using WG_CT4_T256 = WgCfg<2, 1, 0, 1, 16, 16, 1, 4>;
+using WG_CT4_T64 = WgCfg<2, 1, 0, 1, 8, 8, 1, 4>;
+using WG_CT4_T64N4 = WgCfg<2, 1, 0, 1, 4, 4, 4, 4>;
+using WG_CT4_T64N16 = WgCfg<2, 1, 0, 1, 2, 2, 16, 4>;
+
+static const WgChoice kWgK3S1[] = {wchoice<WG_K3S1_T256>(), wchoice<WG_K3S1_T64>(), wchoice<WG_K3S1_T64N4>(),
+                                   wchoice<WG_K3S1_T64N16>()};
+static const WgChoice kWgK3S2[] = {wchoice<WG_K3S2_T64>(), wchoice<WG_K3S2_T64N4>(), wchoice<WG_K3S2_T64N16>()};
+static const WgChoice kWgCT4[] = {wchoice<WG_CT4_T256>(), wchoice<WG_CT4_T64>(), wchoice<WG_CT4_T64N4>(),
+                                  wchoice<WG_CT4_T64N16>()};
+static const WgChoice kWgK5[] = {wchoice<WG_K5S1_T128>()};
+static const WgChoice kWgK5N[] = {wchoice<WG_K5S1_T128_NCHW>()};
+
+// largest tile that is not mostly padding for this map
+static const WgChoice &pick(const WgChoice *c, int n, int LH, int LW, int N) {
+    for (int i = 0; i < n; ++i) {
+        const long tiles = (long)((LW + c[i].tw - 1) / c[i].tw) * ((LH + c[i].th - 1) / c[i].th) * ((N + c[i].tn - 1) / c[i].tn);
+        const double useful = (double)N * LH * LW / ((double)tiles * c[i].th * c[i].tw * c[i].tn);
+        if (useful >= 0.45 || i + 1 == n) return c[i];
+    }
+    return c[n - 1];
+}
+
+int conv2d_bwd_weight_impl(const pws_conv_bwd_weight_args *a, hipStream_t st) {
+    PWS_REQUIRE(a != nullptr, "pws_conv2d_bwd_weight: args is NULL");
+    PWS_REQUIRE(a->n >= 0 && a->h > 0 && a->w > 0 && a->cout > 0 && a->cout % 4 == 0, "pws_conv2d_bwd_weight: bad shape");
+    PWS_REQUIRE(a->nsrc >= 1 && a->nsrc <= 4 && a->gout && a->dw_packed && a->gout_ld >= a->cout && a->gout_ld % 4 == 0 &&
+                    (reinterpret_cast<size_t>(a->gout) & 15) == 0,
+                "pws_conv2d_bwd_weight: bad sources / gout / dw");
+    if (a->n == 0) return PWS_OK;
+    WgradParams p{};
+    p.nsrc = a->nsrc;
+    int cin = 0;
+    const bool nchw = a->src_nchw != 0;
+    if (nchw) {
+        PWS_REQUIRE(a->kind == PWS_CONV_K5S1 && a->nsrc == 1 && a->src[0].ptr, "pws_conv2d_bwd_weight: NCHW source only for k5");
+        p.src_ptr[0] = a->src[0].ptr, p.src_c[0] = a->src[0].channels, cin = a->src[0].channels;
+    } else {
+        for (int s = 0; s < a->nsrc; ++s) {
+            const pws_src &sr = a->src[s];
+            PWS_REQUIRE(sr.ptr && sr.channels > 0 && sr.channels % 16 == 0 && sr.ld >= sr.channels && sr.ld % 4 == 0 &&
+                            (reinterpret_cast<size_t>(sr.ptr) & 15) == 0,
+                        "pws_conv2d_bwd_weight: bad source %d", s);
+            p.src_ptr[s] = sr.ptr, p.src_c[s] = sr.channels, p.src_ld[s] = sr.ld;
+            cin += sr.channels;
+        }
+    }
+    p.cin = cin, p.cin_pad = (cin + 15) / 16 * 16, p.cout = a->cout;
+    p.N = a->n, p.H = a->h, p.W = a->w;
+    p.gout = a->gout, p.gout_ld = a->gout_ld, p.dw = a->dw_packed;
+    PWS_REQUIRE((size_t)a->n * a->h * a->w < (1u << 30), "pws_conv2d_bwd_weight: too large");
+    double k2 = 9;
+    int nclasses = 1;
+    const WgChoice *c = nullptr;
+    switch (a->kind) {
+    case PWS_CONV_K3S1:
+    case PWS_CONVT_K3S1:
+        p.OH = p.LH = a->h, p.OW = p.LW = a->w;
+        c = &pick(kWgK3S1, 4, p.LH, p.LW, p.N);
+        break;
+    case PWS_CONV_K3S2:
+        p.OH = p.LH = (a->h - 1) / 2 + 1, p.OW = p.LW = (a->w - 1) / 2 + 1;
+        c = &pick(kWgK3S2, 3, p.LH, p.LW, p.N);
+        break;
+    case PWS_CONV_K5S1:
+        p.OH = p.LH = a->h, p.OW = p.LW = a->w, k2 = 25;
+        c = nchw ? &kWgK5N[0] : &kWgK5[0];
+        break;
+    case PWS_CONVT_K4S2:
+        p.LH = a->h, p.LW = a->w, p.OH = 2 * a->h, p.OW = 2 * a->w, nclasses = 4, k2 = 4;
+        c = &pick(kWgCT4, 4, p.LH, p.LW, p.N);
+        break;
+    default:
+        set_error("pws_conv2d_bwd_weight: kind %d has no weight gradient here", a->kind);
+        return PWS_EINVAL;
+    }
+    const double out_pix = (double)a->n * p.OH * p.OW;
+    ProfScope prof(KID_WGRAD, 2.0 * out_pix * a->cout * cin * k2,
+                   4.0 * ((double)a->n * a->h * a->w * cin + out_pix * a->cout + k2 * cin * a->cout * (nclasses == 4 ? 4 : 1)), st);
+    return c->launch(p, nclasses, st);
+}
+
+// ------------------------------------------------------------------------------------------------ act' and bias grad
+// dy <- dy * act'(y) in place; dbias[c] += sum over pixels.  One workgroup = 64 pixels x C channels strip, column sums
+// through LDS, one atomic per (workgroup, channel).  HBM-bound: 12 B per element.
+__global__ void __launch_bounds__(256) act_bwd_bias_kernel(float *__restrict__ dy, const float *__restrict__ y, size_t pixels,
+                                                           int c, int act, float *__restrict__ dbias) {
+    extern __shared__ float sbias[];  // c floats
+    const int tid = threadIdx.x;
+    for (int i = tid; i < c; i += 256) sbias[i] = 0.f;
+    __syncthreads();
+    const int c4n = c / 4;
+    const size_t p0 = (size_t)blockIdx.x * 64;
+    const size_t pend = p0 + 64 < pixels ? p0 + 64 : pixels;
+    // lanes walk the strip in float4 units; a lane keeps the same channel quad when 256 % c4n == 0 (all our widths)
+    for (size_t e = p0 * c4n + tid; e < pend * c4n; e += 256) {
+        float4 g = reinterpret_cast<float4 *>(dy)[e];
+        const float4 v = reinterpret_cast<const float4 *>(y)[e];
+        if (act == PWS_ACT_LRELU) {
+            g.x *= v.x > 0.f ? 1.f : 0.2f, g.y *= v.y > 0.f ? 1.f : 0.2f, g.z *= v.z > 0.f ? 1.f : 0.2f, g.w *= v.w > 0.f ? 1.f : 0.2f;
+        } else if (act == PWS_ACT_RELU) {
+            g.x = v.x > 0.f ? g.x : 0.f, g.y = v.y > 0.f ? g.y : 0.f, g.z = v.z > 0.f ? g.z : 0.f, g.w = v.w > 0.f ? g.w : 0.f;
+        }
+        reinterpret_cast<float4 *>(dy)[e] = g;
+        if (dbias) {
+            const int ch = (int)(e % c4n) * 4;
+            atomicAdd(&sbias[ch], g.x), atomicAdd(&sbias[ch + 1], g.y), atomicAdd(&sbias[ch + 2], g.z), atomicAdd(&sbias[ch + 3], g.w);
+        }
+    }
+    if (dbias) {
+        __syncthreads();
+        for (int i = tid; i < c; i += 256) atomicAdd(dbias + i, sbias[i]);
+    }
+}
+
+}  // namespace pws
+
+extern "C" int pws_conv2d_bwd_weight(const pws_conv_bwd_weight_args *args, pws_stream_t stream) {
+    return pws::conv2d_bwd_weight_impl(args, pws::as_stream(stream));
+}
+
+extern "C" int pws_act_bwd_bias(float *dy, const float *y, size_t pixels, int c, int act, float *dbias, pws_stream_t stream) {
+    PWS_REQUIRE(c > 0 && c % 4 == 0 && c * sizeof(float) <= 64 * 1024, "pws_act_bwd_bias: c=%d must be a multiple of 4", c);
+    PWS_REQUIRE(act >= PWS_ACT_NONE && act <= PWS_ACT_RELU, "pws_act_bwd_bias: bad act %d", act);
+    if (pixels == 0) return PWS_OK;
+    PWS_REQUIRE(dy && y && ((reinterpret_cast<size_t>(dy) | reinterpret_cast<size_t>(y)) & 15) == 0,
+                "pws_act_bwd_bias: NULL or unaligned pointer");
+    if (act == PWS_ACT_NONE && !dbias) return PWS_OK;
+    pws::ProfScope prof(pws::KID_ACT_BWD, 2.0 * pixels * c, 12.0 * pixels * c, pws::as_stream(stream));
+    hipLaunchKernelGGL(pws::act_bwd_bias_kernel, dim3((unsigned)((pixels + 63) / 64)), dim3(256), sizeof(float) * c,
+                       pws::as_stream(stream), dy, y, pixels, c, act, dbias);
+    return pws::check_launch("act_bwd_bias_kernel");
+}

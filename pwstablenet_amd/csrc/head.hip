@@ -49,13 +49,15 @@ __global__ void __launch_bounds__(64) theta_hidden_kernel(const float *__restric
 // Phase 2: one workgroup per sample: h = LReLU(sum_slices + b1); theta = LReLU(W2 h + b2).
 __global__ void __launch_bounds__(256) theta_final_kernel(const float *__restrict__ partial, int nslices, int n, int hidden,
                                                           const float *__restrict__ b_flat, const float *__restrict__ w_lin,
-                                                          const float *__restrict__ b_lin, float *__restrict__ theta) {
+                                                          const float *__restrict__ b_lin, float *__restrict__ theta,
+                                                          float *__restrict__ h_saved) {
     extern __shared__ float sh[];  // hidden floats
     const int s = blockIdx.x, tid = threadIdx.x;
     for (int j = tid; j < hidden; j += 256) {
         float acc = b_flat ? b_flat[j] : 0.f;
         for (int sl = 0; sl < nslices; ++sl) acc += partial[((size_t)sl * n + s) * hidden + j];
         sh[j] = lrelu(acc);
+        if (h_saved) h_saved[(size_t)s * hidden + j] = sh[j];
     }
     __syncthreads();
     const int wv = tid >> 6, lane = tid & 63;
@@ -151,6 +153,12 @@ extern "C" size_t pws_theta_head_ws_floats(int n, int c, int hidden) {
 
 extern "C" int pws_theta_head_fwd(const float *x, int n, int c, int hidden, const float *w_flat, const float *b_flat,
                                   const float *w_lin, const float *b_lin, float *ws, float *theta, pws_stream_t stream) {
+    return pws_theta_head_fwd_save(x, n, c, hidden, w_flat, b_flat, w_lin, b_lin, ws, theta, nullptr, stream);
+}
+
+extern "C" int pws_theta_head_fwd_save(const float *x, int n, int c, int hidden, const float *w_flat, const float *b_flat,
+                                       const float *w_lin, const float *b_lin, float *ws, float *theta, float *h_saved,
+                                       pws_stream_t stream) {
     PWS_REQUIRE(n >= 0 && c > 0 && hidden > 0, "pws_theta_head_fwd: bad shape");
     if (n == 0) return PWS_OK;
     PWS_REQUIRE(x && w_flat && w_lin && theta && ws, "pws_theta_head_fwd: NULL pointer (ws needs pws_theta_head_ws_floats())");
@@ -161,7 +169,7 @@ extern "C" int pws_theta_head_fwd(const float *x, int n, int c, int hidden, cons
     hipLaunchKernelGGL(theta_hidden_kernel, dim3((hidden + 63) / 64, nslices), dim3(64), sizeof(float) * TH_NB * kchunk,
                        as_stream(stream), x, n, k1, hidden, kchunk, w_flat, ws);
     hipLaunchKernelGGL(theta_final_kernel, dim3(n), dim3(256), sizeof(float) * hidden, as_stream(stream), ws, nslices, n, hidden,
-                       b_flat, w_lin, b_lin, theta);
+                       b_flat, w_lin, b_lin, theta, h_saved);
     return check_launch("theta_head kernels");
 }
 

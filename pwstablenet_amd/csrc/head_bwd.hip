@@ -1,0 +1,261 @@
+// Backward of the two regression heads (see head.hip): small fp32 VALU kernels, HBM/latency-bound.
+//
+// field head:  grid = r + A(theta),  r = tanh(t1),  t1 = tanh(z),  z = conv3x3(x; W_out) + b_out
+//   g_r = g_grid + g_resid ;  g_z = g_r (1 - r^2)(1 - t1^2) with t1 = atanh(r) (|r| <= tanh(1) = 0.7616, well conditioned)
+//   dtheta[n] = sum_pixels g_grid (x) [bx, by, 1] ;  db_out = sum g_z ;  dW_out[tap][c][o] = sum x[pix+tap-1][c] g_z[pix][o]
+//   dx[pix][c] = sum_{tap,o} g_z[pix+1-tap][o] W_out[tap][c][o]
+// theta head:  theta = L(z2), z2 = W2 h + b2, h = L(z1), z1 = W1 v + b1  (L = LeakyReLU 0.2, v = vec(x_s8))
+#include "common.h"
+
+namespace pws {
+
+__device__ __forceinline__ float lrelu_grad(float y) { return y > 0.f ? 1.f : 0.2f; }
+
+// ---- K1: g_z, db_out, dtheta.  One lane per pixel, 256 pixels (one image row segment) per workgroup.
+__global__ void __launch_bounds__(256) field_gz_kernel(const float *__restrict__ resid, const float *__restrict__ g_grid,
+                                                       const float *__restrict__ g_resid, int H, int W, size_t total, int ac,
+                                                       float *__restrict__ gz, float *__restrict__ db_out,
+                                                       float *__restrict__ dtheta) {
+    __shared__ float red[8][4];
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // dtheta[6], db[2]
+    // all pixels of a workgroup belong to one image when H*W % 256 == 0; otherwise per-lane atomics below
+    const size_t HW = (size_t)H * W;
+    int n = 0;
+    if (p < total) {
+        n = (int)(p / HW);
+        const int xq = (int)(p % W), yq = (int)((p / W) % H);
+        const float2 r = *reinterpret_cast<const float2 *>(resid + p * 2);
+        float2 gg = make_float2(0.f, 0.f), gr = make_float2(0.f, 0.f);
+        if (g_grid) gg = *reinterpret_cast<const float2 *>(g_grid + p * 2);
+        if (g_resid) gr = *reinterpret_cast<const float2 *>(g_resid + p * 2);
+        const float t0 = atanhf(r.x), t1 = atanhf(r.y);
+        const float z0 = (gg.x + gr.x) * (1.f - r.x * r.x) * (1.f - t0 * t0);
+        const float z1 = (gg.y + gr.y) * (1.f - r.y * r.y) * (1.f - t1 * t1);
+        *reinterpret_cast<float2 *>(gz + p * 2) = make_float2(z0, z1);
+        const float bx = ac ? (W > 1 ? (2.f * xq) / (float)(W - 1) - 1.f : 0.f) : (2.f * xq + 1.f) / (float)W - 1.f;
+        const float by = ac ? (H > 1 ? (2.f * yq) / (float)(H - 1) - 1.f : 0.f) : (2.f * yq + 1.f) / (float)H - 1.f;
+        v[0] = gg.x * bx, v[1] = gg.x * by, v[2] = gg.x, v[3] = gg.y * bx, v[4] = gg.y * by, v[5] = gg.y, v[6] = z0, v[7] = z1;
+    }
+    const bool uniform_n = (HW % 256) == 0;
+    if (uniform_n) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float s = v[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            const float s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+            if (threadIdx.x < 6) {
+                if (dtheta) atomicAdd(dtheta + (size_t)n * 6 + threadIdx.x, s);
+            } else if (db_out) {
+                atomicAdd(db_out + threadIdx.x - 6, s);
+            }
+        }
+    } else if (p < total) {
+        if (dtheta)
+            for (int k = 0; k < 6; ++k) atomicAdd(dtheta + (size_t)n * 6 + k, v[k]);
+        if (db_out) atomicAdd(db_out, v[6]), atomicAdd(db_out + 1, v[7]);
+    }
+}
+
+// ---- K2: dx.  One lane = (pixel, 4 channels); weights in LDS.
+__global__ void __launch_bounds__(256) field_dx_kernel(const float *__restrict__ gz, const float *__restrict__ w_out, int N,
+                                                       int H, int W, int C, float *__restrict__ dx, int dx_ld, int accumulate) {
+    extern __shared__ float sw[];  // [9][C][2]
+    for (int i = threadIdx.x; i < 9 * C * 2; i += 256) sw[i] = w_out[i];
+    __syncthreads();
+    const int c4n = C / 4;
+    const size_t total = (size_t)N * H * W * c4n;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int c = (int)(e % c4n) * 4;
+    const size_t pix = e / c4n;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((size_t)W * H));
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        // forward: z[q] += x[q + tap - 1] * W[tap]  =>  dx[p] += gz[p + 1 - tap] * W[tap]
+        const int yy = y + 1 - tap / 3, xx = x + 1 - tap % 3;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        const float2 g = *reinterpret_cast<const float2 *>(gz + (((size_t)n * H + yy) * W + xx) * 2);
+        const float *wp = sw + (tap * C + c) * 2;
+        a.x += g.x * wp[0] + g.y * wp[1], a.y += g.x * wp[2] + g.y * wp[3];
+        a.z += g.x * wp[4] + g.y * wp[5], a.w += g.x * wp[6] + g.y * wp[7];
+    }
+    float4 *d = reinterpret_cast<float4 *>(dx + pix * dx_ld + c);
+    if (accumulate) {
+        const float4 o = *d;
+        a.x += o.x, a.y += o.y, a.z += o.z, a.w += o.w;
+    }
+    *d = a;
+}
+
+// ---- K3: dW_out.  Workgroup = 16x16 pixel tile x 32 channels; lane = (channel, pixel-row group).
+constexpr int FB_T = 16, FB_I = FB_T + 2, FB_CH = 32, FB_LDP = FB_CH + 1;
+
+__global__ void __launch_bounds__(256) field_dw_kernel(const float *__restrict__ x, int ld, const float *__restrict__ gz, int N,
+                                                       int H, int W, int C, float *__restrict__ dw, int tiles_x, int tiles_y) {
+    __shared__ float s_in[FB_I * FB_I * FB_LDP];
+    __shared__ float s_g[FB_T * FB_T * 2];
+    __shared__ float s_red[8 * 32 * 18];
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const int x0 = tx_i * FB_T, y0 = ty_i * FB_T;
+    const int c0 = blockIdx.y * FB_CH;
+    for (int item = tid; item < FB_I * FB_I * (FB_CH / 4); item += 256) {
+        const int pix = item / (FB_CH / 4), c4 = (item % (FB_CH / 4)) * 4;
+        const int iy = y0 - 1 + pix / FB_I, ix = x0 - 1 + pix % FB_I;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W && c0 + c4 < C)
+            v = *reinterpret_cast<const float4 *>(x + ((size_t)(n * H + iy) * W + ix) * ld + c0 + c4);
+        float *d = s_in + pix * FB_LDP + c4;
+        d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+    }
+    {
+        const int ty = tid >> 4, tx = tid & 15, y = y0 + ty, xq = x0 + tx;
+        float2 g = make_float2(0.f, 0.f);
+        if (y < H && xq < W) g = *reinterpret_cast<const float2 *>(gz + (((size_t)n * H + y) * W + xq) * 2);
+        s_g[tid * 2] = g.x, s_g[tid * 2 + 1] = g.y;
+    }
+    __syncthreads();
+    const int c = tid & 31, grp = tid >> 5;  // 8 groups x 2 tile rows each
+    float acc[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) acc[i] = 0.f;
+    for (int ty = grp * 2; ty < grp * 2 + 2; ++ty)
+        for (int tx = 0; tx < FB_T; ++tx) {
+            const float g0 = s_g[(ty * FB_T + tx) * 2], g1 = s_g[(ty * FB_T + tx) * 2 + 1];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float xv = s_in[((ty + tap / 3) * FB_I + tx + tap % 3) * FB_LDP + c];
+                acc[tap * 2] = fmaf(xv, g0, acc[tap * 2]), acc[tap * 2 + 1] = fmaf(xv, g1, acc[tap * 2 + 1]);
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < 18; ++i) s_red[(grp * 32 + c) * 18 + i] = acc[i];
+    __syncthreads();
+    for (int e = tid; e < 32 * 18; e += 256) {
+        const int cc = e / 18, i = e % 18;
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) s += s_red[(g * 32 + cc) * 18 + i];
+        if (c0 + cc < C) atomicAdd(dw + ((size_t)(i / 2) * C + c0 + cc) * 2 + (i & 1), s);
+    }
+}
+
+// ---- theta head backward
+// T1: one workgroup per sample: dz2, dW2 += h (x) dz2, db2 += dz2, dz1 = (W2^T dz2) * L'(h) -> ws, db1 += dz1
+__global__ void __launch_bounds__(256) theta_bwd1_kernel(const float *__restrict__ theta, const float *__restrict__ dtheta,
+                                                         const float *__restrict__ h, int hidden, const float *__restrict__ w_lin,
+                                                         float *__restrict__ dw_lin, float *__restrict__ db_lin,
+                                                         float *__restrict__ db_flat, float *__restrict__ dz1) {
+    __shared__ float dz2[6];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    if (tid < 6) {
+        const float v = dtheta[(size_t)n * 6 + tid] * lrelu_grad(theta[(size_t)n * 6 + tid]);
+        dz2[tid] = v;
+        atomicAdd(db_lin + tid, v);
+    }
+    __syncthreads();
+    for (int j = tid; j < hidden; j += 256) {
+        const float hj = h[(size_t)n * hidden + j];
+        float dh = 0.f;
+#pragma unroll
+        for (int o = 0; o < 6; ++o) {
+            atomicAdd(dw_lin + (size_t)j * 6 + o, hj * dz2[o]);
+            dh = fmaf(w_lin[(size_t)j * 6 + o], dz2[o], dh);
+        }
+        const float d1 = dh * lrelu_grad(hj);
+        dz1[(size_t)n * hidden + j] = d1;
+        atomicAdd(db_flat + j, d1);
+    }
+}
+
+// T2: dW1[k][j] += sum_n v[n][k] dz1[n][j]   (stream-ordered read-modify-write: no atomics needed)
+__global__ void __launch_bounds__(256) theta_bwd2_kernel(const float *__restrict__ v, const float *__restrict__ dz1, int n, int k1,
+                                                         int hidden, float *__restrict__ dw_flat) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)k1 * hidden) return;
+    const int j = (int)(e % hidden), k = (int)(e / hidden);
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s = fmaf(v[(size_t)i * k1 + k], dz1[(size_t)i * hidden + j], s);
+    dw_flat[e] += s;
+}
+
+// T3: dv[n][k] = sum_j W1[k][j] dz1[n][j]: one wave per (n, k), lanes over j
+__global__ void __launch_bounds__(256) theta_bwd3_kernel(const float *__restrict__ w_flat, const float *__restrict__ dz1, int n,
+                                                         int k1, int hidden, float *__restrict__ dv, int accumulate) {
+    const int wave = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (wave >= n * k1) return;
+    const int i = wave / k1, k = wave % k1;
+    float s = 0.f;
+    for (int j = lane; j < hidden; j += 64) s = fmaf(w_flat[(size_t)k * hidden + j], dz1[(size_t)i * hidden + j], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) {
+        float *d = dv + (size_t)i * k1 + k;
+        *d = accumulate ? *d + s : s;
+    }
+}
+
+}  // namespace pws
+
+using namespace pws;
+
+extern "C" int pws_field_head_bwd(const float *x, int ld, int n, int h, int w, int c, const float *w_out, const float *resid,
+                                  const float *g_grid, const float *g_resid, int align_corners, float *dx, int dx_ld,
+                                  int dx_accumulate, float *dw_out, float *db_out, float *dtheta, float *ws, pws_stream_t stream) {
+    PWS_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "pws_field_head_bwd: bad shape");
+    if (n == 0) return PWS_OK;
+    PWS_REQUIRE(x && w_out && resid && (g_grid || g_resid) && ws, "pws_field_head_bwd: NULL pointer");
+    PWS_REQUIRE(9 * c * 2 * sizeof(float) <= 64 * 1024, "pws_field_head_bwd: c=%d too large", c);
+    hipStream_t st = as_stream(stream);
+    const size_t total = (size_t)n * h * w;
+    ProfScope prof(KID_FIELD_HEAD_BWD, 4.0 * total * 18.0 * c, (double)total * (8.0 * c + 32.0), st);
+    if (dtheta) {
+        hipError_t e = hipMemsetAsync(dtheta, 0, sizeof(float) * (size_t)n * 6, st);
+        if (e != hipSuccess) {
+            set_error("pws_field_head_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
+            return PWS_EHIP;
+        }
+    }
+    hipLaunchKernelGGL(field_gz_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, resid, g_grid, g_resid, h, w, total,
+                       align_corners, ws, db_out, dtheta);
+    if (dx) {
+        const size_t items = total * (c / 4);
+        hipLaunchKernelGGL(field_dx_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), sizeof(float) * 18 * c, st, ws, w_out, n, h,
+                           w, c, dx, dx_ld, dx_accumulate);
+    }
+    if (dw_out) {
+        const int tiles_x = (w + FB_T - 1) / FB_T, tiles_y = (h + FB_T - 1) / FB_T;
+        hipLaunchKernelGGL(field_dw_kernel, dim3((unsigned)(tiles_x * tiles_y * n), (unsigned)((c + FB_CH - 1) / FB_CH)), dim3(256), 0,
+                           st, x, ld, ws, n, h, w, c, dw_out, tiles_x, tiles_y);
+    }
+    return check_launch("field_head_bwd kernels");
+}
+
+extern "C" int pws_theta_head_bwd(const float *x, int n, int c, int hidden, const float *w_flat, const float *w_lin,
+                                  const float *h_saved, const float *theta, const float *dtheta, float *dw_flat, float *db_flat,
+                                  float *dw_lin, float *db_lin, float *dx, int dx_accumulate, float *ws, pws_stream_t stream) {
+    PWS_REQUIRE(n >= 0 && c > 0 && hidden > 0, "pws_theta_head_bwd: bad shape");
+    if (n == 0) return PWS_OK;
+    PWS_REQUIRE(x && w_flat && w_lin && h_saved && theta && dtheta && dw_flat && db_flat && dw_lin && db_lin && ws,
+                "pws_theta_head_bwd: NULL pointer");
+    hipStream_t st = as_stream(stream);
+    const int k1 = 4 * c;
+    ProfScope prof(KID_THETA_HEAD_BWD, 4.0 * n * (double)k1 * hidden, 4.0 * 3.0 * (double)k1 * hidden, st);
+    hipLaunchKernelGGL(theta_bwd1_kernel, dim3(n), dim3(256), 0, st, theta, dtheta, h_saved, hidden, w_lin, dw_lin, db_lin, db_flat, ws);
+    const size_t e = (size_t)k1 * hidden;
+    hipLaunchKernelGGL(theta_bwd2_kernel, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, st, x, ws, n, k1, hidden, dw_flat);
+    if (dx) {
+        const size_t waves = (size_t)n * k1;
+        hipLaunchKernelGGL(theta_bwd3_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, st, w_flat, ws, n, k1, hidden, dx,
+                           dx_accumulate);
+    }
+    return check_launch("theta_head_bwd kernels");
+}

@@ -1,15 +1,20 @@
 // Host-side executor of the cascading generator: sequences the HIP kernels of this library on one stream,
 // with all activations in a caller-provided arena.  Mirrors UnetGenerator.forward of the reference
-// (lib/networks_cascading.py:152-237) -- variable names below are the reference's.
+// (lib/networks_cascading.py:152-237) -- variable names below are the reference's -- and its autograd backward
+// (loss_g.backward(), main_new.py:214).
 //
 // Differences in HOW (not in WHAT):
 //   * activations are NHWC; a torch.cat([a, b], 1) is a list of (pointer, channels, stride) sources consumed
 //     directly by the next convolution -- the reference's 43-44 concat copies per forward disappear;
 //   * stage 3's first block (`x32 = down_bottom1(None, x11)`, reference :200) has the same weights and the same
-//     input as stage 2's (`x22`, :178) and is bit-identical, so it is computed once;
+//     input as stage 2's (`x22`, :178) and is bit-identical, so it is computed once (its gradient is the sum of
+//     both uses, which falls out of x22 having one gradient buffer);
 //   * `out` conv + tanh + tanh + permute + affine_grid + add run as one kernel (field head).
-// No allocation, no synchronisation: every launch goes to `stream`, so the whole forward can be captured
-// into a hipGraph by the caller.
+// Backward replays the forward's allocation sequence (no launches) to recover every activation's address in the
+// arena, then walks the recorded ops in reverse: per layer act'/bias-grad, weight grad, data grad into the gradient
+// buffers of the layer's sources (first consumer overwrites, later consumers accumulate -- no zero-fill pass).
+// No allocation, no synchronisation: every launch goes to `stream`.
+#include <unordered_map>
 #include <vector>
 
 #include "common.h"
@@ -18,7 +23,8 @@ namespace pws {
 
 struct Layer {
     int kind, cin, cout;
-    size_t w_off, b_off;  // float offsets into the packed buffer
+    size_t w_off, b_off;  // float offsets into the packed buffer (and into the packed gradient buffer)
+    size_t dg_off;        // float offset into the data-gradient weight buffer (or SIZE_MAX)
 };
 
 enum {
@@ -36,15 +42,17 @@ enum {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Same registration order as the reference's __init__ (lib/networks_cascading.py:112-149) / spec.py.
-static std::vector<Layer> build_layers(int input_nc, int g, size_t *total_floats) {
+static std::vector<Layer> build_layers(int input_nc, int g, size_t *total_floats, size_t *total_dgrad = nullptr) {
     std::vector<Layer> L;
-    size_t off = 0;
+    size_t off = 0, dg = 0;
     auto add = [&](int kind, int cin, int cout) {
-        Layer l{kind, cin, cout, 0, 0};
+        Layer l{kind, cin, cout, 0, 0, (size_t)-1};
         l.w_off = off;
         off = align_up(off + pws_packed_weight_floats(kind, cin, cout), 64);
         l.b_off = off;
         off = align_up(off + (size_t)cout, 64);
+        const size_t d = pws_packed_dgrad_floats(kind, cin, cout);
+        if (d) l.dg_off = dg, dg = align_up(dg + d, 64);
         L.push_back(l);
     };
     const int enc[7][2] = {{g, g}, {g, 2 * g}, {2 * g, 4 * g}, {4 * g, 4 * g}, {4 * g, 4 * g}, {4 * g, 4 * g}, {4 * g, 4 * g}};
@@ -66,6 +74,7 @@ static std::vector<Layer> build_layers(int input_nc, int g, size_t *total_floats
     add(PWS_CONV_K2S1P0, 4 * g, 8 * g);
     add(PWS_CONV_K1, 8 * g, 6);
     if (total_floats) *total_floats = off;
+    if (total_dgrad) *total_dgrad = dg;
     return L;
 }
 
@@ -76,20 +85,27 @@ struct Seg {
 struct Tn {  // a (virtually concatenated) NHWC tensor
     Seg seg[4];
     int nseg, h, w;
-    int channels() const {
-        int c = 0;
-        for (int i = 0; i < nseg; ++i) c += seg[i].c;
-        return c;
-    }
+};
+
+enum { OP_CONV = 0, OP_THETA = 1, OP_FIELD = 2 };
+struct Op {
+    int type, layer, act, stage;
+    bool nchw;
+    Tn in, out;
 };
 
 class Exec {
   public:
-    Exec(const float *packed, const std::vector<Layer> &layers, int n, char *ws, size_t ws_bytes, hipStream_t st, bool dry)
-        : packed_(packed), L_(layers), n_(n), ws_(ws), cap_(ws_bytes), st_(st), dry_(dry) {}
+    Exec(const float *packed, const std::vector<Layer> &layers, int n, char *ws, size_t ws_bytes, hipStream_t st, bool dry,
+         bool launch)
+        : packed_(packed), L_(layers), n_(n), ws_(ws), cap_(ws_bytes), st_(st), dry_(dry), launch_(launch && !dry) {}
 
     size_t used() const { return off_; }
     int rc() const { return rc_; }
+    const std::vector<Op> &tape() const { return tape_; }
+    float *splitk_ws() const { return splitk_ws_; }
+    size_t splitk_bytes() const { return splitk_bytes_; }
+    float *h_saved(int stage) const { return h_saved_[stage]; }
 
     float *alloc(size_t floats) {
         const size_t bytes = align_up(floats * sizeof(float), 256);
@@ -98,7 +114,7 @@ class Exec {
         if (dry_) return nullptr;
         if (off_ > cap_) {
             if (rc_ == PWS_OK) {
-                set_error("pws_netg_forward: workspace too small (%zu B needed so far, %zu B given)", off_, cap_);
+                set_error("pws_netg: workspace too small (%zu B needed so far, %zu B given)", off_, cap_);
                 rc_ = PWS_ENOMEM;
             }
             return nullptr;
@@ -120,10 +136,11 @@ class Exec {
         Tn o{};
         o.nseg = 1, o.h = oh, o.w = ow;
         o.seg[0] = Seg{alloc((size_t)n_ * oh * ow * l.cout), l.cout, l.cout};
-        if (dry_ || rc_ != PWS_OK) return o;
+        tape_.push_back(Op{OP_CONV, layer, act, 0, nchw_c > 0, x, o});
+        if (!launch_ || rc_ != PWS_OK) return o;
         pws_conv_args a{};
         a.kind = l.kind, a.n = n_, a.h = x.h, a.w = x.w;
-        if (nchw_src) {
+        if (nchw_c > 0) {
             a.nsrc = 1, a.src_nchw = 1, a.src[0] = pws_src{nchw_src, nchw_c, 0};
         } else {
             a.nsrc = x.nseg;
@@ -157,30 +174,34 @@ class Exec {
         return x_before ? cat(v, *x_before) : v;
     }
     // theta = linear(flatten(x)) (reference :162-163)
-    void theta(const Tn &x_s8, float *theta_out) {
-        if (dry_ || rc_ != PWS_OK) return;
+    void theta(const Tn &x_s8, int stage, float *theta_out) {
+        tape_.push_back(Op{OP_THETA, L_FLATTEN, 0, stage, false, x_s8, Tn{}});
+        if (!launch_ || rc_ != PWS_OK) return;
         const Layer &f = L_[L_FLATTEN], &l = L_[L_LINEAR];
-        rc_ = pws_theta_head_fwd(x_s8.seg[0].ptr, n_, x_s8.seg[0].c, f.cout, packed_ + f.w_off, packed_ + f.b_off,
-                                 packed_ + l.w_off, packed_ + l.b_off, theta_ws_, theta_out, st_);
+        rc_ = pws_theta_head_fwd_save(x_s8.seg[0].ptr, n_, x_s8.seg[0].c, f.cout, packed_ + f.w_off, packed_ + f.b_off,
+                                      packed_ + l.w_off, packed_ + l.b_off, theta_ws_, theta_out, h_saved_[stage], st_);
     }
     // tanh(out(x)).permute(0,2,3,1) [+ affine_grid(theta)] (reference :174,235-237)
-    void field(const Tn &x, const float *theta_k, int ac, float *resid, float *grid) {
-        if (dry_ || rc_ != PWS_OK) return;
+    void field(const Tn &x, int stage, const float *theta_k, int ac, float *resid, float *grid) {
+        tape_.push_back(Op{OP_FIELD, L_OUT, 0, stage, false, x, Tn{}});
+        if (!launch_ || rc_ != PWS_OK) return;
         const Layer &o = L_[L_OUT];
         rc_ = pws_field_head_fwd(x.seg[0].ptr, x.seg[0].ld, n_, x.h, x.w, x.seg[0].c, packed_ + o.w_off, packed_ + o.b_off,
                                  theta_k, ac, resid, grid, st_);
     }
 
-    // scratch shared by all layers (launches are stream-ordered): split-K partial tiles and the theta head's partials
-    void reserve_scratch(int ngf) {
+    // scratch shared by all layers (launches are stream-ordered): split-K partial tiles, the theta head's partials,
+    // and (training) the hidden activations of the three theta heads
+    void reserve_scratch(int ngf, bool training) {
         splitk_bytes_ = (size_t)(n_ > 8 ? n_ : 8) * (2u << 20);
         splitk_ws_ = alloc(splitk_bytes_ / sizeof(float));
         theta_ws_ = alloc(pws_theta_head_ws_floats(n_, 4 * ngf, 8 * ngf));
         if (!splitk_ws_) splitk_bytes_ = 0;
+        for (int s = 0; s < 3; ++s) h_saved_[s] = training ? alloc((size_t)n_ * 8 * ngf) : nullptr;
     }
 
   private:
-    float *splitk_ws_ = nullptr, *theta_ws_ = nullptr;
+    float *splitk_ws_ = nullptr, *theta_ws_ = nullptr, *h_saved_[3] = {nullptr, nullptr, nullptr};
     size_t splitk_bytes_ = 0;
     const float *packed_;
     const std::vector<Layer> &L_;
@@ -188,20 +209,18 @@ class Exec {
     char *ws_;
     size_t cap_, off_ = 0;
     hipStream_t st_;
-    bool dry_;
+    bool dry_, launch_;
     int rc_ = PWS_OK;
+    std::vector<Op> tape_;
 };
 
-static int run_forward(const float *packed, const float *x, int n, int input_nc, int g, int is_training, int ac, char *ws,
-                       size_t ws_bytes, float *grids, float *resid, float *thetas, hipStream_t st, bool dry, size_t *used) {
+// Runs (or only plans) the forward over the arena of E.  thetas may be NULL (then they live in the arena).
+static void forward_graph(Exec &E, const float *x, int n, int input_nc, int g, int is_training, int ac, float *grids,
+                          float *resid, float *thetas) {
     const int S = 256;
-    size_t total = 0;
-    const std::vector<Layer> layers = build_layers(input_nc, g, &total);
-    Exec E(packed, layers, n, ws, ws_bytes, st, dry);
-    E.reserve_scratch(g);
+    E.reserve_scratch(g, is_training != 0);
     const size_t gsz = (size_t)n * S * S * 2;
     float *th = thetas ? thetas : E.alloc((size_t)3 * n * 6);
-    if (thetas == nullptr && !dry && E.rc() != PWS_OK) return E.rc();
     float *th1 = th, *th2 = th ? th + (size_t)n * 6 : nullptr, *th3 = th ? th + (size_t)2 * n * 6 : nullptr;
 
     Tn in{};
@@ -210,40 +229,137 @@ static int run_forward(const float *packed, const float *x, int n, int input_nc,
     Tn x11 = E.conv(L_TRANSFER, in, PWS_ACT_LRELU, x, input_nc);
     Tn x12 = E.down(1, x11), x13 = E.down(2, x12), x14 = E.down(3, x13), x15 = E.down(4, x14);
     Tn x16 = E.down(5, x15), x17 = E.down(6, x16), x18 = E.down(7, x17);
-    E.theta(x18, th1);
+    E.theta(x18, 0, th1);
     Tn x177 = E.up(7, x18, &x17), x166 = E.up(6, x177, &x16), x155 = E.up(5, x166, &x15);
     Tn x144 = E.up(4, x155, &x14), x133 = E.up(3, x144, &x13), x122 = E.up(2, x133, &x12);
     if (is_training) {
         Tn x111 = E.up(1, x122, nullptr);
-        E.field(x111, th1, ac, resid, grids);
+        E.field(x111, 0, th1, ac, resid, grids);
     }
     // ---- stage 2 (reference :178-198)
     Tn x22 = E.down_bottom(1, nullptr, x11);
     Tn x23 = E.down_bottom(2, &x22, x12), x24 = E.down_bottom(3, &x23, x13), x25 = E.down_bottom(4, &x24, x14);
     Tn x26 = E.down_bottom(5, &x25, x15), x27 = E.down_bottom(6, &x26, x16), x28 = E.down_bottom(7, &x27, x17);
-    E.theta(x28, th2);
+    E.theta(x28, 1, th2);
     Tn x277 = E.up_bottom(7, x18, x28, &x27), x266 = E.up_bottom(6, x177, x277, &x26);
     Tn x255 = E.up_bottom(5, x166, x266, &x25), x244 = E.up_bottom(4, x155, x255, &x24);
     Tn x233 = E.up_bottom(3, x144, x244, &x23), x222 = E.up_bottom(2, x133, x233, &x22);
     if (is_training) {
         Tn x211 = E.up_bottom(1, x122, x222, nullptr);
-        E.field(x211, th2, ac, resid ? resid + gsz : nullptr, grids ? grids + gsz : nullptr);
+        E.field(x211, 1, th2, ac, resid ? resid + gsz : nullptr, grids ? grids + gsz : nullptr);
     }
     // ---- stage 3 (reference :200-219); x32 == x22 (same weights, same input)
     const Tn &x32 = x22;
     Tn x33 = E.down_bottom(2, &x32, x22), x34 = E.down_bottom(3, &x33, x23), x35 = E.down_bottom(4, &x34, x24);
     Tn x36 = E.down_bottom(5, &x35, x25), x37 = E.down_bottom(6, &x36, x26), x38 = E.down_bottom(7, &x37, x27);
-    E.theta(x38, th3);
+    E.theta(x38, 2, th3);
     Tn x377 = E.up_bottom(7, x28, x38, &x37), x366 = E.up_bottom(6, x277, x377, &x36);
     Tn x355 = E.up_bottom(5, x266, x366, &x35), x344 = E.up_bottom(4, x255, x355, &x34);
     Tn x333 = E.up_bottom(3, x244, x344, &x33), x322 = E.up_bottom(2, x233, x333, &x32);
     Tn x311 = E.up_bottom(1, x222, x322, nullptr);
     if (is_training)
-        E.field(x311, th3, ac, resid ? resid + 2 * gsz : nullptr, grids ? grids + 2 * gsz : nullptr);
+        E.field(x311, 2, th3, ac, resid ? resid + 2 * gsz : nullptr, grids ? grids + 2 * gsz : nullptr);
     else
-        E.field(x311, th3, ac, nullptr, grids);
+        E.field(x311, 2, th3, ac, nullptr, grids);
+}
+
+struct GradBuf {
+    float *g;
+    bool written;
+};
+
+// The forward passes its thetas pointer; the planning replay must consume the arena identically, so backward is
+// told whether the forward kept thetas in the arena (thetas_in_arena) -- the Python host always passes its own buffer.
+static int run_backward(const float *packed, const float *packed_dgrad, const float *x, int n, int input_nc, int g, int ac,
+                        char *ws, size_t ws_bytes, const float *resid, const float *thetas, const float *g_grids,
+                        const float *g_resid, float *dpacked, hipStream_t st, bool dry, size_t *used) {
+    const int S = 256;
+    size_t total = 0;
+    const std::vector<Layer> L = build_layers(input_nc, g, &total);
+    Exec E(packed, L, n, ws, ws_bytes, st, dry, /*launch=*/false);
+    float dummy_thetas = 0.f;  // non-NULL: the training forward is always given a caller-owned thetas buffer
+    forward_graph(E, x, n, input_nc, g, 1, ac, nullptr, nullptr, &dummy_thetas);
+    // gradient buffers, one per produced tensor, after the forward region of the arena
+    std::unordered_map<const float *, GradBuf> G;
+    for (size_t i = 0; i < E.tape().size(); ++i) {
+        const Op &op = E.tape()[i];
+        if (op.type != OP_CONV) continue;
+        const Seg &o = op.out.seg[0];
+        float *gp = E.alloc((size_t)n * op.out.h * op.out.w * o.c);
+        if (!dry) G[o.ptr] = GradBuf{gp, false};
+    }
+    float *gz_ws = E.alloc((size_t)n * S * S * 2);
+    float *th_bwd_ws = E.alloc((size_t)n * 8 * g);
+    float *dtheta = E.alloc((size_t)3 * n * 6);
     if (used) *used = E.used();
-    return E.rc();
+    if (dry) return PWS_OK;
+    if (E.rc() != PWS_OK) return E.rc();
+
+    hipError_t e = hipMemsetAsync(dpacked, 0, total * sizeof(float), st);
+    if (e != hipSuccess) {
+        set_error("pws_netg_backward: hipMemsetAsync: %s", hipGetErrorString(e));
+        return PWS_EHIP;
+    }
+    const size_t gsz = (size_t)n * S * S * 2;
+    bool have_dtheta[3] = {false, false, false};
+    int rc = PWS_OK;
+    for (size_t ii = E.tape().size(); ii-- > 0 && rc == PWS_OK;) {
+        const Op &op = E.tape()[ii];
+        if (op.type == OP_FIELD) {
+            const int k = op.stage;
+            const float *gg = g_grids ? g_grids + k * gsz : nullptr, *gr = g_resid ? g_resid + k * gsz : nullptr;
+            if (!gg && !gr) continue;
+            const Seg &xs = op.in.seg[0];
+            GradBuf &gb = G[xs.ptr];
+            const Layer &o = L[L_OUT];
+            rc = pws_field_head_bwd(xs.ptr, xs.ld, n, op.in.h, op.in.w, xs.c, packed + o.w_off, resid + k * gsz, gg, gr, ac, gb.g,
+                                    xs.c, gb.written ? 1 : 0, dpacked + o.w_off, dpacked + o.b_off,
+                                    gg ? dtheta + (size_t)k * n * 6 : nullptr, gz_ws, st);
+            gb.written = true;
+            have_dtheta[k] = gg != nullptr;
+        } else if (op.type == OP_THETA) {
+            const int k = op.stage;
+            if (!have_dtheta[k]) continue;
+            const Seg &xs = op.in.seg[0];
+            GradBuf &gb = G[xs.ptr];
+            const Layer &f = L[L_FLATTEN], &l = L[L_LINEAR];
+            rc = pws_theta_head_bwd(xs.ptr, n, xs.c, f.cout, packed + f.w_off, packed + l.w_off, E.h_saved(k),
+                                    thetas + (size_t)k * n * 6, dtheta + (size_t)k * n * 6, dpacked + f.w_off, dpacked + f.b_off,
+                                    dpacked + l.w_off, dpacked + l.b_off, gb.g, gb.written ? 1 : 0, th_bwd_ws, st);
+            gb.written = true;
+        } else {
+            const Layer &l = L[op.layer];
+            const Seg &o = op.out.seg[0];
+            GradBuf &go = G[o.ptr];
+            if (!go.written) continue;  // nothing downstream asked for a gradient
+            const size_t pixels = (size_t)n * op.out.h * op.out.w;
+            g_prof_tag = op.layer;
+            rc = pws_act_bwd_bias(go.g, o.ptr, pixels, l.cout, op.act, dpacked + l.b_off, st);
+            if (rc != PWS_OK) break;
+            pws_conv_bwd_weight_args wa{};
+            wa.kind = l.kind, wa.n = n, wa.h = op.in.h, wa.w = op.in.w, wa.nsrc = op.in.nseg, wa.src_nchw = op.nchw ? 1 : 0;
+            for (int i = 0; i < op.in.nseg; ++i) wa.src[i] = pws_src{op.in.seg[i].ptr, op.in.seg[i].c, op.in.seg[i].ld};
+            if (op.nchw) wa.src[0] = pws_src{x, input_nc, 0};
+            wa.cout = l.cout, wa.gout = go.g, wa.gout_ld = l.cout, wa.dw_packed = dpacked + l.w_off;
+            rc = pws_conv2d_bwd_weight(&wa, st);
+            if (rc != PWS_OK || op.nchw) {
+                g_prof_tag = -1;
+                continue;  // the window is data: no gradient wrt the first layer's input
+            }
+            pws_conv_bwd_data_args da{};
+            da.kind = l.kind, da.n = n, da.h = op.in.h, da.w = op.in.w, da.cout = l.cout, da.gout = go.g, da.gout_ld = l.cout;
+            da.w_dgrad = packed_dgrad + l.dg_off, da.ndst = op.in.nseg;
+            for (int i = 0; i < op.in.nseg; ++i) {
+                GradBuf &gi = G[op.in.seg[i].ptr];
+                da.dst[i] = pws_dst{gi.g, op.in.seg[i].c, op.in.seg[i].c, gi.written ? 1 : 0};
+                gi.written = true;
+            }
+            da.ws = E.splitk_ws(), da.ws_bytes = E.splitk_bytes();
+            rc = pws_conv2d_bwd_data(&da, st);
+            g_prof_tag = -1;
+        }
+    }
+    return rc;
 }
 
 }  // namespace pws
@@ -255,6 +371,13 @@ extern "C" size_t pws_netg_packed_floats(int input_nc, int ngf) {
     size_t total = 0;
     build_layers(input_nc, ngf, &total);
     return total;
+}
+
+extern "C" size_t pws_netg_packed_dgrad_floats(int input_nc, int ngf) {
+    if (input_nc <= 0 || ngf <= 0 || ngf % 16 != 0) return 0;
+    size_t total = 0, dg = 0;
+    build_layers(input_nc, ngf, &total, &dg);
+    return dg;
 }
 
 extern "C" int pws_netg_pack_weights(const float *const *params, float *packed, int input_nc, int ngf, pws_stream_t stream) {
@@ -282,10 +405,54 @@ extern "C" int pws_netg_pack_weights(const float *const *params, float *packed, 
     return PWS_OK;
 }
 
+extern "C" int pws_netg_pack_weights_dgrad(const float *const *params, float *packed_dgrad, int input_nc, int ngf,
+                                           pws_stream_t stream) {
+    PWS_REQUIRE(params && packed_dgrad, "pws_netg_pack_weights_dgrad: NULL pointer");
+    PWS_REQUIRE(input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_pack_weights_dgrad: bad ngf %d", ngf);
+    size_t total = 0, dg = 0;
+    const std::vector<Layer> L = build_layers(input_nc, ngf, &total, &dg);
+    for (int i = 0; i < L_COUNT; ++i) {
+        if (L[i].dg_off == (size_t)-1) continue;
+        PWS_REQUIRE(params[2 * i], "pws_netg_pack_weights_dgrad: params[%d] is NULL", 2 * i);
+        int rc = pws_pack_conv_weight_dgrad(params[2 * i], packed_dgrad + L[i].dg_off, L[i].kind, L[i].cin, L[i].cout, stream);
+        if (rc != PWS_OK) return rc;
+    }
+    return PWS_OK;
+}
+
+extern "C" int pws_netg_unpack_grads(const float *dpacked, float *const *grads, int input_nc, int ngf, pws_stream_t stream) {
+    PWS_REQUIRE(dpacked && grads, "pws_netg_unpack_grads: NULL pointer");
+    PWS_REQUIRE(input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_unpack_grads: bad ngf %d", ngf);
+    size_t total = 0;
+    const std::vector<Layer> L = build_layers(input_nc, ngf, &total);
+    for (int i = 0; i < L_COUNT; ++i) {
+        PWS_REQUIRE(grads[2 * i] && grads[2 * i + 1], "pws_netg_unpack_grads: grads[%d] is NULL", 2 * i);
+        int rc = pws_unpack_conv_weight(dpacked + L[i].w_off, grads[2 * i], L[i].kind, L[i].cin, L[i].cout, stream);
+        if (rc != PWS_OK) return rc;
+        hipError_t e = hipMemcpyAsync(grads[2 * i + 1], dpacked + L[i].b_off, sizeof(float) * L[i].cout, hipMemcpyDeviceToDevice,
+                                      as_stream(stream));
+        if (e != hipSuccess) {
+            set_error("pws_netg_unpack_grads: hipMemcpyAsync(bias %d): %s", i, hipGetErrorString(e));
+            return PWS_EHIP;
+        }
+    }
+    return PWS_OK;
+}
+
 extern "C" size_t pws_netg_workspace_bytes(int n, int input_nc, int ngf, int is_training) {
     if (n <= 0 || input_nc <= 0 || ngf <= 0 || ngf % 16 != 0) return 0;
+    size_t total = 0;
+    const std::vector<Layer> L = build_layers(input_nc, ngf, &total);
+    Exec E(nullptr, L, n, nullptr, 0, nullptr, /*dry=*/true, false);
+    forward_graph(E, nullptr, n, input_nc, ngf, is_training, 0, nullptr, nullptr, nullptr);
+    return E.used();
+}
+
+extern "C" size_t pws_netg_train_workspace_bytes(int n, int input_nc, int ngf) {
+    if (n <= 0 || input_nc <= 0 || ngf <= 0 || ngf % 16 != 0) return 0;
     size_t used = 0;
-    run_forward(nullptr, nullptr, n, input_nc, ngf, is_training, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, true, &used);
+    run_backward(nullptr, nullptr, nullptr, n, input_nc, ngf, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                 true, &used);
     return used;
 }
 
@@ -296,8 +463,23 @@ extern "C" int pws_netg_forward(const float *packed, const float *x, int n, int 
                 ngf);
     if (n == 0) return PWS_OK;
     PWS_REQUIRE(packed && x && ws && grids, "pws_netg_forward: NULL pointer");
-    PWS_REQUIRE(!is_training || resid, "pws_netg_forward: resid must be given when is_training");
+    PWS_REQUIRE(!is_training || (resid && thetas), "pws_netg_forward: resid and thetas must be given when is_training");
     PWS_REQUIRE((reinterpret_cast<size_t>(ws) & 255) == 0, "pws_netg_forward: workspace must be 256-byte aligned");
-    return run_forward(packed, x, n, input_nc, ngf, is_training, align_corners, static_cast<char *>(ws), ws_bytes, grids, resid,
-                       thetas, as_stream(stream), false, nullptr);
+    size_t total = 0;
+    const std::vector<Layer> L = build_layers(input_nc, ngf, &total);
+    Exec E(packed, L, n, static_cast<char *>(ws), ws_bytes, as_stream(stream), false, true);
+    forward_graph(E, x, n, input_nc, ngf, is_training, align_corners, grids, resid, thetas);
+    return E.rc();
+}
+
+extern "C" int pws_netg_backward(const float *packed, const float *packed_dgrad, const float *x, int n, int input_nc, int ngf,
+                                 int align_corners, void *ws, size_t ws_bytes, const float *resid, const float *thetas,
+                                 const float *g_grids, const float *g_resid, float *dpacked, pws_stream_t stream) {
+    PWS_REQUIRE(n >= 0 && input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_backward: bad n/input_nc/ngf");
+    if (n == 0) return PWS_OK;
+    PWS_REQUIRE(packed && packed_dgrad && x && ws && resid && thetas && dpacked, "pws_netg_backward: NULL pointer");
+    PWS_REQUIRE(g_grids || g_resid, "pws_netg_backward: no output gradient given");
+    PWS_REQUIRE((reinterpret_cast<size_t>(ws) & 255) == 0, "pws_netg_backward: workspace must be 256-byte aligned");
+    return run_backward(packed, packed_dgrad, x, n, input_nc, ngf, align_corners, static_cast<char *>(ws), ws_bytes, resid, thetas,
+                        g_grids, g_resid, dpacked, as_stream(stream), false, nullptr);
 }

@@ -28,6 +28,22 @@ class PwsConvArgs(ctypes.Structure):
                 ("out", ctypes.c_void_p), ("out_ld", ctypes.c_int), ("ws", ctypes.c_void_p), ("ws_bytes", ctypes.c_size_t)]
 
 
+class PwsDst(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("channels", ctypes.c_int), ("ld", ctypes.c_int), ("accumulate", ctypes.c_int)]
+
+
+class PwsConvBwdDataArgs(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int), ("n", ctypes.c_int), ("h", ctypes.c_int), ("w", ctypes.c_int), ("cout", ctypes.c_int),
+                ("gout", ctypes.c_void_p), ("gout_ld", ctypes.c_int), ("w_dgrad", ctypes.c_void_p), ("ndst", ctypes.c_int),
+                ("dst", PwsDst * 4), ("ws", ctypes.c_void_p), ("ws_bytes", ctypes.c_size_t)]
+
+
+class PwsConvBwdWeightArgs(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int), ("n", ctypes.c_int), ("h", ctypes.c_int), ("w", ctypes.c_int), ("nsrc", ctypes.c_int),
+                ("src", PwsSrc * 4), ("src_nchw", ctypes.c_int), ("cout", ctypes.c_int), ("gout", ctypes.c_void_p),
+                ("gout_ld", ctypes.c_int), ("dw_packed", ctypes.c_void_p)]
+
+
 class PwsProfRecord(ctypes.Structure):
     _fields_ = [("kernel_id", ctypes.c_int), ("tag", ctypes.c_int), ("flops", ctypes.c_double),
                 ("bytes", ctypes.c_double), ("ms", ctypes.c_float)]
@@ -43,6 +59,20 @@ SIGNATURES = {
     "pws_packed_weight_floats": (_S, [_I, _I, _I]),
     "pws_pack_conv_weight": (_I, [_P, _P, _I, _I, _I, _P]),
     "pws_conv2d_fwd": (_I, [ctypes.POINTER(PwsConvArgs), _P]),
+    "pws_act_bwd_bias": (_I, [_P, _P, _S, _I, _I, _P, _P]),
+    "pws_packed_dgrad_floats": (_S, [_I, _I, _I]),
+    "pws_pack_conv_weight_dgrad": (_I, [_P, _P, _I, _I, _I, _P]),
+    "pws_conv2d_bwd_data": (_I, [ctypes.POINTER(PwsConvBwdDataArgs), _P]),
+    "pws_conv2d_bwd_weight": (_I, [ctypes.POINTER(PwsConvBwdWeightArgs), _P]),
+    "pws_unpack_conv_weight": (_I, [_P, _P, _I, _I, _I, _P]),
+    "pws_theta_head_fwd_save": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pws_theta_head_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "pws_field_head_bwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "pws_netg_packed_dgrad_floats": (_S, [_I, _I]),
+    "pws_netg_pack_weights_dgrad": (_I, [ctypes.POINTER(_P), _P, _I, _I, _P]),
+    "pws_netg_train_workspace_bytes": (_S, [_I, _I, _I]),
+    "pws_netg_backward": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _S, _P, _P, _P, _P, _P, _P]),
+    "pws_netg_unpack_grads": (_I, [_P, ctypes.POINTER(_P), _I, _I, _P]),
     "pws_theta_head_ws_floats": (_S, [_I, _I, _I]),
     "pws_theta_head_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "pws_field_head_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),

@@ -140,6 +140,8 @@ class UnetGenerator(nn.Module):
             setattr(getattr(self, block_name), seq_name, nn.Sequential(*mods))
         self._packed = None
         self._packed_key = None
+        self._packed_dgrad = None
+        self._packed_dgrad_key = None
         self._ws = {}
 
     # -- parameters in state-dict order: (weight, bias) per layer
@@ -167,6 +169,21 @@ class UnetGenerator(nn.Module):
             self._packed_key = key
         return self._packed
 
+    def packed_dgrad_weights(self):
+        """Second device buffer: the weights in the data-gradient kernels' layout (training only)."""
+        params = self._ordered_params()
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._packed_dgrad is None or key != self._packed_dgrad_key:
+            A.require_cuda(*params)
+            nfl = A.lib().pws_netg_packed_dgrad_floats(self.input_nc, self.ngf)
+            if self._packed_dgrad is None or self._packed_dgrad.numel() != nfl or self._packed_dgrad.device != params[0].device:
+                self._packed_dgrad = torch.empty(nfl, device=params[0].device, dtype=torch.float32)
+            ptrs = (ctypes.c_void_p * len(params))(*[p.data_ptr() for p in params])
+            A.check(A.lib().pws_netg_pack_weights_dgrad(ptrs, A.ptr(self._packed_dgrad), self.input_nc, self.ngf,
+                                                        A.current_stream()), "pws_netg_pack_weights_dgrad")
+            self._packed_dgrad_key = key
+        return self._packed_dgrad
+
     def _workspace(self, n, is_training, device):
         k = (n, bool(is_training), device)
         if k not in self._ws:
@@ -186,12 +203,18 @@ class UnetGenerator(nn.Module):
             return _netg_autograd(self, input1, is_training)
         return self._run(input1, is_training)
 
-    def _run(self, input1, is_training):
+    def _run(self, input1, is_training, train_ctx=None):
+        """train_ctx: dict filled with what backward needs; the arena is then private to this call (the reference's
+        training loop runs two forwards before one backward, main_new.py:101,112,214)."""
         x = input1.contiguous()
         n = x.shape[0]
         S = 256
         packed = self.packed_weights()
-        ws = self._workspace(n, is_training, x.device)
+        if train_ctx is not None:
+            nbytes = A.lib().pws_netg_train_workspace_bytes(n, self.input_nc, self.ngf)
+            ws = torch.empty(nbytes + 256, device=x.device, dtype=torch.uint8)
+        else:
+            ws = self._workspace(n, is_training, x.device)
         ws_ptr = (ws.data_ptr() + 255) // 256 * 256
         ws_bytes = ws.numel() - (ws_ptr - ws.data_ptr())
         ng = 3 if is_training else 1
@@ -202,6 +225,8 @@ class UnetGenerator(nn.Module):
                                          0, ctypes.c_void_p(ws_ptr), ws_bytes, A.ptr(grids), A.ptr(resid), A.ptr(thetas),
                                          A.current_stream()), "pws_netg_forward")
         self.last_thetas = thetas
+        if train_ctx is not None:
+            train_ctx.update(x=x, ws=ws, ws_ptr=ws_ptr, ws_bytes=ws_bytes, grids=grids, resid=resid, thetas=thetas, packed=packed)
         if is_training:
             return [grids[0], grids[1], grids[2]], [resid[0], resid[1], resid[2]]
         return grids[0]

@@ -1,0 +1,40 @@
+"""Fused Adam on the HIP kernel, with the call surface the reference uses: ``optim.Adam(netG.parameters(), lr=...,
+betas=(beta1, 0.999))``, ``.zero_grad()``, ``.step()`` (reference main_new.py:63,213-216).  No weight decay / amsgrad
+(the reference does not use them).  State is fp32 ``exp_avg`` / ``exp_avg_sq`` per parameter, as in torch."""
+import torch
+
+from . import functional as PF
+
+
+class Adam:
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params]
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.state = {}
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self):
+        self.step_count += 1
+        touched = []
+        for p in self.params:
+            if p.grad is None:
+                continue
+            st = self.state.get(p)
+            if st is None:
+                st = self.state[p] = (torch.zeros_like(p), torch.zeros_like(p))
+            g = p.grad.contiguous()
+            PF.adam_step_(p, g, st[0], st[1], self.lr, self.betas[0], self.betas[1], self.eps, self.step_count)
+            touched.append(p)
+        if touched:
+            # the kernel wrote through raw pointers: bump the tensors' version counters (one fused launch) so that
+            # everything keyed on them -- the generator's packed-weight cache -- sees the update
+            torch._foreach_add_(touched, 0.0)

@@ -1,0 +1,278 @@
+"""GPU parity of the training path: data gradient, weight gradient, activation/bias gradient, head backward and the
+whole-generator backward, against PyTorch-CPU autograd of the same ops (oracle/torch_ref.py graph) and against the
+loss / gradient vectors generated from the reference (tests/golden/netg.npz).
+
+Tolerances: gradients are sums over up to 5e5 pixels accumulated with fp32 atomics in a run-dependent order; bounds
+are relative to the largest gradient magnitude of the tensor (2e-4) unless stated.
+"""
+import ctypes
+import zlib
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.nn.functional as F  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+from pwstablenet_amd import synth  # noqa: E402
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def relclose(got, want, tol):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    scale = max(np.abs(want).max(), 1e-12)
+    err = np.abs(got - want).max() / scale
+    assert err < tol, "max err / max|ref| = %.3g (tol %.3g)" % (err, tol)
+
+
+KINDS = {"CONV_K3S1": ("conv", 3, 1, 1), "CONV_K3S2": ("conv", 3, 2, 1), "CONV_K5S1": ("conv", 5, 1, 2),
+         "CONVT_K3S1": ("convT", 3, 1, 1), "CONVT_K4S2": ("convT", 4, 2, 1)}
+
+BWD_CASES = [
+    ("CONV_K3S1", (2, 20, 37), [16, 16], 32), ("CONV_K3S1", (3, 8, 8), [32], 16), ("CONV_K3S1", (5, 4, 4), [16], 64),
+    ("CONV_K3S1", (17, 2, 2), [64], 16),
+    ("CONV_K3S2", (2, 40, 34), [16, 16], 64), ("CONV_K3S2", (2, 16, 16), [32], 32), ("CONV_K3S2", (3, 8, 8), [16], 32),
+    ("CONV_K3S2", (9, 4, 4), [16, 16, 16], 16), ("CONV_K3S2", (2, 21, 9), [16], 16),
+    ("CONVT_K3S1", (2, 18, 21), [16, 32], 48), ("CONVT_K3S1", (2, 4, 4), [16], 16),
+    ("CONVT_K4S2", (2, 17, 19), [32, 16, 16], 64), ("CONVT_K4S2", (2, 8, 8), [16], 32), ("CONVT_K4S2", (3, 4, 4), [16, 16], 16),
+    ("CONVT_K4S2", (18, 2, 2), [32], 64),
+    ("CONV_K5S1", (1, 23, 40), [16], 32),
+]
+
+
+def torch_layer(kname, x, w, b, act):
+    kind, k, s, p = KINDS[kname]
+    y = (F.conv2d if kind == "conv" else F.conv_transpose2d)(x, w, b, stride=s, padding=p)
+    return F.leaky_relu(y, 0.2) if act == 1 else F.relu(y)
+
+
+@pytest.mark.parametrize("kname,shape,src_c,cout", BWD_CASES)
+@pytest.mark.parametrize("act", [1, 2])
+def test_layer_backward_vs_torch_cpu(hip, kname, shape, src_c, cout, act):
+    """One layer: y = act(conv(x)); given dy, check db, dW (packed -> torch layout) and dx (scattered, accumulate)."""
+    A = hip
+    L, st = A.lib(), A.current_stream()
+    kind = getattr(A, kname)
+    n, h, w = shape
+    rs = np.random.RandomState(zlib.crc32(repr((kname, shape, cout, "b")).encode()))
+    cin = sum(src_c)
+    kk = KINDS[kname][1]
+    is_t = KINDS[kname][0] == "convT"
+    x = torch.from_numpy(rs.standard_normal((n, cin, h, w)).astype(np.float32)).requires_grad_(True)
+    wt = torch.from_numpy((rs.standard_normal((cin, cout, kk, kk) if is_t else (cout, cin, kk, kk)) / np.sqrt(cin * kk)).astype(
+        np.float32)).requires_grad_(True)
+    b = torch.from_numpy(rs.standard_normal(cout).astype(np.float32)).requires_grad_(True)
+    y = torch_layer(kname, x, wt, b, act)
+    dy = torch.from_numpy(rs.standard_normal(tuple(y.shape)).astype(np.float32))
+    y.backward(dy)
+
+    # ---- HIP: activation/bias gradient in place
+    d_y, d_dy = nhwc(y.detach()).cuda(), nhwc(dy).cuda()
+    db = torch.zeros(cout, device="cuda")
+    pixels = d_y.shape[0] * d_y.shape[1] * d_y.shape[2]
+    A.check(L.pws_act_bwd_bias(A.ptr(d_dy), A.ptr(d_y), pixels, cout, act, A.ptr(db), st), "act_bwd")
+    relclose(db.cpu().numpy(), b.grad.numpy(), 2e-4)
+    # ---- weight gradient in the forward packed layout, then unpack
+    xs = nhwc(x.detach())
+    srcs, c0 = [], 0
+    for c in src_c:
+        srcs.append(xs[..., c0:c0 + c].contiguous().cuda())
+        c0 += c
+    wa = A.PwsConvBwdWeightArgs()
+    wa.kind, wa.n, wa.h, wa.w, wa.nsrc, wa.cout = kind, n, h, w, len(srcs), cout
+    for i, s_ in enumerate(srcs):
+        wa.src[i].ptr, wa.src[i].channels, wa.src[i].ld = s_.data_ptr(), s_.shape[3], s_.shape[3]
+    dwp = torch.zeros(L.pws_packed_weight_floats(kind, cin, cout), device="cuda")
+    wa.gout, wa.gout_ld, wa.dw_packed = d_dy.data_ptr(), cout, dwp.data_ptr()
+    A.check(L.pws_conv2d_bwd_weight(ctypes.byref(wa), st), "bwd_weight")
+    dw = torch.empty(tuple(wt.shape), device="cuda")
+    A.check(L.pws_unpack_conv_weight(A.ptr(dwp), A.ptr(dw), kind, cin, cout, st), "unpack")
+    relclose(dw.cpu().numpy(), wt.grad.numpy(), 2e-4)
+    if kname == "CONV_K5S1":
+        return  # the first layer's input is data: no data gradient
+    # ---- data gradient, scattered over the sources; second source pre-filled to test accumulation
+    wdg = torch.empty(L.pws_packed_dgrad_floats(kind, cin, cout), device="cuda")
+    d_w = wt.detach().cuda()
+    A.check(L.pws_pack_conv_weight_dgrad(A.ptr(d_w), A.ptr(wdg), kind, cin, cout, st), "pack_dgrad")
+    for ws_mb in (0, 64):
+        da = A.PwsConvBwdDataArgs()
+        da.kind, da.n, da.h, da.w, da.cout = kind, n, h, w, cout
+        da.gout, da.gout_ld, da.w_dgrad, da.ndst = d_dy.data_ptr(), cout, wdg.data_ptr(), len(srcs)
+        outs = []
+        for i, c in enumerate(src_c):
+            acc = 1 if i == 1 else 0
+            o = torch.full((n, h, w, c), 0.5 if acc else float("nan"), device="cuda")
+            outs.append(o)
+            da.dst[i].ptr, da.dst[i].channels, da.dst[i].ld, da.dst[i].accumulate = o.data_ptr(), c, c, acc
+        if ws_mb:
+            wsb = torch.empty(ws_mb << 20, device="cuda", dtype=torch.uint8)
+            da.ws, da.ws_bytes = wsb.data_ptr(), wsb.numel()
+        A.check(L.pws_conv2d_bwd_data(ctypes.byref(da), st), "bwd_data")
+        torch.cuda.synchronize()
+        ref = nhwc(x.grad).numpy()
+        c0 = 0
+        for i, c in enumerate(src_c):
+            got = outs[i].cpu().numpy() - (0.5 if i == 1 else 0.0)
+            assert not np.isnan(got).any()
+            relclose(got, ref[..., c0:c0 + c], 2e-4)
+            c0 += c
+
+
+def test_first_layer_weight_grad_nchw(hip):
+    A = hip
+    L, st = A.lib(), A.current_stream()
+    rs = np.random.RandomState(3)
+    x = torch.from_numpy(rs.standard_normal((2, 31, 37, 50)).astype(np.float32))
+    wt = torch.from_numpy((rs.standard_normal((32, 31, 5, 5)) / 28).astype(np.float32)).requires_grad_(True)
+    y = F.conv2d(x, wt, None, padding=2)
+    dy = torch.from_numpy(rs.standard_normal(tuple(y.shape)).astype(np.float32))
+    y.backward(dy)
+    d_x, d_dy = x.cuda(), nhwc(dy).cuda()
+    wa = A.PwsConvBwdWeightArgs()
+    wa.kind, wa.n, wa.h, wa.w, wa.nsrc, wa.src_nchw, wa.cout = A.CONV_K5S1, 2, 37, 50, 1, 1, 32
+    wa.src[0].ptr, wa.src[0].channels = d_x.data_ptr(), 31
+    dwp = torch.zeros(L.pws_packed_weight_floats(A.CONV_K5S1, 31, 32), device="cuda")
+    wa.gout, wa.gout_ld, wa.dw_packed = d_dy.data_ptr(), 32, dwp.data_ptr()
+    A.check(L.pws_conv2d_bwd_weight(ctypes.byref(wa), st), "bwd_weight")
+    dw = torch.empty((32, 31, 5, 5), device="cuda")
+    A.check(L.pws_unpack_conv_weight(A.ptr(dwp), A.ptr(dw), A.CONV_K5S1, 31, 32, st), "unpack")
+    relclose(dw.cpu().numpy(), wt.grad.numpy(), 2e-4)
+
+
+def test_pack_unpack_roundtrip(hip):
+    A = hip
+    L, st = A.lib(), A.current_stream()
+    for kname, (kind, k, _, _) in KINDS.items():
+        cin, cout = (31, 32) if kname == "CONV_K5S1" else (48, 32)
+        shape = (cin, cout, k, k) if kind == "convT" else (cout, cin, k, k)
+        w = torch.randn(shape, device="cuda")
+        p = torch.empty(L.pws_packed_weight_floats(getattr(A, kname), cin, cout), device="cuda")
+        back = torch.empty_like(w)
+        A.check(L.pws_pack_conv_weight(A.ptr(w), A.ptr(p), getattr(A, kname), cin, cout, st), "pack")
+        A.check(L.pws_unpack_conv_weight(A.ptr(p), A.ptr(back), getattr(A, kname), cin, cout, st), "unpack")
+        assert torch.equal(w, back), kname
+
+
+def make_net(kind, ngf):
+    from pwstablenet_amd.lib.networks_cascading import define_G
+    net = define_G(31, 2, ngf, "normal", 0.02)
+    net.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in synth.make_weights(kind, seed=123, ngf=ngf)})
+    return net.cuda()
+
+
+def l1_warp_loss(grids, frames, target, gs):
+    return sum(F.l1_loss(gs(frames, g) / 127.5 - 1, target / 127.5 - 1) for g in grids)
+
+
+def test_netg_backward_vs_torch_cpu_autograd(hip):
+    """Whole generator, all 92 gradients: HIP backward vs PyTorch-CPU autograd of the restated graph (ngf=16)."""
+    from oracle import torch_ref
+    from pwstablenet_amd import functional as PF
+    kind, ngf, n = "W2", 16, 2
+    torch.set_num_threads(8)
+    weights = synth.make_weights(kind, seed=123, ngf=ngf)
+    xw = torch.from_numpy(synth.make_window(n, 31, 256, seed=9))
+    frames = torch.from_numpy(synth.make_frames(n, 3, 256, 256, seed=10))
+    target = torch.roll(frames, shifts=(2, -3), dims=(2, 3))
+    # CPU reference
+    cparams = [torch.from_numpy(v.copy()).requires_grad_(True) for _, v in weights]
+    cg, cr = torch_ref.netg_forward(cparams, xw, True)
+    closs = l1_warp_loss(cg, frames, target, lambda f, g: F.grid_sample(f, g, align_corners=False)) + \
+        sum((r * r).mean() for r in cr) * 0.1
+    closs.backward()
+    # HIP
+    net = make_net(kind, ngf)
+    grids, resid = net(xw.cuda())
+    loss = l1_warp_loss(grids, frames.cuda(), target.cuda(), PF.grid_sample) + sum((r * r).mean() for r in resid) * 0.1
+    loss.backward()
+    assert abs(loss.item() - closs.item()) < 1e-5 * max(1.0, abs(closs.item()))
+    names = [k for k, _ in weights]
+    worst = 0.0
+    for name, p, cp in zip(names, net.module._ordered_params(), cparams):
+        ref = cp.grad.numpy()
+        got = p.grad.cpu().numpy()
+        scale = max(np.abs(ref).max(), 1e-9)
+        err = np.abs(got - ref).max() / scale
+        worst = max(worst, err)
+        assert err < 2e-3, "%s: max err / max|ref| = %.3g" % (name, err)
+    print("worst relative gradient error over 92 tensors: %.3g" % worst)
+
+
+@pytest.mark.parametrize("tag,kind,ngf,n", [("W1_g16", "W1", 16, 2), ("W2_g16", "W2", 16, 1), ("W1_g64", "W1", 64, 2),
+                                            ("W2_g64", "W2", 64, 2)])
+def test_netg_training_step_vs_reference_golden(hip, netg_golden, tag, kind, ngf, n):
+    """Loss and gradient samples of one training step produced by the reference itself (make_golden.py)."""
+    from pwstablenet_amd import functional as PF
+    g = netg_golden
+    net = make_net(kind, ngf)
+    x = torch.from_numpy(synth.make_window(n, 31, 256, seed=123)).cuda()
+    frames = torch.from_numpy(synth.make_frames(n, 3, 256, 256, seed=321)).cuda()
+    target = torch.roll(frames, shifts=(2, -3), dims=(2, 3))
+    grids, resid = net(x)
+    loss = l1_warp_loss(grids, frames, target, PF.grid_sample)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g[tag + "_loss"][0], rtol=2e-5)
+    named = dict(net.module.named_parameters())
+    for key in g.files:
+        if not key.startswith(tag + "_grad_") or not key.endswith("_csum"):
+            continue
+        name = key[len(tag + "_grad_"):-len("_csum")]
+        grad = named[name].grad.cpu().numpy().astype(np.float64)
+        want = g[key]  # sum, abs-sum, max-abs
+        np.testing.assert_allclose(np.abs(grad).sum(), want[1], rtol=2e-3, err_msg=name)
+        np.testing.assert_allclose(np.abs(grad).max(), want[2], rtol=2e-3, err_msg=name)
+        flat = grad.reshape(-1)
+        idx = np.random.RandomState(7).randint(0, flat.size, 16)
+        np.testing.assert_allclose(flat[idx], g["%s_grad_%s_samples" % (tag, name)], rtol=0, atol=2e-3 * want[2], err_msg=name)
+
+
+def test_two_forwards_one_backward_and_adam(hip):
+    """The reference's loop runs netG twice before one backward (main_new.py:101,112,214); gradients must add up.
+    Then one fused-Adam step must match torch.optim.Adam on the same gradients."""
+    from pwstablenet_amd import functional as PF
+    from pwstablenet_amd.optim import Adam
+    net = make_net("W1", 16)
+    x1 = torch.from_numpy(synth.make_window(1, 31, 256, seed=1)).cuda()
+    x2 = torch.from_numpy(synth.make_window(1, 31, 256, seed=2)).cuda()
+    fr = torch.from_numpy(synth.make_frames(1, 3, 256, 256, seed=3)).cuda()
+
+    def loss_of(x):
+        grids, _ = net(x)
+        return sum((PF.grid_sample(fr, g_) / 255).mean() for g_ in grids)
+
+    net.zero_grad()
+    loss_of(x1).backward()
+    g1 = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad()
+    loss_of(x2).backward()
+    g2 = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad()
+    (loss_of(x1) + loss_of(x2)).backward()
+    for p, a, b in zip(net.parameters(), g1, g2):
+        scale = float((a + b).abs().max()) + 1e-12
+        assert float((p.grad - (a + b)).abs().max()) / scale < 1e-3
+    # Adam parity
+    ref_params = [p.detach().clone().requires_grad_(True) for p in net.parameters()]
+    for rp, p in zip(ref_params, net.parameters()):
+        rp.grad = p.grad.clone()
+    ropt = torch.optim.Adam(ref_params, lr=1e-3, betas=(0.5, 0.999))
+    opt = Adam(net.parameters(), lr=1e-3, betas=(0.5, 0.999))
+    before = net(x1, False).detach().clone() if False else None
+    v0 = [p._version for p in net.parameters()]
+    ropt.step()
+    opt.step()
+    for rp, p in zip(ref_params, net.parameters()):
+        assert float((rp - p).abs().max()) < 2e-6
+    assert all(p._version > v for p, v in zip(net.parameters(), v0)), "version counters must move (packed-weight cache)"
+    with torch.no_grad():
+        out = net(x1, False)
+    assert torch.isfinite(out).all()
