@@ -290,35 +290,53 @@ int conv2d_bwd_weight_impl(const pws_conv_bwd_weight_args *a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------ act' and bias grad
-// dy <- dy * act'(y) in place; dbias[c] += sum over pixels.  One workgroup = 64 pixels x C channels strip, column sums
-// through LDS, one atomic per (workgroup, channel).  HBM-bound: 12 B per element.
+// dy <- dy * act'(y) in place; dbias[c] += sum over pixels.  HBM-bound (12 B per element).
+// A workgroup owns ABB_PIX consecutive pixels; lane t owns channel quad (t % c4n) for every (256 / c4n)-th pixel, so the
+// per-channel sums stay in registers; one LDS pass folds the pixel groups, then one global atomic per channel.
+constexpr int ABB_PIX = 256;
+
 __global__ void __launch_bounds__(256) act_bwd_bias_kernel(float *__restrict__ dy, const float *__restrict__ y, size_t pixels,
                                                            int c, int act, float *__restrict__ dbias) {
-    extern __shared__ float sbias[];  // c floats
+    extern __shared__ float sred[];  // 256 x 4 floats
     const int tid = threadIdx.x;
-    for (int i = tid; i < c; i += 256) sbias[i] = 0.f;
-    __syncthreads();
     const int c4n = c / 4;
-    const size_t p0 = (size_t)blockIdx.x * 64;
-    const size_t pend = p0 + 64 < pixels ? p0 + 64 : pixels;
-    // lanes walk the strip in float4 units; a lane keeps the same channel quad when 256 % c4n == 0 (all our widths)
-    for (size_t e = p0 * c4n + tid; e < pend * c4n; e += 256) {
-        float4 g = reinterpret_cast<float4 *>(dy)[e];
-        const float4 v = reinterpret_cast<const float4 *>(y)[e];
-        if (act == PWS_ACT_LRELU) {
-            g.x *= v.x > 0.f ? 1.f : 0.2f, g.y *= v.y > 0.f ? 1.f : 0.2f, g.z *= v.z > 0.f ? 1.f : 0.2f, g.w *= v.w > 0.f ? 1.f : 0.2f;
-        } else if (act == PWS_ACT_RELU) {
-            g.x = v.x > 0.f ? g.x : 0.f, g.y = v.y > 0.f ? g.y : 0.f, g.z = v.z > 0.f ? g.z : 0.f, g.w = v.w > 0.f ? g.w : 0.f;
+    const int span = c4n < 256 ? c4n : 256;  // channel quads handled per pass
+    const int groups = 256 / span;           // pixel groups (lanes beyond groups*span idle when span does not divide 256)
+    const size_t p0 = (size_t)blockIdx.x * ABB_PIX;
+    const size_t pend = p0 + ABB_PIX < pixels ? p0 + ABB_PIX : pixels;
+    for (int q0 = 0; q0 < c4n; q0 += 256) {  // one pass unless c > 1024
+        const int q = q0 + tid % span;
+        const int grp = tid / span;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < c4n && grp < groups) {
+            for (size_t p = p0 + grp; p < pend; p += groups) {
+                const size_t e = p * c4n + q;
+                float4 g = reinterpret_cast<float4 *>(dy)[e];
+                const float4 v = reinterpret_cast<const float4 *>(y)[e];
+                if (act == PWS_ACT_LRELU) {
+                    g.x *= v.x > 0.f ? 1.f : 0.2f, g.y *= v.y > 0.f ? 1.f : 0.2f, g.z *= v.z > 0.f ? 1.f : 0.2f,
+                        g.w *= v.w > 0.f ? 1.f : 0.2f;
+                } else if (act == PWS_ACT_RELU) {
+                    g.x = v.x > 0.f ? g.x : 0.f, g.y = v.y > 0.f ? g.y : 0.f, g.z = v.z > 0.f ? g.z : 0.f, g.w = v.w > 0.f ? g.w : 0.f;
+                }
+                if (act != PWS_ACT_NONE) reinterpret_cast<float4 *>(dy)[e] = g;
+                s.x += g.x, s.y += g.y, s.z += g.z, s.w += g.w;
+            }
         }
-        reinterpret_cast<float4 *>(dy)[e] = g;
         if (dbias) {
-            const int ch = (int)(e % c4n) * 4;
-            atomicAdd(&sbias[ch], g.x), atomicAdd(&sbias[ch + 1], g.y), atomicAdd(&sbias[ch + 2], g.z), atomicAdd(&sbias[ch + 3], g.w);
+            __syncthreads();
+            reinterpret_cast<float4 *>(sred)[tid] = s;
+            __syncthreads();
+            if (tid < span && q0 + tid < c4n) {
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int g_ = 0; g_ < groups; ++g_) {
+                    const float4 u = reinterpret_cast<const float4 *>(sred)[g_ * span + tid];
+                    t.x += u.x, t.y += u.y, t.z += u.z, t.w += u.w;
+                }
+                float *d = dbias + (size_t)(q0 + tid) * 4;
+                atomicAdd(d, t.x), atomicAdd(d + 1, t.y), atomicAdd(d + 2, t.z), atomicAdd(d + 3, t.w);
+            }
         }
-    }
-    if (dbias) {
-        __syncthreads();
-        for (int i = tid; i < c; i += 256) atomicAdd(dbias + i, sbias[i]);
     }
 }
 
@@ -329,14 +347,14 @@ extern "C" int pws_conv2d_bwd_weight(const pws_conv_bwd_weight_args *args, pws_s
 }
 
 extern "C" int pws_act_bwd_bias(float *dy, const float *y, size_t pixels, int c, int act, float *dbias, pws_stream_t stream) {
-    PWS_REQUIRE(c > 0 && c % 4 == 0 && c * sizeof(float) <= 64 * 1024, "pws_act_bwd_bias: c=%d must be a multiple of 4", c);
+    PWS_REQUIRE(c > 0 && c % 4 == 0, "pws_act_bwd_bias: c=%d must be a positive multiple of 4", c);
     PWS_REQUIRE(act >= PWS_ACT_NONE && act <= PWS_ACT_RELU, "pws_act_bwd_bias: bad act %d", act);
     if (pixels == 0) return PWS_OK;
     PWS_REQUIRE(dy && y && ((reinterpret_cast<size_t>(dy) | reinterpret_cast<size_t>(y)) & 15) == 0,
                 "pws_act_bwd_bias: NULL or unaligned pointer");
     if (act == PWS_ACT_NONE && !dbias) return PWS_OK;
     pws::ProfScope prof(pws::KID_ACT_BWD, 2.0 * pixels * c, 12.0 * pixels * c, pws::as_stream(stream));
-    hipLaunchKernelGGL(pws::act_bwd_bias_kernel, dim3((unsigned)((pixels + 63) / 64)), dim3(256), sizeof(float) * c,
-                       pws::as_stream(stream), dy, y, pixels, c, act, dbias);
+    hipLaunchKernelGGL(pws::act_bwd_bias_kernel, dim3((unsigned)((pixels + pws::ABB_PIX - 1) / pws::ABB_PIX)), dim3(256),
+                       sizeof(float) * 256 * 4, pws::as_stream(stream), dy, y, pixels, c, act, dbias);
     return pws::check_launch("act_bwd_bias_kernel");
 }

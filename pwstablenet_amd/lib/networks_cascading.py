@@ -143,6 +143,16 @@ class UnetGenerator(nn.Module):
         self._packed_dgrad = None
         self._packed_dgrad_key = None
         self._ws = {}
+        self._graph_mode = False
+        self._graphs = {}
+
+    def enable_graph(self, on=True):
+        """Opt-in hipGraph replay of the inference forward (``netG(x, False)`` under ``no_grad``): the ~75 launches of a
+        forward are captured once per (batch, input address, weight version) and replayed as one graph launch.
+        The returned field then lives in a buffer owned by the graph and is OVERWRITTEN by the next call."""
+        self._graph_mode = bool(on)
+        if not on:
+            self._graphs = {}
 
     # -- parameters in state-dict order: (weight, bias) per layer
     def _ordered_params(self):
@@ -201,7 +211,25 @@ class UnetGenerator(nn.Module):
         needs_grad = torch.is_grad_enabled() and (input1.requires_grad or any(p.requires_grad for p in self.parameters()))
         if needs_grad:
             return _netg_autograd(self, input1, is_training)
+        if self._graph_mode and not is_training:
+            return self._run_graph(input1)
         return self._run(input1, is_training)
+
+    def _run_graph(self, input1):
+        x = input1.contiguous()
+        self.packed_weights()
+        key = (x.shape[0], x.data_ptr(), self._packed_key)
+        ent = self._graphs.get(key)
+        if ent is None:
+            self._run(x, False)  # eager warm-up: one-time kernel attribute calls must not happen during capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._run(x, False)
+            self._graphs = {key: (g, out, x)}  # keep one graph; hold x so its address stays valid
+            ent = self._graphs[key]
+        ent[0].replay()
+        return ent[1]
 
     def _run(self, input1, is_training, train_ctx=None):
         """train_ctx: dict filled with what backward needs; the arena is then private to this call (the reference's
