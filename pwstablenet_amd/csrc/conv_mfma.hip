@@ -122,10 +122,14 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_mfma_kernel(const ConvKPar
     const int pad_x = C::SUBPIX == 1 ? 1 - px : (C::SUBPIX == 2 ? 0 : C::PAD);
     const int iy0 = y0 * C::STRIDE - pad_y, ix0 = x0 * C::STRIDE - pad_x;
 
-    // ---- hoisted per-thread staging descriptors (pixel decode is chunk independent)
-    int g_pix[C::ITEMS_IN];   // global pixel index (n*H+iy)*W+ix or -1
-    int l_off[C::ITEMS_IN];   // LDS float offset
+    // ---- hoisted per-thread staging descriptors (pixel decode is chunk independent).
+    // Loads are UNCONDITIONAL (out-of-image / out-of-range items read a valid dummy address and are zeroed by a select
+    // afterwards): a conditional load makes hipcc branch around it and wait vmcnt(0) before the next one, which
+    // serialises the whole prefetch (cdna_hip_programming.md, "register or load" trap).
+    int g_pix[C::ITEMS_IN];   // global pixel index (n*H+iy)*W+ix, 0 when masked
+    int l_off[C::ITEMS_IN];   // LDS float offset, -1 for items past the tile
     int g_c4[C::ITEMS_IN];
+    unsigned ok_mask = 0;
 #pragma unroll
     for (int it = 0; it < C::ITEMS_IN; ++it) {
         const int item = tid + it * C::THREADS;
@@ -133,10 +137,25 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_mfma_kernel(const ConvKPar
         const int lx = pix % C::IW, ly = (pix / C::IW) % C::IH, tn = pix / (C::IW * C::IH);
         const int n = n0 + tn, iy = iy0 + ly, ix = ix0 + lx;
         const bool ok = item < C::PIX * C::C4 && n < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        g_pix[it] = ok ? (n * p.H + iy) * p.W + ix : -1;
+        g_pix[it] = ok ? (n * p.H + iy) * p.W + ix : 0;
+        ok_mask |= ok ? (1u << it) : 0u;
         l_off[it] = item < C::PIX * C::C4 ? pix * C::CKP + c4 * 4 : -1;
         g_c4[it] = c4 * 4;
     }
+    static_assert(C::ITEMS_IN <= 32 && C::ITEMS_W <= 32, "mask width");
+    // weight-slab items: offset inside one [tap][CK][cout] slab, 0 (a valid address) when masked
+    int w_off[C::ITEMS_W];
+    unsigned w_mask = 0;
+#pragma unroll
+    for (int it = 0; it < C::ITEMS_W; ++it) {
+        const int item = tid + it * C::THREADS;
+        const int row = item / (C::BN / 4), q = item % (C::BN / 4);
+        const int tap = row / C::CK, c = row % C::CK;
+        const bool ok = item < C::TAPS * C::CK * (C::BN / 4) && (co0 + q * 4) < p.cout;
+        w_off[it] = ok ? (tap * p.cin_pad + c) * p.cout + co0 + q * 4 : 0;
+        w_mask |= ok ? (1u << it) : 0u;
+    }
+    const float *w_cls = p.w + (size_t)cls * C::TAPS * p.cin_pad * p.cout;
     float4 r_in[C::NCHW ? 1 : C::ITEMS_IN];
     float4 r_w[C::ITEMS_W];
     float r_nchw[C::NCHW ? C::ITEMS_NCHW : 1];
@@ -152,27 +171,20 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_mfma_kernel(const ConvKPar
                 const int n = n0 + tn, iy = iy0 + ly, ix = ix0 + lx;
                 const bool ok = item < C::PIX * C::CK && (c0 + c) < Creal && n < p.N && iy >= 0 && iy < p.H && ix >= 0 &&
                                 ix < p.W;
-                r_nchw[it] = ok ? p.src_ptr[0][((size_t)(n * Creal + c0 + c) * p.H + iy) * p.W + ix] : 0.f;
+                const size_t off = ok ? ((size_t)(n * Creal + c0 + c) * p.H + iy) * p.W + ix : 0;
+                const float v = p.src_ptr[0][off];  // unconditional load, masked by a select
+                r_nchw[it] = ok ? v : 0.f;
             }
         } else {
             const float *sp = p.src_ptr[s] + c0;
             const size_t ld = p.src_ld[s];
 #pragma unroll
-            for (int it = 0; it < C::ITEMS_IN; ++it) {
-                r_in[it] = g_pix[it] >= 0 ? *reinterpret_cast<const float4 *>(sp + (size_t)g_pix[it] * ld + g_c4[it])
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int it = 0; it < C::ITEMS_IN; ++it)
+                r_in[it] = *reinterpret_cast<const float4 *>(sp + (size_t)g_pix[it] * ld + g_c4[it]);
         }
+        const float *wp = w_cls + (size_t)wrow * p.cout;
 #pragma unroll
-        for (int it = 0; it < C::ITEMS_W; ++it) {
-            const int item = tid + it * C::THREADS;
-            const int row = item / (C::BN / 4), q = item % (C::BN / 4);
-            const int tap = row / C::CK, c = row % C::CK;
-            const bool ok = item < C::TAPS * C::CK * (C::BN / 4) && (co0 + q * 4) < p.cout;
-            r_w[it] = ok ? *reinterpret_cast<const float4 *>(
-                               p.w + ((size_t)(cls * C::TAPS + tap) * p.cin_pad + wrow + c) * p.cout + co0 + q * 4)
-                         : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int it = 0; it < C::ITEMS_W; ++it) r_w[it] = *reinterpret_cast<const float4 *>(wp + w_off[it]);
     };
     auto store_chunk = [&]() {
         if constexpr (C::NCHW) {
@@ -186,15 +198,21 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_mfma_kernel(const ConvKPar
 #pragma unroll
             for (int it = 0; it < C::ITEMS_IN; ++it) {
                 if (l_off[it] >= 0) {
+                    const bool ok = (ok_mask >> it) & 1u;
                     float *d = lds_in + l_off[it];
-                    d[0] = r_in[it].x, d[1] = r_in[it].y, d[2] = r_in[it].z, d[3] = r_in[it].w;
+                    d[0] = ok ? r_in[it].x : 0.f, d[1] = ok ? r_in[it].y : 0.f, d[2] = ok ? r_in[it].z : 0.f,
+                    d[3] = ok ? r_in[it].w : 0.f;
                 }
             }
         }
 #pragma unroll
         for (int it = 0; it < C::ITEMS_W; ++it) {
             const int item = tid + it * C::THREADS;
-            if (item < C::TAPS * C::CK * (C::BN / 4)) *reinterpret_cast<float4 *>(lds_w + item * 4) = r_w[it];
+            if (item < C::TAPS * C::CK * (C::BN / 4)) {
+                const bool ok = (w_mask >> it) & 1u;
+                *reinterpret_cast<float4 *>(lds_w + item * 4) =
+                    ok ? r_w[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
 

@@ -87,42 +87,81 @@ __global__ void __launch_bounds__(256, 2) wgrad_mfma_kernel(const WgradParams p)
         const int n0 = tn_i * C::TN, y0 = ty_i * C::TH, x0 = tx_i * C::TW;
         const int iy0 = y0 * C::STRIDE - pad_y, ix0 = x0 * C::STRIDE - pad_x;
         __syncthreads();  // previous tile fully consumed
-        // ---- x halo tile: channels ci0..ci0+31 of (virtually concatenated) sources
+        // ---- x halo tile: channels ci0..ci0+31 of (virtually concatenated) sources.
+        // All loads of a batch are issued unconditionally (masked items read a valid dummy address) before the first
+        // LDS store, so the batch costs one memory latency instead of one per item.
         if constexpr (C::NCHW) {
-            for (int item = tid; item < C::PIX * 32; item += 256) {
-                const int c = item / C::PIX, pix = item % C::PIX;
-                const int lx = pix % C::IW, ly = (pix / C::IW) % C::IH, tn = pix / (C::IW * C::IH);
-                const int n = n0 + tn, iy = iy0 + ly, ix = ix0 + lx, ch = ci0 + c;
-                const bool ok = ch < p.cin && n < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                xs[pix * C::CP + c] = ok ? p.src_ptr[0][((size_t)(n * p.cin + ch) * p.H + iy) * p.W + ix] : 0.f;
+            constexpr int ITS = (C::PIX * 32 + 255) / 256;
+            constexpr int BATCH = 16;
+            for (int it0 = 0; it0 < ITS; it0 += BATCH) {
+                float r[BATCH];
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) {
+                    const int item = tid + (it0 + k) * 256;
+                    const int c = item / C::PIX, pix = item % C::PIX;
+                    const int lx = pix % C::IW, ly = (pix / C::IW) % C::IH, tn = pix / (C::IW * C::IH);
+                    const int n = n0 + tn, iy = iy0 + ly, ix = ix0 + lx, ch = ci0 + c;
+                    const bool ok = item < C::PIX * 32 && ch < p.cin && n < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                    const size_t off = ok ? ((size_t)(n * p.cin + ch) * p.H + iy) * p.W + ix : 0;
+                    const float v = p.src_ptr[0][off];
+                    r[k] = ok ? v : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) {
+                    const int item = tid + (it0 + k) * 256;
+                    if (item < C::PIX * 32) xs[(item % C::PIX) * C::CP + item / C::PIX] = r[k];
+                }
             }
         } else {
-            for (int item = tid; item < C::PIX * 8; item += 256) {
+            constexpr int ITS = (C::PIX * 8 + 255) / 256;
+            float4 r[ITS];
+#pragma unroll
+            for (int k = 0; k < ITS; ++k) {
+                const int item = tid + k * 256;
                 const int pix = item >> 3, c4 = (item & 7) * 4;
                 const int lx = pix % C::IW, ly = (pix / C::IW) % C::IH, tn = pix / (C::IW * C::IH);
                 const int n = n0 + tn, iy = iy0 + ly, ix = ix0 + lx;
                 int ch = ci0 + c4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ch < p.cin && n < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-                    int s = 0;
-                    while (s < p.nsrc - 1 && ch >= p.src_c[s]) ch -= p.src_c[s], ++s;
-                    v = *reinterpret_cast<const float4 *>(p.src_ptr[s] + ((size_t)(n * p.H + iy) * p.W + ix) * p.src_ld[s] + ch);
+                const bool ok = item < C::PIX * 8 && ch < p.cin && n < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                int s = 0;
+                while (s < p.nsrc - 1 && ch >= p.src_c[s]) ch -= p.src_c[s], ++s;
+                const size_t off = ok ? ((size_t)(n * p.H + iy) * p.W + ix) * p.src_ld[s] + ch : 0;
+                const float4 v = *reinterpret_cast<const float4 *>(p.src_ptr[ok ? s : 0] + off);
+                r[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < ITS; ++k) {
+                const int item = tid + k * 256;
+                if (item < C::PIX * 8) {
+                    float *d = xs + (item >> 3) * C::CP + (item & 7) * 4;
+                    d[0] = r[k].x, d[1] = r[k].y, d[2] = r[k].z, d[3] = r[k].w;
                 }
-                float *d = xs + pix * C::CP + c4;
-                d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
             }
         }
         // ---- dy tile: channels co0..co0+31 at the tile's output pixels
-        for (int item = tid; item < C::BM * 8; item += 256) {
-            const int m = item >> 3, c4 = (item & 7) * 4;
-            const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
-            const int n = n0 + tn, y = y0 + ty, x = x0 + tx;
-            const int oy = C::SUBPIX ? 2 * y + py : y, ox = C::SUBPIX ? 2 * x + px : x;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (co0 + c4 < p.cout && n < p.N && y < p.LH && x < p.LW && oy < p.OH && ox < p.OW)
-                v = *reinterpret_cast<const float4 *>(p.gout + ((size_t)(n * p.OH + oy) * p.OW + ox) * p.gout_ld + co0 + c4);
-            float *d = gs + m * C::CP + c4;
-            d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+        {
+            constexpr int ITG = (C::BM * 8 + 255) / 256;
+            float4 r[ITG];
+#pragma unroll
+            for (int k = 0; k < ITG; ++k) {
+                const int item = tid + k * 256;
+                const int m = item >> 3, c4 = (item & 7) * 4;
+                const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
+                const int n = n0 + tn, y = y0 + ty, x = x0 + tx;
+                const int oy = C::SUBPIX ? 2 * y + py : y, ox = C::SUBPIX ? 2 * x + px : x;
+                const bool ok = item < C::BM * 8 && co0 + c4 < p.cout && n < p.N && y < p.LH && x < p.LW && oy < p.OH && ox < p.OW;
+                const size_t off = ok ? ((size_t)(n * p.OH + oy) * p.OW + ox) * p.gout_ld + co0 + c4 : 0;
+                const float4 v = *reinterpret_cast<const float4 *>(p.gout + off);
+                r[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < ITG; ++k) {
+                const int item = tid + k * 256;
+                if (item < C::BM * 8) {
+                    float *d = gs + (item >> 3) * C::CP + (item & 7) * 4;
+                    d[0] = r[k].x, d[1] = r[k].y, d[2] = r[k].z, d[3] = r[k].w;
+                }
+            }
         }
         __syncthreads();
         // ---- this wave's QP pixels: K steps of 2 pixels
@@ -291,8 +330,9 @@ int conv2d_bwd_weight_impl(const pws_conv_bwd_weight_args *a, hipStream_t st) {
 
 // ------------------------------------------------------------------------------------------------ act' and bias grad
 // dy <- dy * act'(y) in place; dbias[c] += sum over pixels.  HBM-bound (12 B per element).
-// A workgroup owns ABB_PIX consecutive pixels; lane t owns channel quad (t % c4n) for every (256 / c4n)-th pixel, so the
-// per-channel sums stay in registers; one LDS pass folds the pixel groups, then one global atomic per channel.
+// Lane t owns channel quad (t % c4n) of every (256 / c4n)-th pixel of the workgroup's (grid-strided) pixels, so the
+// per-channel sums stay in registers; one LDS pass folds the pixel groups, then one global atomic per channel and
+// workgroup (at most 512 workgroups: all of them hit the same c words).
 constexpr int ABB_PIX = 256;
 
 __global__ void __launch_bounds__(256) act_bwd_bias_kernel(float *__restrict__ dy, const float *__restrict__ y, size_t pixels,
@@ -302,14 +342,13 @@ __global__ void __launch_bounds__(256) act_bwd_bias_kernel(float *__restrict__ d
     const int c4n = c / 4;
     const int span = c4n < 256 ? c4n : 256;  // channel quads handled per pass
     const int groups = 256 / span;           // pixel groups (lanes beyond groups*span idle when span does not divide 256)
-    const size_t p0 = (size_t)blockIdx.x * ABB_PIX;
-    const size_t pend = p0 + ABB_PIX < pixels ? p0 + ABB_PIX : pixels;
+    // grid-stride over pixel chunks: few workgroups => few (contended) global atomics on the c bias-gradient words
     for (int q0 = 0; q0 < c4n; q0 += 256) {  // one pass unless c > 1024
         const int q = q0 + tid % span;
         const int grp = tid / span;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q < c4n && grp < groups) {
-            for (size_t p = p0 + grp; p < pend; p += groups) {
+            for (size_t p = (size_t)blockIdx.x * groups + grp; p < pixels; p += (size_t)gridDim.x * groups) {
                 const size_t e = p * c4n + q;
                 float4 g = reinterpret_cast<float4 *>(dy)[e];
                 const float4 v = reinterpret_cast<const float4 *>(y)[e];
@@ -354,7 +393,9 @@ extern "C" int pws_act_bwd_bias(float *dy, const float *y, size_t pixels, int c,
                 "pws_act_bwd_bias: NULL or unaligned pointer");
     if (act == PWS_ACT_NONE && !dbias) return PWS_OK;
     pws::ProfScope prof(pws::KID_ACT_BWD, 2.0 * pixels * c, 12.0 * pixels * c, pws::as_stream(stream));
-    hipLaunchKernelGGL(pws::act_bwd_bias_kernel, dim3((unsigned)((pixels + pws::ABB_PIX - 1) / pws::ABB_PIX)), dim3(256),
-                       sizeof(float) * 256 * 4, pws::as_stream(stream), dy, y, pixels, c, act, dbias);
+    size_t blocks = (pixels + pws::ABB_PIX - 1) / pws::ABB_PIX;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(pws::act_bwd_bias_kernel, dim3((unsigned)blocks), dim3(256), sizeof(float) * 256 * 4,
+                       pws::as_stream(stream), dy, y, pixels, c, act, dbias);
     return pws::check_launch("act_bwd_bias_kernel");
 }
