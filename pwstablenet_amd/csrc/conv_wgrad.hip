@@ -348,18 +348,34 @@ __global__ void __launch_bounds__(256) act_bwd_bias_kernel(float *__restrict__ d
         const int grp = tid / span;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q < c4n && grp < groups) {
-            for (size_t p = (size_t)blockIdx.x * groups + grp; p < pixels; p += (size_t)gridDim.x * groups) {
-                const size_t e = p * c4n + q;
-                float4 g = reinterpret_cast<float4 *>(dy)[e];
-                const float4 v = reinterpret_cast<const float4 *>(y)[e];
-                if (act == PWS_ACT_LRELU) {
-                    g.x *= v.x > 0.f ? 1.f : 0.2f, g.y *= v.y > 0.f ? 1.f : 0.2f, g.z *= v.z > 0.f ? 1.f : 0.2f,
-                        g.w *= v.w > 0.f ? 1.f : 0.2f;
-                } else if (act == PWS_ACT_RELU) {
-                    g.x = v.x > 0.f ? g.x : 0.f, g.y = v.y > 0.f ? g.y : 0.f, g.z = v.z > 0.f ? g.z : 0.f, g.w = v.w > 0.f ? g.w : 0.f;
+            // 4 independent pixel strides in flight per lane (a single dependent load pair per lane is latency-bound)
+            const size_t step = (size_t)gridDim.x * groups;
+            for (size_t pb = (size_t)blockIdx.x * groups + grp; pb < pixels; pb += 4 * step) {
+                float4 g[4], v[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const size_t p = pb + u * step;
+                    ok[u] = p < pixels;
+                    const size_t e = (ok[u] ? p : pb) * c4n + q;
+                    g[u] = reinterpret_cast<float4 *>(dy)[e];
+                    v[u] = reinterpret_cast<const float4 *>(y)[e];
                 }
-                if (act != PWS_ACT_NONE) reinterpret_cast<float4 *>(dy)[e] = g;
-                s.x += g.x, s.y += g.y, s.z += g.z, s.w += g.w;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (!ok[u]) continue;
+                    float4 gg = g[u];
+                    const float4 vv = v[u];
+                    if (act == PWS_ACT_LRELU) {
+                        gg.x *= vv.x > 0.f ? 1.f : 0.2f, gg.y *= vv.y > 0.f ? 1.f : 0.2f, gg.z *= vv.z > 0.f ? 1.f : 0.2f,
+                            gg.w *= vv.w > 0.f ? 1.f : 0.2f;
+                    } else if (act == PWS_ACT_RELU) {
+                        gg.x = vv.x > 0.f ? gg.x : 0.f, gg.y = vv.y > 0.f ? gg.y : 0.f, gg.z = vv.z > 0.f ? gg.z : 0.f,
+                        gg.w = vv.w > 0.f ? gg.w : 0.f;
+                    }
+                    if (act != PWS_ACT_NONE) reinterpret_cast<float4 *>(dy)[(pb + u * step) * c4n + q] = gg;
+                    s.x += gg.x, s.y += gg.y, s.z += gg.z, s.w += gg.w;
+                }
             }
         }
         if (dbias) {
@@ -394,7 +410,7 @@ extern "C" int pws_act_bwd_bias(float *dy, const float *y, size_t pixels, int c,
     if (act == PWS_ACT_NONE && !dbias) return PWS_OK;
     pws::ProfScope prof(pws::KID_ACT_BWD, 2.0 * pixels * c, 12.0 * pixels * c, pws::as_stream(stream));
     size_t blocks = (pixels + pws::ABB_PIX - 1) / pws::ABB_PIX;
-    if (blocks > 512) blocks = 512;
+    if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(pws::act_bwd_bias_kernel, dim3((unsigned)blocks), dim3(256), sizeof(float) * 256 * 4,
                        pws::as_stream(stream), dy, y, pixels, c, act, dbias);
     return pws::check_launch("act_bwd_bias_kernel");
