@@ -211,6 +211,36 @@ def main():
                                         "traffic": None, "avg_launch_us": round(1e3 * ms, 2),
                                         "bytes_per_launch": r[0][3], "frames_per_launch": GB}
         del big, grid
+        # 720p leg of the metric (configs[4] shape, one GPU's share): netG on 256x256 windows + fused field-resize+warp of
+        # 1280x720 RGB frames (reference main_new.py:697-716), frames resident in HBM (PCIe-inclusive rate: DESIGN.md)
+        f720 = torch.rand((B, 3, 720, 1280), device=dev) * 255
+        with torch.no_grad():
+            def step720():
+                return PF.upsample_grid_sample(f720, net(x, False))
+            for _ in range(2):
+                step720()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                o720 = step720()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            A.lib().pws_prof_enable(1)
+            for _ in range(5):
+                step720()
+            A.lib().pws_prof_enable(0)
+        r = [x_ for x_ in A.prof_collect() if x_[0] == "upsample_grid_sample_fwd_kernel"]
+        ms = sorted(x_[4] for x_ in r)[len(r) // 2]
+        gbs = r[0][3] / (ms * 1e-3) / 1e9
+        assert torch.isfinite(o720).all()
+        line["value_720p"] = {"value": round(B * a.steps / dt, 2), "unit": "frames/s", "n_gpus": 1,
+                              "workload": "batch=%d: netG(31x256x256 window, fp32) + fused upsample(256^2 field)+grid_sample of "
+                                          "3x720x1280 fp32 frames" % B,
+                              "roofline_warp": {"kernel": "upsample_grid_sample_fwd_kernel", "bound": "hbm",
+                                                "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                                "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_us": round(1e3 * ms, 2),
+                                                "bytes_per_launch": r[0][3]}}
+        del f720
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(B)
             line["gpu_over_cpu"] = round(fps / line["cpu_baseline"]["value"], 1)

@@ -92,7 +92,7 @@ typedef struct pws_conv_args {
     float *out;       /* NHWC, output height/width implied by kind */
     int out_ld;       /* pixel stride of out in floats (>= cout) */
     void *ws;         /* optional scratch for split-K partial tiles (16-B aligned) or NULL: small-spatial layers */
-    size_t ws_bytes;  /* then run un-split.  Any size works; 32 x n*oh*ow*cout*4 bytes never limits the split. */
+    size_t ws_bytes;  /* then run un-split.  Any size works; 64 x n*oh*ow*cout*4 bytes never limits the split. */
 } pws_conv_args;
 
 int pws_conv2d_fwd(const pws_conv_args *args, pws_stream_t stream);

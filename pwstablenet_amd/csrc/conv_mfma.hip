@@ -411,7 +411,7 @@ constexpr long kFillBlocks = 512;  // 256 CUs x 2 resident workgroups
 // Pick the tile and the K split for one launch.
 //  1. drop tiles that are mostly padding for this extent (a 16x16 tile on an 8x8 map);
 //  2. take the largest remaining tile whose grid has >= kFillBlocks workgroups, else the one with the most workgroups;
-//  3. if the grid is still < kFillBlocks and a workspace was given, split K (>= 2 chunks per split, <= 32 splits).
+//  3. if the grid is still < kFillBlocks and a workspace was given, split K (>= 2 chunks per split, <= 64 splits).
 static int select_and_launch(const TileChoice *cands, int ncand, ConvKParams &kp, int cin_total, float *final_out,
                              float *ws, size_t ws_floats, hipStream_t st, const ProfInfo &pi) {
     const TileChoice *best = nullptr;
@@ -439,7 +439,7 @@ static int select_and_launch(const TileChoice *cands, int ncand, ConvKParams &kp
     const size_t out_floats = (size_t)kp.N * kp.OH * kp.OW * kp.cout;
     if (best_blocks < kFillBlocks && ws && kp.cout % 4 == 0 && total_chunks >= 4) {
         long want = cdiv(kFillBlocks, best_blocks);
-        if (want > 32) want = 32;
+        if (want > 64) want = 64;
         if (want > total_chunks / 2) want = total_chunks / 2;
         while (want > 1 && (size_t)want * out_floats > ws_floats) --want;
         ksplit = (int)want;

@@ -34,10 +34,18 @@ __global__ void __launch_bounds__(64) theta_hidden_kernel(const float *__restric
 #pragma unroll
         for (int s = 0; s < TH_NB; ++s) acc[s] = 0.f;
         if (j < hidden) {
-            for (int k = 0; k < kn; ++k) {
-                const float w = w_flat[(size_t)(k0 + k) * hidden + j];
+            // 8 independent weight loads in flight per lane (one dependent load per k would be latency-bound)
+            for (int kb = 0; kb < kn; kb += 8) {
+                float wv[8];
 #pragma unroll
-                for (int s = 0; s < TH_NB; ++s) acc[s] = fmaf(s < nb ? sx[s * kchunk + k] : 0.f, w, acc[s]);
+                for (int u = 0; u < 8; ++u) wv[u] = w_flat[(size_t)(k0 + (kb + u < kn ? kb + u : kb)) * hidden + j];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (kb + u < kn) {
+#pragma unroll
+                        for (int s = 0; s < TH_NB; ++s) acc[s] = fmaf(s < nb ? sx[s * kchunk + kb + u] : 0.f, wv[u], acc[s]);
+                    }
+                }
             }
 #pragma unroll
             for (int s = 0; s < TH_NB; ++s)
