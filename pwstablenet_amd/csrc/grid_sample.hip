@@ -228,7 +228,9 @@ __global__ void upsample_bilinear_ac_kernel(const float *__restrict__ in, float 
 
 // ---------------------------------------------------------------------------------------------- fused 720p path
 // field [n,fh,fw,2] --(bilinear, align_corners=True, never materialised)--> per-pixel (gx,gy) --> 4-tap gather.
-template <int PPT>
+// NARROW: the PPT pixels of a lane span less than one field cell ((PPT-1)*rx < 1, e.g. 256 -> 1280 columns), so the lane
+// fetches the 3 field columns (x 2 rows) it can touch once instead of 4 loads per pixel.
+template <int PPT, bool NARROW>
 __global__ void __launch_bounds__(256) upsample_grid_sample_fwd_kernel(const float *__restrict__ input,
                                                                        const float *__restrict__ field,
                                                                        float *__restrict__ out, int C, int H, int W, int fh,
@@ -248,15 +250,37 @@ __global__ void __launch_bounds__(256) upsample_grid_sample_fwd_kernel(const flo
     const float2 *f0 = reinterpret_cast<const float2 *>(field) + ((size_t)n * fh + y0) * fw;
     const float2 *f1 = reinterpret_cast<const float2 *>(field) + ((size_t)n * fh + y1) * fw;
     Taps2 t[PPT];
+    if constexpr (NARROW) {
+        const int cb = (int)(rx * ox0);  // first column this lane can touch; it needs cb .. cb+2 at most
+        float2 r0[3], r1[3];
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-        const float sx = rx * (ox0 + i);
-        const int x0 = (int)sx, x1 = x0 + (x0 < fw - 1 ? 1 : 0);
-        const float lx = sx - x0, hx = 1.f - lx;
-        const float2 a = f0[x0], b = f0[x1], c = f1[x0], d = f1[x1];
-        const float gx = hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * d.x);
-        const float gy = hy * (hx * a.y + lx * b.y) + ly * (hx * c.y + lx * d.y);
-        t[i] = make_taps2(gx, gy, H, W, ac != 0);
+        for (int k = 0; k < 3; ++k) {
+            const int col = min(cb + k, fw - 1);
+            r0[k] = f0[col], r1[k] = f1[col];
+        }
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const float sx = rx * (ox0 + i);
+            const int x0 = (int)sx;
+            const float lx = sx - x0, hx = 1.f - lx;
+            const bool second = x0 > cb;  // x0 - cb is 0 or 1; x1 = min(x0 + 1, fw - 1) is column x0 - cb + 1 (clamped loads)
+            const float2 a = second ? r0[1] : r0[0], b = second ? r0[2] : r0[1];
+            const float2 c = second ? r1[1] : r1[0], d = second ? r1[2] : r1[1];
+            const float gx = hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * d.x);
+            const float gy = hy * (hx * a.y + lx * b.y) + ly * (hx * c.y + lx * d.y);
+            t[i] = make_taps2(gx, gy, H, W, ac != 0);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const float sx = rx * (ox0 + i);
+            const int x0 = (int)sx, x1 = x0 + (x0 < fw - 1 ? 1 : 0);
+            const float lx = sx - x0, hx = 1.f - lx;
+            const float2 a = f0[x0], b = f0[x1], c = f1[x0], d = f1[x1];
+            const float gx = hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * d.x);
+            const float gy = hy * (hx * a.y + lx * b.y) + ly * (hx * c.y + lx * d.y);
+            t[i] = make_taps2(gx, gy, H, W, ac != 0);
+        }
     }
     for (int c = 0; c < C; ++c) {
         const float *ip = input + ((size_t)n * C + c) * HW;
@@ -378,12 +402,16 @@ extern "C" int pws_upsample_grid_sample_fwd(const float *input, const float *fie
     if (w % 4 == 0 && aligned16(out)) {
         const size_t groups = total / 4;
         const unsigned nb = (unsigned)((groups + 255) / 256);
-        hipLaunchKernelGGL(upsample_grid_sample_fwd_kernel<4>, dim3(nb), dim3(256), 0, as_stream(stream), input, field, out, c,
-                           h, w, fh, fw, ry, rx, groups, nb, align_corners);
+        if (3.f * rx < 0.999f)
+            hipLaunchKernelGGL((upsample_grid_sample_fwd_kernel<4, true>), dim3(nb), dim3(256), 0, as_stream(stream), input, field,
+                               out, c, h, w, fh, fw, ry, rx, groups, nb, align_corners);
+        else
+            hipLaunchKernelGGL((upsample_grid_sample_fwd_kernel<4, false>), dim3(nb), dim3(256), 0, as_stream(stream), input, field,
+                               out, c, h, w, fh, fw, ry, rx, groups, nb, align_corners);
     } else {
         const unsigned nb = (unsigned)((total + 255) / 256);
-        hipLaunchKernelGGL(upsample_grid_sample_fwd_kernel<1>, dim3(nb), dim3(256), 0, as_stream(stream), input, field, out, c,
-                           h, w, fh, fw, ry, rx, total, nb, align_corners);
+        hipLaunchKernelGGL((upsample_grid_sample_fwd_kernel<1, false>), dim3(nb), dim3(256), 0, as_stream(stream), input, field,
+                           out, c, h, w, fh, fw, ry, rx, total, nb, align_corners);
     }
     return check_launch("upsample_grid_sample_fwd_kernel");
 }

@@ -1,0 +1,105 @@
+"""Streaming video stabilisation: the device-side counterpart of the reference's ``process()`` loop
+(reference main_new.py:612-741) minus its OpenCV I/O (decode, BGR->gray, INTER_AREA resize, MJPG encode stay with the
+caller -- cv2 is not part of the accelerated path).
+
+Per frame i the reference builds a 31-frame window of 256x256 gray frames [i-15, i+15] (the first / last frame
+repeated at the ends, main_new.py:627-633,653-660), runs ``netG(window, False)``, resizes the 256x256 field to the frame
+size (UpsamplingBilinear2d) and warps the full-resolution RGB frame (grid_sample), one frame at a time with a
+host<->device round trip per frame.  Here:
+  * frames are processed in batches of ``batch`` windows per generator call (the windows are overlapping views of one
+    gray-frame buffer, gathered on the device);
+  * field resize + warp is the fused HIP kernel (the resized field is never materialised);
+  * when the inputs live in (pinned) host memory, batch k+1 is copied H2D on a side stream while batch k computes,
+    and results go D2H on a third stream (hipMemcpyAsync through torch, one event per hand-off);
+  * several GPUs take contiguous frame chunks with a 15-frame halo each (``distributed.shard_frames``): no collective.
+"""
+import torch
+
+from . import functional as PF
+
+
+def _windows(gray_padded, start, count, period):
+    """(count, period+1, 256, 256) windows: window b covers padded frames [start+b, start+b+period]."""
+    h, w = gray_padded.shape[-2:]
+    view = torch.as_strided(gray_padded, (count, period + 1, h, w), (h * w, h * w, w, 1),
+                            storage_offset=gray_padded.storage_offset() + start * h * w)
+    return view.contiguous()
+
+
+class VideoStabilizer:
+    def __init__(self, netG, batch=8, period=30, device=None):
+        self.net = netG
+        self.batch = int(batch)
+        self.period = int(period)
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+    def _pad(self, gray, halo_left, halo_right):
+        """Replicates the first / last available frame so that every frame owns a full window (reference :627-633)."""
+        half = self.period // 2
+        need_l, need_r = half - halo_left, half - halo_right
+        parts = []
+        if need_l > 0:
+            parts.append(gray[:1].expand(need_l, -1, -1))
+        parts.append(gray)
+        if need_r > 0:
+            parts.append(gray[-1:].expand(need_r, -1, -1))
+        return torch.cat(parts, 0) if len(parts) > 1 else gray
+
+    @torch.no_grad()
+    def run(self, gray, frames, halo_left=0, halo_right=0, out=None):
+        """gray: (T + halo_left + halo_right, 256, 256) float32 in [-1,1] (``x/255*2-1`` as the reference, :650) for the T
+        frames to stabilise plus whatever real neighbours exist on either side (up to period//2); frames: (T, C, H, W)
+        float32 0..255.  Tensors may be on the device or in (pinned) host memory.  Returns (T, C, H, W) on the inputs' side."""
+        half = self.period // 2
+        if not (0 <= halo_left <= half and 0 <= halo_right <= half):
+            raise ValueError("halo must be within [0, %d]" % half)
+        T = frames.shape[0]
+        if gray.shape[0] != T + halo_left + halo_right:
+            raise ValueError("gray has %d frames, expected %d + %d + %d" % (gray.shape[0], T, halo_left, halo_right))
+        on_host = not frames.is_cuda
+        dev = self.device
+        gray_d = gray.to(dev, non_blocking=True) if not gray.is_cuda else gray  # 256 KB per frame: copied once
+        gp = self._pad(gray_d.contiguous(), halo_left, halo_right).contiguous()
+        if out is None:
+            out = torch.empty_like(frames, pin_memory=on_host) if on_host else torch.empty_like(frames)
+        if T == 0:
+            return out
+        compute = torch.cuda.current_stream(dev)
+        h2d, d2h = (torch.cuda.Stream(dev), torch.cuda.Stream(dev)) if on_host else (None, None)
+
+        def fetch(s):
+            e = min(T, s + self.batch)
+            if not on_host:
+                return frames[s:e], None
+            with torch.cuda.stream(h2d):
+                buf = frames[s:e].to(dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(h2d)
+            return buf, ev
+
+        nxt = fetch(0)
+        pending = []
+        for s in range(0, T, self.batch):
+            e = min(T, s + self.batch)
+            cur, ev = nxt
+            if e < T:
+                nxt = fetch(e)  # overlaps with this batch's compute
+            if ev is not None:
+                compute.wait_event(ev)
+            win = _windows(gp, s, e - s, self.period)
+            field = self.net(win, False)
+            warped = PF.upsample_grid_sample(cur.contiguous(), field)
+            if on_host:
+                done = torch.cuda.Event()
+                done.record(compute)
+                with torch.cuda.stream(d2h):
+                    d2h.wait_event(done)
+                    out[s:e].copy_(warped, non_blocking=True)
+                warped.record_stream(d2h)
+                cur.record_stream(compute)
+                pending.append(warped)
+            else:
+                out[s:e].copy_(warped)
+        if on_host:
+            d2h.synchronize()
+        return out
