@@ -96,11 +96,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ctl_device = None  # device of the control-plane tensors (timing barrier / MAX-reduce); the data path has no collective
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+            ctl_device = torch.device("cuda", local_rank)
+        except Exception as e:  # control plane only: fall back to gloo rather than lose the measurement
+            print("rank %d: nccl init failed (%s); using gloo for the timing barrier" % (rank, e), file=sys.stderr)
+            dist.init_process_group("gloo")
+            ctl_device = torch.device("cpu")
     else:
         torch.cuda.set_device(0)
     if world != a.gpus and rank == 0:
@@ -153,10 +160,10 @@ def main():
         torch.cuda.synchronize()
         A.lib().pws_prof_enable(0)
         recs = A.prof_collect(1 << 16)
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
+        t = torch.tensor([elapsed], device=ctl_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        elapsed = float(t.item())
     assert torch.isfinite(out).all()
 
     if rank == 0:

@@ -13,7 +13,8 @@
 // Backward replays the forward's allocation sequence (no launches) to recover every activation's address in the
 // arena, then walks the recorded ops in reverse: per layer act'/bias-grad, weight grad, data grad into the gradient
 // buffers of the layer's sources (first consumer overwrites, later consumers accumulate -- no zero-fill pass).
-// No allocation, no synchronisation: every launch goes to `stream`.
+// No allocation, no synchronisation: every launch is ordered after the caller's `stream`; the forward forks an internal
+// second queue by events (stage k+1's encoder beside stage k's decoder) and joins it back before returning.
 #include <unordered_map>
 #include <vector>
 
@@ -94,11 +95,57 @@ struct Op {
     Tn in, out;
 };
 
+// Second in-order queue for the branch of the forward that does not depend on the current one (stage k+1's encoder
+// runs beside stage k's decoder), plus the events that fork / join it.  Created lazily once per process (the only
+// runtime objects this library owns); ordering against the caller's stream is by events only, never by a sync.
+struct SideStream {
+    hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> events;
+    size_t next = 0;
+    bool ok = false;
+    bool init() {
+        if (!stream) ok = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess;
+        return ok;
+    }
+    hipEvent_t event() {
+        if (next == events.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+            events.push_back(e);
+        }
+        return events[next++];
+    }
+};
+static thread_local SideStream g_side;
+
 class Exec {
   public:
     Exec(const float *packed, const std::vector<Layer> &layers, int n, char *ws, size_t ws_bytes, hipStream_t st, bool dry,
          bool launch)
-        : packed_(packed), L_(layers), n_(n), ws_(ws), cap_(ws_bytes), st_(st), dry_(dry), launch_(launch && !dry) {}
+        : packed_(packed), L_(layers), n_(n), ws_(ws), cap_(ws_bytes), st_(st), dry_(dry), launch_(launch && !dry) {
+        streams_[0] = st, streams_[1] = st;
+        if (launch_ && g_side.init()) streams_[1] = g_side.stream, g_side.next = 0;
+    }
+
+    // ---- two-queue scheduling: ops go to queue `q`; fork/join are event record + wait (capturable, no host sync)
+    void use(int q) { q_ = q; }
+    bool two_queues() const { return streams_[1] != streams_[0]; }
+    // mark(): "everything issued so far on queue `from`"; wait(): later work on queue `to` starts after that point
+    hipEvent_t mark(int from) {
+        if (!launch_ || !two_queues()) return nullptr;
+        hipEvent_t e = g_side.event();
+        if (!e || hipEventRecord(e, streams_[from]) != hipSuccess) {
+            if (rc_ == PWS_OK) set_error("pws_netg_forward: hipEventRecord failed"), rc_ = PWS_EHIP;
+            return nullptr;
+        }
+        return e;
+    }
+    void wait(int to, hipEvent_t e) {
+        if (!e) return;
+        if (hipStreamWaitEvent(streams_[to], e, 0) != hipSuccess && rc_ == PWS_OK)
+            set_error("pws_netg_forward: hipStreamWaitEvent failed"), rc_ = PWS_EHIP;
+    }
+    void order(int from, int to) { wait(to, mark(from)); }
 
     size_t used() const { return off_; }
     int rc() const { return rc_; }
@@ -148,9 +195,9 @@ class Exec {
         }
         a.cout = l.cout, a.w_packed = packed_ + l.w_off, a.bias = packed_ + l.b_off, a.act = act;
         a.out = o.seg[0].ptr, a.out_ld = l.cout;
-        a.ws = splitk_ws_, a.ws_bytes = splitk_bytes_;
+        a.ws = q_ ? splitk_ws2_ : splitk_ws_, a.ws_bytes = splitk_bytes_;
         g_prof_tag = layer;
-        rc_ = pws_conv2d_fwd(&a, st_);
+        rc_ = pws_conv2d_fwd(&a, streams_[q_]);
         g_prof_tag = -1;
         return o;
     }
@@ -179,7 +226,8 @@ class Exec {
         if (!launch_ || rc_ != PWS_OK) return;
         const Layer &f = L_[L_FLATTEN], &l = L_[L_LINEAR];
         rc_ = pws_theta_head_fwd_save(x_s8.seg[0].ptr, n_, x_s8.seg[0].c, f.cout, packed_ + f.w_off, packed_ + f.b_off,
-                                      packed_ + l.w_off, packed_ + l.b_off, theta_ws_, theta_out, h_saved_[stage], st_);
+                                      packed_ + l.w_off, packed_ + l.b_off, q_ ? theta_ws2_ : theta_ws_, theta_out,
+                                      h_saved_[stage], streams_[q_]);
     }
     // tanh(out(x)).permute(0,2,3,1) [+ affine_grid(theta)] (reference :174,235-237)
     void field(const Tn &x, int stage, const float *theta_k, int ac, float *resid, float *grid) {
@@ -187,7 +235,7 @@ class Exec {
         if (!launch_ || rc_ != PWS_OK) return;
         const Layer &o = L_[L_OUT];
         rc_ = pws_field_head_fwd(x.seg[0].ptr, x.seg[0].ld, n_, x.h, x.w, x.seg[0].c, packed_ + o.w_off, packed_ + o.b_off,
-                                 theta_k, ac, resid, grid, st_);
+                                 theta_k, ac, resid, grid, streams_[q_]);
     }
 
     // scratch shared by all layers (launches are stream-ordered): split-K partial tiles, the theta head's partials,
@@ -195,13 +243,18 @@ class Exec {
     void reserve_scratch(int ngf, bool training) {
         splitk_bytes_ = (size_t)(n_ > 8 ? n_ : 8) * (2u << 20);
         splitk_ws_ = alloc(splitk_bytes_ / sizeof(float));
+        splitk_ws2_ = alloc(splitk_bytes_ / sizeof(float));  // one scratch per queue: the two run concurrently
         theta_ws_ = alloc(pws_theta_head_ws_floats(n_, 4 * ngf, 8 * ngf));
-        if (!splitk_ws_) splitk_bytes_ = 0;
+        theta_ws2_ = alloc(pws_theta_head_ws_floats(n_, 4 * ngf, 8 * ngf));
+        if (!splitk_ws_ || !splitk_ws2_) splitk_bytes_ = 0;
         for (int s = 0; s < 3; ++s) h_saved_[s] = training ? alloc((size_t)n_ * 8 * ngf) : nullptr;
     }
 
   private:
-    float *splitk_ws_ = nullptr, *theta_ws_ = nullptr, *h_saved_[3] = {nullptr, nullptr, nullptr};
+    float *splitk_ws_ = nullptr, *splitk_ws2_ = nullptr, *theta_ws_ = nullptr, *theta_ws2_ = nullptr;
+    float *h_saved_[3] = {nullptr, nullptr, nullptr};
+    hipStream_t streams_[2];
+    int q_ = 0;
     size_t splitk_bytes_ = 0;
     const float *packed_;
     const std::vector<Layer> &L_;
@@ -225,22 +278,45 @@ static void forward_graph(Exec &E, const float *x, int n, int input_nc, int g, i
 
     Tn in{};
     in.nseg = 1, in.h = S, in.w = S, in.seg[0] = Seg{nullptr, input_nc, 0};
-    // ---- stage 1 (reference :153-174)
+    // Queue 0 (the caller's stream): stage-1 encoder, then the three decoders.  Queue 1: the stage-2 and stage-3 encoders,
+    // which only need the previous stage's ENCODER outputs -- so stage 1's latency-bound deep layers and its decoder
+    // overlap with stage 2's big conv_same layers, and stage 2's decoder overlaps with stage 3's encoder.
+    // The thetas of stages 1 and 2 are only outputs of the training mode (reference :235) and are skipped otherwise.
+    // ---- stage 1 encoder (reference :153-160)
+    E.use(0);
     Tn x11 = E.conv(L_TRANSFER, in, PWS_ACT_LRELU, x, input_nc);
     Tn x12 = E.down(1, x11), x13 = E.down(2, x12), x14 = E.down(3, x13), x15 = E.down(4, x14);
+    E.order(0, 1);  // x11..x15 ready: queue 1 may start stage 2's encoder while queue 0 finishes the deep levels
+    // ---- stage 2 encoder, first levels (reference :178-181) on queue 1
+    E.use(1);
+    Tn x22 = E.down_bottom(1, nullptr, x11);
+    Tn x23 = E.down_bottom(2, &x22, x12), x24 = E.down_bottom(3, &x23, x13), x25 = E.down_bottom(4, &x24, x14);
+    E.use(0);
     Tn x16 = E.down(5, x15), x17 = E.down(6, x16), x18 = E.down(7, x17);
-    E.theta(x18, 0, th1);
+    if (is_training) E.theta(x18, 0, th1);
+    E.order(0, 1);  // x16..x18
+    E.use(1);
+    Tn x26 = E.down_bottom(5, &x25, x15), x27 = E.down_bottom(6, &x26, x16), x28 = E.down_bottom(7, &x27, x17);
+    if (is_training) E.theta(x28, 1, th2);
+    hipEvent_t enc2_done = E.mark(1);
+    // ---- stage 1 decoder (reference :166-174) on queue 0, beside the stage-2 encoder
+    E.use(0);
     Tn x177 = E.up(7, x18, &x17), x166 = E.up(6, x177, &x16), x155 = E.up(5, x166, &x15);
     Tn x144 = E.up(4, x155, &x14), x133 = E.up(3, x144, &x13), x122 = E.up(2, x133, &x12);
     if (is_training) {
         Tn x111 = E.up(1, x122, nullptr);
         E.field(x111, 0, th1, ac, resid, grids);
     }
-    // ---- stage 2 (reference :178-198)
-    Tn x22 = E.down_bottom(1, nullptr, x11);
-    Tn x23 = E.down_bottom(2, &x22, x12), x24 = E.down_bottom(3, &x23, x13), x25 = E.down_bottom(4, &x24, x14);
-    Tn x26 = E.down_bottom(5, &x25, x15), x27 = E.down_bottom(6, &x26, x16), x28 = E.down_bottom(7, &x27, x17);
-    E.theta(x28, 1, th2);
+    // ---- stage 3 encoder (reference :200-206) continues on queue 1; x32 == x22 (same weights, same input)
+    E.use(1);
+    const Tn &x32 = x22;
+    Tn x33 = E.down_bottom(2, &x32, x22), x34 = E.down_bottom(3, &x33, x23), x35 = E.down_bottom(4, &x34, x24);
+    Tn x36 = E.down_bottom(5, &x35, x25), x37 = E.down_bottom(6, &x36, x26), x38 = E.down_bottom(7, &x37, x27);
+    E.theta(x38, 2, th3);
+    hipEvent_t enc3_done = E.mark(1);
+    // ---- stage 2 decoder (reference :190-198) on queue 0, beside the stage-3 encoder: waits for stage 2's encoder only
+    E.wait(0, enc2_done);
+    E.use(0);
     Tn x277 = E.up_bottom(7, x18, x28, &x27), x266 = E.up_bottom(6, x177, x277, &x26);
     Tn x255 = E.up_bottom(5, x166, x266, &x25), x244 = E.up_bottom(4, x155, x255, &x24);
     Tn x233 = E.up_bottom(3, x144, x244, &x23), x222 = E.up_bottom(2, x133, x233, &x22);
@@ -248,11 +324,8 @@ static void forward_graph(Exec &E, const float *x, int n, int input_nc, int g, i
         Tn x211 = E.up_bottom(1, x122, x222, nullptr);
         E.field(x211, 1, th2, ac, resid ? resid + gsz : nullptr, grids ? grids + gsz : nullptr);
     }
-    // ---- stage 3 (reference :200-219); x32 == x22 (same weights, same input)
-    const Tn &x32 = x22;
-    Tn x33 = E.down_bottom(2, &x32, x22), x34 = E.down_bottom(3, &x33, x23), x35 = E.down_bottom(4, &x34, x24);
-    Tn x36 = E.down_bottom(5, &x35, x25), x37 = E.down_bottom(6, &x36, x26), x38 = E.down_bottom(7, &x37, x27);
-    E.theta(x38, 2, th3);
+    // ---- stage 3 decoder (reference :212-219): joins queue 1 (nothing is issued there after this point)
+    E.wait(0, enc3_done);
     Tn x377 = E.up_bottom(7, x28, x38, &x37), x366 = E.up_bottom(6, x277, x377, &x36);
     Tn x355 = E.up_bottom(5, x266, x366, &x35), x344 = E.up_bottom(4, x255, x355, &x34);
     Tn x333 = E.up_bottom(3, x244, x344, &x33), x322 = E.up_bottom(2, x233, x333, &x32);
