@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the instrumented (hipEvent) repetition of the K steps")
     ap.add_argument("--no-graph", action="store_true", help="launch the forward eagerly instead of replaying a hipGraph")
+    ap.add_argument("--serial", action="store_true", help="single queue for the whole run (clean per-kernel durations under rocprof)")
     ap.add_argument("--gs-batch", type=int, default=256, help="frames in the grid_sample roofline launch")
     return ap.parse_args()
 
@@ -137,6 +138,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.serial:
+        A.lib().pws_set_option(A.OPT_TWO_QUEUES, 0)
     net.module.enable_graph(not a.no_graph)  # the ~75 launches of a forward replay as one hipGraph launch
     for _ in range(a.warmup):
         step()
@@ -147,11 +150,13 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
-    # Per-kernel events cannot be recorded inside a graph replay, so the roofline comes from an instrumented repetition
-    # of the same K steps, launched eagerly right after the timed region (kernel durations are the same either way).
+    # Per-kernel events cannot be recorded inside a graph replay, and in the timed region two queues overlap kernels
+    # (stage k+1's encoder beside stage k's decoder), so the per-kernel roofline comes from an instrumented repetition of
+    # the same K steps right after the timed region: eager launches on ONE queue, each bracketed by hipEvents.
     recs = []
     if not a.no_prof and rank == 0:
         net.module.enable_graph(False)
+        A.lib().pws_set_option(A.OPT_TWO_QUEUES, 0)
         step()
         torch.cuda.synchronize()
         A.lib().pws_prof_enable(1)
@@ -160,6 +165,7 @@ def main():
         torch.cuda.synchronize()
         A.lib().pws_prof_enable(0)
         recs = A.prof_collect(1 << 16)
+        A.lib().pws_set_option(A.OPT_TWO_QUEUES, 0 if a.serial else 1)
     if world > 1:
         t = torch.tensor([elapsed], device=ctl_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -175,7 +181,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: batch=8 256x256 inference per GPU, fp32 HIP conv + grid_sample; "
                                    "frame-sharded, no collective", "frames_per_gpu_per_step": B,
-                       "launch": "eager" if a.no_graph else "hipGraph replay of the forward + 1 grid_sample launch",
+                       "launch": ("eager" if a.no_graph else "hipGraph replay of the forward + 1 grid_sample launch") +
+                                 (", single queue" if a.serial else ", two queues (stage k+1 encoder beside stage k decoder)"),
                        "window": "31x256x256", "frame": "3x256x256", "weights": "synthetic W1 (pwstablenet_amd.synth)"},
             "netg_tflops_per_gpu": round(fps / world * GFLOP_PER_FRAME_INFER / 1e3, 2),
             "netg_frac_fp32_peak": round(fps / world * GFLOP_PER_FRAME_INFER / 1e3 / PEAK_FP32_TFLOPS, 4),

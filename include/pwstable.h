@@ -47,6 +47,10 @@ typedef void *pws_stream_t; /* hipStream_t */
 
 int pws_version(void);
 const char *pws_last_error(void); /* thread-local, never NULL */
+/* Process-wide options.  PWS_OPT_TWO_QUEUES (default 1): the generator forward forks an internal second queue so that
+ * stage k+1's encoder runs beside stage k's decoder; 0 = issue everything on the caller's stream (clean per-kernel timing). */
+#define PWS_OPT_TWO_QUEUES 1
+int pws_set_option(int key, int value);
 /* Number of compute units / XCDs the library sees on the current device (diagnostics). */
 int pws_device_info(int *compute_units, int *arch_is_gfx950);
 

@@ -4,6 +4,7 @@
 #include "common.h"
 
 namespace pws {
+bool g_two_queues = true;
 bool g_prof_on = false;
 int g_prof_tag = -1;
 namespace {
@@ -101,4 +102,13 @@ extern "C" int pws_prof_collect(pws_prof_record *out, int max_records) {
 
 extern "C" const char *pws_prof_kernel_name(int kernel_id) {
     return (kernel_id >= 0 && kernel_id < pws::KID_COUNT) ? pws::kKernelNames[kernel_id] : "?";
+}
+
+extern "C" int pws_set_option(int key, int value) {
+    if (key == PWS_OPT_TWO_QUEUES) {
+        pws::g_two_queues = value != 0;
+        return PWS_OK;
+    }
+    pws::set_error("pws_set_option: unknown key %d", key);
+    return PWS_EINVAL;
 }

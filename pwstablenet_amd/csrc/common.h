@@ -49,6 +49,7 @@ enum KernelId {
     KID_UPSAMPLE, KID_AFFINE_GRID, KID_ADAM, KID_PACK, KID_DGRAD_K4S2, KID_DGRAD_SP3, KID_WGRAD, KID_ACT_BWD, KID_FIELD_HEAD_BWD,
     KID_THETA_HEAD_BWD, KID_COUNT
 };
+extern bool g_two_queues;
 extern bool g_prof_on;
 extern int g_prof_tag;
 void prof_begin(int kernel_id, double flops, double bytes, hipStream_t st);

@@ -124,7 +124,7 @@ class Exec {
          bool launch)
         : packed_(packed), L_(layers), n_(n), ws_(ws), cap_(ws_bytes), st_(st), dry_(dry), launch_(launch && !dry) {
         streams_[0] = st, streams_[1] = st;
-        if (launch_ && g_side.init()) streams_[1] = g_side.stream, g_side.next = 0;
+        if (launch_ && g_two_queues && g_side.init()) streams_[1] = g_side.stream, g_side.next = 0;
     }
 
     // ---- two-queue scheduling: ops go to queue `q`; fork/join are event record + wait (capturable, no host sync)

@@ -14,6 +14,7 @@ c_f32p = ctypes.c_void_p  # device pointers are passed as integers
 c_stream = ctypes.c_void_p
 
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
+OPT_TWO_QUEUES = 1
 CONV_K3S1, CONV_K3S2, CONV_K5S1, CONVT_K3S1, CONVT_K4S2, CONV_K2S1P0, CONV_K1, CONV_K3S1_OUT = range(8)
 
 
@@ -55,6 +56,7 @@ _F = ctypes.c_float
 SIGNATURES = {
     "pws_version": (_I, []),
     "pws_last_error": (ctypes.c_char_p, []),
+    "pws_set_option": (_I, [_I, _I]),
     "pws_device_info": (_I, [ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "pws_packed_weight_floats": (_S, [_I, _I, _I]),
     "pws_pack_conv_weight": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -7,9 +7,11 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err
-SHORT="python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof --gs-batch 256"
+# (a) the default bench command (two queues: kernels of the two branches overlap, so their durations are inflated)
+rocprofv3 --kernel-trace --stats -d $OUT/trace_default -o trace -- python3 $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/trace_default_bench.json 2> $OUT/trace_default.err
+# (b) the same bench on a single queue, eager launches: clean per-kernel durations (what bench.py's roofline reports)
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python3 $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --serial --no-graph > $OUT/trace_bench.json 2> $OUT/trace.err
+SHORT="python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof --serial --no-graph --gs-batch 256"
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $SHORT > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $SHORT > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F32 SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY -d $OUT/pmc_sq -o pmc -- $SHORT > /dev/null 2> $OUT/pmc_sq.err
