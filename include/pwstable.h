@@ -75,6 +75,11 @@ size_t pws_packed_weight_floats(int kind, int cin, int cout);
 int pws_pack_conv_weight(const float *w_torch, float *w_packed, int kind, int cin, int cout,
                          pws_stream_t stream);
 
+/* Winograd F(2x2,3x3) weights U = G g G^T as [16][cin padded to 16][cout], computed from the PACKED weights of a
+ * K3S1 / CONVT_K3S1 layer (so the transposed conv's tap flip is already applied). */
+size_t pws_packed_wino_floats(int cin, int cout);
+int pws_pack_conv_weight_wino(const float *w_packed, float *w_wino, int cin, int cout, pws_stream_t stream);
+
 /* One NHWC source of a (virtually concatenated) conv input: `channels` channels starting at `ptr`,
  * consecutive pixels `ld` floats apart.  ptr 16-byte aligned, ld % 4 == 0, channels % 16 == 0. */
 typedef struct pws_src {
@@ -95,6 +100,8 @@ typedef struct pws_conv_args {
     int act;          /* PWS_ACT_* */
     float *out;       /* NHWC, output height/width implied by kind */
     int out_ld;       /* pixel stride of out in floats (>= cout) */
+    const float *w_wino; /* optional (K3S1 / CONVT_K3S1): Winograd-domain weights from pws_pack_conv_weight_wino; when
+                            given and the map is large enough the F(2x2,3x3) kernel runs instead of the direct one */
     void *ws;         /* optional scratch for split-K partial tiles (16-B aligned) or NULL: small-spatial layers */
     size_t ws_bytes;  /* then run un-split.  Any size works; 64 x n*oh*ow*cout*4 bytes never limits the split. */
 } pws_conv_args;

@@ -47,7 +47,7 @@ enum KernelId {
     KID_CONV_K3S1_BIG = 0, KID_CONV_K3S1_SMALL, KID_CONV_K3S2_BIG, KID_CONV_K3S2_SMALL, KID_CONV_K5S1, KID_CONVT4_BIG,
     KID_CONVT4_SMALL, KID_THETA_HEAD, KID_FIELD_HEAD, KID_GRID_SAMPLE_FWD, KID_GRID_SAMPLE_BWD, KID_UPSAMPLE_GRID_SAMPLE_FWD,
     KID_UPSAMPLE, KID_AFFINE_GRID, KID_ADAM, KID_PACK, KID_DGRAD_K4S2, KID_DGRAD_SP3, KID_WGRAD, KID_ACT_BWD, KID_FIELD_HEAD_BWD,
-    KID_THETA_HEAD_BWD, KID_COUNT
+    KID_THETA_HEAD_BWD, KID_CONV_WINO, KID_COUNT
 };
 extern bool g_two_queues;
 extern bool g_prof_on;
@@ -64,6 +64,11 @@ struct ProfScope {  // brackets one launch with events when profiling is enabled
         if (on) prof_end(st);
     }
 };
+
+struct ProfHint {
+    double flops, bytes;
+};
+int wino_k3s1_launch(const pws_conv_args *a, const ProfHint &ph, hipStream_t st);  // conv_wino.hip
 
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == PWS_ACT_LRELU) return v > 0.f ? v : 0.2f * v;

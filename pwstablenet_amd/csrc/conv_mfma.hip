@@ -506,9 +506,16 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
     };
     switch (a->kind) {
     case PWS_CONV_K3S1:
-    case PWS_CONVT_K3S1:
+    case PWS_CONVT_K3S1: {
         kp.OH = kp.LH = a->h, kp.OW = kp.LW = a->w;
-        return select_and_launch(kK3S1, 5, kp, kp.cin_pad, a->out, ws, ws_floats, st, info(9, (double)a->n * a->h * a->w));
+        const ProfInfo pi = info(9, (double)a->n * a->h * a->w);
+        // Winograd F(2x2,3x3) when its 16x16-pixel x 64-channel workgroups fill the chip (2.25x fewer multiplies);
+        // the deep, small maps stay on the direct kernel + split-K
+        const long wblocks = cdiv(a->w, 16) * cdiv(a->h, 16) * a->n * cdiv(a->cout, 64);
+        if (a->w_wino && !nchw && a->h >= 16 && a->w >= 16 && wblocks >= 256)
+            return wino_k3s1_launch(a, ProfHint{pi.flops, pi.bytes}, st);
+        return select_and_launch(kK3S1, 5, kp, kp.cin_pad, a->out, ws, ws_floats, st, pi);
+    }
     case PWS_CONV_K3S2:
         kp.OH = kp.LH = (a->h + 2 - 3) / 2 + 1, kp.OW = kp.LW = (a->w + 2 - 3) / 2 + 1;
         return select_and_launch(kK3S2, 5, kp, kp.cin_pad, a->out, ws, ws_floats, st, info(9, (double)a->n * kp.OH * kp.OW));

@@ -26,6 +26,7 @@ struct Layer {
     int kind, cin, cout;
     size_t w_off, b_off;  // float offsets into the packed buffer (and into the packed gradient buffer)
     size_t dg_off;        // float offset into the data-gradient weight buffer (or SIZE_MAX)
+    size_t ww_off;        // float offset of the Winograd-domain weights inside the packed buffer (or SIZE_MAX)
 };
 
 enum {
@@ -47,11 +48,15 @@ static std::vector<Layer> build_layers(int input_nc, int g, size_t *total_floats
     std::vector<Layer> L;
     size_t off = 0, dg = 0;
     auto add = [&](int kind, int cin, int cout) {
-        Layer l{kind, cin, cout, 0, 0, (size_t)-1};
+        Layer l{kind, cin, cout, 0, 0, (size_t)-1, (size_t)-1};
         l.w_off = off;
         off = align_up(off + pws_packed_weight_floats(kind, cin, cout), 64);
         l.b_off = off;
         off = align_up(off + (size_t)cout, 64);
+        if (kind == PWS_CONV_K3S1 || kind == PWS_CONVT_K3S1) {
+            l.ww_off = off;
+            off = align_up(off + pws_packed_wino_floats(cin, cout), 64);
+        }
         const size_t d = pws_packed_dgrad_floats(kind, cin, cout);
         if (d) l.dg_off = dg, dg = align_up(dg + d, 64);
         L.push_back(l);
@@ -194,6 +199,7 @@ class Exec {
             for (int i = 0; i < x.nseg; ++i) a.src[i] = pws_src{x.seg[i].ptr, x.seg[i].c, x.seg[i].ld};
         }
         a.cout = l.cout, a.w_packed = packed_ + l.w_off, a.bias = packed_ + l.b_off, a.act = act;
+        a.w_wino = l.ww_off != (size_t)-1 ? packed_ + l.ww_off : nullptr;
         a.out = o.seg[0].ptr, a.out_ld = l.cout;
         a.ws = q_ ? splitk_ws2_ : splitk_ws_, a.ws_bytes = splitk_bytes_;
         g_prof_tag = layer;
@@ -467,6 +473,8 @@ extern "C" int pws_netg_pack_weights(const float *const *params, float *packed, 
     for (int i = 0; i < L_COUNT; ++i) {
         PWS_REQUIRE(params[2 * i] && params[2 * i + 1], "pws_netg_pack_weights: params[%d] is NULL", 2 * i);
         int rc = pws_pack_conv_weight(params[2 * i], packed + L[i].w_off, L[i].kind, L[i].cin, L[i].cout, stream);
+        if (rc == PWS_OK && L[i].ww_off != (size_t)-1)
+            rc = pws_pack_conv_weight_wino(packed + L[i].w_off, packed + L[i].ww_off, L[i].cin, L[i].cout, stream);
         if (rc != PWS_OK) return rc;
         e = hipMemcpyAsync(packed + L[i].b_off, params[2 * i + 1], sizeof(float) * L[i].cout, hipMemcpyDeviceToDevice,
                            as_stream(stream));

@@ -26,7 +26,8 @@ class PwsConvArgs(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("n", ctypes.c_int), ("h", ctypes.c_int), ("w", ctypes.c_int),
                 ("nsrc", ctypes.c_int), ("src", PwsSrc * 4), ("src_nchw", ctypes.c_int), ("cout", ctypes.c_int),
                 ("w_packed", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("act", ctypes.c_int),
-                ("out", ctypes.c_void_p), ("out_ld", ctypes.c_int), ("ws", ctypes.c_void_p), ("ws_bytes", ctypes.c_size_t)]
+                ("out", ctypes.c_void_p), ("out_ld", ctypes.c_int), ("w_wino", ctypes.c_void_p), ("ws", ctypes.c_void_p),
+                ("ws_bytes", ctypes.c_size_t)]
 
 
 class PwsDst(ctypes.Structure):
@@ -60,6 +61,8 @@ SIGNATURES = {
     "pws_device_info": (_I, [ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "pws_packed_weight_floats": (_S, [_I, _I, _I]),
     "pws_pack_conv_weight": (_I, [_P, _P, _I, _I, _I, _P]),
+    "pws_packed_wino_floats": (_S, [_I, _I]),
+    "pws_pack_conv_weight_wino": (_I, [_P, _P, _I, _I, _P]),
     "pws_conv2d_fwd": (_I, [ctypes.POINTER(PwsConvArgs), _P]),
     "pws_act_bwd_bias": (_I, [_P, _P, _S, _I, _I, _P, _P]),
     "pws_packed_dgrad_floats": (_S, [_I, _I, _I]),

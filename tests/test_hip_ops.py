@@ -28,7 +28,7 @@ def nchw(a):
     return np.ascontiguousarray(a.transpose(0, 3, 1, 2))
 
 
-def run_conv(A, kind, srcs_nhwc, w_torch, bias, act, cout, nchw_src=None, ws_mb=0):
+def run_conv(A, kind, srcs_nhwc, w_torch, bias, act, cout, nchw_src=None, ws_mb=0, wino=False):
     """srcs_nhwc: list of numpy NHWC arrays (virtual concat) or nchw_src: one NCHW array."""
     L = A.lib()
     st = A.current_stream()
@@ -62,6 +62,10 @@ def run_conv(A, kind, srcs_nhwc, w_torch, bias, act, cout, nchw_src=None, ws_mb=
     b = dev(bias) if bias is not None else None
     args.cout, args.w_packed, args.bias, args.act = cout, wp.data_ptr(), (b.data_ptr() if b is not None else None), act
     args.out, args.out_ld = out.data_ptr(), cout
+    if wino:
+        ww = torch.empty(L.pws_packed_wino_floats(cin, cout), device="cuda", dtype=torch.float32)
+        A.check(L.pws_pack_conv_weight_wino(A.ptr(wp), A.ptr(ww), cin, cout, st), "pack_wino")
+        args.w_wino = ww.data_ptr()
     if ws_mb:
         ws = torch.empty(ws_mb << 20, device="cuda", dtype=torch.uint8)
         args.ws, args.ws_bytes = ws.data_ptr(), ws.numel()
@@ -126,6 +130,35 @@ def test_conv_kinds_vs_oracle(hip, oracle, kname, shape, src_c, cout, act):
         assert not np.isnan(got).any(), "kernel left output elements unwritten"
         # outputs are O(1); K <= 2304 products of N(0,1)*N(0,1/K): 5e-5 abs covers the reordered fp32 sum
         np.testing.assert_allclose(nchw(got), ref, rtol=0, atol=5e-5)
+
+
+@pytest.mark.parametrize("kname,shape,src_c,cout", [
+    ("CONV_K3S1", (4, 128, 128), [16, 16], 64),
+    ("CONVT_K3S1", (5, 112, 130), [32], 96),      # ragged extent, cout not a multiple of 64
+    ("CONV_K3S1", (16, 64, 64), [16, 32, 16], 128),
+])
+def test_conv_winograd_vs_oracle(hip, oracle, kname, shape, src_c, cout):
+    """3x3 stride-1 layers through the Winograd F(2x2,3x3) kernel (taken when its workgroups fill the chip)."""
+    A = hip
+    kind = getattr(A, kname)
+    n, h, w = shape
+    rs = np.random.RandomState(zlib.crc32(repr((kname, shape, cout, "w")).encode()))
+    cin = sum(src_c)
+    is_t = kname.startswith("CONVT")
+    x = rs.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (rs.standard_normal((cin, cout, 3, 3) if is_t else (cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rs.standard_normal((cout,)).astype(np.float32)
+    ref = (oracle.conv_transpose2d if is_t else oracle.conv2d)(x, wt, b, 1, 1, oracle.ACT_LRELU)
+    xs = nhwc(x)
+    srcs, c0 = [], 0
+    for c in src_c:
+        srcs.append(np.ascontiguousarray(xs[..., c0:c0 + c]))
+        c0 += c
+    direct = run_conv(A, kind, srcs, wt, b, 1, cout)
+    got = run_conv(A, kind, srcs, wt, b, 1, cout, wino=True)
+    assert not np.isnan(got).any()
+    assert not np.array_equal(got, direct), "the Winograd kernel was not taken"
+    np.testing.assert_allclose(nchw(got), ref, rtol=0, atol=5e-5)  # Winograd rounding: a few 1e-6 at O(1) outputs
 
 
 def test_conv_first_layer_nchw_31ch(hip, oracle):
