@@ -14,6 +14,8 @@
 //   * epilogue: the 16 components of a (tile, channel) live in 8 different waves, so they meet in LDS (16 channels at a
 //     time), then A^T M A + bias + activation, NHWC store.
 // fp32 throughout; the result differs from the direct kernel by Winograd's usual ~1e-6 relative rounding.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace pws {
@@ -33,6 +35,7 @@ struct WinoParams {
     int out_ld, act;
     int tiles_x, tiles_y;
     unsigned ntiles;
+    int ablate;  // measurement knob (PWS_WINO_ABLATE): 1 skip epilogue, 2 skip transform, 4 skip MFMA, 8 skip B loads
 };
 
 constexpr int WN_CK = 8, WN_CKP = 9;
@@ -155,10 +158,11 @@ __global__ void __launch_bounds__(512, 2) wino_k3s1_kernel(const WinoParams p) {
         c0 += WN_CK;
         if (c0 >= p.src_c[s] && s < p.nsrc - 1) ++s, c0 = 0;
         if (ch + 2 < total_chunks) load_raw(s, c0);
-        if (more) load_b(bnxt, (ch + 1) * WN_CK);
+        if (more && !(p.ablate & 8)) load_b(bnxt, (ch + 1) * WN_CK);
         // transform of chunk ch+1 into the other V buffer, interleaved by the scheduler with the MFMAs of chunk ch
-        if (more) transform(vbuf + ((ch + 1) & 1) * WN_V);
+        if (more && !(p.ablate & 2)) transform(vbuf + ((ch + 1) & 1) * WN_V);
         const float *v = vbuf + (ch & 1) * WN_V;
+        if (!(p.ablate & 4))
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -180,6 +184,10 @@ __global__ void __launch_bounds__(512, 2) wino_k3s1_kernel(const WinoParams p) {
     }
 
     // ---- epilogue: 4 rounds of 16 output channels through LDS [xi][tile][16+1]
+    if (p.ablate & 1) {
+        if (acc[0][0][0][0] == 12345.678f) p.out[0] = acc[1][1][1][3];  // keep the accumulators live
+        return;
+    }
     float *mb = lds;
     const int e_tile = tid >> 3;                 // 512 threads = 64 tiles x 8 channel pairs
     const int e_co = (tid & 7) * 2;
@@ -265,6 +273,8 @@ int wino_k3s1_launch(const pws_conv_args *a, const ProfHint &ph, hipStream_t st)
     p.uw = a->w_wino, p.bias = a->bias, p.out = a->out, p.out_ld = a->out_ld, p.act = a->act;
     p.tiles_x = (a->w + 15) / 16, p.tiles_y = (a->h + 15) / 16;
     p.ntiles = (unsigned)(p.tiles_x * p.tiles_y * a->n);
+    static const int ablate = getenv("PWS_WINO_ABLATE") ? atoi(getenv("PWS_WINO_ABLATE")) : 0;
+    p.ablate = ablate;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_k3s1_kernel),

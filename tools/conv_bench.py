@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Single-layer conv micro-benchmark through pws_conv2d_fwd: python tools/conv_bench.py KIND N H W CIN COUT [wino]"""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from pwstablenet_amd import hipabi as A  # noqa: E402
+
+
+def bench(kname, n, h, w, cin, cout, wino):
+    L, st = A.lib(), A.current_stream()
+    kind = getattr(A, kname)
+    k = {"CONV_K3S1": 3, "CONV_K3S2": 3, "CONVT_K3S1": 3, "CONVT_K4S2": 4, "CONV_K5S1": 5}[kname]
+    wt = torch.randn((cout, cin, k, k) if not kname.startswith("CONVT") else (cin, cout, k, k), device="cuda") / (cin * k) ** 0.5
+    wp = torch.empty(L.pws_packed_weight_floats(kind, cin, cout), device="cuda")
+    A.check(L.pws_pack_conv_weight(A.ptr(wt), A.ptr(wp), kind, cin, cout, st), "pack")
+    x = torch.randn((n, h, w, cin), device="cuda")
+    oh, ow = (h, w) if "S1" in kname else ((h // 2, w // 2) if kname == "CONV_K3S2" else (2 * h, 2 * w))
+    out = torch.empty((n, oh, ow, cout), device="cuda")
+    b = torch.randn(cout, device="cuda")
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    a = A.PwsConvArgs()
+    a.kind, a.n, a.h, a.w, a.nsrc, a.cout, a.act = kind, n, h, w, 1, cout, 1
+    a.src[0].ptr, a.src[0].channels, a.src[0].ld = x.data_ptr(), cin, cin
+    a.w_packed, a.bias, a.out, a.out_ld, a.ws, a.ws_bytes = wp.data_ptr(), b.data_ptr(), out.data_ptr(), cout, ws.data_ptr(), ws.numel()
+    if wino:
+        ww = torch.empty(L.pws_packed_wino_floats(cin, cout), device="cuda")
+        A.check(L.pws_pack_conv_weight_wino(A.ptr(wp), A.ptr(ww), cin, cout, st), "wino pack")
+        a.w_wino = ww.data_ptr()
+    for _ in range(3):
+        A.check(L.pws_conv2d_fwd(ctypes.byref(a), st), "conv")
+    torch.cuda.synchronize()
+    L.pws_prof_enable(1)
+    for _ in range(10):
+        A.check(L.pws_conv2d_fwd(ctypes.byref(a), st), "conv")
+    L.pws_prof_enable(0)
+    r = A.prof_collect()
+    ms = sorted(x_[4] for x_ in r)[len(r) // 2]
+    print("%-11s n=%d %dx%d %d->%d %-5s ablate=%s: %8.1f us  %6.1f TFLOP/s (algorithmic)" % (
+        kname, n, h, w, cin, cout, "wino" if wino else "direct", os.environ.get("PWS_WINO_ABLATE", "0"), ms * 1e3,
+        r[0][2] / (ms * 1e-3) / 1e12))
+
+
+if __name__ == "__main__":
+    v = sys.argv[1:]
+    bench(v[0], int(v[1]), int(v[2]), int(v[3]), int(v[4]), int(v[5]), len(v) > 6 and v[6] == "wino")

@@ -18,5 +18,6 @@ rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_
 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT -d $OUT/pmc_grbm -o pmc -- $SHORT > /dev/null 2> $OUT/pmc_grbm.err
 cd $REPO
 python3 tools/summarize_prof.py $OUT $TAG > $OUT/summary.log 2>&1
+rm -rf $OUT/trace $OUT/trace_default $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_grbm   # raw rocpd databases: tens of MB each
 ls -R $OUT | head -50
 tail -40 $OUT/summary.log
