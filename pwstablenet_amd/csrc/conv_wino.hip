@@ -3,16 +3,18 @@
 //     Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A          (Lavin & Gray), d = 4x4 input patch, Y = 2x2 outputs
 // i.e. 16 independent GEMMs  M_xi[tile][co] = sum_ci V_xi[tile][ci] * U_xi[ci][co],  xi = 0..15.
 //
-// Workgroup = 512 threads (8 waves) = one 16x16-pixel output region (8x8 = 64 Winograd tiles) x 64 output channels.
-//   * wave w owns components xi = 2w, 2w+1: 2 comps x (2 tile blocks x 2 channel blocks) of 32x32 accumulators = 128 VGPRs;
-//   * input channels are walked in chunks of 8.  Per chunk the raw halo tile [18x18][8] goes to LDS, one thread per
-//     (tile, channel) applies B^T d B and writes V[xi][tile][8] into the OTHER of two V buffers while the MFMAs of the
-//     current chunk run on the first -- the transform's VALU/LDS work hides under the 64-cycle MFMAs (one barrier pair
-//     per chunk);
-//   * U (the transformed weights, prepared once at pack time as [xi][cin][cout]) is not shared between waves (each wave
-//     has its own components), so the B fragments are read straight from L2 into registers, one chunk ahead;
-//   * epilogue: the 16 components of a (tile, channel) live in 8 different waves, so they meet in LDS (16 channels at a
-//     time), then A^T M A + bias + activation, NHWC store.
+// Workgroup = 256 threads (4 waves) = one 8x16-pixel output region (4x8 = 32 Winograd tiles) x 64 output channels;
+// 76 KB of LDS -> two workgroups per CU, which run out of phase and hide each other's staging (a single 8-wave
+// workgroup per CU measured 35-50 % MFMA utilisation: staging, barriers and the epilogue were fully exposed).
+//   * wave w owns the Winograd ROW i = w, i.e. components xi = 4w .. 4w+3: 4 comps x 2 channel blocks of 32x32
+//     accumulators = 128 VGPRs;
+//   * input channels are walked in chunks of 8.  Per chunk the raw halo tile [10x18][8] and the transformed-weight chunk
+//     U[16][8][64] (prepared once at pack time) go to LDS; one thread per (tile, channel) applies B^T d B and writes
+//     V[xi][tile][8] into the OTHER of two V buffers while the MFMAs of the current chunk run on the first, so the
+//     transform's VALU/LDS work hides under the 64-cycle MFMAs; raw and U of the next chunk are prefetched into registers;
+//   * epilogue: a wave holds all four column components of its row, so the column half of A^T M A is done in registers;
+//     the four rows meet in LDS once (2 partial values per tile and channel), then bias + activation and NHWC stores with
+//     lane = channel (256-B coalesced per pixel).
 // fp32 throughout; the result differs from the direct kernel by Winograd's usual ~1e-6 relative rounding.
 #include <cstdlib>
 
@@ -39,33 +41,38 @@ struct WinoParams {
 };
 
 constexpr int WN_CK = 8, WN_CKP = 9;
-constexpr int WN_RAW = 18 * 18 * WN_CKP;            // floats
-constexpr int WN_V = 16 * 64 * WN_CKP;              // floats per V buffer
-constexpr int WN_LDS_MAIN = WN_RAW + 2 * WN_V;      // 21348 floats = 85.4 KB
-constexpr int WN_MP = 17;                           // epilogue row pad: [xi][tile][16 + 1]
-constexpr int WN_LDS_EPI = 16 * 64 * WN_MP;         // 17408 floats
+constexpr int WN_TH = 8, WN_TW = 16;                        // output pixels per workgroup: 4 x 8 = 32 Winograd tiles
+constexpr int WN_RH = WN_TH + 2, WN_RW = WN_TW + 2;         // raw halo tile
+constexpr int WN_RAW = (WN_RH * WN_RW * WN_CKP + 3) / 4 * 4;  // floats (16-B multiple: U below is float4-accessed)
+constexpr int WN_V = 16 * 32 * WN_CKP;                      // floats per V buffer  [xi][tile][8+1]
+constexpr int WN_U = 16 * WN_CK * 64;                       // floats: U chunk     [xi][k][64 cout]
+constexpr int WN_LDS_MAIN = WN_RAW + 2 * WN_V + WN_U;       // 19028 floats = 76.1 KB  -> 2 workgroups per CU
+constexpr int WN_EP = 65;                                   // epilogue row pad: [i 4][b 2][tile 32][64 + 1]
+constexpr int WN_LDS_EPI = 4 * 2 * 32 * WN_EP;              // 16640 floats
 constexpr int WN_LDS_BYTES = (WN_LDS_MAIN > WN_LDS_EPI ? WN_LDS_MAIN : WN_LDS_EPI) * 4;
+constexpr int WN_RAW_ITEMS = WN_RH * WN_RW * 2;             // float4 items of the raw tile (360)
 
-__global__ void __launch_bounds__(512, 2) wino_k3s1_kernel(const WinoParams p) {
+__global__ void __launch_bounds__(256, 2) wino_k3s1_kernel(const WinoParams p) {
     extern __shared__ float lds[];
     float *raw = lds;
     float *vbuf = lds + WN_RAW;
+    float *ubuf = lds + WN_RAW + 2 * WN_V;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
 
     const unsigned tile = xcd_remap(blockIdx.x, p.ntiles);
     const int tx_i = tile % p.tiles_x, ty_i = (tile / p.tiles_x) % p.tiles_y, n = tile / (p.tiles_x * p.tiles_y);
-    const int y0 = ty_i * 16, x0 = tx_i * 16, co0 = blockIdx.y * 64;
+    const int y0 = ty_i * WN_TH, x0 = tx_i * WN_TW, co0 = blockIdx.y * 64;
 
-    // ---- raw-tile staging descriptors: 324 pixels x 2 float4 = 648 items over 512 threads (2 per thread)
+    // ---- raw-tile staging descriptors: 180 pixels x 2 float4 over 256 threads (2 per thread, second one partial)
     int g_pix[2], l_off[2], g_c4[2];
     bool g_ok[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-        const int item = tid + it * 512;
+        const int item = tid + it * 256;
         const int pix = item >> 1, c4 = (item & 1) * 4;
-        const int ly = pix / 18, lx = pix % 18;
+        const int ly = pix / WN_RW, lx = pix % WN_RW;
         const int iy = y0 - 1 + ly, ix = x0 - 1 + lx;
-        const bool in = item < 648;
+        const bool in = item < WN_RAW_ITEMS;
         g_ok[it] = in && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         g_pix[it] = g_ok[it] ? (n * p.H + iy) * p.W + ix : 0;
         l_off[it] = in ? pix * WN_CKP + c4 : -1;
@@ -88,17 +95,31 @@ __global__ void __launch_bounds__(512, 2) wino_k3s1_kernel(const WinoParams p) {
             }
         }
     };
+    // ---- U chunk [16][8][64]: 2048 float4 over 256 threads = 8 per thread, all unconditional loads
+    float4 r_u[8];
+    const int u_q = (tid & 15) * 4, u_k = (tid >> 4) & 7;      // item = tid + it*256 -> xi = it*2 + (tid >> 7)
+    const bool u_ok = co0 + u_q < p.cout;
+    const float *u_base = p.uw + ((size_t)(tid >> 7) * p.cin_pad + u_k) * p.cout + (u_ok ? co0 + u_q : 0);
+    auto load_u = [&](int wrow) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+            r_u[it] = *reinterpret_cast<const float4 *>(u_base + ((size_t)(2 * it) * p.cin_pad + wrow) * p.cout);
+    };
+    auto store_u = [&]() {
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+            *reinterpret_cast<float4 *>(ubuf + (tid + it * 256) * 4) = u_ok ? r_u[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
     // ---- input transform: thread = (tile t, channel c)
     const int t_tile = tid >> 3, t_c = tid & 7;
-    const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
-    const int t_src = ((2 * t_ty) * 18 + 2 * t_tx) * WN_CKP + t_c;
+    const int t_src = ((2 * (t_tile >> 3)) * WN_RW + 2 * (t_tile & 7)) * WN_CKP + t_c;
     const int t_dst = t_tile * WN_CKP + t_c;
     auto transform = [&](float *vdst) {
         float d[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) d[i][j] = raw[t_src + (i * 18 + j) * WN_CKP];
+            for (int j = 0; j < 4; ++j) d[i][j] = raw[t_src + (i * WN_RW + j) * WN_CKP];
         float t[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -106,43 +127,30 @@ __global__ void __launch_bounds__(512, 2) wino_k3s1_kernel(const WinoParams p) {
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            vdst[t_dst + (i * 4 + 0) * 64 * WN_CKP] = t[i][0] - t[i][2];
-            vdst[t_dst + (i * 4 + 1) * 64 * WN_CKP] = t[i][1] + t[i][2];
-            vdst[t_dst + (i * 4 + 2) * 64 * WN_CKP] = t[i][2] - t[i][1];
-            vdst[t_dst + (i * 4 + 3) * 64 * WN_CKP] = t[i][1] - t[i][3];
+            vdst[t_dst + (i * 4 + 0) * 32 * WN_CKP] = t[i][0] - t[i][2];
+            vdst[t_dst + (i * 4 + 1) * 32 * WN_CKP] = t[i][1] + t[i][2];
+            vdst[t_dst + (i * 4 + 2) * 32 * WN_CKP] = t[i][2] - t[i][1];
+            vdst[t_dst + (i * 4 + 3) * 32 * WN_CKP] = t[i][1] - t[i][3];
         }
     };
-    // ---- B fragments (transformed weights) straight from L2: [comp 2][kk 4][nsub 2]
-    float bcur[2][4][2], bnxt[2][4][2];
-    const bool co_ok0 = co0 + l31 < p.cout, co_ok1 = co0 + 32 + l31 < p.cout;
-    auto load_b = [&](float (&b)[2][4][2], int wrow) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const float *row = p.uw + ((size_t)(2 * wv + c) * p.cin_pad + wrow + 2 * kk + hi) * p.cout + co0;
-                const float v0 = row[co_ok0 ? l31 : 0], v1 = row[co_ok1 ? 32 + l31 : 0];
-                b[c][kk][0] = co_ok0 ? v0 : 0.f, b[c][kk][1] = co_ok1 ? v1 : 0.f;
-            }
-    };
 
-    f32x16 acc[2][2][2];
+    // wave w owns the Winograd row i = w: components xi = 4w + j, j = 0..3, all 32 tiles x 64 channels
+    f32x16 acc[4][2];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
-            for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[c][m][nn][r] = 0.f;
-    const int a_base = (2 * wv * 64 + l31) * WN_CKP + hi;  // + comp*64*CKP + m*32*CKP + 2*kk
+            for (int r = 0; r < 16; ++r) acc[j][nn][r] = 0.f;
+    const int a_base = (4 * wv * 32 + l31) * WN_CKP + hi;   // + j*32*CKP + 2*kk
+    const int b_base = (4 * wv * WN_CK + hi) * 64 + l31;     // + (j*CK + 2*kk)*64 + nt*32
 
     int total_chunks = 0;
     for (int s = 0; s < p.nsrc; ++s) total_chunks += p.src_c[s] / WN_CK;
-    // ---- prologue: chunk 0 raw -> LDS -> V[0]; chunk 1 raw and chunk 0 B fragments in flight
+    // ---- prologue: chunk 0 raw -> LDS -> V[0]; chunk 1 raw and chunk 0 U in registers
     int s = 0, c0 = 0;
     load_raw(s, c0);
-    load_b(bcur, 0);
+    load_u(0);
     store_raw();
     __syncthreads();
     transform(vbuf);
@@ -152,77 +160,62 @@ __global__ void __launch_bounds__(512, 2) wino_k3s1_kernel(const WinoParams p) {
     __syncthreads();
     for (int ch = 0; ch < total_chunks; ++ch) {
         const bool more = ch + 1 < total_chunks;
-        if (more) store_raw();  // chunk ch+1 (raw of chunk ch was consumed by its transform before the last barrier)
+        if (more) store_raw();  // raw of chunk ch+1 (chunk ch's was consumed by its transform before the last barrier)
+        store_u();              // U of chunk ch (the MFMAs of chunk ch-1 finished before the last barrier)
         __syncthreads();
-        // prefetch: raw of chunk ch+2, B fragments of chunk ch+1
         c0 += WN_CK;
         if (c0 >= p.src_c[s] && s < p.nsrc - 1) ++s, c0 = 0;
         if (ch + 2 < total_chunks) load_raw(s, c0);
-        if (more && !(p.ablate & 8)) load_b(bnxt, (ch + 1) * WN_CK);
-        // transform of chunk ch+1 into the other V buffer, interleaved by the scheduler with the MFMAs of chunk ch
+        if (more && !(p.ablate & 8)) load_u((ch + 1) * WN_CK);
+        // transform of chunk ch+1 into the other V buffer; the scheduler interleaves it with the MFMAs of chunk ch
         if (more && !(p.ablate & 2)) transform(vbuf + ((ch + 1) & 1) * WN_V);
         const float *v = vbuf + (ch & 1) * WN_V;
-        if (!(p.ablate & 4))
+        if (!(p.ablate & 4)) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+            for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const float a0 = v[a_base + c * 64 * WN_CKP + 2 * kk];
-                const float a1 = v[a_base + c * 64 * WN_CKP + 32 * WN_CKP + 2 * kk];
-                acc[c][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bcur[c][kk][0], acc[c][0][0], 0, 0, 0);
-                acc[c][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bcur[c][kk][1], acc[c][0][1], 0, 0, 0);
-                acc[c][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bcur[c][kk][0], acc[c][1][0], 0, 0, 0);
-                acc[c][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bcur[c][kk][1], acc[c][1][1], 0, 0, 0);
-            }
-        if (more) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) bcur[c][kk][0] = bnxt[c][kk][0], bcur[c][kk][1] = bnxt[c][kk][1];
+                for (int j = 0; j < 4; ++j) {
+                    const float a = v[a_base + j * 32 * WN_CKP + 2 * kk];
+                    const float b0 = ubuf[b_base + (j * WN_CK + 2 * kk) * 64];
+                    const float b1 = ubuf[b_base + (j * WN_CK + 2 * kk) * 64 + 32];
+                    acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[j][0], 0, 0, 0);
+                    acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[j][1], 0, 0, 0);
+                }
         }
         __syncthreads();
     }
 
-    // ---- epilogue: 4 rounds of 16 output channels through LDS [xi][tile][16+1]
+    // ---- epilogue.  Each wave holds a whole Winograd row (4 column components), so the column half of A^T M A runs in
+    // registers; only 2 partial values per (tile, channel) and row go through LDS, once.
     if (p.ablate & 1) {
-        if (acc[0][0][0][0] == 12345.678f) p.out[0] = acc[1][1][1][3];  // keep the accumulators live
+        if (acc[0][0][0] == 12345.678f) p.out[0] = acc[3][1][3];  // keep the accumulators live
         return;
     }
-    float *mb = lds;
-    const int e_tile = tid >> 3;                 // 512 threads = 64 tiles x 8 channel pairs
-    const int e_co = (tid & 7) * 2;
-    const int e_ty = e_tile >> 3, e_tx = e_tile & 7;
+    float *eb = lds;  // [i = wave][b][tile][64 + 1]
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if ((l31 >> 4) == (q & 1)) {
-            const int col = l31 & 15;
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int trow = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        mb[((2 * wv + c) * 64 + trow) * WN_MP + col] = acc[c][m][q >> 1][r];
-                    }
+        for (int r = 0; r < 16; ++r) {
+            const int trow = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float t0 = acc[0][nt][r] + acc[1][nt][r] + acc[2][nt][r];
+            const float t1 = acc[1][nt][r] - acc[2][nt][r] - acc[3][nt][r];
+            eb[((wv * 2 + 0) * 32 + trow) * WN_EP + nt * 32 + l31] = t0;
+            eb[((wv * 2 + 1) * 32 + trow) * WN_EP + nt * 32 + l31] = t1;
         }
-        __syncthreads();
+    __syncthreads();
+    {
+        const int col = tid & 63;           // lane = channel: 256-B coalesced stores per output pixel
+        const int co = co0 + col;
+        const float bias = (p.bias && co < p.cout) ? p.bias[co] : 0.f;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int col = e_co + u;
-            const int co = co0 + q * 16 + col;
-            float m_[4][4];
+        for (int k = 0; k < 8; ++k) {
+            const int t = (tid >> 6) + 4 * k;
+            float e[4][2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) m_[i][j] = mb[((i * 4 + j) * 64 + e_tile) * WN_MP + col];
-            float t0[4], t1[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) t0[j] = m_[0][j] + m_[1][j] + m_[2][j], t1[j] = m_[1][j] - m_[2][j] - m_[3][j];
-            const float bias = (p.bias && co < p.cout) ? p.bias[co] : 0.f;
-            const float y00 = t0[0] + t0[1] + t0[2], y01 = t0[1] - t0[2] - t0[3];
-            const float y10 = t1[0] + t1[1] + t1[2], y11 = t1[1] - t1[2] - t1[3];
-            const int oy = y0 + 2 * e_ty, ox = x0 + 2 * e_tx;
+            for (int i = 0; i < 4; ++i) e[i][0] = eb[((i * 2 + 0) * 32 + t) * WN_EP + col], e[i][1] = eb[((i * 2 + 1) * 32 + t) * WN_EP + col];
+            const float y00 = e[0][0] + e[1][0] + e[2][0], y01 = e[0][1] + e[1][1] + e[2][1];
+            const float y10 = e[1][0] - e[2][0] - e[3][0], y11 = e[1][1] - e[2][1] - e[3][1];
+            const int oy = y0 + 2 * (t >> 3), ox = x0 + 2 * (t & 7);
             if (co < p.cout) {
                 float *o = p.out + ((size_t)(n * p.H + oy) * p.W + ox) * p.out_ld + co;
                 const size_t rs = (size_t)p.W * p.out_ld;
@@ -232,7 +225,6 @@ __global__ void __launch_bounds__(512, 2) wino_k3s1_kernel(const WinoParams p) {
                 if (oy + 1 < p.H && ox + 1 < p.W) o[rs + p.out_ld] = act_apply(y11 + bias, p.act);
             }
         }
-        __syncthreads();
     }
 }
 
@@ -271,7 +263,7 @@ int wino_k3s1_launch(const pws_conv_args *a, const ProfHint &ph, hipStream_t st)
     }
     p.N = a->n, p.H = a->h, p.W = a->w, p.cin_pad = (cin + 15) / 16 * 16, p.cout = a->cout;
     p.uw = a->w_wino, p.bias = a->bias, p.out = a->out, p.out_ld = a->out_ld, p.act = a->act;
-    p.tiles_x = (a->w + 15) / 16, p.tiles_y = (a->h + 15) / 16;
+    p.tiles_x = (a->w + WN_TW - 1) / WN_TW, p.tiles_y = (a->h + WN_TH - 1) / WN_TH;
     p.ntiles = (unsigned)(p.tiles_x * p.tiles_y * a->n);
     static const int ablate = getenv("PWS_WINO_ABLATE") ? atoi(getenv("PWS_WINO_ABLATE")) : 0;
     p.ablate = ablate;
@@ -286,7 +278,7 @@ int wino_k3s1_launch(const pws_conv_args *a, const ProfHint &ph, hipStream_t st)
         attr_set = true;
     }
     ProfScope prof(KID_CONV_WINO, ph.flops, ph.bytes, st);
-    hipLaunchKernelGGL(wino_k3s1_kernel, dim3(p.ntiles, (a->cout + 63) / 64), dim3(512), WN_LDS_BYTES, st, p);
+    hipLaunchKernelGGL(wino_k3s1_kernel, dim3(p.ntiles, (a->cout + 63) / 64), dim3(256), WN_LDS_BYTES, st, p);
     return check_launch("wino_k3s1_kernel");
 }
 
