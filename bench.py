@@ -201,7 +201,8 @@ def main():
                                 "flops_per_launch": fl / cnt}
             tot_ms = sum(v[3] for v in agg.values())
             line["kernel_time_share"] = {k: round(v[3] / tot_ms, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][3])}
-            line["kernel_tflops"] = {k: round(v[1] / (v[3] * 1e-3) / 1e12, 2) for k, v in agg.items() if v[3] > 0 and "conv" in k}
+            line["kernel_tflops"] = {k: round(v[1] / (v[3] * 1e-3) / 1e12, 2) for k, v in agg.items()
+                                     if v[3] > 0 and ("conv" in k or "wino" in k)}
             line["kernel_time_over_step_time"] = round(tot_ms * 1e-3 / elapsed, 4)
         # grid_sample roofline on a batch large enough not to be launch-latency-bound
         GB = a.gs_batch

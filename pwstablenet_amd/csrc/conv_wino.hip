@@ -37,7 +37,8 @@ struct WinoParams {
     int out_ld, act;
     int tiles_x, tiles_y;
     unsigned ntiles;
-    int ablate;  // measurement knob (PWS_WINO_ABLATE): 1 skip epilogue, 2 skip transform, 4 skip MFMA, 8 skip B loads
+    int ablate;  // measurement knob (env PWS_WINO_ABLATE, tools/conv_bench.py): 1 skip epilogue, 2 skip transform,
+                 // 4 skip MFMA, 8 skip U loads -- results are then wrong on purpose; 0 in normal operation
 };
 
 constexpr int WN_CK = 8, WN_CKP = 9;
@@ -171,16 +172,33 @@ __global__ void __launch_bounds__(256, 2) wino_k3s1_kernel(const WinoParams p) {
         if (more && !(p.ablate & 2)) transform(vbuf + ((ch + 1) & 1) * WN_V);
         const float *v = vbuf + (ch & 1) * WN_V;
         if (!(p.ablate & 4)) {
+            // fragments of k-step kk+1 are requested from LDS before the 8 MFMAs of k-step kk are issued, so the LDS
+            // latency hides under matrix work instead of stalling every MFMA pair
+            float fa[2][4], fb[2][4][2];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+            for (int j = 0; j < 4; ++j) {
+                fa[0][j] = v[a_base + j * 32 * WN_CKP];
+                fb[0][j][0] = ubuf[b_base + (j * WN_CK) * 64], fb[0][j][1] = ubuf[b_base + (j * WN_CK) * 64 + 32];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int cur = kk & 1, nxt = cur ^ 1;
+                if (kk < 3) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        fa[nxt][j] = v[a_base + j * 32 * WN_CKP + 2 * (kk + 1)];
+                        fb[nxt][j][0] = ubuf[b_base + (j * WN_CK + 2 * (kk + 1)) * 64];
+                        fb[nxt][j][1] = ubuf[b_base + (j * WN_CK + 2 * (kk + 1)) * 64 + 32];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the requests above the MFMAs (hipcc otherwise sinks each read to its use)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float a = v[a_base + j * 32 * WN_CKP + 2 * kk];
-                    const float b0 = ubuf[b_base + (j * WN_CK + 2 * kk) * 64];
-                    const float b1 = ubuf[b_base + (j * WN_CK + 2 * kk) * 64 + 32];
-                    acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[j][0], 0, 0, 0);
-                    acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[j][1], 0, 0, 0);
+                    acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][j], fb[cur][j][0], acc[j][0], 0, 0, 0);
+                    acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][j], fb[cur][j][1], acc[j][1], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         __syncthreads();
     }
