@@ -17,6 +17,7 @@
 //     lane = channel (256-B coalesced per pixel).
 // fp32 throughout; the result differs from the direct kernel by Winograd's usual ~1e-6 relative rounding.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -79,37 +80,39 @@ __global__ void __launch_bounds__(256, 2) wino_k3s1_kernel(const WinoParams p) {
         l_off[it] = in ? pix * WN_CKP + c4 : -1;
         g_c4[it] = c4;
     }
-    float4 r_raw[2];
-    auto load_raw = [&](int s, int c0) {
+    // Global loads run TWO chunks ahead of their use (a chunk is only ~1-2 us of matrix work, about one HBM latency):
+    // two register sets each for the raw tile and for U, indexed statically (the chunk loop is unrolled by 2).
+    float4 r_raw[2][2];
+    auto load_raw = [&](float4 (&r)[2], int s, int c0) {
         const float *sp = p.src_ptr[s] + c0;
         const size_t ld = p.src_ld[s];
 #pragma unroll
-        for (int it = 0; it < 2; ++it) r_raw[it] = *reinterpret_cast<const float4 *>(sp + (size_t)g_pix[it] * ld + g_c4[it]);
+        for (int it = 0; it < 2; ++it) r[it] = *reinterpret_cast<const float4 *>(sp + (size_t)g_pix[it] * ld + g_c4[it]);
     };
-    auto store_raw = [&]() {
+    auto store_raw = [&](const float4 (&r)[2]) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             if (l_off[it] >= 0) {
                 float *d = raw + l_off[it];
-                d[0] = g_ok[it] ? r_raw[it].x : 0.f, d[1] = g_ok[it] ? r_raw[it].y : 0.f;
-                d[2] = g_ok[it] ? r_raw[it].z : 0.f, d[3] = g_ok[it] ? r_raw[it].w : 0.f;
+                d[0] = g_ok[it] ? r[it].x : 0.f, d[1] = g_ok[it] ? r[it].y : 0.f;
+                d[2] = g_ok[it] ? r[it].z : 0.f, d[3] = g_ok[it] ? r[it].w : 0.f;
             }
         }
     };
     // ---- U chunk [16][8][64]: 2048 float4 over 256 threads = 8 per thread, all unconditional loads
-    float4 r_u[8];
+    float4 r_u[2][8];
     const int u_q = (tid & 15) * 4, u_k = (tid >> 4) & 7;      // item = tid + it*256 -> xi = it*2 + (tid >> 7)
     const bool u_ok = co0 + u_q < p.cout;
     const float *u_base = p.uw + ((size_t)(tid >> 7) * p.cin_pad + u_k) * p.cout + (u_ok ? co0 + u_q : 0);
-    auto load_u = [&](int wrow) {
+    auto load_u = [&](float4 (&r)[8], int wrow) {
 #pragma unroll
         for (int it = 0; it < 8; ++it)
-            r_u[it] = *reinterpret_cast<const float4 *>(u_base + ((size_t)(2 * it) * p.cin_pad + wrow) * p.cout);
+            r[it] = *reinterpret_cast<const float4 *>(u_base + ((size_t)(2 * it) * p.cin_pad + wrow) * p.cout);
     };
-    auto store_u = [&]() {
+    auto store_u = [&](const float4 (&r)[8]) {
 #pragma unroll
         for (int it = 0; it < 8; ++it)
-            *reinterpret_cast<float4 *>(ubuf + (tid + it * 256) * 4) = u_ok ? r_u[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(ubuf + (tid + it * 256) * 4) = u_ok ? r[it] : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     // ---- input transform: thread = (tile t, channel c)
     const int t_tile = tid >> 3, t_c = tid & 7;
@@ -148,32 +151,37 @@ __global__ void __launch_bounds__(256, 2) wino_k3s1_kernel(const WinoParams p) {
 
     int total_chunks = 0;
     for (int s = 0; s < p.nsrc; ++s) total_chunks += p.src_c[s] / WN_CK;
-    // ---- prologue: chunk 0 raw -> LDS -> V[0]; chunk 1 raw and chunk 0 U in registers
+    // source cursor of the NEXT raw chunk to request
     int s = 0, c0 = 0;
-    load_raw(s, c0);
-    load_u(0);
-    store_raw();
-    __syncthreads();
-    transform(vbuf);
-    c0 += WN_CK;
-    if (c0 >= p.src_c[s] && s < p.nsrc - 1) ++s, c0 = 0;
-    if (total_chunks > 1) load_raw(s, c0);
-    __syncthreads();
-    for (int ch = 0; ch < total_chunks; ++ch) {
-        const bool more = ch + 1 < total_chunks;
-        if (more) store_raw();  // raw of chunk ch+1 (chunk ch's was consumed by its transform before the last barrier)
-        store_u();              // U of chunk ch (the MFMAs of chunk ch-1 finished before the last barrier)
-        __syncthreads();
+    auto advance = [&]() {
         c0 += WN_CK;
         if (c0 >= p.src_c[s] && s < p.nsrc - 1) ++s, c0 = 0;
-        if (ch + 2 < total_chunks) load_raw(s, c0);
-        if (more && !(p.ablate & 8)) load_u((ch + 1) * WN_CK);
+    };
+    // ---- prologue: raw(0) -> LDS -> V[0]; raw(1), raw(2), U(0), U(1) in flight
+    load_raw(r_raw[0], s, c0), advance();
+    load_u(r_u[0], 0);
+    store_raw(r_raw[0]);
+    __syncthreads();
+    transform(vbuf);
+    if (total_chunks > 1) load_raw(r_raw[1], s, c0), advance();   // raw(1) -> set 1
+    if (total_chunks > 2) load_raw(r_raw[0], s, c0), advance();   // raw(2) -> set 0
+    if (total_chunks > 1) load_u(r_u[1], WN_CK);
+    __syncthreads();
+
+    // one chunk; PAR = ch & 1 is a compile-time constant so that the register sets are statically indexed
+    auto chunk = [&](int ch, auto par_c) {
+        constexpr int PAR = decltype(par_c)::value;
+        const bool more = ch + 1 < total_chunks;
+        if (more) store_raw(r_raw[PAR ^ 1]);  // raw(ch+1) lives in set (ch+1)&1; raw(ch) was consumed before the last barrier
+        store_u(r_u[PAR]);                    // U(ch); the MFMAs of chunk ch-1 finished before the last barrier
+        __syncthreads();
+        if (ch + 3 < total_chunks) load_raw(r_raw[PAR ^ 1], s, c0), advance();  // raw(ch+3) into the set just stored
+        if (ch + 2 < total_chunks && !(p.ablate & 8)) load_u(r_u[PAR], (ch + 2) * WN_CK);
         // transform of chunk ch+1 into the other V buffer; the scheduler interleaves it with the MFMAs of chunk ch
-        if (more && !(p.ablate & 2)) transform(vbuf + ((ch + 1) & 1) * WN_V);
-        const float *v = vbuf + (ch & 1) * WN_V;
+        if (more && !(p.ablate & 2)) transform(vbuf + (PAR ^ 1) * WN_V);
+        const float *v = vbuf + PAR * WN_V;
         if (!(p.ablate & 4)) {
-            // fragments of k-step kk+1 are requested from LDS before the 8 MFMAs of k-step kk are issued, so the LDS
-            // latency hides under matrix work instead of stalling every MFMA pair
+            // fragments of k-step kk+1 are requested from LDS before the 8 MFMAs of k-step kk are issued
             float fa[2][4], fb[2][4][2];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -201,6 +209,10 @@ __global__ void __launch_bounds__(256, 2) wino_k3s1_kernel(const WinoParams p) {
             }
         }
         __syncthreads();
+    };
+    for (int ch = 0; ch < total_chunks; ch += 2) {
+        chunk(ch, std::integral_constant<int, 0>{});
+        if (ch + 1 < total_chunks) chunk(ch + 1, std::integral_constant<int, 1>{});
     }
 
     // ---- epilogue.  Each wave holds a whole Winograd row (4 column components), so the column half of A^T M A runs in
