@@ -45,6 +45,37 @@ def parse():
     return ap.parse_args()
 
 
+# bench kernel name -> substrings of the rocprofv3 kernel names (tools/summarize_prof.py) that make it up
+_PMC_NAMES = {
+    "conv_mfma_kernel<convT4,16x16>": ["convT4,tile 1x16x16", "convT4,tile 1x8x16"],
+    "conv_mfma_kernel<k3s1,16x16>": ["k3s1,tile 1x16x16", "k3s1,tile 1x8x16"],
+    "wino_k3s1_kernel<F(2x2,3x3)>": ["wino_k3s1_kernel"],
+    "conv_mfma_kernel<k5s1,16x16>": ["k5s1,tile"],
+    "grid_sample_fwd_kernel": ["grid_sample_fwd2_kernel"],
+}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the committed PMC summary of this round (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    passes, tools/profile_round.sh): (2*FETCH_SIZE + WRITE_SIZE) KB -- FETCH_SIZE counts 128-B requests as 64 B on gfx950
+    (MI355X_MICROARCH.md, HBM section).  None when no summary is committed for this kernel."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    if not os.path.exists(path) or kernel not in _PMC_NAMES:
+        return None
+    try:
+        with open(path) as f:
+            pmc = json.load(f)
+    except Exception:
+        return None
+    tot, n = 0.0, 0
+    for k, v in pmc.items():
+        if any(sub in k for sub in _PMC_NAMES[kernel]) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            d = v["FETCH_SIZE"]["dispatches"]
+            tot += (2.0 * v["FETCH_SIZE"]["mean_per_dispatch"] + v["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0 * d
+            n += d
+    return round(tot / n) if n else None
+
+
 def usable_cores():
     """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
     try:
@@ -196,7 +227,8 @@ def main():
             name, (cnt, fl, by, ms) = dom
             ach = fl / (ms * 1e-3) / 1e12
             line["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS,
-                                "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                                "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": pmc_traffic(name),
+                                "algorithmic_bytes_per_launch": round(by / cnt),
                                 "launches": cnt, "avg_launch_us": round(1e3 * ms / cnt, 2),
                                 "flops_per_launch": fl / cnt}
             tot_ms = sum(v[3] for v in agg.values())

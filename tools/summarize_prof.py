@@ -25,9 +25,9 @@ def short(name):
     m = re.match(r"pws::conv_mfma_kernel<pws::ConvCfg<([^>]*)>\s*>", name)
     if m:
         a = [x.strip() for x in m.group(1).split(",")]
+        sub = {"0": "", "1": ",convT4", "2": ",dgrad-subpix", "true": ",convT4", "false": ""}.get(a[3], "," + a[3])
         return "conv_mfma_kernel<k%ss%s%s,tile %sx%sx%s,CK%s%s>" % (
-            a[0], a[1], ",convT" if a[3].startswith("t") else "", a[6], a[4], a[5], a[7],
-            ",NCHW" if len(a) > 12 and a[12].startswith("t") else "")
+            a[0], a[1], sub, a[6], a[4], a[5], a[7], ",NCHW" if len(a) > 12 and a[12].startswith("t") else "")
     return re.sub(r"\(.*", "", name).replace("pws::", "")[:100]
 
 
