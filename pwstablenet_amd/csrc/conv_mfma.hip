@@ -509,11 +509,11 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
     case PWS_CONVT_K3S1: {
         kp.OH = kp.LH = a->h, kp.OW = kp.LW = a->w;
         const ProfInfo pi = info(9, (double)a->n * a->h * a->w);
-        // Winograd F(2x2,3x3) when its 16x16-pixel x 64-channel workgroups fill the chip (2.25x fewer multiplies);
-        // the deep, small maps stay on the direct kernel + split-K
+        // Winograd F(2x2,3x3) when there is enough of the map to fill the chip (measured cross-over, tools/conv_bench.py:
+        // 256->256 @32x32 x8: 104 -> 79 us; 512->512 @16x16 x8: 106 -> 138 us); the deep maps stay direct + split-K
         const long wblocks = cdiv(a->w, 16) * cdiv(a->h, 16) * a->n * cdiv(a->cout, 64);
         // (measured: with <= 64 input channels the per-workgroup prologue/epilogue outweighs the saving unless the map is huge)
-        if (a->w_wino && !nchw && a->h >= 16 && a->w >= 16 && wblocks >= 256 && (cin >= 128 || wblocks >= 2048))
+        if (a->w_wino && !nchw && a->h >= 16 && a->w >= 16 && wblocks >= 128 && (cin >= 128 || wblocks >= 2048))
             return wino_k3s1_launch(a, ProfHint{pi.flops, pi.bytes}, st);
         return select_and_launch(kK3S1, 5, kp, kp.cin_pad, a->out, ws, ws_floats, st, pi);
     }
