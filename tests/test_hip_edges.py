@@ -56,8 +56,11 @@ def test_non_finite_and_far_fields(hip):
     out = PF.grid_sample(img, grid)
     assert torch.equal(out[0, :, 0, :5], torch.zeros((3, 5), device="cuda"))
     assert torch.isfinite(out).all()
+    # ATen's CPU kernel multiplies a NaN weight (inf - inf) into the masked-out tap and returns NaN at the +-inf pixels;
+    # ATen's GPU kernel skips out-of-range taps and returns 0 there, as this kernel does.  Compare the finite pixels.
     ref = torch.nn.functional.grid_sample(img.cpu(), grid.cpu(), align_corners=False)
-    assert (out.cpu() - ref).abs().max().item() < 1e-5
+    fin = torch.isfinite(ref)
+    assert (out.cpu() - ref)[fin].abs().max().item() < 1e-5 and int((~fin).sum()) == 6
     grid[0, 1, 0] = float("nan")
     assert torch.isnan(PF.grid_sample(img, grid)[0, :, 1, 0]).all()
 
