@@ -50,7 +50,17 @@ const char *pws_last_error(void); /* thread-local, never NULL */
 /* Process-wide options.  PWS_OPT_TWO_QUEUES (default 1): the generator forward forks an internal second queue so that
  * stage k+1's encoder runs beside stage k's decoder; 0 = issue everything on the caller's stream (clean per-kernel timing). */
 #define PWS_OPT_TWO_QUEUES 1
+/* PWS_OPT_MATH (default PWS_MATH_FP32): arithmetic of the generator's conv / transposed-conv contractions inside
+ * pws_netg_forward / pws_netg_backward.  PWS_MATH_BF16: operands rounded to bf16 (round-to-nearest-even) as they are
+ * staged into LDS, products accumulated in fp32 on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16); activations, biases,
+ * gradients and master weights stay fp32 in memory.  (BASELINE configs 3/4: "bf16 with MFMA convs"; tolerance vs fp32
+ * stated in tests/test_hip_bf16.py.)  Layers the bf16 kernels do not cover (first layer: 31-channel NCHW window; heads)
+ * keep fp32 arithmetic. */
+#define PWS_OPT_MATH 2
+#define PWS_MATH_FP32 0
+#define PWS_MATH_BF16 1
 int pws_set_option(int key, int value);
+int pws_get_option(int key); /* current value, or PWS_EINVAL */
 /* Number of compute units / XCDs the library sees on the current device (diagnostics). */
 int pws_device_info(int *compute_units, int *arch_is_gfx950);
 
@@ -80,6 +90,13 @@ int pws_pack_conv_weight(const float *w_torch, float *w_packed, int kind, int ci
 size_t pws_packed_wino_floats(int cin, int cout);
 int pws_pack_conv_weight_wino(const float *w_packed, float *w_wino, int cin, int cout, pws_stream_t stream);
 
+/* bf16 copy of a packed weight for the bf16 matrix-core kernels: w_packed is [planes][krows][ncols] fp32 (the forward
+ * layout: planes = taps (x4 classes for CONVT_K4S2), krows = cin padded to 16, ncols = cout; or the data-gradient layout:
+ * planes = gradient taps, krows = cout, ncols = cin).  Result: [planes][ncols padded to 64][krows padded to 32] bf16
+ * (k contiguous: one MFMA B fragment = 8 consecutive k = one 16-byte read), zero padded.  Size in FLOATS (2 bf16 each). */
+size_t pws_packed_bf16_floats(int planes, int krows, int ncols);
+int pws_pack_weight_bf16(const float *w_packed, void *w_bf16, int planes, int krows, int ncols, pws_stream_t stream);
+
 /* One NHWC source of a (virtually concatenated) conv input: `channels` channels starting at `ptr`,
  * consecutive pixels `ld` floats apart.  ptr 16-byte aligned, ld % 4 == 0, channels % 16 == 0. */
 typedef struct pws_src {
@@ -104,6 +121,9 @@ typedef struct pws_conv_args {
                             given and the map is large enough the F(2x2,3x3) kernel runs instead of the direct one */
     void *ws;         /* optional scratch for split-K partial tiles (16-B aligned) or NULL: small-spatial layers */
     size_t ws_bytes;  /* then run un-split.  Any size works; 64 x n*oh*ow*cout*4 bytes never limits the split. */
+    int math;         /* PWS_MATH_FP32 (0) | PWS_MATH_BF16: needs w_bf16 and every source's channels % 32 == 0,
+                         otherwise the launch runs in fp32 */
+    const void *w_bf16; /* bf16 weights from pws_pack_weight_bf16(w_packed, planes, cin padded to 16, cout) or NULL */
 } pws_conv_args;
 
 int pws_conv2d_fwd(const pws_conv_args *args, pws_stream_t stream);
@@ -143,6 +163,8 @@ typedef struct pws_conv_bwd_data_args {
     pws_dst dst[4];
     void *ws;          /* optional split-K scratch, as in pws_conv_args */
     size_t ws_bytes;
+    int math;          /* as in pws_conv_args (bf16 needs w_dgrad_bf16 and cout % 32 == 0) */
+    const void *w_dgrad_bf16; /* pws_pack_weight_bf16(w_dgrad, dgrad taps, cout, cin) or NULL */
 } pws_conv_bwd_data_args;
 int pws_conv2d_bwd_data(const pws_conv_bwd_data_args *args, pws_stream_t stream);
 
@@ -157,6 +179,7 @@ typedef struct pws_conv_bwd_weight_args {
     int gout_ld;
     float *dw_packed;  /* gradient in the FORWARD packed layout (pws_packed_weight_floats), ACCUMULATED into
                           (fp32 atomics: several pixel ranges, and stages 2/3 share weights) */
+    int math;          /* PWS_MATH_BF16: x and dy rounded to bf16 at LDS staging, fp32 accumulation; dW stays fp32 */
 } pws_conv_bwd_weight_args;
 int pws_conv2d_bwd_weight(const pws_conv_bwd_weight_args *args, pws_stream_t stream);
 

@@ -5,6 +5,7 @@
 
 namespace pws {
 bool g_two_queues = true;
+int g_math = PWS_MATH_FP32;
 bool g_prof_on = false;
 int g_prof_tag = -1;
 namespace {
@@ -32,7 +33,7 @@ const char *const kKernelNames[KID_COUNT] = {
     "grid_sample_bwd_kernel", "upsample_grid_sample_fwd_kernel", "upsample_bilinear_ac_kernel", "affine_grid_kernel",
     "adam_kernel", "pack_weight_kernel", "conv_mfma_kernel<dgrad k4s2>", "conv_mfma_kernel<dgrad subpix k3s2>",
     "wgrad_mfma_kernel", "act_bwd_bias_kernel", "field_head_bwd_kernels", "theta_head_bwd_kernels",
-    "wino_k3s1_kernel<F(2x2,3x3)>"};
+    "wino_k3s1_kernel<F(2x2,3x3)>", "conv_bf16_kernel", "wgrad_bf16_kernel"};
 }  // namespace
 
 void prof_begin(int kernel_id, double flops, double bytes, hipStream_t st) {
@@ -110,6 +111,21 @@ extern "C" int pws_set_option(int key, int value) {
         pws::g_two_queues = value != 0;
         return PWS_OK;
     }
+    if (key == PWS_OPT_MATH) {
+        if (value != PWS_MATH_FP32 && value != PWS_MATH_BF16) {
+            pws::set_error("pws_set_option: PWS_OPT_MATH value %d is not PWS_MATH_FP32 / PWS_MATH_BF16", value);
+            return PWS_EINVAL;
+        }
+        pws::g_math = value;
+        return PWS_OK;
+    }
     pws::set_error("pws_set_option: unknown key %d", key);
+    return PWS_EINVAL;
+}
+
+extern "C" int pws_get_option(int key) {
+    if (key == PWS_OPT_TWO_QUEUES) return pws::g_two_queues ? 1 : 0;
+    if (key == PWS_OPT_MATH) return pws::g_math;
+    pws::set_error("pws_get_option: unknown key %d", key);
     return PWS_EINVAL;
 }

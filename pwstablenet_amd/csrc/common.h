@@ -47,9 +47,10 @@ enum KernelId {
     KID_CONV_K3S1_BIG = 0, KID_CONV_K3S1_SMALL, KID_CONV_K3S2_BIG, KID_CONV_K3S2_SMALL, KID_CONV_K5S1, KID_CONVT4_BIG,
     KID_CONVT4_SMALL, KID_THETA_HEAD, KID_FIELD_HEAD, KID_GRID_SAMPLE_FWD, KID_GRID_SAMPLE_BWD, KID_UPSAMPLE_GRID_SAMPLE_FWD,
     KID_UPSAMPLE, KID_AFFINE_GRID, KID_ADAM, KID_PACK, KID_DGRAD_K4S2, KID_DGRAD_SP3, KID_WGRAD, KID_ACT_BWD, KID_FIELD_HEAD_BWD,
-    KID_THETA_HEAD_BWD, KID_CONV_WINO, KID_COUNT
+    KID_THETA_HEAD_BWD, KID_CONV_WINO, KID_CONV_BF16, KID_WGRAD_BF16, KID_COUNT
 };
 extern bool g_two_queues;
+extern int g_math;  // PWS_OPT_MATH
 extern bool g_prof_on;
 extern int g_prof_tag;
 void prof_begin(int kernel_id, double flops, double bytes, hipStream_t st);
@@ -69,6 +70,17 @@ struct ProfHint {
     double flops, bytes;
 };
 int wino_k3s1_launch(const pws_conv_args *a, const ProfHint &ph, hipStream_t st);  // conv_wino.hip
+
+// bf16 operand helpers (conv_bf16.hip, wgrad_bf16.hip)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// two floats -> two bf16 (round to nearest even) in one dword: v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
+}
 
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == PWS_ACT_LRELU) return v > 0.f ? v : 0.2f * v;

@@ -1,0 +1,328 @@
+// Implicit-GEMM convolution / transposed convolution on the bf16 matrix cores of gfx950
+// (v_mfma_f32_32x32x16_bf16: 16 k per instruction, 8 passes -> 16x the rate of the exact-fp32 MFMA), fp32 accumulation.
+// "bf16 with MFMA convs" of BASELINE configs 3/4; selected per launch by pws_conv_args.math / PWS_OPT_MATH.
+//
+// Same GEMM view, tiling, virtual concat, sub-pixel modes, split-K and epilogue as conv_mfma.hip (M = output pixels,
+// N = cout, K = taps x cin); what differs is the operand path:
+//   * activations stay fp32 in HBM; the halo'd input tile is converted to bf16 (round to nearest even, v_cvt_pk_bf16_f32)
+//     on its way into LDS, as [pixel][CK bf16] rows of CK*2 + 16 bytes;
+//   * weights come pre-packed as bf16 [class*tap][cout padded to 64][cin padded to 32] (pws_pack_weight_bf16: k contiguous),
+//     staged as [tap][cout row][CK bf16] rows of the same pitch;
+//   * an MFMA operand is 8 consecutive k per lane = ONE 16-byte LDS read (ds_read_b128) for 16 k-steps of the fp32 kernel's
+//     scalar reads; the row pitch (80 B for CK = 32, 48 B for CK = 16) spreads 16 consecutive rows over all 64 banks.
+//   * CK = 32 channels per chunk for the stride-1 kinds, 16 for the stride-2 kinds (their halo tile is 4x larger).
+// Numerics: each product is exact in fp32 (bf16 x bf16), sums are fp32; the only rounding added to the fp32 path is the
+// bf16 rounding of the operands (relative 2^-9 each).  tests/test_hip_bf16.py checks the kernel against the fp32 kernel run on
+// pre-rounded operands (tight) and against unrounded fp32 (stated tolerance).
+#include "conv_common.h"
+
+namespace pws {
+
+template <int KS_, int STRIDE_, int PAD_, int SUBPIX_, int TH_, int TW_, int TN_, int CK_, int WM_, int WN_, int MT_, int NT_>
+struct BfCfg {
+    static constexpr int KS = KS_, STRIDE = STRIDE_, PAD = PAD_, TH = TH_, TW = TW_, TN = TN_, CK = CK_;
+    static constexpr int SUBPIX = SUBPIX_;
+    static constexpr bool CONVT = SUBPIX_ != 0;
+    static constexpr int WM = WM_, WN = WN_, MT = MT_, NT = NT_;
+    static constexpr int THREADS = 64 * WM * WN;
+    static constexpr int BM = TH * TW * TN, BN = 32 * NT * WN;
+    static_assert(BM == 32 * MT * WM, "tile pixels must equal the M extent of the wave grid");
+    static_assert(CK == 16 || CK == 32, "CK");
+    static constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
+    static constexpr int PIX = TN * IH * IW;
+    static constexpr int TAPS = KS * KS;
+    static constexpr int PITCH = CK * 2 + 16;          // bytes per LDS row
+    static constexpr int LDS_IN = PIX * PITCH;         // bytes (multiple of 16)
+    static constexpr int LDS_W = TAPS * BN * PITCH;
+    static constexpr int LDS_BYTES = LDS_IN + LDS_W + 16;  // + a 16-byte sink for the staging items past the tile
+    static constexpr int C8 = CK / 8;                  // 8-channel (16-byte bf16) items per row
+    static constexpr int N_IN = PIX * C8, N_W = TAPS * BN * C8;
+    static constexpr int ITEMS_IN = (N_IN + THREADS - 1) / THREADS;
+    static constexpr int ITEMS_W = (N_W + THREADS - 1) / THREADS;
+    static_assert(BN == 64, "weights are padded to 64 output channels per block");
+};
+
+template <class C>
+__global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_kernel(const ConvKParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned char *lds_in = lds_raw;
+    unsigned char *lds_w = lds_raw + C::LDS_IN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wm = wv / C::WN, wn = wv % C::WN;
+
+    const unsigned tile = xcd_remap(blockIdx.x, p.ntiles);
+    const int tx_i = tile % p.tiles_x;
+    const int ty_i = (tile / p.tiles_x) % p.tiles_y;
+    const int tn_i = tile / (p.tiles_x * p.tiles_y);
+    const int n0 = tn_i * C::TN, y0 = ty_i * C::TH, x0 = tx_i * C::TW;
+    const int co0 = blockIdx.y * C::BN;
+    const int cls = C::CONVT ? (int)(blockIdx.z & 3) : 0;
+    const int split = C::CONVT ? (int)(blockIdx.z >> 2) : (int)blockIdx.z;
+    const int py = cls >> 1, px = cls & 1;
+    const int pad_y = C::SUBPIX == 1 ? 1 - py : (C::SUBPIX == 2 ? 0 : C::PAD);
+    const int pad_x = C::SUBPIX == 1 ? 1 - px : (C::SUBPIX == 2 ? 0 : C::PAD);
+    const int iy0 = y0 * C::STRIDE - pad_y, ix0 = x0 * C::STRIDE - pad_x;
+
+    // ---- staging descriptors.  All global loads are unconditional (masked items read a valid dummy address and are
+    // zeroed by a select): a conditional load would make hipcc wait vmcnt(0) per load.
+    int g_pix[C::ITEMS_IN], l_off[C::ITEMS_IN];
+    unsigned ok_mask = 0;
+#pragma unroll
+    for (int it = 0; it < C::ITEMS_IN; ++it) {
+        const int item = tid + it * C::THREADS;
+        const int pix = item / C::C8, c8 = item % C::C8;
+        const int lx = pix % C::IW, ly = (pix / C::IW) % C::IH, tn = pix / (C::IW * C::IH);
+        const int n = n0 + tn, iy = iy0 + ly, ix = ix0 + lx;
+        const bool ok = item < C::N_IN && n < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        g_pix[it] = ok ? (n * p.H + iy) * p.W + ix : 0;
+        ok_mask |= ok ? (1u << it) : 0u;
+        l_off[it] = item < C::N_IN ? pix * C::PITCH + c8 * 16 : C::LDS_IN + C::LDS_W;  // past the tile: the sink
+    }
+    static_assert(C::ITEMS_IN <= 32, "mask width");
+    // weight items: (tap, cout row, 8-k group); rows co0..co0+63 always exist in the padded bf16 weights
+    int w_off[C::ITEMS_W], lw_off[C::ITEMS_W];
+#pragma unroll
+    for (int it = 0; it < C::ITEMS_W; ++it) {
+        const int item = tid + it * C::THREADS;
+        const int row = item / C::C8, c8 = item % C::C8;
+        const int tap = row / C::BN, nn = row % C::BN;
+        w_off[it] = item < C::N_W ? ((tap * p.npad_bf + co0 + nn) * p.kpad_bf + c8 * 8) : 0;
+        lw_off[it] = item < C::N_W ? C::LDS_IN + row * C::PITCH + c8 * 16 : C::LDS_IN + C::LDS_W;
+    }
+    const __bf16 *w_cls = static_cast<const __bf16 *>(p.w_bf) + (size_t)cls * C::TAPS * p.npad_bf * p.kpad_bf;
+    f32x4 r_in[C::ITEMS_IN][2];
+    u32x4 r_w[C::ITEMS_W];
+
+    auto load_chunk = [&](int s, int c0, int wrow) {
+        const float *sp = p.src_ptr[s] + c0;
+        const size_t ld = p.src_ld[s];
+#pragma unroll
+        for (int it = 0; it < C::ITEMS_IN; ++it) {
+            const float *g = sp + (size_t)g_pix[it] * ld + ((tid + it * C::THREADS) % C::C8) * 8;
+            r_in[it][0] = *reinterpret_cast<const f32x4 *>(g);
+            r_in[it][1] = *reinterpret_cast<const f32x4 *>(g + 4);
+        }
+        const __bf16 *wp = w_cls + wrow;
+#pragma unroll
+        for (int it = 0; it < C::ITEMS_W; ++it) r_w[it] = *reinterpret_cast<const u32x4 *>(wp + w_off[it]);
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int it = 0; it < C::ITEMS_IN; ++it) {
+            const bool ok = (ok_mask >> it) & 1u;
+            u32x4 v;
+            v.x = ok ? cvt_pk_bf16(r_in[it][0].x, r_in[it][0].y) : 0u, v.y = ok ? cvt_pk_bf16(r_in[it][0].z, r_in[it][0].w) : 0u;
+            v.z = ok ? cvt_pk_bf16(r_in[it][1].x, r_in[it][1].y) : 0u, v.w = ok ? cvt_pk_bf16(r_in[it][1].z, r_in[it][1].w) : 0u;
+            *reinterpret_cast<u32x4 *>(lds_raw + l_off[it]) = v;
+        }
+#pragma unroll
+        for (int it = 0; it < C::ITEMS_W; ++it) *reinterpret_cast<u32x4 *>(lds_raw + lw_off[it]) = r_w[it];
+    };
+
+    f32x16 acc[C::MT][C::NT];
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    // operand bases (bytes): lane = (row l31, k half hi) reads 16 bytes = k 8*hi .. 8*hi+7 of the current 16-k step
+    int a_base[C::MT];
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt) {
+        const int m = (wm * C::MT + mt) * 32 + l31;
+        const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
+        a_base[mt] = ((tn * C::IH + ty * C::STRIDE) * C::IW + tx * C::STRIDE) * C::PITCH + hi * 16;
+    }
+    const int b_base = (wn * C::NT * 32 + l31) * C::PITCH + hi * 16;
+
+    int total_chunks = 0;
+    for (int s = 0; s < p.nsrc; ++s) total_chunks += p.src_c[s] / C::CK;
+    const int ch_begin = split * p.chunks_per_split;
+    const int ch_end = min(total_chunks, ch_begin + p.chunks_per_split);
+    int s = 0, c0 = ch_begin * C::CK, wrow = ch_begin * C::CK;
+    while (s < p.nsrc - 1 && c0 >= p.src_c[s]) c0 -= p.src_c[s], ++s;
+    if (ch_begin < ch_end) load_chunk(s, c0, wrow);
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+        __syncthreads();  // everyone finished reading the previous chunk from LDS
+        store_chunk();
+        __syncthreads();
+        c0 += C::CK, wrow += C::CK;
+        if (c0 >= p.src_c[s]) ++s, c0 = 0;
+        if (ch + 1 < ch_end) load_chunk(s, c0, wrow);
+
+#pragma unroll
+        for (int tap = 0; tap < C::TAPS; ++tap) {
+            if (C::SUBPIX == 2 && ((!py && tap / C::KS) || (!px && tap % C::KS))) continue;  // block-uniform
+            const int toff = ((tap / C::KS) * C::IW + (tap % C::KS)) * C::PITCH;
+#pragma unroll
+            for (int ks = 0; ks < C::CK / 16; ++ks) {
+                bf16x8 a[C::MT], b[C::NT];
+#pragma unroll
+                for (int mt = 0; mt < C::MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8 *>(lds_in + a_base[mt] + toff + ks * 32);
+#pragma unroll
+                for (int nt = 0; nt < C::NT; ++nt)
+                    b[nt] = *reinterpret_cast<const bf16x8 *>(lds_w + b_base + (tap * C::BN + nt * 32) * C::PITCH + ks * 32);
+#pragma unroll
+                for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < C::NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue (as conv_mfma.hip): bias + activation / gradient scatter, or raw partial sums when K is split
+    const bool partial = p.ksplit > 1;
+    float *part = p.out + (size_t)split * p.split_stride;
+#pragma unroll
+    for (int nt = 0; nt < C::NT; ++nt) {
+        const int co = co0 + (wn * C::NT + nt) * 32 + l31;
+        const bool co_ok = co < p.cout;
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (wm * C::MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
+                const int n = n0 + tn, y = y0 + ty, x = x0 + tx;
+                const int oy = C::CONVT ? 2 * y + py : y, ox = C::CONVT ? 2 * x + px : x;
+                if (co_ok && n < p.N && y < p.LH && x < p.LW && oy < p.OH && ox < p.OW) {
+                    const size_t pix = (size_t)(n * p.OH + oy) * p.OW + ox;
+                    if (partial)
+                        part[pix * p.cout + co] = acc[mt][nt][r];
+                    else
+                        epi_store(p, pix, co, acc[mt][nt][r]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+template <class C>
+static int launch_bf(ConvKParams &kp, hipStream_t st, const ProfInfo &) {
+    static bool attr_set = false;  // benign race: idempotent
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_kernel<C>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(conv_bf16_kernel, %d B LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
+            return PWS_EHIP;
+        }
+        attr_set = true;
+    }
+    dim3 grid(kp.ntiles, (kp.cout + C::BN - 1) / C::BN, kp.nclasses * kp.ksplit);
+    hipLaunchKernelGGL(conv_bf16_kernel<C>, grid, dim3(C::THREADS), C::LDS_BYTES, st, kp);
+    return check_launch("conv_bf16_kernel");
+}
+
+template <class C>
+static constexpr TileChoice bchoice() {
+    return TileChoice{C::TH, C::TW, C::TN, C::CK, C::BN, KID_CONV_BF16, &launch_bf<C>};
+}
+
+//                     KS S  P  subpix TH  TW  TN  CK WM WN MT NT
+using B_K3S1_T256 = BfCfg<3, 1, 1, 0, 16, 16, 1, 32, 4, 1, 2, 2>;
+using B_K3S1_T128 = BfCfg<3, 1, 1, 0, 8, 16, 1, 32, 4, 1, 1, 2>;
+using B_K3S1_T64 = BfCfg<3, 1, 1, 0, 8, 8, 1, 32, 2, 2, 1, 1>;
+using B_K3S1_T64N4 = BfCfg<3, 1, 1, 0, 4, 4, 4, 32, 2, 2, 1, 1>;
+using B_K3S1_T64N16 = BfCfg<3, 1, 1, 0, 2, 2, 16, 32, 2, 2, 1, 1>;
+using B_K3S2_T256 = BfCfg<3, 2, 1, 0, 16, 16, 1, 16, 4, 1, 2, 2>;
+using B_K3S2_T128 = BfCfg<3, 2, 1, 0, 8, 16, 1, 16, 4, 1, 1, 2>;
+using B_K3S2_T64 = BfCfg<3, 2, 1, 0, 8, 8, 1, 16, 2, 2, 1, 1>;
+using B_K3S2_T64N4 = BfCfg<3, 2, 1, 0, 4, 4, 4, 16, 2, 2, 1, 1>;
+using B_K3S2_T64N16 = BfCfg<3, 2, 1, 0, 2, 2, 16, 16, 2, 2, 1, 1>;
+using B_CT4_T256 = BfCfg<2, 1, 0, 1, 16, 16, 1, 32, 4, 1, 2, 2>;
+using B_CT4_T128 = BfCfg<2, 1, 0, 1, 8, 16, 1, 32, 4, 1, 1, 2>;
+using B_CT4_T64 = BfCfg<2, 1, 0, 1, 8, 8, 1, 32, 2, 2, 1, 1>;
+using B_CT4_T64N4 = BfCfg<2, 1, 0, 1, 4, 4, 4, 32, 2, 2, 1, 1>;
+using B_CT4_T64N16 = BfCfg<2, 1, 0, 1, 2, 2, 16, 32, 2, 2, 1, 1>;
+// data-gradient kinds: conv k4 s2 p1 over dy (gradient of ConvTranspose2d k4 s2 p1), sub-pixel gradient of conv k3 s2 p1
+using B_K4S2_T128 = BfCfg<4, 2, 1, 0, 8, 16, 1, 16, 4, 1, 1, 2>;
+using B_K4S2_T64 = BfCfg<4, 2, 1, 0, 8, 8, 1, 16, 2, 2, 1, 1>;
+using B_K4S2_T64N4 = BfCfg<4, 2, 1, 0, 4, 4, 4, 16, 2, 2, 1, 1>;
+using B_K4S2_T64N16 = BfCfg<4, 2, 1, 0, 2, 2, 16, 16, 2, 2, 1, 1>;
+using B_SP3_T256 = BfCfg<2, 1, 0, 2, 16, 16, 1, 32, 4, 1, 2, 2>;
+using B_SP3_T128 = BfCfg<2, 1, 0, 2, 8, 16, 1, 32, 4, 1, 1, 2>;
+using B_SP3_T64 = BfCfg<2, 1, 0, 2, 8, 8, 1, 32, 2, 2, 1, 1>;
+using B_SP3_T64N4 = BfCfg<2, 1, 0, 2, 4, 4, 4, 32, 2, 2, 1, 1>;
+using B_SP3_T64N16 = BfCfg<2, 1, 0, 2, 2, 2, 16, 32, 2, 2, 1, 1>;
+
+static const TileChoice kBK3S1[] = {bchoice<B_K3S1_T256>(), bchoice<B_K3S1_T128>(), bchoice<B_K3S1_T64>(), bchoice<B_K3S1_T64N4>(),
+                                    bchoice<B_K3S1_T64N16>()};
+static const TileChoice kBK3S2[] = {bchoice<B_K3S2_T256>(), bchoice<B_K3S2_T128>(), bchoice<B_K3S2_T64>(), bchoice<B_K3S2_T64N4>(),
+                                    bchoice<B_K3S2_T64N16>()};
+static const TileChoice kBCT4[] = {bchoice<B_CT4_T256>(), bchoice<B_CT4_T128>(), bchoice<B_CT4_T64>(), bchoice<B_CT4_T64N4>(),
+                                   bchoice<B_CT4_T64N16>()};
+static const TileChoice kBK4S2[] = {bchoice<B_K4S2_T128>(), bchoice<B_K4S2_T64>(), bchoice<B_K4S2_T64N4>(), bchoice<B_K4S2_T64N16>()};
+static const TileChoice kBSP3[] = {bchoice<B_SP3_T256>(), bchoice<B_SP3_T128>(), bchoice<B_SP3_T64>(), bchoice<B_SP3_T64N4>(),
+                                   bchoice<B_SP3_T64N16>()};
+
+// Forward kinds.  kp is fully prepared by conv2d_fwd_impl (conv_mfma.hip); returns 1 when this launch is not covered by
+// the bf16 kernels (the caller then runs the fp32 path), else the launch status.
+int conv_bf16_fwd(int kind, ConvKParams &kp, int cin_total, float *out, float *ws, size_t ws_floats, hipStream_t st,
+                  const ProfInfo &pi) {
+    for (int s = 0; s < kp.nsrc; ++s)
+        if (kp.src_c[s] % 32 != 0) return 1;
+    switch (kind) {
+    case PWS_CONV_K3S1:
+    case PWS_CONVT_K3S1: return select_and_launch(kBK3S1, 5, kp, cin_total, out, ws, ws_floats, st, pi);
+    case PWS_CONV_K3S2: return select_and_launch(kBK3S2, 5, kp, cin_total, out, ws, ws_floats, st, pi);
+    case PWS_CONVT_K4S2: return select_and_launch(kBCT4, 5, kp, cin_total, out, ws, ws_floats, st, pi);
+    default: return 1;
+    }
+}
+
+// Data-gradient kinds (kp prepared by conv2d_bwd_data_impl).
+int conv_bf16_dgrad(int kind, ConvKParams &kp, int cout_f, float *ws, size_t ws_floats, hipStream_t st, const ProfInfo &pi) {
+    if (cout_f % 32 != 0) return 1;
+    switch (kind) {
+    case PWS_CONV_K3S1:
+    case PWS_CONVT_K3S1: return select_and_launch(kBK3S1, 5, kp, cout_f, nullptr, ws, ws_floats, st, pi);
+    case PWS_CONV_K3S2: return select_and_launch(kBSP3, 5, kp, cout_f, nullptr, ws, ws_floats, st, pi);
+    case PWS_CONVT_K4S2: return select_and_launch(kBK4S2, 4, kp, cout_f, nullptr, ws, ws_floats, st, pi);
+    default: return 1;
+    }
+}
+
+// [planes][krows][ncols] fp32 -> [planes][ncols padded to 64][krows padded to 32] bf16 (zero padded); one lane per
+// destination pair of k (coalesced 4-byte writes; the strided reads go through L2 -- this runs once per weight update).
+__global__ void pack_bf16_kernel(const float *__restrict__ w, unsigned *__restrict__ out, int krows, int ncols, int kpad, int npad,
+                                 size_t total_pairs) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_pairs) return;
+    const int kp2 = kpad / 2;
+    const int k = (int)(i % kp2) * 2;
+    const size_t t = i / kp2;
+    const int n = (int)(t % npad);
+    const size_t plane = t / npad;
+    float a = 0.f, b = 0.f;
+    if (n < ncols) {
+        const float *src = w + (plane * krows) * ncols + n;
+        if (k < krows) a = src[(size_t)k * ncols];
+        if (k + 1 < krows) b = src[(size_t)(k + 1) * ncols];
+    }
+    out[i] = cvt_pk_bf16(a, b);
+}
+
+}  // namespace pws
+
+extern "C" size_t pws_packed_bf16_floats(int planes, int krows, int ncols) {
+    if (planes <= 0 || krows <= 0 || ncols <= 0) return 0;
+    const size_t kpad = (size_t)(krows + 31) / 32 * 32, npad = (size_t)(ncols + 63) / 64 * 64;
+    return (size_t)planes * npad * kpad / 2;
+}
+
+extern "C" int pws_pack_weight_bf16(const float *w_packed, void *w_bf16, int planes, int krows, int ncols, pws_stream_t stream) {
+    PWS_REQUIRE(w_packed && w_bf16 && planes > 0 && krows > 0 && ncols > 0, "pws_pack_weight_bf16: bad arguments");
+    const int kpad = (krows + 31) / 32 * 32, npad = (ncols + 63) / 64 * 64;
+    const size_t pairs = (size_t)planes * npad * kpad / 2;
+    hipLaunchKernelGGL(pws::pack_bf16_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, pws::as_stream(stream), w_packed,
+                       static_cast<unsigned *>(w_bf16), krows, ncols, kpad, npad, pairs);
+    return pws::check_launch("pack_bf16_kernel");
+}

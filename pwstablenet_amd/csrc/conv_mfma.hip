@@ -22,54 +22,9 @@
 //     small reduce kernel adds the partials, the bias and the activation (deterministic; no atomics).
 //
 // Numerics: fp32 in / fp32 accumulate; v_mfma_f32_32x32x2_f32 is bit-for-bit an fmaf chain in k order.
-#include "common.h"
+#include "conv_common.h"
 
 namespace pws {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct ConvKParams {
-    const float *src_ptr[4];
-    int src_c[4];
-    int src_ld[4];
-    int nsrc;
-    int N, H, W;   // input
-    int LH, LW;    // logical output extent walked by the tiles (conv: OH,OW ; convT k4s2: H,W)
-    int OH, OW;    // output tensor extent
-    int cin_pad;   // rows per tap in the packed weights
-    int cout;
-    const float *w;
-    const float *bias;
-    float *out;     // final output, or the partial buffer when ksplit > 1
-    int out_ld;
-    int act;
-    int tiles_x, tiles_y;
-    unsigned ntiles;
-    int nclasses;   // 4 for the sub-pixel modes, else 1
-    int ksplit;     // >= 1
-    int chunks_per_split;
-    size_t split_stride;  // floats between consecutive partial buffers
-    // data-gradient mode: the output channels are scattered over up to 4 NHWC destinations (the sources of the
-    // forward layer's virtual concat), each either overwritten or accumulated into.  ndst == 0: plain `out`.
-    int ndst;
-    float *dst_ptr[4];
-    int dst_c0[4], dst_c1[4], dst_ld[4], dst_acc[4];
-};
-
-// final store of one output element (pixel index `pix` in the output tensor, channel `co`)
-__device__ __forceinline__ void epi_store(const ConvKParams &p, size_t pix, int co, float v) {
-    if (p.ndst == 0) {
-        p.out[pix * p.out_ld + co] = act_apply(v + (p.bias ? p.bias[co] : 0.f), p.act);
-    } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (s < p.ndst && co >= p.dst_c0[s] && co < p.dst_c1[s]) {
-                float *d = p.dst_ptr[s] + pix * p.dst_ld[s] + (co - p.dst_c0[s]);
-                *d = p.dst_acc[s] ? *d + v : v;
-            }
-        }
-    }
-}
 
 // SUBPIX: 0 = ordinary convolution; 1 = ConvTranspose2d k4 s2 p1 forward (output parity class (py,px) is a 2x2
 // convolution whose window starts at (y+py-1, x+px-1)); 2 = data gradient of Conv2d k3 s2 p1 (class (py,px) is a 2x2
@@ -321,17 +276,12 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvKParams p,
     epi_store(p, pix, co, a.x), epi_store(p, pix, co + 1, a.y), epi_store(p, pix, co + 2, a.z), epi_store(p, pix, co + 3, a.w);
 }
 
+int launch_splitk_reduce(const ConvKParams &kp, const float *partial, size_t total4, hipStream_t st) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, kp, partial, total4);
+    return check_launch("splitk_reduce_kernel");
+}
+
 // ------------------------------------------------------------------------------------------------ host side
-struct ProfInfo {
-    double flops, bytes;
-};
-
-struct TileChoice {  // one instantiation, described for the selector
-    int th, tw, tn, ck, bn;
-    int kid;
-    int (*launch)(ConvKParams &, hipStream_t, const ProfInfo &);
-};
-
 template <class C, int KID>
 static int launch_cfg(ConvKParams &kp, hipStream_t st, const ProfInfo &pi) {
     static bool attr_set = false;  // benign race: idempotent
@@ -404,59 +354,9 @@ static const TileChoice kSP3[] = {choice<SP3_T256, KID_DGRAD_SP3>(), choice<SP3_
 static const TileChoice kK5[] = {choice<K5S1_T256, KID_CONV_K5S1>()};
 static const TileChoice kK5N[] = {choice<K5S1_T256_NCHW, KID_CONV_K5S1>()};
 
-static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
-
-constexpr long kFillBlocks = 512;  // 256 CUs x 2 resident workgroups
-
-// Pick the tile and the K split for one launch.
-//  1. drop tiles that are mostly padding for this extent (a 16x16 tile on an 8x8 map);
-//  2. take the largest remaining tile whose grid has >= kFillBlocks workgroups, else the one with the most workgroups;
-//  3. if the grid is still < kFillBlocks and a workspace was given, split K (>= 2 chunks per split, <= 64 splits).
-static int select_and_launch(const TileChoice *cands, int ncand, ConvKParams &kp, int cin_total, float *final_out,
-                             float *ws, size_t ws_floats, hipStream_t st, const ProfInfo &pi) {
-    const TileChoice *best = nullptr;
-    long best_blocks = -1;
-    double best_score = -1.0;
-    for (int i = 0; i < ncand; ++i) {
-        const TileChoice &c = cands[i];
-        const long tiles = cdiv(kp.LW, c.tw) * cdiv(kp.LH, c.th) * cdiv(kp.N, c.tn);
-        const double useful = (double)kp.N * kp.LH * kp.LW / ((double)tiles * c.th * c.tw * c.tn);
-        if (useful < 0.45 && i + 1 < ncand) continue;
-        // sub-8 spatial tiles exist for maps that are themselves tiny; on a larger map their halo re-reads dominate
-        if (c.th < 8 && c.th < kp.LH && i > 0 && best) continue;
-        const long blocks = tiles * cdiv(kp.cout, c.bn) * kp.nclasses;
-        if (blocks >= kFillBlocks) {
-            best = &c, best_blocks = blocks;
-            break;
-        }
-        if (blocks * useful > best_score) best = &c, best_blocks = blocks, best_score = blocks * useful;
-    }
-    const TileChoice &c = *best;
-    kp.tiles_x = (int)cdiv(kp.LW, c.tw), kp.tiles_y = (int)cdiv(kp.LH, c.th);
-    kp.ntiles = (unsigned)(kp.tiles_x * kp.tiles_y * cdiv(kp.N, c.tn));
-    const int total_chunks = cin_total / c.ck;
-    int ksplit = 1;
-    const size_t out_floats = (size_t)kp.N * kp.OH * kp.OW * kp.cout;
-    if (best_blocks < kFillBlocks && ws && kp.cout % 4 == 0 && total_chunks >= 4) {
-        long want = cdiv(kFillBlocks, best_blocks);
-        if (want > 64) want = 64;
-        if (want > total_chunks / 2) want = total_chunks / 2;
-        while (want > 1 && (size_t)want * out_floats > ws_floats) --want;
-        ksplit = (int)want;
-    }
-    kp.ksplit = ksplit < 1 ? 1 : ksplit;
-    kp.chunks_per_split = (int)cdiv(total_chunks, kp.ksplit);
-    kp.ksplit = (int)cdiv(total_chunks, kp.chunks_per_split);  // no empty splits
-    kp.split_stride = out_floats;
-    kp.out = kp.ksplit > 1 ? ws : final_out;
-    ProfScope prof(c.kid, pi.flops, pi.bytes, st);  // covers the split-K reduce as well
-    int rc = c.launch(kp, st, pi);
-    if (rc != PWS_OK || kp.ksplit == 1) return rc;
-    const size_t total4 = out_floats / 4;
-    kp.out = final_out;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv((long)total4, 256)), dim3(256), 0, st, kp, ws, total4);
-    return check_launch("splitk_reduce_kernel");
-}
+int conv_bf16_fwd(int kind, ConvKParams &kp, int cin_total, float *out, float *ws, size_t ws_floats, hipStream_t st,
+                  const ProfInfo &pi);  // conv_bf16.hip; 1 = not covered
+int conv_bf16_dgrad(int kind, ConvKParams &kp, int cout_f, float *ws, size_t ws_floats, hipStream_t st, const ProfInfo &pi);
 
 int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
     PWS_REQUIRE(a != nullptr, "pws_conv2d_fwd: args is NULL");
@@ -496,6 +396,8 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
     PWS_REQUIRE((size_t)a->n * a->h * a->w < (1u << 31), "pws_conv2d_fwd: n*h*w too large for 32-bit pixel indices");
     float *ws = static_cast<float *>(a->ws);
     const size_t ws_floats = a->ws_bytes / sizeof(float);
+    const bool bf16 = a->math == PWS_MATH_BF16 && a->w_bf16 && !nchw;
+    kp.w_bf = a->w_bf16, kp.kpad_bf = (kp.cin_pad + 31) / 32 * 32, kp.npad_bf = (a->cout + 63) / 64 * 64;
 
     // algorithmic work of this launch (real channels, each tensor touched once)
     auto info = [&](int k2, double out_pix) {
@@ -509,6 +411,10 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
     case PWS_CONVT_K3S1: {
         kp.OH = kp.LH = a->h, kp.OW = kp.LW = a->w;
         const ProfInfo pi = info(9, (double)a->n * a->h * a->w);
+        if (bf16) {
+            const int rc = conv_bf16_fwd(a->kind, kp, kp.cin_pad, a->out, ws, ws_floats, st, pi);
+            if (rc != 1) return rc;
+        }
         // Winograd F(2x2,3x3) when there is enough of the map to fill the chip (measured cross-over, tools/conv_bench.py:
         // 256->256 @32x32 x8: 104 -> 79 us; 512->512 @16x16 x8: 106 -> 138 us); the deep maps stay direct + split-K
         const long wblocks = cdiv(a->w, 16) * cdiv(a->h, 16) * a->n * cdiv(a->cout, 64);
@@ -519,6 +425,10 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
     }
     case PWS_CONV_K3S2:
         kp.OH = kp.LH = (a->h + 2 - 3) / 2 + 1, kp.OW = kp.LW = (a->w + 2 - 3) / 2 + 1;
+        if (bf16) {
+            const int rc = conv_bf16_fwd(a->kind, kp, kp.cin_pad, a->out, ws, ws_floats, st, info(9, (double)a->n * kp.OH * kp.OW));
+            if (rc != 1) return rc;
+        }
         return select_and_launch(kK3S2, 5, kp, kp.cin_pad, a->out, ws, ws_floats, st, info(9, (double)a->n * kp.OH * kp.OW));
     case PWS_CONV_K5S1:
         kp.OH = kp.LH = a->h, kp.OW = kp.LW = a->w;
@@ -528,6 +438,10 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
         kp.LH = a->h, kp.LW = a->w, kp.OH = 2 * a->h, kp.OW = 2 * a->w, kp.nclasses = 4;
         ProfInfo pi = info(4, (double)a->n * kp.OH * kp.OW);  // every output pixel sees 2x2 taps
         pi.bytes += 4.0 * 12.0 * cin * a->cout;              // all 16 taps of the weight are read
+        if (bf16) {
+            const int rc = conv_bf16_fwd(a->kind, kp, kp.cin_pad, a->out, ws, ws_floats, st, pi);
+            if (rc != 1) return rc;
+        }
         return select_and_launch(kCT4, 5, kp, kp.cin_pad, a->out, ws, ws_floats, st, pi);
     }
     default:
@@ -570,16 +484,22 @@ int conv2d_bwd_data_impl(const pws_conv_bwd_data_args *a, hipStream_t st) {
     const double k2 = a->kind == PWS_CONVT_K4S2 ? 4.0 : 9.0;  // taps per forward OUTPUT pixel
     pi.flops = 2.0 * a->n * oh * ow * (double)a->cout * cin_f * k2;
     pi.bytes = 4.0 * ((double)a->n * oh * ow * a->cout + (double)a->n * a->h * a->w * cin_f);
+    if (a->kind == PWS_CONV_K3S2)
+        kp.LH = oh, kp.LW = ow, kp.nclasses = 4;
+    else
+        kp.LH = a->h, kp.LW = a->w;
+    if (a->math == PWS_MATH_BF16 && a->w_dgrad_bf16) {
+        kp.w_bf = a->w_dgrad_bf16, kp.kpad_bf = (a->cout + 31) / 32 * 32, kp.npad_bf = (cin_f + 63) / 64 * 64;
+        const int rc = conv_bf16_dgrad(a->kind, kp, a->cout, ws, ws_floats, st, pi);
+        if (rc != 1) return rc;
+    }
     switch (a->kind) {
     case PWS_CONV_K3S1:
     case PWS_CONVT_K3S1:
-        kp.LH = a->h, kp.LW = a->w;
         return select_and_launch(kK3S1, 5, kp, a->cout, nullptr, ws, ws_floats, st, pi);
     case PWS_CONV_K3S2:
-        kp.LH = oh, kp.LW = ow, kp.nclasses = 4;
         return select_and_launch(kSP3, 5, kp, a->cout, nullptr, ws, ws_floats, st, pi);
     case PWS_CONVT_K4S2:
-        kp.LH = a->h, kp.LW = a->w;
         return select_and_launch(kK4S2, 5, kp, a->cout, nullptr, ws, ws_floats, st, pi);
     default:
         set_error("pws_conv2d_bwd_data: kind %d has no data gradient here", a->kind);

@@ -258,222 +258,6 @@ __global__ void __launch_bounds__(256, 2) wino_k3s1_kernel(const WinoParams p) {
     }
 }
 
-// (helper functions of the wave-specialised kernel below)
-// The two roles are separate NON-INLINED functions: hipcc otherwise allocates the producers' prefetch registers and the
-// matrix waves' 128 accumulator registers side by side (> 256 VGPRs: the accumulators were spilled around every barrier).
-struct WsCtx {
-    int n, y0, x0, co0, total_chunks;
-};
-
-__device__ __attribute__((noinline)) void ws_producer(const WinoParams &p, const WsCtx c, float *vbuf, float *ubuf) {
-    const int tid = threadIdx.x;
-    const int n = c.n, y0 = c.y0, x0 = c.x0, co0 = c.co0, total_chunks = c.total_chunks;
-    // ---------------- producer waves (threads 256..511) ----------------
-    const int ptid = tid & 255;
-    const int t_tile = ptid >> 3, t_c = ptid & 7;
-    const int t_dst = t_tile * WN_CKP + t_c;
-    // the 16 patch positions: pixel index = pix_base + i*W + j where inside the image (mask bit), else pixel 0
-    unsigned pix_ok = 0;
-    const int py0 = y0 - 1 + 2 * (t_tile >> 3), px0 = x0 - 1 + 2 * (t_tile & 7);
-    const int pix_base = (n * p.H + py0) * p.W + px0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int iy = py0 + i, ix = px0 + j;
-            pix_ok |= (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? (1u << (i * 4 + j)) : 0u;
-        }
-    const int u_q = (ptid & 15) * 4, u_k = (ptid >> 4) & 7;
-    const bool u_ok = co0 + u_q < p.cout;
-    const float *u_base = p.uw + ((size_t)(ptid >> 7) * p.cin_pad + u_k) * p.cout + (u_ok ? co0 + u_q : 0);
-    float r_d[2][16];   // input patches: two register sets, requested two chunks ahead (HBM)
-    float4 r_u[8];      // U chunk: one set, requested one chunk ahead (L2-resident)
-    int s = 0, c0 = 0;  // source cursor of the next patch chunk to request
-    auto load_patch = [&](float (&d)[16]) {
-        const float *sp = p.src_ptr[s] + c0 + t_c;
-        const size_t ld = p.src_ld[s];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int pix = ((pix_ok >> k) & 1u) ? pix_base + (k >> 2) * p.W + (k & 3) : 0;
-            d[k] = sp[(size_t)pix * ld];
-        }
-        c0 += WN_CK;
-        if (c0 >= p.src_c[s] && s < p.nsrc - 1) ++s, c0 = 0;
-    };
-    auto load_u = [&](float4 (&r)[8], int wrow) {
-#pragma unroll
-        for (int it = 0; it < 8; ++it)
-            r[it] = *reinterpret_cast<const float4 *>(u_base + ((size_t)(2 * it) * p.cin_pad + wrow) * p.cout);
-    };
-    auto produce = [&](const float (&dr)[16], const float4 (&ur)[8], int buf) {
-        float *vdst = vbuf + buf * WN_V;
-        float *udst = ubuf + buf * WN_U;
-        float d[4][4];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) d[k >> 2][k & 3] = ((pix_ok >> k) & 1u) ? dr[k] : 0.f;
-        float t[4][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            t[0][j] = d[0][j] - d[2][j], t[1][j] = d[1][j] + d[2][j], t[2][j] = d[2][j] - d[1][j], t[3][j] = d[1][j] - d[3][j];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            vdst[t_dst + (i * 4 + 0) * 32 * WN_CKP] = t[i][0] - t[i][2];
-            vdst[t_dst + (i * 4 + 1) * 32 * WN_CKP] = t[i][1] + t[i][2];
-            vdst[t_dst + (i * 4 + 2) * 32 * WN_CKP] = t[i][2] - t[i][1];
-            vdst[t_dst + (i * 4 + 3) * 32 * WN_CKP] = t[i][1] - t[i][3];
-        }
-#pragma unroll
-        for (int it = 0; it < 8; ++it)
-            *reinterpret_cast<float4 *>(udst + (ptid + it * 256) * 4) = u_ok ? ur[it] : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    load_patch(r_d[0]), load_u(r_u, 0);                                      // chunk 0
-    if (total_chunks > 1) load_patch(r_d[1]);                                // patches of chunk 1
-    produce(r_d[0], r_u, 0);
-    if (total_chunks > 1) load_u(r_u, WN_CK);                                // U of chunk 1
-    if (total_chunks > 2) load_patch(r_d[0]);                                // patches of chunk 2
-    __syncthreads();
-    for (int ch = 0; ch < total_chunks; ch += 2) {
-        // while the matrix waves consume buffers 0 (chunk ch): chunk ch+1 (patch set 1) -> buffers 1
-        if (ch + 1 < total_chunks) produce(r_d[1], r_u, 1);
-        if (ch + 2 < total_chunks) load_u(r_u, (ch + 2) * WN_CK);
-        if (ch + 3 < total_chunks) load_patch(r_d[1]);
-        __syncthreads();
-        if (ch + 1 < total_chunks) {
-            // while they consume buffers 1 (chunk ch+1): chunk ch+2 (patch set 0) -> buffers 0
-            if (ch + 2 < total_chunks) produce(r_d[0], r_u, 0);
-            if (ch + 3 < total_chunks) load_u(r_u, (ch + 3) * WN_CK);
-            if (ch + 4 < total_chunks) load_patch(r_d[0]);
-            __syncthreads();
-        }
-    }
-}
-
-__device__ __attribute__((noinline)) void ws_consumer(const WinoParams &p, const WsCtx c, const float *vbuf, const float *ubuf,
-                                                      float *eb) {
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int total_chunks = c.total_chunks;
-    // ---------------- matrix waves (threads 0..255): wave w owns Winograd row i = w ----------------
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][nn][r] = 0.f;
-    const int a_base = (4 * wv * 32 + l31) * WN_CKP + hi;
-    const int b_base = (4 * wv * WN_CK + hi) * 64 + l31;
-    auto consume = [&](int buf) {
-        const float *v = vbuf + buf * WN_V;
-        const float *u = ubuf + buf * WN_U;
-        float fa[2][4], fb[2][4][2];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            fa[0][j] = v[a_base + j * 32 * WN_CKP];
-            fb[0][j][0] = u[b_base + (j * WN_CK) * 64], fb[0][j][1] = u[b_base + (j * WN_CK) * 64 + 32];
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int cur = kk & 1, nxt = cur ^ 1;
-            if (kk < 3) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    fa[nxt][j] = v[a_base + j * 32 * WN_CKP + 2 * (kk + 1)];
-                    fb[nxt][j][0] = u[b_base + (j * WN_CK + 2 * (kk + 1)) * 64];
-                    fb[nxt][j][1] = u[b_base + (j * WN_CK + 2 * (kk + 1)) * 64 + 32];
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][j], fb[cur][j][0], acc[j][0], 0, 0, 0);
-                acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][j], fb[cur][j][1], acc[j][1], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    __builtin_amdgcn_s_setprio(1);  // matrix waves win issue arbitration on their SIMD
-    __syncthreads();
-    for (int ch = 0; ch < total_chunks; ch += 2) {
-        consume(0);
-        __syncthreads();
-        if (ch + 1 < total_chunks) {
-            consume(1);
-            __syncthreads();
-        }
-    }
-    __builtin_amdgcn_s_setprio(0);
-    // column half of A^T M A in registers, rows meet in LDS (the producers are past their last barrier: V/U are dead)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int trow = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float t0 = acc[0][nt][r] + acc[1][nt][r] + acc[2][nt][r];
-            const float t1 = acc[1][nt][r] - acc[2][nt][r] - acc[3][nt][r];
-            eb[((wv * 2 + 0) * 32 + trow) * WN_EP + nt * 32 + l31] = t0;
-            eb[((wv * 2 + 1) * 32 + trow) * WN_EP + nt * 32 + l31] = t1;
-        }
-}
-
-// ------------------------------------------------------------------------------------------------ wave-specialised variant
-// Same tiling (32 Winograd tiles x 64 channels, chunks of 8 input channels) but the workgroup is 8 waves with two roles:
-//   waves 0-3 ("matrix" waves, one per SIMD): nothing but fragment reads and MFMAs on V[cur] / U[cur];
-//   waves 4-7 ("producer" waves, the other wave of each SIMD): global loads two chunks ahead, the B^T d B input transform
-//             straight from registers (no raw LDS tile) and the U chunk, written into V[nxt] / U[nxt].
-// One workgroup barrier per chunk swaps the buffers.  The producers' VALU / LDS / VMEM work runs beside the matrix waves'
-// MFMAs on the same SIMDs instead of in front of them (in the 4-wave kernel every wave does both, and the staging phase of
-// a chunk is as long as its 2048 matrix cycles).
-constexpr int WS_LDS_MAIN = 2 * WN_V + 2 * WN_U;  // 25600 floats = 102.4 KB: one workgroup (8 waves) per CU
-constexpr int WS_LDS_BYTES = (WS_LDS_MAIN > WN_LDS_EPI ? WS_LDS_MAIN : WN_LDS_EPI) * 4;
-
-__global__ void __launch_bounds__(512, 2) wino_k3s1_ws_kernel(const WinoParams p) {
-    extern __shared__ float lds[];
-    float *vbuf = lds;               // [2][16][32][9]
-    float *ubuf = lds + 2 * WN_V;    // [2][16][8][64]
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool producer = wv >= 4;
-
-    const unsigned tile = xcd_remap(blockIdx.x, p.ntiles);
-    const int tx_i = tile % p.tiles_x, ty_i = (tile / p.tiles_x) % p.tiles_y, n = tile / (p.tiles_x * p.tiles_y);
-    const int y0 = ty_i * WN_TH, x0 = tx_i * WN_TW, co0 = blockIdx.y * 64;
-    int total_chunks = 0;
-    for (int s = 0; s < p.nsrc; ++s) total_chunks += p.src_c[s] / WN_CK;
-
-    float *eb = lds;  // epilogue exchange [i][b][tile][64 + 1], reuses the V/U space after the last barrier
-    const WsCtx ctx{n, y0, x0, co0, total_chunks};
-    if (producer)
-        ws_producer(p, ctx, vbuf, ubuf);
-    else
-        ws_consumer(p, ctx, vbuf, ubuf, eb);
-    __syncthreads();
-    {
-        const int col = tid & 63;
-        const int co = co0 + col;
-        const float bias = (p.bias && co < p.cout) ? p.bias[co] : 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int t = (tid >> 6) + 8 * k;
-            float e[4][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) e[i][0] = eb[((i * 2 + 0) * 32 + t) * WN_EP + col], e[i][1] = eb[((i * 2 + 1) * 32 + t) * WN_EP + col];
-            const float y00 = e[0][0] + e[1][0] + e[2][0], y01 = e[0][1] + e[1][1] + e[2][1];
-            const float y10 = e[1][0] - e[2][0] - e[3][0], y11 = e[1][1] - e[2][1] - e[3][1];
-            const int oy = y0 + 2 * (t >> 3), ox = x0 + 2 * (t & 7);
-            if (co < p.cout) {
-                float *o = p.out + ((size_t)(n * p.H + oy) * p.W + ox) * p.out_ld + co;
-                const size_t rs = (size_t)p.W * p.out_ld;
-                if (oy < p.H && ox < p.W) o[0] = act_apply(y00 + bias, p.act);
-                if (oy < p.H && ox + 1 < p.W) o[p.out_ld] = act_apply(y01 + bias, p.act);
-                if (oy + 1 < p.H && ox < p.W) o[rs] = act_apply(y10 + bias, p.act);
-                if (oy + 1 < p.H && ox + 1 < p.W) o[rs + p.out_ld] = act_apply(y11 + bias, p.act);
-            }
-        }
-    }
-}
-
 // U = G g G^T from the packed correlation kernel P[tap][cin_pad][cout] (so conv and flipped convT are both covered)
 __global__ void wino_pack_kernel(const float *__restrict__ pk, float *__restrict__ uw, size_t plane /* cin_pad*cout */) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -522,22 +306,6 @@ int wino_k3s1_launch(const pws_conv_args *a, const ProfHint &ph, hipStream_t st)
             return PWS_EHIP;
         }
         attr_set = true;
-    }
-    static const int variant = getenv("PWS_WINO_VARIANT") ? atoi(getenv("PWS_WINO_VARIANT")) : 0;  // experiment: 1 = wave-specialised
-    if (variant == 1) {
-        static bool attr2 = false;
-        if (!attr2) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_k3s1_ws_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
-            if (e != hipSuccess) {
-                set_error("hipFuncSetAttribute(wino_k3s1_ws_kernel): %s", hipGetErrorString(e));
-                return PWS_EHIP;
-            }
-            attr2 = true;
-        }
-        ProfScope prof(KID_CONV_WINO, ph.flops, ph.bytes, st);
-        hipLaunchKernelGGL(wino_k3s1_ws_kernel, dim3(p.ntiles, (a->cout + 63) / 64), dim3(512), WS_LDS_BYTES, st, p);
-        return check_launch("wino_k3s1_ws_kernel");
     }
     ProfScope prof(KID_CONV_WINO, ph.flops, ph.bytes, st);
     hipLaunchKernelGGL(wino_k3s1_kernel, dim3(p.ntiles, (a->cout + 63) / 64), dim3(256), WN_LDS_BYTES, st, p);

@@ -1,0 +1,193 @@
+"""GPU parity of the bf16 matrix-core path (PWS_MATH_BF16: BASELINE configs 3/4, "bf16 with MFMA convs").
+
+What bf16 math means here: conv operands (activations / gradients and weights) are rounded to bf16 (round to nearest
+even) as they enter LDS; products are exact in fp32 and summed in fp32; everything in memory stays fp32.  So:
+  * TIGHT check: on operands that are already bf16-representable the bf16 kernels must agree with an fp32 reference
+    (PyTorch CPU) up to fp32 summation order: 3e-5 of the tensor's max magnitude (K up to 9216 terms).
+  * STATED bf16 tolerance on arbitrary fp32 operands: each operand carries a relative rounding error <= 2^-9, a product
+    <= 2^-8; for sums of K random-sign terms the error grows like sqrt(K) while the result's magnitude does too, so the
+    per-layer bound is 1.5e-2 of the tensor's max magnitude (measured ~3e-3); whole generator: field 2e-2 absolute in
+    normalised coordinates for the W1 weights (measured in test_netg_bf16_*), warped frame 5e-2 of the 0..255 range / 255.
+"""
+import ctypes
+import zlib
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.nn.functional as F  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+KINDS = {"CONV_K3S1": ("conv", 3, 1, 1), "CONV_K3S2": ("conv", 3, 2, 1), "CONVT_K3S1": ("convT", 3, 1, 1),
+         "CONVT_K4S2": ("convT", 4, 2, 1)}
+TIGHT, STATED = 3e-5, 1.5e-2
+
+CASES = [
+    ("CONV_K3S1", (2, 20, 37), [32], 64), ("CONV_K3S1", (1, 33, 16), [64, 32], 96), ("CONV_K3S1", (3, 8, 8), [32], 16),
+    ("CONV_K3S1", (5, 4, 4), [32], 32), ("CONV_K3S1", (18, 2, 2), [64], 64), ("CONV_K3S1", (2, 16, 16), [64, 64], 64),
+    ("CONV_K3S1", (1, 64, 64), [64], 64),
+    ("CONV_K3S2", (2, 40, 34), [32, 32], 64), ("CONV_K3S2", (2, 16, 16), [32], 32), ("CONV_K3S2", (3, 8, 8), [64], 32),
+    ("CONV_K3S2", (17, 4, 4), [32, 32, 32], 16), ("CONV_K3S2", (2, 21, 9), [32], 16), ("CONV_K3S2", (1, 64, 64), [64], 128),
+    ("CONVT_K3S1", (2, 18, 21), [32, 64], 48), ("CONVT_K3S1", (2, 4, 4), [32], 16), ("CONVT_K3S1", (2, 2, 2), [256], 256),
+    ("CONVT_K4S2", (2, 17, 19), [32, 32, 64], 64), ("CONVT_K4S2", (2, 8, 8), [32], 32), ("CONVT_K4S2", (3, 4, 4), [32, 32], 16),
+    ("CONVT_K4S2", (20, 2, 2), [32], 64), ("CONVT_K4S2", (1, 32, 32), [128, 64], 64),
+]
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def bf16r(t):
+    return t.bfloat16().float()
+
+
+def relerr(got, want):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return np.abs(got - want).max() / max(np.abs(want).max(), 1e-12)
+
+
+def torch_layer(kname, x, w, b, act):
+    kind, k, s, p = KINDS[kname]
+    y = (F.conv2d if kind == "conv" else F.conv_transpose2d)(x, w, b, stride=s, padding=p)
+    return F.leaky_relu(y, 0.2) if act == 1 else F.relu(y)
+
+
+def make_case(kname, shape, src_c, cout, tag):
+    n, h, w = shape
+    rs = np.random.RandomState(zlib.crc32(repr((kname, shape, cout, tag)).encode()))
+    cin, kk, is_t = sum(src_c), KINDS[kname][1], KINDS[kname][0] == "convT"
+    x = torch.from_numpy(rs.standard_normal((n, cin, h, w)).astype(np.float32))
+    wt = torch.from_numpy((rs.standard_normal((cin, cout, kk, kk) if is_t else (cout, cin, kk, kk)) / np.sqrt(cin * kk)).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal(cout).astype(np.float32))
+    return x, wt, b, rs
+
+
+def hip_fwd(A, kname, x, wt, b, act, src_c, cout, ws_mb):
+    L, st = A.lib(), A.current_stream()
+    kind = getattr(A, kname)
+    n, cin, h, w = x.shape
+    wp = torch.empty(L.pws_packed_weight_floats(kind, cin, cout), device="cuda")
+    d_w = wt.cuda()
+    A.check(L.pws_pack_conv_weight(A.ptr(d_w), A.ptr(wp), kind, cin, cout, st), "pack")
+    planes = 16 if kname == "CONVT_K4S2" else 9
+    cin_pad = (cin + 15) // 16 * 16
+    wb = torch.empty(L.pws_packed_bf16_floats(planes, cin_pad, cout), device="cuda")
+    A.check(L.pws_pack_weight_bf16(A.ptr(wp), A.ptr(wb), planes, cin_pad, cout, st), "pack_bf16")
+    xs = nhwc(x)
+    a = A.PwsConvArgs()
+    a.kind, a.n, a.h, a.w, a.nsrc, a.cout, a.act = kind, n, h, w, len(src_c), cout, act
+    keep, c0 = [], 0
+    for i, c in enumerate(src_c):
+        t = xs[..., c0:c0 + c].contiguous().cuda()
+        keep.append(t)
+        a.src[i].ptr, a.src[i].channels, a.src[i].ld = t.data_ptr(), c, c
+        c0 += c
+    oh, ow = (h, w) if "S1" in kname else (((h - 1) // 2 + 1, (w - 1) // 2 + 1) if kname == "CONV_K3S2" else (2 * h, 2 * w))
+    out = torch.full((n, oh, ow, cout), float("nan"), device="cuda")
+    d_b = b.cuda()
+    a.w_packed, a.bias, a.out, a.out_ld = wp.data_ptr(), d_b.data_ptr(), out.data_ptr(), cout
+    a.math, a.w_bf16 = A.MATH_BF16, wb.data_ptr()
+    if ws_mb:
+        ws = torch.empty(ws_mb << 20, dtype=torch.uint8, device="cuda")
+        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
+    L.pws_prof_enable(1)
+    A.check(L.pws_conv2d_fwd(ctypes.byref(a), st), "conv bf16")
+    L.pws_prof_enable(0)
+    names = [r[0] for r in A.prof_collect()]
+    assert names == ["conv_bf16_kernel"], names  # the bf16 kernel really ran (no silent fp32 path)
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+@pytest.mark.parametrize("kname,shape,src_c,cout", CASES)
+@pytest.mark.parametrize("act", [1, 2])
+def test_bf16_conv_forward(hip, kname, shape, src_c, cout, act):
+    x, wt, b, _ = make_case(kname, shape, src_c, cout, "f")
+    xr, wr = bf16r(x), bf16r(wt)
+    want_tight = nhwc(torch_layer(kname, xr, wr, b, act)).numpy()
+    want_fp32 = nhwc(torch_layer(kname, x, wt, b, act)).numpy()
+    for ws_mb in (0, 64):
+        got = hip_fwd(hip, kname, xr, wt, b, act, src_c, cout, ws_mb).numpy()  # weights are rounded by the pack kernel
+        assert not np.isnan(got).any()
+        assert relerr(got, want_tight) < TIGHT, relerr(got, want_tight)
+    got = hip_fwd(hip, kname, x, wt, b, act, src_c, cout, 64).numpy()         # activations rounded while staging
+    assert relerr(got, want_tight) < TIGHT, relerr(got, want_tight)
+    assert relerr(got, want_fp32) < STATED, relerr(got, want_fp32)
+
+
+@pytest.mark.parametrize("kname,shape,src_c,cout", [c for c in CASES if c[3] % 32 == 0])
+def test_bf16_conv_data_gradient(hip, kname, shape, src_c, cout):
+    A = hip
+    L, st = A.lib(), A.current_stream()
+    kind = getattr(A, kname)
+    x, wt, b, rs = make_case(kname, shape, src_c, cout, "d")
+    n, cin, h, w = x.shape
+    wr = bf16r(wt)
+    xg = x.clone().requires_grad_(True)
+    kd, k, s_, p_ = KINDS[kname]
+    y = (F.conv2d if kd == "conv" else F.conv_transpose2d)(xg, wr, None, stride=s_, padding=p_)
+    dy = bf16r(torch.from_numpy(rs.standard_normal(tuple(y.shape)).astype(np.float32)))
+    y.backward(dy)
+    ref = nhwc(xg.grad).numpy()
+    d_dy = nhwc(dy).cuda()
+    wdg = torch.empty(L.pws_packed_dgrad_floats(kind, cin, cout), device="cuda")
+    d_w = wt.cuda()
+    A.check(L.pws_pack_conv_weight_dgrad(A.ptr(d_w), A.ptr(wdg), kind, cin, cout, st), "pack_dgrad")
+    planes = 9 if "S1" in kname else 16
+    wdb = torch.empty(L.pws_packed_bf16_floats(planes, cout, cin), device="cuda")
+    A.check(L.pws_pack_weight_bf16(A.ptr(wdg), A.ptr(wdb), planes, cout, cin, st), "pack_bf16")
+    for ws_mb in (0, 64):
+        da = A.PwsConvBwdDataArgs()
+        da.kind, da.n, da.h, da.w, da.cout = kind, n, h, w, cout
+        da.gout, da.gout_ld, da.w_dgrad, da.ndst = d_dy.data_ptr(), cout, wdg.data_ptr(), len(src_c)
+        da.math, da.w_dgrad_bf16 = A.MATH_BF16, wdb.data_ptr()
+        outs = []
+        for i, c in enumerate(src_c):
+            acc = 1 if i == 1 else 0
+            o = torch.full((n, h, w, c), 0.5 if acc else float("nan"), device="cuda")
+            outs.append(o)
+            da.dst[i].ptr, da.dst[i].channels, da.dst[i].ld, da.dst[i].accumulate = o.data_ptr(), c, c, acc
+        if ws_mb:
+            wsb = torch.empty(ws_mb << 20, device="cuda", dtype=torch.uint8)
+            da.ws, da.ws_bytes = wsb.data_ptr(), wsb.numel()
+        L.pws_prof_enable(1)
+        A.check(L.pws_conv2d_bwd_data(ctypes.byref(da), st), "bwd_data bf16")
+        L.pws_prof_enable(0)
+        assert [r[0] for r in A.prof_collect()] == ["conv_bf16_kernel"]
+        torch.cuda.synchronize()
+        c0 = 0
+        for i, c in enumerate(src_c):
+            got = outs[i].cpu().numpy() - (0.5 if i == 1 else 0.0)
+            assert not np.isnan(got).any()
+            err = np.abs(got - ref[..., c0:c0 + c]).max() / np.abs(ref).max()
+            assert err < TIGHT, err
+            c0 += c
+
+
+def test_bf16_falls_back_to_fp32_for_uncovered_shapes(hip):
+    """Sources that are not multiples of 32 channels run the exact fp32 kernel even when bf16 math is requested."""
+    A = hip
+    x, wt, b, _ = make_case("CONV_K3S1", (1, 8, 8), [16], 16, "u")
+    L, st = A.lib(), A.current_stream()
+    wp = torch.empty(L.pws_packed_weight_floats(A.CONV_K3S1, 16, 16), device="cuda")
+    d_w = wt.cuda()
+    A.check(L.pws_pack_conv_weight(A.ptr(d_w), A.ptr(wp), A.CONV_K3S1, 16, 16, st), "pack")
+    wb = torch.empty(L.pws_packed_bf16_floats(9, 16, 16), device="cuda")
+    A.check(L.pws_pack_weight_bf16(A.ptr(wp), A.ptr(wb), 9, 16, 16, st), "pack_bf16")
+    xs = nhwc(x).cuda()
+    out = torch.empty((1, 8, 8, 16), device="cuda")
+    d_b = b.cuda()
+    a = A.PwsConvArgs()
+    a.kind, a.n, a.h, a.w, a.nsrc, a.cout, a.act = A.CONV_K3S1, 1, 8, 8, 1, 16, 1
+    a.src[0].ptr, a.src[0].channels, a.src[0].ld = xs.data_ptr(), 16, 16
+    a.w_packed, a.bias, a.out, a.out_ld, a.math, a.w_bf16 = wp.data_ptr(), d_b.data_ptr(), out.data_ptr(), 16, A.MATH_BF16, wb.data_ptr()
+    A.check(L.pws_conv2d_fwd(ctypes.byref(a), st), "conv")
+    want = nhwc(torch_layer("CONV_K3S1", x, wt, b, 1)).numpy()
+    assert relerr(out.cpu().numpy(), want) < 1e-5

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Single-layer conv micro-benchmark through pws_conv2d_fwd: python tools/conv_bench.py KIND N H W CIN COUT [wino]"""
+"""Single-layer conv micro-benchmark through pws_conv2d_fwd: python tools/conv_bench.py KIND N H W CIN COUT [wino|bf16]"""
 import ctypes
 import os
 import sys
@@ -10,7 +10,7 @@ import torch  # noqa: E402
 from pwstablenet_amd import hipabi as A  # noqa: E402
 
 
-def bench(kname, n, h, w, cin, cout, wino):
+def bench(kname, n, h, w, cin, cout, wino, bf16=False):
     L, st = A.lib(), A.current_stream()
     kind = getattr(A, kname)
     k = {"CONV_K3S1": 3, "CONV_K3S2": 3, "CONVT_K3S1": 3, "CONVT_K4S2": 4, "CONV_K5S1": 5}[kname]
@@ -30,6 +30,12 @@ def bench(kname, n, h, w, cin, cout, wino):
         ww = torch.empty(L.pws_packed_wino_floats(cin, cout), device="cuda")
         A.check(L.pws_pack_conv_weight_wino(A.ptr(wp), A.ptr(ww), cin, cout, st), "wino pack")
         a.w_wino = ww.data_ptr()
+    if bf16:
+        planes = 16 if kname == "CONVT_K4S2" else k * k
+        cin_pad = (cin + 15) // 16 * 16
+        wb = torch.empty(L.pws_packed_bf16_floats(planes, cin_pad, cout), device="cuda")
+        A.check(L.pws_pack_weight_bf16(A.ptr(wp), A.ptr(wb), planes, cin_pad, cout, st), "bf16 pack")
+        a.math, a.w_bf16 = A.MATH_BF16, wb.data_ptr()
     for _ in range(3):
         A.check(L.pws_conv2d_fwd(ctypes.byref(a), st), "conv")
     torch.cuda.synchronize()
@@ -40,10 +46,10 @@ def bench(kname, n, h, w, cin, cout, wino):
     r = A.prof_collect()
     ms = sorted(x_[4] for x_ in r)[len(r) // 2]
     print("%-11s n=%d %dx%d %d->%d %-5s ablate=%s: %8.1f us  %6.1f TFLOP/s (algorithmic)" % (
-        kname, n, h, w, cin, cout, "wino" if wino else "direct", os.environ.get("PWS_WINO_ABLATE", "0"), ms * 1e3,
+        kname, n, h, w, cin, cout, "bf16" if bf16 else ("wino" if wino else "direct"), os.environ.get("PWS_WINO_ABLATE", "0"), ms * 1e3,
         r[0][2] / (ms * 1e-3) / 1e12))
 
 
 if __name__ == "__main__":
     v = sys.argv[1:]
-    bench(v[0], int(v[1]), int(v[2]), int(v[3]), int(v[4]), int(v[5]), len(v) > 6 and v[6] == "wino")
+    bench(v[0], int(v[1]), int(v[2]), int(v[3]), int(v[4]), int(v[5]), len(v) > 6 and v[6] == "wino", len(v) > 6 and v[6] == "bf16")
