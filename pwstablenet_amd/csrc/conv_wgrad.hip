@@ -269,6 +269,8 @@ static const WgChoice &pick(const WgChoice *c, int n, int LH, int LW, int N) {
     return c[n - 1];
 }
 
+int wgrad_bf16_launch(const pws_conv_bwd_weight_args *a, hipStream_t st);  // wgrad_bf16.hip
+
 int conv2d_bwd_weight_impl(const pws_conv_bwd_weight_args *a, hipStream_t st) {
     PWS_REQUIRE(a != nullptr, "pws_conv2d_bwd_weight: args is NULL");
     PWS_REQUIRE(a->n >= 0 && a->h > 0 && a->w > 0 && a->cout > 0 && a->cout % 4 == 0, "pws_conv2d_bwd_weight: bad shape");
@@ -276,6 +278,10 @@ int conv2d_bwd_weight_impl(const pws_conv_bwd_weight_args *a, hipStream_t st) {
                     (reinterpret_cast<size_t>(a->gout) & 15) == 0,
                 "pws_conv2d_bwd_weight: bad sources / gout / dw");
     if (a->n == 0) return PWS_OK;
+    if (a->math == PWS_MATH_BF16) {
+        const int rc = wgrad_bf16_launch(a, st);  // 1: not covered by the bf16 kernel (first layer, odd channel counts)
+        if (rc != 1) return rc;
+    }
     WgradParams p{};
     p.nsrc = a->nsrc;
     int cin = 0;

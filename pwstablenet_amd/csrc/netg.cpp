@@ -27,7 +27,21 @@ struct Layer {
     size_t w_off, b_off;  // float offsets into the packed buffer (and into the packed gradient buffer)
     size_t dg_off;        // float offset into the data-gradient weight buffer (or SIZE_MAX)
     size_t ww_off;        // float offset of the Winograd-domain weights inside the packed buffer (or SIZE_MAX)
+    size_t wb_off;        // float offset of the bf16 weights inside the packed buffer (or SIZE_MAX)
+    size_t dgb_off;       // float offset of the bf16 data-gradient weights inside the data-gradient buffer (or SIZE_MAX)
 };
+
+// planes of the forward / data-gradient packed layouts of the kinds the bf16 kernels cover (0: not covered)
+static int bf16_planes(int kind) {
+    switch (kind) {
+    case PWS_CONV_K3S1:
+    case PWS_CONV_K3S2:
+    case PWS_CONVT_K3S1: return 9;
+    case PWS_CONVT_K4S2: return 16;
+    default: return 0;
+    }
+}
+static int bf16_dgrad_planes(int kind) { return kind == PWS_CONV_K3S1 || kind == PWS_CONVT_K3S1 ? 9 : 16; }
 
 enum {
     L_TRANSFER = 0,
@@ -48,7 +62,7 @@ static std::vector<Layer> build_layers(int input_nc, int g, size_t *total_floats
     std::vector<Layer> L;
     size_t off = 0, dg = 0;
     auto add = [&](int kind, int cin, int cout) {
-        Layer l{kind, cin, cout, 0, 0, (size_t)-1, (size_t)-1};
+        Layer l{kind, cin, cout, 0, 0, (size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1};
         l.w_off = off;
         off = align_up(off + pws_packed_weight_floats(kind, cin, cout), 64);
         l.b_off = off;
@@ -57,8 +71,16 @@ static std::vector<Layer> build_layers(int input_nc, int g, size_t *total_floats
             l.ww_off = off;
             off = align_up(off + pws_packed_wino_floats(cin, cout), 64);
         }
+        if (bf16_planes(kind) && cin % 32 == 0) {
+            l.wb_off = off;
+            off = align_up(off + pws_packed_bf16_floats(bf16_planes(kind), (cin + 15) / 16 * 16, cout), 64);
+        }
         const size_t d = pws_packed_dgrad_floats(kind, cin, cout);
         if (d) l.dg_off = dg, dg = align_up(dg + d, 64);
+        if (d && bf16_planes(kind) && cout % 32 == 0) {
+            l.dgb_off = dg;
+            dg = align_up(dg + pws_packed_bf16_floats(bf16_dgrad_planes(kind), cout, cin), 64);
+        }
         L.push_back(l);
     };
     const int enc[7][2] = {{g, g}, {g, 2 * g}, {2 * g, 4 * g}, {4 * g, 4 * g}, {4 * g, 4 * g}, {4 * g, 4 * g}, {4 * g, 4 * g}};
@@ -127,7 +149,7 @@ class Exec {
   public:
     Exec(const float *packed, const std::vector<Layer> &layers, int n, char *ws, size_t ws_bytes, hipStream_t st, bool dry,
          bool launch)
-        : packed_(packed), L_(layers), n_(n), ws_(ws), cap_(ws_bytes), st_(st), dry_(dry), launch_(launch && !dry) {
+        : packed_(packed), L_(layers), n_(n), ws_(ws), cap_(ws_bytes), dry_(dry), launch_(launch && !dry) {
         streams_[0] = st, streams_[1] = st;
         if (launch_ && g_two_queues && g_side.init()) streams_[1] = g_side.stream, g_side.next = 0;
     }
@@ -202,6 +224,7 @@ class Exec {
         a.w_wino = l.ww_off != (size_t)-1 ? packed_ + l.ww_off : nullptr;
         a.out = o.seg[0].ptr, a.out_ld = l.cout;
         a.ws = q_ ? splitk_ws2_ : splitk_ws_, a.ws_bytes = splitk_bytes_;
+        if (g_math == PWS_MATH_BF16 && l.wb_off != (size_t)-1) a.math = PWS_MATH_BF16, a.w_bf16 = packed_ + l.wb_off;
         g_prof_tag = layer;
         rc_ = pws_conv2d_fwd(&a, streams_[q_]);
         g_prof_tag = -1;
@@ -267,7 +290,6 @@ class Exec {
     int n_;
     char *ws_;
     size_t cap_, off_ = 0;
-    hipStream_t st_;
     bool dry_, launch_;
     int rc_ = PWS_OK;
     std::vector<Op> tape_;
@@ -420,6 +442,7 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             for (int i = 0; i < op.in.nseg; ++i) wa.src[i] = pws_src{op.in.seg[i].ptr, op.in.seg[i].c, op.in.seg[i].ld};
             if (op.nchw) wa.src[0] = pws_src{x, input_nc, 0};
             wa.cout = l.cout, wa.gout = go.g, wa.gout_ld = l.cout, wa.dw_packed = dpacked + l.w_off;
+            wa.math = g_math;
             rc = pws_conv2d_bwd_weight(&wa, st);
             if (rc != PWS_OK || op.nchw) {
                 g_prof_tag = -1;
@@ -434,6 +457,7 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
                 gi.written = true;
             }
             da.ws = E.splitk_ws(), da.ws_bytes = E.splitk_bytes();
+            if (g_math == PWS_MATH_BF16 && l.dgb_off != (size_t)-1) da.math = PWS_MATH_BF16, da.w_dgrad_bf16 = packed_dgrad + l.dgb_off;
             rc = pws_conv2d_bwd_data(&da, st);
             g_prof_tag = -1;
         }
@@ -475,6 +499,9 @@ extern "C" int pws_netg_pack_weights(const float *const *params, float *packed, 
         int rc = pws_pack_conv_weight(params[2 * i], packed + L[i].w_off, L[i].kind, L[i].cin, L[i].cout, stream);
         if (rc == PWS_OK && L[i].ww_off != (size_t)-1)
             rc = pws_pack_conv_weight_wino(packed + L[i].w_off, packed + L[i].ww_off, L[i].cin, L[i].cout, stream);
+        if (rc == PWS_OK && L[i].wb_off != (size_t)-1)
+            rc = pws_pack_weight_bf16(packed + L[i].w_off, packed + L[i].wb_off, bf16_planes(L[i].kind), (L[i].cin + 15) / 16 * 16,
+                                      L[i].cout, stream);
         if (rc != PWS_OK) return rc;
         e = hipMemcpyAsync(packed + L[i].b_off, params[2 * i + 1], sizeof(float) * L[i].cout, hipMemcpyDeviceToDevice,
                            as_stream(stream));
@@ -496,6 +523,9 @@ extern "C" int pws_netg_pack_weights_dgrad(const float *const *params, float *pa
         if (L[i].dg_off == (size_t)-1) continue;
         PWS_REQUIRE(params[2 * i], "pws_netg_pack_weights_dgrad: params[%d] is NULL", 2 * i);
         int rc = pws_pack_conv_weight_dgrad(params[2 * i], packed_dgrad + L[i].dg_off, L[i].kind, L[i].cin, L[i].cout, stream);
+        if (rc == PWS_OK && L[i].dgb_off != (size_t)-1)
+            rc = pws_pack_weight_bf16(packed_dgrad + L[i].dg_off, packed_dgrad + L[i].dgb_off, bf16_dgrad_planes(L[i].kind),
+                                      L[i].cout, L[i].cin, stream);
         if (rc != PWS_OK) return rc;
     }
     return PWS_OK;

@@ -1,0 +1,315 @@
+// Weight gradient on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulation) -- the PWS_MATH_BF16 variant of
+// conv_wgrad.hip, same result layout:  dP[class][tap][ci][co] += sum_m x[m*S + tap - pad][ci] * dy[m][co]   (K = pixels).
+//
+// The contraction runs over PIXELS, but both operands live in memory as [pixel][channel]: an MFMA operand (8 consecutive k
+// per lane for one channel) is a COLUMN of that image.  gfx950's transposing LDS read does exactly this:
+// ds_read_b64_tr_b16 hands every lane of a 16-lane group one column (4 rows) of a 4x16 bf16 block whose rows are addressed
+// per lane, so the tiles are staged row-major (one coalesced 16-byte write per 8 channels) and read column-major, two reads
+// per operand.  Semantics pinned by tools/probes/tr16_read_probe.hip.
+//
+//   * A workgroup (4 waves) owns 64 input x 64 output channels of one (class, tap group) and a strided subset of the spatial
+//     tiles; wave (a, b) owns the 32 x 32 quadrant (ci half a, co half b) with one accumulator per tap, and walks ALL pixels
+//     of the tile, so no cross-wave reduction is needed; the result is added to dW with fp32 atomics as in conv_wgrad.hip.
+//   * Per tile the halo'd x tile and the dy tile are converted fp32 -> bf16 (RNE) on their way into LDS as two 32-channel
+//     planes of 64-byte rows: the 4 rows x 2 channel halves that one half-wave reads cover all 64 banks exactly once.
+//   * The dy fragment of a 16-pixel k-step is shared by all taps of the step.
+#include "common.h"
+
+namespace pws {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct WgradBfParams {
+    const float *src_ptr[4];
+    int src_c[4];
+    int src_ld[4];
+    int nsrc;
+    int cin, cin_pad, cout;
+    int N, H, W;     // forward input extent
+    int LH, LW;      // logical extent walked by tiles
+    int OH, OW;      // forward output extent (extent of dy)
+    const float *gout;
+    int gout_ld;
+    float *dw;
+    int tiles_x, tiles_y, tiles_n;
+    int ntiles;
+    int ci_blocks, co_blocks;  // of 64 channels
+};
+
+template <int KS_, int STRIDE_, int PAD_, int SUBPIX_, int TH_, int TW_, int TN_, int TG_>
+struct WbCfg {
+    static constexpr int KS = KS_, STRIDE = STRIDE_, PAD = PAD_, SUBPIX = SUBPIX_, TH = TH_, TW = TW_, TN = TN_;
+    static constexpr int TG = TG_;  // taps per workgroup
+    static constexpr int TAPS = KS * KS, NGROUPS = TAPS / TG;
+    static constexpr int BM = TH * TW * TN, KSTEPS = BM / 16;
+    static_assert(BM % 16 == 0 && TAPS % TG == 0, "tile");
+    static constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
+    static constexpr int PIX = TN * IH * IW;
+    static constexpr int ROW = 64;                               // bytes per LDS row: 32 bf16 channels
+    static constexpr int LDS_X = 2 * PIX * ROW, LDS_G = 2 * BM * ROW;
+    static constexpr int LDS_BYTES = LDS_X + LDS_G + 16;         // + sink for staging items past the tile
+};
+
+// halo-tile pixel of tile-local output pixel p
+template <class C>
+__host__ __device__ constexpr int wb_xoff(int p) {
+    return ((p / (C::TH * C::TW)) * C::IH + ((p % (C::TH * C::TW)) / C::TW) * C::STRIDE) * C::IW + (p % C::TW) * C::STRIDE;
+}
+// the k-step walk relies on xoff(16 j + c) == xoff(c) + j * xoff(16) for c < 16
+template <class C>
+constexpr bool wb_linear() {
+    for (int j = 0; j < C::KSTEPS; ++j)
+        for (int c = 0; c < 16; ++c)
+            if (wb_xoff<C>(16 * j + c) != wb_xoff<C>(c) + j * wb_xoff<C>(16)) return false;
+    return true;
+}
+
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char *lds, int off0, int off1) {
+    typedef __attribute__((address_space(3))) s16x4 *lptr;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + off0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + off1));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <class C>
+__global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradBfParams p) {
+    static_assert(wb_linear<C>(), "tile shape breaks the k-step address walk");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int li = lane & 15, lg = lane >> 4;
+
+    const int cb = blockIdx.y;
+    const int ci0 = (cb / p.co_blocks) * 64, co0 = (cb % p.co_blocks) * 64;
+    const int cls = C::SUBPIX ? (int)(blockIdx.z & 3) : 0;
+    const int tg = C::SUBPIX ? (int)(blockIdx.z >> 2) : (int)blockIdx.z;
+    const int py = cls >> 1, px = cls & 1;
+    const int pad_y = C::SUBPIX ? 1 - py : C::PAD, pad_x = C::SUBPIX ? 1 - px : C::PAD;
+    const int wci = wv >> 1, wco = wv & 1;  // this wave's 32 x 32 quadrant
+
+    f32x16 acc[C::TG];
+#pragma unroll
+    for (int t = 0; t < C::TG; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // transposing-read addresses (bytes): read q of a k-step covers pixels 8*(lg>>1) + 4q + (li>>2) of the step, this lane
+    // supplies row (li>>2) and the 4 columns 4*(li&3).. of its group's 16 channels 16*(lg&1)..
+    const int colb = (16 * (lg & 1) + 4 * (li & 3)) * 2;
+    int a_lane[2], b_lane[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = 8 * (lg >> 1) + 4 * q + (li >> 2);
+        a_lane[q] = wci * C::PIX * C::ROW + wb_xoff<C>(c) * C::ROW + colb;
+        b_lane[q] = C::LDS_X + wco * C::BM * C::ROW + c * C::ROW + colb;
+    }
+    constexpr int SINK = C::LDS_X + C::LDS_G;
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int tx_i = tile % p.tiles_x, ty_i = (tile / p.tiles_x) % p.tiles_y, tn_i = tile / (p.tiles_x * p.tiles_y);
+        const int n0 = tn_i * C::TN, y0 = ty_i * C::TH, x0 = tx_i * C::TW;
+        const int iy0 = y0 * C::STRIDE - pad_y, ix0 = x0 * C::STRIDE - pad_x;
+        __syncthreads();  // previous tile fully consumed
+        // ---- x halo tile, channels ci0..ci0+63 of the (virtually concatenated) sources: 8-channel items, loads of a batch
+        // issued unconditionally before the first LDS store (masked items read a valid dummy address)
+        {
+            constexpr int NIT = C::PIX * 8, ITS = (NIT + 255) / 256, BATCH = 4;
+#pragma unroll 1
+            for (int it0 = 0; it0 < ITS; it0 += BATCH) {
+                f32x4 r[BATCH][2];
+                int off[BATCH];
+                bool okv[BATCH];
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) {
+                    const int item = tid + (it0 + k) * 256;
+                    const int pix = item >> 3, c8 = item & 7;
+                    const int lx = pix % C::IW, ly = (pix / C::IW) % C::IH, tn = pix / (C::IW * C::IH);
+                    const int n = n0 + tn, iy = iy0 + ly, ix = ix0 + lx;
+                    int ch = ci0 + c8 * 8;
+                    const bool ok = item < NIT && ch < p.cin && n < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                    int s = 0;
+                    while (s < p.nsrc - 1 && ch >= p.src_c[s]) ch -= p.src_c[s], ++s;
+                    const float *g = p.src_ptr[ok ? s : 0] + (ok ? ((size_t)(n * p.H + iy) * p.W + ix) * p.src_ld[s] + ch : 0);
+                    r[k][0] = *reinterpret_cast<const f32x4 *>(g);
+                    r[k][1] = *reinterpret_cast<const f32x4 *>(g + 4);
+                    okv[k] = ok;
+                    off[k] = item < NIT ? (c8 >> 2) * C::PIX * C::ROW + pix * C::ROW + (c8 & 3) * 16 : SINK;
+                }
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) {
+                    u32x4 v;
+                    v.x = okv[k] ? cvt_pk_bf16(r[k][0].x, r[k][0].y) : 0u, v.y = okv[k] ? cvt_pk_bf16(r[k][0].z, r[k][0].w) : 0u;
+                    v.z = okv[k] ? cvt_pk_bf16(r[k][1].x, r[k][1].y) : 0u, v.w = okv[k] ? cvt_pk_bf16(r[k][1].z, r[k][1].w) : 0u;
+                    *reinterpret_cast<u32x4 *>(lds + off[k]) = v;
+                }
+            }
+        }
+        // ---- dy tile, channels co0..co0+63 at the tile's output pixels
+        {
+            constexpr int NIT = C::BM * 8, ITS = (NIT + 255) / 256, BATCH = 4;
+#pragma unroll 1
+            for (int it0 = 0; it0 < ITS; it0 += BATCH) {
+                f32x4 r[BATCH][2];
+                int off[BATCH];
+                bool okv[BATCH];
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) {
+                    const int item = tid + (it0 + k) * 256;
+                    const int m = item >> 3, c8 = item & 7;
+                    const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
+                    const int n = n0 + tn, y = y0 + ty, x = x0 + tx;
+                    const int oy = C::SUBPIX ? 2 * y + py : y, ox = C::SUBPIX ? 2 * x + px : x;
+                    const int ch = co0 + c8 * 8;
+                    const bool ok = item < NIT && ch < p.cout && n < p.N && y < p.LH && x < p.LW && oy < p.OH && ox < p.OW;
+                    const float *g = p.gout + (ok ? ((size_t)(n * p.OH + oy) * p.OW + ox) * p.gout_ld + ch : 0);
+                    r[k][0] = *reinterpret_cast<const f32x4 *>(g);
+                    r[k][1] = *reinterpret_cast<const f32x4 *>(g + 4);
+                    okv[k] = ok;
+                    off[k] = item < NIT ? C::LDS_X + (c8 >> 2) * C::BM * C::ROW + m * C::ROW + (c8 & 3) * 16 : SINK;
+                }
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) {
+                    u32x4 v;
+                    v.x = okv[k] ? cvt_pk_bf16(r[k][0].x, r[k][0].y) : 0u, v.y = okv[k] ? cvt_pk_bf16(r[k][0].z, r[k][0].w) : 0u;
+                    v.z = okv[k] ? cvt_pk_bf16(r[k][1].x, r[k][1].y) : 0u, v.w = okv[k] ? cvt_pk_bf16(r[k][1].z, r[k][1].w) : 0u;
+                    *reinterpret_cast<u32x4 *>(lds + off[k]) = v;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- K steps of 16 pixels over the whole tile
+#pragma unroll
+        for (int j = 0; j < C::KSTEPS; ++j) {
+            const bf16x8 b = tr_pair(lds, b_lane[0] + j * 16 * C::ROW, b_lane[1] + j * 16 * C::ROW);
+#pragma unroll
+            for (int t = 0; t < C::TG; ++t) {
+                const int tap = (C::NGROUPS == 1 ? 0 : tg * C::TG) + t;  // tg is block-uniform
+                const int toff = ((tap / C::KS) * C::IW + (tap % C::KS)) * C::ROW;
+                const int joff = j * wb_xoff<C>(16) * C::ROW + toff;
+                const bf16x8 a = tr_pair(lds, a_lane[0] + joff, a_lane[1] + joff);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- one atomic per element: rows = input channels of this wave's quadrant, 32 lanes = 32 consecutive output channels
+    const int co = co0 + wco * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < C::TG; ++t) {
+        const int tap = tg * C::TG + t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (ci < p.cin_pad && co < p.cout)
+                atomicAdd(p.dw + ((size_t)(cls * C::TAPS + tap) * p.cin_pad + ci) * p.cout + co, acc[t][r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct WbChoice {
+    int th, tw, tn;
+    int (*launch)(WgradBfParams &, int nclasses, hipStream_t);
+};
+
+template <class C>
+static int launch_wb(WgradBfParams &p, int nclasses, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_bf16_kernel<C>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(wgrad_bf16_kernel, %d B LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
+            return PWS_EHIP;
+        }
+        attr_set = true;
+    }
+    p.tiles_x = (p.LW + C::TW - 1) / C::TW, p.tiles_y = (p.LH + C::TH - 1) / C::TH, p.tiles_n = (p.N + C::TN - 1) / C::TN;
+    p.ntiles = p.tiles_x * p.tiles_y * p.tiles_n;
+    p.ci_blocks = (p.cin_pad + 63) / 64, p.co_blocks = (p.cout + 63) / 64;
+    const long other = (long)p.ci_blocks * p.co_blocks * nclasses * C::NGROUPS;
+    long ps = (1024 + other - 1) / other;  // ~4 workgroups per CU overall
+    if (ps > p.ntiles) ps = p.ntiles;
+    if (ps < 1) ps = 1;
+    dim3 grid((unsigned)ps, (unsigned)(p.ci_blocks * p.co_blocks), (unsigned)(nclasses * C::NGROUPS));
+    hipLaunchKernelGGL(wgrad_bf16_kernel<C>, grid, dim3(256), C::LDS_BYTES, st, p);
+    return check_launch("wgrad_bf16_kernel");
+}
+
+template <class C>
+static constexpr WbChoice wbchoice() {
+    return WbChoice{C::TH, C::TW, C::TN, &launch_wb<C>};
+}
+
+//                       KS S  P  subpix TH  TW  TN  TG
+using WB_K3S1_T256 = WbCfg<3, 1, 1, 0, 16, 16, 1, 9>;
+using WB_K3S1_T64 = WbCfg<3, 1, 1, 0, 8, 8, 1, 9>;
+using WB_K3S1_T64N4 = WbCfg<3, 1, 1, 0, 4, 4, 4, 9>;
+using WB_K3S1_T64N16 = WbCfg<3, 1, 1, 0, 2, 2, 16, 9>;
+using WB_K3S2_T64 = WbCfg<3, 2, 1, 0, 8, 8, 1, 9>;
+using WB_K3S2_T64N4 = WbCfg<3, 2, 1, 0, 4, 4, 4, 9>;
+using WB_K3S2_T64N16 = WbCfg<3, 2, 1, 0, 2, 2, 16, 9>;
+using WB_CT4_T256 = WbCfg<2, 1, 0, 1, 16, 16, 1, 4>;
+using WB_CT4_T64 = WbCfg<2, 1, 0, 1, 8, 8, 1, 4>;
+using WB_CT4_T64N4 = WbCfg<2, 1, 0, 1, 4, 4, 4, 4>;
+using WB_CT4_T64N16 = WbCfg<2, 1, 0, 1, 2, 2, 16, 4>;
+
+static const WbChoice kWbK3S1[] = {wbchoice<WB_K3S1_T256>(), wbchoice<WB_K3S1_T64>(), wbchoice<WB_K3S1_T64N4>(),
+                                   wbchoice<WB_K3S1_T64N16>()};
+static const WbChoice kWbK3S2[] = {wbchoice<WB_K3S2_T64>(), wbchoice<WB_K3S2_T64N4>(), wbchoice<WB_K3S2_T64N16>()};
+static const WbChoice kWbCT4[] = {wbchoice<WB_CT4_T256>(), wbchoice<WB_CT4_T64>(), wbchoice<WB_CT4_T64N4>(),
+                                  wbchoice<WB_CT4_T64N16>()};
+
+static const WbChoice &pick(const WbChoice *c, int n, int LH, int LW, int N) {
+    for (int i = 0; i < n; ++i) {
+        const long tiles = (long)((LW + c[i].tw - 1) / c[i].tw) * ((LH + c[i].th - 1) / c[i].th) * ((N + c[i].tn - 1) / c[i].tn);
+        const double useful = (double)N * LH * LW / ((double)tiles * c[i].th * c[i].tw * c[i].tn);
+        if (useful >= 0.45 || i + 1 == n) return c[i];
+    }
+    return c[n - 1];
+}
+
+// Called by conv2d_bwd_weight_impl after its argument checks.  Returns 1 when the launch is not covered (first layer's
+// NCHW window, sources that are not multiples of 32 channels): the caller then runs the fp32 kernel.
+int wgrad_bf16_launch(const pws_conv_bwd_weight_args *a, hipStream_t st) {
+    if (a->src_nchw) return 1;
+    WgradBfParams p{};
+    p.nsrc = a->nsrc;
+    int cin = 0;
+    for (int s = 0; s < a->nsrc; ++s) {
+        if (a->src[s].channels % 32 != 0) return 1;
+        p.src_ptr[s] = a->src[s].ptr, p.src_c[s] = a->src[s].channels, p.src_ld[s] = a->src[s].ld;
+        cin += a->src[s].channels;
+    }
+    if (a->cout % 8 != 0) return 1;
+    p.cin = cin, p.cin_pad = (cin + 15) / 16 * 16, p.cout = a->cout;
+    p.N = a->n, p.H = a->h, p.W = a->w;
+    p.gout = a->gout, p.gout_ld = a->gout_ld, p.dw = a->dw_packed;
+    double k2 = 9;
+    int nclasses = 1;
+    const WbChoice *c = nullptr;
+    switch (a->kind) {
+    case PWS_CONV_K3S1:
+    case PWS_CONVT_K3S1:
+        p.OH = p.LH = a->h, p.OW = p.LW = a->w;
+        c = &pick(kWbK3S1, 4, p.LH, p.LW, p.N);
+        break;
+    case PWS_CONV_K3S2:
+        p.OH = p.LH = (a->h - 1) / 2 + 1, p.OW = p.LW = (a->w - 1) / 2 + 1;
+        c = &pick(kWbK3S2, 3, p.LH, p.LW, p.N);
+        break;
+    case PWS_CONVT_K4S2:
+        p.LH = a->h, p.LW = a->w, p.OH = 2 * a->h, p.OW = 2 * a->w, nclasses = 4, k2 = 4;
+        c = &pick(kWbCT4, 4, p.LH, p.LW, p.N);
+        break;
+    default: return 1;
+    }
+    const double out_pix = (double)a->n * p.OH * p.OW;
+    ProfScope prof(KID_WGRAD_BF16, 2.0 * out_pix * a->cout * cin * k2,
+                   4.0 * ((double)a->n * a->h * a->w * cin + out_pix * a->cout + k2 * cin * a->cout * (nclasses == 4 ? 4 : 1)), st);
+    return c->launch(p, nclasses, st);
+}
+
+}  // namespace pws

@@ -78,6 +78,9 @@ def _build_parser():
         else:
             p.add_argument("--" + name, type=typ, default=default, help=text)
     p.add_argument("--gpu_ids", type=int, nargs="*", default=[0], help="legacy; ignored (one process per GPU)")
+    # not in the reference: arithmetic of the conv contractions on the MI355X matrix cores (UnetGenerator.set_math)
+    p.add_argument("--math", choices=("fp32", "bf16"), default="fp32",
+                   help="fp32: exact-fp32 MFMA (parity path); bf16: bf16 MFMA with fp32 accumulation (training configs)")
     return p
 
 

@@ -145,6 +145,21 @@ class UnetGenerator(nn.Module):
         self._ws = {}
         self._graph_mode = False
         self._graphs = {}
+        self.math = "bf16" if getattr(opt, "math", "fp32") == "bf16" else "fp32"
+
+    def set_math(self, math):
+        """'fp32' (default; exact-fp32 matrix cores, the parity path) or 'bf16' (conv operands rounded to bf16 in LDS, fp32
+        accumulation on the bf16 matrix cores; master weights, activations and gradients stay fp32 -- BASELINE configs 3/4).
+        Applies to the forward and to the backward of forwards run after the call."""
+        if math not in ("fp32", "bf16"):
+            raise ValueError("UnetGenerator.set_math: expected 'fp32' or 'bf16', got %r" % (math,))
+        if math != self.math:
+            self._graphs = {}
+        self.math = math
+        return self
+
+    def _apply_math(self):
+        A.check(A.lib().pws_set_option(A.OPT_MATH, A.MATH_BF16 if self.math == "bf16" else A.MATH_FP32), "pws_set_option")
 
     def enable_graph(self, on=True):
         """Opt-in hipGraph replay of the inference forward (``netG(x, False)`` under ``no_grad``): the ~75 launches of a
@@ -218,7 +233,7 @@ class UnetGenerator(nn.Module):
     def _run_graph(self, input1):
         x = input1.contiguous()
         self.packed_weights()
-        key = (x.shape[0], x.data_ptr(), self._packed_key)
+        key = (x.shape[0], x.data_ptr(), self._packed_key, self.math)
         ent = self._graphs.get(key)
         if ent is None:
             self._run(x, False)  # eager warm-up: one-time kernel attribute calls must not happen during capture
@@ -249,12 +264,14 @@ class UnetGenerator(nn.Module):
         grids = torch.empty((ng, n, S, S, 2), device=x.device, dtype=torch.float32)
         resid = torch.empty((3, n, S, S, 2), device=x.device, dtype=torch.float32) if is_training else None
         thetas = torch.empty((3, n, 6), device=x.device, dtype=torch.float32)
+        self._apply_math()
         A.check(A.lib().pws_netg_forward(A.ptr(packed), A.ptr(x), n, self.input_nc, self.ngf, int(bool(is_training)),
                                          0, ctypes.c_void_p(ws_ptr), ws_bytes, A.ptr(grids), A.ptr(resid), A.ptr(thetas),
                                          A.current_stream()), "pws_netg_forward")
         self.last_thetas = thetas
         if train_ctx is not None:
-            train_ctx.update(x=x, ws=ws, ws_ptr=ws_ptr, ws_bytes=ws_bytes, grids=grids, resid=resid, thetas=thetas, packed=packed)
+            train_ctx.update(x=x, ws=ws, ws_ptr=ws_ptr, ws_bytes=ws_bytes, grids=grids, resid=resid, thetas=thetas, packed=packed,
+                             math=self.math)
         if is_training:
             return [grids[0], grids[1], grids[2]], [resid[0], resid[1], resid[2]]
         return grids[0]

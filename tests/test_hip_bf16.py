@@ -6,8 +6,9 @@ even) as they enter LDS; products are exact in fp32 and summed in fp32; everythi
     (PyTorch CPU) up to fp32 summation order: 3e-5 of the tensor's max magnitude (K up to 9216 terms).
   * STATED bf16 tolerance on arbitrary fp32 operands: each operand carries a relative rounding error <= 2^-9, a product
     <= 2^-8; for sums of K random-sign terms the error grows like sqrt(K) while the result's magnitude does too, so the
-    per-layer bound is 1.5e-2 of the tensor's max magnitude (measured ~3e-3); whole generator: field 2e-2 absolute in
-    normalised coordinates for the W1 weights (measured in test_netg_bf16_*), warped frame 5e-2 of the 0..255 range / 255.
+    per-layer bound is 1.5e-2 of the tensor's max magnitude (measured ~3e-3); whole generator: stage-3 field 2e-3 absolute in
+    normalised coordinates for the W1 weights, 6e-2 for the saturating W2 set (measured 2.8e-4 / 1.7e-2), warped frame
+    mean error < 2e-3 of the 0..255 range; training gradients: cosine > 0.995, per-tensor relative L2 error < 15 %.
 """
 import ctypes
 import zlib
@@ -191,3 +192,118 @@ def test_bf16_falls_back_to_fp32_for_uncovered_shapes(hip):
     A.check(L.pws_conv2d_fwd(ctypes.byref(a), st), "conv")
     want = nhwc(torch_layer("CONV_K3S1", x, wt, b, 1)).numpy()
     assert relerr(out.cpu().numpy(), want) < 1e-5
+
+
+@pytest.mark.parametrize("kname,shape,src_c,cout", [c for c in CASES if c[3] % 8 == 0])
+def test_bf16_conv_weight_gradient(hip, kname, shape, src_c, cout):
+    """dW from bf16-rounded x and dy (fp32 accumulation, fp32 atomics) against PyTorch-CPU autograd on the same rounded operands."""
+    A = hip
+    L, st = A.lib(), A.current_stream()
+    kind = getattr(A, kname)
+    x, wt, b, rs = make_case(kname, shape, src_c, cout, "w")
+    n, cin, h, w = x.shape
+    xr = bf16r(x)
+    wg = wt.clone().requires_grad_(True)
+    kd, k, s_, p_ = KINDS[kname]
+    y = (F.conv2d if kd == "conv" else F.conv_transpose2d)(xr, wg, None, stride=s_, padding=p_)
+    dy = bf16r(torch.from_numpy(rs.standard_normal(tuple(y.shape)).astype(np.float32)))
+    y.backward(dy)
+    xs = nhwc(x)  # unrounded: the kernel rounds while staging
+    wa = A.PwsConvBwdWeightArgs()
+    wa.kind, wa.n, wa.h, wa.w, wa.nsrc, wa.cout, wa.math = kind, n, h, w, len(src_c), cout, A.MATH_BF16
+    keep, c0 = [], 0
+    for i, c in enumerate(src_c):
+        t = xs[..., c0:c0 + c].contiguous().cuda()
+        keep.append(t)
+        wa.src[i].ptr, wa.src[i].channels, wa.src[i].ld = t.data_ptr(), c, c
+        c0 += c
+    d_dy = nhwc(dy).cuda()
+    dwp = torch.zeros(L.pws_packed_weight_floats(kind, cin, cout), device="cuda")
+    wa.gout, wa.gout_ld, wa.dw_packed = d_dy.data_ptr(), cout, dwp.data_ptr()
+    L.pws_prof_enable(1)
+    A.check(L.pws_conv2d_bwd_weight(ctypes.byref(wa), st), "bwd_weight bf16")
+    L.pws_prof_enable(0)
+    assert [r[0] for r in A.prof_collect()] == ["wgrad_bf16_kernel"]
+    dw = torch.empty(tuple(wt.shape), device="cuda")
+    A.check(L.pws_unpack_conv_weight(A.ptr(dwp), A.ptr(dw), kind, cin, cout, st), "unpack")
+    err = relerr(dw.cpu().numpy(), wg.grad.numpy())
+    assert err < 1e-4, err
+
+
+# ---------------------------------------------------------------------------------------------- whole generator
+def _make_net(kind, ngf):
+    from pwstablenet_amd import synth
+    from pwstablenet_amd.lib.networks_cascading import define_G
+    net = define_G(31, 2, ngf, "normal", 0.02).cuda()
+    net.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in synth.make_weights(kind, ngf=ngf)})
+    return net
+
+
+FIELD_TOL = {"W1": 2e-3, "W2": 6e-2}   # measured 2.8e-4 / 1.7e-2 (W2 saturates the tanh heads: |field| up to 1.9)   # stated bf16 tolerance of the field, normalised coordinates (image = [-1, 1])
+
+
+@pytest.mark.parametrize("kind", ["W1", "W2"])
+def test_netg_bf16_inference_vs_fp32(hip, kind):
+    """Stage-3 field with bf16 conv math against the fp32 path (itself pinned to the reference goldens): stated tolerance,
+    and the warped frame (0..255 frames / 255) through the same grid_sample."""
+    from pwstablenet_amd import functional as PF
+    from pwstablenet_amd import synth
+    net = _make_net(kind, 64)
+    x = torch.from_numpy(synth.make_window(2, 31, seed=7)).cuda()
+    frames = torch.from_numpy(synth.make_frames(2, 3, 256, 256, seed=7)).cuda()
+    with torch.no_grad():
+        f32 = net(x, False).clone()
+        net.module.set_math("bf16")
+        hip.lib().pws_prof_enable(1)
+        f16 = net(x, False).clone()
+        hip.lib().pws_prof_enable(0)
+        names = [r[0] for r in hip.prof_collect()]
+        net.module.set_math("fp32")
+        again = net(x, False)
+    assert names.count("conv_bf16_kernel") >= 40, names   # every covered layer ran on the bf16 matrix cores
+    assert torch.equal(again, f32)                         # switching back restores the exact fp32 path
+    err = (f16 - f32).abs().max().item()
+    assert err < FIELD_TOL[kind], err
+    w32, w16 = PF.grid_sample(frames, f32), PF.grid_sample(frames, f16)
+    werr = ((w16 - w32).abs() / 255.0)
+    assert werr.mean().item() < 2e-3, werr.mean().item()
+    print("bf16 %s: field max err %.3g, warped mean err %.3g max %.3g" % (kind, err, werr.mean().item(), werr.max().item()))
+
+
+def test_netg_bf16_training_step_gradients_vs_fp32(hip):
+    """One training forward + backward (smooth field loss) in bf16 math: loss within 1 % of fp32, cosine similarity > 0.995 over
+    all 48.5 M gradient entries, and every parameter tensor's gradient within 15 % relative L2 error of its fp32 gradient (bf16
+    rounding of activations and gradients accumulates through the 30+ layers between a deep weight and the loss)."""
+    from pwstablenet_amd import synth
+    net = _make_net("W1", 64)
+    x = torch.from_numpy(synth.make_window(2, 31, seed=11)).cuda()
+    tgt = torch.from_numpy(np.random.RandomState(5).standard_normal((2, 256, 256, 2)).astype(np.float32) * 0.1).cuda()
+
+    def step(math):
+        net.module.set_math(math)
+        net.zero_grad(set_to_none=True)
+        grids, resid = net(x)
+        loss = sum(((g - tgt) ** 2).mean() for g in grids) + sum((r ** 2).mean() for r in resid)
+        loss.backward()
+        return loss.item(), [p.grad.clone() for p in net.parameters()]
+
+    l32, g32 = step("fp32")
+    hip.lib().pws_prof_enable(1)
+    l16, g16 = step("bf16")
+    hip.lib().pws_prof_enable(0)
+    names = [r[0] for r in hip.prof_collect()]
+    net.module.set_math("fp32")
+    assert names.count("wgrad_bf16_kernel") >= 40 and names.count("conv_bf16_kernel") >= 80, (names.count("wgrad_bf16_kernel"), names.count("conv_bf16_kernel"))
+    assert abs(l16 - l32) < 1e-2 * abs(l32), (l16, l32)
+    dot = sum((a * b).sum().item() for a, b in zip(g16, g32))
+    n16 = sum((a * a).sum().item() for a in g16) ** 0.5
+    n32 = sum((b * b).sum().item() for b in g32) ** 0.5
+    assert dot / (n16 * n32) > 0.995, dot / (n16 * n32)
+    names_p = [k for k, _ in net.named_parameters()]
+    rel = [(((a - b).norm() / b.norm().clamp_min(1e-20)).item(), k) for a, b, k in zip(g16, g32, names_p)]
+    worst, worst_name = max(rel)
+    print("bf16 training: loss %.6g vs %.6g, grad cosine %.5f, worst per-tensor relative L2 error %.3g (%s)" % (
+        l16, l32, dot / (n16 * n32), worst, worst_name))
+    for r_, k in sorted(rel)[-6:]:
+        print("   %-44s %.4f" % (k, r_))
+    assert worst < 0.15, (worst, worst_name)

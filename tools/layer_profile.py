@@ -21,10 +21,12 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--train", action="store_true")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--math", choices=("fp32", "bf16"), default="fp32")
     a = ap.parse_args()
     net = define_G(31, 2, 64, "normal", 0.02)
     net.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in synth.make_weights("W1", 123, ngf=64)})
     net = net.cuda()
+    net.module.set_math(a.math)
     x = torch.from_numpy(synth.noise_window(a.batch, 31, 256, 123)).cuda()
     names = [ls.name.replace(".0", "").replace(".mpconv", "") for ls in spec.layer_specs()]
     with torch.no_grad():

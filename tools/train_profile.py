@@ -19,10 +19,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--math", choices=("fp32", "bf16"), default="fp32")
     a = ap.parse_args()
     net = define_G(31, 2, 64, "normal", 0.02)
     net.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in synth.make_weights("W1", 123, ngf=64)})
     net = net.cuda()
+    net.module.set_math(a.math)
     opt = Adam(net.parameters(), lr=1e-4, betas=(0.5, 0.999))
     x = torch.from_numpy(synth.noise_window(a.batch, 31, 256, 123)).cuda()
     fr = torch.from_numpy(synth.make_frames(a.batch, 3, 256, 256, 321)).cuda()
@@ -58,7 +60,7 @@ def main():
     for k, (c, fl, ms) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
         print("%-44s %6d %10.3f %9.1f" % (k, c, ms, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0))
     print("sum of profiled kernels %.2f ms; wall per step %.2f ms (batch %d) -> %.1f samples/s" % (tot, wall * 1e3, a.batch, a.batch / wall))
-    slow = sorted([r for r in recs if r[0] in ("wgrad_mfma_kernel", "conv_mfma_kernel<dgrad k4s2>", "conv_mfma_kernel<dgrad subpix k3s2>")],
+    slow = sorted([r for r in recs if r[0] in ("wgrad_mfma_kernel", "wgrad_bf16_kernel", "conv_bf16_kernel", "conv_mfma_kernel<dgrad k4s2>", "conv_mfma_kernel<dgrad subpix k3s2>")],
                   key=lambda r: -r[4])[:14]
     for name, tag, fl, by, ms in slow:
         print("  %-40s %-26s %8.1f us %7.1f TF/s" % (name, names[tag] if 0 <= tag < len(names) else "-", ms * 1e3, fl / (ms * 1e-3) / 1e12))
