@@ -29,6 +29,8 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak (no TF32 on gfx950)
 PEAK_HBM_GBS = 8000.0      # HBM3E spec peak
 GFLOP_PER_FRAME_INFER = 94.48  # de-duplicated inference forward
+GFLOP_PER_SAMPLE_TRAIN = 331.0  # training forward 112.50 + backward (no dgrad for `transfer`)
+PEAK_BF16_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
 def parse():
@@ -42,6 +44,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch the forward eagerly instead of replaying a hipGraph")
     ap.add_argument("--serial", action="store_true", help="single queue for the whole run (clean per-kernel durations under rocprof)")
     ap.add_argument("--gs-batch", type=int, default=256, help="frames in the grid_sample roofline launch")
+    ap.add_argument("--no-extra", action="store_true", help="skip the bf16 inference / training-step legs (extra JSON fields)")
     return ap.parse_args()
 
 
@@ -119,6 +122,72 @@ def cpu_baseline(batch_unused):
     return {"value": round(1.0 / best, 3), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "N=1 frame: PyTorch-CPU restatement of netG(x,False)+grid_sample (oracle/torch_ref.py), "
                       "min of %d runs after 1 warm-up, %d torch threads" % (runs, torch.get_num_threads())}
+
+
+def bf16_legs(net, x, frames, out_fp32, a, PF, A):
+    """Extra fields (not `value`): the same inference step with bf16 conv math (PWS_MATH_BF16: operands rounded to bf16 in
+    LDS, fp32 accumulation, fp32 storage), its error against the fp32 step, and one configs[2]-shaped training step
+    (forward is_training + 3 grid_sample + L1 + backward + fused Adam) per math mode at this batch size."""
+    import torch
+    from pwstablenet_amd.optim import Adam
+    B = x.shape[0]
+    res = {}
+    with torch.no_grad():
+        net.module.enable_graph(False)
+        f32 = net(x, False).clone()
+        net.module.set_math("bf16")
+        f16 = net(x, False).clone()
+        net.module.enable_graph(not a.no_graph)
+
+        def step():
+            return PF.grid_sample(frames, net(x, False))
+        for _ in range(max(a.warmup, 2)):
+            o = step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            o = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    res["inference"] = {"value": round(B * a.steps / dt, 2), "unit": "frames/s", "n_gpus": 1, "dtype": "bf16 operands, f32 accumulate",
+                        "ms_per_step": round(1e3 * dt / a.steps, 4),
+                        "field_max_abs_err_vs_fp32": float((f16 - f32).abs().max()),
+                        "warped_max_abs_err_vs_fp32_over_255": float((o - out_fp32).abs().max() / 255.0),
+                        "netg_tflops": round(B * a.steps / dt * GFLOP_PER_FRAME_INFER / 1e3, 1),
+                        "netg_frac_bf16_peak": round(B * a.steps / dt * GFLOP_PER_FRAME_INFER / 1e3 / PEAK_BF16_TFLOPS, 4)}
+    net.module.enable_graph(False)
+    tg = torch.roll(frames, shifts=(2, -3), dims=(2, 3))
+    train = {}
+    for math in ("fp32", "bf16"):
+        net.module.set_math(math)
+        opt = Adam(net.parameters(), lr=1e-6, betas=(0.5, 0.999))
+
+        def tstep():
+            opt.zero_grad()
+            grids, _ = net(x)
+            loss = sum(torch.nn.functional.l1_loss(PF.grid_sample(frames, g) / 127.5 - 1, tg / 127.5 - 1) for g in grids)
+            loss.backward()
+            opt.step()
+            return loss
+        for _ in range(2):
+            tstep()
+        torch.cuda.synchronize()
+        reps = max(3, a.steps // 4)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            loss = tstep()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert torch.isfinite(loss)
+        train[math] = {"samples_per_s": round(B * reps / dt, 1), "ms_per_step": round(1e3 * dt / reps, 2),
+                       "tflops": round(B * reps / dt * GFLOP_PER_SAMPLE_TRAIN / 1e3, 1)}
+        del opt
+    net.module.set_math("fp32")
+    net.zero_grad(set_to_none=True)
+    res["training_step"] = {"workload": "batch=%d: netG(x) is_training + 3 grid_sample + L1 + backward + fused Adam, one netG "
+                                        "forward per sample (configs[2] runs two per item); fp32 master weights" % B,
+                            "flops_per_sample_gf": GFLOP_PER_SAMPLE_TRAIN, **train}
+    return res
 
 
 def main():
@@ -288,6 +357,8 @@ def main():
                                                 "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_us": round(1e3 * ms, 2),
                                                 "bytes_per_launch": r[0][3]}}
         del f720
+        if not a.no_extra:
+            line["bf16"] = bf16_legs(net, x, frames, out, a, PF, A)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(B)
             line["gpu_over_cpu"] = round(fps / line["cpu_baseline"]["value"], 1)

@@ -97,6 +97,10 @@ int pws_pack_conv_weight_wino(const float *w_packed, float *w_wino, int cin, int
 size_t pws_packed_bf16_floats(int planes, int krows, int ncols);
 int pws_pack_weight_bf16(const float *w_packed, void *w_bf16, int planes, int krows, int ncols, pws_stream_t stream);
 
+/* NCHW fp32 [n,c,h,w] -> NHWC fp32 [n,h,w,cpad], channels c..cpad-1 zero (cpad a multiple of 4, c <= cpad <= 32): the bf16
+ * first layer reads the 31-channel window (main_new.py:650) as a 32-channel NHWC source. */
+int pws_nchw_to_nhwc_pad(const float *x, float *out, int n, int c, int h, int w, int cpad, pws_stream_t stream);
+
 /* One NHWC source of a (virtually concatenated) conv input: `channels` channels starting at `ptr`,
  * consecutive pixels `ld` floats apart.  ptr 16-byte aligned, ld % 4 == 0, channels % 16 == 0. */
 typedef struct pws_src {

@@ -42,6 +42,36 @@ struct BfCfg {
     static_assert(BN == 64, "weights are padded to 64 output channels per block");
 };
 
+// bias + activation / gradient scatter (or raw partial sums when K is split) and the NHWC store, as in conv_mfma.hip
+template <class C>
+__device__ __forceinline__ void bf_epilogue(const ConvKParams &p, f32x16 (&acc)[C::MT][C::NT], int wm, int wn, int l31, int hi, int n0,
+                                            int y0, int x0, int co0, int py, int px, int split) {
+    const bool partial = p.ksplit > 1;
+    float *part = p.out + (size_t)split * p.split_stride;
+#pragma unroll
+    for (int nt = 0; nt < C::NT; ++nt) {
+        const int co = co0 + (wn * C::NT + nt) * 32 + l31;
+        const bool co_ok = co < p.cout;
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (wm * C::MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
+                const int n = n0 + tn, y = y0 + ty, x = x0 + tx;
+                const int oy = C::CONVT ? 2 * y + py : y, ox = C::CONVT ? 2 * x + px : x;
+                if (co_ok && n < p.N && y < p.LH && x < p.LW && oy < p.OH && ox < p.OW) {
+                    const size_t pix = (size_t)(n * p.OH + oy) * p.OW + ox;
+                    if (partial)
+                        part[pix * p.cout + co] = acc[mt][nt][r];
+                    else
+                        epi_store(p, pix, co, acc[mt][nt][r]);
+                }
+            }
+        }
+    }
+}
+
 template <class C>
 __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_kernel(const ConvKParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -176,30 +206,156 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_kernel(const ConvKPar
         }
     }
 
-    // ---- epilogue (as conv_mfma.hip): bias + activation / gradient scatter, or raw partial sums when K is split
-    const bool partial = p.ksplit > 1;
-    float *part = p.out + (size_t)split * p.split_stride;
+    bf_epilogue<C>(p, acc, wm, wn, l31, hi, n0, y0, x0, co0, py, px, split);
+}
+
+// First layer (Conv2d k5 s1 p2, 31 -> 64 channels): 25 taps x 64 output rows of weights do not fit LDS beside the input tile
+// at two workgroups per CU, so the taps are walked one kernel ROW at a time: the halo'd input tile of a 32-channel chunk is
+// staged once, then for each of the 5 tap rows the 5 x 64 weight rows (25.6 KB) are staged and multiplied (the next row's
+// weights are prefetched into registers meanwhile).  The source is the NHWC copy of the NCHW window padded to 32 channels
+// (pws_nchw_to_nhwc_pad).  C = BfCfg<5,1,2,0,16,16,1,32,...>; C::LDS_W is not used (see K5_LDS_BYTES).
+template <class C>
+struct K5Lds {
+    static constexpr int ROWW = C::KS * C::BN * C::PITCH;  // one tap row of weights
+    static constexpr int BYTES = C::LDS_IN + ROWW + 16;
+    static constexpr int N_WR = C::KS * C::BN * C::C8, ITEMS_WR = (N_WR + C::THREADS - 1) / C::THREADS;
+};
+
+template <class C>
+__global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_k5_kernel(const ConvKParams p) {
+    using K = K5Lds<C>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned char *lds_in = lds_raw;
+    unsigned char *lds_w = lds_raw + C::LDS_IN;
+    constexpr int SINK = C::LDS_IN + K::ROWW;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wm = wv / C::WN, wn = wv % C::WN;
+    const unsigned tile = xcd_remap(blockIdx.x, p.ntiles);
+    const int tx_i = tile % p.tiles_x, ty_i = (tile / p.tiles_x) % p.tiles_y, tn_i = tile / (p.tiles_x * p.tiles_y);
+    const int n0 = tn_i * C::TN, y0 = ty_i * C::TH, x0 = tx_i * C::TW;
+    const int co0 = blockIdx.y * C::BN;
+    const int iy0 = y0 - C::PAD, ix0 = x0 - C::PAD;
+
+    f32x16 acc[C::MT][C::NT];
 #pragma unroll
-    for (int nt = 0; nt < C::NT; ++nt) {
-        const int co = co0 + (wn * C::NT + nt) * 32 + l31;
-        const bool co_ok = co < p.cout;
+    for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt) {
+        for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (wm * C::MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
-                const int n = n0 + tn, y = y0 + ty, x = x0 + tx;
-                const int oy = C::CONVT ? 2 * y + py : y, ox = C::CONVT ? 2 * x + px : x;
-                if (co_ok && n < p.N && y < p.LH && x < p.LW && oy < p.OH && ox < p.OW) {
-                    const size_t pix = (size_t)(n * p.OH + oy) * p.OW + ox;
-                    if (partial)
-                        part[pix * p.cout + co] = acc[mt][nt][r];
-                    else
-                        epi_store(p, pix, co, acc[mt][nt][r]);
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    int a_base[C::MT];
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt) {
+        const int m = (wm * C::MT + mt) * 32 + l31;
+        const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
+        a_base[mt] = ((tn * C::IH + ty) * C::IW + tx) * C::PITCH + hi * 16;
+    }
+    const int b_base = (wn * C::NT * 32 + l31) * C::PITCH + hi * 16;
+
+    // weight-row items: (tap in row, cout row, 8-k group)
+    int w_off[K::ITEMS_WR], lw_off[K::ITEMS_WR];
+#pragma unroll
+    for (int it = 0; it < K::ITEMS_WR; ++it) {
+        const int item = tid + it * C::THREADS;
+        const int row = item / C::C8, c8 = item % C::C8;
+        const int tap = row / C::BN, nn = row % C::BN;
+        w_off[it] = item < K::N_WR ? ((tap * p.npad_bf + co0 + nn) * p.kpad_bf + c8 * 8) : 0;
+        lw_off[it] = item < K::N_WR ? C::LDS_IN + row * C::PITCH + c8 * 16 : SINK;
+    }
+    const __bf16 *wbase = static_cast<const __bf16 *>(p.w_bf);
+    u32x4 r_w[K::ITEMS_WR];
+    auto load_wrow = [&](int r, int wrow) {
+        const __bf16 *wp = wbase + (size_t)r * C::KS * p.npad_bf * p.kpad_bf + wrow;
+#pragma unroll
+        for (int it = 0; it < K::ITEMS_WR; ++it) r_w[it] = *reinterpret_cast<const u32x4 *>(wp + w_off[it]);
+    };
+
+    const int nchunks = p.src_c[0] / C::CK;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __syncthreads();
+        // ---- input tile of this channel chunk (batches of 4 items: loads first, then convert + store)
+        {
+            constexpr int ITS = C::ITEMS_IN, BATCH = 4;
+            const float *sp = p.src_ptr[0] + ch * C::CK;
+            const size_t ld = p.src_ld[0];
+#pragma unroll 1
+            for (int it0 = 0; it0 < ITS; it0 += BATCH) {
+                f32x4 r[BATCH][2];
+                int off[BATCH];
+                bool okv[BATCH];
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) {
+                    const int item = tid + (it0 + k) * C::THREADS;
+                    const int pix = item / C::C8, c8 = item % C::C8;
+                    const int lx = pix % C::IW, ly = (pix / C::IW) % C::IH, tn = pix / (C::IW * C::IH);
+                    const int n = n0 + tn, iy = iy0 + ly, ix = ix0 + lx;
+                    const bool ok = item < C::N_IN && n < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                    const float *g = sp + (ok ? ((size_t)(n * p.H + iy) * p.W + ix) * ld + c8 * 8 : 0);
+                    r[k][0] = *reinterpret_cast<const f32x4 *>(g);
+                    r[k][1] = *reinterpret_cast<const f32x4 *>(g + 4);
+                    okv[k] = ok;
+                    off[k] = item < C::N_IN ? pix * C::PITCH + c8 * 16 : SINK;
+                }
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) {
+                    u32x4 v;
+                    v.x = okv[k] ? cvt_pk_bf16(r[k][0].x, r[k][0].y) : 0u, v.y = okv[k] ? cvt_pk_bf16(r[k][0].z, r[k][0].w) : 0u;
+                    v.z = okv[k] ? cvt_pk_bf16(r[k][1].x, r[k][1].y) : 0u, v.w = okv[k] ? cvt_pk_bf16(r[k][1].z, r[k][1].w) : 0u;
+                    *reinterpret_cast<u32x4 *>(lds_raw + off[k]) = v;
                 }
             }
         }
+        load_wrow(0, ch * C::CK);
+#pragma unroll 1
+        for (int r = 0; r < C::KS; ++r) {
+            __syncthreads();  // input tile visible (r == 0) / previous row's weights consumed
+#pragma unroll
+            for (int it = 0; it < K::ITEMS_WR; ++it) *reinterpret_cast<u32x4 *>(lds_raw + lw_off[it]) = r_w[it];
+            __syncthreads();
+            if (r + 1 < C::KS) load_wrow(r + 1, ch * C::CK);
+#pragma unroll
+            for (int t = 0; t < C::KS; ++t) {
+                const int toff = (r * C::IW + t) * C::PITCH;
+#pragma unroll
+                for (int ks = 0; ks < C::CK / 16; ++ks) {
+                    bf16x8 a[C::MT], b[C::NT];
+#pragma unroll
+                    for (int mt = 0; mt < C::MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8 *>(lds_in + a_base[mt] + toff + ks * 32);
+#pragma unroll
+                    for (int nt = 0; nt < C::NT; ++nt)
+                        b[nt] = *reinterpret_cast<const bf16x8 *>(lds_w + b_base + (t * C::BN + nt * 32) * C::PITCH + ks * 32);
+#pragma unroll
+                    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < C::NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    bf_epilogue<C>(p, acc, wm, wn, l31, hi, n0, y0, x0, co0, 0, 0, 0);
+}
+
+// NCHW fp32 [n][c][hw] -> NHWC fp32 [n][hw][cpad] with zero padding channels (cpad <= 32, a multiple of 4): 64 pixels per
+// workgroup through LDS so that both sides are coalesced.
+__global__ void __launch_bounds__(256) nchw_to_nhwc_pad_kernel(const float *__restrict__ x, float *__restrict__ out, int c, int cpad,
+                                                              size_t hw) {
+    __shared__ float t[32][65];
+    const size_t p0 = (size_t)blockIdx.x * 64;
+    const int n = blockIdx.y;
+    const float *xn = x + (size_t)n * c * hw;
+    for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+        const int ch = i >> 6, px = i & 63;
+        t[ch][px] = (ch < c && p0 + px < hw) ? xn[(size_t)ch * hw + p0 + px] : 0.f;
+    }
+    __syncthreads();
+    float *on = out + ((size_t)n * hw + p0) * cpad;
+    for (int i = threadIdx.x; i < 64 * cpad; i += 256) {
+        const int px = i / cpad, ch = i % cpad;
+        if (p0 + px < hw) on[i] = t[ch][px];
     }
 }
 
@@ -263,6 +419,29 @@ static const TileChoice kBK4S2[] = {bchoice<B_K4S2_T128>(), bchoice<B_K4S2_T64>(
 static const TileChoice kBSP3[] = {bchoice<B_SP3_T256>(), bchoice<B_SP3_T128>(), bchoice<B_SP3_T64>(), bchoice<B_SP3_T64N4>(),
                                    bchoice<B_SP3_T64N16>()};
 
+using B_K5S1_T256 = BfCfg<5, 1, 2, 0, 16, 16, 1, 32, 4, 1, 2, 2>;
+
+static int launch_k5(ConvKParams &kp, hipStream_t st, const ProfInfo &pi) {
+    using C = B_K5S1_T256;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_k5_kernel<C>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, K5Lds<C>::BYTES);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(conv_bf16_k5_kernel): %s", hipGetErrorString(e));
+            return PWS_EHIP;
+        }
+        attr_set = true;
+    }
+    kp.tiles_x = (kp.LW + C::TW - 1) / C::TW, kp.tiles_y = (kp.LH + C::TH - 1) / C::TH;
+    kp.ntiles = (unsigned)(kp.tiles_x * kp.tiles_y * kp.N);
+    kp.ksplit = 1, kp.chunks_per_split = 0, kp.split_stride = 0;
+    ProfScope prof(KID_CONV_BF16, pi.flops, pi.bytes, st);
+    hipLaunchKernelGGL(conv_bf16_k5_kernel<C>, dim3(kp.ntiles, (kp.cout + C::BN - 1) / C::BN), dim3(C::THREADS), K5Lds<C>::BYTES, st,
+                       kp);
+    return check_launch("conv_bf16_k5_kernel");
+}
+
 // Forward kinds.  kp is fully prepared by conv2d_fwd_impl (conv_mfma.hip); returns 1 when this launch is not covered by
 // the bf16 kernels (the caller then runs the fp32 path), else the launch status.
 int conv_bf16_fwd(int kind, ConvKParams &kp, int cin_total, float *out, float *ws, size_t ws_floats, hipStream_t st,
@@ -274,6 +453,10 @@ int conv_bf16_fwd(int kind, ConvKParams &kp, int cin_total, float *out, float *w
     case PWS_CONVT_K3S1: return select_and_launch(kBK3S1, 5, kp, cin_total, out, ws, ws_floats, st, pi);
     case PWS_CONV_K3S2: return select_and_launch(kBK3S2, 5, kp, cin_total, out, ws, ws_floats, st, pi);
     case PWS_CONVT_K4S2: return select_and_launch(kBCT4, 5, kp, cin_total, out, ws, ws_floats, st, pi);
+    case PWS_CONV_K5S1:
+        if (kp.nsrc != 1) return 1;
+        kp.out = out;
+        return launch_k5(kp, st, pi);
     default: return 1;
     }
 }
@@ -311,6 +494,16 @@ __global__ void pack_bf16_kernel(const float *__restrict__ w, unsigned *__restri
 }
 
 }  // namespace pws
+
+extern "C" int pws_nchw_to_nhwc_pad(const float *x, float *out, int n, int c, int h, int w, int cpad, pws_stream_t stream) {
+    PWS_REQUIRE(x && out && n >= 0 && c > 0 && h > 0 && w > 0, "pws_nchw_to_nhwc_pad: bad arguments");
+    PWS_REQUIRE(cpad >= c && cpad <= 32 && cpad % 4 == 0, "pws_nchw_to_nhwc_pad: cpad %d must be a multiple of 4 in [c, 32]", cpad);
+    if (n == 0) return PWS_OK;
+    const size_t hw = (size_t)h * w;
+    hipLaunchKernelGGL(pws::nchw_to_nhwc_pad_kernel, dim3((unsigned)((hw + 63) / 64), (unsigned)n), dim3(256), 0, pws::as_stream(stream),
+                       x, out, c, cpad, hw);
+    return pws::check_launch("nchw_to_nhwc_pad_kernel");
+}
 
 extern "C" size_t pws_packed_bf16_floats(int planes, int krows, int ncols) {
     if (planes <= 0 || krows <= 0 || ncols <= 0) return 0;

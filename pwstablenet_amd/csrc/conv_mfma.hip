@@ -432,6 +432,10 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
         return select_and_launch(kK3S2, 5, kp, kp.cin_pad, a->out, ws, ws_floats, st, info(9, (double)a->n * kp.OH * kp.OW));
     case PWS_CONV_K5S1:
         kp.OH = kp.LH = a->h, kp.OW = kp.LW = a->w;
+        if (bf16) {
+            const int rc = conv_bf16_fwd(a->kind, kp, kp.cin_pad, a->out, nullptr, 0, st, info(25, (double)a->n * a->h * a->w));
+            if (rc != 1) return rc;
+        }
         return select_and_launch(nchw ? kK5N : kK5, 1, kp, kp.cin_pad, a->out, nullptr, 0, st,
                                  info(25, (double)a->n * a->h * a->w));
     case PWS_CONVT_K4S2: {

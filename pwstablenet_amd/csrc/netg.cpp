@@ -38,6 +38,7 @@ static int bf16_planes(int kind) {
     case PWS_CONV_K3S2:
     case PWS_CONVT_K3S1: return 9;
     case PWS_CONVT_K4S2: return 16;
+    case PWS_CONV_K5S1: return 25;
     default: return 0;
     }
 }
@@ -71,7 +72,7 @@ static std::vector<Layer> build_layers(int input_nc, int g, size_t *total_floats
             l.ww_off = off;
             off = align_up(off + pws_packed_wino_floats(cin, cout), 64);
         }
-        if (bf16_planes(kind) && cin % 32 == 0) {
+        if (bf16_planes(kind) && ((cin + 15) / 16 * 16) % 32 == 0) {
             l.wb_off = off;
             off = align_up(off + pws_packed_bf16_floats(bf16_planes(kind), (cin + 15) / 16 * 16, cout), 64);
         }
@@ -178,6 +179,7 @@ class Exec {
     int rc() const { return rc_; }
     const std::vector<Op> &tape() const { return tape_; }
     float *splitk_ws() const { return splitk_ws_; }
+    float *x_nhwc() const { return x_nhwc_; }
     size_t splitk_bytes() const { return splitk_bytes_; }
     float *h_saved(int stage) const { return h_saved_[stage]; }
 
@@ -214,7 +216,12 @@ class Exec {
         if (!launch_ || rc_ != PWS_OK) return o;
         pws_conv_args a{};
         a.kind = l.kind, a.n = n_, a.h = x.h, a.w = x.w;
-        if (nchw_c > 0) {
+        if (nchw_c > 0 && g_math == PWS_MATH_BF16 && l.wb_off != (size_t)-1 && x_nhwc_ && nchw_c <= 32) {
+            // bf16 first layer: the NCHW window is re-laid once as a 32-channel NHWC source (kept for the weight gradient)
+            rc_ = pws_nchw_to_nhwc_pad(nchw_src, x_nhwc_, n_, nchw_c, x.h, x.w, 32, streams_[q_]);
+            if (rc_ != PWS_OK) return o;
+            a.nsrc = 1, a.src[0] = pws_src{x_nhwc_, 32, 32};
+        } else if (nchw_c > 0) {
             a.nsrc = 1, a.src_nchw = 1, a.src[0] = pws_src{nchw_src, nchw_c, 0};
         } else {
             a.nsrc = x.nseg;
@@ -277,11 +284,13 @@ class Exec {
         theta_ws2_ = alloc(pws_theta_head_ws_floats(n_, 4 * ngf, 8 * ngf));
         if (!splitk_ws_ || !splitk_ws2_) splitk_bytes_ = 0;
         for (int s = 0; s < 3; ++s) h_saved_[s] = training ? alloc((size_t)n_ * 8 * ngf) : nullptr;
+        x_nhwc_ = alloc((size_t)n_ * 256 * 256 * 32);  // bf16 math: NHWC copy of the window (unused in fp32 math)
     }
 
   private:
     float *splitk_ws_ = nullptr, *splitk_ws2_ = nullptr, *theta_ws_ = nullptr, *theta_ws2_ = nullptr;
     float *h_saved_[3] = {nullptr, nullptr, nullptr};
+    float *x_nhwc_ = nullptr;
     hipStream_t streams_[2];
     int q_ = 0;
     size_t splitk_bytes_ = 0;
@@ -441,6 +450,8 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             wa.kind = l.kind, wa.n = n, wa.h = op.in.h, wa.w = op.in.w, wa.nsrc = op.in.nseg, wa.src_nchw = op.nchw ? 1 : 0;
             for (int i = 0; i < op.in.nseg; ++i) wa.src[i] = pws_src{op.in.seg[i].ptr, op.in.seg[i].c, op.in.seg[i].ld};
             if (op.nchw) wa.src[0] = pws_src{x, input_nc, 0};
+            if (op.nchw && g_math == PWS_MATH_BF16 && l.wb_off != (size_t)-1 && E.x_nhwc() && input_nc <= 32)
+                wa.src_nchw = 0, wa.src[0] = pws_src{E.x_nhwc(), 32, 32};  // the forward's NHWC copy
             wa.cout = l.cout, wa.gout = go.g, wa.gout_ld = l.cout, wa.dw_packed = dpacked + l.w_off;
             wa.math = g_math;
             rc = pws_conv2d_bwd_weight(&wa, st);

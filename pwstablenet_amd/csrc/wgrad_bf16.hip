@@ -251,6 +251,7 @@ using WB_K3S1_T64N16 = WbCfg<3, 1, 1, 0, 2, 2, 16, 9>;
 using WB_K3S2_T64 = WbCfg<3, 2, 1, 0, 8, 8, 1, 9>;
 using WB_K3S2_T64N4 = WbCfg<3, 2, 1, 0, 4, 4, 4, 9>;
 using WB_K3S2_T64N16 = WbCfg<3, 2, 1, 0, 2, 2, 16, 9>;
+using WB_K5S1_T128 = WbCfg<5, 1, 2, 0, 8, 16, 1, 5>;   // first layer: one kernel row of taps per workgroup
 using WB_CT4_T256 = WbCfg<2, 1, 0, 1, 16, 16, 1, 4>;
 using WB_CT4_T64 = WbCfg<2, 1, 0, 1, 8, 8, 1, 4>;
 using WB_CT4_T64N4 = WbCfg<2, 1, 0, 1, 4, 4, 4, 4>;
@@ -259,6 +260,7 @@ using WB_CT4_T64N16 = WbCfg<2, 1, 0, 1, 2, 2, 16, 4>;
 static const WbChoice kWbK3S1[] = {wbchoice<WB_K3S1_T256>(), wbchoice<WB_K3S1_T64>(), wbchoice<WB_K3S1_T64N4>(),
                                    wbchoice<WB_K3S1_T64N16>()};
 static const WbChoice kWbK3S2[] = {wbchoice<WB_K3S2_T64>(), wbchoice<WB_K3S2_T64N4>(), wbchoice<WB_K3S2_T64N16>()};
+static const WbChoice kWbK5[] = {wbchoice<WB_K5S1_T128>()};
 static const WbChoice kWbCT4[] = {wbchoice<WB_CT4_T256>(), wbchoice<WB_CT4_T64>(), wbchoice<WB_CT4_T64N4>(),
                                   wbchoice<WB_CT4_T64N16>()};
 
@@ -303,6 +305,10 @@ int wgrad_bf16_launch(const pws_conv_bwd_weight_args *a, hipStream_t st) {
     case PWS_CONVT_K4S2:
         p.LH = a->h, p.LW = a->w, p.OH = 2 * a->h, p.OW = 2 * a->w, nclasses = 4, k2 = 4;
         c = &pick(kWbCT4, 4, p.LH, p.LW, p.N);
+        break;
+    case PWS_CONV_K5S1:
+        p.OH = p.LH = a->h, p.OW = p.LW = a->w, k2 = 25;
+        c = &kWbK5[0];
         break;
     default: return 1;
     }

@@ -63,6 +63,7 @@ SIGNATURES = {
     "pws_get_option": (_I, [_I]),
     "pws_packed_bf16_floats": (_S, [_I, _I, _I]),
     "pws_pack_weight_bf16": (_I, [_P, _P, _I, _I, _I, _P]),
+    "pws_nchw_to_nhwc_pad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "pws_device_info": (_I, [ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "pws_packed_weight_floats": (_S, [_I, _I, _I]),
     "pws_pack_conv_weight": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -22,7 +22,8 @@ import torch.nn.functional as F  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 KINDS = {"CONV_K3S1": ("conv", 3, 1, 1), "CONV_K3S2": ("conv", 3, 2, 1), "CONVT_K3S1": ("convT", 3, 1, 1),
-         "CONVT_K4S2": ("convT", 4, 2, 1)}
+         "CONVT_K4S2": ("convT", 4, 2, 1), "CONV_K5S1": ("conv", 5, 1, 2)}
+PLANES = {"CONV_K3S1": 9, "CONV_K3S2": 9, "CONVT_K3S1": 9, "CONVT_K4S2": 16, "CONV_K5S1": 25}
 TIGHT, STATED = 3e-5, 1.5e-2
 
 CASES = [
@@ -34,6 +35,7 @@ CASES = [
     ("CONVT_K3S1", (2, 18, 21), [32, 64], 48), ("CONVT_K3S1", (2, 4, 4), [32], 16), ("CONVT_K3S1", (2, 2, 2), [256], 256),
     ("CONVT_K4S2", (2, 17, 19), [32, 32, 64], 64), ("CONVT_K4S2", (2, 8, 8), [32], 32), ("CONVT_K4S2", (3, 4, 4), [32, 32], 16),
     ("CONVT_K4S2", (20, 2, 2), [32], 64), ("CONVT_K4S2", (1, 32, 32), [128, 64], 64),
+    ("CONV_K5S1", (1, 23, 40), [32], 64), ("CONV_K5S1", (2, 16, 16), [32], 64), ("CONV_K5S1", (1, 9, 70), [64], 32),
 ]
 
 
@@ -77,7 +79,7 @@ def hip_fwd(A, kname, x, wt, b, act, src_c, cout, ws_mb):
     wp = torch.empty(L.pws_packed_weight_floats(kind, cin, cout), device="cuda")
     d_w = wt.cuda()
     A.check(L.pws_pack_conv_weight(A.ptr(d_w), A.ptr(wp), kind, cin, cout, st), "pack")
-    planes = 16 if kname == "CONVT_K4S2" else 9
+    planes = PLANES[kname]
     cin_pad = (cin + 15) // 16 * 16
     wb = torch.empty(L.pws_packed_bf16_floats(planes, cin_pad, cout), device="cuda")
     A.check(L.pws_pack_weight_bf16(A.ptr(wp), A.ptr(wb), planes, cin_pad, cout, st), "pack_bf16")
@@ -123,7 +125,7 @@ def test_bf16_conv_forward(hip, kname, shape, src_c, cout, act):
     assert relerr(got, want_fp32) < STATED, relerr(got, want_fp32)
 
 
-@pytest.mark.parametrize("kname,shape,src_c,cout", [c for c in CASES if c[3] % 32 == 0])
+@pytest.mark.parametrize("kname,shape,src_c,cout", [c for c in CASES if c[3] % 32 == 0 and c[0] != "CONV_K5S1"])
 def test_bf16_conv_data_gradient(hip, kname, shape, src_c, cout):
     A = hip
     L, st = A.lib(), A.current_stream()
@@ -307,3 +309,24 @@ def test_netg_bf16_training_step_gradients_vs_fp32(hip):
     for r_, k in sorted(rel)[-6:]:
         print("   %-44s %.4f" % (k, r_))
     assert worst < 0.15, (worst, worst_name)
+
+
+def test_nchw_to_nhwc_pad_and_first_layer_bf16(hip):
+    """The 31-channel NCHW window becomes a 32-channel NHWC source (zero pad channel); the bf16 k5 kernel on it matches
+    the fp32 reference on bf16-rounded operands."""
+    A = hip
+    L, st = A.lib(), A.current_stream()
+    rs = np.random.RandomState(77)
+    x = torch.from_numpy(rs.standard_normal((2, 31, 19, 37)).astype(np.float32))
+    d_x = x.cuda()
+    out = torch.full((2, 19, 37, 32), float("nan"), device="cuda")
+    A.check(L.pws_nchw_to_nhwc_pad(A.ptr(d_x), A.ptr(out), 2, 31, 19, 37, 32, st), "nchw_to_nhwc_pad")
+    got = out.cpu()
+    assert torch.equal(got[..., :31], x.permute(0, 2, 3, 1)) and (got[..., 31] == 0).all()
+    wt = torch.from_numpy((rs.standard_normal((64, 31, 5, 5)) / 28.0).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal(64).astype(np.float32))
+    x32 = torch.cat([x, torch.zeros(2, 1, 19, 37)], 1)
+    w32 = torch.cat([wt, torch.zeros(64, 1, 5, 5)], 1)
+    y = hip_fwd(A, "CONV_K5S1", bf16r(x32), w32, b, 1, [32], 64, 0).numpy()
+    want = nhwc(torch_layer("CONV_K5S1", bf16r(x), bf16r(wt), b, 1)).numpy()
+    assert relerr(y, want) < TIGHT
