@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch the forward eagerly instead of replaying a hipGraph")
     ap.add_argument("--serial", action="store_true", help="single queue for the whole run (clean per-kernel durations under rocprof)")
     ap.add_argument("--gs-batch", type=int, default=256, help="frames in the grid_sample roofline launch")
+    ap.add_argument("--math", choices=("fp32", "bf16"), default="fp32",
+                    help="conv arithmetic of the TIMED region (default fp32 = configs[1], the headline); bf16 is for profiling the "
+                         "bf16 path: metric/dtype fields say so and vs_baseline stays null")
     ap.add_argument("--no-extra", action="store_true", help="skip the bf16 inference / training-step legs (extra JSON fields)")
     return ap.parse_args()
 
@@ -224,6 +227,7 @@ def main():
     net = define_G(31, 2, 64, "normal", 0.02)
     net.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in synth.make_weights("W1", seed=123, ngf=64)})
     net = net.to(dev)
+    net.module.set_math(a.math)
     x = torch.from_numpy(synth.noise_window(B, 31, 256, seed=123 + rank)).to(dev)
     frames = torch.from_numpy(synth.make_frames(B, 3, 256, 256, seed=321 + rank)).to(dev)
 
@@ -275,10 +279,10 @@ def main():
     if rank == 0:
         fps = world * B * a.steps / elapsed
         line = {
-            "metric": "stabilized frames/sec at 256x256 (netG fp32 + grid_sample), whole job",
+            "metric": "stabilized frames/sec at 256x256 (netG %s + grid_sample), whole job" % a.math,
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if a.math == "fp32" else "bf16 operands, f32 accumulate", "data": "synthetic",
             "config": {"workload": "configs[1]: batch=8 256x256 inference per GPU, fp32 HIP conv + grid_sample; "
                                    "frame-sharded, no collective", "frames_per_gpu_per_step": B,
                        "launch": ("eager" if a.no_graph else "hipGraph replay of the forward + 1 grid_sample launch") +
@@ -295,8 +299,9 @@ def main():
             dom = max(agg.items(), key=lambda kv: kv[1][3])
             name, (cnt, fl, by, ms) = dom
             ach = fl / (ms * 1e-3) / 1e12
-            line["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS,
-                                "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": pmc_traffic(name),
+            peak = PEAK_BF16_TFLOPS if "bf16" in name else PEAK_FP32_TFLOPS
+            line["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
+                                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": pmc_traffic(name),
                                 "algorithmic_bytes_per_launch": round(by / cnt),
                                 "launches": cnt, "avg_launch_us": round(1e3 * ms / cnt, 2),
                                 "flops_per_launch": fl / cnt}
@@ -357,7 +362,7 @@ def main():
                                                 "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_us": round(1e3 * ms, 2),
                                                 "bytes_per_launch": r[0][3]}}
         del f720
-        if not a.no_extra:
+        if not a.no_extra and a.math == "fp32":
             line["bf16"] = bf16_legs(net, x, frames, out, a, PF, A)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(B)

@@ -89,6 +89,10 @@ int pws_pack_conv_weight(const float *w_torch, float *w_packed, int kind, int ci
  * K3S1 / CONVT_K3S1 layer (so the transposed conv's tap flip is already applied). */
 size_t pws_packed_wino_floats(int cin, int cout);
 int pws_pack_conv_weight_wino(const float *w_packed, float *w_wino, int cin, int cout, pws_stream_t stream);
+/* The same for ConvTranspose2d k4 s2 p1 (CONVT_K4S2): each of the 4 output parity classes is a 2x2 correlation, run as
+ * Winograd F(3x3,2x2) on 4x4 input patches; U as [4 classes][16][cin padded to 16][cout] from the PACKED weights. */
+size_t pws_packed_wino_ct4_floats(int cin, int cout);
+int pws_pack_conv_weight_wino_ct4(const float *w_packed, float *w_wino, int cin, int cout, pws_stream_t stream);
 
 /* bf16 copy of a packed weight for the bf16 matrix-core kernels: w_packed is [planes][krows][ncols] fp32 (the forward
  * layout: planes = taps (x4 classes for CONVT_K4S2), krows = cin padded to 16, ncols = cout; or the data-gradient layout:
@@ -121,8 +125,9 @@ typedef struct pws_conv_args {
     int act;          /* PWS_ACT_* */
     float *out;       /* NHWC, output height/width implied by kind */
     int out_ld;       /* pixel stride of out in floats (>= cout) */
-    const float *w_wino; /* optional (K3S1 / CONVT_K3S1): Winograd-domain weights from pws_pack_conv_weight_wino; when
-                            given and the map is large enough the F(2x2,3x3) kernel runs instead of the direct one */
+    const float *w_wino; /* optional: Winograd-domain weights from pws_pack_conv_weight_wino (K3S1 / CONVT_K3S1) or
+                            pws_pack_conv_weight_wino_ct4 (CONVT_K4S2); when given and the map is large enough the
+                            F(2x2,3x3) / F(3x3,2x2) kernel runs instead of the direct one */
     void *ws;         /* optional scratch for split-K partial tiles (16-B aligned) or NULL: small-spatial layers */
     size_t ws_bytes;  /* then run un-split.  Any size works; 64 x n*oh*ow*cout*4 bytes never limits the split. */
     int math;         /* PWS_MATH_FP32 (0) | PWS_MATH_BF16: needs w_bf16 and every source's channels % 32 == 0,

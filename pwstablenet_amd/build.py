@@ -22,14 +22,60 @@ def _deps():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
+def _resources(stderr_text):
+    """Parses hipcc's -Rpass-analysis=kernel-resource-usage remarks: {kernel: {vgprs, scratch, occupancy, lds}}."""
+    import re
+    out, cur = {}, None
+    for line in stderr_text.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        if cur is None:
+            continue
+        for key, pat in (("vgprs", r"\bVGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                         ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)"), ("lds", r"LDS Size \[bytes/block\]: (\d+)")):
+            m = re.search(pat, line)
+            if m:
+                cur[key] = int(m.group(1))
+    return out
+
+
 def _compile(src, force):
     s = os.path.join(CSRC, src)
     o = os.path.join(OBJ, src + ".o")
     if not force and os.path.exists(o) and os.path.getmtime(o) >= max(os.path.getmtime(s), _deps()):
         return o, False
-    cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", s, "-o", o]
-    subprocess.check_call(cmd)
+    hip = src.endswith(".hip")
+    cmd = [HIPCC] + FLAGS + (["-x", "hip", "-Rpass-analysis=kernel-resource-usage"] if hip else []) + ["-c", s, "-o", o]
+    r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    if hip:
+        # per-kernel register / scratch / occupancy report next to the object (tests/test_boundary.py reads these:
+        # a refactor that pushes accumulators into scratch must not go unnoticed)
+        import json
+        with open(o + ".resources.json", "w") as f:
+            json.dump(_resources(r.stderr), f, indent=1, sort_keys=True)
+        err = "\n".join(ln for ln in r.stderr.splitlines() if "kernel-resource-usage" not in ln and not ln.lstrip().startswith(("|", "^"))
+                        and not ln.strip()[:1].isdigit())
+    else:
+        err = r.stderr
+    if err.strip():
+        sys.stderr.write(err + "\n")
+    if r.returncode != 0:
+        raise subprocess.CalledProcessError(r.returncode, cmd)
     return o, True
+
+
+def kernel_resources():
+    """{source: {kernel: {...}}} from the last build of each HIP source."""
+    import json
+    out = {}
+    for src in SOURCES:
+        f = os.path.join(OBJ, src + ".o.resources.json")
+        if os.path.exists(f):
+            with open(f) as fh:
+                out[src] = json.load(fh)
+    return out
 
 
 def build(force=False, verbose=True):

@@ -42,35 +42,32 @@ struct BfCfg {
     static_assert(BN == 64, "weights are padded to 64 output channels per block");
 };
 
-// bias + activation / gradient scatter (or raw partial sums when K is split) and the NHWC store, as in conv_mfma.hip
-template <class C>
-__device__ __forceinline__ void bf_epilogue(const ConvKParams &p, f32x16 (&acc)[C::MT][C::NT], int wm, int wn, int l31, int hi, int n0,
-                                            int y0, int x0, int co0, int py, int px, int split) {
-    const bool partial = p.ksplit > 1;
-    float *part = p.out + (size_t)split * p.split_stride;
-#pragma unroll
-    for (int nt = 0; nt < C::NT; ++nt) {
-        const int co = co0 + (wn * C::NT + nt) * 32 + l31;
-        const bool co_ok = co < p.cout;
-#pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (wm * C::MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
-                const int n = n0 + tn, y = y0 + ty, x = x0 + tx;
-                const int oy = C::CONVT ? 2 * y + py : y, ox = C::CONVT ? 2 * x + px : x;
-                if (co_ok && n < p.N && y < p.LH && x < p.LW && oy < p.OH && ox < p.OW) {
-                    const size_t pix = (size_t)(n * p.OH + oy) * p.OW + ox;
-                    if (partial)
-                        part[pix * p.cout + co] = acc[mt][nt][r];
-                    else
-                        epi_store(p, pix, co, acc[mt][nt][r]);
-                }
-            }
-        }
-    }
-}
+// bias + activation / gradient scatter (or raw partial sums when K is split) and the NHWC store, as in conv_mfma.hip.
+// A macro, not a function: passing the accumulator array by reference made hipcc keep it in scratch (732 B per lane).
+#define PWS_BF_EPILOGUE(C, p, acc, wm, wn, l31, hi, n0, y0, x0, co0, py, px, split)                                        \
+    do {                                                                                                                   \
+        const bool partial_ = (p).ksplit > 1;                                                                              \
+        float *part_ = (p).out + (size_t)(split) * (p).split_stride;                                                       \
+        _Pragma("unroll") for (int nt = 0; nt < C::NT; ++nt) {                                                             \
+            const int co = (co0) + ((wn) * C::NT + nt) * 32 + (l31);                                                       \
+            const bool co_ok = co < (p).cout;                                                                              \
+            _Pragma("unroll") for (int mt = 0; mt < C::MT; ++mt) {                                                         \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                           \
+                    const int m = ((wm) * C::MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (hi);                            \
+                    const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);                          \
+                    const int n = (n0) + tn, y = (y0) + ty, x = (x0) + tx;                                                 \
+                    const int oy = C::CONVT ? 2 * y + (py) : y, ox = C::CONVT ? 2 * x + (px) : x;                          \
+                    if (co_ok && n < (p).N && y < (p).LH && x < (p).LW && oy < (p).OH && ox < (p).OW) {                    \
+                        const size_t pix = (size_t)(n * (p).OH + oy) * (p).OW + ox;                                        \
+                        if (partial_)                                                                                      \
+                            part_[pix * (p).cout + co] = acc[mt][nt][r];                                                   \
+                        else                                                                                               \
+                            epi_store(p, pix, co, acc[mt][nt][r]);                                                         \
+                    }                                                                                                      \
+                }                                                                                                          \
+            }                                                                                                              \
+        }                                                                                                                  \
+    } while (0)
 
 template <class C>
 __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_kernel(const ConvKParams p) {
@@ -206,7 +203,7 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_kernel(const ConvKPar
         }
     }
 
-    bf_epilogue<C>(p, acc, wm, wn, l31, hi, n0, y0, x0, co0, py, px, split);
+    PWS_BF_EPILOGUE(C, p, acc, wm, wn, l31, hi, n0, y0, x0, co0, py, px, split);
 }
 
 // First layer (Conv2d k5 s1 p2, 31 -> 64 channels): 25 taps x 64 output rows of weights do not fit LDS beside the input tile
@@ -336,7 +333,7 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_k5_kernel(const ConvK
             }
         }
     }
-    bf_epilogue<C>(p, acc, wm, wn, l31, hi, n0, y0, x0, co0, 0, 0, 0);
+    PWS_BF_EPILOGUE(C, p, acc, wm, wn, l31, hi, n0, y0, x0, co0, 0, 0, 0);
 }
 
 // NCHW fp32 [n][c][hw] -> NHWC fp32 [n][hw][cpad] with zero padding channels (cpad <= 32, a multiple of 4): 64 pixels per

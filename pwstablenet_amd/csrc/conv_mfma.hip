@@ -446,6 +446,12 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
             const int rc = conv_bf16_fwd(a->kind, kp, kp.cin_pad, a->out, ws, ws_floats, st, pi);
             if (rc != 1) return rc;
         }
+        // Winograd F(3x3,2x2) per parity class (4 classes x 12x24-pixel workgroups) when the caller packed the weights for it.
+        // Measured (tools/conv_bench.py, N=8): 256->64 @128x128 646 vs 661 us direct, but 512->64 @64x64 473 vs 333 us -- the
+        // 3-pixel tiles waste 21-41 % of a 64/32-pixel map and the 9-output epilogue is 2.25x the F(2x2,3x3) one -- so the
+        // generator's executor does not pack these weights; the path stays available for large maps.
+        const long wb = cdiv(a->w, 24) * cdiv(a->h, 12) * a->n * cdiv(a->cout, 64) * 4;
+        if (a->w_wino && a->h >= 24 && a->w >= 24 && wb >= 256) return wino_k3s1_launch(a, ProfHint{pi.flops, pi.bytes}, st);
         return select_and_launch(kCT4, 5, kp, kp.cin_pad, a->out, ws, ws_floats, st, pi);
     }
     default:

@@ -16,6 +16,13 @@
 //     the four rows meet in LDS once (2 partial values per tile and channel), then bias + activation and NHWC stores with
 //     lane = channel (256-B coalesced per pixel).
 // fp32 throughout; the result differs from the direct kernel by Winograd's usual ~1e-6 relative rounding.
+//
+// MODE 1 -- the same machinery for ConvTranspose2d k4 s2 p1: each output parity class (py, px) is a 2x2 correlation
+// (pack.hip), i.e. F(3x3, 2x2) on the SAME 4x4 input patches and the same B^T (the interpolation points 0, 1, -1, inf are
+// unchanged), 16 multiplies for 9 outputs x 4 taps = 2.25x fewer as well:
+//     G = [[1,0],[1/2,1/2],[1/2,-1/2],[0,1]]      A^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]]
+// Tiles advance by 3 pixels (raw halo tile 13 x 25 for the 4 x 8 tiles of a workgroup = 12 x 24 class outputs = 24 x 48
+// output pixels of that parity), blockIdx.z = class, epilogue = 3 x 3 outputs per tile in two 32-channel passes.
 #include <cstdlib>
 #include <type_traits>
 
@@ -43,38 +50,48 @@ struct WinoParams {
 };
 
 constexpr int WN_CK = 8, WN_CKP = 9;
-constexpr int WN_TH = 8, WN_TW = 16;                        // output pixels per workgroup: 4 x 8 = 32 Winograd tiles
-constexpr int WN_RH = WN_TH + 2, WN_RW = WN_TW + 2;         // raw halo tile
-constexpr int WN_RAW = (WN_RH * WN_RW * WN_CKP + 3) / 4 * 4;  // floats (16-B multiple: U below is float4-accessed)
 constexpr int WN_V = 16 * 32 * WN_CKP;                      // floats per V buffer  [xi][tile][8+1]
 constexpr int WN_U = 16 * WN_CK * 64;                       // floats: U chunk     [xi][k][64 cout]
-constexpr int WN_LDS_MAIN = WN_RAW + 2 * WN_V + WN_U;       // 19028 floats = 76.1 KB  -> 2 workgroups per CU
-constexpr int WN_EP = 65;                                   // epilogue row pad: [i 4][b 2][tile 32][64 + 1]
-constexpr int WN_LDS_EPI = 4 * 2 * 32 * WN_EP;              // 16640 floats
-constexpr int WN_LDS_BYTES = (WN_LDS_MAIN > WN_LDS_EPI ? WN_LDS_MAIN : WN_LDS_EPI) * 4;
-constexpr int WN_RAW_ITEMS = WN_RH * WN_RW * 2;             // float4 items of the raw tile (360)
 
-__global__ void __launch_bounds__(256, 2) wino_k3s1_kernel(const WinoParams p) {
+template <int MODE>
+struct WinoGeo {
+    static constexpr int OT = MODE == 0 ? 2 : 3;                 // outputs per tile and dimension
+    static constexpr int TH = 4 * OT, TW = 8 * OT;               // (class) output pixels per workgroup: 4 x 8 tiles
+    static constexpr int RH = TH + 4 - OT, RW = TW + 4 - OT;     // raw halo tile
+    static constexpr int RAW = (RH * RW * WN_CKP + 3) / 4 * 4;   // floats (16-B multiple: U below is float4-accessed)
+    static constexpr int LDS_MAIN = RAW + 2 * WN_V + WN_U;       // MODE 0: 19028 floats = 76.1 KB, MODE 1: 79.4 KB -> 2 per CU
+    static constexpr int EPW = MODE == 0 ? 65 : 33;              // epilogue row pad
+    static constexpr int LDS_EPI = MODE == 0 ? 4 * 2 * 32 * 65 : 4 * 3 * 32 * 33;
+    static constexpr int LDS_BYTES = (LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI) * 4;
+    static constexpr int RAW_ITEMS = RH * RW * 2;                // float4 items of the raw tile
+    static constexpr int RITS = (RAW_ITEMS + 255) / 256;         // per thread
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 2) wino_kernel(const WinoParams p) {
+    using G = WinoGeo<MODE>;
     extern __shared__ float lds[];
     float *raw = lds;
-    float *vbuf = lds + WN_RAW;
-    float *ubuf = lds + WN_RAW + 2 * WN_V;
+    float *vbuf = lds + G::RAW;
+    float *ubuf = lds + G::RAW + 2 * WN_V;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
 
     const unsigned tile = xcd_remap(blockIdx.x, p.ntiles);
     const int tx_i = tile % p.tiles_x, ty_i = (tile / p.tiles_x) % p.tiles_y, n = tile / (p.tiles_x * p.tiles_y);
-    const int y0 = ty_i * WN_TH, x0 = tx_i * WN_TW, co0 = blockIdx.y * 64;
+    const int y0 = ty_i * G::TH, x0 = tx_i * G::TW, co0 = blockIdx.y * 64;
+    const int cls = MODE == 1 ? (int)blockIdx.z : 0, py = cls >> 1, px = cls & 1;  // MODE 1: output parity class
 
-    // ---- raw-tile staging descriptors: 180 pixels x 2 float4 over 256 threads (2 per thread, second one partial)
-    int g_pix[2], l_off[2], g_c4[2];
-    bool g_ok[2];
+    // ---- raw-tile staging descriptors: RH x RW pixels x 2 float4 over 256 threads (last item partial)
+    constexpr int RITS = G::RITS;
+    int g_pix[RITS], l_off[RITS], g_c4[RITS];
+    bool g_ok[RITS];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < RITS; ++it) {
         const int item = tid + it * 256;
         const int pix = item >> 1, c4 = (item & 1) * 4;
-        const int ly = pix / WN_RW, lx = pix % WN_RW;
-        const int iy = y0 - 1 + ly, ix = x0 - 1 + lx;
-        const bool in = item < WN_RAW_ITEMS;
+        const int ly = pix / G::RW, lx = pix % G::RW;
+        const int iy = y0 - 1 + ly + (MODE == 1 ? py : 0), ix = x0 - 1 + lx + (MODE == 1 ? px : 0);
+        const bool in = item < G::RAW_ITEMS;
         g_ok[it] = in && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         g_pix[it] = g_ok[it] ? (n * p.H + iy) * p.W + ix : 0;
         l_off[it] = in ? pix * WN_CKP + c4 : -1;
@@ -82,16 +99,16 @@ __global__ void __launch_bounds__(256, 2) wino_k3s1_kernel(const WinoParams p) {
     }
     // Global loads run TWO chunks ahead of their use (a chunk is only ~1-2 us of matrix work, about one HBM latency):
     // two register sets each for the raw tile and for U, indexed statically (the chunk loop is unrolled by 2).
-    float4 r_raw[2][2];
-    auto load_raw = [&](float4 (&r)[2], int s, int c0) {
+    float4 r_raw[2][RITS];
+    auto load_raw = [&](float4 (&r)[RITS], int s, int c0) {
         const float *sp = p.src_ptr[s] + c0;
         const size_t ld = p.src_ld[s];
 #pragma unroll
-        for (int it = 0; it < 2; ++it) r[it] = *reinterpret_cast<const float4 *>(sp + (size_t)g_pix[it] * ld + g_c4[it]);
+        for (int it = 0; it < RITS; ++it) r[it] = *reinterpret_cast<const float4 *>(sp + (size_t)g_pix[it] * ld + g_c4[it]);
     };
-    auto store_raw = [&](const float4 (&r)[2]) {
+    auto store_raw = [&](const float4 (&r)[RITS]) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
+        for (int it = 0; it < RITS; ++it) {
             if (l_off[it] >= 0) {
                 float *d = raw + l_off[it];
                 d[0] = g_ok[it] ? r[it].x : 0.f, d[1] = g_ok[it] ? r[it].y : 0.f;
@@ -103,7 +120,7 @@ __global__ void __launch_bounds__(256, 2) wino_k3s1_kernel(const WinoParams p) {
     float4 r_u[2][8];
     const int u_q = (tid & 15) * 4, u_k = (tid >> 4) & 7;      // item = tid + it*256 -> xi = it*2 + (tid >> 7)
     const bool u_ok = co0 + u_q < p.cout;
-    const float *u_base = p.uw + ((size_t)(tid >> 7) * p.cin_pad + u_k) * p.cout + (u_ok ? co0 + u_q : 0);
+    const float *u_base = p.uw + ((size_t)(cls * 16 + (tid >> 7)) * p.cin_pad + u_k) * p.cout + (u_ok ? co0 + u_q : 0);
     auto load_u = [&](float4 (&r)[8], int wrow) {
 #pragma unroll
         for (int it = 0; it < 8; ++it)
@@ -116,14 +133,14 @@ __global__ void __launch_bounds__(256, 2) wino_k3s1_kernel(const WinoParams p) {
     };
     // ---- input transform: thread = (tile t, channel c)
     const int t_tile = tid >> 3, t_c = tid & 7;
-    const int t_src = ((2 * (t_tile >> 3)) * WN_RW + 2 * (t_tile & 7)) * WN_CKP + t_c;
+    const int t_src = ((G::OT * (t_tile >> 3)) * G::RW + G::OT * (t_tile & 7)) * WN_CKP + t_c;
     const int t_dst = t_tile * WN_CKP + t_c;
     auto transform = [&](float *vdst) {
         float d[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) d[i][j] = raw[t_src + (i * WN_RW + j) * WN_CKP];
+            for (int j = 0; j < 4; ++j) d[i][j] = raw[t_src + (i * G::RW + j) * WN_CKP];
         float t[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -221,38 +238,83 @@ __global__ void __launch_bounds__(256, 2) wino_k3s1_kernel(const WinoParams p) {
         if (acc[0][0][0] == 12345.678f) p.out[0] = acc[3][1][3];  // keep the accumulators live
         return;
     }
-    float *eb = lds;  // [i = wave][b][tile][64 + 1]
+    float *eb = lds;  // MODE 0: [i = wave][b 2][tile][64 + 1]   MODE 1: [i = wave][b 3][tile][32 + 1] per 32-channel pass
+    if constexpr (MODE == 0) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int trow = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float t0 = acc[0][nt][r] + acc[1][nt][r] + acc[2][nt][r];
-            const float t1 = acc[1][nt][r] - acc[2][nt][r] - acc[3][nt][r];
-            eb[((wv * 2 + 0) * 32 + trow) * WN_EP + nt * 32 + l31] = t0;
-            eb[((wv * 2 + 1) * 32 + trow) * WN_EP + nt * 32 + l31] = t1;
+            for (int r = 0; r < 16; ++r) {
+                const int trow = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float t0 = acc[0][nt][r] + acc[1][nt][r] + acc[2][nt][r];
+                const float t1 = acc[1][nt][r] - acc[2][nt][r] - acc[3][nt][r];
+                eb[((wv * 2 + 0) * 32 + trow) * G::EPW + nt * 32 + l31] = t0;
+                eb[((wv * 2 + 1) * 32 + trow) * G::EPW + nt * 32 + l31] = t1;
+            }
+        __syncthreads();
+        {
+            const int col = tid & 63;           // lane = channel: 256-B coalesced stores per output pixel
+            const int co = co0 + col;
+            const float bias = (p.bias && co < p.cout) ? p.bias[co] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int t = (tid >> 6) + 4 * k;
+                float e[4][2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) e[i][0] = eb[((i * 2 + 0) * 32 + t) * G::EPW + col], e[i][1] = eb[((i * 2 + 1) * 32 + t) * G::EPW + col];
+                const float y00 = e[0][0] + e[1][0] + e[2][0], y01 = e[0][1] + e[1][1] + e[2][1];
+                const float y10 = e[1][0] - e[2][0] - e[3][0], y11 = e[1][1] - e[2][1] - e[3][1];
+                const int oy = y0 + 2 * (t >> 3), ox = x0 + 2 * (t & 7);
+                if (co < p.cout) {
+                    float *o = p.out + ((size_t)(n * p.H + oy) * p.W + ox) * p.out_ld + co;
+                    const size_t rs = (size_t)p.W * p.out_ld;
+                    if (oy < p.H && ox < p.W) o[0] = act_apply(y00 + bias, p.act);
+                    if (oy < p.H && ox + 1 < p.W) o[p.out_ld] = act_apply(y01 + bias, p.act);
+                    if (oy + 1 < p.H && ox < p.W) o[rs] = act_apply(y10 + bias, p.act);
+                    if (oy + 1 < p.H && ox + 1 < p.W) o[rs + p.out_ld] = act_apply(y11 + bias, p.act);
+                }
+            }
         }
-    __syncthreads();
-    {
-        const int col = tid & 63;           // lane = channel: 256-B coalesced stores per output pixel
-        const int co = co0 + col;
-        const float bias = (p.bias && co < p.cout) ? p.bias[co] : 0.f;
+    } else {
+        // F(3x3,2x2): three column outputs per row-wave, three rows out; LDS holds one 32-channel half at a time
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int t = (tid >> 6) + 4 * k;
-            float e[4][2];
+        for (int nt = 0; nt < 2; ++nt) {
+            if (nt) __syncthreads();  // the first half has been read
 #pragma unroll
-            for (int i = 0; i < 4; ++i) e[i][0] = eb[((i * 2 + 0) * 32 + t) * WN_EP + col], e[i][1] = eb[((i * 2 + 1) * 32 + t) * WN_EP + col];
-            const float y00 = e[0][0] + e[1][0] + e[2][0], y01 = e[0][1] + e[1][1] + e[2][1];
-            const float y10 = e[1][0] - e[2][0] - e[3][0], y11 = e[1][1] - e[2][1] - e[3][1];
-            const int oy = y0 + 2 * (t >> 3), ox = x0 + 2 * (t & 7);
-            if (co < p.cout) {
-                float *o = p.out + ((size_t)(n * p.H + oy) * p.W + ox) * p.out_ld + co;
-                const size_t rs = (size_t)p.W * p.out_ld;
-                if (oy < p.H && ox < p.W) o[0] = act_apply(y00 + bias, p.act);
-                if (oy < p.H && ox + 1 < p.W) o[p.out_ld] = act_apply(y01 + bias, p.act);
-                if (oy + 1 < p.H && ox < p.W) o[rs] = act_apply(y10 + bias, p.act);
-                if (oy + 1 < p.H && ox + 1 < p.W) o[rs + p.out_ld] = act_apply(y11 + bias, p.act);
+            for (int r = 0; r < 16; ++r) {
+                const int trow = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float m1 = acc[1][nt][r], m2 = acc[2][nt][r];
+                eb[((wv * 3 + 0) * 32 + trow) * G::EPW + l31] = acc[0][nt][r] + m1 + m2;
+                eb[((wv * 3 + 1) * 32 + trow) * G::EPW + l31] = m1 - m2;
+                eb[((wv * 3 + 2) * 32 + trow) * G::EPW + l31] = m1 + m2 - acc[3][nt][r];
+            }
+            __syncthreads();
+            const int col = tid & 31;           // lane = channel: 128-B coalesced stores per output pixel
+            const int co = co0 + nt * 32 + col;
+            const float bias = (p.bias && co < p.cout) ? p.bias[co] : 0.f;
+            const int OH = 2 * p.H, OW = 2 * p.W;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = (tid >> 5) + 8 * k;
+                float e[4][3];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) e[i][b] = eb[((i * 3 + b) * 32 + t) * G::EPW + col];
+                const int yy = y0 + 3 * (t >> 3), xx = x0 + 3 * (t & 7);
+                if (co < p.cout) {
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        const float o0 = e[0][b] + e[1][b] + e[2][b], o1 = e[1][b] - e[2][b], o2 = e[1][b] + e[2][b] - e[3][b];
+                        const int ox = 2 * (xx + b) + px;
+                        if (xx + b < p.W) {
+                            float *o = p.out + ((size_t)(n * OH + 2 * yy + py) * OW + ox) * p.out_ld + co;
+                            const size_t rs = (size_t)2 * OW * p.out_ld;  // next class row = two output rows
+                            if (yy < p.H) o[0] = act_apply(o0 + bias, p.act);
+                            if (yy + 1 < p.H) o[rs] = act_apply(o1 + bias, p.act);
+                            if (yy + 2 < p.H) o[2 * rs] = act_apply(o2 + bias, p.act);
+                        }
+                    }
+                }
             }
         }
     }
@@ -282,7 +344,48 @@ __global__ void wino_pack_kernel(const float *__restrict__ pk, float *__restrict
     }
 }
 
-// Called by conv2d_fwd_impl for eligible launches; returns PWS_OK after launching, or a negative error.
+// MODE 1 weights: U[cls][16][cin_pad][cout] = G g G^T of the 2x2 sub-pixel kernels P[cls][dy*2+dx][cin_pad][cout] (pack.hip)
+__global__ void wino_pack_ct4_kernel(const float *__restrict__ pk, float *__restrict__ uw, size_t plane /* cin_pad*cout */) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cls = blockIdx.y;
+    if (i >= plane) return;
+    float g[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) g[r][s] = pk[(size_t)(cls * 4 + r * 2 + s) * plane + i];
+    float u[4][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) u[0][s] = g[0][s], u[1][s] = 0.5f * (g[0][s] + g[1][s]), u[2][s] = 0.5f * (g[0][s] - g[1][s]), u[3][s] = g[1][s];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float *o = uw + (size_t)(cls * 16 + r * 4) * plane + i;
+        o[0] = u[r][0], o[plane] = 0.5f * (u[r][0] + u[r][1]), o[2 * plane] = 0.5f * (u[r][0] - u[r][1]), o[3 * plane] = u[r][1];
+    }
+}
+
+template <int MODE>
+static int wino_launch(WinoParams &p, int cout, const ProfHint &ph, hipStream_t st) {
+    using G = WinoGeo<MODE>;
+    p.tiles_x = (p.W + G::TW - 1) / G::TW, p.tiles_y = (p.H + G::TH - 1) / G::TH;
+    p.ntiles = (unsigned)(p.tiles_x * p.tiles_y * p.N);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_kernel<MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(wino_kernel<%d>): %s", MODE, hipGetErrorString(e));
+            return PWS_EHIP;
+        }
+        attr_set = true;
+    }
+    ProfScope prof(MODE == 0 ? KID_CONV_WINO : KID_CONV_WINO_CT4, ph.flops, ph.bytes, st);
+    hipLaunchKernelGGL(wino_kernel<MODE>, dim3(p.ntiles, (cout + 63) / 64, MODE == 1 ? 4 : 1), dim3(256), G::LDS_BYTES, st, p);
+    return check_launch("wino_kernel");
+}
+
+// Called by conv2d_fwd_impl for eligible launches (K3S1 / CONVT_K3S1: F(2x2,3x3); CONVT_K4S2: F(3x3,2x2) per parity class);
+// returns PWS_OK after launching, or a negative error.
 int wino_k3s1_launch(const pws_conv_args *a, const ProfHint &ph, hipStream_t st) {
     WinoParams p{};
     p.nsrc = a->nsrc;
@@ -293,26 +396,25 @@ int wino_k3s1_launch(const pws_conv_args *a, const ProfHint &ph, hipStream_t st)
     }
     p.N = a->n, p.H = a->h, p.W = a->w, p.cin_pad = (cin + 15) / 16 * 16, p.cout = a->cout;
     p.uw = a->w_wino, p.bias = a->bias, p.out = a->out, p.out_ld = a->out_ld, p.act = a->act;
-    p.tiles_x = (a->w + WN_TW - 1) / WN_TW, p.tiles_y = (a->h + WN_TH - 1) / WN_TH;
-    p.ntiles = (unsigned)(p.tiles_x * p.tiles_y * a->n);
     static const int ablate = getenv("PWS_WINO_ABLATE") ? atoi(getenv("PWS_WINO_ABLATE")) : 0;
     p.ablate = ablate;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_k3s1_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(wino_k3s1_kernel): %s", hipGetErrorString(e));
-            return PWS_EHIP;
-        }
-        attr_set = true;
-    }
-    ProfScope prof(KID_CONV_WINO, ph.flops, ph.bytes, st);
-    hipLaunchKernelGGL(wino_k3s1_kernel, dim3(p.ntiles, (a->cout + 63) / 64), dim3(256), WN_LDS_BYTES, st, p);
-    return check_launch("wino_k3s1_kernel");
+    return a->kind == PWS_CONVT_K4S2 ? wino_launch<1>(p, a->cout, ph, st) : wino_launch<0>(p, a->cout, ph, st);
 }
 
 }  // namespace pws
+
+extern "C" size_t pws_packed_wino_ct4_floats(int cin, int cout) {
+    if (cin <= 0 || cout <= 0) return 0;
+    return (size_t)4 * 16 * ((cin + 15) / 16 * 16) * cout;
+}
+
+extern "C" int pws_pack_conv_weight_wino_ct4(const float *w_packed, float *w_wino, int cin, int cout, pws_stream_t stream) {
+    PWS_REQUIRE(w_packed && w_wino && cin > 0 && cout > 0, "pws_pack_conv_weight_wino_ct4: bad arguments");
+    const size_t plane = (size_t)((cin + 15) / 16 * 16) * cout;
+    hipLaunchKernelGGL(pws::wino_pack_ct4_kernel, dim3((unsigned)((plane + 255) / 256), 4), dim3(256), 0, pws::as_stream(stream),
+                       w_packed, w_wino, plane);
+    return pws::check_launch("wino_pack_ct4_kernel");
+}
 
 extern "C" size_t pws_packed_wino_floats(int cin, int cout) {
     if (cin <= 0 || cout <= 0) return 0;

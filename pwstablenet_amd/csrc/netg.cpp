@@ -72,6 +72,8 @@ static std::vector<Layer> build_layers(int input_nc, int g, size_t *total_floats
             l.ww_off = off;
             off = align_up(off + pws_packed_wino_floats(cin, cout), 64);
         }
+        // (CONVT_K4S2 has a Winograd F(3x3,2x2) kernel too, conv_wino.hip MODE 1; measured slower than the direct kernel on
+        //  this generator's 32..128-pixel maps, so its weights are not packed here)
         if (bf16_planes(kind) && ((cin + 15) / 16 * 16) % 32 == 0) {
             l.wb_off = off;
             off = align_up(off + pws_packed_bf16_floats(bf16_planes(kind), (cin + 15) / 16 * 16, cout), 64);

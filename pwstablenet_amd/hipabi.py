@@ -69,6 +69,8 @@ SIGNATURES = {
     "pws_pack_conv_weight": (_I, [_P, _P, _I, _I, _I, _P]),
     "pws_packed_wino_floats": (_S, [_I, _I]),
     "pws_pack_conv_weight_wino": (_I, [_P, _P, _I, _I, _P]),
+    "pws_packed_wino_ct4_floats": (_S, [_I, _I]),
+    "pws_pack_conv_weight_wino_ct4": (_I, [_P, _P, _I, _I, _P]),
     "pws_conv2d_fwd": (_I, [ctypes.POINTER(PwsConvArgs), _P]),
     "pws_act_bwd_bias": (_I, [_P, _P, _S, _I, _I, _P, _P]),
     "pws_packed_dgrad_floats": (_S, [_I, _I, _I]),

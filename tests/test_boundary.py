@@ -124,3 +124,25 @@ def test_torch_ref_matches_reference_golden(netg_golden):
         g_inf = torch_ref.netg_forward(params, x, False)
     assert torch.equal(g_inf, grids[2])
     np.testing.assert_allclose(g_inf.numpy(), netg_golden["W2_g16_grid2_full"], rtol=0, atol=1e-6)
+
+
+def test_no_kernel_spills_to_scratch():
+    """hipcc's per-kernel resource report (written by pwstablenet_amd.build): accumulators or prefetch registers that end
+    up in scratch make a kernel several times slower without failing any numerical test (seen once: a by-reference
+    accumulator array put 732 B per lane in scratch).  Known small spills are listed with their budget."""
+    from pwstablenet_amd import build
+    build.build(verbose=False)
+    res = build.kernel_resources()
+    assert {"conv_mfma.hip", "conv_bf16.hip", "wgrad_bf16.hip", "conv_wino.hip", "grid_sample.hip"} <= set(res)
+    allowed = {  # substring of the mangled name -> bytes per lane
+        "conv_mfma_kernelINS_7ConvCfgILi5ELi1ELi2ELi0ELi16ELi16ELi1ELi8ELi4ELi1ELi2ELi2ELb1": 64,   # first layer, NCHW staging
+        "wgrad_mfma_kernelINS_5WgCfgILi3ELi2ELi1ELi0ELi2ELi2ELi16ELi9": 64,
+        "wino_kernelILi1E": 64,                                                                      # F(3x3,2x2), opt-in only
+    }
+    bad = []
+    for src, kernels in res.items():
+        for name, r in kernels.items():
+            budget = max([b for k, b in allowed.items() if k in name] + [0])
+            if r.get("scratch", 0) > budget:
+                bad.append((src, name, r))
+    assert not bad, bad

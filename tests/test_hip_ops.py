@@ -62,7 +62,11 @@ def run_conv(A, kind, srcs_nhwc, w_torch, bias, act, cout, nchw_src=None, ws_mb=
     b = dev(bias) if bias is not None else None
     args.cout, args.w_packed, args.bias, args.act = cout, wp.data_ptr(), (b.data_ptr() if b is not None else None), act
     args.out, args.out_ld = out.data_ptr(), cout
-    if wino:
+    if wino and kind == A.CONVT_K4S2:
+        ww = torch.empty(L.pws_packed_wino_ct4_floats(cin, cout), device="cuda", dtype=torch.float32)
+        A.check(L.pws_pack_conv_weight_wino_ct4(A.ptr(wp), A.ptr(ww), cin, cout, st), "pack_wino_ct4")
+        args.w_wino = ww.data_ptr()
+    elif wino:
         ww = torch.empty(L.pws_packed_wino_floats(cin, cout), device="cuda", dtype=torch.float32)
         A.check(L.pws_pack_conv_weight_wino(A.ptr(wp), A.ptr(ww), cin, cout, st), "pack_wino")
         args.w_wino = ww.data_ptr()
@@ -137,9 +141,13 @@ def test_conv_kinds_vs_oracle(hip, oracle, kname, shape, src_c, cout, act):
     ("CONVT_K3S1", (5, 112, 130), [128], 96),     # ragged extent, cout not a multiple of 64
     ("CONV_K3S1", (16, 64, 64), [64, 32, 32], 128),
     ("CONV_K3S1", (8, 256, 256), [16], 64),       # few input channels: taken only because the map is huge
+    ("CONVT_K4S2", (4, 64, 64), [128, 64], 64),   # transposed conv k4 s2: F(3x3,2x2) per output parity class
+    ("CONVT_K4S2", (3, 50, 77), [64], 96),        # extents not multiples of 3 / of the 12x24 workgroup, ragged cout
+    ("CONVT_K4S2", (8, 128, 128), [32, 32], 64),
 ])
 def test_conv_winograd_vs_oracle(hip, oracle, kname, shape, src_c, cout):
-    """3x3 stride-1 layers through the Winograd F(2x2,3x3) kernel (taken when its workgroups fill the chip)."""
+    """3x3 stride-1 layers through the Winograd F(2x2,3x3) kernel and k4 s2 transposed convs through F(3x3,2x2)
+    (taken when their workgroups fill the chip)."""
     A = hip
     kind = getattr(A, kname)
     n, h, w = shape
@@ -147,9 +155,10 @@ def test_conv_winograd_vs_oracle(hip, oracle, kname, shape, src_c, cout):
     cin = sum(src_c)
     is_t = kname.startswith("CONVT")
     x = rs.standard_normal((n, cin, h, w)).astype(np.float32)
-    wt = (rs.standard_normal((cin, cout, 3, 3) if is_t else (cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    k = 4 if kname == "CONVT_K4S2" else 3
+    wt = (rs.standard_normal((cin, cout, k, k) if is_t else (cout, cin, k, k)) / np.sqrt(cin * 9)).astype(np.float32)
     b = rs.standard_normal((cout,)).astype(np.float32)
-    ref = (oracle.conv_transpose2d if is_t else oracle.conv2d)(x, wt, b, 1, 1, oracle.ACT_LRELU)
+    ref = (oracle.conv_transpose2d if is_t else oracle.conv2d)(x, wt, b, 2 if k == 4 else 1, 1, oracle.ACT_LRELU)
     xs = nhwc(x)
     srcs, c0 = [], 0
     for c in src_c:

@@ -78,7 +78,7 @@ with open(out, "w") as f:
     json.dump(summ, f, indent=1, sort_keys=True)
 print("pmc ->", out)
 for k, cs in sorted(summ.items()):
-    if "conv_mfma" in k or "grid_sample" in k or "field_head" in k or "wino" in k or "wgrad" in k:
+    if "conv_" in k or "grid_sample" in k or "field_head" in k or "wino" in k or "wgrad" in k:
         print(k)
         for cn, v in sorted(cs.items()):
             print("    %-28s %18.1f  (n=%d)" % (cn, v["mean_per_dispatch"], v["dispatches"]))

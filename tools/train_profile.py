@@ -25,6 +25,7 @@ def main():
     net.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in synth.make_weights("W1", 123, ngf=64)})
     net = net.cuda()
     net.module.set_math(a.math)
+    A.lib().pws_set_option(A.OPT_TWO_QUEUES, 0)  # one queue: per-kernel durations are not inflated by overlap
     opt = Adam(net.parameters(), lr=1e-4, betas=(0.5, 0.999))
     x = torch.from_numpy(synth.noise_window(a.batch, 31, 256, 123)).cuda()
     fr = torch.from_numpy(synth.make_frames(a.batch, 3, 256, 256, 321)).cuda()
