@@ -178,11 +178,37 @@ class UnetGenerator(nn.Module):
             out += [conv.weight, conv.bias]
         return out
 
+    def _bn_layers(self):
+        return [getattr(getattr(self, ls.name.split(".")[0]), ls.name.split(".")[1])[1] for ls in self._specs]
+
+    def _effective_params(self):
+        """(weight, bias) per layer as the kernels see them.  ``use_BN`` in eval() mode: BatchNorm2d with running statistics
+        is a per-output-channel affine map directly behind the conv (reference lib/networks_cascading.py:253-341), folded
+        here:  w' = w * g / sqrt(var + eps),  b' = (b - mean) * g / sqrt(var + eps) + beta."""
+        params = self._ordered_params()
+        if not self.use_BN:
+            return params
+        out = []
+        with torch.no_grad():
+            for i, (ls, bn) in enumerate(zip(self._specs, self._bn_layers())):
+                w, b = params[2 * i], params[2 * i + 1]
+                s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                shape = (-1, 1, 1, 1) if ls.kind == "conv" else (1, -1, 1, 1)   # OIHW / IOHW: the OUTPUT channel axis
+                out += [(w * s.view(shape)).contiguous(), ((b - bn.running_mean) * s + bn.bias).contiguous()]
+        return out
+
+    def _weights_key(self):
+        ts = list(self._ordered_params())
+        if self.use_BN:
+            for bn in self._bn_layers():
+                ts += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        return tuple((p.data_ptr(), p._version) for p in ts)
+
     def packed_weights(self):
         """Device buffer with every layer in the kernels' layout; re-packed when a parameter changed."""
-        params = self._ordered_params()
-        key = tuple((p.data_ptr(), p._version) for p in params)
-        if self._packed is None or key != self._packed_key:
+        key = self._weights_key()
+        params = self._effective_params() if (self._packed is None or key != self._packed_key) else None
+        if params is not None:
             A.require_cuda(*params)
             dev = params[0].device
             nfl = A.lib().pws_netg_packed_floats(self.input_nc, self.ngf)
@@ -217,13 +243,16 @@ class UnetGenerator(nn.Module):
         return self._ws[k]
 
     def forward(self, input1, is_training=True):
-        if self.use_BN:
-            raise NotImplementedError("UnetGenerator: the use_BN variant has no HIP path yet (reference default is False)")
         A.require_cuda(input1)
         if input1.dim() != 4 or input1.shape[1] != self.input_nc or input1.shape[2] != 256 or input1.shape[3] != 256:
             raise RuntimeError("UnetGenerator: expected input (N, %d, 256, 256) -- 7 stride-2 levels and the 2x2 flatten "
                                "conv fix the size -- got %s" % (self.input_nc, tuple(input1.shape)))
         needs_grad = torch.is_grad_enabled() and (input1.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if self.use_BN and (self.training or needs_grad):
+            raise NotImplementedError(
+                "UnetGenerator(use_BN=True): only eval() inference is on the HIP path (running statistics folded into the "
+                "convolutions); training-mode BatchNorm (batch statistics + their backward) is not implemented -- call "
+                ".eval() under torch.no_grad(), or train with the reference default use_BN=False")
         if needs_grad:
             return _netg_autograd(self, input1, is_training)
         if self._graph_mode and not is_training:

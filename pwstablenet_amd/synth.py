@@ -83,3 +83,20 @@ def noise_window(n, input_nc=31, size=256, seed=123):
     rs = np.random.RandomState(seed)
     u8 = rs.randint(0, 256, (n, input_nc, size, size)).astype(np.uint8)
     return (u8.astype(np.float32) / np.float32(255) * np.float32(2) - np.float32(1)).astype(np.float32)
+
+
+def make_bn_state(seed=321, input_nc=31, output_nc=2, ngf=64):
+    """BatchNorm2d tensors of the ``use_BN=True`` variant (reference lib/networks_cascading.py:253-341: one BatchNorm2d after
+    every conv, ``<block>.<seq>.1.*``), in state-dict order per layer: weight (gamma), bias (beta), running_mean,
+    running_var, num_batches_tracked.  Non-trivial on purpose so that a wrong fold shows up."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for ls in layer_specs(input_nc, output_nc, ngf):
+        base = ls.name[:-1] + "1"   # "<block>.<seq>.0" -> "<block>.<seq>.1"
+        c = ls.cout
+        out.append((base + ".weight", rs.uniform(0.6, 1.4, c).astype(np.float32)))
+        out.append((base + ".bias", (rs.standard_normal(c) * 0.1).astype(np.float32)))
+        out.append((base + ".running_mean", (rs.standard_normal(c) * 0.1).astype(np.float32)))
+        out.append((base + ".running_var", rs.uniform(0.5, 1.5, c).astype(np.float32)))
+        out.append((base + ".num_batches_tracked", np.array(7, dtype=np.int64)))
+    return out

@@ -146,3 +146,16 @@ def test_no_kernel_spills_to_scratch():
             if r.get("scratch", 0) > budget:
                 bad.append((src, name, r))
     assert not bad, bad
+
+
+def test_use_bn_variant_state_dict_matches_reference_and_training_raises():
+    """use_BN=True (lib/cfg.py:37): same module tree / state-dict keys as the reference built with --use_BN 1
+    (tests/golden/netg_bn.npz holds the reference's key list); training-mode BatchNorm is refused loudly."""
+    import numpy as np
+    import torch
+    from pwstablenet_amd.lib.networks_cascading import SingleDeviceParallel, UnetGenerator
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "netg_bn.npz"))
+    net = SingleDeviceParallel(UnetGenerator(31, 2, 16, use_BN=True))
+    assert list(net.state_dict().keys()) == [str(k) for k in g["keys"]]
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        net.train()(torch.zeros(1, 31, 256, 256))

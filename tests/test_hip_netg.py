@@ -97,3 +97,28 @@ def test_inference_with_grad_mode_on_and_errors(hip):
         net(x.cpu(), False)
     with pytest.raises(RuntimeError):
         net(x[:, :, :128, :128], False)
+
+
+def test_use_bn_eval_inference_vs_reference_golden(hip):
+    """use_BN=True in eval(): BatchNorm running statistics folded into the convs; stage-3 field against the reference built
+    with --use_BN 1 (tests/golden/make_golden_bn.py, N=1, ngf=16).  Tolerance 2e-5: fp32 re-association of the fold."""
+    import os
+    from pwstablenet_amd.lib.networks_cascading import SingleDeviceParallel, UnetGenerator
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "netg_bn.npz"))
+    net = SingleDeviceParallel(UnetGenerator(31, 2, 16, use_BN=True))
+    sd = {"module." + k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_weights("W1", seed=123, ngf=16)}
+    sd.update({"module." + k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_bn_state(seed=321, ngf=16)})
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    x = torch.from_numpy(synth.make_window(1, 31, 256, seed=123)).cuda()
+    with torch.no_grad():
+        field = net(x, False).cpu().numpy()
+    err = np.abs(field - g["field"]).max()
+    assert err < 2e-5, err
+    # changing a running statistic re-folds (the packed-weight cache follows the BatchNorm buffers)
+    with torch.no_grad():
+        net.module.up_bottom1.mpconv[1].running_var.mul_(4.0)
+        field2 = net(x, False).cpu().numpy()
+    assert np.abs(field2 - field).max() > 1e-4
+    with pytest.raises(NotImplementedError):
+        net.train()(x)

@@ -22,6 +22,11 @@ os.makedirs(dest, exist_ok=True)
 
 def short(name):
     name = re.sub(r"^void ", "", name)
+    m = re.match(r"pws::conv_bf16_kernel<pws::BfCfg<([^>]*)>\s*>", name)
+    if m:
+        a = [x.strip() for x in m.group(1).split(",")]
+        sub = {"0": "", "1": ",convT4", "2": ",dgrad-subpix"}.get(a[3], "," + a[3])
+        return "conv_bf16_kernel<k%ss%s%s,tile %sx%sx%s,CK%s>" % (a[0], a[1], sub, a[6], a[4], a[5], a[7])
     m = re.match(r"pws::conv_mfma_kernel<pws::ConvCfg<([^>]*)>\s*>", name)
     if m:
         a = [x.strip() for x in m.group(1).split(",")]
@@ -36,13 +41,15 @@ def db(sub):
     return sqlite3.connect(f[0]) if f else None
 
 
-c = db("trace")
-if c:
+def kernel_stats(sub, suffix):
+    c = db(sub)
+    if not c:
+        return
     agg = defaultdict(list)
     for name, dur in c.execute("select name, duration from kernels"):
         agg[short(name)].append(dur)
     tot = sum(sum(v) for v in agg.values())
-    out = os.path.join(dest, "%s_kernel_stats.csv" % tag)
+    out = os.path.join(dest, "%s_kernel_stats%s.csv" % (tag, suffix))
     with open(out, "w") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns"])
@@ -51,6 +58,10 @@ if c:
     print("kernel stats ->", out)
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:16]:
         print("%6d calls  avg %10.1f us  %6.2f%%  %s" % (len(v), sum(v) / len(v) / 1e3, 100.0 * sum(v) / tot, k))
+
+
+kernel_stats("trace", "")
+kernel_stats("trace_bf16", "_bf16")
 
 summ = defaultdict(dict)
 for sub in sorted(glob.glob(os.path.join(d, "pmc_*"))):
