@@ -363,6 +363,34 @@ def main():
                                                 "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_us": round(1e3 * ms, 2),
                                                 "bytes_per_launch": r[0][3]}}
         del f720
+        if not a.no_extra:
+            # the same leg on uint8 HWC frames (what cv2 hands over / the writer takes, main_new.py:679-721): 6 B/px of frame traffic
+            u720 = torch.randint(0, 256, (B, 720, 1280, 3), device=dev, dtype=torch.uint8)
+            with torch.no_grad():
+                def step720u8():
+                    return PF.upsample_grid_sample_u8(u720, net(x, False), swap_rb=True)
+                for _ in range(2):
+                    step720u8()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(a.steps):
+                    step720u8()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                A.lib().pws_prof_enable(1)
+                for _ in range(5):
+                    step720u8()
+                A.lib().pws_prof_enable(0)
+            r = [x_ for x_ in A.prof_collect() if x_[0] == "upsample_grid_sample_u8_kernel"]
+            ms = sorted(x_[4] for x_ in r)[len(r) // 2]
+            gbs = r[0][3] / (ms * 1e-3) / 1e9
+            line["value_720p_u8"] = {"value": round(B * a.steps / dt, 2), "unit": "frames/s", "n_gpus": 1,
+                                     "workload": "as value_720p with uint8 HWC BGR frames in, uint8 HWC RGB out",
+                                     "roofline_warp": {"kernel": "upsample_grid_sample_u8_kernel", "bound": "hbm",
+                                                       "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                                       "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_us": round(1e3 * ms, 2),
+                                                       "bytes_per_launch": r[0][3]}}
+            del u720
         if not a.no_extra and a.math == "fp32":
             line["bf16"] = bf16_legs(net, x, frames, out, a, PF, A)
         if world == 1 and not a.no_cpu_baseline:

@@ -245,6 +245,13 @@ int pws_upsample_bilinear_ac(const float *in, float *out, int n, int c, int h, i
 int pws_upsample_grid_sample_fwd(const float *input, const float *field, float *out, int n, int c, int h,
                                  int w, int fh, int fw, int align_corners, pws_stream_t stream);
 
+/* The same for uint8 frames in the layout OpenCV hands over (main_new.py:679-684,717-721): frame_hwc / out_hwc are
+ * [n,h,w,3] uint8; the blend runs in fp32 exactly as above and is truncated like numpy's astype(uint8).  swap_rb: output
+ * channel c samples input channel 2-c (the reference's COLOR_BGR2RGB before the warp).  w % 4 == 0, out 4-byte aligned.
+ * 6 bytes per pixel of frame traffic instead of 24. */
+int pws_upsample_grid_sample_u8(const unsigned char *frame_hwc, const float *field, unsigned char *out_hwc, int n, int h, int w,
+                                int fh, int fw, int swap_rb, int align_corners, pws_stream_t stream);
+
 /* Adam (no weight decay / amsgrad) on a flat fp32 buffer, in place; step counts from 1. */
 int pws_adam_step(float *p, const float *g, float *m, float *v, size_t count, float lr, float beta1,
                   float beta2, float eps, int step, pws_stream_t stream);

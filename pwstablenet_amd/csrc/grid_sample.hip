@@ -301,6 +301,95 @@ __global__ void __launch_bounds__(256) upsample_grid_sample_fwd_kernel(const flo
     }
 }
 
+// uint8 HWC variant of the fused 720p path: the frame is what cv2 hands over (main_new.py:679-684: BGR uint8 [h][w][3], converted
+// to RGB float CHW there) and the result is what the reference writes (main_new.py:717-721: float -> astype(uint8) HWC), so a
+// frame moves 3 + 3 bytes per pixel instead of 12 + 12.  Field interpolation and tap weights are the float kernel's, the blend
+// is evaluated in the same order on the same fp32 values, then truncated like numpy's astype(uint8) (values are in [0, 255]).
+// swap_rb: output channel c = input channel 2 - c (the reference's COLOR_BGR2RGB before the warp).
+struct __attribute__((packed, aligned(1))) U8x4 {
+    unsigned v;
+};
+struct __attribute__((packed, aligned(1))) U8x2 {
+    unsigned short v;
+};
+template <bool NARROW>
+__global__ void __launch_bounds__(256) upsample_grid_sample_u8_kernel(const unsigned char *__restrict__ input,
+                                                                      const float *__restrict__ field,
+                                                                      unsigned char *__restrict__ out, int H, int W, int fh, int fw,
+                                                                      float ry, float rx, size_t total_groups, unsigned nblocks,
+                                                                      int ac, int swap_rb) {
+    constexpr int PPT = 4;
+    const unsigned blk = xcd_remap(blockIdx.x, nblocks);
+    const size_t gidx = (size_t)blk * 256 + threadIdx.x;
+    if (gidx >= total_groups) return;
+    const int HW = H * W;
+    const size_t p0 = gidx * PPT;
+    const int n = (int)(p0 / HW);
+    const int hw = (int)(p0 % HW);
+    const int oy = hw / W, ox0 = hw % W;  // W % 4 == 0: the group stays inside one row
+    const float sy = ry * oy;
+    const int y0 = (int)sy, y1 = y0 + (y0 < fh - 1 ? 1 : 0);
+    const float ly = sy - y0, hy = 1.f - ly;
+    const float2 *f0 = reinterpret_cast<const float2 *>(field) + ((size_t)n * fh + y0) * fw;
+    const float2 *f1 = reinterpret_cast<const float2 *>(field) + ((size_t)n * fh + y1) * fw;
+    Taps2 t[PPT];
+    if constexpr (NARROW) {
+        const int cb = (int)(rx * ox0);
+        float2 r0[3], r1[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int col = min(cb + k, fw - 1);
+            r0[k] = f0[col], r1[k] = f1[col];
+        }
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const float sx = rx * (ox0 + i);
+            const int x0 = (int)sx;
+            const float lx = sx - x0, hx = 1.f - lx;
+            const bool second = x0 > cb;
+            const float2 a = second ? r0[1] : r0[0], b = second ? r0[2] : r0[1];
+            const float2 c = second ? r1[1] : r1[0], d = second ? r1[2] : r1[1];
+            const float gx = hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * d.x);
+            const float gy = hy * (hx * a.y + lx * b.y) + ly * (hx * c.y + lx * d.y);
+            t[i] = make_taps2(gx, gy, H, W, ac != 0);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const float sx = rx * (ox0 + i);
+            const int x0 = (int)sx, x1 = x0 + (x0 < fw - 1 ? 1 : 0);
+            const float lx = sx - x0, hx = 1.f - lx;
+            const float2 a = f0[x0], b = f0[x1], c = f1[x0], d = f1[x1];
+            const float gx = hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * d.x);
+            const float gy = hy * (hx * a.y + lx * b.y) + ly * (hx * c.y + lx * d.y);
+            t[i] = make_taps2(gx, gy, H, W, ac != 0);
+        }
+    }
+    const unsigned char *ip = input + (size_t)n * HW * 3;
+    unsigned char res[PPT * 3];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        // the two horizontally adjacent source pixels of a row are 6 consecutive bytes: one 4-byte + one 2-byte unaligned load
+        const unsigned char *q0 = ip + (size_t)t[i].o0 * 3, *q1 = ip + (size_t)t[i].o1 * 3;
+        const unsigned long long u = (unsigned long long)reinterpret_cast<const U8x4 *>(q0)->v |
+                                     ((unsigned long long)reinterpret_cast<const U8x2 *>(q0 + 4)->v << 32);
+        const unsigned long long v = (unsigned long long)reinterpret_cast<const U8x4 *>(q1)->v |
+                                     ((unsigned long long)reinterpret_cast<const U8x2 *>(q1 + 4)->v << 32);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int ci = swap_rb ? 2 - c : c;
+            const float ux = (float)((u >> (8 * ci)) & 0xff), uy = (float)((u >> (8 * (3 + ci))) & 0xff);
+            const float vx = (float)((v >> (8 * ci)) & 0xff), vy = (float)((v >> (8 * (3 + ci))) & 0xff);
+            const float r = ux * t[i].a0 + uy * t[i].b0 + vx * t[i].a1 + vy * t[i].b1;
+            res[i * 3 + c] = (unsigned char)min(max((int)r, 0), 255);
+        }
+    }
+    unsigned *op = reinterpret_cast<unsigned *>(out + ((size_t)n * HW + hw) * 3);  // 12 bytes, 4-byte aligned (hw % 4 == 0)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        op[k] = (unsigned)res[4 * k] | ((unsigned)res[4 * k + 1] << 8) | ((unsigned)res[4 * k + 2] << 16) | ((unsigned)res[4 * k + 3] << 24);
+}
+
 static inline bool aligned16(const void *p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 
 }  // namespace pws
@@ -414,4 +503,26 @@ extern "C" int pws_upsample_grid_sample_fwd(const float *input, const float *fie
                            out, c, h, w, fh, fw, ry, rx, total, nb, align_corners);
     }
     return check_launch("upsample_grid_sample_fwd_kernel");
+}
+
+extern "C" int pws_upsample_grid_sample_u8(const unsigned char *frame_hwc, const float *field, unsigned char *out_hwc, int n, int h,
+                                           int w, int fh, int fw, int swap_rb, int align_corners, pws_stream_t stream) {
+    PWS_REQUIRE(n >= 0 && h > 0 && w > 0 && fh > 0 && fw > 0, "pws_upsample_grid_sample_u8: bad shape");
+    if (n == 0) return PWS_OK;
+    PWS_REQUIRE(frame_hwc && field && out_hwc, "pws_upsample_grid_sample_u8: NULL pointer");
+    PWS_REQUIRE((size_t)h * w < (1u << 29) && w >= 2 && w % 4 == 0, "pws_upsample_grid_sample_u8: w must be a multiple of 4 (got %d)", w);
+    PWS_REQUIRE((reinterpret_cast<size_t>(out_hwc) & 3) == 0, "pws_upsample_grid_sample_u8: out must be 4-byte aligned");
+    const float ry = h > 1 ? (float)(fh - 1) / (float)(h - 1) : 0.f;
+    const float rx = w > 1 ? (float)(fw - 1) / (float)(w - 1) : 0.f;
+    const size_t total = (size_t)n * h * w, groups = total / 4;
+    const unsigned nb = (unsigned)((groups + 255) / 256);
+    ProfScope prof(KID_UPSAMPLE_GRID_SAMPLE_U8, (double)total * (40.0 + 8.0 * 3), (double)total * 6.0 + 8.0 * (double)n * fh * fw,
+                   as_stream(stream));
+    if (3.f * rx < 0.999f)
+        hipLaunchKernelGGL(upsample_grid_sample_u8_kernel<true>, dim3(nb), dim3(256), 0, as_stream(stream), frame_hwc, field, out_hwc, h,
+                           w, fh, fw, ry, rx, groups, nb, align_corners, swap_rb);
+    else
+        hipLaunchKernelGGL(upsample_grid_sample_u8_kernel<false>, dim3(nb), dim3(256), 0, as_stream(stream), frame_hwc, field, out_hwc, h,
+                           w, fh, fw, ry, rx, groups, nb, align_corners, swap_rb);
+    return check_launch("upsample_grid_sample_u8_kernel");
 }

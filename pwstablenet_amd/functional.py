@@ -104,6 +104,24 @@ def upsample_grid_sample(input, field, align_corners=None):
     return out
 
 
+def upsample_grid_sample_u8(frames_hwc, field, swap_rb=False, align_corners=None, out=None):
+    """The 720p step of the reference's ``process()`` on the frames as OpenCV delivers them (main_new.py:679-721):
+    ``frames_hwc`` (N,H,W,3) uint8 -> [optional BGR<->RGB swap] -> float CHW -> grid_sample with the field resized to (H,W)
+    (UpsamplingBilinear2d) -> ``astype(uint8)`` HWC, in one kernel and 6 bytes of frame traffic per pixel.  W % 4 == 0."""
+    A.require_cuda(field)
+    A.require_cuda(frames_hwc, dtype=torch.uint8)
+    if frames_hwc.dim() != 4 or frames_hwc.shape[3] != 3:
+        raise ValueError("upsample_grid_sample_u8: frames must be uint8 (N,H,W,3), got %s %s" % (frames_hwc.dtype, tuple(frames_hwc.shape)))
+    frames_hwc, field = frames_hwc.contiguous(), field.contiguous()
+    n, h, w, _ = frames_hwc.shape
+    if out is None:
+        out = torch.empty_like(frames_hwc)
+    A.check(A.lib().pws_upsample_grid_sample_u8(A.ptr(frames_hwc), A.ptr(field), A.ptr(out), n, h, w, field.shape[1], field.shape[2],
+                                                int(bool(swap_rb)), _ac(align_corners), A.current_stream()),
+            "pws_upsample_grid_sample_u8")
+    return out
+
+
 def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step):
     """In-place fused Adam on flat fp32 CUDA buffers."""
     A.require_cuda(p, g, m, v)

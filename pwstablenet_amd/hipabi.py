@@ -94,6 +94,7 @@ SIGNATURES = {
     "pws_grid_sample_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "pws_upsample_bilinear_ac": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "pws_upsample_grid_sample_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "pws_upsample_grid_sample_u8": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "pws_adam_step": (_I, [_P, _P, _P, _P, _S, _F, _F, _F, _F, _I, _P]),
     "pws_netg_packed_floats": (_S, [_I, _I]),
     "pws_netg_pack_weights": (_I, [ctypes.POINTER(_P), _P, _I, _I, _P]),
@@ -139,9 +140,10 @@ def current_stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def require_cuda(*tensors):
-    """The hot path runs on the GPU only; refuse anything else loudly."""
+def require_cuda(*tensors, dtype=None):
+    """The hot path runs on the GPU only; refuse anything else loudly.  dtype: expected dtype (default torch.float32)."""
     import torch
+    want = dtype or torch.float32
     for t in tensors:
         if t is None:
             continue
@@ -149,8 +151,8 @@ def require_cuda(*tensors):
             raise RuntimeError("pwstablenet_amd: the HIP hot path needs CUDA/HIP tensors (got %s); there is no CPU "
                                "fallback -- move the model and inputs to the GPU" %
                                (t.device if isinstance(t, torch.Tensor) else type(t)))
-        if t.dtype != torch.float32:
-            raise RuntimeError("pwstablenet_amd: fp32 tensors expected, got %s" % t.dtype)
+        if t.dtype != want:
+            raise RuntimeError("pwstablenet_amd: %s tensors expected, got %s" % (want, t.dtype))
 
 
 def ptr(t):

@@ -57,3 +57,68 @@ def test_stream_equals_per_frame_loop(hip):
     # ragged tail / tiny video
     one = vs.run(gray[:1], frames[:1])
     assert one.shape == frames[:1].shape
+
+
+@pytest.mark.parametrize("shape", [(2, 72, 128), (1, 720, 1280), (3, 37, 52)])
+@pytest.mark.parametrize("swap", [False, True])
+def test_u8_hwc_fused_warp(hip, shape, swap):
+    """uint8 HWC frames (what cv2 hands over, main_new.py:679-721): [BGR->RGB] -> float CHW -> grid_sample(resized field) ->
+    astype(uint8) HWC.  Equal to the float HIP path followed by truncation (up to FMA contraction at exact integers); against PyTorch-CPU (the ops the
+    reference calls) at most 1 LSB, and only where the float result sits within 0.02 of an integer (fp32 coordinate
+    conditioning at 720p)."""
+    import torch.nn.functional as F
+    from pwstablenet_amd import functional as PF
+    n, H, W = shape
+    rs = np.random.RandomState(n * 1000 + H)
+    u8 = torch.from_numpy(synth.smooth_frames_u8(n, 3, H, W, seed=H).transpose(0, 2, 3, 1).copy())          # (n,H,W,3) uint8
+    u8[..., 1] = (u8[..., 1].int() * 3 // 4).to(torch.uint8)   # make the channels differ
+    u8[..., 2] = 255 - u8[..., 2]
+    theta = torch.tensor([[1.02, 0.03, 0.01, -0.02, 0.97, 0.02]]).repeat(n, 1).view(n, 2, 3)
+    field = F.affine_grid(theta, (n, 1, 256, 256), align_corners=False) + 0.01 * torch.from_numpy(
+        rs.standard_normal((n, 256, 256, 2)).astype(np.float32))
+    d_u8, d_field = u8.cuda(), field.cuda()
+    got = PF.upsample_grid_sample_u8(d_u8, d_field, swap_rb=swap).cpu()
+    assert got.dtype == torch.uint8 and got.shape == u8.shape
+    # (a) the float HIP path + truncation: same taps and weights; the 4-term blend may be contracted into FMAs differently
+    # by the compiler in the two kernels, so a value within 1e-3 of an integer may truncate to the neighbour
+    fl = d_u8.float().permute(0, 3, 1, 2)
+    if swap:
+        fl = fl.flip(1)
+    via_f = PF.upsample_grid_sample(fl.contiguous(), d_field).permute(0, 2, 3, 1).cpu()
+    da = (got.int() - via_f.to(torch.uint8).int()).abs()
+    assert da.max().item() <= 1
+    # (flat regions of integer-valued frames land exactly on integers, where weights summing to 1 - 1ulp truncate down:
+    #  inherent to astype(uint8) of a bilinear blend, the same happens between any two fp32 evaluations of the reference)
+    # -- and next to the zero-padded border (a 0 -> ~200 step per pixel) a 1-ulp difference of the source coordinate moves
+    # the value by ~1e-2, hence the 0.02 window, as in (b)
+    assert bool(((via_f - via_f.round()).abs() < 0.02)[da > 0].all()) and (da > 0).float().mean().item() < 2e-2
+    # (b) the torch ops the reference calls, on CPU
+    fc = u8.float().permute(0, 3, 1, 2)
+    if swap:
+        fc = fc.flip(1)
+    up = torch.nn.UpsamplingBilinear2d(size=(H, W))(field.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    ref_f = F.grid_sample(fc, up, align_corners=False).permute(0, 2, 3, 1)
+    ref = ref_f.to(torch.uint8)
+    diff = (got.int() - ref.int()).abs()
+    assert diff.max().item() <= 1
+    near_int = (ref_f - ref_f.round()).abs() < 0.02
+    assert bool(near_int[diff > 0].all())
+    # the synthetic frames are smooth AND integer-valued: wherever the 4 taps are equal the blend is exactly v*(1 +- 1ulp),
+    # so truncation is a coin flip between any two fp32 evaluations (3.6 % of the values at 720p, 0.3 % at 72x128)
+    assert (diff > 0).float().mean().item() < 6e-2
+
+
+def test_stream_uint8_frames(hip):
+    """VideoStabilizer with uint8 HWC frames (device and pinned host) equals the float path truncated."""
+    from pwstablenet_amd.stream import VideoStabilizer
+    net = make_net()
+    T, H, W = 11, 72, 128
+    gray = torch.from_numpy(synth.make_window(1, T, 256, seed=4)[0]).cuda()
+    u8 = torch.from_numpy(synth.smooth_frames_u8(T, 3, H, W, seed=9).transpose(0, 2, 3, 1).copy()).cuda()
+    vs = VideoStabilizer(net, batch=4, swap_rb=True)
+    got = vs.run(gray, u8)
+    want = vs.run(gray, u8.float().permute(0, 3, 1, 2).flip(1).contiguous()).permute(0, 2, 3, 1).to(torch.uint8)
+    assert got.dtype == torch.uint8 and (got.int() - want.int()).abs().max().item() <= 1
+    assert (got != want).float().mean().item() < 5e-3
+    got_h = vs.run(gray.cpu().pin_memory(), u8.cpu().pin_memory())
+    assert not got_h.is_cuda and torch.equal(got_h, got.cpu())
