@@ -256,6 +256,11 @@ int pws_upsample_grid_sample_u8(const unsigned char *frame_hwc, const float *fie
 int pws_adam_step(float *p, const float *g, float *m, float *v, size_t count, float lr, float beta1,
                   float beta2, float eps, int step, pws_stream_t stream);
 
+/* The same update for `ntensors` tensors in one launch per 48 tensors (p, g, m, v, counts: HOST arrays of DEVICE pointers /
+ * element counts): a generator has 92 tensors, most of them small. */
+int pws_adam_step_multi(float *const *p, const float *const *g, float *const *m, float *const *v, const size_t *counts,
+                        int ntensors, float lr, float beta1, float beta2, float eps, int step, pws_stream_t stream);
+
 /* ---------------------------------------------------------------- whole generator */
 /* Floats needed for all 46 packed layer weights + 46 biases of a generator (input_nc, ngf). */
 size_t pws_netg_packed_floats(int input_nc, int ngf);

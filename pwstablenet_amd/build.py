@@ -11,14 +11,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libpwstable_hip.so")
-SOURCES = ["abi.cpp", "netg.cpp", "pack.hip", "conv_mfma.hip", "conv_bf16.hip", "conv_wgrad.hip", "wgrad_bf16.hip", "conv_wino.hip", "head.hip", "head_bwd.hip", "grid_sample.hip",
+SOURCES = ["abi.cpp", "netg.cpp", "netg_pack.hip", "pack.hip", "conv_mfma.hip", "conv_bf16.hip", "conv_wgrad.hip", "wgrad_bf16.hip", "conv_wino.hip", "head.hip", "head_bwd.hip", "grid_sample.hip",
            "adam.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
 def _deps():
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(HERE, "..", "include", "pwstable.h"), os.path.abspath(__file__)]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(CSRC, "netg_pack.h"), os.path.join(HERE, "..", "include", "pwstable.h"), os.path.abspath(__file__)]
     return max(os.path.getmtime(h) for h in hdrs)
 
 

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "common.h"
+#include "netg_pack.h"
 
 namespace pws {
 
@@ -107,6 +108,29 @@ static std::vector<Layer> build_layers(int input_nc, int g, size_t *total_floats
     if (total_floats) *total_floats = off;
     if (total_dgrad) *total_dgrad = dg;
     return L;
+}
+
+static int kind_ksize(int kind) {
+    switch (kind) {
+    case PWS_CONV_K5S1: return 5;
+    case PWS_CONVT_K4S2: return 4;
+    case PWS_CONV_K2S1P0: return 2;
+    case PWS_CONV_K1: return 1;
+    default: return 3;
+    }
+}
+static unsigned off32(size_t off) { return off == (size_t)-1 ? kNoOff : (unsigned)off; }
+
+// argument blocks of the whole-generator pack / unpack kernels (netg_pack.hip)
+static void fill_pack_layers(const std::vector<Layer> &L, PackLayer *out) {
+    for (int i = 0; i < L_COUNT; ++i) {
+        const Layer &l = L[i];
+        PackLayer &p = out[i];
+        p.kind = l.kind, p.cin = l.cin, p.cin_pad = (l.cin + 15) / 16 * 16, p.cout = l.cout, p.k = kind_ksize(l.kind);
+        p.planes = l.kind == PWS_CONVT_K4S2 ? 16 : p.k * p.k;
+        p.dg_taps = l.dg_off == (size_t)-1 ? 0 : (l.kind == PWS_CONV_K3S1 || l.kind == PWS_CONVT_K3S1 ? 9 : 16);
+        p.w_off = off32(l.w_off), p.b_off = off32(l.b_off), p.ww_off = off32(l.ww_off), p.dg_off = off32(l.dg_off);
+    }
 }
 
 struct Seg {
@@ -502,28 +526,32 @@ extern "C" int pws_netg_pack_weights(const float *const *params, float *packed, 
                 ngf);
     size_t total = 0;
     const std::vector<Layer> L = build_layers(input_nc, ngf, &total);
-    hipError_t e = hipMemsetAsync(packed, 0, total * sizeof(float), as_stream(stream));
-    if (e != hipSuccess) {
-        set_error("pws_netg_pack_weights: hipMemsetAsync: %s", hipGetErrorString(e));
-        return PWS_EHIP;
-    }
+    PWS_REQUIRE(total < 0xffffffffu, "pws_netg_pack_weights: packed buffer too large for 32-bit offsets");
+    // three launches over all layers (netg_pack.hip): torch layouts -> packed fp32 (+ biases), Winograd, bf16.  Alignment gaps
+    // between the regions are never read, so there is no zero-fill pass.
+    PackAllArgs a{};
+    Bf16AllArgs b{};
+    a.nlayers = b.nlayers = L_COUNT;
+    fill_pack_layers(L, a.layer);
+    unsigned nb = 0, nbw = 0, nbb = 0;
     for (int i = 0; i < L_COUNT; ++i) {
         PWS_REQUIRE(params[2 * i] && params[2 * i + 1], "pws_netg_pack_weights: params[%d] is NULL", 2 * i);
-        int rc = pws_pack_conv_weight(params[2 * i], packed + L[i].w_off, L[i].kind, L[i].cin, L[i].cout, stream);
-        if (rc == PWS_OK && L[i].ww_off != (size_t)-1)
-            rc = pws_pack_conv_weight_wino(packed + L[i].w_off, packed + L[i].ww_off, L[i].cin, L[i].cout, stream);
-        if (rc == PWS_OK && L[i].wb_off != (size_t)-1)
-            rc = pws_pack_weight_bf16(packed + L[i].w_off, packed + L[i].wb_off, bf16_planes(L[i].kind), (L[i].cin + 15) / 16 * 16,
-                                      L[i].cout, stream);
-        if (rc != PWS_OK) return rc;
-        e = hipMemcpyAsync(packed + L[i].b_off, params[2 * i + 1], sizeof(float) * L[i].cout, hipMemcpyDeviceToDevice,
-                           as_stream(stream));
-        if (e != hipSuccess) {
-            set_error("pws_netg_pack_weights: hipMemcpyAsync(bias %d): %s", i, hipGetErrorString(e));
-            return PWS_EHIP;
-        }
+        a.params[2 * i] = params[2 * i], a.params[2 * i + 1] = params[2 * i + 1];
+        const PackLayer &p = a.layer[i];
+        a.first_block[i] = nb;
+        nb += (unsigned)(((size_t)p.planes * p.cin_pad * p.cout + p.cout + 255) / 256);
+        a.first_block_wino[i] = nbw;
+        if (p.ww_off != kNoOff) nbw += (unsigned)(((size_t)p.cin_pad * p.cout + 255) / 256);
+        Bf16Layer &q = b.layer[i];
+        q.planes = p.planes, q.krows = p.cin_pad, q.ncols = p.cout, q.kpad = (p.cin_pad + 31) / 32 * 32, q.npad = (p.cout + 63) / 64 * 64;
+        q.src_off = p.w_off, q.dst_off = off32(L[i].wb_off);
+        b.first_block[i] = nbb;
+        if (q.dst_off != kNoOff) nbb += (unsigned)(q.planes * (q.kpad / 32) * (q.npad / 64));
     }
-    return PWS_OK;
+    a.total_blocks = nb, a.total_blocks_wino = nbw, b.total_blocks = nbb;
+    int rc = launch_pack_all(a, packed, as_stream(stream));
+    if (rc == PWS_OK) rc = launch_bf16_all(b, packed, packed, as_stream(stream));
+    return rc;
 }
 
 extern "C" int pws_netg_pack_weights_dgrad(const float *const *params, float *packed_dgrad, int input_nc, int ngf,
@@ -532,16 +560,31 @@ extern "C" int pws_netg_pack_weights_dgrad(const float *const *params, float *pa
     PWS_REQUIRE(input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_pack_weights_dgrad: bad ngf %d", ngf);
     size_t total = 0, dg = 0;
     const std::vector<Layer> L = build_layers(input_nc, ngf, &total, &dg);
+    PWS_REQUIRE(dg < 0xffffffffu, "pws_netg_pack_weights_dgrad: buffer too large for 32-bit offsets");
+    PackAllArgs a{};
+    Bf16AllArgs b{};
+    a.nlayers = b.nlayers = L_COUNT;
+    fill_pack_layers(L, a.layer);
+    unsigned nb = 0, nbb = 0;
     for (int i = 0; i < L_COUNT; ++i) {
-        if (L[i].dg_off == (size_t)-1) continue;
+        a.params[2 * i] = params[2 * i], a.params[2 * i + 1] = nullptr;
+        const PackLayer &p = a.layer[i];
+        a.first_block_dgrad[i] = nb;
+        Bf16Layer &q = b.layer[i];
+        q = Bf16Layer{};
+        q.dst_off = kNoOff;
+        b.first_block[i] = nbb;
+        if (p.dg_off == kNoOff) continue;
         PWS_REQUIRE(params[2 * i], "pws_netg_pack_weights_dgrad: params[%d] is NULL", 2 * i);
-        int rc = pws_pack_conv_weight_dgrad(params[2 * i], packed_dgrad + L[i].dg_off, L[i].kind, L[i].cin, L[i].cout, stream);
-        if (rc == PWS_OK && L[i].dgb_off != (size_t)-1)
-            rc = pws_pack_weight_bf16(packed_dgrad + L[i].dg_off, packed_dgrad + L[i].dgb_off, bf16_dgrad_planes(L[i].kind),
-                                      L[i].cout, L[i].cin, stream);
-        if (rc != PWS_OK) return rc;
+        nb += (unsigned)(((size_t)p.dg_taps * p.cin * p.cout + 255) / 256);
+        q.planes = p.dg_taps, q.krows = p.cout, q.ncols = p.cin, q.kpad = (p.cout + 31) / 32 * 32, q.npad = (p.cin + 63) / 64 * 64;
+        q.src_off = p.dg_off, q.dst_off = off32(L[i].dgb_off);
+        if (q.dst_off != kNoOff) nbb += (unsigned)(q.planes * (q.kpad / 32) * (q.npad / 64));
     }
-    return PWS_OK;
+    a.total_blocks_dgrad = nb, b.total_blocks = nbb;
+    int rc = launch_dgrad_all(a, packed_dgrad, as_stream(stream));
+    if (rc == PWS_OK) rc = launch_bf16_all(b, packed_dgrad, packed_dgrad, as_stream(stream));
+    return rc;
 }
 
 extern "C" int pws_netg_unpack_grads(const float *dpacked, float *const *grads, int input_nc, int ngf, pws_stream_t stream) {
@@ -549,18 +592,19 @@ extern "C" int pws_netg_unpack_grads(const float *dpacked, float *const *grads, 
     PWS_REQUIRE(input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_unpack_grads: bad ngf %d", ngf);
     size_t total = 0;
     const std::vector<Layer> L = build_layers(input_nc, ngf, &total);
+    UnpackAllArgs a{};
+    a.nlayers = L_COUNT;
+    fill_pack_layers(L, a.layer);
+    unsigned nb = 0;
     for (int i = 0; i < L_COUNT; ++i) {
         PWS_REQUIRE(grads[2 * i] && grads[2 * i + 1], "pws_netg_unpack_grads: grads[%d] is NULL", 2 * i);
-        int rc = pws_unpack_conv_weight(dpacked + L[i].w_off, grads[2 * i], L[i].kind, L[i].cin, L[i].cout, stream);
-        if (rc != PWS_OK) return rc;
-        hipError_t e = hipMemcpyAsync(grads[2 * i + 1], dpacked + L[i].b_off, sizeof(float) * L[i].cout, hipMemcpyDeviceToDevice,
-                                      as_stream(stream));
-        if (e != hipSuccess) {
-            set_error("pws_netg_unpack_grads: hipMemcpyAsync(bias %d): %s", i, hipGetErrorString(e));
-            return PWS_EHIP;
-        }
+        a.grads[2 * i] = grads[2 * i], a.grads[2 * i + 1] = grads[2 * i + 1];
+        const PackLayer &p = a.layer[i];
+        a.first_block[i] = nb;
+        nb += (unsigned)(((size_t)p.k * p.k * p.cin * p.cout + p.cout + 255) / 256);
     }
-    return PWS_OK;
+    a.total_blocks = nb;
+    return launch_unpack_all(a, dpacked, as_stream(stream));  // one launch: 46 weights + 46 biases
 }
 
 extern "C" size_t pws_netg_workspace_bytes(int n, int input_nc, int ngf, int is_training) {

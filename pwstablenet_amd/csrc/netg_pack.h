@@ -1,0 +1,51 @@
+// Argument blocks of the whole-generator pack / unpack kernels (netg_pack.hip), filled by netg.cpp from its layer table.
+#pragma once
+#include "common.h"
+
+namespace pws {
+
+constexpr int kPackMaxLayers = 46;
+constexpr unsigned kNoOff = 0xffffffffu;
+
+struct PackLayer {
+    int kind, cin, cin_pad, cout, k, planes, dg_taps;
+    unsigned w_off, b_off, ww_off, dg_off;  // float offsets (kNoOff: none); 32 bits keep the argument block under 4 KB
+};
+
+struct PackAllArgs {
+    int nlayers;
+    unsigned total_blocks, total_blocks_wino, total_blocks_dgrad;
+    unsigned first_block[kPackMaxLayers], first_block_wino[kPackMaxLayers], first_block_dgrad[kPackMaxLayers];
+    PackLayer layer[kPackMaxLayers];
+    const float *params[2 * kPackMaxLayers];
+};
+
+struct UnpackAllArgs {
+    int nlayers;
+    unsigned total_blocks;
+    unsigned first_block[kPackMaxLayers];
+    PackLayer layer[kPackMaxLayers];
+    float *grads[2 * kPackMaxLayers];
+};
+
+struct Bf16Layer {
+    int planes, krows, ncols, kpad, npad;
+    unsigned src_off, dst_off;  // float offsets into the source / destination buffer (kNoOff: layer has no bf16 copy)
+};
+
+struct Bf16AllArgs {
+    int nlayers;
+    unsigned total_blocks;
+    unsigned first_block[kPackMaxLayers];
+    Bf16Layer layer[kPackMaxLayers];
+};
+
+static_assert(sizeof(PackAllArgs) <= 4096 && sizeof(UnpackAllArgs) <= 4096 && sizeof(Bf16AllArgs) <= 4096,
+              "kernel argument blocks are limited to 4 KB");
+
+int launch_pack_all(const PackAllArgs &a, float *packed, hipStream_t st);
+int launch_dgrad_all(const PackAllArgs &a, float *packed_dgrad, hipStream_t st);
+int launch_bf16_all(const Bf16AllArgs &a, const float *src_base, float *dst_base, hipStream_t st);
+int launch_unpack_all(const UnpackAllArgs &a, const float *dpacked, hipStream_t st);
+
+}  // namespace pws

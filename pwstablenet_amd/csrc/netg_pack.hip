@@ -1,0 +1,196 @@
+// Whole-generator weight (re)packing and gradient unpacking in a handful of launches.
+//
+// A training step changes all 92 tensors, so every step re-packs them into the kernels' layouts (forward fp32, Winograd,
+// bf16, data-gradient fp32 + bf16) and unpacks the 92 gradients: done layer by layer that is ~330 launches of 4-9 us each
+// (1.5-2 ms of a 19 ms step, tools/trace_train.sh).  Here each stage is ONE launch over all layers: the per-layer table
+// (46 entries) and the 92 tensor pointers travel in the kernel arguments, a workgroup finds its layer by its block index.
+// The element-wise index math is the per-layer kernels' (pack.hip, conv_wino.hip, conv_bf16.hip), which stay the public,
+// individually tested entry points.
+#include "netg_pack.h"
+
+namespace pws {
+
+__device__ __forceinline__ int find_layer(const unsigned *first_block, int n, unsigned b) {
+    int lo = 0, hi = n - 1;  // last layer whose first block <= b
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first_block[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ float torch_weight_at(const float *w, int kind, int cin, int cout, int k, size_t t, int ci, int co) {
+    // t = class*taps + tap index in the forward packed layout (pack.hip)
+    if (kind == PWS_CONVT_K4S2) {
+        const int tap = t % 4, cls = t / 4;
+        const int dy = tap >> 1, dx = tap & 1, py = cls >> 1, px = cls & 1;
+        return w[(((size_t)ci * cout + co) * 4 + (3 - py - 2 * dy)) * 4 + (3 - px - 2 * dx)];
+    }
+    if (kind == PWS_CONVT_K3S1) {
+        const int r = t / 3, s = t % 3;
+        return w[(((size_t)ci * cout + co) * 3 + (2 - r)) * 3 + (2 - s)];
+    }
+    const int ky = t / k, kx = t % k;
+    return w[(((size_t)co * cin + ci) * k + ky) * k + kx];
+}
+
+// ---- stage 1: torch layouts -> forward packed fp32 [class*tap][cin_pad][cout] (+ bias), all layers
+__global__ void __launch_bounds__(256) pack_all_kernel(const PackAllArgs a, float *__restrict__ packed) {
+    const int l = find_layer(a.first_block, a.nlayers, blockIdx.x);
+    const PackLayer &L = a.layer[l];
+    const size_t idx = (size_t)(blockIdx.x - a.first_block[l]) * 256 + threadIdx.x;
+    const size_t wtotal = (size_t)L.planes * L.cin_pad * L.cout;
+    if (idx < wtotal) {
+        const int co = idx % L.cout;
+        size_t t = idx / L.cout;
+        const int ci = t % L.cin_pad;
+        t /= L.cin_pad;
+        packed[L.w_off + idx] = ci < L.cin ? torch_weight_at(a.params[2 * l], L.kind, L.cin, L.cout, L.k, t, ci, co) : 0.f;
+    } else if (idx < wtotal + L.cout) {
+        packed[L.b_off + (idx - wtotal)] = a.params[2 * l + 1][idx - wtotal];
+    }
+}
+
+// ---- stage 2: Winograd F(2x2,3x3) weights of the K3S1 / CONVT_K3S1 layers from the packed fp32 weights
+__global__ void __launch_bounds__(256) wino_all_kernel(const PackAllArgs a, float *__restrict__ packed) {
+    const int l = find_layer(a.first_block_wino, a.nlayers, blockIdx.x);
+    const PackLayer &L = a.layer[l];
+    if (L.ww_off == kNoOff) return;
+    const size_t plane = (size_t)L.cin_pad * L.cout;
+    const size_t i = (size_t)(blockIdx.x - a.first_block_wino[l]) * 256 + threadIdx.x;
+    if (i >= plane) return;
+    const float *pk = packed + L.w_off;
+    float *uw = packed + L.ww_off;
+    float g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) g[r][s] = pk[(size_t)(r * 3 + s) * plane + i];
+    float u[4][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        u[0][s] = g[0][s], u[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]), u[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
+        u[3][s] = g[2][s];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        uw[(size_t)(r * 4 + 0) * plane + i] = u[r][0];
+        uw[(size_t)(r * 4 + 1) * plane + i] = 0.5f * (u[r][0] + u[r][1] + u[r][2]);
+        uw[(size_t)(r * 4 + 2) * plane + i] = 0.5f * (u[r][0] - u[r][1] + u[r][2]);
+        uw[(size_t)(r * 4 + 3) * plane + i] = u[r][2];
+    }
+}
+
+// ---- stage 3: bf16 copies [plane][ncols pad 64][krows pad 32] of an fp32 [plane][krows][ncols] layout (forward or data
+// gradient), all layers.  A workgroup transposes a 32 (k) x 64 (n) tile through LDS: coalesced on both sides.
+__global__ void __launch_bounds__(256) bf16_all_kernel(const Bf16AllArgs a, const float *__restrict__ src_base,
+                                                       unsigned *__restrict__ dst_base) {
+    __shared__ float t[32][65];
+    const int l = find_layer(a.first_block, a.nlayers, blockIdx.x);
+    const Bf16Layer &L = a.layer[l];
+    if (L.dst_off == kNoOff) return;
+    unsigned b = blockIdx.x - a.first_block[l];
+    const int kt = L.kpad / 32, nt = L.npad / 64;
+    const int kb = b % kt;
+    b /= kt;
+    const int nb = b % nt, plane = b / nt;
+    const float *src = src_base + (size_t)L.src_off + (size_t)plane * L.krows * L.ncols;
+    for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+        const int k = kb * 32 + (i >> 6), n = nb * 64 + (i & 63);
+        t[i >> 6][i & 63] = (k < L.krows && n < L.ncols) ? src[(size_t)k * L.ncols + n] : 0.f;
+    }
+    __syncthreads();
+    // destination (in dwords = k pairs): [plane][npad][kpad/2]
+    unsigned *dst = dst_base + ((size_t)L.dst_off * 2 + ((size_t)plane * L.npad + nb * 64) * L.kpad + kb * 32) / 2;
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+        const int n = i >> 4, k2 = i & 15;
+        dst[(size_t)n * (L.kpad / 2) + k2] = cvt_pk_bf16(t[2 * k2][n], t[2 * k2 + 1][n]);
+    }
+}
+
+// ---- data-gradient fp32 layouts [tap][cout_f][cin_f] of all layers that have one (pack.hip: pack_dgrad_kernel)
+__global__ void __launch_bounds__(256) dgrad_all_kernel(const PackAllArgs a, float *__restrict__ packed_dgrad) {
+    const int l = find_layer(a.first_block_dgrad, a.nlayers, blockIdx.x);
+    const PackLayer &L = a.layer[l];
+    if (L.dg_off == kNoOff) return;
+    const size_t idx = (size_t)(blockIdx.x - a.first_block_dgrad[l]) * 256 + threadIdx.x;
+    const size_t total = (size_t)L.dg_taps * L.cin * L.cout;
+    if (idx >= total) return;
+    const float *w = a.params[2 * l];
+    const int cin = L.cin, cout = L.cout, kind = L.kind;
+    const int ci = idx % cin;
+    size_t t = idx / cin;
+    const int co = t % cout;
+    t /= cout;
+    float v = 0.f;
+    if (kind == PWS_CONV_K3S1) {
+        const int r = t / 3, s_ = t % 3;
+        v = w[(((size_t)co * cin + ci) * 3 + (2 - r)) * 3 + (2 - s_)];
+    } else if (kind == PWS_CONVT_K3S1) {
+        const int r = t / 3, s_ = t % 3;
+        v = w[(((size_t)ci * cout + co) * 3 + r) * 3 + s_];
+    } else if (kind == PWS_CONV_K3S2) {
+        const int tap = t % 4, cls = t / 4;
+        const int dy = tap >> 1, dx = tap & 1, py = cls >> 1, px = cls & 1;
+        const int ry = py ? (dy ? 0 : 2) : (dy ? -1 : 1), rx = px ? (dx ? 0 : 2) : (dx ? -1 : 1);
+        if (ry >= 0 && rx >= 0) v = w[(((size_t)co * cin + ci) * 3 + ry) * 3 + rx];
+    } else {  // PWS_CONVT_K4S2
+        const int ky = t / 4, kx = t % 4;
+        v = w[(((size_t)ci * cout + co) * 4 + ky) * 4 + kx];
+    }
+    packed_dgrad[L.dg_off + idx] = v;
+}
+
+// ---- gradients: packed layout -> the 92 torch-layout tensors (pack.hip: unpack_weight_kernel) + biases
+__global__ void __launch_bounds__(256) unpack_all_kernel(const UnpackAllArgs a, const float *__restrict__ dpacked) {
+    const int l = find_layer(a.first_block, a.nlayers, blockIdx.x);
+    const PackLayer &L = a.layer[l];
+    const size_t idx = (size_t)(blockIdx.x - a.first_block[l]) * 256 + threadIdx.x;
+    const int k = L.k, cin = L.cin, cout = L.cout, kind = L.kind;
+    const size_t wtotal = (size_t)k * k * cin * cout;
+    if (idx < wtotal) {
+        const int kx = idx % k, ky = (idx / k) % k;
+        const size_t t = idx / ((size_t)k * k);
+        size_t tapcls;
+        int ci, co;
+        if (kind == PWS_CONVT_K4S2 || kind == PWS_CONVT_K3S1) {  // IOHW
+            co = t % cout, ci = t / cout;
+            if (kind == PWS_CONVT_K4S2) {
+                const int py = (3 - ky) & 1, dy = (3 - ky) >> 1, px = (3 - kx) & 1, dx = (3 - kx) >> 1;
+                tapcls = (size_t)(py * 2 + px) * 4 + dy * 2 + dx;
+            } else {
+                tapcls = (size_t)(2 - ky) * 3 + (2 - kx);
+            }
+        } else {  // OIHW
+            ci = t % cin, co = t / cin;
+            tapcls = (size_t)ky * k + kx;
+        }
+        a.grads[2 * l][idx] = dpacked[L.w_off + (tapcls * L.cin_pad + ci) * cout + co];
+    } else if (idx < wtotal + cout) {
+        a.grads[2 * l + 1][idx - wtotal] = dpacked[L.b_off + (idx - wtotal)];
+    }
+}
+
+int launch_pack_all(const PackAllArgs &a, float *packed, hipStream_t st) {
+    hipLaunchKernelGGL(pack_all_kernel, dim3(a.total_blocks), dim3(256), 0, st, a, packed);
+    if (a.total_blocks_wino) hipLaunchKernelGGL(wino_all_kernel, dim3(a.total_blocks_wino), dim3(256), 0, st, a, packed);
+    return check_launch("pack_all_kernel");
+}
+
+int launch_dgrad_all(const PackAllArgs &a, float *packed_dgrad, hipStream_t st) {
+    hipLaunchKernelGGL(dgrad_all_kernel, dim3(a.total_blocks_dgrad), dim3(256), 0, st, a, packed_dgrad);
+    return check_launch("dgrad_all_kernel");
+}
+
+int launch_bf16_all(const Bf16AllArgs &a, const float *src_base, float *dst_base, hipStream_t st) {
+    if (!a.total_blocks) return PWS_OK;
+    hipLaunchKernelGGL(bf16_all_kernel, dim3(a.total_blocks), dim3(256), 0, st, a, src_base, reinterpret_cast<unsigned *>(dst_base));
+    return check_launch("bf16_all_kernel");
+}
+
+int launch_unpack_all(const UnpackAllArgs &a, const float *dpacked, hipStream_t st) {
+    hipLaunchKernelGGL(unpack_all_kernel, dim3(a.total_blocks), dim3(256), 0, st, a, dpacked);
+    return check_launch("unpack_all_kernel");
+}
+
+}  // namespace pws

@@ -96,6 +96,7 @@ SIGNATURES = {
     "pws_upsample_grid_sample_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "pws_upsample_grid_sample_u8": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "pws_adam_step": (_I, [_P, _P, _P, _P, _S, _F, _F, _F, _F, _I, _P]),
+    "pws_adam_step_multi": (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _I, _P]),
     "pws_netg_packed_floats": (_S, [_I, _I]),
     "pws_netg_pack_weights": (_I, [ctypes.POINTER(_P), _P, _I, _I, _P]),
     "pws_netg_workspace_bytes": (_S, [_I, _I, _I, _I]),

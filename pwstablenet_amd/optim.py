@@ -1,9 +1,11 @@
 """Fused Adam on the HIP kernel, with the call surface the reference uses: ``optim.Adam(netG.parameters(), lr=...,
 betas=(beta1, 0.999))``, ``.zero_grad()``, ``.step()`` (reference main_new.py:63,213-216).  No weight decay / amsgrad
 (the reference does not use them).  State is fp32 ``exp_avg`` / ``exp_avg_sq`` per parameter, as in torch."""
+import ctypes
+
 import torch
 
-from . import functional as PF
+from . import hipabi as A
 
 
 class Adam:
@@ -24,17 +26,22 @@ class Adam:
     @torch.no_grad()
     def step(self):
         self.step_count += 1
-        touched = []
+        touched, grads, ms, vs = [], [], [], []
         for p in self.params:
             if p.grad is None:
                 continue
             st = self.state.get(p)
             if st is None:
                 st = self.state[p] = (torch.zeros_like(p), torch.zeros_like(p))
-            g = p.grad.contiguous()
-            PF.adam_step_(p, g, st[0], st[1], self.lr, self.betas[0], self.betas[1], self.eps, self.step_count)
-            touched.append(p)
+            touched.append(p), grads.append(p.grad.contiguous()), ms.append(st[0]), vs.append(st[1])
         if touched:
+            A.require_cuda(*touched, *grads)
+            n = len(touched)
+            arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])  # noqa: E731
+            counts = (ctypes.c_size_t * n)(*[t.numel() for t in touched])
+            # all tensors in one launch per 48 tensors (pws_adam_step_multi); the reference's optim.Adam (main_new.py:63,216)
+            A.check(A.lib().pws_adam_step_multi(arr(touched), arr(grads), arr(ms), arr(vs), counts, n, self.lr, self.betas[0],
+                                                self.betas[1], self.eps, self.step_count, A.current_stream()), "pws_adam_step_multi")
             # the kernel wrote through raw pointers: bump the tensors' version counters (one fused launch) so that
             # everything keyed on them -- the generator's packed-weight cache -- sees the update
             torch._foreach_add_(touched, 0.0)

@@ -357,3 +357,25 @@ def test_heads_vs_oracle(hip, oracle):
                                  st), "field")
     np.testing.assert_allclose(res.cpu().numpy(), ref_res, rtol=0, atol=2e-5)
     np.testing.assert_allclose(grid.cpu().numpy(), ref_grid, rtol=0, atol=5e-5)
+
+
+def test_adam_multi_tensor_matches_single(hip):
+    """pws_adam_step_multi (all tensors in one launch per 48) == pws_adam_step per tensor, bit for bit, over ragged sizes
+    (aligned float4 bodies, scalar tails, > 48 tensors so that the table is split)."""
+    A = hip
+    L, st = A.lib(), A.current_stream()
+    rs = np.random.RandomState(3)
+    sizes = [1, 2, 6, 64, 4097, 5000, 100003, 256] + [rs.randint(1, 3000) for _ in range(60)]
+    ps = [torch.from_numpy(rs.standard_normal(s).astype(np.float32)).cuda() for s in sizes]
+    gs = [torch.from_numpy(rs.standard_normal(s).astype(np.float32)).cuda() for s in sizes]
+    ms = [torch.from_numpy(rs.standard_normal(s).astype(np.float32)).cuda() * 0.1 for s in sizes]
+    vs = [torch.from_numpy(rs.uniform(0, 1, s).astype(np.float32)).cuda() for s in sizes]
+    ref = [[t.clone() for t in grp] for grp in (ps, ms, vs)]
+    for p, g, m, v in zip(ref[0], gs, ref[1], ref[2]):
+        A.check(L.pws_adam_step(A.ptr(p), A.ptr(g), A.ptr(m), A.ptr(v), p.numel(), 1e-3, 0.5, 0.999, 1e-8, 3, st), "adam")
+    n = len(sizes)
+    arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])  # noqa: E731
+    counts = (ctypes.c_size_t * n)(*sizes)
+    A.check(L.pws_adam_step_multi(arr(ps), arr(gs), arr(ms), arr(vs), counts, n, 1e-3, 0.5, 0.999, 1e-8, 3, st), "adam multi")
+    for got, want in zip(ps + ms + vs, ref[0] + ref[1] + ref[2]):
+        assert torch.equal(got, want)
