@@ -98,44 +98,49 @@ __global__ void __launch_bounds__(256) field_dx_kernel(const float *__restrict__
 constexpr int FB_T = 16, FB_I = FB_T + 2, FB_CH = 32, FB_LDP = FB_CH + 1;
 
 __global__ void __launch_bounds__(256) field_dw_kernel(const float *__restrict__ x, int ld, const float *__restrict__ gz, int N,
-                                                       int H, int W, int C, float *__restrict__ dw, int tiles_x, int tiles_y) {
+                                                       int H, int W, int C, float *__restrict__ dw, int tiles_x, int tiles_y,
+                                                       int ntiles) {
     __shared__ float s_in[FB_I * FB_I * FB_LDP];
     __shared__ float s_g[FB_T * FB_T * 2];
     __shared__ float s_red[8 * 32 * 18];
     const int tid = threadIdx.x;
-    const int tile = blockIdx.x;
-    const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-    const int x0 = tx_i * FB_T, y0 = ty_i * FB_T;
     const int c0 = blockIdx.y * FB_CH;
-    for (int item = tid; item < FB_I * FB_I * (FB_CH / 4); item += 256) {
-        const int pix = item / (FB_CH / 4), c4 = (item % (FB_CH / 4)) * 4;
-        const int iy = y0 - 1 + pix / FB_I, ix = x0 - 1 + pix % FB_I;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W && c0 + c4 < C)
-            v = *reinterpret_cast<const float4 *>(x + ((size_t)(n * H + iy) * W + ix) * ld + c0 + c4);
-        float *d = s_in + pix * FB_LDP + c4;
-        d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
-    }
-    {
-        const int ty = tid >> 4, tx = tid & 15, y = y0 + ty, xq = x0 + tx;
-        float2 g = make_float2(0.f, 0.f);
-        if (y < H && xq < W) g = *reinterpret_cast<const float2 *>(gz + (((size_t)n * H + y) * W + xq) * 2);
-        s_g[tid * 2] = g.x, s_g[tid * 2 + 1] = g.y;
-    }
-    __syncthreads();
     const int c = tid & 31, grp = tid >> 5;  // 8 groups x 2 tile rows each
     float acc[18];
 #pragma unroll
     for (int i = 0; i < 18; ++i) acc[i] = 0.f;
-    for (int ty = grp * 2; ty < grp * 2 + 2; ++ty)
-        for (int tx = 0; tx < FB_T; ++tx) {
-            const float g0 = s_g[(ty * FB_T + tx) * 2], g1 = s_g[(ty * FB_T + tx) * 2 + 1];
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const float xv = s_in[((ty + tap / 3) * FB_I + tx + tap % 3) * FB_LDP + c];
-                acc[tap * 2] = fmaf(xv, g0, acc[tap * 2]), acc[tap * 2 + 1] = fmaf(xv, g1, acc[tap * 2 + 1]);
-            }
+    // a workgroup walks a strided subset of the tiles and keeps its partial sums in registers: one round of atomics per
+    // workgroup at the end (one per TILE put 2048 atomics on each of the 1152 addresses: 260 us per call, L2-atomic-bound)
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int x0 = tx_i * FB_T, y0 = ty_i * FB_T;
+        __syncthreads();  // previous tile consumed
+        for (int item = tid; item < FB_I * FB_I * (FB_CH / 4); item += 256) {
+            const int pix = item / (FB_CH / 4), c4 = (item % (FB_CH / 4)) * 4;
+            const int iy = y0 - 1 + pix / FB_I, ix = x0 - 1 + pix % FB_I;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W && c0 + c4 < C)
+                v = *reinterpret_cast<const float4 *>(x + ((size_t)(n * H + iy) * W + ix) * ld + c0 + c4);
+            float *d = s_in + pix * FB_LDP + c4;
+            d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
         }
+        {
+            const int ty = tid >> 4, tx = tid & 15, y = y0 + ty, xq = x0 + tx;
+            float2 g = make_float2(0.f, 0.f);
+            if (y < H && xq < W) g = *reinterpret_cast<const float2 *>(gz + (((size_t)n * H + y) * W + xq) * 2);
+            s_g[tid * 2] = g.x, s_g[tid * 2 + 1] = g.y;
+        }
+        __syncthreads();
+        for (int ty = grp * 2; ty < grp * 2 + 2; ++ty)
+            for (int tx = 0; tx < FB_T; ++tx) {
+                const float g0 = s_g[(ty * FB_T + tx) * 2], g1 = s_g[(ty * FB_T + tx) * 2 + 1];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float xv = s_in[((ty + tap / 3) * FB_I + tx + tap % 3) * FB_LDP + c];
+                    acc[tap * 2] = fmaf(xv, g0, acc[tap * 2]), acc[tap * 2 + 1] = fmaf(xv, g1, acc[tap * 2 + 1]);
+                }
+            }
+    }
 #pragma unroll
     for (int i = 0; i < 18; ++i) s_red[(grp * 32 + c) * 18 + i] = acc[i];
     __syncthreads();
@@ -233,8 +238,11 @@ extern "C" int pws_field_head_bwd(const float *x, int ld, int n, int h, int w, i
     }
     if (dw_out) {
         const int tiles_x = (w + FB_T - 1) / FB_T, tiles_y = (h + FB_T - 1) / FB_T;
-        hipLaunchKernelGGL(field_dw_kernel, dim3((unsigned)(tiles_x * tiles_y * n), (unsigned)((c + FB_CH - 1) / FB_CH)), dim3(256), 0,
-                           st, x, ld, ws, n, h, w, c, dw_out, tiles_x, tiles_y);
+        const int ntiles = tiles_x * tiles_y * n, cblocks = (c + FB_CH - 1) / FB_CH;
+        int gx = (1024 + cblocks - 1) / cblocks;  // ~4 workgroups per CU in total; each walks ntiles / gx tiles
+        if (gx > ntiles) gx = ntiles;
+        hipLaunchKernelGGL(field_dw_kernel, dim3((unsigned)gx, (unsigned)cblocks), dim3(256), 0, st, x, ld, ws, n, h, w, c, dw_out,
+                           tiles_x, tiles_y, ntiles);
     }
     return check_launch("field_head_bwd kernels");
 }

@@ -230,7 +230,9 @@ static int launch_wb(WgradBfParams &p, int nclasses, hipStream_t st) {
     p.ntiles = p.tiles_x * p.tiles_y * p.tiles_n;
     p.ci_blocks = (p.cin_pad + 63) / 64, p.co_blocks = (p.cout + 63) / 64;
     const long other = (long)p.ci_blocks * p.co_blocks * nclasses * C::NGROUPS;
-    long ps = (1024 + other - 1) / other;  // ~4 workgroups per CU overall
+    // ~2 workgroups per CU overall: every workgroup ends with 64 x 64 x taps fp32 atomics on the same addresses, and with
+    // the bf16 MFMA rate that tail is what a 1024-workgroup grid is bound by (64->64 @256x256 x8: 176 us -> 117 us at 512)
+    long ps = (512 + other - 1) / other;
     if (ps > p.ntiles) ps = p.ntiles;
     if (ps < 1) ps = 1;
     dim3 grid((unsigned)ps, (unsigned)(p.ci_blocks * p.co_blocks), (unsigned)(nclasses * C::NGROUPS));
