@@ -59,6 +59,11 @@ const char *pws_last_error(void); /* thread-local, never NULL */
 #define PWS_OPT_MATH 2
 #define PWS_MATH_FP32 0
 #define PWS_MATH_BF16 1
+/* Element type of activations / gradients in HBM for the bf16 path (per call: the `store` fields; whole generator:
+ * PWS_OPT_STORE, default PWS_STORE_FP32).  PWS_STORE_BF16 needs PWS_MATH_BF16. */
+#define PWS_OPT_STORE 3
+#define PWS_STORE_FP32 0
+#define PWS_STORE_BF16 1
 int pws_set_option(int key, int value);
 int pws_get_option(int key); /* current value, or PWS_EINVAL */
 /* Number of compute units / XCDs the library sees on the current device (diagnostics). */
@@ -133,6 +138,9 @@ typedef struct pws_conv_args {
     int math;         /* PWS_MATH_FP32 (0) | PWS_MATH_BF16: needs w_bf16 and every source's channels % 32 == 0,
                          otherwise the launch runs in fp32 */
     const void *w_bf16; /* bf16 weights from pws_pack_weight_bf16(w_packed, planes, cin padded to 16, cout) or NULL */
+    int store;        /* PWS_STORE_FP32 (0) | PWS_STORE_BF16: every src[].ptr and `out` then point to bf16 elements (channels /
+                         ld / out_ld still count ELEMENTS; ld % 8 == 0, out_ld even).  Needs math == PWS_MATH_BF16 and a kind
+                         the bf16 kernels cover.  Halves the activation traffic of the bf16 path. */
 } pws_conv_args;
 
 int pws_conv2d_fwd(const pws_conv_args *args, pws_stream_t stream);
@@ -174,6 +182,7 @@ typedef struct pws_conv_bwd_data_args {
     size_t ws_bytes;
     int math;          /* as in pws_conv_args (bf16 needs w_dgrad_bf16 and cout % 32 == 0) */
     const void *w_dgrad_bf16; /* pws_pack_weight_bf16(w_dgrad, dgrad taps, cout, cin) or NULL */
+    int store;         /* PWS_STORE_BF16: gout and every dst[].ptr hold bf16 elements (accumulation rounds to bf16) */
 } pws_conv_bwd_data_args;
 int pws_conv2d_bwd_data(const pws_conv_bwd_data_args *args, pws_stream_t stream);
 
@@ -189,6 +198,7 @@ typedef struct pws_conv_bwd_weight_args {
     float *dw_packed;  /* gradient in the FORWARD packed layout (pws_packed_weight_floats), ACCUMULATED into
                           (fp32 atomics: several pixel ranges, and stages 2/3 share weights) */
     int math;          /* PWS_MATH_BF16: x and dy rounded to bf16 at LDS staging, fp32 accumulation; dW stays fp32 */
+    int store;         /* PWS_STORE_BF16: src[].ptr and gout hold bf16 elements (dw_packed stays fp32) */
 } pws_conv_bwd_weight_args;
 int pws_conv2d_bwd_weight(const pws_conv_bwd_weight_args *args, pws_stream_t stream);
 

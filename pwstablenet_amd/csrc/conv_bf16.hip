@@ -69,8 +69,13 @@ struct BfCfg {
         }                                                                                                                  \
     } while (0)
 
-template <class C>
+// IO16: activations / gradients live in HBM as bf16 (io_bf16): a staging item is ONE 16-byte load of 8 channels copied to
+// LDS as is, and the epilogue stores channel pairs as dwords.  For that the 64 output channels of a workgroup are dealt to
+// the lanes as (2 l, 2 l + 1) -> (nt 0, nt 1) instead of (l, l + 32): the weight rows are permuted while they are staged
+// (LDS row (nn & 1) * 32 + (nn >> 1) holds output channel nn), the MFMA side is unchanged.  Requires NT == 2.
+template <class C, bool IO16>
 __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_kernel(const ConvKParams p) {
+    static_assert(!IO16 || (C::NT == 2 && C::WN == 1), "bf16 storage pairs the two 32-channel blocks of a wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned char *lds_in = lds_raw;
     unsigned char *lds_w = lds_raw + C::LDS_IN;
@@ -117,20 +122,29 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_kernel(const ConvKPar
         const int row = item / C::C8, c8 = item % C::C8;
         const int tap = row / C::BN, nn = row % C::BN;
         w_off[it] = item < C::N_W ? ((tap * p.npad_bf + co0 + nn) * p.kpad_bf + c8 * 8) : 0;
-        lw_off[it] = item < C::N_W ? C::LDS_IN + row * C::PITCH + c8 * 16 : C::LDS_IN + C::LDS_W;
+        const int lrow = IO16 ? tap * C::BN + (nn & 1) * 32 + (nn >> 1) : row;
+        lw_off[it] = item < C::N_W ? C::LDS_IN + lrow * C::PITCH + c8 * 16 : C::LDS_IN + C::LDS_W;
     }
     const __bf16 *w_cls = static_cast<const __bf16 *>(p.w_bf) + (size_t)cls * C::TAPS * p.npad_bf * p.kpad_bf;
-    f32x4 r_in[C::ITEMS_IN][2];
+    f32x4 r_in[IO16 ? 1 : C::ITEMS_IN][2];
+    u32x4 r_in16[IO16 ? C::ITEMS_IN : 1];
     u32x4 r_w[C::ITEMS_W];
 
     auto load_chunk = [&](int s, int c0, int wrow) {
-        const float *sp = p.src_ptr[s] + c0;
         const size_t ld = p.src_ld[s];
+        if constexpr (IO16) {
+            const __bf16 *sp = reinterpret_cast<const __bf16 *>(p.src_ptr[s]) + c0;
 #pragma unroll
-        for (int it = 0; it < C::ITEMS_IN; ++it) {
-            const float *g = sp + (size_t)g_pix[it] * ld + ((tid + it * C::THREADS) % C::C8) * 8;
-            r_in[it][0] = *reinterpret_cast<const f32x4 *>(g);
-            r_in[it][1] = *reinterpret_cast<const f32x4 *>(g + 4);
+            for (int it = 0; it < C::ITEMS_IN; ++it)
+                r_in16[it] = *reinterpret_cast<const u32x4 *>(sp + (size_t)g_pix[it] * ld + ((tid + it * C::THREADS) % C::C8) * 8);
+        } else {
+            const float *sp = p.src_ptr[s] + c0;
+#pragma unroll
+            for (int it = 0; it < C::ITEMS_IN; ++it) {
+                const float *g = sp + (size_t)g_pix[it] * ld + ((tid + it * C::THREADS) % C::C8) * 8;
+                r_in[it][0] = *reinterpret_cast<const f32x4 *>(g);
+                r_in[it][1] = *reinterpret_cast<const f32x4 *>(g + 4);
+            }
         }
         const __bf16 *wp = w_cls + wrow;
 #pragma unroll
@@ -141,8 +155,12 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_kernel(const ConvKPar
         for (int it = 0; it < C::ITEMS_IN; ++it) {
             const bool ok = (ok_mask >> it) & 1u;
             u32x4 v;
-            v.x = ok ? cvt_pk_bf16(r_in[it][0].x, r_in[it][0].y) : 0u, v.y = ok ? cvt_pk_bf16(r_in[it][0].z, r_in[it][0].w) : 0u;
-            v.z = ok ? cvt_pk_bf16(r_in[it][1].x, r_in[it][1].y) : 0u, v.w = ok ? cvt_pk_bf16(r_in[it][1].z, r_in[it][1].w) : 0u;
+            if constexpr (IO16) {
+                v.x = ok ? r_in16[it].x : 0u, v.y = ok ? r_in16[it].y : 0u, v.z = ok ? r_in16[it].z : 0u, v.w = ok ? r_in16[it].w : 0u;
+            } else {
+                v.x = ok ? cvt_pk_bf16(r_in[it][0].x, r_in[it][0].y) : 0u, v.y = ok ? cvt_pk_bf16(r_in[it][0].z, r_in[it][0].w) : 0u;
+                v.z = ok ? cvt_pk_bf16(r_in[it][1].x, r_in[it][1].y) : 0u, v.w = ok ? cvt_pk_bf16(r_in[it][1].z, r_in[it][1].w) : 0u;
+            }
             *reinterpret_cast<u32x4 *>(lds_raw + l_off[it]) = v;
         }
 #pragma unroll
@@ -203,7 +221,32 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_kernel(const ConvKPar
         }
     }
 
-    PWS_BF_EPILOGUE(C, p, acc, wm, wn, l31, hi, n0, y0, x0, co0, py, px, split);
+    if constexpr (IO16) {
+        // channel pair (2 l31, 2 l31 + 1) of this wave's 64 channels: one dword per pixel and lane, 128 B per pixel and half-wave
+        const bool partial = p.ksplit > 1;
+        float *part = p.out + (size_t)split * p.split_stride;
+        const int co = co0 + 2 * l31;
+        const bool co_ok = co < p.cout;   // cout is even
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (wm * C::MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
+                const int n = n0 + tn, y = y0 + ty, x = x0 + tx;
+                const int oy = C::CONVT ? 2 * y + py : y, ox = C::CONVT ? 2 * x + px : x;
+                if (co_ok && n < p.N && y < p.LH && x < p.LW && oy < p.OH && ox < p.OW) {
+                    const size_t pix = (size_t)(n * p.OH + oy) * p.OW + ox;
+                    if (partial)
+                        *reinterpret_cast<float2 *>(part + pix * p.cout + co) = make_float2(acc[mt][0][r], acc[mt][1][r]);
+                    else
+                        epi_store_pair16(p, pix, co, acc[mt][0][r], acc[mt][1][r]);
+                }
+            }
+        }
+    } else {
+        PWS_BF_EPILOGUE(C, p, acc, wm, wn, l31, hi, n0, y0, x0, co0, py, px, split);
+    }
 }
 
 // First layer (Conv2d k5 s1 p2, 31 -> 64 channels): 25 taps x 64 output rows of weights do not fit LDS beside the input tile
@@ -218,7 +261,7 @@ struct K5Lds {
     static constexpr int N_WR = C::KS * C::BN * C::C8, ITEMS_WR = (N_WR + C::THREADS - 1) / C::THREADS;
 };
 
-template <class C>
+template <class C, bool IO16>
 __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_k5_kernel(const ConvKParams p) {
     using K = K5Lds<C>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -260,7 +303,8 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_k5_kernel(const ConvK
         const int row = item / C::C8, c8 = item % C::C8;
         const int tap = row / C::BN, nn = row % C::BN;
         w_off[it] = item < K::N_WR ? ((tap * p.npad_bf + co0 + nn) * p.kpad_bf + c8 * 8) : 0;
-        lw_off[it] = item < K::N_WR ? C::LDS_IN + row * C::PITCH + c8 * 16 : SINK;
+        const int lrow = IO16 ? tap * C::BN + (nn & 1) * 32 + (nn >> 1) : row;  // channel pairs per lane, see conv_bf16_kernel
+        lw_off[it] = item < K::N_WR ? C::LDS_IN + lrow * C::PITCH + c8 * 16 : SINK;
     }
     const __bf16 *wbase = static_cast<const __bf16 *>(p.w_bf);
     u32x4 r_w[K::ITEMS_WR];
@@ -276,11 +320,13 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_k5_kernel(const ConvK
         // ---- input tile of this channel chunk (batches of 4 items: loads first, then convert + store)
         {
             constexpr int ITS = C::ITEMS_IN, BATCH = 4;
-            const float *sp = p.src_ptr[0] + ch * C::CK;
+            const float *sp = p.src_ptr[0] + (IO16 ? 0 : ch * C::CK);
+            const __bf16 *sp16 = reinterpret_cast<const __bf16 *>(p.src_ptr[0]) + ch * C::CK;
             const size_t ld = p.src_ld[0];
 #pragma unroll 1
             for (int it0 = 0; it0 < ITS; it0 += BATCH) {
                 f32x4 r[BATCH][2];
+                u32x4 r16[BATCH];
                 int off[BATCH];
                 bool okv[BATCH];
 #pragma unroll
@@ -290,17 +336,25 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_k5_kernel(const ConvK
                     const int lx = pix % C::IW, ly = (pix / C::IW) % C::IH, tn = pix / (C::IW * C::IH);
                     const int n = n0 + tn, iy = iy0 + ly, ix = ix0 + lx;
                     const bool ok = item < C::N_IN && n < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                    const float *g = sp + (ok ? ((size_t)(n * p.H + iy) * p.W + ix) * ld + c8 * 8 : 0);
-                    r[k][0] = *reinterpret_cast<const f32x4 *>(g);
-                    r[k][1] = *reinterpret_cast<const f32x4 *>(g + 4);
+                    const size_t e = ok ? ((size_t)(n * p.H + iy) * p.W + ix) * ld + c8 * 8 : 0;
+                    if constexpr (IO16) {
+                        r16[k] = *reinterpret_cast<const u32x4 *>(sp16 + e);
+                    } else {
+                        r[k][0] = *reinterpret_cast<const f32x4 *>(sp + e);
+                        r[k][1] = *reinterpret_cast<const f32x4 *>(sp + e + 4);
+                    }
                     okv[k] = ok;
                     off[k] = item < C::N_IN ? pix * C::PITCH + c8 * 16 : SINK;
                 }
 #pragma unroll
                 for (int k = 0; k < BATCH; ++k) {
                     u32x4 v;
-                    v.x = okv[k] ? cvt_pk_bf16(r[k][0].x, r[k][0].y) : 0u, v.y = okv[k] ? cvt_pk_bf16(r[k][0].z, r[k][0].w) : 0u;
-                    v.z = okv[k] ? cvt_pk_bf16(r[k][1].x, r[k][1].y) : 0u, v.w = okv[k] ? cvt_pk_bf16(r[k][1].z, r[k][1].w) : 0u;
+                    if constexpr (IO16) {
+                        v.x = okv[k] ? r16[k].x : 0u, v.y = okv[k] ? r16[k].y : 0u, v.z = okv[k] ? r16[k].z : 0u, v.w = okv[k] ? r16[k].w : 0u;
+                    } else {
+                        v.x = okv[k] ? cvt_pk_bf16(r[k][0].x, r[k][0].y) : 0u, v.y = okv[k] ? cvt_pk_bf16(r[k][0].z, r[k][0].w) : 0u;
+                        v.z = okv[k] ? cvt_pk_bf16(r[k][1].x, r[k][1].y) : 0u, v.w = okv[k] ? cvt_pk_bf16(r[k][1].z, r[k][1].w) : 0u;
+                    }
                     *reinterpret_cast<u32x4 *>(lds_raw + off[k]) = v;
                 }
             }
@@ -333,7 +387,22 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_k5_kernel(const ConvK
             }
         }
     }
-    PWS_BF_EPILOGUE(C, p, acc, wm, wn, l31, hi, n0, y0, x0, co0, 0, 0, 0);
+    if constexpr (IO16) {
+        const int co = co0 + 2 * l31;
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (wm * C::MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
+                const int n = n0 + tn, y = y0 + ty, x = x0 + tx;
+                if (co < p.cout && n < p.N && y < p.LH && x < p.LW)
+                    epi_store_pair16(p, (size_t)(n * p.OH + y) * p.OW + x, co, acc[mt][0][r], acc[mt][1][r]);
+            }
+        }
+    } else {
+        PWS_BF_EPILOGUE(C, p, acc, wm, wn, l31, hi, n0, y0, x0, co0, 0, 0, 0);
+    }
 }
 
 // NCHW fp32 [n][c][hw] -> NHWC fp32 [n][hw][cpad] with zero padding channels (cpad <= 32, a multiple of 4): 64 pixels per
@@ -357,11 +426,11 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_pad_kernel(const float *__re
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-template <class C>
-static int launch_bf(ConvKParams &kp, hipStream_t st, const ProfInfo &) {
+template <class C, bool IO16>
+static int launch_bf_io(ConvKParams &kp, hipStream_t st) {
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_kernel<C>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_kernel<C, IO16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) {
             set_error("hipFuncSetAttribute(conv_bf16_kernel, %d B LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
@@ -370,51 +439,75 @@ static int launch_bf(ConvKParams &kp, hipStream_t st, const ProfInfo &) {
         attr_set = true;
     }
     dim3 grid(kp.ntiles, (kp.cout + C::BN - 1) / C::BN, kp.nclasses * kp.ksplit);
-    hipLaunchKernelGGL(conv_bf16_kernel<C>, grid, dim3(C::THREADS), C::LDS_BYTES, st, kp);
+    hipLaunchKernelGGL((conv_bf16_kernel<C, IO16>), grid, dim3(C::THREADS), C::LDS_BYTES, st, kp);
     return check_launch("conv_bf16_kernel");
 }
 
-template <class C>
-static constexpr TileChoice bchoice() {
-    return TileChoice{C::TH, C::TW, C::TN, C::CK, C::BN, KID_CONV_BF16, &launch_bf<C>};
+// C: configuration for fp32 storage; CS: same tile with 64 channels per wave, used for bf16 storage (may be C itself)
+template <class C, class CS>
+static int launch_bf(ConvKParams &kp, hipStream_t st, const ProfInfo &) {
+    static_assert(C::TH == CS::TH && C::TW == CS::TW && C::TN == CS::TN && C::CK == CS::CK, "same tile");
+    if (kp.io_bf16) return launch_bf_io<CS, true>(kp, st);
+    return launch_bf_io<C, false>(kp, st);
 }
 
+template <class C, class CS = C>
+static constexpr TileChoice bchoice() {
+    return TileChoice{C::TH, C::TW, C::TN, C::CK, C::BN, KID_CONV_BF16, &launch_bf<C, CS>};
+}
+
+// (*_S: the 64-pixel tiles with 2 waves x 64 channels instead of 4 waves x 32: what the bf16-storage epilogue needs)
 //                     KS S  P  subpix TH  TW  TN  CK WM WN MT NT
 using B_K3S1_T256 = BfCfg<3, 1, 1, 0, 16, 16, 1, 32, 4, 1, 2, 2>;
 using B_K3S1_T128 = BfCfg<3, 1, 1, 0, 8, 16, 1, 32, 4, 1, 1, 2>;
 using B_K3S1_T64 = BfCfg<3, 1, 1, 0, 8, 8, 1, 32, 2, 2, 1, 1>;
+using B_K3S1_T64_S = BfCfg<3, 1, 1, 0, 8, 8, 1, 32, 2, 1, 1, 2>;
 using B_K3S1_T64N4 = BfCfg<3, 1, 1, 0, 4, 4, 4, 32, 2, 2, 1, 1>;
+using B_K3S1_T64N4_S = BfCfg<3, 1, 1, 0, 4, 4, 4, 32, 2, 1, 1, 2>;
 using B_K3S1_T64N16 = BfCfg<3, 1, 1, 0, 2, 2, 16, 32, 2, 2, 1, 1>;
+using B_K3S1_T64N16_S = BfCfg<3, 1, 1, 0, 2, 2, 16, 32, 2, 1, 1, 2>;
 using B_K3S2_T256 = BfCfg<3, 2, 1, 0, 16, 16, 1, 16, 4, 1, 2, 2>;
 using B_K3S2_T128 = BfCfg<3, 2, 1, 0, 8, 16, 1, 16, 4, 1, 1, 2>;
 using B_K3S2_T64 = BfCfg<3, 2, 1, 0, 8, 8, 1, 16, 2, 2, 1, 1>;
+using B_K3S2_T64_S = BfCfg<3, 2, 1, 0, 8, 8, 1, 16, 2, 1, 1, 2>;
 using B_K3S2_T64N4 = BfCfg<3, 2, 1, 0, 4, 4, 4, 16, 2, 2, 1, 1>;
+using B_K3S2_T64N4_S = BfCfg<3, 2, 1, 0, 4, 4, 4, 16, 2, 1, 1, 2>;
 using B_K3S2_T64N16 = BfCfg<3, 2, 1, 0, 2, 2, 16, 16, 2, 2, 1, 1>;
+using B_K3S2_T64N16_S = BfCfg<3, 2, 1, 0, 2, 2, 16, 16, 2, 1, 1, 2>;
 using B_CT4_T256 = BfCfg<2, 1, 0, 1, 16, 16, 1, 32, 4, 1, 2, 2>;
 using B_CT4_T128 = BfCfg<2, 1, 0, 1, 8, 16, 1, 32, 4, 1, 1, 2>;
 using B_CT4_T64 = BfCfg<2, 1, 0, 1, 8, 8, 1, 32, 2, 2, 1, 1>;
+using B_CT4_T64_S = BfCfg<2, 1, 0, 1, 8, 8, 1, 32, 2, 1, 1, 2>;
 using B_CT4_T64N4 = BfCfg<2, 1, 0, 1, 4, 4, 4, 32, 2, 2, 1, 1>;
+using B_CT4_T64N4_S = BfCfg<2, 1, 0, 1, 4, 4, 4, 32, 2, 1, 1, 2>;
 using B_CT4_T64N16 = BfCfg<2, 1, 0, 1, 2, 2, 16, 32, 2, 2, 1, 1>;
+using B_CT4_T64N16_S = BfCfg<2, 1, 0, 1, 2, 2, 16, 32, 2, 1, 1, 2>;
 // data-gradient kinds: conv k4 s2 p1 over dy (gradient of ConvTranspose2d k4 s2 p1), sub-pixel gradient of conv k3 s2 p1
 using B_K4S2_T128 = BfCfg<4, 2, 1, 0, 8, 16, 1, 16, 4, 1, 1, 2>;
 using B_K4S2_T64 = BfCfg<4, 2, 1, 0, 8, 8, 1, 16, 2, 2, 1, 1>;
+using B_K4S2_T64_S = BfCfg<4, 2, 1, 0, 8, 8, 1, 16, 2, 1, 1, 2>;
 using B_K4S2_T64N4 = BfCfg<4, 2, 1, 0, 4, 4, 4, 16, 2, 2, 1, 1>;
+using B_K4S2_T64N4_S = BfCfg<4, 2, 1, 0, 4, 4, 4, 16, 2, 1, 1, 2>;
 using B_K4S2_T64N16 = BfCfg<4, 2, 1, 0, 2, 2, 16, 16, 2, 2, 1, 1>;
+using B_K4S2_T64N16_S = BfCfg<4, 2, 1, 0, 2, 2, 16, 16, 2, 1, 1, 2>;
 using B_SP3_T256 = BfCfg<2, 1, 0, 2, 16, 16, 1, 32, 4, 1, 2, 2>;
 using B_SP3_T128 = BfCfg<2, 1, 0, 2, 8, 16, 1, 32, 4, 1, 1, 2>;
 using B_SP3_T64 = BfCfg<2, 1, 0, 2, 8, 8, 1, 32, 2, 2, 1, 1>;
+using B_SP3_T64_S = BfCfg<2, 1, 0, 2, 8, 8, 1, 32, 2, 1, 1, 2>;
 using B_SP3_T64N4 = BfCfg<2, 1, 0, 2, 4, 4, 4, 32, 2, 2, 1, 1>;
+using B_SP3_T64N4_S = BfCfg<2, 1, 0, 2, 4, 4, 4, 32, 2, 1, 1, 2>;
 using B_SP3_T64N16 = BfCfg<2, 1, 0, 2, 2, 2, 16, 32, 2, 2, 1, 1>;
+using B_SP3_T64N16_S = BfCfg<2, 1, 0, 2, 2, 2, 16, 32, 2, 1, 1, 2>;
 
-static const TileChoice kBK3S1[] = {bchoice<B_K3S1_T256>(), bchoice<B_K3S1_T128>(), bchoice<B_K3S1_T64>(), bchoice<B_K3S1_T64N4>(),
-                                    bchoice<B_K3S1_T64N16>()};
-static const TileChoice kBK3S2[] = {bchoice<B_K3S2_T256>(), bchoice<B_K3S2_T128>(), bchoice<B_K3S2_T64>(), bchoice<B_K3S2_T64N4>(),
-                                    bchoice<B_K3S2_T64N16>()};
-static const TileChoice kBCT4[] = {bchoice<B_CT4_T256>(), bchoice<B_CT4_T128>(), bchoice<B_CT4_T64>(), bchoice<B_CT4_T64N4>(),
-                                   bchoice<B_CT4_T64N16>()};
-static const TileChoice kBK4S2[] = {bchoice<B_K4S2_T128>(), bchoice<B_K4S2_T64>(), bchoice<B_K4S2_T64N4>(), bchoice<B_K4S2_T64N16>()};
-static const TileChoice kBSP3[] = {bchoice<B_SP3_T256>(), bchoice<B_SP3_T128>(), bchoice<B_SP3_T64>(), bchoice<B_SP3_T64N4>(),
-                                   bchoice<B_SP3_T64N16>()};
+static const TileChoice kBK3S1[] = {bchoice<B_K3S1_T256>(), bchoice<B_K3S1_T128>(), bchoice<B_K3S1_T64, B_K3S1_T64_S>(), bchoice<B_K3S1_T64N4, B_K3S1_T64N4_S>(),
+                                    bchoice<B_K3S1_T64N16, B_K3S1_T64N16_S>()};
+static const TileChoice kBK3S2[] = {bchoice<B_K3S2_T256>(), bchoice<B_K3S2_T128>(), bchoice<B_K3S2_T64, B_K3S2_T64_S>(), bchoice<B_K3S2_T64N4, B_K3S2_T64N4_S>(),
+                                    bchoice<B_K3S2_T64N16, B_K3S2_T64N16_S>()};
+static const TileChoice kBCT4[] = {bchoice<B_CT4_T256>(), bchoice<B_CT4_T128>(), bchoice<B_CT4_T64, B_CT4_T64_S>(), bchoice<B_CT4_T64N4, B_CT4_T64N4_S>(),
+                                   bchoice<B_CT4_T64N16, B_CT4_T64N16_S>()};
+static const TileChoice kBK4S2[] = {bchoice<B_K4S2_T128>(), bchoice<B_K4S2_T64, B_K4S2_T64_S>(), bchoice<B_K4S2_T64N4, B_K4S2_T64N4_S>(), bchoice<B_K4S2_T64N16, B_K4S2_T64N16_S>()};
+static const TileChoice kBSP3[] = {bchoice<B_SP3_T256>(), bchoice<B_SP3_T128>(), bchoice<B_SP3_T64, B_SP3_T64_S>(), bchoice<B_SP3_T64N4, B_SP3_T64N4_S>(),
+                                   bchoice<B_SP3_T64N16, B_SP3_T64N16_S>()};
 
 using B_K5S1_T256 = BfCfg<5, 1, 2, 0, 16, 16, 1, 32, 4, 1, 2, 2>;
 
@@ -422,8 +515,11 @@ static int launch_k5(ConvKParams &kp, hipStream_t st, const ProfInfo &pi) {
     using C = B_K5S1_T256;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_k5_kernel<C>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_k5_kernel<C, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, K5Lds<C>::BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_k5_kernel<C, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, K5Lds<C>::BYTES);
         if (e != hipSuccess) {
             set_error("hipFuncSetAttribute(conv_bf16_k5_kernel): %s", hipGetErrorString(e));
             return PWS_EHIP;
@@ -434,8 +530,11 @@ static int launch_k5(ConvKParams &kp, hipStream_t st, const ProfInfo &pi) {
     kp.ntiles = (unsigned)(kp.tiles_x * kp.tiles_y * kp.N);
     kp.ksplit = 1, kp.chunks_per_split = 0, kp.split_stride = 0;
     ProfScope prof(KID_CONV_BF16, pi.flops, pi.bytes, st);
-    hipLaunchKernelGGL(conv_bf16_k5_kernel<C>, dim3(kp.ntiles, (kp.cout + C::BN - 1) / C::BN), dim3(C::THREADS), K5Lds<C>::BYTES, st,
-                       kp);
+    const dim3 grid(kp.ntiles, (kp.cout + C::BN - 1) / C::BN);
+    if (kp.io_bf16)
+        hipLaunchKernelGGL((conv_bf16_k5_kernel<C, true>), grid, dim3(C::THREADS), K5Lds<C>::BYTES, st, kp);
+    else
+        hipLaunchKernelGGL((conv_bf16_k5_kernel<C, false>), grid, dim3(C::THREADS), K5Lds<C>::BYTES, st, kp);
     return check_launch("conv_bf16_k5_kernel");
 }
 

@@ -33,6 +33,7 @@ struct ConvKParams {
     // bf16 math (conv_bf16.hip): weights as [class*taps][npad_bf][kpad_bf] bf16 (pws_pack_weight_bf16)
     const void *w_bf;
     int kpad_bf, npad_bf;
+    int io_bf16;    // bf16 math only: sources, `out` and dst_ptr[] hold bf16 elements (strides in elements), see conv_bf16.hip
     int ndst;
     float *dst_ptr[4];
     int dst_c0[4], dst_c1[4], dst_ld[4], dst_acc[4];
@@ -48,6 +49,29 @@ __device__ __forceinline__ void epi_store(const ConvKParams &p, size_t pix, int 
             if (s < p.ndst && co >= p.dst_c0[s] && co < p.dst_c1[s]) {
                 float *d = p.dst_ptr[s] + pix * p.dst_ld[s] + (co - p.dst_c0[s]);
                 *d = p.dst_acc[s] ? *d + v : v;
+            }
+        }
+    }
+}
+
+// bf16-storage counterparts (conv_bf16.hip with io_bf16): a lane stores the channel pair (co, co + 1) of one pixel as one dword
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+__device__ __forceinline__ void epi_store_pair16(const ConvKParams &p, size_t pix, int co, float v0, float v1) {
+    if (p.ndst == 0) {
+        const float b0 = p.bias ? p.bias[co] : 0.f, b1 = p.bias ? p.bias[co + 1] : 0.f;
+        unsigned *d = reinterpret_cast<unsigned *>(reinterpret_cast<__bf16 *>(p.out) + pix * p.out_ld + co);
+        *d = cvt_pk_bf16(act_apply(v0 + b0, p.act), act_apply(v1 + b1, p.act));
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s < p.ndst && co >= p.dst_c0[s] && co < p.dst_c1[s]) {
+                unsigned *d = reinterpret_cast<unsigned *>(reinterpret_cast<__bf16 *>(p.dst_ptr[s]) + pix * p.dst_ld[s] + (co - p.dst_c0[s]));
+                if (p.dst_acc[s]) {
+                    const unsigned o = *d;
+                    v0 += bf16_lo(o), v1 += bf16_hi(o);
+                }
+                *d = cvt_pk_bf16(v0, v1);
             }
         }
     }

@@ -273,6 +273,10 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvKParams p,
     }
     const size_t pix = (i * 4) / p.cout;
     const int co = (int)((i * 4) % p.cout);
+    if (p.io_bf16) {  // bf16 storage (conv_bf16.hip): channel pairs as dwords
+        epi_store_pair16(p, pix, co, a.x, a.y), epi_store_pair16(p, pix, co + 2, a.z, a.w);
+        return;
+    }
     epi_store(p, pix, co, a.x), epi_store(p, pix, co + 1, a.y), epi_store(p, pix, co + 2, a.z), epi_store(p, pix, co + 3, a.w);
 }
 
@@ -397,6 +401,16 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
     float *ws = static_cast<float *>(a->ws);
     const size_t ws_floats = a->ws_bytes / sizeof(float);
     const bool bf16 = a->math == PWS_MATH_BF16 && a->w_bf16 && !nchw;
+    if (a->store == PWS_STORE_BF16) {
+        PWS_REQUIRE(bf16, "pws_conv2d_fwd: bf16 storage needs math == PWS_MATH_BF16, w_bf16 and NHWC sources");
+        PWS_REQUIRE(a->out_ld % 2 == 0 && a->cout % 2 == 0 && (reinterpret_cast<size_t>(a->out) & 3) == 0,
+                    "pws_conv2d_fwd: bf16 storage needs an even cout / out_ld and a 4-byte aligned out");
+        for (int s = 0; s < a->nsrc; ++s)
+            PWS_REQUIRE(a->src[s].channels % 32 == 0 && a->src[s].ld % 8 == 0,
+                        "pws_conv2d_fwd: bf16 storage needs channels %% 32 == 0 and ld %% 8 == 0 (source %d: %d, %d)", s,
+                        a->src[s].channels, a->src[s].ld);
+        kp.io_bf16 = 1;
+    }
     kp.w_bf = a->w_bf16, kp.kpad_bf = (kp.cin_pad + 31) / 32 * 32, kp.npad_bf = (a->cout + 63) / 64 * 64;
 
     // algorithmic work of this launch (real channels, each tensor touched once)
@@ -498,6 +512,14 @@ int conv2d_bwd_data_impl(const pws_conv_bwd_data_args *a, hipStream_t st) {
         kp.LH = oh, kp.LW = ow, kp.nclasses = 4;
     else
         kp.LH = a->h, kp.LW = a->w;
+    if (a->store == PWS_STORE_BF16) {
+        PWS_REQUIRE(a->math == PWS_MATH_BF16 && a->w_dgrad_bf16 && a->cout % 32 == 0 && a->gout_ld % 8 == 0,
+                    "pws_conv2d_bwd_data: bf16 storage needs bf16 math, w_dgrad_bf16, cout %% 32 == 0 and gout_ld %% 8 == 0");
+        for (int s = 0; s < a->ndst; ++s)
+            PWS_REQUIRE(a->dst[s].channels % 2 == 0 && a->dst[s].ld % 2 == 0 && (reinterpret_cast<size_t>(a->dst[s].ptr) & 3) == 0,
+                        "pws_conv2d_bwd_data: bf16 storage needs even channels / ld and 4-byte aligned destinations");
+        kp.io_bf16 = 1;
+    }
     if (a->math == PWS_MATH_BF16 && a->w_dgrad_bf16) {
         kp.w_bf = a->w_dgrad_bf16, kp.kpad_bf = (a->cout + 31) / 32 * 32, kp.npad_bf = (cin_f + 63) / 64 * 64;
         const int rc = conv_bf16_dgrad(a->kind, kp, a->cout, ws, ws_floats, st, pi);

@@ -16,6 +16,7 @@ c_stream = ctypes.c_void_p
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 OPT_TWO_QUEUES = 1
 OPT_MATH, MATH_FP32, MATH_BF16 = 2, 0, 1
+OPT_STORE, STORE_FP32, STORE_BF16 = 3, 0, 1
 CONV_K3S1, CONV_K3S2, CONV_K5S1, CONVT_K3S1, CONVT_K4S2, CONV_K2S1P0, CONV_K1, CONV_K3S1_OUT = range(8)
 
 
@@ -28,7 +29,7 @@ class PwsConvArgs(ctypes.Structure):
                 ("nsrc", ctypes.c_int), ("src", PwsSrc * 4), ("src_nchw", ctypes.c_int), ("cout", ctypes.c_int),
                 ("w_packed", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("act", ctypes.c_int),
                 ("out", ctypes.c_void_p), ("out_ld", ctypes.c_int), ("w_wino", ctypes.c_void_p), ("ws", ctypes.c_void_p),
-                ("ws_bytes", ctypes.c_size_t), ("math", ctypes.c_int), ("w_bf16", ctypes.c_void_p)]
+                ("ws_bytes", ctypes.c_size_t), ("math", ctypes.c_int), ("w_bf16", ctypes.c_void_p), ("store", ctypes.c_int)]
 
 
 class PwsDst(ctypes.Structure):
@@ -39,13 +40,13 @@ class PwsConvBwdDataArgs(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("n", ctypes.c_int), ("h", ctypes.c_int), ("w", ctypes.c_int), ("cout", ctypes.c_int),
                 ("gout", ctypes.c_void_p), ("gout_ld", ctypes.c_int), ("w_dgrad", ctypes.c_void_p), ("ndst", ctypes.c_int),
                 ("dst", PwsDst * 4), ("ws", ctypes.c_void_p), ("ws_bytes", ctypes.c_size_t), ("math", ctypes.c_int),
-                ("w_dgrad_bf16", ctypes.c_void_p)]
+                ("w_dgrad_bf16", ctypes.c_void_p), ("store", ctypes.c_int)]
 
 
 class PwsConvBwdWeightArgs(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("n", ctypes.c_int), ("h", ctypes.c_int), ("w", ctypes.c_int), ("nsrc", ctypes.c_int),
                 ("src", PwsSrc * 4), ("src_nchw", ctypes.c_int), ("cout", ctypes.c_int), ("gout", ctypes.c_void_p),
-                ("gout_ld", ctypes.c_int), ("dw_packed", ctypes.c_void_p), ("math", ctypes.c_int)]
+                ("gout_ld", ctypes.c_int), ("dw_packed", ctypes.c_void_p), ("math", ctypes.c_int), ("store", ctypes.c_int)]
 
 
 class PwsProfRecord(ctypes.Structure):

@@ -72,7 +72,10 @@ def make_case(kname, shape, src_c, cout, tag):
     return x, wt, b, rs
 
 
-def hip_fwd(A, kname, x, wt, b, act, src_c, cout, ws_mb):
+STORE_TOL = 5e-3   # bf16 storage of the result: relative rounding 2^-9 of each value (<= 2e-3 of max|y|) on top of TIGHT
+
+
+def hip_fwd(A, kname, x, wt, b, act, src_c, cout, ws_mb, store=False):
     L, st = A.lib(), A.current_stream()
     kind = getattr(A, kname)
     n, cin, h, w = x.shape
@@ -89,11 +92,14 @@ def hip_fwd(A, kname, x, wt, b, act, src_c, cout, ws_mb):
     keep, c0 = [], 0
     for i, c in enumerate(src_c):
         t = xs[..., c0:c0 + c].contiguous().cuda()
+        if store:
+            t = t.bfloat16()
         keep.append(t)
         a.src[i].ptr, a.src[i].channels, a.src[i].ld = t.data_ptr(), c, c
         c0 += c
     oh, ow = (h, w) if "S1" in kname else (((h - 1) // 2 + 1, (w - 1) // 2 + 1) if kname == "CONV_K3S2" else (2 * h, 2 * w))
-    out = torch.full((n, oh, ow, cout), float("nan"), device="cuda")
+    out = torch.full((n, oh, ow, cout), float("nan"), device="cuda", dtype=torch.bfloat16 if store else torch.float32)
+    a.store = A.STORE_BF16 if store else A.STORE_FP32
     d_b = b.cuda()
     a.w_packed, a.bias, a.out, a.out_ld = wp.data_ptr(), d_b.data_ptr(), out.data_ptr(), cout
     a.math, a.w_bf16 = A.MATH_BF16, wb.data_ptr()
@@ -106,7 +112,19 @@ def hip_fwd(A, kname, x, wt, b, act, src_c, cout, ws_mb):
     names = [r[0] for r in A.prof_collect()]
     assert names == ["conv_bf16_kernel"], names  # the bf16 kernel really ran (no silent fp32 path)
     torch.cuda.synchronize()
-    return out.cpu()
+    return out.float().cpu()
+
+
+@pytest.mark.parametrize("kname,shape,src_c,cout", [c for c in CASES if c[3] % 2 == 0])
+def test_bf16_storage_conv_forward(hip, kname, shape, src_c, cout):
+    """PWS_STORE_BF16: sources and result are bf16 tensors (8-channel 16-byte staging loads, channel-pair dword stores)."""
+    x, wt, b, _ = make_case(kname, shape, src_c, cout, "s")
+    xr, wr = bf16r(x), bf16r(wt)
+    want = nhwc(torch_layer(kname, xr, wr, b, 1)).numpy()
+    for ws_mb in (0, 64):
+        got = hip_fwd(hip, kname, xr, wt, b, 1, src_c, cout, ws_mb, store=True).numpy()
+        assert not np.isnan(got).any()
+        assert relerr(got, want) < STORE_TOL, relerr(got, want)
 
 
 @pytest.mark.parametrize("kname,shape,src_c,cout", CASES)
@@ -125,8 +143,9 @@ def test_bf16_conv_forward(hip, kname, shape, src_c, cout, act):
     assert relerr(got, want_fp32) < STATED, relerr(got, want_fp32)
 
 
+@pytest.mark.parametrize("store", [False, True])
 @pytest.mark.parametrize("kname,shape,src_c,cout", [c for c in CASES if c[3] % 32 == 0 and c[0] != "CONV_K5S1"])
-def test_bf16_conv_data_gradient(hip, kname, shape, src_c, cout):
+def test_bf16_conv_data_gradient(hip, kname, shape, src_c, cout, store):
     A = hip
     L, st = A.lib(), A.current_stream()
     kind = getattr(A, kname)
@@ -140,6 +159,8 @@ def test_bf16_conv_data_gradient(hip, kname, shape, src_c, cout):
     y.backward(dy)
     ref = nhwc(xg.grad).numpy()
     d_dy = nhwc(dy).cuda()
+    if store:
+        d_dy = d_dy.bfloat16()
     wdg = torch.empty(L.pws_packed_dgrad_floats(kind, cin, cout), device="cuda")
     d_w = wt.cuda()
     A.check(L.pws_pack_conv_weight_dgrad(A.ptr(d_w), A.ptr(wdg), kind, cin, cout, st), "pack_dgrad")
@@ -151,10 +172,11 @@ def test_bf16_conv_data_gradient(hip, kname, shape, src_c, cout):
         da.kind, da.n, da.h, da.w, da.cout = kind, n, h, w, cout
         da.gout, da.gout_ld, da.w_dgrad, da.ndst = d_dy.data_ptr(), cout, wdg.data_ptr(), len(src_c)
         da.math, da.w_dgrad_bf16 = A.MATH_BF16, wdb.data_ptr()
+        da.store = A.STORE_BF16 if store else A.STORE_FP32
         outs = []
         for i, c in enumerate(src_c):
             acc = 1 if i == 1 else 0
-            o = torch.full((n, h, w, c), 0.5 if acc else float("nan"), device="cuda")
+            o = torch.full((n, h, w, c), 0.5 if acc else float("nan"), device="cuda", dtype=torch.bfloat16 if store else torch.float32)
             outs.append(o)
             da.dst[i].ptr, da.dst[i].channels, da.dst[i].ld, da.dst[i].accumulate = o.data_ptr(), c, c, acc
         if ws_mb:
@@ -167,10 +189,10 @@ def test_bf16_conv_data_gradient(hip, kname, shape, src_c, cout):
         torch.cuda.synchronize()
         c0 = 0
         for i, c in enumerate(src_c):
-            got = outs[i].cpu().numpy() - (0.5 if i == 1 else 0.0)
+            got = outs[i].float().cpu().numpy() - (0.5 if i == 1 else 0.0)
             assert not np.isnan(got).any()
             err = np.abs(got - ref[..., c0:c0 + c]).max() / np.abs(ref).max()
-            assert err < TIGHT, err
+            assert err < (2 * STORE_TOL if store else TIGHT), err   # accumulation into 0.5 rounds once more in bf16
             c0 += c
 
 
