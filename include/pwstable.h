@@ -61,6 +61,9 @@ const char *pws_last_error(void); /* thread-local, never NULL */
 #define PWS_MATH_BF16 1
 /* Element type of activations / gradients in HBM for the bf16 path (per call: the `store` fields; whole generator:
  * PWS_OPT_STORE, default PWS_STORE_FP32).  PWS_STORE_BF16 needs PWS_MATH_BF16. */
+/* Whole generator (pws_netg_forward / _backward): with PWS_OPT_MATH = BF16 and PWS_OPT_STORE = BF16 (and ngf % 32 == 0) every
+ * activation and activation gradient inside the arena is bf16; inputs, fields, thetas, weights and weight gradients stay fp32.
+ * The arena size does not depend on the option (the bf16 tensors use half of their slots). */
 #define PWS_OPT_STORE 3
 #define PWS_STORE_FP32 0
 #define PWS_STORE_BF16 1
@@ -109,6 +112,12 @@ int pws_pack_weight_bf16(const float *w_packed, void *w_bf16, int planes, int kr
 /* NCHW fp32 [n,c,h,w] -> NHWC fp32 [n,h,w,cpad], channels c..cpad-1 zero (cpad a multiple of 4, c <= cpad <= 32): the bf16
  * first layer reads the 31-channel window (main_new.py:650) as a 32-channel NHWC source. */
 int pws_nchw_to_nhwc_pad(const float *x, float *out, int n, int c, int h, int w, int cpad, pws_stream_t stream);
+/* ..._s variants: `store` = PWS_STORE_FP32 | PWS_STORE_BF16 selects the element type of the NHWC activation / gradient
+ * tensors (`out` here; x / dx of the heads; dy / y of pws_act_bwd_bias_s), everything else is unchanged and fp32. */
+int pws_nchw_to_nhwc_pad_s(const float *x, float *out, int n, int c, int h, int w, int cpad, int store, pws_stream_t stream);
+/* dst[i] = float(src[i]) for `count` bf16 values; dst (bf16, `count` even) = or += bf16(src[i]). */
+int pws_cvt_bf16_to_f32(const void *src, float *dst, size_t count, pws_stream_t stream);
+int pws_cvt_f32_to_bf16(const float *src, void *dst, size_t count, int accumulate, pws_stream_t stream);
 
 /* One NHWC source of a (virtually concatenated) conv input: `channels` channels starting at `ptr`,
  * consecutive pixels `ld` floats apart.  ptr 16-byte aligned, ld % 4 == 0, channels % 16 == 0. */
@@ -157,6 +166,7 @@ int pws_conv2d_fwd(const pws_conv_args *args, pws_stream_t stream);
 /* dy[i] *= act'(y[i]) (LeakyReLU(0.2): y>0 ? 1 : 0.2 ; ReLU: y>0 ? 1 : 0 ; NONE: 1); dbias[c] += sum over pixels.
  * dy, y: dense NHWC [pixels][c]; dbias (nullable): c floats, ACCUMULATED (fp32 atomics, one per workgroup and channel). */
 int pws_act_bwd_bias(float *dy, const float *y, size_t pixels, int c, int act, float *dbias, pws_stream_t stream);
+int pws_act_bwd_bias_s(float *dy, const float *y, size_t pixels, int c, int act, float *dbias, int store, pws_stream_t stream);
 
 /* Weights re-laid-out for the data-gradient convolution of a layer.  kind in {K3S1, K3S2, CONVT_K3S1, CONVT_K4S2}. */
 size_t pws_packed_dgrad_floats(int kind, int cin, int cout);
@@ -228,12 +238,19 @@ int pws_field_head_fwd(const float *x, int ld, int n, int h, int w, int c, const
                        const float *b_out, const float *theta, int align_corners, float *resid, float *grid,
                        pws_stream_t stream);
 
+int pws_field_head_fwd_s(const float *x, int ld, int n, int h, int w, int c, const float *w_out, const float *b_out,
+                         const float *theta, int align_corners, float *resid, float *grid, int store, pws_stream_t stream);
+
 /* Backward of pws_field_head_fwd.  resid: the forward's residual output; g_grid / g_resid (either nullable): gradients
  * wrt the two outputs.  dx (nullable) [n,h,w,c] overwritten or accumulated; dw_out (packed [9][c][2]) and db_out[2]
  * ACCUMULATED (atomics); dtheta (nullable) [n,6] overwritten; ws: n*h*w*2 floats. */
 int pws_field_head_bwd(const float *x, int ld, int n, int h, int w, int c, const float *w_out, const float *resid,
                        const float *g_grid, const float *g_resid, int align_corners, float *dx, int dx_ld,
                        int dx_accumulate, float *dw_out, float *db_out, float *dtheta, float *ws, pws_stream_t stream);
+
+int pws_field_head_bwd_s(const float *x, int ld, int n, int h, int w, int c, const float *w_out, const float *resid,
+                         const float *g_grid, const float *g_resid, int align_corners, float *dx, int dx_ld, int dx_accumulate,
+                         float *dw_out, float *db_out, float *dtheta, float *ws, int store, pws_stream_t stream);
 
 /* F.affine_grid(theta[n,2,3], (n,*,h,w)) -> grid[n,h,w,2] */
 int pws_affine_grid(const float *theta, float *grid, int n, int h, int w, int align_corners,

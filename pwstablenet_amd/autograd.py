@@ -44,7 +44,7 @@ class _NetGTrain(torch.autograd.Function):
         st = A.current_stream()
         packed, packed_dg = sv["packed"], net.packed_dgrad_weights()
         dpacked = torch.empty_like(packed)
-        A.check(L.pws_set_option(A.OPT_MATH, A.MATH_BF16 if sv.get("math") == "bf16" else A.MATH_FP32), "pws_set_option")
+        net._apply_math(sv.get("math", "fp32"), sv.get("store", "fp32"))  # the arena holds what the forward's mode wrote
         A.check(L.pws_netg_backward(A.ptr(packed), A.ptr(packed_dg), A.ptr(sv["x"]), n, net.input_nc, net.ngf, 0,
                                     ctypes.c_void_p(sv["ws_ptr"]), sv["ws_bytes"], A.ptr(sv["resid"]), A.ptr(sv["thetas"]),
                                     A.ptr(g_grids), A.ptr(g_resid), A.ptr(dpacked), st), "pws_netg_backward")

@@ -6,6 +6,7 @@
 namespace pws {
 bool g_two_queues = true;
 int g_math = PWS_MATH_FP32;
+int g_store = PWS_STORE_FP32;
 bool g_prof_on = false;
 int g_prof_tag = -1;
 namespace {
@@ -120,6 +121,14 @@ extern "C" int pws_set_option(int key, int value) {
         pws::g_math = value;
         return PWS_OK;
     }
+    if (key == PWS_OPT_STORE) {
+        if (value != PWS_STORE_FP32 && value != PWS_STORE_BF16) {
+            pws::set_error("pws_set_option: PWS_OPT_STORE value %d is not PWS_STORE_FP32 / PWS_STORE_BF16", value);
+            return PWS_EINVAL;
+        }
+        pws::g_store = value;
+        return PWS_OK;
+    }
     pws::set_error("pws_set_option: unknown key %d", key);
     return PWS_EINVAL;
 }
@@ -127,6 +136,7 @@ extern "C" int pws_set_option(int key, int value) {
 extern "C" int pws_get_option(int key) {
     if (key == PWS_OPT_TWO_QUEUES) return pws::g_two_queues ? 1 : 0;
     if (key == PWS_OPT_MATH) return pws::g_math;
+    if (key == PWS_OPT_STORE) return pws::g_store;
     pws::set_error("pws_get_option: unknown key %d", key);
     return PWS_EINVAL;
 }

@@ -51,6 +51,7 @@ enum KernelId {
 };
 extern bool g_two_queues;
 extern int g_math;  // PWS_OPT_MATH
+extern int g_store;  // PWS_OPT_STORE (effective only with PWS_MATH_BF16)
 extern bool g_prof_on;
 extern int g_prof_tag;
 void prof_begin(int kernel_id, double flops, double bytes, hipStream_t st);
@@ -80,6 +81,26 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // two floats -> two bf16 (round to nearest even) in one dword: v_cvt_pk_bf16_f32
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
+}
+
+// 4 consecutive elements of an fp32 or bf16 (IO16) tensor; `idx` counts elements and is a multiple of 4
+template <bool IO16>
+__device__ __forceinline__ float4 ld4(const float *base, size_t idx) {
+    if constexpr (IO16) {
+        const uint2 u = *reinterpret_cast<const uint2 *>(reinterpret_cast<const __bf16 *>(base) + idx);
+        return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                           __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+    } else {
+        return *reinterpret_cast<const float4 *>(base + idx);
+    }
+}
+template <bool IO16>
+__device__ __forceinline__ void st4(float *base, size_t idx, const float4 &v) {
+    if constexpr (IO16) {
+        *reinterpret_cast<uint2 *>(reinterpret_cast<__bf16 *>(base) + idx) = make_uint2(cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w));
+    } else {
+        *reinterpret_cast<float4 *>(base + idx) = v;
+    }
 }
 
 __device__ __forceinline__ float act_apply(float v, int act) {

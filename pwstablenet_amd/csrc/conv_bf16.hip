@@ -407,6 +407,7 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_k5_kernel(const ConvK
 
 // NCHW fp32 [n][c][hw] -> NHWC fp32 [n][hw][cpad] with zero padding channels (cpad <= 32, a multiple of 4): 64 pixels per
 // workgroup through LDS so that both sides are coalesced.
+template <bool IO16>
 __global__ void __launch_bounds__(256) nchw_to_nhwc_pad_kernel(const float *__restrict__ x, float *__restrict__ out, int c, int cpad,
                                                               size_t hw) {
     __shared__ float t[32][65];
@@ -418,11 +419,36 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_pad_kernel(const float *__re
         t[ch][px] = (ch < c && p0 + px < hw) ? xn[(size_t)ch * hw + p0 + px] : 0.f;
     }
     __syncthreads();
-    float *on = out + ((size_t)n * hw + p0) * cpad;
-    for (int i = threadIdx.x; i < 64 * cpad; i += 256) {
-        const int px = i / cpad, ch = i % cpad;
-        if (p0 + px < hw) on[i] = t[ch][px];
+    if constexpr (IO16) {
+        unsigned *on = reinterpret_cast<unsigned *>(reinterpret_cast<__bf16 *>(out) + ((size_t)n * hw + p0) * cpad);
+        for (int i = threadIdx.x; i < 64 * cpad / 2; i += 256) {
+            const int px = i / (cpad / 2), ch = (i % (cpad / 2)) * 2;
+            if (p0 + px < hw) on[i] = cvt_pk_bf16(t[ch][px], t[ch + 1][px]);
+        }
+    } else {
+        float *on = out + ((size_t)n * hw + p0) * cpad;
+        for (int i = threadIdx.x; i < 64 * cpad; i += 256) {
+            const int px = i / cpad, ch = i % cpad;
+            if (p0 + px < hw) on[i] = t[ch][px];
+        }
     }
+}
+
+// fp32 <-> bf16 copies of small tensors (the theta head's 2x2x4ngf input and its gradient under bf16 storage)
+__global__ void __launch_bounds__(256) cvt_bf16_to_f32_kernel(const unsigned short *__restrict__ src, float *__restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = __builtin_bit_cast(float, (unsigned)src[i] << 16);
+}
+__global__ void __launch_bounds__(256) cvt_f32_to_bf16_kernel(const float *__restrict__ src, unsigned *__restrict__ dst, size_t npairs,
+                                                             int accumulate) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npairs) return;
+    float a = src[2 * i], b = src[2 * i + 1];
+    if (accumulate) {
+        const unsigned o = dst[i];
+        a += bf16_lo(o), b += bf16_hi(o);
+    }
+    dst[i] = cvt_pk_bf16(a, b);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -592,12 +618,36 @@ __global__ void pack_bf16_kernel(const float *__restrict__ w, unsigned *__restri
 }  // namespace pws
 
 extern "C" int pws_nchw_to_nhwc_pad(const float *x, float *out, int n, int c, int h, int w, int cpad, pws_stream_t stream) {
+    return pws_nchw_to_nhwc_pad_s(x, out, n, c, h, w, cpad, PWS_STORE_FP32, stream);
+}
+
+extern "C" int pws_cvt_bf16_to_f32(const void *src, float *dst, size_t count, pws_stream_t stream) {
+    PWS_REQUIRE(count == 0 || (src && dst), "pws_cvt_bf16_to_f32: NULL pointer");
+    if (count == 0) return PWS_OK;
+    hipLaunchKernelGGL(pws::cvt_bf16_to_f32_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, pws::as_stream(stream),
+                       static_cast<const unsigned short *>(src), dst, count);
+    return pws::check_launch("cvt_bf16_to_f32_kernel");
+}
+
+extern "C" int pws_cvt_f32_to_bf16(const float *src, void *dst, size_t count, int accumulate, pws_stream_t stream) {
+    PWS_REQUIRE(count % 2 == 0 && (count == 0 || (src && dst)), "pws_cvt_f32_to_bf16: count must be even, pointers non-NULL");
+    if (count == 0) return PWS_OK;
+    hipLaunchKernelGGL(pws::cvt_f32_to_bf16_kernel, dim3((unsigned)((count / 2 + 255) / 256)), dim3(256), 0, pws::as_stream(stream), src,
+                       static_cast<unsigned *>(dst), count / 2, accumulate);
+    return pws::check_launch("cvt_f32_to_bf16_kernel");
+}
+
+extern "C" int pws_nchw_to_nhwc_pad_s(const float *x, float *out, int n, int c, int h, int w, int cpad, int store, pws_stream_t stream) {
     PWS_REQUIRE(x && out && n >= 0 && c > 0 && h > 0 && w > 0, "pws_nchw_to_nhwc_pad: bad arguments");
     PWS_REQUIRE(cpad >= c && cpad <= 32 && cpad % 4 == 0, "pws_nchw_to_nhwc_pad: cpad %d must be a multiple of 4 in [c, 32]", cpad);
     if (n == 0) return PWS_OK;
     const size_t hw = (size_t)h * w;
-    hipLaunchKernelGGL(pws::nchw_to_nhwc_pad_kernel, dim3((unsigned)((hw + 63) / 64), (unsigned)n), dim3(256), 0, pws::as_stream(stream),
-                       x, out, c, cpad, hw);
+    if (store == PWS_STORE_BF16)
+        hipLaunchKernelGGL(pws::nchw_to_nhwc_pad_kernel<true>, dim3((unsigned)((hw + 63) / 64), (unsigned)n), dim3(256), 0,
+                           pws::as_stream(stream), x, out, c, cpad, hw);
+    else
+        hipLaunchKernelGGL(pws::nchw_to_nhwc_pad_kernel<false>, dim3((unsigned)((hw + 63) / 64), (unsigned)n), dim3(256), 0,
+                           pws::as_stream(stream), x, out, c, cpad, hw);
     return pws::check_launch("nchw_to_nhwc_pad_kernel");
 }
 

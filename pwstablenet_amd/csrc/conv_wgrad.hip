@@ -282,6 +282,7 @@ int conv2d_bwd_weight_impl(const pws_conv_bwd_weight_args *a, hipStream_t st) {
         const int rc = wgrad_bf16_launch(a, st);  // 1: not covered by the bf16 kernel (first layer, odd channel counts)
         if (rc != 1) return rc;
     }
+    PWS_REQUIRE(a->store != PWS_STORE_BF16, "pws_conv2d_bwd_weight: bf16 storage needs bf16 math and a layer the bf16 kernel covers");
     WgradParams p{};
     p.nsrc = a->nsrc;
     int cin = 0;
@@ -341,6 +342,7 @@ int conv2d_bwd_weight_impl(const pws_conv_bwd_weight_args *a, hipStream_t st) {
 // workgroup (at most 512 workgroups: all of them hit the same c words).
 constexpr int ABB_PIX = 256;
 
+template <bool IO16>
 __global__ void __launch_bounds__(256) act_bwd_bias_kernel(float *__restrict__ dy, const float *__restrict__ y, size_t pixels,
                                                            int c, int act, float *__restrict__ dbias) {
     extern __shared__ float sred[];  // 256 x 4 floats
@@ -364,8 +366,8 @@ __global__ void __launch_bounds__(256) act_bwd_bias_kernel(float *__restrict__ d
                     const size_t p = pb + u * step;
                     ok[u] = p < pixels;
                     const size_t e = (ok[u] ? p : pb) * c4n + q;
-                    g[u] = reinterpret_cast<float4 *>(dy)[e];
-                    v[u] = reinterpret_cast<const float4 *>(y)[e];
+                    g[u] = ld4<IO16>(dy, e * 4);
+                    v[u] = ld4<IO16>(y, e * 4);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -379,7 +381,7 @@ __global__ void __launch_bounds__(256) act_bwd_bias_kernel(float *__restrict__ d
                         gg.x = vv.x > 0.f ? gg.x : 0.f, gg.y = vv.y > 0.f ? gg.y : 0.f, gg.z = vv.z > 0.f ? gg.z : 0.f,
                         gg.w = vv.w > 0.f ? gg.w : 0.f;
                     }
-                    if (act != PWS_ACT_NONE) reinterpret_cast<float4 *>(dy)[(pb + u * step) * c4n + q] = gg;
+                    if (act != PWS_ACT_NONE) st4<IO16>(dy, ((pb + u * step) * c4n + q) * 4, gg);
                     s.x += gg.x, s.y += gg.y, s.z += gg.z, s.w += gg.w;
                 }
             }
@@ -408,16 +410,26 @@ extern "C" int pws_conv2d_bwd_weight(const pws_conv_bwd_weight_args *args, pws_s
 }
 
 extern "C" int pws_act_bwd_bias(float *dy, const float *y, size_t pixels, int c, int act, float *dbias, pws_stream_t stream) {
+    return pws_act_bwd_bias_s(dy, y, pixels, c, act, dbias, PWS_STORE_FP32, stream);
+}
+
+extern "C" int pws_act_bwd_bias_s(float *dy, const float *y, size_t pixels, int c, int act, float *dbias, int store,
+                                  pws_stream_t stream) {
     PWS_REQUIRE(c > 0 && c % 4 == 0, "pws_act_bwd_bias: c=%d must be a positive multiple of 4", c);
     PWS_REQUIRE(act >= PWS_ACT_NONE && act <= PWS_ACT_RELU, "pws_act_bwd_bias: bad act %d", act);
     if (pixels == 0) return PWS_OK;
     PWS_REQUIRE(dy && y && ((reinterpret_cast<size_t>(dy) | reinterpret_cast<size_t>(y)) & 15) == 0,
                 "pws_act_bwd_bias: NULL or unaligned pointer");
     if (act == PWS_ACT_NONE && !dbias) return PWS_OK;
-    pws::ProfScope prof(pws::KID_ACT_BWD, 2.0 * pixels * c, 12.0 * pixels * c, pws::as_stream(stream));
+    const bool io16 = store == PWS_STORE_BF16;
+    pws::ProfScope prof(pws::KID_ACT_BWD, 2.0 * pixels * c, (io16 ? 6.0 : 12.0) * pixels * c, pws::as_stream(stream));
     size_t blocks = (pixels + pws::ABB_PIX - 1) / pws::ABB_PIX;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(pws::act_bwd_bias_kernel, dim3((unsigned)blocks), dim3(256), sizeof(float) * 256 * 4,
-                       pws::as_stream(stream), dy, y, pixels, c, act, dbias);
+    if (io16)
+        hipLaunchKernelGGL(pws::act_bwd_bias_kernel<true>, dim3((unsigned)blocks), dim3(256), sizeof(float) * 256 * 4,
+                           pws::as_stream(stream), dy, y, pixels, c, act, dbias);
+    else
+        hipLaunchKernelGGL(pws::act_bwd_bias_kernel<false>, dim3((unsigned)blocks), dim3(256), sizeof(float) * 256 * 4,
+                           pws::as_stream(stream), dy, y, pixels, c, act, dbias);
     return pws::check_launch("act_bwd_bias_kernel");
 }

@@ -81,6 +81,7 @@ __global__ void __launch_bounds__(256) theta_final_kernel(const float *__restric
 // 16x16 output pixels per workgroup, one lane per pixel, channels staged through LDS CH at a time.
 constexpr int FH_T = 16, FH_I = FH_T + 2, FH_CH = 32, FH_LDP = FH_CH + 4;
 
+template <bool IO16>
 __global__ void __launch_bounds__(256) field_head_kernel(const float *__restrict__ x, int ld, int N, int H, int W, int C,
                                                          const float *__restrict__ w_out, const float *__restrict__ b_out,
                                                          const float *__restrict__ theta, int ac, float *__restrict__ resid,
@@ -102,8 +103,7 @@ __global__ void __launch_bounds__(256) field_head_kernel(const float *__restrict
             const int ly = pix / FH_I, lx = pix % FH_I;
             const int iy = y0 - 1 + ly, ix = x0 - 1 + lx;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-                v = *reinterpret_cast<const float4 *>(x + ((size_t)(n * H + iy) * W + ix) * ld + c0 + c4 * 4);
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ld4<IO16>(x, ((size_t)(n * H + iy) * W + ix) * ld + c0 + c4 * 4);
             *reinterpret_cast<float4 *>(s_in + pix * FH_LDP + c4 * 4) = v;
         }
         for (int item = tid; item < 9 * ch * 2; item += 256) {
@@ -183,6 +183,12 @@ extern "C" int pws_theta_head_fwd_save(const float *x, int n, int c, int hidden,
 
 extern "C" int pws_field_head_fwd(const float *x, int ld, int n, int h, int w, int c, const float *w_out, const float *b_out,
                                   const float *theta, int align_corners, float *resid, float *grid, pws_stream_t stream) {
+    return pws_field_head_fwd_s(x, ld, n, h, w, c, w_out, b_out, theta, align_corners, resid, grid, PWS_STORE_FP32, stream);
+}
+
+extern "C" int pws_field_head_fwd_s(const float *x, int ld, int n, int h, int w, int c, const float *w_out, const float *b_out,
+                                    const float *theta, int align_corners, float *resid, float *grid, int store,
+                                    pws_stream_t stream) {
     PWS_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0, "pws_field_head_fwd: bad shape");
     if (n == 0) return PWS_OK;
     PWS_REQUIRE(x && w_out && (resid || grid), "pws_field_head_fwd: NULL pointer");
@@ -193,7 +199,11 @@ extern "C" int pws_field_head_fwd(const float *x, int ld, int n, int h, int w, i
     const unsigned ntiles = (unsigned)tiles_x * tiles_y * n;
     ProfScope prof(KID_FIELD_HEAD, 2.0 * n * h * w * 18.0 * c,
                    (double)n * h * w * (4.0 * c + (resid ? 8.0 : 0.0) + (grid ? 8.0 : 0.0)), as_stream(stream));
-    hipLaunchKernelGGL(field_head_kernel, dim3(ntiles), dim3(256), 0, as_stream(stream), x, ld, n, h, w, c, w_out, b_out, theta,
-                       align_corners, resid, grid, tiles_x, tiles_y, ntiles);
+    if (store == PWS_STORE_BF16)
+        hipLaunchKernelGGL(field_head_kernel<true>, dim3(ntiles), dim3(256), 0, as_stream(stream), x, ld, n, h, w, c, w_out, b_out,
+                           theta, align_corners, resid, grid, tiles_x, tiles_y, ntiles);
+    else
+        hipLaunchKernelGGL(field_head_kernel<false>, dim3(ntiles), dim3(256), 0, as_stream(stream), x, ld, n, h, w, c, w_out, b_out,
+                           theta, align_corners, resid, grid, tiles_x, tiles_y, ntiles);
     return check_launch("field_head_kernel");
 }

@@ -63,6 +63,7 @@ __global__ void __launch_bounds__(256) field_gz_kernel(const float *__restrict__
 }
 
 // ---- K2: dx.  One lane = (pixel, 4 channels); weights in LDS.
+template <bool IO16>
 __global__ void __launch_bounds__(256) field_dx_kernel(const float *__restrict__ gz, const float *__restrict__ w_out, int N,
                                                        int H, int W, int C, float *__restrict__ dx, int dx_ld, int accumulate) {
     extern __shared__ float sw[];  // [9][C][2]
@@ -86,17 +87,17 @@ __global__ void __launch_bounds__(256) field_dx_kernel(const float *__restrict__
         a.x += g.x * wp[0] + g.y * wp[1], a.y += g.x * wp[2] + g.y * wp[3];
         a.z += g.x * wp[4] + g.y * wp[5], a.w += g.x * wp[6] + g.y * wp[7];
     }
-    float4 *d = reinterpret_cast<float4 *>(dx + pix * dx_ld + c);
     if (accumulate) {
-        const float4 o = *d;
+        const float4 o = ld4<IO16>(dx, pix * dx_ld + c);
         a.x += o.x, a.y += o.y, a.z += o.z, a.w += o.w;
     }
-    *d = a;
+    st4<IO16>(dx, pix * dx_ld + c, a);
 }
 
 // ---- K3: dW_out.  Workgroup = 16x16 pixel tile x 32 channels; lane = (channel, pixel-row group).
 constexpr int FB_T = 16, FB_I = FB_T + 2, FB_CH = 32, FB_LDP = FB_CH + 1;
 
+template <bool IO16>
 __global__ void __launch_bounds__(256) field_dw_kernel(const float *__restrict__ x, int ld, const float *__restrict__ gz, int N,
                                                        int H, int W, int C, float *__restrict__ dw, int tiles_x, int tiles_y,
                                                        int ntiles) {
@@ -119,8 +120,7 @@ __global__ void __launch_bounds__(256) field_dw_kernel(const float *__restrict__
             const int pix = item / (FB_CH / 4), c4 = (item % (FB_CH / 4)) * 4;
             const int iy = y0 - 1 + pix / FB_I, ix = x0 - 1 + pix % FB_I;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W && c0 + c4 < C)
-                v = *reinterpret_cast<const float4 *>(x + ((size_t)(n * H + iy) * W + ix) * ld + c0 + c4);
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W && c0 + c4 < C) v = ld4<IO16>(x, ((size_t)(n * H + iy) * W + ix) * ld + c0 + c4);
             float *d = s_in + pix * FB_LDP + c4;
             d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
         }
@@ -215,6 +215,15 @@ using namespace pws;
 extern "C" int pws_field_head_bwd(const float *x, int ld, int n, int h, int w, int c, const float *w_out, const float *resid,
                                   const float *g_grid, const float *g_resid, int align_corners, float *dx, int dx_ld,
                                   int dx_accumulate, float *dw_out, float *db_out, float *dtheta, float *ws, pws_stream_t stream) {
+    return pws_field_head_bwd_s(x, ld, n, h, w, c, w_out, resid, g_grid, g_resid, align_corners, dx, dx_ld, dx_accumulate, dw_out,
+                                db_out, dtheta, ws, PWS_STORE_FP32, stream);
+}
+
+extern "C" int pws_field_head_bwd_s(const float *x, int ld, int n, int h, int w, int c, const float *w_out, const float *resid,
+                                    const float *g_grid, const float *g_resid, int align_corners, float *dx, int dx_ld,
+                                    int dx_accumulate, float *dw_out, float *db_out, float *dtheta, float *ws, int store,
+                                    pws_stream_t stream) {
+    const bool io16 = store == PWS_STORE_BF16;
     PWS_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "pws_field_head_bwd: bad shape");
     if (n == 0) return PWS_OK;
     PWS_REQUIRE(x && w_out && resid && (g_grid || g_resid) && ws, "pws_field_head_bwd: NULL pointer");
@@ -233,16 +242,24 @@ extern "C" int pws_field_head_bwd(const float *x, int ld, int n, int h, int w, i
                        align_corners, ws, db_out, dtheta);
     if (dx) {
         const size_t items = total * (c / 4);
-        hipLaunchKernelGGL(field_dx_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), sizeof(float) * 18 * c, st, ws, w_out, n, h,
-                           w, c, dx, dx_ld, dx_accumulate);
+        if (io16)
+            hipLaunchKernelGGL(field_dx_kernel<true>, dim3((unsigned)((items + 255) / 256)), dim3(256), sizeof(float) * 18 * c, st, ws,
+                               w_out, n, h, w, c, dx, dx_ld, dx_accumulate);
+        else
+            hipLaunchKernelGGL(field_dx_kernel<false>, dim3((unsigned)((items + 255) / 256)), dim3(256), sizeof(float) * 18 * c, st, ws,
+                               w_out, n, h, w, c, dx, dx_ld, dx_accumulate);
     }
     if (dw_out) {
         const int tiles_x = (w + FB_T - 1) / FB_T, tiles_y = (h + FB_T - 1) / FB_T;
         const int ntiles = tiles_x * tiles_y * n, cblocks = (c + FB_CH - 1) / FB_CH;
         int gx = (1024 + cblocks - 1) / cblocks;  // ~4 workgroups per CU in total; each walks ntiles / gx tiles
         if (gx > ntiles) gx = ntiles;
-        hipLaunchKernelGGL(field_dw_kernel, dim3((unsigned)gx, (unsigned)cblocks), dim3(256), 0, st, x, ld, ws, n, h, w, c, dw_out,
-                           tiles_x, tiles_y, ntiles);
+        if (io16)
+            hipLaunchKernelGGL(field_dw_kernel<true>, dim3((unsigned)gx, (unsigned)cblocks), dim3(256), 0, st, x, ld, ws, n, h, w, c,
+                               dw_out, tiles_x, tiles_y, ntiles);
+        else
+            hipLaunchKernelGGL(field_dw_kernel<false>, dim3((unsigned)gx, (unsigned)cblocks), dim3(256), 0, st, x, ld, ws, n, h, w, c,
+                               dw_out, tiles_x, tiles_y, ntiles);
     }
     return check_launch("field_head_bwd kernels");
 }

@@ -177,6 +177,8 @@ class Exec {
     Exec(const float *packed, const std::vector<Layer> &layers, int n, char *ws, size_t ws_bytes, hipStream_t st, bool dry,
          bool launch)
         : packed_(packed), L_(layers), n_(n), ws_(ws), cap_(ws_bytes), dry_(dry), launch_(launch && !dry) {
+        // bf16 storage of activations: only with bf16 math and when every conv layer is covered by the bf16 kernels
+        io16_ = g_math == PWS_MATH_BF16 && g_store == PWS_STORE_BF16 && layers[L_DOWN1].cin % 32 == 0;
         streams_[0] = st, streams_[1] = st;
         if (launch_ && g_two_queues && g_side.init()) streams_[1] = g_side.stream, g_side.next = 0;
     }
@@ -206,6 +208,9 @@ class Exec {
     const std::vector<Op> &tape() const { return tape_; }
     float *splitk_ws() const { return splitk_ws_; }
     float *x_nhwc() const { return x_nhwc_; }
+    bool io16() const { return io16_; }
+    int store() const { return io16_ ? PWS_STORE_BF16 : PWS_STORE_FP32; }
+    float *theta_x32(int q) const { return theta_x32_[q]; }
     size_t splitk_bytes() const { return splitk_bytes_; }
     float *h_saved(int stage) const { return h_saved_[stage]; }
 
@@ -244,7 +249,7 @@ class Exec {
         a.kind = l.kind, a.n = n_, a.h = x.h, a.w = x.w;
         if (nchw_c > 0 && g_math == PWS_MATH_BF16 && l.wb_off != (size_t)-1 && x_nhwc_ && nchw_c <= 32) {
             // bf16 first layer: the NCHW window is re-laid once as a 32-channel NHWC source (kept for the weight gradient)
-            rc_ = pws_nchw_to_nhwc_pad(nchw_src, x_nhwc_, n_, nchw_c, x.h, x.w, 32, streams_[q_]);
+            rc_ = pws_nchw_to_nhwc_pad_s(nchw_src, x_nhwc_, n_, nchw_c, x.h, x.w, 32, store(), streams_[q_]);
             if (rc_ != PWS_OK) return o;
             a.nsrc = 1, a.src[0] = pws_src{x_nhwc_, 32, 32};
         } else if (nchw_c > 0) {
@@ -258,6 +263,7 @@ class Exec {
         a.out = o.seg[0].ptr, a.out_ld = l.cout;
         a.ws = q_ ? splitk_ws2_ : splitk_ws_, a.ws_bytes = splitk_bytes_;
         if (g_math == PWS_MATH_BF16 && l.wb_off != (size_t)-1) a.math = PWS_MATH_BF16, a.w_bf16 = packed_ + l.wb_off;
+        a.store = store();
         g_prof_tag = layer;
         rc_ = pws_conv2d_fwd(&a, streams_[q_]);
         g_prof_tag = -1;
@@ -287,7 +293,13 @@ class Exec {
         tape_.push_back(Op{OP_THETA, L_FLATTEN, 0, stage, false, x_s8, Tn{}});
         if (!launch_ || rc_ != PWS_OK) return;
         const Layer &f = L_[L_FLATTEN], &l = L_[L_LINEAR];
-        rc_ = pws_theta_head_fwd_save(x_s8.seg[0].ptr, n_, x_s8.seg[0].c, f.cout, packed_ + f.w_off, packed_ + f.b_off,
+        const float *xin = x_s8.seg[0].ptr;
+        if (io16_) {  // the head is an fp32 GEMV: its 2x2xC input is converted once (n x 4C values)
+            rc_ = pws_cvt_bf16_to_f32(xin, theta_x32_[q_], (size_t)n_ * 4 * x_s8.seg[0].c, streams_[q_]);
+            if (rc_ != PWS_OK) return;
+            xin = theta_x32_[q_];
+        }
+        rc_ = pws_theta_head_fwd_save(xin, n_, x_s8.seg[0].c, f.cout, packed_ + f.w_off, packed_ + f.b_off,
                                       packed_ + l.w_off, packed_ + l.b_off, q_ ? theta_ws2_ : theta_ws_, theta_out,
                                       h_saved_[stage], streams_[q_]);
     }
@@ -296,8 +308,8 @@ class Exec {
         tape_.push_back(Op{OP_FIELD, L_OUT, 0, stage, false, x, Tn{}});
         if (!launch_ || rc_ != PWS_OK) return;
         const Layer &o = L_[L_OUT];
-        rc_ = pws_field_head_fwd(x.seg[0].ptr, x.seg[0].ld, n_, x.h, x.w, x.seg[0].c, packed_ + o.w_off, packed_ + o.b_off,
-                                 theta_k, ac, resid, grid, streams_[q_]);
+        rc_ = pws_field_head_fwd_s(x.seg[0].ptr, x.seg[0].ld, n_, x.h, x.w, x.seg[0].c, packed_ + o.w_off, packed_ + o.b_off,
+                                   theta_k, ac, resid, grid, store(), streams_[q_]);
     }
 
     // scratch shared by all layers (launches are stream-ordered): split-K partial tiles, the theta head's partials,
@@ -311,12 +323,15 @@ class Exec {
         if (!splitk_ws_ || !splitk_ws2_) splitk_bytes_ = 0;
         for (int s = 0; s < 3; ++s) h_saved_[s] = training ? alloc((size_t)n_ * 8 * ngf) : nullptr;
         x_nhwc_ = alloc((size_t)n_ * 256 * 256 * 32);  // bf16 math: NHWC copy of the window (unused in fp32 math)
+        theta_x32_[0] = alloc((size_t)n_ * 16 * ngf), theta_x32_[1] = alloc((size_t)n_ * 16 * ngf);  // bf16 storage: fp32 copy of x_s8
     }
 
   private:
     float *splitk_ws_ = nullptr, *splitk_ws2_ = nullptr, *theta_ws_ = nullptr, *theta_ws2_ = nullptr;
     float *h_saved_[3] = {nullptr, nullptr, nullptr};
     float *x_nhwc_ = nullptr;
+    float *theta_x32_[2] = {nullptr, nullptr};
+    bool io16_ = false;
     hipStream_t streams_[2];
     int q_ = 0;
     size_t splitk_bytes_ = 0;
@@ -427,6 +442,7 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
     float *gz_ws = E.alloc((size_t)n * S * S * 2);
     float *th_bwd_ws = E.alloc((size_t)n * 8 * g);
     float *dtheta = E.alloc((size_t)3 * n * 6);
+    float *th_dx32 = E.alloc((size_t)n * 16 * g);  // bf16 storage: fp32 gradient wrt x_s8 before it is folded into the bf16 buffer
     if (used) *used = E.used();
     if (dry) return PWS_OK;
     if (E.rc() != PWS_OK) return E.rc();
@@ -448,9 +464,9 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             const Seg &xs = op.in.seg[0];
             GradBuf &gb = G[xs.ptr];
             const Layer &o = L[L_OUT];
-            rc = pws_field_head_bwd(xs.ptr, xs.ld, n, op.in.h, op.in.w, xs.c, packed + o.w_off, resid + k * gsz, gg, gr, ac, gb.g,
-                                    xs.c, gb.written ? 1 : 0, dpacked + o.w_off, dpacked + o.b_off,
-                                    gg ? dtheta + (size_t)k * n * 6 : nullptr, gz_ws, st);
+            rc = pws_field_head_bwd_s(xs.ptr, xs.ld, n, op.in.h, op.in.w, xs.c, packed + o.w_off, resid + k * gsz, gg, gr, ac, gb.g,
+                                      xs.c, gb.written ? 1 : 0, dpacked + o.w_off, dpacked + o.b_off,
+                                      gg ? dtheta + (size_t)k * n * 6 : nullptr, gz_ws, E.store(), st);
             gb.written = true;
             have_dtheta[k] = gg != nullptr;
         } else if (op.type == OP_THETA) {
@@ -459,9 +475,20 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             const Seg &xs = op.in.seg[0];
             GradBuf &gb = G[xs.ptr];
             const Layer &f = L[L_FLATTEN], &l = L[L_LINEAR];
-            rc = pws_theta_head_bwd(xs.ptr, n, xs.c, f.cout, packed + f.w_off, packed + l.w_off, E.h_saved(k),
-                                    thetas + (size_t)k * n * 6, dtheta + (size_t)k * n * 6, dpacked + f.w_off, dpacked + f.b_off,
-                                    dpacked + l.w_off, dpacked + l.b_off, gb.g, gb.written ? 1 : 0, th_bwd_ws, st);
+            if (E.io16()) {
+                // fp32 head on an fp32 copy of its bf16 input; its input gradient goes through an fp32 scratch
+                const size_t cnt = (size_t)n * 4 * xs.c;
+                rc = pws_cvt_bf16_to_f32(xs.ptr, E.theta_x32(0), cnt, st);
+                if (rc == PWS_OK)
+                    rc = pws_theta_head_bwd(E.theta_x32(0), n, xs.c, f.cout, packed + f.w_off, packed + l.w_off, E.h_saved(k),
+                                            thetas + (size_t)k * n * 6, dtheta + (size_t)k * n * 6, dpacked + f.w_off,
+                                            dpacked + f.b_off, dpacked + l.w_off, dpacked + l.b_off, th_dx32, 0, th_bwd_ws, st);
+                if (rc == PWS_OK) rc = pws_cvt_f32_to_bf16(th_dx32, gb.g, cnt, gb.written ? 1 : 0, st);
+            } else {
+                rc = pws_theta_head_bwd(xs.ptr, n, xs.c, f.cout, packed + f.w_off, packed + l.w_off, E.h_saved(k),
+                                        thetas + (size_t)k * n * 6, dtheta + (size_t)k * n * 6, dpacked + f.w_off, dpacked + f.b_off,
+                                        dpacked + l.w_off, dpacked + l.b_off, gb.g, gb.written ? 1 : 0, th_bwd_ws, st);
+            }
             gb.written = true;
         } else {
             const Layer &l = L[op.layer];
@@ -470,7 +497,7 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             if (!go.written) continue;  // nothing downstream asked for a gradient
             const size_t pixels = (size_t)n * op.out.h * op.out.w;
             g_prof_tag = op.layer;
-            rc = pws_act_bwd_bias(go.g, o.ptr, pixels, l.cout, op.act, dpacked + l.b_off, st);
+            rc = pws_act_bwd_bias_s(go.g, o.ptr, pixels, l.cout, op.act, dpacked + l.b_off, E.store(), st);
             if (rc != PWS_OK) break;
             pws_conv_bwd_weight_args wa{};
             wa.kind = l.kind, wa.n = n, wa.h = op.in.h, wa.w = op.in.w, wa.nsrc = op.in.nseg, wa.src_nchw = op.nchw ? 1 : 0;
@@ -479,7 +506,7 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             if (op.nchw && g_math == PWS_MATH_BF16 && l.wb_off != (size_t)-1 && E.x_nhwc() && input_nc <= 32)
                 wa.src_nchw = 0, wa.src[0] = pws_src{E.x_nhwc(), 32, 32};  // the forward's NHWC copy
             wa.cout = l.cout, wa.gout = go.g, wa.gout_ld = l.cout, wa.dw_packed = dpacked + l.w_off;
-            wa.math = g_math;
+            wa.math = g_math, wa.store = E.store();
             rc = pws_conv2d_bwd_weight(&wa, st);
             if (rc != PWS_OK || op.nchw) {
                 g_prof_tag = -1;
@@ -495,6 +522,7 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             }
             da.ws = E.splitk_ws(), da.ws_bytes = E.splitk_bytes();
             if (g_math == PWS_MATH_BF16 && l.dgb_off != (size_t)-1) da.math = PWS_MATH_BF16, da.w_dgrad_bf16 = packed_dgrad + l.dgb_off;
+            da.store = E.store();
             rc = pws_conv2d_bwd_data(&da, st);
             g_prof_tag = -1;
         }

@@ -32,6 +32,7 @@ struct WgradBfParams {
     const float *gout;
     int gout_ld;
     float *dw;
+    int io_bf16;     // x sources and gout hold bf16 elements
     int tiles_x, tiles_y, tiles_n;
     int ntiles;
     int ci_blocks, co_blocks;  // of 64 channels
@@ -74,7 +75,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char *lds, int off0, in
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <class C>
+template <class C, bool IO16>
 __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradBfParams p) {
     static_assert(wb_linear<C>(), "tile shape breaks the k-step address walk");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -119,6 +120,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradBfParams 
 #pragma unroll 1
             for (int it0 = 0; it0 < ITS; it0 += BATCH) {
                 f32x4 r[BATCH][2];
+                u32x4 r16[BATCH];
                 int off[BATCH];
                 bool okv[BATCH];
 #pragma unroll
@@ -131,17 +133,26 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradBfParams 
                     const bool ok = item < NIT && ch < p.cin && n < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
                     int s = 0;
                     while (s < p.nsrc - 1 && ch >= p.src_c[s]) ch -= p.src_c[s], ++s;
-                    const float *g = p.src_ptr[ok ? s : 0] + (ok ? ((size_t)(n * p.H + iy) * p.W + ix) * p.src_ld[s] + ch : 0);
-                    r[k][0] = *reinterpret_cast<const f32x4 *>(g);
-                    r[k][1] = *reinterpret_cast<const f32x4 *>(g + 4);
+                    const size_t e = ok ? ((size_t)(n * p.H + iy) * p.W + ix) * p.src_ld[s] + ch : 0;
+                    if constexpr (IO16) {
+                        r16[k] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const __bf16 *>(p.src_ptr[ok ? s : 0]) + e);
+                    } else {
+                        const float *g = p.src_ptr[ok ? s : 0] + e;
+                        r[k][0] = *reinterpret_cast<const f32x4 *>(g);
+                        r[k][1] = *reinterpret_cast<const f32x4 *>(g + 4);
+                    }
                     okv[k] = ok;
                     off[k] = item < NIT ? (c8 >> 2) * C::PIX * C::ROW + pix * C::ROW + (c8 & 3) * 16 : SINK;
                 }
 #pragma unroll
                 for (int k = 0; k < BATCH; ++k) {
                     u32x4 v;
-                    v.x = okv[k] ? cvt_pk_bf16(r[k][0].x, r[k][0].y) : 0u, v.y = okv[k] ? cvt_pk_bf16(r[k][0].z, r[k][0].w) : 0u;
-                    v.z = okv[k] ? cvt_pk_bf16(r[k][1].x, r[k][1].y) : 0u, v.w = okv[k] ? cvt_pk_bf16(r[k][1].z, r[k][1].w) : 0u;
+                    if constexpr (IO16) {
+                        v.x = okv[k] ? r16[k].x : 0u, v.y = okv[k] ? r16[k].y : 0u, v.z = okv[k] ? r16[k].z : 0u, v.w = okv[k] ? r16[k].w : 0u;
+                    } else {
+                        v.x = okv[k] ? cvt_pk_bf16(r[k][0].x, r[k][0].y) : 0u, v.y = okv[k] ? cvt_pk_bf16(r[k][0].z, r[k][0].w) : 0u;
+                        v.z = okv[k] ? cvt_pk_bf16(r[k][1].x, r[k][1].y) : 0u, v.w = okv[k] ? cvt_pk_bf16(r[k][1].z, r[k][1].w) : 0u;
+                    }
                     *reinterpret_cast<u32x4 *>(lds + off[k]) = v;
                 }
             }
@@ -152,6 +163,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradBfParams 
 #pragma unroll 1
             for (int it0 = 0; it0 < ITS; it0 += BATCH) {
                 f32x4 r[BATCH][2];
+                u32x4 r16[BATCH];
                 int off[BATCH];
                 bool okv[BATCH];
 #pragma unroll
@@ -163,17 +175,25 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradBfParams 
                     const int oy = C::SUBPIX ? 2 * y + py : y, ox = C::SUBPIX ? 2 * x + px : x;
                     const int ch = co0 + c8 * 8;
                     const bool ok = item < NIT && ch < p.cout && n < p.N && y < p.LH && x < p.LW && oy < p.OH && ox < p.OW;
-                    const float *g = p.gout + (ok ? ((size_t)(n * p.OH + oy) * p.OW + ox) * p.gout_ld + ch : 0);
-                    r[k][0] = *reinterpret_cast<const f32x4 *>(g);
-                    r[k][1] = *reinterpret_cast<const f32x4 *>(g + 4);
+                    const size_t e = ok ? ((size_t)(n * p.OH + oy) * p.OW + ox) * p.gout_ld + ch : 0;
+                    if constexpr (IO16) {
+                        r16[k] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const __bf16 *>(p.gout) + e);
+                    } else {
+                        r[k][0] = *reinterpret_cast<const f32x4 *>(p.gout + e);
+                        r[k][1] = *reinterpret_cast<const f32x4 *>(p.gout + e + 4);
+                    }
                     okv[k] = ok;
                     off[k] = item < NIT ? C::LDS_X + (c8 >> 2) * C::BM * C::ROW + m * C::ROW + (c8 & 3) * 16 : SINK;
                 }
 #pragma unroll
                 for (int k = 0; k < BATCH; ++k) {
                     u32x4 v;
-                    v.x = okv[k] ? cvt_pk_bf16(r[k][0].x, r[k][0].y) : 0u, v.y = okv[k] ? cvt_pk_bf16(r[k][0].z, r[k][0].w) : 0u;
-                    v.z = okv[k] ? cvt_pk_bf16(r[k][1].x, r[k][1].y) : 0u, v.w = okv[k] ? cvt_pk_bf16(r[k][1].z, r[k][1].w) : 0u;
+                    if constexpr (IO16) {
+                        v.x = okv[k] ? r16[k].x : 0u, v.y = okv[k] ? r16[k].y : 0u, v.z = okv[k] ? r16[k].z : 0u, v.w = okv[k] ? r16[k].w : 0u;
+                    } else {
+                        v.x = okv[k] ? cvt_pk_bf16(r[k][0].x, r[k][0].y) : 0u, v.y = okv[k] ? cvt_pk_bf16(r[k][0].z, r[k][0].w) : 0u;
+                        v.z = okv[k] ? cvt_pk_bf16(r[k][1].x, r[k][1].y) : 0u, v.w = okv[k] ? cvt_pk_bf16(r[k][1].z, r[k][1].w) : 0u;
+                    }
                     *reinterpret_cast<u32x4 *>(lds + off[k]) = v;
                 }
             }
@@ -218,8 +238,11 @@ template <class C>
 static int launch_wb(WgradBfParams &p, int nclasses, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_bf16_kernel<C>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_bf16_kernel<C, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_bf16_kernel<C, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) {
             set_error("hipFuncSetAttribute(wgrad_bf16_kernel, %d B LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
             return PWS_EHIP;
@@ -236,7 +259,10 @@ static int launch_wb(WgradBfParams &p, int nclasses, hipStream_t st) {
     if (ps > p.ntiles) ps = p.ntiles;
     if (ps < 1) ps = 1;
     dim3 grid((unsigned)ps, (unsigned)(p.ci_blocks * p.co_blocks), (unsigned)(nclasses * C::NGROUPS));
-    hipLaunchKernelGGL(wgrad_bf16_kernel<C>, grid, dim3(256), C::LDS_BYTES, st, p);
+    if (p.io_bf16)
+        hipLaunchKernelGGL((wgrad_bf16_kernel<C, true>), grid, dim3(256), C::LDS_BYTES, st, p);
+    else
+        hipLaunchKernelGGL((wgrad_bf16_kernel<C, false>), grid, dim3(256), C::LDS_BYTES, st, p);
     return check_launch("wgrad_bf16_kernel");
 }
 
@@ -288,6 +314,15 @@ int wgrad_bf16_launch(const pws_conv_bwd_weight_args *a, hipStream_t st) {
         cin += a->src[s].channels;
     }
     if (a->cout % 8 != 0) return 1;
+    p.io_bf16 = a->store == PWS_STORE_BF16;
+    if (p.io_bf16) {
+        bool ok = a->gout_ld % 8 == 0;
+        for (int s = 0; s < a->nsrc; ++s) ok = ok && a->src[s].ld % 8 == 0;
+        if (!ok) {
+            set_error("pws_conv2d_bwd_weight: bf16 storage needs ld %% 8 == 0 for every source and for gout");
+            return PWS_EINVAL;
+        }
+    }
     p.cin = cin, p.cin_pad = (cin + 15) / 16 * 16, p.cout = a->cout;
     p.N = a->n, p.H = a->h, p.W = a->w;
     p.gout = a->gout, p.gout_ld = a->gout_ld, p.dw = a->dw_packed;

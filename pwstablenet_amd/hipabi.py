@@ -65,6 +65,9 @@ SIGNATURES = {
     "pws_packed_bf16_floats": (_S, [_I, _I, _I]),
     "pws_pack_weight_bf16": (_I, [_P, _P, _I, _I, _I, _P]),
     "pws_nchw_to_nhwc_pad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "pws_nchw_to_nhwc_pad_s": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "pws_cvt_bf16_to_f32": (_I, [_P, _P, _S, _P]),
+    "pws_cvt_f32_to_bf16": (_I, [_P, _P, _S, _I, _P]),
     "pws_device_info": (_I, [ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "pws_packed_weight_floats": (_S, [_I, _I, _I]),
     "pws_pack_conv_weight": (_I, [_P, _P, _I, _I, _I, _P]),
@@ -74,6 +77,7 @@ SIGNATURES = {
     "pws_pack_conv_weight_wino_ct4": (_I, [_P, _P, _I, _I, _P]),
     "pws_conv2d_fwd": (_I, [ctypes.POINTER(PwsConvArgs), _P]),
     "pws_act_bwd_bias": (_I, [_P, _P, _S, _I, _I, _P, _P]),
+    "pws_act_bwd_bias_s": (_I, [_P, _P, _S, _I, _I, _P, _I, _P]),
     "pws_packed_dgrad_floats": (_S, [_I, _I, _I]),
     "pws_pack_conv_weight_dgrad": (_I, [_P, _P, _I, _I, _I, _P]),
     "pws_conv2d_bwd_data": (_I, [ctypes.POINTER(PwsConvBwdDataArgs), _P]),
@@ -82,6 +86,7 @@ SIGNATURES = {
     "pws_theta_head_fwd_save": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pws_theta_head_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "pws_field_head_bwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "pws_field_head_bwd_s": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P]),
     "pws_netg_packed_dgrad_floats": (_S, [_I, _I]),
     "pws_netg_pack_weights_dgrad": (_I, [ctypes.POINTER(_P), _P, _I, _I, _P]),
     "pws_netg_train_workspace_bytes": (_S, [_I, _I, _I]),
@@ -90,6 +95,7 @@ SIGNATURES = {
     "pws_theta_head_ws_floats": (_S, [_I, _I, _I]),
     "pws_theta_head_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "pws_field_head_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
+    "pws_field_head_fwd_s": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
     "pws_affine_grid": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "pws_grid_sample_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "pws_grid_sample_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -145,21 +145,31 @@ class UnetGenerator(nn.Module):
         self._ws = {}
         self._graph_mode = False
         self._graphs = {}
-        self.math = "bf16" if getattr(opt, "math", "fp32") == "bf16" else "fp32"
+        self.math, self.store = "fp32", "fp32"
+        if getattr(opt, "math", "fp32") == "bf16":
+            self.set_math("bf16")
 
-    def set_math(self, math):
-        """'fp32' (default; exact-fp32 matrix cores, the parity path) or 'bf16' (conv operands rounded to bf16 in LDS, fp32
-        accumulation on the bf16 matrix cores; master weights, activations and gradients stay fp32 -- BASELINE configs 3/4).
+    def set_math(self, math, store=None):
+        """'fp32' (default; exact-fp32 matrix cores, the parity path) or 'bf16' (BASELINE configs 3/4: conv contractions on the
+        bf16 matrix cores with fp32 accumulation; master weights, biases, fields and weight gradients stay fp32).
+        ``store``: element type of the activations / activation gradients inside the arena -- 'bf16' (default with bf16 math
+        when ngf % 32 == 0: half the HBM traffic of every layer) or 'fp32' (operands are rounded while they are staged).
         Applies to the forward and to the backward of forwards run after the call."""
         if math not in ("fp32", "bf16"):
             raise ValueError("UnetGenerator.set_math: expected 'fp32' or 'bf16', got %r" % (math,))
-        if math != self.math:
+        if store is None:
+            store = "bf16" if (math == "bf16" and self.ngf % 32 == 0) else "fp32"
+        if store not in ("fp32", "bf16") or (store == "bf16" and (math != "bf16" or self.ngf % 32 != 0)):
+            raise ValueError("UnetGenerator.set_math: store=%r needs math='bf16' and ngf %% 32 == 0" % (store,))
+        if (math, store) != (self.math, self.store):
             self._graphs = {}
-        self.math = math
+        self.math, self.store = math, store
         return self
 
-    def _apply_math(self):
-        A.check(A.lib().pws_set_option(A.OPT_MATH, A.MATH_BF16 if self.math == "bf16" else A.MATH_FP32), "pws_set_option")
+    def _apply_math(self, math=None, store=None):
+        math, store = math or self.math, store or self.store
+        A.check(A.lib().pws_set_option(A.OPT_MATH, A.MATH_BF16 if math == "bf16" else A.MATH_FP32), "pws_set_option")
+        A.check(A.lib().pws_set_option(A.OPT_STORE, A.STORE_BF16 if store == "bf16" else A.STORE_FP32), "pws_set_option")
 
     def enable_graph(self, on=True):
         """Opt-in hipGraph replay of the inference forward (``netG(x, False)`` under ``no_grad``): the ~75 launches of a
@@ -262,7 +272,7 @@ class UnetGenerator(nn.Module):
     def _run_graph(self, input1):
         x = input1.contiguous()
         self.packed_weights()
-        key = (x.shape[0], x.data_ptr(), self._packed_key, self.math)
+        key = (x.shape[0], x.data_ptr(), self._packed_key, self.math, self.store)
         ent = self._graphs.get(key)
         if ent is None:
             self._run(x, False)  # eager warm-up: one-time kernel attribute calls must not happen during capture
@@ -300,7 +310,7 @@ class UnetGenerator(nn.Module):
         self.last_thetas = thetas
         if train_ctx is not None:
             train_ctx.update(x=x, ws=ws, ws_ptr=ws_ptr, ws_bytes=ws_bytes, grids=grids, resid=resid, thetas=thetas, packed=packed,
-                             math=self.math)
+                             math=self.math, store=self.store)
         if is_training:
             return [grids[0], grids[1], grids[2]], [resid[0], resid[1], resid[2]]
         return grids[0]

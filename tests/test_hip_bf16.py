@@ -218,8 +218,9 @@ def test_bf16_falls_back_to_fp32_for_uncovered_shapes(hip):
     assert relerr(out.cpu().numpy(), want) < 1e-5
 
 
+@pytest.mark.parametrize("store", [False, True])
 @pytest.mark.parametrize("kname,shape,src_c,cout", [c for c in CASES if c[3] % 8 == 0])
-def test_bf16_conv_weight_gradient(hip, kname, shape, src_c, cout):
+def test_bf16_conv_weight_gradient(hip, kname, shape, src_c, cout, store):
     """dW from bf16-rounded x and dy (fp32 accumulation, fp32 atomics) against PyTorch-CPU autograd on the same rounded operands."""
     A = hip
     L, st = A.lib(), A.current_stream()
@@ -232,16 +233,21 @@ def test_bf16_conv_weight_gradient(hip, kname, shape, src_c, cout):
     y = (F.conv2d if kd == "conv" else F.conv_transpose2d)(xr, wg, None, stride=s_, padding=p_)
     dy = bf16r(torch.from_numpy(rs.standard_normal(tuple(y.shape)).astype(np.float32)))
     y.backward(dy)
-    xs = nhwc(x)  # unrounded: the kernel rounds while staging
+    xs = nhwc(x)  # unrounded: the kernel rounds while staging (fp32 storage) / .bfloat16() rounds the same way (bf16 storage)
     wa = A.PwsConvBwdWeightArgs()
     wa.kind, wa.n, wa.h, wa.w, wa.nsrc, wa.cout, wa.math = kind, n, h, w, len(src_c), cout, A.MATH_BF16
+    wa.store = A.STORE_BF16 if store else A.STORE_FP32
     keep, c0 = [], 0
     for i, c in enumerate(src_c):
         t = xs[..., c0:c0 + c].contiguous().cuda()
+        if store:
+            t = t.bfloat16()
         keep.append(t)
         wa.src[i].ptr, wa.src[i].channels, wa.src[i].ld = t.data_ptr(), c, c
         c0 += c
     d_dy = nhwc(dy).cuda()
+    if store:
+        d_dy = d_dy.bfloat16()
     dwp = torch.zeros(L.pws_packed_weight_floats(kind, cin, cout), device="cuda")
     wa.gout, wa.gout_ld, wa.dw_packed = d_dy.data_ptr(), cout, dwp.data_ptr()
     L.pws_prof_enable(1)
@@ -266,8 +272,9 @@ def _make_net(kind, ngf):
 FIELD_TOL = {"W1": 2e-3, "W2": 6e-2}   # measured 2.8e-4 / 1.7e-2 (W2 saturates the tanh heads: |field| up to 1.9)   # stated bf16 tolerance of the field, normalised coordinates (image = [-1, 1])
 
 
+@pytest.mark.parametrize("store", ["bf16", "fp32"])
 @pytest.mark.parametrize("kind", ["W1", "W2"])
-def test_netg_bf16_inference_vs_fp32(hip, kind):
+def test_netg_bf16_inference_vs_fp32(hip, kind, store):
     """Stage-3 field with bf16 conv math against the fp32 path (itself pinned to the reference goldens): stated tolerance,
     and the warped frame (0..255 frames / 255) through the same grid_sample."""
     from pwstablenet_amd import functional as PF
@@ -277,7 +284,7 @@ def test_netg_bf16_inference_vs_fp32(hip, kind):
     frames = torch.from_numpy(synth.make_frames(2, 3, 256, 256, seed=7)).cuda()
     with torch.no_grad():
         f32 = net(x, False).clone()
-        net.module.set_math("bf16")
+        net.module.set_math("bf16", store=store)
         hip.lib().pws_prof_enable(1)
         f16 = net(x, False).clone()
         hip.lib().pws_prof_enable(0)
@@ -291,10 +298,12 @@ def test_netg_bf16_inference_vs_fp32(hip, kind):
     w32, w16 = PF.grid_sample(frames, f32), PF.grid_sample(frames, f16)
     werr = ((w16 - w32).abs() / 255.0)
     assert werr.mean().item() < 2e-3, werr.mean().item()
-    print("bf16 %s: field max err %.3g, warped mean err %.3g max %.3g" % (kind, err, werr.mean().item(), werr.max().item()))
+    print("bf16 math / %s storage, %s: field max err %.3g, warped mean err %.3g max %.3g" % (
+        store, kind, err, werr.mean().item(), werr.max().item()))
 
 
-def test_netg_bf16_training_step_gradients_vs_fp32(hip):
+@pytest.mark.parametrize("store", ["bf16", "fp32"])
+def test_netg_bf16_training_step_gradients_vs_fp32(hip, store):
     """One training forward + backward (smooth field loss) in bf16 math: loss within 1 % of fp32, cosine similarity > 0.995 over
     all 48.5 M gradient entries, and every parameter tensor's gradient within 15 % relative L2 error of its fp32 gradient (bf16
     rounding of activations and gradients accumulates through the 30+ layers between a deep weight and the loss)."""
@@ -304,7 +313,7 @@ def test_netg_bf16_training_step_gradients_vs_fp32(hip):
     tgt = torch.from_numpy(np.random.RandomState(5).standard_normal((2, 256, 256, 2)).astype(np.float32) * 0.1).cuda()
 
     def step(math):
-        net.module.set_math(math)
+        net.module.set_math(math, store=store if math == "bf16" else None)
         net.zero_grad(set_to_none=True)
         grids, resid = net(x)
         loss = sum(((g - tgt) ** 2).mean() for g in grids) + sum((r ** 2).mean() for r in resid)
@@ -326,8 +335,8 @@ def test_netg_bf16_training_step_gradients_vs_fp32(hip):
     names_p = [k for k, _ in net.named_parameters()]
     rel = [(((a - b).norm() / b.norm().clamp_min(1e-20)).item(), k) for a, b, k in zip(g16, g32, names_p)]
     worst, worst_name = max(rel)
-    print("bf16 training: loss %.6g vs %.6g, grad cosine %.5f, worst per-tensor relative L2 error %.3g (%s)" % (
-        l16, l32, dot / (n16 * n32), worst, worst_name))
+    print("bf16 training (%s storage): loss %.6g vs %.6g, grad cosine %.5f, worst per-tensor relative L2 error %.3g (%s)" % (
+        store, l16, l32, dot / (n16 * n32), worst, worst_name))
     for r_, k in sorted(rel)[-6:]:
         print("   %-44s %.4f" % (k, r_))
     assert worst < 0.15, (worst, worst_name)
