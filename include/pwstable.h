@@ -166,7 +166,11 @@ int pws_conv2d_fwd(const pws_conv_args *args, pws_stream_t stream);
 /* dy[i] *= act'(y[i]) (LeakyReLU(0.2): y>0 ? 1 : 0.2 ; ReLU: y>0 ? 1 : 0 ; NONE: 1); dbias[c] += sum over pixels.
  * dy, y: dense NHWC [pixels][c]; dbias (nullable): c floats, ACCUMULATED (fp32 atomics, one per workgroup and channel). */
 int pws_act_bwd_bias(float *dy, const float *y, size_t pixels, int c, int act, float *dbias, pws_stream_t stream);
-int pws_act_bwd_bias_s(float *dy, const float *y, size_t pixels, int c, int act, float *dbias, int store, pws_stream_t stream);
+/* ws (optional, 16-byte aligned, pws_act_bwd_bias_ws_bytes(c) bytes): the workgroups' partial bias sums go through slabs
+ * and a second small launch instead of contended atomics. */
+size_t pws_act_bwd_bias_ws_bytes(int c);
+int pws_act_bwd_bias_s(float *dy, const float *y, size_t pixels, int c, int act, float *dbias, int store, void *ws,
+                       size_t ws_bytes, pws_stream_t stream);
 
 /* Weights re-laid-out for the data-gradient convolution of a layer.  kind in {K3S1, K3S2, CONVT_K3S1, CONVT_K4S2}. */
 size_t pws_packed_dgrad_floats(int kind, int cin, int cout);

@@ -443,6 +443,8 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
     float *th_bwd_ws = E.alloc((size_t)n * 8 * g);
     float *dtheta = E.alloc((size_t)3 * n * 6);
     float *th_dx32 = E.alloc((size_t)n * 16 * g);  // bf16 storage: fp32 gradient wrt x_s8 before it is folded into the bf16 buffer
+    const size_t abb_bytes = pws_act_bwd_bias_ws_bytes(16 * g);  // slabs of the bias-gradient reduction (max cout <= 16 ngf)
+    float *abb_ws = E.alloc(abb_bytes / sizeof(float));
     if (used) *used = E.used();
     if (dry) return PWS_OK;
     if (E.rc() != PWS_OK) return E.rc();
@@ -497,7 +499,7 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             if (!go.written) continue;  // nothing downstream asked for a gradient
             const size_t pixels = (size_t)n * op.out.h * op.out.w;
             g_prof_tag = op.layer;
-            rc = pws_act_bwd_bias_s(go.g, o.ptr, pixels, l.cout, op.act, dpacked + l.b_off, E.store(), st);
+            rc = pws_act_bwd_bias_s(go.g, o.ptr, pixels, l.cout, op.act, dpacked + l.b_off, E.store(), abb_ws, abb_bytes, st);
             if (rc != PWS_OK) break;
             pws_conv_bwd_weight_args wa{};
             wa.kind = l.kind, wa.n = n, wa.h = op.in.h, wa.w = op.in.w, wa.nsrc = op.in.nseg, wa.src_nchw = op.nchw ? 1 : 0;

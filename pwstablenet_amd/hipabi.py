@@ -77,7 +77,8 @@ SIGNATURES = {
     "pws_pack_conv_weight_wino_ct4": (_I, [_P, _P, _I, _I, _P]),
     "pws_conv2d_fwd": (_I, [ctypes.POINTER(PwsConvArgs), _P]),
     "pws_act_bwd_bias": (_I, [_P, _P, _S, _I, _I, _P, _P]),
-    "pws_act_bwd_bias_s": (_I, [_P, _P, _S, _I, _I, _P, _I, _P]),
+    "pws_act_bwd_bias_s": (_I, [_P, _P, _S, _I, _I, _P, _I, _P, _S, _P]),
+    "pws_act_bwd_bias_ws_bytes": (_S, [_I]),
     "pws_packed_dgrad_floats": (_S, [_I, _I, _I]),
     "pws_pack_conv_weight_dgrad": (_I, [_P, _P, _I, _I, _I, _P]),
     "pws_conv2d_bwd_data": (_I, [ctypes.POINTER(PwsConvBwdDataArgs), _P]),

@@ -295,3 +295,31 @@ def test_two_forwards_one_backward_and_adam(hip):
     with torch.no_grad():
         out = net(x1, False)
     assert torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("store", [0, 1])
+@pytest.mark.parametrize("pixels,c,act", [(5000, 64, 1), (300, 2048, 2), (70000, 128, 2), (17, 8, 1)])
+def test_act_bwd_bias_slab_reduction_equals_atomic_path(hip, pixels, c, act, store):
+    """pws_act_bwd_bias_s with a scratch buffer (partial sums as slabs + a second small launch) against the atomic path and
+    PyTorch, for fp32 and bf16 storage; repeated calls accumulate into dbias."""
+    A = hip
+    L, st = A.lib(), A.current_stream()
+    rs = np.random.RandomState(pixels + c)
+    y = torch.from_numpy(rs.standard_normal((pixels, c)).astype(np.float32)).cuda()
+    dy = torch.from_numpy(rs.standard_normal((pixels, c)).astype(np.float32)).cuda()
+    dt = torch.bfloat16 if store else torch.float32
+    y_s, dy0 = y.to(dt), dy.to(dt)
+    slope = 0.2 if act == 1 else 0.0
+    want = dy0.float() * torch.where(y_s.float() > 0, torch.ones_like(y), torch.full_like(y, slope))
+    ws = torch.full((L.pws_act_bwd_bias_ws_bytes(c) // 4,), float("nan"), device="cuda")
+    db = torch.zeros(c, device="cuda")
+    for rep in range(2):
+        d = dy0.clone()
+        A.check(L.pws_act_bwd_bias_s(A.ptr(d), A.ptr(y_s), pixels, c, act, A.ptr(db), store, A.ptr(ws), ws.numel() * 4, st), "act_bwd ws")
+        got = d.float()
+        assert (got - want.to(dt).float()).abs().max().item() <= 1e-6
+    relclose(db.cpu().numpy(), (2 * want.to(dt).float().sum(0)).cpu().numpy(), 2e-4 if not store else 2e-3)
+    db2 = torch.zeros(c, device="cuda")
+    d = dy0.clone()
+    A.check(L.pws_act_bwd_bias_s(A.ptr(d), A.ptr(y_s), pixels, c, act, A.ptr(db2), store, None, 0, st), "act_bwd atomics")
+    relclose(db2.cpu().numpy(), want.to(dt).float().sum(0).cpu().numpy(), 2e-4 if not store else 2e-3)
