@@ -36,8 +36,8 @@ PEAK_BF16_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step (configs[1]: 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the instrumented (hipEvent) repetition of the K steps")
@@ -128,9 +128,9 @@ def cpu_baseline(batch_unused):
                       "min of %d runs after 1 warm-up, %d torch threads" % (runs, torch.get_num_threads())}
 
 
-def bf16_legs(net, x, frames, out_fp32, a, PF, A):
-    """Extra fields (not `value`): the same inference step with bf16 conv math (PWS_MATH_BF16: operands rounded to bf16 in
-    LDS, fp32 accumulation, fp32 storage), its error against the fp32 step, and one configs[2]-shaped training step
+def bf16_legs(net, x, frames, out_fp32, a, PF, A, synth):
+    """Extra fields (not `value`): the same inference step with bf16 conv math and bf16 activation storage (PWS_MATH_BF16 +
+    PWS_STORE_BF16: bf16 matrix cores, fp32 accumulation; weights, biases, fields fp32), its error against the fp32 step, and one configs[2]-shaped training step
     (forward is_training + 3 grid_sample + L1 + backward + fused Adam) per math mode at this batch size."""
     import torch
     from pwstablenet_amd.optim import Adam
@@ -153,7 +153,7 @@ def bf16_legs(net, x, frames, out_fp32, a, PF, A):
             o = step()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    res["inference"] = {"value": round(B * a.steps / dt, 2), "unit": "frames/s", "n_gpus": 1, "dtype": "bf16 operands, f32 accumulate",
+    res["inference"] = {"value": round(B * a.steps / dt, 2), "unit": "frames/s", "n_gpus": 1, "dtype": "bf16 operands + activation storage, f32 accumulate",
                         "ms_per_step": round(1e3 * dt / a.steps, 4),
                         "field_max_abs_err_vs_fp32": float((f16 - f32).abs().max()),
                         "warped_max_abs_err_vs_fp32_over_255": float((o - out_fp32).abs().max() / 255.0),
@@ -186,6 +186,35 @@ def bf16_legs(net, x, frames, out_fp32, a, PF, A):
         train[math] = {"samples_per_s": round(B * reps / dt, 1), "ms_per_step": round(1e3 * dt / reps, 2),
                        "tflops": round(B * reps / dt * GFLOP_PER_SAMPLE_TRAIN / 1e3, 1)}
         del opt
+    # configs[2] batch size (32 samples per step) in bf16: one training forward per sample (the reference's step runs two per item)
+    try:
+        B32 = 32
+        x32 = torch.from_numpy(synth.noise_window(B32, 31, 256, seed=77)).to(x.device)
+        f32_ = torch.from_numpy(synth.make_frames(B32, 3, 256, 256, seed=78)).to(x.device)
+        tg32 = torch.roll(f32_, shifts=(2, -3), dims=(2, 3))
+        net.module.set_math("bf16")
+        opt = Adam(net.parameters(), lr=1e-6, betas=(0.5, 0.999))
+
+        def tstep32():
+            opt.zero_grad()
+            grids, _ = net(x32)
+            loss = sum(torch.nn.functional.l1_loss(PF.grid_sample(f32_, g) / 127.5 - 1, tg32 / 127.5 - 1) for g in grids)
+            loss.backward()
+            opt.step()
+            return loss
+        tstep32()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            loss = tstep32()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        assert torch.isfinite(loss)
+        train["bf16_batch32"] = {"samples_per_s": round(B32 / dt, 1), "ms_per_step": round(1e3 * dt, 2),
+                                 "tflops": round(B32 / dt * GFLOP_PER_SAMPLE_TRAIN / 1e3, 1)}
+        del opt, x32, f32_, tg32
+    except Exception as e:  # an extra leg must never cost the headline line
+        train["bf16_batch32"] = {"error": str(e)[:200]}
     net.module.set_math("fp32")
     net.zero_grad(set_to_none=True)
     res["training_step"] = {"workload": "batch=%d: netG(x) is_training + 3 grid_sample + L1 + backward + fused Adam, one netG "
@@ -392,7 +421,7 @@ def main():
                                                        "bytes_per_launch": r[0][3]}}
             del u720
         if not a.no_extra and a.math == "fp32":
-            line["bf16"] = bf16_legs(net, x, frames, out, a, PF, A)
+            line["bf16"] = bf16_legs(net, x, frames, out, a, PF, A, synth)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(B)
             line["gpu_over_cpu"] = round(fps / line["cpu_baseline"]["value"], 1)
