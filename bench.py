@@ -420,6 +420,28 @@ def main():
                                                        "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_us": round(1e3 * ms, 2),
                                                        "bytes_per_launch": r[0][3]}}
             del u720
+            # configs[4] shape on one GPU, PCIe inclusive: 96 uint8 720p frames + their 256x256 gray planes in PINNED HOST memory
+            # -> VideoStabilizer (H2D on a side stream, batched windows, netG fp32, fused u8 warp, D2H on a third stream) -> host
+            try:
+                from pwstablenet_amd.stream import VideoStabilizer
+                T = 96
+                gray_h = torch.from_numpy(synth.make_window(1, T, 256, seed=5)[0]).pin_memory()
+                u8_h = torch.randint(0, 256, (T, 720, 1280, 3), dtype=torch.uint8).pin_memory()
+                vs = VideoStabilizer(net, batch=B, swap_rb=True)
+                vs.run(gray_h[:2 * B], u8_h[:2 * B])
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                out_h = vs.run(gray_h, u8_h)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                line["value_720p_stream_u8"] = {"value": round(T / dt, 1), "unit": "frames/s", "n_gpus": 1,
+                                                "workload": "%d uint8 1280x720 frames from pinned host memory to pinned host memory "
+                                                            "(2.76 MB each way per frame over PCIe), batch %d windows per netG call" % (T, B),
+                                                "pcie_gb_per_s_each_way": round(T * 2.7648e-3 / dt, 2)}
+                assert not out_h.is_cuda
+                del gray_h, u8_h, out_h
+            except Exception as e:  # an extra leg must never cost the headline line
+                line["value_720p_stream_u8"] = {"error": str(e)[:200]}
         if not a.no_extra and a.math == "fp32":
             line["bf16"] = bf16_legs(net, x, frames, out, a, PF, A, synth)
         if world == 1 and not a.no_cpu_baseline:

@@ -6,7 +6,8 @@
  * hipStream_t passed as void*, NULL = the default stream); nothing here allocates, frees or
  * synchronises -- scratch comes from the caller (`ws`), sized by the matching *_workspace_bytes().
  * Return value: 0 on success, negative errno-style code otherwise (pws_last_error() has the text).
- * Re-entrant per stream; thread-safe (no global mutable state besides the thread-local error string).
+ * Re-entrant per stream.  Global mutable state: the thread-local error string, the process-wide options of pws_set_option()
+ * (read at call time by the whole-generator entry points) and the measurement hooks (pws_prof_*, off by default).
  *
  * Reference interfaces replaced (paths relative to the mindazhao/PWStableNet checkout; the reference has
  * no native code -- each entry point replaces the PyTorch/ATen op the reference dispatches at that line):
