@@ -100,3 +100,31 @@ def make_bn_state(seed=321, input_nc=31, output_nc=2, ngf=64):
         out.append((base + ".running_var", rs.uniform(0.5, 1.5, c).astype(np.float32)))
         out.append((base + ".num_batches_tracked", np.array(7, dtype=np.int64)))
     return out
+
+
+def make_train_batch(n, seed=123, size=256, period=30, number_feature=400, stable_extra=0):
+    """One item batch as the reference's ``customData.__getitem__`` collates it (lib/utils.py:154-244), synthetic:
+      images1, images2     uint8 (n, period+1 + 3 + 3 + stable_extra, size, size): the gray window, the unstable RGB frame,
+                           the stable RGB frame (+ the discriminator's gray frames when GAN training is on);
+      features1, features2 float64 (n, number_feature, 6): [stable x, y, 1, unstable x, y, 1] in normalised coordinates;
+      affine1, affine2     float64 (n, 2, 3) (crop boxes for the discriminator; unused without GAN);
+      feature_adjacent     float64 (n, 2, 3): affine map between the two consecutive stable frames.
+    The second item is the first one a frame later (a small extra shift), as in the reference."""
+    rs = np.random.RandomState(seed)
+    c = period + 1 + 3 + 3 + stable_extra
+    base = smooth_frames_u8(n, c + 1, size, size, seed + 1)
+    images1, images2 = base[:, :c].copy(), base[:, 1:c + 1].copy()
+
+    def feats():
+        stable = rs.uniform(-0.96, 0.96, (n, number_feature, 2))
+        unstable = stable + rs.normal(0, 0.03, (n, number_feature, 2))
+        one = np.ones((n, number_feature, 1))
+        return np.concatenate([stable, one, unstable, one], axis=2)
+
+    def near_identity(scale):
+        return np.array([[1, 0, 0], [0, 1, 0]], dtype=np.float64)[None] + rs.normal(0, scale, (n, 2, 3))
+
+    features1, features2 = feats(), feats()
+    affine1, affine2 = near_identity(0.01), near_identity(0.01)
+    feature_adjacent = near_identity(0.02)
+    return images1, features1, affine1, images2, features2, affine2, feature_adjacent

@@ -1,0 +1,119 @@
+"""Pins oracle/objective_ref.py (the restated training objective around the hot path) to tests/golden/objective.npz, which
+tests/golden/make_golden_objective.py produced by calling the reference's own pre_propossing / loss_calulate /
+loss_pixel1 / generate_affine_matrix / netG on CPU.  Tolerances are absolute and stated per check (fp32 sums)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from pwstablenet_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def og():
+    return np.load(os.path.join(GOLDEN, "objective.npz"))
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from oracle import objective_ref
+    return objective_ref
+
+
+def _csum(a):
+    a = np.asarray(a, dtype=np.float64)
+    return np.array([a.sum(), np.abs(a).sum(), np.abs(a).max()])
+
+
+def _field(og_mod, n, size, seed, amp):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mgo", os.path.join(GOLDEN, "make_golden_objective.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)   # the generator script's input synthesis only; its main() (which imports the reference) is not run
+    return m.smooth_field(n, size, seed, amp)
+
+
+def test_pre_processing(og, ref):
+    n, size, nf = int(og["cfg"][0]), int(og["cfg"][1]), int(og["cfg"][2])
+    images1, features1 = synth.make_train_batch(n, seed=11, size=size, number_feature=nf)[:2]
+    st, un, fs, fu = ref.pre_processing(torch.from_numpy(images1), torch.from_numpy(features1).float())
+    np.testing.assert_allclose(_csum(st.numpy()), og["pre_stable_csum"], rtol=1e-7)
+    np.testing.assert_allclose(_csum(un.numpy()), og["pre_unstable_csum"], rtol=1e-7)
+    np.testing.assert_array_equal(fs.numpy(), og["pre_fs"])
+    np.testing.assert_array_equal(fu.numpy(), og["pre_fu"])
+    idx = np.random.RandomState(7).randint(0, un.numel(), 32)
+    np.testing.assert_array_equal(un.numpy().reshape(-1)[idx], og["pre_unstable_samples"])
+
+
+def test_loss_calculate_values_and_gradients(og, ref):
+    n, size, nf = int(og["cfg"][0]), int(og["cfg"][1]), int(og["cfg"][2])
+    images1, features1 = synth.make_train_batch(n, seed=11, size=size, number_feature=nf)[:2]
+    st, un, fs, fu = ref.pre_processing(torch.from_numpy(images1), torch.from_numpy(features1).float())
+    grid_np, _ = _field(og, n, size, 21, 0.05)
+    grid = torch.from_numpy(grid_np).requires_grad_(True)
+    fake = F.grid_sample((un[:, 31:34] + 1) * 127.5, grid, align_corners=False) / 127.5 - 1
+    fake.retain_grad()
+    mse, delta, feat = ref.loss_calculate(grid, fs, fu, fake, st, n, size, nf)
+    (mse + feat).backward()
+    np.testing.assert_allclose([mse.item(), delta.item(), feat.item()], og["lc_values"], rtol=2e-6)
+    np.testing.assert_allclose(fake.detach().numpy()[:, :, ::8, ::8], og["lc_fake_sub"], atol=1e-6)
+    np.testing.assert_allclose(grid.grad.numpy()[:, ::8, ::8], og["lc_ggrid_sub"], atol=1e-7)
+    np.testing.assert_allclose(_csum(grid.grad.numpy()), og["lc_ggrid_csum"], rtol=1e-5)
+    np.testing.assert_allclose(_csum(fake.grad.numpy()), og["lc_gfake_csum"], rtol=1e-5)
+
+
+def test_shape_basis_and_loss(og, ref):
+    n, size, block = int(og["cfg"][0]), int(og["cfg"][1]), int(og["cfg"][3])
+    np.testing.assert_allclose(ref.shape_basis(block).reshape(block, block, 4), og["shape_basis_block"], atol=1e-15)
+    _, resid_np = _field(og, n, size, 21, 0.05)
+    resid = torch.from_numpy(resid_np).requires_grad_(True)
+    lp = ref.loss_shape(resid, block, size)
+    lp.backward()
+    np.testing.assert_allclose(lp.item(), og["shape_value"][0], rtol=1e-6)
+    np.testing.assert_allclose(resid.grad.numpy()[:, ::8, ::8], og["shape_gresid_sub"], atol=1e-5)
+    np.testing.assert_allclose(_csum(resid.grad.numpy())[1:], og["shape_gresid_csum"][1:], rtol=1e-5)   # the plain sum cancels to ~0
+
+
+def test_shape_loss_of_blockwise_bilinear_field_is_zero(ref):
+    """What the term means: a field that is bilinear inside every block costs nothing."""
+    a = ref.shape_basis(4)                                    # 16 x 4
+    coef = np.random.RandomState(0).standard_normal((1, 4, 4, 4, 2))   # (n, by, bx, corner, xy)
+    blocks = np.einsum("pk,nyxkc->nyxpc", a, coef).reshape(1, 4, 4, 4, 4, 2)   # (n, by, bx, py, px, c)
+    field = torch.from_numpy(blocks.transpose(0, 1, 3, 2, 4, 5).reshape(1, 16, 16, 2).astype(np.float32))
+    assert ref.loss_shape(field, block=4, size=16).item() < 1e-5
+
+
+def test_whole_step_against_reference(og, ref):
+    """One generator step of train() (main_new.py:84-214): restated netG (oracle/torch_ref.py) + restated objective
+    against the losses and parameter gradients the reference produced."""
+    from oracle import torch_ref
+    n, size, nf = int(og["cfg"][0]), int(og["cfg"][1]), int(og["cfg"][2])
+    params = [torch.from_numpy(v).requires_grad_(True) for _, v in synth.make_weights("W1", seed=123, ngf=64)]
+    names = [k for k, _ in synth.make_weights("W1", seed=123, ngf=64)]
+    b = [torch.from_numpy(t) for t in synth.make_train_batch(n, seed=31, size=size, number_feature=nf)]
+    st1, un1, fs1, fu1 = ref.pre_processing(b[0], b[1].float())
+    st2, un2, fs2, fu2 = ref.pre_processing(b[3], b[4].float())
+    torch.set_num_threads(8)
+    g1, r1 = torch_ref.netg_forward(params, un1[:, :31])
+    g2, r2 = torch_ref.netg_forward(params, un2[:, :31])
+    res = ref.objective(g1, r1, g2, r2, un1, st1, fs1, fu1, un2, st2, fs2, fu2, b[6].float(), n, size=size,
+                        number_feature=nf, lamd=int(og["cfg"][4]), block=int(og["cfg"][3]))
+    res["loss_g"].backward()
+    got = [res[k].item() for k in ("loss_g", "loss_mse", "loss_feature", "loss_delta", "loss_g2", "loss_pixel")]
+    np.testing.assert_allclose(got, og["step_W1_losses"], rtol=2e-5)
+    np.testing.assert_allclose(_csum(res["fake1"][2].detach().numpy()), og["step_W1_fake1_2_csum"], rtol=1e-5)
+    np.testing.assert_allclose(_csum(res["fake2"][0].detach().numpy()), og["step_W1_fake2_0_csum"], rtol=1e-5)
+    for k in og.files:
+        if k.startswith("step_W1_grad_") and k.endswith("_samples"):
+            nm = k[len("step_W1_grad_"):-len("_samples")]
+            g = params[names.index(nm)].grad.numpy()
+            idx = np.random.RandomState(7).randint(0, g.size, 16)
+            ref_s = og[k]
+            # the shape term is an un-normalised L1 sum (gradients of O(1e2)); sign(r) flips at |r| ~ 1e-9 move single pixels
+            np.testing.assert_allclose(g.reshape(-1)[idx], ref_s, rtol=2e-3, atol=2e-3 * np.abs(ref_s).max())
+            cs = og["step_W1_grad_%s_csum" % nm]
+            np.testing.assert_allclose(_csum(g)[1], cs[1], rtol=2e-3)
