@@ -293,6 +293,53 @@ int pws_adam_step(float *p, const float *g, float *m, float *v, size_t count, fl
 int pws_adam_step_multi(float *const *p, const float *const *g, float *const *m, float *const *v, const size_t *counts,
                         int ntensors, float lr, float beta1, float beta2, float eps, int step, pws_stream_t stream);
 
+/* ---------------------------------------------------------------- training objective around the path
+ * The per-step losses the reference's train() wraps round netG + grid_sample (main_new.py:101-118,184-212;
+ * lib/utils.py:246-255,339-362,405-447), generator part, no GAN; the VGG perceptual term stays with the caller (it gets
+ * the warped frames and hands back a gradient through `gextra`).  All tensors carry m samples (the reference's two
+ * forwards per item pair batched: branch 1 = samples [0,n), branch 2 = [n,2n)), fields [m,h,w,2], frames [m,3,h,w].
+ * Sums are accumulated into caller-zeroed DOUBLE slot arrays of PWS_OBJ_SLOTS entries per quantity (one f64 atomic per
+ * workgroup, spread over the slots); pws_objective_finalize reduces them. */
+#define PWS_OBJ_SLOTS 64
+/* images.float()*(1/255)*2-1 (lib/utils.py:247) for `per_sample` contiguous bytes of each of m samples; strides in elements */
+int pws_u8_normalize(const unsigned char *src, size_t src_nstride, float *dst, size_t dst_nstride, int m, size_t per_sample,
+                     pws_stream_t stream);
+/* fake = grid_sample((src+1)*127.5, grid)/127.5 - 1 (main_new.py:106-107); src: 3 planes per sample, sample i at
+ * src + i*src_nstride (a view of image_unstable[:, period+1 : period+4]).  target/l1_slots (both or neither):
+ * l1_slots += sum|target - fake| (lib/utils.py:349), target sample i at target + i*tgt_nstride. */
+int pws_warp_norm_fwd(const float *src, size_t src_nstride, const float *grid, float *fake, const float *target,
+                      size_t tgt_nstride, double *l1_slots, int m, int h, int w, pws_stream_t stream);
+/* `scale` in the backward entry points: nullable DEVICE pointer to one float that multiplies the host coefficient (the
+ * upstream gradient of the loss, which autograd holds on the device: reading it there avoids a host synchronisation).
+ * ggrid (=, or += when accumulate) (d fake/d grid)^T (c_l1*scale*sign(fake - target) + gextra); target, gextra nullable */
+int pws_warp_norm_bwd(const float *src, size_t src_nstride, const float *grid, const float *target, size_t tgt_nstride,
+                      float c_l1, const float *scale, const float *gextra, float *ggrid, int accumulate, int m, int h, int w,
+                      pws_stream_t stream);
+/* slots += sum|grid_sample(fake2, affine_grid(theta[n,6])) - fake1| (main_new.py:195-198); fake1, fake2: [n,3,h,w] */
+int pws_temporal_l1_fwd(const float *fake1, const float *fake2, const float *theta, double *slots, int n, int h, int w,
+                        pws_stream_t stream);
+/* gfake1 -= c*sign(d) (plain read-modify-write), gfake2 += c*sign(d)*bilinear weights (atomics): both must be initialised */
+int pws_temporal_l1_bwd(const float *fake1, const float *fake2, const float *theta, float c, const float *scale, float *gfake1,
+                        float *gfake2, int n, int h, int w, pws_stream_t stream);
+/* features [m,nf,6] = [stable x,y,1, unstable x,y,1] (lib/utils.py:225); slots += sum_k |unstable_k - grid[stable_k]|^2
+ * with the reference's index int((coord+1)*size/2) (lib/utils.py:341-345) */
+int pws_feature_loss_fwd(const float *grid, const float *features, double *slots, int m, int nf, int h, int w,
+                         pws_stream_t stream);
+/* ggrid += c * d(sum)/d grid (atomics; ggrid must be initialised) */
+int pws_feature_loss_bwd(const float *grid, const float *features, float c, const float *scale, float *ggrid, int m, int nf,
+                         int h, int w, pws_stream_t stream);
+/* slots_dx += sum|grid[:,:,1:]-grid[:,:,:-1]|, slots_dy likewise along h (lib/utils.py:351-357; reported, not optimised) */
+int pws_field_smoothness(const float *grid, double *slots_dx, double *slots_dy, int m, int h, int w, pws_stream_t stream);
+/* loss_pixel1 (lib/utils.py:405-425): fp64 L1 residual of the least-squares fit of generate_affine_matrix's bilinear
+ * corner basis to every (size/block)^2-pixel block of resid [m,size,size,2]; requires size == block*block as the
+ * reference's basis does.  bwd: gresid = c * d(sum)/d resid, overwritten. */
+int pws_shape_loss_fwd(const float *resid, double *slots, int m, int size, int block, pws_stream_t stream);
+int pws_shape_loss_bwd(const float *resid, double c, const float *scale, float *gresid, int m, int size, int block,
+                       pws_stream_t stream);
+/* out[j] = sum_q coef[j*nq+q] * (sum of the PWS_OBJ_SLOTS slots of quantity q), j < nout <= 64; slots [nq][PWS_OBJ_SLOTS],
+ * coef [nout][nq] device doubles */
+int pws_objective_finalize(const double *slots, int nq, const double *coef, int nout, float *out, pws_stream_t stream);
+
 /* ---------------------------------------------------------------- whole generator */
 /* Floats needed for all 46 packed layer weights + 46 biases of a generator (input_nc, ngf). */
 size_t pws_netg_packed_floats(int input_nc, int ngf);

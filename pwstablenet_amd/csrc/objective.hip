@@ -1,0 +1,567 @@
+// Training objective around the hot path (HBM-bound, fp32 data, fp64 sums): the per-step losses the reference's
+// train() wraps round netG + grid_sample (reference main_new.py:101-118,184-212; lib/utils.py:246-255,339-362,
+// 405-447), as fused forward / backward kernels.
+//
+//   u8_normalize            images.float()*(1/255)*2-1                                     lib/utils.py:247
+//   warp_norm fwd/bwd       fake = grid_sample((rgb+1)*127.5, field)/127.5-1  + sum|stable-fake|   main_new.py:106-107, lib/utils.py:349
+//   temporal_l1 fwd/bwd     sum|grid_sample(fake2, affine_grid(adjacent)) - fake1|          main_new.py:195-198
+//   feature_loss fwd/bwd    sum_k |unstable_k - field[stable_k]|^2                          lib/utils.py:341-345
+//   field_smoothness        sum|d field/dx|, sum|d field/dy| (monitor only)                 lib/utils.py:351-357
+//   shape_loss fwd/bwd      fp64 L1 residual of a per-block bilinear least-squares fit      lib/utils.py:405-425
+//
+// Batched layout: the reference runs the generator twice per step (item, item one frame later); without BatchNorm the two
+// forwards are one batch of 2n samples, so every tensor here carries m = 2n samples, branch 1 first.
+// Sums: every kernel reduces in fp32 per lane, fp64 per workgroup, and adds ONE double per workgroup into one of
+// PWS_OBJ_SLOTS slots of its quantity (hardware f64 atomics; 64 slots keep same-address contention off the L2 atomics
+// units); pws_objective_finalize adds the slots up in order.  The order of the per-slot additions is not fixed, which
+// moves a sum by ~1e-16 relative: invisible after the final conversion to fp32.
+#include "common.h"
+
+namespace pws {
+
+constexpr int kSlots = PWS_OBJ_SLOTS;
+
+struct __attribute__((packed, aligned(4))) F2Uo {
+    float x, y;
+};
+
+__device__ __forceinline__ float unnorm_o(float g, int size) {  // align_corners=False (what the reference's torch runs)
+    return fmaf(g, 0.5f * (float)size, 0.5f * (float)(size - 1));
+}
+
+// workgroup sum of a per-lane float -> one f64 atomic per workgroup
+template <int NV>
+__device__ __forceinline__ void block_accumulate(const float (&v)[NV], double *const (&dst)[NV]) {
+    __shared__ double red[NV][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double d = (double)v[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off, 64);
+        if (lane == 0) red[k][wave] = d;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        const int nw = (blockDim.x + 63) >> 6;
+        double s = 0.0;
+        for (int w = 0; w < nw; ++w) s += red[threadIdx.x][w];
+        unsafeAtomicAdd(dst[threadIdx.x] + (blockIdx.x % kSlots), s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pre-processing
+__global__ void __launch_bounds__(256) u8_normalize_kernel(const unsigned char *__restrict__ src, size_t src_nstride,
+                                                           float *__restrict__ dst, size_t dst_nstride, size_t per4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // group of 4 bytes inside one sample
+    if (i >= per4) return;
+    const unsigned u = *reinterpret_cast<const unsigned *>(src + (size_t)blockIdx.y * src_nstride + i * 4);
+    float4 o;
+    o.x = (float)(u & 0xff) * (1.f / 255) * 2 - 1;   // the reference's operation order: x * (1/255) * 2 - 1
+    o.y = (float)((u >> 8) & 0xff) * (1.f / 255) * 2 - 1;
+    o.z = (float)((u >> 16) & 0xff) * (1.f / 255) * 2 - 1;
+    o.w = (float)(u >> 24) * (1.f / 255) * 2 - 1;
+    *reinterpret_cast<float4 *>(dst + (size_t)blockIdx.y * dst_nstride + i * 4) = o;
+}
+
+// ------------------------------------------------------------------------------------------------ warp + L1
+struct TapsO {
+    int o0, o1;
+    float a0, b0, a1, b1;
+};
+__device__ __forceinline__ TapsO make_taps_o(float gx, float gy, int H, int W) {
+    const float ix = unnorm_o(gx, W), iy = unnorm_o(gy, H);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx, wx0 = 1.f - wx1, wy1 = iy - fy, wy0 = 1.f - wy1;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    const int xs = min(max(x0, 0), W - 2);
+    const int sel = x0 - xs;
+    const float wl = sel == 0 ? (vx0 ? wx0 : 0.f) : (sel == -1 ? (vx1 ? wx1 : 0.f) : 0.f);
+    const float wr = sel == 0 ? (vx1 ? wx1 : 0.f) : (sel == 1 ? (vx0 ? wx0 : 0.f) : 0.f);
+    const float r0 = vy0 ? wy0 : 0.f, r1 = vy1 ? wy1 : 0.f;
+    TapsO t;
+    t.o0 = min(max(y0, 0), H - 1) * W + xs, t.o1 = min(max(y1, 0), H - 1) * W + xs;
+    t.a0 = wl * r0, t.b0 = wr * r0, t.a1 = wl * r1, t.b1 = wr * r1;
+    return t;
+}
+
+// 4 pixels per lane: float4 field reads, float4 plane stores, paired 8-byte taps (as grid_sample_fwd2_kernel)
+__global__ void __launch_bounds__(256) warp_norm_fwd_kernel(const float *__restrict__ src, size_t src_nstride,
+                                                            const float *__restrict__ grid, float *__restrict__ fake,
+                                                            const float *__restrict__ target, size_t tgt_nstride,
+                                                            double *__restrict__ l1_slots, int H, int W, size_t total_groups,
+                                                            unsigned nblocks) {
+    const unsigned blk = xcd_remap(blockIdx.x, nblocks);
+    const size_t gidx = (size_t)blk * 256 + threadIdx.x;
+    const int HW = H * W;
+    float acc[1] = {0.f};
+    if (gidx < total_groups) {
+        const size_t p0 = gidx * 4;
+        const int n = (int)(p0 / HW), hw = (int)(p0 % HW);
+        const float4 ga = *reinterpret_cast<const float4 *>(grid + p0 * 2);
+        const float4 gb = *reinterpret_cast<const float4 *>(grid + p0 * 2 + 4);
+        TapsO t[4] = {make_taps_o(ga.x, ga.y, H, W), make_taps_o(ga.z, ga.w, H, W), make_taps_o(gb.x, gb.y, H, W),
+                      make_taps_o(gb.z, gb.w, H, W)};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float *ip = src + (size_t)n * src_nstride + (size_t)c * HW;
+            float r[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const F2Uo u = *reinterpret_cast<const F2Uo *>(ip + t[i].o0);
+                const F2Uo v = *reinterpret_cast<const F2Uo *>(ip + t[i].o1);
+                const float s = ((u.x + 1.f) * 127.5f) * t[i].a0 + ((u.y + 1.f) * 127.5f) * t[i].b0 +
+                                ((v.x + 1.f) * 127.5f) * t[i].a1 + ((v.y + 1.f) * 127.5f) * t[i].b1;
+                r[i] = s / 127.5f - 1.f;
+            }
+            *reinterpret_cast<float4 *>(fake + ((size_t)n * 3 + c) * HW + hw) = make_float4(r[0], r[1], r[2], r[3]);
+            if (target) {
+                const float4 tg = *reinterpret_cast<const float4 *>(target + (size_t)n * tgt_nstride + (size_t)c * HW + hw);
+                acc[0] += fabsf(tg.x - r[0]) + fabsf(tg.y - r[1]) + fabsf(tg.z - r[2]) + fabsf(tg.w - r[3]);
+            }
+        }
+    }
+    if (l1_slots) {
+        double *const dst[1] = {l1_slots};
+        block_accumulate<1>(acc, dst);
+    }
+}
+
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+// one lane per pixel: gfake = c_l1*sign(fake - target) + gextra ; ggrid = (d fake / d field)^T gfake
+__global__ void __launch_bounds__(256) warp_norm_bwd_kernel(const float *__restrict__ src, size_t src_nstride,
+                                                            const float *__restrict__ grid,
+                                                            const float *__restrict__ target, size_t tgt_nstride, float c_l1,
+                                                            const float *__restrict__ scale,
+                                                            const float *__restrict__ gextra, float *__restrict__ ggrid,
+                                                            int accumulate, int H, int W, size_t total, unsigned nblocks) {
+    const unsigned blk = xcd_remap(blockIdx.x, nblocks);
+    const size_t p = (size_t)blk * 256 + threadIdx.x;
+    if (p >= total) return;
+    const int HW = H * W;
+    const int n = (int)(p / HW), hw = (int)(p % HW);
+    const float2 g = *reinterpret_cast<const float2 *>(grid + p * 2);
+    if (scale) c_l1 *= *scale;
+    const float ix = unnorm_o(g.x, W), iy = unnorm_o(g.y, H);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx, wx0 = 1.f - wx1, wy1 = iy - fy, wy0 = 1.f - wy1;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1), cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+    float gix = 0.f, giy = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float *ip = src + (size_t)n * src_nstride + (size_t)c * HW;
+        const float v00 = (vy0 && vx0) ? (ip[cy0 * W + cx0] + 1.f) * 127.5f : 0.f;
+        const float v01 = (vy0 && vx1) ? (ip[cy0 * W + cx1] + 1.f) * 127.5f : 0.f;
+        const float v10 = (vy1 && vx0) ? (ip[cy1 * W + cx0] + 1.f) * 127.5f : 0.f;
+        const float v11 = (vy1 && vx1) ? (ip[cy1 * W + cx1] + 1.f) * 127.5f : 0.f;
+        float gf = gextra ? gextra[((size_t)n * 3 + c) * HW + hw] : 0.f;
+        if (target) {
+            const float fk = (v00 * (wx0 * wy0) + v01 * (wx1 * wy0) + v10 * (wx0 * wy1) + v11 * (wx1 * wy1)) / 127.5f - 1.f;
+            gf += c_l1 * sgn(fk - target[(size_t)n * tgt_nstride + (size_t)c * HW + hw]);
+        }
+        gix += gf * ((v01 - v00) * wy0 + (v11 - v10) * wy1);
+        giy += gf * ((v10 - v00) * wx0 + (v11 - v01) * wx1);
+    }
+    const float sx = 0.5f * (float)W / 127.5f, sy = 0.5f * (float)H / 127.5f;
+    float2 o = make_float2(gix * sx, giy * sy);
+    float2 *q = reinterpret_cast<float2 *>(ggrid + p * 2);
+    if (accumulate) {
+        const float2 old = *q;
+        o.x += old.x, o.y += old.y;
+    }
+    *q = o;
+}
+
+// ------------------------------------------------------------------------------------------------ temporal consistency
+__device__ __forceinline__ float base_o(int j, int size) { return (2.f * j + 1.f) / (float)size - 1.f; }
+
+struct Taps4 {
+    int o00, o01, o10, o11;
+    float w00, w01, w10, w11;
+};
+__device__ __forceinline__ Taps4 make_taps4(float gx, float gy, int H, int W) {
+    const float ix = unnorm_o(gx, W), iy = unnorm_o(gy, H);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx, wx0 = 1.f - wx1, wy1 = iy - fy, wy0 = 1.f - wy1;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1), cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+    Taps4 t;
+    t.o00 = cy0 * W + cx0, t.o01 = cy0 * W + cx1, t.o10 = cy1 * W + cx0, t.o11 = cy1 * W + cx1;
+    t.w00 = (vy0 && vx0) ? wx0 * wy0 : 0.f, t.w01 = (vy0 && vx1) ? wx1 * wy0 : 0.f;
+    t.w10 = (vy1 && vx0) ? wx0 * wy1 : 0.f, t.w11 = (vy1 && vx1) ? wx1 * wy1 : 0.f;
+    return t;
+}
+
+// BWD=false: sum |o21 - fake1| ; BWD=true: gfake1 += -c*sign(d) (plain), gfake2 += c*sign(d)*weights (atomics)
+template <bool BWD>
+__global__ void __launch_bounds__(256) temporal_l1_kernel(const float *__restrict__ fake1, const float *__restrict__ fake2,
+                                                          const float *__restrict__ theta, double *__restrict__ slots, float c,
+                                                          const float *__restrict__ scale, float *__restrict__ gfake1, float *__restrict__ gfake2, int H, int W,
+                                                          size_t total, unsigned nblocks) {
+    const unsigned blk = xcd_remap(blockIdx.x, nblocks);
+    const size_t p = (size_t)blk * 256 + threadIdx.x;
+    const int HW = H * W;
+    float acc[1] = {0.f};
+    if constexpr (BWD) {
+        if (scale) c *= *scale;
+    }
+    if (p < total) {
+        const int n = (int)(p / HW), hw = (int)(p % HW);
+        const int y_ = hw / W, x_ = hw % W;
+        const float *th = theta + (size_t)n * 6;
+        const float bx = base_o(x_, W), by = base_o(y_, H);
+        const Taps4 t = make_taps4(th[0] * bx + th[1] * by + th[2], th[3] * bx + th[4] * by + th[5], H, W);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const size_t pl = ((size_t)n * 3 + ch) * HW;
+            const float *ip = fake2 + pl;
+            const float o21 = ip[t.o00] * t.w00 + ip[t.o01] * t.w01 + ip[t.o10] * t.w10 + ip[t.o11] * t.w11;
+            const float d = o21 - fake1[pl + hw];
+            if constexpr (BWD) {
+                const float s = c * sgn(d);
+                gfake1[pl + hw] -= s;
+                if (s != 0.f) {
+                    float *gp = gfake2 + pl;
+                    if (t.w00 != 0.f) atomicAdd(gp + t.o00, s * t.w00);
+                    if (t.w01 != 0.f) atomicAdd(gp + t.o01, s * t.w01);
+                    if (t.w10 != 0.f) atomicAdd(gp + t.o10, s * t.w10);
+                    if (t.w11 != 0.f) atomicAdd(gp + t.o11, s * t.w11);
+                }
+            } else {
+                acc[0] += fabsf(d);
+            }
+        }
+    }
+    if constexpr (!BWD) {
+        double *const dst[1] = {slots};
+        block_accumulate<1>(acc, dst);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ feature points
+// features: (m, nf, 6) = [stable x, stable y, 1, unstable x, unstable y, 1] (lib/utils.py:225, :246-254).
+// index = int((coord+1)*size/2): truncation toward zero, negative indices wrap once like Python's (the reference indexes a
+// tensor with them); anything still outside is an IndexError in the reference and is clamped here (host wrapper validates).
+__device__ __forceinline__ int feat_index(float coord, int size) {
+    int i = (int)((coord + 1.f) * (float)size / 2.f);
+    if (i < 0) i += size;
+    return min(max(i, 0), size - 1);
+}
+template <bool BWD>
+__global__ void __launch_bounds__(256) feature_loss_kernel(const float *__restrict__ grid, const float *__restrict__ features,
+                                                           double *__restrict__ slots, float c, const float *__restrict__ scale,
+                                                           float *__restrict__ ggrid, int nf, int H, int W, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // (sample, point)
+    float acc[1] = {0.f};
+    if (i < total) {
+        const int n = (int)(i / nf);
+        const float *f = features + i * 6;
+        const int ix = feat_index(f[0], W), iy = feat_index(f[1], H);
+        const size_t q = (((size_t)n * H + iy) * W + ix) * 2;
+        const float dx = f[3] - grid[q], dy = f[4] - grid[q + 1];
+        if constexpr (BWD) {
+            if (scale) c *= *scale;
+            atomicAdd(ggrid + q, -2.f * c * dx);   // several points may share a pixel
+            atomicAdd(ggrid + q + 1, -2.f * c * dy);
+        } else {
+            acc[0] = dx * dx + dy * dy;
+        }
+    }
+    if constexpr (!BWD) {
+        double *const dst[1] = {slots};
+        block_accumulate<1>(acc, dst);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ smoothness (monitor)
+__global__ void __launch_bounds__(256) field_smoothness_kernel(const float *__restrict__ grid, double *__restrict__ slots_dx,
+                                                               double *__restrict__ slots_dy, int H, int W, size_t total,
+                                                               unsigned nblocks) {
+    const unsigned blk = xcd_remap(blockIdx.x, nblocks);
+    const size_t p = (size_t)blk * 256 + threadIdx.x;
+    float acc[2] = {0.f, 0.f};
+    if (p < total) {
+        const int hw = (int)(p % ((size_t)H * W));
+        const int y_ = hw / W, x_ = hw % W;
+        const float2 g = *reinterpret_cast<const float2 *>(grid + p * 2);
+        if (x_ + 1 < W) {
+            const float2 r = *reinterpret_cast<const float2 *>(grid + (p + 1) * 2);
+            acc[0] = fabsf(g.x - r.x) + fabsf(g.y - r.y);
+        }
+        if (y_ + 1 < H) {
+            const float2 d = *reinterpret_cast<const float2 *>(grid + (p + W) * 2);
+            acc[1] = fabsf(g.x - d.x) + fabsf(g.y - d.y);
+        }
+    }
+    double *const dst[2] = {slots_dx, slots_dy};
+    block_accumulate<2>(acc, dst);
+}
+
+// ------------------------------------------------------------------------------------------------ shape loss (fp64)
+// One workgroup per bs x bs block of the residual field (bs*bs <= 1024 lanes).  The reference's basis A (bs*bs x 4,
+// generate_affine_matrix) is separable: column k = a_{k/2}(y) * a_{k%2}(x), a_0(t) = (L-t)/L, a_1(t) = t/L, L = bs-1, so
+// (A^T A)^-1 = G^-1 (x) G^-1 with the 2x2 Gram matrix G of {a_0, a_1}; its three distinct entries come in as arguments.
+// r = B - A (A^T A)^-1 A^T B per coordinate; forward: sum|r|; backward: g = c * (s - A (A^T A)^-1 A^T s), s = sign(r).
+__device__ __forceinline__ void reduce8(double (&v)[8], double (*sh)[16], int nwaves) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+        if (lane == 0) sh[k][wave] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        double s = 0.0;
+        for (int w = 0; w < nwaves; ++w) s += sh[k][w];
+        v[k] = s;
+    }
+    __syncthreads();
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(1024) shape_loss_kernel(const float *__restrict__ resid, double *__restrict__ slots, double c,
+                                                          const float *__restrict__ scale, float *__restrict__ gresid, int size, int nblk, int bs, double gi00,
+                                                          double gi01, double gi11) {
+    __shared__ double sh[8][16];
+    const int b = blockIdx.x;  // (sample, block row, block col)
+    const int n = b / (nblk * nblk), by = (b / nblk) % nblk, bx = b % nblk;
+    const int px = threadIdx.x % bs, py = threadIdx.x / bs;
+    const bool live = py < bs;
+    const int nwaves = (blockDim.x + 63) >> 6;
+    const double L = (double)(bs - 1);
+    const double ax[2] = {(L - px) / L, px / L}, ay[2] = {(L - py) / L, py / L};
+    double a[4] = {ay[0] * ax[0], ay[0] * ax[1], ay[1] * ax[0], ay[1] * ax[1]};  // Q11, Q21, Q12, Q22 (lib/utils.py:438-441)
+    const size_t q = (((size_t)n * size + (size_t)by * bs + py) * size + (size_t)bx * bs + px) * 2;
+    double bxy[2] = {0.0, 0.0};
+    if (live) {
+        const float2 r = *reinterpret_cast<const float2 *>(resid + q);
+        bxy[0] = r.x, bxy[1] = r.y;
+    } else {
+        a[0] = a[1] = a[2] = a[3] = 0.0;
+    }
+    const double gi[2][2] = {{gi00, gi01}, {gi01, gi11}};
+    auto project = [&](const double (&val)[2], double (&out)[2]) {
+        double t[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[2 * k] = a[k] * val[0], t[2 * k + 1] = a[k] * val[1];
+        reduce8(t, sh, nwaves);  // A^T val, all lanes hold it
+        out[0] = out[1] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double cx = 0.0, cy = 0.0;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const double g = gi[k >> 1][l >> 1] * gi[k & 1][l & 1];
+                cx += g * t[2 * l], cy += g * t[2 * l + 1];
+            }
+            out[0] += a[k] * cx, out[1] += a[k] * cy;
+        }
+    };
+    double proj[2];
+    project(bxy, proj);
+    const double r0 = live ? proj[0] - bxy[0] : 0.0, r1 = live ? proj[1] - bxy[1] : 0.0;   // AB - B, as torch.dist(AB, B, 1)
+    if constexpr (!BWD) {
+        double t[8] = {fabs(r0) + fabs(r1), 0, 0, 0, 0, 0, 0, 0};
+        reduce8(t, sh, nwaves);
+        if (threadIdx.x == 0) unsafeAtomicAdd(slots + (blockIdx.x % kSlots), t[0]);
+    } else {
+        // d sum|PB - B| / dB = (P - I)^T s = P s - s   (P symmetric), s = sign(PB - B)
+        const double s[2] = {r0 > 0 ? 1.0 : (r0 < 0 ? -1.0 : 0.0), r1 > 0 ? 1.0 : (r1 < 0 ? -1.0 : 0.0)};
+        double ps[2];
+        project(s, ps);
+        if (scale) c *= (double)*scale;
+        if (live) *reinterpret_cast<float2 *>(gresid + q) = make_float2((float)(c * (ps[0] - s[0])), (float)(c * (ps[1] - s[1])));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ finalize
+__global__ void objective_finalize_kernel(const double *__restrict__ slots, int nq, const double *__restrict__ coef,
+                                          int nout, float *__restrict__ out) {
+    // out[j] = sum_q coef[j*nq + q] * (sum of quantity q's slots); one lane per output, slots added in index order
+    const int j = threadIdx.x;
+    if (j >= nout) return;
+    double r = 0.0;
+    for (int q = 0; q < nq; ++q) {
+        const double cf = coef[(size_t)j * nq + q];
+        if (cf == 0.0) continue;
+        double s = 0.0;
+        for (int k = 0; k < kSlots; ++k) s += slots[(size_t)q * kSlots + k];
+        r += cf * s;
+    }
+    out[j] = (float)r;
+}
+
+static inline bool al16(const void *p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
+
+}  // namespace pws
+
+using namespace pws;
+
+extern "C" int pws_u8_normalize(const unsigned char *src, size_t src_nstride, float *dst, size_t dst_nstride, int m,
+                                size_t per_sample, pws_stream_t stream) {
+    PWS_REQUIRE(m >= 0, "pws_u8_normalize: bad shape");
+    if (m == 0 || per_sample == 0) return PWS_OK;
+    PWS_REQUIRE(src && dst, "pws_u8_normalize: NULL pointer");
+    PWS_REQUIRE(per_sample % 4 == 0 && src_nstride % 4 == 0 && dst_nstride % 4 == 0 && (reinterpret_cast<size_t>(src) & 3) == 0 &&
+                    al16(dst), "pws_u8_normalize: sizes / strides must be multiples of 4 elements, src 4-byte and dst 16-byte aligned");
+    PWS_REQUIRE(m <= 65535, "pws_u8_normalize: more than 65535 samples");
+    const size_t per4 = per_sample / 4;
+    ProfScope prof(KID_OBJECTIVE, 3.0 * m * (double)per_sample, 5.0 * m * (double)per_sample, as_stream(stream));
+    hipLaunchKernelGGL(u8_normalize_kernel, dim3((unsigned)((per4 + 255) / 256), m), dim3(256), 0, as_stream(stream), src,
+                       src_nstride, dst, dst_nstride, per4);
+    return check_launch("u8_normalize_kernel");
+}
+
+extern "C" int pws_warp_norm_fwd(const float *src, size_t src_nstride, const float *grid, float *fake, const float *target,
+                                 size_t tgt_nstride, double *l1_slots, int m, int h, int w, pws_stream_t stream) {
+    PWS_REQUIRE(m >= 0 && h > 0 && w >= 2, "pws_warp_norm_fwd: bad shape");
+    if (m == 0) return PWS_OK;
+    PWS_REQUIRE(src && grid && fake, "pws_warp_norm_fwd: NULL pointer");
+    PWS_REQUIRE((target != nullptr) == (l1_slots != nullptr), "pws_warp_norm_fwd: target and l1_slots go together");
+    PWS_REQUIRE(((size_t)h * w) % 4 == 0 && (size_t)h * w < (1u << 30) && al16(grid) && al16(fake) &&
+                    (!target || (al16(target) && tgt_nstride % 4 == 0)),
+                "pws_warp_norm_fwd: h*w must be a multiple of 4 and grid / fake / target 16-byte aligned");
+    const size_t groups = (size_t)m * h * w / 4;
+    const unsigned nb = (unsigned)((groups + 255) / 256);
+    ProfScope prof(KID_OBJECTIVE, 120.0 * m * h * w, (double)m * h * w * (8.0 + 12.0 + 12.0 + (target ? 12.0 : 0.0)), as_stream(stream));
+    hipLaunchKernelGGL(warp_norm_fwd_kernel, dim3(nb), dim3(256), 0, as_stream(stream), src, src_nstride, grid, fake, target,
+                       tgt_nstride, l1_slots, h, w, groups, nb);
+    return check_launch("warp_norm_fwd_kernel");
+}
+
+extern "C" int pws_warp_norm_bwd(const float *src, size_t src_nstride, const float *grid, const float *target,
+                                 size_t tgt_nstride, float c_l1, const float *scale, const float *gextra, float *ggrid,
+                                 int accumulate, int m, int h, int w, pws_stream_t stream) {
+    PWS_REQUIRE(m >= 0 && h > 0 && w > 0, "pws_warp_norm_bwd: bad shape");
+    if (m == 0) return PWS_OK;
+    PWS_REQUIRE(src && grid && ggrid, "pws_warp_norm_bwd: NULL pointer");
+    PWS_REQUIRE((size_t)h * w < (1u << 30), "pws_warp_norm_bwd: plane too large");
+    const size_t total = (size_t)m * h * w;
+    const unsigned nb = (unsigned)((total + 255) / 256);
+    ProfScope prof(KID_OBJECTIVE, 150.0 * total, (double)total * (8.0 + 12.0 + 8.0 + (target ? 12.0 : 0.0) + (gextra ? 12.0 : 0.0)),
+                   as_stream(stream));
+    hipLaunchKernelGGL(warp_norm_bwd_kernel, dim3(nb), dim3(256), 0, as_stream(stream), src, src_nstride, grid, target,
+                       tgt_nstride, c_l1, scale, gextra, ggrid, accumulate, h, w, total, nb);
+    return check_launch("warp_norm_bwd_kernel");
+}
+
+extern "C" int pws_temporal_l1_fwd(const float *fake1, const float *fake2, const float *theta, double *slots, int n, int h,
+                                   int w, pws_stream_t stream) {
+    PWS_REQUIRE(n >= 0 && h > 0 && w > 0, "pws_temporal_l1_fwd: bad shape");
+    if (n == 0) return PWS_OK;
+    PWS_REQUIRE(fake1 && fake2 && theta && slots, "pws_temporal_l1_fwd: NULL pointer");
+    const size_t total = (size_t)n * h * w;
+    const unsigned nb = (unsigned)((total + 255) / 256);
+    ProfScope prof(KID_OBJECTIVE, 90.0 * total, 24.0 * total, as_stream(stream));
+    hipLaunchKernelGGL(temporal_l1_kernel<false>, dim3(nb), dim3(256), 0, as_stream(stream), fake1, fake2, theta, slots, 0.f,
+                       (const float *)nullptr, (float *)nullptr, (float *)nullptr, h, w, total, nb);
+    return check_launch("temporal_l1_kernel<fwd>");
+}
+
+extern "C" int pws_temporal_l1_bwd(const float *fake1, const float *fake2, const float *theta, float c, const float *scale,
+                                   float *gfake1, float *gfake2, int n, int h, int w, pws_stream_t stream) {
+    PWS_REQUIRE(n >= 0 && h > 0 && w > 0, "pws_temporal_l1_bwd: bad shape");
+    if (n == 0) return PWS_OK;
+    PWS_REQUIRE(fake1 && fake2 && theta && gfake1 && gfake2, "pws_temporal_l1_bwd: NULL pointer");
+    const size_t total = (size_t)n * h * w;
+    const unsigned nb = (unsigned)((total + 255) / 256);
+    ProfScope prof(KID_OBJECTIVE, 110.0 * total, 72.0 * total, as_stream(stream));
+    hipLaunchKernelGGL(temporal_l1_kernel<true>, dim3(nb), dim3(256), 0, as_stream(stream), fake1, fake2, theta,
+                       (double *)nullptr, c, scale, gfake1, gfake2, h, w, total, nb);
+    return check_launch("temporal_l1_kernel<bwd>");
+}
+
+extern "C" int pws_feature_loss_fwd(const float *grid, const float *features, double *slots, int m, int nf, int h, int w,
+                                    pws_stream_t stream) {
+    PWS_REQUIRE(m >= 0 && nf >= 0 && h > 0 && w > 0, "pws_feature_loss_fwd: bad shape");
+    if (m == 0 || nf == 0) return PWS_OK;
+    PWS_REQUIRE(grid && features && slots, "pws_feature_loss_fwd: NULL pointer");
+    const size_t total = (size_t)m * nf;
+    hipLaunchKernelGGL(feature_loss_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), grid,
+                       features, slots, 0.f, (const float *)nullptr, (float *)nullptr, nf, h, w, total);
+    return check_launch("feature_loss_kernel<fwd>");
+}
+
+extern "C" int pws_feature_loss_bwd(const float *grid, const float *features, float c, const float *scale, float *ggrid, int m,
+                                    int nf, int h, int w, pws_stream_t stream) {
+    PWS_REQUIRE(m >= 0 && nf >= 0 && h > 0 && w > 0, "pws_feature_loss_bwd: bad shape");
+    if (m == 0 || nf == 0) return PWS_OK;
+    PWS_REQUIRE(grid && features && ggrid, "pws_feature_loss_bwd: NULL pointer");
+    const size_t total = (size_t)m * nf;
+    hipLaunchKernelGGL(feature_loss_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), grid,
+                       features, (double *)nullptr, c, scale, ggrid, nf, h, w, total);
+    return check_launch("feature_loss_kernel<bwd>");
+}
+
+extern "C" int pws_field_smoothness(const float *grid, double *slots_dx, double *slots_dy, int m, int h, int w,
+                                    pws_stream_t stream) {
+    PWS_REQUIRE(m >= 0 && h > 0 && w > 0, "pws_field_smoothness: bad shape");
+    if (m == 0) return PWS_OK;
+    PWS_REQUIRE(grid && slots_dx && slots_dy, "pws_field_smoothness: NULL pointer");
+    const size_t total = (size_t)m * h * w;
+    const unsigned nb = (unsigned)((total + 255) / 256);
+    ProfScope prof(KID_OBJECTIVE, 10.0 * total, 8.0 * total, as_stream(stream));
+    hipLaunchKernelGGL(field_smoothness_kernel, dim3(nb), dim3(256), 0, as_stream(stream), grid, slots_dx, slots_dy, h, w, total, nb);
+    return check_launch("field_smoothness_kernel");
+}
+
+static int shape_args(const char *who, int m, int size, int block, int *bs, double *gi) {
+    PWS_REQUIRE(m >= 0 && size > 0 && block > 1 && size % block == 0, "%s: bad shape", who);
+    *bs = size / block;
+    // the reference builds the basis for a block x block patch and applies it to (size/block)^2-pixel patches
+    // (lib/utils.py:413-414, main_new.py:78): the two only agree when size == block^2
+    PWS_REQUIRE(*bs == block, "%s: the reference's basis requires size == block*block (got size %d, block %d)", who, size, block);
+    PWS_REQUIRE(*bs * *bs <= 1024, "%s: blocks of more than 1024 pixels", who);
+    const double L = *bs - 1;
+    double g00 = 0, g01 = 0, g11 = 0;
+    for (int t = 0; t < *bs; ++t) {
+        const double a0 = (L - t) / L, a1 = t / L;
+        g00 += a0 * a0, g01 += a0 * a1, g11 += a1 * a1;
+    }
+    const double det = g00 * g11 - g01 * g01;
+    gi[0] = g11 / det, gi[1] = -g01 / det, gi[2] = g00 / det;
+    return PWS_OK;
+}
+
+extern "C" int pws_shape_loss_fwd(const float *resid, double *slots, int m, int size, int block, pws_stream_t stream) {
+    int bs = 0;
+    double gi[3];
+    const int rc = shape_args("pws_shape_loss_fwd", m, size, block, &bs, gi);
+    if (rc != PWS_OK) return rc;
+    if (m == 0) return PWS_OK;
+    PWS_REQUIRE(resid && slots, "pws_shape_loss_fwd: NULL pointer");
+    const int threads = ((bs * bs + 63) / 64) * 64;
+    ProfScope prof(KID_OBJECTIVE, 120.0 * m * size * size, 8.0 * m * size * size, as_stream(stream));
+    hipLaunchKernelGGL(shape_loss_kernel<false>, dim3((unsigned)(m * block * block)), dim3(threads), 0, as_stream(stream), resid,
+                       slots, 0.0, (const float *)nullptr, (float *)nullptr, size, block, bs, gi[0], gi[1], gi[2]);
+    return check_launch("shape_loss_kernel<fwd>");
+}
+
+extern "C" int pws_shape_loss_bwd(const float *resid, double c, const float *scale, float *gresid, int m, int size, int block,
+                                  pws_stream_t stream) {
+    int bs = 0;
+    double gi[3];
+    const int rc = shape_args("pws_shape_loss_bwd", m, size, block, &bs, gi);
+    if (rc != PWS_OK) return rc;
+    if (m == 0) return PWS_OK;
+    PWS_REQUIRE(resid && gresid, "pws_shape_loss_bwd: NULL pointer");
+    const int threads = ((bs * bs + 63) / 64) * 64;
+    ProfScope prof(KID_OBJECTIVE, 240.0 * m * size * size, 16.0 * m * size * size, as_stream(stream));
+    hipLaunchKernelGGL(shape_loss_kernel<true>, dim3((unsigned)(m * block * block)), dim3(threads), 0, as_stream(stream), resid,
+                       (double *)nullptr, c, scale, gresid, size, block, bs, gi[0], gi[1], gi[2]);
+    return check_launch("shape_loss_kernel<bwd>");
+}
+
+extern "C" int pws_objective_finalize(const double *slots, int nq, const double *coef, int nout, float *out, pws_stream_t stream) {
+    PWS_REQUIRE(nq > 0 && nout > 0 && nout <= 64, "pws_objective_finalize: bad shape");
+    PWS_REQUIRE(slots && coef && out, "pws_objective_finalize: NULL pointer");
+    hipLaunchKernelGGL(objective_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), slots, nq, coef, nout, out);
+    return check_launch("objective_finalize_kernel");
+}

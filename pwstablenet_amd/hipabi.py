@@ -17,6 +17,7 @@ ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 OPT_TWO_QUEUES = 1
 OPT_MATH, MATH_FP32, MATH_BF16 = 2, 0, 1
 OPT_STORE, STORE_FP32, STORE_BF16 = 3, 0, 1
+OBJ_SLOTS = 64
 CONV_K3S1, CONV_K3S2, CONV_K5S1, CONVT_K3S1, CONVT_K4S2, CONV_K2S1P0, CONV_K1, CONV_K3S1_OUT = range(8)
 
 
@@ -109,6 +110,17 @@ SIGNATURES = {
     "pws_netg_pack_weights": (_I, [ctypes.POINTER(_P), _P, _I, _I, _P]),
     "pws_netg_workspace_bytes": (_S, [_I, _I, _I, _I]),
     "pws_netg_forward": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _S, _P, _P, _P, _P]),
+    "pws_u8_normalize": (_I, [_P, _S, _P, _S, _I, _S, _P]),
+    "pws_warp_norm_fwd": (_I, [_P, _S, _P, _P, _P, _S, _P, _I, _I, _I, _P]),
+    "pws_warp_norm_bwd": (_I, [_P, _S, _P, _P, _S, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "pws_temporal_l1_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "pws_temporal_l1_bwd": (_I, [_P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
+    "pws_feature_loss_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "pws_feature_loss_bwd": (_I, [_P, _P, _F, _P, _P, _I, _I, _I, _I, _P]),
+    "pws_field_smoothness": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "pws_shape_loss_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
+    "pws_shape_loss_bwd": (_I, [_P, ctypes.c_double, _P, _P, _I, _I, _I, _P]),
+    "pws_objective_finalize": (_I, [_P, _I, _P, _I, _P, _P]),
     "pws_prof_enable": (_I, [_I]),
     "pws_prof_collect": (_I, [ctypes.POINTER(PwsProfRecord), _I]),
     "pws_prof_kernel_name": (ctypes.c_char_p, [_I]),

@@ -1,0 +1,325 @@
+"""Parity of the HIP training-objective kernels (csrc/objective.hip, pwstablenet_amd/objective.py) with
+  * oracle/objective_ref.py (the torch-CPU restatement of lib/utils.py:246-447 and main_new.py:101-118,184-212) on the
+    same seeded inputs, forward values and gradients;
+  * tests/golden/objective.npz, produced by the REFERENCE's own pre_propossing / loss_calulate / loss_pixel1 / netG.
+Tolerances (fp32 data, fp64 sums on our side, fp32 pairwise sums in torch): scalar losses rtol 2e-5; per-pixel field
+gradients are compared on the scale of their own maximum."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from pwstablenet_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def og():
+    return np.load(os.path.join(GOLDEN, "objective.npz"))
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from oracle import objective_ref
+    return objective_ref
+
+
+def _smooth_field(n, size, seed, amp):
+    spec = importlib.util.spec_from_file_location("mgo", os.path.join(GOLDEN, "make_golden_objective.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.smooth_field(n, size, seed, amp)
+
+
+def _csum(a):
+    a = np.asarray(a, dtype=np.float64)
+    return np.array([a.sum(), np.abs(a).sum(), np.abs(a).max()])
+
+
+def _close_except_few(got, want, atol, frac=1e-4, cap=None, msg=""):
+    """|got - want| <= atol except for at most `frac` of the elements, which stay below `cap`.  The exceptions are the
+    ill-conditioned pixels every fp32 evaluation has: a sample that lands within ~1e-5 px of the zero-padded border, or an
+    L1 term whose argument is within rounding of 0 (sign() flips there and moves one tap by its full coefficient)."""
+    err = np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64))
+    cap = 100 * atol if cap is None else cap
+    assert err.max() <= cap and np.mean(err > atol) <= frac, (msg, err.max(), float(np.mean(err > atol)), atol, cap)
+
+
+def _slots(dev, nq=1):
+    return torch.zeros((nq, 64), device=dev, dtype=torch.float64)
+
+
+def test_u8_normalize_is_bit_exact(hip):
+    from pwstablenet_amd.objective import pre_propossing, u8_normalize
+    rs = np.random.RandomState(0)
+    img = torch.from_numpy(rs.randint(0, 256, (3, 37, 64, 64)).astype(np.uint8))
+    want = img.float() * (1. / 255) * 2 - 1
+    got = u8_normalize(img.cuda())
+    assert torch.equal(got.cpu(), want)
+    got = u8_normalize(img.cuda()[:, 31:])                      # channel-range view, strided samples
+    assert torch.equal(got.cpu(), want[:, 31:])
+    feats = torch.from_numpy(rs.standard_normal((3, 5, 6)).astype(np.float32))
+    st, un, fs, fu = pre_propossing(img.cuda(), feats.cuda())
+    assert torch.equal(st.cpu(), want[:, 34:]) and torch.equal(un.cpu(), want[:, :34])
+    assert torch.equal(fs.cpu(), feats[:, :, 0:3].permute(0, 2, 1)) and fu.shape == (3, 3, 5)
+    all_values = torch.arange(256, dtype=torch.uint8).repeat(4).view(1, 1, 32, 32)
+    assert torch.equal(u8_normalize(all_values.cuda()).cpu(), all_values.float() * (1. / 255) * 2 - 1)
+
+
+def _inputs(n, seed, amp=0.05, size=256, nf=400):
+    b = synth.make_train_batch(n, seed=seed, size=size, number_feature=nf)
+    imgs = torch.from_numpy(np.concatenate([b[0], b[3]], 0))
+    norm = imgs.float() * (1. / 255) * 2 - 1
+    feats = torch.from_numpy(np.concatenate([b[1], b[4]], 0)).float()
+    adj = torch.from_numpy(b[6]).float()
+    grid_np, resid_np = _smooth_field(2 * n, size, seed + 1, amp)
+    return norm, feats, adj, torch.from_numpy(grid_np), torch.from_numpy(resid_np)
+
+
+def test_warp_norm_fwd_bwd_vs_torch(hip):
+    L, st = hip.lib(), hip.current_stream
+    norm, _, _, grid, _ = _inputs(2, 3, amp=0.3)        # 0.3: a good part of the field leaves [-1,1] -> zero-padding taps
+    m = norm.shape[0]
+    gridr = grid.clone().requires_grad_(True)
+    fake_ref = F.grid_sample((norm[:, 31:34] + 1) * 127.5, gridr, align_corners=False) / 127.5 - 1
+    target = norm[:, 34:37]
+    l1_ref = (target - fake_ref).abs().sum()
+    gextra = torch.from_numpy(np.random.RandomState(5).standard_normal(tuple(fake_ref.shape)).astype(np.float32)) * 1e-3
+    c_l1 = 1.0 / fake_ref.numel()
+    (l1_ref * c_l1 + (fake_ref * gextra).sum()).backward()
+    d = norm.cuda()
+    g = grid.cuda()
+    fake = torch.empty((m, 3, 256, 256), device="cuda")
+    slots = _slots("cuda")
+    hip.check(L.pws_warp_norm_fwd(hip.ptr(d[:, 31:]), d.stride(0), hip.ptr(g), hip.ptr(fake), hip.ptr(d[:, 34:]), d.stride(0),
+                                  hip.ptr(slots), m, 256, 256, st()), "fwd")
+    # conditioning: the pixel coordinate carries ~W/2 * 2^-24 px of rounding whatever the operation order, and the zero
+    # padding makes a 0 -> ~1 step (on the [-1,1] scale) at the image border, which this field crosses on purpose:
+    # a handful of border pixels move by up to ~3e-5; everywhere else the agreement is ~1e-6
+    err = np.abs(fake.cpu().numpy() - fake_ref.detach().numpy())
+    assert err.max() < 6e-5 and np.mean(err > 2e-6) < 2e-3, (err.max(), np.mean(err > 2e-6))
+    np.testing.assert_allclose(slots.sum().item(), l1_ref.item(), rtol=1e-6)
+    gg = torch.empty_like(g)
+    hip.check(L.pws_warp_norm_bwd(hip.ptr(d[:, 31:]), d.stride(0), hip.ptr(g), hip.ptr(d[:, 34:]), d.stride(0), c_l1, None,
+                                  hip.ptr(gextra.cuda()), hip.ptr(gg), 0, m, 256, 256, st()), "bwd")
+    want = gridr.grad.numpy()
+    np.testing.assert_allclose(gg.cpu().numpy(), want, atol=2e-5 * np.abs(want).max())
+    # accumulate=1 adds to what is there; scale multiplies the L1 coefficient only
+    gg2 = gg.clone()
+    half = torch.tensor([0.5], device="cuda")
+    hip.check(L.pws_warp_norm_bwd(hip.ptr(d[:, 31:]), d.stride(0), hip.ptr(g), hip.ptr(d[:, 34:]), d.stride(0), 2 * c_l1,
+                                  hip.ptr(half), hip.ptr(gextra.cuda()), hip.ptr(gg2), 1, m, 256, 256, st()), "bwd acc")
+    np.testing.assert_allclose(gg2.cpu().numpy(), 2 * want, atol=4e-5 * np.abs(want).max())
+
+
+def test_temporal_l1_fwd_bwd_vs_torch(hip):
+    L, st = hip.lib(), hip.current_stream
+    rs = np.random.RandomState(2)
+    n = 2
+    f1 = torch.from_numpy(synth.make_frames(n, 3, 256, 256, seed=4) / 127.5 - 1).float().requires_grad_(True)
+    f2 = torch.from_numpy(synth.make_frames(n, 3, 256, 256, seed=5) / 127.5 - 1).float().requires_grad_(True)
+    theta = torch.tensor([[1, 0, 0, 0, 1, 0]], dtype=torch.float32).repeat(n, 1) + torch.from_numpy(rs.normal(0, 0.05, (n, 6))).float()
+    grid = F.affine_grid(theta.view(-1, 2, 3), f1.size(), align_corners=False)
+    s_ref = (F.grid_sample(f2, grid, align_corners=False) - f1).abs().sum()
+    c = 10.0 / f1.numel()
+    (s_ref * c).backward()
+    slots = _slots("cuda")
+    d1, d2, th = f1.detach().cuda(), f2.detach().cuda(), theta.cuda()
+    hip.check(L.pws_temporal_l1_fwd(hip.ptr(d1), hip.ptr(d2), hip.ptr(th), hip.ptr(slots), n, 256, 256, st()), "fwd")
+    np.testing.assert_allclose(slots.sum().item(), s_ref.item(), rtol=2e-6)
+    g1, g2 = torch.zeros_like(d1), torch.zeros_like(d2)
+    hip.check(L.pws_temporal_l1_bwd(hip.ptr(d1), hip.ptr(d2), hip.ptr(th), c, None, hip.ptr(g1), hip.ptr(g2), n, 256, 256, st()), "bwd")
+    _close_except_few(g1.cpu().numpy(), f1.grad.numpy(), 1e-9, frac=1e-3, cap=2.01 * c, msg="gfake1")
+    # d = o21 - fake1 of two smooth frames crosses zero along curves; a pixel within rounding of the curve flips its sign
+    # and its 4 scattered taps: up to 1e-3 of the elements, each by at most 2c
+    _close_except_few(g2.cpu().numpy(), f2.grad.numpy(), 1e-4 * c, frac=1e-3, cap=2.01 * c, msg="gfake2")
+    # both gradients ACCUMULATE onto what the caller put there; scale multiplies the coefficient
+    two = torch.tensor([2.0], device="cuda")
+    hip.check(L.pws_temporal_l1_bwd(hip.ptr(d1), hip.ptr(d2), hip.ptr(th), c, hip.ptr(two), hip.ptr(g1), hip.ptr(g2), n, 256, 256, st()), "bwd")
+    _close_except_few(g1.cpu().numpy(), 3 * f1.grad.numpy(), 1e-8, frac=1e-3, cap=6.01 * c, msg="gfake1 x3")
+    _close_except_few(g2.cpu().numpy(), 3 * f2.grad.numpy(), 3e-4 * c, frac=1e-3, cap=6.01 * c, msg="gfake2 x3")
+
+
+def test_feature_and_smoothness_vs_reference_functions(hip, ref):
+    L, st = hip.lib(), hip.current_stream
+    norm, feats, _, grid, _ = _inputs(2, 7)
+    m, nf = feats.shape[0], feats.shape[1]
+    gridr = grid.clone().requires_grad_(True)
+    fs, fu = feats[:, :, 0:3].permute(0, 2, 1), feats[:, :, 3:6].permute(0, 2, 1)
+    fake = torch.zeros((m, 3, 256, 256))
+    _, delta, feat = ref.loss_calculate(gridr, fs, fu, fake, torch.zeros((m, 3, 256, 256)), m, 256, nf)
+    feat.backward()
+    g, f = grid.cuda(), feats.cuda()
+    slots = _slots("cuda", 3)
+    sp = slots.data_ptr()
+    import ctypes
+    q = [ctypes.c_void_p(sp + k * 64 * 8) for k in range(3)]
+    hip.check(L.pws_feature_loss_fwd(hip.ptr(g), hip.ptr(f), q[0], m, nf, 256, 256, st()), "feat")
+    hip.check(L.pws_field_smoothness(hip.ptr(g), q[1], q[2], m, 256, 256, st()), "smooth")
+    s = slots.sum(1).cpu().numpy()
+    np.testing.assert_allclose(s[0] / (nf * m), feat.item(), rtol=1e-5)
+    np.testing.assert_allclose((s[1] / (m * 256 * 255 * 2) + s[2] / (m * 255 * 256 * 2)) / 2, delta.item(), rtol=1e-5)
+    gg = torch.zeros_like(g)
+    hip.check(L.pws_feature_loss_bwd(hip.ptr(g), hip.ptr(f), 1.0 / (nf * m), None, hip.ptr(gg), m, nf, 256, 256, st()), "featb")
+    np.testing.assert_allclose(gg.cpu().numpy(), gridr.grad.numpy(), atol=1e-8)
+    # index semantics at the edges: -1.0 -> 0, just below 1.0 -> size-1, negative indices wrap like Python's
+    f2 = f.clone()
+    f2[0, 0, 0:2] = torch.tensor([-1.0, 0.999])
+    f2[0, 1, 0:2] = torch.tensor([-1.004, 0.0])       # int(-0.512) = 0
+    f2[0, 2, 0:2] = torch.tensor([-1.02, 0.0])        # int(-2.56) = -2 -> column 254
+    want = []
+    for k in range(3):
+        ix = int((float(f2[0, k, 0]) + 1) * 256 / 2)
+        iy = int((float(f2[0, k, 1]) + 1) * 256 / 2)
+        want.append(grid[0, iy, ix])                   # python indexing wraps negatives
+    gg.zero_()
+    hip.check(L.pws_feature_loss_bwd(hip.ptr(g), hip.ptr(f2), 1.0, None, hip.ptr(gg), 1, 3, 256, 256, st()), "featb")
+    nz = gg[0].abs().sum(-1).nonzero().cpu().numpy().tolist()
+    assert sorted(nz) == sorted([[int((0.999 + 1) * 128), 0], [128, 0], [128, 254]])
+
+
+@pytest.mark.parametrize("size,block", [(256, 16), (64, 8), (16, 4)])
+def test_shape_loss_fwd_bwd_vs_reference_function(hip, ref, size, block):
+    L, st = hip.lib(), hip.current_stream
+    _, resid_np = _smooth_field(3, size, 9, 0.05)
+    r = torch.from_numpy(resid_np).requires_grad_(True)
+    lp = ref.loss_shape(r, block, size)
+    (lp * 0.5).backward()
+    d = torch.from_numpy(resid_np).cuda()
+    slots = _slots("cuda")
+    hip.check(L.pws_shape_loss_fwd(hip.ptr(d), hip.ptr(slots), 3, size, block, st()), "shape")
+    np.testing.assert_allclose(slots.sum().item(), lp.item(), rtol=2e-6)
+    gr = torch.empty_like(d)
+    hip.check(L.pws_shape_loss_bwd(hip.ptr(d), 0.5, None, hip.ptr(gr), 3, size, block, st()), "shapeb")
+    want = r.grad.numpy()
+    np.testing.assert_allclose(gr.cpu().numpy(), want, atol=1e-5)
+    assert L.pws_shape_loss_fwd(hip.ptr(d), hip.ptr(slots), 3, size, block * 2, st()) == -22   # size != block^2: refused
+
+
+def test_components_vs_reference_goldens(hip, og):
+    """The reference's own loss_calulate / loss_pixel1 outputs (tests/golden/objective.npz)."""
+    from pwstablenet_amd.objective import StabObjective
+    n, size, nf = int(og["cfg"][0]), int(og["cfg"][1]), int(og["cfg"][2])
+    images1, features1 = synth.make_train_batch(n, seed=11, size=size, number_feature=nf)[:2]
+    norm = (torch.from_numpy(images1).float() * (1. / 255) * 2 - 1).cuda()
+    grid_np, resid_np = _smooth_field(n, size, 21, 0.05)
+    L, st = hip.lib(), hip.current_stream
+    g, f = torch.from_numpy(grid_np).cuda(), torch.from_numpy(features1).float().cuda()
+    fake = torch.empty((n, 3, size, size), device="cuda")
+    slots = _slots("cuda", 5)
+    import ctypes
+    q = [ctypes.c_void_p(slots.data_ptr() + k * 64 * 8) for k in range(5)]
+    hip.check(L.pws_warp_norm_fwd(hip.ptr(norm[:, 31:]), norm.stride(0), hip.ptr(g), hip.ptr(fake), hip.ptr(norm[:, 34:]),
+                                  norm.stride(0), q[0], n, size, size, st()), "fwd")
+    hip.check(L.pws_feature_loss_fwd(hip.ptr(g), hip.ptr(f), q[1], n, nf, size, size, st()), "feat")
+    hip.check(L.pws_field_smoothness(hip.ptr(g), q[2], q[3], n, size, size, st()), "smooth")
+    r = torch.from_numpy(resid_np).cuda()
+    hip.check(L.pws_shape_loss_fwd(hip.ptr(r), q[4], n, size, 16, st()), "shape")
+    s = slots.sum(1).cpu().numpy()
+    mse = s[0] / (n * 3 * size * size)
+    feat = s[1] / (nf * n)
+    delta = (s[2] / (n * size * (size - 1) * 2) + s[3] / (n * (size - 1) * size * 2)) / 2
+    np.testing.assert_allclose([mse, delta, feat], og["lc_values"], rtol=2e-6)
+    np.testing.assert_allclose(s[4], og["shape_value"][0], rtol=2e-6)
+    _close_except_few(fake.cpu().numpy()[:, :, ::8, ::8], og["lc_fake_sub"], 2e-6, frac=2e-3, cap=6e-5, msg="fake")
+    gg = torch.empty_like(g)
+    hip.check(L.pws_warp_norm_bwd(hip.ptr(norm[:, 31:]), norm.stride(0), hip.ptr(g), hip.ptr(norm[:, 34:]), norm.stride(0),
+                                  1.0 / (n * 3 * size * size), None, None, hip.ptr(gg), 0, n, size, size, st()), "bwd")
+    hip.check(L.pws_feature_loss_bwd(hip.ptr(g), hip.ptr(f), 1.0 / (nf * n), None, hip.ptr(gg), n, nf, size, size, st()), "featb")
+    want = og["lc_ggrid_sub"]
+    np.testing.assert_allclose(gg.cpu().numpy()[:, ::8, ::8], want, atol=2e-5 * np.abs(want).max())
+    np.testing.assert_allclose(_csum(gg.cpu().numpy())[1], og["lc_ggrid_csum"][1], rtol=1e-4)
+    gr = torch.empty_like(r)
+    hip.check(L.pws_shape_loss_bwd(hip.ptr(r), 1.0, None, hip.ptr(gr), n, size, 16, st()), "shapeb")
+    np.testing.assert_allclose(gr.cpu().numpy()[:, ::8, ::8], og["shape_gresid_sub"], atol=1e-5)
+    np.testing.assert_allclose(_csum(gr.cpu().numpy())[1:], og["shape_gresid_csum"][1:], rtol=1e-5)
+    assert StabObjective(batchSize=n).batch == n
+
+
+def _net(kind="W1", ngf=64):
+    from pwstablenet_amd.lib.networks_cascading import define_G
+    net = define_G(31, 2, ngf, "normal", 0.02)
+    net.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in synth.make_weights(kind, seed=123, ngf=ngf)})
+    return net.cuda()
+
+
+def test_whole_step_vs_reference_golden(hip, og):
+    """train_step (two forwards batched as one, objective, backward) against the losses and parameter gradients of one
+    generator step of the reference (tests/golden/make_golden_objective.py: step_golden)."""
+    from pwstablenet_amd.objective import LOSS_NAMES, StabObjective, train_step
+    n, size, nf = int(og["cfg"][0]), int(og["cfg"][1]), int(og["cfg"][2])
+    net = _net("W1", 64)
+    batch = [torch.from_numpy(t).cuda() for t in synth.make_train_batch(n, seed=31, size=size, number_feature=nf)]
+
+    class NoStep:
+        def zero_grad(self):
+            net.zero_grad()
+
+        def step(self):
+            pass
+    obj = StabObjective(batchSize=n, number_feature=nf, lamd=int(og["cfg"][4]), block=int(og["cfg"][3]))
+    out = train_step(net, NoStep(), batch, obj)
+    got = [out[k].item() for k in LOSS_NAMES]
+    np.testing.assert_allclose(got, og["step_W1_losses"], rtol=5e-5)
+    np.testing.assert_allclose(_csum(out.fake[2][:n].detach().cpu().numpy()), og["step_W1_fake1_2_csum"], rtol=1e-4)
+    np.testing.assert_allclose(_csum(out.fake[0][n:].detach().cpu().numpy()), og["step_W1_fake2_0_csum"], rtol=1e-4)
+    named = dict(net.module.named_parameters())
+    for k in og.files:
+        if k.startswith("step_W1_grad_") and k.endswith("_samples"):
+            nm = k[len("step_W1_grad_"):-len("_samples")]
+            gnp = named[nm].grad.cpu().numpy()
+            idx = np.random.RandomState(7).randint(0, gnp.size, 16)
+            want = og[k]
+            # the un-normalised shape term dominates (gradients O(1e2)); sign(r) of near-zero residuals moves single pixels
+            np.testing.assert_allclose(gnp.reshape(-1)[idx], want, rtol=5e-3, atol=5e-3 * np.abs(want).max())
+            np.testing.assert_allclose(_csum(gnp)[1], og["step_W1_grad_%s_csum" % nm][1], rtol=5e-3)
+
+
+def test_objective_autograd_semantics(hip, ref):
+    """Upstream scaling of loss_g, a caller-side term on the returned warped frames (the VGG hook), and the restated
+    composition (oracle/objective_ref.py) on random smooth fields with ngf-independent inputs."""
+    from pwstablenet_amd.objective import StabObjective
+    n = 2
+    norm, feats, adj, grid, resid = _inputs(n, 13)
+    obj = StabObjective(batchSize=n)
+    grids_ref = [(grid + 0.01 * k).clone().requires_grad_(True) for k in range(3)]
+    resid_ref = [resid.clone().requires_grad_(True) for _ in range(3)]
+    fs, fu = feats[:, :, 0:3].permute(0, 2, 1), feats[:, :, 3:6].permute(0, 2, 1)
+    r = ref.objective([g[:n] for g in grids_ref], [x[:n] for x in resid_ref], [g[n:] for g in grids_ref], [x[n:] for x in resid_ref],
+                      norm[:n, :34], norm[:n, 34:], fs[:n], fu[:n], norm[n:, :34], norm[n:, 34:], fs[n:], fu[n:], adj, n)
+    w = torch.from_numpy(np.random.RandomState(3).standard_normal((n, 3, 256, 256)).astype(np.float32)) * 1e-3
+    extra_ref = (r["fake1"][1] * w).sum()
+    (0.5 * r["loss_g"] + extra_ref).backward()
+    d = norm.cuda()
+    grids = [g.detach().cuda().requires_grad_(True) for g in grids_ref]
+    resids = [x.detach().cuda().requires_grad_(True) for x in resid_ref]
+    out = obj(grids, resids, d[:, 31:34], d[:, 34:], feats.cuda(), adj.cuda())
+    for name in ("loss_g", "loss_mse", "loss_feature", "loss_delta", "loss_g2", "loss_pixel"):
+        np.testing.assert_allclose(out[name].item(), float(r[name]), rtol=2e-5, err_msg=name)
+    (0.5 * out.loss_g + (out.fake[1][:n] * w.cuda()).sum()).backward()
+    for k in range(3):
+        want = grids_ref[k].grad.numpy()
+        _close_except_few(grids[k].grad.cpu().numpy(), want, 5e-5 * np.abs(want).max(), cap=0.05 * np.abs(want).max(), msg="grid %d" % k)
+    want = resid_ref[2].grad.numpy()
+    np.testing.assert_allclose(resids[2].grad.cpu().numpy(), want, atol=1e-5)
+    assert resids[0].grad is None and resids[1].grad is None
+
+
+def test_objective_refuses_cpu_tensors_and_bad_shapes(hip):
+    from pwstablenet_amd.objective import StabObjective, check_features_host, u8_normalize
+    with pytest.raises(RuntimeError):
+        u8_normalize(torch.zeros((1, 3, 8, 8), dtype=torch.uint8))
+    obj = StabObjective(batchSize=1)
+    g = [torch.zeros((3, 256, 256, 2), device="cuda")] * 3
+    with pytest.raises(ValueError):
+        obj(g, g, None, None, torch.zeros((3, 400, 6), device="cuda"), torch.zeros((1, 6), device="cuda"))
+    with pytest.raises(NotImplementedError):
+        StabObjective(use_gan=True)
+    check_features_host(torch.zeros((2, 4, 6)))
+    with pytest.raises(IndexError):
+        check_features_host(torch.full((2, 4, 6), 1.5))
