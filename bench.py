@@ -128,6 +128,36 @@ def cpu_baseline(batch_unused):
                       "min of %d runs after 1 warm-up, %d torch threads" % (runs, torch.get_num_threads())}
 
 
+def configs2_step_leg(net, dev, n_items, math, reps, sync=None, seed=500):
+    """BASELINE configs[2] / [3] step, per GPU: n_items item pairs -> 2*n_items generator forwards (is_training), 6 fused
+    warp+L1 launches, temporal / feature / smoothness / fp64 shape terms, backward through all of it, [gradient
+    all-reduce,] fused Adam (reference main_new.py:84-216 without GAN and without the VGG term, which needs torchvision
+    weights).  ``pwstablenet_amd.objective.train_step``; uint8 item tensors resident in HBM."""
+    import torch
+    from pwstablenet_amd import synth
+    from pwstablenet_amd.objective import StabObjective, train_step
+    from pwstablenet_amd.optim import Adam
+    net.module.enable_graph(False)
+    net.module.set_math(math)
+    small = synth.make_train_batch(4, seed=seed)     # 4 distinct items tiled to n_items (host-side synthesis is slow)
+    rep = (n_items + 3) // 4
+    batch = [torch.from_numpy(t).repeat((rep,) + (1,) * (t.ndim - 1))[:n_items].to(dev) for t in small]
+    obj = StabObjective(batchSize=n_items)
+    opt = Adam(net.parameters(), lr=1e-6, betas=(0.5, 0.999))
+    out = train_step(net, opt, batch, obj, sync_gradients=sync)   # warm-up (allocations, weight re-pack)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = train_step(net, opt, batch, obj, sync_gradients=sync)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    loss = float(out.loss_g)
+    assert loss == loss and abs(loss) != float("inf"), loss
+    del opt, batch
+    net.zero_grad(set_to_none=True)
+    return dt, loss
+
+
 def bf16_legs(net, x, frames, out_fp32, a, PF, A, synth):
     """Extra fields (not `value`): the same inference step with bf16 conv math and bf16 activation storage (PWS_MATH_BF16 +
     PWS_STORE_BF16: bf16 matrix cores, fp32 accumulation; weights, biases, fields fp32), its error against the fp32 step, and one configs[2]-shaped training step
@@ -186,35 +216,17 @@ def bf16_legs(net, x, frames, out_fp32, a, PF, A, synth):
         train[math] = {"samples_per_s": round(B * reps / dt, 1), "ms_per_step": round(1e3 * dt / reps, 2),
                        "tflops": round(B * reps / dt * GFLOP_PER_SAMPLE_TRAIN / 1e3, 1)}
         del opt
-    # configs[2] batch size (32 samples per step) in bf16: one training forward per sample (the reference's step runs two per item)
+    # configs[2] itself: batch=32 ITEM PAIRS per step = 64 generator forwards + the objective, bf16 math
     try:
-        B32 = 32
-        x32 = torch.from_numpy(synth.noise_window(B32, 31, 256, seed=77)).to(x.device)
-        f32_ = torch.from_numpy(synth.make_frames(B32, 3, 256, 256, seed=78)).to(x.device)
-        tg32 = torch.roll(f32_, shifts=(2, -3), dims=(2, 3))
-        net.module.set_math("bf16")
-        opt = Adam(net.parameters(), lr=1e-6, betas=(0.5, 0.999))
-
-        def tstep32():
-            opt.zero_grad()
-            grids, _ = net(x32)
-            loss = sum(torch.nn.functional.l1_loss(PF.grid_sample(f32_, g) / 127.5 - 1, tg32 / 127.5 - 1) for g in grids)
-            loss.backward()
-            opt.step()
-            return loss
-        tstep32()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            loss = tstep32()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 3
-        assert torch.isfinite(loss)
-        train["bf16_batch32"] = {"samples_per_s": round(B32 / dt, 1), "ms_per_step": round(1e3 * dt, 2),
-                                 "tflops": round(B32 / dt * GFLOP_PER_SAMPLE_TRAIN / 1e3, 1)}
-        del opt, x32, f32_, tg32
+        dt, loss = configs2_step_leg(net, x.device, 32, "bf16", 3)
+        train["configs2_bf16_batch32"] = {
+            "workload": "configs[2]: 32 item pairs per step = 64 netG forwards (is_training) + fused warp/L1 x6, temporal, feature, "
+                        "smoothness, fp64 shape terms + backward + fused Adam (train() of main_new.py:84-216, no GAN, no VGG term)",
+            "items_per_s": round(32 / dt, 1), "forwards_per_s": round(64 / dt, 1), "ms_per_step": round(1e3 * dt, 2),
+            "tflops": round(64 / dt * GFLOP_PER_SAMPLE_TRAIN / 1e3, 1),
+            "frac_bf16_peak": round(64 / dt * GFLOP_PER_SAMPLE_TRAIN / 1e3 / PEAK_BF16_TFLOPS, 4), "loss_g": round(loss, 4)}
     except Exception as e:  # an extra leg must never cost the headline line
-        train["bf16_batch32"] = {"error": str(e)[:200]}
+        train["configs2_bf16_batch32"] = {"error": str(e)[:200]}
     net.module.set_math("fp32")
     net.zero_grad(set_to_none=True)
     res["training_step"] = {"workload": "batch=%d: netG(x) is_training + 3 grid_sample + L1 + backward + fused Adam, one netG "
@@ -234,8 +246,14 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # test hooks (one-GPU boxes): PWS_BENCH_ONE_DEVICE=1 puts every rank on cuda:0, PWS_BENCH_BACKEND=gloo routes the
+        # collectives through the host -- exercises the multi-rank control flow where RCCL cannot run
+        if os.environ.get("PWS_BENCH_ONE_DEVICE") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         try:
+            if os.environ.get("PWS_BENCH_BACKEND", "nccl") != "nccl":
+                raise RuntimeError("PWS_BENCH_BACKEND=%s" % os.environ["PWS_BENCH_BACKEND"])
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
             ctl_device = torch.device("cuda", local_rank)
         except Exception as e:  # control plane only: fall back to gloo rather than lose the measurement
@@ -254,7 +272,9 @@ def main():
     from pwstablenet_amd.lib.networks_cascading import define_G
 
     B = a.batch
-    net = define_G(31, 2, 64, "normal", 0.02)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):   # define_G prints like the reference's init_weights; stdout carries ONE JSON line
+        net = define_G(31, 2, 64, "normal", 0.02)
     net.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in synth.make_weights("W1", seed=123, ngf=64)})
     net = net.to(dev)
     net.module.set_math(a.math)
@@ -392,7 +412,7 @@ def main():
                                                 "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_us": round(1e3 * ms, 2),
                                                 "bytes_per_launch": r[0][3]}}
         del f720
-        if not a.no_extra:
+        if not a.no_extra and world == 1:
             # the same leg on uint8 HWC frames (what cv2 hands over / the writer takes, main_new.py:679-721): 6 B/px of frame traffic
             u720 = torch.randint(0, 256, (B, 720, 1280, 3), device=dev, dtype=torch.uint8)
             with torch.no_grad():
@@ -442,11 +462,60 @@ def main():
                 del gray_h, u8_h, out_h
             except Exception as e:  # an extra leg must never cost the headline line
                 line["value_720p_stream_u8"] = {"error": str(e)[:200]}
-        if not a.no_extra and a.math == "fp32":
+        if not a.no_extra and a.math == "fp32" and world == 1:
             line["bf16"] = bf16_legs(net, x, frames, out, a, PF, A, synth)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(B)
             line["gpu_over_cpu"] = round(fps / line["cpu_baseline"]["value"], 1)
+    else:
+        line = None
+    if world > 1 and not a.no_extra:
+        # configs[3] on this node: 32 item pairs per GPU per step, replicas + ONE flat-bucket RCCL all-reduce of the 48.5 M
+        # gradients per step.  Every rank takes part; a watchdog keeps a stuck collective from costing the headline.
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(300.0):
+                if rank == 0:
+                    line["training_ddp"] = {"error": "did not finish within 300 s"}
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            from pwstablenet_amd import distributed as D
+            nbytes = [0]
+
+            def sync(params):
+                nbytes[0] = sum(p.grad.numel() * 4 for p in params if p.grad is not None)
+                D.allreduce_gradients(params)
+            dist.barrier()
+            dt, loss = configs2_step_leg(net, dev, 32, "bf16", 3, sync=sync, seed=500 + rank)
+            t = torch.tensor([dt], device=ctl_device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            # the collective alone, same buckets, for the xGMI bus-bandwidth figure
+            flat = torch.zeros(nbytes[0] // 4, device=dev)
+            dist.all_reduce(flat)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                dist.all_reduce(flat)
+            torch.cuda.synchronize()
+            ar = (time.perf_counter() - t1) / 5
+            if rank == 0:
+                line["training_ddp"] = {
+                    "workload": "configs[3]: 32 item pairs per GPU per step (64 netG forwards + objective + backward), bf16 math, "
+                                "gradient all-reduce over RCCL in 64 MB flat buckets, fused Adam; weak scaling",
+                    "items_per_s": round(world * 32 / dt, 1), "ms_per_step": round(1e3 * dt, 2),
+                    "tflops_per_gpu": round(64 / dt * GFLOP_PER_SAMPLE_TRAIN / 1e3, 1), "loss_g_rank0": round(loss, 4),
+                    "allreduce_bytes": nbytes[0], "allreduce_alone_ms": round(1e3 * ar, 3),
+                    "allreduce_bus_gb_per_s": round(2.0 * (world - 1) / world * nbytes[0] / ar / 1e9, 1)}
+        except Exception as e:
+            if rank == 0:
+                line["training_ddp"] = {"error": str(e)[:300]}
+        done.set()
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -216,12 +216,14 @@ def check_features_host(features, size=256):
         raise IndexError("feature coordinates index the %dx%d field out of bounds" % (size, size))
 
 
-def train_step(netG, optimizerG, batch, objective, perceptual=None, period=30):
+def train_step(netG, optimizerG, batch, objective, perceptual=None, period=30, sync_gradients=None):
     """One generator step of the reference's ``train()`` (main_new.py:84-118,184-216) on device tensors.
 
     batch: (images1, features1, affine1, images2, features2, affine2, feature_adjacent) as ``customData`` collates them
     (images uint8 (n, period+1+3+3[+..], 256, 256); affine1/2 are only used by the discriminator).
-    The two generator forwards of the reference run as ONE batch of 2n windows.  Returns the ObjectiveResult."""
+    The two generator forwards of the reference run as ONE batch of 2n windows.  ``sync_gradients(params)``: called
+    between backward and the optimizer step (data-parallel training: ``distributed.allreduce_gradients``).
+    Returns the ObjectiveResult."""
     images1, features1, _a1, images2, features2, _a2, feature_adjacent = batch
     n, c = images1.shape[0], images1.shape[1]
     h, w = images1.shape[2], images1.shape[3]
@@ -237,5 +239,7 @@ def train_step(netG, optimizerG, batch, objective, perceptual=None, period=30):
     loss = out.loss_g if perceptual is None else out.loss_g + perceptual(out.fake, rest[:, 3:6])
     optimizerG.zero_grad()
     loss.backward()
+    if sync_gradients is not None:
+        sync_gradients(list(netG.parameters()))
     optimizerG.step()
     return out
