@@ -360,28 +360,53 @@ def main():
             line["kernel_tflops"] = {k: round(v[1] / (v[3] * 1e-3) / 1e12, 2) for k, v in agg.items()
                                      if v[3] > 0 and ("conv" in k or "wino" in k)}
             line["kernel_time_over_step_time"] = round(tot_ms * 1e-3 / elapsed, 4)
-        # grid_sample roofline on a batch large enough not to be launch-latency-bound
+        # grid_sample roofline on a batch large enough not to be launch-latency-bound (537 MB per launch: beyond the 256 MB
+        # Infinity Cache).  Field = what a stabiliser emits: a random ~5 % affine map + a smooth +-2 px residual; the same
+        # launch on a field with 1 px of WHITE NOISE per pixel (no trained generator emits that) is reported beside it.
         GB = a.gs_batch
         big = torch.rand((GB, 3, 256, 256), device=dev) * 255
         theta = torch.tensor([1, 0, 0, 0, 1, 0], device=dev, dtype=torch.float32).repeat(GB, 1)
         theta = theta + 0.05 * torch.randn_like(theta)
-        grid = PF.affine_grid(theta, (GB, 3, 256, 256)) + (2.0 / 256) * torch.randn((GB, 256, 256, 2), device=dev)  # ~1 px jitter
-        with torch.no_grad():
-            for _ in range(3):
-                PF.grid_sample(big, grid)
-            torch.cuda.synchronize()
-            A.lib().pws_prof_enable(1)
-            for _ in range(20):
-                PF.grid_sample(big, grid)
-            A.lib().pws_prof_enable(0)
-        r = [x_ for x_ in A.prof_collect() if x_[0] == "grid_sample_fwd_kernel"]
-        ms = sorted(x_[4] for x_ in r)[len(r) // 2]  # median launch
-        gbs = r[0][3] / (ms * 1e-3) / 1e9
+        base = PF.affine_grid(theta, (GB, 3, 256, 256))
+        ramp = torch.linspace(0, 6.28, 256, device=dev)
+        smooth = base + (4.0 / 256) * (torch.sin(3 * ramp).view(1, 256, 1, 1) * torch.cos(2 * ramp).view(1, 1, 256, 1))
+        noisy = base + (2.0 / 256) * torch.randn((GB, 256, 256, 2), device=dev)  # ~1 px jitter
+        res_gs = {}
+        for tag, grid in (("smooth", smooth), ("noisy", noisy)):
+            with torch.no_grad():
+                for _ in range(3):
+                    PF.grid_sample(big, grid)
+                torch.cuda.synchronize()
+                A.lib().pws_prof_enable(1)
+                for _ in range(20):
+                    PF.grid_sample(big, grid)
+                A.lib().pws_prof_enable(0)
+            r = [x_ for x_ in A.prof_collect() if x_[0] == "grid_sample_fwd_kernel"]
+            ms = sorted(x_[4] for x_ in r)[len(r) // 2]  # median launch
+            res_gs[tag] = (r[0][3] / (ms * 1e-3) / 1e9, ms, r[0][3])
+        gbs, ms, by = res_gs["smooth"]
         line["roofline_grid_sample"] = {"kernel": "grid_sample_fwd_kernel", "bound": "hbm", "achieved": round(gbs, 1),
                                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                                         "traffic": None, "avg_launch_us": round(1e3 * ms, 2),
-                                        "bytes_per_launch": r[0][3], "frames_per_launch": GB}
-        del big, grid
+                                        "bytes_per_launch": by, "frames_per_launch": GB,
+                                        "field": "random 5% affine + smooth +-2 px residual",
+                                        "achieved_white_noise_field": round(res_gs["noisy"][0], 1),
+                                        "frac_white_noise_field": round(res_gs["noisy"][0] / PEAK_HBM_GBS, 4),
+                                        "frac_of_measured_copy_rate": None}
+        # the practical ceiling: a plain device copy of the same number of bytes (read half, write half)
+        cp_src = torch.empty(int(by // 8), device=dev)
+        cp_dst = torch.empty_like(cp_src)
+        for _ in range(3):
+            cp_dst.copy_(cp_src)
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        for e0, e1 in evs:
+            e0.record(); cp_dst.copy_(cp_src); e1.record()  # noqa: E702
+        torch.cuda.synchronize()
+        cp_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)[5]
+        line["roofline_grid_sample"]["device_copy_same_bytes_gb_per_s"] = round(by / (cp_ms * 1e-3) / 1e9, 1)
+        line["roofline_grid_sample"]["frac_of_measured_copy_rate"] = round(gbs / (by / (cp_ms * 1e-3) / 1e9), 4)
+        del big, base, smooth, noisy, cp_src, cp_dst
         # 720p leg of the metric (configs[4] shape, one GPU's share): netG on 256x256 windows + fused field-resize+warp of
         # 1280x720 RGB frames (reference main_new.py:697-716), frames resident in HBM (PCIe-inclusive rate: DESIGN.md)
         f720 = torch.rand((B, 3, 720, 1280), device=dev) * 255
@@ -411,6 +436,33 @@ def main():
                                                 "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                                 "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_us": round(1e3 * ms, 2),
                                                 "bytes_per_launch": r[0][3]}}
+        # the same kernel on the field a stabiliser emits (2 % affine + smooth residual) instead of the random-weight
+        # generator's (whose residual jumps by up to ~100 px between neighbouring 256x256 cells), inputs rotated so that
+        # they come from HBM, not from the Infinity Cache
+        try:
+            rot = [f720] + [torch.rand((B, 3, 720, 1280), device=dev) * 255 for _ in range(3)]
+            th = torch.tensor([1, 0, 0, 0, 1, 0], device=dev, dtype=torch.float32).repeat(B, 1)
+            ramp = torch.linspace(0, 6.28, 256, device=dev)
+            fsm = PF.affine_grid(th + 0.02 * torch.randn_like(th), (B, 3, 256, 256)) + \
+                (4.0 / 256) * (torch.sin(3 * ramp).view(1, 256, 1, 1) * torch.cos(2 * ramp).view(1, 1, 256, 1))
+            with torch.no_grad():
+                for b_ in rot:
+                    PF.upsample_grid_sample(b_, fsm)
+                torch.cuda.synchronize()
+                A.lib().pws_prof_enable(1)
+                for i_ in range(12):
+                    PF.upsample_grid_sample(rot[i_ % 4], fsm)
+                A.lib().pws_prof_enable(0)
+            r = [x_ for x_ in A.prof_collect() if x_[0] == "upsample_grid_sample_fwd_kernel"]
+            ms = sorted(x_[4] for x_ in r)[len(r) // 2]
+            rw = line["value_720p"]["roofline_warp"]
+            rw["field"] = "netG with random synthetic weights"
+            rw["achieved_smooth_field"] = round(r[0][3] / (ms * 1e-3) / 1e9, 1)
+            rw["frac_smooth_field"] = round(r[0][3] / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+            rw["avg_launch_us_smooth_field"] = round(1e3 * ms, 2)
+            del rot, fsm
+        except Exception as e:
+            line["value_720p"]["roofline_warp"]["smooth_field_error"] = str(e)[:200]
         del f720
         if not a.no_extra and world == 1:
             # the same leg on uint8 HWC frames (what cv2 hands over / the writer takes, main_new.py:679-721): 6 B/px of frame traffic

@@ -68,6 +68,8 @@ const char *pws_last_error(void); /* thread-local, never NULL */
 #define PWS_OPT_STORE 3
 #define PWS_STORE_FP32 0
 #define PWS_STORE_BF16 1
+/* Measurement only: selects alternative kernel variants that the scripts under tools/ compare (0 = the product default). */
+#define PWS_OPT_EXPERIMENT 100
 int pws_set_option(int key, int value);
 int pws_get_option(int key); /* current value, or PWS_EINVAL */
 /* Number of compute units / XCDs the library sees on the current device (diagnostics). */

@@ -7,6 +7,7 @@ namespace pws {
 bool g_two_queues = true;
 int g_math = PWS_MATH_FP32;
 int g_store = PWS_STORE_FP32;
+int g_experiment = 0;
 bool g_prof_on = false;
 int g_prof_tag = -1;
 namespace {
@@ -129,6 +130,10 @@ extern "C" int pws_set_option(int key, int value) {
         pws::g_store = value;
         return PWS_OK;
     }
+    if (key == PWS_OPT_EXPERIMENT) {
+        pws::g_experiment = value;
+        return PWS_OK;
+    }
     pws::set_error("pws_set_option: unknown key %d", key);
     return PWS_EINVAL;
 }
@@ -137,6 +142,7 @@ extern "C" int pws_get_option(int key) {
     if (key == PWS_OPT_TWO_QUEUES) return pws::g_two_queues ? 1 : 0;
     if (key == PWS_OPT_MATH) return pws::g_math;
     if (key == PWS_OPT_STORE) return pws::g_store;
+    if (key == PWS_OPT_EXPERIMENT) return pws::g_experiment;
     pws::set_error("pws_get_option: unknown key %d", key);
     return PWS_EINVAL;
 }

@@ -52,6 +52,7 @@ enum KernelId {
 extern bool g_two_queues;
 extern int g_math;  // PWS_OPT_MATH
 extern int g_store;  // PWS_OPT_STORE (effective only with PWS_MATH_BF16)
+extern int g_experiment;  // PWS_OPT_EXPERIMENT: selects measured kernel variants (tools/*_bench.py); 0 = product default
 extern bool g_prof_on;
 extern int g_prof_tag;
 void prof_begin(int kernel_id, double flops, double bytes, hipStream_t st);
