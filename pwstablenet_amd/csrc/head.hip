@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) theta_final_kernel(const float *__restric
 }
 
 // 16x16 output pixels per workgroup, one lane per pixel, channels staged through LDS CH at a time.
-constexpr int FH_T = 16, FH_I = FH_T + 2, FH_CH = 32, FH_LDP = FH_CH + 4;
+constexpr int FH_T = 16, FH_I = FH_T + 2, FH_CH = 16, FH_LDP = FH_CH + 4;
 
 template <bool IO16>
 __global__ void __launch_bounds__(256) field_head_kernel(const float *__restrict__ x, int ld, int N, int H, int W, int C,
@@ -87,7 +87,6 @@ __global__ void __launch_bounds__(256) field_head_kernel(const float *__restrict
                                                          const float *__restrict__ theta, int ac, float *__restrict__ resid,
                                                          float *__restrict__ grid, int tiles_x, int tiles_y, unsigned ntiles) {
     __shared__ float s_in[FH_I * FH_I * FH_LDP];
-    __shared__ float s_w[9 * FH_CH * 2];
     const int tid = threadIdx.x;
     const unsigned tile = xcd_remap(blockIdx.x, ntiles);
     const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
@@ -106,23 +105,20 @@ __global__ void __launch_bounds__(256) field_head_kernel(const float *__restrict
             if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ld4<IO16>(x, ((size_t)(n * H + iy) * W + ix) * ld + c0 + c4 * 4);
             *reinterpret_cast<float4 *>(s_in + pix * FH_LDP + c4 * 4) = v;
         }
-        for (int item = tid; item < 9 * ch * 2; item += 256) {
-            const int tap = item / (ch * 2), r = item % (ch * 2);
-            s_w[item] = w_out[((size_t)tap * C + c0) * 2 + r];
-        }
         __syncthreads();
+        // The weights are the same for every lane: read through the scalar unit (wave-uniform address -> s_load), not LDS.
+        // With them in LDS the kernel was LDS-bandwidth-bound (48 B of ds_read per 8 FMAs; 259 us at N=32, 256x256x64).
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const float *ip = s_in + ((ty + tap / 3) * FH_I + tx + tap % 3) * FH_LDP;
-            const float *wp = s_w + tap * ch * 2;
+            const float *wp = w_out + ((size_t)tap * C + c0) * 2;
             for (int c4 = 0; c4 < c4n; ++c4) {
                 const float4 v = *reinterpret_cast<const float4 *>(ip + c4 * 4);
-                const float4 wa = *reinterpret_cast<const float4 *>(wp + c4 * 8);      // (c,0),(c,1),(c+1,0),(c+1,1)
-                const float4 wb = *reinterpret_cast<const float4 *>(wp + c4 * 8 + 4);  // (c+2,*),(c+3,*)
-                acc0 = fmaf(v.x, wa.x, acc0), acc1 = fmaf(v.x, wa.y, acc1);
-                acc0 = fmaf(v.y, wa.z, acc0), acc1 = fmaf(v.y, wa.w, acc1);
-                acc0 = fmaf(v.z, wb.x, acc0), acc1 = fmaf(v.z, wb.y, acc1);
-                acc0 = fmaf(v.w, wb.z, acc0), acc1 = fmaf(v.w, wb.w, acc1);
+                const float *wq = wp + c4 * 8;  // (c,0),(c,1),(c+1,0),(c+1,1),(c+2,*),(c+3,*)
+                acc0 = fmaf(v.x, wq[0], acc0), acc1 = fmaf(v.x, wq[1], acc1);
+                acc0 = fmaf(v.y, wq[2], acc0), acc1 = fmaf(v.y, wq[3], acc1);
+                acc0 = fmaf(v.z, wq[4], acc0), acc1 = fmaf(v.z, wq[5], acc1);
+                acc0 = fmaf(v.w, wq[6], acc0), acc1 = fmaf(v.w, wq[7], acc1);
             }
         }
     }
@@ -194,7 +190,7 @@ extern "C" int pws_field_head_fwd_s(const float *x, int ld, int n, int h, int w,
     PWS_REQUIRE(x && w_out && (resid || grid), "pws_field_head_fwd: NULL pointer");
     const int ch = c < FH_CH ? c : FH_CH;
     PWS_REQUIRE(c % 4 == 0 && c % ch == 0 && ld % 4 == 0 && ld >= c && (reinterpret_cast<size_t>(x) & 15) == 0,
-                "pws_field_head_fwd: c=%d must be a multiple of 4 (and of 32 when > 32), ld %% 4 == 0, x 16-B aligned", c);
+                "pws_field_head_fwd: c=%d must be a multiple of 4 (and of 16 when > 16), ld %% 4 == 0, x 16-B aligned", c);
     const int tiles_x = (w + FH_T - 1) / FH_T, tiles_y = (h + FH_T - 1) / FH_T;
     const unsigned ntiles = (unsigned)tiles_x * tiles_y * n;
     ProfScope prof(KID_FIELD_HEAD, 2.0 * n * h * w * 18.0 * c,

@@ -11,20 +11,22 @@ namespace pws {
 
 __device__ __forceinline__ float lrelu_grad(float y) { return y > 0.f ? 1.f : 0.2f; }
 
-// ---- K1: g_z, db_out, dtheta.  One lane per pixel, 256 pixels (one image row segment) per workgroup.
+// ---- K1: g_z, db_out, dtheta.  Workgroup = (slice of one image, image): every lane walks its slice 256 pixels at a time
+// and keeps the 8 partial sums in registers, so there is ONE round of 8 atomics per workgroup (one round per 256 pixels put
+// 8192 x 8 atomics on a handful of addresses at N=32: 112 us for a 67 MB elementwise pass).
 __global__ void __launch_bounds__(256) field_gz_kernel(const float *__restrict__ resid, const float *__restrict__ g_grid,
-                                                       const float *__restrict__ g_resid, int H, int W, size_t total, int ac,
+                                                       const float *__restrict__ g_resid, int H, int W, int slices, int ac,
                                                        float *__restrict__ gz, float *__restrict__ db_out,
                                                        float *__restrict__ dtheta) {
     __shared__ float red[8][4];
-    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // dtheta[6], db[2]
-    // all pixels of a workgroup belong to one image when H*W % 256 == 0; otherwise per-lane atomics below
+    const int n = blockIdx.y;
     const size_t HW = (size_t)H * W;
-    int n = 0;
-    if (p < total) {
-        n = (int)(p / HW);
-        const int xq = (int)(p % W), yq = (int)((p / W) % H);
+    const size_t per = (HW + slices - 1) / slices;
+    const size_t q_lo = (size_t)blockIdx.x * per, q_hi = q_lo + per < HW ? q_lo + per : HW;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // dtheta[6], db[2]
+    for (size_t q = q_lo + threadIdx.x; q < q_hi; q += 256) {
+        const size_t p = (size_t)n * HW + q;
+        const int xq = (int)(q % W), yq = (int)(q / W);
         const float2 r = *reinterpret_cast<const float2 *>(resid + p * 2);
         float2 gg = make_float2(0.f, 0.f), gr = make_float2(0.f, 0.f);
         if (g_grid) gg = *reinterpret_cast<const float2 *>(g_grid + p * 2);
@@ -35,63 +37,78 @@ __global__ void __launch_bounds__(256) field_gz_kernel(const float *__restrict__
         *reinterpret_cast<float2 *>(gz + p * 2) = make_float2(z0, z1);
         const float bx = ac ? (W > 1 ? (2.f * xq) / (float)(W - 1) - 1.f : 0.f) : (2.f * xq + 1.f) / (float)W - 1.f;
         const float by = ac ? (H > 1 ? (2.f * yq) / (float)(H - 1) - 1.f : 0.f) : (2.f * yq + 1.f) / (float)H - 1.f;
-        v[0] = gg.x * bx, v[1] = gg.x * by, v[2] = gg.x, v[3] = gg.y * bx, v[4] = gg.y * by, v[5] = gg.y, v[6] = z0, v[7] = z1;
+        v[0] += gg.x * bx, v[1] += gg.x * by, v[2] += gg.x, v[3] += gg.y * bx, v[4] += gg.y * by, v[5] += gg.y, v[6] += z0, v[7] += z1;
     }
-    const bool uniform_n = (HW % 256) == 0;
-    if (uniform_n) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float s = v[k];
+    for (int k = 0; k < 8; ++k) {
+        float s = v[k];
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-            if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s;
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const float s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        if (threadIdx.x < 6) {
+            if (dtheta) atomicAdd(dtheta + (size_t)n * 6 + threadIdx.x, s);
+        } else if (db_out) {
+            atomicAdd(db_out + threadIdx.x - 6, s);
         }
-        __syncthreads();
-        if (threadIdx.x < 8) {
-            const float s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
-            if (threadIdx.x < 6) {
-                if (dtheta) atomicAdd(dtheta + (size_t)n * 6 + threadIdx.x, s);
-            } else if (db_out) {
-                atomicAdd(db_out + threadIdx.x - 6, s);
-            }
-        }
-    } else if (p < total) {
-        if (dtheta)
-            for (int k = 0; k < 6; ++k) atomicAdd(dtheta + (size_t)n * 6 + k, v[k]);
-        if (db_out) atomicAdd(db_out, v[6]), atomicAdd(db_out + 1, v[7]);
     }
 }
 
-// ---- K2: dx.  One lane = (pixel, 4 channels); weights in LDS.
+// ---- K2: dx.  One lane per pixel: its 9 g_z taps sit in registers, the weights are wave-uniform and come through the
+// scalar unit, so the 18 * C FMAs per pixel run at VALU rate; the result leaves in 16-byte pieces (8 bf16 / 4 fp32
+// channels).  (One lane per (pixel, 4 channels) with the weights in LDS was LDS-bound with bank conflicts between the
+// channel groups: 531 us at N=32, 256x256x64, against a VALU floor of ~65 us.)
 template <bool IO16>
 __global__ void __launch_bounds__(256) field_dx_kernel(const float *__restrict__ gz, const float *__restrict__ w_out, int N,
                                                        int H, int W, int C, float *__restrict__ dx, int dx_ld, int accumulate) {
-    extern __shared__ float sw[];  // [9][C][2]
-    for (int i = threadIdx.x; i < 9 * C * 2; i += 256) sw[i] = w_out[i];
-    __syncthreads();
-    const int c4n = C / 4;
-    const size_t total = (size_t)N * H * W * c4n;
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
-    const int c = (int)(e % c4n) * 4;
-    const size_t pix = e / c4n;
+    constexpr int VEC = IO16 ? 8 : 4;
+    const size_t total = (size_t)N * H * W;
+    const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= total) return;
     const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((size_t)W * H));
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 g[9];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         // forward: z[q] += x[q + tap - 1] * W[tap]  =>  dx[p] += gz[p + 1 - tap] * W[tap]
         const int yy = y + 1 - tap / 3, xx = x + 1 - tap % 3;
-        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-        const float2 g = *reinterpret_cast<const float2 *>(gz + (((size_t)n * H + yy) * W + xx) * 2);
-        const float *wp = sw + (tap * C + c) * 2;
-        a.x += g.x * wp[0] + g.y * wp[1], a.y += g.x * wp[2] + g.y * wp[3];
-        a.z += g.x * wp[4] + g.y * wp[5], a.w += g.x * wp[6] + g.y * wp[7];
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const float2 v = *reinterpret_cast<const float2 *>(gz + (((size_t)n * H + (ok ? yy : y)) * W + (ok ? xx : x)) * 2);
+        g[tap] = ok ? v : make_float2(0.f, 0.f);
     }
-    if (accumulate) {
-        const float4 o = ld4<IO16>(dx, pix * dx_ld + c);
-        a.x += o.x, a.y += o.y, a.z += o.z, a.w += o.w;
+    for (int c = 0; c < C; c += VEC) {
+        float a[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) a[k] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float *wp = w_out + ((size_t)tap * C + c) * 2;  // wave-uniform -> scalar loads
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) a[k] = fmaf(g[tap].x, wp[2 * k], fmaf(g[tap].y, wp[2 * k + 1], a[k]));
+        }
+        if constexpr (!IO16) {
+            float4 o = make_float4(a[0], a[1], a[2], a[3]);
+            if (accumulate) {
+                const float4 old = ld4<false>(dx, pix * dx_ld + c);
+                o.x += old.x, o.y += old.y, o.z += old.z, o.w += old.w;
+            }
+            st4<false>(dx, pix * dx_ld + c, o);
+        }
+        if constexpr (IO16) {
+            __bf16 *d = reinterpret_cast<__bf16 *>(dx) + pix * dx_ld + c;
+            if (accumulate) {
+                const uint4 u = *reinterpret_cast<const uint4 *>(d);
+                a[0] += __builtin_bit_cast(float, u.x << 16), a[1] += __builtin_bit_cast(float, u.x & 0xffff0000u);
+                a[2] += __builtin_bit_cast(float, u.y << 16), a[3] += __builtin_bit_cast(float, u.y & 0xffff0000u);
+                a[4] += __builtin_bit_cast(float, u.z << 16), a[5] += __builtin_bit_cast(float, u.z & 0xffff0000u);
+                a[6] += __builtin_bit_cast(float, u.w << 16), a[7] += __builtin_bit_cast(float, u.w & 0xffff0000u);
+            }
+            *reinterpret_cast<uint4 *>(d) = make_uint4(cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3]), cvt_pk_bf16(a[4], a[5]),
+                                                       cvt_pk_bf16(a[6], a[7]));
+        }
     }
-    st4<IO16>(dx, pix * dx_ld + c, a);
 }
 
 // ---- K3: dW_out.  Workgroup = 16x16 pixel tile x 32 channels; lane = (channel, pixel-row group).
@@ -101,9 +118,10 @@ template <bool IO16>
 __global__ void __launch_bounds__(256) field_dw_kernel(const float *__restrict__ x, int ld, const float *__restrict__ gz, int N,
                                                        int H, int W, int C, float *__restrict__ dw, int tiles_x, int tiles_y,
                                                        int ntiles) {
-    __shared__ float s_in[FB_I * FB_I * FB_LDP];
+    __shared__ float s_in[FB_I * FB_I * FB_LDP];   // the final cross-group reduction re-uses it (s_red)
     __shared__ float s_g[FB_T * FB_T * 2];
-    __shared__ float s_red[8 * 32 * 18];
+    static_assert(FB_I * FB_I * FB_LDP >= 8 * 32 * 18, "s_red fits in s_in");
+    float *s_red = s_in;
     const int tid = threadIdx.x;
     const int c0 = blockIdx.y * FB_CH;
     const int c = tid & 31, grp = tid >> 5;  // 8 groups x 2 tile rows each
@@ -111,26 +129,44 @@ __global__ void __launch_bounds__(256) field_dw_kernel(const float *__restrict__
 #pragma unroll
     for (int i = 0; i < 18; ++i) acc[i] = 0.f;
     // a workgroup walks a strided subset of the tiles and keeps its partial sums in registers: one round of atomics per
-    // workgroup at the end (one per TILE put 2048 atomics on each of the 1152 addresses: 260 us per call, L2-atomic-bound)
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // workgroup at the end (one per TILE put 2048 atomics on each of the 1152 addresses: 260 us per call, L2-atomic-bound).
+    // The next tile is fetched into registers while the current one is consumed out of LDS (with 2-3 resident workgroups per
+    // CU the load -> LDS -> barrier -> compute chain otherwise exposes the full global latency per tile).
+    constexpr int NITEM = (FB_I * FB_I * (FB_CH / 4) + 255) / 256;
+    float4 pre[NITEM];
+    float2 pre_g;
+    auto fetch = [&](int tile) {
         const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int x0 = tx_i * FB_T, y0 = ty_i * FB_T;
-        __syncthreads();  // previous tile consumed
-        for (int item = tid; item < FB_I * FB_I * (FB_CH / 4); item += 256) {
+#pragma unroll
+        for (int it = 0; it < NITEM; ++it) {
+            const int item = tid + it * 256;
             const int pix = item / (FB_CH / 4), c4 = (item % (FB_CH / 4)) * 4;
             const int iy = y0 - 1 + pix / FB_I, ix = x0 - 1 + pix % FB_I;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W && c0 + c4 < C) v = ld4<IO16>(x, ((size_t)(n * H + iy) * W + ix) * ld + c0 + c4);
-            float *d = s_in + pix * FB_LDP + c4;
-            d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+            const bool ok = item < FB_I * FB_I * (FB_CH / 4) && iy >= 0 && iy < H && ix >= 0 && ix < W && c0 + c4 < C;
+            // unconditional load from a valid address, zeroed by a select: a conditional load would serialise on vmcnt(0)
+            const float4 v = ld4<IO16>(x, ok ? ((size_t)(n * H + iy) * W + ix) * ld + c0 + c4 : 0);
+            pre[it] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        {
-            const int ty = tid >> 4, tx = tid & 15, y = y0 + ty, xq = x0 + tx;
-            float2 g = make_float2(0.f, 0.f);
-            if (y < H && xq < W) g = *reinterpret_cast<const float2 *>(gz + (((size_t)n * H + y) * W + xq) * 2);
-            s_g[tid * 2] = g.x, s_g[tid * 2 + 1] = g.y;
+        const int ty = tid >> 4, tx = tid & 15, y = y0 + ty, xq = x0 + tx;
+        const bool okg = y < H && xq < W;
+        const float2 g = *reinterpret_cast<const float2 *>(gz + (okg ? (((size_t)n * H + y) * W + xq) * 2 : 0));
+        pre_g = okg ? g : make_float2(0.f, 0.f);
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();  // previous tile consumed
+#pragma unroll
+        for (int it = 0; it < NITEM; ++it) {
+            const int item = tid + it * 256;
+            if (item < FB_I * FB_I * (FB_CH / 4)) {
+                float *d = s_in + (item / (FB_CH / 4)) * FB_LDP + (item % (FB_CH / 4)) * 4;
+                d[0] = pre[it].x, d[1] = pre[it].y, d[2] = pre[it].z, d[3] = pre[it].w;
+            }
         }
+        s_g[tid * 2] = pre_g.x, s_g[tid * 2 + 1] = pre_g.y;
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);  // in flight during the FMAs below
         for (int ty = grp * 2; ty < grp * 2 + 2; ++ty)
             for (int tx = 0; tx < FB_T; ++tx) {
                 const float g0 = s_g[(ty * FB_T + tx) * 2], g1 = s_g[(ty * FB_T + tx) * 2 + 1];
@@ -141,6 +177,7 @@ __global__ void __launch_bounds__(256) field_dw_kernel(const float *__restrict__
                 }
             }
     }
+    __syncthreads();  // every lane is done reading the last tile out of s_in
 #pragma unroll
     for (int i = 0; i < 18; ++i) s_red[(grp * 32 + c) * 18 + i] = acc[i];
     __syncthreads();
@@ -238,16 +275,24 @@ extern "C" int pws_field_head_bwd_s(const float *x, int ld, int n, int h, int w,
             return PWS_EHIP;
         }
     }
-    hipLaunchKernelGGL(field_gz_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, resid, g_grid, g_resid, h, w, total,
-                       align_corners, ws, db_out, dtheta);
+    {
+        // ~2048 workgroups over the batch, at least 1024 pixels each
+        int slices = (2048 + n - 1) / n;
+        const int max_slices = (int)(((size_t)h * w + 1023) / 1024);
+        if (slices > max_slices) slices = max_slices;
+        if (slices < 1) slices = 1;
+        PWS_REQUIRE(n <= 65535, "pws_field_head_bwd: more than 65535 samples");
+        hipLaunchKernelGGL(field_gz_kernel, dim3((unsigned)slices, (unsigned)n), dim3(256), 0, st, resid, g_grid, g_resid, h, w, slices,
+                           align_corners, ws, db_out, dtheta);
+    }
     if (dx) {
-        const size_t items = total * (c / 4);
+        PWS_REQUIRE(!io16 || (c % 8 == 0 && dx_ld % 8 == 0), "pws_field_head_bwd: bf16 storage needs c and dx_ld to be multiples of 8");
         if (io16)
-            hipLaunchKernelGGL(field_dx_kernel<true>, dim3((unsigned)((items + 255) / 256)), dim3(256), sizeof(float) * 18 * c, st, ws,
-                               w_out, n, h, w, c, dx, dx_ld, dx_accumulate);
+            hipLaunchKernelGGL(field_dx_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, w_out, n, h, w, c,
+                               dx, dx_ld, dx_accumulate);
         else
-            hipLaunchKernelGGL(field_dx_kernel<false>, dim3((unsigned)((items + 255) / 256)), dim3(256), sizeof(float) * 18 * c, st, ws,
-                               w_out, n, h, w, c, dx, dx_ld, dx_accumulate);
+            hipLaunchKernelGGL(field_dx_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, w_out, n, h, w, c,
+                               dx, dx_ld, dx_accumulate);
     }
     if (dw_out) {
         const int tiles_x = (w + FB_T - 1) / FB_T, tiles_y = (h + FB_T - 1) / FB_T;
