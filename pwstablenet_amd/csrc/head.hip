@@ -95,17 +95,30 @@ __global__ void __launch_bounds__(256) field_head_kernel(const float *__restrict
     const int ch = C < FH_CH ? C : FH_CH;  // channels per stage (C % ch == 0 checked on the host)
     const int c4n = ch / 4;
     float acc0 = b_out ? b_out[0] : 0.f, acc1 = b_out ? b_out[1] : 0.f;
+    // the next channel stage is fetched into registers while the current one is consumed out of LDS
+    constexpr int NITEM = (FH_I * FH_I * (FH_CH / 4) + 255) / 256;
+    float4 pre[NITEM];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int it = 0; it < NITEM; ++it) {
+            const int item = tid + it * 256;
+            const int pix = item / c4n, c4 = item % c4n;
+            const int iy = y0 - 1 + pix / FH_I, ix = x0 - 1 + pix % FH_I;
+            const bool ok = item < FH_I * FH_I * c4n && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const float4 v = ld4<IO16>(x, ok ? ((size_t)(n * H + iy) * W + ix) * ld + c0 + c4 * 4 : 0);  // unconditional load
+            pre[it] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    fetch(0);
     for (int c0 = 0; c0 < C; c0 += ch) {
         __syncthreads();
-        for (int item = tid; item < FH_I * FH_I * c4n; item += 256) {
-            const int pix = item / c4n, c4 = item % c4n;
-            const int ly = pix / FH_I, lx = pix % FH_I;
-            const int iy = y0 - 1 + ly, ix = x0 - 1 + lx;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ld4<IO16>(x, ((size_t)(n * H + iy) * W + ix) * ld + c0 + c4 * 4);
-            *reinterpret_cast<float4 *>(s_in + pix * FH_LDP + c4 * 4) = v;
+#pragma unroll
+        for (int it = 0; it < NITEM; ++it) {
+            const int item = tid + it * 256;
+            if (item < FH_I * FH_I * c4n) *reinterpret_cast<float4 *>(s_in + (item / c4n) * FH_LDP + (item % c4n) * 4) = pre[it];
         }
         __syncthreads();
+        if (c0 + ch < C) fetch(c0 + ch);
         // The weights are the same for every lane: read through the scalar unit (wave-uniform address -> s_load), not LDS.
         // With them in LDS the kernel was LDS-bandwidth-bound (48 B of ds_read per 8 FMAs; 259 us at N=32, 256x256x64).
 #pragma unroll
