@@ -31,8 +31,18 @@ struct BfCfg {
     static constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
     static constexpr int PIX = TN * IH * IW;
     static constexpr int TAPS = KS * KS;
-    static constexpr int PITCH = CK * 2 + 16;          // bytes per LDS row
-    static constexpr int LDS_IN = PIX * PITCH;         // bytes (multiple of 16)
+    static constexpr int PITCH = CK * 2 + 16;          // bytes per LDS pixel row
+    // Bytes per TILE row of the input image in LDS.  An MFMA A-operand read (ds_read_b128) is served in four groups of 16
+    // lanes = {tile-row r: 8 pixels, tile-row r+1: the other 8 columns} for TW = 16 (four rows x 4 pixels for TW = 8); with
+    // the 80-byte pixel pitch (5 x 16 B, odd) the 16 addresses fall into 16 different 4-bank slots only if consecutive tile
+    // rows start 0 (TW = 16) or 8 (TW = 8) slots apart mod 16.  IW * PITCH alone gave 2-way conflicts on every A read
+    // (rocprofv3: SQ_LDS_BANK_CONFLICT 38 % of SQ_LDS_IDX_ACTIVE).  Stride-2 tiles step two pixels per lane: left as is.
+    static constexpr int ROWP_MIN = IW * PITCH;
+    static constexpr bool ROW_ALIGN = STRIDE == 1 && PITCH == 80 && (TW == 16 || TW == 8);
+    static constexpr int ROW_RES = TW == 8 ? 128 : 0;
+    static constexpr int ROWP = ROW_ALIGN ? ((ROWP_MIN - ROW_RES + 255) / 256) * 256 + ROW_RES : ROWP_MIN;
+    static_assert(ROWP >= ROWP_MIN && ROWP % 16 == 0, "row pitch");
+    static constexpr int LDS_IN = TN * IH * ROWP;      // bytes (multiple of 16)
     static constexpr int LDS_W = TAPS * BN * PITCH;
     static constexpr int LDS_BYTES = LDS_IN + LDS_W + 16;  // + a 16-byte sink for the staging items past the tile
     static constexpr int C8 = CK / 8;                  // 8-channel (16-byte bf16) items per row
@@ -111,7 +121,7 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_kernel(const ConvKPar
         const bool ok = item < C::N_IN && n < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         g_pix[it] = ok ? (n * p.H + iy) * p.W + ix : 0;
         ok_mask |= ok ? (1u << it) : 0u;
-        l_off[it] = item < C::N_IN ? pix * C::PITCH + c8 * 16 : C::LDS_IN + C::LDS_W;  // past the tile: the sink
+        l_off[it] = item < C::N_IN ? (tn * C::IH + ly) * C::ROWP + lx * C::PITCH + c8 * 16 : C::LDS_IN + C::LDS_W;  // else: the sink
     }
     static_assert(C::ITEMS_IN <= 32, "mask width");
     // weight items: (tap, cout row, 8-k group); rows co0..co0+63 always exist in the padded bf16 weights
@@ -181,7 +191,7 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_kernel(const ConvKPar
     for (int mt = 0; mt < C::MT; ++mt) {
         const int m = (wm * C::MT + mt) * 32 + l31;
         const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
-        a_base[mt] = ((tn * C::IH + ty * C::STRIDE) * C::IW + tx * C::STRIDE) * C::PITCH + hi * 16;
+        a_base[mt] = (tn * C::IH + ty * C::STRIDE) * C::ROWP + tx * C::STRIDE * C::PITCH + hi * 16;
     }
     const int b_base = (wn * C::NT * 32 + l31) * C::PITCH + hi * 16;
 
@@ -203,7 +213,7 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_kernel(const ConvKPar
 #pragma unroll
         for (int tap = 0; tap < C::TAPS; ++tap) {
             if (C::SUBPIX == 2 && ((!py && tap / C::KS) || (!px && tap % C::KS))) continue;  // block-uniform
-            const int toff = ((tap / C::KS) * C::IW + (tap % C::KS)) * C::PITCH;
+            const int toff = (tap / C::KS) * C::ROWP + (tap % C::KS) * C::PITCH;
 #pragma unroll
             for (int ks = 0; ks < C::CK / 16; ++ks) {
                 bf16x8 a[C::MT], b[C::NT];
@@ -291,7 +301,7 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_k5_kernel(const ConvK
     for (int mt = 0; mt < C::MT; ++mt) {
         const int m = (wm * C::MT + mt) * 32 + l31;
         const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
-        a_base[mt] = ((tn * C::IH + ty) * C::IW + tx) * C::PITCH + hi * 16;
+        a_base[mt] = (tn * C::IH + ty) * C::ROWP + tx * C::PITCH + hi * 16;
     }
     const int b_base = (wn * C::NT * 32 + l31) * C::PITCH + hi * 16;
 
@@ -344,7 +354,7 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_k5_kernel(const ConvK
                         r[k][1] = *reinterpret_cast<const f32x4 *>(sp + e + 4);
                     }
                     okv[k] = ok;
-                    off[k] = item < C::N_IN ? pix * C::PITCH + c8 * 16 : SINK;
+                    off[k] = item < C::N_IN ? (tn * C::IH + ly) * C::ROWP + lx * C::PITCH + c8 * 16 : SINK;
                 }
 #pragma unroll
                 for (int k = 0; k < BATCH; ++k) {
@@ -369,7 +379,7 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_k5_kernel(const ConvK
             if (r + 1 < C::KS) load_wrow(r + 1, ch * C::CK);
 #pragma unroll
             for (int t = 0; t < C::KS; ++t) {
-                const int toff = (r * C::IW + t) * C::PITCH;
+                const int toff = r * C::ROWP + t * C::PITCH;
 #pragma unroll
                 for (int ks = 0; ks < C::CK / 16; ++ks) {
                     bf16x8 a[C::MT], b[C::NT];

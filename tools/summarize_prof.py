@@ -62,6 +62,7 @@ def kernel_stats(sub, suffix):
 
 kernel_stats("trace", "")
 kernel_stats("trace_bf16", "_bf16")
+kernel_stats("trace_train", "_train_bf16")
 
 summ = defaultdict(dict)
 for sub in sorted(glob.glob(os.path.join(d, "pmc_*"))):
