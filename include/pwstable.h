@@ -368,7 +368,16 @@ size_t pws_netg_train_workspace_bytes(int n, int input_nc, int ngf);
 int pws_netg_backward(const float *packed, const float *packed_dgrad, const float *x, int n, int input_nc, int ngf,
                       int align_corners, void *ws, size_t ws_bytes, const float *resid, const float *thetas,
                       const float *g_grids, const float *g_resid, float *dpacked, pws_stream_t stream);
-/* grads: HOST array of 92 DEVICE pointers (torch layouts, state-dict order), overwritten. */
+/* The same backward cut into `nparts` consecutive runs of the reversed layer tape; call part = 0 .. nparts-1 in order on the
+ * same arguments.  final_mask (nullable, HOST, 46 bytes, one per layer in state-dict order): set to 1 for every layer whose
+ * weight / bias gradient in `dpacked` is complete once this run has executed -- a data-parallel host unpacks and all-reduces
+ * those on a second stream while the next run computes (gradient exchange overlapped with backward). */
+int pws_netg_backward_part(const float *packed, const float *packed_dgrad, const float *x, int n, int input_nc, int ngf,
+                           int align_corners, void *ws, size_t ws_bytes, const float *resid, const float *thetas,
+                           const float *g_grids, const float *g_resid, float *dpacked, int part, int nparts,
+                           unsigned char *final_mask, pws_stream_t stream);
+/* grads: HOST array of 92 DEVICE pointers (torch layouts, state-dict order), overwritten; a layer whose weight AND bias
+ * pointers are NULL is skipped. */
 int pws_netg_unpack_grads(const float *dpacked, float *const *grads, int input_nc, int ngf, pws_stream_t stream);
 
 /* ---------------------------------------------------------------- measurement hooks (bench / tests only)

@@ -45,13 +45,48 @@ class _NetGTrain(torch.autograd.Function):
         packed, packed_dg = sv["packed"], net.packed_dgrad_weights()
         dpacked = torch.empty_like(packed)
         net._apply_math(sv.get("math", "fp32"), sv.get("store", "fp32"))  # the arena holds what the forward's mode wrote
-        A.check(L.pws_netg_backward(A.ptr(packed), A.ptr(packed_dg), A.ptr(sv["x"]), n, net.input_nc, net.ngf, 0,
-                                    ctypes.c_void_p(sv["ws_ptr"]), sv["ws_bytes"], A.ptr(sv["resid"]), A.ptr(sv["thetas"]),
-                                    A.ptr(g_grids), A.ptr(g_resid), A.ptr(dpacked), st), "pws_netg_backward")
         params = net._ordered_params()
         grads = [torch.empty_like(p) for p in params]
-        ptrs = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
-        A.check(L.pws_netg_unpack_grads(A.ptr(dpacked), ptrs, net.input_nc, net.ngf, st), "pws_netg_unpack_grads")
+        sync = getattr(net, "grad_sync", None)
+        if sync is None or sync.nparts == 1:
+            A.check(L.pws_netg_backward(A.ptr(packed), A.ptr(packed_dg), A.ptr(sv["x"]), n, net.input_nc, net.ngf, 0,
+                                        ctypes.c_void_p(sv["ws_ptr"]), sv["ws_bytes"], A.ptr(sv["resid"]), A.ptr(sv["thetas"]),
+                                        A.ptr(g_grids), A.ptr(g_resid), A.ptr(dpacked), st), "pws_netg_backward")
+            ptrs = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+            A.check(L.pws_netg_unpack_grads(A.ptr(dpacked), ptrs, net.input_nc, net.ngf, st), "pws_netg_unpack_grads")
+            if sync is not None:
+                sync.collectives = 0
+                sync.allreduce(grads)
+        else:
+            # overlapped gradient exchange (distributed.OverlappedGradSync): backward in runs; after each run the layers whose
+            # gradients are final are unpacked + all-reduced on the communication stream while the next run computes
+            nl = len(params) // 2
+            main, comm = torch.cuda.current_stream(dev), sync.stream(dev)
+            mask = (ctypes.c_ubyte * nl)()
+            done = [False] * nl
+            sync.collectives = 0
+            for part in range(sync.nparts):
+                A.check(L.pws_netg_backward_part(A.ptr(packed), A.ptr(packed_dg), A.ptr(sv["x"]), n, net.input_nc, net.ngf, 0,
+                                                 ctypes.c_void_p(sv["ws_ptr"]), sv["ws_bytes"], A.ptr(sv["resid"]),
+                                                 A.ptr(sv["thetas"]), A.ptr(g_grids), A.ptr(g_resid), A.ptr(dpacked), part,
+                                                 sync.nparts, mask, st), "pws_netg_backward_part")
+                newly = [i for i in range(nl) if mask[i] and not done[i]]
+                if not newly:
+                    continue
+                ready = torch.cuda.Event()
+                ready.record(main)
+                with torch.cuda.stream(comm):
+                    comm.wait_event(ready)
+                    ptrs = (ctypes.c_void_p * len(grads))()
+                    for i in newly:
+                        ptrs[2 * i], ptrs[2 * i + 1] = grads[2 * i].data_ptr(), grads[2 * i + 1].data_ptr()
+                    A.check(L.pws_netg_unpack_grads(A.ptr(dpacked), ptrs, net.input_nc, net.ngf, A.current_stream()),
+                            "pws_netg_unpack_grads")
+                    sync.allreduce([grads[k] for i in newly for k in (2 * i, 2 * i + 1)])
+                for i in newly:
+                    done[i] = True
+            assert all(done), "pws_netg_backward_part: a layer never became final"
+            main.wait_stream(comm)
         ctx.saved = None  # release the arena
         return (None, None) + tuple(grads)
 

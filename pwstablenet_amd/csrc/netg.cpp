@@ -421,9 +421,14 @@ struct GradBuf {
 
 // The forward passes its thetas pointer; the planning replay must consume the arena identically, so backward is
 // told whether the forward kept thetas in the arena (thetas_in_arena) -- the Python host always passes its own buffer.
+// part / nparts: the reversed tape is cut into nparts runs of (almost) equal op count and only run `part` is launched (the
+// bookkeeping of every earlier run is replayed without launching), so that a data-parallel host can all-reduce the weight
+// gradients that are already final while the later runs still compute.  final_mask (nullable, one byte per layer): 1 once no
+// op of a later run contributes to that layer's gradient.
 static int run_backward(const float *packed, const float *packed_dgrad, const float *x, int n, int input_nc, int g, int ac,
                         char *ws, size_t ws_bytes, const float *resid, const float *thetas, const float *g_grids,
-                        const float *g_resid, float *dpacked, hipStream_t st, bool dry, size_t *used) {
+                        const float *g_resid, float *dpacked, hipStream_t st, bool dry, size_t *used, int part = 0,
+                        int nparts = 1, unsigned char *final_mask = nullptr) {
     const int S = 256;
     size_t total = 0;
     const std::vector<Layer> L = build_layers(input_nc, g, &total);
@@ -449,16 +454,34 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
     if (dry) return PWS_OK;
     if (E.rc() != PWS_OK) return E.rc();
 
-    hipError_t e = hipMemsetAsync(dpacked, 0, total * sizeof(float), st);
-    if (e != hipSuccess) {
-        set_error("pws_netg_backward: hipMemsetAsync: %s", hipGetErrorString(e));
-        return PWS_EHIP;
+    if (part == 0) {
+        hipError_t e = hipMemsetAsync(dpacked, 0, total * sizeof(float), st);
+        if (e != hipSuccess) {
+            set_error("pws_netg_backward: hipMemsetAsync: %s", hipGetErrorString(e));
+            return PWS_EHIP;
+        }
+    }
+    const size_t T = E.tape().size();
+    const size_t r_begin = T * (size_t)part / nparts, r_end = T * (size_t)(part + 1) / nparts;  // reversed positions of this run
+    if (final_mask) {
+        // a layer is final once every op that uses it lies at a reversed position < r_end
+        for (int i = 0; i < L_COUNT; ++i) final_mask[i] = 1;
+        for (size_t ii = 0; ii < T; ++ii) {
+            if (T - 1 - ii < r_end) continue;
+            const Op &op = E.tape()[ii];
+            if (op.type == OP_FIELD) final_mask[L_OUT] = 0;
+            else if (op.type == OP_THETA) final_mask[L_FLATTEN] = 0, final_mask[L_LINEAR] = 0;
+            else final_mask[op.layer] = 0;
+        }
     }
     const size_t gsz = (size_t)n * S * S * 2;
     bool have_dtheta[3] = {false, false, false};
     int rc = PWS_OK;
-    for (size_t ii = E.tape().size(); ii-- > 0 && rc == PWS_OK;) {
+    for (size_t ii = T; ii-- > 0 && rc == PWS_OK;) {
         const Op &op = E.tape()[ii];
+        const size_t r = T - 1 - ii;
+        if (r >= r_end) break;
+        const bool run = r >= r_begin;  // earlier runs: replay the bookkeeping (written / have_dtheta flags) only
         if (op.type == OP_FIELD) {
             const int k = op.stage;
             const float *gg = g_grids ? g_grids + k * gsz : nullptr, *gr = g_resid ? g_resid + k * gsz : nullptr;
@@ -466,9 +489,10 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             const Seg &xs = op.in.seg[0];
             GradBuf &gb = G[xs.ptr];
             const Layer &o = L[L_OUT];
-            rc = pws_field_head_bwd_s(xs.ptr, xs.ld, n, op.in.h, op.in.w, xs.c, packed + o.w_off, resid + k * gsz, gg, gr, ac, gb.g,
-                                      xs.c, gb.written ? 1 : 0, dpacked + o.w_off, dpacked + o.b_off,
-                                      gg ? dtheta + (size_t)k * n * 6 : nullptr, gz_ws, E.store(), st);
+            if (run)
+                rc = pws_field_head_bwd_s(xs.ptr, xs.ld, n, op.in.h, op.in.w, xs.c, packed + o.w_off, resid + k * gsz, gg, gr, ac, gb.g,
+                                          xs.c, gb.written ? 1 : 0, dpacked + o.w_off, dpacked + o.b_off,
+                                          gg ? dtheta + (size_t)k * n * 6 : nullptr, gz_ws, E.store(), st);
             gb.written = true;
             have_dtheta[k] = gg != nullptr;
         } else if (op.type == OP_THETA) {
@@ -477,6 +501,10 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             const Seg &xs = op.in.seg[0];
             GradBuf &gb = G[xs.ptr];
             const Layer &f = L[L_FLATTEN], &l = L[L_LINEAR];
+            if (!run) {
+                gb.written = true;
+                continue;
+            }
             if (E.io16()) {
                 // fp32 head on an fp32 copy of its bf16 input; its input gradient goes through an fp32 scratch
                 const size_t cnt = (size_t)n * 4 * xs.c;
@@ -498,6 +526,11 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             GradBuf &go = G[o.ptr];
             if (!go.written) continue;  // nothing downstream asked for a gradient
             const size_t pixels = (size_t)n * op.out.h * op.out.w;
+            if (!run) {
+                if (!op.nchw)
+                    for (int i = 0; i < op.in.nseg; ++i) G[op.in.seg[i].ptr].written = true;
+                continue;
+            }
             g_prof_tag = op.layer;
             rc = pws_act_bwd_bias_s(go.g, o.ptr, pixels, l.cout, op.act, dpacked + l.b_off, E.store(), abb_ws, abb_bytes, st);
             if (rc != PWS_OK) break;
@@ -617,6 +650,24 @@ extern "C" int pws_netg_pack_weights_dgrad(const float *const *params, float *pa
     return rc;
 }
 
+extern "C" int pws_netg_backward_part(const float *packed, const float *packed_dgrad, const float *x, int n, int input_nc, int ngf,
+                                      int align_corners, void *ws, size_t ws_bytes, const float *resid, const float *thetas,
+                                      const float *g_grids, const float *g_resid, float *dpacked, int part, int nparts,
+                                      unsigned char *final_mask, pws_stream_t stream) {
+    PWS_REQUIRE(n >= 0 && input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_backward_part: bad n/input_nc/ngf");
+    PWS_REQUIRE(nparts >= 1 && part >= 0 && part < nparts, "pws_netg_backward_part: part %d of %d", part, nparts);
+    if (n == 0) {
+        if (final_mask)
+            for (int i = 0; i < L_COUNT; ++i) final_mask[i] = 1;
+        return PWS_OK;
+    }
+    PWS_REQUIRE(packed && packed_dgrad && x && ws && resid && thetas && dpacked, "pws_netg_backward_part: NULL pointer");
+    PWS_REQUIRE(g_grids || g_resid, "pws_netg_backward_part: no output gradient given");
+    PWS_REQUIRE((reinterpret_cast<size_t>(ws) & 255) == 0, "pws_netg_backward_part: workspace must be 256-byte aligned");
+    return run_backward(packed, packed_dgrad, x, n, input_nc, ngf, align_corners, static_cast<char *>(ws), ws_bytes, resid, thetas,
+                        g_grids, g_resid, dpacked, as_stream(stream), false, nullptr, part, nparts, final_mask);
+}
+
 extern "C" int pws_netg_unpack_grads(const float *dpacked, float *const *grads, int input_nc, int ngf, pws_stream_t stream) {
     PWS_REQUIRE(dpacked && grads, "pws_netg_unpack_grads: NULL pointer");
     PWS_REQUIRE(input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_unpack_grads: bad ngf %d", ngf);
@@ -627,14 +678,17 @@ extern "C" int pws_netg_unpack_grads(const float *dpacked, float *const *grads, 
     fill_pack_layers(L, a.layer);
     unsigned nb = 0;
     for (int i = 0; i < L_COUNT; ++i) {
-        PWS_REQUIRE(grads[2 * i] && grads[2 * i + 1], "pws_netg_unpack_grads: grads[%d] is NULL", 2 * i);
+        // a layer whose two pointers are both NULL is skipped (part-wise unpacking, pws_netg_backward_part)
+        PWS_REQUIRE((grads[2 * i] != nullptr) == (grads[2 * i + 1] != nullptr), "pws_netg_unpack_grads: grads[%d], grads[%d]: one is NULL",
+                    2 * i, 2 * i + 1);
         a.grads[2 * i] = grads[2 * i], a.grads[2 * i + 1] = grads[2 * i + 1];
         const PackLayer &p = a.layer[i];
         a.first_block[i] = nb;
-        nb += (unsigned)(((size_t)p.k * p.k * p.cin * p.cout + p.cout + 255) / 256);
+        if (grads[2 * i]) nb += (unsigned)(((size_t)p.k * p.k * p.cin * p.cout + p.cout + 255) / 256);
     }
     a.total_blocks = nb;
-    return launch_unpack_all(a, dpacked, as_stream(stream));  // one launch: 46 weights + 46 biases
+    if (nb == 0) return PWS_OK;
+    return launch_unpack_all(a, dpacked, as_stream(stream));  // one launch: up to 46 weights + 46 biases
 }
 
 extern "C" size_t pws_netg_workspace_bytes(int n, int input_nc, int ngf, int is_training) {

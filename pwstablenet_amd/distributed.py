@@ -59,29 +59,66 @@ def max_over_ranks(value, device=None):
     return float(t.item())
 
 
+def allreduce_tensors(tensors, bucket_bytes=64 << 20):
+    """Averages the given fp32 tensors over ranks in place, in flat buckets of ~bucket_bytes, on the CURRENT stream.
+    Returns the number of collectives issued (0 without a process group)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    world = dist.get_world_size()
+    n_coll, i = 0, 0
+    while i < len(tensors):
+        j, size = i, 0
+        while j < len(tensors) and (size == 0 or size + tensors[j].numel() * 4 <= bucket_bytes):
+            size += tensors[j].numel() * 4
+            j += 1
+        flat = torch.cat([g.reshape(-1) for g in tensors[i:j]])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(world)
+        off = 0
+        for g in tensors[i:j]:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+        n_coll += 1
+        i = j
+    return n_coll
+
+
 def allreduce_gradients(params, bucket_bytes=64 << 20):
     """Averages ``p.grad`` over ranks in place, in flat buckets of ~bucket_bytes.
 
     Shared-weight gradients (stages 2 and 3 use the same modules) are already accumulated locally by backward before
     this is called.  Returns the number of collectives issued.
     """
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return 0
-    world = dist.get_world_size()
-    grads = [p.grad for p in params if p.grad is not None]
-    n_coll, i = 0, 0
-    while i < len(grads):
-        j, size = i, 0
-        while j < len(grads) and (size == 0 or size + grads[j].numel() * 4 <= bucket_bytes):
-            size += grads[j].numel() * 4
-            j += 1
-        flat = torch.cat([g.reshape(-1) for g in grads[i:j]])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.div_(world)
-        off = 0
-        for g in grads[i:j]:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
-        n_coll += 1
-        i = j
-    return n_coll
+    return allreduce_tensors([p.grad for p in params if p.grad is not None], bucket_bytes)
+
+
+class OverlappedGradSync:
+    """Gradient exchange overlapped with backward.  ``enable_overlapped_grad_sync(netG)`` attaches one to the
+    generator; its backward then runs as ``nparts`` consecutive runs of the reversed layer tape (``pws_netg_backward_part``)
+    and, after each run, the weight gradients that are already final (the C side reports them) are unpacked and all-reduced
+    on a second stream while the next run computes.  ``p.grad`` arrive averaged: no ``allreduce_gradients`` call after
+    ``backward()``.  Without a process group (one GPU) the collectives are skipped, everything else runs the same."""
+
+    def __init__(self, nparts=4, bucket_bytes=64 << 20):
+        if nparts < 1:
+            raise ValueError("nparts must be >= 1")
+        self.nparts, self.bucket_bytes = int(nparts), int(bucket_bytes)
+        self._streams = {}
+        self.collectives = 0   # issued by the last backward (diagnostics)
+
+    def stream(self, device):
+        key = str(device)
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device)
+        return self._streams[key]
+
+    def allreduce(self, tensors):
+        self.collectives += allreduce_tensors(tensors, self.bucket_bytes)
+
+
+def enable_overlapped_grad_sync(netG, nparts=4, bucket_bytes=64 << 20):
+    """netG: what ``define_G`` returned (or its ``.module``).  Returns the OverlappedGradSync; ``netG.grad_sync = None`` turns
+    it off again."""
+    target = getattr(netG, "module", netG)
+    target.grad_sync = OverlappedGradSync(nparts, bucket_bytes)
+    return target.grad_sync

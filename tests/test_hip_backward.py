@@ -323,3 +323,41 @@ def test_act_bwd_bias_slab_reduction_equals_atomic_path(hip, pixels, c, act, sto
     d = dy0.clone()
     A.check(L.pws_act_bwd_bias_s(A.ptr(d), A.ptr(y_s), pixels, c, act, A.ptr(db2), store, None, 0, st), "act_bwd atomics")
     relclose(db2.cpu().numpy(), want.to(dt).float().sum(0).cpu().numpy(), 2e-4 if not store else 2e-3)
+
+
+@pytest.mark.parametrize("nparts", [2, 4, 7])
+def test_backward_in_parts_with_overlapped_grad_sync(hip, nparts):
+    """distributed.OverlappedGradSync: backward as `nparts` runs of the reversed tape (pws_netg_backward_part), each run's
+    final layers unpacked on a second stream (all-reduced there when a process group exists).  Same gradients as the
+    one-call backward; every layer becomes final exactly once; earlier runs are not re-launched."""
+    import ctypes
+    from pwstablenet_amd import distributed as D
+    from pwstablenet_amd import functional as PF
+    net = make_net("W1", 16)
+    x = torch.from_numpy(synth.make_window(2, 31, 256, seed=4)).cuda()
+    fr = torch.from_numpy(synth.make_frames(2, 3, 256, 256, seed=5)).cuda()
+
+    def run():
+        net.zero_grad()
+        grids, resid = net(x)
+        (sum((PF.grid_sample(fr, g_) / 255).mean() for g_ in grids) + 0.1 * resid[2].abs().mean()).backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in net.parameters()]
+    ref = run()
+    sync = D.enable_overlapped_grad_sync(net, nparts=nparts)
+    got = run()
+    assert sync.collectives == 0   # no process group here: the collectives are skipped, the rest is the same path
+    for a, b in zip(got, ref):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) / scale < 1e-4   # fp32 atomics order in the weight-gradient kernels
+    net.module.grad_sync = None
+    # the C side's final-layer report: monotone, complete after the last run
+    L = hip.lib()
+    seen = None
+    for part in range(nparts):
+        mask = (ctypes.c_ubyte * 46)()
+        assert L.pws_netg_backward_part(None, None, None, 0, 31, 16, 0, None, 0, None, None, None, None, None, part, nparts, mask,
+                                        None) == 0
+        assert all(mask)   # n = 0: nothing to do, everything is final
+    assert L.pws_netg_backward_part(None, None, None, 1, 31, 16, 0, None, 0, None, None, None, None, None, 3, 2, None, None) == -22
+    del seen
