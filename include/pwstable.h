@@ -342,6 +342,16 @@ int pws_shape_loss_bwd(const float *resid, double c, const float *scale, float *
  * coef [nout][nq] device doubles */
 int pws_objective_finalize(const double *slots, int nq, const double *coef, int nout, float *out, pws_stream_t stream);
 
+/* ---- VGG-16 perceptual term (lib/utils.py:11-32): the 13 conv3x3+ReLU layers run on pws_conv2d_fwd /
+ * pws_conv2d_bwd_data (frozen weights: no weight gradient); these are the remaining pieces.  NHWC fp32. */
+/* nn.MaxPool2d(2, 2): y[n,h/2,w/2,c]; h, w even, c % 4 == 0 */
+int pws_maxpool2x2_fwd(const float *x, float *y, int n, int h, int w, int c, pws_stream_t stream);
+/* dx (overwritten) = dy routed to the first maximum of each window in row-major scan order (ATen's argmax), 0 elsewhere */
+int pws_maxpool2x2_bwd(const float *x, const float *dy, float *dx, int n, int h, int w, int c, pws_stream_t stream);
+/* nn.MSELoss pieces: slots[PWS_OBJ_SLOTS] (caller-zeroed doubles) += sum (a-b)^2 ;  ga = c * (*scale) * 2 (a-b) */
+int pws_sqdiff_sum(const float *a, const float *b, size_t count, double *slots, pws_stream_t stream);
+int pws_sqdiff_bwd(const float *a, const float *b, size_t count, float c, const float *scale, float *ga, pws_stream_t stream);
+
 /* ---------------------------------------------------------------- whole generator */
 /* Floats needed for all 46 packed layer weights + 46 biases of a generator (input_nc, ngf). */
 size_t pws_netg_packed_floats(int input_nc, int ngf);

@@ -98,3 +98,25 @@ def objective(grids1, resid1, grids2, resid2, image_unstable1, image_stable1, fe
     loss_g = loss_g1 + loss_g2 * lamd
     return {"loss_g": loss_g, "loss_mse": loss_mse, "loss_feature": loss_feature, "loss_delta": loss_delta,
             "loss_g2": loss_g2, "loss_pixel": loss_pixel, "fake1": fake1, "fake2": fake2}
+
+
+VGG16_CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M")
+
+
+def vgg16_features(params, x):
+    """``nn.Sequential(*list(vgg16.features)[:31])`` (lib/utils.py:14-15) as functional calls; params: [w, b] per conv in
+    order.  PARITY UNPINNED against the reference for this function: torchvision and its pretrained weights are absent here,
+    so tests run it with seeded random weights (same arithmetic, arbitrary weights)."""
+    i = 0
+    for v in VGG16_CFG:
+        if v == "M":
+            x = F.max_pool2d(x, 2, 2)
+        else:
+            x = F.relu(F.conv2d(x, params[i], params[i + 1], padding=1))
+            i += 2
+    return x
+
+
+def generator_loss(params, out_images, target_images):
+    """lib/utils.py:22-32: MSELoss between the VGG features of the two image batches."""
+    return F.mse_loss(vgg16_features(params, out_images), vgg16_features(params, target_images))

@@ -1,0 +1,137 @@
+// Small HBM-bound kernels of the VGG-16 perceptual term (reference lib/utils.py:11-32: nn.Sequential(*vgg16.features[:31])
+// -> 13 x (conv3x3 + ReLU, run by the conv kernels of this library) and 5 x MaxPool2d(2, 2); MSELoss between the features of
+// the warped frame and of the stable frame).  NHWC fp32, one lane per (output pixel, 4 channels).
+#include "common.h"
+
+namespace pws {
+
+// y[n,oy,ox,c] = max over the 2x2 window (H, W even)
+__global__ void __launch_bounds__(256) maxpool2x2_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int OH, int OW, int C4,
+                                                             size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i % C4);
+    const size_t op = i / C4;
+    const int ox = (int)(op % OW), oy = (int)((op / OW) % OH);
+    const size_t n = op / ((size_t)OW * OH);
+    const int W = 2 * OW, C = 4 * C4;
+    const float *p = x + ((n * 2 * OH + 2 * oy) * W + 2 * ox) * C + 4 * c4;
+    const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + C);
+    const float4 c = *reinterpret_cast<const float4 *>(p + (size_t)W * C), d = *reinterpret_cast<const float4 *>(p + (size_t)W * C + C);
+    float4 r;
+    r.x = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x)), r.y = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));
+    r.z = fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z)), r.w = fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w));
+    *reinterpret_cast<float4 *>(y + op * C + 4 * c4) = r;
+}
+
+// dx = dy routed to the FIRST maximum of the window in scan order (row-major), as ATen's saved argmax does; the other
+// three positions get 0 (dx is fully overwritten)
+__device__ __forceinline__ void route(float a, float b, float c, float d, float g, float &ga, float &gb, float &gc, float &gd) {
+    int k = 0;
+    float m = a;
+    if (b > m) m = b, k = 1;
+    if (c > m) m = c, k = 2;
+    if (d > m) m = d, k = 3;
+    ga = k == 0 ? g : 0.f, gb = k == 1 ? g : 0.f, gc = k == 2 ? g : 0.f, gd = k == 3 ? g : 0.f;
+}
+__global__ void __launch_bounds__(256) maxpool2x2_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                             float *__restrict__ dx, int OH, int OW, int C4, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i % C4);
+    const size_t op = i / C4;
+    const int ox = (int)(op % OW), oy = (int)((op / OW) % OH);
+    const size_t n = op / ((size_t)OW * OH);
+    const int W = 2 * OW, C = 4 * C4;
+    const size_t o = ((n * 2 * OH + 2 * oy) * W + 2 * ox) * C + 4 * c4;
+    const float *p = x + o;
+    const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + C);
+    const float4 c = *reinterpret_cast<const float4 *>(p + (size_t)W * C), d = *reinterpret_cast<const float4 *>(p + (size_t)W * C + C);
+    const float4 g = *reinterpret_cast<const float4 *>(dy + op * C + 4 * c4);
+    float4 ga, gb, gc, gd;
+    route(a.x, b.x, c.x, d.x, g.x, ga.x, gb.x, gc.x, gd.x);
+    route(a.y, b.y, c.y, d.y, g.y, ga.y, gb.y, gc.y, gd.y);
+    route(a.z, b.z, c.z, d.z, g.z, ga.z, gb.z, gc.z, gd.z);
+    route(a.w, b.w, c.w, d.w, g.w, ga.w, gb.w, gc.w, gd.w);
+    float *q = dx + o;
+    *reinterpret_cast<float4 *>(q) = ga, *reinterpret_cast<float4 *>(q + C) = gb;
+    *reinterpret_cast<float4 *>(q + (size_t)W * C) = gc, *reinterpret_cast<float4 *>(q + (size_t)W * C + C) = gd;
+}
+
+// slots += sum (a - b)^2 (fp32 per lane, fp64 per workgroup, one f64 atomic per workgroup into one of PWS_OBJ_SLOTS slots)
+__global__ void __launch_bounds__(256) sqdiff_sum_kernel(const float *__restrict__ a, const float *__restrict__ b, size_t count4,
+                                                         double *__restrict__ slots) {
+    __shared__ double red[4];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count4; i += (size_t)gridDim.x * 256) {
+        const float4 u = *reinterpret_cast<const float4 *>(a + i * 4), v = *reinterpret_cast<const float4 *>(b + i * 4);
+        const float dx = u.x - v.x, dy = u.y - v.y, dz = u.z - v.z, dw = u.w - v.w;
+        s += dx * dx + dy * dy + dz * dz + dw * dw;
+    }
+    double d = (double)s;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(slots + (blockIdx.x % PWS_OBJ_SLOTS), red[0] + red[1] + red[2] + red[3]);
+}
+
+// ga = c * scale * 2 (a - b)
+__global__ void __launch_bounds__(256) sqdiff_bwd_kernel(const float *__restrict__ a, const float *__restrict__ b, size_t count4, float c,
+                                                         const float *__restrict__ scale, float *__restrict__ ga) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count4) return;
+    if (scale) c *= *scale;
+    const float4 u = *reinterpret_cast<const float4 *>(a + i * 4), v = *reinterpret_cast<const float4 *>(b + i * 4);
+    *reinterpret_cast<float4 *>(ga + i * 4) = make_float4(2.f * c * (u.x - v.x), 2.f * c * (u.y - v.y), 2.f * c * (u.z - v.z), 2.f * c * (u.w - v.w));
+}
+
+static inline bool a16(const void *p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
+
+}  // namespace pws
+
+using namespace pws;
+
+extern "C" int pws_maxpool2x2_fwd(const float *x, float *y, int n, int h, int w, int c, pws_stream_t stream) {
+    PWS_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0 && h % 2 == 0 && w % 2 == 0 && c % 4 == 0,
+                "pws_maxpool2x2_fwd: h, w must be even and c a multiple of 4 (got %d x %d x %d)", h, w, c);
+    if (n == 0) return PWS_OK;
+    PWS_REQUIRE(x && y && a16(x) && a16(y), "pws_maxpool2x2_fwd: NULL or unaligned pointer");
+    const size_t total = (size_t)n * (h / 2) * (w / 2) * (c / 4);
+    ProfScope prof(KID_OBJECTIVE, 3.0 * total * 4, 20.0 * total * 4, as_stream(stream));
+    hipLaunchKernelGGL(maxpool2x2_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), x, y, h / 2, w / 2,
+                       c / 4, total);
+    return check_launch("maxpool2x2_fwd_kernel");
+}
+
+extern "C" int pws_maxpool2x2_bwd(const float *x, const float *dy, float *dx, int n, int h, int w, int c, pws_stream_t stream) {
+    PWS_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0 && h % 2 == 0 && w % 2 == 0 && c % 4 == 0,
+                "pws_maxpool2x2_bwd: h, w must be even and c a multiple of 4 (got %d x %d x %d)", h, w, c);
+    if (n == 0) return PWS_OK;
+    PWS_REQUIRE(x && dy && dx && a16(x) && a16(dy) && a16(dx), "pws_maxpool2x2_bwd: NULL or unaligned pointer");
+    const size_t total = (size_t)n * (h / 2) * (w / 2) * (c / 4);
+    ProfScope prof(KID_OBJECTIVE, 8.0 * total * 4, 36.0 * total * 4, as_stream(stream));
+    hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), x, dy, dx, h / 2,
+                       w / 2, c / 4, total);
+    return check_launch("maxpool2x2_bwd_kernel");
+}
+
+extern "C" int pws_sqdiff_sum(const float *a, const float *b, size_t count, double *slots, pws_stream_t stream) {
+    PWS_REQUIRE(count % 4 == 0, "pws_sqdiff_sum: count must be a multiple of 4");
+    if (count == 0) return PWS_OK;
+    PWS_REQUIRE(a && b && slots && a16(a) && a16(b), "pws_sqdiff_sum: NULL or unaligned pointer");
+    size_t blocks = (count / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sqdiff_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a, b, count / 4, slots);
+    return check_launch("sqdiff_sum_kernel");
+}
+
+extern "C" int pws_sqdiff_bwd(const float *a, const float *b, size_t count, float c, const float *scale, float *ga,
+                              pws_stream_t stream) {
+    PWS_REQUIRE(count % 4 == 0, "pws_sqdiff_bwd: count must be a multiple of 4");
+    if (count == 0) return PWS_OK;
+    PWS_REQUIRE(a && b && ga && a16(a) && a16(b) && a16(ga), "pws_sqdiff_bwd: NULL or unaligned pointer");
+    hipLaunchKernelGGL(sqdiff_bwd_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, as_stream(stream), a, b, count / 4, c,
+                       scale, ga);
+    return check_launch("sqdiff_bwd_kernel");
+}

@@ -122,6 +122,10 @@ SIGNATURES = {
     "pws_shape_loss_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "pws_shape_loss_bwd": (_I, [_P, ctypes.c_double, _P, _P, _I, _I, _I, _P]),
     "pws_objective_finalize": (_I, [_P, _I, _P, _I, _P, _P]),
+    "pws_maxpool2x2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "pws_maxpool2x2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "pws_sqdiff_sum": (_I, [_P, _P, _S, _P, _P]),
+    "pws_sqdiff_bwd": (_I, [_P, _P, _S, _F, _P, _P, _P]),
     "pws_prof_enable": (_I, [_I]),
     "pws_prof_collect": (_I, [ctypes.POINTER(PwsProfRecord), _I]),
     "pws_prof_kernel_name": (ctypes.c_char_p, [_I]),
