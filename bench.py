@@ -128,7 +128,7 @@ def cpu_baseline(batch_unused):
                       "min of %d runs after 1 warm-up, %d torch threads" % (runs, torch.get_num_threads())}
 
 
-def configs2_step_leg(net, dev, n_items, math, reps, sync=None, seed=500):
+def configs2_step_leg(net, dev, n_items, math, reps, sync=None, seed=500, perceptual=None):
     """BASELINE configs[2] / [3] step, per GPU: n_items item pairs -> 2*n_items generator forwards (is_training), 6 fused
     warp+L1 launches, temporal / feature / smoothness / fp64 shape terms, backward through all of it, [gradient
     all-reduce,] fused Adam (reference main_new.py:84-216 without GAN and without the VGG term, which needs torchvision
@@ -144,11 +144,11 @@ def configs2_step_leg(net, dev, n_items, math, reps, sync=None, seed=500):
     batch = [torch.from_numpy(t).repeat((rep,) + (1,) * (t.ndim - 1))[:n_items].to(dev) for t in small]
     obj = StabObjective(batchSize=n_items)
     opt = Adam(net.parameters(), lr=1e-6, betas=(0.5, 0.999))
-    out = train_step(net, opt, batch, obj, sync_gradients=sync)   # warm-up (allocations, weight re-pack)
+    out = train_step(net, opt, batch, obj, sync_gradients=sync, perceptual=perceptual)   # warm-up (allocations, weight re-pack)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
-        out = train_step(net, opt, batch, obj, sync_gradients=sync)
+        out = train_step(net, opt, batch, obj, sync_gradients=sync, perceptual=perceptual)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     loss = float(out.loss_g.detach())
@@ -227,6 +227,20 @@ def bf16_legs(net, x, frames, out_fp32, a, PF, A, synth):
             "frac_bf16_peak": round(64 / dt * GFLOP_PER_SAMPLE_TRAIN / 1e3 / PEAK_BF16_TFLOPS, 4), "loss_g": round(loss, 4)}
     except Exception as e:  # an extra leg must never cost the headline line
         train["configs2_bf16_batch32"] = {"error": str(e)[:200]}
+    # the same step with the VGG-16 perceptual term of train() (main_new.py:191-192) on top: 4 x 64 VGG forwards (3 stages of
+    # warped frames + the stable frames) and the data-gradient backward of the 3 x 64, bf16 math, random VGG weights
+    try:
+        from pwstablenet_amd.perceptual import GeneratorLoss, VGG16Features, perceptual_term
+        crit = GeneratorLoss(VGG16Features("bf16").init_random(0)).to(x.device)
+        dt, loss = configs2_step_leg(net, x.device, 32, "bf16", 2, perceptual=perceptual_term(crit))
+        vgg_gf = 64 * (4 * 40.1 + 3 * 40.1)   # fwd of 4 x 64 images + dgrad of 3 x 64 (conv1_1's input gradient included)
+        train["configs2_bf16_batch32_with_vgg"] = {
+            "workload": "configs2_bf16_batch32 + VGG-16 features[:31] perceptual MSE per stage and branch (frozen random weights)",
+            "items_per_s": round(32 / dt, 1), "ms_per_step": round(1e3 * dt, 2),
+            "tflops": round((64 * GFLOP_PER_SAMPLE_TRAIN + vgg_gf) / dt / 1e3, 1)}
+        del crit
+    except Exception as e:
+        train["configs2_bf16_batch32_with_vgg"] = {"error": str(e)[:200]}
     net.module.set_math("fp32")
     net.zero_grad(set_to_none=True)
     res["training_step"] = {"workload": "batch=%d: netG(x) is_training + 3 grid_sample + L1 + backward + fused Adam, one netG "
