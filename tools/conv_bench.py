@@ -12,6 +12,7 @@ from pwstablenet_amd import hipabi as A  # noqa: E402
 
 def bench(kname, n, h, w, cin, cout, wino, bf16=False):
     L, st = A.lib(), A.current_stream()
+    L.pws_set_option(100, int(os.environ.get("PWS_EXPERIMENT", "0")))
     kind = getattr(A, kname)
     k = {"CONV_K3S1": 3, "CONV_K3S2": 3, "CONVT_K3S1": 3, "CONVT_K4S2": 4, "CONV_K5S1": 5}[kname]
     wt = torch.randn((cout, cin, k, k) if not kname.startswith("CONVT") else (cin, cout, k, k), device="cuda") / (cin * k) ** 0.5
