@@ -318,6 +318,28 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
+    # 720p leg of the metric on EVERY rank (configs[4] shape, frame-sharded, no collective): netG on 256x256 windows + fused
+    # field-resize+warp of 1280x720 RGB frames (reference main_new.py:697-716), frames resident in HBM
+    f720 = torch.rand((B, 3, 720, 1280), device=dev) * 255
+
+    def step720():
+        with torch.no_grad():
+            return PF.upsample_grid_sample(f720, net(x, False))
+    for _ in range(2):
+        step720()
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(a.steps):
+        o720 = step720()
+    torch.cuda.synchronize()
+    dt720 = time.perf_counter() - t1
+    barrier()
+    assert torch.isfinite(o720).all()
+    del o720
+    if world > 1:
+        t = torch.tensor([dt720], device=ctl_device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt720 = float(t.item())
     # Per-kernel events cannot be recorded inside a graph replay, and in the timed region two queues overlap kernels
     # (stage k+1's encoder beside stage k's decoder), so the per-kernel roofline comes from an instrumented repetition of
     # the same K steps right after the timed region: eager launches on ONE queue, each bracketed by hipEvents.
@@ -421,20 +443,8 @@ def main():
         line["roofline_grid_sample"]["device_copy_same_bytes_gb_per_s"] = round(by / (cp_ms * 1e-3) / 1e9, 1)
         line["roofline_grid_sample"]["frac_of_measured_copy_rate"] = round(gbs / (by / (cp_ms * 1e-3) / 1e9), 4)
         del big, base, smooth, noisy, cp_src, cp_dst
-        # 720p leg of the metric (configs[4] shape, one GPU's share): netG on 256x256 windows + fused field-resize+warp of
-        # 1280x720 RGB frames (reference main_new.py:697-716), frames resident in HBM (PCIe-inclusive rate: DESIGN.md)
-        f720 = torch.rand((B, 3, 720, 1280), device=dev) * 255
+        # roofline of the fused 720p warp (the timing of the leg itself ran on every rank above)
         with torch.no_grad():
-            def step720():
-                return PF.upsample_grid_sample(f720, net(x, False))
-            for _ in range(2):
-                step720()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(a.steps):
-                o720 = step720()
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
             A.lib().pws_prof_enable(1)
             for _ in range(5):
                 step720()
@@ -442,10 +452,9 @@ def main():
         r = [x_ for x_ in A.prof_collect() if x_[0] == "upsample_grid_sample_fwd_kernel"]
         ms = sorted(x_[4] for x_ in r)[len(r) // 2]
         gbs = r[0][3] / (ms * 1e-3) / 1e9
-        assert torch.isfinite(o720).all()
-        line["value_720p"] = {"value": round(B * a.steps / dt, 2), "unit": "frames/s", "n_gpus": 1,
-                              "workload": "batch=%d: netG(31x256x256 window, fp32) + fused upsample(256^2 field)+grid_sample of "
-                                          "3x720x1280 fp32 frames" % B,
+        line["value_720p"] = {"value": round(world * B * a.steps / dt720, 2), "unit": "frames/s", "n_gpus": world,
+                              "workload": "batch=%d per GPU: netG(31x256x256 window, fp32) + fused upsample(256^2 field)+grid_sample "
+                                          "of 3x720x1280 fp32 frames; frame-sharded, no collective" % B,
                               "roofline_warp": {"kernel": "upsample_grid_sample_fwd_kernel", "bound": "hbm",
                                                 "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                                 "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_us": round(1e3 * ms, 2),
