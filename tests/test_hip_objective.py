@@ -323,3 +323,31 @@ def test_objective_refuses_cpu_tensors_and_bad_shapes(hip):
     check_features_host(torch.zeros((2, 4, 6)))
     with pytest.raises(IndexError):
         check_features_host(torch.full((2, 4, 6), 1.5))
+
+
+def test_batched_forwards_equal_the_reference_two_forward_loop(hip):
+    """The reference runs netG on the item and on the item one frame later (main_new.py:101,112); train_step runs both as
+    one batch of 2n windows.  Without BatchNorm the samples are independent: same fields, and the same parameter gradients
+    as two forwards + one backward."""
+    from pwstablenet_amd import functional as PF
+    net = _net("W1", 16)
+    x1 = torch.from_numpy(synth.make_window(2, 31, 256, seed=1)).cuda()
+    x2 = torch.from_numpy(synth.make_window(2, 31, 256, seed=2)).cuda()
+    fr = torch.from_numpy(synth.make_frames(4, 3, 256, 256, seed=3)).cuda()
+
+    def loss_of(grids, frames):
+        return sum((PF.grid_sample(frames, g_) / 255).abs().mean() for g_ in grids)
+    net.zero_grad()
+    ga, _ = net(x1)
+    gb, _ = net(x2)
+    (loss_of(ga, fr[:2]) * 0.5 + loss_of(gb, fr[2:]) * 0.5).backward()
+    ref_grads = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad()
+    gc, _ = net(torch.cat([x1, x2], 0))
+    for k in range(3):
+        np.testing.assert_allclose(gc[k][:2].detach().cpu().numpy(), ga[k].detach().cpu().numpy(), atol=2e-6)
+        np.testing.assert_allclose(gc[k][2:].detach().cpu().numpy(), gb[k].detach().cpu().numpy(), atol=2e-6)
+    loss_of(gc, fr).backward()
+    for p, r in zip(net.parameters(), ref_grads):
+        scale = float(r.abs().max()) + 1e-12
+        assert float((p.grad - r).abs().max()) / scale < 2e-3
