@@ -515,26 +515,28 @@ def main():
                                                        "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_us": round(1e3 * ms, 2),
                                                        "bytes_per_launch": r[0][3]}}
             del u720
-            # configs[4] shape on one GPU, PCIe inclusive: 96 uint8 720p frames + their 256x256 gray planes in PINNED HOST memory
-            # -> VideoStabilizer (H2D on a side stream, batched windows, netG fp32, fused u8 warp, D2H on a third stream) -> host
+            # configs[4] shape on one GPU, PCIe inclusive, the whole device side of process(): 192 decoded uint8 720p frames in
+            # PINNED HOST memory -> VideoStabilizer.run_video (H2D per 64-frame chunk on a side stream, gray + INTER_AREA window
+            # planes computed on the device from the uploaded frames, batched windows, netG fp32, fused u8 warp, the 2x
+            # INTER_AREA down-scale of the output as main_new.py:723, D2H on a third stream) -> 640x360 frames in host memory
             try:
                 from pwstablenet_amd.stream import VideoStabilizer
-                T = 96
-                gray_h = torch.from_numpy(synth.make_window(1, T, 256, seed=5)[0]).pin_memory()
+                T = 192
                 u8_h = torch.randint(0, 256, (T, 720, 1280, 3), dtype=torch.uint8).pin_memory()
                 vs = VideoStabilizer(net, batch=B, swap_rb=True)
-                vs.run(gray_h[:2 * B], u8_h[:2 * B])
+                vs.run_video(u8_h[:4 * B], chunk=2 * B, half_size_output=True)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                out_h = vs.run(gray_h, u8_h)
+                out_h = vs.run_video(u8_h, chunk=64, half_size_output=True)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t1
                 line["value_720p_stream_u8"] = {"value": round(T / dt, 1), "unit": "frames/s", "n_gpus": 1,
-                                                "workload": "%d uint8 1280x720 frames from pinned host memory to pinned host memory "
-                                                            "(2.76 MB each way per frame over PCIe), batch %d windows per netG call" % (T, B),
-                                                "pcie_gb_per_s_each_way": round(T * 2.7648e-3 / dt, 2)}
-                assert not out_h.is_cuda
-                del gray_h, u8_h, out_h
+                                                "workload": "%d uint8 1280x720 frames, pinned host -> device (2.76 MB per frame) -> gray+"
+                                                            "INTER_AREA window planes on the device -> batch %d windows per netG call -> "
+                                                            "fused u8 warp -> 2x INTER_AREA -> pinned host (0.69 MB per frame)" % (T, B),
+                                                "pcie_h2d_gb_per_s": round(T * 2.7648e-3 / dt, 2)}
+                assert not out_h.is_cuda and tuple(out_h.shape) == (T, 360, 640, 3)
+                del u8_h, out_h
             except Exception as e:  # an extra leg must never cost the headline line
                 line["value_720p_stream_u8"] = {"error": str(e)[:200]}
         if not a.no_extra and a.math == "fp32" and world == 1:

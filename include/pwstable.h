@@ -286,6 +286,15 @@ int pws_upsample_grid_sample_fwd(const float *input, const float *field, float *
 int pws_upsample_grid_sample_u8(const unsigned char *frame_hwc, const float *field, unsigned char *out_hwc, int n, int h, int w,
                                 int fh, int fw, int swap_rb, int align_corners, pws_stream_t stream);
 
+/* The image processing either side of the path in the reference's video loop, on the device (csrc/frameio.hip; follows
+ * OpenCV 4.x's algorithms -- cv2 is not available to pin against):
+ * out[n,oh,ow] = cv2.resize(cv2.cvtColor(frame, COLOR_BGR2GRAY), (ow, oh), INTER_AREA) [/255*2-1 when normalize]
+ * (main_new.py:639-643,653-667); frames [n,h,w,3] uint8 as cv2 delivers them (swap_rb: they are RGB instead). */
+int pws_gray_area_u8(const unsigned char *frames_hwc, float *out, int n, int h, int w, int oh, int ow, int normalize, int swap_rb,
+                     pws_stream_t stream);
+/* out[n,h/2,w/2,3] = cv2.resize(in, (w/2, h/2), INTER_AREA) [+ R<->B swap] (main_new.py:723-725) */
+int pws_area_half_u8(const unsigned char *in_hwc, unsigned char *out_hwc, int n, int h, int w, int swap_rb, pws_stream_t stream);
+
 /* Adam (no weight decay / amsgrad) on a flat fp32 buffer, in place; step counts from 1. */
 int pws_adam_step(float *p, const float *g, float *m, float *v, size_t count, float lr, float beta1,
                   float beta2, float eps, int step, pws_stream_t stream);

@@ -126,6 +126,8 @@ SIGNATURES = {
     "pws_maxpool2x2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "pws_sqdiff_sum": (_I, [_P, _P, _S, _P, _P]),
     "pws_sqdiff_bwd": (_I, [_P, _P, _S, _F, _P, _P, _P]),
+    "pws_gray_area_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "pws_area_half_u8": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "pws_prof_enable": (_I, [_I]),
     "pws_prof_collect": (_I, [ctypes.POINTER(PwsProfRecord), _I]),
     "pws_prof_kernel_name": (ctypes.c_char_p, [_I]),

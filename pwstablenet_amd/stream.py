@@ -16,6 +16,37 @@ host<->device round trip per frame.  Here:
 import torch
 
 from . import functional as PF
+from . import hipabi as A
+
+
+def window_planes(frames_hwc, size=256, frames_are_rgb=False, out=None):
+    """``cv2.resize(cv2.cvtColor(frame, COLOR_BGR2GRAY), (size, size), INTER_AREA) / 255 * 2 - 1`` for a batch of decoded
+    frames (reference main_new.py:639-643,653-667) on the device: (T, H, W, 3) uint8 -> (T, size, size) float32."""
+    A.require_cuda(frames_hwc, dtype=torch.uint8)
+    if frames_hwc.dim() != 4 or frames_hwc.shape[3] != 3:
+        raise ValueError("window_planes: frames must be (T, H, W, 3) uint8, got %s" % (tuple(frames_hwc.shape),))
+    frames_hwc = frames_hwc.contiguous()
+    t, h, w, _ = frames_hwc.shape
+    if out is None:
+        out = torch.empty((t, size, size), device=frames_hwc.device, dtype=torch.float32)
+    A.require_cuda(out)
+    if tuple(out.shape) != (t, size, size) or not out.is_contiguous():
+        raise ValueError("window_planes: out must be a contiguous (T, %d, %d) float32 tensor" % (size, size))
+    A.check(A.lib().pws_gray_area_u8(A.ptr(frames_hwc), A.ptr(out), t, h, w, size, size, 1, int(bool(frames_are_rgb)),
+                                     A.current_stream()), "pws_gray_area_u8")
+    return out
+
+
+def area_half(frames_hwc, swap_rb=False):
+    """``cv2.cvtColor(cv2.resize(frame, (W/2, H/2), INTER_AREA), COLOR_BGR2RGB)`` of the output frames (main_new.py:723-725;
+    the swap is optional): (T, H, W, 3) uint8 -> (T, H/2, W/2, 3) uint8."""
+    A.require_cuda(frames_hwc, dtype=torch.uint8)
+    frames_hwc = frames_hwc.contiguous()
+    t, h, w, _ = frames_hwc.shape
+    out = torch.empty((t, h // 2, w // 2, 3), device=frames_hwc.device, dtype=torch.uint8)
+    A.check(A.lib().pws_area_half_u8(A.ptr(frames_hwc), A.ptr(out), t, h, w, int(bool(swap_rb)), A.current_stream()),
+            "pws_area_half_u8")
+    return out
 
 
 def _windows(gray_padded, start, count, period):
@@ -108,4 +139,66 @@ class VideoStabilizer:
                 out[s:e].copy_(warped)
         if on_host:
             d2h.synchronize()
+        return out
+
+    @torch.no_grad()
+    def run_video(self, frames, chunk=64, half_size_output=False, frames_are_rgb=False):
+        """The whole device side of the reference's ``process()`` loop for one decoded clip: ``frames`` (T, H, W, 3) uint8 as
+        cv2 delivers them, in (pinned) host memory or on the device.  Per chunk of ``chunk`` frames: H2D on a side stream,
+        gray + INTER_AREA 256x256 window planes computed there from the uploaded frames (so nothing but the uint8 frames
+        crosses PCIe and the host does no per-frame image processing), the generator on batched windows, the fused uint8
+        resize+warp, optionally the 2x INTER_AREA down-scale of the output (main_new.py:723), D2H on a third stream.  Chunk
+        k+1 uploads while chunk k computes; window planes are kept for the whole clip (256 KB per frame), frames per chunk.
+        Returns (T, H, W, 3) -- or (T, H/2, W/2, 3) -- uint8 on the inputs' side."""
+        T = frames.shape[0]
+        on_host = not frames.is_cuda
+        dev = self.device
+        half = self.period // 2
+        h, w = frames.shape[1], frames.shape[2]
+        oshape = (T, h // 2, w // 2, 3) if half_size_output else (T, h, w, 3)
+        out = torch.empty(oshape, dtype=torch.uint8, pin_memory=True) if on_host else torch.empty(oshape, dtype=torch.uint8, device=dev)
+        if T == 0:
+            return out
+        compute = torch.cuda.current_stream(dev)
+        up, down = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        gray_all = torch.empty((T, 256, 256), device=dev, dtype=torch.float32)
+        chunks = [(s, min(T, s + chunk)) for s in range(0, T, chunk)]
+        up.wait_stream(compute)   # gray_all was allocated on the compute stream
+
+        def upload(c):
+            s, e = chunks[c]
+            with torch.cuda.stream(up):
+                buf = frames[s:e].to(dev, non_blocking=True) if on_host else frames[s:e]
+                window_planes(buf, 256, frames_are_rgb, out=gray_all[s:e])
+                ev = torch.cuda.Event()
+                ev.record(up)
+            return buf, ev
+        staged, uploaded = {}, 0
+        for c, (s, e) in enumerate(chunks):
+            # a chunk's windows reach `half` frames past its end: every chunk that holds one of those frames must be on the
+            # device (and its planes computed) first; one chunk further ahead keeps the upload stream busy during this compute
+            need = min(T, e + half)
+            while uploaded < len(chunks) and (chunks[uploaded][0] < need or uploaded <= c + 1):
+                staged[uploaded] = upload(uploaded)
+                uploaded += 1
+            for k in range(c, uploaded):
+                if chunks[k][0] < need:
+                    compute.wait_event(staged[k][1])
+            buf, ev = staged.pop(c)
+            hl, hr = min(half, s), min(half, T - e)
+            warped = self.run(gray_all[s - hl:e + hr], buf, halo_left=hl, halo_right=hr)
+            if half_size_output:
+                warped = area_half(warped)
+            if on_host:
+                buf.record_stream(compute)
+                done = torch.cuda.Event()
+                done.record(compute)
+                with torch.cuda.stream(down):
+                    down.wait_event(done)
+                    out[s:e].copy_(warped, non_blocking=True)
+                warped.record_stream(down)
+            else:
+                out[s:e].copy_(warped)
+        if on_host:
+            down.synchronize()
         return out

@@ -122,3 +122,61 @@ def test_stream_uint8_frames(hip):
     assert (got != want).float().mean().item() < 5e-3
     got_h = vs.run(gray.cpu().pin_memory(), u8.cpu().pin_memory())
     assert not got_h.is_cuda and torch.equal(got_h, got.cpu())
+
+
+def _clip_u8(T, H, W, seed):
+    """A shaky clip: one smooth scene under small per-frame translations + a little sensor noise, (T, H, W, 3) uint8."""
+    rs = np.random.RandomState(seed)
+    base = synth.smooth_frames_u8(1, T, H, W, seed)[0]                                  # (T, H, W): consecutive = shifted scene
+    col = np.stack([base * 0.9, base * 1.0, base * 0.8], -1) + rs.randint(-3, 4, (T, H, W, 3))
+    return np.clip(col, 0, 255).astype(np.uint8)
+
+
+def test_window_planes_and_area_half_vs_opencv_restatement(hip):
+    """gray + INTER_AREA window planes and the 2x output down-scale against oracle/frameio_ref.py (the numpy restatement of
+    OpenCV's cvtColor / resize algorithms; cv2 itself is not available here).  Same float operations in the same order:
+    bit-exact."""
+    from oracle import frameio_ref as R
+    from pwstablenet_amd.stream import area_half, window_planes
+    for (H, W) in ((720, 1280), (300, 412)):            # x5 / x2.8125 (the reference's 720p) and a ratio irrational in both axes
+        clip = _clip_u8(2, H, W, 7)
+        clip[0] = np.random.RandomState(1).randint(0, 256, (H, W, 3))   # white noise: every rounding case
+        got = window_planes(torch.from_numpy(clip).cuda()).cpu().numpy()
+        want = np.stack([R.window_plane(f) for f in clip])
+        assert got.shape == (2, 256, 256)
+        lvl = np.abs(got - want) * 127.5                                  # in gray levels
+        assert lvl.max() < 1e-3, (H, W, lvl.max(), float(np.mean(lvl > 1e-3)))
+    rgb = window_planes(torch.from_numpy(clip[..., ::-1].copy()).cuda(), frames_are_rgb=True).cpu().numpy()
+    assert np.array_equal(rgb, got)
+    half = area_half(torch.from_numpy(clip).cuda(), swap_rb=True).cpu().numpy()
+    want = np.stack([R.resize_area_half_u8(f)[..., ::-1] for f in clip])
+    assert np.array_equal(half, want)
+    L = hip.lib()
+    assert L.pws_gray_area_u8(None, None, 1, 100, 100, 256, 256, 1, 0, None) == -22     # up-scaling is refused
+    assert L.pws_area_half_u8(None, None, 1, 101, 100, 0, None) == -22
+
+
+@pytest.mark.parametrize("on_host,half_out", [(False, False), (True, True)])
+def test_run_video_equals_run_on_host_prepared_planes(hip, on_host, half_out):
+    """run_video (frames only: window planes computed on the device per uploaded chunk, chunk k+1 uploading while chunk k
+    computes) == run() on planes prepared the reference's way on the host (restated OpenCV steps)."""
+    from oracle import frameio_ref as R
+    from pwstablenet_amd.stream import VideoStabilizer
+    net = make_net()
+    T, H, W = 37, 288, 320
+    clip = _clip_u8(T, H, W, 11)
+    planes = torch.from_numpy(np.stack([R.window_plane(f) for f in clip])).cuda()
+    frames = torch.from_numpy(clip)
+    vs = VideoStabilizer(net, batch=4, swap_rb=True)
+    want = vs.run(planes, frames.cuda()).cpu().numpy()
+    if half_out:
+        want = np.stack([R.resize_area_half_u8(f) for f in want])
+    src = frames.pin_memory() if on_host else frames.cuda()
+    got = vs.run_video(src, chunk=10, half_size_output=half_out)
+    assert got.is_cuda != on_host and got.dtype == torch.uint8
+    got = got.cpu().numpy()
+    assert got.shape == want.shape
+    # chunks of 10 end in a batch of 2 windows where run() had 4: another tile selection inside the generator, fields equal to
+    # ~1e-6, and astype(uint8) truncation turns that into one gray level at the rare pixel that sits on an integer
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1 and np.mean(d > 0) < 1e-3, (d.max(), float(np.mean(d > 0)))
