@@ -361,6 +361,19 @@ int pws_maxpool2x2_bwd(const float *x, const float *dy, float *dx, int n, int h,
 int pws_sqdiff_sum(const float *a, const float *b, size_t count, double *slots, pws_stream_t stream);
 int pws_sqdiff_bwd(const float *a, const float *b, size_t count, float c, const float *scale, float *ga, pws_stream_t stream);
 
+/* ---- training-mode BatchNorm2d + activation (the use_BN variant, lib/networks_cascading.py:253-341: conv -> BatchNorm2d ->
+ * LeakyReLU / ReLU in every block), NHWC fp32 [pixels][c], any c.  ws: pws_bn_ws_bytes(c) bytes of scratch.
+ * fwd: stats[2c] = (batch mean, 1/sqrt(biased var + eps)) saved for backward; y = act(gamma * xhat + beta); running_mean /
+ *      running_var (nullable pair) updated `repeat` times with momentum and the UNBIASED variance, as torch does per call.
+ * bwd: dy is overwritten by dz; dgamma / dbeta (nullable) are ACCUMULATED (a module used by several stages adds up).
+ * pixels == 1 is refused like torch ("Expected more than 1 value per channel when training"). */
+size_t pws_bn_ws_bytes(int c);
+int pws_bn_train_fwd(const float *z, size_t pixels, int c, const float *gamma, const float *beta, int act, float *y, float *stats,
+                     float *running_mean, float *running_var, float momentum, float eps, int repeat, void *ws, size_t ws_bytes,
+                     pws_stream_t stream);
+int pws_bn_train_bwd(float *dy, const float *y, const float *z, const float *stats, const float *gamma, int act, size_t pixels, int c,
+                     float *dgamma, float *dbeta, void *ws, size_t ws_bytes, pws_stream_t stream);
+
 /* ---------------------------------------------------------------- whole generator */
 /* Floats needed for all 46 packed layer weights + 46 biases of a generator (input_nc, ngf). */
 size_t pws_netg_packed_floats(int input_nc, int ngf);

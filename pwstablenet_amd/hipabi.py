@@ -128,6 +128,9 @@ SIGNATURES = {
     "pws_sqdiff_bwd": (_I, [_P, _P, _S, _F, _P, _P, _P]),
     "pws_gray_area_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "pws_area_half_u8": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "pws_bn_ws_bytes": (_S, [_I]),
+    "pws_bn_train_fwd": (_I, [_P, _S, _I, _P, _P, _I, _P, _P, _P, _P, _F, _F, _I, _P, _S, _P]),
+    "pws_bn_train_bwd": (_I, [_P, _P, _P, _P, _P, _I, _S, _I, _P, _P, _P, _S, _P]),
     "pws_prof_enable": (_I, [_I]),
     "pws_prof_collect": (_I, [ctypes.POINTER(PwsProfRecord), _I]),
     "pws_prof_kernel_name": (ctypes.c_char_p, [_I]),
