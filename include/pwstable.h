@@ -408,6 +408,21 @@ int pws_netg_backward_part(const float *packed, const float *packed_dgrad, const
                            int align_corners, void *ws, size_t ws_bytes, const float *resid, const float *thetas,
                            const float *g_grids, const float *g_resid, float *dpacked, int part, int nparts,
                            unsigned char *final_mask, pws_stream_t stream);
+/* ---- use_BN=True training (lib/cfg.py:37; lib/networks_cascading.py:253-341: BatchNorm2d after every conv, batch statistics).
+ * bn_params / bn_running / dbn: flat buffers of pws_netg_bn_floats() floats, per layer in state-dict order
+ * [gamma(cout) | beta(cout)], [running_mean | running_var], [dgamma | dbeta].  The forward is the is_training one (6 fields) and
+ * updates bn_running (nullable) with `momentum` once per call of a module, as torch does (down_bottom1, which the reference
+ * evaluates twice on the same input, is computed once and updated twice); n >= 2 (the theta head has one value per sample and
+ * channel).  `packed` holds the raw (un-folded) conv weights.  fp32 math / storage only; arena:
+ * pws_netg_train_workspace_bytes_bn.  dpacked's bias entries stay zero: a bias in front of a BatchNorm has no gradient. */
+size_t pws_netg_bn_floats(int input_nc, int ngf);
+size_t pws_netg_train_workspace_bytes_bn(int n, int input_nc, int ngf);
+int pws_netg_forward_bn(const float *packed, const float *bn_params, float *bn_running, float momentum, float eps, const float *x,
+                        int n, int input_nc, int ngf, int align_corners, void *ws, size_t ws_bytes, float *grids, float *resid,
+                        float *thetas, pws_stream_t stream);
+int pws_netg_backward_bn(const float *packed, const float *packed_dgrad, const float *bn_params, float eps, const float *x, int n,
+                         int input_nc, int ngf, int align_corners, void *ws, size_t ws_bytes, const float *resid, const float *thetas,
+                         const float *g_grids, const float *g_resid, float *dpacked, float *dbn, pws_stream_t stream);
 /* grads: HOST array of 92 DEVICE pointers (torch layouts, state-dict order), overwritten; a layer whose weight AND bias
  * pointers are NULL is skipped. */
 int pws_netg_unpack_grads(const float *dpacked, float *const *grads, int input_nc, int ngf, pws_stream_t stream);

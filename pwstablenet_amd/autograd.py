@@ -102,6 +102,110 @@ class _NetGInferNoGrad(torch.autograd.Function):
                            "call netG(x) (is_training=True) to train")
 
 
+# calls of each module per forward of the reference (lib/networks_cascading.py:152-237): nn.BatchNorm2d counts them
+def _bn_uses(net):
+    uses = []
+    for ls in net._specs:
+        block = ls.name.split(".")[0]
+        if block in ("out", "flatten", "linear"):
+            uses.append(3)
+        elif block.startswith(("down_bottom", "up_bottom")):
+            uses.append(2)
+        else:
+            uses.append(1)
+    return uses
+
+
+class _NetGTrainBN(torch.autograd.Function):
+    """use_BN=True in train() mode: the whole forward / backward through pws_netg_forward_bn / pws_netg_backward_bn (BatchNorm2d
+    with batch statistics after every conv; running statistics updated in place as nn.BatchNorm2d does)."""
+
+    @staticmethod
+    def forward(ctx, net_ref, input1, *params):
+        net = net_ref[0]
+        A.require_cuda(input1)
+        L, st = A.lib(), A.current_stream()
+        x = input1.contiguous()
+        n, dev = x.shape[0], x.device
+        if n < 2:
+            raise ValueError("Expected more than 1 value per channel when training (use_BN=True: the theta head normalises over "
+                             "the batch), got batch size %d" % n)
+        bns = net._bn_layers()
+        packed = net.packed_weights(raw=True)
+        with torch.no_grad():
+            bn_params = torch.cat([t.detach().reshape(-1) for bn in bns for t in (bn.weight, bn.bias)]).contiguous()
+            running = torch.cat([t.reshape(-1) for bn in bns for t in (bn.running_mean, bn.running_var)]).contiguous()
+        assert bn_params.numel() == L.pws_netg_bn_floats(net.input_nc, net.ngf)
+        nbytes = L.pws_netg_train_workspace_bytes_bn(n, net.input_nc, net.ngf)
+        ws = torch.empty(nbytes + 256, device=dev, dtype=torch.uint8)
+        ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+        ws_bytes = ws.numel() - (ws_ptr - ws.data_ptr())
+        grids = torch.empty((3, n, 256, 256, 2), device=dev, dtype=torch.float32)
+        resid = torch.empty((3, n, 256, 256, 2), device=dev, dtype=torch.float32)
+        thetas = torch.empty((3, n, 6), device=dev, dtype=torch.float32)
+        net._apply_math("fp32", "fp32")
+        eps, mom = float(bns[0].eps), float(bns[0].momentum if bns[0].momentum is not None else 0.1)
+        A.check(L.pws_netg_forward_bn(A.ptr(packed), A.ptr(bn_params), A.ptr(running), mom, eps, A.ptr(x), n, net.input_nc, net.ngf, 0,
+                                      ctypes.c_void_p(ws_ptr), ws_bytes, A.ptr(grids), A.ptr(resid), A.ptr(thetas), st),
+                "pws_netg_forward_bn")
+        with torch.no_grad():   # running statistics back into the modules (plumbing), call counters as nn.BatchNorm2d keeps them
+            off = 0
+            for bn, uses in zip(bns, _bn_uses(net)):
+                c = bn.num_features
+                bn.running_mean.copy_(running[off:off + c])
+                bn.running_var.copy_(running[off + c:off + 2 * c])
+                bn.num_batches_tracked += uses
+                off += 2 * c
+        net.last_thetas = thetas
+        ctx.net_ref = net_ref
+        ctx.saved = dict(x=x, ws=ws, ws_ptr=ws_ptr, ws_bytes=ws_bytes, resid=resid, thetas=thetas, packed=packed, bn_params=bn_params,
+                         eps=eps)
+        return (grids[0], grids[1], grids[2], resid[0], resid[1], resid[2])
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        net, sv = ctx.net_ref[0], ctx.saved
+        if sv is None:
+            raise RuntimeError("pwstablenet_amd: backward through the generator twice (the activation arena was released)")
+        n, dev = sv["x"].shape[0], sv["x"].device
+
+        def stack(gs):
+            if all(g is None for g in gs):
+                return None
+            return torch.stack([g.contiguous() if g is not None else torch.zeros((n, 256, 256, 2), device=dev) for g in gs])
+        g_grids, g_resid = stack(gouts[0:3]), stack(gouts[3:6])
+        nconv = len(net._ordered_params())
+        if g_grids is None and g_resid is None:
+            return (None, None) + (None,) * (2 * nconv)
+        L, st = A.lib(), A.current_stream()
+        packed, packed_dg = sv["packed"], net.packed_dgrad_weights()
+        dpacked = torch.empty_like(packed)
+        dbn = torch.empty_like(sv["bn_params"])
+        net._apply_math("fp32", "fp32")
+        A.check(L.pws_netg_backward_bn(A.ptr(packed), A.ptr(packed_dg), A.ptr(sv["bn_params"]), sv["eps"], A.ptr(sv["x"]), n, net.input_nc,
+                                       net.ngf, 0, ctypes.c_void_p(sv["ws_ptr"]), sv["ws_bytes"], A.ptr(sv["resid"]), A.ptr(sv["thetas"]),
+                                       A.ptr(g_grids), A.ptr(g_resid), A.ptr(dpacked), A.ptr(dbn), st), "pws_netg_backward_bn")
+        params = net._ordered_params()
+        grads = [torch.empty_like(p) for p in params]
+        ptrs = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+        A.check(L.pws_netg_unpack_grads(A.ptr(dpacked), ptrs, net.input_nc, net.ngf, st), "pws_netg_unpack_grads")
+        bn_grads, off = [], 0
+        for bn in net._bn_layers():
+            c = bn.num_features
+            bn_grads += [dbn[off:off + c].clone(), dbn[off + c:off + 2 * c].clone()]
+            off += 2 * c
+        ctx.saved = None
+        return (None, None) + tuple(grads) + tuple(bn_grads)
+
+
+def netg_apply_bn(net, input1):
+    if input1.requires_grad:
+        raise NotImplementedError("pwstablenet_amd: gradient wrt the input window is not provided (the window is data)")
+    params = net._ordered_params() + [t for bn in net._bn_layers() for t in (bn.weight, bn.bias)]
+    out = _NetGTrainBN.apply([net], input1, *params)
+    return list(out[:3]), list(out[3:])
+
+
 def netg_apply(net, input1, is_training):
     params = net._ordered_params()
     if input1.requires_grad:

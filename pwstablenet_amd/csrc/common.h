@@ -71,6 +71,18 @@ struct ProfScope {  // brackets one launch with events when profiling is enabled
 struct ProfHint {
     double flops, bytes;
 };
+// use_BN training path: pieces of the two heads sequenced by netg.cpp (head.hip / head_bwd.hip)
+int theta_z1(const float *x, int n, int c, int hidden, const float *w_flat, const float *b_flat, float *ws, float *z1, hipStream_t st);
+int theta_z2(const float *h, int n, int hidden, const float *w_lin, const float *b_lin, float *z2, hipStream_t st);
+int field_head_raw(const float *x, int ld, int n, int h, int w, int c, const float *w_out, const float *b_out, float *z, hipStream_t st);
+int field_bn_finish(const float *yhat, const float *theta, int n, int h, int w, int ac, float *resid, float *grid, hipStream_t st);
+int field_bwd_gz(const float *resid, const float *g_grid, const float *g_resid, int n, int h, int w, int ac, float *gz, float *db_out,
+                 float *dtheta, hipStream_t st);
+int field_bwd_dx_dw(const float *x, int ld, const float *gz, int n, int h, int w, int c, const float *w_out, float *dx, int dx_ld,
+                    int dx_accumulate, float *dw_out, int store, hipStream_t st);
+int theta_bwd_bn_lin(const float *dz2, const float *h, int n, int hidden, const float *w_lin, float *dw_lin, float *dh, hipStream_t st);
+int theta_bwd_flat(const float *x, int n, int c, int hidden, const float *w_flat, const float *dz1, float *dw_flat, float *dx,
+                   int dx_accumulate, hipStream_t st);
 int wino_k3s1_launch(const pws_conv_args *a, const ProfHint &ph, hipStream_t st);  // conv_wino.hip
 
 // bf16 operand helpers (conv_bf16.hip, wgrad_bf16.hip)

@@ -85,7 +85,7 @@ template <bool IO16>
 __global__ void __launch_bounds__(256) field_head_kernel(const float *__restrict__ x, int ld, int N, int H, int W, int C,
                                                          const float *__restrict__ w_out, const float *__restrict__ b_out,
                                                          const float *__restrict__ theta, int ac, float *__restrict__ resid,
-                                                         float *__restrict__ grid, int tiles_x, int tiles_y, unsigned ntiles) {
+                                                         float *__restrict__ grid, int tiles_x, int tiles_y, unsigned ntiles, int raw) {
     __shared__ float s_in[FH_I * FH_I * FH_LDP];
     const int tid = threadIdx.x;
     const unsigned tile = xcd_remap(blockIdx.x, ntiles);
@@ -136,7 +136,11 @@ __global__ void __launch_bounds__(256) field_head_kernel(const float *__restrict
         }
     }
     const int y = y0 + ty, xq = x0 + tx;
-    if (y < H && xq < W) {
+    if (y < H && xq < W && raw) {
+        // use_BN training: the pre-normalisation conv output; BatchNorm, tanh(tanh(.)) and the affine add follow in
+        // field_bn_finish_kernel once the batch statistics are known
+        *reinterpret_cast<float2 *>(resid + (((size_t)n * H + y) * W + xq) * 2) = make_float2(acc0, acc1);
+    } else if (y < H && xq < W) {
         const float r0 = tanhf(tanhf(acc0)), r1 = tanhf(tanhf(acc1));
         const size_t p = ((size_t)n * H + y) * W + xq;
         if (resid) *reinterpret_cast<float2 *>(resid + p * 2) = make_float2(r0, r1);
@@ -154,6 +158,52 @@ __global__ void __launch_bounds__(256) field_head_kernel(const float *__restrict
     }
 }
 
+
+// ---- use_BN training-mode pieces of the two heads (netg.cpp sequences them with pws_bn_train_fwd in between)
+// z1[n][j] = sum over K slices of the hidden pre-activations + b1[j]   (theta_hidden_kernel's partials)
+__global__ void __launch_bounds__(256) theta_sum_kernel(const float *__restrict__ partial, int nslices, int n, int hidden,
+                                                        const float *__restrict__ b_flat, float *__restrict__ z1) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)n * hidden) return;
+    const int j = (int)(e % hidden);
+    float acc = b_flat ? b_flat[j] : 0.f;
+    for (int sl = 0; sl < nslices; ++sl) acc += partial[(size_t)sl * n * hidden + e];
+    z1[e] = acc;
+}
+// z2[n][o] = sum_j h[n][j] W2[j][o] + b2[o]: one wave per (sample, output)
+__global__ void __launch_bounds__(256) theta_z2_kernel(const float *__restrict__ h, int n, int hidden, const float *__restrict__ w_lin,
+                                                       const float *__restrict__ b_lin, float *__restrict__ z2) {
+    const int wave = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (wave >= n * 6) return;
+    const int s = wave / 6, o = wave % 6;
+    float acc = 0.f;
+    for (int j = lane; j < hidden; j += 64) acc = fmaf(h[(size_t)s * hidden + j], w_lin[(size_t)j * 6 + o], acc);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) z2[(size_t)s * 6 + o] = acc + (b_lin ? b_lin[o] : 0.f);
+}
+// r = tanh(tanh(yhat)); resid = r; grid = r + affine_grid(theta)   (yhat: the BatchNorm output of the `out` conv)
+__global__ void __launch_bounds__(256) field_bn_finish_kernel(const float *__restrict__ yhat, const float *__restrict__ theta, int H, int W,
+                                                              size_t total, int ac, float *__restrict__ resid, float *__restrict__ grid) {
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= total) return;
+    const float2 v = *reinterpret_cast<const float2 *>(yhat + p * 2);
+    const float r0 = tanhf(tanhf(v.x)), r1 = tanhf(tanhf(v.y));
+    if (resid) *reinterpret_cast<float2 *>(resid + p * 2) = make_float2(r0, r1);
+    if (grid) {
+        const int xq = (int)(p % W), y = (int)((p / W) % H);
+        const size_t n = p / ((size_t)W * H);
+        float a0 = 0.f, a1 = 0.f;
+        if (theta) {
+            const float *t = theta + n * 6;
+            const float bx = ac ? (W > 1 ? (2.f * xq) / (float)(W - 1) - 1.f : 0.f) : (2.f * xq + 1.f) / (float)W - 1.f;
+            const float by = ac ? (H > 1 ? (2.f * y) / (float)(H - 1) - 1.f : 0.f) : (2.f * y + 1.f) / (float)H - 1.f;
+            a0 = t[0] * bx + t[1] * by + t[2], a1 = t[3] * bx + t[4] * by + t[5];
+        }
+        *reinterpret_cast<float2 *>(grid + p * 2) = make_float2(r0 + a0, r1 + a1);
+    }
+}
+
 }  // namespace pws
 
 using namespace pws;
@@ -162,6 +212,36 @@ static int theta_slices(int k1) {
     int kchunk = 64;
     return (k1 + kchunk - 1) / kchunk;
 }
+
+// ---- host helpers of the use_BN training path (declared in common.h, called by netg.cpp; not part of the C ABI)
+namespace pws {
+int theta_z1(const float *x, int n, int c, int hidden, const float *w_flat, const float *b_flat, float *ws, float *z1, hipStream_t st) {
+    const int k1 = 4 * c, kchunk = 64, nslices = theta_slices(k1);
+    hipLaunchKernelGGL(theta_hidden_kernel, dim3((hidden + 63) / 64, nslices), dim3(64), sizeof(float) * TH_NB * kchunk, st, x, n, k1, hidden,
+                       kchunk, w_flat, ws);
+    const size_t e = (size_t)n * hidden;
+    hipLaunchKernelGGL(theta_sum_kernel, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, st, ws, nslices, n, hidden, b_flat, z1);
+    return check_launch("theta_z1 kernels");
+}
+int theta_z2(const float *h, int n, int hidden, const float *w_lin, const float *b_lin, float *z2, hipStream_t st) {
+    const size_t waves = (size_t)n * 6;
+    hipLaunchKernelGGL(theta_z2_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, st, h, n, hidden, w_lin, b_lin, z2);
+    return check_launch("theta_z2_kernel");
+}
+int field_head_raw(const float *x, int ld, int n, int h, int w, int c, const float *w_out, const float *b_out, float *z, hipStream_t st) {
+    const int tiles_x = (w + FH_T - 1) / FH_T, tiles_y = (h + FH_T - 1) / FH_T;
+    const unsigned ntiles = (unsigned)tiles_x * tiles_y * n;
+    hipLaunchKernelGGL(field_head_kernel<false>, dim3(ntiles), dim3(256), 0, st, x, ld, n, h, w, c, w_out, b_out, (const float *)nullptr, 0, z,
+                       (float *)nullptr, tiles_x, tiles_y, ntiles, 1);
+    return check_launch("field_head_kernel<raw>");
+}
+int field_bn_finish(const float *yhat, const float *theta, int n, int h, int w, int ac, float *resid, float *grid, hipStream_t st) {
+    const size_t total = (size_t)n * h * w;
+    hipLaunchKernelGGL(field_bn_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, yhat, theta, h, w, total, ac, resid,
+                       grid);
+    return check_launch("field_bn_finish_kernel");
+}
+}  // namespace pws
 
 extern "C" size_t pws_theta_head_ws_floats(int n, int c, int hidden) {
     if (n <= 0 || c <= 0 || hidden <= 0) return 0;
@@ -210,9 +290,9 @@ extern "C" int pws_field_head_fwd_s(const float *x, int ld, int n, int h, int w,
                    (double)n * h * w * (4.0 * c + (resid ? 8.0 : 0.0) + (grid ? 8.0 : 0.0)), as_stream(stream));
     if (store == PWS_STORE_BF16)
         hipLaunchKernelGGL(field_head_kernel<true>, dim3(ntiles), dim3(256), 0, as_stream(stream), x, ld, n, h, w, c, w_out, b_out,
-                           theta, align_corners, resid, grid, tiles_x, tiles_y, ntiles);
+                           theta, align_corners, resid, grid, tiles_x, tiles_y, ntiles, 0);
     else
         hipLaunchKernelGGL(field_head_kernel<false>, dim3(ntiles), dim3(256), 0, as_stream(stream), x, ld, n, h, w, c, w_out, b_out,
-                           theta, align_corners, resid, grid, tiles_x, tiles_y, ntiles);
+                           theta, align_corners, resid, grid, tiles_x, tiles_y, ntiles, 0);
     return check_launch("field_head_kernel");
 }

@@ -195,13 +195,15 @@ __global__ void __launch_bounds__(256) field_dw_kernel(const float *__restrict__
 __global__ void __launch_bounds__(256) theta_bwd1_kernel(const float *__restrict__ theta, const float *__restrict__ dtheta,
                                                          const float *__restrict__ h, int hidden, const float *__restrict__ w_lin,
                                                          float *__restrict__ dw_lin, float *__restrict__ db_lin,
-                                                         float *__restrict__ db_flat, float *__restrict__ dz1) {
+                                                         float *__restrict__ db_flat, float *__restrict__ dz1, int bn) {
+    // bn (use_BN training): `dtheta` already IS dz2 (BatchNorm backward ran on it) and the output is dh, the gradient wrt the
+    // BatchNorm output of the hidden layer (its own BatchNorm backward follows); the conv biases get no gradient (BN removes it)
     __shared__ float dz2[6];
     const int n = blockIdx.x, tid = threadIdx.x;
     if (tid < 6) {
-        const float v = dtheta[(size_t)n * 6 + tid] * lrelu_grad(theta[(size_t)n * 6 + tid]);
+        const float v = bn ? dtheta[(size_t)n * 6 + tid] : dtheta[(size_t)n * 6 + tid] * lrelu_grad(theta[(size_t)n * 6 + tid]);
         dz2[tid] = v;
-        atomicAdd(db_lin + tid, v);
+        if (!bn) atomicAdd(db_lin + tid, v);
     }
     __syncthreads();
     for (int j = tid; j < hidden; j += 256) {
@@ -212,9 +214,9 @@ __global__ void __launch_bounds__(256) theta_bwd1_kernel(const float *__restrict
             atomicAdd(dw_lin + (size_t)j * 6 + o, hj * dz2[o]);
             dh = fmaf(w_lin[(size_t)j * 6 + o], dz2[o], dh);
         }
-        const float d1 = dh * lrelu_grad(hj);
+        const float d1 = bn ? dh : dh * lrelu_grad(hj);
         dz1[(size_t)n * hidden + j] = d1;
-        atomicAdd(db_flat + j, d1);
+        if (!bn) atomicAdd(db_flat + j, d1);
     }
 }
 
@@ -256,18 +258,11 @@ extern "C" int pws_field_head_bwd(const float *x, int ld, int n, int h, int w, i
                                 db_out, dtheta, ws, PWS_STORE_FP32, stream);
 }
 
-extern "C" int pws_field_head_bwd_s(const float *x, int ld, int n, int h, int w, int c, const float *w_out, const float *resid,
-                                    const float *g_grid, const float *g_resid, int align_corners, float *dx, int dx_ld,
-                                    int dx_accumulate, float *dw_out, float *db_out, float *dtheta, float *ws, int store,
-                                    pws_stream_t stream) {
-    const bool io16 = store == PWS_STORE_BF16;
-    PWS_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "pws_field_head_bwd: bad shape");
-    if (n == 0) return PWS_OK;
-    PWS_REQUIRE(x && w_out && resid && (g_grid || g_resid) && ws, "pws_field_head_bwd: NULL pointer");
-    PWS_REQUIRE(9 * c * 2 * sizeof(float) <= 64 * 1024, "pws_field_head_bwd: c=%d too large", c);
-    hipStream_t st = as_stream(stream);
-    const size_t total = (size_t)n * h * w;
-    ProfScope prof(KID_FIELD_HEAD_BWD, 4.0 * total * 18.0 * c, (double)total * (8.0 * c + 32.0), st);
+// The field head's backward in two halves (netg.cpp puts the BatchNorm backward of the `out` layer between them when use_BN):
+// gz: gz = d loss / d (input of tanh(tanh(.))), dtheta, [db_out];  dx_dw: data and weight gradient of the 3x3 conv from gz.
+namespace pws {
+int field_bwd_gz(const float *resid, const float *g_grid, const float *g_resid, int n, int h, int w, int ac, float *gz, float *db_out,
+                 float *dtheta, hipStream_t st) {
     if (dtheta) {
         hipError_t e = hipMemsetAsync(dtheta, 0, sizeof(float) * (size_t)n * 6, st);
         if (e != hipSuccess) {
@@ -275,24 +270,29 @@ extern "C" int pws_field_head_bwd_s(const float *x, int ld, int n, int h, int w,
             return PWS_EHIP;
         }
     }
-    {
-        // ~2048 workgroups over the batch, at least 1024 pixels each
-        int slices = (2048 + n - 1) / n;
-        const int max_slices = (int)(((size_t)h * w + 1023) / 1024);
-        if (slices > max_slices) slices = max_slices;
-        if (slices < 1) slices = 1;
-        PWS_REQUIRE(n <= 65535, "pws_field_head_bwd: more than 65535 samples");
-        hipLaunchKernelGGL(field_gz_kernel, dim3((unsigned)slices, (unsigned)n), dim3(256), 0, st, resid, g_grid, g_resid, h, w, slices,
-                           align_corners, ws, db_out, dtheta);
-    }
+    // ~2048 workgroups over the batch, at least 1024 pixels each
+    int slices = (2048 + n - 1) / n;
+    const int max_slices = (int)(((size_t)h * w + 1023) / 1024);
+    if (slices > max_slices) slices = max_slices;
+    if (slices < 1) slices = 1;
+    PWS_REQUIRE(n <= 65535, "pws_field_head_bwd: more than 65535 samples");
+    hipLaunchKernelGGL(field_gz_kernel, dim3((unsigned)slices, (unsigned)n), dim3(256), 0, st, resid, g_grid, g_resid, h, w, slices, ac, gz,
+                       db_out, dtheta);
+    return check_launch("field_gz_kernel");
+}
+
+int field_bwd_dx_dw(const float *x, int ld, const float *gz, int n, int h, int w, int c, const float *w_out, float *dx, int dx_ld,
+                    int dx_accumulate, float *dw_out, int store, hipStream_t st) {
+    const bool io16 = store == PWS_STORE_BF16;
+    const size_t total = (size_t)n * h * w;
     if (dx) {
         PWS_REQUIRE(!io16 || (c % 8 == 0 && dx_ld % 8 == 0), "pws_field_head_bwd: bf16 storage needs c and dx_ld to be multiples of 8");
         if (io16)
-            hipLaunchKernelGGL(field_dx_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, w_out, n, h, w, c,
-                               dx, dx_ld, dx_accumulate);
+            hipLaunchKernelGGL(field_dx_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gz, w_out, n, h, w, c, dx,
+                               dx_ld, dx_accumulate);
         else
-            hipLaunchKernelGGL(field_dx_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, w_out, n, h, w, c,
-                               dx, dx_ld, dx_accumulate);
+            hipLaunchKernelGGL(field_dx_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gz, w_out, n, h, w, c, dx,
+                               dx_ld, dx_accumulate);
     }
     if (dw_out) {
         const int tiles_x = (w + FB_T - 1) / FB_T, tiles_y = (h + FB_T - 1) / FB_T;
@@ -300,13 +300,50 @@ extern "C" int pws_field_head_bwd_s(const float *x, int ld, int n, int h, int w,
         int gx = (1024 + cblocks - 1) / cblocks;  // ~4 workgroups per CU in total; each walks ntiles / gx tiles
         if (gx > ntiles) gx = ntiles;
         if (io16)
-            hipLaunchKernelGGL(field_dw_kernel<true>, dim3((unsigned)gx, (unsigned)cblocks), dim3(256), 0, st, x, ld, ws, n, h, w, c,
-                               dw_out, tiles_x, tiles_y, ntiles);
+            hipLaunchKernelGGL(field_dw_kernel<true>, dim3((unsigned)gx, (unsigned)cblocks), dim3(256), 0, st, x, ld, gz, n, h, w, c, dw_out,
+                               tiles_x, tiles_y, ntiles);
         else
-            hipLaunchKernelGGL(field_dw_kernel<false>, dim3((unsigned)gx, (unsigned)cblocks), dim3(256), 0, st, x, ld, ws, n, h, w, c,
-                               dw_out, tiles_x, tiles_y, ntiles);
+            hipLaunchKernelGGL(field_dw_kernel<false>, dim3((unsigned)gx, (unsigned)cblocks), dim3(256), 0, st, x, ld, gz, n, h, w, c, dw_out,
+                               tiles_x, tiles_y, ntiles);
     }
     return check_launch("field_head_bwd kernels");
+}
+
+// theta head, use_BN: dz2 given -> dW2 += h (x) dz2, dh = W2^T dz2 (no activation derivative: the BatchNorm backward of the hidden
+// layer follows);  then, with dz1:  dW1 += v (x) dz1, dv = W1 dz1
+int theta_bwd_bn_lin(const float *dz2, const float *h, int n, int hidden, const float *w_lin, float *dw_lin, float *dh, hipStream_t st) {
+    hipLaunchKernelGGL(theta_bwd1_kernel, dim3(n), dim3(256), 0, st, (const float *)nullptr, dz2, h, hidden, w_lin, dw_lin, (float *)nullptr,
+                       (float *)nullptr, dh, 1);
+    return check_launch("theta_bwd1_kernel<bn>");
+}
+int theta_bwd_flat(const float *x, int n, int c, int hidden, const float *w_flat, const float *dz1, float *dw_flat, float *dx,
+                   int dx_accumulate, hipStream_t st) {
+    const int k1 = 4 * c;
+    const size_t e = (size_t)k1 * hidden;
+    hipLaunchKernelGGL(theta_bwd2_kernel, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, st, x, dz1, n, k1, hidden, dw_flat);
+    if (dx) {
+        const size_t waves = (size_t)n * k1;
+        hipLaunchKernelGGL(theta_bwd3_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, st, w_flat, dz1, n, k1, hidden, dx,
+                           dx_accumulate);
+    }
+    return check_launch("theta_bwd2/3 kernels");
+}
+}  // namespace pws
+
+extern "C" int pws_field_head_bwd_s(const float *x, int ld, int n, int h, int w, int c, const float *w_out, const float *resid,
+                                    const float *g_grid, const float *g_resid, int align_corners, float *dx, int dx_ld,
+                                    int dx_accumulate, float *dw_out, float *db_out, float *dtheta, float *ws, int store,
+                                    pws_stream_t stream) {
+    PWS_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "pws_field_head_bwd: bad shape");
+    if (n == 0) return PWS_OK;
+    PWS_REQUIRE(x && w_out && resid && (g_grid || g_resid) && ws, "pws_field_head_bwd: NULL pointer");
+    PWS_REQUIRE(9 * c * 2 * sizeof(float) <= 64 * 1024, "pws_field_head_bwd: c=%d too large", c);
+    hipStream_t st = as_stream(stream);
+    const size_t total = (size_t)n * h * w;
+    ProfScope prof(KID_FIELD_HEAD_BWD, 4.0 * total * 18.0 * c, (double)total * (8.0 * c + 32.0), st);
+    int rc = field_bwd_gz(resid, g_grid, g_resid, n, h, w, align_corners, ws, db_out, dtheta, st);
+    if (rc == PWS_OK) rc = field_bwd_dx_dw(x, ld, ws, n, h, w, c, w_out, dx, dx_ld, dx_accumulate, dw_out, store, st);
+    return rc;
 }
 
 extern "C" int pws_theta_head_bwd(const float *x, int n, int c, int hidden, const float *w_flat, const float *w_lin,
@@ -319,7 +356,7 @@ extern "C" int pws_theta_head_bwd(const float *x, int n, int c, int hidden, cons
     hipStream_t st = as_stream(stream);
     const int k1 = 4 * c;
     ProfScope prof(KID_THETA_HEAD_BWD, 4.0 * n * (double)k1 * hidden, 4.0 * 3.0 * (double)k1 * hidden, st);
-    hipLaunchKernelGGL(theta_bwd1_kernel, dim3(n), dim3(256), 0, st, theta, dtheta, h_saved, hidden, w_lin, dw_lin, db_lin, db_flat, ws);
+    hipLaunchKernelGGL(theta_bwd1_kernel, dim3(n), dim3(256), 0, st, theta, dtheta, h_saved, hidden, w_lin, dw_lin, db_lin, db_flat, ws, 0);
     const size_t e = (size_t)k1 * hidden;
     hipLaunchKernelGGL(theta_bwd2_kernel, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, st, x, ws, n, k1, hidden, dw_flat);
     if (dx) {

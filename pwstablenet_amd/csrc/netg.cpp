@@ -147,6 +147,18 @@ struct Op {
     int type, layer, act, stage;
     bool nchw;
     Tn in, out;
+    // use_BN training: pre-normalisation values and saved (mean, invstd) of the BatchNorms of this op
+    //   conv : aux[0] = z, aux[1] = stats          field: aux[0] = z, aux[1] = stats, aux[2] = BatchNorm output
+    //   theta: aux[0] = z1, aux[1] = stats1, aux[2] = z2, aux[3] = stats2
+    float *aux[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+// Training-mode BatchNorm configuration of one forward / backward (use_BN=True, reference lib/networks_cascading.py:253-341).
+// params / running: flat buffers, per layer in state-dict order [gamma(cout) | beta(cout)] resp. [running_mean | running_var].
+struct BnCfg {
+    const float *params = nullptr;
+    float *running = nullptr;
+    float momentum = 0.1f, eps = 1e-5f;
 };
 
 // Second in-order queue for the branch of the forward that does not depend on the current one (stage k+1's encoder
@@ -175,8 +187,14 @@ static thread_local SideStream g_side;
 class Exec {
   public:
     Exec(const float *packed, const std::vector<Layer> &layers, int n, char *ws, size_t ws_bytes, hipStream_t st, bool dry,
-         bool launch)
+         bool launch, const BnCfg *bn = nullptr)
         : packed_(packed), L_(layers), n_(n), ws_(ws), cap_(ws_bytes), dry_(dry), launch_(launch && !dry) {
+        if (bn) {
+            bn_on_ = true, bn_ = *bn;
+            size_t off = 0;
+            for (int i = 0; i < L_COUNT; ++i) bn_off_[i] = off, off += 2 * (size_t)layers[i].cout;
+            bn_total_ = off;
+        }
         // bf16 storage of activations: only with bf16 math and when every conv layer is covered by the bf16 kernels
         io16_ = g_math == PWS_MATH_BF16 && g_store == PWS_STORE_BF16 && layers[L_DOWN1].cin % 32 == 0;
         streams_[0] = st, streams_[1] = st;
@@ -213,6 +231,20 @@ class Exec {
     float *theta_x32(int q) const { return theta_x32_[q]; }
     size_t splitk_bytes() const { return splitk_bytes_; }
     float *h_saved(int stage) const { return h_saved_[stage]; }
+    bool bn_on() const { return bn_on_; }
+    size_t bn_off(int layer) const { return bn_off_[layer]; }
+    size_t bn_total() const { return bn_total_; }
+    float *bn_ws(int q) const { return bn_ws_[q]; }
+    size_t bn_ws_bytes() const { return bn_ws_bytes_; }
+    const float *gamma(int layer) const { return bn_.params + bn_off_[layer]; }
+    const float *beta(int layer) const { return bn_.params + bn_off_[layer] + L_[layer].cout; }
+    // y = act(BatchNorm_train(z)) of `layer` on the current queue; stats saved, running statistics updated `repeat` times
+    int bn_forward(int layer, const float *z, size_t pixels, int act, float *y, float *stats, int repeat) {
+        const int c = L_[layer].cout;
+        float *rm = bn_.running ? bn_.running + bn_off_[layer] : nullptr;
+        return pws_bn_train_fwd(z, pixels, c, gamma(layer), beta(layer), act, y, stats, rm, rm ? rm + c : nullptr, bn_.momentum, bn_.eps,
+                                repeat, bn_ws_[q_], bn_ws_bytes_, streams_[q_]);
+    }
 
     float *alloc(size_t floats) {
         const size_t bytes = align_up(floats * sizeof(float), 256);
@@ -243,7 +275,9 @@ class Exec {
         Tn o{};
         o.nseg = 1, o.h = oh, o.w = ow;
         o.seg[0] = Seg{alloc((size_t)n_ * oh * ow * l.cout), l.cout, l.cout};
-        tape_.push_back(Op{OP_CONV, layer, act, 0, nchw_c > 0, x, o});
+        Op op{OP_CONV, layer, act, 0, nchw_c > 0, x, o};
+        if (bn_on_) op.aux[0] = alloc((size_t)n_ * oh * ow * l.cout), op.aux[1] = alloc(2 * (size_t)l.cout);
+        tape_.push_back(op);
         if (!launch_ || rc_ != PWS_OK) return o;
         pws_conv_args a{};
         a.kind = l.kind, a.n = n_, a.h = x.h, a.w = x.w;
@@ -258,15 +292,21 @@ class Exec {
             a.nsrc = x.nseg;
             for (int i = 0; i < x.nseg; ++i) a.src[i] = pws_src{x.seg[i].ptr, x.seg[i].c, x.seg[i].ld};
         }
-        a.cout = l.cout, a.w_packed = packed_ + l.w_off, a.bias = packed_ + l.b_off, a.act = act;
+        a.cout = l.cout, a.w_packed = packed_ + l.w_off, a.bias = packed_ + l.b_off, a.act = bn_on_ ? PWS_ACT_NONE : act;
         a.w_wino = l.ww_off != (size_t)-1 ? packed_ + l.ww_off : nullptr;
-        a.out = o.seg[0].ptr, a.out_ld = l.cout;
+        a.out = bn_on_ ? op.aux[0] : o.seg[0].ptr, a.out_ld = l.cout;
         a.ws = q_ ? splitk_ws2_ : splitk_ws_, a.ws_bytes = splitk_bytes_;
         if (g_math == PWS_MATH_BF16 && l.wb_off != (size_t)-1) a.math = PWS_MATH_BF16, a.w_bf16 = packed_ + l.wb_off;
         a.store = store();
         g_prof_tag = layer;
         rc_ = pws_conv2d_fwd(&a, streams_[q_]);
         g_prof_tag = -1;
+        if (bn_on_ && rc_ == PWS_OK) {
+            // down_bottom1 is called twice per forward by the reference (x22, x32: same input, same weights) and computed once
+            // here: its running statistics take both updates
+            const int repeat = (layer == L_DB1_CS || layer == L_DB1_CS + 1) ? 2 : 1;
+            rc_ = bn_forward(layer, op.aux[0], (size_t)n_ * oh * ow, act, o.seg[0].ptr, op.aux[1], repeat);
+        }
         return o;
     }
 
@@ -290,10 +330,25 @@ class Exec {
     }
     // theta = linear(flatten(x)) (reference :162-163)
     void theta(const Tn &x_s8, int stage, float *theta_out) {
-        tape_.push_back(Op{OP_THETA, L_FLATTEN, 0, stage, false, x_s8, Tn{}});
+        Op op{OP_THETA, L_FLATTEN, 0, stage, false, x_s8, Tn{}};
+        if (bn_on_) {
+            const int hidden = L_[L_FLATTEN].cout;
+            op.aux[0] = alloc((size_t)n_ * hidden), op.aux[1] = alloc(2 * (size_t)hidden);
+            op.aux[2] = alloc((size_t)n_ * 6), op.aux[3] = alloc(12);
+        }
+        tape_.push_back(op);
         if (!launch_ || rc_ != PWS_OK) return;
         const Layer &f = L_[L_FLATTEN], &l = L_[L_LINEAR];
         const float *xin = x_s8.seg[0].ptr;
+        if (bn_on_) {
+            // flatten -> BatchNorm over the n samples -> LeakyReLU -> linear -> BatchNorm -> LeakyReLU (reference :148-149 with use_BN)
+            rc_ = theta_z1(xin, n_, x_s8.seg[0].c, f.cout, packed_ + f.w_off, packed_ + f.b_off, q_ ? theta_ws2_ : theta_ws_, op.aux[0],
+                           streams_[q_]);
+            if (rc_ == PWS_OK) rc_ = bn_forward(L_FLATTEN, op.aux[0], (size_t)n_, PWS_ACT_LRELU, h_saved_[stage], op.aux[1], 1);
+            if (rc_ == PWS_OK) rc_ = theta_z2(h_saved_[stage], n_, f.cout, packed_ + l.w_off, packed_ + l.b_off, op.aux[2], streams_[q_]);
+            if (rc_ == PWS_OK) rc_ = bn_forward(L_LINEAR, op.aux[2], (size_t)n_, PWS_ACT_LRELU, theta_out, op.aux[3], 1);
+            return;
+        }
         if (io16_) {  // the head is an fp32 GEMV: its 2x2xC input is converted once (n x 4C values)
             rc_ = pws_cvt_bf16_to_f32(xin, theta_x32_[q_], (size_t)n_ * 4 * x_s8.seg[0].c, streams_[q_]);
             if (rc_ != PWS_OK) return;
@@ -305,9 +360,22 @@ class Exec {
     }
     // tanh(out(x)).permute(0,2,3,1) [+ affine_grid(theta)] (reference :174,235-237)
     void field(const Tn &x, int stage, const float *theta_k, int ac, float *resid, float *grid) {
-        tape_.push_back(Op{OP_FIELD, L_OUT, 0, stage, false, x, Tn{}});
+        Op op{OP_FIELD, L_OUT, 0, stage, false, x, Tn{}};
+        if (bn_on_) {
+            const size_t e = (size_t)n_ * x.h * x.w * 2;
+            op.aux[0] = alloc(e), op.aux[1] = alloc(4), op.aux[2] = alloc(e);
+        }
+        tape_.push_back(op);
         if (!launch_ || rc_ != PWS_OK) return;
         const Layer &o = L_[L_OUT];
+        if (bn_on_) {
+            // out conv -> BatchNorm(2) -> tanh, then the second tanh + permute + affine add (reference :128,174 with use_BN)
+            rc_ = field_head_raw(x.seg[0].ptr, x.seg[0].ld, n_, x.h, x.w, x.seg[0].c, packed_ + o.w_off, packed_ + o.b_off, op.aux[0],
+                                 streams_[q_]);
+            if (rc_ == PWS_OK) rc_ = bn_forward(L_OUT, op.aux[0], (size_t)n_ * x.h * x.w, PWS_ACT_NONE, op.aux[2], op.aux[1], 1);
+            if (rc_ == PWS_OK) rc_ = field_bn_finish(op.aux[2], theta_k, n_, x.h, x.w, ac, resid, grid, streams_[q_]);
+            return;
+        }
         rc_ = pws_field_head_fwd_s(x.seg[0].ptr, x.seg[0].ld, n_, x.h, x.w, x.seg[0].c, packed_ + o.w_off, packed_ + o.b_off,
                                    theta_k, ac, resid, grid, store(), streams_[q_]);
     }
@@ -324,6 +392,10 @@ class Exec {
         for (int s = 0; s < 3; ++s) h_saved_[s] = training ? alloc((size_t)n_ * 8 * ngf) : nullptr;
         x_nhwc_ = alloc((size_t)n_ * 256 * 256 * 32);  // bf16 math: NHWC copy of the window (unused in fp32 math)
         theta_x32_[0] = alloc((size_t)n_ * 16 * ngf), theta_x32_[1] = alloc((size_t)n_ * 16 * ngf);  // bf16 storage: fp32 copy of x_s8
+        if (bn_on_) {
+            bn_ws_bytes_ = pws_bn_ws_bytes(16 * ngf);   // slabs of the BatchNorm reductions, one scratch per queue
+            bn_ws_[0] = alloc(bn_ws_bytes_ / sizeof(float)), bn_ws_[1] = alloc(bn_ws_bytes_ / sizeof(float));
+        }
     }
 
   private:
@@ -331,6 +403,10 @@ class Exec {
     float *h_saved_[3] = {nullptr, nullptr, nullptr};
     float *x_nhwc_ = nullptr;
     float *theta_x32_[2] = {nullptr, nullptr};
+    bool bn_on_ = false;
+    BnCfg bn_;
+    size_t bn_off_[L_COUNT] = {}, bn_total_ = 0, bn_ws_bytes_ = 0;
+    float *bn_ws_[2] = {nullptr, nullptr};
     bool io16_ = false;
     hipStream_t streams_[2];
     int q_ = 0;
@@ -428,11 +504,11 @@ struct GradBuf {
 static int run_backward(const float *packed, const float *packed_dgrad, const float *x, int n, int input_nc, int g, int ac,
                         char *ws, size_t ws_bytes, const float *resid, const float *thetas, const float *g_grids,
                         const float *g_resid, float *dpacked, hipStream_t st, bool dry, size_t *used, int part = 0,
-                        int nparts = 1, unsigned char *final_mask = nullptr) {
+                        int nparts = 1, unsigned char *final_mask = nullptr, const BnCfg *bn = nullptr, float *dbn = nullptr) {
     const int S = 256;
     size_t total = 0;
     const std::vector<Layer> L = build_layers(input_nc, g, &total);
-    Exec E(packed, L, n, ws, ws_bytes, st, dry, /*launch=*/false);
+    Exec E(packed, L, n, ws, ws_bytes, st, dry, /*launch=*/false, bn);
     float dummy_thetas = 0.f;  // non-NULL: the training forward is always given a caller-owned thetas buffer
     forward_graph(E, x, n, input_nc, g, 1, ac, nullptr, nullptr, &dummy_thetas);
     // gradient buffers, one per produced tensor, after the forward region of the arena
@@ -454,6 +530,19 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
     if (dry) return PWS_OK;
     if (E.rc() != PWS_OK) return E.rc();
 
+    if (part == 0 && bn && dbn) {
+        hipError_t e = hipMemsetAsync(dbn, 0, E.bn_total() * sizeof(float), st);
+        if (e != hipSuccess) {
+            set_error("pws_netg_backward: hipMemsetAsync: %s", hipGetErrorString(e));
+            return PWS_EHIP;
+        }
+    }
+    // BatchNorm backward of `layer`: dy -> dz in place, dgamma / dbeta accumulated
+    auto bn_backward = [&](int layer, float *dy, const float *y, const float *z, const float *stats, int act, size_t pixels) {
+        const int c = L[layer].cout;
+        float *dg = dbn + E.bn_off(layer);
+        return pws_bn_train_bwd(dy, y, z, stats, E.gamma(layer), act, pixels, c, dg, dg + c, E.bn_ws(0), E.bn_ws_bytes(), st);
+    };
     if (part == 0) {
         hipError_t e = hipMemsetAsync(dpacked, 0, total * sizeof(float), st);
         if (e != hipSuccess) {
@@ -489,7 +578,13 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             const Seg &xs = op.in.seg[0];
             GradBuf &gb = G[xs.ptr];
             const Layer &o = L[L_OUT];
-            if (run)
+            if (run && bn) {
+                rc = field_bwd_gz(resid + k * gsz, gg, gr, n, op.in.h, op.in.w, ac, gz_ws, nullptr, gg ? dtheta + (size_t)k * n * 6 : nullptr, st);
+                if (rc == PWS_OK) rc = bn_backward(L_OUT, gz_ws, nullptr, op.aux[0], op.aux[1], PWS_ACT_NONE, (size_t)n * op.in.h * op.in.w);
+                if (rc == PWS_OK)
+                    rc = field_bwd_dx_dw(xs.ptr, xs.ld, gz_ws, n, op.in.h, op.in.w, xs.c, packed + o.w_off, gb.g, xs.c, gb.written ? 1 : 0,
+                                         dpacked + o.w_off, E.store(), st);
+            } else if (run)
                 rc = pws_field_head_bwd_s(xs.ptr, xs.ld, n, op.in.h, op.in.w, xs.c, packed + o.w_off, resid + k * gsz, gg, gr, ac, gb.g,
                                           xs.c, gb.written ? 1 : 0, dpacked + o.w_off, dpacked + o.b_off,
                                           gg ? dtheta + (size_t)k * n * 6 : nullptr, gz_ws, E.store(), st);
@@ -502,6 +597,16 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             GradBuf &gb = G[xs.ptr];
             const Layer &f = L[L_FLATTEN], &l = L[L_LINEAR];
             if (!run) {
+                gb.written = true;
+                continue;
+            }
+            if (bn) {
+                float *dz2 = dtheta + (size_t)k * n * 6;   // overwritten by the BatchNorm backward
+                rc = bn_backward(L_LINEAR, dz2, thetas + (size_t)k * n * 6, op.aux[2], op.aux[3], PWS_ACT_LRELU, (size_t)n);
+                if (rc == PWS_OK) rc = theta_bwd_bn_lin(dz2, E.h_saved(k), n, f.cout, packed + l.w_off, dpacked + l.w_off, th_bwd_ws, st);
+                if (rc == PWS_OK) rc = bn_backward(L_FLATTEN, th_bwd_ws, E.h_saved(k), op.aux[0], op.aux[1], PWS_ACT_LRELU, (size_t)n);
+                if (rc == PWS_OK)
+                    rc = theta_bwd_flat(xs.ptr, n, xs.c, f.cout, packed + f.w_off, th_bwd_ws, dpacked + f.w_off, gb.g, gb.written ? 1 : 0, st);
                 gb.written = true;
                 continue;
             }
@@ -532,7 +637,10 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
                 continue;
             }
             g_prof_tag = op.layer;
-            rc = pws_act_bwd_bias_s(go.g, o.ptr, pixels, l.cout, op.act, dpacked + l.b_off, E.store(), abb_ws, abb_bytes, st);
+            if (bn)   // the conv bias gets no gradient: BatchNorm removes any per-channel constant (torch returns rounding noise)
+                rc = bn_backward(op.layer, go.g, o.ptr, op.aux[0], op.aux[1], op.act, pixels);
+            else
+                rc = pws_act_bwd_bias_s(go.g, o.ptr, pixels, l.cout, op.act, dpacked + l.b_off, E.store(), abb_ws, abb_bytes, st);
             if (rc != PWS_OK) break;
             pws_conv_bwd_weight_args wa{};
             wa.kind = l.kind, wa.n = n, wa.h = op.in.h, wa.w = op.in.w, wa.nsrc = op.in.nseg, wa.src_nchw = op.nchw ? 1 : 0;
@@ -666,6 +774,57 @@ extern "C" int pws_netg_backward_part(const float *packed, const float *packed_d
     PWS_REQUIRE((reinterpret_cast<size_t>(ws) & 255) == 0, "pws_netg_backward_part: workspace must be 256-byte aligned");
     return run_backward(packed, packed_dgrad, x, n, input_nc, ngf, align_corners, static_cast<char *>(ws), ws_bytes, resid, thetas,
                         g_grids, g_resid, dpacked, as_stream(stream), false, nullptr, part, nparts, final_mask);
+}
+
+// ---- use_BN=True training (BatchNorm2d after every conv, batch statistics): fp32 math and storage only
+extern "C" size_t pws_netg_bn_floats(int input_nc, int ngf) {
+    if (input_nc <= 0 || ngf <= 0 || ngf % 16 != 0) return 0;
+    size_t total = 0, bn = 0;
+    for (const Layer &l : build_layers(input_nc, ngf, &total)) bn += 2 * (size_t)l.cout;
+    return bn;
+}
+
+extern "C" size_t pws_netg_train_workspace_bytes_bn(int n, int input_nc, int ngf) {
+    if (n <= 0 || input_nc <= 0 || ngf <= 0 || ngf % 16 != 0) return 0;
+    size_t used = 0;
+    BnCfg bn;
+    run_backward(nullptr, nullptr, nullptr, n, input_nc, ngf, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true,
+                 &used, 0, 1, nullptr, &bn, nullptr);
+    return used;
+}
+
+extern "C" int pws_netg_forward_bn(const float *packed, const float *bn_params, float *bn_running, float momentum, float eps,
+                                   const float *x, int n, int input_nc, int ngf, int align_corners, void *ws, size_t ws_bytes,
+                                   float *grids, float *resid, float *thetas, pws_stream_t stream) {
+    PWS_REQUIRE(n >= 0 && input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_forward_bn: bad n/input_nc/ngf %d/%d/%d", n, input_nc, ngf);
+    if (n == 0) return PWS_OK;
+    PWS_REQUIRE(n >= 2, "pws_netg_forward_bn: training-mode BatchNorm needs more than 1 value per channel (the theta head has one per "
+                        "sample): n >= 2, as torch");
+    PWS_REQUIRE(packed && bn_params && x && ws && grids && resid && thetas, "pws_netg_forward_bn: NULL pointer");
+    PWS_REQUIRE(g_math == PWS_MATH_FP32, "pws_netg_forward_bn: the use_BN training path runs in fp32 (PWS_OPT_MATH is bf16)");
+    PWS_REQUIRE((reinterpret_cast<size_t>(ws) & 255) == 0, "pws_netg_forward_bn: workspace must be 256-byte aligned");
+    size_t total = 0;
+    const std::vector<Layer> L = build_layers(input_nc, ngf, &total);
+    BnCfg bn;
+    bn.params = bn_params, bn.running = bn_running, bn.momentum = momentum, bn.eps = eps;
+    Exec E(packed, L, n, static_cast<char *>(ws), ws_bytes, as_stream(stream), false, true, &bn);
+    forward_graph(E, x, n, input_nc, ngf, 1, align_corners, grids, resid, thetas);
+    return E.rc();
+}
+
+extern "C" int pws_netg_backward_bn(const float *packed, const float *packed_dgrad, const float *bn_params, float eps, const float *x,
+                                    int n, int input_nc, int ngf, int align_corners, void *ws, size_t ws_bytes, const float *resid,
+                                    const float *thetas, const float *g_grids, const float *g_resid, float *dpacked, float *dbn,
+                                    pws_stream_t stream) {
+    PWS_REQUIRE(n >= 2 && input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_backward_bn: bad n/input_nc/ngf");
+    PWS_REQUIRE(packed && packed_dgrad && bn_params && x && ws && resid && thetas && dpacked && dbn, "pws_netg_backward_bn: NULL pointer");
+    PWS_REQUIRE(g_grids || g_resid, "pws_netg_backward_bn: no output gradient given");
+    PWS_REQUIRE(g_math == PWS_MATH_FP32, "pws_netg_backward_bn: the use_BN training path runs in fp32 (PWS_OPT_MATH is bf16)");
+    PWS_REQUIRE((reinterpret_cast<size_t>(ws) & 255) == 0, "pws_netg_backward_bn: workspace must be 256-byte aligned");
+    BnCfg bn;
+    bn.params = bn_params, bn.eps = eps;
+    return run_backward(packed, packed_dgrad, x, n, input_nc, ngf, align_corners, static_cast<char *>(ws), ws_bytes, resid, thetas, g_grids,
+                        g_resid, dpacked, as_stream(stream), false, nullptr, 0, 1, nullptr, &bn, dbn);
 }
 
 extern "C" int pws_netg_unpack_grads(const float *dpacked, float *const *grads, int input_nc, int ngf, pws_stream_t stream) {

@@ -214,10 +214,13 @@ class UnetGenerator(nn.Module):
                 ts += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
         return tuple((p.data_ptr(), p._version) for p in ts)
 
-    def packed_weights(self):
-        """Device buffer with every layer in the kernels' layout; re-packed when a parameter changed."""
-        key = self._weights_key()
-        params = self._effective_params() if (self._packed is None or key != self._packed_key) else None
+    def packed_weights(self, raw=False):
+        """Device buffer with every layer in the kernels' layout; re-packed when a parameter changed.  raw: the conv weights as
+        they are (training-mode BatchNorm normalises with batch statistics), not folded with the running statistics."""
+        key = (("raw",) + tuple((p.data_ptr(), p._version) for p in self._ordered_params())) if raw else (("eff",) + self._weights_key())
+        params = None
+        if self._packed is None or key != self._packed_key:
+            params = self._ordered_params() if raw else self._effective_params()
         if params is not None:
             A.require_cuda(*params)
             dev = params[0].device
@@ -258,11 +261,18 @@ class UnetGenerator(nn.Module):
             raise RuntimeError("UnetGenerator: expected input (N, %d, 256, 256) -- 7 stride-2 levels and the 2x2 flatten "
                                "conv fix the size -- got %s" % (self.input_nc, tuple(input1.shape)))
         needs_grad = torch.is_grad_enabled() and (input1.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if self.use_BN and (self.training or needs_grad):
+        if self.use_BN and self.training:
+            # train() mode: batch statistics, running statistics updated, as nn.BatchNorm2d (the reference's forward always
+            # returns the six training outputs here; netG(x, False) in train() mode still normalises with batch statistics)
+            if self.math != "fp32":
+                raise NotImplementedError("UnetGenerator(use_BN=True).train(): the BatchNorm training path runs in fp32 (set_math('fp32'))")
+            from ..autograd import netg_apply_bn
+            grids, resid = netg_apply_bn(self, input1)
+            return (grids, resid) if is_training else grids[2]
+        if self.use_BN and needs_grad:
             raise NotImplementedError(
-                "UnetGenerator(use_BN=True): only eval() inference is on the HIP path (running statistics folded into the "
-                "convolutions); training-mode BatchNorm (batch statistics + their backward) is not implemented -- call "
-                ".eval() under torch.no_grad(), or train with the reference default use_BN=False")
+                "UnetGenerator(use_BN=True).eval(): gradients through the folded (running-statistics) BatchNorm are not "
+                "provided -- call .train() to train, or run inference under torch.no_grad()")
         if needs_grad:
             return _netg_autograd(self, input1, is_training)
         if self._graph_mode and not is_training:

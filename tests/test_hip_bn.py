@@ -68,3 +68,79 @@ def test_bn_refuses_one_value_per_channel_and_repeats_running_update(hip):
     m, v = z.mean(0), z.var(0, unbiased=True)
     np.testing.assert_allclose(rm.cpu().numpy(), (0.19 * m).cpu().numpy(), atol=1e-6)            # two updates: 1 - 0.9^2
     np.testing.assert_allclose(rv.cpu().numpy(), (0.81 + 0.19 * v).cpu().numpy(), rtol=1e-5)
+
+
+def _bn_net(ngf=16):
+    from pwstablenet_amd.lib.networks_cascading import SingleDeviceParallel, UnetGenerator
+    net = SingleDeviceParallel(UnetGenerator(31, 2, ngf, use_BN=True))
+    sd = {"module." + k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_weights("W1", seed=123, ngf=ngf)}
+    sd.update({"module." + k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_bn_state(seed=321, ngf=ngf)})
+    net.load_state_dict(sd, strict=True)
+    return net.cuda()
+
+
+@pytest.mark.parametrize("n,tag", [(2, "train"), (6, "train6")])
+def test_use_bn_training_step_vs_reference_golden(hip, n, tag):
+    """use_BN=True in train() mode: forward (batch statistics), loss, gradients of conv and BatchNorm parameters, running
+    statistics and call counters against what the reference built with --use_BN 1 produced (tests/golden/make_golden_bn.py)."""
+    from pwstablenet_amd import functional as PF
+    g = np.load(os.path.join(GOLDEN, "netg_bn.npz"))
+    net = _bn_net(16).train()
+    x = torch.from_numpy(synth.make_window(n, 31, 256, seed=77)).cuda()
+    frames = torch.from_numpy(synth.make_frames(n, 3, 256, 256, seed=78)).cuda()
+    target = torch.roll(frames, shifts=(2, -3), dims=(2, 3))
+    net.zero_grad()
+    grids, resid = net(x)
+    loss = sum(F.l1_loss(PF.grid_sample(frames, g_) / 127.5 - 1, target / 127.5 - 1) for g_ in grids) + \
+        0.05 * sum((r ** 2).mean() for r in resid)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g[tag + "_loss"][0], rtol=2e-4)
+    for k in range(3):
+        # conditioning: the theta head's BatchNorms normalise over the n = 2 samples, xhat = d / sqrt(d^2 + eps) with d^2 ~ eps;
+        # d xhat / d z ~ 50, so the ~1e-5 summation-order differences of the 1024-term GEMV show up as a few 1e-4 in the affine
+        # part of the field (the residual part, checked below, is not affected)
+        np.testing.assert_allclose(grids[k].detach().cpu().numpy()[:, ::8, ::8], g[tag + "_grid%d_sub" % k], atol=1.5e-3)
+        r = resid[k].detach().double()
+        np.testing.assert_allclose([float(r.abs().sum()), float(r.abs().max())], g[tag + "_resid%d_csum" % k][1:], rtol=2e-3)
+    # Gradients.  BatchNorm over n = 2 samples (8-32 values per channel in the deepest layers) divides by standard deviations of
+    # the order of sqrt(eps): summation-order noise of the fp32 convolutions is amplified by 1e2-1e3, and the reference's OWN
+    # fp32 gradients sit 0.2 % - 30 % (of the tensor's maximum) away from the same step computed in float64.  The yardstick is
+    # therefore that float64 result: this path must be as close to it as the reference's fp32 run is (factor 3 + 2e-3 of max).
+    named = dict(net.module.named_parameters())
+    for key in g.files:
+        if key.startswith(tag + "64_grad_") and key.endswith("_samples"):
+            nm = key[len(tag + "64_grad_"):-len("_samples")]
+            got = named[nm].grad.cpu().numpy()
+            idx = np.random.RandomState(7).randint(0, got.size, 16)
+            if nm.endswith(".0.bias"):
+                # a conv bias in front of a BatchNorm has no gradient: torch returns rounding noise, this path exact zeros
+                assert np.abs(got).max() == 0.0 and np.abs(g[key]).max() < 1e-10
+                continue
+            ref_err, ref_max = g[tag + "64_grad_%s_full_err32" % nm]
+            err = np.abs(got.reshape(-1)[idx].astype(np.float64) - g[key]).max()
+            assert err <= 3 * ref_err + 2e-3 * ref_max, (nm, err, ref_err, ref_max)
+            cs = g[tag + "_grad_%s_csum" % nm]
+            np.testing.assert_allclose(np.abs(got.astype(np.float64)).sum(), cs[1], rtol=6e-2, err_msg=nm)
+    sd = net.state_dict()
+    for key in g.files:
+        if key.startswith(tag + "_rm_"):
+            nm = key[len(tag + "_rm_"):]
+            np.testing.assert_allclose(sd["module." + nm + ".running_mean"].cpu().numpy(), g[key], atol=2e-5, err_msg=nm)
+            np.testing.assert_allclose(sd["module." + nm + ".running_var"].cpu().numpy(), g[tag + "_rv_" + nm], rtol=2e-4, atol=1e-6,
+                                       err_msg=nm)
+            assert int(sd["module." + nm + ".num_batches_tracked"]) == int(g[tag + "_nbt_" + nm][0]), nm
+
+
+def test_use_bn_training_errors_and_eval_still_folds(hip):
+    net = _bn_net(16).train()
+    with pytest.raises(ValueError):        # torch: "Expected more than 1 value per channel when training"
+        net(torch.zeros((1, 31, 256, 256), device="cuda"))
+    net.module.set_math("bf16")
+    with pytest.raises(NotImplementedError):
+        net(torch.zeros((2, 31, 256, 256), device="cuda"))
+    net.module.set_math("fp32")
+    g = np.load(os.path.join(GOLDEN, "netg_bn.npz"))
+    net = _bn_net(16).eval()
+    with torch.no_grad():
+        field = net(torch.from_numpy(synth.make_window(1, 31, 256, seed=123)).cuda(), False)
+    np.testing.assert_allclose(field.cpu().numpy(), g["field"], atol=5e-4)
