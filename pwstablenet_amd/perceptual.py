@@ -152,7 +152,7 @@ class VGG16Features(nn.Module):
             if self.math == "bf16" and cin % 32 == 0:
                 wb = torch.empty(L.pws_packed_bf16_floats(9, cin, cout), device=dev, dtype=torch.float32)
                 A.check(L.pws_pack_weight_bf16(A.ptr(wp), A.ptr(wb), 9, cin, cout, st), "pws_pack_weight_bf16")
-            if self.math == "bf16" and cout % 32 == 0 and cin % 32 == 0:
+            if self.math == "bf16" and cout % 32 == 0:   # the gradient's contraction runs over cout; cin is padded to 64 by the pack
                 dgb = torch.empty(L.pws_packed_bf16_floats(9, cout, cin), device=dev, dtype=torch.float32)
                 A.check(L.pws_pack_weight_bf16(A.ptr(dg), A.ptr(dgb), 9, cout, cin, st), "pws_pack_weight_bf16")
             packs.append({"w": wp, "b": m.bias.detach().contiguous(), "wino": ww, "dg": dg, "bf16": wb, "dg_bf16": dgb})
