@@ -474,6 +474,8 @@ extern "C" int pws_act_bwd_bias_s(float *dy, const float *y, size_t pixels, int 
     if (dbias && ws && ws_bytes >= pws_act_bwd_bias_ws_bytes(c) && (reinterpret_cast<size_t>(ws) & 15) == 0) {
         slabs = static_cast<float *>(ws);
         if (blocks > (size_t)pws::ABB_MAX_BLOCKS) blocks = pws::ABB_MAX_BLOCKS;
+    } else if (!dbias) {
+        if (blocks > 4096) blocks = 4096;   // no bias gradient (frozen layers): a plain elementwise pass, fill the chip
     } else if (blocks > 128) {
         blocks = 128;  // atomic tail: fewer, longer workgroups win (see the kernel comment)
     }
