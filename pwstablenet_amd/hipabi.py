@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpwstable_hip.so")
+LIB_PATH = os.environ.get("PWS_LIB_PATH") or os.path.join(_HERE, "libpwstable_hip.so")   # PWS_LIB_PATH: A/B builds (tools only)
 
 c_f32p = ctypes.c_void_p  # device pointers are passed as integers
 c_stream = ctypes.c_void_p
