@@ -35,6 +35,11 @@ def bench(kname, n, h, w, cin, cout, wino, bf16=False):
         ww = torch.empty(L.pws_packed_wino_floats(cin, cout), device="cuda")
         A.check(L.pws_pack_conv_weight_wino(A.ptr(wp), A.ptr(ww), cin, cout, st), "wino pack")
         a.w_wino = ww.data_ptr()
+    store16 = bool(int(os.environ.get("CONV_BENCH_STORE16", "0")))
+    if bf16 and store16:   # bf16 activation storage: sources and output hold bf16 elements
+        x = x.bfloat16()
+        out = out.bfloat16()
+        a.src[0].ptr, a.out, a.store = x.data_ptr(), out.data_ptr(), 1
     if bf16:
         planes = 16 if kname == "CONVT_K4S2" else k * k
         cin_pad = (cin + 15) // 16 * 16
@@ -44,7 +49,7 @@ def bench(kname, n, h, w, cin, cout, wino, bf16=False):
     # CONV_BENCH_ROTATE=k: cycle over k input/output buffer pairs so that repeated launches do not find their
     # activations in the 256 MB MALL / L2 (what a layer sees inside the network)
     rot = int(os.environ.get("CONV_BENCH_ROTATE", "1"))
-    xs = [x] + [torch.randn_like(x) for _ in range(rot - 1)]
+    xs = [x] + [torch.randn_like(x.float()).to(x.dtype) for _ in range(rot - 1)]
     outs = [out] + [torch.empty_like(out) for _ in range(rot - 1)]
 
     def launch(i):
