@@ -106,8 +106,9 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(batch_unused):
-    """Hot path on the host cores: netG(window, False) + grid_sample, N=1, min over a bounded number of runs."""
+def cpu_baseline(batch_unused, gpu_step=None):
+    """Hot path on the host cores: netG(window, False) + grid_sample, N=1, min over a bounded number of runs.  gpu_step(x, frame)
+    -> (field, warped) on the device: the same frame through the HIP path, for the metric's error figures against the CPU path."""
     import torch
     from oracle import torch_ref
     from pwstablenet_amd import synth
@@ -123,9 +124,18 @@ def cpu_baseline(batch_unused):
         torch_ref.stabilize_step(params, x, fr)
         best = min(best, time.time() - t0)
         runs += 1
-    return {"value": round(1.0 / best, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "N=1 frame: PyTorch-CPU restatement of netG(x,False)+grid_sample (oracle/torch_ref.py), "
-                      "min of %d runs after 1 warm-up, %d torch threads" % (runs, torch.get_num_threads())}
+    res = {"value": round(1.0 / best, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": "N=1 frame: PyTorch-CPU restatement of netG(x,False)+grid_sample (oracle/torch_ref.py), "
+                     "min of %d runs after 1 warm-up, %d torch threads" % (runs, torch.get_num_threads())}
+    if gpu_step is not None:
+        with torch.no_grad():
+            ref_field = torch_ref.netg_forward(params, x, is_training=False)
+            ref_warp = torch.nn.functional.grid_sample(fr, ref_field, mode="bilinear", padding_mode="zeros", align_corners=False)
+            field, warped = gpu_step(x, fr)
+        res["parity_vs_cpu_path"] = {"warp_field_max_abs_err": float((field.cpu() - ref_field).abs().max()),
+                                     "warped_frame_max_abs_err_on_pm1_scale": float((warped.cpu() - ref_warp).abs().max() / 127.5),
+                                     "bound": "1e-3 (north_star, fp32)"}
+    return res
 
 
 def configs2_step_leg(net, dev, n_items, math, reps, sync=None, seed=500, perceptual=None):
@@ -542,7 +552,12 @@ def main():
         if not a.no_extra and a.math == "fp32" and world == 1:
             line["bf16"] = bf16_legs(net, x, frames, out, a, PF, A, synth)
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(B)
+            def gpu_one(xc, fc):
+                net.module.enable_graph(False)
+                net.module.set_math("fp32")
+                f_ = net(xc.to(dev), False)
+                return f_, PF.grid_sample(fc.to(dev), f_)
+            line["cpu_baseline"] = cpu_baseline(B, gpu_one)
             line["gpu_over_cpu"] = round(fps / line["cpu_baseline"]["value"], 1)
     else:
         line = None
