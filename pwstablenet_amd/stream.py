@@ -142,18 +142,25 @@ class VideoStabilizer:
         return out
 
     @torch.no_grad()
-    def run_video(self, frames, chunk=64, half_size_output=False, frames_are_rgb=False):
+    def run_video(self, frames, chunk=64, half_size_output=False, frames_are_rgb=False, halo_left=0, halo_right=0):
         """The whole device side of the reference's ``process()`` loop for one decoded clip: ``frames`` (T, H, W, 3) uint8 as
         cv2 delivers them, in (pinned) host memory or on the device.  Per chunk of ``chunk`` frames: H2D on a side stream,
         gray + INTER_AREA 256x256 window planes computed there from the uploaded frames (so nothing but the uint8 frames
         crosses PCIe and the host does no per-frame image processing), the generator on batched windows, the fused uint8
         resize+warp, optionally the 2x INTER_AREA down-scale of the output (main_new.py:723), D2H on a third stream.  Chunk
         k+1 uploads while chunk k computes; window planes are kept for the whole clip (256 KB per frame), frames per chunk.
-        Returns (T, H, W, 3) -- or (T, H/2, W/2, 3) -- uint8 on the inputs' side."""
-        T = frames.shape[0]
+        halo_left / halo_right: ``frames`` additionally holds that many real neighbour frames before / after the T frames to
+        stabilise (a rank's shard of a longer clip, ``distributed.shard_frames``: up to period//2 each); they only feed the
+        windows.  Returns (T, H, W, 3) -- or (T, H/2, W/2, 3) -- uint8 on the inputs' side."""
+        half = self.period // 2
+        if not (0 <= halo_left <= half and 0 <= halo_right <= half):
+            raise ValueError("halo must be within [0, %d]" % half)
+        n_all = frames.shape[0]
+        T = n_all - halo_left - halo_right
+        if T < 0:
+            raise ValueError("frames holds %d frames, fewer than the halos %d + %d" % (n_all, halo_left, halo_right))
         on_host = not frames.is_cuda
         dev = self.device
-        half = self.period // 2
         h, w = frames.shape[1], frames.shape[2]
         oshape = (T, h // 2, w // 2, 3) if half_size_output else (T, h, w, 3)
         out = torch.empty(oshape, dtype=torch.uint8, pin_memory=True) if on_host else torch.empty(oshape, dtype=torch.uint8, device=dev)
@@ -161,8 +168,10 @@ class VideoStabilizer:
             return out
         compute = torch.cuda.current_stream(dev)
         up, down = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-        gray_all = torch.empty((T, 256, 256), device=dev, dtype=torch.float32)
-        chunks = [(s, min(T, s + chunk)) for s in range(0, T, chunk)]
+        gray_all = torch.empty((n_all, 256, 256), device=dev, dtype=torch.float32)
+        # chunk bounds in the index space of `frames`: the first / last chunk carry the halo frames with them
+        chunks = [(s if s > halo_left else 0, min(halo_left + T, s + chunk) if s + chunk < halo_left + T else n_all)
+                  for s in range(halo_left, halo_left + T, chunk)]
         up.wait_stream(compute)   # gray_all was allocated on the compute stream
 
         def upload(c):
@@ -177,7 +186,7 @@ class VideoStabilizer:
         for c, (s, e) in enumerate(chunks):
             # a chunk's windows reach `half` frames past its end: every chunk that holds one of those frames must be on the
             # device (and its planes computed) first; one chunk further ahead keeps the upload stream busy during this compute
-            need = min(T, e + half)
+            need = min(n_all, e + half)
             while uploaded < len(chunks) and (chunks[uploaded][0] < need or uploaded <= c + 1):
                 staged[uploaded] = upload(uploaded)
                 uploaded += 1
@@ -185,10 +194,13 @@ class VideoStabilizer:
                 if chunks[k][0] < need:
                     compute.wait_event(staged[k][1])
             buf, ev = staged.pop(c)
-            hl, hr = min(half, s), min(half, T - e)
-            warped = self.run(gray_all[s - hl:e + hr], buf, halo_left=hl, halo_right=hr)
+            # core frames of this chunk (the halo frames at the clip's ends are uploaded with it but not stabilised)
+            cs, ce = max(s, halo_left), min(e, halo_left + T)
+            hl, hr = min(half, cs), min(half, n_all - ce)
+            warped = self.run(gray_all[cs - hl:ce + hr], buf[cs - s:ce - s], halo_left=hl, halo_right=hr)
             if half_size_output:
                 warped = area_half(warped)
+            s, e = cs - halo_left, ce - halo_left   # position in the output
             if on_host:
                 buf.record_stream(compute)
                 done = torch.cuda.Event()
