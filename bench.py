@@ -574,6 +574,34 @@ def main():
                     print(json.dumps(line), flush=True)
                 os._exit(0)
         threading.Thread(target=watchdog, daemon=True).start()
+        # configs[4] on this node, PCIe inclusive: every rank stabilises its own shard of 128 decoded uint8 720p frames from
+        # pinned host memory to pinned host memory (VideoStabilizer.run_video: frames up, window planes + generator + fused warp
+        # + 2x down-scale on the device, 640x360 frames down); no collective, the host's PCIe / memory system is shared
+        try:
+            from pwstablenet_amd.stream import VideoStabilizer
+            Ts = 128
+            net.module.enable_graph(False)
+            net.module.set_math("fp32")
+            u8_h = torch.randint(0, 256, (Ts, 720, 1280, 3), dtype=torch.uint8).pin_memory()
+            vs = VideoStabilizer(net, batch=B, swap_rb=True)
+            vs.run_video(u8_h[:4 * B], chunk=2 * B, half_size_output=True)
+            barrier()
+            t1 = time.perf_counter()
+            out_h = vs.run_video(u8_h, chunk=64, half_size_output=True)
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - t1
+            barrier()
+            t = torch.tensor([dts], device=ctl_device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if rank == 0:
+                line["value_720p_stream_u8"] = {"value": round(world * Ts / float(t.item()), 1), "unit": "frames/s", "n_gpus": world,
+                                                "workload": "%d uint8 1280x720 frames per GPU, pinned host -> device -> window planes, netG fp32 "
+                                                            "(batch %d), fused u8 warp, 2x INTER_AREA -> pinned host; frame-sharded, no "
+                                                            "collective" % (Ts, B)}
+            del u8_h, out_h, vs
+        except Exception as e:
+            if rank == 0:
+                line["value_720p_stream_u8"] = {"error": str(e)[:300]}
         try:
             from pwstablenet_amd import distributed as D
             nbytes = [0]
