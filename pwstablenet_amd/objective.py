@@ -96,10 +96,14 @@ class _Objective(torch.autograd.Function):
                 "pws_objective_finalize")
         ctx.cfg = cfg
         ctx.save_for_backward(rgb, stable, features, theta, resid, *grids, *fakes)
-        return (losses,) + tuple(fakes)
+        # loss_g is the objective; the full vector (loss_g, loss_mse, ...) is a report and carries no gradient: asking for the
+        # gradient of, say, loss_mse alone raises in autograd instead of silently returning zeros
+        loss_g = losses[0:1].clone()
+        ctx.mark_non_differentiable(losses)
+        return (loss_g, losses) + tuple(fakes)
 
     @staticmethod
-    def backward(ctx, g_losses, *g_fakes):
+    def backward(ctx, g_loss, _g_report, *g_fakes):
         cfg = ctx.cfg
         L_ = cfg["num_layer"]
         sv = ctx.saved_tensors
@@ -111,11 +115,11 @@ class _Objective(torch.autograd.Function):
         rgb_p, rgb_s = _planes(rgb, h, w, "rgb")
         stb_p, stb_s = _planes(stable, h, w, "stable")
         # d loss_g / d(.) times the upstream gradient of loss_g, which stays on the device (no host sync): the kernels
-        # read it through `scale`.  The other five entries of `losses` are reports, not objectives.
-        if g_losses is None:
+        # read it through `scale`.
+        if g_loss is None:
             scale = torch.zeros(1, device=rgb.device, dtype=torch.float32)
         else:
-            scale = g_losses[0:1].contiguous()
+            scale = g_loss.reshape(1).to(torch.float32).contiguous()
         cnt = float(n) * 3 * h * w
         c_l1, c_t = 1.0 / cnt, cfg["lamd"] / cnt
         c_f = 1.0 / (cfg["number_feature"] * cfg["batch"])
@@ -202,8 +206,9 @@ class StabObjective:
                "num_layer": self.num_layer, "coef": lambda dev: self._coef_matrix(n, dev)}
         out = _Objective.apply(cfg, rgb_unstable, image_stable, features.to(dtype=torch.float32).contiguous(), theta,
                                *grids, resid[self.num_layer - 1])
-        losses, fakes = out[0], list(out[1:])
+        loss_g, losses, fakes = out[0], out[1], list(out[2:])
         res = ObjectiveResult({name: losses[i] for i, name in enumerate(LOSS_NAMES)})
+        res["loss_g"] = loss_g[0]      # the differentiable one; the other five are reports (no gradient)
         res["fake"] = fakes
         return res
 

@@ -351,3 +351,19 @@ def test_batched_forwards_equal_the_reference_two_forward_loop(hip):
     for p, r in zip(net.parameters(), ref_grads):
         scale = float(r.abs().max()) + 1e-12
         assert float((p.grad - r).abs().max()) / scale < 2e-3
+
+
+def test_reports_carry_no_gradient(hip):
+    """Only loss_g is an objective: back-propagating one of the reported components raises instead of returning zeros."""
+    from pwstablenet_amd.objective import StabObjective
+    n = 1
+    norm, feats, adj, grid, resid = _inputs(n, 17)
+    d = norm.cuda()
+    grids = [grid.cuda().requires_grad_(True) for _ in range(3)]
+    resids = [resid.cuda().requires_grad_(True) for _ in range(3)]
+    out = StabObjective(batchSize=n)(grids, resids, d[:, 31:34], d[:, 34:], feats.cuda(), adj.cuda())
+    assert out.loss_g.requires_grad and not out.loss_mse.requires_grad and not out.loss_pixel.requires_grad
+    with pytest.raises(RuntimeError):
+        out.loss_mse.backward()
+    out.loss_g.backward()
+    assert grids[0].grad is not None and float(grids[0].grad.abs().max()) > 0
