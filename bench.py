@@ -489,10 +489,13 @@ def main():
             r = [x_ for x_ in A.prof_collect() if x_[0] == "upsample_grid_sample_fwd_kernel"]
             ms = sorted(x_[4] for x_ in r)[len(r) // 2]
             rw = line["value_720p"]["roofline_warp"]
-            rw["field"] = "netG with random synthetic weights"
-            rw["achieved_smooth_field"] = round(r[0][3] / (ms * 1e-3) / 1e9, 1)
-            rw["frac_smooth_field"] = round(r[0][3] / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
-            rw["avg_launch_us_smooth_field"] = round(1e3 * ms, 2)
+            # headline figures = the stabiliser's field; the random-weight generator's field is kept beside them
+            rw["achieved_random_weight_field"], rw["frac_random_weight_field"] = rw["achieved"], rw["frac"]
+            rw["avg_launch_us_random_weight_field"] = rw["avg_launch_us"]
+            rw["field"] = "2 % affine + smooth +-2 px residual, inputs rotated through 4 buffers (HBM, not Infinity Cache)"
+            rw["achieved"] = round(r[0][3] / (ms * 1e-3) / 1e9, 1)
+            rw["frac"] = round(r[0][3] / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+            rw["avg_launch_us"] = round(1e3 * ms, 2)
             del rot, fsm
         except Exception as e:
             line["value_720p"]["roofline_warp"]["smooth_field_error"] = str(e)[:200]
