@@ -79,6 +79,76 @@ struct BfCfg {
         }                                                                                                                  \
     } while (0)
 
+// bf16-storage epilogue with 16-byte stores (p.epi16, no K split).  The MFMA result layout gives a lane ONE channel pair of 16
+// scattered pixel rows: stored as is (epi_store_pair16) that is 16 * MT dword stores per lane, each with its own address math
+// (and a read-modify-write per dword in the accumulating gradient scatter) -- measured at 20-52 % of the kernel's time.  Here
+// every wave turns its 32 pixels x 64 channels of one `mt` pass round in LDS (fp32, 8 KB per wave, over the operand tiles
+// that are dead by now): a lane writes its pairs with ds_write_b64 and reads back 8 CONSECUTIVE channels of one pixel, so
+// that bias / activation / accumulation run on 8 channels at a time and a pixel's 64 channels leave as 8 x 16-byte stores
+// (4 per lane and pass instead of 16).  Row layout: sixteen 16-byte slots, slot (h * 8 + g) = channels 8 g + 4 h .. + 3, the
+// two halves swapped on odd rows: the 32-lane write groups and the 16-lane read groups (2 rows x 8 lanes) are both bank
+// conflict-free.  The arithmetic is that of epi_store_pair16 (fp32 sums, one rounding to bf16).
+#define PWS_BF_EPI16(C, p, acc, wv, wm, lane, l31, hi, n0, y0, x0, co0, py, px, lds_raw, LDS_AVAIL)                       \
+    do {                                                                                                                   \
+        static_assert(C::WM * C::WN * 8192 <= (LDS_AVAIL), "the epilogue tiles reuse the operand tiles' LDS");            \
+        __syncthreads(); /* every wave is done with the operand tiles */                                                  \
+        unsigned char *et_ = (lds_raw) + (wv) * 8192;                                                                      \
+        const int g_ = (lane) & 7;                                                                                         \
+        const int co_ = (co0) + g_ * 8;                                                                                    \
+        const bool co_ok_ = co_ < (p).cout;                                                                                \
+        float b_[8];                                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) b_[k] = ((p).bias && co_ok_) ? (p).bias[co_ + k] : 0.f;             \
+        __bf16 *dbase_ = reinterpret_cast<__bf16 *>((p).out) + co_;                                                        \
+        size_t dld_ = (p).out_ld;                                                                                          \
+        bool dacc_ = false, dok_ = co_ok_;                                                                                 \
+        if ((p).ndst != 0) {                                                                                               \
+            dok_ = false;                                                                                                  \
+            _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                                             \
+                if (s_ < (p).ndst && co_ >= (p).dst_c0[s_] && co_ < (p).dst_c1[s_]) {                                      \
+                    dbase_ = reinterpret_cast<__bf16 *>((p).dst_ptr[s_]) + (co_ - (p).dst_c0[s_]);                         \
+                    dld_ = (p).dst_ld[s_], dacc_ = (p).dst_acc[s_] != 0, dok_ = true;                                      \
+                }                                                                                                          \
+            }                                                                                                              \
+        }                                                                                                                  \
+        const int wslot_ = (((l31) >> 1) & 1) * 8 + ((l31) >> 2);                                                          \
+        _Pragma("unroll") for (int mt = 0; mt < C::MT; ++mt) {                                                             \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                               \
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (hi);                                                         \
+                *reinterpret_cast<float2 *>(et_ + row * 256 + ((wslot_ ^ ((r & 1) * 8)) * 16) + ((l31) & 1) * 8) =         \
+                    make_float2(acc[mt][0][r], acc[mt][1][r]);                                                             \
+            }                                                                                                              \
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                         \
+            __builtin_amdgcn_wave_barrier();                                                                               \
+            _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                                             \
+                const int row = it * 8 + ((lane) >> 3);                                                                    \
+                const int sw_ = (row & 1) * 8;                                                                             \
+                const float4 lo_ = *reinterpret_cast<const float4 *>(et_ + row * 256 + ((g_ ^ sw_) * 16));                 \
+                const float4 hi_ = *reinterpret_cast<const float4 *>(et_ + row * 256 + (((8 + g_) ^ sw_) * 16));           \
+                const int m = ((wm) * C::MT + mt) * 32 + row;                                                              \
+                const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);                              \
+                const int n = (n0) + tn, y = (y0) + ty, x = (x0) + tx;                                                     \
+                const int oy = C::CONVT ? 2 * y + (py) : y, ox = C::CONVT ? 2 * x + (px) : x;                              \
+                if (dok_ && n < (p).N && y < (p).LH && x < (p).LW && oy < (p).OH && ox < (p).OW) {                         \
+                    float v_[8] = {lo_.x, lo_.y, lo_.z, lo_.w, hi_.x, hi_.y, hi_.z, hi_.w};                                \
+                    u32x4 *d_ = reinterpret_cast<u32x4 *>(dbase_ + ((size_t)(n * (p).OH + oy) * (p).OW + ox) * dld_);      \
+                    if ((p).ndst == 0) {                                                                                   \
+                        _Pragma("unroll") for (int k = 0; k < 8; ++k) v_[k] = act_apply(v_[k] + b_[k], (p).act);           \
+                    } else if (dacc_) {                                                                                    \
+                        const u32x4 o_ = *d_;                                                                              \
+                        v_[0] += bf16_lo(o_.x), v_[1] += bf16_hi(o_.x), v_[2] += bf16_lo(o_.y), v_[3] += bf16_hi(o_.y);    \
+                        v_[4] += bf16_lo(o_.z), v_[5] += bf16_hi(o_.z), v_[6] += bf16_lo(o_.w), v_[7] += bf16_hi(o_.w);    \
+                    }                                                                                                      \
+                    u32x4 w_;                                                                                              \
+                    w_.x = cvt_pk_bf16(v_[0], v_[1]), w_.y = cvt_pk_bf16(v_[2], v_[3]);                                    \
+                    w_.z = cvt_pk_bf16(v_[4], v_[5]), w_.w = cvt_pk_bf16(v_[6], v_[7]);                                    \
+                    *d_ = w_;                                                                                              \
+                }                                                                                                          \
+            }                                                                                                              \
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                         \
+            __builtin_amdgcn_wave_barrier();                                                                               \
+        }                                                                                                                  \
+    } while (0)
+
 // IO16: activations / gradients live in HBM as bf16 (io_bf16): a staging item is ONE 16-byte load of 8 channels copied to
 // LDS as is, and the epilogue stores channel pairs as dwords.  For that the 64 output channels of a workgroup are dealt to
 // the lanes as (2 l, 2 l + 1) -> (nt 0, nt 1) instead of (l, l + 32): the weight rows are permuted while they are staged
@@ -234,6 +304,10 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_kernel(const ConvKPar
     if constexpr (IO16) {
         // channel pair (2 l31, 2 l31 + 1) of this wave's 64 channels: one dword per pixel and lane, 128 B per pixel and half-wave
         const bool partial = p.ksplit > 1;
+        if (p.epi16 && !partial) {   // block-uniform
+            PWS_BF_EPI16(C, p, acc, wv, wm, lane, l31, hi, n0, y0, x0, co0, py, px, lds_raw, C::LDS_BYTES);
+            return;
+        }
         float *part = p.out + (size_t)split * p.split_stride;
         const int co = co0 + 2 * l31;
         const bool co_ok = co < p.cout;   // cout is even
@@ -398,6 +472,10 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_k5_kernel(const ConvK
         }
     }
     if constexpr (IO16) {
+        if (p.epi16) {   // block-uniform
+            PWS_BF_EPI16(C, p, acc, wv, wm, lane, l31, hi, n0, y0, x0, co0, 0, 0, lds_raw, K::BYTES);
+            return;
+        }
         const int co = co0 + 2 * l31;
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt) {

@@ -34,6 +34,8 @@ struct ConvKParams {
     const void *w_bf;
     int kpad_bf, npad_bf;
     int io_bf16;    // bf16 math only: sources, `out` and dst_ptr[] hold bf16 elements (strides in elements), see conv_bf16.hip
+    int epi16;      // io_bf16 only: every output row / destination segment is a whole number of 16-byte (8-channel) groups at
+                    // 16-byte aligned addresses -> the LDS-transposed epilogue with 16-byte stores (PWS_BF_EPI16)
     int ndst;
     float *dst_ptr[4];
     int dst_c0[4], dst_c1[4], dst_ld[4], dst_acc[4];

@@ -410,6 +410,7 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
                         "pws_conv2d_fwd: bf16 storage needs channels %% 32 == 0 and ld %% 8 == 0 (source %d: %d, %d)", s,
                         a->src[s].channels, a->src[s].ld);
         kp.io_bf16 = 1;
+        kp.epi16 = a->cout % 8 == 0 && a->out_ld % 8 == 0 && (reinterpret_cast<size_t>(a->out) & 15) == 0;
     }
     kp.w_bf = a->w_bf16, kp.kpad_bf = (kp.cin_pad + 31) / 32 * 32, kp.npad_bf = (a->cout + 63) / 64 * 64;
 
@@ -519,6 +520,9 @@ int conv2d_bwd_data_impl(const pws_conv_bwd_data_args *a, hipStream_t st) {
             PWS_REQUIRE(a->dst[s].channels % 2 == 0 && a->dst[s].ld % 2 == 0 && (reinterpret_cast<size_t>(a->dst[s].ptr) & 3) == 0,
                         "pws_conv2d_bwd_data: bf16 storage needs even channels / ld and 4-byte aligned destinations");
         kp.io_bf16 = 1;
+        kp.epi16 = 1;
+        for (int s = 0; s < a->ndst; ++s)
+            if (a->dst[s].channels % 8 || a->dst[s].ld % 8 || (reinterpret_cast<size_t>(a->dst[s].ptr) & 15)) kp.epi16 = 0;
     }
     if (a->math == PWS_MATH_BF16 && a->w_dgrad_bf16) {
         kp.w_bf = a->w_dgrad_bf16, kp.kpad_bf = (a->cout + 31) / 32 * 32, kp.npad_bf = (cin_f + 63) / 64 * 64;
