@@ -14,6 +14,7 @@
 //     planes of 64-byte rows: the 4 rows x 2 channel halves that one half-wave reads cover all 64 banks exactly once.
 //   * The dy fragment of a 16-pixel k-step is shared by all taps of the step.
 #include "common.h"
+#include <type_traits>
 
 namespace pws {
 
@@ -38,17 +39,21 @@ struct WgradBfParams {
     int ci_blocks, co_blocks;  // of 64 channels
 };
 
-template <int KS_, int STRIDE_, int PAD_, int SUBPIX_, int TH_, int TW_, int TN_, int TG_>
+template <int KS_, int STRIDE_, int PAD_, int SUBPIX_, int TH_, int TW_, int TN_, int TG_, bool CI32_ = false>
 struct WbCfg {
     static constexpr int KS = KS_, STRIDE = STRIDE_, PAD = PAD_, SUBPIX = SUBPIX_, TH = TH_, TW = TW_, TN = TN_;
     static constexpr int TG = TG_;  // taps per workgroup
-    static constexpr int TAPS = KS * KS, NGROUPS = TAPS / TG;
+    // CI32: layers with <= 32 (padded) input channels (the first layer): a workgroup owns 32 input x 64 output channels and its
+    // two wave pairs take two consecutive tap groups instead of two input-channel halves (no wave multiplies zeros)
+    static constexpr bool CI32 = CI32_;
+    static constexpr int TAPS = KS * KS, NGROUPS = CI32 ? (TAPS / TG + 1) / 2 : TAPS / TG;
+    static constexpr int XPL = CI32 ? 1 : 2;                     // 32-channel planes of the x tile
     static constexpr int BM = TH * TW * TN, KSTEPS = BM / 16;
     static_assert(BM % 16 == 0 && TAPS % TG == 0, "tile");
     static constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
     static constexpr int PIX = TN * IH * IW;
     static constexpr int ROW = 64;                               // bytes per LDS row: 32 bf16 channels
-    static constexpr int LDS_X = 2 * PIX * ROW, LDS_G = 2 * BM * ROW;
+    static constexpr int LDS_X = XPL * PIX * ROW, LDS_G = 2 * BM * ROW;
     static constexpr int LDS_BYTES = LDS_X + LDS_G + 16;         // + sink for staging items past the tile
 };
 
@@ -83,12 +88,13 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradBfParams 
     const int li = lane & 15, lg = lane >> 4;
 
     const int cb = blockIdx.y;
-    const int ci0 = (cb / p.co_blocks) * 64, co0 = (cb % p.co_blocks) * 64;
+    const int ci0 = (cb / p.co_blocks) * (C::CI32 ? 32 : 64), co0 = (cb % p.co_blocks) * 64;
     const int cls = C::SUBPIX ? (int)(blockIdx.z & 3) : 0;
     const int tg = C::SUBPIX ? (int)(blockIdx.z >> 2) : (int)blockIdx.z;
     const int py = cls >> 1, px = cls & 1;
     const int pad_y = C::SUBPIX ? 1 - py : C::PAD, pad_x = C::SUBPIX ? 1 - px : C::PAD;
-    const int wci = wv >> 1, wco = wv & 1;  // this wave's 32 x 32 quadrant
+    const int wci = C::CI32 ? 0 : wv >> 1, wco = wv & 1;  // this wave's 32 x 32 quadrant
+    const int wtg = C::CI32 ? 2 * tg + (wv >> 1) : tg;     // ... and tap group (wave-uniform)
 
     f32x16 acc[C::TG];
 #pragma unroll
@@ -108,109 +114,218 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradBfParams 
     }
     constexpr int SINK = C::LDS_X + C::LDS_G;
 
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-        const int tx_i = tile % p.tiles_x, ty_i = (tile / p.tiles_x) % p.tiles_y, tn_i = tile / (p.tiles_x * p.tiles_y);
-        const int n0 = tn_i * C::TN, y0 = ty_i * C::TH, x0 = tx_i * C::TW;
-        const int iy0 = y0 * C::STRIDE - pad_y, ix0 = x0 * C::STRIDE - pad_x;
-        __syncthreads();  // previous tile fully consumed
-        // ---- x halo tile, channels ci0..ci0+63 of the (virtually concatenated) sources: 8-channel items, loads of a batch
-        // issued unconditionally before the first LDS store (masked items read a valid dummy address)
-        {
-            constexpr int NIT = C::PIX * 8, ITS = (NIT + 255) / 256, BATCH = 4;
-#pragma unroll 1
-            for (int it0 = 0; it0 < ITS; it0 += BATCH) {
-                f32x4 r[BATCH][2];
-                u32x4 r16[BATCH];
-                int off[BATCH];
-                bool okv[BATCH];
-#pragma unroll
-                for (int k = 0; k < BATCH; ++k) {
-                    const int item = tid + (it0 + k) * 256;
-                    const int pix = item >> 3, c8 = item & 7;
-                    const int lx = pix % C::IW, ly = (pix / C::IW) % C::IH, tn = pix / (C::IW * C::IH);
-                    const int n = n0 + tn, iy = iy0 + ly, ix = ix0 + lx;
-                    int ch = ci0 + c8 * 8;
-                    const bool ok = item < NIT && ch < p.cin && n < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                    int s = 0;
-                    while (s < p.nsrc - 1 && ch >= p.src_c[s]) ch -= p.src_c[s], ++s;
-                    const size_t e = ok ? ((size_t)(n * p.H + iy) * p.W + ix) * p.src_ld[s] + ch : 0;
-                    if constexpr (IO16) {
-                        r16[k] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const __bf16 *>(p.src_ptr[ok ? s : 0]) + e);
-                    } else {
-                        const float *g = p.src_ptr[ok ? s : 0] + e;
-                        r[k][0] = *reinterpret_cast<const f32x4 *>(g);
-                        r[k][1] = *reinterpret_cast<const f32x4 *>(g + 4);
-                    }
-                    okv[k] = ok;
-                    off[k] = item < NIT ? (c8 >> 2) * C::PIX * C::ROW + pix * C::ROW + (c8 & 3) * 16 : SINK;
-                }
-#pragma unroll
-                for (int k = 0; k < BATCH; ++k) {
-                    u32x4 v;
-                    if constexpr (IO16) {
-                        v.x = okv[k] ? r16[k].x : 0u, v.y = okv[k] ? r16[k].y : 0u, v.z = okv[k] ? r16[k].z : 0u, v.w = okv[k] ? r16[k].w : 0u;
-                    } else {
-                        v.x = okv[k] ? cvt_pk_bf16(r[k][0].x, r[k][0].y) : 0u, v.y = okv[k] ? cvt_pk_bf16(r[k][0].z, r[k][0].w) : 0u;
-                        v.z = okv[k] ? cvt_pk_bf16(r[k][1].x, r[k][1].y) : 0u, v.w = okv[k] ? cvt_pk_bf16(r[k][1].z, r[k][1].w) : 0u;
-                    }
-                    *reinterpret_cast<u32x4 *>(lds + off[k]) = v;
-                }
-            }
-        }
-        // ---- dy tile, channels co0..co0+63 at the tile's output pixels
-        {
-            constexpr int NIT = C::BM * 8, ITS = (NIT + 255) / 256, BATCH = 4;
-#pragma unroll 1
-            for (int it0 = 0; it0 < ITS; it0 += BATCH) {
-                f32x4 r[BATCH][2];
-                u32x4 r16[BATCH];
-                int off[BATCH];
-                bool okv[BATCH];
-#pragma unroll
-                for (int k = 0; k < BATCH; ++k) {
-                    const int item = tid + (it0 + k) * 256;
-                    const int m = item >> 3, c8 = item & 7;
-                    const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
-                    const int n = n0 + tn, y = y0 + ty, x = x0 + tx;
-                    const int oy = C::SUBPIX ? 2 * y + py : y, ox = C::SUBPIX ? 2 * x + px : x;
-                    const int ch = co0 + c8 * 8;
-                    const bool ok = item < NIT && ch < p.cout && n < p.N && y < p.LH && x < p.LW && oy < p.OH && ox < p.OW;
-                    const size_t e = ok ? ((size_t)(n * p.OH + oy) * p.OW + ox) * p.gout_ld + ch : 0;
-                    if constexpr (IO16) {
-                        r16[k] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const __bf16 *>(p.gout) + e);
-                    } else {
-                        r[k][0] = *reinterpret_cast<const f32x4 *>(p.gout + e);
-                        r[k][1] = *reinterpret_cast<const f32x4 *>(p.gout + e + 4);
-                    }
-                    okv[k] = ok;
-                    off[k] = item < NIT ? C::LDS_X + (c8 >> 2) * C::BM * C::ROW + m * C::ROW + (c8 & 3) * 16 : SINK;
-                }
-#pragma unroll
-                for (int k = 0; k < BATCH; ++k) {
-                    u32x4 v;
-                    if constexpr (IO16) {
-                        v.x = okv[k] ? r16[k].x : 0u, v.y = okv[k] ? r16[k].y : 0u, v.z = okv[k] ? r16[k].z : 0u, v.w = okv[k] ? r16[k].w : 0u;
-                    } else {
-                        v.x = okv[k] ? cvt_pk_bf16(r[k][0].x, r[k][0].y) : 0u, v.y = okv[k] ? cvt_pk_bf16(r[k][0].z, r[k][0].w) : 0u;
-                        v.z = okv[k] ? cvt_pk_bf16(r[k][1].x, r[k][1].y) : 0u, v.w = okv[k] ? cvt_pk_bf16(r[k][1].z, r[k][1].w) : 0u;
-                    }
-                    *reinterpret_cast<u32x4 *>(lds + off[k]) = v;
-                }
-            }
-        }
-        __syncthreads();
+    auto compute = [&]() {
         // ---- K steps of 16 pixels over the whole tile
 #pragma unroll
         for (int j = 0; j < C::KSTEPS; ++j) {
             const bf16x8 b = tr_pair(lds, b_lane[0] + j * 16 * C::ROW, b_lane[1] + j * 16 * C::ROW);
 #pragma unroll
             for (int t = 0; t < C::TG; ++t) {
-                const int tap = (C::NGROUPS == 1 ? 0 : tg * C::TG) + t;  // tg is block-uniform
+                const int tap = (C::NGROUPS == 1 ? 0 : wtg * C::TG) + t;  // wave-uniform
+                if (C::CI32 && tap >= C::TAPS) continue;
                 const int toff = ((tap / C::KS) * C::IW + (tap % C::KS)) * C::ROW;
                 const int joff = j * wb_xoff<C>(16) * C::ROW + toff;
                 const bf16x8 a = tr_pair(lds, a_lane[0] + joff, a_lane[1] + joff);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
             }
+        }
+    };
+
+    if constexpr (IO16) {
+        // bf16 storage: the whole tile (x halo + dy) of the NEXT tile is in flight in registers while the matrix cores work on
+        // the current one (a staging item is one 16-byte load; 256 % 8 == 0, so a lane keeps ONE 8-channel group for all its
+        // items: source, channel offset and LDS column are tile-invariant, and an item's LDS row is p0 + 32 * it).
+        // Before: batches of 4 loads, each batch waited for before its LDS stores -- 7 exposed memory latencies per tile, which
+        // was 80 % of the kernel's time (64->64 @256x256 x32: 305 us, 116 us with the loads removed but the rest in place).
+        constexpr int XC = 4 * C::XPL, XPP = 256 / XC;   // 16-byte groups per x pixel, x pixels per pass of the workgroup
+        constexpr int XITS = (C::PIX + XPP - 1) / XPP, GITS = (C::BM * 8 + 255) / 256;
+        static_assert(XITS <= 16 && GITS <= 16, "mask width");
+        const int c8 = tid & 7, p0 = tid >> 3;
+        const int cx = tid % XC, px0 = tid / XC;
+        int xch = ci0 + cx * 8, xs = 0;
+        const bool xc_ok = xch < p.cin;
+        while (xs < p.nsrc - 1 && xch >= p.src_c[xs]) xch -= p.src_c[xs], ++xs;
+        if (!xc_ok) xs = 0, xch = 0;
+        const __bf16 *xsrc = reinterpret_cast<const __bf16 *>(p.src_ptr[xs]) + xch;
+        const size_t xld = p.src_ld[xs];
+        const bool gc_ok = co0 + c8 * 8 < p.cout;
+        const __bf16 *gsrc = reinterpret_cast<const __bf16 *>(p.gout) + (gc_ok ? co0 + c8 * 8 : 0);
+        const int xl0 = (cx >> 2) * C::PIX * C::ROW + px0 * C::ROW + (cx & 3) * 16;
+        const int gl0 = C::LDS_X + (c8 >> 2) * C::BM * C::ROW + p0 * C::ROW + (c8 & 3) * 16;
+        u32x4 rx[XITS], rg[GITS];
+        unsigned okx = 0, okg = 0;
+
+        int n0 = 0, y0 = 0, x0 = 0;
+        auto locate = [&](int tile) {
+            const int tx_i = tile % p.tiles_x, ty_i = (tile / p.tiles_x) % p.tiles_y, tn_i = tile / (p.tiles_x * p.tiles_y);
+            n0 = tn_i * C::TN, y0 = ty_i * C::TH, x0 = tx_i * C::TW;
+        };
+        auto issue_x = [&](auto B, auto E) {   // items [B, E); all loads unconditional (masked items read a valid dummy address)
+            const int iy0 = y0 * C::STRIDE - pad_y, ix0 = x0 * C::STRIDE - pad_x;
+            if (B.value == 0) okx = 0;
+#pragma unroll
+            for (int it = B.value; it < E.value; ++it) {
+                const int pix = px0 + XPP * it;
+                const int lx = pix % C::IW, ly = (pix / C::IW) % C::IH, tn = pix / (C::IW * C::IH);
+                const int n = n0 + tn, iy = iy0 + ly, ix = ix0 + lx;
+                const bool ok = pix < C::PIX && xc_ok && n < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                const size_t e = ok ? (size_t)((n * p.H + iy) * p.W + ix) * xld : 0;
+                rx[it] = *reinterpret_cast<const u32x4 *>(xsrc + e);
+                okx |= ok ? (1u << it) : 0u;
+            }
+        };
+        auto issue_g = [&]() {
+            okg = 0;
+#pragma unroll
+            for (int it = 0; it < GITS; ++it) {
+                const int m = p0 + 32 * it;
+                const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
+                const int n = n0 + tn, y = y0 + ty, x = x0 + tx;
+                const int oy = C::SUBPIX ? 2 * y + py : y, ox = C::SUBPIX ? 2 * x + px : x;
+                const bool ok = m < C::BM && gc_ok && n < p.N && y < p.LH && x < p.LW && oy < p.OH && ox < p.OW;
+                const size_t e = ok ? (size_t)((n * p.OH + oy) * p.OW + ox) * p.gout_ld : 0;
+                rg[it] = *reinterpret_cast<const u32x4 *>(gsrc + e);
+                okg |= ok ? (1u << it) : 0u;
+            }
+        };
+        auto commit_x = [&](auto B, auto E) {
+#pragma unroll
+            for (int it = B.value; it < E.value; ++it) {
+                const bool ok = (okx >> it) & 1u;
+                u32x4 v;
+                v.x = ok ? rx[it].x : 0u, v.y = ok ? rx[it].y : 0u, v.z = ok ? rx[it].z : 0u, v.w = ok ? rx[it].w : 0u;
+                const int off = (XPP * it + XPP - 1 < C::PIX || px0 + XPP * it < C::PIX) ? xl0 + it * XPP * C::ROW : SINK;
+                *reinterpret_cast<u32x4 *>(lds + off) = v;
+            }
+        };
+        auto commit_g = [&]() {
+#pragma unroll
+            for (int it = 0; it < GITS; ++it) {
+                const bool ok = (okg >> it) & 1u;
+                u32x4 v;
+                v.x = ok ? rg[it].x : 0u, v.y = ok ? rg[it].y : 0u, v.z = ok ? rg[it].z : 0u, v.w = ok ? rg[it].w : 0u;
+                const int off = (32 * it + 31 < C::BM || p0 + 32 * it < C::BM) ? gl0 + it * 32 * C::ROW : SINK;
+                *reinterpret_cast<u32x4 *>(lds + off) = v;
+            }
+        };
+
+        // the prefetch registers live across the matrix phase beside the TG accumulators: where that does not fit the 256
+        // registers of a wave at 2 workgroups per CU, the x tile (in at most two parts) and the dy tile are each loaded in one go
+        // just before they are stored (2-3 exposed latencies per tile)
+        constexpr bool PREFETCH = (XITS + GITS) * 4 + C::TG * 16 <= 192;
+        constexpr int XH = XITS > 11 ? (XITS + 1) / 2 : XITS;
+        constexpr std::integral_constant<int, 0> I0;
+        constexpr std::integral_constant<int, XH> IH_;
+        constexpr std::integral_constant<int, XITS> IX;
+        int tile = blockIdx.x;
+        if (PREFETCH && tile < p.ntiles) locate(tile), issue_x(I0, IX), issue_g();
+        for (; tile < p.ntiles; tile += gridDim.x) {
+            __syncthreads();  // previous tile fully consumed
+            if constexpr (PREFETCH) {
+                commit_x(I0, IX), commit_g();
+            } else {
+                locate(tile);
+                issue_x(I0, IH_), commit_x(I0, IH_);
+                if constexpr (XH < XITS) issue_x(IH_, IX), commit_x(IH_, IX);
+                issue_g(), commit_g();
+            }
+            __syncthreads();
+            if (PREFETCH && tile + (int)gridDim.x < p.ntiles) locate(tile + gridDim.x), issue_x(I0, IX), issue_g();
+            compute();
+        }
+    } else {
+        for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+            const int tx_i = tile % p.tiles_x, ty_i = (tile / p.tiles_x) % p.tiles_y, tn_i = tile / (p.tiles_x * p.tiles_y);
+            const int n0 = tn_i * C::TN, y0 = ty_i * C::TH, x0 = tx_i * C::TW;
+            const int iy0 = y0 * C::STRIDE - pad_y, ix0 = x0 * C::STRIDE - pad_x;
+            __syncthreads();  // previous tile fully consumed
+            // ---- x halo tile, channels ci0..ci0+63 of the (virtually concatenated) sources: 8-channel items, loads of a batch
+            // issued unconditionally before the first LDS store (masked items read a valid dummy address)
+            {
+                constexpr int NIT = C::PIX * 8, ITS = (NIT + 255) / 256, BATCH = 4;
+    #pragma unroll 1
+                for (int it0 = 0; it0 < ITS; it0 += BATCH) {
+                    f32x4 r[BATCH][2];
+                    u32x4 r16[BATCH];
+                    int off[BATCH];
+                    bool okv[BATCH];
+    #pragma unroll
+                    for (int k = 0; k < BATCH; ++k) {
+                        const int item = tid + (it0 + k) * 256;
+                        const int pix = item >> 3, c8 = item & 7;
+                        const int lx = pix % C::IW, ly = (pix / C::IW) % C::IH, tn = pix / (C::IW * C::IH);
+                        const int n = n0 + tn, iy = iy0 + ly, ix = ix0 + lx;
+                        int ch = ci0 + c8 * 8;
+                        const bool ok = item < NIT && ch < p.cin && n < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                        int s = 0;
+                        while (s < p.nsrc - 1 && ch >= p.src_c[s]) ch -= p.src_c[s], ++s;
+                        const size_t e = ok ? ((size_t)(n * p.H + iy) * p.W + ix) * p.src_ld[s] + ch : 0;
+                        if constexpr (IO16) {
+                            r16[k] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const __bf16 *>(p.src_ptr[ok ? s : 0]) + e);
+                        } else {
+                            const float *g = p.src_ptr[ok ? s : 0] + e;
+                            r[k][0] = *reinterpret_cast<const f32x4 *>(g);
+                            r[k][1] = *reinterpret_cast<const f32x4 *>(g + 4);
+                        }
+                        okv[k] = ok;
+                        off[k] = item < NIT && c8 < 4 * C::XPL ? (c8 >> 2) * C::PIX * C::ROW + pix * C::ROW + (c8 & 3) * 16 : SINK;
+                    }
+    #pragma unroll
+                    for (int k = 0; k < BATCH; ++k) {
+                        u32x4 v;
+                        if constexpr (IO16) {
+                            v.x = okv[k] ? r16[k].x : 0u, v.y = okv[k] ? r16[k].y : 0u, v.z = okv[k] ? r16[k].z : 0u, v.w = okv[k] ? r16[k].w : 0u;
+                        } else {
+                            v.x = okv[k] ? cvt_pk_bf16(r[k][0].x, r[k][0].y) : 0u, v.y = okv[k] ? cvt_pk_bf16(r[k][0].z, r[k][0].w) : 0u;
+                            v.z = okv[k] ? cvt_pk_bf16(r[k][1].x, r[k][1].y) : 0u, v.w = okv[k] ? cvt_pk_bf16(r[k][1].z, r[k][1].w) : 0u;
+                        }
+                        *reinterpret_cast<u32x4 *>(lds + off[k]) = v;
+                    }
+                }
+            }
+            // ---- dy tile, channels co0..co0+63 at the tile's output pixels
+            {
+                constexpr int NIT = C::BM * 8, ITS = (NIT + 255) / 256, BATCH = 4;
+    #pragma unroll 1
+                for (int it0 = 0; it0 < ITS; it0 += BATCH) {
+                    f32x4 r[BATCH][2];
+                    u32x4 r16[BATCH];
+                    int off[BATCH];
+                    bool okv[BATCH];
+    #pragma unroll
+                    for (int k = 0; k < BATCH; ++k) {
+                        const int item = tid + (it0 + k) * 256;
+                        const int m = item >> 3, c8 = item & 7;
+                        const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
+                        const int n = n0 + tn, y = y0 + ty, x = x0 + tx;
+                        const int oy = C::SUBPIX ? 2 * y + py : y, ox = C::SUBPIX ? 2 * x + px : x;
+                        const int ch = co0 + c8 * 8;
+                        const bool ok = item < NIT && ch < p.cout && n < p.N && y < p.LH && x < p.LW && oy < p.OH && ox < p.OW;
+                        const size_t e = ok ? ((size_t)(n * p.OH + oy) * p.OW + ox) * p.gout_ld + ch : 0;
+                        if constexpr (IO16) {
+                            r16[k] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const __bf16 *>(p.gout) + e);
+                        } else {
+                            r[k][0] = *reinterpret_cast<const f32x4 *>(p.gout + e);
+                            r[k][1] = *reinterpret_cast<const f32x4 *>(p.gout + e + 4);
+                        }
+                        okv[k] = ok;
+                        off[k] = item < NIT ? C::LDS_X + (c8 >> 2) * C::BM * C::ROW + m * C::ROW + (c8 & 3) * 16 : SINK;
+                    }
+    #pragma unroll
+                    for (int k = 0; k < BATCH; ++k) {
+                        u32x4 v;
+                        if constexpr (IO16) {
+                            v.x = okv[k] ? r16[k].x : 0u, v.y = okv[k] ? r16[k].y : 0u, v.z = okv[k] ? r16[k].z : 0u, v.w = okv[k] ? r16[k].w : 0u;
+                        } else {
+                            v.x = okv[k] ? cvt_pk_bf16(r[k][0].x, r[k][0].y) : 0u, v.y = okv[k] ? cvt_pk_bf16(r[k][0].z, r[k][0].w) : 0u;
+                            v.z = okv[k] ? cvt_pk_bf16(r[k][1].x, r[k][1].y) : 0u, v.w = okv[k] ? cvt_pk_bf16(r[k][1].z, r[k][1].w) : 0u;
+                        }
+                        *reinterpret_cast<u32x4 *>(lds + off[k]) = v;
+                    }
+                }
+            }
+            __syncthreads();
+            compute();
         }
     }
 
@@ -218,7 +333,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradBfParams 
     const int co = co0 + wco * 32 + l31;
 #pragma unroll
     for (int t = 0; t < C::TG; ++t) {
-        const int tap = tg * C::TG + t;
+        const int tap = wtg * C::TG + t;
+        if (C::CI32 && tap >= C::TAPS) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ci = ci0 + wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -251,7 +367,7 @@ static int launch_wb(WgradBfParams &p, int nclasses, hipStream_t st) {
     }
     p.tiles_x = (p.LW + C::TW - 1) / C::TW, p.tiles_y = (p.LH + C::TH - 1) / C::TH, p.tiles_n = (p.N + C::TN - 1) / C::TN;
     p.ntiles = p.tiles_x * p.tiles_y * p.tiles_n;
-    p.ci_blocks = (p.cin_pad + 63) / 64, p.co_blocks = (p.cout + 63) / 64;
+    p.ci_blocks = C::CI32 ? (p.cin_pad + 31) / 32 : (p.cin_pad + 63) / 64, p.co_blocks = (p.cout + 63) / 64;
     const long other = (long)p.ci_blocks * p.co_blocks * nclasses * C::NGROUPS;
     // ~2 workgroups per CU overall: every workgroup ends with 64 x 64 x taps fp32 atomics on the same addresses, and with
     // the bf16 MFMA rate that tail is what a 1024-workgroup grid is bound by (64->64 @256x256 x8: 176 us -> 117 us at 512)
@@ -273,6 +389,7 @@ static constexpr WbChoice wbchoice() {
 
 //                       KS S  P  subpix TH  TW  TN  TG
 using WB_K3S1_T256 = WbCfg<3, 1, 1, 0, 16, 16, 1, 9>;
+using WB_K3S1_T128 = WbCfg<3, 1, 1, 0, 8, 16, 1, 9>;
 using WB_K3S1_T64 = WbCfg<3, 1, 1, 0, 8, 8, 1, 9>;
 using WB_K3S1_T64N4 = WbCfg<3, 1, 1, 0, 4, 4, 4, 9>;
 using WB_K3S1_T64N16 = WbCfg<3, 1, 1, 0, 2, 2, 16, 9>;
@@ -280,15 +397,16 @@ using WB_K3S2_T64 = WbCfg<3, 2, 1, 0, 8, 8, 1, 9>;
 using WB_K3S2_T64N4 = WbCfg<3, 2, 1, 0, 4, 4, 4, 9>;
 using WB_K3S2_T64N16 = WbCfg<3, 2, 1, 0, 2, 2, 16, 9>;
 using WB_K5S1_T128 = WbCfg<5, 1, 2, 0, 8, 16, 1, 5>;   // first layer: one kernel row of taps per workgroup
+using WB_K5S1_T256H = WbCfg<5, 1, 2, 0, 16, 16, 1, 5, true>;   // ... <= 32 input channels: two kernel rows per workgroup
 using WB_CT4_T256 = WbCfg<2, 1, 0, 1, 16, 16, 1, 4>;
 using WB_CT4_T64 = WbCfg<2, 1, 0, 1, 8, 8, 1, 4>;
 using WB_CT4_T64N4 = WbCfg<2, 1, 0, 1, 4, 4, 4, 4>;
 using WB_CT4_T64N16 = WbCfg<2, 1, 0, 1, 2, 2, 16, 4>;
 
-static const WbChoice kWbK3S1[] = {wbchoice<WB_K3S1_T256>(), wbchoice<WB_K3S1_T64>(), wbchoice<WB_K3S1_T64N4>(),
+static const WbChoice kWbK3S1[] = {wbchoice<WB_K3S1_T256>(), wbchoice<WB_K3S1_T128>(), wbchoice<WB_K3S1_T64>(), wbchoice<WB_K3S1_T64N4>(),
                                    wbchoice<WB_K3S1_T64N16>()};
 static const WbChoice kWbK3S2[] = {wbchoice<WB_K3S2_T64>(), wbchoice<WB_K3S2_T64N4>(), wbchoice<WB_K3S2_T64N16>()};
-static const WbChoice kWbK5[] = {wbchoice<WB_K5S1_T128>()};
+static const WbChoice kWbK5[] = {wbchoice<WB_K5S1_T128>(), wbchoice<WB_K5S1_T256H>()};
 static const WbChoice kWbCT4[] = {wbchoice<WB_CT4_T256>(), wbchoice<WB_CT4_T64>(), wbchoice<WB_CT4_T64N4>(),
                                   wbchoice<WB_CT4_T64N16>()};
 
@@ -333,7 +451,7 @@ int wgrad_bf16_launch(const pws_conv_bwd_weight_args *a, hipStream_t st) {
     case PWS_CONV_K3S1:
     case PWS_CONVT_K3S1:
         p.OH = p.LH = a->h, p.OW = p.LW = a->w;
-        c = &pick(kWbK3S1, 4, p.LH, p.LW, p.N);
+        c = &pick(kWbK3S1 + (g_experiment == 1 ? 0 : 1), g_experiment == 1 ? 5 : 4, p.LH, p.LW, p.N);
         break;
     case PWS_CONV_K3S2:
         p.OH = p.LH = (a->h - 1) / 2 + 1, p.OW = p.LW = (a->w - 1) / 2 + 1;
@@ -345,7 +463,7 @@ int wgrad_bf16_launch(const pws_conv_bwd_weight_args *a, hipStream_t st) {
         break;
     case PWS_CONV_K5S1:
         p.OH = p.LH = a->h, p.OW = p.LW = a->w, k2 = 25;
-        c = &kWbK5[0];
+        c = &kWbK5[p.cin_pad <= 32 && g_experiment != 2 ? 1 : 0];
         break;
     default: return 1;
     }

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--math", choices=("fp32", "bf16"), default="fp32")
+    ap.add_argument("--list", type=int, default=0, help="also list the N slowest launches of any kernel")
     a = ap.parse_args()
     net = define_G(31, 2, 64, "normal", 0.02)
     net.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in synth.make_weights("W1", 123, ngf=64)})
@@ -65,6 +66,10 @@ def main():
                   key=lambda r: -r[4])[:14]
     for name, tag, fl, by, ms in slow:
         print("  %-40s %-26s %8.1f us %7.1f TF/s" % (name, names[tag] if 0 <= tag < len(names) else "-", ms * 1e3, fl / (ms * 1e-3) / 1e12))
+    if a.list:   # every launch, slowest first, with its algorithmic bytes
+        for name, tag, fl, by, ms in sorted(recs, key=lambda r: -r[4])[:a.list]:
+            print("  . %-38s %-26s %8.1f us %7.1f TF/s %7.1f GB/s" % (name, names[tag] if 0 <= tag < len(names) else "-", ms * 1e3,
+                                                                fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9))
 
 
 if __name__ == "__main__":
