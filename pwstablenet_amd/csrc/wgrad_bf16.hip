@@ -451,7 +451,7 @@ int wgrad_bf16_launch(const pws_conv_bwd_weight_args *a, hipStream_t st) {
     case PWS_CONV_K3S1:
     case PWS_CONVT_K3S1:
         p.OH = p.LH = a->h, p.OW = p.LW = a->w;
-        c = &pick(kWbK3S1 + (g_experiment == 1 ? 0 : 1), g_experiment == 1 ? 5 : 4, p.LH, p.LW, p.N);
+        c = &pick(kWbK3S1, 5, p.LH, p.LW, p.N);
         break;
     case PWS_CONV_K3S2:
         p.OH = p.LH = (a->h - 1) / 2 + 1, p.OW = p.LW = (a->w - 1) / 2 + 1;
@@ -463,7 +463,7 @@ int wgrad_bf16_launch(const pws_conv_bwd_weight_args *a, hipStream_t st) {
         break;
     case PWS_CONV_K5S1:
         p.OH = p.LH = a->h, p.OW = p.LW = a->w, k2 = 25;
-        c = &kWbK5[p.cin_pad <= 32 && g_experiment != 2 ? 1 : 0];
+        c = &kWbK5[p.cin_pad <= 32 ? 1 : 0];
         break;
     default: return 1;
     }
