@@ -357,6 +357,9 @@ int pws_objective_finalize(const double *slots, int nq, const double *coef, int 
 int pws_maxpool2x2_fwd(const float *x, float *y, int n, int h, int w, int c, pws_stream_t stream);
 /* dx (overwritten) = dy routed to the first maximum of each window in row-major scan order (ATen's argmax), 0 elsewhere */
 int pws_maxpool2x2_bwd(const float *x, const float *dy, float *dx, int n, int h, int w, int c, pws_stream_t stream);
+/* the same with the element type of x / y / dy / dx given by `store` (PWS_STORE_BF16: bf16 elements, c % 8 == 0) */
+int pws_maxpool2x2_fwd_s(const void *x, void *y, int n, int h, int w, int c, int store, pws_stream_t stream);
+int pws_maxpool2x2_bwd_s(const void *x, const void *dy, void *dx, int n, int h, int w, int c, int store, pws_stream_t stream);
 /* nn.MSELoss pieces: slots[PWS_OBJ_SLOTS] (caller-zeroed doubles) += sum (a-b)^2 ;  ga = c * (*scale) * 2 (a-b) */
 int pws_sqdiff_sum(const float *a, const float *b, size_t count, double *slots, pws_stream_t stream);
 int pws_sqdiff_bwd(const float *a, const float *b, size_t count, float c, const float *scale, float *ga, pws_stream_t stream);

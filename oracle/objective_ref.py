@@ -103,16 +103,21 @@ def objective(grids1, resid1, grids2, resid2, image_unstable1, image_stable1, fe
 VGG16_CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M")
 
 
-def vgg16_features(params, x):
+def vgg16_features(params, x, store_bf16=False):
     """``nn.Sequential(*list(vgg16.features)[:31])`` (lib/utils.py:14-15) as functional calls; params: [w, b] per conv in
     order.  PARITY UNPINNED against the reference for this function: torchvision and its pretrained weights are absent here,
-    so tests run it with seeded random weights (same arithmetic, arbitrary weights)."""
+    so tests run it with seeded random weights (same arithmetic, arbitrary weights).
+    ``store_bf16``: model of the HIP path's bf16 mode -- weights, the input and every layer's output rounded to bf16 (fp32
+    accumulation, fp32 bias); the casts' backward rounds the activation gradients to bf16 the same way."""
+    def rnd(t):
+        return t.bfloat16().float() if store_bf16 else t
+    x = rnd(x)
     i = 0
     for v in VGG16_CFG:
         if v == "M":
             x = F.max_pool2d(x, 2, 2)
         else:
-            x = F.relu(F.conv2d(x, params[i], params[i + 1], padding=1))
+            x = rnd(F.relu(F.conv2d(x, rnd(params[i]), params[i + 1], padding=1)))
             i += 2
     return x
 

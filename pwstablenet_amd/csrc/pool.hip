@@ -1,6 +1,6 @@
 // Small HBM-bound kernels of the VGG-16 perceptual term (reference lib/utils.py:11-32: nn.Sequential(*vgg16.features[:31])
 // -> 13 x (conv3x3 + ReLU, run by the conv kernels of this library) and 5 x MaxPool2d(2, 2); MSELoss between the features of
-// the warped frame and of the stable frame).  NHWC fp32, one lane per (output pixel, 4 channels).
+// the warped frame and of the stable frame).  NHWC fp32, one lane per (output pixel, 4 channels); bf16-storage variants of the pooling: 8 channels per lane.
 #include "common.h"
 
 namespace pws {
@@ -56,6 +56,58 @@ __global__ void __launch_bounds__(256) maxpool2x2_bwd_kernel(const float *__rest
     float *q = dx + o;
     *reinterpret_cast<float4 *>(q) = ga, *reinterpret_cast<float4 *>(q + C) = gb;
     *reinterpret_cast<float4 *>(q + (size_t)W * C) = gc, *reinterpret_cast<float4 *>(q + (size_t)W * C + C) = gd;
+}
+
+// bf16-storage variants (PWS_STORE_BF16): one lane per (output pixel, 8 channels) = one 16-byte load per window position.
+// max / routing on the fp32 expansions are exact (the result is one of the inputs, or 0).
+__device__ __forceinline__ void unpack8(const u32x4 u, float (&f)[8]) {
+    f[0] = __builtin_bit_cast(float, u.x << 16), f[1] = __builtin_bit_cast(float, u.x & 0xffff0000u);
+    f[2] = __builtin_bit_cast(float, u.y << 16), f[3] = __builtin_bit_cast(float, u.y & 0xffff0000u);
+    f[4] = __builtin_bit_cast(float, u.z << 16), f[5] = __builtin_bit_cast(float, u.z & 0xffff0000u);
+    f[6] = __builtin_bit_cast(float, u.w << 16), f[7] = __builtin_bit_cast(float, u.w & 0xffff0000u);
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+    u32x4 u;
+    u.x = cvt_pk_bf16(f[0], f[1]), u.y = cvt_pk_bf16(f[2], f[3]), u.z = cvt_pk_bf16(f[4], f[5]), u.w = cvt_pk_bf16(f[6], f[7]);
+    return u;
+}
+__global__ void __launch_bounds__(256) maxpool2x2_fwd16_kernel(const __bf16 *__restrict__ x, __bf16 *__restrict__ y, int OH, int OW, int C8,
+                                                               size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c8 = (int)(i % C8);
+    const size_t op = i / C8;
+    const int ox = (int)(op % OW), oy = (int)((op / OW) % OH);
+    const size_t n = op / ((size_t)OW * OH);
+    const int W = 2 * OW, C = 8 * C8;
+    const __bf16 *p = x + ((n * 2 * OH + 2 * oy) * W + 2 * ox) * C + 8 * c8;
+    float a[8], b[8], c[8], d[8], r[8];
+    unpack8(*reinterpret_cast<const u32x4 *>(p), a), unpack8(*reinterpret_cast<const u32x4 *>(p + C), b);
+    unpack8(*reinterpret_cast<const u32x4 *>(p + (size_t)W * C), c), unpack8(*reinterpret_cast<const u32x4 *>(p + (size_t)W * C + C), d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = fmaxf(fmaxf(a[k], b[k]), fmaxf(c[k], d[k]));
+    *reinterpret_cast<u32x4 *>(y + op * C + 8 * c8) = pack8(r);
+}
+__global__ void __launch_bounds__(256) maxpool2x2_bwd16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ dy,
+                                                               __bf16 *__restrict__ dx, int OH, int OW, int C8, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c8 = (int)(i % C8);
+    const size_t op = i / C8;
+    const int ox = (int)(op % OW), oy = (int)((op / OW) % OH);
+    const size_t n = op / ((size_t)OW * OH);
+    const int W = 2 * OW, C = 8 * C8;
+    const size_t o = ((n * 2 * OH + 2 * oy) * W + 2 * ox) * C + 8 * c8;
+    const __bf16 *p = x + o;
+    float a[8], b[8], c[8], d[8], g[8], ga[8], gb[8], gc[8], gd[8];
+    unpack8(*reinterpret_cast<const u32x4 *>(p), a), unpack8(*reinterpret_cast<const u32x4 *>(p + C), b);
+    unpack8(*reinterpret_cast<const u32x4 *>(p + (size_t)W * C), c), unpack8(*reinterpret_cast<const u32x4 *>(p + (size_t)W * C + C), d);
+    unpack8(*reinterpret_cast<const u32x4 *>(dy + op * C + 8 * c8), g);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) route(a[k], b[k], c[k], d[k], g[k], ga[k], gb[k], gc[k], gd[k]);
+    __bf16 *q = dx + o;
+    *reinterpret_cast<u32x4 *>(q) = pack8(ga), *reinterpret_cast<u32x4 *>(q + C) = pack8(gb);
+    *reinterpret_cast<u32x4 *>(q + (size_t)W * C) = pack8(gc), *reinterpret_cast<u32x4 *>(q + (size_t)W * C + C) = pack8(gd);
 }
 
 // slots += sum (a - b)^2 (fp32 per lane, fp64 per workgroup, one f64 atomic per workgroup into one of PWS_OBJ_SLOTS slots)
@@ -114,6 +166,36 @@ extern "C" int pws_maxpool2x2_bwd(const float *x, const float *dy, float *dx, in
     hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), x, dy, dx, h / 2,
                        w / 2, c / 4, total);
     return check_launch("maxpool2x2_bwd_kernel");
+}
+
+extern "C" int pws_maxpool2x2_fwd_s(const void *x, void *y, int n, int h, int w, int c, int store, pws_stream_t stream) {
+    if (store == PWS_STORE_FP32) return pws_maxpool2x2_fwd(static_cast<const float *>(x), static_cast<float *>(y), n, h, w, c, stream);
+    PWS_REQUIRE(store == PWS_STORE_BF16, "pws_maxpool2x2_fwd_s: bad store %d", store);
+    PWS_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0 && h % 2 == 0 && w % 2 == 0 && c % 8 == 0,
+                "pws_maxpool2x2_fwd_s: h, w must be even and c a multiple of 8 for bf16 storage (got %d x %d x %d)", h, w, c);
+    if (n == 0) return PWS_OK;
+    PWS_REQUIRE(x && y && a16(x) && a16(y), "pws_maxpool2x2_fwd_s: NULL or unaligned pointer");
+    const size_t total = (size_t)n * (h / 2) * (w / 2) * (c / 8);
+    ProfScope prof(KID_OBJECTIVE, 3.0 * total * 8, 10.0 * total * 8, as_stream(stream));
+    hipLaunchKernelGGL(maxpool2x2_fwd16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       static_cast<const __bf16 *>(x), static_cast<__bf16 *>(y), h / 2, w / 2, c / 8, total);
+    return check_launch("maxpool2x2_fwd16_kernel");
+}
+
+extern "C" int pws_maxpool2x2_bwd_s(const void *x, const void *dy, void *dx, int n, int h, int w, int c, int store,
+                                    pws_stream_t stream) {
+    if (store == PWS_STORE_FP32)
+        return pws_maxpool2x2_bwd(static_cast<const float *>(x), static_cast<const float *>(dy), static_cast<float *>(dx), n, h, w, c, stream);
+    PWS_REQUIRE(store == PWS_STORE_BF16, "pws_maxpool2x2_bwd_s: bad store %d", store);
+    PWS_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0 && h % 2 == 0 && w % 2 == 0 && c % 8 == 0,
+                "pws_maxpool2x2_bwd_s: h, w must be even and c a multiple of 8 for bf16 storage (got %d x %d x %d)", h, w, c);
+    if (n == 0) return PWS_OK;
+    PWS_REQUIRE(x && dy && dx && a16(x) && a16(dy) && a16(dx), "pws_maxpool2x2_bwd_s: NULL or unaligned pointer");
+    const size_t total = (size_t)n * (h / 2) * (w / 2) * (c / 8);
+    ProfScope prof(KID_OBJECTIVE, 8.0 * total * 8, 18.0 * total * 8, as_stream(stream));
+    hipLaunchKernelGGL(maxpool2x2_bwd16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       static_cast<const __bf16 *>(x), static_cast<const __bf16 *>(dy), static_cast<__bf16 *>(dx), h / 2, w / 2, c / 8, total);
+    return check_launch("maxpool2x2_bwd16_kernel");
 }
 
 extern "C" int pws_sqdiff_sum(const float *a, const float *b, size_t count, double *slots, pws_stream_t stream) {

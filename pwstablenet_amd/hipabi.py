@@ -128,6 +128,8 @@ SIGNATURES = {
     "pws_objective_finalize": (_I, [_P, _I, _P, _I, _P, _P]),
     "pws_maxpool2x2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "pws_maxpool2x2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "pws_maxpool2x2_fwd_s": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "pws_maxpool2x2_bwd_s": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "pws_sqdiff_sum": (_I, [_P, _P, _S, _P, _P]),
     "pws_sqdiff_bwd": (_I, [_P, _P, _S, _F, _P, _P, _P]),
     "pws_gray_area_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
