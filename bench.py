@@ -552,16 +552,17 @@ def main():
                 del u8_h, out_h
             except Exception as e:  # an extra leg must never cost the headline line
                 line["value_720p_stream_u8"] = {"error": str(e)[:200]}
-        if not a.no_extra and a.math == "fp32" and world == 1:
-            line["bf16"] = bf16_legs(net, x, frames, out, a, PF, A, synth)
         if world == 1 and not a.no_cpu_baseline:
-            def gpu_one(xc, fc):
+            def gpu_one(xc, fc):   # before the training legs below, which move the weights
                 net.module.enable_graph(False)
                 net.module.set_math("fp32")
                 f_ = net(xc.to(dev), False)
                 return f_, PF.grid_sample(fc.to(dev), f_)
             line["cpu_baseline"] = cpu_baseline(B, gpu_one)
             line["gpu_over_cpu"] = round(fps / line["cpu_baseline"]["value"], 1)
+            net.module.enable_graph(not a.no_graph)
+        if not a.no_extra and a.math == "fp32" and world == 1:
+            line["bf16"] = bf16_legs(net, x, frames, out, a, PF, A, synth)
     else:
         line = None
     if world > 1 and not a.no_extra:
