@@ -549,6 +549,20 @@ def main():
                                                             "fused u8 warp -> 2x INTER_AREA -> pinned host (0.69 MB per frame)" % (T, B),
                                                 "pcie_h2d_gb_per_s": round(T * 2.7648e-3 / dt, 2)}
                 assert not out_h.is_cuda and tuple(out_h.shape) == (T, 360, 640, 3)
+                if a.math == "fp32":   # the same clip with the generator on the bf16 matrix cores (an extra, never `value`)
+                    net.module.set_math("bf16")
+                    vs.run_video(u8_h[:4 * B], chunk=2 * B, half_size_output=True)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    out_b = vs.run_video(u8_h, chunk=64, half_size_output=True)
+                    torch.cuda.synchronize()
+                    dtb = time.perf_counter() - t1
+                    net.module.set_math("fp32")
+                    diff = (out_b.to(torch.int16) - out_h.to(torch.int16)).abs()
+                    line["value_720p_stream_u8"]["bf16_generator"] = {
+                        "value": round(T / dtb, 1), "unit": "frames/s", "pcie_h2d_gb_per_s": round(T * 2.7648e-3 / dtb, 2),
+                        "output_gray_levels_vs_fp32": {"max": int(diff.max()), "mean": round(float(diff.float().mean()), 4)}}
+                    del out_b
                 del u8_h, out_h
             except Exception as e:  # an extra leg must never cost the headline line
                 line["value_720p_stream_u8"] = {"error": str(e)[:200]}
