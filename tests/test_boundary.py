@@ -159,3 +159,35 @@ def test_use_bn_variant_state_dict_matches_reference_and_training_raises():
     assert list(net.state_dict().keys()) == [str(k) for k in g["keys"]]
     with pytest.raises((NotImplementedError, RuntimeError)):
         net.train()(torch.zeros(1, 31, 256, 256))
+
+
+def test_checkpoint_files_in_the_reference_format(tmp_path):
+    """main_new.py:433-443 / :469-471: ``{'net': state_dict (module.-prefixed), 'epoch': n}`` under
+    checkpoint/<dir>/netG_model_epoch_<n>.pth.  A file built from the REFERENCE's key / shape list (tests/golden/reference_meta.json)
+    loads strictly; a file written here holds exactly those keys, on the host; un-prefixed state dicts are re-keyed."""
+    import torch
+    from pwstablenet_amd.checkpoint import checkpoint_path, load_checkpoint, save_checkpoint
+    from pwstablenet_amd.lib.networks_cascading import define_G
+    net = define_G(31, 2, 64, "normal", 0.02)
+    g = torch.Generator().manual_seed(0)
+    ref_state = {k: torch.randn(shape, generator=g) * 0.01 for k, shape in META["state_dict"]}   # what the authors' file holds
+    ref_file = tmp_path / "netG_model_epoch_35.pth"
+    torch.save({"net": ref_state, "epoch": 35}, ref_file)
+    assert load_checkpoint(net, str(ref_file)) == 35
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, ref_state[k]), k
+    path = save_checkpoint(net, 36, "unet_512", root=str(tmp_path / "checkpoint"))
+    assert path == checkpoint_path("unet_512", 36, root=str(tmp_path / "checkpoint")) and path.endswith("checkpoint/unet_512/netG_model_epoch_36.pth")
+    back = torch.load(path, weights_only=True)
+    assert set(back) == {"net", "epoch"} and back["epoch"] == 36
+    assert [[k, list(v.shape)] for k, v in back["net"].items()] == META["state_dict"]
+    assert all(not v.is_cuda for v in back["net"].values())
+    bare = tmp_path / "bare.pth"
+    torch.save({k[len("module."):]: v + 1 for k, v in ref_state.items()}, bare)       # saved from netG.module
+    assert load_checkpoint(net, str(bare)) is None
+    assert torch.equal(net.state_dict()["module.out.mpconv.0.bias"], ref_state["module.out.mpconv.0.bias"] + 1)
+    broken = dict(ref_state)
+    broken.pop("module.linear.mpconv.0.bias")
+    torch.save({"net": broken, "epoch": 1}, bare)
+    with pytest.raises(RuntimeError):
+        load_checkpoint(net, str(bare))
