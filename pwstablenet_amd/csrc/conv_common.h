@@ -25,6 +25,9 @@ struct ConvKParams {
     int tiles_x, tiles_y;
     unsigned ntiles;
     int nclasses;   // 4 for the sub-pixel modes, else 1
+    int cls_inner;  // sub-pixel modes: the 4 parity classes of a tile are 4 consecutive block slots of ONE XCD (grid.x = 4 ntiles)
+                    // instead of grid.z planes launched far apart: they stage the same input tile, which then comes from that
+                    // XCD's L2 three times out of four instead of from HBM (see conv_block_coords)
     int ksplit;     // >= 1
     int chunks_per_split;
     size_t split_stride;  // floats between consecutive partial buffers
@@ -77,6 +80,25 @@ __device__ __forceinline__ void epi_store_pair16(const ConvKParams &p, size_t pi
             }
         }
     }
+}
+
+// Block -> (tile, parity class, K split).  Plain mode: blockIdx.x = tile slot (XCD-remapped), blockIdx.z = class + 4 * split.
+// cls_inner (ntiles % 8 == 0): blockIdx.x = ((tile_slot * 4 + class) * 8 + xcd), blockIdx.z = split.
+__device__ __forceinline__ void conv_block_coords(const ConvKParams &p, bool subpix, unsigned &tile, int &cls, int &split) {
+    if (subpix && p.cls_inner) {
+        const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        cls = (int)(slot & 3u), split = (int)blockIdx.z;
+        tile = xcd_remap(((slot >> 2) << 3) | xcd, p.ntiles);
+    } else {
+        tile = xcd_remap(blockIdx.x, p.ntiles);
+        cls = subpix ? (int)(blockIdx.z & 3) : 0;
+        split = subpix ? (int)(blockIdx.z >> 2) : (int)blockIdx.z;
+    }
+}
+static inline dim3 conv_grid(ConvKParams &kp, int bn) {
+    kp.cls_inner = kp.nclasses == 4 && kp.ntiles % 8 == 0 && g_experiment != 9 ? 1 : 0;
+    const unsigned gy = (unsigned)((kp.cout + bn - 1) / bn);
+    return kp.cls_inner ? dim3(kp.ntiles * 4, gy, (unsigned)kp.ksplit) : dim3(kp.ntiles, gy, (unsigned)(kp.nclasses * kp.ksplit));
 }
 
 struct ProfInfo {

@@ -64,14 +64,14 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_mfma_kernel(const ConvKPar
     const int wm = wv / C::WN, wn = wv % C::WN;
 
     // ---- which tile / output-channel group / parity class / K split
-    const unsigned tile = xcd_remap(blockIdx.x, p.ntiles);
+    unsigned tile;
+    int cls, split;
+    conv_block_coords(p, C::CONVT, tile, cls, split);
     const int tx_i = tile % p.tiles_x;
     const int ty_i = (tile / p.tiles_x) % p.tiles_y;
     const int tn_i = tile / (p.tiles_x * p.tiles_y);
     const int n0 = tn_i * C::TN, y0 = ty_i * C::TH, x0 = tx_i * C::TW;
     const int co0 = blockIdx.y * C::BN;
-    const int cls = C::CONVT ? (int)(blockIdx.z & 3) : 0;
-    const int split = C::CONVT ? (int)(blockIdx.z >> 2) : (int)blockIdx.z;
     const int py = cls >> 1, px = cls & 1;
     const int pad_y = C::SUBPIX == 1 ? 1 - py : (C::SUBPIX == 2 ? 0 : C::PAD);
     const int pad_x = C::SUBPIX == 1 ? 1 - px : (C::SUBPIX == 2 ? 0 : C::PAD);
@@ -298,7 +298,7 @@ static int launch_cfg(ConvKParams &kp, hipStream_t st, const ProfInfo &pi) {
         }
         attr_set = true;
     }
-    dim3 grid(kp.ntiles, (kp.cout + C::BN - 1) / C::BN, kp.nclasses * kp.ksplit);
+    const dim3 grid = conv_grid(kp, C::BN);
     hipLaunchKernelGGL(conv_mfma_kernel<C>, grid, dim3(C::THREADS), C::LDS_BYTES, st, kp);
     return check_launch("conv_mfma_kernel");
 }
