@@ -184,6 +184,14 @@ typedef struct pws_dst {
     int channels;
     int ld;
     int accumulate;  /* 0: overwrite, 1: add to what is there (a tensor consumed by several layers) */
+    /* Optional, bf16 storage only (store == PWS_STORE_BF16): this call completes the gradient of the tensor `act_y` (the forward
+     * tensor this destination is the gradient of, bf16 NHWC, pixel stride act_y_ld, same channels) -- the epilogue then
+     * multiplies the (accumulated) sum by act'(act_y) for act = PWS_ACT_LRELU / PWS_ACT_RELU before the single rounding, which
+     * saves the separate pws_act_bwd_bias pass over that tensor (a bias gradient, if one is needed, is then taken with
+     * pws_act_bwd_bias_s(..., PWS_ACT_NONE, ...)).  act_y == NULL or act == PWS_ACT_NONE: plain gradient. */
+    const void *act_y;
+    int act_y_ld;
+    int act;
 } pws_dst;
 
 typedef struct pws_conv_bwd_data_args {
@@ -359,7 +367,9 @@ int pws_maxpool2x2_fwd(const float *x, float *y, int n, int h, int w, int c, pws
 int pws_maxpool2x2_bwd(const float *x, const float *dy, float *dx, int n, int h, int w, int c, pws_stream_t stream);
 /* the same with the element type of x / y / dy / dx given by `store` (PWS_STORE_BF16: bf16 elements, c % 8 == 0) */
 int pws_maxpool2x2_fwd_s(const void *x, void *y, int n, int h, int w, int c, int store, pws_stream_t stream);
-int pws_maxpool2x2_bwd_s(const void *x, const void *dy, void *dx, int n, int h, int w, int c, int store, pws_stream_t stream);
+/* relu_mask != 0 (bf16 storage only): x is a ReLU output and dx is the gradient wrt the pre-activation, dx *= (x > 0) */
+int pws_maxpool2x2_bwd_s(const void *x, const void *dy, void *dx, int n, int h, int w, int c, int store, int relu_mask,
+                         pws_stream_t stream);
 /* nn.MSELoss pieces: slots[PWS_OBJ_SLOTS] (caller-zeroed doubles) += sum (a-b)^2 ;  ga = c * (*scale) * 2 (a-b) */
 int pws_sqdiff_sum(const float *a, const float *b, size_t count, double *slots, pws_stream_t stream);
 int pws_sqdiff_bwd(const float *a, const float *b, size_t count, float c, const float *scale, float *ga, pws_stream_t stream);

@@ -101,12 +101,19 @@ struct BfCfg {
         __bf16 *dbase_ = reinterpret_cast<__bf16 *>((p).out) + co_;                                                        \
         size_t dld_ = (p).out_ld;                                                                                          \
         bool dacc_ = false, dok_ = co_ok_;                                                                                 \
+        const __bf16 *ybase_ = nullptr;                                                                                    \
+        size_t yld_ = 0;                                                                                                   \
+        float yslope_ = 1.f;                                                                                               \
         if ((p).ndst != 0) {                                                                                               \
             dok_ = false;                                                                                                  \
             _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                                             \
                 if (s_ < (p).ndst && co_ >= (p).dst_c0[s_] && co_ < (p).dst_c1[s_]) {                                      \
                     dbase_ = reinterpret_cast<__bf16 *>((p).dst_ptr[s_]) + (co_ - (p).dst_c0[s_]);                         \
                     dld_ = (p).dst_ld[s_], dacc_ = (p).dst_acc[s_] != 0, dok_ = true;                                      \
+                    if ((p).dst_act[s_] != PWS_ACT_NONE) {                                                                 \
+                        ybase_ = static_cast<const __bf16 *>((p).dst_y[s_]) + (co_ - (p).dst_c0[s_]);                      \
+                        yld_ = (p).dst_y_ld[s_], yslope_ = (p).dst_act[s_] == PWS_ACT_LRELU ? 0.2f : 0.f;                  \
+                    }                                                                                                      \
                 }                                                                                                          \
             }                                                                                                              \
         }                                                                                                                  \
@@ -137,6 +144,13 @@ struct BfCfg {
                         const u32x4 o_ = *d_;                                                                              \
                         v_[0] += bf16_lo(o_.x), v_[1] += bf16_hi(o_.x), v_[2] += bf16_lo(o_.y), v_[3] += bf16_hi(o_.y);    \
                         v_[4] += bf16_lo(o_.z), v_[5] += bf16_hi(o_.z), v_[6] += bf16_lo(o_.w), v_[7] += bf16_hi(o_.w);    \
+                    }                                                                                                      \
+                    if (ybase_) { /* act'(y) of the tensor this destination is the gradient of */                          \
+                        const u32x4 y_ = *reinterpret_cast<const u32x4 *>(ybase_ + ((size_t)(n * (p).OH + oy) * (p).OW + ox) * yld_); \
+                        v_[0] *= bf16_lo(y_.x) > 0.f ? 1.f : yslope_, v_[1] *= bf16_hi(y_.x) > 0.f ? 1.f : yslope_;        \
+                        v_[2] *= bf16_lo(y_.y) > 0.f ? 1.f : yslope_, v_[3] *= bf16_hi(y_.y) > 0.f ? 1.f : yslope_;        \
+                        v_[4] *= bf16_lo(y_.z) > 0.f ? 1.f : yslope_, v_[5] *= bf16_hi(y_.z) > 0.f ? 1.f : yslope_;        \
+                        v_[6] *= bf16_lo(y_.w) > 0.f ? 1.f : yslope_, v_[7] *= bf16_hi(y_.w) > 0.f ? 1.f : yslope_;        \
                     }                                                                                                      \
                     u32x4 w_;                                                                                              \
                     w_.x = cvt_pk_bf16(v_[0], v_[1]), w_.y = cvt_pk_bf16(v_[2], v_[3]);                                    \

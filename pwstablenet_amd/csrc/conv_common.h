@@ -42,6 +42,9 @@ struct ConvKParams {
     int ndst;
     float *dst_ptr[4];
     int dst_c0[4], dst_c1[4], dst_ld[4], dst_acc[4];
+    // bf16 storage only: the sum is multiplied by act'(dst_y) (the forward tensor this destination is the gradient of)
+    const void *dst_y[4];
+    int dst_y_ld[4], dst_act[4];
 };
 
 // final store of one output element (pixel index `pix` in the output tensor, channel `co`)
@@ -75,6 +78,12 @@ __device__ __forceinline__ void epi_store_pair16(const ConvKParams &p, size_t pi
                 if (p.dst_acc[s]) {
                     const unsigned o = *d;
                     v0 += bf16_lo(o), v1 += bf16_hi(o);
+                }
+                if (p.dst_act[s] != PWS_ACT_NONE) {
+                    const unsigned y = *reinterpret_cast<const unsigned *>(static_cast<const __bf16 *>(p.dst_y[s]) + pix * p.dst_y_ld[s] +
+                                                                           (co - p.dst_c0[s]));
+                    const float sl = p.dst_act[s] == PWS_ACT_LRELU ? 0.2f : 0.f;
+                    v0 *= bf16_lo(y) > 0.f ? 1.f : sl, v1 *= bf16_hi(y) > 0.f ? 1.f : sl;
                 }
                 *d = cvt_pk_bf16(v0, v1);
             }

@@ -498,6 +498,13 @@ int conv2d_bwd_data_impl(const pws_conv_bwd_data_args *a, hipStream_t st) {
         PWS_REQUIRE(d.ptr && d.channels > 0 && d.ld >= d.channels, "pws_conv2d_bwd_data: bad destination %d", s);
         kp.dst_ptr[s] = d.ptr, kp.dst_c0[s] = cin_f, kp.dst_c1[s] = cin_f + d.channels, kp.dst_ld[s] = d.ld;
         kp.dst_acc[s] = d.accumulate ? 1 : 0;
+        if (d.act_y && d.act != PWS_ACT_NONE) {
+            PWS_REQUIRE(a->store == PWS_STORE_BF16 && (d.act == PWS_ACT_LRELU || d.act == PWS_ACT_RELU),
+                        "pws_conv2d_bwd_data: the fused act' (dst[%d].act_y) needs bf16 storage and PWS_ACT_LRELU / PWS_ACT_RELU", s);
+            PWS_REQUIRE(d.act_y_ld >= d.channels && d.act_y_ld % 2 == 0 && (reinterpret_cast<size_t>(d.act_y) & 3) == 0,
+                        "pws_conv2d_bwd_data: bad act_y / act_y_ld of destination %d", s);
+            kp.dst_y[s] = d.act_y, kp.dst_y_ld[s] = d.act_y_ld, kp.dst_act[s] = d.act;
+        }
         cin_f += d.channels;
     }
     PWS_REQUIRE(cin_f % 4 == 0, "pws_conv2d_bwd_data: total destination channels %d must be a multiple of 4", cin_f);
@@ -522,7 +529,9 @@ int conv2d_bwd_data_impl(const pws_conv_bwd_data_args *a, hipStream_t st) {
         kp.io_bf16 = 1;
         kp.epi16 = 1;
         for (int s = 0; s < a->ndst; ++s)
-            if (a->dst[s].channels % 8 || a->dst[s].ld % 8 || (reinterpret_cast<size_t>(a->dst[s].ptr) & 15)) kp.epi16 = 0;
+            if (a->dst[s].channels % 8 || a->dst[s].ld % 8 || (reinterpret_cast<size_t>(a->dst[s].ptr) & 15) ||
+                (kp.dst_act[s] != PWS_ACT_NONE && (kp.dst_y_ld[s] % 8 || (reinterpret_cast<size_t>(kp.dst_y[s]) & 15))))
+                kp.epi16 = 0;
     }
     if (a->math == PWS_MATH_BF16 && a->w_dgrad_bf16) {
         kp.w_bf = a->w_dgrad_bf16, kp.kpad_bf = (a->cout + 31) / 32 * 32, kp.npad_bf = (cin_f + 63) / 64 * 64;

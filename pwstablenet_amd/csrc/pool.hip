@@ -88,8 +88,11 @@ __global__ void __launch_bounds__(256) maxpool2x2_fwd16_kernel(const __bf16 *__r
     for (int k = 0; k < 8; ++k) r[k] = fmaxf(fmaxf(a[k], b[k]), fmaxf(c[k], d[k]));
     *reinterpret_cast<u32x4 *>(y + op * C + 8 * c8) = pack8(r);
 }
+// relu_mask: x is the output of a ReLU; dx is additionally multiplied by ReLU'(x) = (x > 0), i.e. it is the gradient wrt the
+// PRE-activation (the routed position holds the window maximum: the mask only matters where that maximum is 0)
 __global__ void __launch_bounds__(256) maxpool2x2_bwd16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ dy,
-                                                               __bf16 *__restrict__ dx, int OH, int OW, int C8, size_t total) {
+                                                               __bf16 *__restrict__ dx, int OH, int OW, int C8, size_t total,
+                                                               int relu_mask) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int c8 = (int)(i % C8);
@@ -104,7 +107,13 @@ __global__ void __launch_bounds__(256) maxpool2x2_bwd16_kernel(const __bf16 *__r
     unpack8(*reinterpret_cast<const u32x4 *>(p + (size_t)W * C), c), unpack8(*reinterpret_cast<const u32x4 *>(p + (size_t)W * C + C), d);
     unpack8(*reinterpret_cast<const u32x4 *>(dy + op * C + 8 * c8), g);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) route(a[k], b[k], c[k], d[k], g[k], ga[k], gb[k], gc[k], gd[k]);
+    for (int k = 0; k < 8; ++k) {
+        route(a[k], b[k], c[k], d[k], g[k], ga[k], gb[k], gc[k], gd[k]);
+        if (relu_mask) {
+            ga[k] = a[k] > 0.f ? ga[k] : 0.f, gb[k] = b[k] > 0.f ? gb[k] : 0.f;
+            gc[k] = c[k] > 0.f ? gc[k] : 0.f, gd[k] = d[k] > 0.f ? gd[k] : 0.f;
+        }
+    }
     __bf16 *q = dx + o;
     *reinterpret_cast<u32x4 *>(q) = pack8(ga), *reinterpret_cast<u32x4 *>(q + C) = pack8(gb);
     *reinterpret_cast<u32x4 *>(q + (size_t)W * C) = pack8(gc), *reinterpret_cast<u32x4 *>(q + (size_t)W * C + C) = pack8(gd);
@@ -182,10 +191,12 @@ extern "C" int pws_maxpool2x2_fwd_s(const void *x, void *y, int n, int h, int w,
     return check_launch("maxpool2x2_fwd16_kernel");
 }
 
-extern "C" int pws_maxpool2x2_bwd_s(const void *x, const void *dy, void *dx, int n, int h, int w, int c, int store,
+extern "C" int pws_maxpool2x2_bwd_s(const void *x, const void *dy, void *dx, int n, int h, int w, int c, int store, int relu_mask,
                                     pws_stream_t stream) {
-    if (store == PWS_STORE_FP32)
+    if (store == PWS_STORE_FP32) {
+        PWS_REQUIRE(!relu_mask, "pws_maxpool2x2_bwd_s: relu_mask needs bf16 storage");
         return pws_maxpool2x2_bwd(static_cast<const float *>(x), static_cast<const float *>(dy), static_cast<float *>(dx), n, h, w, c, stream);
+    }
     PWS_REQUIRE(store == PWS_STORE_BF16, "pws_maxpool2x2_bwd_s: bad store %d", store);
     PWS_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0 && h % 2 == 0 && w % 2 == 0 && c % 8 == 0,
                 "pws_maxpool2x2_bwd_s: h, w must be even and c a multiple of 8 for bf16 storage (got %d x %d x %d)", h, w, c);
@@ -194,7 +205,8 @@ extern "C" int pws_maxpool2x2_bwd_s(const void *x, const void *dy, void *dx, int
     const size_t total = (size_t)n * (h / 2) * (w / 2) * (c / 8);
     ProfScope prof(KID_OBJECTIVE, 8.0 * total * 8, 18.0 * total * 8, as_stream(stream));
     hipLaunchKernelGGL(maxpool2x2_bwd16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
-                       static_cast<const __bf16 *>(x), static_cast<const __bf16 *>(dy), static_cast<__bf16 *>(dx), h / 2, w / 2, c / 8, total);
+                       static_cast<const __bf16 *>(x), static_cast<const __bf16 *>(dy), static_cast<__bf16 *>(dx), h / 2, w / 2, c / 8, total,
+                       relu_mask ? 1 : 0);
     return check_launch("maxpool2x2_bwd16_kernel");
 }
 

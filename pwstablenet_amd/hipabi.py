@@ -34,7 +34,8 @@ class PwsConvArgs(ctypes.Structure):
 
 
 class PwsDst(ctypes.Structure):
-    _fields_ = [("ptr", ctypes.c_void_p), ("channels", ctypes.c_int), ("ld", ctypes.c_int), ("accumulate", ctypes.c_int)]
+    _fields_ = [("ptr", ctypes.c_void_p), ("channels", ctypes.c_int), ("ld", ctypes.c_int), ("accumulate", ctypes.c_int),
+                ("act_y", ctypes.c_void_p), ("act_y_ld", ctypes.c_int), ("act", ctypes.c_int)]
 
 
 class PwsConvBwdDataArgs(ctypes.Structure):
@@ -129,7 +130,7 @@ SIGNATURES = {
     "pws_maxpool2x2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "pws_maxpool2x2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "pws_maxpool2x2_fwd_s": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "pws_maxpool2x2_bwd_s": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "pws_maxpool2x2_bwd_s": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "pws_sqdiff_sum": (_I, [_P, _P, _S, _P, _P]),
     "pws_sqdiff_bwd": (_I, [_P, _P, _S, _F, _P, _P, _P]),
     "pws_gray_area_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

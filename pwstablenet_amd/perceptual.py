@@ -86,24 +86,41 @@ class _VGGFn(torch.autograd.Function):
             g = g16
         else:
             g = g.clone()   # modified in place below
-        for kind, xin, out in reversed(acts):
+        # bf16 storage: ReLU' of a layer's output is applied by whatever PRODUCES the gradient of that output -- the next conv's
+        # data-gradient epilogue (pws_dst.act_y) or the max-pool backward (relu_mask) -- so no separate pass over the gradient;
+        # only the last conv's output gradient (it comes from the caller) takes the elementwise pass
+        masked = False   # g already is the gradient wrt the pre-activation of the tensor it belongs to
+        ra = list(reversed(acts))
+        for idx, (kind, xin, out) in enumerate(ra):
             h, w = xin.shape[1], xin.shape[2]
+            prev_is_conv = idx + 1 < len(ra) and ra[idx + 1][0] != "M"   # xin is a conv + ReLU output
             if kind == "M":
                 dx = torch.empty_like(xin)
-                A.check(L.pws_maxpool2x2_bwd_s(A.ptr(xin), A.ptr(g), A.ptr(dx), n, h, w, xin.shape[3], store, st), "pws_maxpool2x2_bwd_s")
+                fuse = s16 and prev_is_conv
+                if s16:
+                    A.check(L.pws_maxpool2x2_bwd_s(A.ptr(xin), A.ptr(g), A.ptr(dx), n, h, w, xin.shape[3], store, 1 if fuse else 0, st),
+                            "pws_maxpool2x2_bwd_s")
+                else:
+                    A.check(L.pws_maxpool2x2_bwd(A.ptr(xin), A.ptr(g), A.ptr(dx), n, h, w, xin.shape[3], st), "pws_maxpool2x2_bwd")
+                masked = fuse
             else:
                 pk = packs[kind]
                 cout = out.shape[3]
-                A.check(L.pws_act_bwd_bias_s(A.ptr(g), A.ptr(out), n * h * w, cout, A.ACT_RELU, None, store, None, 0, st),
-                        "pws_act_bwd_bias_s")
+                if not masked:
+                    A.check(L.pws_act_bwd_bias_s(A.ptr(g), A.ptr(out), n * h * w, cout, A.ACT_RELU, None, store, None, 0, st),
+                            "pws_act_bwd_bias_s")
                 dx = torch.empty_like(xin)
                 d = A.PwsConvBwdDataArgs()
                 d.kind, d.n, d.h, d.w, d.cout = A.CONV_K3S1, n, h, w, cout
                 d.gout, d.gout_ld, d.w_dgrad, d.ndst = g.data_ptr(), cout, pk["dg"].data_ptr(), 1
                 d.dst[0].ptr, d.dst[0].channels, d.dst[0].ld, d.dst[0].accumulate = dx.data_ptr(), xin.shape[3], xin.shape[3], 0
+                fuse = s16 and prev_is_conv
+                if fuse:
+                    d.dst[0].act_y, d.dst[0].act_y_ld, d.dst[0].act = xin.data_ptr(), xin.shape[3], A.ACT_RELU
                 if s16:
                     d.math, d.w_dgrad_bf16, d.store = A.MATH_BF16, pk["dg_bf16"].data_ptr(), store
                 A.check(L.pws_conv2d_bwd_data(ctypes.byref(d), st), "pws_conv2d_bwd_data")
+                masked = fuse
             g = dx
         ctx.acts = None
         if s16:

@@ -196,6 +196,73 @@ def test_bf16_conv_data_gradient(hip, kname, shape, src_c, cout, store):
             c0 += c
 
 
+@pytest.mark.parametrize("act", ["ACT_LRELU", "ACT_RELU"])
+@pytest.mark.parametrize("kname,shape,src_c,cout", [c for c in CASES if c[3] % 32 == 0 and c[0] != "CONV_K5S1"])
+def test_bf16_data_gradient_with_fused_activation_gradient(hip, kname, shape, src_c, cout, act):
+    """pws_dst.act_y: the epilogue multiplies the (accumulated) gradient of a destination by act'(y) of the forward tensor it
+    belongs to -- checked against the plain call followed by the elementwise product (LeakyReLU: one more bf16 rounding in
+    the two-step version, so one bf16 ulp; ReLU: bit-identical).  With and without K split, aligned (16-byte epilogue) and
+    unaligned (dword epilogue: ld = c + 2) forward tensors; fp32 storage rejects the option."""
+    A = hip
+    L, st = A.lib(), A.current_stream()
+    kind = getattr(A, kname)
+    x, wt, b, rs = make_case(kname, shape, src_c, cout, "d")
+    n, cin, h, w = x.shape
+    kd, k, s_, p_ = KINDS[kname]
+    oh, ow = (h, w) if s_ == 1 else ((h // 2, w // 2) if kd == "conv" else (2 * h, 2 * w))
+    d_dy = torch.from_numpy(rs.standard_normal((n, oh, ow, cout)).astype(np.float32)).cuda().bfloat16()
+    wdg = torch.empty(L.pws_packed_dgrad_floats(kind, cin, cout), device="cuda")
+    A.check(L.pws_pack_conv_weight_dgrad(A.ptr(wt.cuda()), A.ptr(wdg), kind, cin, cout, st), "pack_dgrad")
+    planes = 9 if "S1" in kname else 16
+    wdb = torch.empty(L.pws_packed_bf16_floats(planes, cout, cin), device="cuda")
+    A.check(L.pws_pack_weight_bf16(A.ptr(wdg), A.ptr(wdb), planes, cout, cin, st), "pack_bf16")
+    slope = 0.2 if act == "ACT_LRELU" else 0.0
+    for ws_mb, pad in ((0, 0), (64, 0), (0, 2)):
+        ys = [torch.from_numpy(rs.standard_normal((n, h, w, c + pad)).astype(np.float32)).cuda().bfloat16() for c in src_c]
+
+        def run(fused):
+            da = A.PwsConvBwdDataArgs()
+            da.kind, da.n, da.h, da.w, da.cout = kind, n, h, w, cout
+            da.gout, da.gout_ld, da.w_dgrad, da.ndst = d_dy.data_ptr(), cout, wdg.data_ptr(), len(src_c)
+            da.math, da.w_dgrad_bf16, da.store = A.MATH_BF16, wdb.data_ptr(), A.STORE_BF16
+            outs = []
+            for i, c in enumerate(src_c):
+                acc = 1 if i == 1 else 0
+                o = torch.full((n, h, w, c), 0.5 if acc else float("nan"), device="cuda", dtype=torch.bfloat16)
+                outs.append(o)
+                da.dst[i].ptr, da.dst[i].channels, da.dst[i].ld, da.dst[i].accumulate = o.data_ptr(), c, c, acc
+                if fused and i != 2:   # a third destination, if any, stays plain
+                    da.dst[i].act_y, da.dst[i].act_y_ld, da.dst[i].act = ys[i].data_ptr(), c + pad, getattr(A, act)
+            if ws_mb:
+                wsb = torch.empty(ws_mb << 20, device="cuda", dtype=torch.uint8)
+                da.ws, da.ws_bytes = wsb.data_ptr(), wsb.numel()
+            A.check(L.pws_conv2d_bwd_data(ctypes.byref(da), st), "bwd_data")
+            torch.cuda.synchronize()
+            return [o.float() for o in outs]
+        plain, fused = run(False), run(True)
+        for i, c in enumerate(src_c):
+            want = plain[i]
+            if i != 2:
+                yv = ys[i][..., :c].float()
+                want = want * torch.where(yv > 0, torch.ones_like(yv), torch.full_like(yv, slope))
+            want = want.bfloat16().float()
+            got = fused[i]
+            assert not torch.isnan(got).any()
+            if act == "ACT_RELU":
+                assert torch.equal(got, want), (i, ws_mb, pad)
+            else:
+                err = float((got - want).abs().max() / want.abs().max())
+                assert err < 2 ** -7, (i, ws_mb, pad, err)     # the two-step product rounds twice
+    da = A.PwsConvBwdDataArgs()
+    da.kind, da.n, da.h, da.w, da.cout = kind, n, h, w, cout
+    d32 = d_dy.float()
+    da.gout, da.gout_ld, da.w_dgrad, da.ndst = d32.data_ptr(), cout, wdg.data_ptr(), 1
+    o = torch.empty((n, h, w, cin), device="cuda")
+    da.dst[0].ptr, da.dst[0].channels, da.dst[0].ld = o.data_ptr(), cin, cin
+    da.dst[0].act_y, da.dst[0].act_y_ld, da.dst[0].act = o.data_ptr(), cin, getattr(A, act)
+    assert L.pws_conv2d_bwd_data(ctypes.byref(da), st) == -22 and b"bf16 storage" in L.pws_last_error()
+
+
 def test_bf16_falls_back_to_fp32_for_uncovered_shapes(hip):
     """Sources that are not multiples of 32 channels run the exact fp32 kernel even when bf16 math is requested."""
     A = hip

@@ -55,9 +55,16 @@ def test_maxpool_bf16_storage_is_exact(hip):
     hip.check(L.pws_maxpool2x2_fwd_s(hip.ptr(d), hip.ptr(y), 3, 6, 8, 16, hip.STORE_BF16, st()), "fwd_s")
     assert torch.equal(y.float().cpu(), y_ref.detach().permute(0, 2, 3, 1))
     dx = torch.full_like(d, float("nan"))
-    hip.check(L.pws_maxpool2x2_bwd_s(hip.ptr(d), hip.ptr(gy.permute(0, 2, 3, 1).contiguous().cuda()), hip.ptr(dx), 3, 6, 8, 16,
-                                     hip.STORE_BF16, st()), "bwd_s")
+    gyd = gy.permute(0, 2, 3, 1).contiguous().cuda()
+    hip.check(L.pws_maxpool2x2_bwd_s(hip.ptr(d), hip.ptr(gyd), hip.ptr(dx), 3, 6, 8, 16, hip.STORE_BF16, 0, st()), "bwd_s")
     assert torch.equal(dx.float().cpu(), xr.grad.permute(0, 2, 3, 1))
+    # relu_mask: x taken as a ReLU output -> the gradient wrt the pre-activation (zero where the routed maximum is <= 0)
+    xq = x.float().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    F.max_pool2d(F.relu(xq), 2, 2).backward(gy.float())
+    hip.check(L.pws_maxpool2x2_bwd_s(hip.ptr(d), hip.ptr(gyd), hip.ptr(dx), 3, 6, 8, 16, hip.STORE_BF16, 1, st()), "bwd_s mask")
+    want = xr.grad.permute(0, 2, 3, 1) * (x.float() > 0)
+    assert torch.equal(dx.float().cpu(), want)
+    assert torch.equal((want != 0), (xq.grad.permute(0, 2, 3, 1) != 0) & (want != 0))   # never a gradient where ReLU blocks it
     assert L.pws_maxpool2x2_fwd_s(hip.ptr(d), hip.ptr(y), 3, 6, 8, 12, hip.STORE_BF16, st()) == -22   # c % 8
     xf, yf = x.float().cuda(), torch.empty((3, 3, 4, 16), device="cuda")
     hip.check(L.pws_maxpool2x2_fwd_s(hip.ptr(xf), hip.ptr(yf), 3, 6, 8, 16, hip.STORE_FP32, st()), "fwd_s fp32")
