@@ -349,7 +349,8 @@ constexpr int ABB_MAX_BLOCKS = 1024;  // slab reduction (two launches); measured
 // -- every workgroup hits the same c words, and cross-XCD atomics on one line serialise (measured per training step, batch 8:
 // 1024 workgroups 3.4 ms, 128 workgroups 2.2 ms).  (An in-kernel ticket + last-arriver reduction was tried: its release fence
 // has to write back the L2 lines the dy stores just dirtied -- 4.2 ms.)
-template <bool IO16>
+// NOACT: act == PWS_ACT_NONE known at compile time (bias sum of an already pre-activation gradient: y is not read at all)
+template <bool IO16, bool NOACT>
 __global__ void __launch_bounds__(256) act_bwd_bias_kernel(float *__restrict__ dy, const float *__restrict__ y, size_t pixels,
                                                            int c, int act, float *__restrict__ dbias, float *__restrict__ ws) {
     constexpr int VEC = IO16 ? 8 : 4, NV = VEC / 4;
@@ -378,7 +379,11 @@ __global__ void __launch_bounds__(256) act_bwd_bias_kernel(float *__restrict__ d
                     ok[u] = p < pixels;
                     const size_t e = ((ok[u] ? p : pb) * cvn + q) * VEC;
 #pragma unroll
-                    for (int h = 0; h < NV; ++h) g[u][h] = ld4<IO16>(dy, e + 4 * h), v[u][h] = ld4<IO16>(y, e + 4 * h);
+                    for (int h = 0; h < NV; ++h) {
+                        g[u][h] = ld4<IO16>(dy, e + 4 * h);
+                        if constexpr (!NOACT) v[u][h] = ld4<IO16>(y, e + 4 * h);
+                        else v[u][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -468,7 +473,7 @@ extern "C" int pws_act_bwd_bias_s(float *dy, const float *y, size_t pixels, int 
                 "pws_act_bwd_bias: NULL or unaligned pointer");
     if (act == PWS_ACT_NONE && !dbias) return PWS_OK;
     const bool io16 = store == PWS_STORE_BF16;
-    pws::ProfScope prof(pws::KID_ACT_BWD, 2.0 * pixels * c, (io16 ? 6.0 : 12.0) * pixels * c, pws::as_stream(stream));
+    pws::ProfScope prof(pws::KID_ACT_BWD, 2.0 * pixels * c, (act == PWS_ACT_NONE ? 1.0 : 3.0) * (io16 ? 2.0 : 4.0) * pixels * c, pws::as_stream(stream));
     size_t blocks = (pixels + pws::ABB_PIX - 1) / pws::ABB_PIX;
     float *slabs = nullptr;
     if (dbias && ws && ws_bytes >= pws_act_bwd_bias_ws_bytes(c) && (reinterpret_cast<size_t>(ws) & 15) == 0) {
@@ -479,11 +484,18 @@ extern "C" int pws_act_bwd_bias_s(float *dy, const float *y, size_t pixels, int 
     } else if (blocks > 128) {
         blocks = 128;  // atomic tail: fewer, longer workgroups win (see the kernel comment)
     }
-    if (io16)
-        hipLaunchKernelGGL(pws::act_bwd_bias_kernel<true>, dim3((unsigned)blocks), dim3(256), sizeof(float) * 256 * 8,
+    const bool noact = act == PWS_ACT_NONE;
+    if (io16 && noact)
+        hipLaunchKernelGGL((pws::act_bwd_bias_kernel<true, true>), dim3((unsigned)blocks), dim3(256), sizeof(float) * 256 * 8,
+                           pws::as_stream(stream), dy, y, pixels, c, act, dbias, slabs);
+    else if (io16)
+        hipLaunchKernelGGL((pws::act_bwd_bias_kernel<true, false>), dim3((unsigned)blocks), dim3(256), sizeof(float) * 256 * 8,
+                           pws::as_stream(stream), dy, y, pixels, c, act, dbias, slabs);
+    else if (noact)
+        hipLaunchKernelGGL((pws::act_bwd_bias_kernel<false, true>), dim3((unsigned)blocks), dim3(256), sizeof(float) * 256 * 4,
                            pws::as_stream(stream), dy, y, pixels, c, act, dbias, slabs);
     else
-        hipLaunchKernelGGL(pws::act_bwd_bias_kernel<false>, dim3((unsigned)blocks), dim3(256), sizeof(float) * 256 * 4,
+        hipLaunchKernelGGL((pws::act_bwd_bias_kernel<false, false>), dim3((unsigned)blocks), dim3(256), sizeof(float) * 256 * 4,
                            pws::as_stream(stream), dy, y, pixels, c, act, dbias, slabs);
     if (slabs)
         hipLaunchKernelGGL(pws::bias_slab_reduce_kernel, dim3((unsigned)((c + 15) / 16)), dim3(256), 0, pws::as_stream(stream), slabs,

@@ -19,6 +19,8 @@
 #include <vector>
 
 #include "common.h"
+#include <cstdlib>
+#include <cstdio>
 #include "netg_pack.h"
 
 namespace pws {
@@ -493,6 +495,8 @@ static void forward_graph(Exec &E, const float *x, int n, int input_nc, int g, i
 struct GradBuf {
     float *g;
     bool written;
+    bool preact;   // the buffer already holds the gradient wrt the producer's PRE-activation (act' fused into the last data-gradient
+                   // call that wrote it, pws_dst.act_y): the producer then needs the bias sum only
 };
 
 // The forward passes its thetas pointer; the planning replay must consume the arena identically, so backward is
@@ -518,7 +522,7 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
         if (op.type != OP_CONV) continue;
         const Seg &o = op.out.seg[0];
         float *gp = E.alloc((size_t)n * op.out.h * op.out.w * o.c);
-        if (!dry) G[o.ptr] = GradBuf{gp, false};
+        if (!dry) G[o.ptr] = GradBuf{gp, false, false};
     }
     float *gz_ws = E.alloc((size_t)n * S * S * 2);
     float *th_bwd_ws = E.alloc((size_t)n * 8 * g);
@@ -564,6 +568,40 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
         }
     }
     const size_t gsz = (size_t)n * S * S * 2;
+    // bf16 storage: act' of a conv output is applied by the LAST data-gradient call that writes its gradient buffer
+    // (pws_dst.act_y) instead of by a separate pass over the buffer.  A dry sweep finds, per tensor, the tape position of that
+    // last writer (same control flow as the real sweep below) and the op that produced the tensor.
+    std::unordered_map<const float *, size_t> last_writer, producer;
+    const bool fuse_act = E.io16() && !bn && g_math == PWS_MATH_BF16 && g_experiment != 11;
+    if (fuse_act) {
+        std::unordered_map<const float *, bool> wr;
+        bool hd[3] = {false, false, false};
+        for (size_t ii = T; ii-- > 0;) {
+            const Op &op = E.tape()[ii];
+            if (op.type == OP_FIELD) {
+                const float *gg = g_grids ? g_grids + op.stage * gsz : nullptr, *gr = g_resid ? g_resid + op.stage * gsz : nullptr;
+                if (!gg && !gr) continue;
+                wr[op.in.seg[0].ptr] = true, last_writer[op.in.seg[0].ptr] = ii, hd[op.stage] = gg != nullptr;
+            } else if (op.type == OP_THETA) {
+                if (!hd[op.stage]) continue;
+                wr[op.in.seg[0].ptr] = true, last_writer[op.in.seg[0].ptr] = ii;
+            } else {
+                producer[op.out.seg[0].ptr] = ii;
+                if (!wr[op.out.seg[0].ptr] || op.nchw) continue;
+                for (int i = 0; i < op.in.nseg; ++i) wr[op.in.seg[i].ptr] = true, last_writer[op.in.seg[i].ptr] = ii;
+            }
+        }
+    }
+    // act to fuse into the data-gradient call of tape position ii for the destination that is the gradient of tensor t (0: none)
+    auto fused_act = [&](size_t ii, const float *t) -> int {
+        if (!fuse_act) return PWS_ACT_NONE;
+        const auto lw = last_writer.find(t);
+        const auto pr = producer.find(t);
+        if (lw == last_writer.end() || lw->second != ii || pr == producer.end()) return PWS_ACT_NONE;
+        const Op &pop = E.tape()[pr->second];
+        if (L[E.tape()[ii].layer].dgb_off == (size_t)-1) return PWS_ACT_NONE;   // this call runs an fp32 kernel
+        return pop.act == PWS_ACT_LRELU || pop.act == PWS_ACT_RELU ? pop.act : PWS_ACT_NONE;
+    };
     bool have_dtheta[3] = {false, false, false};
     int rc = PWS_OK;
     for (size_t ii = T; ii-- > 0 && rc == PWS_OK;) {
@@ -633,14 +671,19 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             const size_t pixels = (size_t)n * op.out.h * op.out.w;
             if (!run) {
                 if (!op.nchw)
-                    for (int i = 0; i < op.in.nseg; ++i) G[op.in.seg[i].ptr].written = true;
+                    for (int i = 0; i < op.in.nseg; ++i) {
+                        GradBuf &gi = G[op.in.seg[i].ptr];
+                        gi.written = true;
+                        if (fused_act(ii, op.in.seg[i].ptr) != PWS_ACT_NONE) gi.preact = true;
+                    }
                 continue;
             }
             g_prof_tag = op.layer;
             if (bn)   // the conv bias gets no gradient: BatchNorm removes any per-channel constant (torch returns rounding noise)
                 rc = bn_backward(op.layer, go.g, o.ptr, op.aux[0], op.aux[1], op.act, pixels);
             else
-                rc = pws_act_bwd_bias_s(go.g, o.ptr, pixels, l.cout, op.act, dpacked + l.b_off, E.store(), abb_ws, abb_bytes, st);
+                rc = pws_act_bwd_bias_s(go.g, o.ptr, pixels, l.cout, go.preact ? PWS_ACT_NONE : op.act, dpacked + l.b_off, E.store(), abb_ws,
+                                        abb_bytes, st);
             if (rc != PWS_OK) break;
             pws_conv_bwd_weight_args wa{};
             wa.kind = l.kind, wa.n = n, wa.h = op.in.h, wa.w = op.in.w, wa.nsrc = op.in.nseg, wa.src_nchw = op.nchw ? 1 : 0;
@@ -660,8 +703,11 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             da.w_dgrad = packed_dgrad + l.dg_off, da.ndst = op.in.nseg;
             for (int i = 0; i < op.in.nseg; ++i) {
                 GradBuf &gi = G[op.in.seg[i].ptr];
-                da.dst[i] = pws_dst{gi.g, op.in.seg[i].c, op.in.seg[i].c, gi.written ? 1 : 0};
+                da.dst[i] = pws_dst{gi.g, op.in.seg[i].c, op.in.seg[i].c, gi.written ? 1 : 0, nullptr, 0, PWS_ACT_NONE};
                 gi.written = true;
+                const int fa = fused_act(ii, op.in.seg[i].ptr);
+                if (fa != PWS_ACT_NONE)
+                    da.dst[i].act_y = op.in.seg[i].ptr, da.dst[i].act_y_ld = op.in.seg[i].ld, da.dst[i].act = fa, gi.preact = true;
             }
             da.ws = E.splitk_ws(), da.ws_bytes = E.splitk_bytes();
             if (g_math == PWS_MATH_BF16 && l.dgb_off != (size_t)-1) da.math = PWS_MATH_BF16, da.w_dgrad_bf16 = packed_dgrad + l.dgb_off;

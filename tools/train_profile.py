@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--math", choices=("fp32", "bf16"), default="fp32")
     ap.add_argument("--list", type=int, default=0, help="also list the N slowest launches of any kernel")
     a = ap.parse_args()
+    A.lib().pws_set_option(100, int(os.environ.get("PWS_EXPERIMENT", "0")))   # A/B switches of measured variants
     net = define_G(31, 2, 64, "normal", 0.02)
     net.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in synth.make_weights("W1", 123, ngf=64)})
     net = net.cuda()
