@@ -224,6 +224,9 @@ typedef struct pws_conv_bwd_weight_args {
                           (fp32 atomics: several pixel ranges, and stages 2/3 share weights) */
     int math;          /* PWS_MATH_BF16: x and dy rounded to bf16 at LDS staging, fp32 accumulation; dW stays fp32 */
     int store;         /* PWS_STORE_BF16: src[].ptr and gout hold bf16 elements (dw_packed stays fp32) */
+    float *dbias;      /* optional: dbias[co] += sum over the pixels of gout[., co] (fp32 atomics), taken from the dy tiles the
+                          weight-gradient kernel stages anyway -- for a gout that already is the gradient wrt the pre-activation
+                          (pws_dst.act_y) this replaces the pws_act_bwd_bias pass */
 } pws_conv_bwd_weight_args;
 int pws_conv2d_bwd_weight(const pws_conv_bwd_weight_args *args, pws_stream_t stream);
 

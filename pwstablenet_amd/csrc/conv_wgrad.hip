@@ -283,6 +283,14 @@ int conv2d_bwd_weight_impl(const pws_conv_bwd_weight_args *a, hipStream_t st) {
         if (rc != 1) return rc;
     }
     PWS_REQUIRE(a->store != PWS_STORE_BF16, "pws_conv2d_bwd_weight: bf16 storage needs bf16 math and a layer the bf16 kernel covers");
+    if (a->dbias) {   // the fp32 kernels do not take the bias sum along: one elementwise pass (y is not read for PWS_ACT_NONE)
+        const int oh = a->kind == PWS_CONV_K3S2 ? (a->h - 1) / 2 + 1 : (a->kind == PWS_CONVT_K4S2 ? 2 * a->h : a->h);
+        const int ow = a->kind == PWS_CONV_K3S2 ? (a->w - 1) / 2 + 1 : (a->kind == PWS_CONVT_K4S2 ? 2 * a->w : a->w);
+        PWS_REQUIRE(a->gout_ld == a->cout, "pws_conv2d_bwd_weight: dbias with the fp32 kernels needs a dense gout");
+        const int rc = pws_act_bwd_bias_s(const_cast<float *>(a->gout), a->gout, (size_t)a->n * oh * ow, a->cout, PWS_ACT_NONE, a->dbias,
+                                          PWS_STORE_FP32, nullptr, 0, st);
+        if (rc != PWS_OK) return rc;
+    }
     WgradParams p{};
     p.nsrc = a->nsrc;
     int cin = 0;

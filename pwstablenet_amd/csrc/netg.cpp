@@ -681,9 +681,8 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             g_prof_tag = op.layer;
             if (bn)   // the conv bias gets no gradient: BatchNorm removes any per-channel constant (torch returns rounding noise)
                 rc = bn_backward(op.layer, go.g, o.ptr, op.aux[0], op.aux[1], op.act, pixels);
-            else
-                rc = pws_act_bwd_bias_s(go.g, o.ptr, pixels, l.cout, go.preact ? PWS_ACT_NONE : op.act, dpacked + l.b_off, E.store(), abb_ws,
-                                        abb_bytes, st);
+            else if (!go.preact)   // (a pre-activation gradient needs the bias sum only: the weight-gradient kernel takes it along)
+                rc = pws_act_bwd_bias_s(go.g, o.ptr, pixels, l.cout, op.act, dpacked + l.b_off, E.store(), abb_ws, abb_bytes, st);
             if (rc != PWS_OK) break;
             pws_conv_bwd_weight_args wa{};
             wa.kind = l.kind, wa.n = n, wa.h = op.in.h, wa.w = op.in.w, wa.nsrc = op.in.nseg, wa.src_nchw = op.nchw ? 1 : 0;
@@ -693,6 +692,7 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
                 wa.src_nchw = 0, wa.src[0] = pws_src{E.x_nhwc(), 32, 32};  // the forward's NHWC copy
             wa.cout = l.cout, wa.gout = go.g, wa.gout_ld = l.cout, wa.dw_packed = dpacked + l.w_off;
             wa.math = g_math, wa.store = E.store();
+            wa.dbias = !bn && go.preact ? dpacked + l.b_off : nullptr;
             rc = pws_conv2d_bwd_weight(&wa, st);
             if (rc != PWS_OK || op.nchw) {
                 g_prof_tag = -1;

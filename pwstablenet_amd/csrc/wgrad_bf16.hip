@@ -37,6 +37,7 @@ struct WgradBfParams {
     int tiles_x, tiles_y, tiles_n;
     int ntiles;
     int ci_blocks, co_blocks;  // of 64 channels
+    float *dbias;    // optional: dbias[co] += column sums of dy (pws_conv_bwd_weight_args.dbias)
 };
 
 template <int KS_, int STRIDE_, int PAD_, int SUBPIX_, int TH_, int TW_, int TN_, int TG_, bool CI32_ = false>
@@ -114,11 +115,23 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradBfParams 
     }
     constexpr int SINK = C::LDS_X + C::LDS_G;
 
+    // bias gradient: the waves of the first wave pair of the workgroups of input-channel block 0 / tap group 0 see every pixel of
+    // dy exactly once (tiles partition the pixels, the parity classes the pixels of a tile)
+    const bool do_bias = p.dbias != nullptr && cb / p.co_blocks == 0 && tg == 0 && (wv >> 1) == 0;
+    float bsum = 0.f;
     auto compute = [&]() {
         // ---- K steps of 16 pixels over the whole tile
 #pragma unroll
         for (int j = 0; j < C::KSTEPS; ++j) {
             const bf16x8 b = tr_pair(lds, b_lane[0] + j * 16 * C::ROW, b_lane[1] + j * 16 * C::ROW);
+            if (do_bias) {   // wave-uniform: this lane holds 8 pixels of dy column l31 (masked pixels are zeros)
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                const bf16x2 one2 = {(__bf16)1.0f, (__bf16)1.0f};
+                bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(b, b, 0, 1), one2, bsum, false);   // v_dot2_f32_bf16: exact products
+                bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(b, b, 2, 3), one2, bsum, false);
+                bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(b, b, 4, 5), one2, bsum, false);
+                bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(b, b, 6, 7), one2, bsum, false);
+            }
 #pragma unroll
             for (int t = 0; t < C::TG; ++t) {
                 const int tap = (C::NGROUPS == 1 ? 0 : wtg * C::TG) + t;  // wave-uniform
@@ -331,6 +344,10 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradBfParams 
 
     // ---- one atomic per element: rows = input channels of this wave's quadrant, 32 lanes = 32 consecutive output channels
     const int co = co0 + wco * 32 + l31;
+    if (do_bias) {
+        bsum += __shfl_xor(bsum, 32, 64);   // the two k halves
+        if (hi == 0 && co < p.cout) atomicAdd(p.dbias + co, bsum);
+    }
 #pragma unroll
     for (int t = 0; t < C::TG; ++t) {
         const int tap = wtg * C::TG + t;
@@ -397,7 +414,8 @@ using WB_K3S2_T64 = WbCfg<3, 2, 1, 0, 8, 8, 1, 9>;
 using WB_K3S2_T64N4 = WbCfg<3, 2, 1, 0, 4, 4, 4, 9>;
 using WB_K3S2_T64N16 = WbCfg<3, 2, 1, 0, 2, 2, 16, 9>;
 using WB_K5S1_T128 = WbCfg<5, 1, 2, 0, 8, 16, 1, 5>;   // first layer: one kernel row of taps per workgroup
-using WB_K5S1_T256H = WbCfg<5, 1, 2, 0, 16, 16, 1, 5, true>;   // ... <= 32 input channels: two kernel rows per workgroup
+using WB_K5S1_T128H = WbCfg<5, 1, 2, 0, 8, 16, 1, 5, true>;    // ... <= 32 input channels: two kernel rows per workgroup (the 16x16
+                                                                // tile of this kind runs out of registers: 272 B of scratch, 3.4x slower)
 using WB_CT4_T256 = WbCfg<2, 1, 0, 1, 16, 16, 1, 4>;
 using WB_CT4_T64 = WbCfg<2, 1, 0, 1, 8, 8, 1, 4>;
 using WB_CT4_T64N4 = WbCfg<2, 1, 0, 1, 4, 4, 4, 4>;
@@ -406,7 +424,7 @@ using WB_CT4_T64N16 = WbCfg<2, 1, 0, 1, 2, 2, 16, 4>;
 static const WbChoice kWbK3S1[] = {wbchoice<WB_K3S1_T256>(), wbchoice<WB_K3S1_T128>(), wbchoice<WB_K3S1_T64>(), wbchoice<WB_K3S1_T64N4>(),
                                    wbchoice<WB_K3S1_T64N16>()};
 static const WbChoice kWbK3S2[] = {wbchoice<WB_K3S2_T64>(), wbchoice<WB_K3S2_T64N4>(), wbchoice<WB_K3S2_T64N16>()};
-static const WbChoice kWbK5[] = {wbchoice<WB_K5S1_T128>(), wbchoice<WB_K5S1_T256H>()};
+static const WbChoice kWbK5[] = {wbchoice<WB_K5S1_T128>(), wbchoice<WB_K5S1_T128H>()};
 static const WbChoice kWbCT4[] = {wbchoice<WB_CT4_T256>(), wbchoice<WB_CT4_T64>(), wbchoice<WB_CT4_T64N4>(),
                                   wbchoice<WB_CT4_T64N16>()};
 
@@ -443,7 +461,7 @@ int wgrad_bf16_launch(const pws_conv_bwd_weight_args *a, hipStream_t st) {
     }
     p.cin = cin, p.cin_pad = (cin + 15) / 16 * 16, p.cout = a->cout;
     p.N = a->n, p.H = a->h, p.W = a->w;
-    p.gout = a->gout, p.gout_ld = a->gout_ld, p.dw = a->dw_packed;
+    p.gout = a->gout, p.gout_ld = a->gout_ld, p.dw = a->dw_packed, p.dbias = a->dbias;
     double k2 = 9;
     int nclasses = 1;
     const WbChoice *c = nullptr;

@@ -317,6 +317,9 @@ def test_bf16_conv_weight_gradient(hip, kname, shape, src_c, cout, store):
         d_dy = d_dy.bfloat16()
     dwp = torch.zeros(L.pws_packed_weight_floats(kind, cin, cout), device="cuda")
     wa.gout, wa.gout_ld, wa.dw_packed = d_dy.data_ptr(), cout, dwp.data_ptr()
+    # dbias: the column sums of dy taken along by the same kernel (accumulated: starts from 0.25 here)
+    db = torch.full((cout,), 0.25, device="cuda")
+    wa.dbias = db.data_ptr()
     L.pws_prof_enable(1)
     A.check(L.pws_conv2d_bwd_weight(ctypes.byref(wa), st), "bwd_weight bf16")
     L.pws_prof_enable(0)
@@ -325,6 +328,8 @@ def test_bf16_conv_weight_gradient(hip, kname, shape, src_c, cout, store):
     A.check(L.pws_unpack_conv_weight(A.ptr(dwp), A.ptr(dw), kind, cin, cout, st), "unpack")
     err = relerr(dw.cpu().numpy(), wg.grad.numpy())
     assert err < 1e-4, err
+    want_db = dy.double().sum(dim=(0, 2, 3)).numpy()
+    np.testing.assert_allclose(db.cpu().numpy() - 0.25, want_db, rtol=0, atol=2e-5 * np.abs(dy.numpy()).sum(axis=(0, 2, 3)).max())
 
 
 # ---------------------------------------------------------------------------------------------- whole generator
