@@ -68,7 +68,9 @@ const char *pws_last_error(void); /* thread-local, never NULL */
 #define PWS_OPT_STORE 3
 #define PWS_STORE_FP32 0
 #define PWS_STORE_BF16 1
-/* Measurement only: selects alternative kernel variants that the scripts under tools/ compare (0 = the product default). */
+/* Measurement only: selects alternative kernel variants that the scripts under tools/ compare (0 = the product default).
+ * 1: non-temporal loads / stores in grid_sample at any size; 9: sub-pixel conv classes as grid.z planes (not on consecutive block
+ * slots of one XCD); 11: no fused act' / bias gradient in the bf16 generator backward (separate pws_act_bwd_bias passes). */
 #define PWS_OPT_EXPERIMENT 100
 int pws_set_option(int key, int value);
 int pws_get_option(int key); /* current value, or PWS_EINVAL */
