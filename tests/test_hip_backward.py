@@ -325,15 +325,18 @@ def test_act_bwd_bias_slab_reduction_equals_atomic_path(hip, pixels, c, act, sto
     relclose(db2.cpu().numpy(), want.to(dt).float().sum(0).cpu().numpy(), 2e-4 if not store else 2e-3)
 
 
-@pytest.mark.parametrize("nparts", [2, 4, 7])
-def test_backward_in_parts_with_overlapped_grad_sync(hip, nparts):
+@pytest.mark.parametrize("nparts,math", [(2, "fp32"), (4, "fp32"), (7, "fp32"), (3, "bf16"), (5, "bf16")])
+def test_backward_in_parts_with_overlapped_grad_sync(hip, nparts, math):
     """distributed.OverlappedGradSync: backward as `nparts` runs of the reversed tape (pws_netg_backward_part), each run's
     final layers unpacked on a second stream (all-reduced there when a process group exists).  Same gradients as the
     one-call backward; every layer becomes final exactly once; earlier runs are not re-launched."""
     import ctypes
     from pwstablenet_amd import distributed as D
     from pwstablenet_amd import functional as PF
-    net = make_net("W1", 16)
+    # bf16 (ngf 32: bf16 storage): the runs must also replay which gradient buffers already hold pre-activation gradients (act'
+    # fused into their last data-gradient writer, bias sums taken by the weight-gradient kernels)
+    net = make_net("W1", 32 if math == "bf16" else 16)
+    net.module.set_math(math)
     x = torch.from_numpy(synth.make_window(2, 31, 256, seed=4)).cuda()
     fr = torch.from_numpy(synth.make_frames(2, 3, 256, 256, seed=5)).cuda()
 
@@ -349,7 +352,7 @@ def test_backward_in_parts_with_overlapped_grad_sync(hip, nparts):
     assert sync.collectives == 0   # no process group here: the collectives are skipped, the rest is the same path
     for a, b in zip(got, ref):
         scale = float(b.abs().max()) + 1e-12
-        assert float((a - b).abs().max()) / scale < 1e-4   # fp32 atomics order in the weight-gradient kernels
+        assert float((a - b).abs().max()) / scale < 1e-4   # fp32 atomics order in the weight-gradient kernels (same arithmetic otherwise)
     net.module.grad_sync = None
     # the C side's final-layer report: monotone, complete after the last run
     L = hip.lib()
