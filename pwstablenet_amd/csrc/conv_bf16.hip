@@ -674,9 +674,9 @@ int conv_bf16_fwd(int kind, ConvKParams &kp, int cin_total, float *out, float *w
         if (kp.src_c[s] % 32 != 0) return 1;
     switch (kind) {
     case PWS_CONV_K3S1:
-    case PWS_CONVT_K3S1: return select_and_launch(kBK3S1, 5, kp, cin_total, out, ws, ws_floats, st, pi);
-    case PWS_CONV_K3S2: return select_and_launch(kBK3S2, 5, kp, cin_total, out, ws, ws_floats, st, pi);
-    case PWS_CONVT_K4S2: return select_and_launch(kBCT4, 5, kp, cin_total, out, ws, ws_floats, st, pi);
+    case PWS_CONVT_K3S1: return select_and_launch(kBK3S1, 5, kp, cin_total, out, ws, ws_floats, st, pi, kFillBlocksBf16);
+    case PWS_CONV_K3S2: return select_and_launch(kBK3S2, 5, kp, cin_total, out, ws, ws_floats, st, pi, kFillBlocksBf16);
+    case PWS_CONVT_K4S2: return select_and_launch(kBCT4, 5, kp, cin_total, out, ws, ws_floats, st, pi, kFillBlocksBf16);
     case PWS_CONV_K5S1:
         if (kp.nsrc != 1) return 1;
         kp.out = out;
@@ -690,9 +690,9 @@ int conv_bf16_dgrad(int kind, ConvKParams &kp, int cout_f, float *ws, size_t ws_
     if (cout_f % 32 != 0) return 1;
     switch (kind) {
     case PWS_CONV_K3S1:
-    case PWS_CONVT_K3S1: return select_and_launch(kBK3S1, 5, kp, cout_f, nullptr, ws, ws_floats, st, pi);
-    case PWS_CONV_K3S2: return select_and_launch(kBSP3, 5, kp, cout_f, nullptr, ws, ws_floats, st, pi);
-    case PWS_CONVT_K4S2: return select_and_launch(kBK4S2, 4, kp, cout_f, nullptr, ws, ws_floats, st, pi);
+    case PWS_CONVT_K3S1: return select_and_launch(kBK3S1, 5, kp, cout_f, nullptr, ws, ws_floats, st, pi, kFillBlocksBf16);
+    case PWS_CONV_K3S2: return select_and_launch(kBSP3, 5, kp, cout_f, nullptr, ws, ws_floats, st, pi, kFillBlocksBf16);
+    case PWS_CONVT_K4S2: return select_and_launch(kBK4S2, 4, kp, cout_f, nullptr, ws, ws_floats, st, pi, kFillBlocksBf16);
     default: return 1;
     }
 }

@@ -124,14 +124,17 @@ int launch_splitk_reduce(const ConvKParams &kp, const float *partial, size_t tot
 
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
-constexpr long kFillBlocks = 512;  // 256 CUs x 2 resident workgroups
+constexpr long kFillBlocks = 512;      // 256 CUs x 2 resident workgroups
+constexpr long kFillBlocksBf16 = 256;  // bf16 kernels: one workgroup per CU is enough before K is split (the 4x shorter kernels pay
+                                       // relatively more for the split-K reduce launches: N=8 inference 4550 -> 4700 frames/s;
+                                       // 128 / 384 / 512 measured 4580 / 4580 / 4550; fp32: 512 best, 256 and 1024 -2 %)
 
 // Pick the tile and the K split for one launch.
 //  1. drop tiles that are mostly padding for this extent (a 16x16 tile on an 8x8 map);
-//  2. take the largest remaining tile whose grid has >= kFillBlocks workgroups, else the one with the most workgroups;
-//  3. if the grid is still < kFillBlocks and a workspace was given, split K (>= 2 chunks per split, <= 64 splits).
+//  2. take the largest remaining tile whose grid has >= kFill workgroups, else the one with the most workgroups;
+//  3. if the grid is still < kFill and a workspace was given, split K (>= 2 chunks per split, <= 64 splits).
 [[maybe_unused]] static int select_and_launch(const TileChoice *cands, int ncand, ConvKParams &kp, int cin_total, float *final_out,
-                             float *ws, size_t ws_floats, hipStream_t st, const ProfInfo &pi) {
+                             float *ws, size_t ws_floats, hipStream_t st, const ProfInfo &pi, long kFill = kFillBlocks) {
     const TileChoice *best = nullptr;
     long best_blocks = -1;
     double best_score = -1.0;
@@ -143,7 +146,7 @@ constexpr long kFillBlocks = 512;  // 256 CUs x 2 resident workgroups
         // sub-8 spatial tiles exist for maps that are themselves tiny; on a larger map their halo re-reads dominate
         if (c.th < 8 && c.th < kp.LH && i > 0 && best) continue;
         const long blocks = tiles * cdiv(kp.cout, c.bn) * kp.nclasses;
-        if (blocks >= kFillBlocks) {
+        if (blocks >= kFill) {
             best = &c, best_blocks = blocks;
             break;
         }
@@ -155,8 +158,8 @@ constexpr long kFillBlocks = 512;  // 256 CUs x 2 resident workgroups
     const int total_chunks = cin_total / c.ck;
     int ksplit = 1;
     const size_t out_floats = (size_t)kp.N * kp.OH * kp.OW * kp.cout;
-    if (best_blocks < kFillBlocks && ws && kp.cout % 4 == 0 && total_chunks >= 4) {
-        long want = cdiv(kFillBlocks, best_blocks);
+    if (best_blocks < kFill && ws && kp.cout % 4 == 0 && total_chunks >= 4) {
+        long want = cdiv(kFill, best_blocks);
         if (want > 64) want = 64;
         if (want > total_chunks / 2) want = total_chunks / 2;
         while (want > 1 && (size_t)want * out_floats > ws_floats) --want;
