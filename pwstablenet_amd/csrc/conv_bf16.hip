@@ -164,7 +164,8 @@ struct BfCfg {
     } while (0)
 
 // IO16: activations / gradients live in HBM as bf16 (io_bf16): a staging item is ONE 16-byte load of 8 channels copied to
-// LDS as is, and the epilogue stores channel pairs as dwords.  For that the 64 output channels of a workgroup are dealt to
+// LDS as is, and the epilogue stores 8 consecutive channels as 16 bytes (PWS_BF_EPI16 above; channel pairs as dwords where a
+// destination is not 16-byte aligned and for split-K partials).  For that the 64 output channels of a workgroup are dealt to
 // the lanes as (2 l, 2 l + 1) -> (nt 0, nt 1) instead of (l, l + 32): the weight rows are permuted while they are staged
 // (LDS row (nn & 1) * 32 + (nn >> 1) holds output channel nn), the MFMA side is unchanged.  Requires NT == 2.
 template <class C, bool IO16>
