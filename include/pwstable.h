@@ -272,6 +272,13 @@ int pws_field_head_bwd_s(const float *x, int ld, int n, int h, int w, int c, con
                          const float *g_grid, const float *g_resid, int align_corners, float *dx, int dx_ld, int dx_accumulate,
                          float *dw_out, float *db_out, float *dtheta, float *ws, int store, pws_stream_t stream);
 
+/* The same; dx_act = PWS_ACT_LRELU / PWS_ACT_RELU (bf16 storage only): this call completes the gradient of x, which is the
+ * output of that activation -- dx (after the accumulation) is multiplied by act'(x), as pws_dst.act_y does for the
+ * data-gradient calls.  PWS_ACT_NONE: pws_field_head_bwd_s. */
+int pws_field_head_bwd_act(const float *x, int ld, int n, int h, int w, int c, const float *w_out, const float *resid,
+                           const float *g_grid, const float *g_resid, int align_corners, float *dx, int dx_ld, int dx_accumulate,
+                           float *dw_out, float *db_out, float *dtheta, float *ws, int store, int dx_act, pws_stream_t stream);
+
 /* F.affine_grid(theta[n,2,3], (n,*,h,w)) -> grid[n,h,w,2] */
 int pws_affine_grid(const float *theta, float *grid, int n, int h, int w, int align_corners,
                     pws_stream_t stream);

@@ -79,7 +79,7 @@ int field_bn_finish(const float *yhat, const float *theta, int n, int h, int w, 
 int field_bwd_gz(const float *resid, const float *g_grid, const float *g_resid, int n, int h, int w, int ac, float *gz, float *db_out,
                  float *dtheta, hipStream_t st);
 int field_bwd_dx_dw(const float *x, int ld, const float *gz, int n, int h, int w, int c, const float *w_out, float *dx, int dx_ld,
-                    int dx_accumulate, float *dw_out, int store, hipStream_t st);
+                    int dx_accumulate, float *dw_out, int store, hipStream_t st, int dx_act = 0);
 int theta_bwd_bn_lin(const float *dz2, const float *h, int n, int hidden, const float *w_lin, float *dw_lin, float *dh, hipStream_t st);
 int theta_bwd_flat(const float *x, int n, int c, int hidden, const float *w_flat, const float *dz1, float *dw_flat, float *dx,
                    int dx_accumulate, hipStream_t st);

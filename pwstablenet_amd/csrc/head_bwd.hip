@@ -111,6 +111,78 @@ __global__ void __launch_bounds__(256) field_dx_kernel(const float *__restrict__
     }
 }
 
+// bf16 storage: the same arithmetic (one lane per pixel, weights through the scalar unit), but the results of a workgroup's 256
+// pixels x 64 channels meet in LDS (fp32, rows of 64 + 4 floats: conflict-free both ways) and leave as 16-byte accesses that are
+// contiguous over the 8 lanes of a pixel -- with a lane per pixel the read-modify-write of dx was 64 separate 16-byte pieces 128
+// bytes apart per wave instruction.  dx_act: this call completes the gradient of x, itself the output of an activation: the
+// (accumulated) sum is multiplied by act'(x) (what pws_dst.act_y does in the data-gradient epilogues).
+constexpr int FDX_PITCH = 68;   // floats per pixel row of the LDS tile
+__global__ void __launch_bounds__(256) field_dx16_kernel(const float *__restrict__ gz, const float *__restrict__ w_out, int N, int H,
+                                                         int W, int C, __bf16 *__restrict__ dx, int dx_ld, int accumulate,
+                                                         const __bf16 *__restrict__ xact, int x_ld, int dx_act) {
+    extern __shared__ float s_tile[];   // [256][FDX_PITCH]
+    const size_t total = (size_t)N * H * W;
+    const size_t pix0 = (size_t)blockIdx.x * 256, pix = pix0 + threadIdx.x;
+    const bool live = pix < total;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H), n = live ? (int)(pix / ((size_t)W * H)) : 0;
+    float2 g[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y + 1 - tap / 3, xx = x + 1 - tap % 3;
+        const bool ok = live && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const float2 v = *reinterpret_cast<const float2 *>(gz + (((size_t)n * H + (ok ? yy : 0)) * W + (ok ? xx : 0)) * 2);
+        g[tap] = ok ? v : make_float2(0.f, 0.f);
+    }
+    for (int cb = 0; cb < C; cb += 64) {   // 64 channels per pass through the tile
+        const int cw = C - cb < 64 ? C - cb : 64;
+        for (int c = 0; c < cw; c += 8) {
+            float a[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = 0.f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float *wp = w_out + ((size_t)tap * C + cb + c) * 2;  // wave-uniform -> scalar loads
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] = fmaf(g[tap].x, wp[2 * k], fmaf(g[tap].y, wp[2 * k + 1], a[k]));
+            }
+            float *t = s_tile + threadIdx.x * FDX_PITCH + c;
+            *reinterpret_cast<float4 *>(t) = make_float4(a[0], a[1], a[2], a[3]);
+            *reinterpret_cast<float4 *>(t + 4) = make_float4(a[4], a[5], a[6], a[7]);
+        }
+        __syncthreads();
+        const int q = threadIdx.x & 7, groups = cw / 8;
+        const float sl = dx_act == PWS_ACT_LRELU ? 0.2f : 0.f;
+#pragma unroll 2
+        for (int it = 0; it < 8; ++it) {
+            const int p = it * 32 + (threadIdx.x >> 3);
+            const size_t gp = pix0 + p;
+            if (gp < total && q < groups) {
+                const float4 lo = *reinterpret_cast<const float4 *>(s_tile + p * FDX_PITCH + q * 8);
+                const float4 hi = *reinterpret_cast<const float4 *>(s_tile + p * FDX_PITCH + q * 8 + 4);
+                float a[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                __bf16 *d = dx + gp * dx_ld + cb + q * 8;
+                if (accumulate) {
+                    const uint4 u = *reinterpret_cast<const uint4 *>(d);
+                    a[0] += __builtin_bit_cast(float, u.x << 16), a[1] += __builtin_bit_cast(float, u.x & 0xffff0000u);
+                    a[2] += __builtin_bit_cast(float, u.y << 16), a[3] += __builtin_bit_cast(float, u.y & 0xffff0000u);
+                    a[4] += __builtin_bit_cast(float, u.z << 16), a[5] += __builtin_bit_cast(float, u.z & 0xffff0000u);
+                    a[6] += __builtin_bit_cast(float, u.w << 16), a[7] += __builtin_bit_cast(float, u.w & 0xffff0000u);
+                }
+                if (dx_act != PWS_ACT_NONE) {
+                    const uint4 u = *reinterpret_cast<const uint4 *>(xact + gp * x_ld + cb + q * 8);
+                    a[0] *= __builtin_bit_cast(float, u.x << 16) > 0.f ? 1.f : sl, a[1] *= __builtin_bit_cast(float, u.x & 0xffff0000u) > 0.f ? 1.f : sl;
+                    a[2] *= __builtin_bit_cast(float, u.y << 16) > 0.f ? 1.f : sl, a[3] *= __builtin_bit_cast(float, u.y & 0xffff0000u) > 0.f ? 1.f : sl;
+                    a[4] *= __builtin_bit_cast(float, u.z << 16) > 0.f ? 1.f : sl, a[5] *= __builtin_bit_cast(float, u.z & 0xffff0000u) > 0.f ? 1.f : sl;
+                    a[6] *= __builtin_bit_cast(float, u.w << 16) > 0.f ? 1.f : sl, a[7] *= __builtin_bit_cast(float, u.w & 0xffff0000u) > 0.f ? 1.f : sl;
+                }
+                *reinterpret_cast<uint4 *>(d) = make_uint4(cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3]), cvt_pk_bf16(a[4], a[5]),
+                                                           cvt_pk_bf16(a[6], a[7]));
+            }
+        }
+        __syncthreads();   // the tile is rewritten by the next 64 channels
+    }
+}
+
 // ---- K3: dW_out.  Workgroup = 16x16 pixel tile x 32 channels; lane = (channel, pixel-row group).
 constexpr int FB_T = 16, FB_I = FB_T + 2, FB_CH = 32, FB_LDP = FB_CH + 1;
 
@@ -282,15 +354,28 @@ int field_bwd_gz(const float *resid, const float *g_grid, const float *g_resid, 
 }
 
 int field_bwd_dx_dw(const float *x, int ld, const float *gz, int n, int h, int w, int c, const float *w_out, float *dx, int dx_ld,
-                    int dx_accumulate, float *dw_out, int store, hipStream_t st) {
+                    int dx_accumulate, float *dw_out, int store, hipStream_t st, int dx_act) {
     const bool io16 = store == PWS_STORE_BF16;
+    PWS_REQUIRE(dx_act == PWS_ACT_NONE || (io16 && dx && (dx_act == PWS_ACT_LRELU || dx_act == PWS_ACT_RELU) && ld % 8 == 0),
+                "pws_field_head_bwd: dx_act needs bf16 storage, dx, PWS_ACT_LRELU / PWS_ACT_RELU and ld %% 8 == 0");
     const size_t total = (size_t)n * h * w;
     if (dx) {
         PWS_REQUIRE(!io16 || (c % 8 == 0 && dx_ld % 8 == 0), "pws_field_head_bwd: bf16 storage needs c and dx_ld to be multiples of 8");
-        if (io16)
-            hipLaunchKernelGGL(field_dx_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gz, w_out, n, h, w, c, dx,
-                               dx_ld, dx_accumulate);
-        else
+        if (io16) {
+            static bool attr_set = false;  // benign race: idempotent
+            constexpr int lds_bytes = 256 * FDX_PITCH * (int)sizeof(float);
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&field_dx16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   lds_bytes);
+                if (e != hipSuccess) {
+                    set_error("hipFuncSetAttribute(field_dx16_kernel): %s", hipGetErrorString(e));
+                    return PWS_EHIP;
+                }
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(field_dx16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), lds_bytes, st, gz, w_out, n, h, w, c,
+                               reinterpret_cast<__bf16 *>(dx), dx_ld, dx_accumulate, reinterpret_cast<const __bf16 *>(x), ld, dx_act);
+        } else
             hipLaunchKernelGGL(field_dx_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gz, w_out, n, h, w, c, dx,
                                dx_ld, dx_accumulate);
     }
@@ -334,6 +419,14 @@ extern "C" int pws_field_head_bwd_s(const float *x, int ld, int n, int h, int w,
                                     const float *g_grid, const float *g_resid, int align_corners, float *dx, int dx_ld,
                                     int dx_accumulate, float *dw_out, float *db_out, float *dtheta, float *ws, int store,
                                     pws_stream_t stream) {
+    return pws_field_head_bwd_act(x, ld, n, h, w, c, w_out, resid, g_grid, g_resid, align_corners, dx, dx_ld, dx_accumulate, dw_out, db_out,
+                                  dtheta, ws, store, PWS_ACT_NONE, stream);
+}
+
+extern "C" int pws_field_head_bwd_act(const float *x, int ld, int n, int h, int w, int c, const float *w_out, const float *resid,
+                                      const float *g_grid, const float *g_resid, int align_corners, float *dx, int dx_ld,
+                                      int dx_accumulate, float *dw_out, float *db_out, float *dtheta, float *ws, int store, int dx_act,
+                                      pws_stream_t stream) {
     PWS_REQUIRE(n >= 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "pws_field_head_bwd: bad shape");
     if (n == 0) return PWS_OK;
     PWS_REQUIRE(x && w_out && resid && (g_grid || g_resid) && ws, "pws_field_head_bwd: NULL pointer");
@@ -342,7 +435,7 @@ extern "C" int pws_field_head_bwd_s(const float *x, int ld, int n, int h, int w,
     const size_t total = (size_t)n * h * w;
     ProfScope prof(KID_FIELD_HEAD_BWD, 4.0 * total * 18.0 * c, (double)total * (8.0 * c + 32.0), st);
     int rc = field_bwd_gz(resid, g_grid, g_resid, n, h, w, align_corners, ws, db_out, dtheta, st);
-    if (rc == PWS_OK) rc = field_bwd_dx_dw(x, ld, ws, n, h, w, c, w_out, dx, dx_ld, dx_accumulate, dw_out, store, st);
+    if (rc == PWS_OK) rc = field_bwd_dx_dw(x, ld, ws, n, h, w, c, w_out, dx, dx_ld, dx_accumulate, dw_out, store, st, dx_act);
     return rc;
 }
 

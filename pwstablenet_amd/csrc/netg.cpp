@@ -599,7 +599,8 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
         const auto pr = producer.find(t);
         if (lw == last_writer.end() || lw->second != ii || pr == producer.end()) return PWS_ACT_NONE;
         const Op &pop = E.tape()[pr->second];
-        if (L[E.tape()[ii].layer].dgb_off == (size_t)-1) return PWS_ACT_NONE;   // this call runs an fp32 kernel
+        if (E.tape()[ii].type == OP_THETA) return PWS_ACT_NONE;   // the theta head's (tiny) backward does not take the option
+        if (E.tape()[ii].type == OP_CONV && L[E.tape()[ii].layer].dgb_off == (size_t)-1) return PWS_ACT_NONE;   // this call runs an fp32 kernel
         return pop.act == PWS_ACT_LRELU || pop.act == PWS_ACT_RELU ? pop.act : PWS_ACT_NONE;
     };
     bool have_dtheta[3] = {false, false, false};
@@ -623,10 +624,11 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
                     rc = field_bwd_dx_dw(xs.ptr, xs.ld, gz_ws, n, op.in.h, op.in.w, xs.c, packed + o.w_off, gb.g, xs.c, gb.written ? 1 : 0,
                                          dpacked + o.w_off, E.store(), st);
             } else if (run)
-                rc = pws_field_head_bwd_s(xs.ptr, xs.ld, n, op.in.h, op.in.w, xs.c, packed + o.w_off, resid + k * gsz, gg, gr, ac, gb.g,
-                                          xs.c, gb.written ? 1 : 0, dpacked + o.w_off, dpacked + o.b_off,
-                                          gg ? dtheta + (size_t)k * n * 6 : nullptr, gz_ws, E.store(), st);
+                rc = pws_field_head_bwd_act(xs.ptr, xs.ld, n, op.in.h, op.in.w, xs.c, packed + o.w_off, resid + k * gsz, gg, gr, ac, gb.g,
+                                            xs.c, gb.written ? 1 : 0, dpacked + o.w_off, dpacked + o.b_off,
+                                            gg ? dtheta + (size_t)k * n * 6 : nullptr, gz_ws, E.store(), fused_act(ii, xs.ptr), st);
             gb.written = true;
+            if (fused_act(ii, xs.ptr) != PWS_ACT_NONE) gb.preact = true;
             have_dtheta[k] = gg != nullptr;
         } else if (op.type == OP_THETA) {
             const int k = op.stage;

@@ -91,6 +91,7 @@ SIGNATURES = {
     "pws_theta_head_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "pws_field_head_bwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
     "pws_field_head_bwd_s": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P]),
+    "pws_field_head_bwd_act": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _P]),
     "pws_netg_packed_dgrad_floats": (_S, [_I, _I]),
     "pws_netg_pack_weights_dgrad": (_I, [ctypes.POINTER(_P), _P, _I, _I, _P]),
     "pws_netg_train_workspace_bytes": (_S, [_I, _I, _I]),

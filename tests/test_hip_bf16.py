@@ -263,6 +263,52 @@ def test_bf16_data_gradient_with_fused_activation_gradient(hip, kname, shape, sr
     assert L.pws_conv2d_bwd_data(ctypes.byref(da), st) == -22 and b"bf16 storage" in L.pws_last_error()
 
 
+@pytest.mark.parametrize("act,acc,c", [("ACT_RELU", 1, 32), ("ACT_LRELU", 1, 64), ("ACT_RELU", 0, 64), ("ACT_NONE", 1, 96)])
+def test_field_head_backward_bf16_storage_and_fused_activation_gradient(hip, act, acc, c):
+    """bf16 storage: the data gradient of the field head (LDS-transposed, 16-byte accesses) against the fp32-storage kernel on
+    the same bf16 values, and pws_field_head_bwd_act -- dx (after the accumulation) times act'(x) -- against the plain call
+    followed by the product; weight / bias / theta gradients are those of the plain call.  A pixel count that is not a
+    multiple of the 256-pixel workgroup, channel counts below / at / above one 64-channel pass."""
+    A = hip
+    L, st = A.lib(), A.current_stream()
+    rs = np.random.RandomState(7)
+    n, h, w = 2, 23, 41
+    x = torch.from_numpy(rs.standard_normal((n, h, w, c)).astype(np.float32)).cuda().bfloat16()
+    w_out = torch.from_numpy((rs.standard_normal((9, c, 2)) * 0.05).astype(np.float32)).cuda()
+    resid = torch.from_numpy(np.tanh(rs.standard_normal((n, h, w, 2))).astype(np.float32) * 0.5).cuda()
+    gg = torch.from_numpy(rs.standard_normal((n, h, w, 2)).astype(np.float32)).cuda()
+    old = torch.from_numpy(rs.standard_normal((n, h, w, c)).astype(np.float32)).cuda().bfloat16()
+
+    def run(fn, store, *extra):
+        xs, dx = (x, old.clone()) if store == A.STORE_BF16 else (x.float(), old.float())
+        dw, db, dth = torch.zeros((9, c, 2), device="cuda"), torch.zeros(2, device="cuda"), torch.zeros((n, 6), device="cuda")
+        ws = torch.empty(n * h * w * 2, device="cuda")
+        A.check(fn(A.ptr(xs), c, n, h, w, c, A.ptr(w_out), A.ptr(resid), A.ptr(gg), None, 0, A.ptr(dx), c, acc, A.ptr(dw), A.ptr(db),
+                   A.ptr(dth), A.ptr(ws), store, *extra, st), "field bwd")
+        torch.cuda.synchronize()
+        return dx.float(), dw, db, dth
+    ref32 = run(L.pws_field_head_bwd_s, A.STORE_FP32)
+    plain = run(L.pws_field_head_bwd_s, A.STORE_BF16)
+    assert torch.equal(plain[0], ref32[0].bfloat16().float())       # same fp32 sums, one rounding
+    for a_, b_ in zip(ref32[1:], plain[1:]):
+        np.testing.assert_allclose(b_.cpu().numpy(), a_.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(a_.abs().max()))
+    if act != "ACT_NONE":
+        fused = run(L.pws_field_head_bwd_act, A.STORE_BF16, getattr(A, act))
+        slope = 0.2 if act == "ACT_LRELU" else 0.0
+        xv = x.float()
+        want = (plain[0] * torch.where(xv > 0, torch.ones_like(xv), torch.full_like(xv, slope))).bfloat16().float()
+        if act == "ACT_RELU":
+            assert torch.equal(fused[0], want)
+        else:
+            assert float((fused[0] - want).abs().max() / want.abs().max()) < 2 ** -7   # the two-step product rounds twice
+        for a_, b_ in zip(plain[1:], fused[1:]):
+            np.testing.assert_allclose(b_.cpu().numpy(), a_.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(a_.abs().max()))   # atomics order
+        xf = x.float()
+        assert L.pws_field_head_bwd_act(A.ptr(xf), c, n, h, w, c, A.ptr(w_out), A.ptr(resid), A.ptr(gg), None, 0, A.ptr(xf.clone()), c, 0,
+                                        None, None, None, A.ptr(torch.empty(n * h * w * 2, device="cuda")), A.STORE_FP32, getattr(A, act),
+                                        st) == -22
+
+
 def test_bf16_falls_back_to_fp32_for_uncovered_shapes(hip):
     """Sources that are not multiples of 32 channels run the exact fp32 kernel even when bf16 math is requested."""
     A = hip
