@@ -2,7 +2,11 @@
 """Benchmark of the hot path: stabilized frames/s = frames for which ``field = netG(window, False)`` AND
 ``warped = grid_sample(frame, field)`` completed (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W            # N=1 directly; N>1 under torch.distributed.run
+    python bench.py --gpus N --steps K --warmup W
+N=1 runs in this process.  N>1: either already under torch.distributed.run (RANK / WORLD_SIZE in the environment, one rank per
+GPU over RCCL), or -- when WORLD_SIZE is unset -- this process starts `python -m torch.distributed.run --nproc-per-node N` on
+itself BEFORE anything touches the GPU, relays the ranks' output and exits with their code (it never measures one GPU and
+calls it N).  WORLD_SIZE != --gpus is an error.
 
 Workload at every N: BASELINE.json configs[1] per GPU -- batch=8 windows of 31x256x256 (fp32) through the HIP
 generator + HIP grid_sample of 8 RGB 256x256 frames; inputs are synthetic and resident in HBM before the timed
@@ -31,6 +35,26 @@ PEAK_HBM_GBS = 8000.0      # HBM3E spec peak
 GFLOP_PER_FRAME_INFER = 94.48  # de-duplicated inference forward
 GFLOP_PER_SAMPLE_TRAIN = 331.0  # training forward 112.50 + backward (no dgrad for `transfer`)
 PEAK_BF16_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+def self_launch(a):
+    """--gpus N > 1 without a launcher: start N ranks of this script under torch.distributed.run as a CHILD process (this
+    process has not touched the GPU and never will: re-exec'ing or forking a process that initialised HIP takes the box down),
+    pass their stdout / stderr through and return their exit code."""
+    import socket
+    import subprocess
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env["PWS_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without WORLD_SIZE: launching %s" % (a.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
 
 
 def parse():
@@ -63,24 +87,47 @@ _PMC_NAMES = {
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch from the committed PMC summary of this round (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    passes, tools/profile_round.sh): (2*FETCH_SIZE + WRITE_SIZE) KB -- FETCH_SIZE counts 128-B requests as 64 B on gfx950
-    (MI355X_MICROARCH.md, HBM section).  None when no summary is committed for this kernel."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
-    if not os.path.exists(path) or kernel not in _PMC_NAMES:
+    """HBM bytes per launch from a committed PMC summary (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
+    tools/profile_round.sh): (2*FETCH_SIZE + WRITE_SIZE) KB -- FETCH_SIZE counts 128-B requests as 64 B on gfx950
+    (MI355X_MICROARCH.md, HBM section).  Only a summary whose `_meta.source_hash` equals the hash of the kernel sources this
+    library was built from counts (a stale summary would silently describe other kernels): else None."""
+    import glob
+    if kernel not in _PMC_NAMES:
         return None
     try:
-        with open(path) as f:
-            pmc = json.load(f)
+        from pwstablenet_amd.build import source_hash
+        want = source_hash()
     except Exception:
         return None
-    tot, n = 0.0, 0
-    for k, v in pmc.items():
-        if any(sub in k for sub in _PMC_NAMES[kernel]) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-            d = v["FETCH_SIZE"]["dispatches"]
-            tot += (2.0 * v["FETCH_SIZE"]["mean_per_dispatch"] + v["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0 * d
-            n += d
-    return round(tot / n) if n else None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+        try:
+            with open(path) as f:
+                pmc = json.load(f)
+        except Exception:
+            continue
+        if pmc.get("_meta", {}).get("source_hash") != want:
+            continue
+        tot, n = 0.0, 0
+        for k, v in pmc.items():
+            if k != "_meta" and any(sub in k for sub in _PMC_NAMES[kernel]) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                d = v["FETCH_SIZE"]["dispatches"]
+                tot += (2.0 * v["FETCH_SIZE"]["mean_per_dispatch"] + v["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0 * d
+                n += d
+        if n:
+            return round(tot / n)
+    return None
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
 
 
 def usable_cores():
@@ -106,9 +153,10 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(batch_unused, gpu_step=None):
-    """Hot path on the host cores: netG(window, False) + grid_sample, N=1, min over a bounded number of runs.  gpu_step(x, frame)
-    -> (field, warped) on the device: the same frame through the HIP path, for the metric's error figures against the CPU path."""
+def cpu_baseline(timed=None):
+    """Hot path on the host cores: netG(window, False) + grid_sample, N=1, min over a bounded number of runs.
+    timed = (x, frames, field, warped) as CPU tensors: the inputs of the TIMED region (batch 8) and what its launch path --
+    hipGraph replay, two queues -- produced for them; the CPU path runs on the same inputs for the metric's error figures."""
     import torch
     from oracle import torch_ref
     from pwstablenet_amd import synth
@@ -124,9 +172,13 @@ def cpu_baseline(batch_unused, gpu_step=None):
         torch_ref.stabilize_step(params, x, fr)
         best = min(best, time.time() - t0)
         runs += 1
-    res = {"value": round(1.0 / best, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+    res = {"value": round(1.0 / best, 3), "unit": "frames/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
            "sample": "N=1 frame: PyTorch-CPU restatement of netG(x,False)+grid_sample (oracle/torch_ref.py), "
-                     "min of %d runs after 1 warm-up, %d torch threads" % (runs, torch.get_num_threads())}
+                     "min of %d runs after 1 warm-up, %d torch threads" % (runs, torch.get_num_threads()),
+           # the reference's own Python cannot travel to this box: its numbers measured in the build container
+           "reference_cpu_container": {"fps": 4.5, "fps_batch8": 4.3, "cores": 8,
+                                       "what": "reference netG(x, False) imported unmodified, torch 2.10 CPU (oneDNN, AVX-512)",
+                                       "source": "BASELINE.md section 2 / SURVEY.md section 6"}}
     # the split SURVEY 8(d) asks for, bounded (~8 s): generator only / grid_sample only at N=1, end to end at N=8
     def best_of(fn, max_runs, budget_s):
         fn()
@@ -147,13 +199,15 @@ def cpu_baseline(batch_unused, gpu_step=None):
         t_n8 = best_of(lambda: torch_ref.stabilize_step(params, x8, fr8), 2, 4.0)
     res["detail"] = {"netg_only_fps_n1": round(1.0 / t_net, 3), "grid_sample_only_fps_n1": round(1.0 / t_gs, 1),
                      "end_to_end_fps_n8": round(8.0 / t_n8, 3)}
-    if gpu_step is not None:
+    if timed is not None:
+        xt, frt, field, warped = timed
         with torch.no_grad():
-            ref_field = torch_ref.netg_forward(params, x, is_training=False)
-            ref_warp = torch.nn.functional.grid_sample(fr, ref_field, mode="bilinear", padding_mode="zeros", align_corners=False)
-            field, warped = gpu_step(x, fr)
-        res["parity_vs_cpu_path"] = {"warp_field_max_abs_err": float((field.cpu() - ref_field).abs().max()),
-                                     "warped_frame_max_abs_err_on_pm1_scale": float((warped.cpu() - ref_warp).abs().max() / 127.5),
+            ref_field = torch_ref.netg_forward(params, xt, is_training=False)
+            ref_warp = torch.nn.functional.grid_sample(frt, ref_field, mode="bilinear", padding_mode="zeros", align_corners=False)
+        res["parity_vs_cpu_path"] = {"what": "the TIMED launch path (as config.launch says) on the timed region's own batch of %d "
+                                             "windows / frames vs the CPU path on the same inputs" % xt.shape[0],
+                                     "warp_field_max_abs_err": float((field - ref_field).abs().max()),
+                                     "warped_frame_max_abs_err_on_pm1_scale": float((warped - ref_warp).abs().max() / 127.5),
                                      "bound": "1e-3 (north_star, fp32)"}
     return res
 
@@ -281,12 +335,19 @@ def bf16_legs(net, x, frames, out_fp32, a, PF, A, synth):
 
 def main():
     a = parse()
-    import torch
-    import torch.distributed as dist
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a %d-GPU number as a %d-GPU one" % (a.gpus, world, world, a.gpus),
+              file=sys.stderr)
+        sys.exit(2)
+    import torch
+    import torch.distributed as dist
     ctl_device = None  # device of the control-plane tensors (timing barrier / MAX-reduce); the data path has no collective
+    control_plane = "none (single process)"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -294,20 +355,32 @@ def main():
         # collectives through the host -- exercises the multi-rank control flow where RCCL cannot run
         if os.environ.get("PWS_BENCH_ONE_DEVICE") == "1":
             local_rank = 0
-        torch.cuda.set_device(local_rank)
-        try:
-            if os.environ.get("PWS_BENCH_BACKEND", "nccl") != "nccl":
-                raise RuntimeError("PWS_BENCH_BACKEND=%s" % os.environ["PWS_BENCH_BACKEND"])
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
-            ctl_device = torch.device("cuda", local_rank)
-        except Exception as e:  # control plane only: fall back to gloo rather than lose the measurement
-            print("rank %d: nccl init failed (%s); using gloo for the timing barrier" % (rank, e), file=sys.stderr)
+        launch_check = os.environ.get("PWS_BENCH_LAUNCH_CHECK") == "1"   # CPU test of the launcher + control plane: no GPU work
+        if not launch_check:
+            torch.cuda.set_device(local_rank)
+        if os.environ.get("PWS_BENCH_BACKEND", "nccl") != "nccl":
+            # explicit test hook only; a FAILED RCCL init is fatal (a gloo run must never pass for an RCCL one)
             dist.init_process_group("gloo")
             ctl_device = torch.device("cpu")
+            control_plane = "gloo (PWS_BENCH_BACKEND test hook: RCCL not exercised)"
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+            ctl_device = torch.device("cuda", local_rank)
+            control_plane = "rccl"
+        if launch_check:
+            t = torch.tensor([1.0 + rank], dtype=torch.float64, device=ctl_device)
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if rank == 0:
+                print(json.dumps({"launch_check": True, "n_gpus": world, "gpus_arg": a.gpus, "max_over_ranks": float(t.item()),
+                                  "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
+                                  "control_plane": control_plane,
+                                  "self_launched": os.environ.get("PWS_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+            dist.barrier()
+            dist.destroy_process_group()
+            return
     else:
         torch.cuda.set_device(0)
-    if world != a.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
     dev = torch.device("cuda", torch.cuda.current_device())
 
     from pwstablenet_amd import functional as PF
@@ -348,6 +421,11 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
+    # what the timed launch path produced for its inputs (one more replay of the same path), for parity_vs_cpu_path
+    timed_pair = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        with torch.no_grad():
+            timed_pair = (net(x, False).cpu(), step().cpu())
     # 720p leg of the metric on EVERY rank (configs[4] shape, frame-sharded, no collective): netG on 256x256 windows + fused
     # field-resize+warp of 1280x720 RGB frames (reference main_new.py:697-716), frames resident in HBM
     f720 = torch.rand((B, 3, 720, 1280), device=dev) * 255
@@ -396,7 +474,9 @@ def main():
         fps = world * B * a.steps / elapsed
         line = {
             "metric": "stabilized frames/sec at 256x256 (netG %s + grid_sample), whole job" % a.math,
-            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world,
+            "rccl_ranks": dist.get_world_size() if world > 1 and dist.get_backend() == "nccl" else (1 if world == 1 else 0),
+            "control_plane": control_plane, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if a.math == "fp32" else "bf16 operands, f32 accumulate", "data": "synthetic",
             "config": {"workload": "configs[1]: batch=8 256x256 inference per GPU, fp32 HIP conv + grid_sample; "
@@ -587,14 +667,8 @@ def main():
             except Exception as e:  # an extra leg must never cost the headline line
                 line["value_720p_stream_u8"] = {"error": str(e)[:200]}
         if world == 1 and not a.no_cpu_baseline:
-            def gpu_one(xc, fc):   # before the training legs below, which move the weights
-                net.module.enable_graph(False)
-                net.module.set_math("fp32")
-                f_ = net(xc.to(dev), False)
-                return f_, PF.grid_sample(fc.to(dev), f_)
-            line["cpu_baseline"] = cpu_baseline(B, gpu_one)
+            line["cpu_baseline"] = cpu_baseline((x.cpu(), frames.cpu()) + timed_pair if a.math == "fp32" else None)
             line["gpu_over_cpu"] = round(fps / line["cpu_baseline"]["value"], 1)
-            net.module.enable_graph(not a.no_graph)
         if not a.no_extra and a.math == "fp32" and world == 1:
             line["bf16"] = bf16_legs(net, x, frames, out, a, PF, A, synth)
     else:

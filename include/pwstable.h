@@ -6,8 +6,10 @@
  * hipStream_t passed as void*, NULL = the default stream); nothing here allocates, frees or
  * synchronises -- scratch comes from the caller (`ws`), sized by the matching *_workspace_bytes().
  * Return value: 0 on success, negative errno-style code otherwise (pws_last_error() has the text).
- * Re-entrant per stream.  Global mutable state: the thread-local error string, the process-wide options of pws_set_option()
- * (read at call time by the whole-generator entry points) and the measurement hooks (pws_prof_*, off by default).
+ * Re-entrant per stream and per thread.  Global mutable state: the thread-local error string, the process-wide DEFAULTS of
+ * pws_set_option() (read only by the entry points that take no pws_netg_opts; the *_opts entry points carry math / store / queue
+ * mode in their arguments and read no global), the per-(thread, device) side queue of the generator forward and the
+ * measurement hooks (pws_prof_*, off by default).
  *
  * Reference interfaces replaced (paths relative to the mindazhao/PWStableNet checkout; the reference has
  * no native code -- each entry point replaces the PyTorch/ATen op the reference dispatches at that line):
@@ -412,6 +414,19 @@ int pws_netg_forward(const float *packed, const float *x, int n, int input_nc, i
                      int align_corners, void *ws, size_t ws_bytes, float *grids, float *resid, float *thetas,
                      pws_stream_t stream);
 
+/* The same forward with its mode in the ARGUMENTS instead of the process-wide pws_set_option() defaults: two generators with
+ * different arithmetic may run from two host threads (or on two devices) at once.  opts == NULL: as pws_netg_forward. */
+typedef struct pws_netg_opts {
+    int math;       /* PWS_MATH_FP32 / PWS_MATH_BF16 */
+    int store;      /* PWS_STORE_FP32 / PWS_STORE_BF16 (needs PWS_MATH_BF16 and ngf % 32 == 0) */
+    int two_queues; /* 1: fork the internal second queue (stage k+1 encoder beside stage k decoder); 0: caller's stream only;
+                       -1: the process default (PWS_OPT_TWO_QUEUES) */
+    int reserved;   /* must be 0 */
+} pws_netg_opts;
+int pws_netg_forward_opts(const float *packed, const float *x, int n, int input_nc, int ngf, int is_training, int align_corners,
+                          void *ws, size_t ws_bytes, float *grids, float *resid, float *thetas, const pws_netg_opts *opts,
+                          pws_stream_t stream);
+
 /* ---- training: backward of the whole generator (is_training=1 forward must have run on the SAME ws, untouched since).
  * Data-gradient weights: a second packed buffer (pws_netg_packed_dgrad_floats) filled by pws_netg_pack_weights_dgrad.
  * g_grids / g_resid: [3][n,256,256,2] each, or NULL as a whole (no gradient wrt that output list).
@@ -433,6 +448,12 @@ int pws_netg_backward_part(const float *packed, const float *packed_dgrad, const
                            int align_corners, void *ws, size_t ws_bytes, const float *resid, const float *thetas,
                            const float *g_grids, const float *g_resid, float *dpacked, int part, int nparts,
                            unsigned char *final_mask, pws_stream_t stream);
+/* pws_netg_backward / pws_netg_backward_part with the mode of the forward that filled `ws` passed explicitly (opts must equal the
+ * forward's; NULL: the process defaults).  part = 0, nparts = 1, final_mask = NULL is the whole backward. */
+int pws_netg_backward_opts(const float *packed, const float *packed_dgrad, const float *x, int n, int input_nc, int ngf,
+                           int align_corners, void *ws, size_t ws_bytes, const float *resid, const float *thetas,
+                           const float *g_grids, const float *g_resid, float *dpacked, int part, int nparts,
+                           unsigned char *final_mask, const pws_netg_opts *opts, pws_stream_t stream);
 /* ---- use_BN=True training (lib/cfg.py:37; lib/networks_cascading.py:253-341: BatchNorm2d after every conv, batch statistics).
  * bn_params / bn_running / dbn: flat buffers of pws_netg_bn_floats() floats, per layer in state-dict order
  * [gamma(cout) | beta(cout)], [running_mean | running_var], [dgamma | dbeta].  The forward is the is_training one (6 fields) and

@@ -42,16 +42,25 @@ class _NetGTrain(torch.autograd.Function):
             return (None, None) + (None,) * 92
         L = A.lib()
         st = A.current_stream()
+        # the packed weights are ONE buffer shared by every forward of this generator and re-packed in place when a parameter
+        # changes: a backward that runs after optimizer.step() / load_state_dict() would silently use the new weights (torch
+        # raises "modified by an inplace operation" in this situation; so does this)
+        if sv["packed"] is not net._packed or net._weights_key() != sv["weights_key"]:
+            raise RuntimeError("pwstablenet_amd: one of the generator's parameters was modified (optimizer.step / load_state_dict / "
+                               "another forward after a change) between netG(x) and its backward; the packed weights of that "
+                               "forward are gone -- call backward() before updating the parameters")
         packed, packed_dg = sv["packed"], net.packed_dgrad_weights()
         dpacked = torch.empty_like(packed)
-        net._apply_math(sv.get("math", "fp32"), sv.get("store", "fp32"))  # the arena holds what the forward's mode wrote
+        opts = net._opts(sv.get("math", "fp32"), sv.get("store", "fp32"))  # the arena holds what the forward's mode wrote
+        ac = sv.get("ac", 0)
         params = net._ordered_params()
         grads = [torch.empty_like(p) for p in params]
         sync = getattr(net, "grad_sync", None)
         if sync is None or sync.nparts == 1:
-            A.check(L.pws_netg_backward(A.ptr(packed), A.ptr(packed_dg), A.ptr(sv["x"]), n, net.input_nc, net.ngf, 0,
-                                        ctypes.c_void_p(sv["ws_ptr"]), sv["ws_bytes"], A.ptr(sv["resid"]), A.ptr(sv["thetas"]),
-                                        A.ptr(g_grids), A.ptr(g_resid), A.ptr(dpacked), st), "pws_netg_backward")
+            A.check(L.pws_netg_backward_opts(A.ptr(packed), A.ptr(packed_dg), A.ptr(sv["x"]), n, net.input_nc, net.ngf, ac,
+                                             ctypes.c_void_p(sv["ws_ptr"]), sv["ws_bytes"], A.ptr(sv["resid"]), A.ptr(sv["thetas"]),
+                                             A.ptr(g_grids), A.ptr(g_resid), A.ptr(dpacked), 0, 1, None, ctypes.byref(opts), st),
+                    "pws_netg_backward_opts")
             ptrs = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
             A.check(L.pws_netg_unpack_grads(A.ptr(dpacked), ptrs, net.input_nc, net.ngf, st), "pws_netg_unpack_grads")
             if sync is not None:
@@ -66,10 +75,10 @@ class _NetGTrain(torch.autograd.Function):
             done = [False] * nl
             sync.collectives = 0
             for part in range(sync.nparts):
-                A.check(L.pws_netg_backward_part(A.ptr(packed), A.ptr(packed_dg), A.ptr(sv["x"]), n, net.input_nc, net.ngf, 0,
+                A.check(L.pws_netg_backward_opts(A.ptr(packed), A.ptr(packed_dg), A.ptr(sv["x"]), n, net.input_nc, net.ngf, ac,
                                                  ctypes.c_void_p(sv["ws_ptr"]), sv["ws_bytes"], A.ptr(sv["resid"]),
                                                  A.ptr(sv["thetas"]), A.ptr(g_grids), A.ptr(g_resid), A.ptr(dpacked), part,
-                                                 sync.nparts, mask, st), "pws_netg_backward_part")
+                                                 sync.nparts, mask, ctypes.byref(opts), st), "pws_netg_backward_opts")
                 newly = [i for i in range(nl) if mask[i] and not done[i]]
                 if not newly:
                     continue
@@ -143,9 +152,8 @@ class _NetGTrainBN(torch.autograd.Function):
         grids = torch.empty((3, n, 256, 256, 2), device=dev, dtype=torch.float32)
         resid = torch.empty((3, n, 256, 256, 2), device=dev, dtype=torch.float32)
         thetas = torch.empty((3, n, 6), device=dev, dtype=torch.float32)
-        net._apply_math("fp32", "fp32")
         eps, mom = float(bns[0].eps), float(bns[0].momentum if bns[0].momentum is not None else 0.1)
-        A.check(L.pws_netg_forward_bn(A.ptr(packed), A.ptr(bn_params), A.ptr(running), mom, eps, A.ptr(x), n, net.input_nc, net.ngf, 0,
+        A.check(L.pws_netg_forward_bn(A.ptr(packed), A.ptr(bn_params), A.ptr(running), mom, eps, A.ptr(x), n, net.input_nc, net.ngf, int(net.align_corners),
                                       ctypes.c_void_p(ws_ptr), ws_bytes, A.ptr(grids), A.ptr(resid), A.ptr(thetas), st),
                 "pws_netg_forward_bn")
         with torch.no_grad():   # running statistics back into the modules (plumbing), call counters as nn.BatchNorm2d keeps them
@@ -159,7 +167,7 @@ class _NetGTrainBN(torch.autograd.Function):
         net.last_thetas = thetas
         ctx.net_ref = net_ref
         ctx.saved = dict(x=x, ws=ws, ws_ptr=ws_ptr, ws_bytes=ws_bytes, resid=resid, thetas=thetas, packed=packed, bn_params=bn_params,
-                         eps=eps)
+                         eps=eps, ac=int(net.align_corners))
         return (grids[0], grids[1], grids[2], resid[0], resid[1], resid[2])
 
     @staticmethod
@@ -181,9 +189,8 @@ class _NetGTrainBN(torch.autograd.Function):
         packed, packed_dg = sv["packed"], net.packed_dgrad_weights()
         dpacked = torch.empty_like(packed)
         dbn = torch.empty_like(sv["bn_params"])
-        net._apply_math("fp32", "fp32")
         A.check(L.pws_netg_backward_bn(A.ptr(packed), A.ptr(packed_dg), A.ptr(sv["bn_params"]), sv["eps"], A.ptr(sv["x"]), n, net.input_nc,
-                                       net.ngf, 0, ctypes.c_void_p(sv["ws_ptr"]), sv["ws_bytes"], A.ptr(sv["resid"]), A.ptr(sv["thetas"]),
+                                       net.ngf, sv["ac"], ctypes.c_void_p(sv["ws_ptr"]), sv["ws_bytes"], A.ptr(sv["resid"]), A.ptr(sv["thetas"]),
                                        A.ptr(g_grids), A.ptr(g_resid), A.ptr(dpacked), A.ptr(dbn), st), "pws_netg_backward_bn")
         params = net._ordered_params()
         grads = [torch.empty_like(p) for p in params]

@@ -17,6 +17,18 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources and headers the library is built from: profile summaries under
+    profiles/ carry it (`_meta.source_hash`), and bench.py only quotes counter-derived figures whose hash matches the build."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(SOURCES + ["common.h", "conv_common.h", "netg_pack.h"])
+    for f in files + [os.path.join("..", "..", "include", "pwstable.h")]:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read() + b"\0")
+    return h.hexdigest()[:16]
+
+
 def _deps():
     hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(CSRC, "netg_pack.h"), os.path.join(HERE, "..", "include", "pwstable.h"), os.path.abspath(__file__)]
     return max(os.path.getmtime(h) for h in hdrs)

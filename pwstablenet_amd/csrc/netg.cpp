@@ -135,6 +135,27 @@ static void fill_pack_layers(const std::vector<Layer> &L, PackLayer *out) {
     }
 }
 
+// Mode of one forward / backward: carried by value from the entry point's arguments (pws_netg_opts) -- the executor reads no
+// process-wide option, so two generators with different arithmetic can run from two host threads.
+struct NetgOpts {
+    int math, store;
+    bool two_queues;
+};
+static NetgOpts opts_defaults() { return NetgOpts{g_math, g_store, g_two_queues}; }
+static int opts_from(const pws_netg_opts *o, NetgOpts *out) {
+    if (!o) {
+        *out = opts_defaults();
+        return PWS_OK;
+    }
+    PWS_REQUIRE(o->math == PWS_MATH_FP32 || o->math == PWS_MATH_BF16, "pws_netg_opts: math %d", o->math);
+    PWS_REQUIRE(o->store == PWS_STORE_FP32 || o->store == PWS_STORE_BF16, "pws_netg_opts: store %d", o->store);
+    PWS_REQUIRE(o->store == PWS_STORE_FP32 || o->math == PWS_MATH_BF16, "pws_netg_opts: PWS_STORE_BF16 needs PWS_MATH_BF16");
+    PWS_REQUIRE(o->two_queues >= -1 && o->two_queues <= 1 && o->reserved == 0, "pws_netg_opts: two_queues %d / reserved %d", o->two_queues,
+                o->reserved);
+    *out = NetgOpts{o->math, o->store, o->two_queues < 0 ? g_two_queues : o->two_queues != 0};
+    return PWS_OK;
+}
+
 struct Seg {
     float *ptr;
     int c, ld;
@@ -184,13 +205,19 @@ struct SideStream {
         return events[next++];
     }
 };
-static thread_local SideStream g_side;
+// one per host thread AND device: a thread that drives two GPUs, or two threads on one GPU, never share a queue or an event pool
+static SideStream &side_stream() {
+    static thread_local std::unordered_map<int, SideStream> per_device;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return per_device[dev];
+}
 
 class Exec {
   public:
     Exec(const float *packed, const std::vector<Layer> &layers, int n, char *ws, size_t ws_bytes, hipStream_t st, bool dry,
-         bool launch, const BnCfg *bn = nullptr)
-        : packed_(packed), L_(layers), n_(n), ws_(ws), cap_(ws_bytes), dry_(dry), launch_(launch && !dry) {
+         bool launch, const NetgOpts &o, const BnCfg *bn = nullptr)
+        : math_(o.math), packed_(packed), L_(layers), n_(n), ws_(ws), cap_(ws_bytes), dry_(dry), launch_(launch && !dry) {
         if (bn) {
             bn_on_ = true, bn_ = *bn;
             size_t off = 0;
@@ -198,9 +225,12 @@ class Exec {
             bn_total_ = off;
         }
         // bf16 storage of activations: only with bf16 math and when every conv layer is covered by the bf16 kernels
-        io16_ = g_math == PWS_MATH_BF16 && g_store == PWS_STORE_BF16 && layers[L_DOWN1].cin % 32 == 0;
+        io16_ = o.math == PWS_MATH_BF16 && o.store == PWS_STORE_BF16 && layers[L_DOWN1].cin % 32 == 0;
         streams_[0] = st, streams_[1] = st;
-        if (launch_ && g_two_queues && g_side.init()) streams_[1] = g_side.stream, g_side.next = 0;
+        if (launch_ && o.two_queues) {
+            side_ = &side_stream();
+            if (side_->init()) streams_[1] = side_->stream, side_->next = 0;
+        }
     }
 
     // ---- two-queue scheduling: ops go to queue `q`; fork/join are event record + wait (capturable, no host sync)
@@ -209,7 +239,7 @@ class Exec {
     // mark(): "everything issued so far on queue `from`"; wait(): later work on queue `to` starts after that point
     hipEvent_t mark(int from) {
         if (!launch_ || !two_queues()) return nullptr;
-        hipEvent_t e = g_side.event();
+        hipEvent_t e = side_->event();
         if (!e || hipEventRecord(e, streams_[from]) != hipSuccess) {
             if (rc_ == PWS_OK) set_error("pws_netg_forward: hipEventRecord failed"), rc_ = PWS_EHIP;
             return nullptr;
@@ -229,6 +259,7 @@ class Exec {
     float *splitk_ws() const { return splitk_ws_; }
     float *x_nhwc() const { return x_nhwc_; }
     bool io16() const { return io16_; }
+    int math() const { return math_; }
     int store() const { return io16_ ? PWS_STORE_BF16 : PWS_STORE_FP32; }
     float *theta_x32(int q) const { return theta_x32_[q]; }
     size_t splitk_bytes() const { return splitk_bytes_; }
@@ -283,7 +314,7 @@ class Exec {
         if (!launch_ || rc_ != PWS_OK) return o;
         pws_conv_args a{};
         a.kind = l.kind, a.n = n_, a.h = x.h, a.w = x.w;
-        if (nchw_c > 0 && g_math == PWS_MATH_BF16 && l.wb_off != (size_t)-1 && x_nhwc_ && nchw_c <= 32) {
+        if (nchw_c > 0 && math_ == PWS_MATH_BF16 && l.wb_off != (size_t)-1 && x_nhwc_ && nchw_c <= 32) {
             // bf16 first layer: the NCHW window is re-laid once as a 32-channel NHWC source (kept for the weight gradient)
             rc_ = pws_nchw_to_nhwc_pad_s(nchw_src, x_nhwc_, n_, nchw_c, x.h, x.w, 32, store(), streams_[q_]);
             if (rc_ != PWS_OK) return o;
@@ -298,7 +329,7 @@ class Exec {
         a.w_wino = l.ww_off != (size_t)-1 ? packed_ + l.ww_off : nullptr;
         a.out = bn_on_ ? op.aux[0] : o.seg[0].ptr, a.out_ld = l.cout;
         a.ws = q_ ? splitk_ws2_ : splitk_ws_, a.ws_bytes = splitk_bytes_;
-        if (g_math == PWS_MATH_BF16 && l.wb_off != (size_t)-1) a.math = PWS_MATH_BF16, a.w_bf16 = packed_ + l.wb_off;
+        if (math_ == PWS_MATH_BF16 && l.wb_off != (size_t)-1) a.math = PWS_MATH_BF16, a.w_bf16 = packed_ + l.wb_off;
         a.store = store();
         g_prof_tag = layer;
         rc_ = pws_conv2d_fwd(&a, streams_[q_]);
@@ -410,6 +441,8 @@ class Exec {
     size_t bn_off_[L_COUNT] = {}, bn_total_ = 0, bn_ws_bytes_ = 0;
     float *bn_ws_[2] = {nullptr, nullptr};
     bool io16_ = false;
+    int math_ = PWS_MATH_FP32;
+    SideStream *side_ = nullptr;
     hipStream_t streams_[2];
     int q_ = 0;
     size_t splitk_bytes_ = 0;
@@ -508,11 +541,13 @@ struct GradBuf {
 static int run_backward(const float *packed, const float *packed_dgrad, const float *x, int n, int input_nc, int g, int ac,
                         char *ws, size_t ws_bytes, const float *resid, const float *thetas, const float *g_grids,
                         const float *g_resid, float *dpacked, hipStream_t st, bool dry, size_t *used, int part = 0,
-                        int nparts = 1, unsigned char *final_mask = nullptr, const BnCfg *bn = nullptr, float *dbn = nullptr) {
+                        int nparts = 1, unsigned char *final_mask = nullptr, const BnCfg *bn = nullptr, float *dbn = nullptr,
+                        const NetgOpts *opts = nullptr) {
     const int S = 256;
     size_t total = 0;
     const std::vector<Layer> L = build_layers(input_nc, g, &total);
-    Exec E(packed, L, n, ws, ws_bytes, st, dry, /*launch=*/false, bn);
+    const NetgOpts mode = opts ? *opts : opts_defaults();
+    Exec E(packed, L, n, ws, ws_bytes, st, dry, /*launch=*/false, mode, bn);
     float dummy_thetas = 0.f;  // non-NULL: the training forward is always given a caller-owned thetas buffer
     forward_graph(E, x, n, input_nc, g, 1, ac, nullptr, nullptr, &dummy_thetas);
     // gradient buffers, one per produced tensor, after the forward region of the arena
@@ -572,7 +607,7 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
     // (pws_dst.act_y) instead of by a separate pass over the buffer.  A dry sweep finds, per tensor, the tape position of that
     // last writer (same control flow as the real sweep below) and the op that produced the tensor.
     std::unordered_map<const float *, size_t> last_writer, producer;
-    const bool fuse_act = E.io16() && !bn && g_math == PWS_MATH_BF16 && g_experiment != 11;
+    const bool fuse_act = E.io16() && !bn && mode.math == PWS_MATH_BF16 && g_experiment != 11;
     if (fuse_act) {
         std::unordered_map<const float *, bool> wr;
         bool hd[3] = {false, false, false};
@@ -690,10 +725,10 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             wa.kind = l.kind, wa.n = n, wa.h = op.in.h, wa.w = op.in.w, wa.nsrc = op.in.nseg, wa.src_nchw = op.nchw ? 1 : 0;
             for (int i = 0; i < op.in.nseg; ++i) wa.src[i] = pws_src{op.in.seg[i].ptr, op.in.seg[i].c, op.in.seg[i].ld};
             if (op.nchw) wa.src[0] = pws_src{x, input_nc, 0};
-            if (op.nchw && g_math == PWS_MATH_BF16 && l.wb_off != (size_t)-1 && E.x_nhwc() && input_nc <= 32)
+            if (op.nchw && mode.math == PWS_MATH_BF16 && l.wb_off != (size_t)-1 && E.x_nhwc() && input_nc <= 32)
                 wa.src_nchw = 0, wa.src[0] = pws_src{E.x_nhwc(), 32, 32};  // the forward's NHWC copy
             wa.cout = l.cout, wa.gout = go.g, wa.gout_ld = l.cout, wa.dw_packed = dpacked + l.w_off;
-            wa.math = g_math, wa.store = E.store();
+            wa.math = mode.math, wa.store = E.store();
             wa.dbias = !bn && go.preact ? dpacked + l.b_off : nullptr;
             rc = pws_conv2d_bwd_weight(&wa, st);
             if (rc != PWS_OK || op.nchw) {
@@ -712,7 +747,7 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
                     da.dst[i].act_y = op.in.seg[i].ptr, da.dst[i].act_y_ld = op.in.seg[i].ld, da.dst[i].act = fa, gi.preact = true;
             }
             da.ws = E.splitk_ws(), da.ws_bytes = E.splitk_bytes();
-            if (g_math == PWS_MATH_BF16 && l.dgb_off != (size_t)-1) da.math = PWS_MATH_BF16, da.w_dgrad_bf16 = packed_dgrad + l.dgb_off;
+            if (mode.math == PWS_MATH_BF16 && l.dgb_off != (size_t)-1) da.math = PWS_MATH_BF16, da.w_dgrad_bf16 = packed_dgrad + l.dgb_off;
             da.store = E.store();
             rc = pws_conv2d_bwd_data(&da, st);
             g_prof_tag = -1;
@@ -810,18 +845,8 @@ extern "C" int pws_netg_backward_part(const float *packed, const float *packed_d
                                       int align_corners, void *ws, size_t ws_bytes, const float *resid, const float *thetas,
                                       const float *g_grids, const float *g_resid, float *dpacked, int part, int nparts,
                                       unsigned char *final_mask, pws_stream_t stream) {
-    PWS_REQUIRE(n >= 0 && input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_backward_part: bad n/input_nc/ngf");
-    PWS_REQUIRE(nparts >= 1 && part >= 0 && part < nparts, "pws_netg_backward_part: part %d of %d", part, nparts);
-    if (n == 0) {
-        if (final_mask)
-            for (int i = 0; i < L_COUNT; ++i) final_mask[i] = 1;
-        return PWS_OK;
-    }
-    PWS_REQUIRE(packed && packed_dgrad && x && ws && resid && thetas && dpacked, "pws_netg_backward_part: NULL pointer");
-    PWS_REQUIRE(g_grids || g_resid, "pws_netg_backward_part: no output gradient given");
-    PWS_REQUIRE((reinterpret_cast<size_t>(ws) & 255) == 0, "pws_netg_backward_part: workspace must be 256-byte aligned");
-    return run_backward(packed, packed_dgrad, x, n, input_nc, ngf, align_corners, static_cast<char *>(ws), ws_bytes, resid, thetas,
-                        g_grids, g_resid, dpacked, as_stream(stream), false, nullptr, part, nparts, final_mask);
+    return pws_netg_backward_opts(packed, packed_dgrad, x, n, input_nc, ngf, align_corners, ws, ws_bytes, resid, thetas, g_grids, g_resid,
+                                  dpacked, part, nparts, final_mask, nullptr, stream);
 }
 
 // ---- use_BN=True training (BatchNorm2d after every conv, batch statistics): fp32 math and storage only
@@ -836,8 +861,9 @@ extern "C" size_t pws_netg_train_workspace_bytes_bn(int n, int input_nc, int ngf
     if (n <= 0 || input_nc <= 0 || ngf <= 0 || ngf % 16 != 0) return 0;
     size_t used = 0;
     BnCfg bn;
+    const NetgOpts o{PWS_MATH_FP32, PWS_STORE_FP32, false};
     run_backward(nullptr, nullptr, nullptr, n, input_nc, ngf, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true,
-                 &used, 0, 1, nullptr, &bn, nullptr);
+                 &used, 0, 1, nullptr, &bn, nullptr, &o);
     return used;
 }
 
@@ -849,13 +875,13 @@ extern "C" int pws_netg_forward_bn(const float *packed, const float *bn_params, 
     PWS_REQUIRE(n >= 2, "pws_netg_forward_bn: training-mode BatchNorm needs more than 1 value per channel (the theta head has one per "
                         "sample): n >= 2, as torch");
     PWS_REQUIRE(packed && bn_params && x && ws && grids && resid && thetas, "pws_netg_forward_bn: NULL pointer");
-    PWS_REQUIRE(g_math == PWS_MATH_FP32, "pws_netg_forward_bn: the use_BN training path runs in fp32 (PWS_OPT_MATH is bf16)");
     PWS_REQUIRE((reinterpret_cast<size_t>(ws) & 255) == 0, "pws_netg_forward_bn: workspace must be 256-byte aligned");
     size_t total = 0;
     const std::vector<Layer> L = build_layers(input_nc, ngf, &total);
     BnCfg bn;
     bn.params = bn_params, bn.running = bn_running, bn.momentum = momentum, bn.eps = eps;
-    Exec E(packed, L, n, static_cast<char *>(ws), ws_bytes, as_stream(stream), false, true, &bn);
+    const NetgOpts o{PWS_MATH_FP32, PWS_STORE_FP32, g_two_queues};   // the BatchNorm training path is fp32 whatever the defaults say
+    Exec E(packed, L, n, static_cast<char *>(ws), ws_bytes, as_stream(stream), false, true, o, &bn);
     forward_graph(E, x, n, input_nc, ngf, 1, align_corners, grids, resid, thetas);
     return E.rc();
 }
@@ -867,12 +893,12 @@ extern "C" int pws_netg_backward_bn(const float *packed, const float *packed_dgr
     PWS_REQUIRE(n >= 2 && input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_backward_bn: bad n/input_nc/ngf");
     PWS_REQUIRE(packed && packed_dgrad && bn_params && x && ws && resid && thetas && dpacked && dbn, "pws_netg_backward_bn: NULL pointer");
     PWS_REQUIRE(g_grids || g_resid, "pws_netg_backward_bn: no output gradient given");
-    PWS_REQUIRE(g_math == PWS_MATH_FP32, "pws_netg_backward_bn: the use_BN training path runs in fp32 (PWS_OPT_MATH is bf16)");
     PWS_REQUIRE((reinterpret_cast<size_t>(ws) & 255) == 0, "pws_netg_backward_bn: workspace must be 256-byte aligned");
     BnCfg bn;
     bn.params = bn_params, bn.eps = eps;
+    const NetgOpts o{PWS_MATH_FP32, PWS_STORE_FP32, g_two_queues};
     return run_backward(packed, packed_dgrad, x, n, input_nc, ngf, align_corners, static_cast<char *>(ws), ws_bytes, resid, thetas, g_grids,
-                        g_resid, dpacked, as_stream(stream), false, nullptr, 0, 1, nullptr, &bn, dbn);
+                        g_resid, dpacked, as_stream(stream), false, nullptr, 0, 1, nullptr, &bn, dbn, &o);
 }
 
 extern "C" int pws_netg_unpack_grads(const float *dpacked, float *const *grads, int input_nc, int ngf, pws_stream_t stream) {
@@ -902,7 +928,7 @@ extern "C" size_t pws_netg_workspace_bytes(int n, int input_nc, int ngf, int is_
     if (n <= 0 || input_nc <= 0 || ngf <= 0 || ngf % 16 != 0) return 0;
     size_t total = 0;
     const std::vector<Layer> L = build_layers(input_nc, ngf, &total);
-    Exec E(nullptr, L, n, nullptr, 0, nullptr, /*dry=*/true, false);
+    Exec E(nullptr, L, n, nullptr, 0, nullptr, /*dry=*/true, false, NetgOpts{PWS_MATH_FP32, PWS_STORE_FP32, false});   // the arena layout does not depend on the mode
     forward_graph(E, nullptr, n, input_nc, ngf, is_training, 0, nullptr, nullptr, nullptr);
     return E.used();
 }
@@ -910,35 +936,60 @@ extern "C" size_t pws_netg_workspace_bytes(int n, int input_nc, int ngf, int is_
 extern "C" size_t pws_netg_train_workspace_bytes(int n, int input_nc, int ngf) {
     if (n <= 0 || input_nc <= 0 || ngf <= 0 || ngf % 16 != 0) return 0;
     size_t used = 0;
+    const NetgOpts o{PWS_MATH_FP32, PWS_STORE_FP32, false};   // the arena layout does not depend on the mode
     run_backward(nullptr, nullptr, nullptr, n, input_nc, ngf, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                 true, &used);
+                 true, &used, 0, 1, nullptr, nullptr, nullptr, &o);
     return used;
 }
 
-extern "C" int pws_netg_forward(const float *packed, const float *x, int n, int input_nc, int ngf, int is_training,
-                                int align_corners, void *ws, size_t ws_bytes, float *grids, float *resid, float *thetas,
-                                pws_stream_t stream) {
+extern "C" int pws_netg_forward_opts(const float *packed, const float *x, int n, int input_nc, int ngf, int is_training,
+                                     int align_corners, void *ws, size_t ws_bytes, float *grids, float *resid, float *thetas,
+                                     const pws_netg_opts *opts, pws_stream_t stream) {
     PWS_REQUIRE(n >= 0 && input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_forward: bad n/input_nc/ngf %d/%d/%d", n, input_nc,
                 ngf);
+    NetgOpts o;
+    if (int rc = opts_from(opts, &o)) return rc;
     if (n == 0) return PWS_OK;
     PWS_REQUIRE(packed && x && ws && grids, "pws_netg_forward: NULL pointer");
     PWS_REQUIRE(!is_training || (resid && thetas), "pws_netg_forward: resid and thetas must be given when is_training");
     PWS_REQUIRE((reinterpret_cast<size_t>(ws) & 255) == 0, "pws_netg_forward: workspace must be 256-byte aligned");
     size_t total = 0;
     const std::vector<Layer> L = build_layers(input_nc, ngf, &total);
-    Exec E(packed, L, n, static_cast<char *>(ws), ws_bytes, as_stream(stream), false, true);
+    Exec E(packed, L, n, static_cast<char *>(ws), ws_bytes, as_stream(stream), false, true, o);
     forward_graph(E, x, n, input_nc, ngf, is_training, align_corners, grids, resid, thetas);
     return E.rc();
+}
+
+extern "C" int pws_netg_forward(const float *packed, const float *x, int n, int input_nc, int ngf, int is_training,
+                                int align_corners, void *ws, size_t ws_bytes, float *grids, float *resid, float *thetas,
+                                pws_stream_t stream) {
+    return pws_netg_forward_opts(packed, x, n, input_nc, ngf, is_training, align_corners, ws, ws_bytes, grids, resid, thetas, nullptr,
+                                 stream);
+}
+
+extern "C" int pws_netg_backward_opts(const float *packed, const float *packed_dgrad, const float *x, int n, int input_nc, int ngf,
+                                      int align_corners, void *ws, size_t ws_bytes, const float *resid, const float *thetas,
+                                      const float *g_grids, const float *g_resid, float *dpacked, int part, int nparts,
+                                      unsigned char *final_mask, const pws_netg_opts *opts, pws_stream_t stream) {
+    PWS_REQUIRE(n >= 0 && input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_backward: bad n/input_nc/ngf");
+    PWS_REQUIRE(nparts >= 1 && part >= 0 && part < nparts, "pws_netg_backward: part %d of %d", part, nparts);
+    NetgOpts o;
+    if (int rc = opts_from(opts, &o)) return rc;
+    if (n == 0) {
+        if (final_mask)
+            for (int i = 0; i < L_COUNT; ++i) final_mask[i] = 1;
+        return PWS_OK;
+    }
+    PWS_REQUIRE(packed && packed_dgrad && x && ws && resid && thetas && dpacked, "pws_netg_backward: NULL pointer");
+    PWS_REQUIRE(g_grids || g_resid, "pws_netg_backward: no output gradient given");
+    PWS_REQUIRE((reinterpret_cast<size_t>(ws) & 255) == 0, "pws_netg_backward: workspace must be 256-byte aligned");
+    return run_backward(packed, packed_dgrad, x, n, input_nc, ngf, align_corners, static_cast<char *>(ws), ws_bytes, resid, thetas,
+                        g_grids, g_resid, dpacked, as_stream(stream), false, nullptr, part, nparts, final_mask, nullptr, nullptr, &o);
 }
 
 extern "C" int pws_netg_backward(const float *packed, const float *packed_dgrad, const float *x, int n, int input_nc, int ngf,
                                  int align_corners, void *ws, size_t ws_bytes, const float *resid, const float *thetas,
                                  const float *g_grids, const float *g_resid, float *dpacked, pws_stream_t stream) {
-    PWS_REQUIRE(n >= 0 && input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_backward: bad n/input_nc/ngf");
-    if (n == 0) return PWS_OK;
-    PWS_REQUIRE(packed && packed_dgrad && x && ws && resid && thetas && dpacked, "pws_netg_backward: NULL pointer");
-    PWS_REQUIRE(g_grids || g_resid, "pws_netg_backward: no output gradient given");
-    PWS_REQUIRE((reinterpret_cast<size_t>(ws) & 255) == 0, "pws_netg_backward: workspace must be 256-byte aligned");
-    return run_backward(packed, packed_dgrad, x, n, input_nc, ngf, align_corners, static_cast<char *>(ws), ws_bytes, resid, thetas,
-                        g_grids, g_resid, dpacked, as_stream(stream), false, nullptr);
+    return pws_netg_backward_opts(packed, packed_dgrad, x, n, input_nc, ngf, align_corners, ws, ws_bytes, resid, thetas, g_grids, g_resid,
+                                  dpacked, 0, 1, nullptr, nullptr, stream);
 }

@@ -92,6 +92,35 @@ def allreduce_gradients(params, bucket_bytes=64 << 20):
     return allreduce_tensors([p.grad for p in params if p.grad is not None], bucket_bytes)
 
 
+def broadcast_parameters(netG, src=0, check=False):
+    """Makes every rank start from rank ``src``'s generator: parameters AND buffers (BatchNorm running statistics) go out as
+    ONE flat fp32 bucket (194 MB: a single large xGMI message, not 92 small ones) and are copied back in place (version
+    counters bump, so the packed-weight cache re-packs).  ``define_G`` initialises from the local torch RNG and a checkpoint
+    may have been loaded on one rank only: without this the replicas diverge silently.  The reference's ``nn.DataParallel``
+    re-broadcasts rank 0's parameters on every forward (lib/networks_cascading.py:51-52); one process per GPU does it once.
+    check=True: instead of overwriting, raise if this rank's values differ from ``src``'s.  Returns the number of floats."""
+    target = getattr(netG, "module", netG)
+    tensors = list(target.parameters()) + [b for b in target.buffers() if b.dtype.is_floating_point]   # copy_ under no_grad bumps ._version
+    if not tensors:
+        return 0
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return sum(t.numel() for t in tensors)
+    with torch.no_grad():
+        flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors])
+        mine = flat.clone() if check else None
+        dist.broadcast(flat, src=src)
+        if check:
+            if not torch.equal(mine, flat):
+                raise RuntimeError("broadcast_parameters(check=True): rank %d's generator differs from rank %d's in %d values"
+                                   % (dist.get_rank(), src, int((mine != flat).sum())))
+            return flat.numel()
+        off = 0
+        for t in tensors:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+    return off
+
+
 class OverlappedGradSync:
     """Gradient exchange overlapped with backward.  ``enable_overlapped_grad_sync(netG)`` attaches one to the
     generator; its backward then runs as ``nparts`` consecutive runs of the reversed layer tape (``pws_netg_backward_part``)
@@ -116,9 +145,11 @@ class OverlappedGradSync:
         self.collectives += allreduce_tensors(tensors, self.bucket_bytes)
 
 
-def enable_overlapped_grad_sync(netG, nparts=4, bucket_bytes=64 << 20):
+def enable_overlapped_grad_sync(netG, nparts=4, bucket_bytes=64 << 20, broadcast=True):
     """netG: what ``define_G`` returned (or its ``.module``).  Returns the OverlappedGradSync; ``netG.grad_sync = None`` turns
-    it off again."""
+    it off again.  broadcast: first make every replica equal to rank 0's (``broadcast_parameters``)."""
     target = getattr(netG, "module", netG)
+    if broadcast:
+        broadcast_parameters(target, src=0)
     target.grad_sync = OverlappedGradSync(nparts, bucket_bytes)
     return target.grad_sync

@@ -52,6 +52,10 @@ class PwsConvBwdWeightArgs(ctypes.Structure):
                 ("dbias", ctypes.c_void_p)]
 
 
+class PwsNetgOpts(ctypes.Structure):
+    _fields_ = [("math", ctypes.c_int), ("store", ctypes.c_int), ("two_queues", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
 class PwsProfRecord(ctypes.Structure):
     _fields_ = [("kernel_id", ctypes.c_int), ("tag", ctypes.c_int), ("flops", ctypes.c_double),
                 ("bytes", ctypes.c_double), ("ms", ctypes.c_float)]
@@ -118,6 +122,8 @@ SIGNATURES = {
     "pws_netg_pack_weights": (_I, [ctypes.POINTER(_P), _P, _I, _I, _P]),
     "pws_netg_workspace_bytes": (_S, [_I, _I, _I, _I]),
     "pws_netg_forward": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _S, _P, _P, _P, _P]),
+    "pws_netg_forward_opts": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _S, _P, _P, _P, ctypes.POINTER(PwsNetgOpts), _P]),
+    "pws_netg_backward_opts": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _S, _P, _P, _P, _P, _P, _I, _I, _P, ctypes.POINTER(PwsNetgOpts), _P]),
     "pws_u8_normalize": (_I, [_P, _S, _P, _S, _I, _S, _P]),
     "pws_warp_norm_fwd": (_I, [_P, _S, _P, _P, _P, _S, _P, _I, _I, _I, _P]),
     "pws_warp_norm_bwd": (_I, [_P, _S, _P, _P, _S, _F, _P, _P, _P, _I, _I, _I, _I, _P]),

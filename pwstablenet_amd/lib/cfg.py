@@ -81,6 +81,11 @@ def _build_parser():
     # not in the reference: arithmetic of the conv contractions on the MI355X matrix cores (UnetGenerator.set_math)
     p.add_argument("--math", choices=("fp32", "bf16"), default="fp32",
                    help="fp32: exact-fp32 MFMA (parity path); bf16: bf16 MFMA with fp32 accumulation (training configs)")
+    # not in the reference: coordinate convention of affine_grid / grid_sample.  The reference is pinned to "pytorch 0.4.0+"
+    # (README.md:27), where both behaved as align_corners=True; the torch it can be imported with today (>= 1.3) defaults to
+    # False, which is what the goldens and this build default to.  Set it to load checkpoints trained under torch < 1.3.
+    p.add_argument("--align_corners", type=int, choices=(0, 1), default=0,
+                   help="0: torch >= 1.3 semantics of affine_grid / grid_sample (default); 1: torch < 1.3 (legacy checkpoints)")
     return p
 
 

@@ -144,8 +144,14 @@ class UnetGenerator(nn.Module):
         self._packed_dgrad_key = None
         self._ws = {}
         self._graph_mode = False
-        self._graphs = {}
+        self._graph_alias = False
+        self._graph = None
         self.math, self.store = "fp32", "fp32"
+        # coordinate convention of the fused affine_grid (and of the functional.grid_sample default the drivers should pass):
+        # False = torch >= 1.3 defaults (goldens); True = torch < 1.3, what checkpoints trained on the reference's pinned
+        # "pytorch 0.4.0+" expect
+        self.align_corners = bool(getattr(opt, "align_corners", 0))
+        self.two_queues = None   # None: the process default (PWS_OPT_TWO_QUEUES); True / False: per generator
         if getattr(opt, "math", "fp32") == "bf16":
             self.set_math("bf16")
 
@@ -162,22 +168,26 @@ class UnetGenerator(nn.Module):
         if store not in ("fp32", "bf16") or (store == "bf16" and (math != "bf16" or self.ngf % 32 != 0)):
             raise ValueError("UnetGenerator.set_math: store=%r needs math='bf16' and ngf %% 32 == 0" % (store,))
         if (math, store) != (self.math, self.store):
-            self._graphs = {}
+            self._graph = None
         self.math, self.store = math, store
         return self
 
-    def _apply_math(self, math=None, store=None):
+    def _opts(self, math=None, store=None):
+        """The mode of one executor call as the C ABI takes it (pws_netg_opts): carried in the call's arguments, no
+        process-wide state is written."""
         math, store = math or self.math, store or self.store
-        A.check(A.lib().pws_set_option(A.OPT_MATH, A.MATH_BF16 if math == "bf16" else A.MATH_FP32), "pws_set_option")
-        A.check(A.lib().pws_set_option(A.OPT_STORE, A.STORE_BF16 if store == "bf16" else A.STORE_FP32), "pws_set_option")
+        tq = -1 if self.two_queues is None else int(bool(self.two_queues))
+        return A.PwsNetgOpts(A.MATH_BF16 if math == "bf16" else A.MATH_FP32, A.STORE_BF16 if store == "bf16" else A.STORE_FP32, tq, 0)
 
-    def enable_graph(self, on=True):
+    def enable_graph(self, on=True, alias_output=False):
         """Opt-in hipGraph replay of the inference forward (``netG(x, False)`` under ``no_grad``): the ~75 launches of a
-        forward are captured once per (batch, input address, weight version) and replayed as one graph launch.
-        The returned field then lives in a buffer owned by the graph and is OVERWRITTEN by the next call."""
+        forward are captured once per (batch, weight version, mode) and replayed as one graph launch.  The graph owns its
+        activation arena and its output buffer; every call returns a fresh tensor (a 0.5 MB/frame device copy) unless
+        ``alias_output=True``, in which case the returned field is the graph's own buffer and is OVERWRITTEN by the next call."""
         self._graph_mode = bool(on)
+        self._graph_alias = bool(alias_output)
         if not on:
-            self._graphs = {}
+            self._graph = None
 
     # -- parameters in state-dict order: (weight, bias) per layer
     def _ordered_params(self):
@@ -279,25 +289,39 @@ class UnetGenerator(nn.Module):
             return self._run_graph(input1)
         return self._run(input1, is_training)
 
+    def _capture(self, x, key, static_input):
+        """Captures one forward on ``x`` (or on a private copy of it: ``static_input``) with an arena private to the graph."""
+        xg = x.clone() if static_input else x
+        nbytes = A.lib().pws_netg_workspace_bytes(xg.shape[0], self.input_nc, self.ngf, 0)
+        ws = torch.empty(nbytes + 256, device=xg.device, dtype=torch.uint8)
+        self._run(xg, False, ws=ws)  # eager warm-up: one-time kernel attribute calls must not happen during capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = self._run(xg, False, ws=ws)
+        # one graph is kept; it holds its input tensor (address baked in), its arena and its output
+        self._graph = dict(key=key, g=g, out=out, x=xg, ws=ws, static=static_input)
+        return self._graph
+
     def _run_graph(self, input1):
         x = input1.contiguous()
         self.packed_weights()
-        key = (x.shape[0], x.data_ptr(), self._packed_key, self.math, self.store)
-        ent = self._graphs.get(key)
-        if ent is None:
-            self._run(x, False)  # eager warm-up: one-time kernel attribute calls must not happen during capture
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = self._run(x, False)
-            self._graphs = {key: (g, out, x)}  # keep one graph; hold x so its address stays valid
-            ent = self._graphs[key]
-        ent[0].replay()
-        return ent[1]
+        key = (tuple(x.shape), str(x.device), self._packed.data_ptr(), self._packed_key, self.math, self.store, self.align_corners,
+               self.two_queues)
+        ent = self._graph
+        if ent is None or ent["key"] != key:
+            ent = self._capture(x, key, static_input=False)
+        elif x.data_ptr() != ent["x"].data_ptr():
+            # a different input buffer: from now on the graph reads a private static buffer that every call copies into
+            if not ent["static"]:
+                ent = self._capture(x, key, static_input=True)
+            ent["x"].copy_(x)
+        ent["g"].replay()
+        return ent["out"] if self._graph_alias else ent["out"].clone()
 
-    def _run(self, input1, is_training, train_ctx=None):
+    def _run(self, input1, is_training, train_ctx=None, ws=None):
         """train_ctx: dict filled with what backward needs; the arena is then private to this call (the reference's
-        training loop runs two forwards before one backward, main_new.py:101,112,214)."""
+        training loop runs two forwards before one backward, main_new.py:101,112,214).  ws: caller-owned arena (graph capture)."""
         x = input1.contiguous()
         n = x.shape[0]
         S = 256
@@ -305,7 +329,7 @@ class UnetGenerator(nn.Module):
         if train_ctx is not None:
             nbytes = A.lib().pws_netg_train_workspace_bytes(n, self.input_nc, self.ngf)
             ws = torch.empty(nbytes + 256, device=x.device, dtype=torch.uint8)
-        else:
+        elif ws is None:
             ws = self._workspace(n, is_training, x.device)
         ws_ptr = (ws.data_ptr() + 255) // 256 * 256
         ws_bytes = ws.numel() - (ws_ptr - ws.data_ptr())
@@ -313,14 +337,15 @@ class UnetGenerator(nn.Module):
         grids = torch.empty((ng, n, S, S, 2), device=x.device, dtype=torch.float32)
         resid = torch.empty((3, n, S, S, 2), device=x.device, dtype=torch.float32) if is_training else None
         thetas = torch.empty((3, n, 6), device=x.device, dtype=torch.float32)
-        self._apply_math()
-        A.check(A.lib().pws_netg_forward(A.ptr(packed), A.ptr(x), n, self.input_nc, self.ngf, int(bool(is_training)),
-                                         0, ctypes.c_void_p(ws_ptr), ws_bytes, A.ptr(grids), A.ptr(resid), A.ptr(thetas),
-                                         A.current_stream()), "pws_netg_forward")
+        ac = int(self.align_corners)
+        opts = self._opts()
+        A.check(A.lib().pws_netg_forward_opts(A.ptr(packed), A.ptr(x), n, self.input_nc, self.ngf, int(bool(is_training)),
+                                              ac, ctypes.c_void_p(ws_ptr), ws_bytes, A.ptr(grids), A.ptr(resid), A.ptr(thetas),
+                                              ctypes.byref(opts), A.current_stream()), "pws_netg_forward_opts")
         self.last_thetas = thetas
         if train_ctx is not None:
             train_ctx.update(x=x, ws=ws, ws_ptr=ws_ptr, ws_bytes=ws_bytes, grids=grids, resid=resid, thetas=thetas, packed=packed,
-                             math=self.math, store=self.store)
+                             math=self.math, store=self.store, ac=ac, weights_key=self._weights_key())
         if is_training:
             return [grids[0], grids[1], grids[2]], [resid[0], resid[1], resid[2]]
         return grids[0]

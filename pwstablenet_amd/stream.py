@@ -64,6 +64,9 @@ class VideoStabilizer:
         self.batch = int(batch)
         self.period = int(period)
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        # grid_sample follows the generator's coordinate convention (UnetGenerator.align_corners: torch >= 1.3 default False;
+        # True for checkpoints trained under the reference's pinned torch 0.4)
+        self.align_corners = bool(getattr(getattr(netG, "module", netG), "align_corners", False))
 
     def _pad(self, gray, halo_left, halo_right):
         """Replicates the first / last available frame so that every frame owns a full window (reference :627-633)."""
@@ -123,9 +126,9 @@ class VideoStabilizer:
             win = _windows(gp, s, e - s, self.period)
             field = self.net(win, False)
             if cur.dtype == torch.uint8:
-                warped = PF.upsample_grid_sample_u8(cur.contiguous(), field, swap_rb=self.swap_rb)
+                warped = PF.upsample_grid_sample_u8(cur.contiguous(), field, swap_rb=self.swap_rb, align_corners=self.align_corners)
             else:
-                warped = PF.upsample_grid_sample(cur.contiguous(), field)
+                warped = PF.upsample_grid_sample(cur.contiguous(), field, align_corners=self.align_corners)
             if on_host:
                 done = torch.cuda.Event()
                 done.record(compute)
@@ -142,7 +145,7 @@ class VideoStabilizer:
         return out
 
     @torch.no_grad()
-    def run_video(self, frames, chunk=64, half_size_output=False, frames_are_rgb=False, halo_left=0, halo_right=0):
+    def run_video(self, frames, chunk=64, half_size_output=False, frames_are_rgb=False, halo_left=0, halo_right=0, crop=None):
         """The whole device side of the reference's ``process()`` loop for one decoded clip: ``frames`` (T, H, W, 3) uint8 as
         cv2 delivers them, in (pinned) host memory or on the device.  Per chunk of ``chunk`` frames: H2D on a side stream,
         gray + INTER_AREA 256x256 window planes computed there from the uploaded frames (so nothing but the uint8 frames
@@ -151,7 +154,12 @@ class VideoStabilizer:
         k+1 uploads while chunk k computes; window planes are kept for the whole clip (256 KB per frame), frames per chunk.
         halo_left / halo_right: ``frames`` additionally holds that many real neighbour frames before / after the T frames to
         stabilise (a rank's shard of a longer clip, ``distributed.shard_frames``: up to period//2 each); they only feed the
-        windows.  Returns (T, H, W, 3) -- or (T, H/2, W/2, 3) -- uint8 on the inputs' side."""
+        windows.  crop = (x_start, x_end, y_start, y_end[, threshold]): the reference's crop window of the OUTPUT frame
+        (main_new.py:607-610,729-730: ``samples[int(y_start)+threshold:int(y_end)-threshold, int(x_start)+threshold:
+        int(x_end)-threshold]``, applied after the down-scale), sliced on the device so that only the cropped frames cross PCIe;
+        the reference's live values (0, 640, 0, 360, threshold 0) are the whole 640x360 frame.  The 3x3 GaussianBlur(sigma=0.2)
+        that follows in the reference (:731) is the identity on 8-bit frames and is not run.
+        Returns (T, H, W, 3) -- or (T, H/2, W/2, 3), or the crop window of it -- uint8 on the inputs' side."""
         half = self.period // 2
         if not (0 <= halo_left <= half and 0 <= halo_right <= half):
             raise ValueError("halo must be within [0, %d]" % half)
@@ -162,7 +170,16 @@ class VideoStabilizer:
         on_host = not frames.is_cuda
         dev = self.device
         h, w = frames.shape[1], frames.shape[2]
-        oshape = (T, h // 2, w // 2, 3) if half_size_output else (T, h, w, 3)
+        oh, ow = (h // 2, w // 2) if half_size_output else (h, w)
+        cy0, cy1, cx0, cx1 = 0, oh, 0, ow
+        if crop is not None:
+            if len(crop) not in (4, 5):
+                raise ValueError("crop must be (x_start, x_end, y_start, y_end[, threshold])")
+            th = int(crop[4]) if len(crop) == 5 else 0
+            cx0, cx1, cy0, cy1 = int(crop[0]) + th, int(crop[1]) - th, int(crop[2]) + th, int(crop[3]) - th
+            if not (0 <= cx0 < cx1 <= ow and 0 <= cy0 < cy1 <= oh):
+                raise ValueError("crop window x [%d, %d) y [%d, %d) does not lie inside the %d x %d output frame" % (cx0, cx1, cy0, cy1, ow, oh))
+        oshape = (T, cy1 - cy0, cx1 - cx0, 3)
         out = torch.empty(oshape, dtype=torch.uint8, pin_memory=True) if on_host else torch.empty(oshape, dtype=torch.uint8, device=dev)
         if T == 0:
             return out
@@ -200,6 +217,8 @@ class VideoStabilizer:
             warped = self.run(gray_all[cs - hl:ce + hr], buf[cs - s:ce - s], halo_left=hl, halo_right=hr)
             if half_size_output:
                 warped = area_half(warped)
+            if crop is not None:
+                warped = warped[:, cy0:cy1, cx0:cx1, :].contiguous()   # packed on the device: only the window crosses PCIe
             s, e = cs - halo_left, ce - halo_left   # position in the output
             if on_host:
                 buf.record_stream(compute)

@@ -50,6 +50,25 @@ def _worker(rank, world, port, q):
     mean = sum(range(1, world + 1)) / world
     for i, p in enumerate(params):
         assert torch.allclose(p.grad, torch.full_like(p, mean * (i + 1)))
+    # replicas start equal: parameters + BatchNorm buffers of rank 0 reach every rank as one flat bucket
+    torch.manual_seed(100 + rank)   # define_G initialises from the LOCAL torch RNG: the ranks differ before the broadcast
+    m = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4))
+    m[1].running_mean.fill_(float(rank + 1))
+    if rank != 0:
+        with pytest.raises(RuntimeError):
+            D.broadcast_parameters(m, src=0, check=True)
+    else:
+        D.broadcast_parameters(m, src=0, check=True)
+    versions = [p._version for p in m.parameters()]
+    nfl = D.broadcast_parameters(m, src=0)
+    assert nfl == sum(p.numel() for p in m.parameters()) + 8
+    assert all(p._version > v for p, v in zip(m.parameters(), versions))   # the packed-weight cache keys on the version counters
+    D.broadcast_parameters(m, src=0, check=True)
+    assert float(m[1].running_mean[0]) == 1.0 and int(m[1].num_batches_tracked) == 0
+    chk = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).double().sum().reshape(1)
+    both = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(both, chk)
+    assert all(torch.equal(b, both[0]) for b in both)
     # inference sharding: ranks process disjoint frames, results gathered for the check only
     s, e, _, _ = D.shard_frames(10, rank, world)
     mine = torch.zeros(10)
@@ -72,3 +91,24 @@ def test_two_ranks_gloo():
         assert p.exitcode == 0
     got = sorted(q.get(timeout=5) for _ in range(world))
     assert [g[0] for g in got] == [0, 1] and all(g[1] >= 2 for g in got)
+
+
+def test_bench_launches_its_own_ranks_and_refuses_a_world_size_mismatch():
+    """`python bench.py --gpus N` without a launcher must start N ranks itself: here with the control-plane
+    check hook (no GPU work) over gloo.  A WORLD_SIZE that contradicts --gpus is an error, not a warning."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(PWS_BENCH_LAUNCH_CHECK="1", PWS_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line == {"launch_check": True, "n_gpus": 2, "gpus_arg": 2, "max_over_ranks": 2.0, "rccl_ranks": 0,
+                    "control_plane": "gloo (PWS_BENCH_BACKEND test hook: RCCL not exercised)", "self_launched": True}
+    env2 = dict(env, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "refusing" in r.stderr

@@ -182,6 +182,30 @@ def test_run_video_equals_run_on_host_prepared_planes(hip, on_host, half_out):
     assert d.max() <= 1 and np.mean(d > 0) < 1e-3, (d.max(), float(np.mean(d > 0)))
 
 
+def test_run_video_crop_window(hip):
+    """The reference's crop of the output frame (main_new.py:607-610,729-730) as an argument of run_video: sliced on the device
+    before the copy back; the live values of the reference (the whole 640x360 frame, threshold 0) change nothing."""
+    from pwstablenet_amd.stream import VideoStabilizer
+    net = make_net()
+    T, H, W = 9, 288, 320
+    frames = torch.from_numpy(_clip_u8(T, H, W, 5))
+    vs = VideoStabilizer(net, batch=4, swap_rb=True)
+    full = vs.run_video(frames.pin_memory(), chunk=4, half_size_output=True)
+    assert tuple(full.shape) == (T, H // 2, W // 2, 3)
+    same = vs.run_video(frames.pin_memory(), chunk=4, half_size_output=True, crop=(0, W // 2, 0, H // 2))
+    assert torch.equal(same, full)
+    x0, x1, y0, y1, th = 10, 150, 4, 140, 3
+    got = vs.run_video(frames.pin_memory(), chunk=4, half_size_output=True, crop=(x0, x1, y0, y1, th))
+    assert not got.is_cuda and got.is_contiguous() and tuple(got.shape) == (T, y1 - y0 - 2 * th, x1 - x0 - 2 * th, 3)
+    assert torch.equal(got, full[:, y0 + th:y1 - th, x0 + th:x1 - th, :])
+    got_d = vs.run_video(frames.cuda(), chunk=4, crop=(16, 300, 8, 280))          # device-resident clip, full-size output
+    assert got_d.is_cuda and tuple(got_d.shape) == (T, 272, 284, 3)
+    with pytest.raises(ValueError):
+        vs.run_video(frames.cuda(), crop=(0, W + 1, 0, H))
+    with pytest.raises(ValueError):
+        vs.run_video(frames.cuda(), crop=(5, 5, 0, H))
+
+
 def test_run_video_sharded_with_halos_equals_whole_clip(hip):
     """configs[4] sharding: every rank gets a contiguous chunk of the clip plus up to 15 real neighbour frames on either side
     (distributed.shard_frames) and runs run_video on its slice; concatenated == the whole clip on one GPU."""

@@ -41,6 +41,7 @@ def main():
     net.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in synth.make_weights("W1", 123, ngf=64)})  # same on all ranks
     net = net.to(dev)
     net.module.set_math(a.math)
+    D.broadcast_parameters(net, src=0)   # replicas start equal whatever each rank initialised / loaded
     opt = Adam(net.parameters(), lr=a.lr, betas=(0.5, 0.999))
     small = synth.make_train_batch(min(a.batch, 4), seed=100 + rank)
     rep = (a.batch + 3) // 4
