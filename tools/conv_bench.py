@@ -10,6 +10,46 @@ import torch  # noqa: E402
 from pwstablenet_amd import hipabi as A  # noqa: E402
 
 
+def bench_dgrad(kname, n, h, w, cin, cout):
+    """Data gradient of the layer (forward input n x h x w x cin, forward cout) with bf16 math and storage, one destination."""
+    L, st = A.lib(), A.current_stream()
+    L.pws_set_option(100, int(os.environ.get("PWS_EXPERIMENT", "0")))
+    kind = getattr(A, kname)
+    k = {"CONV_K3S1": 3, "CONV_K3S2": 3, "CONVT_K3S1": 3, "CONVT_K4S2": 4}[kname]
+    wt = torch.randn((cout, cin, k, k) if not kname.startswith("CONVT") else (cin, cout, k, k), device="cuda") / (cin * k) ** 0.5
+    wdg = torch.empty(L.pws_packed_dgrad_floats(kind, cin, cout), device="cuda")
+    A.check(L.pws_pack_conv_weight_dgrad(A.ptr(wt), A.ptr(wdg), kind, cin, cout, st), "pack_dgrad")
+    planes = 9 if "S1" in kname else 16
+    wdb = torch.empty(L.pws_packed_bf16_floats(planes, cout, cin), device="cuda")
+    A.check(L.pws_pack_weight_bf16(A.ptr(wdg), A.ptr(wdb), planes, cout, cin, st), "pack_bf16")
+    oh, ow = (h, w) if "S1" in kname else ((h // 2, w // 2) if kname == "CONV_K3S2" else (2 * h, 2 * w))
+    rot = int(os.environ.get("CONV_BENCH_ROTATE", "1"))
+    dys = [torch.randn((n, oh, ow, cout), device="cuda").bfloat16() for _ in range(rot)]
+    dxs = [torch.empty((n, h, w, cin), device="cuda", dtype=torch.bfloat16) for _ in range(rot)]
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    da = A.PwsConvBwdDataArgs()
+    da.kind, da.n, da.h, da.w, da.cout = kind, n, h, w, cout
+    da.gout_ld, da.w_dgrad, da.ndst = cout, wdg.data_ptr(), 1
+    da.math, da.w_dgrad_bf16, da.store = A.MATH_BF16, wdb.data_ptr(), A.STORE_BF16
+    da.dst[0].channels, da.dst[0].ld, da.dst[0].accumulate = cin, cin, 0
+    da.ws, da.ws_bytes = ws.data_ptr(), ws.numel()
+
+    def launch(i):
+        da.gout, da.dst[0].ptr = dys[i % rot].data_ptr(), dxs[i % rot].data_ptr()
+        A.check(L.pws_conv2d_bwd_data(ctypes.byref(da), st), "bwd_data")
+    for i in range(3):
+        launch(i)
+    torch.cuda.synchronize()
+    L.pws_prof_enable(1)
+    for i in range(12):
+        launch(i)
+    L.pws_prof_enable(0)
+    r = A.prof_collect()
+    ms = sorted(x_[4] for x_ in r)[len(r) // 2]
+    print("%-11s n=%d %dx%d %d->%d dgrad exp=%s %-18s: %8.1f us  %6.1f TFLOP/s (algorithmic)" % (
+        kname, n, h, w, cin, cout, os.environ.get("PWS_EXPERIMENT", "0"), r[0][0], ms * 1e3, r[0][2] / (ms * 1e-3) / 1e12))
+
+
 def bench(kname, n, h, w, cin, cout, wino, bf16=False):
     L, st = A.lib(), A.current_stream()
     L.pws_set_option(100, int(os.environ.get("PWS_EXPERIMENT", "0")))
@@ -64,11 +104,14 @@ def bench(kname, n, h, w, cin, cout, wino, bf16=False):
     L.pws_prof_enable(0)
     r = A.prof_collect()
     ms = sorted(x_[4] for x_ in r)[len(r) // 2]
-    print("%-11s n=%d %dx%d %d->%d %-5s ablate=%s: %8.1f us  %6.1f TFLOP/s (algorithmic)" % (
-        kname, n, h, w, cin, cout, "bf16" if bf16 else ("wino" if wino else "direct"), os.environ.get("PWS_WINO_ABLATE", "0"), ms * 1e3,
+    print("%-11s n=%d %dx%d %d->%d %-5s exp=%s %-18s: %8.1f us  %6.1f TFLOP/s (algorithmic)" % (
+        kname, n, h, w, cin, cout, "bf16" if bf16 else ("wino" if wino else "direct"), os.environ.get("PWS_EXPERIMENT", "0"), r[0][0], ms * 1e3,
         r[0][2] / (ms * 1e-3) / 1e12))
 
 
 if __name__ == "__main__":
     v = sys.argv[1:]
+    if len(v) > 7 and v[7] == "dgrad":
+        bench_dgrad(v[0], int(v[1]), int(v[2]), int(v[3]), int(v[4]), int(v[5]))
+        sys.exit(0)
     bench(v[0], int(v[1]), int(v[2]), int(v[3]), int(v[4]), int(v[5]), len(v) > 6 and v[6] == "wino", len(v) > 6 and v[6] == "bf16")
