@@ -76,7 +76,11 @@ struct RgCfg {
     static constexpr int TAPS = KS * KS;
     static constexpr int NPLANES = MODE >= RM_K3S2 ? 4 : 1;   // input parity planes
     static constexpr int NCLS = (MODE == RM_CT4 || MODE == RM_SP3) ? 4 : 1;   // output parity classes
-    static constexpr int WAVES = 8, THREADS = 512;
+    // 8 matrix waves (two per SIMD, each 2 tile rows x 64 channels) + 4 loader waves (one per SIMD) that do nothing but issue
+    // the LDS-DMA pieces: a DMA piece blocks its wave for the ~30-70 cycles the texture addresser takes per piece, 75 pieces per
+    // group -- issued by the matrix waves themselves that time ADDS to the matrix phase (measured: DMA-only, MFMA-only and
+    // epilogue-only timings of the one-role kernel summed to its run time), issued by waves of their own it hides under it
+    static constexpr int MWAVES = 8, LWAVES = 4, THREADS = 64 * (MWAVES + LWAVES);
     static_assert(TW == 32 && TH == 16, "a wave's operand is one 32-pixel tile row; 8 waves x 2 rows");
     static constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
     static constexpr int CKG = 32;                                // input channels per K group
@@ -85,18 +89,16 @@ struct RgCfg {
     static constexpr int IN_SLOTS = IH * IW * SPP;                // 16-byte slots of the input image of one group
     static constexpr int IN_WI = (IN_SLOTS + 63) / 64;            // wave-instructions (64 slots each)
     static constexpr int W_WI = TAPS * 64 * SPP / 64;             // TAPS x 64 rows x SPP slots
-    static constexpr int NL = (IN_WI + W_WI + WAVES - 1) / WAVES; // DMA instructions per wave and group
-    static constexpr int NLG = NL;
-    static constexpr int GROUP_BYTES = NL * WAVES * 1024;
+    static constexpr int NL = (IN_WI + W_WI + LWAVES - 1) / LWAVES; // DMA instructions per loader wave and group
+    static constexpr int GROUP_BYTES = NL * LWAVES * 1024;
     static constexpr int W_OFF = IN_WI * 1024;
     static constexpr int LDS_BYTES = R * GROUP_BYTES;
-    // the `it` whose 8 wave-instructions hold input pieces on the first waves and weight pieces on the others (-1: none)
-    static constexpr int MIX_IT = IN_WI % WAVES == 0 ? -1 : IN_WI / WAVES;
-    static constexpr int NSTORE = 8;                              // epilogue store instructions per wave and unit
+    // the `it` whose 4 wave-instructions hold input pieces on the first loader waves and weight pieces on the others (-1: none)
+    static constexpr int MIX_IT = IN_WI % LWAVES == 0 ? -1 : IN_WI / LWAVES;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-    static_assert(GROUP_BYTES >= WAVES * 4096, "the epilogue's transposition tiles live in the group buffer just consumed");
+    static_assert(GROUP_BYTES >= MWAVES * 4096, "the epilogue's transposition tiles live in the group buffer just consumed");
     static_assert(R >= 2 && R <= 4, "ring depth");
-    static_assert((R - 2) * NLG + NSTORE <= 63, "vmcnt is 6 bits");
+    static_assert((R - 2) * NL <= 63, "vmcnt is 6 bits");
 };
 
 // one LDS-DMA: 64 lanes x 16 bytes, lane l lands at lds_addr + 16 l; source = rsrc base + soff + voff (lanes beyond
@@ -146,7 +148,7 @@ __device__ __forceinline__ RingUnit ring_unit(const RingParams &p, unsigned u) {
 }
 
 template <class C, bool DG>   // DG: data-gradient epilogue (scatter over the forward layer's sources, accumulate, act')
-__global__ void __launch_bounds__(C::THREADS, 2) conv_ring_kernel(const RingParams p) {
+__global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -155,8 +157,7 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_ring_kernel(const RingPara
     // Units: XCD x (blocks x, x + 8, ...) takes the contiguous chunk [x U / 8, (x + 1) U / 8) and deals it round-robin to its
     // workgroups, so that at any time the ~32 workgroups of an XCD sit on ~32 CONSECUTIVE units: the 4 parity classes / the
     // 64-channel blocks of one tile (same input tile) and neighbouring tiles (shared halo) are staged by different CUs at about
-    // the same time and come from that XCD's L2 once.  (Contiguous ranges per workgroup re-read each input tile from HBM for
-    // every class: 32 workgroups x 287 KB of tile thrash the 4 MB L2.)
+    // the same time and come from that XCD's L2 once (rocprofv3: HBM reads = 1.2x the input tensor).
     const unsigned G = gridDim.x;
     const unsigned nxc = G < (unsigned)kXcds ? G : (unsigned)kXcds;
     const unsigned xcd = blockIdx.x % nxc, slot = blockIdx.x / nxc;
@@ -167,217 +168,208 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_ring_kernel(const RingPara
     const unsigned u_begin = c_begin + slot, u_end = c_end, u_step = nx;
     const unsigned my_units = (u_end - u_begin + u_step - 1) / u_step;
     const int ngroups = C::NPLANES * p.gpp;   // K groups of one unit
+    const unsigned total = my_units * (unsigned)ngroups;
 
-    // ---- this lane's DMA items: item `it` = 16-byte slot it * 512 + tid of a group image; the wave-instruction
-    // (it * 8 + wv) is wave-uniformly an input piece, a weight piece or filler.  A row (pixel / weight row) is 64 bytes = 32
-    // channels = ONE 64-byte L2 request, 4 lanes; its four 16-byte slots are permuted by XOR with bits 2..3 of the pixel's x
-    // (of the row index): the permutation is applied to the SOURCE offset here and to the ds_read_b128 address in the matrix phase.
-    int ia[C::NL], ib[C::NL];   // input: (ly << 16 | lx), c16  /  weights: tap slot, nn * kpad * 2 + c16  /  filler: -1
+    // Both roles walk the same sequence of groups s = 0 .. total - 1 and meet at the same barriers:
+    //   B_s : group s has landed in buffer s % R (every loader waited for its own pieces first) and every matrix wave is done
+    //         reading group s - 1, whose buffer the loaders now refill with group s + R - 1;
+    //   E   : (last group of a unit only) every matrix wave is done with the operands of that group, whose buffer the matrix
+    //         waves then use for the epilogue's transposition tiles.
+    if (wv >= C::MWAVES) {
+        // =========================================================================================== loader waves
+        const int lw = wv - C::MWAVES;
+        // item `it` of this lane = 16-byte slot (it * 4 + lw) * 64 + lane of a group image; the wave-instruction (it * 4 + lw) is
+        // wave-uniformly an input piece, a weight piece or filler.  A row (pixel / weight row) is 64 bytes = 32 channels = ONE
+        // 64-byte L2 request, 4 lanes; its four 16-byte slots are permuted by XOR with bits 2..3 of the pixel's x (of the row
+        // index): applied to the SOURCE offset here and to the ds_read_b128 address in the matrix phase.
+        int ia[C::NL], ib[C::NL];   // input: (ly << 16 | lx), c16  /  weights: tap slot, nn * kpad * 2 + c16  /  filler: -1
 #pragma unroll
-    for (int it = 0; it < C::NL; ++it) {
-        const int wi = it * C::WAVES + wv;
-        const int j = wi * 64 + lane;
-        if (wi < C::IN_WI) {
-            const int q = j / C::SPP, sp = j % C::SPP;
-            const int lx = q % C::IW, ly = q / C::IW;
-            ia[it] = j < C::IN_SLOTS ? (ly << 16 | lx) : -1;
-            ib[it] = (sp ^ ((lx >> 2) & 3)) * 16;
-        } else if (wi < C::IN_WI + C::W_WI) {
-            const int jj = j - C::IN_WI * 64;
-            const int row = jj / C::SPP, sp = jj % C::SPP;
-            const int t = row >> 6, rr = row & 63;
-            const int nn = (rr & 31) * 2 + (rr >> 5);   // LDS row rr holds output channel nn: a lane's two 32-channel blocks
-                                                        // are the channel pair (2 l, 2 l + 1) -> 16-byte epilogue stores
-            ia[it] = t;
-            ib[it] = nn * p.kpad * 2 + (sp ^ ((rr >> 2) & 3)) * 16;
-        } else {
-            ia[it] = -1, ib[it] = 0;
-        }
-    }
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w_bf), 0, (int)p.w_bytes, 0x00020000);
-
-    // ---- operand read offsets inside a group image (bytes): lane (l31, hi) reads k-slot 2 ks + hi of its row
-    int a_off[2][C::KS][2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int dx = 0; dx < C::KS; ++dx)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int lx = l31 + dx;
-                a_off[mt][dx][ks] = ((wv * 2 + mt) * C::IW + lx) * C::ROWB + (((2 * ks + hi) ^ ((lx >> 2) & 3)) << 4);
+        for (int it = 0; it < C::NL; ++it) {
+            const int wi = it * C::LWAVES + lw;
+            const int j = wi * 64 + lane;
+            if (wi < C::IN_WI) {
+                const int q = j / C::SPP, sp = j % C::SPP;
+                const int lx = q % C::IW, ly = q / C::IW;
+                ia[it] = j < C::IN_SLOTS ? (ly << 16 | lx) : -1;
+                ib[it] = (sp ^ ((lx >> 2) & 3)) * 16;
+            } else if (wi < C::IN_WI + C::W_WI) {
+                const int jj = j - C::IN_WI * 64;
+                const int row = jj / C::SPP, sp = jj % C::SPP;
+                const int t = row >> 6, rr = row & 63;
+                const int nn = (rr & 31) * 2 + (rr >> 5);   // LDS row rr holds output channel nn: a lane's two 32-channel blocks
+                                                            // are the channel pair (2 l, 2 l + 1) -> 16-byte epilogue stores
+                ia[it] = t;
+                ib[it] = nn * p.kpad * 2 + (sp ^ ((rr >> 2) & 3)) * 16;
+            } else {
+                ia[it] = -1, ib[it] = 0;
             }
-    int b_off[2];
+        }
+        const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w_bf), 0, (int)p.w_bytes, 0x00020000);
+        // cursor: (unit, plane, source, channel) of the next group to stage
+        unsigned pu = u_begin;
+        int pplane = 0, ps = 0, pc0 = 0, pwrow = 0, pbuf = 0;
+        RingUnit PU = ring_unit(p, pu);
+        auto stage = [&]() {
+            const unsigned d_base = uni((unsigned)(pbuf * C::GROUP_BYTES)) + (unsigned)(lw * 1024);
+            pbuf = pbuf + 1 == C::R ? 0 : pbuf + 1;
+            if (pu >= u_end || ((p.ablate & 1) && pu != u_begin)) {
+                if ((p.ablate & 1) && pu < u_end) {   // keep the cursor moving
+                    pc0 += C::CKG;
+                    if (pc0 >= sel4(p.src_c, ps)) {
+                        pc0 = 0, ++ps;
+                        if (ps == p.nsrc) {
+                            ps = 0, ++pplane;
+                            if (pplane == C::NPLANES) pplane = 0, pu += u_step;
+                        }
+                    }
+                }
+                // past the last group: filler pieces keep every loader's DMA count per group constant (the counted waits)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) b_off[ks] = C::W_OFF + l31 * C::ROWB + (((2 * ks + hi) ^ ((l31 >> 2) & 3)) << 4);
-
-    f32x16 acc[2][2];
-
-    // ---- producer cursor: (unit, plane, source, channel) of the next group to stage.  Staging a group = prep() (the per-lane
-    // source offsets of its NLG pieces, a few dozen VALU / SALU instructions) + NLG x issue(k), which the matrix phase spreads
-    // between its MFMAs: a wave that issued all pieces in one block would leave the matrix pipe of its SIMD idle for the
-    // ~1000 issue cycles of that block, every group, because its partner wave does the same at the same time.
-    unsigned pu = u_begin;
-    int pplane = 0, ps = 0, pc0 = 0, pwrow = 0, pbuf = 0;
-    RingUnit PU = ring_unit(p, pu);
-    unsigned dv[C::NLG];                 // voffset of piece k
-    __amdgpu_buffer_rsrc_t d_rin = rsrc_w, d_rmix = rsrc_w;
-    unsigned d_sin = 0, d_sw = 0, d_smix = 0, d_base = 0;
-    auto prep = [&]() {
-        d_base = uni((unsigned)(pbuf * C::GROUP_BYTES));
-        pbuf = pbuf + 1 == C::R ? 0 : pbuf + 1;
-        if (pu >= u_end || ((p.ablate & 1) && pu != u_begin)) {
-            if ((p.ablate & 1) && pu < u_end) {   // keep the cursor moving
-                pc0 += C::CKG;
-                if (pc0 >= sel4(p.src_c, ps)) {
-                    pc0 = 0, ++ps;
-                    if (ps == p.nsrc) {
-                        ps = 0, ++pplane;
-                        if (pplane == C::NPLANES) pplane = 0, pu += u_step;
+                for (int it = 0; it < C::NL; ++it) ring_dma16(d_base + (unsigned)(it * C::LWAVES * 1024), kRingOob, rsrc_w, 0u);
+                return;
+            }
+            const int a = pplane >> 1, b = pplane & 1;
+            int oy, ox;   // view coordinates of the halo's first pixel
+            if constexpr (C::MODE == RM_K3S1) oy = PU.y0 * C::TH - 1, ox = PU.x0 * C::TW - 1;
+            else if constexpr (C::MODE == RM_CT4) oy = PU.y0 * C::TH - (1 - PU.py), ox = PU.x0 * C::TW - (1 - PU.px);
+            else if constexpr (C::MODE == RM_SP3) oy = PU.y0 * C::TH, ox = PU.x0 * C::TW;
+            else oy = PU.y0 * C::TH - a, ox = PU.x0 * C::TW - b;
+            const int ld = sel4(p.src_ld, ps);
+            const size_t img = (size_t)p.H * p.W * ld * 2;   // bytes of one sample
+            const char *base_in = uni(static_cast<const char *>(sel4(p.src_ptr, ps)) + (size_t)PU.n0 * img);
+            const __amdgpu_buffer_rsrc_t d_rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base_in), 0, (int)uni((unsigned)img), 0x00020000);
+            const unsigned ldb = (unsigned)ld * 2u;
+            const unsigned d_sin = uni((unsigned)(pc0 * 2));
+            const unsigned d_sw = uni((unsigned)(((size_t)PU.co0 * p.kpad + pwrow) * 2));
+            const unsigned wplane = (unsigned)(p.npad * p.kpad * 2);
+            // descriptor / scalar offset of the straddling wave-instruction (wave-uniform selects)
+            const bool mix_in = C::MIX_IT >= 0 && C::MIX_IT * C::LWAVES + lw < C::IN_WI;
+            const __amdgpu_buffer_rsrc_t d_rmix = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char *>(uni(mix_in ? base_in : static_cast<const char *>(p.w_bf))), 0, (int)uni(mix_in ? (unsigned)img : (unsigned)p.w_bytes),
+                0x00020000);
+            const unsigned d_smix = uni(mix_in ? d_sin : d_sw);
+#pragma unroll
+            for (int it = 0; it < C::NL; ++it) {
+                // kind of this wave-instruction: compile-time except for the one `it` that straddles the input / weight boundary
+                const bool in_ct = (it + 1) * C::LWAVES <= C::IN_WI, w_ct = it * C::LWAVES >= C::IN_WI;
+                unsigned v_in = kRingOob, v_w = kRingOob;
+                if (!w_ct) {
+                    const int ly = ia[it] >> 16, lx = ia[it] & 0xffff;
+                    int ry = oy + ly, rx = ox + lx;
+                    if constexpr (C::NPLANES == 4) ry = 2 * ry + a, rx = 2 * rx + b;
+                    const bool ok = ia[it] >= 0 && ry >= 0 && ry < p.H && rx >= 0 && rx < p.W;
+                    v_in = ok ? (unsigned)(ry * p.W + rx) * ldb + (unsigned)ib[it] : kRingOob;
+                }
+                if (!in_ct) {
+                    const int t = ia[it];
+                    int wt = t;   // plane of the packed weights this tap slot reads
+                    bool ok = t >= 0;
+                    const int ty = t >> 1, tx = t & 1;
+                    if constexpr (C::MODE == RM_CT4 || C::MODE == RM_SP3) wt = (PU.py * 2 + PU.px) * 4 + t;
+                    if constexpr (C::MODE == RM_SP3) ok = ok && ty <= PU.py && tx <= PU.px;
+                    if constexpr (C::MODE == RM_K3S2) wt = (a ? 2 * ty : 1) * 3 + (b ? 2 * tx : 1), ok = ok && ty <= a && tx <= b;
+                    if constexpr (C::MODE == RM_K4S2) wt = (2 * ty + 1 - a) * 4 + (2 * tx + 1 - b);
+                    v_w = ok ? (unsigned)wt * wplane + (unsigned)ib[it] : kRingOob;
+                }
+                const unsigned dst = d_base + (unsigned)(it * C::LWAVES * 1024);
+                if (in_ct) ring_dma16(dst, v_in, d_rin, d_sin);
+                else if (w_ct) ring_dma16(dst, v_w, rsrc_w, d_sw);
+                else ring_dma16(dst, mix_in ? v_in : v_w, d_rmix, d_smix);
+            }
+            // advance
+            pc0 += C::CKG, pwrow += C::CKG;
+            if (pc0 >= sel4(p.src_c, ps)) {
+                pc0 = 0, ++ps;
+                if (ps == p.nsrc) {
+                    ps = 0, pwrow = 0, ++pplane;
+                    if (pplane == C::NPLANES) {
+                        pplane = 0, pu += u_step;
+                        if (pu < u_end) PU = ring_unit(p, pu);
                     }
                 }
             }
-            // past the last group: filler pieces keep every wave's DMA count per group constant (the counted waits)
+        };
 #pragma unroll
-            for (int k = 0; k < C::NLG; ++k) dv[k] = kRingOob;
-            d_rin = rsrc_w, d_rmix = rsrc_w, d_sin = 0, d_sw = 0, d_smix = 0;
-            return;
-        }
-        const int a = pplane >> 1, b = pplane & 1;
-        int oy, ox;   // view coordinates of the halo's first pixel
-        if constexpr (C::MODE == RM_K3S1) oy = PU.y0 * C::TH - 1, ox = PU.x0 * C::TW - 1;
-        else if constexpr (C::MODE == RM_CT4) oy = PU.y0 * C::TH - (1 - PU.py), ox = PU.x0 * C::TW - (1 - PU.px);
-        else if constexpr (C::MODE == RM_SP3) oy = PU.y0 * C::TH, ox = PU.x0 * C::TW;
-        else oy = PU.y0 * C::TH - a, ox = PU.x0 * C::TW - b;
-        const int ld = sel4(p.src_ld, ps);
-        const size_t img = (size_t)p.H * p.W * ld * 2;   // bytes of one sample
-        const char *base_in = uni(static_cast<const char *>(sel4(p.src_ptr, ps)) + (size_t)PU.n0 * img);
-        d_rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base_in), 0, (int)uni((unsigned)img), 0x00020000);
-        const unsigned ldb = (unsigned)ld * 2u;
-        d_sin = uni((unsigned)(pc0 * 2));
-        d_sw = uni((unsigned)(((size_t)PU.co0 * p.kpad + pwrow) * 2));
-        const unsigned wplane = (unsigned)(p.npad * p.kpad * 2);
-#pragma unroll
-        for (int it = 0; it < C::NL; ++it) {
-            // kind of this wave-instruction: compile-time except for the one `it` whose 8 wave-instructions straddle the
-            // input / weight boundary -- both candidates are computed there and selected without a branch (a branch inside
-            // the matrix phase would cut the basic block hipcc schedules the ds_reads and MFMAs in)
-            const bool in_ct = (it + 1) * C::WAVES <= C::IN_WI, w_ct = it * C::WAVES >= C::IN_WI;
-            const bool is_in = in_ct || (!w_ct && it * C::WAVES + wv < C::IN_WI);
-            unsigned v_in = kRingOob, v_w = kRingOob;
-            if (!w_ct) {
-                const int ly = ia[it] >> 16, lx = ia[it] & 0xffff;
-                int ry = oy + ly, rx = ox + lx;
-                if constexpr (C::NPLANES == 4) ry = 2 * ry + a, rx = 2 * rx + b;
-                const bool ok = ia[it] >= 0 && ry >= 0 && ry < p.H && rx >= 0 && rx < p.W;
-                v_in = ok ? (unsigned)(ry * p.W + rx) * ldb + (unsigned)ib[it] : kRingOob;
-            }
-            if (!in_ct) {
-                const int t = ia[it];
-                int wt = t;   // plane of the packed weights this tap slot reads
-                bool ok = t >= 0;
-                const int ty = t >> 1, tx = t & 1;
-                if constexpr (C::MODE == RM_CT4 || C::MODE == RM_SP3) wt = (PU.py * 2 + PU.px) * 4 + t;
-                if constexpr (C::MODE == RM_SP3) ok = ok && ty <= PU.py && tx <= PU.px;
-                if constexpr (C::MODE == RM_K3S2) wt = (a ? 2 * ty : 1) * 3 + (b ? 2 * tx : 1), ok = ok && ty <= a && tx <= b;
-                if constexpr (C::MODE == RM_K4S2) wt = (2 * ty + 1 - a) * 4 + (2 * tx + 1 - b);
-                v_w = ok ? (unsigned)wt * wplane + (unsigned)ib[it] : kRingOob;
-            }
-            const unsigned voff = in_ct ? v_in : (w_ct ? v_w : (is_in ? v_in : v_w));
-            dv[it] = voff;
-        }
-        // descriptor / scalar offset of the straddling wave-instruction (wave-uniform selects)
-        {
-            const bool mix_in = C::MIX_IT >= 0 && C::MIX_IT * C::WAVES + wv < C::IN_WI;
-            d_rmix = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(uni(mix_in ? base_in : static_cast<const char *>(p.w_bf))), 0,
-                                                       (int)uni(mix_in ? (unsigned)img : (unsigned)p.w_bytes), 0x00020000);
-            d_smix = uni(mix_in ? d_sin : d_sw);
-        }
-        // advance
-        pc0 += C::CKG, pwrow += C::CKG;
-        if (pc0 >= sel4(p.src_c, ps)) {
-            pc0 = 0, ++ps;
-            if (ps == p.nsrc) {
-                ps = 0, pwrow = 0, ++pplane;
-                if (pplane == C::NPLANES) {
-                    pplane = 0, pu += u_step;
-                    if (pu < u_end) PU = ring_unit(p, pu);
-                }
+        for (int i = 0; i < C::R - 1; ++i) stage();
+        int cg = 0;
+        for (unsigned s = 0; s < total; ++s) {
+            ring_wait_vmcnt<(C::R - 2) * C::NL>();   // this wave's pieces of group s have landed (R > 2: younger groups may still fly)
+            __builtin_amdgcn_s_barrier();            // B_s
+            stage();                                 // group s + R - 1 into the buffer group s - 1 occupied
+            if (++cg == ngroups) {
+                cg = 0;
+                __builtin_amdgcn_s_barrier();        // E
             }
         }
-    };
-    auto issue = [&](int it) {   // `it` compile-time after unrolling: no branch in here
-        const unsigned dst = d_base + (unsigned)(it * C::WAVES * 1024) + (unsigned)(wv * 1024);
-        if ((it + 1) * C::WAVES <= C::IN_WI)
-            ring_dma16(dst, dv[it], d_rin, d_sin);
-        else if (it * C::WAVES >= C::IN_WI)
-            ring_dma16(dst, dv[it], rsrc_w, d_sw);
-        else
-            ring_dma16(dst, dv[it], d_rmix, d_smix);
-    };
+        ring_wait_vmcnt<0>();   // the filler pieces still target this workgroup's LDS
+        return;
+    }
 
-    // ---- epilogue state, filled one matrix phase ahead (see the loop)
+    // =============================================================================================== matrix waves
+    // operand read offsets inside a group image (bytes): lane (l31, hi) reads k-slot 2 ks + hi of its row
+    // (the second 16-channel half, ks = 1, is the same address with bit 5 flipped: the slot index is (2 ks + hi) ^ f)
+    int a_off[2][C::KS];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int dx = 0; dx < C::KS; ++dx) {
+            const int lx = l31 + dx;
+            a_off[mt][dx] = ((wv * 2 + mt) * C::IW + lx) * C::ROWB + ((hi ^ ((lx >> 2) & 3)) << 4);
+        }
+    const int b_off = C::W_OFF + l31 * C::ROWB + ((hi ^ ((l31 >> 2) & 3)) << 4);
+
+    f32x16 acc[2][2];
+
+    // epilogue state, requested one matrix phase ahead (see the loop)
+    constexpr int PF = DG ? 1 : 0;   // store slots whose old value / forward value are requested a phase ahead; the others follow two
+                                     // slots ahead of their use inside the epilogue (8 slots x 8 registers do not fit beside the accumulators)
     const int g8 = lane & 7;
     float bsv[8];
-    bool e_ok[8];
-    size_t e_off[8];
+    bool e_ok1 = false;           // this lane's channel group has a destination (tiles are whole: conv_ring_try)
+    unsigned e_pix0 = 0, e_dy = 0;   // output pixel of store slot 0; pixel step of one tile row
     u32x4 e_old[DG ? 8 : 1], e_y[DG ? 8 : 1];
     unsigned char *e_dbase = nullptr;
-    bool e_hasy = false;
+    const unsigned char *e_ybase = nullptr;
+    size_t e_dld2 = 0, e_yld2 = 0;   // pixel strides in bytes
+    bool e_hasy = false, e_dacc = false;
     float e_slope = 1.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) bsv[k] = 0.f, e_ok[k] = false, e_off[k] = 0;
+    for (int k = 0; k < 8; ++k) bsv[k] = 0.f;
 
-    // ---- consumer cursor
+    constexpr int SO = C::NCLS == 4 ? 2 : 1;   // output stride of the parity classes
+    auto e_pix = [&](int slot) {   // slot = (mt * 2 + h2) * 2 + itr, compile-time after unrolling
+        return e_pix0 + (unsigned)(slot >> 2) * e_dy + (unsigned)((((slot >> 1) & 1) * 16 + (slot & 1) * 8) * SO);
+    };
+
     unsigned cu = u_begin;
     int cg = 0, cplane = 0, cgp = 0, cbuf = 0;
     RingUnit CU = ring_unit(p, cu);
-    const unsigned total = my_units * (unsigned)ngroups;
-    bool after_epilogue = false;
-
-#pragma unroll
-    for (int i = 0; i < C::R - 1; ++i) {
-        prep();
-#pragma unroll
-        for (int k = 0; k < C::NLG; ++k) issue(k);
-    }
 
     for (unsigned s = 0; s < total; ++s) {
-        // this wave's pieces of group s have landed; what may still fly: the younger groups (R > 2) and, right after an epilogue,
-        // its NSTORE stores, which were issued behind every piece of group s (vector memory operations retire in order: the
-        // count names exactly the operations allowed to be outstanding; waiting for the stores as well would expose the HBM
-        // write latency of 64 KB per unit)
-        if (after_epilogue) ring_wait_vmcnt<(C::R - 2) * C::NLG + C::NSTORE>();
-        else ring_wait_vmcnt<(C::R - 2) * C::NLG>();
-        after_epilogue = false;
-        __builtin_amdgcn_s_barrier();             // ... and everybody else's; every wave is done reading group s - 1
         asm volatile("" ::: "memory");
-        prep();                                   // group s + R - 1 goes into the buffer group s - 1 occupied: its pieces are
-                                                  // issued between the MFMAs below
+        __builtin_amdgcn_s_barrier();   // B_s
+        asm volatile("" ::: "memory");
 
         const bool last_group = cg == ngroups - 1;
         if (last_group) {
             // ---- what the epilogue needs from memory (bias; or the old gradient values and the forward tensor for act'), requested
-            // ONE matrix phase ahead of its use: hipcc waits vmcnt(0) before the first use, which also covers the DMAs above --
-            // by then a whole matrix phase old.
+            // ONE matrix phase ahead of its use
             const int co = CU.co0 + g8 * 8;
             const bool co_ok = co < p.cout;
             __bf16 *dbase = reinterpret_cast<__bf16 *>(p.out) + co;
             size_t dld = p.out_ld;
-            bool dacc = false, dok = co_ok;
-            const __bf16 *ybase = nullptr;
-            size_t yld = 0;
-            e_slope = 1.f;
+            bool dok = co_ok;
+            e_ybase = nullptr, e_yld2 = 0, e_dacc = false, e_slope = 1.f;
             if constexpr (DG) {
                 dok = false;
 #pragma unroll
                 for (int s_ = 0; s_ < 4; ++s_) {
                     if (s_ < p.ndst && co >= p.dst_c0[s_] && co < p.dst_c1[s_]) {
                         dbase = reinterpret_cast<__bf16 *>(p.dst_ptr[s_]) + (co - p.dst_c0[s_]);
-                        dld = p.dst_ld[s_], dacc = p.dst_acc[s_] != 0, dok = true;
+                        dld = p.dst_ld[s_], e_dacc = p.dst_acc[s_] != 0, dok = true;
                         if (p.dst_act[s_] != PWS_ACT_NONE) {
-                            ybase = static_cast<const __bf16 *>(p.dst_y[s_]) + (co - p.dst_c0[s_]);
-                            yld = p.dst_y_ld[s_], e_slope = p.dst_act[s_] == PWS_ACT_LRELU ? 0.2f : 0.f;
+                            e_ybase = reinterpret_cast<const unsigned char *>(static_cast<const __bf16 *>(p.dst_y[s_]) + (co - p.dst_c0[s_]));
+                            e_yld2 = (size_t)p.dst_y_ld[s_] * 2, e_slope = p.dst_act[s_] == PWS_ACT_LRELU ? 0.2f : 0.f;
                         }
                     }
                 }
@@ -386,22 +378,23 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_ring_kernel(const RingPara
                 for (int k = 0; k < 8; ++k) bsv[k] = (p.bias && co_ok) ? p.bias[co + k] : 0.f;
             }
             e_dbase = reinterpret_cast<unsigned char *>(dbase);
-            e_hasy = ybase != nullptr;
-            constexpr int SO = C::NCLS == 4 ? 2 : 1;   // output stride of the parity classes
-#pragma unroll
-            for (int slot = 0; slot < 8; ++slot) {
-                const int mt = slot >> 2, h2 = (slot >> 1) & 1, itr = slot & 1;
-                // pass rows: (rr & 3) + 4 hi + 8 (rr >> 2) + 16 h2 of the wave's 32-pixel tile row (= x inside the tile)
-                const int xt = h2 * 16 + itr * 8 + (lane >> 3);
-                const int y = CU.y0 * C::TH + wv * 2 + mt, x = CU.x0 * C::TW + xt;
+            e_dld2 = dld * 2;
+            e_hasy = e_ybase != nullptr;
+            {
+                // store slot (mt, h2, itr): pixel (y0 + 2 wv + mt, x0 + 16 h2 + 8 itr + lane / 8) of the class grid
+                const int y = CU.y0 * C::TH + wv * 2, x = CU.x0 * C::TW + (lane >> 3);
                 const int oy = SO * y + (C::NCLS == 4 ? CU.py : 0), ox = SO * x + (C::NCLS == 4 ? CU.px : 0);
-                e_ok[slot] = dok && y < p.LH && x < p.LW && oy < p.OH && ox < p.OW;
-                const size_t pix = (size_t)(CU.n0 * p.OH + oy) * p.OW + ox;
-                e_off[slot] = pix * dld * 2;
-                if constexpr (DG) {
+                e_pix0 = (unsigned)((CU.n0 * p.OH + oy) * p.OW + ox);
+                e_dy = (unsigned)(SO * p.OW);
+                e_ok1 = dok;
+            }
+            if constexpr (DG) {
+#pragma unroll
+                for (int slot = 0; slot < PF; ++slot) {
+                    const unsigned pix = e_pix(slot);
                     e_old[slot] = (u32x4){0u, 0u, 0u, 0u}, e_y[slot] = (u32x4){0u, 0u, 0u, 0u};
-                    if (e_ok[slot] && dacc) e_old[slot] = *reinterpret_cast<const u32x4 *>(e_dbase + e_off[slot]);
-                    if (e_ok[slot] && e_hasy) e_y[slot] = *reinterpret_cast<const u32x4 *>(ybase + pix * yld);
+                    if (e_ok1 && e_dacc) e_old[slot] = *reinterpret_cast<const u32x4 *>(e_dbase + pix * e_dld2);
+                    if (e_ok1 && e_hasy) e_y[slot] = *reinterpret_cast<const u32x4 *>(e_ybase + pix * e_yld2);
                 }
             }
         }
@@ -418,62 +411,22 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_ring_kernel(const RingPara
         if constexpr (C::MODE == RM_SP3) tapmask = CU.py ? (CU.px ? 0xfu : 0x5u) : (CU.px ? 0x3u : 0x1u);
         if constexpr (C::MODE == RM_K3S2) tapmask = (cplane >> 1) ? ((cplane & 1) ? 0xfu : 0x5u) : ((cplane & 1) ? 0x3u : 0x1u);
         const unsigned gb = (unsigned)(cbuf * C::GROUP_BYTES);
-        // one straight-line basic block per tap mask: the taps a class / plane does not have are compiled out, the next group's
-        // DMA pieces are dealt evenly to the remaining steps
-        auto phase = [&](auto mask_c) {
-            constexpr unsigned MASK = decltype(mask_c)::value;
-            constexpr int NV = __builtin_popcount(MASK), NT = NV * 2;   // steps of this phase: (tap, 16-channel half)
-            constexpr int NI = NT > 2 ? NT / 2 : 1;                     // the pieces go out during the first NI steps: a piece
-                                                                        // issued at the end of the phase would be waited for at once
-#pragma unroll
-            for (int ty = 0; ty < C::KS; ++ty)
-#pragma unroll
-                for (int tx = 0; tx < C::KS; ++tx) {
-                    const int tap = ty * C::KS + tx;
-                    if (!((MASK >> tap) & 1u)) continue;
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        bf16x8 av[2], bv[2];
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt)
-                            av[mt] = *reinterpret_cast<const bf16x8 *>(lds + gb + (unsigned)(a_off[mt][tx][ks] + ty * C::IW * C::ROWB));
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
-                            bv[nt] = *reinterpret_cast<const bf16x8 *>(lds + gb + (unsigned)(b_off[ks] + (tap * 64 + nt * 32) * C::ROWB));
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                            for (int nt = 0; nt < 2; ++nt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
-                        const int step = __builtin_popcount(MASK & ((1u << tap) - 1u)) * 2 + ks;   // folds after unrolling
-#pragma unroll
-                        for (int k = 0; k < C::NLG; ++k)   // (constant trip count: the condition folds with the unrolled tap loops)
-                            if (k * NI / C::NLG == step) issue(k);
-                    }
-                }
-        };
-        if (p.ablate & 2) {
-            // (measurement) matrix phase skipped: the pieces are still issued
-#pragma unroll
-            for (int k = 0; k < C::NLG; ++k) issue(k);
-        } else if constexpr (C::MODE == RM_SP3 || C::MODE == RM_K3S2) {
-            // 1, 2 or 4 taps, known per class / plane only at run time: a wave-uniform branch per tap (one straight-line copy of the
-            // phase per mask costs ~90 more live registers: spills); the pieces go out first
-#pragma unroll
-            for (int k = 0; k < C::NLG; ++k) issue(k);
+        if (!(p.ablate & 2)) {
 #pragma unroll
             for (int tap = 0; tap < C::TAPS; ++tap) {
-                if (!((tapmask >> tap) & 1u)) continue;
+                if constexpr (C::MODE == RM_SP3 || C::MODE == RM_K3S2) {
+                    if (!((tapmask >> tap) & 1u)) continue;   // wave-uniform: 1, 2 or 4 taps per class / plane
+                }
                 const int ty = tap / C::KS, tx = tap % C::KS;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     bf16x8 av[2], bv[2];
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
-                        av[mt] = *reinterpret_cast<const bf16x8 *>(lds + gb + (unsigned)(a_off[mt][tx][ks] + ty * C::IW * C::ROWB));
+                        av[mt] = *reinterpret_cast<const bf16x8 *>(lds + gb + (unsigned)((a_off[mt][tx] ^ (ks * 32)) + ty * C::IW * C::ROWB));
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
-                        bv[nt] = *reinterpret_cast<const bf16x8 *>(lds + gb + (unsigned)(b_off[ks] + (tap * 64 + nt * 32) * C::ROWB));
+                        bv[nt] = *reinterpret_cast<const bf16x8 *>(lds + gb + (unsigned)((b_off ^ (ks * 32)) + (tap * 64 + nt * 32) * C::ROWB));
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -481,80 +434,84 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_ring_kernel(const RingPara
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
                 }
             }
-        } else {
-            phase(std::integral_constant<unsigned, (1u << C::TAPS) - 1u>{});
         }
 
-        if (last_group && (p.ablate & 4)) {
-            cg = 0, cplane = 0, cgp = 0, cu += u_step;
-            if (cu < u_end) CU = ring_unit(p, cu);
-        } else if (last_group) {
+        if (last_group) {
             // ---- epilogue of unit cu.  Every wave turns its 2 x (32 pixels x 64 channels) round through LDS in 16-pixel passes
-            // (fp32, 4 KB per wave, inside the group buffer just consumed: the barrier below retires everybody's operand reads;
-            // the next DMA into this buffer is issued behind the next iteration's barrier), so that bias / activation /
-            // accumulation work on 8 consecutive channels and leave as 16-byte stores (layout as PWS_BF_EPI16, conv_bf16.hip).
+            // (fp32, 4 KB per wave, inside the group buffer just consumed: barrier E retires everybody's operand reads; the loaders
+            // refill this buffer only behind the next B), so that bias / activation / accumulation work on 8 consecutive channels
+            // and leave as 16-byte stores (layout as PWS_BF_EPI16, conv_bf16.hip).
             asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();   // E
             asm volatile("" ::: "memory");
-            unsigned char *et = lds + gb + wv * 4096;
-            const int wslot = ((l31 >> 1) & 1) * 8 + (l31 >> 2);
+            if (!(p.ablate & 4)) {
+                unsigned char *et = lds + gb + wv * 4096;
+                const int wslot = ((l31 >> 1) & 1) * 8 + (l31 >> 2);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+                for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
+                    for (int h2 = 0; h2 < 2; ++h2) {
 #pragma unroll
-                    for (int rr = 0; rr < 8; ++rr) {
-                        const int r = h2 * 8 + rr;
-                        const int row = (rr & 3) + 8 * (rr >> 2) + 4 * hi;   // 0..15 inside the pass
-                        *reinterpret_cast<float2 *>(et + row * 256 + ((wslot ^ ((rr & 1) * 8)) * 16) + (l31 & 1) * 8) =
-                            make_float2(acc[mt][0][r], acc[mt][1][r]);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
+                        for (int rr = 0; rr < 8; ++rr) {
+                            const int r = h2 * 8 + rr;
+                            const int row = (rr & 3) + 8 * (rr >> 2) + 4 * hi;   // 0..15 inside the pass
+                            *reinterpret_cast<float2 *>(et + row * 256 + ((wslot ^ ((rr & 1) * 8)) * 16) + (l31 & 1) * 8) =
+                                make_float2(acc[mt][0][r], acc[mt][1][r]);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int itr = 0; itr < 2; ++itr) {
-                        const int slot = (mt * 2 + h2) * 2 + itr;
-                        const int row = itr * 8 + (lane >> 3);
-                        const int sw = (row & 1) * 8;
-                        const float4 lo = *reinterpret_cast<const float4 *>(et + row * 256 + ((g8 ^ sw) * 16));
-                        const float4 hi4 = *reinterpret_cast<const float4 *>(et + row * 256 + (((8 + g8) ^ sw) * 16));
-                        if (e_ok[slot]) {
-                            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
-                            if constexpr (!DG) {
-#pragma unroll
-                                for (int k = 0; k < 8; ++k) v[k] = act_apply(v[k] + bsv[k], p.act);
-                            } else {
-                                const u32x4 o = e_old[slot];   // zeros when this destination is overwritten
-                                v[0] += bf16_lo(o.x), v[1] += bf16_hi(o.x), v[2] += bf16_lo(o.y), v[3] += bf16_hi(o.y);
-                                v[4] += bf16_lo(o.z), v[5] += bf16_hi(o.z), v[6] += bf16_lo(o.w), v[7] += bf16_hi(o.w);
-                                if (e_hasy) {   // act'(y) of the tensor this destination is the gradient of
-                                    const u32x4 yv = e_y[slot];
-                                    v[0] *= bf16_lo(yv.x) > 0.f ? 1.f : e_slope, v[1] *= bf16_hi(yv.x) > 0.f ? 1.f : e_slope;
-                                    v[2] *= bf16_lo(yv.y) > 0.f ? 1.f : e_slope, v[3] *= bf16_hi(yv.y) > 0.f ? 1.f : e_slope;
-                                    v[4] *= bf16_lo(yv.z) > 0.f ? 1.f : e_slope, v[5] *= bf16_hi(yv.z) > 0.f ? 1.f : e_slope;
-                                    v[6] *= bf16_lo(yv.w) > 0.f ? 1.f : e_slope, v[7] *= bf16_hi(yv.w) > 0.f ? 1.f : e_slope;
+                        for (int itr = 0; itr < 2; ++itr) {
+                            const int slot = (mt * 2 + h2) * 2 + itr;
+                            if constexpr (DG) {   // rolling request, two slots ahead
+                                const int nx2 = slot + PF;
+                                if (nx2 < 8) {
+                                    const unsigned pix2 = e_pix(nx2);
+                                    e_old[nx2] = (u32x4){0u, 0u, 0u, 0u}, e_y[nx2] = (u32x4){0u, 0u, 0u, 0u};
+                                    if (e_ok1 && e_dacc) e_old[nx2] = *reinterpret_cast<const u32x4 *>(e_dbase + pix2 * e_dld2);
+                                    if (e_ok1 && e_hasy) e_y[nx2] = *reinterpret_cast<const u32x4 *>(e_ybase + pix2 * e_yld2);
                                 }
                             }
-                            u32x4 wq;
-                            wq.x = cvt_pk_bf16(v[0], v[1]), wq.y = cvt_pk_bf16(v[2], v[3]);
-                            wq.z = cvt_pk_bf16(v[4], v[5]), wq.w = cvt_pk_bf16(v[6], v[7]);
-                            *reinterpret_cast<u32x4 *>(e_dbase + e_off[slot]) = wq;
+                            const int row = itr * 8 + (lane >> 3);
+                            const int sw = (row & 1) * 8;
+                            const float4 lo = *reinterpret_cast<const float4 *>(et + row * 256 + ((g8 ^ sw) * 16));
+                            const float4 hi4 = *reinterpret_cast<const float4 *>(et + row * 256 + (((8 + g8) ^ sw) * 16));
+                            if (e_ok1) {
+                                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+                                if constexpr (!DG) {
+#pragma unroll
+                                    for (int k = 0; k < 8; ++k) v[k] = act_apply(v[k] + bsv[k], p.act);
+                                } else {
+                                    const u32x4 o = e_old[slot];   // zeros when this destination is overwritten
+                                    v[0] += bf16_lo(o.x), v[1] += bf16_hi(o.x), v[2] += bf16_lo(o.y), v[3] += bf16_hi(o.y);
+                                    v[4] += bf16_lo(o.z), v[5] += bf16_hi(o.z), v[6] += bf16_lo(o.w), v[7] += bf16_hi(o.w);
+                                    if (e_hasy) {   // act'(y) of the tensor this destination is the gradient of
+                                        const u32x4 yv = e_y[slot];
+                                        v[0] *= bf16_lo(yv.x) > 0.f ? 1.f : e_slope, v[1] *= bf16_hi(yv.x) > 0.f ? 1.f : e_slope;
+                                        v[2] *= bf16_lo(yv.y) > 0.f ? 1.f : e_slope, v[3] *= bf16_hi(yv.y) > 0.f ? 1.f : e_slope;
+                                        v[4] *= bf16_lo(yv.z) > 0.f ? 1.f : e_slope, v[5] *= bf16_hi(yv.z) > 0.f ? 1.f : e_slope;
+                                        v[6] *= bf16_lo(yv.w) > 0.f ? 1.f : e_slope, v[7] *= bf16_hi(yv.w) > 0.f ? 1.f : e_slope;
+                                    }
+                                }
+                                u32x4 wq;
+                                wq.x = cvt_pk_bf16(v[0], v[1]), wq.y = cvt_pk_bf16(v[2], v[3]);
+                                wq.z = cvt_pk_bf16(v[4], v[5]), wq.w = cvt_pk_bf16(v[6], v[7]);
+                                *reinterpret_cast<u32x4 *>(e_dbase + e_pix(slot) * e_dld2) = wq;
+                            }
                         }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
                 }
             }
             cg = 0, cplane = 0, cgp = 0, cu += u_step;
             if (cu < u_end) CU = ring_unit(p, cu);
-            after_epilogue = true;
         } else {
             ++cg;
             if (++cgp == p.gpp) cgp = 0, ++cplane;
         }
         cbuf = cbuf + 1 == C::R ? 0 : cbuf + 1;
     }
-    ring_wait_vmcnt<0>();   // the filler pieces still target this workgroup's LDS
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -589,10 +546,10 @@ static int ring_launch(RingParams &rp, hipStream_t st) {
 
 //                         mode   TH  TW  R
 using RG_K3S1 = RgCfg<RM_K3S1, 16, 32, 2>;
-using RG_CT4 = RgCfg<RM_CT4, 16, 32, 2>;
-using RG_SP3 = RgCfg<RM_SP3, 16, 32, 2>;
-using RG_K3S2 = RgCfg<RM_K3S2, 16, 32, 2>;
-using RG_K4S2 = RgCfg<RM_K4S2, 16, 32, 2>;
+using RG_CT4 = RgCfg<RM_CT4, 16, 32, 3>;
+using RG_SP3 = RgCfg<RM_SP3, 16, 32, 3>;
+using RG_K3S2 = RgCfg<RM_K3S2, 16, 32, 3>;
+using RG_K4S2 = RgCfg<RM_K4S2, 16, 32, 3>;
 
 // Runs the launch described by kp (prepared by conv2d_fwd_impl / conv2d_bwd_data_impl, conv_mfma.hip) on the ring kernel when it
 // is covered: bf16 storage with 16-byte epilogue stores, every source a multiple of 32 channels, a logical map of at least
