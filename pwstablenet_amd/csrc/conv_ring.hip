@@ -62,16 +62,16 @@ struct RingParams {
     int dst_c0[4], dst_c1[4], dst_ld[4], dst_acc[4];
     const void *dst_y[4];
     int dst_y_ld[4], dst_act[4];
-    int tiles_x, tiles_y;
+    int tiles_x, tiles_y, tn;   // tn: samples per tile
     unsigned ncob, ncls, nunits;
     int gpp;              // K groups per plane = sum(src_c) / 32
     int ablate;           // measurement only (PWS_OPT_EXPERIMENT 41..43): 1 = the DMA pieces fetch nothing after the first groups,
                           // 2 = no matrix phase, 4 = no epilogue -- results are meaningless, only the timing is read
 };
 
-template <int MODE_, int TH_, int TW_, int R_>
+template <int MODE_, int TH_, int TW_, int TN_, int R_>
 struct RgCfg {
-    static constexpr int MODE = MODE_, TH = TH_, TW = TW_, R = R_;
+    static constexpr int MODE = MODE_, TH = TH_, TW = TW_, TN = TN_, R = R_;
     static constexpr int KS = MODE == RM_K3S1 ? 3 : 2;
     static constexpr int TAPS = KS * KS;
     static constexpr int NPLANES = MODE >= RM_K3S2 ? 4 : 1;   // input parity planes
@@ -81,12 +81,13 @@ struct RgCfg {
     // group -- issued by the matrix waves themselves that time ADDS to the matrix phase (measured: DMA-only, MFMA-only and
     // epilogue-only timings of the one-role kernel summed to its run time), issued by waves of their own it hides under it
     static constexpr int MWAVES = 8, LWAVES = 4, THREADS = 64 * (MWAVES + LWAVES);
-    static_assert(TW == 32 && TH == 16, "a wave's operand is one 32-pixel tile row; 8 waves x 2 rows");
+    // 512 pixels per tile = TN samples x TH x TW; a matrix wave's operand is 32 consecutive tile pixels = 32 / TW tile rows
+    static_assert(TH * TW * TN == 512 && (TW == 32 || TW == 16 || TW == 8) && (TH & (TH - 1)) == 0, "tile");
     static constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
     static constexpr int CKG = 32;                                // input channels per K group
     static constexpr int ROWB = CKG * 2;                          // bytes per LDS row (pixel / weight row): one 64-byte L2 request
     static constexpr int SPP = ROWB / 16;                         // 16-byte slots per row
-    static constexpr int IN_SLOTS = IH * IW * SPP;                // 16-byte slots of the input image of one group
+    static constexpr int IN_SLOTS = TN * IH * IW * SPP;           // 16-byte slots of the input image of one group
     static constexpr int IN_WI = (IN_SLOTS + 63) / 64;            // wave-instructions (64 slots each)
     static constexpr int W_WI = TAPS * 64 * SPP / 64;             // TAPS x 64 rows x SPP slots
     static constexpr int NL = (IN_WI + W_WI + LWAVES - 1) / LWAVES; // DMA instructions per loader wave and group
@@ -142,7 +143,7 @@ __device__ __forceinline__ RingUnit ring_unit(const RingParams &p, unsigned u) {
     const unsigned cob = rest % p.ncob, tile = rest / p.ncob;
     const unsigned tx = tile % (unsigned)p.tiles_x, t2 = tile / (unsigned)p.tiles_x;
     const unsigned ty = t2 % (unsigned)p.tiles_y;
-    r.n0 = (int)(t2 / (unsigned)p.tiles_y);
+    r.n0 = (int)(t2 / (unsigned)p.tiles_y) * p.tn;
     r.y0 = (int)ty, r.x0 = (int)tx, r.co0 = (int)cob * 64, r.py = (int)(cls >> 1), r.px = (int)(cls & 1);
     return r;
 }
@@ -182,15 +183,15 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
         // wave-uniformly an input piece, a weight piece or filler.  A row (pixel / weight row) is 64 bytes = 32 channels = ONE
         // 64-byte L2 request, 4 lanes; its four 16-byte slots are permuted by XOR with bits 2..3 of the pixel's x (of the row
         // index): applied to the SOURCE offset here and to the ds_read_b128 address in the matrix phase.
-        int ia[C::NL], ib[C::NL];   // input: (ly << 16 | lx), c16  /  weights: tap slot, nn * kpad * 2 + c16  /  filler: -1
+        int ia[C::NL], ib[C::NL];   // input: (tn << 20 | ly << 10 | lx), c16  /  weights: tap slot, nn * kpad * 2 + c16  /  filler: -1
 #pragma unroll
         for (int it = 0; it < C::NL; ++it) {
             const int wi = it * C::LWAVES + lw;
             const int j = wi * 64 + lane;
             if (wi < C::IN_WI) {
                 const int q = j / C::SPP, sp = j % C::SPP;
-                const int lx = q % C::IW, ly = q / C::IW;
-                ia[it] = j < C::IN_SLOTS ? (ly << 16 | lx) : -1;
+                const int lx = q % C::IW, ly = (q / C::IW) % C::IH, tn = q / (C::IW * C::IH);
+                ia[it] = j < C::IN_SLOTS ? (tn << 20 | ly << 10 | lx) : -1;
                 ib[it] = (sp ^ ((lx >> 2) & 3)) * 16;
             } else if (wi < C::IN_WI + C::W_WI) {
                 const int jj = j - C::IN_WI * 64;
@@ -235,8 +236,9 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
             else if constexpr (C::MODE == RM_SP3) oy = PU.y0 * C::TH, ox = PU.x0 * C::TW;
             else oy = PU.y0 * C::TH - a, ox = PU.x0 * C::TW - b;
             const int ld = sel4(p.src_ld, ps);
-            const size_t img = (size_t)p.H * p.W * ld * 2;   // bytes of one sample
-            const char *base_in = uni(static_cast<const char *>(sel4(p.src_ptr, ps)) + (size_t)PU.n0 * img);
+            const size_t img1 = (size_t)p.H * p.W * ld * 2;   // bytes of one sample
+            const size_t img = img1 * C::TN;                   // ... of the samples of a tile (N % TN == 0: conv_ring_try)
+            const char *base_in = uni(static_cast<const char *>(sel4(p.src_ptr, ps)) + (size_t)PU.n0 * img1);
             const __amdgpu_buffer_rsrc_t d_rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base_in), 0, (int)uni((unsigned)img), 0x00020000);
             const unsigned ldb = (unsigned)ld * 2u;
             const unsigned d_sin = uni((unsigned)(pc0 * 2));
@@ -254,11 +256,11 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
                 const bool in_ct = (it + 1) * C::LWAVES <= C::IN_WI, w_ct = it * C::LWAVES >= C::IN_WI;
                 unsigned v_in = kRingOob, v_w = kRingOob;
                 if (!w_ct) {
-                    const int ly = ia[it] >> 16, lx = ia[it] & 0xffff;
+                    const int tn = ia[it] >> 20, ly = (ia[it] >> 10) & 0x3ff, lx = ia[it] & 0x3ff;
                     int ry = oy + ly, rx = ox + lx;
                     if constexpr (C::NPLANES == 4) ry = 2 * ry + a, rx = 2 * rx + b;
                     const bool ok = ia[it] >= 0 && ry >= 0 && ry < p.H && rx >= 0 && rx < p.W;
-                    v_in = ok ? (unsigned)(ry * p.W + rx) * ldb + (unsigned)ib[it] : kRingOob;
+                    v_in = ok ? (unsigned)((tn * p.H + ry) * p.W + rx) * ldb + (unsigned)ib[it] : kRingOob;
                 }
                 if (!in_ct) {
                     const int t = ia[it];
@@ -313,8 +315,10 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int dx = 0; dx < C::KS; ++dx) {
-            const int lx = l31 + dx;
-            a_off[mt][dx] = ((wv * 2 + mt) * C::IW + lx) * C::ROWB + ((hi ^ ((lx >> 2) & 3)) << 4);
+            const int m = (wv * 2 + mt) * 32 + l31;   // tile pixel of this lane's operand row
+            const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
+            const int lx = tx + dx;
+            a_off[mt][dx] = ((tn * C::IH + ty) * C::IW + lx) * C::ROWB + ((hi ^ ((lx >> 2) & 3)) << 4);
         }
     const int b_off = C::W_OFF + l31 * C::ROWB + ((hi ^ ((l31 >> 2) & 3)) << 4);
 
@@ -326,7 +330,6 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
     const int g8 = lane & 7;
     float bsv[8];
     bool e_ok1 = false;           // this lane's channel group has a destination (tiles are whole: conv_ring_try)
-    unsigned e_pix0 = 0, e_dy = 0;   // output pixel of store slot 0; pixel step of one tile row
     u32x4 e_old[DG ? 8 : 1], e_y[DG ? 8 : 1];
     unsigned char *e_dbase = nullptr;
     const unsigned char *e_ybase = nullptr;
@@ -337,13 +340,17 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
     for (int k = 0; k < 8; ++k) bsv[k] = 0.f;
 
     constexpr int SO = C::NCLS == 4 ? 2 : 1;   // output stride of the parity classes
-    auto e_pix = [&](int slot) {   // slot = (mt * 2 + h2) * 2 + itr, compile-time after unrolling
-        return e_pix0 + (unsigned)(slot >> 2) * e_dy + (unsigned)((((slot >> 1) & 1) * 16 + (slot & 1) * 8) * SO);
-    };
-
     unsigned cu = u_begin;
     int cg = 0, cplane = 0, cgp = 0, cbuf = 0;
     RingUnit CU = ring_unit(p, cu);
+    // output pixel index of store slot (mt, h2, itr): tile pixel m = (2 wv + mt) * 32 + 16 h2 + 8 itr + lane / 8 of unit CU
+    auto e_pix = [&](int slot) {   // slot = (mt * 2 + h2) * 2 + itr, compile-time after unrolling
+        const int m = (wv * 2 + (slot >> 2)) * 32 + ((slot >> 1) & 1) * 16 + (slot & 1) * 8 + (lane >> 3);
+        const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
+        const int y = CU.y0 * C::TH + ty, x = CU.x0 * C::TW + tx;
+        const int oy = SO * y + (C::NCLS == 4 ? CU.py : 0), ox = SO * x + (C::NCLS == 4 ? CU.px : 0);
+        return (unsigned)(((CU.n0 + tn) * p.OH + oy) * p.OW + ox);
+    };
 
     for (unsigned s = 0; s < total; ++s) {
         asm volatile("" ::: "memory");
@@ -380,14 +387,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
             e_dbase = reinterpret_cast<unsigned char *>(dbase);
             e_dld2 = dld * 2;
             e_hasy = e_ybase != nullptr;
-            {
-                // store slot (mt, h2, itr): pixel (y0 + 2 wv + mt, x0 + 16 h2 + 8 itr + lane / 8) of the class grid
-                const int y = CU.y0 * C::TH + wv * 2, x = CU.x0 * C::TW + (lane >> 3);
-                const int oy = SO * y + (C::NCLS == 4 ? CU.py : 0), ox = SO * x + (C::NCLS == 4 ? CU.px : 0);
-                e_pix0 = (unsigned)((CU.n0 * p.OH + oy) * p.OW + ox);
-                e_dy = (unsigned)(SO * p.OW);
-                e_ok1 = dok;
-            }
+            e_ok1 = dok;
             if constexpr (DG) {
 #pragma unroll
                 for (int slot = 0; slot < PF; ++slot) {
@@ -533,9 +533,9 @@ static int ring_launch(RingParams &rp, hipStream_t st) {
         hipDeviceProp_t prop;
         ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
-    rp.tiles_x = (rp.LW + C::TW - 1) / C::TW, rp.tiles_y = (rp.LH + C::TH - 1) / C::TH;
+    rp.tiles_x = rp.LW / C::TW, rp.tiles_y = rp.LH / C::TH, rp.tn = C::TN;   // whole tiles only (conv_ring_try)
     rp.ncob = (unsigned)((rp.cout + 63) / 64), rp.ncls = (unsigned)C::NCLS;
-    rp.nunits = (unsigned)(rp.tiles_x * rp.tiles_y) * (unsigned)rp.N * rp.ncob * rp.ncls;
+    rp.nunits = (unsigned)(rp.tiles_x * rp.tiles_y) * (unsigned)(rp.N / C::TN) * rp.ncob * rp.ncls;
     int cin = 0;
     for (int s = 0; s < rp.nsrc; ++s) cin += rp.src_c[s];
     rp.gpp = cin / C::CKG;
@@ -544,12 +544,15 @@ static int ring_launch(RingParams &rp, hipStream_t st) {
     return check_launch("conv_ring_kernel");
 }
 
-//                         mode   TH  TW  R
-using RG_K3S1 = RgCfg<RM_K3S1, 16, 32, 2>;
-using RG_CT4 = RgCfg<RM_CT4, 16, 32, 3>;
-using RG_SP3 = RgCfg<RM_SP3, 16, 32, 3>;
-using RG_K3S2 = RgCfg<RM_K3S2, 16, 32, 3>;
-using RG_K4S2 = RgCfg<RM_K4S2, 16, 32, 3>;
+// Tile shapes: 16 x 32 pixels of one sample for maps at least 32 wide, 16 x 16 x 2 samples for 16-wide maps, 8 x 8 x 8 samples for
+// 8 x 8 maps (2x2-tap kinds only: the 3x3 kind's group of 8 halo'd samples does not fit two ring buffers).
+template <int MODE, bool DG>
+static int ring_launch_tile(int tw, RingParams &rp, hipStream_t st) {
+    if (tw == 32) return ring_launch<RgCfg<MODE, 16, 32, 1, MODE == RM_K3S1 ? 2 : 3>, DG>(rp, st);
+    if (tw == 16) return ring_launch<RgCfg<MODE, 16, 16, 2, 2>, DG>(rp, st);
+    if constexpr (MODE != RM_K3S1) return ring_launch<RgCfg<MODE, 8, 8, 8, 2>, DG>(rp, st);
+    return 1;
+}
 
 // Runs the launch described by kp (prepared by conv2d_fwd_impl / conv2d_bwd_data_impl, conv_mfma.hip) on the ring kernel when it
 // is covered: bf16 storage with 16-byte epilogue stores, every source a multiple of 32 channels, a logical map of at least
@@ -558,7 +561,11 @@ int conv_ring_try(int kind, bool dgrad, const ConvKParams &kp, hipStream_t st, c
     if (!kp.io_bf16 || !kp.epi16 || g_experiment == 20) return 1;
     for (int s = 0; s < kp.nsrc; ++s)
         if (kp.src_c[s] % 32 != 0 || kp.src_ld[s] % 8 != 0 || (reinterpret_cast<size_t>(kp.src_ptr[s]) & 15)) return 1;
-    if (kp.LW < 32 || kp.LH < 16 || kp.LW % 32 != 0 || kp.LH % 16 != 0) return 1;
+    int tw;   // tile shape by map size: whole tiles only
+    if (kp.LW % 32 == 0 && kp.LH % 16 == 0) tw = 32;
+    else if (kp.LW % 16 == 0 && kp.LH % 16 == 0 && kp.N % 2 == 0) tw = 16;
+    else if (kp.LW % 8 == 0 && kp.LH % 8 == 0 && kp.N % 8 == 0) tw = 8;
+    else return 1;
     int mode;
     int planes;
     if (kind == PWS_CONV_K3S1 || kind == PWS_CONVT_K3S1) mode = RM_K3S1, planes = 9;
@@ -580,15 +587,16 @@ int conv_ring_try(int kind, bool dgrad, const ConvKParams &kp, hipStream_t st, c
     if (rp.w_bytes >= (1u << 31)) return 1;
     rp.bias = kp.bias, rp.act = kp.act, rp.out = kp.out, rp.out_ld = kp.out_ld, rp.ndst = kp.ndst;
     rp.ablate = g_experiment >= 41 && g_experiment <= 47 ? g_experiment - 40 : 0;
-    const long units = (long)(kp.LW / 32) * (kp.LH / 16) * kp.N * ((kp.cout + 63) / 64) * ((mode == RM_CT4 || mode == RM_SP3) ? 4 : 1);
+    if (tw == 8 && mode == RM_K3S1) return 1;
+    const long units = (long)kp.LW * kp.LH * kp.N / 512 * ((kp.cout + 63) / 64) * ((mode == RM_CT4 || mode == RM_SP3) ? 4 : 1);
     if (units < 192 && g_experiment != 21) return 1;   // too few units for 256 persistent workgroups: the split-K kernels do better
     ProfScope prof(KID_CONV_RING, pi.flops, pi.bytes, st);
     switch (mode) {
-    case RM_K3S1: return dgrad ? ring_launch<RG_K3S1, true>(rp, st) : ring_launch<RG_K3S1, false>(rp, st);
-    case RM_CT4: return ring_launch<RG_CT4, false>(rp, st);
-    case RM_SP3: return ring_launch<RG_SP3, true>(rp, st);
-    case RM_K3S2: return ring_launch<RG_K3S2, false>(rp, st);
-    default: return ring_launch<RG_K4S2, true>(rp, st);
+    case RM_K3S1: return dgrad ? ring_launch_tile<RM_K3S1, true>(tw, rp, st) : ring_launch_tile<RM_K3S1, false>(tw, rp, st);
+    case RM_CT4: return ring_launch_tile<RM_CT4, false>(tw, rp, st);
+    case RM_SP3: return ring_launch_tile<RM_SP3, true>(tw, rp, st);
+    case RM_K3S2: return ring_launch_tile<RM_K3S2, false>(tw, rp, st);
+    default: return ring_launch_tile<RM_K4S2, true>(tw, rp, st);
     }
 }
 

@@ -25,12 +25,17 @@ FWD = [
     ("CONVT_K3S1", (2, 32, 32), [64], 64), ("CONVT_K3S1", (1, 16, 32), [32, 32], 200),
     ("CONV_K3S2", (2, 32, 64), [32, 32], 64), ("CONV_K3S2", (1, 64, 64), [64], 128), ("CONV_K3S2", (3, 32, 64), [32], 72),
     ("CONVT_K4S2", (2, 16, 32), [32, 64], 64), ("CONVT_K4S2", (1, 32, 32), [128, 64], 64), ("CONVT_K4S2", (2, 16, 32), [32], 40),
+    # 16-wide maps: tiles of 16 x 16 x 2 samples; 8 x 8 maps: tiles of 8 x 8 x 8 samples (2x2-tap kinds)
+    ("CONV_K3S1", (2, 16, 16), [64], 64), ("CONVT_K3S1", (4, 32, 16), [32, 32], 72), ("CONVT_K4S2", (4, 16, 16), [32, 32], 96),
+    ("CONV_K3S2", (2, 32, 32), [64], 64), ("CONVT_K4S2", (8, 8, 8), [64], 64), ("CONV_K3S2", (8, 16, 16), [32], 64),
 ]
 # data gradients: (kind, (n, h, w) of the forward INPUT = extent of dx, forward sources = destinations, forward cout)
 BWD = [
     ("CONV_K3S1", (2, 16, 32), [64], 64), ("CONV_K3S1", (1, 32, 64), [64, 32], 96), ("CONVT_K3S1", (2, 16, 32), [32, 64, 32], 64),
     ("CONV_K3S2", (2, 32, 64), [32, 32], 64), ("CONV_K3S2", (1, 64, 128), [64], 32), ("CONV_K3S2", (1, 32, 64), [128], 96),
     ("CONVT_K4S2", (2, 16, 32), [32, 64], 64), ("CONVT_K4S2", (1, 32, 32), [128, 64], 32), ("CONVT_K4S2", (1, 16, 64), [64], 96),
+    ("CONV_K3S1", (2, 16, 16), [64], 64), ("CONVT_K4S2", (2, 16, 16), [64, 64], 32), ("CONV_K3S2", (2, 32, 32), [32, 32], 64),
+    ("CONVT_K4S2", (8, 8, 8), [64], 64), ("CONV_K3S2", (8, 16, 16), [64], 32),
 ]
 
 
