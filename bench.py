@@ -552,7 +552,73 @@ def main():
         cp_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)[5]
         line["roofline_grid_sample"]["device_copy_same_bytes_gb_per_s"] = round(by / (cp_ms * 1e-3) / 1e9, 1)
         line["roofline_grid_sample"]["frac_of_measured_copy_rate"] = round(gbs / (by / (cp_ms * 1e-3) / 1e9), 4)
+        # grid_sample backward, the field gradient of a warp (frame = data, main_new.py:106-118): 40 B/pixel, same batch / field
+        try:
+            gsm = smooth.clone().requires_grad_(True)
+            gup = torch.randn((GB, 3, 256, 256), device=dev)
+            for _ in range(2):
+                PF.grid_sample(big, gsm).backward(gup)
+            gsm.grad = None
+            torch.cuda.synchronize()
+            A.lib().pws_prof_enable(1)
+            for _ in range(10):
+                PF.grid_sample(big, gsm).backward(gup)
+                gsm.grad = None
+            A.lib().pws_prof_enable(0)
+            r = [x_ for x_ in A.prof_collect() if x_[0] == "grid_sample_bwd_kernel"]
+            ms = sorted(x_[4] for x_ in r)[len(r) // 2]
+            byb = 40.0 * GB * 256 * 256
+            line["roofline_grid_sample_bwd"] = {"kernel": "grid_sample_bwd_field_kernel", "bound": "hbm",
+                                                "achieved": round(byb / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                                "frac": round(byb / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                                                "avg_launch_us": round(1e3 * ms, 2), "bytes_per_launch": byb, "frames_per_launch": GB,
+                                                "what": "gradient wrt the field only (8 field + 12 upstream + 12 frame + 8 result B/px)"}
+            del gsm, gup
+        except Exception as e:
+            line["roofline_grid_sample_bwd"] = {"error": str(e)[:200]}
         del big, base, smooth, noisy, cp_src, cp_dst
+        # the objective kernels round the path (csrc/objective.hip: warp + L1, temporal, feature, smoothness, shape terms, forward and
+        # backward) on 2 x 128 samples: algorithmic bytes of every launch over the sum of their durations
+        try:
+            from pwstablenet_amd.objective import StabObjective
+            no, mo = 128, 256
+            th = torch.tensor([1, 0, 0, 0, 1, 0], device=dev, dtype=torch.float32).repeat(mo, 1)
+            ramp = torch.linspace(0, 6.28, 256, device=dev)
+            res_o = (2.0 / 256) * torch.stack([torch.sin(3 * ramp).view(1, 256, 1) * torch.cos(2 * ramp).view(1, 1, 256),
+                                               torch.cos(2 * ramp).view(1, 256, 1) * torch.sin(ramp).view(1, 1, 256)], -1).repeat(mo, 1, 1, 1)
+            grids_o = [(PF.affine_grid(th + 0.02 * torch.randn_like(th), (mo, 3, 256, 256)) + res_o).requires_grad_(True) for _ in range(3)]
+            resid_o = [res_o.clone().requires_grad_(True) for _ in range(3)]
+            rgb_o = torch.rand((mo, 3, 256, 256), device=dev) * 2 - 1
+            stab_o = torch.rand((mo, 3, 256, 256), device=dev) * 2 - 1
+            st_ = torch.rand((mo, 400, 2), device=dev) * 1.9 - 0.95
+            one_ = torch.ones((mo, 400, 1), device=dev)
+            feats_o = torch.cat([st_, one_, st_ + 0.02 * torch.randn_like(st_), one_], 2)
+            adj_o = (torch.tensor([1, 0, 0, 0, 1, 0], device=dev, dtype=torch.float32).repeat(no, 1) + 0.01 * torch.randn((no, 6), device=dev))
+            objective_o = StabObjective(batchSize=no)
+
+            def obj_step():
+                o_ = objective_o(grids_o, resid_o, rgb_o, stab_o, feats_o, adj_o)
+                o_.loss_g.backward()
+                for t_ in grids_o + resid_o:
+                    t_.grad = None
+            obj_step()
+            torch.cuda.synchronize()
+            A.lib().pws_prof_enable(1)
+            for _ in range(3):
+                obj_step()
+            A.lib().pws_prof_enable(0)
+            r = [x_ for x_ in A.prof_collect() if x_[0] == "objective_kernels"]
+            tot_b, tot_ms = sum(x_[3] for x_ in r), sum(x_[4] for x_ in r)
+            slow = sorted(r, key=lambda x_: -x_[4])[0]
+            line["roofline_objective"] = {"kernel": "objective kernels (csrc/objective.hip), forward + backward, 256 samples", "bound": "hbm",
+                                          "achieved": round(tot_b / (tot_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                          "frac": round(tot_b / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                                          "launches_per_step": len(r) // 3, "ms_per_step": round(tot_ms / 3, 3),
+                                          "bytes_per_step": tot_b / 3,
+                                          "slowest_launch": {"us": round(1e3 * slow[4], 1), "gb_per_s": round(slow[3] / (slow[4] * 1e-3) / 1e9, 1)}}
+            del grids_o, resid_o, rgb_o, stab_o, feats_o, res_o
+        except Exception as e:
+            line["roofline_objective"] = {"error": str(e)[:200]}
         # roofline of the fused 720p warp (the timing of the leg itself ran on every rank above)
         with torch.no_grad():
             A.lib().pws_prof_enable(1)

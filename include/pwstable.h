@@ -71,8 +71,12 @@ const char *pws_last_error(void); /* thread-local, never NULL */
 #define PWS_STORE_FP32 0
 #define PWS_STORE_BF16 1
 /* Measurement only: selects alternative kernel variants that the scripts under tools/ compare (0 = the product default).
- * 1: non-temporal loads / stores in grid_sample at any size; 9: sub-pixel conv classes as grid.z planes (not on consecutive block
- * slots of one XCD); 11: no fused act' / bias gradient in the bf16 generator backward (separate pws_act_bwd_bias passes). */
+ * 1: non-temporal loads / stores in grid_sample at any size; 2: the general grid_sample backward kernel also for the field-only
+ * gradient; 9: sub-pixel conv classes as grid.z planes (not on consecutive block slots of one XCD); 11: no fused act' / bias
+ * gradient in the bf16 generator backward (separate pws_act_bwd_bias passes); 20: first-generation conv_bf16_kernel instead of
+ * the persistent LDS-ring kernel (conv_ring.hip); 21: the ring kernel also for launches too small to fill the chip; 41..47:
+ * timing-only ablations of the ring kernel (bit 0: the DMA pieces fetch nothing, bit 1: no matrix phase, bit 2: no epilogue --
+ * results are meaningless). */
 #define PWS_OPT_EXPERIMENT 100
 int pws_set_option(int key, int value);
 int pws_get_option(int key); /* current value, or PWS_EINVAL */

@@ -208,6 +208,89 @@ __global__ void __launch_bounds__(256) grid_sample_bwd_kernel(const float *__res
     }
 }
 
+// Gradient wrt the FIELD only (the frame is data: reference main_new.py:106-118, what loss_g.backward() needs of every warp):
+// no scatter, so the forward's access pattern applies -- 4 consecutive pixels per lane, one 32-byte field read, one 16-byte read of
+// every upstream channel plane, the two taps of a source row as ONE unaligned 8-byte gather, one 32-byte store of the result.
+//   d out / d ix = (v01 - v00) wy0 + (v11 - v10) wy1 ,  d out / d iy = (v10 - v00) wx0 + (v11 - v01) wx1   (out-of-range taps = 0)
+// are folded into 8 coefficients per pixel of the four fetched values (left / right of row pair 0 and 1); a channel then costs
+// 2 gathers + 10 FMAs per pixel.  Algorithmic traffic (C = 3): 8 (field) + 12 (upstream) + 12 (frame) + 8 (result) = 40 B/pixel.
+struct TapsG {
+    int o0, o1;              // offsets of the two row pairs inside a channel plane
+    float xl0, xr0, xl1, xr1;  // d/d ix coefficients of (pair0.x, pair0.y, pair1.x, pair1.y)
+    float yl0, yr0, yl1, yr1;  // d/d iy
+};
+__device__ __forceinline__ TapsG make_taps_g(float gx, float gy, int H, int W, bool ac) {
+    const float ix = unnormalize(gx, W, ac), iy = unnormalize(gy, H, ac);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx, wx0 = 1.f - wx1, wy1 = iy - fy, wy0 = 1.f - wy1;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    const int xs = min(max(x0, 0), W - 2);
+    const int sel = x0 - xs;   // 0: pair = (x0, x1); -1: pair.x = x1 (x0 left of the image); +1: pair.y = x0 (x1 right of it)
+    // coefficient of tap (x0, row) / (x1, row), zero when the tap is out of range
+    const float cx0_0 = vx0 && vy0 ? -wy0 : 0.f, cx1_0 = vx1 && vy0 ? wy0 : 0.f, cx0_1 = vx0 && vy1 ? -wy1 : 0.f, cx1_1 = vx1 && vy1 ? wy1 : 0.f;
+    const float cy0_0 = vx0 && vy0 ? -wx0 : 0.f, cy1_0 = vx1 && vy0 ? -wx1 : 0.f, cy0_1 = vx0 && vy1 ? wx0 : 0.f, cy1_1 = vx1 && vy1 ? wx1 : 0.f;
+    TapsG t;
+    t.o0 = min(max(y0, 0), H - 1) * W + xs, t.o1 = min(max(y1, 0), H - 1) * W + xs;
+    t.xl0 = sel == 0 ? cx0_0 : (sel == -1 ? cx1_0 : 0.f), t.xr0 = sel == 0 ? cx1_0 : (sel == 1 ? cx0_0 : 0.f);
+    t.xl1 = sel == 0 ? cx0_1 : (sel == -1 ? cx1_1 : 0.f), t.xr1 = sel == 0 ? cx1_1 : (sel == 1 ? cx0_1 : 0.f);
+    t.yl0 = sel == 0 ? cy0_0 : (sel == -1 ? cy1_0 : 0.f), t.yr0 = sel == 0 ? cy1_0 : (sel == 1 ? cy0_0 : 0.f);
+    t.yl1 = sel == 0 ? cy0_1 : (sel == -1 ? cy1_1 : 0.f), t.yr1 = sel == 0 ? cy1_1 : (sel == 1 ? cy0_1 : 0.f);
+    return t;
+}
+
+template <bool NT>
+__global__ void __launch_bounds__(256) grid_sample_bwd_field_kernel(const float *__restrict__ gout, const float *__restrict__ input,
+                                                                    const float *__restrict__ grid, float *__restrict__ ggrid, int C,
+                                                                    int H, int W, int HoWo, size_t total_groups, unsigned nblocks,
+                                                                    int ac) {
+    const unsigned blk = xcd_remap(blockIdx.x, nblocks);
+    const size_t gidx = (size_t)blk * 256 + threadIdx.x;
+    if (gidx >= total_groups) return;
+    const size_t p0 = gidx * 4;   // HoWo % 4 == 0: the 4 pixels stay inside one image
+    const int n = (int)(p0 / HoWo);
+    const int hw = (int)(p0 % HoWo);
+    f32x4 a, b;
+    if constexpr (NT) {
+        a = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(grid + p0 * 2));
+        b = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(grid + p0 * 2 + 4));
+    } else {
+        a = *reinterpret_cast<const f32x4 *>(grid + p0 * 2);
+        b = *reinterpret_cast<const f32x4 *>(grid + p0 * 2 + 4);
+    }
+    const float g[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    TapsG t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = make_taps_g(g[2 * i], g[2 * i + 1], H, W, ac != 0);
+    const size_t plane = (size_t)H * W;
+    float gix[4] = {0.f, 0.f, 0.f, 0.f}, giy[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) {
+        const float *ip = input + ((size_t)n * C + c) * plane;
+        const float *gp = gout + ((size_t)n * C + c) * HoWo + hw;
+        f32x4 go;
+        if constexpr (NT) go = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(gp));
+        else go = *reinterpret_cast<const f32x4 *>(gp);
+        const float gov[4] = {go.x, go.y, go.z, go.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const F2U u = *reinterpret_cast<const F2U *>(ip + t[i].o0);
+            const F2U v = *reinterpret_cast<const F2U *>(ip + t[i].o1);
+            gix[i] += gov[i] * (u.x * t[i].xl0 + u.y * t[i].xr0 + v.x * t[i].xl1 + v.y * t[i].xr1);
+            giy[i] += gov[i] * (u.x * t[i].yl0 + u.y * t[i].yr0 + v.x * t[i].yl1 + v.y * t[i].yr1);
+        }
+    }
+    const float sx = ac ? 0.5f * (float)(W - 1) : 0.5f * (float)W;
+    const float sy = ac ? 0.5f * (float)(H - 1) : 0.5f * (float)H;
+    const f32x4 o0 = {gix[0] * sx, giy[0] * sy, gix[1] * sx, giy[1] * sy}, o1 = {gix[2] * sx, giy[2] * sy, gix[3] * sx, giy[3] * sy};
+    if constexpr (NT) {
+        __builtin_nontemporal_store(o0, reinterpret_cast<f32x4 *>(ggrid + p0 * 2));
+        __builtin_nontemporal_store(o1, reinterpret_cast<f32x4 *>(ggrid + p0 * 2 + 4));
+    } else {
+        *reinterpret_cast<f32x4 *>(ggrid + p0 * 2) = o0;
+        *reinterpret_cast<f32x4 *>(ggrid + p0 * 2 + 4) = o1;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- affine_grid
 __device__ __forceinline__ float base_coord(int j, int size, bool ac) {
     if (ac) return size > 1 ? (2.f * j) / (float)(size - 1) - 1.f : 0.f;
@@ -470,6 +553,18 @@ extern "C" int pws_grid_sample_bwd(const float *gout, const float *input, const 
     ProfScope prof(KID_GRID_SAMPLE_BWD, (double)total * (20.0 + 16.0 * c),
                    (double)total * (8.0 + 4.0 * c + (ggrid ? 8.0 : 0.0)) + (ginput ? 8.0 : 4.0) * c * (double)n * h * w,
                    as_stream(stream));
+    if (!ginput && (ho * wo) % 4 == 0 && w >= 2 && aligned16(grid) && aligned16(gout) && aligned16(ggrid) && g_experiment != 2) {
+        // the field gradient alone: 4 pixels per lane, vector loads, paired gathers (see the kernel)
+        const size_t groups = total / 4;
+        const unsigned nbg = (unsigned)((groups + 255) / 256);
+        if ((double)total * (16.0 + 8.0 * c) > 256e6)   // beyond the Infinity Cache: streaming hints, as the forward
+            hipLaunchKernelGGL(grid_sample_bwd_field_kernel<true>, dim3(nbg), dim3(256), 0, as_stream(stream), gout, input, grid, ggrid, c,
+                               h, w, ho * wo, groups, nbg, align_corners);
+        else
+            hipLaunchKernelGGL(grid_sample_bwd_field_kernel<false>, dim3(nbg), dim3(256), 0, as_stream(stream), gout, input, grid, ggrid,
+                               c, h, w, ho * wo, groups, nbg, align_corners);
+        return check_launch("grid_sample_bwd_field_kernel");
+    }
     hipLaunchKernelGGL(grid_sample_bwd_kernel, dim3(nb), dim3(256), 0, as_stream(stream), gout, input, grid, ginput, ggrid, c,
                        h, w, ho * wo, total, nb, align_corners);
     return check_launch("grid_sample_bwd_kernel");

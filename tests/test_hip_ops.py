@@ -237,7 +237,44 @@ def test_grid_sample_vs_oracle(hip, oracle, shape):
     gg2 = torch.empty_like(d_grid)
     A.check(L.pws_grid_sample_bwd(A.ptr(d_gout), A.ptr(d_img), A.ptr(d_grid), None, A.ptr(gg2), n, c, h, w, h, w, 0, st), "bwd")
     torch.cuda.synchronize()
-    assert torch.equal(gg, gg2)
+    # (the field-only call runs grid_sample_bwd_field_kernel where the shape allows: same terms, another summation order)
+    np.testing.assert_allclose(gg2.cpu().numpy(), rgg, rtol=1e-4, atol=0.5)
+    np.testing.assert_allclose(gg2.cpu().numpy(), gg.cpu().numpy(), rtol=1e-5, atol=2e-2)
+
+
+@pytest.mark.parametrize("ac", [0, 1])
+@pytest.mark.parametrize("shape", [(2, 3, 64, 96, 64, 96), (1, 1, 40, 52, 24, 36), (3, 3, 17, 33, 8, 10), (1, 3, 256, 256, 256, 256)])
+def test_grid_sample_field_gradient_kernel(hip, oracle, shape, ac):
+    """The 4-pixel-per-lane field-gradient kernel (frame = data, reference main_new.py:106-118): fields that leave the image on
+    every side, exact-integer and half-integer coordinates, output size != input size, both coordinate conventions; against the C
+    oracle and against the general backward kernel (PWS_OPT_EXPERIMENT 2)."""
+    A = hip
+    n, c, h, w, ho, wo = shape
+    rs = np.random.RandomState(11 + ac)
+    img = synth.make_frames(n, c, h, w, seed=8)
+    theta = (np.array([1.2, 0.1, 0, -0.1, 1.2, 0], np.float32) + 0.05 * rs.standard_normal((n, 6))).astype(np.float32)
+    grid = oracle.affine_grid(theta, ho, wo, align_corners=bool(ac)) + 0.03 * rs.standard_normal((n, ho, wo, 2)).astype(np.float32)
+    grid[:, 0, :4] = np.array([[-1, -1], [1, 1], [0, 0], [1.0 - 1.0 / w, -1.0 + 1.0 / h]], np.float32)   # corners / centre / pixel centres
+    grid[:, 1, :2] = np.array([[-1.5, 0.3], [0.2, 1.7]], np.float32)                                    # fully outside
+    gout = rs.standard_normal((n, c, ho, wo)).astype(np.float32)
+    _, rgg = oracle.grid_sample_bwd(gout, img, grid, align_corners=bool(ac), want_input=False)
+    L, st = A.lib(), A.current_stream()
+    d_img, d_grid, d_gout = dev(img), dev(grid), dev(gout)
+    got = {}
+    for exp in (0, 2):
+        assert L.pws_set_option(100, exp) == 0
+        gg = torch.full_like(d_grid, float("nan"))
+        L.pws_prof_enable(1)
+        A.check(L.pws_grid_sample_bwd(A.ptr(d_gout), A.ptr(d_img), A.ptr(d_grid), None, A.ptr(gg), n, c, h, w, ho, wo, ac, st), "bwd")
+        L.pws_prof_enable(0)
+        assert [r[0] for r in A.prof_collect()] == ["grid_sample_bwd_kernel"]
+        torch.cuda.synchronize()
+        got[exp] = gg.cpu().numpy()
+    L.pws_set_option(100, 0)
+    assert not np.isnan(got[0]).any()
+    scale = np.abs(rgg).max()
+    assert np.abs(got[0] - rgg).max() < 2e-5 * scale + 1e-3, np.abs(got[0] - rgg).max() / scale
+    assert np.abs(got[0] - got[2]).max() < 2e-5 * scale + 1e-3
 
 
 def test_grid_sample_linearity_full_size(hip):
