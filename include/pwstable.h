@@ -74,7 +74,9 @@ const char *pws_last_error(void); /* thread-local, never NULL */
  * 1: non-temporal loads / stores in grid_sample at any size; 2: the general grid_sample backward kernel also for the field-only
  * gradient; 9: sub-pixel conv classes as grid.z planes (not on consecutive block slots of one XCD); 11: no fused act' / bias
  * gradient in the bf16 generator backward (separate pws_act_bwd_bias passes); 20: first-generation conv_bf16_kernel instead of
- * the persistent LDS-ring kernel (conv_ring.hip); 21: the ring kernel also for launches too small to fill the chip; 41..47:
+ * the persistent LDS-ring kernel (conv_ring.hip); 21: the ring kernel also for launches too small to fill the chip; 22: the
+ * first-generation conv_mfma_kernel instead of the fp32 ring kernel (conv_ring_f32.hip); 23 / 24: the fp32 ring kernel also for
+ * small launches, with 8 x 32 / 16 x 32 tiles; 41..47:
  * timing-only ablations of the ring kernel (bit 0: the DMA pieces fetch nothing, bit 1: no matrix phase, bit 2: no epilogue --
  * results are meaningless). */
 #define PWS_OPT_EXPERIMENT 100

@@ -361,6 +361,7 @@ static const TileChoice kK5N[] = {choice<K5S1_T256_NCHW, KID_CONV_K5S1>()};
 int conv_bf16_fwd(int kind, ConvKParams &kp, int cin_total, float *out, float *ws, size_t ws_floats, hipStream_t st,
                   const ProfInfo &pi);  // conv_bf16.hip; 1 = not covered
 int conv_bf16_dgrad(int kind, ConvKParams &kp, int cout_f, float *ws, size_t ws_floats, hipStream_t st, const ProfInfo &pi);
+int conv_ringf_try(int kind, const ConvKParams &kp, hipStream_t st, const ProfInfo &pi);   // conv_ring_f32.hip; 1 = not covered
 
 int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
     PWS_REQUIRE(a != nullptr, "pws_conv2d_fwd: args is NULL");
@@ -436,12 +437,22 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
         // (measured: with <= 64 input channels the per-workgroup prologue/epilogue outweighs the saving unless the map is huge)
         if (a->w_wino && !nchw && a->h >= 16 && a->w >= 16 && wblocks >= 128 && (cin >= 128 || wblocks >= 2048))
             return wino_k3s1_launch(a, ProfHint{pi.flops, pi.bytes}, st);
+        if (!bf16 && !nchw) {   // the persistent LDS-ring kernel (exact fp32) where it is covered
+            kp.out = a->out;
+            const int rc = conv_ringf_try(a->kind, kp, st, pi);
+            if (rc != 1) return rc;
+        }
         return select_and_launch(kK3S1, 5, kp, kp.cin_pad, a->out, ws, ws_floats, st, pi);
     }
     case PWS_CONV_K3S2:
         kp.OH = kp.LH = (a->h + 2 - 3) / 2 + 1, kp.OW = kp.LW = (a->w + 2 - 3) / 2 + 1;
         if (bf16) {
             const int rc = conv_bf16_fwd(a->kind, kp, kp.cin_pad, a->out, ws, ws_floats, st, info(9, (double)a->n * kp.OH * kp.OW));
+            if (rc != 1) return rc;
+        }
+        if (!bf16 && !nchw) {
+            kp.out = a->out;
+            const int rc = conv_ringf_try(a->kind, kp, st, info(9, (double)a->n * kp.OH * kp.OW));
             if (rc != 1) return rc;
         }
         return select_and_launch(kK3S2, 5, kp, kp.cin_pad, a->out, ws, ws_floats, st, info(9, (double)a->n * kp.OH * kp.OW));
@@ -467,6 +478,11 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
         // generator's executor does not pack these weights; the path stays available for large maps.
         const long wb = cdiv(a->w, 24) * cdiv(a->h, 12) * a->n * cdiv(a->cout, 64) * 4;
         if (a->w_wino && a->h >= 24 && a->w >= 24 && wb >= 256) return wino_k3s1_launch(a, ProfHint{pi.flops, pi.bytes}, st);
+        if (!bf16 && !nchw) {
+            kp.out = a->out;
+            const int rc = conv_ringf_try(a->kind, kp, st, pi);
+            if (rc != 1) return rc;
+        }
         return select_and_launch(kCT4, 5, kp, kp.cin_pad, a->out, ws, ws_floats, st, pi);
     }
     default:

@@ -136,6 +136,55 @@ def test_conv_kinds_vs_oracle(hip, oracle, kname, shape, src_c, cout, act):
         np.testing.assert_allclose(nchw(got), ref, rtol=0, atol=5e-5)
 
 
+RINGF_CASES = [
+    ("CONV_K3S1", (2, 16, 32), [16], 64), ("CONV_K3S1", (1, 24, 64), [32, 16], 96), ("CONVT_K3S1", (2, 16, 32), [16, 16, 16, 16], 36),
+    ("CONV_K3S2", (2, 32, 64), [16, 16], 64), ("CONV_K3S2", (1, 48, 64), [32], 72), ("CONVT_K4S2", (2, 16, 32), [32, 16], 64),
+    ("CONVT_K4S2", (1, 8, 64), [16], 40),
+]
+
+
+@pytest.mark.parametrize("force", [23, 24])
+@pytest.mark.parametrize("kname,shape,src_c,cout", RINGF_CASES)
+@pytest.mark.parametrize("act", [1, 2])
+def test_fp32_ring_kernel_vs_oracle(hip, oracle, kname, shape, src_c, cout, act, force):
+    """conv_ringf_kernel (csrc/conv_ring_f32.hip: persistent LDS-ring, exact fp32 MFMA) forced for small launches with both tile
+    heights (PWS_OPT_EXPERIMENT 23 / 24), against the C oracle and against conv_mfma_kernel (22): 3x3 s1, transposed 3x3 s1,
+    3x3 s2 as parity planes, transposed 4x4 s2 as parity classes, virtual concats, cout ending inside a 64-channel block."""
+    A = hip
+    L = A.lib()
+    kind = getattr(A, kname)
+    n, h, w = shape
+    rs = np.random.RandomState(zlib.crc32(repr((kname, shape, cout, "rf")).encode()))
+    cin = sum(src_c)
+    x = rs.standard_normal((n, cin, h, w)).astype(np.float32)
+    k = {"CONV_K3S1": 3, "CONV_K3S2": 3, "CONVT_K3S1": 3, "CONVT_K4S2": 4}[kname]
+    is_t = kname.startswith("CONVT")
+    wt = (rs.standard_normal((cin, cout, k, k) if is_t else (cout, cin, k, k)) / np.sqrt(cin * k * k / (4 if kname == "CONVT_K4S2" else 1))).astype(np.float32)
+    b = rs.standard_normal((cout,)).astype(np.float32)
+    s_, p_ = {"CONV_K3S1": (1, 1), "CONV_K3S2": (2, 1), "CONVT_K3S1": (1, 1), "CONVT_K4S2": (2, 1)}[kname]
+    ref = (oracle.conv_transpose2d if is_t else oracle.conv2d)(x, wt, b, s_, p_, {1: oracle.ACT_LRELU, 2: oracle.ACT_RELU}[act])
+    xs = nhwc(x)
+    srcs, c0 = [], 0
+    for c in src_c:
+        srcs.append(np.ascontiguousarray(xs[..., c0:c0 + c]))
+        c0 += c
+    got = {}
+    try:
+        for exp in (force, 22):
+            assert L.pws_set_option(100, exp) == 0
+            L.pws_prof_enable(1)
+            got[exp] = run_conv(A, kind, srcs, wt, b, act, cout, ws_mb=64)
+            L.pws_prof_enable(0)
+            names = [r[0] for r in A.prof_collect()]
+            assert (names == ["conv_ringf_kernel"]) == (exp != 22), (exp, names)
+    finally:
+        L.pws_prof_enable(0)
+        L.pws_set_option(100, 0)
+    assert not np.isnan(got[force]).any()
+    np.testing.assert_allclose(nchw(got[force]), ref, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(got[force], got[22], rtol=0, atol=5e-5)
+
+
 @pytest.mark.parametrize("kname,shape,src_c,cout", [
     ("CONV_K3S1", (4, 128, 128), [64, 64], 64),
     ("CONVT_K3S1", (5, 112, 130), [128], 96),     # ragged extent, cout not a multiple of 64
