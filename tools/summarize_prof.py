@@ -33,6 +33,16 @@ def short(name):
         sub = {"0": "", "1": ",convT4", "2": ",dgrad-subpix", "true": ",convT4", "false": ""}.get(a[3], "," + a[3])
         return "conv_mfma_kernel<k%ss%s%s,tile %sx%sx%s,CK%s%s>" % (
             a[0], a[1], sub, a[6], a[4], a[5], a[7], ",NCHW" if len(a) > 12 and a[12].startswith("t") else "")
+    m = re.match(r"pws::conv_ring_kernel<pws::RgCfg<([^>]*)>,\s*(true|false)\s*>", name)
+    if m:   # persistent LDS-ring bf16 conv (conv_ring.hip): mode, tile, ring depth, epilogue kind
+        a = [x.strip() for x in m.group(1).split(",")]
+        mode = {"0": "k3s1", "1": "convT4", "2": "dgrad-subpix k3s2", "3": "k3s2 planes", "4": "dgrad k4s2 planes"}.get(a[0], a[0])
+        return "conv_ring_kernel<%s,tile %sx%sx%s,R%s,%s>" % (mode, a[3], a[1], a[2], a[4], "dgrad" if m.group(2) == "true" else "fwd")
+    m = re.match(r"pws::conv_ringf_kernel<pws::RfCfg<([^>]*)>\s*>", name)
+    if m:
+        a = [x.strip() for x in m.group(1).split(",")]
+        mode = {"0": "k3s1", "1": "convT4", "2": "k3s2 planes"}.get(a[0], a[0])
+        return "conv_ringf_kernel<%s,tile %sx32,R%s>" % (mode, a[1], a[2])
     return re.sub(r"\(.*", "", name).replace("pws::", "")[:100]
 
 
@@ -63,6 +73,7 @@ def kernel_stats(sub, suffix):
 kernel_stats("trace", "")
 kernel_stats("trace_bf16", "_bf16")
 kernel_stats("trace_train", "_train_bf16")
+kernel_stats("trace_configs2", "_configs2_bf16")
 
 summ = defaultdict(dict)
 for sub in sorted(glob.glob(os.path.join(d, "pmc_*"))):
@@ -86,10 +97,18 @@ for sub in sorted(glob.glob(os.path.join(d, "pmc_*"))):
         for cn, vals in cs.items():
             summ[k][cn] = {"mean_per_dispatch": sum(vals) / len(vals), "dispatches": len(vals)}
 out = os.path.join(dest, "%s_pmc.json" % tag)
+try:   # the kernels these counters describe: bench.py quotes counter-derived figures only when this matches its own build
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from pwstablenet_amd.build import source_hash
+    summ["_meta"] = {"source_hash": source_hash(), "tag": tag}
+except Exception as e:
+    summ["_meta"] = {"source_hash": None, "error": str(e)}
 with open(out, "w") as f:
     json.dump(summ, f, indent=1, sort_keys=True)
 print("pmc ->", out)
 for k, cs in sorted(summ.items()):
+    if k == "_meta":
+        continue
     if "conv_" in k or "grid_sample" in k or "field_head" in k or "wino" in k or "wgrad" in k:
         print(k)
         for cn, v in sorted(cs.items()):
