@@ -352,7 +352,9 @@ def test_backward_in_parts_with_overlapped_grad_sync(hip, nparts, math):
     assert sync.collectives == 0   # no process group here: the collectives are skipped, the rest is the same path
     for a, b in zip(got, ref):
         scale = float(b.abs().max()) + 1e-12
-        assert float((a - b).abs().max()) / scale < 1e-4   # fp32 atomics order in the weight-gradient kernels (same arithmetic otherwise)
+        # fp32 atomics order in the weight-gradient kernels (same arithmetic otherwise); the bf16 kernels' many pixel-split
+        # partial sums cancel more strongly on the small tensors (seen: 2.4e-4 of a tensor's maximum, run to run)
+        assert float((a - b).abs().max()) / scale < (1e-4 if math == "fp32" else 1e-3)
     net.module.grad_sync = None
     # the C side's final-layer report: monotone, complete after the last run
     L = hip.lib()
