@@ -107,7 +107,8 @@ int pws_pack_conv_weight(const float *w_torch, float *w_packed, int kind, int ci
                          pws_stream_t stream);
 
 /* Winograd F(2x2,3x3) weights U = G g G^T as [16][cin padded to 16][cout], computed from the PACKED weights of a
- * K3S1 / CONVT_K3S1 layer (so the transposed conv's tap flip is already applied). */
+ * K3S1 / CONVT_K3S1 layer (so the transposed conv's tap flip is already applied); when cout % 32 == 0 the same values follow
+ * once more in the layout of the LDS-ring Winograd kernel (pws_packed_wino_floats covers both). */
 size_t pws_packed_wino_floats(int cin, int cout);
 int pws_pack_conv_weight_wino(const float *w_packed, float *w_wino, int cin, int cout, pws_stream_t stream);
 /* The same for ConvTranspose2d k4 s2 p1 (CONVT_K4S2): each of the 4 output parity classes is a 2x2 correlation, run as

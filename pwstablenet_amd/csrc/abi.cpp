@@ -36,7 +36,8 @@ const char *const kKernelNames[KID_COUNT] = {
     "adam_kernel", "pack_weight_kernel", "conv_mfma_kernel<dgrad k4s2>", "conv_mfma_kernel<dgrad subpix k3s2>",
     "wgrad_mfma_kernel", "act_bwd_bias_kernel", "field_head_bwd_kernels", "theta_head_bwd_kernels",
     "wino_k3s1_kernel<F(2x2,3x3)>", "conv_bf16_kernel", "wgrad_bf16_kernel",
-    "wino_ct4_kernel<F(3x3,2x2)>", "upsample_grid_sample_u8_kernel", "objective_kernels", "conv_ring_kernel", "conv_ringf_kernel"};
+    "wino_ct4_kernel<F(3x3,2x2)>", "upsample_grid_sample_u8_kernel", "objective_kernels", "conv_ring_kernel", "conv_ringf_kernel",
+    "wino_ring_kernel<F(2x2,3x3)>"};
 }  // namespace
 
 void prof_begin(int kernel_id, double flops, double bytes, hipStream_t st) {

@@ -47,7 +47,7 @@ enum KernelId {
     KID_CONV_K3S1_BIG = 0, KID_CONV_K3S1_SMALL, KID_CONV_K3S2_BIG, KID_CONV_K3S2_SMALL, KID_CONV_K5S1, KID_CONVT4_BIG,
     KID_CONVT4_SMALL, KID_THETA_HEAD, KID_FIELD_HEAD, KID_GRID_SAMPLE_FWD, KID_GRID_SAMPLE_BWD, KID_UPSAMPLE_GRID_SAMPLE_FWD,
     KID_UPSAMPLE, KID_AFFINE_GRID, KID_ADAM, KID_PACK, KID_DGRAD_K4S2, KID_DGRAD_SP3, KID_WGRAD, KID_ACT_BWD, KID_FIELD_HEAD_BWD,
-    KID_THETA_HEAD_BWD, KID_CONV_WINO, KID_CONV_BF16, KID_WGRAD_BF16, KID_CONV_WINO_CT4, KID_UPSAMPLE_GRID_SAMPLE_U8, KID_OBJECTIVE, KID_CONV_RING, KID_CONV_RINGF, KID_COUNT
+    KID_THETA_HEAD_BWD, KID_CONV_WINO, KID_CONV_BF16, KID_WGRAD_BF16, KID_CONV_WINO_CT4, KID_UPSAMPLE_GRID_SAMPLE_U8, KID_OBJECTIVE, KID_CONV_RING, KID_CONV_RINGF, KID_CONV_WRING, KID_COUNT
 };
 extern bool g_two_queues;
 extern int g_math;  // PWS_OPT_MATH
@@ -84,6 +84,18 @@ int theta_bwd_bn_lin(const float *dz2, const float *h, int n, int hidden, const 
 int theta_bwd_flat(const float *x, int n, int c, int hidden, const float *w_flat, const float *dz1, float *dw_flat, float *dx,
                    int dx_accumulate, hipStream_t st);
 int wino_k3s1_launch(const pws_conv_args *a, const ProfHint &ph, hipStream_t st);  // conv_wino.hip
+// conv_wring.hip: Winograd F(2x2,3x3) on the LDS ring.  Its weights follow the component-major ones in the buffer of
+// pws_pack_conv_weight_wino when wring_layout_ok(): element (component xi, input channel ci, output channel co) at wring_index.
+int wring_try(const pws_conv_args *a, const ProfHint &ph, hipStream_t st);   // 1: not covered
+int wring_pack(const float *uw, float *ur, int cin_pad, int cout, hipStream_t st);
+__host__ __device__ inline bool wring_layout_ok(int cin_pad, int cout) { return cin_pad % 16 == 0 && cout % 32 == 0; }
+// [32-channel block][16-channel chunk][xi][nt][kq][co16][st]: co = 32 block + 2 co16 + nt, ci = 16 chunk + 4 kq + st -- one
+// (block, chunk) is 32 KB contiguous, and inside it a 1 KB run is one lane-linear B-operand image of v_mfma_f32_16x16x4_f32
+__host__ __device__ inline size_t wring_index(int xi, int ci, int co, int nchunks) {
+    const int cob = co >> 5, c32 = co & 31, co16 = c32 >> 1, nt = c32 & 1;
+    const int chunk = ci >> 4, kq = (ci >> 2) & 3, st = ci & 3;
+    return ((((((size_t)cob * nchunks + chunk) * 16 + xi) * 2 + nt) * 4 + kq) * 16 + co16) * 4 + st;
+}
 
 // bf16 operand helpers (conv_bf16.hip, wgrad_bf16.hip)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

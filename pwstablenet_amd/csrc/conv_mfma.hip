@@ -433,6 +433,10 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
         }
         // Winograd F(2x2,3x3) when there is enough of the map to fill the chip (measured cross-over, tools/conv_bench.py:
         // 256->256 @32x32 x8: 104 -> 79 us; 512->512 @16x16 x8: 106 -> 138 us); the deep maps stay direct + split-K
+        if (a->w_wino && !nchw && !bf16) {   // second-generation Winograd (persistent LDS ring) where whole 16 x 32 units fill the chip
+            const int rc = wring_try(a, ProfHint{pi.flops, pi.bytes}, st);
+            if (rc != 1) return rc;
+        }
         const long wblocks = cdiv(a->w, 16) * cdiv(a->h, 16) * a->n * cdiv(a->cout, 64);
         // (measured: with <= 64 input channels the per-workgroup prologue/epilogue outweighs the saving unless the map is huge)
         if (a->w_wino && !nchw && a->h >= 16 && a->w >= 16 && wblocks >= 128 && (cin >= 128 || wblocks >= 2048))

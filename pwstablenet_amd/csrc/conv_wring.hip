@@ -1,0 +1,452 @@
+// Winograd F(2x2, 3x3) for the 3x3 stride-1 layers (Conv2d k3 s1 p1 and ConvTranspose2d k3 s1 p1 = flipped correlation) in exact
+// fp32 on the persistent LDS-ring structure of conv_ring.hip: second generation of conv_wino.hip for the launches that fill
+// the chip (BASELINE configs[1], the headline `value`: the six 38.7-GFLOP conv_same layers are 21 % of the step).
+//
+// Why (profiles/r02_pmc.json): wino_kernel<0> keeps the fp32 matrix pipe 45-50 % busy.  Per 8-channel chunk a
+// workgroup stages 32 KB of transformed weights for only 32 tiles x 64 channels (2 048 matrix cycles per wave), global -> VGPR ->
+// LDS, writes the transformed input V to LDS and reads it back, and pays two barriers.  Here:
+//   * a unit = 16 x 32 output pixels (8 x 16 Winograd tiles) x 32 output channels, walked by ONE persistent 8-wave workgroup per
+//     CU; its K dimension streams through an LDS ring of R = 2 slots of 16 input channels, filled by LDS-DMA
+//     (buffer_load_dwordx4 ... lds) one slot ahead, one s_barrier per slot; consecutive units form one stream (the first slot of
+//     the next unit is in flight under the last matrix phase and the epilogue of the current one).  A slot = raw halo tile
+//     18 x 34 pixels x 64 bytes (one L2 request per pixel) + 32 KB of transformed weights for 128 tiles: 72 KB per 8 192 matrix
+//     cycles per SIMD = 8.8 bytes per clock and CU (the first-generation kernel needs 18.5 at full rate);
+//   * a wave owns ONE TILE ROW (16 tiles) x 32 channels x ALL 16 Winograd components on v_mfma_f32_16x16x4_f32 (128 accumulator
+//     registers): lane (tile tx = lane & 15, kq = lane >> 4) reads the 4 x 4 patch of ITS tile for ITS four channels
+//     (16 ds_read_b128), applies B^T d B in registers and feeds the 16 x 4 results straight into the matrix instructions as A
+//     operands -- no V buffer, no transform pass, no second barrier; the B operand (transformed weights, four k-steps per
+//     ds_read_b128) comes from a pack-time layout that is lane-linear in LDS and contiguous in memory (1 KB per DMA instruction);
+//   * the whole output transform A^T M A happens inside a lane (it holds all 16 components of its 4 tiles x 2 channels): no
+//     cross-wave reduction through LDS; bias + activation, 8-byte stores (channel pair) that are 128 bytes contiguous per 16 lanes;
+//   * the matrix waves issue the DMA pieces themselves (9 per wave and slot, right behind the barrier): 128 accumulators + 64
+//     operand registers need the 256-register budget of two waves per SIMD, which leaves no room for dedicated loader waves; at 32
+//     cycles per fp32 matrix instruction the partner wave of the SIMD covers the ~50 cycles a piece blocks its wave;
+//   * raw-tile LDS layout: pixel rows of 64 bytes; inside an image row the even-x pixels come first, then the odd ones, and the
+//     four 16-byte slots of a pixel are permuted (slot' = P[s] ^ ((x / 2 / 4) & 3), P = {0, 3, 1, 2}), so that the 16 lanes the
+//     hardware serves together in a ds_read_b128 (tiles x and channel slots mixed) hit 16 different 4-bank groups for the
+//     patch columns 0 and 1 and at most two-way conflicts for columns 2 and 3.  Zero padding = DMA offsets beyond num_records.
+// Numerics: as conv_wino.hip (fp32 Winograd, ~1e-6 relative to the direct form); the K order differs.
+#include <type_traits>
+
+#include "conv_common.h"
+
+namespace pws {
+
+struct WringParams {
+    const float *src_ptr[4];  // fp32 NHWC sources of the virtual concat, each a multiple of 16 channels
+    int src_c[4], src_ld[4];
+    int nsrc;
+    int N, H, W, cout;
+    const float *ur;          // ring layout of the transformed weights (wring_index, common.h)
+    unsigned ur_bytes;
+    const float *bias;
+    int act;
+    float *out;
+    int out_ld;
+    int tiles_x, tiles_y;
+    unsigned ncob, nunits;
+    int nchunks;              // sum(src_c) / 16
+    int ablate;               // measurement only (PWS_OPT_EXPERIMENT 51..57, or 1000 + mask): 1 = DMA pieces fetch nothing after the
+                              // first slot, 2 = no matrix phase, 4 = no epilogue stores, 8 = no A-operand reads, 16 = no B-operand
+                              // reads, 32 = no barrier / DMA wait, 64 = no DMA instructions -- results are meaningless, only the
+                              // timing is read
+};
+
+constexpr int WR_TH = 16, WR_TW = 32;                 // output pixels of a unit
+constexpr int WR_RH = WR_TH + 2, WR_RW = WR_TW + 2;   // raw halo tile
+constexpr int WR_ROW_SLOTS = WR_RW * 4;               // 16-byte slots per raw image row (136)
+constexpr int WR_ROW_BYTES = WR_ROW_SLOTS * 16;       // 2176
+constexpr int WR_RAW_SLOTS = WR_RH * WR_ROW_SLOTS;    // 2448
+constexpr int WR_RAW_PIECES = (WR_RAW_SLOTS + 63) / 64;   // 39 DMA instructions (1 KB each)
+constexpr int WR_U_OFF = WR_RAW_PIECES * 1024;
+constexpr int WR_U_PIECES = 32;                       // 16 components x 16 channels x 32 output channels x 4 bytes
+constexpr int WR_PIECES = WR_RAW_PIECES + WR_U_PIECES;    // 71
+constexpr int WR_WAVES = 8;
+constexpr int WR_NIT = (WR_PIECES + WR_WAVES - 1) / WR_WAVES;   // 9 pieces per wave and slot
+constexpr int WR_RAW_IT = (WR_RAW_PIECES + WR_WAVES - 1) / WR_WAVES;   // its 0..4 can be raw pieces
+constexpr int WR_GROUP_BYTES = WR_NIT * WR_WAVES * 1024;  // 72 KB
+constexpr int WR_LDS_BYTES = 2 * WR_GROUP_BYTES;
+static_assert(WR_LDS_BYTES <= 160 * 1024, "LDS");
+
+// (the DMA / wait / uniformity helpers are those of conv_ring.hip; see the comments there)
+__device__ __forceinline__ void wring_dma16(unsigned lds_addr, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff));
+}
+// timing-only variants of the statement above (ablation): the DMA without the M0 writes (lands wherever M0 points), the M0 writes alone
+__device__ __forceinline__ void wring_dma16_nom0(unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned soff) {
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff));
+}
+__device__ __forceinline__ void wring_m0_only(unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "s"(lds_addr));
+}
+constexpr unsigned kWringOob = 0x7ffffff0u;
+__device__ __forceinline__ unsigned uniw(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ const char *uniw(const char *ptr) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+    return reinterpret_cast<const char *>(((unsigned long long)uniw((unsigned)(a >> 32)) << 32) | uniw((unsigned)a));
+}
+template <class T>
+__device__ __forceinline__ T selw4(const T (&a)[4], int i) {
+    return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3]));
+}
+
+struct WringUnit {
+    int n, y0, x0, cob;
+};
+__device__ __forceinline__ WringUnit wring_unit(const WringParams &p, unsigned u) {
+    WringUnit r;
+    const unsigned cob = u % p.ncob, tile = u / p.ncob;
+    const unsigned tx = tile % (unsigned)p.tiles_x, t2 = tile / (unsigned)p.tiles_x;
+    r.cob = (int)cob, r.x0 = (int)tx, r.y0 = (int)(t2 % (unsigned)p.tiles_y), r.n = (int)(t2 / (unsigned)p.tiles_y);
+    return r;
+}
+
+template <int ABL>   // ABL: timing-only ablation mask (WringParams.ablate), 0 in the product
+__global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const WringParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+
+    // unit assignment: as conv_ring.hip (XCD-contiguous chunk, round-robin inside the XCD); the 32-channel blocks of one tile are
+    // consecutive units, so the CUs of an XCD stage the same raw tile at about the same time and it comes from that L2 once
+    const unsigned G = gridDim.x;
+    const unsigned nxc = G < (unsigned)kXcds ? G : (unsigned)kXcds;
+    const unsigned xcd = blockIdx.x % nxc, slot = blockIdx.x / nxc;
+    const unsigned nx = G / nxc + (xcd < G % nxc ? 1u : 0u);
+    const unsigned c_begin = (unsigned)((unsigned long long)xcd * p.nunits / nxc);
+    const unsigned c_end = (unsigned)((unsigned long long)(xcd + 1) * p.nunits / nxc);
+    if (c_begin + slot >= c_end) return;
+    const unsigned u_begin = c_begin + slot, u_end = c_end, u_step = nx;
+    const unsigned my_units = (u_end - u_begin + u_step - 1) / u_step;
+    const int nchunks = p.nchunks;
+    const unsigned total = my_units * (unsigned)nchunks;
+
+    // ---- DMA descriptors of this lane: piece pc = it * 8 + wv covers the 16-byte LDS slots pc * 64 + lane of a slot image.
+    // Raw slot j -> (image row, pixel x, channel slot s): row = j / 136; inside the row 4 consecutive slots are one pixel, pixels
+    // ordered even x first; the pixel's slots are permuted (header).
+    int ia[WR_RAW_IT], ib[WR_RAW_IT];
+#pragma unroll
+    for (int it = 0; it < WR_RAW_IT; ++it) {
+        const int pc = it * WR_WAVES + wv;
+        const int j = pc * 64 + lane;
+        ia[it] = -1, ib[it] = 0;
+        if (pc < WR_RAW_PIECES && j < WR_RAW_SLOTS) {
+            const int row = j / WR_ROW_SLOTS, r = j - row * WR_ROW_SLOTS;
+            const int pp = r >> 2, sp = r & 3;
+            const int par = pp >= WR_RW / 2 ? 1 : 0, q = pp - par * (WR_RW / 2);
+            const int px = 2 * q + par;
+            const int s = (0x78 >> (2 * (sp ^ ((q >> 2) & 3)))) & 3;   // inverse of P = {0, 3, 1, 2}
+            ia[it] = row << 10 | px, ib[it] = s * 16;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.ur), 0, (int)p.ur_bytes, 0x00020000);
+    unsigned pu = u_begin;
+    int ps = 0, pc0 = 0, pchunk = 0, pbuf = 0;
+    bool pfirst = true;
+    WringUnit PU = wring_unit(p, pu);
+    // One slot's DMA = prep() (scalar: descriptors of the slot the cursor points at, then the cursor moves on) followed by
+    // piece(0 .. WR_NIT - 1), which the matrix phase spreads over its first groups of matrix instructions.  Piece it of wave wv:
+    // it = 0 .. 4 raw piece it * 8 + wv (it = 4: waves 0 .. 6 only), it = 5 .. 8 weight piece (it - 5) * 8 + wv.
+    __amdgpu_buffer_rsrc_t d_rin = rsrc_u;
+    unsigned d_base = 0, d_sin = 0, d_su = 0, d_ldb = 0;
+    int d_oy = 0, d_ox = 0;
+    bool d_kill = false;   // past the last slot (or ablation): the pieces fetch nothing (offsets beyond num_records)
+    int s_ld = p.src_ld[0], s_c = p.src_c[0];   // source ps
+    const char *s_ptr = reinterpret_cast<const char *>(p.src_ptr[0]);
+    auto prep = [&]() {
+        d_kill = pu >= u_end || ((ABL & 1) && !pfirst) || (ABL & 64);
+        pfirst = false;
+        d_base = uniw((unsigned)(pbuf * WR_GROUP_BYTES));
+        pbuf ^= 1;
+        if (pu < u_end) {
+            const size_t img = (size_t)p.H * p.W * s_ld * 4;   // bytes of one sample
+            const char *base_in = uniw(s_ptr + (size_t)PU.n * img);
+            d_rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base_in), 0, (int)uniw((unsigned)img), 0x00020000);
+            d_ldb = (unsigned)s_ld * 4u;
+            d_sin = uniw((unsigned)(pc0 * 4));
+            d_oy = PU.y0 * WR_TH - 1, d_ox = PU.x0 * WR_TW - 1;
+            d_su = uniw((unsigned)(((unsigned)PU.cob * (unsigned)nchunks + (unsigned)pchunk) * (unsigned)(WR_U_PIECES * 1024)));
+            pc0 += 16, ++pchunk;
+            if (pc0 >= s_c) {
+                pc0 = 0, ++ps;
+                if (ps == p.nsrc) {
+                    ps = 0, pchunk = 0, pu += u_step;
+                    if (pu < u_end) PU = wring_unit(p, pu);
+                }
+                s_ld = selw4(p.src_ld, ps), s_c = selw4(p.src_c, ps), s_ptr = reinterpret_cast<const char *>(selw4(p.src_ptr, ps));
+            }
+        }
+    };
+    auto piece = [&](auto it_c) {
+        constexpr int it = decltype(it_c)::value;
+        if constexpr (it < WR_RAW_IT) {
+            const int pc = it * WR_WAVES + wv;   // wave-uniform
+            if (it * WR_WAVES + WR_WAVES <= WR_RAW_PIECES || pc < WR_RAW_PIECES) {
+                const int ly = ia[it] >> 10, lx = ia[it] & 0x3ff;
+                const int ry = d_oy + ly, rx = d_ox + lx;
+                const bool ok = ia[it] >= 0 && ry >= 0 && ry < p.H && rx >= 0 && rx < p.W && !d_kill;
+                const unsigned v = ok ? (unsigned)(ry * p.W + rx) * d_ldb + (unsigned)ib[it] : kWringOob;
+                if constexpr (ABL & 128) wring_dma16_nom0(v, d_rin, d_sin);
+                else if constexpr (ABL & 256) wring_m0_only(d_base + (unsigned)(pc * 1024));
+                else wring_dma16(d_base + (unsigned)(pc * 1024), v, d_rin, d_sin);
+            }
+        } else {
+            const int u = (it - WR_RAW_IT) * WR_WAVES + wv;
+            const unsigned v = d_kill ? kWringOob : (unsigned)(lane * 16);
+            if constexpr (ABL & 128) wring_dma16_nom0(v, rsrc_u, d_su + (unsigned)(u * 1024));
+            else if constexpr (ABL & 256) wring_m0_only(d_base + (unsigned)(WR_U_OFF + u * 1024));
+            else wring_dma16(d_base + (unsigned)(WR_U_OFF + u * 1024), v, rsrc_u, d_su + (unsigned)(u * 1024));
+        }
+    };
+    auto stage_all = [&]() {   // the whole slot at once (prologue)
+        prep();
+        piece(std::integral_constant<int, 0>{}), piece(std::integral_constant<int, 1>{}), piece(std::integral_constant<int, 2>{});
+        piece(std::integral_constant<int, 3>{}), piece(std::integral_constant<int, 4>{}), piece(std::integral_constant<int, 5>{});
+        piece(std::integral_constant<int, 6>{}), piece(std::integral_constant<int, 7>{}), piece(std::integral_constant<int, 8>{});
+    };
+    static_assert(WR_RAW_IT + WR_U_PIECES / WR_WAVES == 9 && WR_U_PIECES % WR_WAVES == 0, "piece() calls below");
+
+    // ---- operand addresses.  A: patch pixel (a, b) of tile (wv, l15) = raw pixel (2 wv + a, 2 l15 + b), channel slot kq
+    int offb[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int q = l15 + (b >> 1), par = b & 1;
+        const int sp = ((0x9C >> (2 * kq)) & 3) ^ ((q >> 2) & 3);   // P[kq] ^ Q
+        offb[b] = 2 * wv * WR_ROW_BYTES + ((par * (WR_RW / 2) + q) * 4 + sp) * 16;
+    }
+    const int b_off = WR_U_OFF + lane * 16;   // + (xi * 2 + nt) * 1024
+    const bool half1 = wv >= 4;
+
+    f32x4 acc[16][2];
+    unsigned cu = u_begin;
+    int cchunk = 0, cbuf = 0;
+    WringUnit CU = wring_unit(p, cu);
+
+    stage_all();   // slot 0
+    for (unsigned s = 0; s < total; ++s) {
+        if (!(ABL & 32)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of slot s have landed (and its epilogue stores are out)
+            __builtin_amdgcn_s_barrier();                       // everybody's have; everybody is done reading slot s - 1
+        }
+        asm volatile("" ::: "memory");
+        prep();                                             // slot s + 1 goes into the buffer slot s - 1 occupied (pieces: below)
+
+        if (cchunk == 0) {
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[xi][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const unsigned char *gbp = lds + (unsigned)(cbuf * WR_GROUP_BYTES);
+        if (!(ABL & 2)) {
+            // The matrix phase is laid out by hand in 64 groups of two matrix instructions (the two 16-channel halves of one
+            // component and k-step: alternating accumulators, so no instruction waits for its predecessor's 40-cycle result),
+            // fenced by sched_barrier: left to itself hipcc sinks every ds_read to its first use and waits for it there, and
+            // chains the four k-steps of one accumulator back to back.  What else a wave has to do is dealt to the groups so that
+            // nothing is needed long before it is there, and so that the two waves of a SIMD do not do the same thing at once:
+            //   head        : the 4 patch pixels component 0 needs and its B operands -- the other 12 pixels follow in the groups
+            //                 of components 0 .. 2 (ablation: all 16 reads in the head cost 33 us of a 208 us launch);
+            //   group (xi, 0): the B operands of component xi + 1 (two ds_read_b128, a component = 256 matrix cycles ahead);
+            //   group (xi, 3): B^T d B for component xi + 1 (hipcc shares the column-pass terms between components);
+            //   group (xi, 0) for the waves 0 - 3, (xi, 2) for their SIMD partners 4 - 7, xi < 9: DMA piece xi of the next slot
+            //                 (a wave-uniform branch; two instances of the phase with compile-time positions spill: the
+            //                 accumulators of the two instances do not meet in the same registers).
+            f32x4 d[4][4];
+            auto rd = [&](int a, int b) {
+                d[a][b] = (ABL & 8) ? (f32x4){(float)lane, 1.f, (float)a, (float)b} : *reinterpret_cast<const f32x4 *>(gbp + offb[b] + a * WR_ROW_BYTES);
+            };
+            auto colop = [&](int i, int b) -> f32x4 {
+                return i == 0 ? d[0][b] - d[2][b] : (i == 1 ? d[1][b] + d[2][b] : (i == 2 ? d[2][b] - d[1][b] : d[1][b] - d[3][b]));
+            };
+            auto vop = [&](int xi) -> f32x4 {
+                const int i = xi >> 2, j = xi & 3;
+                f32x4 v = j == 0 ? colop(i, 0) - colop(i, 2) : (j == 1 ? colop(i, 1) + colop(i, 2) : (j == 2 ? colop(i, 2) - colop(i, 1) : colop(i, 1) - colop(i, 3)));
+                asm volatile("" : "+v"(v));   // computed here, not where hipcc finds its first use
+                return v;
+            };
+            f32x4 bq[2][2];
+            const bool nob = (ABL & 16) != 0;
+            rd(0, 0), rd(0, 2), rd(2, 0), rd(2, 2);
+            bq[0][0] = nob ? (f32x4){1.f, 2.f, 3.f, (float)lane} : *reinterpret_cast<const f32x4 *>(gbp + b_off);
+            bq[0][1] = nob ? (f32x4){1.f, 2.f, 3.f, (float)lane} : *reinterpret_cast<const f32x4 *>(gbp + b_off + 1024);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 vq[2];
+            vq[0] = vop(0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) {
+                const int cur = xi & 1, nxt = cur ^ 1;
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    if (st == 0 && xi < 15) {
+                        bq[nxt][0] = nob ? bq[cur][1] : *reinterpret_cast<const f32x4 *>(gbp + b_off + ((xi + 1) * 2 + 0) * 1024);
+                        bq[nxt][1] = nob ? bq[cur][0] : *reinterpret_cast<const f32x4 *>(gbp + b_off + ((xi + 1) * 2 + 1) * 1024);
+                    }
+                    // the remaining patch pixels, each two groups or more ahead of the first component that needs it
+                    if (xi == 0 && st == 1) rd(0, 1), rd(2, 1);
+                    if (xi == 0 && st == 2) rd(0, 3), rd(2, 3);
+                    if (xi == 1 && st == 1) rd(1, 0), rd(1, 2);
+                    if (xi == 1 && st == 2) rd(1, 1), rd(1, 3);
+                    if (xi == 2 && st == 1) rd(3, 0), rd(3, 2);
+                    if (xi == 2 && st == 2) rd(3, 1), rd(3, 3);
+                    if (xi < 9 && (st == 0 || st == 2) && (st == 2) == half1) {   // wave-uniform
+                        if (xi == 0) piece(std::integral_constant<int, 0>{});
+                        if (xi == 1) piece(std::integral_constant<int, 1>{});
+                        if (xi == 2) piece(std::integral_constant<int, 2>{});
+                        if (xi == 3) piece(std::integral_constant<int, 3>{});
+                        if (xi == 4) piece(std::integral_constant<int, 4>{});
+                        if (xi == 5) piece(std::integral_constant<int, 5>{});
+                        if (xi == 6) piece(std::integral_constant<int, 6>{});
+                        if (xi == 7) piece(std::integral_constant<int, 7>{});
+                        if (xi == 8) piece(std::integral_constant<int, 8>{});
+                    }
+                    if (st == 3 && xi < 15) vq[nxt] = vop(xi + 1);
+                    acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vq[cur][st], bq[cur][0][st], acc[xi][0], 0, 0, 0);
+                    acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vq[cur][st], bq[cur][1][st], acc[xi][1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+            piece(std::integral_constant<int, 0>{}), piece(std::integral_constant<int, 1>{}), piece(std::integral_constant<int, 2>{});
+            piece(std::integral_constant<int, 3>{}), piece(std::integral_constant<int, 4>{}), piece(std::integral_constant<int, 5>{});
+            piece(std::integral_constant<int, 6>{}), piece(std::integral_constant<int, 7>{}), piece(std::integral_constant<int, 8>{});
+        }
+
+        if (cchunk == nchunks - 1) {
+            // ---- epilogue of unit cu: lane (l15, kq) holds, for the tiles tx = 4 kq + r of its wave's tile row and the channel pair
+            // (2 l15, 2 l15 + 1) of the unit's block, all 16 components: Y = A^T M A in registers, bias, activation, 8-byte stores
+            const int co = CU.cob * 32 + 2 * l15;
+            float bs0 = 0.f, bs1 = 0.f;
+            if (p.bias) bs0 = p.bias[co], bs1 = p.bias[co + 1];
+            const int oy = CU.y0 * WR_TH + 2 * wv;
+            float *orow = p.out + ((size_t)(CU.n * p.H + oy) * p.W + CU.x0 * WR_TW) * p.out_ld + co;
+            const size_t rs = (size_t)p.W * p.out_ld;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float y[2][2][2];   // [nt][row][col]
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    float tc[4][2];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float m0 = acc[i * 4 + 0][nt][r], m1 = acc[i * 4 + 1][nt][r], m2 = acc[i * 4 + 2][nt][r], m3 = acc[i * 4 + 3][nt][r];
+                        tc[i][0] = m0 + m1 + m2, tc[i][1] = m1 - m2 - m3;
+                    }
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        y[nt][0][b] = tc[0][b] + tc[1][b] + tc[2][b];
+                        y[nt][1][b] = tc[1][b] - tc[2][b] - tc[3][b];
+                    }
+                }
+                if (!(ABL & 4)) {
+                    float *o = orow + (size_t)(2 * (4 * kq + r)) * p.out_ld;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            *reinterpret_cast<float2 *>(o + a * rs + (size_t)b * p.out_ld) =
+                                make_float2(act_apply(y[0][a][b] + bs0, p.act), act_apply(y[1][a][b] + bs1, p.act));
+                } else if (y[0][0][0] == 12345.678f) {
+                    p.out[0] = y[1][1][1];   // keep the accumulators live
+                }
+            }
+            cchunk = 0, cu += u_step;
+            if (cu < u_end) CU = wring_unit(p, cu);
+        } else {
+            ++cchunk;
+        }
+        cbuf ^= 1;
+    }
+}
+
+// U ring layout from the component-major layout uw[16][cin_pad][cout] of pws_pack_conv_weight_wino (cin_pad % 16 == 0, cout % 32 == 0)
+__global__ void wring_pack_kernel(const float *__restrict__ uw, float *__restrict__ ur, int cin_pad, int cout) {
+    const size_t plane = (size_t)cin_pad * cout;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plane) return;
+    const int co = (int)(i % cout), ci = (int)(i / cout);
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) ur[wring_index(xi, ci, co, cin_pad / 16)] = uw[(size_t)xi * plane + i];
+}
+
+int wring_pack(const float *uw, float *ur, int cin_pad, int cout, hipStream_t st) {
+    const size_t plane = (size_t)cin_pad * cout;
+    hipLaunchKernelGGL(wring_pack_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, uw, ur, cin_pad, cout);
+    return check_launch("wring_pack_kernel");
+}
+
+template <int ABL>
+static int wring_launch(const WringParams &p, unsigned grid, hipStream_t st) {
+    static bool attr_set = false;   // benign race: idempotent
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_ring_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS_BYTES);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(wino_ring_kernel, %d B LDS): %s", WR_LDS_BYTES, hipGetErrorString(e));
+            return PWS_EHIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wino_ring_kernel<ABL>, dim3(grid), dim3(WR_WAVES * 64), WR_LDS_BYTES, st, p);
+    return check_launch("wino_ring_kernel");
+}
+
+// Runs a 3x3 stride-1 forward launch on the Winograd ring kernel when it is covered: fp32 NHWC sources in multiples of 16
+// channels (16-byte aligned), whole 16 x 32 units, cout a multiple of 32, 8-byte aligned output pixels and enough units to occupy
+// the chip.  `uw` = the buffer of pws_pack_conv_weight_wino (ring layout behind the component-major one).  Returns 1 when not
+// covered (the caller goes on to wino_kernel<0> / the direct kernels).
+int wring_try(const pws_conv_args *a, const ProfHint &ph, hipStream_t st) {
+    if (!a->w_wino || g_experiment == 50) return 1;
+    if (a->h % WR_TH != 0 || a->w % WR_TW != 0 || a->cout % 32 != 0 || a->out_ld % 2 != 0 || (reinterpret_cast<size_t>(a->out) & 7)) return 1;
+    int cin = 0;
+    for (int s = 0; s < a->nsrc; ++s) {
+        const pws_src &sr = a->src[s];
+        if (sr.channels % 16 != 0 || sr.ld % 4 != 0 || (reinterpret_cast<size_t>(sr.ptr) & 15)) return 1;
+        if ((size_t)a->h * a->w * 4 * sr.ld >= (1u << 31)) return 1;
+        cin += sr.channels;
+    }
+    const size_t plane = (size_t)cin * a->cout;
+    if (16 * plane * 4 >= (1u << 31)) return 1;
+    WringParams p{};
+    for (int s = 0; s < a->nsrc; ++s) p.src_ptr[s] = a->src[s].ptr, p.src_c[s] = a->src[s].channels, p.src_ld[s] = a->src[s].ld;
+    p.nsrc = a->nsrc, p.N = a->n, p.H = a->h, p.W = a->w, p.cout = a->cout;
+    p.ur = a->w_wino + 16 * plane, p.ur_bytes = (unsigned)(16 * plane * 4);
+    p.bias = a->bias, p.act = a->act, p.out = a->out, p.out_ld = a->out_ld;
+    p.tiles_x = a->w / WR_TW, p.tiles_y = a->h / WR_TH;
+    p.ncob = (unsigned)(a->cout / 32);
+    p.nunits = (unsigned)(p.tiles_x * p.tiles_y) * (unsigned)a->n * p.ncob;
+    p.nchunks = cin / 16;
+    p.ablate = g_experiment >= 51 && g_experiment <= 57 ? g_experiment - 50 : (g_experiment >= 1000 && g_experiment < 1512 ? g_experiment - 1000 : 0);
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    // a unit is nchunks x 8 192 matrix cycles: fewer units than CUs leave CUs idle for the whole launch, and a non-integer number of
+    // rounds costs its tail -- taken from 3/4 of the chip upwards (PWS_OPT_EXPERIMENT 58 forces it for the tests)
+    if (p.nunits < (unsigned)(ncu * 3 / 4) && g_experiment != 58) return 1;
+    ProfScope prof(KID_CONV_WRING, ph.flops, ph.bytes, st);
+    const unsigned grid = p.nunits < (unsigned)ncu ? p.nunits : (unsigned)ncu;   // one persistent workgroup per CU
+    switch (p.ablate) {
+    case 0: return wring_launch<0>(p, grid, st);
+    case 1: return wring_launch<1>(p, grid, st);
+    case 2: return wring_launch<2>(p, grid, st);
+    case 4: return wring_launch<4>(p, grid, st);
+    case 64: return wring_launch<64>(p, grid, st);
+    case 96: return wring_launch<96>(p, grid, st);
+    case 104: return wring_launch<104>(p, grid, st);
+    case 112: return wring_launch<112>(p, grid, st);
+    case 120: return wring_launch<120>(p, grid, st);
+    case 124: return wring_launch<124>(p, grid, st);
+    case 128: return wring_launch<128>(p, grid, st);
+    case 256: return wring_launch<256>(p, grid, st);
+    default: set_error("wino_ring_kernel: ablation mask %d is not instantiated", p.ablate); return PWS_EINVAL;
+    }
+}
+
+}  // namespace pws

@@ -79,6 +79,17 @@ __global__ void __launch_bounds__(256) wino_all_kernel(const PackAllArgs a, floa
         uw[(size_t)(r * 4 + 2) * plane + i] = 0.5f * (u[r][0] - u[r][1] + u[r][2]);
         uw[(size_t)(r * 4 + 3) * plane + i] = u[r][2];
     }
+    if (wring_layout_ok(L.cin_pad, L.cout)) {   // the ring layout of the same values (conv_wring.hip) behind the component-major one
+        float *ur = uw + 16 * plane;
+        const int co = (int)(i % L.cout), ci = (int)(i / L.cout), nch = L.cin_pad / 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ur[wring_index(r * 4 + 0, ci, co, nch)] = u[r][0];
+            ur[wring_index(r * 4 + 1, ci, co, nch)] = 0.5f * (u[r][0] + u[r][1] + u[r][2]);
+            ur[wring_index(r * 4 + 2, ci, co, nch)] = 0.5f * (u[r][0] - u[r][1] + u[r][2]);
+            ur[wring_index(r * 4 + 3, ci, co, nch)] = u[r][2];
+        }
+    }
 }
 
 // ---- stage 3: bf16 copies [plane][ncols pad 64][krows pad 32] of an fp32 [plane][krows][ncols] layout (forward or data

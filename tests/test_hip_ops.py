@@ -220,6 +220,48 @@ def test_conv_winograd_vs_oracle(hip, oracle, kname, shape, src_c, cout):
     np.testing.assert_allclose(nchw(got), ref, rtol=0, atol=5e-5)  # Winograd rounding: a few 1e-6 at O(1) outputs
 
 
+@pytest.mark.parametrize("kname,shape,src_c,cout", [
+    ("CONV_K3S1", (2, 32, 64), [32, 16], 64),     # virtual concat of two sources, 3 chunks, several units per image
+    ("CONVT_K3S1", (3, 16, 32), [64], 32),        # one unit per image (all four borders inside the unit), flipped taps
+    ("CONV_K3S1", (1, 48, 96), [16], 96),         # one chunk per unit: every barrier is a unit boundary
+    ("CONV_K3S1", (8, 64, 64), [128], 128),       # >= 256 units: several units per workgroup (the product's regime)
+])
+def test_conv_winograd_ring_vs_oracle(hip, oracle, kname, shape, src_c, cout):
+    """3x3 stride-1 layers through the persistent LDS-ring Winograd kernel (conv_wring.hip; PWS_OPT_EXPERIMENT 58 takes it
+    whatever the number of units, 50 switches it off) against the C oracle and the first-generation Winograd kernel."""
+    A = hip
+    L = A.lib()
+    kind = getattr(A, kname)
+    n, h, w = shape
+    rs = np.random.RandomState(zlib.crc32(repr((kname, shape, cout, "wr")).encode()))
+    cin = sum(src_c)
+    is_t = kname.startswith("CONVT")
+    x = rs.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (rs.standard_normal((cin, cout, 3, 3) if is_t else (cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rs.standard_normal((cout,)).astype(np.float32)
+    ref = (oracle.conv_transpose2d if is_t else oracle.conv2d)(x, wt, b, 1, 1, oracle.ACT_LRELU)
+    xs = nhwc(x)
+    srcs, c0 = [], 0
+    for c in src_c:
+        srcs.append(np.ascontiguousarray(xs[..., c0:c0 + c]))
+        c0 += c
+    got = {}
+    try:
+        for force in (58, 50):
+            L.pws_set_option(100, force)
+            L.pws_prof_enable(1)
+            got[force] = run_conv(A, kind, srcs, wt, b, 1, cout, wino=True)
+            L.pws_prof_enable(0)
+            names = [r[0] for r in A.prof_collect()]
+            assert ("wino_ring_kernel<F(2x2,3x3)>" in names) == (force == 58), names
+    finally:
+        L.pws_prof_enable(0)
+        L.pws_set_option(100, 0)
+    assert not np.isnan(got[58]).any()
+    np.testing.assert_allclose(nchw(got[58]), ref, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(got[58], got[50], rtol=0, atol=5e-5)
+
+
 def test_conv_first_layer_nchw_31ch(hip, oracle):
     """transfer: k5 s1 p2 on the reference's NCHW 31-channel window (lib/networks_cascading.py:112,153)."""
     A = hip
