@@ -107,14 +107,20 @@ int pws_pack_conv_weight(const float *w_torch, float *w_packed, int kind, int ci
                          pws_stream_t stream);
 
 /* Winograd F(2x2,3x3) weights U = G g G^T as [16][cin padded to 16][cout], computed from the PACKED weights of a
- * K3S1 / CONVT_K3S1 layer (so the transposed conv's tap flip is already applied); when cout % 32 == 0 the same values follow
- * once more in the layout of the LDS-ring Winograd kernel (pws_packed_wino_floats covers both). */
+ * K3S1 / CONVT_K3S1 layer (so the transposed conv's tap flip is already applied). */
 size_t pws_packed_wino_floats(int cin, int cout);
 int pws_pack_conv_weight_wino(const float *w_packed, float *w_wino, int cin, int cout, pws_stream_t stream);
 /* The same for ConvTranspose2d k4 s2 p1 (CONVT_K4S2): each of the 4 output parity classes is a 2x2 correlation, run as
  * Winograd F(3x3,2x2) on 4x4 input patches; U as [4 classes][16][cin padded to 16][cout] from the PACKED weights. */
 size_t pws_packed_wino_ct4_floats(int cin, int cout);
 int pws_pack_conv_weight_wino_ct4(const float *w_packed, float *w_wino, int cin, int cout, pws_stream_t stream);
+
+/* Winograd weights in the layout of the persistent LDS-ring kernel (second generation, taken when the map consists of whole
+ * 16 x 32-pixel units and fills the chip): F(2x2,3x3) for K3S1 / CONVT_K3S1 (16 components), F(2x2,2x2) per output parity class
+ * for CONVT_K4S2 (2 x 18 components), from the PACKED weights.  Needs cout % 32 == 0 (pws_packed_wring_floats returns 0
+ * otherwise: leave pws_conv_args.w_wring NULL). */
+size_t pws_packed_wring_floats(int kind, int cin, int cout);
+int pws_pack_conv_weight_wring(const float *w_packed, float *w_wring, int kind, int cin, int cout, pws_stream_t stream);
 
 /* bf16 copy of a packed weight for the bf16 matrix-core kernels: w_packed is [planes][krows][ncols] fp32 (the forward
  * layout: planes = taps (x4 classes for CONVT_K4S2), krows = cin padded to 16, ncols = cout; or the data-gradient layout:
@@ -164,6 +170,8 @@ typedef struct pws_conv_args {
     int store;        /* PWS_STORE_FP32 (0) | PWS_STORE_BF16: every src[].ptr and `out` then point to bf16 elements (channels /
                          ld / out_ld still count ELEMENTS; ld % 8 == 0, out_ld even).  Needs math == PWS_MATH_BF16 and a kind
                          the bf16 kernels cover.  Halves the activation traffic of the bf16 path. */
+    const float *w_wring; /* optional: ring-layout Winograd weights from pws_pack_conv_weight_wring (K3S1 / CONVT_K3S1 / CONVT_K4S2,
+                         fp32 NHWC sources): tried before w_wino and the direct kernels */
 } pws_conv_args;
 
 int pws_conv2d_fwd(const pws_conv_args *args, pws_stream_t stream);

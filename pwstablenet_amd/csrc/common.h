@@ -47,7 +47,7 @@ enum KernelId {
     KID_CONV_K3S1_BIG = 0, KID_CONV_K3S1_SMALL, KID_CONV_K3S2_BIG, KID_CONV_K3S2_SMALL, KID_CONV_K5S1, KID_CONVT4_BIG,
     KID_CONVT4_SMALL, KID_THETA_HEAD, KID_FIELD_HEAD, KID_GRID_SAMPLE_FWD, KID_GRID_SAMPLE_BWD, KID_UPSAMPLE_GRID_SAMPLE_FWD,
     KID_UPSAMPLE, KID_AFFINE_GRID, KID_ADAM, KID_PACK, KID_DGRAD_K4S2, KID_DGRAD_SP3, KID_WGRAD, KID_ACT_BWD, KID_FIELD_HEAD_BWD,
-    KID_THETA_HEAD_BWD, KID_CONV_WINO, KID_CONV_BF16, KID_WGRAD_BF16, KID_CONV_WINO_CT4, KID_UPSAMPLE_GRID_SAMPLE_U8, KID_OBJECTIVE, KID_CONV_RING, KID_CONV_RINGF, KID_CONV_WRING, KID_COUNT
+    KID_THETA_HEAD_BWD, KID_CONV_WINO, KID_CONV_BF16, KID_WGRAD_BF16, KID_CONV_WINO_CT4, KID_UPSAMPLE_GRID_SAMPLE_U8, KID_OBJECTIVE, KID_CONV_RING, KID_CONV_RINGF, KID_CONV_WRING, KID_CONV_WRING_CT4, KID_COUNT
 };
 extern bool g_two_queues;
 extern int g_math;  // PWS_OPT_MATH
@@ -84,18 +84,66 @@ int theta_bwd_bn_lin(const float *dz2, const float *h, int n, int hidden, const 
 int theta_bwd_flat(const float *x, int n, int c, int hidden, const float *w_flat, const float *dz1, float *dw_flat, float *dx,
                    int dx_accumulate, hipStream_t st);
 int wino_k3s1_launch(const pws_conv_args *a, const ProfHint &ph, hipStream_t st);  // conv_wino.hip
-// conv_wring.hip: Winograd F(2x2,3x3) on the LDS ring.  Its weights follow the component-major ones in the buffer of
-// pws_pack_conv_weight_wino when wring_layout_ok(): element (component xi, input channel ci, output channel co) at wring_index.
+// conv_wring.hip: Winograd on the persistent LDS ring (F(2x2,3x3) for the 3x3 stride-1 kinds, F(2x2,2x2) per parity class for the
+// transposed k4 s2 kind); weights = pws_conv_args.w_wring (pws_pack_conv_weight_wring).
 int wring_try(const pws_conv_args *a, const ProfHint &ph, hipStream_t st);   // 1: not covered
-int wring_pack(const float *uw, float *ur, int cin_pad, int cout, hipStream_t st);
-__host__ __device__ inline bool wring_layout_ok(int cin_pad, int cout) { return cin_pad % 16 == 0 && cout % 32 == 0; }
-// [32-channel block][16-channel chunk][xi][nt][kq][co16][st]: co = 32 block + 2 co16 + nt, ci = 16 chunk + 4 kq + st -- one
-// (block, chunk) is 32 KB contiguous, and inside it a 1 KB run is one lane-linear B-operand image of v_mfma_f32_16x16x4_f32
-__host__ __device__ inline size_t wring_index(int xi, int ci, int co, int nchunks) {
+int wring_pack(const float *pk, float *ur, int cin_pad, int cout, int ct4, hipStream_t st);
+// Ring layout [32-channel block][16-channel chunk][component xi][nt][kq][co16][st]: co = 32 block + 2 co16 + nt,
+// ci = 16 chunk + 4 kq + st -- one (block, chunk) is NC x 2 KB contiguous, and inside it a 1 KB run is one lane-linear B-operand
+// image of v_mfma_f32_16x16x4_f32 (lane = kq * 16 + co16 supplies the k-steps st = 0..3 of its channel).
+__host__ __device__ inline size_t wring_index(int nc, int xi, int ci, int co, int nchunks) {
     const int cob = co >> 5, c32 = co & 31, co16 = c32 >> 1, nt = c32 & 1;
     const int chunk = ci >> 4, kq = (ci >> 2) & 3, st = ci & 3;
-    return ((((((size_t)cob * nchunks + chunk) * 16 + xi) * 2 + nt) * 4 + kq) * 16 + co16) * 4 + st;
+    return ((((((size_t)cob * nchunks + chunk) * nc + xi) * 2 + nt) * 4 + kq) * 16 + co16) * 4 + st;
 }
+#ifdef __HIPCC__
+// element i = ci * cout + co of a layer's ring-layout Winograd weights from its packed weights pk[plane index][cin_pad][cout]
+__device__ inline void wring_pack_element(const float *__restrict__ pk, float *__restrict__ ur, size_t plane, size_t i, int cin_pad, int cout,
+                                          int ct4) {
+    const int co = (int)(i % cout), ci = (int)(i / cout), nch = cin_pad / 16;
+    if (!ct4) {   // F(2x2,3x3): U = G g G^T, G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]]
+        float g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) g[r][s] = pk[(size_t)(r * 3 + s) * plane + i];
+        float u[4][3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            u[0][s] = g[0][s], u[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]), u[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
+            u[3][s] = g[2][s];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ur[wring_index(16, r * 4 + 0, ci, co, nch)] = u[r][0];
+            ur[wring_index(16, r * 4 + 1, ci, co, nch)] = 0.5f * (u[r][0] + u[r][1] + u[r][2]);
+            ur[wring_index(16, r * 4 + 2, ci, co, nch)] = 0.5f * (u[r][0] - u[r][1] + u[r][2]);
+            ur[wring_index(16, r * 4 + 3, ci, co, nch)] = u[r][2];
+        }
+    } else {      // F(2x2,2x2) per parity class: G = [[1,0],[1,1],[0,1]]; [py][... 18 components = (px, i, j) ...]
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                float g[2][2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) g[r][s] = pk[(size_t)((py * 2 + px) * 4 + r * 2 + s) * plane + i];
+                float u[3][2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) u[0][s] = g[0][s], u[1][s] = g[0][s] + g[1][s], u[2][s] = g[1][s];
+                float *o = ur + (size_t)py * 18 * plane;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    o[wring_index(18, px * 9 + r * 3 + 0, ci, co, nch)] = u[r][0];
+                    o[wring_index(18, px * 9 + r * 3 + 1, ci, co, nch)] = u[r][0] + u[r][1];
+                    o[wring_index(18, px * 9 + r * 3 + 2, ci, co, nch)] = u[r][1];
+                }
+            }
+    }
+}
+#endif
 
 // bf16 operand helpers (conv_bf16.hip, wgrad_bf16.hip)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -433,7 +433,7 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
         }
         // Winograd F(2x2,3x3) when there is enough of the map to fill the chip (measured cross-over, tools/conv_bench.py:
         // 256->256 @32x32 x8: 104 -> 79 us; 512->512 @16x16 x8: 106 -> 138 us); the deep maps stay direct + split-K
-        if (a->w_wino && !nchw && !bf16) {   // second-generation Winograd (persistent LDS ring) where whole 16 x 32 units fill the chip
+        if (a->w_wring && !nchw && !bf16) {   // second-generation Winograd (persistent LDS ring) where whole 16 x 32 units fill the chip
             const int rc = wring_try(a, ProfHint{pi.flops, pi.bytes}, st);
             if (rc != 1) return rc;
         }
@@ -480,6 +480,10 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
         // Measured (tools/conv_bench.py, N=8): 256->64 @128x128 646 vs 661 us direct, but 512->64 @64x64 473 vs 333 us -- the
         // 3-pixel tiles waste 21-41 % of a 64/32-pixel map and the 9-output epilogue is 2.25x the F(2x2,3x3) one -- so the
         // generator's executor does not pack these weights; the path stays available for large maps.
+        if (a->w_wring && !nchw && !bf16) {   // Winograd F(2x2,2x2) per parity class on the LDS ring (whole 16 x 32 input units)
+            const int rc = wring_try(a, ProfHint{pi.flops, pi.bytes}, st);
+            if (rc != 1) return rc;
+        }
         const long wb = cdiv(a->w, 24) * cdiv(a->h, 12) * a->n * cdiv(a->cout, 64) * 4;
         if (a->w_wino && a->h >= 24 && a->w >= 24 && wb >= 256) return wino_k3s1_launch(a, ProfHint{pi.flops, pi.bytes}, st);
         if (!bf16 && !nchw) {

@@ -418,9 +418,7 @@ extern "C" int pws_pack_conv_weight_wino_ct4(const float *w_packed, float *w_win
 
 extern "C" size_t pws_packed_wino_floats(int cin, int cout) {
     if (cin <= 0 || cout <= 0) return 0;
-    const int cin_pad = (cin + 15) / 16 * 16;
-    // the ring layout of the same values (conv_wring.hip) follows the component-major one where that kernel can run
-    return (size_t)16 * cin_pad * cout * (pws::wring_layout_ok(cin_pad, cout) ? 2 : 1);
+    return (size_t)16 * ((cin + 15) / 16 * 16) * cout;
 }
 
 extern "C" int pws_pack_conv_weight_wino(const float *w_packed, float *w_wino, int cin, int cout, pws_stream_t stream) {
@@ -428,8 +426,5 @@ extern "C" int pws_pack_conv_weight_wino(const float *w_packed, float *w_wino, i
     const size_t plane = (size_t)((cin + 15) / 16 * 16) * cout;
     hipLaunchKernelGGL(pws::wino_pack_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, pws::as_stream(stream), w_packed,
                        w_wino, plane);
-    const int rc = pws::check_launch("wino_pack_kernel");
-    const int cin_pad = (cin + 15) / 16 * 16;
-    if (rc != PWS_OK || !pws::wring_layout_ok(cin_pad, cout)) return rc;
-    return pws::wring_pack(w_wino, w_wino + 16 * plane, cin_pad, cout, pws::as_stream(stream));
+    return pws::check_launch("wino_pack_kernel");
 }

@@ -26,6 +26,14 @@
 //     hardware serves together in a ds_read_b128 (tiles x and channel slots mixed) hit 16 different 4-bank groups for the
 //     patch columns 0 and 1 and at most two-way conflicts for columns 2 and 3.  Zero padding = DMA offsets beyond num_records.
 // Numerics: as conv_wino.hip (fp32 Winograd, ~1e-6 relative to the direct form); the K order differs.
+//
+// MODE 1 -- ConvTranspose2d k4 s2 p1 on the same machinery: output parity class (py, px) is a 2x2 correlation of the input
+// (pack.hip), run as Winograd F(2x2, 2x2): 3x3 patches, 9 multiplies for 4 outputs x 4 taps (1.78x fewer), transforms with
+// coefficients 0 / +-1 only:   B^T = [[1,-1,0],[0,1,0],[0,-1,1]]   G = [[1,0],[1,1],[0,1]]   A^T = [[1,1,0],[0,1,1]].
+// The four classes of a tile read the SAME 4x4 patch as F(2x2,3x3) (class (py, px) its 3x3 sub-patch at (py, px)), so the raw tile,
+// its LDS layout and the DMA are unchanged; a unit = 16 x 32 class pixels x 32 channels x the two classes of one py (2 x 9 = 18
+// components, 144 accumulator registers, 36 KB of weights per slot), and its outputs are the rows 2 y + py of a 32 x 64 region.
+// Unlike F(3x3,2x2) (conv_wino.hip MODE 1: 3-pixel tiles waste 21-41 % of a 64- or 32-pixel map) the tiles divide the maps.
 #include <type_traits>
 
 #include "conv_common.h"
@@ -44,7 +52,7 @@ struct WringParams {
     float *out;
     int out_ld;
     int tiles_x, tiles_y;
-    unsigned ncob, nunits;
+    unsigned ncob, ncls, nunits;
     int nchunks;              // sum(src_c) / 16
     int ablate;               // measurement only (PWS_OPT_EXPERIMENT 51..57, or 1000 + mask): 1 = DMA pieces fetch nothing after the
                               // first slot, 2 = no matrix phase, 4 = no epilogue stores, 8 = no A-operand reads, 16 = no B-operand
@@ -59,14 +67,20 @@ constexpr int WR_ROW_BYTES = WR_ROW_SLOTS * 16;       // 2176
 constexpr int WR_RAW_SLOTS = WR_RH * WR_ROW_SLOTS;    // 2448
 constexpr int WR_RAW_PIECES = (WR_RAW_SLOTS + 63) / 64;   // 39 DMA instructions (1 KB each)
 constexpr int WR_U_OFF = WR_RAW_PIECES * 1024;
-constexpr int WR_U_PIECES = 32;                       // 16 components x 16 channels x 32 output channels x 4 bytes
-constexpr int WR_PIECES = WR_RAW_PIECES + WR_U_PIECES;    // 71
 constexpr int WR_WAVES = 8;
-constexpr int WR_NIT = (WR_PIECES + WR_WAVES - 1) / WR_WAVES;   // 9 pieces per wave and slot
 constexpr int WR_RAW_IT = (WR_RAW_PIECES + WR_WAVES - 1) / WR_WAVES;   // its 0..4 can be raw pieces
-constexpr int WR_GROUP_BYTES = WR_NIT * WR_WAVES * 1024;  // 72 KB
-constexpr int WR_LDS_BYTES = 2 * WR_GROUP_BYTES;
-static_assert(WR_LDS_BYTES <= 160 * 1024, "LDS");
+template <int MODE>
+struct WrGeo {
+    static constexpr int NC = MODE == 0 ? 16 : 18;       // components a wave accumulates
+    static constexpr int NCLS = MODE == 0 ? 1 : 2;       // units per (tile, channel block): MODE 1 = the two py
+    static constexpr int U_PIECES = NC * 2;              // NC components x 16 channels x 32 output channels x 4 bytes / 1 KB
+    static constexpr int U_IT = (U_PIECES + WR_WAVES - 1) / WR_WAVES;
+    static constexpr int NIT = WR_RAW_IT + U_IT;         // DMA pieces per wave and slot (9 / 10)
+    static constexpr int GROUP_BYTES = (WR_RAW_PIECES + U_PIECES) * 1024 + (MODE == 0 ? 1024 : 0);   // 72 KB / 75 KB
+    static constexpr int LDS_BYTES = 2 * GROUP_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(NIT <= NC, "one DMA piece per component");
+};
 
 // (the DMA / wait / uniformity helpers are those of conv_ring.hip; see the comments there)
 __device__ __forceinline__ void wring_dma16(unsigned lds_addr, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned soff) {
@@ -95,18 +109,22 @@ __device__ __forceinline__ T selw4(const T (&a)[4], int i) {
 }
 
 struct WringUnit {
-    int n, y0, x0, cob;
+    int n, y0, x0, cob, py;
 };
 __device__ __forceinline__ WringUnit wring_unit(const WringParams &p, unsigned u) {
     WringUnit r;
-    const unsigned cob = u % p.ncob, tile = u / p.ncob;
+    const unsigned cls = u % p.ncls, u2 = u / p.ncls;
+    const unsigned cob = u2 % p.ncob, tile = u2 / p.ncob;
+    r.py = (int)cls;
     const unsigned tx = tile % (unsigned)p.tiles_x, t2 = tile / (unsigned)p.tiles_x;
     r.cob = (int)cob, r.x0 = (int)tx, r.y0 = (int)(t2 % (unsigned)p.tiles_y), r.n = (int)(t2 / (unsigned)p.tiles_y);
     return r;
 }
 
-template <int ABL>   // ABL: timing-only ablation mask (WringParams.ablate), 0 in the product
+template <int MODE, int ABL>   // ABL: timing-only ablation mask (WringParams.ablate), 0 in the product
 __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const WringParams p) {
+    using G_ = WrGeo<MODE>;
+    constexpr int NC = G_::NC;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -129,19 +147,19 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
     // ---- DMA descriptors of this lane: piece pc = it * 8 + wv covers the 16-byte LDS slots pc * 64 + lane of a slot image.
     // Raw slot j -> (image row, pixel x, channel slot s): row = j / 136; inside the row 4 consecutive slots are one pixel, pixels
     // ordered even x first; the pixel's slots are permuted (header).
-    int ia[WR_RAW_IT], ib[WR_RAW_IT];
+    int ia[WR_RAW_IT];   // s << 20 | row << 10 | x, or -1
 #pragma unroll
     for (int it = 0; it < WR_RAW_IT; ++it) {
         const int pc = it * WR_WAVES + wv;
         const int j = pc * 64 + lane;
-        ia[it] = -1, ib[it] = 0;
+        ia[it] = -1;
         if (pc < WR_RAW_PIECES && j < WR_RAW_SLOTS) {
             const int row = j / WR_ROW_SLOTS, r = j - row * WR_ROW_SLOTS;
             const int pp = r >> 2, sp = r & 3;
             const int par = pp >= WR_RW / 2 ? 1 : 0, q = pp - par * (WR_RW / 2);
             const int px = 2 * q + par;
             const int s = (0x78 >> (2 * (sp ^ ((q >> 2) & 3)))) & 3;   // inverse of P = {0, 3, 1, 2}
-            ia[it] = row << 10 | px, ib[it] = s * 16;
+            ia[it] = s << 20 | row << 10 | px;
         }
     }
     const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.ur), 0, (int)p.ur_bytes, 0x00020000);
@@ -161,7 +179,7 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
     auto prep = [&]() {
         d_kill = pu >= u_end || ((ABL & 1) && !pfirst) || (ABL & 64);
         pfirst = false;
-        d_base = uniw((unsigned)(pbuf * WR_GROUP_BYTES));
+        d_base = uniw((unsigned)(pbuf * G_::GROUP_BYTES));
         pbuf ^= 1;
         if (pu < u_end) {
             const size_t img = (size_t)p.H * p.W * s_ld * 4;   // bytes of one sample
@@ -170,7 +188,7 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
             d_ldb = (unsigned)s_ld * 4u;
             d_sin = uniw((unsigned)(pc0 * 4));
             d_oy = PU.y0 * WR_TH - 1, d_ox = PU.x0 * WR_TW - 1;
-            d_su = uniw((unsigned)(((unsigned)PU.cob * (unsigned)nchunks + (unsigned)pchunk) * (unsigned)(WR_U_PIECES * 1024)));
+            d_su = uniw((unsigned)((((unsigned)PU.py * p.ncob + (unsigned)PU.cob) * (unsigned)nchunks + (unsigned)pchunk) * (unsigned)(G_::U_PIECES * 1024)));
             pc0 += 16, ++pchunk;
             if (pc0 >= s_c) {
                 pc0 = 0, ++ps;
@@ -187,20 +205,22 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
         if constexpr (it < WR_RAW_IT) {
             const int pc = it * WR_WAVES + wv;   // wave-uniform
             if (it * WR_WAVES + WR_WAVES <= WR_RAW_PIECES || pc < WR_RAW_PIECES) {
-                const int ly = ia[it] >> 10, lx = ia[it] & 0x3ff;
+                const int ly = (ia[it] >> 10) & 0x3ff, lx = ia[it] & 0x3ff;
                 const int ry = d_oy + ly, rx = d_ox + lx;
                 const bool ok = ia[it] >= 0 && ry >= 0 && ry < p.H && rx >= 0 && rx < p.W && !d_kill;
-                const unsigned v = ok ? (unsigned)(ry * p.W + rx) * d_ldb + (unsigned)ib[it] : kWringOob;
+                const unsigned v = ok ? (unsigned)(ry * p.W + rx) * d_ldb + (unsigned)((ia[it] >> 20) * 16) : kWringOob;
                 if constexpr (ABL & 128) wring_dma16_nom0(v, d_rin, d_sin);
                 else if constexpr (ABL & 256) wring_m0_only(d_base + (unsigned)(pc * 1024));
                 else wring_dma16(d_base + (unsigned)(pc * 1024), v, d_rin, d_sin);
             }
         } else {
             const int u = (it - WR_RAW_IT) * WR_WAVES + wv;
-            const unsigned v = d_kill ? kWringOob : (unsigned)(lane * 16);
-            if constexpr (ABL & 128) wring_dma16_nom0(v, rsrc_u, d_su + (unsigned)(u * 1024));
-            else if constexpr (ABL & 256) wring_m0_only(d_base + (unsigned)(WR_U_OFF + u * 1024));
-            else wring_dma16(d_base + (unsigned)(WR_U_OFF + u * 1024), v, rsrc_u, d_su + (unsigned)(u * 1024));
+            if ((it - WR_RAW_IT) * WR_WAVES + WR_WAVES <= G_::U_PIECES || u < G_::U_PIECES) {   // wave-uniform
+                const unsigned v = d_kill ? kWringOob : (unsigned)(lane * 16);
+                if constexpr (ABL & 128) wring_dma16_nom0(v, rsrc_u, d_su + (unsigned)(u * 1024));
+                else if constexpr (ABL & 256) wring_m0_only(d_base + (unsigned)(WR_U_OFF + u * 1024));
+                else wring_dma16(d_base + (unsigned)(WR_U_OFF + u * 1024), v, rsrc_u, d_su + (unsigned)(u * 1024));
+            }
         }
     };
     auto stage_all = [&]() {   // the whole slot at once (prologue)
@@ -208,8 +228,9 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
         piece(std::integral_constant<int, 0>{}), piece(std::integral_constant<int, 1>{}), piece(std::integral_constant<int, 2>{});
         piece(std::integral_constant<int, 3>{}), piece(std::integral_constant<int, 4>{}), piece(std::integral_constant<int, 5>{});
         piece(std::integral_constant<int, 6>{}), piece(std::integral_constant<int, 7>{}), piece(std::integral_constant<int, 8>{});
+        if constexpr (G_::NIT > 9) piece(std::integral_constant<int, 9>{});
     };
-    static_assert(WR_RAW_IT + WR_U_PIECES / WR_WAVES == 9 && WR_U_PIECES % WR_WAVES == 0, "piece() calls below");
+    static_assert(G_::NIT == 9 || G_::NIT == 10, "piece() calls");
 
     // ---- operand addresses.  A: patch pixel (a, b) of tile (wv, l15) = raw pixel (2 wv + a, 2 l15 + b), channel slot kq
     int offb[4];
@@ -217,12 +238,12 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
     for (int b = 0; b < 4; ++b) {
         const int q = l15 + (b >> 1), par = b & 1;
         const int sp = ((0x9C >> (2 * kq)) & 3) ^ ((q >> 2) & 3);   // P[kq] ^ Q
-        offb[b] = 2 * wv * WR_ROW_BYTES + ((par * (WR_RW / 2) + q) * 4 + sp) * 16;
+        offb[b] = ((par * (WR_RW / 2) + q) * 4 + sp) * 16;
     }
     const int b_off = WR_U_OFF + lane * 16;   // + (xi * 2 + nt) * 1024
     const bool half1 = wv >= 4;
 
-    f32x4 acc[16][2];
+    f32x4 acc[NC][2];
     unsigned cu = u_begin;
     int cchunk = 0, cbuf = 0;
     WringUnit CU = wring_unit(p, cu);
@@ -238,11 +259,13 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
 
         if (cchunk == 0) {
 #pragma unroll
-            for (int xi = 0; xi < 16; ++xi)
+            for (int xi = 0; xi < NC; ++xi)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) acc[xi][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        const unsigned char *gbp = lds + (unsigned)(cbuf * WR_GROUP_BYTES);
+        const unsigned char *gbp = lds + (unsigned)(cbuf * G_::GROUP_BYTES);
+        // first patch row of this wave's tiles in the raw tile (MODE 1: the classes py = 1 start one row further down)
+        const unsigned char *gap = gbp + (unsigned)((2 * wv + (MODE == 1 ? CU.py : 0)) * WR_ROW_BYTES);
         if (!(ABL & 2)) {
             // The matrix phase is laid out by hand in 64 groups of two matrix instructions (the two 16-channel halves of one
             // component and k-step: alternating accumulators, so no instruction waits for its predecessor's 40-cycle result),
@@ -256,45 +279,65 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
             //   group (xi, 0) for the waves 0 - 3, (xi, 2) for their SIMD partners 4 - 7, xi < 9: DMA piece xi of the next slot
             //                 (a wave-uniform branch; two instances of the phase with compile-time positions spill: the
             //                 accumulators of the two instances do not meet in the same registers).
-            f32x4 d[4][4];
+            constexpr int NR = MODE == 0 ? 4 : 3;   // patch rows
+            f32x4 d[NR][4];
             auto rd = [&](int a, int b) {
-                d[a][b] = (ABL & 8) ? (f32x4){(float)lane, 1.f, (float)a, (float)b} : *reinterpret_cast<const f32x4 *>(gbp + offb[b] + a * WR_ROW_BYTES);
+                d[a][b] = (ABL & 8) ? (f32x4){(float)lane, 1.f, (float)a, (float)b} : *reinterpret_cast<const f32x4 *>(gap + offb[b] + a * WR_ROW_BYTES);
             };
             auto colop = [&](int i, int b) -> f32x4 {
-                return i == 0 ? d[0][b] - d[2][b] : (i == 1 ? d[1][b] + d[2][b] : (i == 2 ? d[2][b] - d[1][b] : d[1][b] - d[3][b]));
+                if constexpr (MODE == 0) return i == 0 ? d[0][b] - d[2][b] : (i == 1 ? d[1][b] + d[2][b] : (i == 2 ? d[2][b] - d[1][b] : d[1][b] - d[3][b]));
+                else return i == 0 ? d[0][b] - d[1][b] : (i == 1 ? d[1][b] : d[2][b] - d[1][b]);
             };
             auto vop = [&](int xi) -> f32x4 {
-                const int i = xi >> 2, j = xi & 3;
-                f32x4 v = j == 0 ? colop(i, 0) - colop(i, 2) : (j == 1 ? colop(i, 1) + colop(i, 2) : (j == 2 ? colop(i, 2) - colop(i, 1) : colop(i, 1) - colop(i, 3)));
+                f32x4 v;
+                if constexpr (MODE == 0) {
+                    const int i = xi >> 2, j = xi & 3;
+                    v = j == 0 ? colop(i, 0) - colop(i, 2) : (j == 1 ? colop(i, 1) + colop(i, 2) : (j == 2 ? colop(i, 2) - colop(i, 1) : colop(i, 1) - colop(i, 3)));
+                } else {   // component xi = (px class, i, j): the 3x3 sub-patch starts at column px
+                    const int c0 = xi / 9, i = (xi % 9) / 3, j = xi % 3;
+                    v = j == 0 ? colop(i, c0) - colop(i, c0 + 1) : (j == 1 ? colop(i, c0 + 1) : colop(i, c0 + 2) - colop(i, c0 + 1));
+                }
                 asm volatile("" : "+v"(v));   // computed here, not where hipcc finds its first use
                 return v;
             };
-            f32x4 bq[2][2];
+            // B operands of the components xi .. xi + BD - 1 (requested BD - 1 components ahead; MODE 1 has no registers for a third set)
+            constexpr int BD = MODE == 0 ? 3 : 2;
+            f32x4 bq[BD][2];
             const bool nob = (ABL & 16) != 0;
-            rd(0, 0), rd(0, 2), rd(2, 0), rd(2, 2);
-            bq[0][0] = nob ? (f32x4){1.f, 2.f, 3.f, (float)lane} : *reinterpret_cast<const f32x4 *>(gbp + b_off);
-            bq[0][1] = nob ? (f32x4){1.f, 2.f, 3.f, (float)lane} : *reinterpret_cast<const f32x4 *>(gbp + b_off + 1024);
+            auto rdb = [&](int slot, int xi) {
+                bq[slot][0] = nob ? (f32x4){1.f, 2.f, 3.f, (float)(lane + xi)} : *reinterpret_cast<const f32x4 *>(gbp + b_off + (xi * 2 + 0) * 1024);
+                bq[slot][1] = nob ? (f32x4){1.f, 2.f, 3.f, (float)(lane - xi)} : *reinterpret_cast<const f32x4 *>(gbp + b_off + (xi * 2 + 1) * 1024);
+            };
+            if constexpr (MODE == 0) rd(0, 0), rd(0, 2), rd(2, 0), rd(2, 2);
+            else rd(0, 0), rd(1, 0), rd(0, 1), rd(1, 1);
+            rdb(0, 0);
+            if constexpr (BD == 3) rdb(1, 1);
             __builtin_amdgcn_sched_barrier(0);
             f32x4 vq[2];
             vq[0] = vop(0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int xi = 0; xi < 16; ++xi) {
+            for (int xi = 0; xi < NC; ++xi) {
                 const int cur = xi & 1, nxt = cur ^ 1;
+                const int bc = xi % BD;
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
-                    if (st == 0 && xi < 15) {
-                        bq[nxt][0] = nob ? bq[cur][1] : *reinterpret_cast<const f32x4 *>(gbp + b_off + ((xi + 1) * 2 + 0) * 1024);
-                        bq[nxt][1] = nob ? bq[cur][0] : *reinterpret_cast<const f32x4 *>(gbp + b_off + ((xi + 1) * 2 + 1) * 1024);
-                    }
+                    if (st == 1 && xi < NC - (BD - 1)) rdb((xi + BD - 1) % BD, xi + BD - 1);
                     // the remaining patch pixels, each two groups or more ahead of the first component that needs it
-                    if (xi == 0 && st == 1) rd(0, 1), rd(2, 1);
-                    if (xi == 0 && st == 2) rd(0, 3), rd(2, 3);
-                    if (xi == 1 && st == 1) rd(1, 0), rd(1, 2);
-                    if (xi == 1 && st == 2) rd(1, 1), rd(1, 3);
-                    if (xi == 2 && st == 1) rd(3, 0), rd(3, 2);
-                    if (xi == 2 && st == 2) rd(3, 1), rd(3, 3);
-                    if (xi < 9 && (st == 0 || st == 2) && (st == 2) == half1) {   // wave-uniform
+                    if constexpr (MODE == 0) {
+                        if (xi == 0 && st == 1) rd(0, 1), rd(2, 1);
+                        if (xi == 0 && st == 2) rd(0, 3), rd(2, 3);
+                        if (xi == 1 && st == 1) rd(1, 0), rd(1, 2);
+                        if (xi == 1 && st == 2) rd(1, 1), rd(1, 3);
+                        if (xi == 2 && st == 1) rd(3, 0), rd(3, 2);
+                        if (xi == 2 && st == 2) rd(3, 1), rd(3, 3);
+                    } else {
+                        if (xi == 0 && st == 1) rd(0, 2), rd(1, 2);
+                        if (xi == 1 && st == 1) rd(2, 0), rd(2, 1);
+                        if (xi == 2 && st == 1) rd(2, 2), rd(0, 3);
+                        if (xi == 3 && st == 1) rd(1, 3), rd(2, 3);
+                    }
+                    if (xi < G_::NIT && (st == 0 || st == 2) && (st == 2) == half1) {   // wave-uniform
                         if (xi == 0) piece(std::integral_constant<int, 0>{});
                         if (xi == 1) piece(std::integral_constant<int, 1>{});
                         if (xi == 2) piece(std::integral_constant<int, 2>{});
@@ -304,10 +347,13 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
                         if (xi == 6) piece(std::integral_constant<int, 6>{});
                         if (xi == 7) piece(std::integral_constant<int, 7>{});
                         if (xi == 8) piece(std::integral_constant<int, 8>{});
+                        if constexpr (G_::NIT > 9) {
+                            if (xi == 9) piece(std::integral_constant<int, 9>{});
+                        }
                     }
-                    if (st == 3 && xi < 15) vq[nxt] = vop(xi + 1);
-                    acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vq[cur][st], bq[cur][0][st], acc[xi][0], 0, 0, 0);
-                    acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vq[cur][st], bq[cur][1][st], acc[xi][1], 0, 0, 0);
+                    if (st == 3 && xi < NC - 1) vq[nxt] = vop(xi + 1);
+                    acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vq[cur][st], bq[bc][0][st], acc[xi][0], 0, 0, 0);
+                    acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vq[cur][st], bq[bc][1][st], acc[xi][1], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -315,44 +361,82 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
             piece(std::integral_constant<int, 0>{}), piece(std::integral_constant<int, 1>{}), piece(std::integral_constant<int, 2>{});
             piece(std::integral_constant<int, 3>{}), piece(std::integral_constant<int, 4>{}), piece(std::integral_constant<int, 5>{});
             piece(std::integral_constant<int, 6>{}), piece(std::integral_constant<int, 7>{}), piece(std::integral_constant<int, 8>{});
+            if constexpr (G_::NIT > 9) piece(std::integral_constant<int, 9>{});
         }
 
         if (cchunk == nchunks - 1) {
             // ---- epilogue of unit cu: lane (l15, kq) holds, for the tiles tx = 4 kq + r of its wave's tile row and the channel pair
-            // (2 l15, 2 l15 + 1) of the unit's block, all 16 components: Y = A^T M A in registers, bias, activation, 8-byte stores
+            // (2 l15, 2 l15 + 1) of the unit's block, all components: Y = A^T M A in registers, bias, activation, 8-byte stores
             const int co = CU.cob * 32 + 2 * l15;
             float bs0 = 0.f, bs1 = 0.f;
             if (p.bias) bs0 = p.bias[co], bs1 = p.bias[co + 1];
-            const int oy = CU.y0 * WR_TH + 2 * wv;
-            float *orow = p.out + ((size_t)(CU.n * p.H + oy) * p.W + CU.x0 * WR_TW) * p.out_ld + co;
-            const size_t rs = (size_t)p.W * p.out_ld;
+            if constexpr (MODE == 0) {
+                const int oy = CU.y0 * WR_TH + 2 * wv;
+                float *orow = p.out + ((size_t)(CU.n * p.H + oy) * p.W + CU.x0 * WR_TW) * p.out_ld + co;
+                const size_t rs = (size_t)p.W * p.out_ld;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float y[2][2][2];   // [nt][row][col]
+                for (int r = 0; r < 4; ++r) {
+                    float y[2][2][2];   // [nt][row][col]
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    float tc[4][2];
+                    for (int nt = 0; nt < 2; ++nt) {
+                        float tc[4][2];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float m0 = acc[i * 4 + 0][nt][r], m1 = acc[i * 4 + 1][nt][r], m2 = acc[i * 4 + 2][nt][r], m3 = acc[i * 4 + 3][nt][r];
-                        tc[i][0] = m0 + m1 + m2, tc[i][1] = m1 - m2 - m3;
+                        for (int i = 0; i < 4; ++i) {
+                            const float m0 = acc[i * 4 + 0][nt][r], m1 = acc[i * 4 + 1][nt][r], m2 = acc[i * 4 + 2][nt][r], m3 = acc[i * 4 + 3][nt][r];
+                            tc[i][0] = m0 + m1 + m2, tc[i][1] = m1 - m2 - m3;
+                        }
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            y[nt][0][b] = tc[0][b] + tc[1][b] + tc[2][b];
+                            y[nt][1][b] = tc[1][b] - tc[2][b] - tc[3][b];
+                        }
                     }
+                    if (!(ABL & 4)) {
+                        float *o = orow + (size_t)(2 * (4 * kq + r)) * p.out_ld;
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        y[nt][0][b] = tc[0][b] + tc[1][b] + tc[2][b];
-                        y[nt][1][b] = tc[1][b] - tc[2][b] - tc[3][b];
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b)
+                                *reinterpret_cast<float2 *>(o + a * rs + (size_t)b * p.out_ld) =
+                                    make_float2(act_apply(y[0][a][b] + bs0, p.act), act_apply(y[1][a][b] + bs1, p.act));
+                    } else if (y[0][0][0] == 12345.678f) {
+                        p.out[0] = y[1][1][1];   // keep the accumulators live
                     }
                 }
-                if (!(ABL & 4)) {
-                    float *o = orow + (size_t)(2 * (4 * kq + r)) * p.out_ld;
+            } else {
+                // class outputs (2 ty + a, 2 tx + b) of class (py, px) = output pixels (2 (16 y0 + 2 wv + a) + py, 2 (32 x0 + 2 tx + b) + px)
+                const int OW = 2 * p.W;
+                const int oy = 2 * (CU.y0 * WR_TH + 2 * wv) + CU.py;
+                float *orow = p.out + ((size_t)(CU.n * 2 * p.H + oy) * OW + 2 * CU.x0 * WR_TW) * p.out_ld + co;
+                const size_t rs = (size_t)2 * OW * p.out_ld;   // next class row = two output rows
 #pragma unroll
-                    for (int a = 0; a < 2; ++a)
+                for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                        for (int b = 0; b < 2; ++b)
-                            *reinterpret_cast<float2 *>(o + a * rs + (size_t)b * p.out_ld) =
-                                make_float2(act_apply(y[0][a][b] + bs0, p.act), act_apply(y[1][a][b] + bs1, p.act));
-                } else if (y[0][0][0] == 12345.678f) {
-                    p.out[0] = y[1][1][1];   // keep the accumulators live
+                    for (int pxc = 0; pxc < 2; ++pxc) {
+                        float y[2][2][2];   // [nt][row][col]
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            float tc[3][2];
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                const float m0 = acc[pxc * 9 + i * 3 + 0][nt][r], m1 = acc[pxc * 9 + i * 3 + 1][nt][r], m2 = acc[pxc * 9 + i * 3 + 2][nt][r];
+                                tc[i][0] = m0 + m1, tc[i][1] = m1 + m2;
+                            }
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) y[nt][0][b] = tc[0][b] + tc[1][b], y[nt][1][b] = tc[1][b] + tc[2][b];
+                        }
+                        if (!(ABL & 4)) {
+                            float *o = orow + (size_t)(2 * (2 * (4 * kq + r)) + pxc) * p.out_ld;
+#pragma unroll
+                            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                                for (int b = 0; b < 2; ++b)
+                                    *reinterpret_cast<float2 *>(o + a * rs + (size_t)(2 * b) * p.out_ld) =
+                                        make_float2(act_apply(y[0][a][b] + bs0, p.act), act_apply(y[1][a][b] + bs1, p.act));
+                        } else if (y[0][0][0] == 12345.678f) {
+                            p.out[0] = y[1][1][1];   // keep the accumulators live
+                        }
+                    }
                 }
             }
             cchunk = 0, cu += u_step;
@@ -364,43 +448,46 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
     }
 }
 
-// U ring layout from the component-major layout uw[16][cin_pad][cout] of pws_pack_conv_weight_wino (cin_pad % 16 == 0, cout % 32 == 0)
-__global__ void wring_pack_kernel(const float *__restrict__ uw, float *__restrict__ ur, int cin_pad, int cout) {
+// ---- weights.  K3S1 / CONVT_K3S1: U = G g G^T (F(2x2,3x3), 16 components) of the packed correlation kernel
+// P[tap][cin_pad][cout]; CONVT_K4S2: per output parity class U = G g G^T (F(2x2,2x2), 9 components) of the 2x2 sub-pixel kernel
+// P[cls * 4 + dy * 2 + dx][cin_pad][cout] (pack.hip), the two px classes of one py being the 18 components of a unit.
+__global__ void wring_pack_kernel(const float *__restrict__ pk, float *__restrict__ ur, int cin_pad, int cout, int ct4) {
     const size_t plane = (size_t)cin_pad * cout;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= plane) return;
-    const int co = (int)(i % cout), ci = (int)(i / cout);
-#pragma unroll
-    for (int xi = 0; xi < 16; ++xi) ur[wring_index(xi, ci, co, cin_pad / 16)] = uw[(size_t)xi * plane + i];
+    wring_pack_element(pk, ur, plane, i, cin_pad, cout, ct4);
 }
 
-int wring_pack(const float *uw, float *ur, int cin_pad, int cout, hipStream_t st) {
+int wring_pack(const float *pk, float *ur, int cin_pad, int cout, int ct4, hipStream_t st) {
     const size_t plane = (size_t)cin_pad * cout;
-    hipLaunchKernelGGL(wring_pack_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, uw, ur, cin_pad, cout);
+    hipLaunchKernelGGL(wring_pack_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, pk, ur, cin_pad, cout, ct4);
     return check_launch("wring_pack_kernel");
 }
 
-template <int ABL>
+template <int MODE, int ABL>
 static int wring_launch(const WringParams &p, unsigned grid, hipStream_t st) {
     static bool attr_set = false;   // benign race: idempotent
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_ring_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_ring_kernel<MODE, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           WrGeo<MODE>::LDS_BYTES);
         if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(wino_ring_kernel, %d B LDS): %s", WR_LDS_BYTES, hipGetErrorString(e));
+            set_error("hipFuncSetAttribute(wino_ring_kernel, %d B LDS): %s", WrGeo<MODE>::LDS_BYTES, hipGetErrorString(e));
             return PWS_EHIP;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(wino_ring_kernel<ABL>, dim3(grid), dim3(WR_WAVES * 64), WR_LDS_BYTES, st, p);
+    hipLaunchKernelGGL((wino_ring_kernel<MODE, ABL>), dim3(grid), dim3(WR_WAVES * 64), WrGeo<MODE>::LDS_BYTES, st, p);
     return check_launch("wino_ring_kernel");
 }
 
-// Runs a 3x3 stride-1 forward launch on the Winograd ring kernel when it is covered: fp32 NHWC sources in multiples of 16
-// channels (16-byte aligned), whole 16 x 32 units, cout a multiple of 32, 8-byte aligned output pixels and enough units to occupy
-// the chip.  `uw` = the buffer of pws_pack_conv_weight_wino (ring layout behind the component-major one).  Returns 1 when not
-// covered (the caller goes on to wino_kernel<0> / the direct kernels).
+// Runs a 3x3 stride-1 (Winograd F(2x2,3x3)) or transposed k4 s2 (F(2x2,2x2) per parity class) forward launch on the Winograd ring
+// kernel when it is covered: fp32 NHWC sources in multiples of 16 channels (16-byte aligned), an input map of whole 16 x 32 units,
+// cout a multiple of 32, 8-byte aligned output pixels, a->w_wring (pws_pack_conv_weight_wring) and enough units to occupy the chip.
+// Returns 1 when not covered (the caller goes on to the first-generation Winograd kernel / the direct kernels).
 int wring_try(const pws_conv_args *a, const ProfHint &ph, hipStream_t st) {
-    if (!a->w_wino || g_experiment == 50) return 1;
+    if (!a->w_wring || g_experiment == 50) return 1;
+    const bool ct4 = a->kind == PWS_CONVT_K4S2;
+    if (!ct4 && a->kind != PWS_CONV_K3S1 && a->kind != PWS_CONVT_K3S1) return 1;
     if (a->h % WR_TH != 0 || a->w % WR_TW != 0 || a->cout % 32 != 0 || a->out_ld % 2 != 0 || (reinterpret_cast<size_t>(a->out) & 7)) return 1;
     int cin = 0;
     for (int s = 0; s < a->nsrc; ++s) {
@@ -410,15 +497,16 @@ int wring_try(const pws_conv_args *a, const ProfHint &ph, hipStream_t st) {
         cin += sr.channels;
     }
     const size_t plane = (size_t)cin * a->cout;
-    if (16 * plane * 4 >= (1u << 31)) return 1;
+    const size_t ur_bytes = (size_t)(ct4 ? 36 : 16) * plane * 4;
+    if (ur_bytes >= (1u << 31)) return 1;
     WringParams p{};
     for (int s = 0; s < a->nsrc; ++s) p.src_ptr[s] = a->src[s].ptr, p.src_c[s] = a->src[s].channels, p.src_ld[s] = a->src[s].ld;
     p.nsrc = a->nsrc, p.N = a->n, p.H = a->h, p.W = a->w, p.cout = a->cout;
-    p.ur = a->w_wino + 16 * plane, p.ur_bytes = (unsigned)(16 * plane * 4);
+    p.ur = a->w_wring, p.ur_bytes = (unsigned)ur_bytes;
     p.bias = a->bias, p.act = a->act, p.out = a->out, p.out_ld = a->out_ld;
     p.tiles_x = a->w / WR_TW, p.tiles_y = a->h / WR_TH;
-    p.ncob = (unsigned)(a->cout / 32);
-    p.nunits = (unsigned)(p.tiles_x * p.tiles_y) * (unsigned)a->n * p.ncob;
+    p.ncob = (unsigned)(a->cout / 32), p.ncls = ct4 ? 2u : 1u;
+    p.nunits = (unsigned)(p.tiles_x * p.tiles_y) * (unsigned)a->n * p.ncob * p.ncls;
     p.nchunks = cin / 16;
     p.ablate = g_experiment >= 51 && g_experiment <= 57 ? g_experiment - 50 : (g_experiment >= 1000 && g_experiment < 1512 ? g_experiment - 1000 : 0);
     static int ncu = 0;
@@ -427,26 +515,45 @@ int wring_try(const pws_conv_args *a, const ProfHint &ph, hipStream_t st) {
         hipDeviceProp_t prop;
         ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
-    // a unit is nchunks x 8 192 matrix cycles: fewer units than CUs leave CUs idle for the whole launch, and a non-integer number of
-    // rounds costs its tail -- taken from 3/4 of the chip upwards (PWS_OPT_EXPERIMENT 58 forces it for the tests)
+    // a unit is nchunks x 8 192 (9 216) matrix cycles: fewer units than CUs leave CUs idle for the whole launch, and a non-integer
+    // number of rounds costs its tail -- taken from 3/4 of the chip upwards (PWS_OPT_EXPERIMENT 58 forces it for the tests)
     if (p.nunits < (unsigned)(ncu * 3 / 4) && g_experiment != 58) return 1;
-    ProfScope prof(KID_CONV_WRING, ph.flops, ph.bytes, st);
+    ProfScope prof(ct4 ? KID_CONV_WRING_CT4 : KID_CONV_WRING, ph.flops, ph.bytes, st);
     const unsigned grid = p.nunits < (unsigned)ncu ? p.nunits : (unsigned)ncu;   // one persistent workgroup per CU
+    if (ct4) {
+        switch (p.ablate) {
+        case 0: return wring_launch<1, 0>(p, grid, st);
+        case 64: return wring_launch<1, 64>(p, grid, st);
+        case 120: return wring_launch<1, 120>(p, grid, st);
+        default: set_error("wino_ring_kernel<1>: ablation mask %d is not instantiated", p.ablate); return PWS_EINVAL;
+        }
+    }
     switch (p.ablate) {
-    case 0: return wring_launch<0>(p, grid, st);
-    case 1: return wring_launch<1>(p, grid, st);
-    case 2: return wring_launch<2>(p, grid, st);
-    case 4: return wring_launch<4>(p, grid, st);
-    case 64: return wring_launch<64>(p, grid, st);
-    case 96: return wring_launch<96>(p, grid, st);
-    case 104: return wring_launch<104>(p, grid, st);
-    case 112: return wring_launch<112>(p, grid, st);
-    case 120: return wring_launch<120>(p, grid, st);
-    case 124: return wring_launch<124>(p, grid, st);
-    case 128: return wring_launch<128>(p, grid, st);
-    case 256: return wring_launch<256>(p, grid, st);
-    default: set_error("wino_ring_kernel: ablation mask %d is not instantiated", p.ablate); return PWS_EINVAL;
+    case 0: return wring_launch<0, 0>(p, grid, st);
+    case 1: return wring_launch<0, 1>(p, grid, st);
+    case 2: return wring_launch<0, 2>(p, grid, st);
+    case 4: return wring_launch<0, 4>(p, grid, st);
+    case 24: return wring_launch<0, 24>(p, grid, st);
+    case 88: return wring_launch<0, 88>(p, grid, st);
+    case 64: return wring_launch<0, 64>(p, grid, st);
+    case 96: return wring_launch<0, 96>(p, grid, st);
+    case 120: return wring_launch<0, 120>(p, grid, st);
+    default: set_error("wino_ring_kernel<0>: ablation mask %d is not instantiated", p.ablate); return PWS_EINVAL;
     }
 }
 
 }  // namespace pws
+
+extern "C" size_t pws_packed_wring_floats(int kind, int cin, int cout) {
+    if (cin <= 0 || cout <= 0 || cout % 32 != 0) return 0;
+    const size_t plane = (size_t)((cin + 15) / 16 * 16) * cout;
+    if (kind == PWS_CONV_K3S1 || kind == PWS_CONVT_K3S1) return 16 * plane;
+    if (kind == PWS_CONVT_K4S2) return 36 * plane;
+    return 0;
+}
+
+extern "C" int pws_pack_conv_weight_wring(const float *w_packed, float *w_wring, int kind, int cin, int cout, pws_stream_t stream) {
+    PWS_REQUIRE(w_packed && w_wring && pws_packed_wring_floats(kind, cin, cout) > 0, "pws_pack_conv_weight_wring: bad arguments (kind %d, cout %d)", kind,
+                cout);
+    return pws::wring_pack(w_packed, w_wring, (cin + 15) / 16 * 16, cout, kind == PWS_CONVT_K4S2 ? 1 : 0, pws::as_stream(stream));
+}

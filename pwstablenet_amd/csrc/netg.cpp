@@ -30,6 +30,7 @@ struct Layer {
     size_t w_off, b_off;  // float offsets into the packed buffer (and into the packed gradient buffer)
     size_t dg_off;        // float offset into the data-gradient weight buffer (or SIZE_MAX)
     size_t ww_off;        // float offset of the Winograd-domain weights inside the packed buffer (or SIZE_MAX)
+    size_t wr_off;        // ... of the ring-layout Winograd weights (conv_wring.hip; or SIZE_MAX)
     size_t wb_off;        // float offset of the bf16 weights inside the packed buffer (or SIZE_MAX)
     size_t dgb_off;       // float offset of the bf16 data-gradient weights inside the data-gradient buffer (or SIZE_MAX)
 };
@@ -65,8 +66,9 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static std::vector<Layer> build_layers(int input_nc, int g, size_t *total_floats, size_t *total_dgrad = nullptr) {
     std::vector<Layer> L;
     size_t off = 0, dg = 0;
-    auto add = [&](int kind, int cin, int cout) {
-        Layer l{kind, cin, cout, 0, 0, (size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1};
+    // ring: the layer runs on maps of whole 16 x 32 units at the reference's 256 x 256 input (conv_wring.hip)
+    auto add = [&](int kind, int cin, int cout, bool ring = false) {
+        Layer l{kind, cin, cout, 0, 0, (size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1};
         l.w_off = off;
         off = align_up(off + pws_packed_weight_floats(kind, cin, cout), 64);
         l.b_off = off;
@@ -74,6 +76,10 @@ static std::vector<Layer> build_layers(int input_nc, int g, size_t *total_floats
         if (kind == PWS_CONV_K3S1 || kind == PWS_CONVT_K3S1) {
             l.ww_off = off;
             off = align_up(off + pws_packed_wino_floats(cin, cout), 64);
+        }
+        if (ring && pws_packed_wring_floats(kind, cin, cout)) {
+            l.wr_off = off;
+            off = align_up(off + pws_packed_wring_floats(kind, cin, cout), 64);
         }
         // (CONVT_K4S2 has a Winograd F(3x3,2x2) kernel too, conv_wino.hip MODE 1; measured slower than the direct kernel on
         //  this generator's 32..128-pixel maps, so its weights are not packed here)
@@ -93,17 +99,17 @@ static std::vector<Layer> build_layers(int input_nc, int g, size_t *total_floats
     add(PWS_CONV_K5S1, input_nc, g);
     for (int i = 0; i < 7; ++i) add(PWS_CONV_K3S2, enc[i][0], enc[i][1]);
     const int dec[7][2] = {{4 * g, 4 * g}, {8 * g, 4 * g}, {8 * g, 4 * g}, {8 * g, 4 * g}, {8 * g, 2 * g}, {4 * g, g}, {2 * g, g}};
-    for (int j = 0; j < 7; ++j) add(PWS_CONVT_K4S2, dec[j][0], dec[j][1]);  // up7..up1
+    for (int j = 0; j < 7; ++j) add(PWS_CONVT_K4S2, dec[j][0], dec[j][1], j >= 4);  // up7..up1 (up3..up1: inputs of 32^2..128^2)
     add(PWS_CONV_K3S1_OUT, g, 2);
     for (int i = 0; i < 7; ++i) {
-        add(PWS_CONV_K3S1, enc[i][0], enc[i][0]);
+        add(PWS_CONV_K3S1, enc[i][0], enc[i][0], i < 4);   // down_bottom1..4.conv_same: maps of 256^2..32^2
         add(PWS_CONV_K3S2, i == 0 ? enc[i][0] : 2 * enc[i][0], enc[i][1]);
     }
     const int ub[7][3] = {{4 * g, 4 * g, 8 * g}, {8 * g, 4 * g, 16 * g}, {8 * g, 4 * g, 16 * g}, {8 * g, 4 * g, 16 * g},
                           {8 * g, 2 * g, 16 * g}, {4 * g, g, 8 * g}, {2 * g, g, 4 * g}};  // (input_nc, output_nc, inner_nc)
     for (int j = 0; j < 7; ++j) {
-        add(PWS_CONVT_K4S2, ub[j][2], ub[j][1]);
-        add(PWS_CONVT_K3S1, ub[j][0], ub[j][0]);
+        add(PWS_CONVT_K4S2, ub[j][2], ub[j][1], j >= 4);   // up_bottom3..1: inputs of 32^2..128^2
+        add(PWS_CONVT_K3S1, ub[j][0], ub[j][0], j >= 4);
     }
     add(PWS_CONV_K2S1P0, 4 * g, 8 * g);
     add(PWS_CONV_K1, 8 * g, 6);
@@ -131,7 +137,7 @@ static void fill_pack_layers(const std::vector<Layer> &L, PackLayer *out) {
         p.kind = l.kind, p.cin = l.cin, p.cin_pad = (l.cin + 15) / 16 * 16, p.cout = l.cout, p.k = kind_ksize(l.kind);
         p.planes = l.kind == PWS_CONVT_K4S2 ? 16 : p.k * p.k;
         p.dg_taps = l.dg_off == (size_t)-1 ? 0 : (l.kind == PWS_CONV_K3S1 || l.kind == PWS_CONVT_K3S1 ? 9 : 16);
-        p.w_off = off32(l.w_off), p.b_off = off32(l.b_off), p.ww_off = off32(l.ww_off), p.dg_off = off32(l.dg_off);
+        p.w_off = off32(l.w_off), p.b_off = off32(l.b_off), p.ww_off = off32(l.ww_off), p.dg_off = off32(l.dg_off), p.wr_off = off32(l.wr_off);
     }
 }
 
@@ -327,6 +333,7 @@ class Exec {
         }
         a.cout = l.cout, a.w_packed = packed_ + l.w_off, a.bias = packed_ + l.b_off, a.act = bn_on_ ? PWS_ACT_NONE : act;
         a.w_wino = l.ww_off != (size_t)-1 ? packed_ + l.ww_off : nullptr;
+        a.w_wring = l.wr_off != (size_t)-1 ? packed_ + l.wr_off : nullptr;
         a.out = bn_on_ ? op.aux[0] : o.seg[0].ptr, a.out_ld = l.cout;
         a.ws = q_ ? splitk_ws2_ : splitk_ws_, a.ws_bytes = splitk_bytes_;
         if (math_ == PWS_MATH_BF16 && l.wb_off != (size_t)-1) a.math = PWS_MATH_BF16, a.w_bf16 = packed_ + l.wb_off;
@@ -795,7 +802,7 @@ extern "C" int pws_netg_pack_weights(const float *const *params, float *packed, 
         a.first_block[i] = nb;
         nb += (unsigned)(((size_t)p.planes * p.cin_pad * p.cout + p.cout + 255) / 256);
         a.first_block_wino[i] = nbw;
-        if (p.ww_off != kNoOff) nbw += (unsigned)(((size_t)p.cin_pad * p.cout + 255) / 256);
+        if (p.ww_off != kNoOff || p.wr_off != kNoOff) nbw += (unsigned)(((size_t)p.cin_pad * p.cout + 255) / 256);
         Bf16Layer &q = b.layer[i];
         q.planes = p.planes, q.krows = p.cin_pad, q.ncols = p.cout, q.kpad = (p.cin_pad + 31) / 32 * 32, q.npad = (p.cout + 63) / 64 * 64;
         q.src_off = p.w_off, q.dst_off = off32(L[i].wb_off);

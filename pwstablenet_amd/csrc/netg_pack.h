@@ -10,6 +10,7 @@ constexpr unsigned kNoOff = 0xffffffffu;
 struct PackLayer {
     int kind, cin, cin_pad, cout, k, planes, dg_taps;
     unsigned w_off, b_off, ww_off, dg_off;  // float offsets (kNoOff: none); 32 bits keep the argument block under 4 KB
+    unsigned wr_off;                        // ring-layout Winograd weights (conv_wring.hip)
 };
 
 struct PackAllArgs {

@@ -51,15 +51,18 @@ __global__ void __launch_bounds__(256) pack_all_kernel(const PackAllArgs a, floa
     }
 }
 
-// ---- stage 2: Winograd F(2x2,3x3) weights of the K3S1 / CONVT_K3S1 layers from the packed fp32 weights
+// ---- stage 2: Winograd weights from the packed fp32 weights: F(2x2,3x3) of the K3S1 / CONVT_K3S1 layers (component-major for
+// conv_wino.hip, ring layout for conv_wring.hip) and the ring-layout F(2x2,2x2) weights of the large-map CONVT_K4S2 layers
 __global__ void __launch_bounds__(256) wino_all_kernel(const PackAllArgs a, float *__restrict__ packed) {
     const int l = find_layer(a.first_block_wino, a.nlayers, blockIdx.x);
     const PackLayer &L = a.layer[l];
-    if (L.ww_off == kNoOff) return;
+    if (L.ww_off == kNoOff && L.wr_off == kNoOff) return;
     const size_t plane = (size_t)L.cin_pad * L.cout;
     const size_t i = (size_t)(blockIdx.x - a.first_block_wino[l]) * 256 + threadIdx.x;
     if (i >= plane) return;
     const float *pk = packed + L.w_off;
+    if (L.wr_off != kNoOff) wring_pack_element(pk, packed + L.wr_off, plane, i, L.cin_pad, L.cout, L.kind == PWS_CONVT_K4S2 ? 1 : 0);
+    if (L.ww_off == kNoOff) return;
     float *uw = packed + L.ww_off;
     float g[3][3];
 #pragma unroll
@@ -78,17 +81,6 @@ __global__ void __launch_bounds__(256) wino_all_kernel(const PackAllArgs a, floa
         uw[(size_t)(r * 4 + 1) * plane + i] = 0.5f * (u[r][0] + u[r][1] + u[r][2]);
         uw[(size_t)(r * 4 + 2) * plane + i] = 0.5f * (u[r][0] - u[r][1] + u[r][2]);
         uw[(size_t)(r * 4 + 3) * plane + i] = u[r][2];
-    }
-    if (wring_layout_ok(L.cin_pad, L.cout)) {   // the ring layout of the same values (conv_wring.hip) behind the component-major one
-        float *ur = uw + 16 * plane;
-        const int co = (int)(i % L.cout), ci = (int)(i / L.cout), nch = L.cin_pad / 16;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            ur[wring_index(r * 4 + 0, ci, co, nch)] = u[r][0];
-            ur[wring_index(r * 4 + 1, ci, co, nch)] = 0.5f * (u[r][0] + u[r][1] + u[r][2]);
-            ur[wring_index(r * 4 + 2, ci, co, nch)] = 0.5f * (u[r][0] - u[r][1] + u[r][2]);
-            ur[wring_index(r * 4 + 3, ci, co, nch)] = u[r][2];
-        }
     }
 }
 

@@ -30,7 +30,8 @@ class PwsConvArgs(ctypes.Structure):
                 ("nsrc", ctypes.c_int), ("src", PwsSrc * 4), ("src_nchw", ctypes.c_int), ("cout", ctypes.c_int),
                 ("w_packed", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("act", ctypes.c_int),
                 ("out", ctypes.c_void_p), ("out_ld", ctypes.c_int), ("w_wino", ctypes.c_void_p), ("ws", ctypes.c_void_p),
-                ("ws_bytes", ctypes.c_size_t), ("math", ctypes.c_int), ("w_bf16", ctypes.c_void_p), ("store", ctypes.c_int)]
+                ("ws_bytes", ctypes.c_size_t), ("math", ctypes.c_int), ("w_bf16", ctypes.c_void_p), ("store", ctypes.c_int),
+                ("w_wring", ctypes.c_void_p)]
 
 
 class PwsDst(ctypes.Structure):
@@ -80,6 +81,8 @@ SIGNATURES = {
     "pws_pack_conv_weight": (_I, [_P, _P, _I, _I, _I, _P]),
     "pws_packed_wino_floats": (_S, [_I, _I]),
     "pws_pack_conv_weight_wino": (_I, [_P, _P, _I, _I, _P]),
+    "pws_packed_wring_floats": (_S, [_I, _I, _I]),
+    "pws_pack_conv_weight_wring": (_I, [_P, _P, _I, _I, _I, _P]),
     "pws_packed_wino_ct4_floats": (_S, [_I, _I]),
     "pws_pack_conv_weight_wino_ct4": (_I, [_P, _P, _I, _I, _P]),
     "pws_conv2d_fwd": (_I, [ctypes.POINTER(PwsConvArgs), _P]),

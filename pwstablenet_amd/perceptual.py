@@ -57,6 +57,8 @@ class _VGGFn(torch.autograd.Function):
                 a.cout, a.w_packed, a.bias, a.act = v, pk["w"].data_ptr(), pk["b"].data_ptr(), A.ACT_RELU
                 a.out, a.out_ld = out.data_ptr(), v
                 a.w_wino = pk["wino"].data_ptr()
+                if pk["wring"] is not None:
+                    a.w_wring = pk["wring"].data_ptr()
                 if s16:
                     a.math, a.w_bf16, a.store = A.MATH_BF16, pk["bf16"].data_ptr(), A.STORE_BF16
                 A.check(L.pws_conv2d_fwd(ctypes.byref(a), st), "pws_conv2d_fwd")
@@ -187,6 +189,10 @@ class VGG16Features(nn.Module):
             A.check(L.pws_pack_conv_weight(A.ptr(w), A.ptr(wp), A.CONV_K3S1, cin, cout, st), "pws_pack_conv_weight")
             ww = torch.empty(L.pws_packed_wino_floats(cin, cout), device=dev, dtype=torch.float32)
             A.check(L.pws_pack_conv_weight_wino(A.ptr(wp), A.ptr(ww), cin, cout, st), "pws_pack_conv_weight_wino")
+            wr = None
+            if math != "bf16" and L.pws_packed_wring_floats(A.CONV_K3S1, cin, cout):   # LDS-ring Winograd (fp32 path, cout % 32 == 0)
+                wr = torch.empty(L.pws_packed_wring_floats(A.CONV_K3S1, cin, cout), device=dev, dtype=torch.float32)
+                A.check(L.pws_pack_conv_weight_wring(A.ptr(wp), A.ptr(wr), A.CONV_K3S1, cin, cout, st), "pws_pack_conv_weight_wring")
             dg = torch.empty(L.pws_packed_dgrad_floats(A.CONV_K3S1, cin, cout), device=dev, dtype=torch.float32)
             A.check(L.pws_pack_conv_weight_dgrad(A.ptr(w), A.ptr(dg), A.CONV_K3S1, cin, cout, st), "pws_pack_conv_weight_dgrad")
             wb = dgb = None
@@ -196,7 +202,7 @@ class VGG16Features(nn.Module):
             if math == "bf16" and cout % 32 == 0:   # the gradient's contraction runs over cout; cin is padded to 64 by the pack
                 dgb = torch.empty(L.pws_packed_bf16_floats(9, cout, cin), device=dev, dtype=torch.float32)
                 A.check(L.pws_pack_weight_bf16(A.ptr(dg), A.ptr(dgb), 9, cout, cin, st), "pws_pack_weight_bf16")
-            packs.append({"w": wp, "b": m.bias.detach().contiguous(), "wino": ww, "dg": dg, "bf16": wb, "dg_bf16": dgb})
+            packs.append({"w": wp, "b": m.bias.detach().contiguous(), "wino": ww, "wring": wr, "dg": dg, "bf16": wb, "dg_bf16": dgb})
         self._packs, self._key = packs, key
         return packs
 

@@ -70,6 +70,10 @@ def run_conv(A, kind, srcs_nhwc, w_torch, bias, act, cout, nchw_src=None, ws_mb=
         ww = torch.empty(L.pws_packed_wino_floats(cin, cout), device="cuda", dtype=torch.float32)
         A.check(L.pws_pack_conv_weight_wino(A.ptr(wp), A.ptr(ww), cin, cout, st), "pack_wino")
         args.w_wino = ww.data_ptr()
+    if wino and L.pws_packed_wring_floats(kind, cin, cout):   # ring-layout Winograd weights (conv_wring.hip)
+        wr = torch.empty(L.pws_packed_wring_floats(kind, cin, cout), device="cuda", dtype=torch.float32)
+        A.check(L.pws_pack_conv_weight_wring(A.ptr(wp), A.ptr(wr), kind, cin, cout, st), "pack_wring")
+        args.w_wring = wr.data_ptr()
     if ws_mb:
         ws = torch.empty(ws_mb << 20, device="cuda", dtype=torch.uint8)
         args.ws, args.ws_bytes = ws.data_ptr(), ws.numel()
@@ -225,10 +229,14 @@ def test_conv_winograd_vs_oracle(hip, oracle, kname, shape, src_c, cout):
     ("CONVT_K3S1", (3, 16, 32), [64], 32),        # one unit per image (all four borders inside the unit), flipped taps
     ("CONV_K3S1", (1, 48, 96), [16], 96),         # one chunk per unit: every barrier is a unit boundary
     ("CONV_K3S1", (8, 64, 64), [128], 128),       # >= 256 units: several units per workgroup (the product's regime)
+    ("CONVT_K4S2", (2, 16, 32), [64], 32),        # transposed k4 s2 as F(2x2,2x2) per parity class: one tile block per image
+    ("CONVT_K4S2", (1, 32, 64), [32, 16], 64),    # virtual concat, several tile blocks
+    ("CONVT_K4S2", (8, 32, 32), [128], 128),      # 256 units
 ])
 def test_conv_winograd_ring_vs_oracle(hip, oracle, kname, shape, src_c, cout):
-    """3x3 stride-1 layers through the persistent LDS-ring Winograd kernel (conv_wring.hip; PWS_OPT_EXPERIMENT 58 takes it
-    whatever the number of units, 50 switches it off) against the C oracle and the first-generation Winograd kernel."""
+    """3x3 stride-1 layers (F(2x2,3x3)) and transposed k4 s2 layers (F(2x2,2x2) per parity class) through the persistent LDS-ring
+    Winograd kernel (conv_wring.hip; PWS_OPT_EXPERIMENT 58 takes it whatever the number of units, 50 switches it off) against the C
+    oracle and the kernels that run otherwise."""
     A = hip
     L = A.lib()
     kind = getattr(A, kname)
@@ -237,14 +245,16 @@ def test_conv_winograd_ring_vs_oracle(hip, oracle, kname, shape, src_c, cout):
     cin = sum(src_c)
     is_t = kname.startswith("CONVT")
     x = rs.standard_normal((n, cin, h, w)).astype(np.float32)
-    wt = (rs.standard_normal((cin, cout, 3, 3) if is_t else (cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    k = 4 if kname == "CONVT_K4S2" else 3
+    wt = (rs.standard_normal((cin, cout, k, k) if is_t else (cout, cin, k, k)) / np.sqrt(cin * 9)).astype(np.float32)
     b = rs.standard_normal((cout,)).astype(np.float32)
-    ref = (oracle.conv_transpose2d if is_t else oracle.conv2d)(x, wt, b, 1, 1, oracle.ACT_LRELU)
+    ref = (oracle.conv_transpose2d if is_t else oracle.conv2d)(x, wt, b, 2 if k == 4 else 1, 1, oracle.ACT_LRELU)
     xs = nhwc(x)
     srcs, c0 = [], 0
     for c in src_c:
         srcs.append(np.ascontiguousarray(xs[..., c0:c0 + c]))
         c0 += c
+    ring_name = "wino_ring_kernel<convT4,F(2x2,2x2)>" if k == 4 else "wino_ring_kernel<F(2x2,3x3)>"
     got = {}
     try:
         for force in (58, 50):
@@ -253,7 +263,7 @@ def test_conv_winograd_ring_vs_oracle(hip, oracle, kname, shape, src_c, cout):
             got[force] = run_conv(A, kind, srcs, wt, b, 1, cout, wino=True)
             L.pws_prof_enable(0)
             names = [r[0] for r in A.prof_collect()]
-            assert ("wino_ring_kernel<F(2x2,3x3)>" in names) == (force == 58), names
+            assert (ring_name in names) == (force == 58), names
     finally:
         L.pws_prof_enable(0)
         L.pws_set_option(100, 0)

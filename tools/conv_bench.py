@@ -75,6 +75,10 @@ def bench(kname, n, h, w, cin, cout, wino, bf16=False):
         ww = torch.empty(L.pws_packed_wino_floats(cin, cout), device="cuda")
         A.check(L.pws_pack_conv_weight_wino(A.ptr(wp), A.ptr(ww), cin, cout, st), "wino pack")
         a.w_wino = ww.data_ptr()
+    if wino and L.pws_packed_wring_floats(kind, cin, cout):
+        wr = torch.empty(L.pws_packed_wring_floats(kind, cin, cout), device="cuda")
+        A.check(L.pws_pack_conv_weight_wring(A.ptr(wp), A.ptr(wr), kind, cin, cout, st), "wring pack")
+        a.w_wring = wr.data_ptr()
     store16 = bool(int(os.environ.get("CONV_BENCH_STORE16", "0")))
     if bf16 and store16:   # bf16 activation storage: sources and output hold bf16 elements
         x = x.bfloat16()
