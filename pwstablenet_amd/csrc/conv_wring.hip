@@ -34,6 +34,8 @@
 // its LDS layout and the DMA are unchanged; a unit = 16 x 32 class pixels x 32 channels x the two classes of one py (2 x 9 = 18
 // components, 144 accumulator registers, 36 KB of weights per slot), and its outputs are the rows 2 y + py of a 32 x 64 region.
 // Unlike F(3x3,2x2) (conv_wino.hip MODE 1: 3-pixel tiles waste 21-41 % of a 64- or 32-pixel map) the tiles divide the maps.
+// MODE 2 -- the same with ONE class per unit (9 components, 72 accumulators, 18 KB of weights per slot out of the MODE 1 layout):
+// twice the units for the launches whose MODE 1 units do not fill the chip, at 1.4x the staged bytes per matrix instruction.
 #include <type_traits>
 
 #include "conv_common.h"
@@ -71,8 +73,8 @@ constexpr int WR_WAVES = 8;
 constexpr int WR_RAW_IT = (WR_RAW_PIECES + WR_WAVES - 1) / WR_WAVES;   // its 0..4 can be raw pieces
 template <int MODE>
 struct WrGeo {
-    static constexpr int NC = MODE == 0 ? 16 : 18;       // components a wave accumulates
-    static constexpr int NCLS = MODE == 0 ? 1 : 2;       // units per (tile, channel block): MODE 1 = the two py
+    static constexpr int NC = MODE == 0 ? 16 : (MODE == 1 ? 18 : 9);   // components a wave accumulates
+    static constexpr int NCLS = MODE == 0 ? 1 : (MODE == 1 ? 2 : 4);   // units per (tile, channel block): MODE 1 = the two py, MODE 2 = the four classes
     static constexpr int U_PIECES = NC * 2;              // NC components x 16 channels x 32 output channels x 4 bytes / 1 KB
     static constexpr int U_IT = (U_PIECES + WR_WAVES - 1) / WR_WAVES;
     static constexpr int NIT = WR_RAW_IT + U_IT;         // DMA pieces per wave and slot (9 / 10)
@@ -115,7 +117,7 @@ __device__ __forceinline__ WringUnit wring_unit(const WringParams &p, unsigned u
     WringUnit r;
     const unsigned cls = u % p.ncls, u2 = u / p.ncls;
     const unsigned cob = u2 % p.ncob, tile = u2 / p.ncob;
-    r.py = (int)cls;
+    r.py = (int)cls;   // MODE 1: py; MODE 2: py * 2 + px
     const unsigned tx = tile % (unsigned)p.tiles_x, t2 = tile / (unsigned)p.tiles_x;
     r.cob = (int)cob, r.x0 = (int)tx, r.y0 = (int)(t2 % (unsigned)p.tiles_y), r.n = (int)(t2 / (unsigned)p.tiles_y);
     return r;
@@ -188,7 +190,11 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
             d_ldb = (unsigned)s_ld * 4u;
             d_sin = uniw((unsigned)(pc0 * 4));
             d_oy = PU.y0 * WR_TH - 1, d_ox = PU.x0 * WR_TW - 1;
-            d_su = uniw((unsigned)((((unsigned)PU.py * p.ncob + (unsigned)PU.cob) * (unsigned)nchunks + (unsigned)pchunk) * (unsigned)(G_::U_PIECES * 1024)));
+            if constexpr (MODE == 2)   // the px half of the MODE 1 block of (py, channel block, chunk)
+                d_su = uniw((unsigned)(((((unsigned)(PU.py >> 1) * p.ncob + (unsigned)PU.cob) * (unsigned)nchunks + (unsigned)pchunk) * 2u + (unsigned)(PU.py & 1)) *
+                                       (unsigned)(G_::U_PIECES * 1024)));
+            else
+                d_su = uniw((unsigned)((((unsigned)PU.py * p.ncob + (unsigned)PU.cob) * (unsigned)nchunks + (unsigned)pchunk) * (unsigned)(G_::U_PIECES * 1024)));
             pc0 += 16, ++pchunk;
             if (pc0 >= s_c) {
                 pc0 = 0, ++ps;
@@ -227,10 +233,11 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
         prep();
         piece(std::integral_constant<int, 0>{}), piece(std::integral_constant<int, 1>{}), piece(std::integral_constant<int, 2>{});
         piece(std::integral_constant<int, 3>{}), piece(std::integral_constant<int, 4>{}), piece(std::integral_constant<int, 5>{});
-        piece(std::integral_constant<int, 6>{}), piece(std::integral_constant<int, 7>{}), piece(std::integral_constant<int, 8>{});
+        piece(std::integral_constant<int, 6>{}), piece(std::integral_constant<int, 7>{});
+        if constexpr (G_::NIT > 8) piece(std::integral_constant<int, 8>{});
         if constexpr (G_::NIT > 9) piece(std::integral_constant<int, 9>{});
     };
-    static_assert(G_::NIT == 9 || G_::NIT == 10, "piece() calls");
+    static_assert(G_::NIT >= 8 && G_::NIT <= 10, "piece() calls");
 
     // ---- operand addresses.  A: patch pixel (a, b) of tile (wv, l15) = raw pixel (2 wv + a, 2 l15 + b), channel slot kq
     int offb[4];
@@ -265,7 +272,11 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
         }
         const unsigned char *gbp = lds + (unsigned)(cbuf * G_::GROUP_BYTES);
         // first patch row of this wave's tiles in the raw tile (MODE 1: the classes py = 1 start one row further down)
-        const unsigned char *gap = gbp + (unsigned)((2 * wv + (MODE == 1 ? CU.py : 0)) * WR_ROW_BYTES);
+        const unsigned char *gap = gbp + (unsigned)((2 * wv + (MODE == 1 ? CU.py : (MODE == 2 ? CU.py >> 1 : 0))) * WR_ROW_BYTES);
+        int offc[4] = {offb[0], offb[1], offb[2], offb[3]};   // patch column offsets (MODE 2: the class's 3x3 sub-patch starts at column px)
+        if constexpr (MODE == 2) {
+            if (CU.py & 1) offc[0] = offb[1], offc[1] = offb[2], offc[2] = offb[3];
+        }
         if (!(ABL & 2)) {
             // The matrix phase is laid out by hand in 64 groups of two matrix instructions (the two 16-channel halves of one
             // component and k-step: alternating accumulators, so no instruction waits for its predecessor's 40-cycle result),
@@ -282,7 +293,7 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
             constexpr int NR = MODE == 0 ? 4 : 3;   // patch rows
             f32x4 d[NR][4];
             auto rd = [&](int a, int b) {
-                d[a][b] = (ABL & 8) ? (f32x4){(float)lane, 1.f, (float)a, (float)b} : *reinterpret_cast<const f32x4 *>(gap + offb[b] + a * WR_ROW_BYTES);
+                d[a][b] = (ABL & 8) ? (f32x4){(float)lane, 1.f, (float)a, (float)b} : *reinterpret_cast<const f32x4 *>(gap + offc[b] + a * WR_ROW_BYTES);
             };
             auto colop = [&](int i, int b) -> f32x4 {
                 if constexpr (MODE == 0) return i == 0 ? d[0][b] - d[2][b] : (i == 1 ? d[1][b] + d[2][b] : (i == 2 ? d[2][b] - d[1][b] : d[1][b] - d[3][b]));
@@ -294,14 +305,14 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
                     const int i = xi >> 2, j = xi & 3;
                     v = j == 0 ? colop(i, 0) - colop(i, 2) : (j == 1 ? colop(i, 1) + colop(i, 2) : (j == 2 ? colop(i, 2) - colop(i, 1) : colop(i, 1) - colop(i, 3)));
                 } else {   // component xi = (px class, i, j): the 3x3 sub-patch starts at column px
-                    const int c0 = xi / 9, i = (xi % 9) / 3, j = xi % 3;
+                    const int c0 = MODE == 2 ? 0 : xi / 9, i = (xi % 9) / 3, j = xi % 3;
                     v = j == 0 ? colop(i, c0) - colop(i, c0 + 1) : (j == 1 ? colop(i, c0 + 1) : colop(i, c0 + 2) - colop(i, c0 + 1));
                 }
                 asm volatile("" : "+v"(v));   // computed here, not where hipcc finds its first use
                 return v;
             };
             // B operands of the components xi .. xi + BD - 1 (requested BD - 1 components ahead; MODE 1 has no registers for a third set)
-            constexpr int BD = MODE == 0 ? 3 : 2;
+            constexpr int BD = MODE == 1 ? 2 : 3;
             f32x4 bq[BD][2];
             const bool nob = (ABL & 16) != 0;
             auto rdb = [&](int slot, int xi) {
@@ -334,8 +345,11 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
                     } else {
                         if (xi == 0 && st == 1) rd(0, 2), rd(1, 2);
                         if (xi == 1 && st == 1) rd(2, 0), rd(2, 1);
-                        if (xi == 2 && st == 1) rd(2, 2), rd(0, 3);
-                        if (xi == 3 && st == 1) rd(1, 3), rd(2, 3);
+                        if (xi == 2 && st == 1) rd(2, 2);
+                        if constexpr (MODE == 1) {
+                            if (xi == 2 && st == 2) rd(0, 3);
+                            if (xi == 3 && st == 1) rd(1, 3), rd(2, 3);
+                        }
                     }
                     if (xi < G_::NIT && (st == 0 || st == 2) && (st == 2) == half1) {   // wave-uniform
                         if (xi == 0) piece(std::integral_constant<int, 0>{});
@@ -346,7 +360,9 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
                         if (xi == 5) piece(std::integral_constant<int, 5>{});
                         if (xi == 6) piece(std::integral_constant<int, 6>{});
                         if (xi == 7) piece(std::integral_constant<int, 7>{});
-                        if (xi == 8) piece(std::integral_constant<int, 8>{});
+                        if constexpr (G_::NIT > 8) {
+                            if (xi == 8) piece(std::integral_constant<int, 8>{});
+                        }
                         if constexpr (G_::NIT > 9) {
                             if (xi == 9) piece(std::integral_constant<int, 9>{});
                         }
@@ -360,7 +376,8 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
         } else {
             piece(std::integral_constant<int, 0>{}), piece(std::integral_constant<int, 1>{}), piece(std::integral_constant<int, 2>{});
             piece(std::integral_constant<int, 3>{}), piece(std::integral_constant<int, 4>{}), piece(std::integral_constant<int, 5>{});
-            piece(std::integral_constant<int, 6>{}), piece(std::integral_constant<int, 7>{}), piece(std::integral_constant<int, 8>{});
+            piece(std::integral_constant<int, 6>{}), piece(std::integral_constant<int, 7>{});
+            if constexpr (G_::NIT > 8) piece(std::integral_constant<int, 8>{});
             if constexpr (G_::NIT > 9) piece(std::integral_constant<int, 9>{});
         }
 
@@ -406,13 +423,15 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
             } else {
                 // class outputs (2 ty + a, 2 tx + b) of class (py, px) = output pixels (2 (16 y0 + 2 wv + a) + py, 2 (32 x0 + 2 tx + b) + px)
                 const int OW = 2 * p.W;
-                const int oy = 2 * (CU.y0 * WR_TH + 2 * wv) + CU.py;
+                const int cpy = MODE == 2 ? CU.py >> 1 : CU.py;
+                const int oy = 2 * (CU.y0 * WR_TH + 2 * wv) + cpy;
                 float *orow = p.out + ((size_t)(CU.n * 2 * p.H + oy) * OW + 2 * CU.x0 * WR_TW) * p.out_ld + co;
                 const size_t rs = (size_t)2 * OW * p.out_ld;   // next class row = two output rows
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                    for (int pxc = 0; pxc < 2; ++pxc) {
+                    for (int pxc = 0; pxc < (MODE == 2 ? 1 : 2); ++pxc) {
+                        const int cpx = MODE == 2 ? (CU.py & 1) : pxc;
                         float y[2][2][2];   // [nt][row][col]
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt) {
@@ -426,7 +445,7 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
                             for (int b = 0; b < 2; ++b) y[nt][0][b] = tc[0][b] + tc[1][b], y[nt][1][b] = tc[1][b] + tc[2][b];
                         }
                         if (!(ABL & 4)) {
-                            float *o = orow + (size_t)(2 * (2 * (4 * kq + r)) + pxc) * p.out_ld;
+                            float *o = orow + (size_t)(2 * (2 * (4 * kq + r)) + cpx) * p.out_ld;
 #pragma unroll
                             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -505,21 +524,32 @@ int wring_try(const pws_conv_args *a, const ProfHint &ph, hipStream_t st) {
     p.ur = a->w_wring, p.ur_bytes = (unsigned)ur_bytes;
     p.bias = a->bias, p.act = a->act, p.out = a->out, p.out_ld = a->out_ld;
     p.tiles_x = a->w / WR_TW, p.tiles_y = a->h / WR_TH;
-    p.ncob = (unsigned)(a->cout / 32), p.ncls = ct4 ? 2u : 1u;
-    p.nunits = (unsigned)(p.tiles_x * p.tiles_y) * (unsigned)a->n * p.ncob * p.ncls;
-    p.nchunks = cin / 16;
-    p.ablate = g_experiment >= 51 && g_experiment <= 57 ? g_experiment - 50 : (g_experiment >= 1000 && g_experiment < 1512 ? g_experiment - 1000 : 0);
     static int ncu = 0;
     if (ncu == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
         ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
+    p.ncob = (unsigned)(a->cout / 32), p.ncls = ct4 ? 2u : 1u;
+    p.nunits = (unsigned)(p.tiles_x * p.tiles_y) * (unsigned)a->n * p.ncob * p.ncls;
+    // transposed kind: one class per unit (MODE 2) when the two-class units leave CUs without work (PWS_OPT_EXPERIMENT 59 forces it)
+    const bool mode2 = ct4 && ((p.nunits < (unsigned)ncu && g_experiment != 60) || g_experiment == 59);
+    if (mode2) p.ncls = 4, p.nunits *= 2;
+    p.nchunks = cin / 16;
+    p.ablate = g_experiment >= 51 && g_experiment <= 57 ? g_experiment - 50 : (g_experiment >= 1000 && g_experiment < 1512 ? g_experiment - 1000 : 0);
     // a unit is nchunks x 8 192 (9 216) matrix cycles: fewer units than CUs leave CUs idle for the whole launch, and a non-integer
-    // number of rounds costs its tail -- taken from 3/4 of the chip upwards (PWS_OPT_EXPERIMENT 58 forces it for the tests)
-    if (p.nunits < (unsigned)(ncu * 3 / 4) && g_experiment != 58) return 1;
+    // number of rounds costs its tail -- taken from 3/4 of the chip upwards (PWS_OPT_EXPERIMENT 58 / 59 force it for the tests)
+    if (p.nunits < (unsigned)(ncu * 3 / 4) && g_experiment != 58 && g_experiment != 59) return 1;
     ProfScope prof(ct4 ? KID_CONV_WRING_CT4 : KID_CONV_WRING, ph.flops, ph.bytes, st);
     const unsigned grid = p.nunits < (unsigned)ncu ? p.nunits : (unsigned)ncu;   // one persistent workgroup per CU
+    if (mode2) {
+        switch (p.ablate) {
+        case 0: return wring_launch<2, 0>(p, grid, st);
+        case 64: return wring_launch<2, 64>(p, grid, st);
+        case 120: return wring_launch<2, 120>(p, grid, st);
+        default: set_error("wino_ring_kernel<2>: ablation mask %d is not instantiated", p.ablate); return PWS_EINVAL;
+        }
+    }
     if (ct4) {
         switch (p.ablate) {
         case 0: return wring_launch<1, 0>(p, grid, st);

@@ -257,19 +257,21 @@ def test_conv_winograd_ring_vs_oracle(hip, oracle, kname, shape, src_c, cout):
     ring_name = "wino_ring_kernel<convT4,F(2x2,2x2)>" if k == 4 else "wino_ring_kernel<F(2x2,3x3)>"
     got = {}
     try:
-        for force in (58, 50):
+        for force in (58, 59, 50) if k == 4 else (58, 50):   # 59: one parity class per unit (the variant for launches of few units)
             L.pws_set_option(100, force)
             L.pws_prof_enable(1)
             got[force] = run_conv(A, kind, srcs, wt, b, 1, cout, wino=True)
             L.pws_prof_enable(0)
             names = [r[0] for r in A.prof_collect()]
-            assert (ring_name in names) == (force == 58), names
+            assert (ring_name in names) == (force != 50), names
     finally:
         L.pws_prof_enable(0)
         L.pws_set_option(100, 0)
     assert not np.isnan(got[58]).any()
     np.testing.assert_allclose(nchw(got[58]), ref, rtol=0, atol=5e-5)
     np.testing.assert_allclose(got[58], got[50], rtol=0, atol=5e-5)
+    if 59 in got:
+        np.testing.assert_allclose(nchw(got[59]), ref, rtol=0, atol=5e-5)
 
 
 def test_conv_first_layer_nchw_31ch(hip, oracle):
