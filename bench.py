@@ -80,10 +80,17 @@ _PMC_NAMES = {
     "conv_mfma_kernel<convT4,16x16>": ["convT4,tile 1x16x16", "convT4,tile 1x8x16"],
     "conv_mfma_kernel<k3s1,16x16>": ["k3s1,tile 1x16x16", "k3s1,tile 1x8x16"],
     "wino_k3s1_kernel<F(2x2,3x3)>": ["wino_k3s1_kernel", "wino_kernel<0>"],
+    "wino_ring_kernel<F(2x2,3x3)>": ["wino_ring_kernel<F(2x2,3x3)"],
+    "wino_ring_kernel<convT4,F(2x2,2x2)>": ["wino_ring_kernel<convT4"],
     "conv_bf16_kernel": ["conv_bf16_kernel", "conv_bf16_k5_kernel"],
     "conv_mfma_kernel<k5s1,16x16>": ["k5s1,tile"],
     "grid_sample_fwd_kernel": ["grid_sample_fwd2_kernel"],
 }
+
+
+# multiplies of the direct convolution per multiply the Winograd kernels execute (conv_wino.hip / conv_wring.hip)
+WINOGRAD_REDUCTION = {"wino_k3s1_kernel<F(2x2,3x3)>": 2.25, "wino_ct4_kernel<F(3x3,2x2)>": 2.25, "wino_ring_kernel<F(2x2,3x3)>": 2.25,
+                      "wino_ring_kernel<convT4,F(2x2,2x2)>": 16.0 / 9.0}
 
 
 def pmc_traffic(kernel):
@@ -494,13 +501,22 @@ def main():
                 e[0] += 1; e[1] += fl; e[2] += by; e[3] += ms  # noqa: E702
             dom = max(agg.items(), key=lambda kv: kv[1][3])
             name, (cnt, fl, by, ms) = dom
-            ach = fl / (ms * 1e-3) / 1e12
+            # Winograd kernels: `fl` counts the DIRECT convolution's flops (the algorithmic work of the layer); the matrix
+            # cores execute 1 / reduction of them, and the roofline fraction is taken on the EXECUTED flops (utilisation), with the
+            # direct-equivalent rate quoted beside it
+            red = WINOGRAD_REDUCTION.get(name, 1.0)
+            ach = fl / red / (ms * 1e-3) / 1e12
             peak = PEAK_BF16_TFLOPS if "bf16" in name else PEAK_FP32_TFLOPS
             line["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
                                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": pmc_traffic(name),
                                 "algorithmic_bytes_per_launch": round(by / cnt),
                                 "launches": cnt, "avg_launch_us": round(1e3 * ms / cnt, 2),
-                                "flops_per_launch": fl / cnt}
+                                "flops_per_launch": fl / red / cnt}
+            if red != 1.0:
+                line["roofline"]["winograd_reduction"] = round(red, 4)
+                line["roofline"]["direct_equivalent_tflops"] = round(fl / (ms * 1e-3) / 1e12, 2)
+                line["roofline"]["what"] = ("achieved / frac = matrix-core flops actually executed (direct flops / reduction) over the "
+                                            "launch time: utilisation of the fp32 MFMA peak; direct_equivalent_tflops = direct flops / time")
             tot_ms = sum(v[3] for v in agg.values())
             line["kernel_time_share"] = {k: round(v[3] / tot_ms, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][3])}
             line["kernel_tflops"] = {k: round(v[1] / (v[3] * 1e-3) / 1e12, 2) for k, v in agg.items()
