@@ -178,25 +178,32 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
     bool d_kill = false;   // past the last slot (or ablation): the pieces fetch nothing (offsets beyond num_records)
     int s_ld = p.src_ld[0], s_c = p.src_c[0];   // source ps
     const char *s_ptr = reinterpret_cast<const char *>(p.src_ptr[0]);
+    unsigned d_su0 = 0;     // weight offset of chunk 0 of unit pu
+    bool p_new = true;      // the cursor entered a new unit or source: the descriptors below are recomputed (once per unit, typically)
     auto prep = [&]() {
         d_kill = pu >= u_end || ((ABL & 1) && !pfirst) || (ABL & 64);
         pfirst = false;
         d_base = uniw((unsigned)(pbuf * G_::GROUP_BYTES));
         pbuf ^= 1;
         if (pu < u_end) {
-            const size_t img = (size_t)p.H * p.W * s_ld * 4;   // bytes of one sample
-            const char *base_in = uniw(s_ptr + (size_t)PU.n * img);
-            d_rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base_in), 0, (int)uniw((unsigned)img), 0x00020000);
-            d_ldb = (unsigned)s_ld * 4u;
-            d_sin = uniw((unsigned)(pc0 * 4));
-            d_oy = PU.y0 * WR_TH - 1, d_ox = PU.x0 * WR_TW - 1;
-            if constexpr (MODE == 2)   // the px half of the MODE 1 block of (py, channel block, chunk)
-                d_su = uniw((unsigned)(((((unsigned)(PU.py >> 1) * p.ncob + (unsigned)PU.cob) * (unsigned)nchunks + (unsigned)pchunk) * 2u + (unsigned)(PU.py & 1)) *
-                                       (unsigned)(G_::U_PIECES * 1024)));
-            else
-                d_su = uniw((unsigned)((((unsigned)PU.py * p.ncob + (unsigned)PU.cob) * (unsigned)nchunks + (unsigned)pchunk) * (unsigned)(G_::U_PIECES * 1024)));
+            if (p_new) {
+                p_new = false;
+                const size_t img = (size_t)p.H * p.W * s_ld * 4;   // bytes of one sample
+                const char *base_in = uniw(s_ptr + (size_t)PU.n * img);
+                d_rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base_in), 0, (int)uniw((unsigned)img), 0x00020000);
+                d_ldb = (unsigned)s_ld * 4u;
+                d_oy = PU.y0 * WR_TH - 1, d_ox = PU.x0 * WR_TW - 1;
+                if constexpr (MODE == 2)   // the px half of the MODE 1 block of (py, channel block, chunk)
+                    d_su0 = uniw((unsigned)(((((unsigned)(PU.py >> 1) * p.ncob + (unsigned)PU.cob) * (unsigned)nchunks) * 2u + (unsigned)(PU.py & 1)) *
+                                            (unsigned)(G_::U_PIECES * 1024)));
+                else
+                    d_su0 = uniw((unsigned)((((unsigned)PU.py * p.ncob + (unsigned)PU.cob) * (unsigned)nchunks) * (unsigned)(G_::U_PIECES * 1024)));
+            }
+            d_sin = (unsigned)(pc0 * 4);
+            d_su = d_su0 + (unsigned)pchunk * (unsigned)((MODE == 2 ? 2 : 1) * G_::U_PIECES * 1024);
             pc0 += 16, ++pchunk;
             if (pc0 >= s_c) {
+                p_new = true;
                 pc0 = 0, ++ps;
                 if (ps == p.nsrc) {
                     ps = 0, pchunk = 0, pu += u_step;
