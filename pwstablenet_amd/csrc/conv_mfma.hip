@@ -362,6 +362,7 @@ int conv_bf16_fwd(int kind, ConvKParams &kp, int cin_total, float *out, float *w
                   const ProfInfo &pi);  // conv_bf16.hip; 1 = not covered
 int conv_bf16_dgrad(int kind, ConvKParams &kp, int cout_f, float *ws, size_t ws_floats, hipStream_t st, const ProfInfo &pi);
 int conv_ringf_try(int kind, const ConvKParams &kp, hipStream_t st, const ProfInfo &pi);   // conv_ring_f32.hip; 1 = not covered
+int conv_skinny_try(int kind, ConvKParams &kp, float *final_out, float *ws, size_t ws_floats, hipStream_t st, const ProfInfo &pi);  // conv_skinny.hip; 1 = not covered
 
 int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
     PWS_REQUIRE(a != nullptr, "pws_conv2d_fwd: args is NULL");
@@ -443,7 +444,9 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
             return wino_k3s1_launch(a, ProfHint{pi.flops, pi.bytes}, st);
         if (!bf16 && !nchw) {   // the persistent LDS-ring kernel (exact fp32) where it is covered
             kp.out = a->out;
-            const int rc = conv_ringf_try(a->kind, kp, st, pi);
+            int rc = conv_ringf_try(a->kind, kp, st, pi);
+            if (rc != 1) return rc;
+            rc = conv_skinny_try(a->kind, kp, a->out, ws, ws_floats, st, pi);   // the deep levels: one-shot weight fetch
             if (rc != 1) return rc;
         }
         return select_and_launch(kK3S1, 5, kp, kp.cin_pad, a->out, ws, ws_floats, st, pi);
@@ -456,7 +459,9 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
         }
         if (!bf16 && !nchw) {
             kp.out = a->out;
-            const int rc = conv_ringf_try(a->kind, kp, st, info(9, (double)a->n * kp.OH * kp.OW));
+            int rc = conv_ringf_try(a->kind, kp, st, info(9, (double)a->n * kp.OH * kp.OW));
+            if (rc != 1) return rc;
+            rc = conv_skinny_try(a->kind, kp, a->out, ws, ws_floats, st, info(9, (double)a->n * kp.OH * kp.OW));
             if (rc != 1) return rc;
         }
         return select_and_launch(kK3S2, 5, kp, kp.cin_pad, a->out, ws, ws_floats, st, info(9, (double)a->n * kp.OH * kp.OW));
@@ -488,7 +493,9 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
         if (a->w_wino && a->h >= 24 && a->w >= 24 && wb >= 256) return wino_k3s1_launch(a, ProfHint{pi.flops, pi.bytes}, st);
         if (!bf16 && !nchw) {
             kp.out = a->out;
-            const int rc = conv_ringf_try(a->kind, kp, st, pi);
+            int rc = conv_ringf_try(a->kind, kp, st, pi);
+            if (rc != 1) return rc;
+            rc = conv_skinny_try(a->kind, kp, a->out, ws, ws_floats, st, pi);
             if (rc != 1) return rc;
         }
         return select_and_launch(kCT4, 5, kp, kp.cin_pad, a->out, ws, ws_floats, st, pi);

@@ -208,19 +208,38 @@ def test_netg_backward_vs_torch_cpu_autograd(hip, kind, loss_kind, tol):
     cg, cr = torch_ref.netg_forward(cparams, xw, True)
     closs = loss_fn(cg, cr, frames, target, tfield, lambda f, g_: F.grid_sample(f, g_, align_corners=False))
     closs.backward()
+    # the same step in float64: the yardstick for what an fp32 evaluation of these gradients can deliver.  The deep layers' gradients
+    # are sums of strongly cancelling terms: torch's own fp32 step sits a few 1e-4 of a tensor's maximum away from it, and so does
+    # this path -- by how much depends on the summation order, i.e. on which kernel a layer runs on (measured on the "field" / W1
+    # case: 3.1e-4 with conv_mfma_kernel's small tiles on the deep levels, 7.0e-4 with conv_skinny_kernel, same arithmetic)
+    dparams = [torch.from_numpy(v.astype(np.float64)).requires_grad_(True) for _, v in weights]
+    dg, dr = torch_ref.netg_forward(dparams, xw.double(), True)
+    dloss = loss_fn(dg, dr, frames.double(), target.double(), tfield.double(), lambda f, g_: F.grid_sample(f, g_, align_corners=False))
+    dloss.backward()
     net = make_net(kind, ngf)
     grids, resid = net(xw.cuda())
     loss = loss_fn(grids, resid, frames.cuda(), target.cuda(), tfield.cuda(), PF.grid_sample)
     loss.backward()
     assert abs(loss.item() - closs.item()) < 1e-5 * max(1.0, abs(closs.item()))
-    worst = 0.0
-    for (name, _), p, cp in zip(weights, net.module._ordered_params(), cparams):
+    worst = worst_cpu = worst_hip64 = 0.0
+    errs = []
+    for (name, _), p, cp, dp in zip(weights, net.module._ordered_params(), cparams, dparams):
         ref = cp.grad.numpy()
+        ref64 = dp.grad.numpy()
         got = p.grad.cpu().numpy()
+        scale64 = max(np.abs(ref64).max(), 1e-12)
         err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12)
-        worst = max(worst, err)
-        assert err < tol, "%s: max err / max|ref| = %.3g" % (name, err)
-    print("%s/%s: worst relative gradient error over 92 tensors: %.3g" % (kind, loss_kind, worst))
+        e_cpu = np.abs(ref - ref64).max() / scale64
+        e_hip = np.abs(got - ref64).max() / scale64
+        worst, worst_cpu, worst_hip64 = max(worst, err), max(worst_cpu, e_cpu), max(worst_hip64, e_hip)
+        errs.append((name, err, e_cpu, e_hip))
+    print("%s/%s: worst relative gradient error over 92 tensors: vs torch fp32 %.3g; vs the float64 step: this path %.3g, torch fp32 %.3g"
+          % (kind, loss_kind, worst, worst_hip64, worst_cpu))
+    for name, err, e_cpu, e_hip in errs:
+        # as close to the float64 gradient as torch's own fp32 step is on its worst tensor (x3), or within the stated tolerance
+        assert e_hip < max(tol, 3 * worst_cpu), "%s: |hip - f64| / max|f64| = %.3g (torch fp32: %.3g on this tensor, %.3g worst)" % (
+            name, e_hip, e_cpu, worst_cpu)
+        assert err < 4 * max(tol, 3 * worst_cpu), "%s: max err / max|ref| = %.3g" % (name, err)
 
 
 @pytest.mark.parametrize("tag,kind,ngf,n", [("W1_g16", "W1", 16, 2), ("W2_g16", "W2", 16, 1), ("W1_g64", "W1", 64, 2),

@@ -274,6 +274,54 @@ def test_conv_winograd_ring_vs_oracle(hip, oracle, kname, shape, src_c, cout):
         np.testing.assert_allclose(nchw(got[59]), ref, rtol=0, atol=5e-5)
 
 
+@pytest.mark.parametrize("kname,shape,src_c,cout", [
+    ("CONV_K3S1", (8, 4, 4), [512], 512),          # M = 128: two M tiles per wave; 32 chunks -> one per workgroup
+    ("CONVT_K3S1", (8, 2, 2), [64, 32], 80),       # M = 32 (2 x 2 wave grid), virtual concat, cout not a multiple of 64 / 16
+    ("CONV_K3S2", (8, 2, 2), [512, 512], 512),     # 2x2 -> 1x1: M = 8, 64 chunks
+    ("CONV_K3S2", (8, 8, 8), [128, 128], 96),      # 8x8 -> 4x4: M = 128
+    ("CONV_K3S2", (3, 5, 7), [48], 32),            # ragged extent: 3x4 outputs per sample, M = 36 (padding pixels in the last tile)
+    ("CONVT_K4S2", (8, 1, 1), [512], 512),         # 1x1 -> 2x2: M = 8 per parity class
+    ("CONVT_K4S2", (8, 4, 4), [512, 512], 256),    # 4x4 -> 8x8: M = 128 per class, 8 chunks of 2x2 taps per workgroup
+    ("CONVT_K4S2", (2, 3, 5), [32, 16], 20),       # ragged, cout % 16 != 0
+])
+def test_conv_skinny_vs_oracle(hip, oracle, kname, shape, src_c, cout):
+    """The deep levels' one-shot kernel (conv_skinny.hip: at most 128 output pixels per parity class, all weights of a workgroup
+    in one LDS-DMA burst, split-K through the workspace) against the C oracle and conv_mfma_kernel's small tiles."""
+    A = hip
+    L = A.lib()
+    kind = getattr(A, kname)
+    n, h, w = shape
+    rs = np.random.RandomState(zlib.crc32(repr((kname, shape, cout, "sk")).encode()))
+    cin = sum(src_c)
+    is_t = kname.startswith("CONVT")
+    k = 4 if kname == "CONVT_K4S2" else 3
+    stride = 2 if kname in ("CONVT_K4S2", "CONV_K3S2") else 1
+    x = rs.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (rs.standard_normal((cin, cout, k, k) if is_t else (cout, cin, k, k)) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rs.standard_normal((cout,)).astype(np.float32)
+    ref = (oracle.conv_transpose2d if is_t else oracle.conv2d)(x, wt, b, stride, 1, oracle.ACT_LRELU)
+    xs = nhwc(x)
+    srcs, c0 = [], 0
+    for c in src_c:
+        srcs.append(np.ascontiguousarray(xs[..., c0:c0 + c]))
+        c0 += c
+    got = {}
+    try:
+        for force in (0, 70):
+            L.pws_set_option(100, force)
+            L.pws_prof_enable(1)
+            got[force] = run_conv(A, kind, srcs, wt, b, 1, cout, ws_mb=64)
+            L.pws_prof_enable(0)
+            names = [r[0] for r in A.prof_collect()]
+            assert ("conv_skinny_kernel" in names) == (force == 0), names
+    finally:
+        L.pws_prof_enable(0)
+        L.pws_set_option(100, 0)
+    assert not np.isnan(got[0]).any()
+    np.testing.assert_allclose(nchw(got[0]), ref, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(got[0], got[70], rtol=0, atol=5e-5)
+
+
 def test_conv_first_layer_nchw_31ch(hip, oracle):
     """transfer: k5 s1 p2 on the reference's NCHW 31-channel window (lib/networks_cascading.py:112,153)."""
     A = hip
