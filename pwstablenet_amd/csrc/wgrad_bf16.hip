@@ -440,6 +440,8 @@ static const WbChoice &pick(const WbChoice *c, int n, int LH, int LW, int N) {
 
 // Called by conv2d_bwd_weight_impl after its argument checks.  Returns 1 when the launch is not covered (first layer's
 // NCHW window, sources that are not multiples of 32 channels): the caller then runs the fp32 kernel.
+int wgrad_ring_try(const pws_conv_bwd_weight_args *a, int cin, hipStream_t st);   // wgrad_ring.hip; 1 = not covered
+
 int wgrad_bf16_launch(const pws_conv_bwd_weight_args *a, hipStream_t st) {
     if (a->src_nchw) return 1;
     WgradBfParams p{};
@@ -459,6 +461,10 @@ int wgrad_bf16_launch(const pws_conv_bwd_weight_args *a, hipStream_t st) {
             set_error("pws_conv2d_bwd_weight: bf16 storage needs ld %% 8 == 0 for every source and for gout");
             return PWS_EINVAL;
         }
+    }
+    if (p.io_bf16) {   // the persistent LDS-ring kernel where it is covered (stride-1 kinds, whole 16 x 16 tiles, long tile streams)
+        const int rc = wgrad_ring_try(a, cin, st);
+        if (rc != 1) return rc;
     }
     p.cin = cin, p.cin_pad = (cin + 15) / 16 * 16, p.cout = a->cout;
     p.N = a->n, p.H = a->h, p.W = a->w;

@@ -1,0 +1,324 @@
+// bf16 weight gradient (K = pixels) on a persistent LDS ring: second generation of wgrad_bf16.hip for the launches that dominate
+// BASELINE configs[2] / [3] (bf16 activation storage, 16 x 16-pixel tiles, at least 64 input and output channels).
+//     dP[class][tap][ci][co] += sum_m x[m * S + tap - pad][ci] * dy[m][co]
+//
+// Why (profiles/r02_kernel_stats_configs2_bf16.csv): wgrad_bf16_kernel is 30 % of the configs[2] step at ~620 TFLOP/s.  Its tiles
+// go global -> VGPR -> ds_write_b128 -> LDS; the 3x3 kind has no registers left to keep the next tile in flight during the matrix
+// phase (144 accumulators + 76 staging registers), so every tile pays 2-3 exposed memory latencies, 19 LDS stores per lane and two
+// barriers.  Here the tile image in LDS is byte for byte what lies in memory (rows [pixel][32 channels] of 64 bytes), so it is filled
+// by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPR stage, no LDS store instructions), one tile ahead, by 4 loader waves; the 8
+// matrix waves only wait at ONE barrier per tile.  Unlike the forward / data-gradient ring (conv_ring.hip) there is no per-unit
+// epilogue: a workgroup keeps its 64 x 64 x taps accumulators over all the tiles it walks and adds them to dW once, at the end.
+//   * workgroup = 64 input x 64 output channels x ALL taps of one parity class, one per CU; matrix wave = (32 x 32 quadrant, tap
+//     half): 5 / 4 (3x3) or 2 / 2 (2x2 class kernels) accumulators of 16 registers -> 168 registers leave room for 3 waves per SIMD
+//     (8 matrix + 4 loader waves);
+//   * operands by the transposing LDS read ds_read_b64_tr_b16, addresses as in wgrad_bf16.hip (the tile image is the same);
+//   * zero padding / masked pixels: DMA offsets beyond the descriptor's num_records deliver zeros.
+#include <type_traits>
+
+#include "common.h"
+
+namespace pws {
+
+typedef float wr_f32x16 __attribute__((ext_vector_type(16)));
+typedef short wr_s16x4 __attribute__((ext_vector_type(4)));
+
+struct WgradRingParams {
+    const void *src_ptr[4];   // bf16 NHWC sources of the forward layer's virtual concat (multiples of 32 channels)
+    int src_c[4], src_ld[4];
+    int nsrc;
+    int cin, cin_pad, cout;
+    int N, H, W;     // forward input extent
+    int LH, LW;      // logical extent walked by tiles
+    int OH, OW;      // forward output extent (extent of dy)
+    const void *gout;
+    int gout_ld;
+    float *dw;
+    int tiles_x, tiles_y, ntiles;
+    int ci_blocks, co_blocks;
+    float *dbias;
+};
+
+template <int KS_, int PAD_, int SUBPIX_>
+struct WrgCfg {
+    static constexpr int KS = KS_, PAD = PAD_, SUBPIX = SUBPIX_, TH = 16, TW = 16;   // stride 1 kinds, 16 x 16-pixel tiles of one sample
+    static constexpr int TAPS = KS * KS;
+    static constexpr int NT0 = (TAPS + 1) / 2;            // taps of the first wave half (the second takes the rest)
+    static constexpr int BM = TH * TW, KSTEPS = BM / 16;
+    static constexpr int IH = TH + KS - 1, IW = TW + KS - 1, PIX = IH * IW;
+    static constexpr int ROW = 64;                        // bytes per LDS row: 32 bf16 channels
+    static constexpr int XPP = (PIX * 4 + 63) / 64;       // DMA pieces (1 KB) per 32-channel plane of the x tile
+    static constexpr int GPP = BM * 4 / 64;               // ... of the dy tile
+    static constexpr int XP_BYTES = XPP * 1024, G_OFF = 2 * XP_BYTES, GP_BYTES = GPP * 1024;
+    static constexpr int PIECES = 2 * XPP + 2 * GPP;
+    static constexpr int MWAVES = 8, LWAVES = 4, THREADS = 64 * (MWAVES + LWAVES);
+    static constexpr int NL = (PIECES + LWAVES - 1) / LWAVES;
+    static constexpr int IMG_BYTES = NL * LWAVES * 1024;
+    static constexpr int R = 2, LDS_BYTES = R * IMG_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+__device__ __forceinline__ void wrg_dma16(unsigned lds_addr, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff));
+}
+constexpr unsigned kWrgOob = 0x7ffffff0u;
+__device__ __forceinline__ unsigned uniq(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ const char *uniq(const char *ptr) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+    return reinterpret_cast<const char *>(((unsigned long long)uniq((unsigned)(a >> 32)) << 32) | uniq((unsigned)a));
+}
+template <class T>
+__device__ __forceinline__ T wrgsel4(const T (&a)[4], int i) {
+    return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3]));
+}
+__device__ __forceinline__ bf16x8 wrg_tr_pair(const unsigned char *lds, int off0, int off1) {
+    typedef __attribute__((address_space(3))) wr_s16x4 *lptr;
+    const wr_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + off0));
+    const wr_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + off1));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <class C>
+__global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRingParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5, li = lane & 15, lg = lane >> 4;
+
+    const int cb = blockIdx.y;
+    const int ci0 = (cb / p.co_blocks) * 64, co0 = (cb % p.co_blocks) * 64;
+    const int cls = C::SUBPIX ? (int)blockIdx.z : 0;
+    const int py = cls >> 1, px = cls & 1;
+    const int pad_y = C::SUBPIX ? 1 - py : C::PAD, pad_x = C::SUBPIX ? 1 - px : C::PAD;
+    const int my_tiles = ((int)blockIdx.x < p.ntiles) ? (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+
+    if (wv >= C::MWAVES) {
+        // =========================================================================================== loader waves
+        const int lw = wv - C::MWAVES;
+        // piece pc = it * 4 + lw of a tile image: [x plane 0 | x plane 1 | dy plane 0 | dy plane 1], a plane = rows of 64 bytes (4 lanes)
+        int desc[C::NL];   // kind << 28 | row-in-plane << 2 | 16-byte slot, or -1 (filler / past the plane)
+#pragma unroll
+        for (int it = 0; it < C::NL; ++it) {
+            const int pc = it * C::LWAVES + lw;
+            int kind, pl0;
+            if (pc < C::XPP) kind = 0, pl0 = 0;
+            else if (pc < 2 * C::XPP) kind = 1, pl0 = C::XPP;
+            else if (pc < 2 * C::XPP + C::GPP) kind = 2, pl0 = 2 * C::XPP;
+            else kind = 3, pl0 = 2 * C::XPP + C::GPP;
+            const int j = (pc - pl0) * 64 + lane;
+            const int row = j >> 2, sp = j & 3;
+            const bool ok = pc < C::PIECES && row < (kind < 2 ? C::PIX : C::BM);
+            desc[it] = ok ? (kind << 28 | row << 2 | sp) : -1;
+        }
+        // channel block of the x planes inside the virtual concat (sources are multiples of 32 channels: a plane lies in one source)
+        int xs[2], xch[2];
+        bool xok[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            int ch = ci0 + q * 32, s = 0;
+            xok[q] = ch < p.cin;
+            while (s < p.nsrc - 1 && ch >= wrgsel4(p.src_c, s)) ch -= wrgsel4(p.src_c, s), ++s;
+            xs[q] = xok[q] ? s : 0, xch[q] = xok[q] ? ch : 0;
+        }
+        const bool gok[2] = {co0 < p.cout, co0 + 32 < p.cout};
+        int tile = blockIdx.x, pbuf = 0;
+        auto stage = [&]() {
+            const unsigned d_base = uniq((unsigned)(pbuf * C::IMG_BYTES)) + (unsigned)(lw * 1024);
+            pbuf ^= 1;
+            const bool live = tile < p.ntiles;
+            const int tt = live ? tile : 0;
+            const int tx_i = tt % p.tiles_x, ty_i = (tt / p.tiles_x) % p.tiles_y, n0 = tt / (p.tiles_x * p.tiles_y);
+            const int y0 = ty_i * C::TH, x0 = tx_i * C::TW;
+            const int iy0 = y0 - pad_y, ix0 = x0 - pad_x;
+            // descriptors: one sample of each tensor (offsets stay below 2^31 whatever the batch)
+            __amdgpu_buffer_rsrc_t rx[2];
+            unsigned ldx[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int ld = wrgsel4(p.src_ld, xs[q]);
+                const size_t img = (size_t)p.H * p.W * ld * 2;
+                const char *b = uniq(static_cast<const char *>(wrgsel4(p.src_ptr, xs[q])) + (size_t)n0 * img + (size_t)xch[q] * 2);
+                rx[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(b), 0, (int)uniq((unsigned)(img - (size_t)xch[q] * 2)), 0x00020000);
+                ldx[q] = (unsigned)ld * 2u;
+            }
+            const size_t gimg = (size_t)p.OH * p.OW * p.gout_ld * 2;
+            const char *gb = uniq(static_cast<const char *>(p.gout) + (size_t)n0 * gimg + (size_t)co0 * 2);
+            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gb), 0, (int)uniq((unsigned)(gimg - (size_t)co0 * 2)), 0x00020000);
+            const unsigned ldg = (unsigned)p.gout_ld * 2u;
+#pragma unroll
+            for (int it = 0; it < C::NL; ++it) {
+                const int pc = it * C::LWAVES + lw;   // wave-uniform: the kind of a piece is too
+                const int row = (desc[it] >> 2) & 0x3ffffff, sp = desc[it] & 3;
+                unsigned v = kWrgOob;
+                const unsigned dst = d_base + (unsigned)(it * C::LWAVES * 1024);
+                if (pc < 2 * C::XPP) {
+                    const int q = pc < C::XPP ? 0 : 1;
+                    const int lx = row % C::IW, ly = row / C::IW;
+                    const int iy = iy0 + ly, ix = ix0 + lx;
+                    const bool ok = live && desc[it] >= 0 && xok[q] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                    if (ok) v = (unsigned)(iy * p.W + ix) * ldx[q] + (unsigned)(sp * 16);
+                    wrg_dma16(dst, v, q ? rx[1] : rx[0], 0u);
+                } else {
+                    const int q = pc < 2 * C::XPP + C::GPP ? 0 : 1;
+                    const int tx = row % C::TW, ty = row / C::TW;
+                    const int y = y0 + ty, x = x0 + tx;
+                    const int oy = C::SUBPIX ? 2 * y + py : y, ox = C::SUBPIX ? 2 * x + px : x;
+                    const bool ok = live && desc[it] >= 0 && gok[q] && y < p.LH && x < p.LW && oy < p.OH && ox < p.OW;
+                    if (ok) v = (unsigned)(oy * p.OW + ox) * ldg + (unsigned)(q * 64 + sp * 16);
+                    wrg_dma16(dst, v, rg, 0u);
+                }
+            }
+            tile += gridDim.x;
+        };
+        stage();
+        for (int s = 0; s < my_tiles; ++s) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile s have landed
+            __builtin_amdgcn_s_barrier();                       // B_s: everybody's have; the matrix waves are done with tile s - 1
+            stage();                                            // tile s + 1 into the buffer tile s - 1 occupied (fillers past the end)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the filler pieces still target this workgroup's LDS
+        return;
+    }
+
+    // =============================================================================================== matrix waves
+    const int quad = wv & 3, th = wv >> 2;
+    const int wci = quad >> 1, wco = quad & 1;
+    const int t0 = th ? C::NT0 : 0, nt = th ? C::TAPS - C::NT0 : C::NT0;   // wave-uniform
+    wr_f32x16 acc[C::NT0];
+#pragma unroll
+    for (int t = 0; t < C::NT0; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // transposing-read addresses (bytes), as wgrad_bf16.hip: read q of a k-step covers pixels 8 * (lg >> 1) + 4 q + (li >> 2) of the step,
+    // this lane supplies row (li >> 2) and the 4 columns 4 * (li & 3) .. of its group's 16 channels 16 * (lg & 1) ..
+    const int colb = (16 * (lg & 1) + 4 * (li & 3)) * 2;
+    int a_lane[2], b_lane[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = 8 * (lg >> 1) + 4 * q + (li >> 2);   // pixel of the k-step = tile pixel 16 j + c = (row j, column c)
+        a_lane[q] = wci * C::XP_BYTES + c * C::ROW + colb;
+        b_lane[q] = C::G_OFF + wco * C::GP_BYTES + c * C::ROW + colb;
+    }
+    const bool do_bias = p.dbias != nullptr && cb / p.co_blocks == 0 && th == 0 && wci == 0;
+    float bsum = 0.f;
+
+    int cbuf = 0;
+    for (int s = 0; s < my_tiles; ++s) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // B_s
+        asm volatile("" ::: "memory");
+        const unsigned char *img = lds + (unsigned)(cbuf * C::IMG_BYTES);
+#pragma unroll
+        for (int j = 0; j < C::KSTEPS; ++j) {   // k-step j = the 16 pixels of tile row j
+            const bf16x8 b = wrg_tr_pair(img, b_lane[0] + j * 16 * C::ROW, b_lane[1] + j * 16 * C::ROW);
+            if (do_bias) {   // wave-uniform: this lane holds 8 pixels of dy column l31 (masked pixels are zeros)
+                const bf16x2 one2 = {(__bf16)1.0f, (__bf16)1.0f};
+                bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(b, b, 0, 1), one2, bsum, false);
+                bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(b, b, 2, 3), one2, bsum, false);
+                bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(b, b, 4, 5), one2, bsum, false);
+                bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(b, b, 6, 7), one2, bsum, false);
+            }
+#pragma unroll
+            for (int t = 0; t < C::NT0; ++t) {
+                if (t < nt) {
+                    const int tap = t0 + t;   // wave-uniform
+                    const int toff = ((tap / C::KS) * C::IW + (tap % C::KS)) * C::ROW;
+                    const int joff = j * C::IW * C::ROW + toff;
+                    const bf16x8 a = wrg_tr_pair(img, a_lane[0] + joff, a_lane[1] + joff);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        cbuf ^= 1;
+    }
+
+    // ---- one atomic per element: rows = input channels of this wave's quadrant, 32 lanes = 32 consecutive output channels
+    const int co = co0 + wco * 32 + l31;
+    if (do_bias) {
+        bsum += __shfl_xor(bsum, 32, 64);   // the two k halves
+        if (hi == 0 && co < p.cout) atomicAdd(p.dbias + co, bsum);
+    }
+#pragma unroll
+    for (int t = 0; t < C::NT0; ++t) {
+        if (t < nt) {
+            const int tap = t0 + t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (ci < p.cin_pad && co < p.cout) atomicAdd(p.dw + ((size_t)(cls * C::TAPS + tap) * p.cin_pad + ci) * p.cout + co, acc[t][r]);
+            }
+        }
+    }
+}
+
+template <class C>
+static int wrg_launch(WgradRingParams &p, int nclasses, hipStream_t st) {
+    static bool attr_set = false;   // benign race: idempotent
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_ring_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(wgrad_ring_kernel, %d B LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
+            return PWS_EHIP;
+        }
+        attr_set = true;
+    }
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    p.tiles_x = (p.LW + C::TW - 1) / C::TW, p.tiles_y = (p.LH + C::TH - 1) / C::TH;
+    p.ntiles = p.tiles_x * p.tiles_y * p.N;
+    p.ci_blocks = (p.cin_pad + 63) / 64, p.co_blocks = (p.cout + 63) / 64;
+    const long other = (long)p.ci_blocks * p.co_blocks * nclasses;
+    // one workgroup per CU and round: the pixel tiles are split over as many workgroups as it takes to give every CU one
+    long ps = (ncu + other - 1) / other;
+    if (ps > p.ntiles) ps = p.ntiles;
+    if (ps < 1) ps = 1;
+    hipLaunchKernelGGL((wgrad_ring_kernel<C>), dim3((unsigned)ps, (unsigned)(p.ci_blocks * p.co_blocks), (unsigned)nclasses), dim3(C::THREADS), C::LDS_BYTES,
+                       st, p);
+    return check_launch("wgrad_ring_kernel");
+}
+
+// Called by wgrad_bf16_launch (wgrad_bf16.hip) with its checked arguments for the stride-1 kinds with bf16 storage.  Returns 1 when
+// not covered: fewer than 64 (padded) input channels, maps that 16 x 16 tiles cover badly, too few tiles for a stream.
+int wgrad_ring_try(const pws_conv_bwd_weight_args *a, int cin, hipStream_t st) {
+    if (a->store != PWS_STORE_BF16 || g_experiment == 80) return 1;
+    if (a->kind != PWS_CONV_K3S1 && a->kind != PWS_CONVT_K3S1 && a->kind != PWS_CONVT_K4S2) return 1;
+    if (cin < 64 || a->cout < 32 || a->h % 16 != 0 || a->w % 16 != 0) return 1;
+    // Measured (tools/wgrad_ring_bench.sh, batch 64, bf16 storage): 3x3 layers of >= 128 channels 329-343 us against 341-358 us of
+    // wgrad_bf16_kernel (+4-5 %); 64 -> 64 @256^2 397 vs 372 us and the transposed kind 464-874 vs 410-767 us (its two-tap waves read
+    // a dy fragment per two matrix instructions) -- so only the former is taken (PWS_OPT_EXPERIMENT 81 takes every covered launch).
+    // Both kernels stage ~1.07 GB per launch at ~3 TB/s: the tile stream, not the matrix pipe, sets the pace of either.
+    if ((a->kind == PWS_CONVT_K4S2 || cin < 128) && g_experiment != 81) return 1;
+    for (int s = 0; s < a->nsrc; ++s)
+        if ((size_t)a->h * a->w * a->src[s].ld * 2 >= (1u << 31) || (reinterpret_cast<size_t>(a->src[s].ptr) & 15) || a->src[s].ld % 8 != 0) return 1;
+    const int oh = a->kind == PWS_CONVT_K4S2 ? 2 * a->h : a->h, ow = a->kind == PWS_CONVT_K4S2 ? 2 * a->w : a->w;
+    if ((size_t)oh * ow * a->gout_ld * 2 >= (1u << 31) || (reinterpret_cast<size_t>(a->gout) & 15) || a->gout_ld % 8 != 0) return 1;
+    WgradRingParams p{};
+    p.nsrc = a->nsrc;
+    for (int s = 0; s < a->nsrc; ++s) p.src_ptr[s] = a->src[s].ptr, p.src_c[s] = a->src[s].channels, p.src_ld[s] = a->src[s].ld;
+    p.cin = cin, p.cin_pad = (cin + 15) / 16 * 16, p.cout = a->cout;
+    p.N = a->n, p.H = a->h, p.W = a->w, p.LH = a->h, p.LW = a->w, p.OH = oh, p.OW = ow;
+    p.gout = a->gout, p.gout_ld = a->gout_ld, p.dw = a->dw_packed, p.dbias = a->dbias;
+    const int nclasses = a->kind == PWS_CONVT_K4S2 ? 4 : 1;
+    const long tiles = (long)(a->h / 16) * (a->w / 16) * a->n;
+    const long other = (long)((p.cin_pad + 63) / 64) * ((a->cout + 63) / 64) * nclasses;
+    // a workgroup should stream at least a few tiles (its prologue is one exposed tile load, its tail the atomics)
+    if (tiles * other < 256 * 4 && g_experiment != 81) return 1;
+    const double k2 = a->kind == PWS_CONVT_K4S2 ? 4 : 9;
+    const double out_pix = (double)a->n * oh * ow;
+    ProfScope prof(KID_WGRAD_RING, 2.0 * out_pix * a->cout * cin * k2,
+                   4.0 * ((double)a->n * a->h * a->w * cin + out_pix * a->cout + k2 * cin * a->cout * (nclasses == 4 ? 4 : 1)), st);
+    if (a->kind == PWS_CONVT_K4S2) return wrg_launch<WrgCfg<2, 0, 1>>(p, nclasses, st);
+    return wrg_launch<WrgCfg<3, 1, 0>>(p, nclasses, st);
+}
+
+}  // namespace pws

@@ -378,6 +378,64 @@ def test_bf16_conv_weight_gradient(hip, kname, shape, src_c, cout, store):
     np.testing.assert_allclose(db.cpu().numpy() - 0.25, want_db, rtol=0, atol=2e-5 * np.abs(dy.numpy()).sum(axis=(0, 2, 3)).max())
 
 
+@pytest.mark.parametrize("kname,shape,src_c,cout", [
+    ("CONV_K3S1", (2, 32, 48), [64, 64], 96),      # two input-channel blocks, cout 96: the second 64-block has one 32-channel plane
+    ("CONVT_K3S1", (1, 16, 16), [64], 64),         # one tile per workgroup: the stream is prologue + tail only
+    ("CONV_K3S1", (3, 16, 32), [96], 32),          # 96 input channels: block 1 has one plane; 32 output channels: one dy plane
+    ("CONVT_K4S2", (2, 16, 32), [128, 64], 64),    # 4 parity classes of 2x2 taps (2 + 2 per wave half), virtual concat
+    ("CONV_K3S1", (8, 64, 64), [128], 128),        # 128 tiles x 4 blocks: several tiles per workgroup, pixel split over workgroups
+])
+def test_bf16_weight_gradient_ring(hip, kname, shape, src_c, cout):
+    """The persistent LDS-ring weight-gradient kernel (csrc/wgrad_ring.hip: bf16 storage, LDS-DMA tile stream; PWS_OPT_EXPERIMENT 81
+    takes it whatever the number of tiles, 80 switches it off) against PyTorch-CPU autograd on the same rounded operands and
+    against wgrad_bf16_kernel; dbias taken along."""
+    A = hip
+    L, st = A.lib(), A.current_stream()
+    kind = getattr(A, kname)
+    x, wt, b, rs = make_case(kname, shape, src_c, cout, "wr")
+    n, cin, h, w = x.shape
+    xr = bf16r(x)
+    wg = wt.clone().requires_grad_(True)
+    kd, k, s_, p_ = KINDS[kname]
+    y = (F.conv2d if kd == "conv" else F.conv_transpose2d)(xr, wg, None, stride=s_, padding=p_)
+    dy = bf16r(torch.from_numpy(rs.standard_normal(tuple(y.shape)).astype(np.float32)))
+    y.backward(dy)
+    xs = nhwc(x)
+    wa = A.PwsConvBwdWeightArgs()
+    wa.kind, wa.n, wa.h, wa.w, wa.nsrc, wa.cout, wa.math = kind, n, h, w, len(src_c), cout, A.MATH_BF16
+    wa.store = A.STORE_BF16
+    keep, c0 = [], 0
+    for i, c in enumerate(src_c):
+        t = xs[..., c0:c0 + c].contiguous().cuda().bfloat16()
+        keep.append(t)
+        wa.src[i].ptr, wa.src[i].channels, wa.src[i].ld = t.data_ptr(), c, c
+        c0 += c
+    d_dy = nhwc(dy).cuda().bfloat16()
+    want_db = dy.double().sum(dim=(0, 2, 3)).numpy()
+    got = {}
+    try:
+        for force, name in ((81, "wgrad_ring_kernel"), (80, "wgrad_bf16_kernel")):
+            L.pws_set_option(100, force)
+            dwp = torch.zeros(L.pws_packed_weight_floats(kind, cin, cout), device="cuda")
+            wa.gout, wa.gout_ld, wa.dw_packed = d_dy.data_ptr(), cout, dwp.data_ptr()
+            db = torch.full((cout,), 0.25, device="cuda")
+            wa.dbias = db.data_ptr()
+            L.pws_prof_enable(1)
+            A.check(L.pws_conv2d_bwd_weight(ctypes.byref(wa), st), "bwd_weight bf16")
+            L.pws_prof_enable(0)
+            assert [r[0] for r in A.prof_collect()] == [name]
+            dw = torch.empty(tuple(wt.shape), device="cuda")
+            A.check(L.pws_unpack_conv_weight(A.ptr(dwp), A.ptr(dw), kind, cin, cout, st), "unpack")
+            got[force] = dw.cpu().numpy()
+            err = relerr(got[force], wg.grad.numpy())
+            assert err < 1e-4, (name, err)
+            np.testing.assert_allclose(db.cpu().numpy() - 0.25, want_db, rtol=0, atol=2e-5 * np.abs(dy.numpy()).sum(axis=(0, 2, 3)).max())
+    finally:
+        L.pws_prof_enable(0)
+        L.pws_set_option(100, 0)
+    assert relerr(got[81], got[80]) < 2e-5   # same products, fp32 summation order only
+
+
 # ---------------------------------------------------------------------------------------------- whole generator
 def _make_net(kind, ngf):
     from pwstablenet_amd import synth
