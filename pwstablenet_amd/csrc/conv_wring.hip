@@ -56,32 +56,38 @@ struct WringParams {
     int tiles_x, tiles_y;
     unsigned ncob, ncls, nunits;
     int nchunks;              // sum(src_c) / 16
+    int ksplit, cps;          // K split: a unit covers the cps = nchunks / ksplit chunks [ks * cps, (ks + 1) * cps) and writes its raw sums to
+    size_t split_stride;      // out + ks * split_stride (dense [pixel][cout]); splitk_reduce_kernel adds them, bias + activation there
     int ablate;               // measurement only (PWS_OPT_EXPERIMENT 51..57, or 1000 + mask): 1 = DMA pieces fetch nothing after the
                               // first slot, 2 = no matrix phase, 4 = no epilogue stores, 8 = no A-operand reads, 16 = no B-operand
                               // reads, 32 = no barrier / DMA wait, 64 = no DMA instructions -- results are meaningless, only the
                               // timing is read
 };
 
-constexpr int WR_TH = 16, WR_TW = 32;                 // output pixels of a unit
-constexpr int WR_RH = WR_TH + 2, WR_RW = WR_TW + 2;   // raw halo tile
-constexpr int WR_ROW_SLOTS = WR_RW * 4;               // 16-byte slots per raw image row (136)
-constexpr int WR_ROW_BYTES = WR_ROW_SLOTS * 16;       // 2176
-constexpr int WR_RAW_SLOTS = WR_RH * WR_ROW_SLOTS;    // 2448
-constexpr int WR_RAW_PIECES = (WR_RAW_SLOTS + 63) / 64;   // 39 DMA instructions (1 KB each)
-constexpr int WR_U_OFF = WR_RAW_PIECES * 1024;
+constexpr int WR_TH = 16, WR_TW = 32;                 // output (class) pixels of a unit: 8 x 16 Winograd tiles
+constexpr int WR_RH = WR_TH + 2;                      // rows of the raw halo tile
 constexpr int WR_WAVES = 8;
-constexpr int WR_RAW_IT = (WR_RAW_PIECES + WR_WAVES - 1) / WR_WAVES;   // its 0..4 can be raw pieces
-template <int MODE>
+// G16 = 0: maps that are multiples of 32 pixels wide, a unit = 16 x 32 pixels of one sample, raw rows of 34 pixels.
+// G16 = 1: 16-pixel-wide maps, a unit = 16 x 16 pixels of TWO samples (tiles 0..7 of a tile row = sample A, 8..15 = sample B), raw rows
+//          = [18 pixels of A | 18 pixels of B]: the deep 16 x 16 levels of a batch run on the same code.
+template <int MODE, int G16>
 struct WrGeo {
+    static constexpr int RWV = G16 ? 36 : 34;             // pixels per raw row
+    static constexpr int HALF = RWV / 2;                  // even-x pixels come first in an LDS row, then the odd ones
+    static constexpr int ROW_SLOTS = RWV * 4, ROW_BYTES = ROW_SLOTS * 16;
+    static constexpr int RAW_SLOTS = WR_RH * ROW_SLOTS;
+    static constexpr int RAW_PIECES = (RAW_SLOTS + 63) / 64;   // 39 / 41 DMA instructions (1 KB each)
+    static constexpr int RAW_IT = (RAW_PIECES + WR_WAVES - 1) / WR_WAVES;
+    static constexpr int U_OFF = RAW_PIECES * 1024;
     static constexpr int NC = MODE == 0 ? 16 : (MODE == 1 ? 18 : 9);   // components a wave accumulates
     static constexpr int NCLS = MODE == 0 ? 1 : (MODE == 1 ? 2 : 4);   // units per (tile, channel block): MODE 1 = the two py, MODE 2 = the four classes
     static constexpr int U_PIECES = NC * 2;              // NC components x 16 channels x 32 output channels x 4 bytes / 1 KB
     static constexpr int U_IT = (U_PIECES + WR_WAVES - 1) / WR_WAVES;
-    static constexpr int NIT = WR_RAW_IT + U_IT;         // DMA pieces per wave and slot (9 / 10)
-    static constexpr int GROUP_BYTES = (WR_RAW_PIECES + U_PIECES) * 1024 + (MODE == 0 ? 1024 : 0);   // 72 KB / 75 KB
+    static constexpr int NIT = RAW_IT + U_IT;            // DMA pieces per wave and slot (8 .. 11)
+    static constexpr int GROUP_BYTES = (RAW_PIECES + U_PIECES) * 1024;
     static constexpr int LDS_BYTES = 2 * GROUP_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-    static_assert(NIT <= NC, "one DMA piece per component");
+    static_assert(NIT <= NC + 2 && NIT <= 11, "DMA pieces are dealt to the first components");
 };
 
 // (the DMA / wait / uniformity helpers are those of conv_ring.hip; see the comments there)
@@ -111,21 +117,24 @@ __device__ __forceinline__ T selw4(const T (&a)[4], int i) {
 }
 
 struct WringUnit {
-    int n, y0, x0, cob, py;
+    int n, y0, x0, cob, py, ks;
 };
 __device__ __forceinline__ WringUnit wring_unit(const WringParams &p, unsigned u) {
     WringUnit r;
     const unsigned cls = u % p.ncls, u2 = u / p.ncls;
-    const unsigned cob = u2 % p.ncob, tile = u2 / p.ncob;
+    const unsigned cob = u2 % p.ncob, u3 = u2 / p.ncob;
+    const unsigned tile = u3 / (unsigned)p.ksplit;
+    r.ks = (int)(u3 % (unsigned)p.ksplit);
     r.py = (int)cls;   // MODE 1: py; MODE 2: py * 2 + px
     const unsigned tx = tile % (unsigned)p.tiles_x, t2 = tile / (unsigned)p.tiles_x;
     r.cob = (int)cob, r.x0 = (int)tx, r.y0 = (int)(t2 % (unsigned)p.tiles_y), r.n = (int)(t2 / (unsigned)p.tiles_y);
     return r;
 }
 
-template <int MODE, int ABL>   // ABL: timing-only ablation mask (WringParams.ablate), 0 in the product
+template <int MODE, int G16, int ABL>   // ABL: timing-only ablation mask (WringParams.ablate), 0 in the product
 __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const WringParams p) {
-    using G_ = WrGeo<MODE>;
+    using G_ = WrGeo<MODE, G16>;
+    constexpr int WR_ROW_BYTES = G_::ROW_BYTES, WR_U_OFF = G_::U_OFF, WR_RAW_IT = G_::RAW_IT, WR_RAW_PIECES = G_::RAW_PIECES;
     constexpr int NC = G_::NC;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -143,7 +152,7 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
     if (c_begin + slot >= c_end) return;
     const unsigned u_begin = c_begin + slot, u_end = c_end, u_step = nx;
     const unsigned my_units = (u_end - u_begin + u_step - 1) / u_step;
-    const int nchunks = p.nchunks;
+    const int nchunks = p.cps;   // chunks of a unit (its K split)
     const unsigned total = my_units * (unsigned)nchunks;
 
     // ---- DMA descriptors of this lane: piece pc = it * 8 + wv covers the 16-byte LDS slots pc * 64 + lane of a slot image.
@@ -155,11 +164,11 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
         const int pc = it * WR_WAVES + wv;
         const int j = pc * 64 + lane;
         ia[it] = -1;
-        if (pc < WR_RAW_PIECES && j < WR_RAW_SLOTS) {
-            const int row = j / WR_ROW_SLOTS, r = j - row * WR_ROW_SLOTS;
+        if (pc < WR_RAW_PIECES && j < G_::RAW_SLOTS) {
+            const int row = j / G_::ROW_SLOTS, r = j - row * G_::ROW_SLOTS;
             const int pp = r >> 2, sp = r & 3;
-            const int par = pp >= WR_RW / 2 ? 1 : 0, q = pp - par * (WR_RW / 2);
-            const int px = 2 * q + par;
+            const int par = pp >= G_::HALF ? 1 : 0, q = pp - par * G_::HALF;
+            const int px = 2 * q + par;   // G16: 0..17 = sample A, 18..35 = sample B
             const int s = (0x78 >> (2 * (sp ^ ((q >> 2) & 3)))) & 3;   // inverse of P = {0, 3, 1, 2}
             ia[it] = s << 20 | row << 10 | px;
         }
@@ -169,6 +178,16 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
     int ps = 0, pc0 = 0, pchunk = 0, pbuf = 0;
     bool pfirst = true;
     WringUnit PU = wring_unit(p, pu);
+    int s_ld = p.src_ld[0], s_c = p.src_c[0];   // source ps
+    const char *s_ptr = reinterpret_cast<const char *>(p.src_ptr[0]);
+    auto seek = [&]() {   // cursor to the first chunk of unit PU's K split
+        int c = PU.ks * nchunks * 16;
+        ps = 0;
+        while (ps < p.nsrc - 1 && c >= selw4(p.src_c, ps)) c -= selw4(p.src_c, ps), ++ps;
+        pc0 = c, pchunk = 0;
+        s_ld = selw4(p.src_ld, ps), s_c = selw4(p.src_c, ps), s_ptr = reinterpret_cast<const char *>(selw4(p.src_ptr, ps));
+    };
+    seek();
     // One slot's DMA = prep() (scalar: descriptors of the slot the cursor points at, then the cursor moves on) followed by
     // piece(0 .. WR_NIT - 1), which the matrix phase spreads over its first groups of matrix instructions.  Piece it of wave wv:
     // it = 0 .. 4 raw piece it * 8 + wv (it = 4: waves 0 .. 6 only), it = 5 .. 8 weight piece (it - 5) * 8 + wv.
@@ -176,9 +195,7 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
     unsigned d_base = 0, d_sin = 0, d_su = 0, d_ldb = 0;
     int d_oy = 0, d_ox = 0;
     bool d_kill = false;   // past the last slot (or ablation): the pieces fetch nothing (offsets beyond num_records)
-    int s_ld = p.src_ld[0], s_c = p.src_c[0];   // source ps
-    const char *s_ptr = reinterpret_cast<const char *>(p.src_ptr[0]);
-    unsigned d_su0 = 0;     // weight offset of chunk 0 of unit pu
+    unsigned d_su0 = 0;     // weight offset of the first chunk of unit pu
     bool p_new = true;      // the cursor entered a new unit or source: the descriptors below are recomputed (once per unit, typically)
     auto prep = [&]() {
         d_kill = pu >= u_end || ((ABL & 1) && !pfirst) || (ABL & 64);
@@ -189,26 +206,30 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
             if (p_new) {
                 p_new = false;
                 const size_t img = (size_t)p.H * p.W * s_ld * 4;   // bytes of one sample
-                const char *base_in = uniw(s_ptr + (size_t)PU.n * img);
-                d_rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base_in), 0, (int)uniw((unsigned)img), 0x00020000);
+                const char *base_in = uniw(s_ptr + (size_t)(PU.n * (G16 ? 2 : 1)) * img);
+                d_rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base_in), 0, (int)uniw((unsigned)(img * (G16 ? 2 : 1))), 0x00020000);
                 d_ldb = (unsigned)s_ld * 4u;
                 d_oy = PU.y0 * WR_TH - 1, d_ox = PU.x0 * WR_TW - 1;
+                const unsigned chunk0 = (unsigned)(PU.ks * nchunks);   // of all p.nchunks chunks of the layer
                 if constexpr (MODE == 2)   // the px half of the MODE 1 block of (py, channel block, chunk)
-                    d_su0 = uniw((unsigned)(((((unsigned)(PU.py >> 1) * p.ncob + (unsigned)PU.cob) * (unsigned)nchunks) * 2u + (unsigned)(PU.py & 1)) *
+                    d_su0 = uniw((unsigned)(((((unsigned)(PU.py >> 1) * p.ncob + (unsigned)PU.cob) * (unsigned)p.nchunks + chunk0) * 2u + (unsigned)(PU.py & 1)) *
                                             (unsigned)(G_::U_PIECES * 1024)));
                 else
-                    d_su0 = uniw((unsigned)((((unsigned)PU.py * p.ncob + (unsigned)PU.cob) * (unsigned)nchunks) * (unsigned)(G_::U_PIECES * 1024)));
+                    d_su0 = uniw((unsigned)((((unsigned)PU.py * p.ncob + (unsigned)PU.cob) * (unsigned)p.nchunks + chunk0) * (unsigned)(G_::U_PIECES * 1024)));
             }
             d_sin = (unsigned)(pc0 * 4);
             d_su = d_su0 + (unsigned)pchunk * (unsigned)((MODE == 2 ? 2 : 1) * G_::U_PIECES * 1024);
             pc0 += 16, ++pchunk;
-            if (pc0 >= s_c) {
+            if (pchunk == nchunks) {   // the unit's K split is staged: on to the next unit
+                p_new = true;
+                pu += u_step;
+                if (pu < u_end) {
+                    PU = wring_unit(p, pu);
+                    seek();
+                }
+            } else if (pc0 >= s_c) {   // next source of the virtual concat
                 p_new = true;
                 pc0 = 0, ++ps;
-                if (ps == p.nsrc) {
-                    ps = 0, pchunk = 0, pu += u_step;
-                    if (pu < u_end) PU = wring_unit(p, pu);
-                }
                 s_ld = selw4(p.src_ld, ps), s_c = selw4(p.src_c, ps), s_ptr = reinterpret_cast<const char *>(selw4(p.src_ptr, ps));
             }
         }
@@ -218,10 +239,12 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
         if constexpr (it < WR_RAW_IT) {
             const int pc = it * WR_WAVES + wv;   // wave-uniform
             if (it * WR_WAVES + WR_WAVES <= WR_RAW_PIECES || pc < WR_RAW_PIECES) {
-                const int ly = (ia[it] >> 10) & 0x3ff, lx = ia[it] & 0x3ff;
+                const int ly = (ia[it] >> 10) & 0x3ff;
+                int lx = ia[it] & 0x3ff, smp = 0;
+                if constexpr (G16) smp = lx >= G_::HALF ? 1 : 0, lx -= smp * G_::HALF;
                 const int ry = d_oy + ly, rx = d_ox + lx;
                 const bool ok = ia[it] >= 0 && ry >= 0 && ry < p.H && rx >= 0 && rx < p.W && !d_kill;
-                const unsigned v = ok ? (unsigned)(ry * p.W + rx) * d_ldb + (unsigned)((ia[it] >> 20) * 16) : kWringOob;
+                const unsigned v = ok ? (unsigned)((smp * p.H + ry) * p.W + rx) * d_ldb + (unsigned)((ia[it] >> 20) * 16) : kWringOob;
                 if constexpr (ABL & 128) wring_dma16_nom0(v, d_rin, d_sin);
                 else if constexpr (ABL & 256) wring_m0_only(d_base + (unsigned)(pc * 1024));
                 else wring_dma16(d_base + (unsigned)(pc * 1024), v, d_rin, d_sin);
@@ -243,16 +266,17 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
         piece(std::integral_constant<int, 6>{}), piece(std::integral_constant<int, 7>{});
         if constexpr (G_::NIT > 8) piece(std::integral_constant<int, 8>{});
         if constexpr (G_::NIT > 9) piece(std::integral_constant<int, 9>{});
+        if constexpr (G_::NIT > 10) piece(std::integral_constant<int, 10>{});
     };
-    static_assert(G_::NIT >= 8 && G_::NIT <= 10, "piece() calls");
+    static_assert(G_::NIT >= 8 && G_::NIT <= 11, "piece() calls");
 
     // ---- operand addresses.  A: patch pixel (a, b) of tile (wv, l15) = raw pixel (2 wv + a, 2 l15 + b), channel slot kq
     int offb[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        const int q = l15 + (b >> 1), par = b & 1;
+        const int q = (G16 ? (l15 >> 3) * (G_::HALF / 2) + (l15 & 7) : l15) + (b >> 1), par = b & 1;   // G16: tiles 8..15 = the second sample
         const int sp = ((0x9C >> (2 * kq)) & 3) ^ ((q >> 2) & 3);   // P[kq] ^ Q
-        offb[b] = ((par * (WR_RW / 2) + q) * 4 + sp) * 16;
+        offb[b] = ((par * G_::HALF + q) * 4 + sp) * 16;
     }
     const int b_off = WR_U_OFF + lane * 16;   // + (xi * 2 + nt) * 1024
     const bool half1 = wv >= 4;
@@ -262,6 +286,9 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
     int cchunk = 0, cbuf = 0;
     WringUnit CU = wring_unit(p, cu);
 
+    // static priority for the second-dispatched half: at equal priority the older wave of a SIMD wins every arbitration and its partner
+    // takes the leftovers (MI355X_MICROARCH.md, two waves per SIMD); measured 189 -> 184.5 us on the 256 -> 256 @64^2 launch
+    if (half1 && !(ABL & 512)) __builtin_amdgcn_s_setprio(1);
     stage_all();   // slot 0
     for (unsigned s = 0; s < total; ++s) {
         if (!(ABL & 32)) {
@@ -319,7 +346,7 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
                 return v;
             };
             // B operands of the components xi .. xi + BD - 1 (requested BD - 1 components ahead; MODE 1 has no registers for a third set)
-            constexpr int BD = MODE == 1 ? 2 : 3;
+            constexpr int BD = (MODE == 1 || (MODE == 0 && G16)) ? 2 : 3;
             f32x4 bq[BD][2];
             const bool nob = (ABL & 16) != 0;
             auto rdb = [&](int slot, int xi) {
@@ -373,6 +400,9 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
                         if constexpr (G_::NIT > 9) {
                             if (xi == 9) piece(std::integral_constant<int, 9>{});
                         }
+                        if constexpr (G_::NIT > 10) {
+                            if (xi == 10) piece(std::integral_constant<int, 10>{});
+                        }
                     }
                     if (st == 3 && xi < NC - 1) vq[nxt] = vop(xi + 1);
                     acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vq[cur][st], bq[bc][0][st], acc[xi][0], 0, 0, 0);
@@ -386,18 +416,29 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
             piece(std::integral_constant<int, 6>{}), piece(std::integral_constant<int, 7>{});
             if constexpr (G_::NIT > 8) piece(std::integral_constant<int, 8>{});
             if constexpr (G_::NIT > 9) piece(std::integral_constant<int, 9>{});
+            if constexpr (G_::NIT > 10) piece(std::integral_constant<int, 10>{});
         }
 
         if (cchunk == nchunks - 1) {
             // ---- epilogue of unit cu: lane (l15, kq) holds, for the tiles tx = 4 kq + r of its wave's tile row and the channel pair
             // (2 l15, 2 l15 + 1) of the unit's block, all components: Y = A^T M A in registers, bias, activation, 8-byte stores
+            // K split: raw sums into this split's dense [pixel][cout] buffer (bias and activation in splitk_reduce_kernel)
             const int co = CU.cob * 32 + 2 * l15;
+            const bool part = p.ksplit > 1;
             float bs0 = 0.f, bs1 = 0.f;
-            if (p.bias) bs0 = p.bias[co], bs1 = p.bias[co + 1];
+            if (p.bias && !part) bs0 = p.bias[co], bs1 = p.bias[co + 1];
+            const int eact = part ? PWS_ACT_NONE : p.act;
+            const size_t eld = part ? (size_t)p.cout : (size_t)p.out_ld;
+            float *eout = p.out + (part ? (size_t)CU.ks * p.split_stride : 0);
+            // tile tx = 4 kq + r of the wave's tile row: G16 -> sample 2 n + (tx >> 3), column 2 (tx & 7); else sample n, column 32 x0 + 2 tx
+            auto tile_px = [&](int r, int &smp, int &cx) {
+                const int tx = 4 * kq + r;
+                if constexpr (G16) smp = CU.n * 2 + (tx >> 3), cx = 2 * (tx & 7);
+                else smp = CU.n, cx = CU.x0 * WR_TW + 2 * tx;
+            };
             if constexpr (MODE == 0) {
                 const int oy = CU.y0 * WR_TH + 2 * wv;
-                float *orow = p.out + ((size_t)(CU.n * p.H + oy) * p.W + CU.x0 * WR_TW) * p.out_ld + co;
-                const size_t rs = (size_t)p.W * p.out_ld;
+                const size_t rs = (size_t)p.W * eld;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float y[2][2][2];   // [nt][row][col]
@@ -416,13 +457,15 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
                         }
                     }
                     if (!(ABL & 4)) {
-                        float *o = orow + (size_t)(2 * (4 * kq + r)) * p.out_ld;
+                        int smp, cx;
+                        tile_px(r, smp, cx);
+                        float *o = eout + ((size_t)(smp * p.H + oy) * p.W + cx) * eld + co;
 #pragma unroll
                         for (int a = 0; a < 2; ++a)
 #pragma unroll
                             for (int b = 0; b < 2; ++b)
-                                *reinterpret_cast<float2 *>(o + a * rs + (size_t)b * p.out_ld) =
-                                    make_float2(act_apply(y[0][a][b] + bs0, p.act), act_apply(y[1][a][b] + bs1, p.act));
+                                *reinterpret_cast<float2 *>(o + a * rs + (size_t)b * eld) =
+                                    make_float2(act_apply(y[0][a][b] + bs0, eact), act_apply(y[1][a][b] + bs1, eact));
                     } else if (y[0][0][0] == 12345.678f) {
                         p.out[0] = y[1][1][1];   // keep the accumulators live
                     }
@@ -432,8 +475,7 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
                 const int OW = 2 * p.W;
                 const int cpy = MODE == 2 ? CU.py >> 1 : CU.py;
                 const int oy = 2 * (CU.y0 * WR_TH + 2 * wv) + cpy;
-                float *orow = p.out + ((size_t)(CU.n * 2 * p.H + oy) * OW + 2 * CU.x0 * WR_TW) * p.out_ld + co;
-                const size_t rs = (size_t)2 * OW * p.out_ld;   // next class row = two output rows
+                const size_t rs = (size_t)2 * OW * eld;   // next class row = two output rows
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -452,13 +494,15 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
                             for (int b = 0; b < 2; ++b) y[nt][0][b] = tc[0][b] + tc[1][b], y[nt][1][b] = tc[1][b] + tc[2][b];
                         }
                         if (!(ABL & 4)) {
-                            float *o = orow + (size_t)(2 * (2 * (4 * kq + r)) + cpx) * p.out_ld;
+                            int smp, cx;
+                            tile_px(r, smp, cx);
+                            float *o = eout + ((size_t)(smp * 2 * p.H + oy) * OW + 2 * cx + cpx) * eld + co;
 #pragma unroll
                             for (int a = 0; a < 2; ++a)
 #pragma unroll
                                 for (int b = 0; b < 2; ++b)
-                                    *reinterpret_cast<float2 *>(o + a * rs + (size_t)(2 * b) * p.out_ld) =
-                                        make_float2(act_apply(y[0][a][b] + bs0, p.act), act_apply(y[1][a][b] + bs1, p.act));
+                                    *reinterpret_cast<float2 *>(o + a * rs + (size_t)(2 * b) * eld) =
+                                        make_float2(act_apply(y[0][a][b] + bs0, eact), act_apply(y[1][a][b] + bs1, eact));
                         } else if (y[0][0][0] == 12345.678f) {
                             p.out[0] = y[1][1][1];   // keep the accumulators live
                         }
@@ -490,36 +534,40 @@ int wring_pack(const float *pk, float *ur, int cin_pad, int cout, int ct4, hipSt
     return check_launch("wring_pack_kernel");
 }
 
-template <int MODE, int ABL>
+template <int MODE, int G16, int ABL>
 static int wring_launch(const WringParams &p, unsigned grid, hipStream_t st) {
+    using G = WrGeo<MODE, G16>;
     static bool attr_set = false;   // benign race: idempotent
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_ring_kernel<MODE, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           WrGeo<MODE>::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_ring_kernel<MODE, G16, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           G::LDS_BYTES);
         if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(wino_ring_kernel, %d B LDS): %s", WrGeo<MODE>::LDS_BYTES, hipGetErrorString(e));
+            set_error("hipFuncSetAttribute(wino_ring_kernel, %d B LDS): %s", G::LDS_BYTES, hipGetErrorString(e));
             return PWS_EHIP;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((wino_ring_kernel<MODE, ABL>), dim3(grid), dim3(WR_WAVES * 64), WrGeo<MODE>::LDS_BYTES, st, p);
+    hipLaunchKernelGGL((wino_ring_kernel<MODE, G16, ABL>), dim3(grid), dim3(WR_WAVES * 64), G::LDS_BYTES, st, p);
     return check_launch("wino_ring_kernel");
 }
 
 // Runs a 3x3 stride-1 (Winograd F(2x2,3x3)) or transposed k4 s2 (F(2x2,2x2) per parity class) forward launch on the Winograd ring
-// kernel when it is covered: fp32 NHWC sources in multiples of 16 channels (16-byte aligned), an input map of whole 16 x 32 units,
-// cout a multiple of 32, 8-byte aligned output pixels, a->w_wring (pws_pack_conv_weight_wring) and enough units to occupy the chip.
+// kernel when it is covered: fp32 NHWC sources in multiples of 16 channels (16-byte aligned), an input map of whole units -- 16 x 32
+// pixels of one sample, or 16 x 16 pixels of two samples for 16-pixel-wide maps --, cout a multiple of 32, 8-byte aligned output
+// pixels, a->w_wring (pws_pack_conv_weight_wring) and enough units to occupy the chip, if need be by splitting K over units
+// (partial sums in a->ws, added by splitk_reduce_kernel).
 // Returns 1 when not covered (the caller goes on to the first-generation Winograd kernel / the direct kernels).
 int wring_try(const pws_conv_args *a, const ProfHint &ph, hipStream_t st) {
     if (!a->w_wring || g_experiment == 50) return 1;
     const bool ct4 = a->kind == PWS_CONVT_K4S2;
     if (!ct4 && a->kind != PWS_CONV_K3S1 && a->kind != PWS_CONVT_K3S1) return 1;
-    if (a->h % WR_TH != 0 || a->w % WR_TW != 0 || a->cout % 32 != 0 || a->out_ld % 2 != 0 || (reinterpret_cast<size_t>(a->out) & 7)) return 1;
+    const bool g16 = a->w == 16 && a->n % 2 == 0 && g_experiment != 61;
+    if (a->h % WR_TH != 0 || (!g16 && a->w % WR_TW != 0) || a->cout % 32 != 0 || a->out_ld % 2 != 0 || (reinterpret_cast<size_t>(a->out) & 7)) return 1;
     int cin = 0;
     for (int s = 0; s < a->nsrc; ++s) {
         const pws_src &sr = a->src[s];
         if (sr.channels % 16 != 0 || sr.ld % 4 != 0 || (reinterpret_cast<size_t>(sr.ptr) & 15)) return 1;
-        if ((size_t)a->h * a->w * 4 * sr.ld >= (1u << 31)) return 1;
+        if ((size_t)a->h * a->w * 4 * sr.ld * 2 >= (1u << 31)) return 1;
         cin += sr.channels;
     }
     const size_t plane = (size_t)cin * a->cout;
@@ -530,7 +578,7 @@ int wring_try(const pws_conv_args *a, const ProfHint &ph, hipStream_t st) {
     p.nsrc = a->nsrc, p.N = a->n, p.H = a->h, p.W = a->w, p.cout = a->cout;
     p.ur = a->w_wring, p.ur_bytes = (unsigned)ur_bytes;
     p.bias = a->bias, p.act = a->act, p.out = a->out, p.out_ld = a->out_ld;
-    p.tiles_x = a->w / WR_TW, p.tiles_y = a->h / WR_TH;
+    p.tiles_x = g16 ? 1 : a->w / WR_TW, p.tiles_y = a->h / WR_TH;
     static int ncu = 0;
     if (ncu == 0) {
         int dev = 0;
@@ -538,45 +586,65 @@ int wring_try(const pws_conv_args *a, const ProfHint &ph, hipStream_t st) {
         ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
     p.ncob = (unsigned)(a->cout / 32), p.ncls = ct4 ? 2u : 1u;
-    p.nunits = (unsigned)(p.tiles_x * p.tiles_y) * (unsigned)a->n * p.ncob * p.ncls;
+    const unsigned tiles = (unsigned)(p.tiles_x * p.tiles_y) * (unsigned)(g16 ? a->n / 2 : a->n);
+    unsigned units1 = tiles * p.ncob * p.ncls;
     // transposed kind: one class per unit (MODE 2) when the two-class units leave CUs without work (PWS_OPT_EXPERIMENT 59 forces it)
-    const bool mode2 = ct4 && ((p.nunits < (unsigned)ncu && g_experiment != 60) || g_experiment == 59);
-    if (mode2) p.ncls = 4, p.nunits *= 2;
+    const bool mode2 = ct4 && ((units1 < (unsigned)ncu && g_experiment != 60) || g_experiment == 59);
+    if (mode2) p.ncls = 4, units1 *= 2;
     p.nchunks = cin / 16;
-    p.ablate = g_experiment >= 51 && g_experiment <= 57 ? g_experiment - 50 : (g_experiment >= 1000 && g_experiment < 1512 ? g_experiment - 1000 : 0);
-    // a unit is nchunks x 8 192 (9 216) matrix cycles: fewer units than CUs leave CUs idle for the whole launch, and a non-integer
+    // K split over units when there are still fewer units than CUs: the smallest divisor of the chunk count that fills the chip (at most
+    // 8 splits, at least 4 chunks per unit), partial sums through the caller's workspace (PWS_OPT_EXPERIMENT 62: never split)
+    const size_t out_floats = (size_t)a->n * (ct4 ? 4 : 1) * a->h * a->w * a->cout;
+    int ksplit = 1;
+    if (units1 < (unsigned)ncu && a->ws && g_experiment != 62) {
+        for (int k = 2; k <= 8; ++k) {
+            if (p.nchunks % k != 0 || p.nchunks / k < 4 || (size_t)k * out_floats * 4 > a->ws_bytes) continue;
+            ksplit = k;
+            if (units1 * (unsigned)k >= (unsigned)ncu) break;
+        }
+    }
+    p.ksplit = ksplit, p.cps = p.nchunks / ksplit, p.split_stride = out_floats;
+    p.nunits = units1 * (unsigned)ksplit;
+    if (ksplit > 1) p.out = static_cast<float *>(a->ws);
+    p.ablate = g_experiment >= 51 && g_experiment <= 57 ? g_experiment - 50 : (g_experiment >= 1000 && g_experiment < 2024 ? g_experiment - 1000 : 0);
+    // a unit is cps x 8 192 (9 216) matrix cycles: fewer units than CUs leave CUs idle for the whole launch, and a non-integer
     // number of rounds costs its tail -- taken from 3/4 of the chip upwards (PWS_OPT_EXPERIMENT 58 / 59 force it for the tests)
     if (p.nunits < (unsigned)(ncu * 3 / 4) && g_experiment != 58 && g_experiment != 59) return 1;
-    ProfScope prof(ct4 ? KID_CONV_WRING_CT4 : KID_CONV_WRING, ph.flops, ph.bytes, st);
+    ProfScope prof(ct4 ? KID_CONV_WRING_CT4 : KID_CONV_WRING, ph.flops, ph.bytes, st);   // covers the split-K reduce as well
     const unsigned grid = p.nunits < (unsigned)ncu ? p.nunits : (unsigned)ncu;   // one persistent workgroup per CU
-    if (mode2) {
-        switch (p.ablate) {
-        case 0: return wring_launch<2, 0>(p, grid, st);
-        case 64: return wring_launch<2, 64>(p, grid, st);
-        case 120: return wring_launch<2, 120>(p, grid, st);
-        default: set_error("wino_ring_kernel<2>: ablation mask %d is not instantiated", p.ablate); return PWS_EINVAL;
+    int rc;
+    const int mode = mode2 ? 2 : (ct4 ? 1 : 0);
+    if (p.ablate == 0) {
+        switch (mode * 2 + (g16 ? 1 : 0)) {
+        case 0: rc = wring_launch<0, 0, 0>(p, grid, st); break;
+        case 1: rc = wring_launch<0, 1, 0>(p, grid, st); break;
+        case 2: rc = wring_launch<1, 0, 0>(p, grid, st); break;
+        case 3: rc = wring_launch<1, 1, 0>(p, grid, st); break;
+        case 4: rc = wring_launch<2, 0, 0>(p, grid, st); break;
+        default: rc = wring_launch<2, 1, 0>(p, grid, st); break;
         }
-    }
-    if (ct4) {
+    } else if (mode == 0 && !g16) {   // timing-only ablations (tools/wring_ablate.sh)
         switch (p.ablate) {
-        case 0: return wring_launch<1, 0>(p, grid, st);
-        case 64: return wring_launch<1, 64>(p, grid, st);
-        case 120: return wring_launch<1, 120>(p, grid, st);
-        default: set_error("wino_ring_kernel<1>: ablation mask %d is not instantiated", p.ablate); return PWS_EINVAL;
+        case 1: rc = wring_launch<0, 0, 1>(p, grid, st); break;
+        case 2: rc = wring_launch<0, 0, 2>(p, grid, st); break;
+        case 4: rc = wring_launch<0, 0, 4>(p, grid, st); break;
+        case 24: rc = wring_launch<0, 0, 24>(p, grid, st); break;
+        case 88: rc = wring_launch<0, 0, 88>(p, grid, st); break;
+        case 64: rc = wring_launch<0, 0, 64>(p, grid, st); break;
+        case 96: rc = wring_launch<0, 0, 96>(p, grid, st); break;
+        case 120: rc = wring_launch<0, 0, 120>(p, grid, st); break;
+        case 512: rc = wring_launch<0, 0, 512>(p, grid, st); break;
+        default: set_error("wino_ring_kernel<0>: ablation mask %d is not instantiated", p.ablate); return PWS_EINVAL;
         }
+    } else {
+        set_error("wino_ring_kernel: ablations are instantiated for F(2x2,3x3) on 32-pixel-wide maps only");
+        return PWS_EINVAL;
     }
-    switch (p.ablate) {
-    case 0: return wring_launch<0, 0>(p, grid, st);
-    case 1: return wring_launch<0, 1>(p, grid, st);
-    case 2: return wring_launch<0, 2>(p, grid, st);
-    case 4: return wring_launch<0, 4>(p, grid, st);
-    case 24: return wring_launch<0, 24>(p, grid, st);
-    case 88: return wring_launch<0, 88>(p, grid, st);
-    case 64: return wring_launch<0, 64>(p, grid, st);
-    case 96: return wring_launch<0, 96>(p, grid, st);
-    case 120: return wring_launch<0, 120>(p, grid, st);
-    default: set_error("wino_ring_kernel<0>: ablation mask %d is not instantiated", p.ablate); return PWS_EINVAL;
-    }
+    if (rc != PWS_OK || ksplit == 1) return rc;
+    ConvKParams kp{};
+    kp.cout = a->cout, kp.bias = a->bias, kp.out = a->out, kp.out_ld = a->out_ld, kp.act = a->act;
+    kp.ksplit = ksplit, kp.split_stride = out_floats;
+    return launch_splitk_reduce(kp, static_cast<const float *>(a->ws), out_floats / 4, st);
 }
 
 }  // namespace pws

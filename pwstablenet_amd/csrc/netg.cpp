@@ -66,7 +66,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static std::vector<Layer> build_layers(int input_nc, int g, size_t *total_floats, size_t *total_dgrad = nullptr) {
     std::vector<Layer> L;
     size_t off = 0, dg = 0;
-    // ring: the layer runs on maps of whole 16 x 32 units at the reference's 256 x 256 input (conv_wring.hip)
+    // ring: the layer runs on maps of whole 16 x 32 (or, two samples at a time, 16 x 16) units at the reference's 256 x 256 input (conv_wring.hip)
     auto add = [&](int kind, int cin, int cout, bool ring = false) {
         Layer l{kind, cin, cout, 0, 0, (size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1};
         l.w_off = off;
@@ -99,7 +99,7 @@ static std::vector<Layer> build_layers(int input_nc, int g, size_t *total_floats
     add(PWS_CONV_K5S1, input_nc, g);
     for (int i = 0; i < 7; ++i) add(PWS_CONV_K3S2, enc[i][0], enc[i][1]);
     const int dec[7][2] = {{4 * g, 4 * g}, {8 * g, 4 * g}, {8 * g, 4 * g}, {8 * g, 4 * g}, {8 * g, 2 * g}, {4 * g, g}, {2 * g, g}};
-    for (int j = 0; j < 7; ++j) add(PWS_CONVT_K4S2, dec[j][0], dec[j][1], j >= 4);  // up7..up1 (up3..up1: inputs of 32^2..128^2)
+    for (int j = 0; j < 7; ++j) add(PWS_CONVT_K4S2, dec[j][0], dec[j][1], j >= 3);  // up7..up1 (up4..up1: inputs of 16^2..128^2)
     add(PWS_CONV_K3S1_OUT, g, 2);
     for (int i = 0; i < 7; ++i) {
         add(PWS_CONV_K3S1, enc[i][0], enc[i][0], i < 4);   // down_bottom1..4.conv_same: maps of 256^2..32^2
@@ -108,8 +108,8 @@ static std::vector<Layer> build_layers(int input_nc, int g, size_t *total_floats
     const int ub[7][3] = {{4 * g, 4 * g, 8 * g}, {8 * g, 4 * g, 16 * g}, {8 * g, 4 * g, 16 * g}, {8 * g, 4 * g, 16 * g},
                           {8 * g, 2 * g, 16 * g}, {4 * g, g, 8 * g}, {2 * g, g, 4 * g}};  // (input_nc, output_nc, inner_nc)
     for (int j = 0; j < 7; ++j) {
-        add(PWS_CONVT_K4S2, ub[j][2], ub[j][1], j >= 4);   // up_bottom3..1: inputs of 32^2..128^2
-        add(PWS_CONVT_K3S1, ub[j][0], ub[j][0], j >= 4);
+        add(PWS_CONVT_K4S2, ub[j][2], ub[j][1], j >= 3);   // up_bottom4..1: inputs of 16^2..128^2
+        add(PWS_CONVT_K3S1, ub[j][0], ub[j][0], j >= 3);
     }
     add(PWS_CONV_K2S1P0, 4 * g, 8 * g);
     add(PWS_CONV_K1, 8 * g, 6);

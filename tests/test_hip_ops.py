@@ -232,6 +232,11 @@ def test_conv_winograd_vs_oracle(hip, oracle, kname, shape, src_c, cout):
     ("CONVT_K4S2", (2, 16, 32), [64], 32),        # transposed k4 s2 as F(2x2,2x2) per parity class: one tile block per image
     ("CONVT_K4S2", (1, 32, 64), [32, 16], 64),    # virtual concat, several tile blocks
     ("CONVT_K4S2", (8, 32, 32), [128], 128),      # 256 units
+    ("CONV_K3S1", (4, 16, 16), [64], 64),         # 16-pixel-wide map: a unit = 16 x 16 pixels of two samples
+    ("CONVT_K4S2", (2, 32, 16), [32, 32], 32),    # ... transposed kind, two row blocks, virtual concat
+    ("CONV_K3S1", (2, 16, 32), [128], 64),        # K split over units (8 chunks -> 2 x 4), partial sums through the workspace
+    ("CONVT_K4S2", (4, 16, 16), [256], 64),       # 16-wide + K split (16 chunks -> 4 x 4) + both class variants
+    ("CONVT_K3S1", (6, 16, 16), [96, 32], 32),    # 16-wide, K split 2 x 4 across the source boundary of a virtual concat
 ])
 def test_conv_winograd_ring_vs_oracle(hip, oracle, kname, shape, src_c, cout):
     """3x3 stride-1 layers (F(2x2,3x3)) and transposed k4 s2 layers (F(2x2,2x2) per parity class) through the persistent LDS-ring
@@ -260,7 +265,7 @@ def test_conv_winograd_ring_vs_oracle(hip, oracle, kname, shape, src_c, cout):
         for force in (58, 59, 50) if k == 4 else (58, 50):   # 59: one parity class per unit (the variant for launches of few units)
             L.pws_set_option(100, force)
             L.pws_prof_enable(1)
-            got[force] = run_conv(A, kind, srcs, wt, b, 1, cout, wino=True)
+            got[force] = run_conv(A, kind, srcs, wt, b, 1, cout, wino=True, ws_mb=64)
             L.pws_prof_enable(0)
             names = [r[0] for r in A.prof_collect()]
             assert (ring_name in names) == (force != 50), names
