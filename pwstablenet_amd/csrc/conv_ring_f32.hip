@@ -390,7 +390,9 @@ int conv_ringf_try(int kind, const ConvKParams &kp, hipStream_t st, const ProfIn
     // the 8 x 32-tile variant and the transposed kind stay available to the tests (PWS_OPT_EXPERIMENT 23 / 24).
     int th;
     const bool forced = g_experiment == 23 || g_experiment == 24;
-    if (kp.LH % 16 == 0 && (per256 / 2 >= 512 || g_experiment == 24)) th = 16;
+    // (stride-2 kind: from one 16 x 32 unit per CU upwards -- 64 -> 64 @256^2 x 8 = 256 units: 113 vs 136 us of conv_mfma_kernel; with
+    //  fewer units than CUs the persistent kernel loses: 128 -> 128 @128^2 x 8 = 128 units 188 vs 109 us)
+    if (kp.LH % 16 == 0 && (per256 / 2 >= (mode == RF_K3S2 ? 256 : 512) || g_experiment == 24)) th = 16;
     else if (forced) th = 8;
     else return 1;
     if (mode == RF_CT4 && !forced) return 1;

@@ -159,6 +159,105 @@ __global__ void __launch_bounds__(256) field_head_kernel(const float *__restrict
 }
 
 
+// bf16 storage, 64 input channels (BASELINE configs[2] / [3]): the same layer on the bf16 matrix cores.  A conv with TWO output
+// channels wastes 15/16 of a matrix tile as a 3x3 implicit GEMM -- but  z[p][o] = sum_tap Y[p + tap][tap, o]  with the POINTWISE
+// product  Y[q][(tap, o)] = sum_c x[q][c] W[tap][c][o]:  one 64 -> 18 (of 32) GEMM per halo pixel, then a 9-point stencil sum over
+// Y.  A operands come straight from global memory (a lane's 8 consecutive channels of its pixel = one 16-byte load: x is read once,
+// never staged), the weights sit in registers as three bf16 terms (w = hi + mid + lo to 2^-26: the products are as exact as the fp32
+// kernel's; a (hi, lo) pair left 1.4e-5 on the field), Y goes through 23 KB of LDS.  The VALU kernel above needs 1152 FMAs per pixel (341 us at 64 x 256^2 x 64, 3x its HBM
+// time); this one is bound by the read of x.
+__global__ void __launch_bounds__(256) field_head16_mfma_kernel(const __bf16 *__restrict__ x, int ld, int N, int H, int W,
+                                                                const float *__restrict__ w_out, const float *__restrict__ b_out,
+                                                                const float *__restrict__ theta, int ac, float *__restrict__ resid,
+                                                                float *__restrict__ grid, int tiles_x, int tiles_y, unsigned ntiles, int raw) {
+    constexpr int C = 64, NPIX = FH_I * FH_I, YP = 18;   // Y row = 18 floats: the stencil's float2 reads of 16 neighbouring pixels hit 32 different banks
+    __shared__ float ys[NPIX * YP];
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const unsigned tile = xcd_remap(blockIdx.x, ntiles);
+    const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const int x0 = tx_i * FH_T, y0 = ty_i * FH_T;
+    // B operand: column l31 = (tap, o), this lane's 8 channels of each of the four 16-channel k-steps, split hi + lo
+    bf16x8 bh[4], bl[4], bl2[4];
+    {
+        const int tap = l31 >> 1, o = l31 & 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float w = l31 < 18 ? w_out[((size_t)tap * C + ks * 16 + hi * 8 + i) * 2 + o] : 0.f;
+                const __bf16 h = (__bf16)w;
+                const float r1 = w - (float)h;
+                const __bf16 m = (__bf16)r1;
+                bh[ks][i] = h, bl[ks][i] = m, bl2[ks][i] = (__bf16)(r1 - (float)m);
+            }
+    }
+    constexpr int MT = (NPIX + 31) / 32;   // 11 tiles of 32 halo pixels: wave w takes the tiles w, w + 4, w + 8
+    constexpr int MTW = (MT + 3) / 4;
+    // all loads of the wave first (12 x 16 bytes per lane in flight), then the matrix instructions
+    bf16x8 a[MTW][4];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int q = (wv + 4 * i) * 32 + l31;
+        const int iy = y0 - 1 + q / FH_I, ix = x0 - 1 + q % FH_I;
+        const bool ok = q < NPIX && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const __bf16 *px = x + (ok ? ((size_t)(n * H + iy) * W + ix) * ld + hi * 8 : 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(px + ks * 16);   // unconditional load, masked below
+            a[i][ks] = __builtin_bit_cast(bf16x8, ok ? v : (u32x4){0u, 0u, 0u, 0u});
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int mt = wv + 4 * i;
+        if (mt >= MT) break;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], bh[ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], bl[ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], bl2[ks], acc, 0, 0, 0);
+        }
+        if (l31 < 18) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qq = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (qq < NPIX) ys[qq * YP + l31] = acc[r];
+            }
+        }
+    }
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    float acc0 = b_out ? b_out[0] : 0.f, acc1 = b_out ? b_out[1] : 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const float2 v = *reinterpret_cast<const float2 *>(ys + ((ty + tap / 3) * FH_I + tx + tap % 3) * YP + tap * 2);
+        acc0 += v.x, acc1 += v.y;
+    }
+    const int y = y0 + ty, xq = x0 + tx;
+    if (y < H && xq < W && raw) {
+        *reinterpret_cast<float2 *>(resid + (((size_t)n * H + y) * W + xq) * 2) = make_float2(acc0, acc1);
+    } else if (y < H && xq < W) {
+        const float r0 = tanhf(tanhf(acc0)), r1 = tanhf(tanhf(acc1));
+        const size_t p = ((size_t)n * H + y) * W + xq;
+        if (resid) *reinterpret_cast<float2 *>(resid + p * 2) = make_float2(r0, r1);
+        if (grid) {
+            float a0 = 0.f, a1 = 0.f;
+            if (theta) {
+                const float *t = theta + (size_t)n * 6;
+                const float bx = ac ? (W > 1 ? (2.f * xq) / (float)(W - 1) - 1.f : 0.f) : (2.f * xq + 1.f) / (float)W - 1.f;
+                const float by = ac ? (H > 1 ? (2.f * y) / (float)(H - 1) - 1.f : 0.f) : (2.f * y + 1.f) / (float)H - 1.f;
+                a0 = t[0] * bx + t[1] * by + t[2];
+                a1 = t[3] * bx + t[4] * by + t[5];
+            }
+            *reinterpret_cast<float2 *>(grid + p * 2) = make_float2(r0 + a0, r1 + a1);
+        }
+    }
+}
+
 // ---- use_BN training-mode pieces of the two heads (netg.cpp sequences them with pws_bn_train_fwd in between)
 // z1[n][j] = sum over K slices of the hidden pre-activations + b1[j]   (theta_hidden_kernel's partials)
 __global__ void __launch_bounds__(256) theta_sum_kernel(const float *__restrict__ partial, int nslices, int n, int hidden,
@@ -288,7 +387,10 @@ extern "C" int pws_field_head_fwd_s(const float *x, int ld, int n, int h, int w,
     const unsigned ntiles = (unsigned)tiles_x * tiles_y * n;
     ProfScope prof(KID_FIELD_HEAD, 2.0 * n * h * w * 18.0 * c,
                    (double)n * h * w * (4.0 * c + (resid ? 8.0 : 0.0) + (grid ? 8.0 : 0.0)), as_stream(stream));
-    if (store == PWS_STORE_BF16)
+    if (store == PWS_STORE_BF16 && c == 64 && ld % 8 == 0 && g_experiment != 90)   // the matrix-core kernel (see its comment)
+        hipLaunchKernelGGL(field_head16_mfma_kernel, dim3(ntiles), dim3(256), 0, as_stream(stream), reinterpret_cast<const __bf16 *>(x), ld, n, h, w,
+                           w_out, b_out, theta, align_corners, resid, grid, tiles_x, tiles_y, ntiles, 0);
+    else if (store == PWS_STORE_BF16)
         hipLaunchKernelGGL(field_head_kernel<true>, dim3(ntiles), dim3(256), 0, as_stream(stream), x, ld, n, h, w, c, w_out, b_out,
                            theta, align_corners, resid, grid, tiles_x, tiles_y, ntiles, 0);
     else

@@ -309,6 +309,43 @@ def test_field_head_backward_bf16_storage_and_fused_activation_gradient(hip, act
                                         st) == -22
 
 
+@pytest.mark.parametrize("shape", [(3, 37, 45), (2, 64, 64), (1, 16, 16)])
+def test_field_head_forward_bf16_storage_matrix_core_kernel(hip, shape):
+    """Field head on bf16-stored activations of 64 channels: the matrix-core kernel (pointwise 64 -> 18 product + 9-point stencil,
+    weights as three bf16 terms; PWS_OPT_EXPERIMENT 90 switches it off) against the VALU kernel and against torch on the same
+    rounded input -- both in fp32 arithmetic on exact bf16 inputs, so they agree to summation order."""
+    A = hip
+    L, st = A.lib(), A.current_stream()
+    n, h, w = shape
+    c = 64
+    rs = np.random.RandomState(h * 100 + w)
+    x = bf16r(torch.from_numpy(rs.standard_normal((n, c, h, w)).astype(np.float32)))
+    wo = torch.from_numpy((rs.standard_normal((2, c, 3, 3)) / 12).astype(np.float32))
+    bo = torch.from_numpy(rs.standard_normal(2).astype(np.float32))
+    theta = torch.from_numpy((np.array([1, 0, 0, 0, 1, 0], np.float32) + 0.1 * rs.standard_normal((n, 6))).astype(np.float32))
+    ref_res = torch.tanh(torch.tanh(F.conv2d(x.double(), wo.double(), bo.double(), padding=1))).permute(0, 2, 3, 1)
+    ref_grid = ref_res + F.affine_grid(theta.double().view(n, 2, 3), (n, 3, h, w), align_corners=False)
+    po = torch.empty(L.pws_packed_weight_floats(A.CONV_K3S1_OUT, c, 2), device="cuda")
+    d_wo, d_bo, d_th = wo.cuda(), bo.cuda(), theta.cuda()
+    A.check(L.pws_pack_conv_weight(A.ptr(d_wo), A.ptr(po), A.CONV_K3S1_OUT, c, 2, st), "pack")
+    d_x = nhwc(x).cuda().bfloat16()
+    got = {}
+    try:
+        for exp in (0, 90):
+            L.pws_set_option(100, exp)
+            res = torch.full((n, h, w, 2), float("nan"), device="cuda")
+            grid = torch.full((n, h, w, 2), float("nan"), device="cuda")
+            A.check(L.pws_field_head_fwd_s(A.ptr(d_x), c, n, h, w, c, A.ptr(po), A.ptr(d_bo), A.ptr(d_th), 0, A.ptr(res), A.ptr(grid),
+                                           A.STORE_BF16, st), "field")
+            got[exp] = (res.cpu().numpy(), grid.cpu().numpy())
+    finally:
+        L.pws_set_option(100, 0)
+    for exp in (0, 90):
+        np.testing.assert_allclose(got[exp][0], ref_res.numpy(), rtol=0, atol=5e-6)   # measured 3.0e-6 (fp32 sums of 576 terms, tanh twice)
+        np.testing.assert_allclose(got[exp][1], ref_grid.numpy(), rtol=0, atol=6e-6)
+    assert not np.array_equal(got[0][0], got[90][0]) or n * h * w < 512   # two different kernels ran
+
+
 def test_bf16_falls_back_to_fp32_for_uncovered_shapes(hip):
     """Sources that are not multiples of 32 channels run the exact fp32 kernel even when bf16 math is requested."""
     A = hip
