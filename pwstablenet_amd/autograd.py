@@ -22,6 +22,7 @@ class _NetGTrain(torch.autograd.Function):
         saved = {}
         grids, resid = net._run(input1, True, train_ctx=saved)
         ctx.net_ref, ctx.saved = net_ref, saved
+        ctx.set_materialize_grads(False)   # unused outputs arrive as None in backward (handled there), not as materialised zeros
         return tuple(grids) + tuple(resid)
 
     @staticmethod

@@ -25,7 +25,9 @@ __global__ void __launch_bounds__(64) theta_hidden_kernel(const float *__restric
     const int j = blockIdx.x * 64 + lane;
     const int slice = blockIdx.y;
     const int k0 = slice * kchunk, kn = min(kchunk, k1 - k0);
-    for (int n0 = 0; n0 < n; n0 += TH_NB) {
+    // groups of TH_NB samples are spread over blockIdx.z (a training batch of 64 was 8 serial passes of every wave over its weights:
+    // 205 us per call in the configs[2] step)
+    for (int n0 = blockIdx.z * TH_NB; n0 < n; n0 += gridDim.z * TH_NB) {
         const int nb = min(TH_NB, n - n0);
         __syncthreads();
         for (int i = lane; i < nb * kn; i += 64) sx[(i / kn) * kchunk + i % kn] = x[(size_t)(n0 + i / kn) * k1 + k0 + i % kn];
@@ -316,7 +318,7 @@ static int theta_slices(int k1) {
 namespace pws {
 int theta_z1(const float *x, int n, int c, int hidden, const float *w_flat, const float *b_flat, float *ws, float *z1, hipStream_t st) {
     const int k1 = 4 * c, kchunk = 64, nslices = theta_slices(k1);
-    hipLaunchKernelGGL(theta_hidden_kernel, dim3((hidden + 63) / 64, nslices), dim3(64), sizeof(float) * TH_NB * kchunk, st, x, n, k1, hidden,
+    hipLaunchKernelGGL(theta_hidden_kernel, dim3((hidden + 63) / 64, nslices, (unsigned)((n + TH_NB - 1) / TH_NB)), dim3(64), sizeof(float) * TH_NB * kchunk, st, x, n, k1, hidden,
                        kchunk, w_flat, ws);
     const size_t e = (size_t)n * hidden;
     hipLaunchKernelGGL(theta_sum_kernel, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, st, ws, nslices, n, hidden, b_flat, z1);
@@ -362,7 +364,7 @@ extern "C" int pws_theta_head_fwd_save(const float *x, int n, int c, int hidden,
     PWS_REQUIRE(hidden * sizeof(float) <= 64 * 1024, "pws_theta_head_fwd: hidden = %d exceeds 64 KB of LDS", hidden);
     ProfScope prof(KID_THETA_HEAD, 2.0 * n * ((double)k1 * hidden + 6.0 * hidden), 4.0 * ((double)k1 * hidden + n * k1),
                    as_stream(stream));
-    hipLaunchKernelGGL(theta_hidden_kernel, dim3((hidden + 63) / 64, nslices), dim3(64), sizeof(float) * TH_NB * kchunk,
+    hipLaunchKernelGGL(theta_hidden_kernel, dim3((hidden + 63) / 64, nslices, (unsigned)((n + TH_NB - 1) / TH_NB)), dim3(64), sizeof(float) * TH_NB * kchunk,
                        as_stream(stream), x, n, k1, hidden, kchunk, w_flat, ws);
     hipLaunchKernelGGL(theta_final_kernel, dim3(n), dim3(256), sizeof(float) * hidden, as_stream(stream), ws, nslices, n, hidden,
                        b_flat, w_lin, b_lin, theta, h_saved);

@@ -100,6 +100,7 @@ class _Objective(torch.autograd.Function):
         # gradient of, say, loss_mse alone raises in autograd instead of silently returning zeros
         loss_g = losses[0:1].clone()
         ctx.mark_non_differentiable(losses)
+        ctx.set_materialize_grads(False)   # outputs nobody differentiates arrive as None in backward, not as zero tensors (50 MB each)
         return (loss_g, losses) + tuple(fakes)
 
     @staticmethod
