@@ -638,6 +638,42 @@ static const TileChoice kBK4S2[] = {bchoice<B_K4S2_T128>(), bchoice<B_K4S2_T64, 
 static const TileChoice kBSP3[] = {bchoice<B_SP3_T256>(), bchoice<B_SP3_T128>(), bchoice<B_SP3_T64, B_SP3_T64_S>(), bchoice<B_SP3_T64N4, B_SP3_T64N4_S>(),
                                    bchoice<B_SP3_T64N16, B_SP3_T64N16_S>()};
 
+// 256-pixel tiles for the DEEP maps of a training batch (8 x 8 x 4 samples, 4 x 4 x 16, 2 x 2 x 64): at batch 64 these levels hold
+// 256 .. 4096 pixels, and the 64-pixel tiles above re-read a layer's weights once per tile (512 -> 512 @4x4 x 64: 16 tiles x 9.4 MB
+// from L2 per launch, 26 us = 183 TFLOP/s); a 256-pixel tile quarters that and has the 2 x 2 fragments per wave of the large-map
+// tiles.  Stride-1 kinds only (the stride-2 kinds' input tiles of 256 output pixels exceed half the LDS).
+using B_K3S1_D8 = BfCfg<3, 1, 1, 0, 8, 8, 4, 16, 4, 1, 2, 2>;
+using B_K3S1_D4 = BfCfg<3, 1, 1, 0, 4, 4, 16, 16, 4, 1, 2, 2>;
+using B_K3S1_D2 = BfCfg<3, 1, 1, 0, 2, 2, 64, 16, 4, 1, 2, 2>;
+using B_CT4_D8 = BfCfg<2, 1, 0, 1, 8, 8, 4, 32, 4, 1, 2, 2>;
+using B_CT4_D4 = BfCfg<2, 1, 0, 1, 4, 4, 16, 32, 4, 1, 2, 2>;
+using B_CT4_D2 = BfCfg<2, 1, 0, 1, 2, 2, 64, 32, 4, 1, 2, 2>;
+using B_SP3_D8 = BfCfg<2, 1, 0, 2, 8, 8, 4, 32, 4, 1, 2, 2>;
+using B_SP3_D4 = BfCfg<2, 1, 0, 2, 4, 4, 16, 32, 4, 1, 2, 2>;
+using B_SP3_D2 = BfCfg<2, 1, 0, 2, 2, 2, 64, 32, 4, 1, 2, 2>;
+static const TileChoice kBK3S1Deep[] = {bchoice<B_K3S1_D8>(), bchoice<B_K3S1_D4>(), bchoice<B_K3S1_D2>()};
+static const TileChoice kBCT4Deep[] = {bchoice<B_CT4_D8>(), bchoice<B_CT4_D4>(), bchoice<B_CT4_D2>()};
+static const TileChoice kBSP3Deep[] = {bchoice<B_SP3_D8>(), bchoice<B_SP3_D4>(), bchoice<B_SP3_D2>()};
+
+// the deep tile of this launch, or nullptr: the map is exactly 8 x 8 / 4 x 4 / 2 x 2, the batch fills the tile's samples, and K is
+// long enough for the K split to give every CU work (PWS_OPT_EXPERIMENT 95: never, 96: whenever the map fits)
+static const TileChoice *deep_tile(const TileChoice *deep, const ConvKParams &kp, int cin_total) {
+    if (g_experiment == 95) return nullptr;
+    const int idx = (kp.LH == 8 && kp.LW == 8) ? 0 : ((kp.LH == 4 && kp.LW == 4) ? 1 : ((kp.LH == 2 && kp.LW == 2) ? 2 : -1));
+    if (idx < 0) return nullptr;
+    const TileChoice &c = deep[idx];
+    if (g_experiment == 96) return &c;
+    // measured at batch 64 (tools/conv_bench.py, bf16 storage): 8 x 8: 512 -> 512 3x3 51.5 -> 43.7 us; 4 x 4: transposed 1024 -> 512 47.7 ->
+    // 43.9 us but 3x3 512 -> 512 26.4 -> 27.2 us; 2 x 2: 16.7 -> 21.0 us -- the deep launches are bound by their chunk-serial K loop and
+    // the K-split reduce, not by weight re-reads: only the two winning cases are taken
+    if (idx == 2 || (idx == 1 && kp.nclasses != 4)) return nullptr;
+    if (kp.N < c.tn) return nullptr;
+    const long blocks = cdiv(kp.N, c.tn) * cdiv(kp.cout, 64) * kp.nclasses;
+    const long chunks = cin_total / c.ck;
+    if (blocks * (chunks / 2) < 128) return nullptr;
+    return &c;
+}
+
 using B_K5S1_T256 = BfCfg<5, 1, 2, 0, 16, 16, 1, 32, 4, 1, 2, 2>;
 
 static int launch_k5(ConvKParams &kp, hipStream_t st, const ProfInfo &pi) {
@@ -682,9 +718,13 @@ int conv_bf16_fwd(int kind, ConvKParams &kp, int cin_total, float *out, float *w
     }
     switch (kind) {
     case PWS_CONV_K3S1:
-    case PWS_CONVT_K3S1: return select_and_launch(kBK3S1, 5, kp, cin_total, out, ws, ws_floats, st, pi, kFillBlocksBf16);
+    case PWS_CONVT_K3S1:
+        if (const TileChoice *d = deep_tile(kBK3S1Deep, kp, cin_total)) return select_and_launch(d, 1, kp, cin_total, out, ws, ws_floats, st, pi, kFillBlocksBf16);
+        return select_and_launch(kBK3S1, 5, kp, cin_total, out, ws, ws_floats, st, pi, kFillBlocksBf16);
     case PWS_CONV_K3S2: return select_and_launch(kBK3S2, 5, kp, cin_total, out, ws, ws_floats, st, pi, kFillBlocksBf16);
-    case PWS_CONVT_K4S2: return select_and_launch(kBCT4, 5, kp, cin_total, out, ws, ws_floats, st, pi, kFillBlocksBf16);
+    case PWS_CONVT_K4S2:
+        if (const TileChoice *d = deep_tile(kBCT4Deep, kp, cin_total)) return select_and_launch(d, 1, kp, cin_total, out, ws, ws_floats, st, pi, kFillBlocksBf16);
+        return select_and_launch(kBCT4, 5, kp, cin_total, out, ws, ws_floats, st, pi, kFillBlocksBf16);
     case PWS_CONV_K5S1:
         if (kp.nsrc != 1) return 1;
         kp.out = out;
@@ -702,8 +742,12 @@ int conv_bf16_dgrad(int kind, ConvKParams &kp, int cout_f, float *ws, size_t ws_
     }
     switch (kind) {
     case PWS_CONV_K3S1:
-    case PWS_CONVT_K3S1: return select_and_launch(kBK3S1, 5, kp, cout_f, nullptr, ws, ws_floats, st, pi, kFillBlocksBf16);
-    case PWS_CONV_K3S2: return select_and_launch(kBSP3, 5, kp, cout_f, nullptr, ws, ws_floats, st, pi, kFillBlocksBf16);
+    case PWS_CONVT_K3S1:
+        if (const TileChoice *d = deep_tile(kBK3S1Deep, kp, cout_f)) return select_and_launch(d, 1, kp, cout_f, nullptr, ws, ws_floats, st, pi, kFillBlocksBf16);
+        return select_and_launch(kBK3S1, 5, kp, cout_f, nullptr, ws, ws_floats, st, pi, kFillBlocksBf16);
+    case PWS_CONV_K3S2:
+        if (const TileChoice *d = deep_tile(kBSP3Deep, kp, cout_f)) return select_and_launch(d, 1, kp, cout_f, nullptr, ws, ws_floats, st, pi, kFillBlocksBf16);
+        return select_and_launch(kBSP3, 5, kp, cout_f, nullptr, ws, ws_floats, st, pi, kFillBlocksBf16);
     case PWS_CONVT_K4S2: return select_and_launch(kBK4S2, 4, kp, cout_f, nullptr, ws, ws_floats, st, pi, kFillBlocksBf16);
     default: return 1;
     }

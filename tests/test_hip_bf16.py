@@ -309,6 +309,32 @@ def test_field_head_backward_bf16_storage_and_fused_activation_gradient(hip, act
                                         st) == -22
 
 
+DEEP_CASES = [
+    ("CONV_K3S1", (8, 8, 8), [64], 64), ("CONVT_K3S1", (32, 4, 4), [64, 32], 96), ("CONV_K3S1", (64, 2, 2), [32], 64),
+    ("CONV_K3S1", (7, 4, 4), [32], 32),            # fewer samples than the 4 x 4 x 16 tile holds
+    ("CONVT_K4S2", (8, 8, 8), [64], 64), ("CONVT_K4S2", (20, 4, 4), [32, 32], 32), ("CONVT_K4S2", (64, 2, 2), [32], 64),
+    ("CONV_K3S2", (8, 16, 16), [32], 64), ("CONV_K3S2", (18, 8, 8), [64, 32], 32),   # data gradient = sub-pixel classes over an 8 x 8 / 4 x 4 dy
+]
+
+
+@pytest.mark.parametrize("kname,shape,src_c,cout", DEEP_CASES)
+def test_bf16_deep_map_tiles(hip, kname, shape, src_c, cout):
+    """The 256-pixel tiles of the deep maps (8 x 8 x 4 samples, 4 x 4 x 16, 2 x 2 x 64; PWS_OPT_EXPERIMENT 96 takes them whenever the
+    map fits, whatever the batch and K): forward (fp32 and bf16 storage, with and without K split), data gradient, fused act'."""
+    L = hip.lib()
+    L.pws_set_option(100, 96)
+    try:
+        if kname != "CONV_K3S2":
+            test_bf16_storage_conv_forward(hip, kname, shape, src_c, cout)
+            test_bf16_conv_forward(hip, kname, shape, src_c, cout, 1)
+        if cout % 32 == 0:
+            for store in (False, True):
+                test_bf16_conv_data_gradient(hip, kname, shape, src_c, cout, store)
+            test_bf16_data_gradient_with_fused_activation_gradient(hip, kname, shape, src_c, cout, "ACT_LRELU")
+    finally:
+        L.pws_set_option(100, 0)
+
+
 @pytest.mark.parametrize("shape", [(3, 37, 45), (2, 64, 64), (1, 16, 16)])
 def test_field_head_forward_bf16_storage_matrix_core_kernel(hip, shape):
     """Field head on bf16-stored activations of 64 channels: the matrix-core kernel (pointwise 64 -> 18 product + 9-point stencil,
