@@ -260,6 +260,86 @@ __global__ void __launch_bounds__(256) field_head16_mfma_kernel(const __bf16 *__
     }
 }
 
+// The same formulation in exact fp32 (BASELINE configs[1]: fp32 storage, 64 channels) on v_mfma_f32_32x32x2_f32: k-step j of lane
+// half `hi` is channel 32 hi + j, so a lane reads the 32 consecutive channels of its pixel (8 x 16 bytes) and holds the matching 32
+// weights of its column (tap, o).  Products and sums are fp32 as in the VALU kernel (the summation order differs).
+__global__ void __launch_bounds__(256) field_head32_mfma_kernel(const float *__restrict__ x, int ld, int N, int H, int W,
+                                                                const float *__restrict__ w_out, const float *__restrict__ b_out,
+                                                                const float *__restrict__ theta, int ac, float *__restrict__ resid,
+                                                                float *__restrict__ grid, int tiles_x, int tiles_y, unsigned ntiles, int raw) {
+    constexpr int C = 64, NPIX = FH_I * FH_I, YP = 18;
+    __shared__ float ys[NPIX * YP];
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const unsigned tile = xcd_remap(blockIdx.x, ntiles);
+    const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const int x0 = tx_i * FH_T, y0 = ty_i * FH_T;
+    float bw[32];
+    {
+        const int tap = l31 >> 1, o = l31 & 1;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) bw[j] = l31 < 18 ? w_out[((size_t)tap * C + hi * 32 + j) * 2 + o] : 0.f;
+    }
+    constexpr int MT = (NPIX + 31) / 32, MTW = (MT + 3) / 4;
+    f32x4 a[MTW][8];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int q = (wv + 4 * i) * 32 + l31;
+        const int iy = y0 - 1 + q / FH_I, ix = x0 - 1 + q % FH_I;
+        const bool ok = q < NPIX && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const float *px = x + (ok ? ((size_t)(n * H + iy) * W + ix) * ld + hi * 32 : 0);
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(px + k4 * 4);   // unconditional load, masked below
+            a[i][k4] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int mt = wv + 4 * i;
+        if (mt >= MT) break;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j >> 2][j & 3], bw[j], acc, 0, 0, 0);
+        if (l31 < 18) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qq = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (qq < NPIX) ys[qq * YP + l31] = acc[r];
+            }
+        }
+    }
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    float acc0 = b_out ? b_out[0] : 0.f, acc1 = b_out ? b_out[1] : 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const float2 v = *reinterpret_cast<const float2 *>(ys + ((ty + tap / 3) * FH_I + tx + tap % 3) * YP + tap * 2);
+        acc0 += v.x, acc1 += v.y;
+    }
+    const int y = y0 + ty, xq = x0 + tx;
+    if (y < H && xq < W && raw) {
+        *reinterpret_cast<float2 *>(resid + (((size_t)n * H + y) * W + xq) * 2) = make_float2(acc0, acc1);
+    } else if (y < H && xq < W) {
+        const float r0 = tanhf(tanhf(acc0)), r1 = tanhf(tanhf(acc1));
+        const size_t p = ((size_t)n * H + y) * W + xq;
+        if (resid) *reinterpret_cast<float2 *>(resid + p * 2) = make_float2(r0, r1);
+        if (grid) {
+            float a0 = 0.f, a1 = 0.f;
+            if (theta) {
+                const float *t = theta + (size_t)n * 6;
+                const float bx = ac ? (W > 1 ? (2.f * xq) / (float)(W - 1) - 1.f : 0.f) : (2.f * xq + 1.f) / (float)W - 1.f;
+                const float by = ac ? (H > 1 ? (2.f * y) / (float)(H - 1) - 1.f : 0.f) : (2.f * y + 1.f) / (float)H - 1.f;
+                a0 = t[0] * bx + t[1] * by + t[2];
+                a1 = t[3] * bx + t[4] * by + t[5];
+            }
+            *reinterpret_cast<float2 *>(grid + p * 2) = make_float2(r0 + a0, r1 + a1);
+        }
+    }
+}
+
 // ---- use_BN training-mode pieces of the two heads (netg.cpp sequences them with pws_bn_train_fwd in between)
 // z1[n][j] = sum over K slices of the hidden pre-activations + b1[j]   (theta_hidden_kernel's partials)
 __global__ void __launch_bounds__(256) theta_sum_kernel(const float *__restrict__ partial, int nslices, int n, int hidden,
@@ -395,6 +475,9 @@ extern "C" int pws_field_head_fwd_s(const float *x, int ld, int n, int h, int w,
     else if (store == PWS_STORE_BF16)
         hipLaunchKernelGGL(field_head_kernel<true>, dim3(ntiles), dim3(256), 0, as_stream(stream), x, ld, n, h, w, c, w_out, b_out,
                            theta, align_corners, resid, grid, tiles_x, tiles_y, ntiles, 0);
+    else if (c == 64 && g_experiment != 90)
+        hipLaunchKernelGGL(field_head32_mfma_kernel, dim3(ntiles), dim3(256), 0, as_stream(stream), x, ld, n, h, w, w_out, b_out, theta, align_corners,
+                           resid, grid, tiles_x, tiles_y, ntiles, 0);
     else
         hipLaunchKernelGGL(field_head_kernel<false>, dim3(ntiles), dim3(256), 0, as_stream(stream), x, ld, n, h, w, c, w_out, b_out,
                            theta, align_corners, resid, grid, tiles_x, tiles_y, ntiles, 0);
