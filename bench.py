@@ -80,8 +80,8 @@ _PMC_NAMES = {
     "conv_mfma_kernel<convT4,16x16>": ["convT4,tile 1x16x16", "convT4,tile 1x8x16"],
     "conv_mfma_kernel<k3s1,16x16>": ["k3s1,tile 1x16x16", "k3s1,tile 1x8x16"],
     "wino_k3s1_kernel<F(2x2,3x3)>": ["wino_k3s1_kernel", "wino_kernel<0>"],
-    "wino_ring_kernel<F(2x2,3x3)>": ["wino_ring_kernel<F(2x2,3x3)"],
-    "wino_ring_kernel<convT4,F(2x2,2x2)>": ["wino_ring_kernel<convT4"],
+    "wino_ring_kernel<F(2x2,3x3)>": ["wino_ring_kernel<F(2x2,3x3)"],          # 32-wide and 16-wide map geometries
+    "wino_ring_kernel<convT4,F(2x2,2x2)>": ["wino_ring_kernel<convT4"],        # 1 or 2 classes per unit, both geometries
     "conv_bf16_kernel": ["conv_bf16_kernel", "conv_bf16_k5_kernel"],
     "conv_mfma_kernel<k5s1,16x16>": ["k5s1,tile"],
     "grid_sample_fwd_kernel": ["grid_sample_fwd2_kernel"],

@@ -38,10 +38,10 @@ def short(name):
         a = [x.strip() for x in m.group(1).split(",")]
         mode = {"0": "k3s1", "1": "convT4", "2": "dgrad-subpix k3s2", "3": "k3s2 planes", "4": "dgrad k4s2 planes"}.get(a[0], a[0])
         return "conv_ring_kernel<%s,tile %sx%sx%s,R%s,%s>" % (mode, a[3], a[1], a[2], a[4], "dgrad" if m.group(2) == "true" else "fwd")
-    m = re.match(r"pws::wino_ring_kernel<(\d+),\s*(\d+)>", name)
-    if m:   # persistent LDS-ring Winograd kernel (conv_wring.hip): mode, ablation mask (0 in the product)
-        return "wino_ring_kernel<%s%s>" % ({"0": "F(2x2,3x3)", "1": "convT4,F(2x2,2x2),2 classes per unit", "2": "convT4,F(2x2,2x2),1 class per unit"}[m.group(1)],
-                                         "" if m.group(2) == "0" else ",ablation %s" % m.group(2))
+    m = re.match(r"(?:pws::)?wino_ring_kernel<(\d+),\s*(\d+),\s*(\d+)>", name)
+    if m:   # persistent LDS-ring Winograd kernel (conv_wring.hip): mode, map geometry, ablation mask (0 in the product)
+        return "wino_ring_kernel<%s%s%s>" % ({"0": "F(2x2,3x3)", "1": "convT4,F(2x2,2x2),2 classes per unit", "2": "convT4,F(2x2,2x2),1 class per unit"}[m.group(1)],
+                                           ",16-wide maps (2 samples per unit)" if m.group(2) == "1" else "", "" if m.group(3) == "0" else ",ablation %s" % m.group(3))
     m = re.match(r"pws::conv_ringf_kernel<pws::RfCfg<([^>]*)>\s*>", name)
     if m:
         a = [x.strip() for x in m.group(1).split(",")]
