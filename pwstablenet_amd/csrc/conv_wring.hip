@@ -155,24 +155,31 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
     const int nchunks = p.cps;   // chunks of a unit (its K split)
     const unsigned total = my_units * (unsigned)nchunks;
 
-    // ---- DMA descriptors of this lane: piece pc = it * 8 + wv covers the 16-byte LDS slots pc * 64 + lane of a slot image.
+    // ---- DMA offsets of this lane: piece pc = it * 8 + wv covers the 16-byte LDS slots pc * 64 + lane of a slot image.
     // Raw slot j -> (image row, pixel x, channel slot s): row = j / 136; inside the row 4 consecutive slots are one pixel, pixels
-    // ordered even x first; the pixel's slots are permuted (header).
-    int ia[WR_RAW_IT];   // s << 20 | row << 10 | x, or -1
+    // ordered even x first; the pixel's slots are permuted (header).  The byte offsets of a unit's raw pieces do not change from
+    // slot to slot (the chunk goes into the scalar offset), so they are computed once per unit: every plain VALU instruction beside
+    // the fp32 matrix instructions costs ~6 cycles of matrix time (tools/probes/mfma_f32_probe.hip: 155 TFLOP/s alone, 131 with one
+    // v_add_f32 per matrix instruction, 119 with two) -- recomputing them per slot was a third of the phase's VALU work.
+    constexpr int VRAW_N = WR_RAW_IT < 5 ? WR_RAW_IT : 5;   // (the 41st raw piece of the 16-wide geometry, half a piece of wave 0: on the fly)
+    unsigned vraw[VRAW_N];
 #pragma unroll
-    for (int it = 0; it < WR_RAW_IT; ++it) {
-        const int pc = it * WR_WAVES + wv;
+    for (int it = 0; it < VRAW_N; ++it) vraw[it] = kWringOob;
+    auto raw_off = [&](int pc, int oy, int ox, unsigned ldb) -> unsigned {   // byte offset of this lane's 16 bytes of raw piece pc
         const int j = pc * 64 + lane;
-        ia[it] = -1;
+        unsigned v = kWringOob;
         if (pc < WR_RAW_PIECES && j < G_::RAW_SLOTS) {
             const int row = j / G_::ROW_SLOTS, r = j - row * G_::ROW_SLOTS;
             const int pp = r >> 2, sp = r & 3;
             const int par = pp >= G_::HALF ? 1 : 0, q = pp - par * G_::HALF;
-            const int px = 2 * q + par;   // G16: 0..17 = sample A, 18..35 = sample B
-            const int s = (0x78 >> (2 * (sp ^ ((q >> 2) & 3)))) & 3;   // inverse of P = {0, 3, 1, 2}
-            ia[it] = s << 20 | row << 10 | px;
+            int lx = 2 * q + par, smp = 0;   // G16: 0..17 = sample A, 18..35 = sample B
+            if constexpr (G16) smp = lx >= G_::HALF ? 1 : 0, lx -= smp * G_::HALF;
+            const int sl = (0x78 >> (2 * (sp ^ ((q >> 2) & 3)))) & 3;   // inverse of P = {0, 3, 1, 2}
+            const int ry = oy + row, rx = ox + lx;
+            if (ry >= 0 && ry < p.H && rx >= 0 && rx < p.W) v = (unsigned)((smp * p.H + ry) * p.W + rx) * ldb + (unsigned)(sl * 16);
         }
-    }
+        return v;
+    };
     const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.ur), 0, (int)p.ur_bytes, 0x00020000);
     unsigned pu = u_begin;
     int ps = 0, pc0 = 0, pchunk = 0, pbuf = 0;
@@ -191,7 +198,7 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
     // One slot's DMA = prep() (scalar: descriptors of the slot the cursor points at, then the cursor moves on) followed by
     // piece(0 .. WR_NIT - 1), which the matrix phase spreads over its first groups of matrix instructions.  Piece it of wave wv:
     // it = 0 .. 4 raw piece it * 8 + wv (it = 4: waves 0 .. 6 only), it = 5 .. 8 weight piece (it - 5) * 8 + wv.
-    __amdgpu_buffer_rsrc_t d_rin = rsrc_u;
+    __amdgpu_buffer_rsrc_t d_rin = rsrc_u, d_rk = rsrc_u, d_ruk = rsrc_u;   // d_rk / d_ruk: what the pieces use (no records when killed)
     unsigned d_base = 0, d_sin = 0, d_su = 0, d_ldb = 0;
     int d_oy = 0, d_ox = 0;
     bool d_kill = false;   // past the last slot (or ablation): the pieces fetch nothing (offsets beyond num_records)
@@ -200,6 +207,7 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
     auto prep = [&]() {
         d_kill = pu >= u_end || ((ABL & 1) && !pfirst) || (ABL & 64);
         pfirst = false;
+        const __amdgpu_buffer_rsrc_t r_none = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.ur), 0, 0, 0x00020000);   // every offset out of range: zeros
         d_base = uniw((unsigned)(pbuf * G_::GROUP_BYTES));
         pbuf ^= 1;
         if (pu < u_end) {
@@ -210,6 +218,8 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
                 d_rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base_in), 0, (int)uniw((unsigned)(img * (G16 ? 2 : 1))), 0x00020000);
                 d_ldb = (unsigned)s_ld * 4u;
                 d_oy = PU.y0 * WR_TH - 1, d_ox = PU.x0 * WR_TW - 1;
+#pragma unroll
+                for (int it = 0; it < VRAW_N; ++it) vraw[it] = raw_off(it * WR_WAVES + wv, d_oy, d_ox, d_ldb);
                 const unsigned chunk0 = (unsigned)(PU.ks * nchunks);   // of all p.nchunks chunks of the layer
                 if constexpr (MODE == 2)   // the px half of the MODE 1 block of (py, channel block, chunk)
                     d_su0 = uniw((unsigned)(((((unsigned)(PU.py >> 1) * p.ncob + (unsigned)PU.cob) * (unsigned)p.nchunks + chunk0) * 2u + (unsigned)(PU.py & 1)) *
@@ -233,29 +243,28 @@ __global__ void __launch_bounds__(WR_WAVES * 64, 2) wino_ring_kernel(const Wring
                 s_ld = selw4(p.src_ld, ps), s_c = selw4(p.src_c, ps), s_ptr = reinterpret_cast<const char *>(selw4(p.src_ptr, ps));
             }
         }
+        d_ruk = d_kill ? r_none : rsrc_u;
+        d_rk = d_kill ? r_none : d_rin;
     };
+    const unsigned l16 = (unsigned)(lane * 16);
     auto piece = [&](auto it_c) {
         constexpr int it = decltype(it_c)::value;
         if constexpr (it < WR_RAW_IT) {
             const int pc = it * WR_WAVES + wv;   // wave-uniform
             if (it * WR_WAVES + WR_WAVES <= WR_RAW_PIECES || pc < WR_RAW_PIECES) {
-                const int ly = (ia[it] >> 10) & 0x3ff;
-                int lx = ia[it] & 0x3ff, smp = 0;
-                if constexpr (G16) smp = lx >= G_::HALF ? 1 : 0, lx -= smp * G_::HALF;
-                const int ry = d_oy + ly, rx = d_ox + lx;
-                const bool ok = ia[it] >= 0 && ry >= 0 && ry < p.H && rx >= 0 && rx < p.W && !d_kill;
-                const unsigned v = ok ? (unsigned)((smp * p.H + ry) * p.W + rx) * d_ldb + (unsigned)((ia[it] >> 20) * 16) : kWringOob;
-                if constexpr (ABL & 128) wring_dma16_nom0(v, d_rin, d_sin);
+                unsigned v;
+                if constexpr (it < VRAW_N) v = vraw[it];   // no VALU work here (see vraw)
+                else v = raw_off(pc, d_oy, d_ox, d_ldb);
+                if constexpr (ABL & 128) wring_dma16_nom0(v, d_rk, d_sin);
                 else if constexpr (ABL & 256) wring_m0_only(d_base + (unsigned)(pc * 1024));
-                else wring_dma16(d_base + (unsigned)(pc * 1024), v, d_rin, d_sin);
+                else wring_dma16(d_base + (unsigned)(pc * 1024), v, d_rk, d_sin);
             }
         } else {
             const int u = (it - WR_RAW_IT) * WR_WAVES + wv;
             if ((it - WR_RAW_IT) * WR_WAVES + WR_WAVES <= G_::U_PIECES || u < G_::U_PIECES) {   // wave-uniform
-                const unsigned v = d_kill ? kWringOob : (unsigned)(lane * 16);
-                if constexpr (ABL & 128) wring_dma16_nom0(v, rsrc_u, d_su + (unsigned)(u * 1024));
+                if constexpr (ABL & 128) wring_dma16_nom0(l16, d_ruk, d_su + (unsigned)(u * 1024));
                 else if constexpr (ABL & 256) wring_m0_only(d_base + (unsigned)(WR_U_OFF + u * 1024));
-                else wring_dma16(d_base + (unsigned)(WR_U_OFF + u * 1024), v, rsrc_u, d_su + (unsigned)(u * 1024));
+                else wring_dma16(d_base + (unsigned)(WR_U_OFF + u * 1024), l16, d_ruk, d_su + (unsigned)(u * 1024));
             }
         }
     };
