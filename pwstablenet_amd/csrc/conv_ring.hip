@@ -412,26 +412,57 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
         if constexpr (C::MODE == RM_K3S2) tapmask = (cplane >> 1) ? ((cplane & 1) ? 0xfu : 0x5u) : ((cplane & 1) ? 0x3u : 0x1u);
         const unsigned gb = (unsigned)(cbuf * C::GROUP_BYTES);
         if (!(p.ablate & 2)) {
+            if constexpr (C::MODE != RM_K3S1) {
+                // sub-pixel / stride-2 kinds take 1, 2 or 4 of the taps by class / plane (wave-uniform mask); the k4s2 kinds measured
+                // 1-2 % slower with the pipelined loop below: plain loop
 #pragma unroll
-            for (int tap = 0; tap < C::TAPS; ++tap) {
-                if constexpr (C::MODE == RM_SP3 || C::MODE == RM_K3S2) {
-                    if (!((tapmask >> tap) & 1u)) continue;   // wave-uniform: 1, 2 or 4 taps per class / plane
+                for (int tap = 0; tap < C::TAPS; ++tap) {
+                    if (!((tapmask >> tap) & 1u)) continue;
+                    const int ty = tap / C::KS, tx = tap % C::KS;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        bf16x8 av[2], bv[2];
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+                            av[mt] = *reinterpret_cast<const bf16x8 *>(lds + gb + (unsigned)((a_off[mt][tx] ^ (ks * 32)) + ty * C::IW * C::ROWB));
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            bv[nt] = *reinterpret_cast<const bf16x8 *>(lds + gb + (unsigned)((b_off ^ (ks * 32)) + (tap * 64 + nt * 32) * C::ROWB));
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+                    }
                 }
-                const int ty = tap / C::KS, tx = tap % C::KS;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    bf16x8 av[2], bv[2];
+            } else {
+                // 3x3 stride 1 (+4 to +7 % measured): the operands of step (tap, ks) + 2 are requested before the four matrix instructions of step (tap, ks) are
+                // issued, fenced by sched_barrier -- left to itself hipcc sinks every ds_read_b128 to its first use and waits for it
+                // there (49 s_waitcnt for 72 matrix instructions: every group of four paid an LDS round trip)
+                constexpr int NS = C::TAPS * 2, PD = (DG && C::MODE == RM_K3S1) ? 1 : 2;   // the dgrad epilogue needs the registers
+                bf16x8 av[PD + 1][2], bv[PD + 1][2];
+                auto rd = [&](int slot, int st) {
+                    const int tap = st >> 1, ks = st & 1, ty = tap / C::KS, tx = tap % C::KS;
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
-                        av[mt] = *reinterpret_cast<const bf16x8 *>(lds + gb + (unsigned)((a_off[mt][tx] ^ (ks * 32)) + ty * C::IW * C::ROWB));
+                        av[slot][mt] = *reinterpret_cast<const bf16x8 *>(lds + gb + (unsigned)((a_off[mt][tx] ^ (ks * 32)) + ty * C::IW * C::ROWB));
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
-                        bv[nt] = *reinterpret_cast<const bf16x8 *>(lds + gb + (unsigned)((b_off ^ (ks * 32)) + (tap * 64 + nt * 32) * C::ROWB));
+                        bv[slot][nt] = *reinterpret_cast<const bf16x8 *>(lds + gb + (unsigned)((b_off ^ (ks * 32)) + (tap * 64 + nt * 32) * C::ROWB));
+                };
+#pragma unroll
+                for (int st = 0; st < PD; ++st) rd(st, st);
+#pragma unroll
+                for (int st = 0; st < NS; ++st) {
+                    if (st + PD < NS) rd((st + PD) % (PD + 1), st + PD);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int cur = st % (PD + 1);
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][mt], bv[cur][nt], acc[mt][nt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }

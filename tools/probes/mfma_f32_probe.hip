@@ -8,6 +8,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int NA, int V, int WAVES, int PK = 0, int SA = 0>
 __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) k(float *out, int iters) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[32768];
+    if (SA >= 2) { for (int i = threadIdx.x; i < 8192; i += WAVES * 64) ((float *)lds)[i] = 1.f; __syncthreads(); }
     f32x4 acc[NA];
     for (int a = 0; a < NA; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float x = (float)threadIdx.x, y = 1.0f + (float)(threadIdx.x & 3), z = 0.f;
@@ -25,7 +27,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4) k(float *out, int iters
                     if (PK) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(zz) : "v"(yy));
                     else asm volatile("v_add_f32 %0, %0, %1" : "+v"(z) : "v"(y));
                 }
-                if (SA) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc));
+                if (SA == 1) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc));
+                if (SA == 2) { if ((a & 1) == 0) { f32x4 t = *reinterpret_cast<const f32x4 *>(lds + ((threadIdx.x * 16 + r * 1024) & 32767)); asm volatile("" :: "v"(t)); } }   // 1 ds_read_b128 per 2 MFMAs
+                if (SA == 3) { f32x4 t = *reinterpret_cast<const f32x4 *>(lds + ((threadIdx.x * 16 + r * 1024) & 32767)); asm volatile("" :: "v"(t)); }   // 1 per MFMA
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -69,6 +73,8 @@ int main() {
     run<2, 2, 8, 1>("8 waves, 2 acc, 2 v_pk_add_f32 per MFMA");
     run<2, 0, 8, 0, 1>("8 waves, 2 acc, 1 SALU per MFMA");
     run<2, 4, 8>("8 waves, 2 acc, 4 VALU per MFMA");
+    run<2, 0, 8, 0, 2>("8 waves, 2 acc, 1 ds_read_b128 per 2 MFMAs");
+    run<2, 0, 8, 0, 3>("8 waves, 2 acc, 1 ds_read_b128 per MFMA");
     run<2, 1, 4>("4 waves, 2 acc, 1 VALU per MFMA");
     run<2, 2, 4>("4 waves, 2 acc, 2 VALU per MFMA");
     return 0;
