@@ -176,10 +176,14 @@ __device__ __forceinline__ void st4(float *base, size_t idx, const float4 &v) {
     }
 }
 
+// Branch-free on purpose: with `act` a kernel argument hipcc turned the three-way if into scalar compares and branches PER VALUE
+// (s_cmp / s_cbranch x 3 around every element of an epilogue: the bf16 ring kernel's epilogue took 8 400 cycles per unit).  Same
+// results as the if chain for every input (NaN and -inf included): mul, and, cmp, cndmask.
 __device__ __forceinline__ float act_apply(float v, int act) {
-    if (act == PWS_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
-    if (act == PWS_ACT_RELU) return v > 0.f ? v : 0.f;
-    return v;
+    const float slope = act == PWS_ACT_LRELU ? 0.2f : 1.f;
+    const unsigned keep = act == PWS_ACT_RELU ? 0u : 0xffffffffu;
+    const float t = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, slope * v) & keep);
+    return v > 0.f ? v : t;
 }
 
 }  // namespace pws

@@ -119,6 +119,8 @@ __device__ __forceinline__ void ring_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+__device__ const u32x4 g_ring_zero16 = {0u, 0u, 0u, 0u};   // what the epilogue's loads read in place of an absent tensor
+
 constexpr unsigned kRingOob = 0x7ffffff0u;   // voffset no descriptor of this kernel reaches (num_records < 2^31)
 
 // wave-uniform values the compiler cannot prove uniform (an "s" asm operand needs the proof): through v_readfirstlane
@@ -333,12 +335,18 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
     u32x4 e_old[DG ? 8 : 1], e_y[DG ? 8 : 1];
     unsigned char *e_dbase = nullptr;
     const unsigned char *e_ybase = nullptr;
-    size_t e_dld2 = 0, e_yld2 = 0;   // pixel strides in bytes
+    unsigned e_dld2 = 0, e_yld2 = 0;   // pixel strides in bytes
     bool e_hasy = false, e_dacc = false;
     float e_slope = 1.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) bsv[k] = 0.f;
 
+    // The epilogue's loads are unconditional in control flow (a lane without the tensor reads 16 zero bytes instead): a load inside
+    // an if leaves a control-flow merge behind, and hipcc waits vmcnt(0) at the first use
+    // after every merge -- which serialised the rolling requests and the stores of the data-gradient epilogue.
+    auto e_load = [&](const unsigned char *ptr, bool have) {
+        return *reinterpret_cast<const u32x4 *>(have ? ptr : reinterpret_cast<const unsigned char *>(&g_ring_zero16));
+    };
     constexpr int SO = C::NCLS == 4 ? 2 : 1;   // output stride of the parity classes
     unsigned cu = u_begin;
     int cg = 0, cplane = 0, cgp = 0, cbuf = 0;
@@ -376,7 +384,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
                         dld = p.dst_ld[s_], e_dacc = p.dst_acc[s_] != 0, dok = true;
                         if (p.dst_act[s_] != PWS_ACT_NONE) {
                             e_ybase = reinterpret_cast<const unsigned char *>(static_cast<const __bf16 *>(p.dst_y[s_]) + (co - p.dst_c0[s_]));
-                            e_yld2 = (size_t)p.dst_y_ld[s_] * 2, e_slope = p.dst_act[s_] == PWS_ACT_LRELU ? 0.2f : 0.f;
+                            e_yld2 = (unsigned)p.dst_y_ld[s_] * 2u, e_slope = p.dst_act[s_] == PWS_ACT_LRELU ? 0.2f : 0.f;
                         }
                     }
                 }
@@ -385,16 +393,15 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
                 for (int k = 0; k < 8; ++k) bsv[k] = (p.bias && co_ok) ? p.bias[co + k] : 0.f;
             }
             e_dbase = reinterpret_cast<unsigned char *>(dbase);
-            e_dld2 = dld * 2;
+            e_dld2 = (unsigned)dld * 2u;
             e_hasy = e_ybase != nullptr;
             e_ok1 = dok;
             if constexpr (DG) {
 #pragma unroll
                 for (int slot = 0; slot < PF; ++slot) {
                     const unsigned pix = e_pix(slot);
-                    e_old[slot] = (u32x4){0u, 0u, 0u, 0u}, e_y[slot] = (u32x4){0u, 0u, 0u, 0u};
-                    if (e_ok1 && e_dacc) e_old[slot] = *reinterpret_cast<const u32x4 *>(e_dbase + pix * e_dld2);
-                    if (e_ok1 && e_hasy) e_y[slot] = *reinterpret_cast<const u32x4 *>(e_ybase + pix * e_yld2);
+                    e_old[slot] = e_load(e_dbase + (size_t)pix * e_dld2, e_ok1 && e_dacc);
+                    e_y[slot] = e_load(e_ybase + (size_t)pix * e_yld2, e_ok1 && e_hasy);
                 }
             }
         }
@@ -439,7 +446,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
                 // 3x3 stride 1 (+4 to +7 % measured): the operands of step (tap, ks) + 2 are requested before the four matrix instructions of step (tap, ks) are
                 // issued, fenced by sched_barrier -- left to itself hipcc sinks every ds_read_b128 to its first use and waits for it
                 // there (49 s_waitcnt for 72 matrix instructions: every group of four paid an LDS round trip)
-                constexpr int NS = C::TAPS * 2, PD = (DG && C::MODE == RM_K3S1) ? 1 : 2;   // the dgrad epilogue needs the registers
+                constexpr int NS = C::TAPS * 2, PD = DG ? 1 : 2;   // the data-gradient epilogue needs the registers
                 bf16x8 av[PD + 1][2], bv[PD + 1][2];
                 auto rd = [&](int slot, int st) {
                     const int tap = st >> 1, ks = st & 1, ty = tap / C::KS, tx = tap % C::KS;
@@ -476,6 +483,10 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
             __builtin_amdgcn_s_barrier();   // E
             asm volatile("" ::: "memory");
             if (!(p.ablate & 4)) {
+                if constexpr (!DG) {   // the one wait for the bias values, on a path every lane takes
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(bsv[k]));
+                }
                 unsigned char *et = lds + gb + wv * 4096;
                 const int wslot = ((l31 >> 1) & 1) * 8 + (l31 >> 2);
 #pragma unroll
@@ -498,37 +509,39 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
                                 const int nx2 = slot + PF;
                                 if (nx2 < 8) {
                                     const unsigned pix2 = e_pix(nx2);
-                                    e_old[nx2] = (u32x4){0u, 0u, 0u, 0u}, e_y[nx2] = (u32x4){0u, 0u, 0u, 0u};
-                                    if (e_ok1 && e_dacc) e_old[nx2] = *reinterpret_cast<const u32x4 *>(e_dbase + pix2 * e_dld2);
-                                    if (e_ok1 && e_hasy) e_y[nx2] = *reinterpret_cast<const u32x4 *>(e_ybase + pix2 * e_yld2);
+                                    e_old[nx2] = e_load(e_dbase + (size_t)pix2 * e_dld2, e_ok1 && e_dacc);
+                                    e_y[nx2] = e_load(e_ybase + (size_t)pix2 * e_yld2, e_ok1 && e_hasy);
                                 }
                             }
                             const int row = itr * 8 + (lane >> 3);
                             const int sw = (row & 1) * 8;
                             const float4 lo = *reinterpret_cast<const float4 *>(et + row * 256 + ((g8 ^ sw) * 16));
                             const float4 hi4 = *reinterpret_cast<const float4 *>(et + row * 256 + (((8 + g8) ^ sw) * 16));
-                            if (e_ok1) {
-                                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
-                                if constexpr (!DG) {
+                            // straight-line on purpose: only the store itself is predicated (a block that short gets no skip
+                            // branch), so hipcc counts the outstanding stores exactly instead of waiting vmcnt(0) at every
+                            // control-flow merge -- which made each of the four passes wait for the previous pass's stores to be
+                            // acknowledged (3.5 us per unit)
+                            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+                            if constexpr (!DG) {
 #pragma unroll
-                                    for (int k = 0; k < 8; ++k) v[k] = act_apply(v[k] + bsv[k], p.act);
-                                } else {
-                                    const u32x4 o = e_old[slot];   // zeros when this destination is overwritten
-                                    v[0] += bf16_lo(o.x), v[1] += bf16_hi(o.x), v[2] += bf16_lo(o.y), v[3] += bf16_hi(o.y);
-                                    v[4] += bf16_lo(o.z), v[5] += bf16_hi(o.z), v[6] += bf16_lo(o.w), v[7] += bf16_hi(o.w);
-                                    if (e_hasy) {   // act'(y) of the tensor this destination is the gradient of
-                                        const u32x4 yv = e_y[slot];
-                                        v[0] *= bf16_lo(yv.x) > 0.f ? 1.f : e_slope, v[1] *= bf16_hi(yv.x) > 0.f ? 1.f : e_slope;
-                                        v[2] *= bf16_lo(yv.y) > 0.f ? 1.f : e_slope, v[3] *= bf16_hi(yv.y) > 0.f ? 1.f : e_slope;
-                                        v[4] *= bf16_lo(yv.z) > 0.f ? 1.f : e_slope, v[5] *= bf16_hi(yv.z) > 0.f ? 1.f : e_slope;
-                                        v[6] *= bf16_lo(yv.w) > 0.f ? 1.f : e_slope, v[7] *= bf16_hi(yv.w) > 0.f ? 1.f : e_slope;
-                                    }
-                                }
-                                u32x4 wq;
-                                wq.x = cvt_pk_bf16(v[0], v[1]), wq.y = cvt_pk_bf16(v[2], v[3]);
-                                wq.z = cvt_pk_bf16(v[4], v[5]), wq.w = cvt_pk_bf16(v[6], v[7]);
-                                *reinterpret_cast<u32x4 *>(e_dbase + e_pix(slot) * e_dld2) = wq;
+                                for (int k = 0; k < 8; ++k) v[k] = act_apply(v[k] + bsv[k], p.act);
+                            } else {
+                                const u32x4 o = e_old[slot];   // zeros when this destination is overwritten
+                                v[0] += bf16_lo(o.x), v[1] += bf16_hi(o.x), v[2] += bf16_lo(o.y), v[3] += bf16_hi(o.y);
+                                v[4] += bf16_lo(o.z), v[5] += bf16_hi(o.z), v[6] += bf16_lo(o.w), v[7] += bf16_hi(o.w);
+                                // act'(y) of the tensor this destination is the gradient of (no such tensor: e_slope == 1)
+                                const u32x4 yv = e_y[slot];
+                                v[0] *= bf16_lo(yv.x) > 0.f ? 1.f : e_slope, v[1] *= bf16_hi(yv.x) > 0.f ? 1.f : e_slope;
+                                v[2] *= bf16_lo(yv.y) > 0.f ? 1.f : e_slope, v[3] *= bf16_hi(yv.y) > 0.f ? 1.f : e_slope;
+                                v[4] *= bf16_lo(yv.z) > 0.f ? 1.f : e_slope, v[5] *= bf16_hi(yv.z) > 0.f ? 1.f : e_slope;
+                                v[6] *= bf16_lo(yv.w) > 0.f ? 1.f : e_slope, v[7] *= bf16_hi(yv.w) > 0.f ? 1.f : e_slope;
                             }
+                            u32x4 wq;
+                            wq.x = cvt_pk_bf16(v[0], v[1]), wq.y = cvt_pk_bf16(v[2], v[3]);
+                            wq.z = cvt_pk_bf16(v[4], v[5]), wq.w = cvt_pk_bf16(v[6], v[7]);
+                            unsigned char *dptr = e_dbase + (size_t)e_pix(slot) * e_dld2;
+                            asm volatile("" ::"v"(wq.x), "v"(wq.y), "v"(wq.z), "v"(wq.w), "v"(dptr));   // nothing sinks into the if
+                            if (e_ok1) *reinterpret_cast<u32x4 *>(dptr) = wq;
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
