@@ -177,13 +177,17 @@ __device__ __forceinline__ void st4(float *base, size_t idx, const float4 &v) {
 }
 
 // Branch-free on purpose: with `act` a kernel argument hipcc turned the three-way if into scalar compares and branches PER VALUE
-// (s_cmp / s_cbranch x 3 around every element of an epilogue: the bf16 ring kernel's epilogue took 8 400 cycles per unit).  Same
-// results as the if chain for every input (NaN and -inf included): mul, and, cmp, cndmask.
+// (s_cmp / s_cbranch x 3 around every element of an epilogue).  Same results as
+//     LRELU: v > 0 ? v : 0.2 v      RELU: v > 0 ? v : 0      NONE: v
+// for every input, NaN and infinities included, in three instructions (mul, and, max) with no VCC round trip:
+// max(v, t) with t = 0.2 v / +0 / v picks v for v > 0 and t otherwise (0.2 v > v for v < 0), and a NaN v gives NaN, 0, NaN.
 __device__ __forceinline__ float act_apply(float v, int act) {
     const float slope = act == PWS_ACT_LRELU ? 0.2f : 1.f;
     const unsigned keep = act == PWS_ACT_RELU ? 0u : 0xffffffffu;
     const float t = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, slope * v) & keep);
-    return v > 0.f ? v : t;
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(t));   // the builtin would canonicalise t first (one more instruction)
+    return r;
 }
 
 }  // namespace pws

@@ -29,6 +29,7 @@
 //     no 4x larger halo per matrix instruction, no strided (bank-conflicted) operand reads.
 // Arithmetic is that of conv_bf16_kernel: bf16 x bf16 products exact in fp32, fp32 accumulation (v_mfma_f32_32x32x16_bf16), the
 // K order differs (plane-major for the stride-2 kinds), one rounding to bf16 in the epilogue.
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -65,6 +66,10 @@ struct RingParams {
     int tiles_x, tiles_y, tn;   // tn: samples per tile
     unsigned ncob, ncls, nunits;
     int gpp;              // K groups per plane = sum(src_c) / 32
+#ifdef PWS_RING_TIMERS
+    unsigned long long *timers;   // [workgroup][matrix wave][8]
+#endif
+    int stagger;          // workgroups delay their start by (slot % 4) * stagger ticks of 10 ns (see conv_ring_try)
     int ablate;           // measurement only (PWS_OPT_EXPERIMENT 41..43): 1 = the DMA pieces fetch nothing after the first groups,
                           // 2 = no matrix phase, 4 = no epilogue -- results are meaningless, only the timing is read
 };
@@ -93,11 +98,20 @@ struct RgCfg {
     static constexpr int NL = (IN_WI + W_WI + LWAVES - 1) / LWAVES; // DMA instructions per loader wave and group
     static constexpr int GROUP_BYTES = NL * LWAVES * 1024;
     static constexpr int W_OFF = IN_WI * 1024;
-    static constexpr int LDS_BYTES = R * GROUP_BYTES;
+    static constexpr int LDS_RING_BYTES = R * GROUP_BYTES;
+    // the layer's bias vector (conv_ring_try: cout <= BIAS_FLOATS) sits behind the ring -- or, where the ring fills the LDS (the
+    // 3x3 kind on 16-wide maps: 2 x 80 KB), in the filler tail of the last ring buffer, which a ring of depth 2 need not write
+    // (its waits are vmcnt(0): no piece count to keep constant)
+    static constexpr int FILL_BYTES = (NL * LWAVES - IN_WI - W_WI) * 1024;
+    static constexpr bool BIAS_IN_FILL = LDS_RING_BYTES + 4096 > 160 * 1024;
+    static constexpr int BIAS_FLOATS = BIAS_IN_FILL ? 512 : 1024;
+    static constexpr int BIAS_OFF = BIAS_IN_FILL ? LDS_RING_BYTES - BIAS_FLOATS * 4 : LDS_RING_BYTES;
+    static constexpr int LDS_BYTES = BIAS_IN_FILL ? LDS_RING_BYTES : LDS_RING_BYTES + BIAS_FLOATS * 4;
+    static constexpr bool SKIP_FILL = R == 2;
+    static_assert(!BIAS_IN_FILL || (SKIP_FILL && FILL_BYTES >= BIAS_FLOATS * 4), "bias slot");
     // the `it` whose 4 wave-instructions hold input pieces on the first loader waves and weight pieces on the others (-1: none)
     static constexpr int MIX_IT = IN_WI % LWAVES == 0 ? -1 : IN_WI / LWAVES;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-    static_assert(GROUP_BYTES >= MWAVES * 4096, "the epilogue's transposition tiles live in the group buffer just consumed");
     static_assert(R >= 2 && R <= 4, "ring depth");
     static_assert((R - 2) * NL <= 63, "vmcnt is 6 bits");
 };
@@ -173,11 +187,10 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
     const int ngroups = C::NPLANES * p.gpp;   // K groups of one unit
     const unsigned total = my_units * (unsigned)ngroups;
 
-    // Both roles walk the same sequence of groups s = 0 .. total - 1 and meet at the same barriers:
+    // Both roles walk the same sequence of groups s = 0 .. total - 1 and meet at one barrier per group:
     //   B_s : group s has landed in buffer s % R (every loader waited for its own pieces first) and every matrix wave is done
-    //         reading group s - 1, whose buffer the loaders now refill with group s + R - 1;
-    //   E   : (last group of a unit only) every matrix wave is done with the operands of that group, whose buffer the matrix
-    //         waves then use for the epilogue's transposition tiles.
+    //         reading group s - 1, whose buffer the loaders now refill with group s + R - 1.
+    // The epilogue of a unit uses no LDS (it stores straight from the accumulators), so nothing else needs ordering.
     if (wv >= C::MWAVES) {
         // =========================================================================================== loader waves
         const int lw = wv - C::MWAVES;
@@ -199,8 +212,18 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
                 const int jj = j - C::IN_WI * 64;
                 const int row = jj / C::SPP, sp = jj % C::SPP;
                 const int t = row >> 6, rr = row & 63;
-                const int nn = (rr & 31) * 2 + (rr >> 5);   // LDS row rr holds output channel nn: a lane's two 32-channel blocks
-                                                            // are the channel pair (2 l, 2 l + 1) -> 16-byte epilogue stores
+                // LDS row rr = nt * 32 + i feeds row i of matrix tile nt, whose results land in register r = 4 (i / 8) + i % 4 of
+                // lane half (i / 4) % 2 (v_mfma_f32_32x32x16 result layout).  Row rr holds output channel
+                // 16 q + 8 * half + r % 8 with q = 2 nt + r / 8, so that a lane ends up with four groups of 8 consecutive channels of its
+                // pixel in acc[mt][0..1][0..15] and the epilogue stores straight from the accumulators (16-byte stores, no
+                // transposition through LDS)
+                const int ri = rr & 31;
+                const int rreg = (ri >> 3) * 4 + (ri & 3), rhalf = (ri >> 2) & 1, rnt = rr >> 5;
+                // 8-channel groups alternate between the lane halves (channel = 16 q + 8 half + k, q = 2 nt + r / 8), so that the
+                // two halves' 16-byte stores of one instruction form whole 32-byte sectors (halves holding 32 consecutive
+                // channels each, i.e. two half-written sectors per pixel and instruction, measured 8 % slower on the 64 -> 64
+                // layer at 256 x 256)
+                const int nn = (rnt * 2 + (rreg >> 3)) * 16 + rhalf * 8 + (rreg & 7);
                 ia[it] = t;
                 ib[it] = nn * p.kpad * 2 + (sp ^ ((rr >> 2) & 3)) * 16;
             } else {
@@ -227,6 +250,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
                     }
                 }
                 // past the last group: filler pieces keep every loader's DMA count per group constant (the counted waits)
+                if constexpr (C::SKIP_FILL) return;
 #pragma unroll
                 for (int it = 0; it < C::NL; ++it) ring_dma16(d_base + (unsigned)(it * C::LWAVES * 1024), kRingOob, rsrc_w, 0u);
                 return;
@@ -276,6 +300,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
                     v_w = ok ? (unsigned)wt * wplane + (unsigned)ib[it] : kRingOob;
                 }
                 const unsigned dst = d_base + (unsigned)(it * C::LWAVES * 1024);
+                if (C::SKIP_FILL && it * C::LWAVES + lw >= C::IN_WI + C::W_WI) continue;   // filler (wave-uniform)
                 if (in_ct) ring_dma16(dst, v_in, d_rin, d_sin);
                 else if (w_ct) ring_dma16(dst, v_w, rsrc_w, d_sw);
                 else ring_dma16(dst, mix_in ? v_in : v_w, d_rmix, d_smix);
@@ -295,15 +320,10 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
         };
 #pragma unroll
         for (int i = 0; i < C::R - 1; ++i) stage();
-        int cg = 0;
         for (unsigned s = 0; s < total; ++s) {
             ring_wait_vmcnt<(C::R - 2) * C::NL>();   // this wave's pieces of group s have landed (R > 2: younger groups may still fly)
             __builtin_amdgcn_s_barrier();            // B_s
             stage();                                 // group s + R - 1 into the buffer group s - 1 occupied
-            if (++cg == ngroups) {
-                cg = 0;
-                __builtin_amdgcn_s_barrier();        // E
-            }
         }
         ring_wait_vmcnt<0>();   // the filler pieces still target this workgroup's LDS
         return;
@@ -326,20 +346,25 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
 
     f32x16 acc[2][2];
 
-    // epilogue state, requested one matrix phase ahead (see the loop)
-    constexpr int PF = DG ? 1 : 0;   // store slots whose old value / forward value are requested a phase ahead; the others follow two
-                                     // slots ahead of their use inside the epilogue (8 slots x 8 registers do not fit beside the accumulators)
-    const int g8 = lane & 7;
-    float bsv[8];
-    bool e_ok1 = false;           // this lane's channel group has a destination (tiles are whole: conv_ring_try)
-    u32x4 e_old[DG ? 8 : 1], e_y[DG ? 8 : 1];
-    unsigned char *e_dbase = nullptr;
-    const unsigned char *e_ybase = nullptr;
-    unsigned e_dld2 = 0, e_yld2 = 0;   // pixel strides in bytes
-    bool e_hasy = false, e_dacc = false;
-    float e_slope = 1.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) bsv[k] = 0.f;
+    // epilogue state.  The matrix instructions run transposed (weights as the A operand, pixels as B): lane (l31, hi) holds, for
+    // each of its two pixels (mt), the 32 channels co0 + 32 hi + [0, 32) in acc[mt][0..1][0..15] -- four 16-byte stores per pixel
+    // straight from the registers.  (First version: pixels as A, a [16 pixel][64 channel] fp32 round trip through LDS per wave and
+    // pass to get 8 consecutive channels per lane; tools/ring_timers.py: that epilogue took 3.5 us per unit = 22-36 % of the
+    // launch, bound by its ~700 vector instructions per wave and the LDS round trips, plus a workgroup barrier to free the LDS
+    // it used.)
+    constexpr int PF = 1;          // data-gradient: store slots whose old value / forward value are requested ahead of their use
+    constexpr int NSLOT = 8;       // slot = mt * 4 + q: pixel mt, 8-channel group q of the lane's 32 channels
+    // destination of the unit's two 32-channel blocks (block b = channels co0 + 32 b + [0, 32) = store slots q = 2 b, 2 b + 1;
+    // data gradient: a block lies in ONE source of the forward layer, sources being multiples of 32 channels): pointers already
+    // at this lane's first group (+ 8 hi channels)
+    struct EpiBlock {
+        unsigned char *d;
+        const unsigned char *y;
+        unsigned dld2, yld2;   // pixel strides in bytes
+        bool ok, acc, hasy;
+        float slope;
+    } eb[2] = {};
+    u32x4 e_old[DG ? NSLOT : 1], e_y[DG ? NSLOT : 1];
 
     // The epilogue's loads are unconditional in control flow (a lane without the tensor reads 16 zero bytes instead): a load inside
     // an if leaves a control-flow merge behind, and hipcc waits vmcnt(0) at the first use
@@ -351,57 +376,78 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
     unsigned cu = u_begin;
     int cg = 0, cplane = 0, cgp = 0, cbuf = 0;
     RingUnit CU = ring_unit(p, cu);
-    // output pixel index of store slot (mt, h2, itr): tile pixel m = (2 wv + mt) * 32 + 16 h2 + 8 itr + lane / 8 of unit CU
-    auto e_pix = [&](int slot) {   // slot = (mt * 2 + h2) * 2 + itr, compile-time after unrolling
-        const int m = (wv * 2 + (slot >> 2)) * 32 + ((slot >> 1) & 1) * 16 + (slot & 1) * 8 + (lane >> 3);
+    // output pixel index of this lane's pixel mt of unit CU: tile pixel m = (2 wv + mt) * 32 + l31
+    auto e_pix = [&](int mt) {
+        const int m = (wv * 2 + mt) * 32 + l31;
         const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
         const int y = CU.y0 * C::TH + ty, x = CU.x0 * C::TW + tx;
         const int oy = SO * y + (C::NCLS == 4 ? CU.py : 0), ox = SO * x + (C::NCLS == 4 ? CU.px : 0);
         return (unsigned)(((CU.n0 + tn) * p.OH + oy) * p.OW + ox);
     };
+    // the bias vector lives in LDS behind the ring, staged once: a lane needs 32 different values per unit.  Every matrix wave
+    // sees it after the first barrier B of the loop.
+    const float *const lds_bias = reinterpret_cast<const float *>(lds + C::BIAS_OFF);
+    if constexpr (!DG) {
+        float *wb = reinterpret_cast<float *>(lds + C::BIAS_OFF);
+        for (int c = tid; c < C::BIAS_FLOATS; c += C::MWAVES * 64) wb[c] = (p.bias && c < p.cout) ? p.bias[c] : 0.f;
+    }
 
+#ifdef PWS_RING_TIMERS   // diagnostic build (tools/ring_timers.sh): where a matrix wave's time goes, in s_memrealtime ticks (10 ns)
+    unsigned long long t_wait = 0, t_mat = 0, t_epi = 0, t_pre = 0;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+#define PWS_RT() __builtin_amdgcn_s_memrealtime()
+#endif
+    if (p.stagger > 0) {
+        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)((slot & 3u) * (unsigned)p.stagger);
+        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
+    }
     for (unsigned s = 0; s < total; ++s) {
+#ifdef PWS_RING_TIMERS
+        const unsigned long long t0 = PWS_RT();
+#endif
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();   // B_s
         asm volatile("" ::: "memory");
+#ifdef PWS_RING_TIMERS
+        const unsigned long long t1 = PWS_RT();
+        t_wait += t1 - t0;
+#endif
 
         const bool last_group = cg == ngroups - 1;
         if (last_group) {
-            // ---- what the epilogue needs from memory (bias; or the old gradient values and the forward tensor for act'), requested
-            // ONE matrix phase ahead of its use
-            const int co = CU.co0 + g8 * 8;
-            const bool co_ok = co < p.cout;
-            __bf16 *dbase = reinterpret_cast<__bf16 *>(p.out) + co;
-            size_t dld = p.out_ld;
-            bool dok = co_ok;
-            e_ybase = nullptr, e_yld2 = 0, e_dacc = false, e_slope = 1.f;
-            if constexpr (DG) {
-                dok = false;
+            // ---- where this unit's channels go; data gradient: the old gradient values and the forward tensor (for act') of the
+            // first store slot are requested ONE matrix phase ahead of their use
 #pragma unroll
-                for (int s_ = 0; s_ < 4; ++s_) {
-                    if (s_ < p.ndst && co >= p.dst_c0[s_] && co < p.dst_c1[s_]) {
-                        dbase = reinterpret_cast<__bf16 *>(p.dst_ptr[s_]) + (co - p.dst_c0[s_]);
-                        dld = p.dst_ld[s_], e_dacc = p.dst_acc[s_] != 0, dok = true;
-                        if (p.dst_act[s_] != PWS_ACT_NONE) {
-                            e_ybase = reinterpret_cast<const unsigned char *>(static_cast<const __bf16 *>(p.dst_y[s_]) + (co - p.dst_c0[s_]));
-                            e_yld2 = (unsigned)p.dst_y_ld[s_] * 2u, e_slope = p.dst_act[s_] == PWS_ACT_LRELU ? 0.2f : 0.f;
+            for (int b = 0; b < 2; ++b) {
+                const int co = CU.co0 + 32 * b;
+                EpiBlock e{};
+                e.slope = 1.f;
+                if constexpr (!DG) {
+                    e.d = reinterpret_cast<unsigned char *>(reinterpret_cast<__bf16 *>(p.out) + co + hi * 8);
+                    e.dld2 = (unsigned)p.out_ld * 2u, e.ok = co < p.cout;
+                } else {
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) {
+                        if (s_ < p.ndst && co >= p.dst_c0[s_] && co < p.dst_c1[s_]) {
+                            e.d = reinterpret_cast<unsigned char *>(reinterpret_cast<__bf16 *>(p.dst_ptr[s_]) + (co - p.dst_c0[s_]) + hi * 8);
+                            e.dld2 = (unsigned)p.dst_ld[s_] * 2u, e.acc = p.dst_acc[s_] != 0, e.ok = true;
+                            if (p.dst_act[s_] != PWS_ACT_NONE) {
+                                e.y = reinterpret_cast<const unsigned char *>(static_cast<const __bf16 *>(p.dst_y[s_]) + (co - p.dst_c0[s_]) + hi * 8);
+                                e.yld2 = (unsigned)p.dst_y_ld[s_] * 2u, e.slope = p.dst_act[s_] == PWS_ACT_LRELU ? 0.2f : 0.f;
+                                e.hasy = true;
+                            }
                         }
                     }
                 }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) bsv[k] = (p.bias && co_ok) ? p.bias[co + k] : 0.f;
+                eb[b] = e;
             }
-            e_dbase = reinterpret_cast<unsigned char *>(dbase);
-            e_dld2 = (unsigned)dld * 2u;
-            e_hasy = e_ybase != nullptr;
-            e_ok1 = dok;
             if constexpr (DG) {
 #pragma unroll
                 for (int slot = 0; slot < PF; ++slot) {
-                    const unsigned pix = e_pix(slot);
-                    e_old[slot] = e_load(e_dbase + (size_t)pix * e_dld2, e_ok1 && e_dacc);
-                    e_y[slot] = e_load(e_ybase + (size_t)pix * e_yld2, e_ok1 && e_hasy);
+                    const unsigned pix = e_pix(slot >> 2);
+                    const EpiBlock &e = eb[(slot >> 1) & 1];
+                    e_old[slot] = e_load(e.d + (size_t)pix * e.dld2 + (slot & 1) * 32, e.ok && e.acc);
+                    e_y[slot] = e_load(e.y + (size_t)pix * e.yld2 + (slot & 1) * 32, e.ok && e.hasy);
                 }
             }
         }
@@ -414,6 +460,10 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
         }
+#ifdef PWS_RING_TIMERS
+        const unsigned long long t2 = PWS_RT();
+        t_pre += t2 - t1;
+#endif
         unsigned tapmask = (1u << C::TAPS) - 1u;
         if constexpr (C::MODE == RM_SP3) tapmask = CU.py ? (CU.px ? 0xfu : 0x5u) : (CU.px ? 0x3u : 0x1u);
         if constexpr (C::MODE == RM_K3S2) tapmask = (cplane >> 1) ? ((cplane & 1) ? 0xfu : 0x5u) : ((cplane & 1) ? 0x3u : 0x1u);
@@ -439,7 +489,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
                         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                             for (int nt = 0; nt < 2; ++nt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[nt], av[mt], acc[mt][nt], 0, 0, 0);
                     }
                 }
             } else {
@@ -468,94 +518,91 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
                     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][mt], bv[cur][nt], acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[cur][nt], av[cur][mt], acc[mt][nt], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
 
+#ifdef PWS_RING_TIMERS
+        asm volatile("s_nop 0" ::: "memory");
+        const unsigned long long t3 = PWS_RT();
+        t_mat += t3 - t2;
+#endif
         if (last_group) {
-            // ---- epilogue of unit cu.  Every wave turns its 2 x (32 pixels x 64 channels) round through LDS in 16-pixel passes
-            // (fp32, 4 KB per wave, inside the group buffer just consumed: barrier E retires everybody's operand reads; the loaders
-            // refill this buffer only behind the next B), so that bias / activation / accumulation work on 8 consecutive channels
-            // and leave as 16-byte stores (layout as PWS_BF_EPI16, conv_bf16.hip).
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_barrier();   // E
-            asm volatile("" ::: "memory");
+            // ---- epilogue of unit cu, straight from the accumulators: slot (mt, q) = channels co0 + 32 hi + 8 q + [0, 8) of pixel mt
+            // = acc[mt][q / 2][8 (q % 2) + k].  No LDS, no barrier: the waves run into the next unit's first group on their own.
             if (!(p.ablate & 4)) {
-                if constexpr (!DG) {   // the one wait for the bias values, on a path every lane takes
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(bsv[k]));
-                }
-                unsigned char *et = lds + gb + wv * 4096;
-                const int wslot = ((l31 >> 1) & 1) * 8 + (l31 >> 2);
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
+                    const unsigned pix = e_pix(mt);
 #pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2) {
-#pragma unroll
-                        for (int rr = 0; rr < 8; ++rr) {
-                            const int r = h2 * 8 + rr;
-                            const int row = (rr & 3) + 8 * (rr >> 2) + 4 * hi;   // 0..15 inside the pass
-                            *reinterpret_cast<float2 *>(et + row * 256 + ((wslot ^ ((rr & 1) * 8)) * 16) + (l31 & 1) * 8) =
-                                make_float2(acc[mt][0][r], acc[mt][1][r]);
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                        for (int itr = 0; itr < 2; ++itr) {
-                            const int slot = (mt * 2 + h2) * 2 + itr;
-                            if constexpr (DG) {   // rolling request, two slots ahead
-                                const int nx2 = slot + PF;
-                                if (nx2 < 8) {
-                                    const unsigned pix2 = e_pix(nx2);
-                                    e_old[nx2] = e_load(e_dbase + (size_t)pix2 * e_dld2, e_ok1 && e_dacc);
-                                    e_y[nx2] = e_load(e_ybase + (size_t)pix2 * e_yld2, e_ok1 && e_hasy);
-                                }
+                    for (int q = 0; q < 4; ++q) {
+                        const int slot = mt * 4 + q;
+                        const EpiBlock &e = eb[q >> 1];
+                        if constexpr (DG) {   // rolling request, PF slots ahead
+                            const int nx2 = slot + PF;
+                            if (nx2 < NSLOT) {
+                                const unsigned pix2 = e_pix(nx2 >> 2);
+                                const EpiBlock &e2 = eb[(nx2 >> 1) & 1];
+                                e_old[nx2] = e_load(e2.d + (size_t)pix2 * e2.dld2 + (nx2 & 1) * 32, e2.ok && e2.acc);
+                                e_y[nx2] = e_load(e2.y + (size_t)pix2 * e2.yld2 + (nx2 & 1) * 32, e2.ok && e2.hasy);
                             }
-                            const int row = itr * 8 + (lane >> 3);
-                            const int sw = (row & 1) * 8;
-                            const float4 lo = *reinterpret_cast<const float4 *>(et + row * 256 + ((g8 ^ sw) * 16));
-                            const float4 hi4 = *reinterpret_cast<const float4 *>(et + row * 256 + (((8 + g8) ^ sw) * 16));
-                            // straight-line on purpose: only the store itself is predicated (a block that short gets no skip
-                            // branch), so hipcc counts the outstanding stores exactly instead of waiting vmcnt(0) at every
-                            // control-flow merge -- which made each of the four passes wait for the previous pass's stores to be
-                            // acknowledged (3.5 us per unit)
-                            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
-                            if constexpr (!DG) {
-#pragma unroll
-                                for (int k = 0; k < 8; ++k) v[k] = act_apply(v[k] + bsv[k], p.act);
-                            } else {
-                                const u32x4 o = e_old[slot];   // zeros when this destination is overwritten
-                                v[0] += bf16_lo(o.x), v[1] += bf16_hi(o.x), v[2] += bf16_lo(o.y), v[3] += bf16_hi(o.y);
-                                v[4] += bf16_lo(o.z), v[5] += bf16_hi(o.z), v[6] += bf16_lo(o.w), v[7] += bf16_hi(o.w);
-                                // act'(y) of the tensor this destination is the gradient of (no such tensor: e_slope == 1)
-                                const u32x4 yv = e_y[slot];
-                                v[0] *= bf16_lo(yv.x) > 0.f ? 1.f : e_slope, v[1] *= bf16_hi(yv.x) > 0.f ? 1.f : e_slope;
-                                v[2] *= bf16_lo(yv.y) > 0.f ? 1.f : e_slope, v[3] *= bf16_hi(yv.y) > 0.f ? 1.f : e_slope;
-                                v[4] *= bf16_lo(yv.z) > 0.f ? 1.f : e_slope, v[5] *= bf16_hi(yv.z) > 0.f ? 1.f : e_slope;
-                                v[6] *= bf16_lo(yv.w) > 0.f ? 1.f : e_slope, v[7] *= bf16_hi(yv.w) > 0.f ? 1.f : e_slope;
-                            }
-                            u32x4 wq;
-                            wq.x = cvt_pk_bf16(v[0], v[1]), wq.y = cvt_pk_bf16(v[2], v[3]);
-                            wq.z = cvt_pk_bf16(v[4], v[5]), wq.w = cvt_pk_bf16(v[6], v[7]);
-                            unsigned char *dptr = e_dbase + (size_t)e_pix(slot) * e_dld2;
-                            asm volatile("" ::"v"(wq.x), "v"(wq.y), "v"(wq.z), "v"(wq.w), "v"(dptr));   // nothing sinks into the if
-                            if (e_ok1) *reinterpret_cast<u32x4 *>(dptr) = wq;
                         }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
+                        // straight-line on purpose: only the store itself is predicated (a block that short gets no skip branch), so
+                        // hipcc counts the outstanding loads and stores exactly instead of waiting vmcnt(0) at every control-flow merge
+                        float v[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = acc[mt][q >> 1][(q & 1) * 8 + k];
+                        if constexpr (!DG) {
+                            const float4 b0 = *reinterpret_cast<const float4 *>(lds_bias + CU.co0 + q * 16 + hi * 8);
+                            const float4 b1 = *reinterpret_cast<const float4 *>(lds_bias + CU.co0 + q * 16 + hi * 8 + 4);
+                            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) v[k] = act_apply(v[k] + bb[k], p.act);
+                        } else {
+                            const u32x4 o = e_old[slot];   // zeros when this destination is overwritten
+                            v[0] += bf16_lo(o.x), v[1] += bf16_hi(o.x), v[2] += bf16_lo(o.y), v[3] += bf16_hi(o.y);
+                            v[4] += bf16_lo(o.z), v[5] += bf16_hi(o.z), v[6] += bf16_lo(o.w), v[7] += bf16_hi(o.w);
+                            // act'(y) of the tensor this destination is the gradient of (no such tensor: slope == 1)
+                            const u32x4 yv = e_y[slot];
+                            const float sl = e.slope;
+                            v[0] *= bf16_lo(yv.x) > 0.f ? 1.f : sl, v[1] *= bf16_hi(yv.x) > 0.f ? 1.f : sl;
+                            v[2] *= bf16_lo(yv.y) > 0.f ? 1.f : sl, v[3] *= bf16_hi(yv.y) > 0.f ? 1.f : sl;
+                            v[4] *= bf16_lo(yv.z) > 0.f ? 1.f : sl, v[5] *= bf16_hi(yv.z) > 0.f ? 1.f : sl;
+                            v[6] *= bf16_lo(yv.w) > 0.f ? 1.f : sl, v[7] *= bf16_hi(yv.w) > 0.f ? 1.f : sl;
+                        }
+                        u32x4 wq;
+                        wq.x = cvt_pk_bf16(v[0], v[1]), wq.y = cvt_pk_bf16(v[2], v[3]);
+                        wq.z = cvt_pk_bf16(v[4], v[5]), wq.w = cvt_pk_bf16(v[6], v[7]);
+                        unsigned char *dptr = e.d + (size_t)pix * e.dld2 + (q & 1) * 32;
+                        asm volatile("" ::"v"(wq.x), "v"(wq.y), "v"(wq.z), "v"(wq.w), "v"(dptr));   // nothing sinks into the if
+                        const bool st_ok = DG ? e.ok : CU.co0 + q * 16 + hi * 8 < p.cout;   // (cout % 8 == 0: epi16)
+#if defined(PWS_RING_TIMERS) && PWS_RING_TIMERS == 2   // diagnostic: no stores
+                        if (st_ok && wq.x == 0x12345678u && wq.y == 0x9abcdef0u) *reinterpret_cast<u32x4 *>(dptr) = wq;
+#else
+                        if (st_ok) *reinterpret_cast<u32x4 *>(dptr) = wq;
+#endif
                     }
                 }
             }
             cg = 0, cplane = 0, cgp = 0, cu += u_step;
             if (cu < u_end) CU = ring_unit(p, cu);
+#ifdef PWS_RING_TIMERS
+            t_epi += PWS_RT() - t3;
+#endif
         } else {
             ++cg;
             if (++cgp == p.gpp) cgp = 0, ++cplane;
         }
         cbuf = cbuf + 1 == C::R ? 0 : cbuf + 1;
     }
+#ifdef PWS_RING_TIMERS
+    if (lane == 0 && p.timers) {
+        unsigned long long *t = p.timers + ((size_t)blockIdx.x * C::MWAVES + wv) * 8;
+        t[0] = t_wait, t[1] = t_pre, t[2] = t_mat, t[3] = t_epi, t[4] = PWS_RT() - t_begin, t[5] = total, t[6] = my_units;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -630,8 +677,16 @@ int conv_ring_try(int kind, bool dgrad, const ConvKParams &kp, hipStream_t st, c
     rp.w_bytes = (size_t)planes * kp.npad_bf * kp.kpad_bf * 2;
     if (rp.w_bytes >= (1u << 31)) return 1;
     rp.bias = kp.bias, rp.act = kp.act, rp.out = kp.out, rp.out_ld = kp.out_ld, rp.ndst = kp.ndst;
+#ifdef PWS_RING_TIMERS
+    {   // tools/ring_timers.py passes the buffer's address through the environment
+        const char *e = getenv("PWS_RING_TIMERS_PTR");
+        rp.timers = e ? reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 0)) : nullptr;
+    }
+#endif
+    rp.stagger = g_experiment >= 110 && g_experiment <= 129 ? (g_experiment - 110) * 50 : 0;
     rp.ablate = g_experiment >= 41 && g_experiment <= 47 ? g_experiment - 40 : 0;
     if (tw == 8 && mode == RM_K3S1) return 1;
+    if (kp.cout > (tw == 16 && mode == RM_K3S1 ? 512 : 1024)) return 1;   // the bias vector's LDS slot (RgCfg::BIAS_FLOATS)
     const long units = (long)kp.LW * kp.LH * kp.N / 512 * ((kp.cout + 63) / 64) * ((mode == RM_CT4 || mode == RM_SP3) ? 4 : 1);
     if (units < 192 && g_experiment != 21) return 1;   // too few units for 256 persistent workgroups: the split-K kernels do better
     ProfScope prof(KID_CONV_RING, pi.flops, pi.bytes, st);
