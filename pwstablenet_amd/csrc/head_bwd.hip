@@ -112,11 +112,13 @@ __global__ void __launch_bounds__(256) field_dx_kernel(const float *__restrict__
 }
 
 // bf16 storage: the same arithmetic (one lane per pixel, weights through the scalar unit), but the results of a workgroup's 256
-// pixels x 64 channels meet in LDS (fp32, rows of 64 + 4 floats: conflict-free both ways) and leave as 16-byte accesses that are
+// pixels x FDX_CH channels meet in LDS (fp32, rows of FDX_CH + 4 floats) and leave as 16-byte accesses that are
 // contiguous over the 8 lanes of a pixel -- with a lane per pixel the read-modify-write of dx was 64 separate 16-byte pieces 128
 // bytes apart per wave instruction.  dx_act: this call completes the gradient of x, itself the output of an activation: the
 // (accumulated) sum is multiplied by act'(x) (what pws_dst.act_y does in the data-gradient epilogues).
-constexpr int FDX_PITCH = 68;   // floats per pixel row of the LDS tile
+constexpr int FDX_CH = 32;               // channels per pass through the tile (64: 70 KB of LDS = 8 waves per CU, too few to hide the
+                                        // read-modify-write's latency; 32: 37 KB = 16 waves: 497 -> 340 us at 64 x 256 x 256; 16: half-line accesses, 500 us)
+constexpr int FDX_PITCH = FDX_CH + 4;   // floats per pixel row of the LDS tile
 __global__ void __launch_bounds__(256) field_dx16_kernel(const float *__restrict__ gz, const float *__restrict__ w_out, int N, int H,
                                                          int W, int C, __bf16 *__restrict__ dx, int dx_ld, int accumulate,
                                                          const __bf16 *__restrict__ xact, int x_ld, int dx_act) {
@@ -133,8 +135,8 @@ __global__ void __launch_bounds__(256) field_dx16_kernel(const float *__restrict
         const float2 v = *reinterpret_cast<const float2 *>(gz + (((size_t)n * H + (ok ? yy : 0)) * W + (ok ? xx : 0)) * 2);
         g[tap] = ok ? v : make_float2(0.f, 0.f);
     }
-    for (int cb = 0; cb < C; cb += 64) {   // 64 channels per pass through the tile
-        const int cw = C - cb < 64 ? C - cb : 64;
+    for (int cb = 0; cb < C; cb += FDX_CH) {   // FDX_CH channels per pass through the tile
+        const int cw = C - cb < FDX_CH ? C - cb : FDX_CH;
         for (int c = 0; c < cw; c += 8) {
             float a[8];
 #pragma unroll
@@ -150,11 +152,12 @@ __global__ void __launch_bounds__(256) field_dx16_kernel(const float *__restrict
             *reinterpret_cast<float4 *>(t + 4) = make_float4(a[4], a[5], a[6], a[7]);
         }
         __syncthreads();
-        const int q = threadIdx.x & 7, groups = cw / 8;
+        constexpr int LPP = FDX_CH / 8;   // lanes per pixel
+        const int q = threadIdx.x % LPP, groups = cw / 8;
         const float sl = dx_act == PWS_ACT_LRELU ? 0.2f : 0.f;
 #pragma unroll 2
-        for (int it = 0; it < 8; ++it) {
-            const int p = it * 32 + (threadIdx.x >> 3);
+        for (int it = 0; it < LPP; ++it) {
+            const int p = it * (256 / LPP) + threadIdx.x / LPP;
             const size_t gp = pix0 + p;
             if (gp < total && q < groups) {
                 const float4 lo = *reinterpret_cast<const float4 *>(s_tile + p * FDX_PITCH + q * 8);
