@@ -140,6 +140,27 @@ def test_conv_kinds_vs_oracle(hip, oracle, kname, shape, src_c, cout, act):
         np.testing.assert_allclose(nchw(got), ref, rtol=0, atol=5e-5)
 
 
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_conv_epilogue_activation_on_non_finite_values(hip, oracle, act):
+    """The epilogues' activation is branch-free arithmetic (common.h: act_apply = max(v, (slope v) & keep)); it must treat
+    +-inf, NaN and +-0 exactly like the reference's LeakyReLU(0.2) / ReLU / identity.  A bias of +-inf / NaN / 0 on a zero input makes
+    the pre-activation exactly that value."""
+    A = hip
+    cout, cin = 16, 16
+    x = np.zeros((1, 8, 8, cin), np.float32)
+    wt = np.ones((cout, cin, 3, 3), np.float32)
+    b = np.array([np.inf, -np.inf, np.nan, 0.0, -0.0, 1.5, -1.5, 3e38, -3e38, 1e-40, -1e-40, 2.0, -2.0, np.inf, -np.inf, np.nan], np.float32)
+    got = run_conv(A, A.CONV_K3S1, [x], wt, b, act, cout)[0, 4, 4]
+    with np.errstate(invalid="ignore", over="ignore"):
+        want = b.copy() if act == 0 else (np.where(b > 0, b, np.float32(0.2) * b) if act == 1 else np.where(b > 0, b, np.float32(0.0)))
+    want = want.astype(np.float32)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), (got, want)
+    fin = ~np.isnan(want)
+    # flush-to-zero of the 1e-40 denormal by the matrix pipeline's bias add is allowed: compare with denormals flushed
+    flush = lambda a: np.where(np.abs(a) < np.float32(1.2e-38), np.float32(0) * a, a)
+    np.testing.assert_array_equal(flush(got[fin]), flush(want[fin]))
+
+
 RINGF_CASES = [
     ("CONV_K3S1", (2, 16, 32), [16], 64), ("CONV_K3S1", (1, 24, 64), [32, 16], 96), ("CONVT_K3S1", (2, 16, 32), [16, 16, 16, 16], 36),
     ("CONV_K3S2", (2, 32, 64), [16, 16], 64), ("CONV_K3S2", (1, 48, 64), [32], 72), ("CONVT_K4S2", (2, 16, 32), [32, 16], 64),
