@@ -69,7 +69,6 @@ struct RingParams {
 #ifdef PWS_RING_TIMERS
     unsigned long long *timers;   // [workgroup][matrix wave][8]
 #endif
-    int stagger;          // workgroups delay their start by (slot % 4) * stagger ticks of 10 ns (see conv_ring_try)
     int ablate;           // measurement only (PWS_OPT_EXPERIMENT 41..43): 1 = the DMA pieces fetch nothing after the first groups,
                           // 2 = no matrix phase, 4 = no epilogue -- results are meaningless, only the timing is read
 };
@@ -397,10 +396,6 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
 #define PWS_RT() __builtin_amdgcn_s_memrealtime()
 #endif
-    if (p.stagger > 0) {
-        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)((slot & 3u) * (unsigned)p.stagger);
-        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
-    }
     for (unsigned s = 0; s < total; ++s) {
 #ifdef PWS_RING_TIMERS
         const unsigned long long t0 = PWS_RT();
@@ -683,7 +678,6 @@ int conv_ring_try(int kind, bool dgrad, const ConvKParams &kp, hipStream_t st, c
         rp.timers = e ? reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 0)) : nullptr;
     }
 #endif
-    rp.stagger = g_experiment >= 110 && g_experiment <= 129 ? (g_experiment - 110) * 50 : 0;
     rp.ablate = g_experiment >= 41 && g_experiment <= 47 ? g_experiment - 40 : 0;
     if (tw == 8 && mode == RM_K3S1) return 1;
     if (kp.cout > (tw == 16 && mode == RM_K3S1 ? 512 : 1024)) return 1;   // the bias vector's LDS slot (RgCfg::BIAS_FLOATS)
