@@ -39,18 +39,24 @@ struct WgradRingParams {
     float *dbias;
 };
 
-template <int KS_, int PAD_, int SUBPIX_>
+template <int KS_, int PAD_, int SUBPIX_, bool CI32_ = false>
 struct WrgCfg {
     static constexpr int KS = KS_, PAD = PAD_, SUBPIX = SUBPIX_, TH = 16, TW = 16;   // stride 1 kinds, 16 x 16-pixel tiles of one sample
+    // CI32: the first layer (5x5, 31 -> 32 padded input channels): ONE 32-channel plane of x, a workgroup = 32 input x 64 output
+    // channels x all 25 taps, matrix wave = (output-channel half, tap quarter): 7 / 7 / 7 / 4 accumulators.  (wgrad_bf16_kernel
+    // walked the tensors three times, once per group of 10 taps: 2.7 GB of HBM traffic for 0.8 GB of operands.)
+    static constexpr bool CI32 = CI32_;
+    static constexpr int XPL = CI32 ? 1 : 2;              // 32-channel planes of the x tile
+    static constexpr int NTG = CI32 ? 4 : 2;              // tap groups: matrix wave = (32 x 32 quadrant, tap group)
     static constexpr int TAPS = KS * KS;
-    static constexpr int NT0 = (TAPS + 1) / 2;            // taps of the first wave half (the second takes the rest)
+    static constexpr int NT0 = (TAPS + NTG - 1) / NTG;    // taps of a wave (the last group takes the rest)
     static constexpr int BM = TH * TW, KSTEPS = BM / 16;
     static constexpr int IH = TH + KS - 1, IW = TW + KS - 1, PIX = IH * IW;
     static constexpr int ROW = 64;                        // bytes per LDS row: 32 bf16 channels
     static constexpr int XPP = (PIX * 4 + 63) / 64;       // DMA pieces (1 KB) per 32-channel plane of the x tile
     static constexpr int GPP = BM * 4 / 64;               // ... of the dy tile
-    static constexpr int XP_BYTES = XPP * 1024, G_OFF = 2 * XP_BYTES, GP_BYTES = GPP * 1024;
-    static constexpr int PIECES = 2 * XPP + 2 * GPP;
+    static constexpr int XP_BYTES = XPP * 1024, G_OFF = XPL * XP_BYTES, GP_BYTES = GPP * 1024;
+    static constexpr int PIECES = XPL * XPP + 2 * GPP;
     static constexpr int MWAVES = 8, LWAVES = 4, THREADS = 64 * (MWAVES + LWAVES);
     static constexpr int NL = (PIECES + LWAVES - 1) / LWAVES;
     static constexpr int IMG_BYTES = NL * LWAVES * 1024;
@@ -106,10 +112,9 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
         for (int it = 0; it < C::NL; ++it) {
             const int pc = it * C::LWAVES + lw;
             int kind, pl0;
-            if (pc < C::XPP) kind = 0, pl0 = 0;
-            else if (pc < 2 * C::XPP) kind = 1, pl0 = C::XPP;
-            else if (pc < 2 * C::XPP + C::GPP) kind = 2, pl0 = 2 * C::XPP;
-            else kind = 3, pl0 = 2 * C::XPP + C::GPP;
+            if (pc < C::XPL * C::XPP) kind = pc / C::XPP, pl0 = kind * C::XPP;
+            else if (pc < C::XPL * C::XPP + C::GPP) kind = 2, pl0 = C::XPL * C::XPP;
+            else kind = 3, pl0 = C::XPL * C::XPP + C::GPP;
             const int j = (pc - pl0) * 64 + lane;
             const int row = j >> 2, sp = j & 3;
             const bool ok = pc < C::PIECES && row < (kind < 2 ? C::PIX : C::BM);
@@ -121,7 +126,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             int ch = ci0 + q * 32, s = 0;
-            xok[q] = ch < p.cin;
+            xok[q] = q < C::XPL && ch < p.cin;
             while (s < p.nsrc - 1 && ch >= wrgsel4(p.src_c, s)) ch -= wrgsel4(p.src_c, s), ++s;
             xs[q] = xok[q] ? s : 0, xch[q] = xok[q] ? ch : 0;
         }
@@ -156,7 +161,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
                 const int row = (desc[it] >> 2) & 0x3ffffff, sp = desc[it] & 3;
                 unsigned v = kWrgOob;
                 const unsigned dst = d_base + (unsigned)(it * C::LWAVES * 1024);
-                if (pc < 2 * C::XPP) {
+                if (pc < C::XPL * C::XPP) {
                     const int q = pc < C::XPP ? 0 : 1;
                     const int lx = row % C::IW, ly = row / C::IW;
                     const int iy = iy0 + ly, ix = ix0 + lx;
@@ -164,7 +169,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
                     if (ok) v = (unsigned)(iy * p.W + ix) * ldx[q] + (unsigned)(sp * 16);
                     wrg_dma16(dst, v, q ? rx[1] : rx[0], 0u);
                 } else {
-                    const int q = pc < 2 * C::XPP + C::GPP ? 0 : 1;
+                    const int q = pc < C::XPL * C::XPP + C::GPP ? 0 : 1;
                     const int tx = row % C::TW, ty = row / C::TW;
                     const int y = y0 + ty, x = x0 + tx;
                     const int oy = C::SUBPIX ? 2 * y + py : y, ox = C::SUBPIX ? 2 * x + px : x;
@@ -186,9 +191,9 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
     }
 
     // =============================================================================================== matrix waves
-    const int quad = wv & 3, th = wv >> 2;
-    const int wci = quad >> 1, wco = quad & 1;
-    const int t0 = th ? C::NT0 : 0, nt = th ? C::TAPS - C::NT0 : C::NT0;   // wave-uniform
+    const int quad = C::CI32 ? (wv & 1) : (wv & 3), th = C::CI32 ? (wv >> 1) : (wv >> 2);   // quadrant, tap group
+    const int wci = C::CI32 ? 0 : quad >> 1, wco = C::CI32 ? quad : quad & 1;
+    const int t0 = th * C::NT0, nt = C::TAPS - t0 < C::NT0 ? C::TAPS - t0 : C::NT0;   // wave-uniform
     wr_f32x16 acc[C::NT0];
 #pragma unroll
     for (int t = 0; t < C::NT0; ++t)
@@ -214,7 +219,8 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
         __builtin_amdgcn_s_barrier();   // B_s
         asm volatile("" ::: "memory");
         const unsigned char *img = lds + (unsigned)(cbuf * C::IMG_BYTES);
-#pragma unroll
+        constexpr int UNR = C::CI32 ? 2 : C::KSTEPS;   // (7 accumulators: fully unrolled, hipcc hoists operand reads until it spills)
+#pragma unroll UNR
         for (int j = 0; j < C::KSTEPS; ++j) {   // k-step j = the 16 pixels of tile row j
             const bf16x8 b = wrg_tr_pair(img, b_lane[0] + j * 16 * C::ROW, b_lane[1] + j * 16 * C::ROW);
             if (do_bias) {   // wave-uniform: this lane holds 8 pixels of dy column l31 (masked pixels are zeros)
@@ -291,13 +297,16 @@ static int wrg_launch(WgradRingParams &p, int nclasses, hipStream_t st) {
 // not covered: fewer than 64 (padded) input channels, maps that 16 x 16 tiles cover badly, too few tiles for a stream.
 int wgrad_ring_try(const pws_conv_bwd_weight_args *a, int cin, hipStream_t st) {
     if (a->store != PWS_STORE_BF16 || g_experiment == 80) return 1;
-    if (a->kind != PWS_CONV_K3S1 && a->kind != PWS_CONVT_K3S1 && a->kind != PWS_CONVT_K4S2) return 1;
-    if (cin < 64 || a->cout < 32 || a->h % 16 != 0 || a->w % 16 != 0) return 1;
-    // Measured (tools/wgrad_ring_bench.sh, batch 64, bf16 storage): 3x3 layers of >= 128 channels 329-343 us against 341-358 us of
+    if (a->kind != PWS_CONV_K3S1 && a->kind != PWS_CONVT_K3S1 && a->kind != PWS_CONVT_K4S2 && a->kind != PWS_CONV_K5S1) return 1;
+    const bool first = a->kind == PWS_CONV_K5S1;   // the first layer: one source of 32 (31 + padding) channels
+    if (first && (cin != 32 || a->nsrc != 1)) return 1;
+    if ((!first && cin < 64) || a->cout < 32 || a->h % 16 != 0 || a->w % 16 != 0) return 1;
+    // Measured (tools/wgrad_ring_bench.sh, batch 64, bf16 storage): the first layer (5x5, 32 -> 64 @256^2) 480 us against 1110 us;
+    // 3x3 layers of >= 128 channels 329-343 us against 341-358 us of
     // wgrad_bf16_kernel (+4-5 %); 64 -> 64 @256^2 397 vs 372 us and the transposed kind 464-874 vs 410-767 us (its two-tap waves read
     // a dy fragment per two matrix instructions) -- so only the former is taken (PWS_OPT_EXPERIMENT 81 takes every covered launch).
     // Both kernels stage ~1.07 GB per launch at ~3 TB/s: the tile stream, not the matrix pipe, sets the pace of either.
-    if ((a->kind == PWS_CONVT_K4S2 || cin < 128) && g_experiment != 81) return 1;
+    if (!first && (a->kind == PWS_CONVT_K4S2 || cin < 128) && g_experiment != 81) return 1;
     for (int s = 0; s < a->nsrc; ++s)
         if ((size_t)a->h * a->w * a->src[s].ld * 2 >= (1u << 31) || (reinterpret_cast<size_t>(a->src[s].ptr) & 15) || a->src[s].ld % 8 != 0) return 1;
     const int oh = a->kind == PWS_CONVT_K4S2 ? 2 * a->h : a->h, ow = a->kind == PWS_CONVT_K4S2 ? 2 * a->w : a->w;
@@ -313,11 +322,12 @@ int wgrad_ring_try(const pws_conv_bwd_weight_args *a, int cin, hipStream_t st) {
     const long other = (long)((p.cin_pad + 63) / 64) * ((a->cout + 63) / 64) * nclasses;
     // a workgroup should stream at least a few tiles (its prologue is one exposed tile load, its tail the atomics)
     if (tiles * other < 256 * 4 && g_experiment != 81) return 1;
-    const double k2 = a->kind == PWS_CONVT_K4S2 ? 4 : 9;
+    const double k2 = a->kind == PWS_CONVT_K4S2 ? 4 : (first ? 25 : 9);
     const double out_pix = (double)a->n * oh * ow;
     ProfScope prof(KID_WGRAD_RING, 2.0 * out_pix * a->cout * cin * k2,
                    4.0 * ((double)a->n * a->h * a->w * cin + out_pix * a->cout + k2 * cin * a->cout * (nclasses == 4 ? 4 : 1)), st);
     if (a->kind == PWS_CONVT_K4S2) return wrg_launch<WrgCfg<2, 0, 1>>(p, nclasses, st);
+    if (first) return wrg_launch<WrgCfg<5, 2, 0, true>>(p, nclasses, st);
     return wrg_launch<WrgCfg<3, 1, 0>>(p, nclasses, st);
 }
 
