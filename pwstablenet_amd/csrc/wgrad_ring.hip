@@ -41,22 +41,30 @@ struct WgradRingParams {
 
 template <int KS_, int PAD_, int SUBPIX_, bool CI32_ = false>
 struct WrgCfg {
-    static constexpr int KS = KS_, PAD = PAD_, SUBPIX = SUBPIX_, TH = 16, TW = 16;   // stride 1 kinds, 16 x 16-pixel tiles of one sample
+    static constexpr int KS = KS_, PAD = PAD_, SUBPIX = SUBPIX_;
+    // SUBPIX: 0 = dense kinds; 1 = one parity class of the transposed k4 s2 layers per workgroup (2x2 taps: a wave's dy fragment
+    // feeds only two matrix instructions -- measured slower than wgrad_bf16_kernel); 2 = the class PAIR (py, 0) and (py, 1) per
+    // workgroup: both read the same x tile (one more halo column), a matrix wave = (32 x 32 quadrant, class) owns all four taps of
+    // its class, so a dy fragment feeds four matrix instructions and the x tile is staged once for eight taps.  The pair's tiles are
+    // 8 x 16 pixels (x 9 x 18 + dy 2 x 8 x 16 pixels x 64 channels: 56 KB per tile, two in the ring).
+    static constexpr bool PAIR = SUBPIX == 2;
+    static constexpr int TH = PAIR ? 8 : 16, TW = 16;     // stride 1 kinds, tiles of one sample
     // CI32: the first layer (5x5, 31 -> 32 padded input channels): ONE 32-channel plane of x, a workgroup = 32 input x 64 output
     // channels x all 25 taps, matrix wave = (output-channel half, tap quarter): 7 / 7 / 7 / 4 accumulators.  (wgrad_bf16_kernel
     // walked the tensors three times, once per group of 10 taps: 2.7 GB of HBM traffic for 0.8 GB of operands.)
     static constexpr bool CI32 = CI32_;
     static constexpr int XPL = CI32 ? 1 : 2;              // 32-channel planes of the x tile
-    static constexpr int NTG = CI32 ? 4 : 2;              // tap groups: matrix wave = (32 x 32 quadrant, tap group)
+    static constexpr int NTG = CI32 ? 4 : (PAIR ? 1 : 2); // tap groups: matrix wave = (32 x 32 quadrant, tap group [or class of the pair])
+    static constexpr int NG = PAIR ? 4 : 2;               // 32-channel planes of dy: (class of the pair,) output-channel half
     static constexpr int TAPS = KS * KS;
     static constexpr int NT0 = (TAPS + NTG - 1) / NTG;    // taps of a wave (the last group takes the rest)
     static constexpr int BM = TH * TW, KSTEPS = BM / 16;
-    static constexpr int IH = TH + KS - 1, IW = TW + KS - 1, PIX = IH * IW;
+    static constexpr int IH = TH + KS - 1, IW = TW + KS - 1 + (PAIR ? 1 : 0), PIX = IH * IW;
     static constexpr int ROW = 64;                        // bytes per LDS row: 32 bf16 channels
     static constexpr int XPP = (PIX * 4 + 63) / 64;       // DMA pieces (1 KB) per 32-channel plane of the x tile
     static constexpr int GPP = BM * 4 / 64;               // ... of the dy tile
     static constexpr int XP_BYTES = XPP * 1024, G_OFF = XPL * XP_BYTES, GP_BYTES = GPP * 1024;
-    static constexpr int PIECES = XPL * XPP + 2 * GPP;
+    static constexpr int PIECES = XPL * XPP + NG * GPP;
     static constexpr int MWAVES = 8, LWAVES = 4, THREADS = 64 * (MWAVES + LWAVES);
     static constexpr int NL = (PIECES + LWAVES - 1) / LWAVES;
     static constexpr int IMG_BYTES = NL * LWAVES * 1024;
@@ -98,9 +106,10 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
 
     const int cb = blockIdx.y;
     const int ci0 = (cb / p.co_blocks) * 64, co0 = (cb % p.co_blocks) * 64;
-    const int cls = C::SUBPIX ? (int)blockIdx.z : 0;
-    const int py = cls >> 1, px = cls & 1;
-    const int pad_y = C::SUBPIX ? 1 - py : C::PAD, pad_x = C::SUBPIX ? 1 - px : C::PAD;
+    // blockIdx.z: the parity class (SUBPIX 1) or py of the class pair (SUBPIX 2: px is the matrix wave's / the dy plane's)
+    const int cls = C::SUBPIX == 1 ? (int)blockIdx.z : 0;
+    const int py = C::PAIR ? (int)blockIdx.z : cls >> 1, px = cls & 1;
+    const int pad_y = C::SUBPIX ? 1 - py : C::PAD, pad_x = C::PAIR ? 1 : (C::SUBPIX ? 1 - px : C::PAD);
     const int my_tiles = ((int)blockIdx.x < p.ntiles) ? (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
 
     if (wv >= C::MWAVES) {
@@ -113,12 +122,11 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
             const int pc = it * C::LWAVES + lw;
             int kind, pl0;
             if (pc < C::XPL * C::XPP) kind = pc / C::XPP, pl0 = kind * C::XPP;
-            else if (pc < C::XPL * C::XPP + C::GPP) kind = 2, pl0 = C::XPL * C::XPP;
-            else kind = 3, pl0 = C::XPL * C::XPP + C::GPP;
+            else kind = 2 + (pc - C::XPL * C::XPP) / C::GPP, pl0 = C::XPL * C::XPP + (kind - 2) * C::GPP;   // dy plane kind - 2
             const int j = (pc - pl0) * 64 + lane;
             const int row = j >> 2, sp = j & 3;
             const bool ok = pc < C::PIECES && row < (kind < 2 ? C::PIX : C::BM);
-            desc[it] = ok ? (kind << 28 | row << 2 | sp) : -1;
+            desc[it] = ok ? (kind << 27 | row << 2 | sp) : -1;
         }
         // channel block of the x planes inside the virtual concat (sources are multiples of 32 channels: a plane lies in one source)
         int xs[2], xch[2];
@@ -158,7 +166,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
 #pragma unroll
             for (int it = 0; it < C::NL; ++it) {
                 const int pc = it * C::LWAVES + lw;   // wave-uniform: the kind of a piece is too
-                const int row = (desc[it] >> 2) & 0x3ffffff, sp = desc[it] & 3;
+                const int row = (desc[it] >> 2) & 0x1ffffff, sp = desc[it] & 3;
                 unsigned v = kWrgOob;
                 const unsigned dst = d_base + (unsigned)(it * C::LWAVES * 1024);
                 if (pc < C::XPL * C::XPP) {
@@ -169,10 +177,11 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
                     if (ok) v = (unsigned)(iy * p.W + ix) * ldx[q] + (unsigned)(sp * 16);
                     wrg_dma16(dst, v, q ? rx[1] : rx[0], 0u);
                 } else {
-                    const int q = pc < C::XPL * C::XPP + C::GPP ? 0 : 1;
+                    const int g = (pc - C::XPL * C::XPP) / C::GPP;   // dy plane: (class of the pair,) output-channel half
+                    const int q = g & 1, gpx = C::PAIR ? g >> 1 : px;
                     const int tx = row % C::TW, ty = row / C::TW;
                     const int y = y0 + ty, x = x0 + tx;
-                    const int oy = C::SUBPIX ? 2 * y + py : y, ox = C::SUBPIX ? 2 * x + px : x;
+                    const int oy = C::SUBPIX ? 2 * y + py : y, ox = C::SUBPIX ? 2 * x + gpx : x;
                     const bool ok = live && desc[it] >= 0 && gok[q] && y < p.LH && x < p.LW && oy < p.OH && ox < p.OW;
                     if (ok) v = (unsigned)(oy * p.OW + ox) * ldg + (unsigned)(q * 64 + sp * 16);
                     wrg_dma16(dst, v, rg, 0u);
@@ -191,9 +200,10 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
     }
 
     // =============================================================================================== matrix waves
-    const int quad = C::CI32 ? (wv & 1) : (wv & 3), th = C::CI32 ? (wv >> 1) : (wv >> 2);   // quadrant, tap group
+    const int quad = C::CI32 ? (wv & 1) : (wv & 3), th = C::CI32 ? (wv >> 1) : (wv >> 2);   // quadrant, tap group (PAIR: class px)
     const int wci = C::CI32 ? 0 : quad >> 1, wco = C::CI32 ? quad : quad & 1;
-    const int t0 = th * C::NT0, nt = C::TAPS - t0 < C::NT0 ? C::TAPS - t0 : C::NT0;   // wave-uniform
+    const int t0 = C::PAIR ? 0 : th * C::NT0, nt = C::TAPS - t0 < C::NT0 ? C::TAPS - t0 : C::NT0;   // wave-uniform
+    const int wpx = C::PAIR ? th : 0;   // this wave's class of the pair: its x columns start one to the right for px = 1
     wr_f32x16 acc[C::NT0];
 #pragma unroll
     for (int t = 0; t < C::NT0; ++t)
@@ -208,9 +218,9 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
     for (int q = 0; q < 2; ++q) {
         const int c = 8 * (lg >> 1) + 4 * q + (li >> 2);   // pixel of the k-step = tile pixel 16 j + c = (row j, column c)
         a_lane[q] = wci * C::XP_BYTES + c * C::ROW + colb;
-        b_lane[q] = C::G_OFF + wco * C::GP_BYTES + c * C::ROW + colb;
+        b_lane[q] = C::G_OFF + (wpx * 2 + wco) * C::GP_BYTES + c * C::ROW + colb;
     }
-    const bool do_bias = p.dbias != nullptr && cb / p.co_blocks == 0 && th == 0 && wci == 0;
+    const bool do_bias = p.dbias != nullptr && cb / p.co_blocks == 0 && (C::PAIR || th == 0) && wci == 0;   // PAIR: both classes' dy
     float bsum = 0.f;
 
     int cbuf = 0;
@@ -234,7 +244,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
             for (int t = 0; t < C::NT0; ++t) {
                 if (t < nt) {
                     const int tap = t0 + t;   // wave-uniform
-                    const int toff = ((tap / C::KS) * C::IW + (tap % C::KS)) * C::ROW;
+                    const int toff = ((tap / C::KS) * C::IW + (tap % C::KS) + wpx) * C::ROW;
                     const int joff = j * C::IW * C::ROW + toff;
                     const bf16x8 a = wrg_tr_pair(img, a_lane[0] + joff, a_lane[1] + joff);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
@@ -257,7 +267,8 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ci = ci0 + wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (ci < p.cin_pad && co < p.cout) atomicAdd(p.dw + ((size_t)(cls * C::TAPS + tap) * p.cin_pad + ci) * p.cout + co, acc[t][r]);
+                const int ocls = C::PAIR ? py * 2 + wpx : cls;
+                if (ci < p.cin_pad && co < p.cout) atomicAdd(p.dw + ((size_t)(ocls * C::TAPS + tap) * p.cin_pad + ci) * p.cout + co, acc[t][r]);
             }
         }
     }
@@ -283,6 +294,7 @@ static int wrg_launch(WgradRingParams &p, int nclasses, hipStream_t st) {
     p.tiles_x = (p.LW + C::TW - 1) / C::TW, p.tiles_y = (p.LH + C::TH - 1) / C::TH;
     p.ntiles = p.tiles_x * p.tiles_y * p.N;
     p.ci_blocks = (p.cin_pad + 63) / 64, p.co_blocks = (p.cout + 63) / 64;
+    if (C::PAIR) nclasses = 2;   // grid.z = py: a workgroup takes the classes (py, 0) and (py, 1)
     const long other = (long)p.ci_blocks * p.co_blocks * nclasses;
     // one workgroup per CU and round: the pixel tiles are split over as many workgroups as it takes to give every CU one
     long ps = (ncu + other - 1) / other;
@@ -300,13 +312,17 @@ int wgrad_ring_try(const pws_conv_bwd_weight_args *a, int cin, hipStream_t st) {
     if (a->kind != PWS_CONV_K3S1 && a->kind != PWS_CONVT_K3S1 && a->kind != PWS_CONVT_K4S2 && a->kind != PWS_CONV_K5S1) return 1;
     const bool first = a->kind == PWS_CONV_K5S1;   // the first layer: one source of 32 (31 + padding) channels
     if (first && (cin != 32 || a->nsrc != 1)) return 1;
-    if ((!first && cin < 64) || a->cout < 32 || a->h % 16 != 0 || a->w % 16 != 0) return 1;
+    const bool ct4 = a->kind == PWS_CONVT_K4S2;
+    if ((!first && cin < 64) || a->cout < 32 || a->h % (ct4 ? 8 : 16) != 0 || a->w % 16 != 0) return 1;
     // Measured (tools/wgrad_ring_bench.sh, batch 64, bf16 storage): the first layer (5x5, 32 -> 64 @256^2) 480 us against 1110 us;
     // 3x3 layers of >= 128 channels 329-343 us against 341-358 us of
     // wgrad_bf16_kernel (+4-5 %); 64 -> 64 @256^2 397 vs 372 us and the transposed kind 464-874 vs 410-767 us (its two-tap waves read
     // a dy fragment per two matrix instructions) -- so only the former is taken (PWS_OPT_EXPERIMENT 81 takes every covered launch).
     // Both kernels stage ~1.07 GB per launch at ~3 TB/s: the tile stream, not the matrix pipe, sets the pace of either.
-    if (!first && (a->kind == PWS_CONVT_K4S2 || cin < 128) && g_experiment != 81) return 1;
+    // The transposed kind as class pairs (SUBPIX 2): 780 / 416 / 421 / 217 us on the four decoder shapes against 807 / 436 / 423 / 207 us
+    // of wgrad_bf16_kernel (one class per workgroup, SUBPIX 1: 910 / 488 / 485 / 248): 54 KB staged per 2 x 1024 matrix cycles is
+    // more than the LDS-DMA delivers -- not taken either (81 takes the pairs, 82 the single classes).
+    if (!first && (ct4 || cin < 128) && g_experiment != 81 && g_experiment != 82) return 1;
     for (int s = 0; s < a->nsrc; ++s)
         if ((size_t)a->h * a->w * a->src[s].ld * 2 >= (1u << 31) || (reinterpret_cast<size_t>(a->src[s].ptr) & 15) || a->src[s].ld % 8 != 0) return 1;
     const int oh = a->kind == PWS_CONVT_K4S2 ? 2 * a->h : a->h, ow = a->kind == PWS_CONVT_K4S2 ? 2 * a->w : a->w;
@@ -318,15 +334,16 @@ int wgrad_ring_try(const pws_conv_bwd_weight_args *a, int cin, hipStream_t st) {
     p.N = a->n, p.H = a->h, p.W = a->w, p.LH = a->h, p.LW = a->w, p.OH = oh, p.OW = ow;
     p.gout = a->gout, p.gout_ld = a->gout_ld, p.dw = a->dw_packed, p.dbias = a->dbias;
     const int nclasses = a->kind == PWS_CONVT_K4S2 ? 4 : 1;
-    const long tiles = (long)(a->h / 16) * (a->w / 16) * a->n;
-    const long other = (long)((p.cin_pad + 63) / 64) * ((a->cout + 63) / 64) * nclasses;
+    const long tiles = (long)(a->h / (ct4 ? 8 : 16)) * (a->w / 16) * a->n;
+    const long other = (long)((p.cin_pad + 63) / 64) * ((a->cout + 63) / 64) * (ct4 ? 2 : 1);
     // a workgroup should stream at least a few tiles (its prologue is one exposed tile load, its tail the atomics)
     if (tiles * other < 256 * 4 && g_experiment != 81) return 1;
     const double k2 = a->kind == PWS_CONVT_K4S2 ? 4 : (first ? 25 : 9);
     const double out_pix = (double)a->n * oh * ow;
     ProfScope prof(KID_WGRAD_RING, 2.0 * out_pix * a->cout * cin * k2,
                    4.0 * ((double)a->n * a->h * a->w * cin + out_pix * a->cout + k2 * cin * a->cout * (nclasses == 4 ? 4 : 1)), st);
-    if (a->kind == PWS_CONVT_K4S2) return wrg_launch<WrgCfg<2, 0, 1>>(p, nclasses, st);
+    if (ct4 && g_experiment == 82) return (a->h % 16 == 0) ? wrg_launch<WrgCfg<2, 0, 1>>(p, nclasses, st) : 1;   // one class per workgroup (A/B)
+    if (ct4) return wrg_launch<WrgCfg<2, 0, 2>>(p, nclasses, st);
     if (first) return wrg_launch<WrgCfg<5, 2, 0, true>>(p, nclasses, st);
     return wrg_launch<WrgCfg<3, 1, 0>>(p, nclasses, st);
 }

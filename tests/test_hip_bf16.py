@@ -447,6 +447,7 @@ def test_bf16_conv_weight_gradient(hip, kname, shape, src_c, cout, store):
     ("CONV_K3S1", (3, 16, 32), [96], 32),          # 96 input channels: block 1 has one plane; 32 output channels: one dy plane
     ("CONVT_K4S2", (2, 16, 32), [128, 64], 64),    # 4 parity classes of 2x2 taps (2 + 2 per wave half), virtual concat
     ("CONV_K3S1", (8, 64, 64), [128], 128),        # 128 tiles x 4 blocks: several tiles per workgroup, pixel split over workgroups
+    ("CONVT_K4S2", (3, 24, 48), [64], 96),         # class pairs per workgroup on 8 x 16 tiles: 24 rows = 3 tiles; cout 96
     ("CONV_K5S1", (2, 32, 48), [32], 64),          # the first layer's shape: one 32-channel plane, 25 taps over 4 tap groups (7 / 7 / 7 / 4)
     ("CONV_K5S1", (1, 16, 16), [32], 96),          # one tile; cout 96: the second output block has one dy plane
 ])
