@@ -706,6 +706,8 @@ static int launch_k5(ConvKParams &kp, hipStream_t st, const ProfInfo &pi) {
 // Forward kinds.  kp is fully prepared by conv2d_fwd_impl (conv_mfma.hip); returns 1 when this launch is not covered by
 // the bf16 kernels (the caller then runs the fp32 path), else the launch status.
 int conv_ring_try(int kind, bool dgrad, const ConvKParams &kp, hipStream_t st, const ProfInfo &pi);   // conv_ring.hip; 1 = not covered
+int conv_skinny16_try(int kind, bool dgrad, ConvKParams &kp, int kchan, float *final_out, float *ws, size_t ws_floats, hipStream_t st,
+                      const ProfInfo &pi);   // conv_skinny16.hip (the deep levels, bf16 storage); 1 = not covered
 
 int conv_bf16_fwd(int kind, ConvKParams &kp, int cin_total, float *out, float *ws, size_t ws_floats, hipStream_t st,
                   const ProfInfo &pi) {
@@ -713,7 +715,9 @@ int conv_bf16_fwd(int kind, ConvKParams &kp, int cin_total, float *out, float *w
         if (kp.src_c[s] % 32 != 0) return 1;
     if (kind != PWS_CONV_K5S1) {   // the persistent LDS-ring kernel takes the launches it covers (bf16 storage, maps >= 16 x 32)
         kp.out = out;
-        const int rc = conv_ring_try(kind, false, kp, st, pi);
+        int rc = conv_ring_try(kind, false, kp, st, pi);
+        if (rc != 1) return rc;
+        rc = conv_skinny16_try(kind, false, kp, cin_total, out, ws, ws_floats, st, pi);
         if (rc != 1) return rc;
     }
     switch (kind) {
@@ -737,7 +741,9 @@ int conv_bf16_fwd(int kind, ConvKParams &kp, int cin_total, float *out, float *w
 int conv_bf16_dgrad(int kind, ConvKParams &kp, int cout_f, float *ws, size_t ws_floats, hipStream_t st, const ProfInfo &pi) {
     if (cout_f % 32 != 0) return 1;
     {
-        const int rc = conv_ring_try(kind, true, kp, st, pi);
+        int rc = conv_ring_try(kind, true, kp, st, pi);
+        if (rc != 1) return rc;
+        rc = conv_skinny16_try(kind, true, kp, cout_f, nullptr, ws, ws_floats, st, pi);
         if (rc != 1) return rc;
     }
     switch (kind) {

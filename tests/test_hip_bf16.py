@@ -72,10 +72,13 @@ def make_case(kname, shape, src_c, cout, tag):
     return x, wt, b, rs
 
 
+# kernels of the bf16 path: the tiled kernel, the one-shot kernel of the deep levels (bf16 storage, <= 256 pixels per class, workspace
+# given: csrc/conv_skinny16.hip), the persistent LDS-ring kernel
+BF16_CONV_KERNELS = ("conv_bf16_kernel", "conv_skinny16_kernel", "conv_ring_kernel")
 STORE_TOL = 5e-3   # bf16 storage of the result: relative rounding 2^-9 of each value (<= 2e-3 of max|y|) on top of TIGHT
 
 
-def hip_fwd(A, kname, x, wt, b, act, src_c, cout, ws_mb, store=False):
+def hip_fwd(A, kname, x, wt, b, act, src_c, cout, ws_mb, store=False, expect=None):
     L, st = A.lib(), A.current_stream()
     kind = getattr(A, kname)
     n, cin, h, w = x.shape
@@ -110,7 +113,7 @@ def hip_fwd(A, kname, x, wt, b, act, src_c, cout, ws_mb, store=False):
     A.check(L.pws_conv2d_fwd(ctypes.byref(a), st), "conv bf16")
     L.pws_prof_enable(0)
     names = [r[0] for r in A.prof_collect()]
-    assert names == ["conv_bf16_kernel"], names  # the bf16 kernel really ran (no silent fp32 path)
+    assert len(names) == 1 and names[0] in ((expect,) if expect else BF16_CONV_KERNELS), names  # a bf16 kernel really ran (no silent fp32 path)
     torch.cuda.synchronize()
     return out.float().cpu()
 
@@ -185,7 +188,8 @@ def test_bf16_conv_data_gradient(hip, kname, shape, src_c, cout, store):
         L.pws_prof_enable(1)
         A.check(L.pws_conv2d_bwd_data(ctypes.byref(da), st), "bwd_data bf16")
         L.pws_prof_enable(0)
-        assert [r[0] for r in A.prof_collect()] == ["conv_bf16_kernel"]
+        names = [r[0] for r in A.prof_collect()]
+        assert len(names) == 1 and names[0] in BF16_CONV_KERNELS, names
         torch.cuda.synchronize()
         c0 = 0
         for i, c in enumerate(src_c):
@@ -441,6 +445,37 @@ def test_bf16_conv_weight_gradient(hip, kname, shape, src_c, cout, store):
     np.testing.assert_allclose(db.cpu().numpy() - 0.25, want_db, rtol=0, atol=2e-5 * np.abs(dy.numpy()).sum(axis=(0, 2, 3)).max())
 
 
+SKINNY16_CASES = [
+    ("CONV_K3S1", (5, 4, 4), [32], 32), ("CONV_K3S1", (18, 2, 2), [64], 64), ("CONV_K3S1", (3, 8, 8), [32, 64], 96),
+    ("CONVT_K3S1", (7, 1, 1), [64], 40), ("CONV_K3S2", (6, 8, 8), [64], 64), ("CONV_K3S2", (3, 5, 7), [32, 32], 72),
+    ("CONV_K3S2", (9, 2, 2), [128], 128), ("CONVT_K4S2", (5, 4, 4), [64, 32], 64), ("CONVT_K4S2", (20, 1, 1), [128], 32),
+    ("CONVT_K4S2", (2, 3, 4), [32], 96),
+]
+
+
+@pytest.mark.parametrize("kname,shape,src_c,cout", SKINNY16_CASES)
+def test_bf16_one_shot_kernel_forward(hip, kname, shape, src_c, cout):
+    """conv_skinny16_kernel (csrc/conv_skinny16.hip: one LDS-DMA burst of bf16 weights per workgroup, A operands from global memory,
+    K split + the ordinary reduce epilogue) on every forward kind it covers, taken for every size up to 4096 pixels (PWS_OPT_EXPERIMENT
+    72) and switched off (71 -> conv_bf16_kernel): both against PyTorch-CPU on the same rounded operands.  Its data-gradient kinds run
+    in test_bf16_conv_data_gradient (the small-map cases with bf16 storage and a workspace)."""
+    A = hip
+    L = A.lib()
+    x, wt, b, _ = make_case(kname, shape, src_c, cout, "sk16")
+    xr, wr = bf16r(x), bf16r(wt)
+    want = nhwc(torch_layer(kname, xr, wr, b, 1)).numpy()
+    got = {}
+    try:
+        for e, name in ((72, "conv_skinny16_kernel"), (71, "conv_bf16_kernel")):
+            L.pws_set_option(100, e)
+            got[e] = hip_fwd(A, kname, xr, wt, b, 1, src_c, cout, 64, store=True, expect=name).numpy()
+            assert not np.isnan(got[e]).any()
+            assert relerr(got[e], want) < STORE_TOL, (name, relerr(got[e], want))
+    finally:
+        L.pws_set_option(100, 0)
+    assert relerr(got[72], got[71]) < STORE_TOL   # same products; fp32 summation order and the bf16 rounding of the result
+
+
 @pytest.mark.parametrize("kname,shape,src_c,cout", [
     ("CONV_K3S1", (2, 32, 48), [64, 64], 96),      # two input-channel blocks, cout 96: the second 64-block has one 32-channel plane
     ("CONVT_K3S1", (1, 16, 16), [64], 64),         # one tile per workgroup: the stream is prologue + tail only
@@ -533,7 +568,7 @@ def test_netg_bf16_inference_vs_fp32(hip, kind, store):
         names = [r[0] for r in hip.prof_collect()]
         net.module.set_math("fp32")
         again = net(x, False)
-    assert names.count("conv_bf16_kernel") >= 40, names   # every covered layer ran on the bf16 matrix cores
+    assert sum(names.count(k) for k in BF16_CONV_KERNELS) >= 40, names   # every covered layer ran on the bf16 matrix cores
     assert torch.equal(again, f32)                         # switching back restores the exact fp32 path
     err = (f16 - f32).abs().max().item()
     assert err < FIELD_TOL[kind], err
@@ -568,7 +603,8 @@ def test_netg_bf16_training_step_gradients_vs_fp32(hip, store):
     hip.lib().pws_prof_enable(0)
     names = [r[0] for r in hip.prof_collect()]
     net.module.set_math("fp32")
-    assert names.count("wgrad_bf16_kernel") >= 40 and names.count("conv_bf16_kernel") >= 80, (names.count("wgrad_bf16_kernel"), names.count("conv_bf16_kernel"))
+    nconv = sum(names.count(k) for k in BF16_CONV_KERNELS)
+    assert names.count("wgrad_bf16_kernel") >= 40 and nconv >= 80, (names.count("wgrad_bf16_kernel"), nconv)
     assert abs(l16 - l32) < 1e-2 * abs(l32), (l16, l32)
     dot = sum((a * b).sum().item() for a, b in zip(g16, g32))
     n16 = sum((a * a).sum().item() for a in g16) ** 0.5
