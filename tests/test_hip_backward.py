@@ -371,9 +371,14 @@ def test_backward_in_parts_with_overlapped_grad_sync(hip, nparts, math):
     assert sync.collectives == 0   # no process group here: the collectives are skipped, the rest is the same path
     for a, b in zip(got, ref):
         scale = float(b.abs().max()) + 1e-12
-        # fp32 atomics order in the weight-gradient kernels (same arithmetic otherwise); the bf16 kernels' many pixel-split
-        # partial sums cancel more strongly on the small tensors (seen: 2.4e-4 of a tensor's maximum, run to run)
-        assert float((a - b).abs().max()) / scale < (1e-4 if math == "fp32" else 1e-3)
+        # fp32: atomics order in the weight-gradient kernels (same arithmetic otherwise).  bf16 (= bf16 storage of the gradient
+        # tensors too): the 1e-7 noise of the fp32 atomics upstream (theta / bias sums) flips single gradient values that sit on a
+        # bf16 rounding boundary by one ulp (2^-9) -- run to run, with or without parts: two identical whole backward runs differ by
+        # a reproducible 1.5e-3 rms on down_bottom4.conv_same's weight gradient (dominated by a few pixels whose dy flips) in a third
+        # of the runs, everything else by 4e-7.  A wrong replay (a layer missing, act' applied twice) is an O(1) error.
+        assert float((a - b).abs().max()) / scale < (1e-4 if math == "fp32" else 2e-2)
+        rms = float((a - b).double().pow(2).mean().sqrt()) / (float(b.double().pow(2).mean().sqrt()) + 1e-20)
+        assert rms < (1e-4 if math == "fp32" else 6e-3), rms
     net.module.grad_sync = None
     # the C side's final-layer report: monotone, complete after the last run
     L = hip.lib()
