@@ -800,7 +800,8 @@ extern "C" int pws_netg_pack_weights(const float *const *params, float *packed, 
         a.params[2 * i] = params[2 * i], a.params[2 * i + 1] = params[2 * i + 1];
         const PackLayer &p = a.layer[i];
         a.first_block[i] = nb;
-        nb += (unsigned)(((size_t)p.planes * p.cin_pad * p.cout + p.cout + 255) / 256);
+        if (pack_tiled(p.kind)) nb += pack_tiles(p.kind, p.cin_pad, p.cout, p.k) + (unsigned)((p.cout + 255) / 256);   // tiles + bias blocks
+        else nb += (unsigned)(((size_t)p.planes * p.cin_pad * p.cout + p.cout + 255) / 256);
         a.first_block_wino[i] = nbw;
         if (p.ww_off != kNoOff || p.wr_off != kNoOff) nbw += (unsigned)(((size_t)p.cin_pad * p.cout + 255) / 256);
         Bf16Layer &q = b.layer[i];
@@ -837,7 +838,8 @@ extern "C" int pws_netg_pack_weights_dgrad(const float *const *params, float *pa
         b.first_block[i] = nbb;
         if (p.dg_off == kNoOff) continue;
         PWS_REQUIRE(params[2 * i], "pws_netg_pack_weights_dgrad: params[%d] is NULL", 2 * i);
-        nb += (unsigned)(((size_t)p.dg_taps * p.cin * p.cout + 255) / 256);
+        if (pack_tiled(p.kind)) nb += pack_tiles(p.kind, p.cin, p.cout, p.k);
+        else nb += (unsigned)(((size_t)p.dg_taps * p.cin * p.cout + 255) / 256);
         q.planes = p.dg_taps, q.krows = p.cout, q.ncols = p.cin, q.kpad = (p.cout + 31) / 32 * 32, q.npad = (p.cin + 63) / 64 * 64;
         q.src_off = p.dg_off, q.dst_off = off32(L[i].dgb_off);
         if (q.dst_off != kNoOff) nbb += (unsigned)(q.planes * (q.kpad / 32) * (q.npad / 64));
@@ -924,7 +926,8 @@ extern "C" int pws_netg_unpack_grads(const float *dpacked, float *const *grads, 
         a.grads[2 * i] = grads[2 * i], a.grads[2 * i + 1] = grads[2 * i + 1];
         const PackLayer &p = a.layer[i];
         a.first_block[i] = nb;
-        if (grads[2 * i]) nb += (unsigned)(((size_t)p.k * p.k * p.cin * p.cout + p.cout + 255) / 256);
+        if (grads[2 * i] && pack_tiled(p.kind)) nb += pack_tiles(p.kind, p.cin, p.cout, p.k) + (unsigned)((p.cout + 255) / 256);
+        else if (grads[2 * i]) nb += (unsigned)(((size_t)p.k * p.k * p.cin * p.cout + p.cout + 255) / 256);
     }
     a.total_blocks = nb;
     if (nb == 0) return PWS_OK;

@@ -41,6 +41,25 @@ struct Bf16AllArgs {
     Bf16Layer layer[kPackMaxLayers];
 };
 
+// The big layers (the five conv kinds of the encoder / decoder) are repacked tile by tile through LDS: a workgroup moves TA x 32
+// (first x second torch dimension) x all k*k taps, reading the torch tensor in runs of 32 * k*k floats and writing the packed one in runs
+// of TA or 32 floats -- both sides coalesced (netg_pack.hip).  The heads' small tensors keep the one-thread-per-element path.
+#ifdef __HIPCC__
+#define PWS_PACK_HD __host__ __device__
+#else
+#define PWS_PACK_HD
+#endif
+PWS_PACK_HD static inline bool pack_tiled(int kind) {
+    return kind == PWS_CONV_K3S1 || kind == PWS_CONV_K3S2 || kind == PWS_CONV_K5S1 || kind == PWS_CONVT_K3S1 || kind == PWS_CONVT_K4S2;
+}
+PWS_PACK_HD static inline bool pack_iohw(int kind) { return kind == PWS_CONVT_K3S1 || kind == PWS_CONVT_K4S2; }   // torch layout [cin][cout][k][k]
+PWS_PACK_HD static inline int pack_tile_a(int kk) { return kk <= 9 ? 32 : (kk <= 16 ? 16 : 8); }
+// tiles of a layer: first torch dimension A in steps of TA, second B in steps of 32 (cin counted up to cin_pad where it is padded)
+PWS_PACK_HD static inline unsigned pack_tiles(int kind, int cin_rows, int cout, int k) {
+    const int A = pack_iohw(kind) ? cin_rows : cout, B = pack_iohw(kind) ? cout : cin_rows, ta = pack_tile_a(k * k);
+    return (unsigned)(((A + ta - 1) / ta) * ((B + 31) / 32));
+}
+
 static_assert(sizeof(PackAllArgs) <= 4096 && sizeof(UnpackAllArgs) <= 4096 && sizeof(Bf16AllArgs) <= 4096,
               "kernel argument blocks are limited to 4 KB");
 

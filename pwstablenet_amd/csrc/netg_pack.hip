@@ -34,10 +34,109 @@ __device__ __forceinline__ float torch_weight_at(const float *w, int kind, int c
     return w[(((size_t)co * cin + ci) * k + ky) * k + kx];
 }
 
+// ---- tiled repacking of the big layers (pack_tiled, netg_pack.h; one thread per packed element read a 4-byte value per lane out of
+// lines k*k*cin floats apart: pack / data-gradient pack / unpack of the 48.5 M weights 234 / 282 / 242 us -> 200 / 195 / 169 us).  Tile image in LDS: L[a][b][q] = torch element (a0 + a, b0 + b, tap q),
+// pitches PB = kk | 1 (odd) and PA = 32 PB + 1 (odd): walking a or b with the lanes is conflict-free.
+constexpr int kPackTileFloats = 32 * (32 * 9 + 1);   // 9 taps: 32 x 32 x 9; 16 taps: 16 x 32 x 16; 25 taps: 8 x 32 x 25 -- all <= this
+struct PackTile {
+    int A, B, kk, TA, PB, PA, a0, b0;
+    bool iohw;
+};
+// rows: the extent of the cin dimension the tiles cover (cin_pad for the forward layout, cin else)
+__device__ __forceinline__ PackTile pack_tile_of(const PackLayer &L, unsigned b, int rows) {
+    PackTile t;
+    t.iohw = L.kind == PWS_CONVT_K3S1 || L.kind == PWS_CONVT_K4S2;
+    t.kk = L.k * L.k;
+    t.A = t.iohw ? rows : L.cout, t.B = t.iohw ? L.cout : rows;
+    t.TA = pack_tile_a(t.kk), t.PB = t.kk | 1, t.PA = 32 * t.PB + 1;
+    const unsigned tiles_b = (unsigned)((t.B + 31) / 32);
+    t.a0 = (int)(b / tiles_b) * t.TA, t.b0 = (int)(b % tiles_b) * 32;
+    return t;
+}
+// torch tensor -> tile (coalesced runs of 32 * kk floats); elements outside [A_real x B_real] are zeros.  KK = taps (compile time:
+// the index arithmetic per element is divisions by constants)
+template <int KK>
+__device__ __forceinline__ void pack_tile_load_k(const PackTile &t, const float *__restrict__ w, int A_real, int B_real, float *lds) {
+    constexpr int TA = KK <= 9 ? 32 : (KK <= 16 ? 16 : 8), PB = KK | 1, PA = 32 * PB + 1;
+    for (int i = threadIdx.x; i < TA * 32 * KK; i += 256) {
+        const int a = i / (32 * KK), rem = i - a * 32 * KK;
+        const int b = rem / KK, q = rem - b * KK;
+        const int ga = t.a0 + a, gb = t.b0 + b;
+        lds[a * PA + b * PB + q] = (ga < A_real && gb < B_real) ? w[((size_t)ga * B_real + gb) * KK + q] : 0.f;
+    }
+}
+__device__ __forceinline__ void pack_tile_load(const PackTile &t, const float *__restrict__ w, int A_real, int B_real, float *lds) {
+    if (t.kk == 9) pack_tile_load_k<9>(t, w, A_real, B_real, lds);
+    else if (t.kk == 16) pack_tile_load_k<16>(t, w, A_real, B_real, lds);
+    else pack_tile_load_k<25>(t, w, A_real, B_real, lds);
+}
+// tile -> torch tensor
+template <int KK>
+__device__ __forceinline__ void pack_tile_store_k(const PackTile &t, float *__restrict__ w, int A_real, int B_real, const float *lds) {
+    constexpr int TA = KK <= 9 ? 32 : (KK <= 16 ? 16 : 8), PB = KK | 1, PA = 32 * PB + 1;
+    for (int i = threadIdx.x; i < TA * 32 * KK; i += 256) {
+        const int a = i / (32 * KK), rem = i - a * 32 * KK;
+        const int b = rem / KK, q = rem - b * KK;
+        const int ga = t.a0 + a, gb = t.b0 + b;
+        if (ga < A_real && gb < B_real) w[((size_t)ga * B_real + gb) * KK + q] = lds[a * PA + b * PB + q];
+    }
+}
+__device__ __forceinline__ void pack_tile_store(const PackTile &t, float *__restrict__ w, int A_real, int B_real, const float *lds) {
+    if (t.kk == 9) pack_tile_store_k<9>(t, w, A_real, B_real, lds);
+    else if (t.kk == 16) pack_tile_store_k<16>(t, w, A_real, B_real, lds);
+    else pack_tile_store_k<25>(t, w, A_real, B_real, lds);
+}
+// tap q of the torch tensor that plane t of the forward packed layout holds (torch_weight_at)
+__device__ __forceinline__ int pack_fwd_tap(int kind, int k, int t) {
+    if (kind == PWS_CONVT_K4S2) {
+        const int tap = t & 3, cls = t >> 2;
+        return (3 - (cls >> 1) - 2 * (tap >> 1)) * 4 + (3 - (cls & 1) - 2 * (tap & 1));
+    }
+    if (kind == PWS_CONVT_K3S1) return (2 - t / 3) * 3 + (2 - t % 3);
+    return t;
+}
+// tap q of the torch tensor that plane t of the data-gradient layout holds, or -1 (a zero plane element)
+__device__ __forceinline__ int pack_dgrad_tap(int kind, int t) {
+    if (kind == PWS_CONV_K3S1) return (2 - t / 3) * 3 + (2 - t % 3);
+    if (kind == PWS_CONVT_K3S1) return t;
+    if (kind == PWS_CONV_K3S2) {
+        const int tap = t & 3, cls = t >> 2;
+        const int dy = tap >> 1, dx = tap & 1, py = cls >> 1, px = cls & 1;
+        const int ry = py ? (dy ? 0 : 2) : (dy ? -1 : 1), rx = px ? (dx ? 0 : 2) : (dx ? -1 : 1);
+        return (ry >= 0 && rx >= 0) ? ry * 3 + rx : -1;
+    }
+    return t;   // PWS_CONVT_K4S2
+}
+
 // ---- stage 1: torch layouts -> forward packed fp32 [class*tap][cin_pad][cout] (+ bias), all layers
 __global__ void __launch_bounds__(256) pack_all_kernel(const PackAllArgs a, float *__restrict__ packed) {
+    __shared__ float lds[kPackTileFloats];
     const int l = find_layer(a.first_block, a.nlayers, blockIdx.x);
     const PackLayer &L = a.layer[l];
+    if (pack_tiled(L.kind)) {
+        const unsigned b = blockIdx.x - a.first_block[l];
+        const unsigned ntiles = pack_tiles(L.kind, L.cin_pad, L.cout, L.k);
+        if (b >= ntiles) {   // the bias blocks behind the tiles
+            const unsigned i = (b - ntiles) * 256 + threadIdx.x;
+            if (i < (unsigned)L.cout) packed[L.b_off + i] = a.params[2 * l + 1][i];
+            return;
+        }
+        const PackTile t = pack_tile_of(L, b, L.cin_pad);
+        pack_tile_load(t, a.params[2 * l], t.iohw ? L.cin : L.cout, t.iohw ? L.cout : L.cin, lds);
+        __syncthreads();
+        // packed [plane][ci][co]: lanes walk co (torch dimension a for OIHW, b for IOHW)
+        const int nf = t.iohw ? 32 : t.TA, ns = t.iohw ? t.TA : 32;   // fast (co) / slow (ci) extents of the tile
+        const int lf = 31 - __builtin_clz((unsigned)nf), ls = 31 - __builtin_clz((unsigned)ns);
+        const int n = L.planes * ns * nf;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int f = i & (nf - 1), s_ = (i >> lf) & (ns - 1), pl = i >> (lf + ls);   // nf, ns: powers of two
+            const int q = pack_fwd_tap(L.kind, L.k, pl);
+            const int la = t.iohw ? s_ : f, lb = t.iohw ? f : s_;
+            const int ci = (t.iohw ? t.a0 : t.b0) + s_, co = (t.iohw ? t.b0 : t.a0) + f;
+            if (ci < L.cin_pad && co < L.cout) packed[L.w_off + ((size_t)pl * L.cin_pad + ci) * L.cout + co] = lds[la * t.PA + lb * t.PB + q];
+        }
+        return;
+    }
     const size_t idx = (size_t)(blockIdx.x - a.first_block[l]) * 256 + threadIdx.x;
     const size_t wtotal = (size_t)L.planes * L.cin_pad * L.cout;
     if (idx < wtotal) {
@@ -113,9 +212,28 @@ __global__ void __launch_bounds__(256) bf16_all_kernel(const Bf16AllArgs a, cons
 
 // ---- data-gradient fp32 layouts [tap][cout_f][cin_f] of all layers that have one (pack.hip: pack_dgrad_kernel)
 __global__ void __launch_bounds__(256) dgrad_all_kernel(const PackAllArgs a, float *__restrict__ packed_dgrad) {
+    __shared__ float lds[kPackTileFloats];
     const int l = find_layer(a.first_block_dgrad, a.nlayers, blockIdx.x);
     const PackLayer &L = a.layer[l];
     if (L.dg_off == kNoOff) return;
+    if (pack_tiled(L.kind)) {
+        const PackTile t = pack_tile_of(L, blockIdx.x - a.first_block_dgrad[l], L.cin);
+        pack_tile_load(t, a.params[2 * l], t.A, t.B, lds);
+        __syncthreads();
+        // [plane][co][ci]: lanes walk ci (torch dimension b for OIHW, a for IOHW)
+        const int nf = t.iohw ? t.TA : 32, ns = t.iohw ? 32 : t.TA;
+        const int lf = 31 - __builtin_clz((unsigned)nf), ls = 31 - __builtin_clz((unsigned)ns);
+        const int n = L.dg_taps * ns * nf;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int f = i & (nf - 1), s_ = (i >> lf) & (ns - 1), pl = i >> (lf + ls);
+            const int q = pack_dgrad_tap(L.kind, pl);
+            const int la = t.iohw ? f : s_, lb = t.iohw ? s_ : f;
+            const int ci = (t.iohw ? t.a0 : t.b0) + f, co = (t.iohw ? t.b0 : t.a0) + s_;
+            if (ci < L.cin && co < L.cout)
+                packed_dgrad[L.dg_off + ((size_t)pl * L.cout + co) * L.cin + ci] = q >= 0 ? lds[la * t.PA + lb * t.PB + q] : 0.f;
+        }
+        return;
+    }
     const size_t idx = (size_t)(blockIdx.x - a.first_block_dgrad[l]) * 256 + threadIdx.x;
     const size_t total = (size_t)L.dg_taps * L.cin * L.cout;
     if (idx >= total) return;
@@ -146,8 +264,33 @@ __global__ void __launch_bounds__(256) dgrad_all_kernel(const PackAllArgs a, flo
 
 // ---- gradients: packed layout -> the 92 torch-layout tensors (pack.hip: unpack_weight_kernel) + biases
 __global__ void __launch_bounds__(256) unpack_all_kernel(const UnpackAllArgs a, const float *__restrict__ dpacked) {
+    __shared__ float lds[kPackTileFloats];
     const int l = find_layer(a.first_block, a.nlayers, blockIdx.x);
     const PackLayer &L = a.layer[l];
+    if (pack_tiled(L.kind)) {
+        const unsigned b = blockIdx.x - a.first_block[l];
+        const unsigned ntiles = pack_tiles(L.kind, L.cin, L.cout, L.k);
+        if (b >= ntiles) {   // the bias blocks behind the tiles
+            const unsigned i = (b - ntiles) * 256 + threadIdx.x;
+            if (i < (unsigned)L.cout) a.grads[2 * l + 1][i] = dpacked[L.b_off + i];
+            return;
+        }
+        const PackTile t = pack_tile_of(L, b, L.cin);
+        // packed [plane][ci][co] -> tile: lanes walk co; every tap q of the torch tensor lies in exactly one plane
+        const int nf = t.iohw ? 32 : t.TA, ns = t.iohw ? t.TA : 32;
+        const int lf = 31 - __builtin_clz((unsigned)nf), ls = 31 - __builtin_clz((unsigned)ns);
+        const int n = L.planes * ns * nf;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int f = i & (nf - 1), s_ = (i >> lf) & (ns - 1), pl = i >> (lf + ls);
+            const int q = pack_fwd_tap(L.kind, L.k, pl);
+            const int la = t.iohw ? s_ : f, lb = t.iohw ? f : s_;
+            const int ci = (t.iohw ? t.a0 : t.b0) + s_, co = (t.iohw ? t.b0 : t.a0) + f;
+            lds[la * t.PA + lb * t.PB + q] = (ci < L.cin && co < L.cout) ? dpacked[L.w_off + ((size_t)pl * L.cin_pad + ci) * L.cout + co] : 0.f;
+        }
+        __syncthreads();
+        pack_tile_store(t, a.grads[2 * l], t.A, t.B, lds);
+        return;
+    }
     const size_t idx = (size_t)(blockIdx.x - a.first_block[l]) * 256 + threadIdx.x;
     const int k = L.k, cin = L.cin, cout = L.cout, kind = L.kind;
     const size_t wtotal = (size_t)k * k * cin * cout;
