@@ -72,6 +72,8 @@ def parse():
                     help="conv arithmetic of the TIMED region (default fp32 = configs[1], the headline); bf16 is for profiling the "
                          "bf16 path: metric/dtype fields say so and vs_baseline stays null")
     ap.add_argument("--no-extra", action="store_true", help="skip the bf16 inference / training-step legs (extra JSON fields)")
+    ap.add_argument("--ddp-items", type=int, default=32, help="item pairs per GPU per step of the N>1 training leg (configs[3]: 32)")
+    ap.add_argument("--stream-frames", type=int, default=128, help="720p frames per GPU of the N>1 streaming leg (configs[4])")
     return ap.parse_args()
 
 
@@ -760,20 +762,30 @@ def main():
         # gradients per step.  Every rank takes part; a watchdog keeps a stuck collective from costing the headline.
         import threading
         done = threading.Event()
+        limit = float(os.environ.get("PWS_BENCH_WATCHDOG_S", "300"))   # (the variable is a test hook)
+        # rank 0 arrives here after its single-rank legs (rooflines, CPU baseline): until every rank has arrived the deadline
+        # covers that section too; from the rendezvous on, `limit` seconds on every rank (the others a little later, so that
+        # rank 0's line is out before a non-zero exit of another rank makes the launcher end the job)
+        deadline = [time.time() + limit + 900.0]
 
         def watchdog():
-            if not done.wait(300.0):
-                if rank == 0:
-                    line["training_ddp"] = {"error": "did not finish within 300 s"}
-                    print(json.dumps(line), flush=True)
-                os._exit(0)
+            # a stuck collective must not cost the headline LINE (rank 0 still prints it, with the error), but it is a failure:
+            # the process exits non-zero so that no driver mistakes a hung RCCL run for a clean one
+            while not done.wait(min(1.0, max(0.001, limit / 4))):
+                if time.time() > deadline[0]:
+                    if rank == 0:
+                        line["training_ddp"] = {"error": "did not finish within %g s (watchdog; exit code 3)" % limit}
+                        print(json.dumps(line), flush=True)
+                    os._exit(3)
         threading.Thread(target=watchdog, daemon=True).start()
+        dist.barrier()
+        deadline[0] = time.time() + limit + (0.0 if rank == 0 else 20.0)
         # configs[4] on this node, PCIe inclusive: every rank stabilises its own shard of 128 decoded uint8 720p frames from
         # pinned host memory to pinned host memory (VideoStabilizer.run_video: frames up, window planes + generator + fused warp
         # + 2x down-scale on the device, 640x360 frames down); no collective, the host's PCIe / memory system is shared
         try:
             from pwstablenet_amd.stream import VideoStabilizer
-            Ts = 128
+            Ts = a.stream_frames
             net.module.enable_graph(False)
             net.module.set_math("fp32")
             u8_h = torch.randint(0, 256, (Ts, 720, 1280, 3), dtype=torch.uint8).pin_memory()
@@ -804,7 +816,8 @@ def main():
                 nbytes[0] = sum(p.grad.numel() * 4 for p in params if p.grad is not None)
                 D.allreduce_gradients(params)
             dist.barrier()
-            dt, loss = configs2_step_leg(net, dev, 32, "bf16", 3, sync=sync, seed=500 + rank)
+            NI = a.ddp_items
+            dt, loss = configs2_step_leg(net, dev, NI, "bf16", 3, sync=sync, seed=500 + rank)
             t = torch.tensor([dt], device=ctl_device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -812,7 +825,7 @@ def main():
             # gradients that are final after each run are all-reduced on a second stream while the next run computes)
             gs = D.enable_overlapped_grad_sync(net, nparts=4)
             dist.barrier()
-            dt_ov, _ = configs2_step_leg(net, dev, 32, "bf16", 3, sync=None, seed=500 + rank)
+            dt_ov, _ = configs2_step_leg(net, dev, NI, "bf16", 3, sync=None, seed=500 + rank)
             ncoll = gs.collectives
             net.module.grad_sync = None
             t = torch.tensor([dt_ov], device=ctl_device, dtype=torch.float64)
@@ -829,12 +842,14 @@ def main():
             ar = (time.perf_counter() - t1) / 5
             if rank == 0:
                 line["training_ddp"] = {
-                    "workload": "configs[3]: 32 item pairs per GPU per step (64 netG forwards + objective + backward), bf16 math, "
-                                "gradient all-reduce over RCCL in 64 MB flat buckets, fused Adam; weak scaling",
-                    "items_per_s": round(world * 32 / min(dt, dt_ov), 1), "ms_per_step": round(1e3 * min(dt, dt_ov), 2),
+                    "workload": "configs[3]: %d item pairs per GPU per step (%d netG forwards + objective + backward), bf16 math, "
+                                "gradient all-reduce over %s in 64 MB flat buckets, fused Adam; weak scaling"
+                                % (NI, 2 * NI, "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (test hook)"),
+                    "items_per_gpu_per_step": NI,
+                    "items_per_s": round(world * NI / min(dt, dt_ov), 1), "ms_per_step": round(1e3 * min(dt, dt_ov), 2),
                     "ms_per_step_allreduce_after_backward": round(1e3 * dt, 2),
                     "ms_per_step_allreduce_overlapped": round(1e3 * dt_ov, 2), "overlapped_collectives_per_step": ncoll,
-                    "tflops_per_gpu": round(64 / min(dt, dt_ov) * GFLOP_PER_SAMPLE_TRAIN / 1e3, 1), "loss_g_rank0": round(loss, 4),
+                    "tflops_per_gpu": round(2 * NI / min(dt, dt_ov) * GFLOP_PER_SAMPLE_TRAIN / 1e3, 1), "loss_g_rank0": round(loss, 4),
                     "allreduce_bytes": nbytes[0], "allreduce_alone_ms": round(1e3 * ar, 3),
                     "allreduce_bus_gb_per_s": round(2.0 * (world - 1) / world * nbytes[0] / ar / 1e9, 1)}
         except Exception as e:

@@ -311,6 +311,14 @@ int pws_grid_sample_bwd(const float *gout, const float *input, const float *grid
 /* Bilinear resize with align_corners=True of an NCHW tensor (reference resizes the field as NCHW). */
 int pws_upsample_bilinear_ac(const float *in, float *out, int n, int c, int h, int w, int ho, int wo,
                              pws_stream_t stream);
+/* Adjoint of pws_upsample_bilinear_ac: gin[n,c,h,w] (overwritten) from gout[n,c,ho,wo]; deterministic gather.  autograd of
+ * torch.nn.UpsamplingBilinear2d when the reference's video loop runs with gradients enabled (main_new.py:697-710). */
+int pws_upsample_bilinear_ac_bwd(const float *gout, float *gin, int n, int c, int h, int w, int ho, int wo,
+                                 pws_stream_t stream);
+/* Adjoint of pws_affine_grid: gtheta[n,6] (overwritten) = sum over h,w of ggrid[n,h,w,:] (x) [x_w, y_h, 1]; autograd of
+ * F.affine_grid (lib/networks_cascading.py:164,188,210; main_new.py:195) for callers outside the fused field head. */
+int pws_affine_grid_bwd(const float *ggrid, float *gtheta, int n, int h, int w, int align_corners, pws_stream_t stream);
+
 /* Fused 720p path: field[n,fh,fw,2] is resized on the fly (align_corners=True) to (h,w) and applied to
  * input[n,c,h,w] -> out[n,c,h,w]; the resized field is never materialised. */
 int pws_upsample_grid_sample_fwd(const float *input, const float *field, float *out, int n, int c, int h,

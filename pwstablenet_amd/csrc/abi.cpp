@@ -9,7 +9,7 @@ int g_math = PWS_MATH_FP32;
 int g_store = PWS_STORE_FP32;
 int g_experiment = 0;
 bool g_prof_on = false;
-int g_prof_tag = -1;
+thread_local int g_prof_tag = -1;
 namespace {
 struct ProfEntry {
     hipEvent_t a, b;

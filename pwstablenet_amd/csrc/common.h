@@ -42,6 +42,23 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
     return base + slot;
 }
 
+// One-time launcher state (LDS opt-in via hipFuncSetAttribute, CU count) is per DEVICE: the attribute lands on the current
+// device's function object and two devices of one process may differ -- include/pwstable.h promises use on several devices.
+constexpr int kMaxDevices = 32;
+inline int current_device_slot() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return (int)((unsigned)d % kMaxDevices);
+}
+struct PerDeviceFlag {
+    bool v[kMaxDevices] = {};
+    bool &cur() { return v[current_device_slot()]; }
+};
+struct PerDeviceInt {
+    int v[kMaxDevices] = {};
+    int &cur() { return v[current_device_slot()]; }
+};
+
 // Kernel ids for the measurement hooks (pws_prof_*).
 enum KernelId {
     KID_CONV_K3S1_BIG = 0, KID_CONV_K3S1_SMALL, KID_CONV_K3S2_BIG, KID_CONV_K3S2_SMALL, KID_CONV_K5S1, KID_CONVT4_BIG,
@@ -54,7 +71,7 @@ extern int g_math;  // PWS_OPT_MATH
 extern int g_store;  // PWS_OPT_STORE (effective only with PWS_MATH_BF16)
 extern int g_experiment;  // PWS_OPT_EXPERIMENT: selects measured kernel variants (tools/*_bench.py); 0 = product default
 extern bool g_prof_on;
-extern int g_prof_tag;
+extern thread_local int g_prof_tag;  // the layer a launch belongs to, per calling thread
 void prof_begin(int kernel_id, double flops, double bytes, hipStream_t st);
 void prof_end(hipStream_t st);
 struct ProfScope {  // brackets one launch with events when profiling is enabled; free otherwise

@@ -557,7 +557,8 @@ __global__ void __launch_bounds__(256) cvt_f32_to_bf16_kernel(const float *__res
 // ------------------------------------------------------------------------------------------------ host side
 template <class C, bool IO16>
 static int launch_bf_io(ConvKParams &kp, hipStream_t st) {
-    static bool attr_set = false;  // benign race: idempotent
+    static PerDeviceFlag attr_set_dev;
+    bool &attr_set = attr_set_dev.cur();   // hipFuncSetAttribute acts on the CURRENT device's function object
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_kernel<C, IO16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -678,7 +679,8 @@ using B_K5S1_T256 = BfCfg<5, 1, 2, 0, 16, 16, 1, 32, 4, 1, 2, 2>;
 
 static int launch_k5(ConvKParams &kp, hipStream_t st, const ProfInfo &pi) {
     using C = B_K5S1_T256;
-    static bool attr_set = false;
+    static PerDeviceFlag attr_set_dev;
+    bool &attr_set = attr_set_dev.cur();   // hipFuncSetAttribute acts on the CURRENT device's function object
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_k5_kernel<C, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, K5Lds<C>::BYTES);

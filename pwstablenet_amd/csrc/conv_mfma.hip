@@ -288,7 +288,8 @@ int launch_splitk_reduce(const ConvKParams &kp, const float *partial, size_t tot
 // ------------------------------------------------------------------------------------------------ host side
 template <class C, int KID>
 static int launch_cfg(ConvKParams &kp, hipStream_t st, const ProfInfo &pi) {
-    static bool attr_set = false;  // benign race: idempotent
+    static PerDeviceFlag attr_set_dev;
+    bool &attr_set = attr_set_dev.cur();   // hipFuncSetAttribute acts on the CURRENT device's function object
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<C>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);

@@ -325,7 +325,8 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ringf_kernel(const RingfPa
 // ------------------------------------------------------------------------------------------------ host side
 template <class C>
 static int ringf_launch(RingfParams &rp, hipStream_t st) {
-    static bool attr_set = false;   // benign race: idempotent
+    static PerDeviceFlag attr_set_dev;
+    bool &attr_set = attr_set_dev.cur();   // hipFuncSetAttribute acts on the CURRENT device's function object
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ringf_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            C::LDS_BYTES);
@@ -335,7 +336,8 @@ static int ringf_launch(RingfParams &rp, hipStream_t st) {
         }
         attr_set = true;
     }
-    static int ncu = 0;
+    static PerDeviceInt ncu_dev;
+    int &ncu = ncu_dev.cur();
     if (ncu == 0) {
         int dev = 0;
         hipDeviceProp_t prop;

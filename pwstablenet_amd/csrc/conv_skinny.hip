@@ -198,7 +198,8 @@ __global__ void __launch_bounds__(256) conv_skinny_kernel(const SkParams p) {
 
 template <int MT_W, int NT_W, int WM>
 static int skinny_launch(const SkParams &p, unsigned grid, int lds_bytes, hipStream_t st) {
-    static bool attr_set = false;   // benign race: idempotent
+    static PerDeviceFlag attr_set_dev;
+    bool &attr_set = attr_set_dev.cur();   // hipFuncSetAttribute acts on the CURRENT device's function object
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_skinny_kernel<MT_W, NT_W, WM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024);

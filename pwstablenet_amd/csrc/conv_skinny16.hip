@@ -193,7 +193,8 @@ __global__ void __launch_bounds__(256) conv_skinny16_kernel(const Sk16Params p) 
 
 template <int MT_W, int NT_W, int WM, int MAXT>
 static int skinny16_launch(const Sk16Params &p, unsigned grid, int lds_bytes, hipStream_t st) {
-    static bool attr_set = false;   // benign race: idempotent
+    static PerDeviceFlag attr_set_dev;
+    bool &attr_set = attr_set_dev.cur();   // hipFuncSetAttribute acts on the CURRENT device's function object
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_skinny16_kernel<MT_W, NT_W, WM, MAXT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

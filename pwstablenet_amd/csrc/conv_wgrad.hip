@@ -209,7 +209,8 @@ struct WgChoice {
 
 template <class C>
 static int launch_wg(WgradParams &p, int nclasses, hipStream_t st) {
-    static bool attr_set = false;
+    static PerDeviceFlag attr_set_dev;
+    bool &attr_set = attr_set_dev.cur();   // hipFuncSetAttribute acts on the CURRENT device's function object
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_mfma_kernel<C>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);

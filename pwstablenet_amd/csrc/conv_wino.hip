@@ -369,7 +369,8 @@ static int wino_launch(WinoParams &p, int cout, const ProfHint &ph, hipStream_t 
     using G = WinoGeo<MODE>;
     p.tiles_x = (p.W + G::TW - 1) / G::TW, p.tiles_y = (p.H + G::TH - 1) / G::TH;
     p.ntiles = (unsigned)(p.tiles_x * p.tiles_y * p.N);
-    static bool attr_set = false;
+    static PerDeviceFlag attr_set_dev;
+    bool &attr_set = attr_set_dev.cur();   // hipFuncSetAttribute acts on the CURRENT device's function object
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_kernel<MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);

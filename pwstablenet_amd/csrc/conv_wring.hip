@@ -546,7 +546,8 @@ int wring_pack(const float *pk, float *ur, int cin_pad, int cout, int ct4, hipSt
 template <int MODE, int G16, int ABL>
 static int wring_launch(const WringParams &p, unsigned grid, hipStream_t st) {
     using G = WrGeo<MODE, G16>;
-    static bool attr_set = false;   // benign race: idempotent
+    static PerDeviceFlag attr_set_dev;
+    bool &attr_set = attr_set_dev.cur();   // hipFuncSetAttribute acts on the CURRENT device's function object
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_ring_kernel<MODE, G16, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            G::LDS_BYTES);
@@ -588,7 +589,8 @@ int wring_try(const pws_conv_args *a, const ProfHint &ph, hipStream_t st) {
     p.ur = a->w_wring, p.ur_bytes = (unsigned)ur_bytes;
     p.bias = a->bias, p.act = a->act, p.out = a->out, p.out_ld = a->out_ld;
     p.tiles_x = g16 ? 1 : a->w / WR_TW, p.tiles_y = a->h / WR_TH;
-    static int ncu = 0;
+    static PerDeviceInt ncu_dev;
+    int &ncu = ncu_dev.cur();
     if (ncu == 0) {
         int dev = 0;
         hipDeviceProp_t prop;

@@ -308,18 +308,89 @@ __global__ void affine_grid_kernel(const float *__restrict__ theta, float *__res
 }
 
 // ---------------------------------------------------------------------------------------------- upsample (ac=True)
+// Source index of an output pixel as torch computes it: scale * index ROUNDED to fp32, then split into floor and fraction.
+// hipcc contracts a plain `scale * index - floor` into one fma (the exact product: the fraction moves by up to an ulp of the
+// index, 1.5e-5 at 255, i.e. 5e-5 on the interpolated value) -- __fmul_rn does not stop it (it inlines to an fmul that carries
+// the contract flag); the empty asm pins the rounded product in a register.
+__device__ __forceinline__ float mul_rounded(float a, float b) {
+    float p = a * b;
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
 __global__ void upsample_bilinear_ac_kernel(const float *__restrict__ in, float *__restrict__ out, int H, int W, int Ho,
                                             int Wo, float ry, float rx, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int ox = (int)(i % Wo), oy = (int)((i / Wo) % Ho);
     const size_t nc = i / ((size_t)Wo * Ho);
-    const float sy = ry * oy, sx = rx * ox;
+    const float sy = mul_rounded(ry, (float)oy), sx = mul_rounded(rx, (float)ox);
     const int y0 = (int)sy, x0 = (int)sx;
     const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
     const float ly = sy - y0, hy = 1.f - ly, lx = sx - x0, hx = 1.f - lx;
     const float *ip = in + nc * (size_t)H * W;
     out[i] = hy * (hx * ip[y0 * W + x0] + lx * ip[y0 * W + x1]) + ly * (hx * ip[y1 * W + x0] + lx * ip[y1 * W + x1]);
+}
+
+// Adjoint of the resize above (autograd of UpsamplingBilinear2d when the driver's video loop runs with gradients enabled,
+// reference main_new.py:697-710 has no no_grad): one lane per INPUT element gathers the output elements whose taps touch it,
+// re-deriving every output's (y0, y1, ly) with the forward's own arithmetic, so the two are exact adjoints and the sum is
+// deterministic (no atomics).
+__global__ void upsample_bilinear_ac_bwd_kernel(const float *__restrict__ gout, float *__restrict__ gin, int H, int W, int Ho,
+                                                int Wo, float ry, float rx, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const size_t nc = i / ((size_t)W * H);
+    // outputs with ry*oy in (y-1, y+1), widened by one on both sides against rounding; membership is re-checked below
+    int oy_lo = 0, oy_hi = Ho - 1, ox_lo = 0, ox_hi = Wo - 1;
+    if (ry > 0.f) oy_lo = max(0, (int)floorf((float)(y - 1) / ry) - 1), oy_hi = min(Ho - 1, (int)ceilf((float)(y + 1) / ry) + 1);
+    if (rx > 0.f) ox_lo = max(0, (int)floorf((float)(x - 1) / rx) - 1), ox_hi = min(Wo - 1, (int)ceilf((float)(x + 1) / rx) + 1);
+    const float *gp = gout + nc * (size_t)Ho * Wo;
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        const float sy = mul_rounded(ry, (float)oy);
+        const int y0 = (int)sy, y1 = y0 + (y0 < H - 1 ? 1 : 0);
+        const float ly = sy - y0;
+        const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+        if (wy == 0.f) continue;
+        float row = 0.f;
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            const float sx = mul_rounded(rx, (float)ox);
+            const int x0 = (int)sx, x1 = x0 + (x0 < W - 1 ? 1 : 0);
+            const float lx = sx - x0;
+            const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+            row = fmaf(wx, gp[(size_t)oy * Wo + ox], row);
+        }
+        acc = fmaf(wy, row, acc);
+    }
+    gin[i] = acc;
+}
+
+// Adjoint of affine_grid: gtheta[n] = sum_{h,w} ggrid[n,h,w,:] (x) [x_w, y_h, 1]  (autograd of F.affine_grid when theta carries a
+// gradient).  One workgroup per sample, fp64 partial sums per lane, LDS tree: deterministic.
+__global__ void __launch_bounds__(256) affine_grid_bwd_kernel(const float *__restrict__ ggrid, float *__restrict__ gtheta, int H,
+                                                              int W, int ac) {
+    const int n = blockIdx.x;
+    const float2 *g = reinterpret_cast<const float2 *>(ggrid) + (size_t)n * H * W;
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (int p = threadIdx.x; p < H * W; p += 256) {
+        const float x = base_coord(p % W, W, ac != 0), y = base_coord(p / W, H, ac != 0);
+        const float2 v = g[p];
+        s[0] += (double)v.x * x, s[1] += (double)v.x * y, s[2] += v.x;
+        s[3] += (double)v.y * x, s[4] += (double)v.y * y, s[5] += v.y;
+    }
+    __shared__ double red[6][256];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) red[k][threadIdx.x] = s[k];
+    __syncthreads();
+    for (int step = 128; step > 0; step >>= 1) {
+        if ((int)threadIdx.x < step)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + step];
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) gtheta[(size_t)n * 6 + threadIdx.x] = (float)red[threadIdx.x][0];
 }
 
 // ---------------------------------------------------------------------------------------------- fused 720p path
@@ -340,14 +411,14 @@ __global__ void __launch_bounds__(256) upsample_grid_sample_fwd_kernel(const flo
     const int n = (int)(p0 / HW);
     const int hw = (int)(p0 % HW);
     const int oy = hw / W, ox0 = hw % W;  // W % PPT == 0: the group stays inside one row
-    const float sy = ry * oy;
+    const float sy = mul_rounded(ry, (float)oy);
     const int y0 = (int)sy, y1 = y0 + (y0 < fh - 1 ? 1 : 0);
     const float ly = sy - y0, hy = 1.f - ly;
     const float2 *f0 = reinterpret_cast<const float2 *>(field) + ((size_t)n * fh + y0) * fw;
     const float2 *f1 = reinterpret_cast<const float2 *>(field) + ((size_t)n * fh + y1) * fw;
     Taps2 t[PPT];
     if constexpr (NARROW) {
-        const int cb = (int)(rx * ox0);  // first column this lane can touch; it needs cb .. cb+2 at most
+        const int cb = (int)mul_rounded(rx, (float)ox0);  // first column this lane can touch; it needs cb .. cb+2 at most
         float2 r0[3], r1[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -356,7 +427,7 @@ __global__ void __launch_bounds__(256) upsample_grid_sample_fwd_kernel(const flo
         }
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
-            const float sx = rx * (ox0 + i);
+            const float sx = mul_rounded(rx, (float)(ox0 + i));
             const int x0 = (int)sx;
             const float lx = sx - x0, hx = 1.f - lx;
             const bool second = x0 > cb;  // x0 - cb is 0 or 1; x1 = min(x0 + 1, fw - 1) is column x0 - cb + 1 (clamped loads)
@@ -369,7 +440,7 @@ __global__ void __launch_bounds__(256) upsample_grid_sample_fwd_kernel(const flo
     } else {
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
-            const float sx = rx * (ox0 + i);
+            const float sx = mul_rounded(rx, (float)(ox0 + i));
             const int x0 = (int)sx, x1 = x0 + (x0 < fw - 1 ? 1 : 0);
             const float lx = sx - x0, hx = 1.f - lx;
             const float2 a = f0[x0], b = f0[x1], c = f1[x0], d = f1[x1];
@@ -427,14 +498,14 @@ __global__ void __launch_bounds__(256) upsample_grid_sample_u8_kernel(const unsi
     const int n = (int)(p0 / HW);
     const int hw = (int)(p0 % HW);
     const int oy = hw / W, ox0 = hw % W;  // W % 4 == 0: the group stays inside one row
-    const float sy = ry * oy;
+    const float sy = mul_rounded(ry, (float)oy);
     const int y0 = (int)sy, y1 = y0 + (y0 < fh - 1 ? 1 : 0);
     const float ly = sy - y0, hy = 1.f - ly;
     const float2 *f0 = reinterpret_cast<const float2 *>(field) + ((size_t)n * fh + y0) * fw;
     const float2 *f1 = reinterpret_cast<const float2 *>(field) + ((size_t)n * fh + y1) * fw;
     Taps2 t[PPT];
     if constexpr (NARROW) {
-        const int cb = (int)(rx * ox0);
+        const int cb = (int)mul_rounded(rx, (float)ox0);
         float2 r0[3], r1[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -443,7 +514,7 @@ __global__ void __launch_bounds__(256) upsample_grid_sample_u8_kernel(const unsi
         }
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
-            const float sx = rx * (ox0 + i);
+            const float sx = mul_rounded(rx, (float)(ox0 + i));
             const int x0 = (int)sx;
             const float lx = sx - x0, hx = 1.f - lx;
             const bool second = x0 > cb;
@@ -456,7 +527,7 @@ __global__ void __launch_bounds__(256) upsample_grid_sample_u8_kernel(const unsi
     } else {
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
-            const float sx = rx * (ox0 + i);
+            const float sx = mul_rounded(rx, (float)(ox0 + i));
             const int x0 = (int)sx, x1 = x0 + (x0 < fw - 1 ? 1 : 0);
             const float lx = sx - x0, hx = 1.f - lx;
             const float2 a = f0[x0], b = f0[x1], c = f1[x0], d = f1[x1];
@@ -576,6 +647,7 @@ extern "C" int pws_affine_grid(const float *theta, float *grid, int n, int h, in
     if (n == 0) return PWS_OK;
     PWS_REQUIRE(theta && grid, "pws_affine_grid: NULL pointer");
     const size_t total = (size_t)n * h * w;
+    ProfScope prof(KID_AFFINE_GRID, 0.0, 8.0 * (double)total, as_stream(stream));
     hipLaunchKernelGGL(affine_grid_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), theta, grid,
                        h, w, total, align_corners);
     return check_launch("affine_grid_kernel");
@@ -589,9 +661,35 @@ extern "C" int pws_upsample_bilinear_ac(const float *in, float *out, int n, int 
     const float ry = ho > 1 ? (float)(h - 1) / (float)(ho - 1) : 0.f;
     const float rx = wo > 1 ? (float)(w - 1) / (float)(wo - 1) : 0.f;
     const size_t total = (size_t)n * c * ho * wo;
+    ProfScope prof(KID_UPSAMPLE, 0.0, 4.0 * (double)total + 4.0 * (double)n * c * h * w, as_stream(stream));
     hipLaunchKernelGGL(upsample_bilinear_ac_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), in,
                        out, h, w, ho, wo, ry, rx, total);
     return check_launch("upsample_bilinear_ac_kernel");
+}
+
+extern "C" int pws_upsample_bilinear_ac_bwd(const float *gout, float *gin, int n, int c, int h, int w, int ho, int wo,
+                                            pws_stream_t stream) {
+    PWS_REQUIRE(n >= 0 && c > 0 && h > 0 && w > 0 && ho > 0 && wo > 0, "pws_upsample_bilinear_ac_bwd: bad shape");
+    if (n == 0) return PWS_OK;
+    PWS_REQUIRE(gout && gin, "pws_upsample_bilinear_ac_bwd: NULL pointer");
+    const float ry = ho > 1 ? (float)(h - 1) / (float)(ho - 1) : 0.f;
+    const float rx = wo > 1 ? (float)(w - 1) / (float)(wo - 1) : 0.f;
+    const size_t total = (size_t)n * c * h * w;
+    ProfScope prof(KID_UPSAMPLE, 0.0, 4.0 * (double)total + 4.0 * (double)n * c * ho * wo, as_stream(stream));
+    hipLaunchKernelGGL(upsample_bilinear_ac_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       gout, gin, h, w, ho, wo, ry, rx, total);
+    return check_launch("upsample_bilinear_ac_bwd_kernel");
+}
+
+extern "C" int pws_affine_grid_bwd(const float *ggrid, float *gtheta, int n, int h, int w, int align_corners,
+                                   pws_stream_t stream) {
+    PWS_REQUIRE(n >= 0 && h > 0 && w > 0, "pws_affine_grid_bwd: bad shape");
+    if (n == 0) return PWS_OK;
+    PWS_REQUIRE(ggrid && gtheta, "pws_affine_grid_bwd: NULL pointer");
+    ProfScope prof(KID_AFFINE_GRID, 0.0, 8.0 * (double)n * h * w, as_stream(stream));
+    hipLaunchKernelGGL(affine_grid_bwd_kernel, dim3((unsigned)n), dim3(256), 0, as_stream(stream), ggrid, gtheta, h, w,
+                       align_corners);
+    return check_launch("affine_grid_bwd_kernel");
 }
 
 extern "C" int pws_upsample_grid_sample_fwd(const float *input, const float *field, float *out, int n, int c, int h, int w,

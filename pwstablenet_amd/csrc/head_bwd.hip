@@ -365,7 +365,8 @@ int field_bwd_dx_dw(const float *x, int ld, const float *gz, int n, int h, int w
     if (dx) {
         PWS_REQUIRE(!io16 || (c % 8 == 0 && dx_ld % 8 == 0), "pws_field_head_bwd: bf16 storage needs c and dx_ld to be multiples of 8");
         if (io16) {
-            static bool attr_set = false;  // benign race: idempotent
+            static PerDeviceFlag attr_set_dev;
+            bool &attr_set = attr_set_dev.cur();   // hipFuncSetAttribute acts on the CURRENT device's function object
             constexpr int lds_bytes = 256 * FDX_PITCH * (int)sizeof(float);
             if (!attr_set) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&field_dx16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -369,7 +369,8 @@ struct WbChoice {
 
 template <class C>
 static int launch_wb(WgradBfParams &p, int nclasses, hipStream_t st) {
-    static bool attr_set = false;
+    static PerDeviceFlag attr_set_dev;
+    bool &attr_set = attr_set_dev.cur();   // hipFuncSetAttribute acts on the CURRENT device's function object
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_bf16_kernel<C, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);

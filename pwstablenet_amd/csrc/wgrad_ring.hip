@@ -276,7 +276,8 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
 
 template <class C>
 static int wrg_launch(WgradRingParams &p, int nclasses, hipStream_t st) {
-    static bool attr_set = false;   // benign race: idempotent
+    static PerDeviceFlag attr_set_dev;
+    bool &attr_set = attr_set_dev.cur();   // hipFuncSetAttribute acts on the CURRENT device's function object
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_ring_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) {
@@ -285,7 +286,8 @@ static int wrg_launch(WgradRingParams &p, int nclasses, hipStream_t st) {
         }
         attr_set = true;
     }
-    static int ncu = 0;
+    static PerDeviceInt ncu_dev;
+    int &ncu = ncu_dev.cur();
     if (ncu == 0) {
         int dev = 0;
         hipDeviceProp_t prop;

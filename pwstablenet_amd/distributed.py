@@ -95,12 +95,18 @@ def allreduce_gradients(params, bucket_bytes=64 << 20):
 def broadcast_parameters(netG, src=0, check=False):
     """Makes every rank start from rank ``src``'s generator: parameters AND buffers (BatchNorm running statistics) go out as
     ONE flat fp32 bucket (194 MB: a single large xGMI message, not 92 small ones) and are copied back in place (version
-    counters bump, so the packed-weight cache re-packs).  ``define_G`` initialises from the local torch RNG and a checkpoint
-    may have been loaded on one rank only: without this the replicas diverge silently.  The reference's ``nn.DataParallel``
-    re-broadcasts rank 0's parameters on every forward (lib/networks_cascading.py:51-52); one process per GPU does it once.
-    check=True: instead of overwriting, raise if this rank's values differ from ``src``'s.  Returns the number of floats."""
+    counters bump, so the packed-weight cache re-packs); integer buffers (BatchNorm's ``num_batches_tracked``) follow in a
+    second, int64 bucket.  ``define_G`` initialises from the local torch RNG and a checkpoint may have been loaded on one rank
+    only: without this the replicas diverge silently.  The reference's ``nn.DataParallel`` re-broadcasts rank 0's parameters on
+    every forward (lib/networks_cascading.py:51-52); one process per GPU does it once.
+    This is a COLLECTIVE: every rank of the default group must call it, with the tensors where the backend can reach them
+    (device-resident under RCCL -- call ``netG.cuda()`` first).
+    check=True: instead of overwriting, compare with ``src``'s values; the verdict is MAX-reduced, so EVERY rank raises together
+    if ANY rank differs (no rank runs on into the next collective and hangs).  Returns the number of floats."""
     target = getattr(netG, "module", netG)
-    tensors = list(target.parameters()) + [b for b in target.buffers() if b.dtype.is_floating_point]   # copy_ under no_grad bumps ._version
+    every = list(target.parameters()) + list(target.buffers())
+    tensors = [t for t in every if t.dtype.is_floating_point]   # copy_ under no_grad bumps ._version
+    ints = [t for t in every if not t.dtype.is_floating_point]
     if not tensors:
         return 0
     if not dist.is_initialized() or dist.get_world_size() == 1:
@@ -109,15 +115,27 @@ def broadcast_parameters(netG, src=0, check=False):
         flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors])
         mine = flat.clone() if check else None
         dist.broadcast(flat, src=src)
+        iflat = imine = None
+        if ints:
+            iflat = torch.cat([t.detach().reshape(-1).to(torch.int64) for t in ints])
+            imine = iflat.clone() if check else None
+            dist.broadcast(iflat, src=src)
         if check:
-            if not torch.equal(mine, flat):
-                raise RuntimeError("broadcast_parameters(check=True): rank %d's generator differs from rank %d's in %d values"
-                                   % (dist.get_rank(), src, int((mine != flat).sum())))
+            ndiff = int((mine != flat).sum()) + (int((imine != iflat).sum()) if ints else 0)
+            worst = torch.tensor([float(ndiff)], dtype=torch.float64, device=flat.device)
+            dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+            if float(worst.item()) > 0:
+                raise RuntimeError("broadcast_parameters(check=True): the replicas are not identical -- rank %d differs from rank "
+                                   "%d in %d values (worst rank: %d values)" % (dist.get_rank(), src, ndiff, int(worst.item())))
             return flat.numel()
         off = 0
         for t in tensors:
             t.copy_(flat[off:off + t.numel()].view_as(t))
             off += t.numel()
+        ioff = 0
+        for t in ints:
+            t.copy_(iflat[ioff:ioff + t.numel()].view_as(t).to(t.dtype))
+            ioff += t.numel()
     return off
 
 
@@ -147,7 +165,8 @@ class OverlappedGradSync:
 
 def enable_overlapped_grad_sync(netG, nparts=4, bucket_bytes=64 << 20, broadcast=True):
     """netG: what ``define_G`` returned (or its ``.module``).  Returns the OverlappedGradSync; ``netG.grad_sync = None`` turns
-    it off again.  broadcast: first make every replica equal to rank 0's (``broadcast_parameters``)."""
+    it off again.  broadcast: first make every replica equal to rank 0's (``broadcast_parameters`` -- a COLLECTIVE: every
+    rank must make this call, after ``netG.cuda()`` under RCCL; pass broadcast=False to attach the exchange without it)."""
     target = getattr(netG, "module", netG)
     if broadcast:
         broadcast_parameters(target, src=0)

@@ -54,28 +54,65 @@ def grid_sample(input, grid, mode="bilinear", padding_mode="zeros", align_corner
     return _GridSample.apply(input, grid, _ac(align_corners))
 
 
+class _AffineGrid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, theta, n, h, w, align_corners):
+        A.require_cuda(theta)
+        theta = theta.contiguous().view(n, 6)
+        grid = torch.empty((n, h, w, 2), device=theta.device, dtype=torch.float32)
+        A.check(A.lib().pws_affine_grid(A.ptr(theta), A.ptr(grid), n, h, w, align_corners, A.current_stream()), "pws_affine_grid")
+        ctx.dims = (n, h, w, align_corners)
+        return grid
+
+    @staticmethod
+    def backward(ctx, ggrid):
+        n, h, w, ac = ctx.dims
+        ggrid = ggrid.contiguous()
+        gtheta = torch.empty((n, 2, 3), device=ggrid.device, dtype=torch.float32)
+        A.check(A.lib().pws_affine_grid_bwd(A.ptr(ggrid), A.ptr(gtheta), n, h, w, ac, A.current_stream()), "pws_affine_grid_bwd")
+        return gtheta, None, None, None, None
+
+
 def affine_grid(theta, size, align_corners=None):
+    """F.affine_grid(theta (N,2,3), size (N,C,H,W)) -> (N,H,W,2) (reference lib/networks_cascading.py:164, main_new.py:195)."""
     A.require_cuda(theta)
+    if len(size) != 4:
+        raise NotImplementedError("affine_grid: 2-D grids only (size = (N, C, H, W))")
     n, h, w = int(size[0]), int(size[-2]), int(size[-1])
-    theta = theta.contiguous().view(n, 6)
-    if theta.requires_grad and torch.is_grad_enabled():
-        raise NotImplementedError("affine_grid: backward is provided through netG's fused field head only")
-    grid = torch.empty((n, h, w, 2), device=theta.device, dtype=torch.float32)
-    A.check(A.lib().pws_affine_grid(A.ptr(theta), A.ptr(grid), n, h, w, _ac(align_corners), A.current_stream()),
-            "pws_affine_grid")
-    return grid
+    if theta.numel() != n * 6:
+        raise RuntimeError("affine_grid: expected theta of shape (%d, 2, 3), got %s" % (n, tuple(theta.shape)))
+    return _AffineGrid.apply(theta, n, h, w, _ac(align_corners))
+
+
+class _UpsampleBilinearAC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ho, wo):
+        A.require_cuda(x)
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        out = torch.empty((n, c, ho, wo), device=x.device, dtype=torch.float32)
+        A.check(A.lib().pws_upsample_bilinear_ac(A.ptr(x), A.ptr(out), n, c, h, w, ho, wo, A.current_stream()),
+                "pws_upsample_bilinear_ac")
+        ctx.dims = (n, c, h, w, ho, wo)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        n, c, h, w, ho, wo = ctx.dims
+        gout = gout.contiguous()
+        gin = torch.empty((n, c, h, w), device=gout.device, dtype=torch.float32)
+        A.check(A.lib().pws_upsample_bilinear_ac_bwd(A.ptr(gout), A.ptr(gin), n, c, h, w, ho, wo, A.current_stream()),
+                "pws_upsample_bilinear_ac_bwd")
+        return gin, None, None
 
 
 def upsample_bilinear2d(x, size):
     """torch.nn.UpsamplingBilinear2d(size=size)(x): bilinear, align_corners=True (reference main_new.py:708)."""
-    A.require_cuda(x)
-    x = x.contiguous()
-    n, c, h, w = x.shape
-    ho, wo = int(size[0]), int(size[1])
-    out = torch.empty((n, c, ho, wo), device=x.device, dtype=torch.float32)
-    A.check(A.lib().pws_upsample_bilinear_ac(A.ptr(x), A.ptr(out), n, c, h, w, ho, wo, A.current_stream()),
-            "pws_upsample_bilinear_ac")
-    return out
+    if x.dim() != 4:
+        raise RuntimeError("upsample_bilinear2d: expected (N,C,H,W), got %s" % (tuple(x.shape),))
+    if isinstance(size, int):
+        size = (size, size)
+    return _UpsampleBilinearAC.apply(x, int(size[0]), int(size[1]))
 
 
 class UpsamplingBilinear2d(torch.nn.Module):

@@ -17,6 +17,7 @@ ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 OPT_TWO_QUEUES = 1
 OPT_MATH, MATH_FP32, MATH_BF16 = 2, 0, 1
 OPT_STORE, STORE_FP32, STORE_BF16 = 3, 0, 1
+OPT_EXPERIMENT = 100   # measured kernel variants (tools, per-path tests); 0 = product default
 OBJ_SLOTS = 64
 CONV_K3S1, CONV_K3S2, CONV_K5S1, CONVT_K3S1, CONVT_K4S2, CONV_K2S1P0, CONV_K1, CONV_K3S1_OUT = range(8)
 
@@ -117,6 +118,8 @@ SIGNATURES = {
     "pws_grid_sample_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "pws_grid_sample_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "pws_upsample_bilinear_ac": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "pws_upsample_bilinear_ac_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "pws_affine_grid_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "pws_upsample_grid_sample_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "pws_upsample_grid_sample_u8": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "pws_adam_step": (_I, [_P, _P, _P, _P, _S, _F, _F, _F, _F, _I, _P]),

@@ -293,7 +293,11 @@ class UnetGenerator(nn.Module):
         """Captures one forward on ``x`` (or on a private copy of it: ``static_input``) with an arena private to the graph."""
         xg = x.clone() if static_input else x
         nbytes = A.lib().pws_netg_workspace_bytes(xg.shape[0], self.input_nc, self.ngf, 0)
-        ws = torch.empty(nbytes + 256, device=xg.device, dtype=torch.uint8)
+        old, self._graph = self._graph, None   # drop the previous graph first; its arena is reused when it has the right size
+        ws = old["ws"] if old is not None and old["ws"].numel() == nbytes + 256 and old["ws"].device == xg.device else None
+        del old
+        if ws is None:
+            ws = torch.empty(nbytes + 256, device=xg.device, dtype=torch.uint8)
         self._run(xg, False, ws=ws)  # eager warm-up: one-time kernel attribute calls must not happen during capture
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -306,8 +310,9 @@ class UnetGenerator(nn.Module):
     def _run_graph(self, input1):
         x = input1.contiguous()
         self.packed_weights()
-        key = (tuple(x.shape), str(x.device), self._packed.data_ptr(), self._packed_key, self.math, self.store, self.align_corners,
-               self.two_queues)
+        # the packed buffer is re-packed IN PLACE at a fixed address when a parameter changes (packed_weights() above, outside the
+        # graph), so a weight update needs no re-capture: the key holds the buffer's address, not the parameter versions
+        key = (tuple(x.shape), str(x.device), self._packed.data_ptr(), self.math, self.store, self.align_corners, self.two_queues)
         ent = self._graph
         if ent is None or ent["key"] != key:
             ent = self._capture(x, key, static_input=False)

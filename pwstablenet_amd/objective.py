@@ -139,7 +139,11 @@ class _Objective(torch.autograd.Function):
         gresid = None
         if cfg["shapeloss"]:
             gresid = torch.empty_like(resid)
-            A.check(lib.pws_shape_loss_bwd(A.ptr(resid), float(cfg["shapeloss_weight"]), A.ptr(scale), A.ptr(gresid), m,
+            dp_world = cfg.get("dp_world")
+            if dp_world is None:
+                import torch.distributed as dist
+                dp_world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+            A.check(lib.pws_shape_loss_bwd(A.ptr(resid), float(cfg["shapeloss_weight"]) * float(dp_world), A.ptr(scale), A.ptr(gresid), m,
                                            cfg["size"], cfg["block"], st), "pws_shape_loss_bwd")
         return (None, None, None, None, None) + tuple(ggrids) + (gresid,)
 
@@ -165,6 +169,14 @@ class StabObjective:
         self.block = int(get("block", 16))
         self.num_layer = int(get("num_layer", 3))
         self.period = int(kw.get("period", 30))
+        # Data parallelism (one process per GPU, gradients AVERAGED over ranks -- distributed.allreduce_tensors): every term of
+        # loss_g is a mean over the batch except the shape term, which the reference SUMS over items and pixels
+        # (lib/utils.py:421 torch.dist(AB, B, 1)).  The reference's nn.DataParallel evaluates the loss on the gathered outputs of the
+        # whole batch, so its gradient of that term is the sum over ALL items; averaging the ranks' gradients would deliver 1/world
+        # of it.  grad_average_world (None: the default process group's size when backward runs) multiplies the GRADIENT of the
+        # sum-type term so that the averaged gradient equals the reference's; the reported loss values stay local
+        # (loss_pixel of the job = SUM of the ranks', the other terms = their MEAN).
+        self.grad_average_world = kw.get("grad_average_world", None)
         if self.num_layer != 3:
             raise NotImplementedError("StabObjective: the generator has 3 cascaded stages (num_layer=%d)" % self.num_layer)
         if bool(get("use_gan", False)):
@@ -204,7 +216,7 @@ class StabObjective:
             raise ValueError("StabObjective: feature_adjacent must hold n = %d affine maps, got %s" % (n, tuple(feature_adjacent.shape)))
         cfg = {"size": self.size, "number_feature": self.number_feature, "batch": self.batch, "lamd": self.lamd,
                "shapeloss": self.shapeloss, "shapeloss_weight": self.shapeloss_weight, "block": self.block,
-               "num_layer": self.num_layer, "coef": lambda dev: self._coef_matrix(n, dev)}
+               "num_layer": self.num_layer, "coef": lambda dev: self._coef_matrix(n, dev), "dp_world": self.grad_average_world}
         out = _Objective.apply(cfg, rgb_unstable, image_stable, features.to(dtype=torch.float32).contiguous(), theta,
                                *grids, resid[self.num_layer - 1])
         loss_g, losses, fakes = out[0], out[1], list(out[2:])

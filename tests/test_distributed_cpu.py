@@ -54,17 +54,16 @@ def _worker(rank, world, port, q):
     torch.manual_seed(100 + rank)   # define_G initialises from the LOCAL torch RNG: the ranks differ before the broadcast
     m = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4))
     m[1].running_mean.fill_(float(rank + 1))
-    if rank != 0:
-        with pytest.raises(RuntimeError):
-            D.broadcast_parameters(m, src=0, check=True)
-    else:
+    m[1].num_batches_tracked.fill_(5 * (rank + 1))
+    # check=True: EVERY rank raises when ANY differs (the src rank too -- a rank that carried on would hang in its next collective)
+    with pytest.raises(RuntimeError, match="not identical"):
         D.broadcast_parameters(m, src=0, check=True)
     versions = [p._version for p in m.parameters()]
     nfl = D.broadcast_parameters(m, src=0)
     assert nfl == sum(p.numel() for p in m.parameters()) + 8
     assert all(p._version > v for p, v in zip(m.parameters(), versions))   # the packed-weight cache keys on the version counters
     D.broadcast_parameters(m, src=0, check=True)
-    assert float(m[1].running_mean[0]) == 1.0 and int(m[1].num_batches_tracked) == 0
+    assert float(m[1].running_mean[0]) == 1.0 and int(m[1].num_batches_tracked) == 5   # integer buffers follow (second bucket)
     chk = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).double().sum().reshape(1)
     both = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(both, chk)

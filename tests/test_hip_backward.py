@@ -178,68 +178,94 @@ def l2_warp_loss(grids, frames, target, gs):
     return sum(F.mse_loss(gs(frames, g) / 127.5 - 1, target / 127.5 - 1) for g in grids)
 
 
+# Pinned per-tensor tolerance of the whole-generator gradient check, per kernel path (PWS_OPT_EXPERIMENT selects which kernels the
+# deep / stride-2 layers run on: 0 = product default, 70 = conv_skinny_kernel off (conv_mfma_kernel's small tiles on the deep
+# levels), 22 = conv_ringf_kernel off).  A tensor passes if it is within `tol` of the float64 step (relative to the tensor's
+# largest gradient) OR at most 3x as far from it as torch's own fp32 step is ON THE SAME TENSOR -- and never beyond `cap`.
+_GRAD_TOL = {   # (loss_kind, kind) -> {experiment: (tol, cap)}
+    ("field", "W1"): {0: (1e-3, 3e-3), 70: (5e-4, 2e-3), 22: (1e-3, 3e-3)},
+    ("field", "W2"): {0: (2e-3, 3e-2), 70: (2e-3, 3e-2), 22: (2e-3, 3e-2)},   # cap: the float64 step itself takes other ReLU branches (W2 saturates)
+    ("warp", "W1"): {0: (1e-2, 4e-2), 70: (1e-2, 4e-2), 22: (1e-2, 4e-2)},
+    ("warp", "W2"): {0: (1e-2, 4e-2), 70: (1e-2, 4e-2), 22: (1e-2, 4e-2)},
+}
+
+
+@pytest.mark.parametrize("experiment", [0, 70, 22])
 @pytest.mark.parametrize("kind", ["W1", "W2"])
-@pytest.mark.parametrize("loss_kind,tol", [("field", 5e-4), ("warp", 1e-2)])
-def test_netg_backward_vs_torch_cpu_autograd(hip, kind, loss_kind, tol):
-    if kind == "W2" and loss_kind == "field":
-        tol = 2e-3  # W2 saturates: LeakyReLU/ReLU masks of near-zero pre-activations flip between two fp32 evaluations
-    """Whole generator, all 92 gradients: HIP backward vs PyTorch-CPU autograd of the restated graph (ngf=16).
+@pytest.mark.parametrize("loss_kind", ["field", "warp"])
+def test_netg_backward_vs_torch_cpu_autograd(hip, cpu_grad_ref, kind, loss_kind, experiment):
+    """Whole generator, all 92 gradients: HIP backward vs PyTorch-CPU autograd of the restated graph (ngf=16), per kernel path.
 
-    "field": a smooth loss on the six outputs themselves -> isolates the generator backward (measured <= 1e-4 of each
-    tensor's largest gradient).  "warp": the loss goes through grid_sample of a uint8-quantised frame; d(warp)/d(field)
-    is piecewise constant in the source cell, so two fp32 evaluations of the same coordinate that fall on either side of
-    a cell border take different (equally valid) derivatives -- a few 1e-3 relative, independent of the generator."""
-    from oracle import torch_ref
+    "field": a smooth loss on the six outputs themselves -> isolates the generator backward.  "warp": the loss goes through
+    grid_sample of a uint8-quantised frame; d(warp)/d(field) is piecewise constant in the source cell, so two fp32 evaluations of
+    the same coordinate that fall on either side of a cell border take different (equally valid) derivatives -- a few 1e-3
+    relative, independent of the generator.  W2 saturates: LeakyReLU / ReLU masks of near-zero pre-activations flip between two
+    fp32 evaluations.  The float64 step is the yardstick: the deep layers' gradients are sums of strongly cancelling terms,
+    torch's own fp32 step sits a few 1e-4 of a tensor's maximum away from it, and how far this path sits depends on the
+    summation order, i.e. on which kernel a layer runs on -- hence one pinned tolerance per path, judged tensor by tensor."""
     from pwstablenet_amd import functional as PF
-    ngf, n = 16, 2
-    torch.set_num_threads(8)
-    weights = synth.make_weights(kind, seed=123, ngf=ngf)
-    xw = torch.from_numpy(synth.make_window(n, 31, 256, seed=9))
-    frames = torch.from_numpy(synth.make_frames(n, 3, 256, 256, seed=10))
-    target = torch.roll(frames, shifts=(2, -3), dims=(2, 3))
-    tfield = torch.from_numpy(np.random.RandomState(5).standard_normal((n, 256, 256, 2)).astype(np.float32)) * 0.3
-
-    def loss_fn(grids, resid, fr, tg, tf, gs):
-        if loss_kind == "field":
-            return sum(((g_ - tf) ** 2).mean() for g_ in grids) + 0.1 * sum((r * r).mean() for r in resid)
-        return l2_warp_loss(grids, fr, tg, gs) + 0.1 * sum((r * r).mean() for r in resid)
-
-    cparams = [torch.from_numpy(v.copy()).requires_grad_(True) for _, v in weights]
-    cg, cr = torch_ref.netg_forward(cparams, xw, True)
-    closs = loss_fn(cg, cr, frames, target, tfield, lambda f, g_: F.grid_sample(f, g_, align_corners=False))
-    closs.backward()
-    # the same step in float64: the yardstick for what an fp32 evaluation of these gradients can deliver.  The deep layers' gradients
-    # are sums of strongly cancelling terms: torch's own fp32 step sits a few 1e-4 of a tensor's maximum away from it, and so does
-    # this path -- by how much depends on the summation order, i.e. on which kernel a layer runs on (measured on the "field" / W1
-    # case: 3.1e-4 with conv_mfma_kernel's small tiles on the deep levels, 7.0e-4 with conv_skinny_kernel, same arithmetic)
-    dparams = [torch.from_numpy(v.astype(np.float64)).requires_grad_(True) for _, v in weights]
-    dg, dr = torch_ref.netg_forward(dparams, xw.double(), True)
-    dloss = loss_fn(dg, dr, frames.double(), target.double(), tfield.double(), lambda f, g_: F.grid_sample(f, g_, align_corners=False))
-    dloss.backward()
-    net = make_net(kind, ngf)
-    grids, resid = net(xw.cuda())
-    loss = loss_fn(grids, resid, frames.cuda(), target.cuda(), tfield.cuda(), PF.grid_sample)
-    loss.backward()
-    assert abs(loss.item() - closs.item()) < 1e-5 * max(1.0, abs(closs.item()))
-    worst = worst_cpu = worst_hip64 = 0.0
-    errs = []
-    for (name, _), p, cp, dp in zip(weights, net.module._ordered_params(), cparams, dparams):
-        ref = cp.grad.numpy()
-        ref64 = dp.grad.numpy()
+    tol, cap = _GRAD_TOL[(loss_kind, kind)][experiment]
+    weights, xw, frames, target, tfield, loss_fn, closs, cgrads, dgrads = cpu_grad_ref(kind, loss_kind)
+    L = hip.lib()
+    L.pws_set_option(hip.OPT_EXPERIMENT, experiment)
+    try:
+        net = make_net(kind, 16)
+        grids, resid = net(xw.cuda())
+        loss = loss_fn(grids, resid, frames.cuda(), target.cuda(), tfield.cuda(), PF.grid_sample)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        L.pws_set_option(hip.OPT_EXPERIMENT, 0)
+    assert abs(loss.item() - closs) < 1e-5 * max(1.0, abs(closs))
+    rows, bad = [], []
+    for (name, _), p, ref, ref64 in zip(weights, net.module._ordered_params(), cgrads, dgrads):
         got = p.grad.cpu().numpy()
         scale64 = max(np.abs(ref64).max(), 1e-12)
-        err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12)
         e_cpu = np.abs(ref - ref64).max() / scale64
         e_hip = np.abs(got - ref64).max() / scale64
-        worst, worst_cpu, worst_hip64 = max(worst, err), max(worst_cpu, e_cpu), max(worst_hip64, e_hip)
-        errs.append((name, err, e_cpu, e_hip))
-    print("%s/%s: worst relative gradient error over 92 tensors: vs torch fp32 %.3g; vs the float64 step: this path %.3g, torch fp32 %.3g"
-          % (kind, loss_kind, worst, worst_hip64, worst_cpu))
-    for name, err, e_cpu, e_hip in errs:
-        # as close to the float64 gradient as torch's own fp32 step is on its worst tensor (x3), or within the stated tolerance
-        assert e_hip < max(tol, 3 * worst_cpu), "%s: |hip - f64| / max|f64| = %.3g (torch fp32: %.3g on this tensor, %.3g worst)" % (
-            name, e_hip, e_cpu, worst_cpu)
-        assert err < 4 * max(tol, 3 * worst_cpu), "%s: max err / max|ref| = %.3g" % (name, err)
+        rows.append((e_hip, e_cpu, name))
+        if not (e_hip < max(tol, 3 * e_cpu) and e_hip < cap):
+            bad.append("%s: |hip - f64| / max|f64| = %.3g, torch fp32 on this tensor %.3g (tol %.3g, cap %.3g)" % (name, e_hip, e_cpu, tol, cap))
+    rows.sort(reverse=True)
+    print("%s/%s experiment %d: worst tensors vs the float64 step (this path / torch fp32): %s" % (
+        kind, loss_kind, experiment, "; ".join("%s %.2g/%.2g" % (nm, a, b) for a, b, nm in rows[:4])))
+    assert not bad, "\n".join(bad)
+
+
+@pytest.fixture(scope="module")
+def cpu_grad_ref():
+    """torch-CPU fp32 and float64 autograd of the restated graph, computed once per (weights, loss) and shared by the kernel paths."""
+    from oracle import torch_ref
+    cache = {}
+
+    def get(kind, loss_kind):
+        if (kind, loss_kind) in cache:
+            return cache[(kind, loss_kind)]
+        ngf, n = 16, 2
+        torch.set_num_threads(8)
+        weights = synth.make_weights(kind, seed=123, ngf=ngf)
+        xw = torch.from_numpy(synth.make_window(n, 31, 256, seed=9))
+        frames = torch.from_numpy(synth.make_frames(n, 3, 256, 256, seed=10))
+        target = torch.roll(frames, shifts=(2, -3), dims=(2, 3))
+        tfield = torch.from_numpy(np.random.RandomState(5).standard_normal((n, 256, 256, 2)).astype(np.float32)) * 0.3
+
+        def loss_fn(grids, resid, fr, tg, tf, gs):
+            if loss_kind == "field":
+                return sum(((g_ - tf) ** 2).mean() for g_ in grids) + 0.1 * sum((r * r).mean() for r in resid)
+            return l2_warp_loss(grids, fr, tg, gs) + 0.1 * sum((r * r).mean() for r in resid)
+
+        cpu_gs = lambda f, g_: F.grid_sample(f, g_, align_corners=False)  # noqa: E731
+        cparams = [torch.from_numpy(v.copy()).requires_grad_(True) for _, v in weights]
+        cg, cr = torch_ref.netg_forward(cparams, xw, True)
+        closs = loss_fn(cg, cr, frames, target, tfield, cpu_gs)
+        closs.backward()
+        dparams = [torch.from_numpy(v.astype(np.float64)).requires_grad_(True) for _, v in weights]
+        dg, dr = torch_ref.netg_forward(dparams, xw.double(), True)
+        loss_fn(dg, dr, frames.double(), target.double(), tfield.double(), cpu_gs).backward()
+        cache[(kind, loss_kind)] = (weights, xw, frames, target, tfield, loss_fn, float(closs), [p.grad.numpy() for p in cparams],
+                                    [p.grad.numpy() for p in dparams])
+        return cache[(kind, loss_kind)]
+    return get
 
 
 @pytest.mark.parametrize("tag,kind,ngf,n", [("W1_g16", "W1", 16, 2), ("W2_g16", "W2", 16, 1), ("W1_g64", "W1", 64, 2),

@@ -1,0 +1,89 @@
+"""Data-parallel equivalence on the GPU through a REAL process group (VERDICT r02 missing #1): two ranks x 16 item
+pairs == one rank x 32 item pairs, for both exchange modes (all-reduce after backward; OverlappedGradSync with collectives > 0),
+after broadcast_parameters made differing replicas equal.  The ranks are fresh child processes on cuda:0 over gloo (a one-GPU box
+cannot run RCCL between ranks; the driver's multi-GPU run exercises the transport).  Replaces: nn.DataParallel
+(lib/networks_cascading.py:51-52) around the step of main_new.py:101-118,214-216."""
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "ddp_equivalence_worker.py")
+ITEMS, NGF = 32, 32
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(mode, math, out_dir, world):
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, WORKER, mode, math, str(ITEMS), str(NGF), out_dir], env=dict(base, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return torch.load(os.path.join(out_dir, mode + ".pt"))
+
+
+@pytest.fixture(scope="module", params=["fp32", "bf16"])
+def runs(request, hip):
+    math = request.param
+    with tempfile.TemporaryDirectory() as d:
+        yield math, _run("single", math, d, 1), _run("allreduce", math, d, 2), _run("overlap", math, d, 2)
+
+
+def _cos(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "overlap"])
+def test_two_ranks_equal_one_rank_on_the_same_items(runs, mode):
+    math, single, ar, ov = runs
+    got = ar if mode == "allreduce" else ov
+    assert got["collectives"] > 0, "the exchange must really have gone through the process group"
+    # the objective's terms over all items: the shape term is a SUM over items (lib/utils.py:421) -> sum of the ranks'; every other
+    # term is a mean over the batch -> mean of the ranks'
+    rt = 2e-5 if math == "fp32" else 2e-2
+    for name in ("loss_mse", "loss_feature", "loss_delta", "loss_g2", "loss_pixel"):
+        job = got["losses"][name] / (1 if name == "loss_pixel" else got["world"])
+        assert abs(job - single["losses"][name]) <= rt * max(1e-3, abs(single["losses"][name])), (name, job, single["losses"][name])
+    worst = 0.0
+    for i, (g, s) in enumerate(zip(got["grads"], single["grads"])):
+        scale = float(s.abs().max()) + 1e-20
+        err = float((g - s).abs().max()) / scale
+        worst = max(worst, err)
+        if math == "fp32":
+            # same kernels on half the batch each: K-splits / atomics order differ, nothing else
+            assert err < 3e-4, (i, err)   # measured 1.5e-4 (a deep layer: its gradient is a strongly cancelling sum)
+        else:
+            assert _cos(g, s) > 0.99, (i, _cos(g, s))
+    # weights after ONE fused Adam step: the update is lr * g / (|g| + eps) at step 1, i.e. lr * sign(g) for all but vanishing
+    # gradients -- compared as an update direction (cosine) plus a bound on the step size
+    cos_w = min(_cos(a - b, sa - sb) for a, b, sa, sb in zip(got["after"], got["before"], single["after"], single["before"]) if a.numel() > 64)
+    for a, b, s0 in zip(got["after"], got["before"], single["before"]):
+        assert torch.equal(b, s0)                                   # broadcast: every replica started from rank 0's weights
+        assert float((a - b).abs().max()) <= 1e-3 * 1.0001          # |update| <= lr
+    print("%s / %s: worst gradient error %.3g of a tensor's max, worst update cosine %.5f, %d collectives"
+          % (math, mode, worst, cos_w, got["collectives"]))
+    assert cos_w > (0.995 if math == "fp32" else 0.95)

@@ -29,23 +29,24 @@ def make_net(kind="W1", ngf=64):
     return net.cuda()
 
 
-@pytest.fixture(scope="module")
-def cpu_ref8():
-    """The CPU path on bench.py's own rank-0 inputs (batch 8): ~1.5 s on the box's host cores."""
+@pytest.fixture(scope="module", params=["W1", "W2"])
+def cpu_ref8(request):
+    """The CPU path on bench.py's own rank-0 inputs (batch 8): ~1.5 s on the box's host cores.  W1: the bench's weights; W2:
+    saturating residuals and a field that leaves [-1, 1] (out-of-range taps) at the timed batch size."""
     from oracle import torch_ref
-    params = [torch.from_numpy(v) for _, v in synth.make_weights("W1", seed=123, ngf=64)]
+    params = [torch.from_numpy(v) for _, v in synth.make_weights(request.param, seed=123, ngf=64)]
     x = torch.from_numpy(synth.noise_window(8, 31, 256, seed=123))
     fr = torch.from_numpy(synth.make_frames(8, 3, 256, 256, seed=321))
     with torch.no_grad():
         field = torch_ref.netg_forward(params, x, is_training=False)
         warped = torch.nn.functional.grid_sample(fr, field, mode="bilinear", padding_mode="zeros", align_corners=False)
-    return x, fr, field, warped
+    return x, fr, field, warped, request.param
 
 
 def test_configs1_graph_two_queue_path_vs_cpu_oracle(hip, cpu_ref8):
     from pwstablenet_amd import functional as PF
-    x_h, fr_h, ref_field, ref_warp = cpu_ref8
-    net = make_net()
+    x_h, fr_h, ref_field, ref_warp, kind = cpu_ref8
+    net = make_net(kind)
     x, fr = x_h.cuda(), fr_h.cuda()
     assert hip.lib().pws_get_option(hip.OPT_TWO_QUEUES) == 1   # the product default, what the bench times
     with torch.no_grad():
@@ -57,7 +58,9 @@ def test_configs1_graph_two_queue_path_vs_cpu_oracle(hip, cpu_ref8):
     assert net.module._graph is not None and not net.module._graph["static"]
     ferr = float((f2.cpu() - ref_field).abs().max())
     werr = float((w2.cpu() - ref_warp).abs().max()) / 127.5
-    print("configs[1] graph + two queues, batch 8: field max-abs err %.3g, warped-frame err %.3g vs the CPU path" % (ferr, werr))
+    print("configs[1] graph + two queues, batch 8, %s: field max-abs err %.3g, warped-frame err %.3g vs the CPU path" % (kind, ferr, werr))
+    if kind == "W2":
+        assert float(ref_field.abs().max()) > 1.2   # the case is what it claims: taps outside the frame
     assert ferr < FIELD_TOL and werr < WARP_TOL
     assert torch.equal(f1, eager) and torch.equal(f2, eager)   # no atomics, ordered split-K sums: the schedule changes nothing
     assert f1.data_ptr() != f2.data_ptr()                      # fresh tensors: a later call does not overwrite f1
@@ -91,6 +94,23 @@ def test_graph_replay_on_changed_contents_other_address_and_alias_mode(hip):
         keep = ha.clone()
         hb = net(xb, False)
         assert ha.data_ptr() == hb.data_ptr() and torch.equal(hb, eb) and not torch.equal(ha, keep)
+
+
+def test_graph_follows_a_weight_update_without_recapture(hip):
+    """the packed buffer is re-packed in place at a fixed address, so an optimizer step / load_state_dict needs no
+    re-capture -- and the replay must compute with the NEW weights."""
+    net = make_net("W1", 32)
+    x = torch.from_numpy(synth.make_window(4, 31, 256, seed=4)).cuda()
+    with torch.no_grad():
+        net.module.enable_graph(True)
+        a = net(x, False)
+        g = net.module._graph["g"]
+        net.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in synth.make_weights("W2", seed=7, ngf=32)})
+        b = net(x, False)
+        assert net.module._graph["g"] is g, "a weight update must not re-capture"
+        net.module.enable_graph(False)
+        want = net(x, False)
+    assert torch.equal(b, want) and float((a - b).abs().max()) > 1e-3
 
 
 def test_graph_survives_replacement_of_the_eager_arena(hip):
@@ -241,9 +261,35 @@ def test_bench_self_launches_its_ranks(hip):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(PWS_BENCH_ONE_DEVICE="1", PWS_BENCH_BACKEND="gloo")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extra",
-                        "--no-prof", "--gs-batch", "8"], env=env, capture_output=True, text=True, timeout=900)
+    # the N>1 legs included, at a small size: the configs[3] step with both gradient-exchange modes (training_ddp) and the
+    # frame-sharded streaming leg
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-prof", "--gs-batch", "8", "--ddp-items", "4", "--stream-frames", "32"], env=env, capture_output=True, text=True,
+                       timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 0 and "gloo" in line["control_plane"], line
     assert line["value"] > 0 and line["config"]["frames_per_gpu_per_step"] == 8
+    ddp = line["training_ddp"]
+    assert "error" not in ddp, ddp
+    assert ddp["items_per_gpu_per_step"] == 4 and ddp["items_per_s"] > 0 and ddp["overlapped_collectives_per_step"] > 0
+    assert ddp["allreduce_bytes"] == 4 * 48535944 and "gloo" in ddp["workload"]
+    assert line["value_720p_stream_u8"]["value"] > 0 and line["value_720p_stream_u8"]["n_gpus"] == 2
+
+
+def test_bench_watchdog_exits_non_zero(hip):
+    """A hung collective in the N>1 legs must not look like a clean run: the watchdog still prints the
+    headline line (with the error) but the job exits non-zero.  Forced here by a watchdog limit of 10 ms."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PWS_BENCH_ONE_DEVICE="1", PWS_BENCH_BACKEND="gloo", PWS_BENCH_WATCHDOG_S="0.01")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-prof", "--gs-batch", "8", "--ddp-items", "4", "--stream-frames", "32"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode != 0
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["value"] > 0 and "watchdog" in line["training_ddp"]["error"]

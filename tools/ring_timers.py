@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where conv_ring_kernel's matrix waves spend their cycles (diagnostic build, tools/ring_timers.sh):
-    PWS_LIB_PATH=$PWD/ring_timers.so python tools/ring_timers.py KIND N H W CIN COUT [dgrad]
+    PWS_LIB_PATH=$PWD/tools/_bin/ring_timers.so python tools/ring_timers.py KIND N H W CIN COUT [dgrad]
 Per matrix wave the kernel accumulates s_memrealtime (100 MHz) deltas: waiting at barrier B (operands of the next group not landed / other waves
 late), group set-up, matrix phase, epilogue (barrier E included)."""
 import os

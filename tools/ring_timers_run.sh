@@ -1,6 +1,6 @@
 #!/bin/bash
-# usage: bash tools/ring_timers_run.sh [lib ...]   (default ring_timers.so; build with tools/ring_timers.sh)
-for lib in ${@:-ring_timers.so}; do
+# usage: bash tools/ring_timers_run.sh [lib ...]   (default tools/_bin/ring_timers.so; build with tools/ring_timers.sh)
+for lib in ${@:-tools/_bin/ring_timers.so}; do
   echo "== $lib"
   export PWS_LIB_PATH=$PWD/$lib
   python tools/ring_timers.py CONV_K3S1 64 256 256 64 64
