@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define PWS_VERSION 1
+#define PWS_VERSION 2   /* 2: pws_netg_opts carries flags + x_sample_stride (round 3) */
 
 #define PWS_OK 0
 #define PWS_EINVAL (-22) /* bad argument / unsupported shape */
@@ -152,7 +152,8 @@ typedef struct pws_conv_args {
     int n, h, w;      /* batch and INPUT height/width */
     int nsrc;         /* 1..4 sources, concatenated along channels in this order */
     pws_src src[4];
-    int src_nchw;     /* 1: src[0] is a dense NCHW tensor with `channels` channels (any count); nsrc==1 */
+    int src_nchw;     /* 1: src[0] is an NCHW tensor with `channels` channels (any count), planes dense; nsrc==1.  src[0].ld: floats
+                         between consecutive SAMPLES (0 = dense = channels * h * w; h * w for overlapping sliding windows) */
     int cout;         /* multiple of 4 */
     const float *w_packed;
     const float *bias; /* cout floats or NULL */
@@ -246,6 +247,8 @@ typedef struct pws_conv_bwd_weight_args {
     float *dbias;      /* optional: dbias[co] += sum over the pixels of gout[., co] (fp32 atomics), taken from the dy tiles the
                           weight-gradient kernel stages anyway -- for a gout that already is the gradient wrt the pre-activation
                           (pws_dst.act_y) this replaces the pws_act_bwd_bias pass */
+    int deterministic; /* 1: no pixel split -- every element of dw_packed / dbias receives exactly one fp32 atomic add from this
+                          launch, so repeated runs are bit-identical (slower: one workgroup per channel block) */
 } pws_conv_bwd_weight_args;
 int pws_conv2d_bwd_weight(const pws_conv_bwd_weight_args *args, pws_stream_t stream);
 
@@ -339,6 +342,11 @@ int pws_gray_area_u8(const unsigned char *frames_hwc, float *out, int n, int h, 
                      pws_stream_t stream);
 /* out[n,h/2,w/2,3] = cv2.resize(in, (w/2, h/2), INTER_AREA) [+ R<->B swap] (main_new.py:723-725) */
 int pws_area_half_u8(const unsigned char *in_hwc, unsigned char *out_hwc, int n, int h, int w, int swap_rb, pws_stream_t stream);
+/* out[n,oh,ow,3] = cv2.resize(in[n,h,w,3], (ow, oh), INTER_AREA) [+ R<->B swap] for ANY down-scaling ratio: the reference writes
+ * every output frame at (640, 360) whatever the source size (main_new.py:723).  2 x 2 -> pws_area_half_u8; both ratios integer
+ * (1080p, 2160p) -> OpenCV's integer-area path (int sum * float(1/area), round half to even); otherwise its area tables. */
+int pws_area_resize_u8(const unsigned char *in_hwc, unsigned char *out_hwc, int n, int h, int w, int oh, int ow, int swap_rb,
+                       pws_stream_t stream);
 
 /* Adam (no weight decay / amsgrad) on a flat fp32 buffer, in place; step counts from 1. */
 int pws_adam_step(float *p, const float *g, float *m, float *v, size_t count, float lr, float beta1,
@@ -444,8 +452,14 @@ typedef struct pws_netg_opts {
     int store;      /* PWS_STORE_FP32 / PWS_STORE_BF16 (needs PWS_MATH_BF16 and ngf % 32 == 0) */
     int two_queues; /* 1: fork the internal second queue (stage k+1 encoder beside stage k decoder); 0: caller's stream only;
                        -1: the process default (PWS_OPT_TWO_QUEUES) */
-    int reserved;   /* must be 0 */
+    int flags;      /* bit set of PWS_NETG_*; unknown bits are refused */
+    size_t x_sample_stride; /* floats between consecutive samples of the window tensor x; 0 = dense (input_nc * 256 * 256).  The
+                               windows of a video are OVERLAPPING views of one plane buffer (window b = planes b .. b+30,
+                               main_new.py:627-673): stride 256 * 256 reads them in place instead of from a gathered copy.
+                               Inference forward only (the backward reads x dense). */
 } pws_netg_opts;
+#define PWS_NETG_DETERMINISTIC 1   /* backward: every weight / bias gradient element receives exactly ONE fp32 atomic add per
+                                      launch (no pixel split across workgroups), so two runs give bit-identical gradients; slower */
 int pws_netg_forward_opts(const float *packed, const float *x, int n, int input_nc, int ngf, int is_training, int align_corners,
                           void *ws, size_t ws_bytes, float *grids, float *resid, float *thetas, const pws_netg_opts *opts,
                           pws_stream_t stream);

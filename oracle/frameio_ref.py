@@ -8,6 +8,7 @@ and serves as the checker of csrc/frameio.hip:
                            (computeResizeAreaTab + ResizeArea_Invoker: float weights, horizontal pass first, rows in order,
                            saturate_cast<uchar> = round half to even)
   * ``resize_area_half_u8`` the 2 x 2 integer fast path of the same flag: (a + b + c + d + 2) >> 2
+  * ``resize_area_u8_hwc``  the output frame's resize to (640, 360) from any source size (main_new.py:723): dispatch as cv::resize
 Reference call sites: main_new.py:639 (window frames), :653-656 / :664-667 (new frame), :723-725 (output frame).
 """
 import numpy as np
@@ -65,6 +66,21 @@ def resize_area_half_u8(img):
     """img: (H, W, C) uint8 with even H, W -> (H/2, W/2, C)."""
     s = img.astype(np.int32)
     return ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+
+
+def resize_area_u8_hwc(img, oh, ow):
+    """cv2.resize(img (H, W, C) uint8, (ow, oh), interpolation=cv2.INTER_AREA), down-scaling, as cv::resize dispatches it
+    (imgproc/resize.cpp): 2 x 2 -> the SIMD path (resize_area_half_u8); both ratios integer -> resizeAreaFast_<uchar, int>:
+    int sum of the iscale_y x iscale_x block * float(1 / area), cvRound (half to even); else the area tables per channel."""
+    h, w, c = img.shape
+    if h == 2 * oh and w == 2 * ow:
+        return resize_area_half_u8(img)
+    if h % oh == 0 and w % ow == 0:
+        ky, kx = h // oh, w // ow
+        s = img.astype(np.int64).reshape(oh, ky, ow, kx, c).sum(axis=(1, 3))
+        v = (s.astype(np.float32) * np.float32(np.float32(1.0) / np.float32(kx * ky))).astype(np.float32)
+        return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+    return np.stack([resize_area_u8(img[..., k], oh, ow) for k in range(c)], axis=-1)
 
 
 def window_plane(frame_bgr, size=256):

@@ -10,6 +10,7 @@ int g_store = PWS_STORE_FP32;
 int g_experiment = 0;
 bool g_prof_on = false;
 thread_local int g_prof_tag = -1;
+thread_local bool t_deterministic = false;
 namespace {
 struct ProfEntry {
     hipEvent_t a, b;

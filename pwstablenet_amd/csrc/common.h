@@ -59,12 +59,33 @@ struct PerDeviceInt {
     int &cur() { return v[current_device_slot()]; }
 };
 
+#if defined(__HIPCC__)
+// a * b rounded to fp32 as a value of its own.  hipcc's default -ffp-contract=fast fuses a product into the add / subtract that
+// consumes it (v_fma / v_fmac on the EXACT product) -- also through __fmul_rn / __fadd_rn, which inline to plain fmul / fadd (seen
+// in the ISA).  Where the CPU code this library restates rounds the product first (torch's source index, OpenCV's scalar area
+// resize), the empty asm pins the rounded product in a register and the consumer cannot fuse it.
+__device__ __forceinline__ float mul_rounded(float a, float b) {
+    float p = a * b;
+    asm volatile("" : "+v"(p));
+    return p;
+}
+#endif
+
 // Kernel ids for the measurement hooks (pws_prof_*).
 enum KernelId {
     KID_CONV_K3S1_BIG = 0, KID_CONV_K3S1_SMALL, KID_CONV_K3S2_BIG, KID_CONV_K3S2_SMALL, KID_CONV_K5S1, KID_CONVT4_BIG,
     KID_CONVT4_SMALL, KID_THETA_HEAD, KID_FIELD_HEAD, KID_GRID_SAMPLE_FWD, KID_GRID_SAMPLE_BWD, KID_UPSAMPLE_GRID_SAMPLE_FWD,
     KID_UPSAMPLE, KID_AFFINE_GRID, KID_ADAM, KID_PACK, KID_DGRAD_K4S2, KID_DGRAD_SP3, KID_WGRAD, KID_ACT_BWD, KID_FIELD_HEAD_BWD,
     KID_THETA_HEAD_BWD, KID_CONV_WINO, KID_CONV_BF16, KID_WGRAD_BF16, KID_CONV_WINO_CT4, KID_UPSAMPLE_GRID_SAMPLE_U8, KID_OBJECTIVE, KID_CONV_RING, KID_CONV_RINGF, KID_CONV_WRING, KID_CONV_WRING_CT4, KID_CONV_SKINNY, KID_WGRAD_RING, KID_CONV_SKINNY16, KID_COUNT
+};
+// Deterministic accumulation (PWS_NETG_DETERMINISTIC / pws_conv_bwd_weight_args.deterministic): while set on the calling thread,
+// every launcher that accumulates with fp32 atomics gives each address ONE adding workgroup per launch (no pixel split), the head
+// kernels sum in a fixed order.  Set for the duration of one entry-point call only.
+extern thread_local bool t_deterministic;
+struct DeterministicScope {
+    bool prev;
+    explicit DeterministicScope(bool on) : prev(t_deterministic) { t_deterministic = on || prev; }
+    ~DeterministicScope() { t_deterministic = prev; }
 };
 extern bool g_two_queues;
 extern int g_math;  // PWS_OPT_MATH
@@ -84,6 +105,8 @@ struct ProfScope {  // brackets one launch with events when profiling is enabled
         if (on) prof_end(st);
     }
 };
+
+int nchw_to_nhwc_pad_strided(const float *x, size_t sample_stride, float *out, int n, int c, int h, int w, int cpad, int store, hipStream_t st);   // conv_bf16.hip
 
 struct ProfHint {
     double flops, bytes;

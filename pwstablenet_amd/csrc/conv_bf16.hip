@@ -512,11 +512,11 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_k5_kernel(const ConvK
 // workgroup through LDS so that both sides are coalesced.
 template <bool IO16>
 __global__ void __launch_bounds__(256) nchw_to_nhwc_pad_kernel(const float *__restrict__ x, float *__restrict__ out, int c, int cpad,
-                                                              size_t hw) {
+                                                              size_t hw, size_t sstride) {
     __shared__ float t[32][65];
     const size_t p0 = (size_t)blockIdx.x * 64;
     const int n = blockIdx.y;
-    const float *xn = x + (size_t)n * c * hw;
+    const float *xn = x + (size_t)n * sstride;   // sstride: floats between samples (c * hw when dense; hw for sliding windows)
     for (int i = threadIdx.x; i < 32 * 64; i += 256) {
         const int ch = i >> 6, px = i & 63;
         t[ch][px] = (ch < c && p0 + px < hw) ? xn[(size_t)ch * hw + p0 + px] : 0.f;
@@ -803,18 +803,24 @@ extern "C" int pws_cvt_f32_to_bf16(const float *src, void *dst, size_t count, in
     return pws::check_launch("cvt_f32_to_bf16_kernel");
 }
 
-extern "C" int pws_nchw_to_nhwc_pad_s(const float *x, float *out, int n, int c, int h, int w, int cpad, int store, pws_stream_t stream) {
+namespace pws {
+// sample_stride: floats between consecutive samples of x (0 = dense)
+int nchw_to_nhwc_pad_strided(const float *x, size_t sample_stride, float *out, int n, int c, int h, int w, int cpad, int store, hipStream_t st) {
     PWS_REQUIRE(x && out && n >= 0 && c > 0 && h > 0 && w > 0, "pws_nchw_to_nhwc_pad: bad arguments");
     PWS_REQUIRE(cpad >= c && cpad <= 32 && cpad % 4 == 0, "pws_nchw_to_nhwc_pad: cpad %d must be a multiple of 4 in [c, 32]", cpad);
     if (n == 0) return PWS_OK;
     const size_t hw = (size_t)h * w;
+    const size_t ss = sample_stride ? sample_stride : (size_t)c * hw;
     if (store == PWS_STORE_BF16)
-        hipLaunchKernelGGL(pws::nchw_to_nhwc_pad_kernel<true>, dim3((unsigned)((hw + 63) / 64), (unsigned)n), dim3(256), 0,
-                           pws::as_stream(stream), x, out, c, cpad, hw);
+        hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<true>, dim3((unsigned)((hw + 63) / 64), (unsigned)n), dim3(256), 0, st, x, out, c, cpad, hw, ss);
     else
-        hipLaunchKernelGGL(pws::nchw_to_nhwc_pad_kernel<false>, dim3((unsigned)((hw + 63) / 64), (unsigned)n), dim3(256), 0,
-                           pws::as_stream(stream), x, out, c, cpad, hw);
-    return pws::check_launch("nchw_to_nhwc_pad_kernel");
+        hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<false>, dim3((unsigned)((hw + 63) / 64), (unsigned)n), dim3(256), 0, st, x, out, c, cpad, hw, ss);
+    return check_launch("nchw_to_nhwc_pad_kernel");
+}
+}  // namespace pws
+
+extern "C" int pws_nchw_to_nhwc_pad_s(const float *x, float *out, int n, int c, int h, int w, int cpad, int store, pws_stream_t stream) {
+    return pws::nchw_to_nhwc_pad_strided(x, 0, out, n, c, h, w, cpad, store, pws::as_stream(stream));
 }
 
 extern "C" size_t pws_packed_bf16_floats(int planes, int krows, int ncols) {

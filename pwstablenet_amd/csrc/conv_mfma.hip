@@ -118,6 +118,7 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_mfma_kernel(const ConvKPar
     auto load_chunk = [&](int s, int c0, int wrow) {
         if constexpr (C::NCHW) {
             const int Creal = p.src_c[0];
+            const size_t sstride = p.src_ld[0] ? (size_t)p.src_ld[0] : (size_t)Creal * p.H * p.W;   // floats between samples
 #pragma unroll
             for (int it = 0; it < C::ITEMS_NCHW; ++it) {
                 const int item = tid + it * C::THREADS;
@@ -126,7 +127,7 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_mfma_kernel(const ConvKPar
                 const int n = n0 + tn, iy = iy0 + ly, ix = ix0 + lx;
                 const bool ok = item < C::PIX * C::CK && (c0 + c) < Creal && n < p.N && iy >= 0 && iy < p.H && ix >= 0 &&
                                 ix < p.W;
-                const size_t off = ok ? ((size_t)(n * Creal + c0 + c) * p.H + iy) * p.W + ix : 0;
+                const size_t off = ok ? (size_t)n * sstride + ((size_t)(c0 + c) * p.H + iy) * p.W + ix : 0;
                 const float v = p.src_ptr[0][off];  // unconditional load, masked by a select
                 r_nchw[it] = ok ? v : 0.f;
             }
@@ -383,7 +384,8 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
     if (nchw) {
         PWS_REQUIRE(a->kind == PWS_CONV_K5S1 && a->nsrc == 1, "pws_conv2d_fwd: NCHW source only for the k5 first layer");
         PWS_REQUIRE(a->src[0].ptr && a->src[0].channels > 0, "pws_conv2d_fwd: bad NCHW source");
-        kp.src_ptr[0] = a->src[0].ptr, kp.src_c[0] = a->src[0].channels, kp.src_ld[0] = 0;
+        PWS_REQUIRE(a->src[0].ld >= 0, "pws_conv2d_fwd: NCHW source: ld is the sample stride in floats (0 = dense)");
+        kp.src_ptr[0] = a->src[0].ptr, kp.src_c[0] = a->src[0].channels, kp.src_ld[0] = a->src[0].ld;
         cin = a->src[0].channels;
     } else {
         for (int s = 0; s < a->nsrc; ++s) {

@@ -226,7 +226,7 @@ static int launch_wg(WgradParams &p, int nclasses, hipStream_t st) {
     const long other = (long)p.ci_blocks * p.co_blocks * nclasses * C::NGROUPS;
     long ps = (1024 + other - 1) / other;  // ~4 workgroups per CU overall
     if (ps > p.ntiles) ps = p.ntiles;
-    if (ps < 1) ps = 1;
+    if (ps < 1 || t_deterministic) ps = 1;
     dim3 grid((unsigned)ps, (unsigned)(p.ci_blocks * p.co_blocks), (unsigned)(nclasses * C::NGROUPS));
     hipLaunchKernelGGL(wgrad_mfma_kernel<C>, grid, dim3(256), C::LDS_BYTES, st, p);
     return check_launch("wgrad_mfma_kernel");
@@ -279,6 +279,9 @@ int conv2d_bwd_weight_impl(const pws_conv_bwd_weight_args *a, hipStream_t st) {
                     (reinterpret_cast<size_t>(a->gout) & 15) == 0,
                 "pws_conv2d_bwd_weight: bad sources / gout / dw");
     if (a->n == 0) return PWS_OK;
+    PWS_REQUIRE(!(t_deterministic && a->dbias),
+                "pws_conv2d_bwd_weight: deterministic with dbias: the parity classes / the scratch-less bias pass add in arrival order -- pass "
+                "dbias = NULL and sum the bias with pws_act_bwd_bias_s(act = PWS_ACT_NONE) and a workspace (ordered slab sums)");
     if (a->math == PWS_MATH_BF16) {
         const int rc = wgrad_bf16_launch(a, st);  // 1: not covered by the bf16 kernel (first layer, odd channel counts)
         if (rc != 1) return rc;
@@ -464,6 +467,7 @@ __global__ void __launch_bounds__(256) bias_slab_reduce_kernel(const float *__re
 }  // namespace pws
 
 extern "C" int pws_conv2d_bwd_weight(const pws_conv_bwd_weight_args *args, pws_stream_t stream) {
+    pws::DeterministicScope det(args && args->deterministic != 0);
     return pws::conv2d_bwd_weight_impl(args, pws::as_stream(stream));
 }
 

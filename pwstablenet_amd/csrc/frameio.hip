@@ -8,7 +8,8 @@
 //   * BGR2GRAY, 8-bit: (B*3735 + G*19235 + R*9798 + 2^14) >> 15                       (imgproc color_rgb: RGB2Gray<uchar>)
 //   * INTER_AREA, non-integer ratio: computeResizeAreaTab / ResizeArea_Invoker -- per destination cell the covered source
 //     pixels with fractional weights in float, horizontal pass first, rows accumulated in order, saturate_cast<uchar>
-//     (round half to even); float products and sums are evaluated without FMA contraction, as the scalar C++ does
+//     (round half to even); every product is rounded before it is added (mul_rounded, common.h: no FMA contraction), as the
+//     scalar C++ does
 //   * INTER_AREA, ratio 2 x 2, 8-bit: (a + b + c + d + 2) >> 2                              (ResizeAreaFastVec_SIMD_8u)
 #include "common.h"
 
@@ -75,9 +76,9 @@ __global__ void __launch_bounds__(256) gray_area_u8_kernel(const unsigned char *
         float buf = 0.f;
         for (int k = 0; k < tx.n; ++k) {
             tx.tap(k, sk, alpha);
-            buf = __fadd_rn(buf, __fmul_rn((float)gray_u8(row + (size_t)sk * 3, swap_rb), alpha));
+            buf = buf + mul_rounded((float)gray_u8(row + (size_t)sk * 3, swap_rb), alpha);
         }
-        sum = j == 0 ? __fmul_rn(beta, buf) : __fadd_rn(sum, __fmul_rn(beta, buf));
+        sum = j == 0 ? mul_rounded(beta, buf) : sum + mul_rounded(beta, buf);
     }
     const float g8 = fminf(fmaxf(rintf(sum), 0.f), 255.f);   // saturate_cast<uchar>: round half to even, clamp
     out[i] = normalize ? g8 / 255 * 2 - 1 : g8;              // main_new.py:643: x.float() / 255 * 2 - 1
@@ -96,6 +97,62 @@ __global__ void __launch_bounds__(256) area_half_u8_kernel(const unsigned char *
     unsigned char r[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) r[c] = (unsigned char)((p[c] + p[3 + c] + q[c] + q[3 + c] + 2) >> 2);
+    unsigned char *o = out + i * 3;
+    o[0] = swap_rb ? r[2] : r[0], o[1] = r[1], o[2] = swap_rb ? r[0] : r[2];
+}
+
+// ---- cv2.resize(frame, (ow, oh), INTER_AREA) of a 3-channel 8-bit frame for ANY down-scaling ratio (reference main_new.py:723:
+// every output frame goes to (640, 360) whatever the source size).  OpenCV 4.x, imgproc/resize.cpp:
+//   * both ratios integer (1080p -> 3 x 3, 2160p -> 6 x 6): resizeAreaFast_<uchar, int, ...>: the int sum of the iscale_y x iscale_x
+//     source pixels times float(1 / area), saturate_cast<uchar> (cvRound: half to even).  (2 x 2 has its own SIMD path,
+//     (a + b + c + d + 2) >> 2: area_half_u8_kernel above.)
+//   * otherwise computeResizeAreaTab + ResizeArea_Invoker per channel, exactly as gray_area_u8_kernel does for one plane.
+// one lane per destination pixel (3 channels)
+__global__ void __launch_bounds__(256) area_int_u8_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict__ out, int H, int W,
+                                                          int OH, int OW, int ky, int kx, float scale, int swap_rb, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ox = (int)(i % OW), oy = (int)((i / OW) % OH);
+    const size_t n = i / ((size_t)OW * OH);
+    const unsigned char *p = in + ((n * H + (size_t)oy * ky) * W + (size_t)ox * kx) * 3;
+    int s0 = 0, s1 = 0, s2 = 0;
+    for (int j = 0; j < ky; ++j) {
+        const unsigned char *q = p + (size_t)j * W * 3;
+        for (int k = 0; k < kx; ++k) s0 += q[3 * k], s1 += q[3 * k + 1], s2 += q[3 * k + 2];
+    }
+    const float r0 = fminf(fmaxf(rintf(mul_rounded((float)s0, scale)), 0.f), 255.f);
+    const float r1 = fminf(fmaxf(rintf(mul_rounded((float)s1, scale)), 0.f), 255.f);
+    const float r2 = fminf(fmaxf(rintf(mul_rounded((float)s2, scale)), 0.f), 255.f);
+    unsigned char *o = out + i * 3;
+    o[0] = (unsigned char)(swap_rb ? r2 : r0), o[1] = (unsigned char)r1, o[2] = (unsigned char)(swap_rb ? r0 : r2);
+}
+
+__global__ void __launch_bounds__(256) area_tab_u8_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict__ out, int H, int W,
+                                                          int OH, int OW, double sy, double sx, int swap_rb, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int dx = (int)(i % OW), dy = (int)((i / OW) % OH);
+    const size_t n = i / ((size_t)OW * OH);
+    const AreaAxis tx = area_axis(dx, W, sx), ty = area_axis(dy, H, sy);
+    const unsigned char *f = in + n * (size_t)H * W * 3;
+    float sum[3] = {0.f, 0.f, 0.f};
+    for (int j = 0; j < ty.n; ++j) {
+        int sj, sk;
+        float beta, alpha;
+        ty.tap(j, sj, beta);
+        const unsigned char *row = f + (size_t)sj * W * 3;
+        float buf[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < tx.n; ++k) {
+            tx.tap(k, sk, alpha);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) buf[c] = buf[c] + mul_rounded((float)row[(size_t)sk * 3 + c], alpha);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sum[c] = j == 0 ? mul_rounded(beta, buf[c]) : sum[c] + mul_rounded(beta, buf[c]);
+    }
+    unsigned char r[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r[c] = (unsigned char)fminf(fmaxf(rintf(sum[c]), 0.f), 255.f);
     unsigned char *o = out + i * 3;
     o[0] = swap_rb ? r[2] : r[0], o[1] = r[1], o[2] = swap_rb ? r[0] : r[2];
 }
@@ -130,4 +187,27 @@ extern "C" int pws_area_half_u8(const unsigned char *in_hwc, unsigned char *out_
     hipLaunchKernelGGL(area_half_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), in_hwc, out_hwc, h, w,
                        swap_rb, total);
     return check_launch("area_half_u8_kernel");
+}
+
+extern "C" int pws_area_resize_u8(const unsigned char *in_hwc, unsigned char *out_hwc, int n, int h, int w, int oh, int ow, int swap_rb,
+                                  pws_stream_t stream) {
+    PWS_REQUIRE(n >= 0 && h > 0 && w > 0 && oh > 0 && ow > 0 && oh <= h && ow <= w, "pws_area_resize_u8: bad shape (down-scaling only)");
+    if (n == 0) return PWS_OK;
+    PWS_REQUIRE(in_hwc && out_hwc, "pws_area_resize_u8: NULL pointer");
+    if (h == 2 * oh && w == 2 * ow) return pws_area_half_u8(in_hwc, out_hwc, n, h, w, swap_rb, stream);   // OpenCV's 2 x 2 SIMD path
+    const size_t total = (size_t)n * oh * ow;
+    const unsigned nb = (unsigned)((total + 255) / 256);
+    ProfScope prof(KID_OBJECTIVE, 3.0 * n * h * w, 3.0 * n * h * w + 3.0 * total, as_stream(stream));
+    if (h % oh == 0 && w % ow == 0) {
+        // cv::resize: is_area_fast when both scale factors are integers; scale = 1.f / (iscale_x * iscale_y)
+        const int ky = h / oh, kx = w / ow;
+        hipLaunchKernelGGL(area_int_u8_kernel, dim3(nb), dim3(256), 0, as_stream(stream), in_hwc, out_hwc, h, w, oh, ow, ky, kx,
+                           1.f / (float)(kx * ky), swap_rb, total);
+        return check_launch("area_int_u8_kernel");
+    }
+    PWS_REQUIRE((double)h / oh <= AREA_MAX_TAPS - 2 && (double)w / ow <= AREA_MAX_TAPS - 2, "pws_area_resize_u8: scale above %d",
+                AREA_MAX_TAPS - 2);
+    const double sy = 1.0 / ((double)oh / h), sx = 1.0 / ((double)ow / w);
+    hipLaunchKernelGGL(area_tab_u8_kernel, dim3(nb), dim3(256), 0, as_stream(stream), in_hwc, out_hwc, h, w, oh, ow, sy, sx, swap_rb, total);
+    return check_launch("area_tab_u8_kernel");
 }

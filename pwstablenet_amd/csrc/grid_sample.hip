@@ -308,16 +308,9 @@ __global__ void affine_grid_kernel(const float *__restrict__ theta, float *__res
 }
 
 // ---------------------------------------------------------------------------------------------- upsample (ac=True)
-// Source index of an output pixel as torch computes it: scale * index ROUNDED to fp32, then split into floor and fraction.
-// hipcc contracts a plain `scale * index - floor` into one fma (the exact product: the fraction moves by up to an ulp of the
-// index, 1.5e-5 at 255, i.e. 5e-5 on the interpolated value) -- __fmul_rn does not stop it (it inlines to an fmul that carries
-// the contract flag); the empty asm pins the rounded product in a register.
-__device__ __forceinline__ float mul_rounded(float a, float b) {
-    float p = a * b;
-    asm volatile("" : "+v"(p));
-    return p;
-}
-
+// Source index of an output pixel as torch computes it: scale * index ROUNDED to fp32 (mul_rounded, common.h), then split into
+// floor and fraction.  A contracted `scale * index - floor` (one fma on the exact product) moves the fraction by up to an ulp of the
+// index, 1.5e-5 at 255, i.e. 5e-5 on the interpolated value.
 __global__ void upsample_bilinear_ac_kernel(const float *__restrict__ in, float *__restrict__ out, int H, int W, int Ho,
                                             int Wo, float ry, float rx, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -265,16 +265,37 @@ __global__ void __launch_bounds__(256) field_dw_kernel(const float *__restrict__
     }
 }
 
+// Deterministic mode: db_out[k] += sum over all pixels of gz[.][k], ONE workgroup, fixed order (strided partial sums per lane, then
+// a fixed tree) -- the per-sample workgroups of field_gz_kernel would add to db_out in arrival order.
+__global__ void __launch_bounds__(256) ordered_sum2_kernel(const float *__restrict__ gz, size_t pixels, float *__restrict__ db_out) {
+    __shared__ float red[2][256];
+    float s0 = 0.f, s1 = 0.f;
+    for (size_t p = threadIdx.x; p < pixels; p += 256) {
+        const float2 v = *reinterpret_cast<const float2 *>(gz + p * 2);
+        s0 += v.x, s1 += v.y;
+    }
+    red[0][threadIdx.x] = s0, red[1][threadIdx.x] = s1;
+    __syncthreads();
+    for (int step = 128; step > 0; step >>= 1) {
+        if ((int)threadIdx.x < step) red[0][threadIdx.x] += red[0][threadIdx.x + step], red[1][threadIdx.x] += red[1][threadIdx.x + step];
+        __syncthreads();
+    }
+    if (threadIdx.x < 2) db_out[threadIdx.x] += red[threadIdx.x][0];
+}
+
 // ---- theta head backward
-// T1: one workgroup per sample: dz2, dW2 += h (x) dz2, db2 += dz2, dz1 = (W2^T dz2) * L'(h) -> ws, db1 += dz1
+// T1: one workgroup per sample (serial_n > 0: ONE workgroup walks the samples 0 .. serial_n-1 in order -- deterministic mode: every
+// address then receives its adds from one lane in a fixed order): dz2, dW2 += h (x) dz2, db2 += dz2, dz1 = (W2^T dz2) * L'(h) -> ws, db1 += dz1
 __global__ void __launch_bounds__(256) theta_bwd1_kernel(const float *__restrict__ theta, const float *__restrict__ dtheta,
                                                          const float *__restrict__ h, int hidden, const float *__restrict__ w_lin,
                                                          float *__restrict__ dw_lin, float *__restrict__ db_lin,
-                                                         float *__restrict__ db_flat, float *__restrict__ dz1, int bn) {
+                                                         float *__restrict__ db_flat, float *__restrict__ dz1, int bn, int serial_n) {
     // bn (use_BN training): `dtheta` already IS dz2 (BatchNorm backward ran on it) and the output is dh, the gradient wrt the
     // BatchNorm output of the hidden layer (its own BatchNorm backward follows); the conv biases get no gradient (BN removes it)
     __shared__ float dz2[6];
-    const int n = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    for (int n = serial_n > 0 ? 0 : (int)blockIdx.x; n < (serial_n > 0 ? serial_n : (int)blockIdx.x + 1); ++n) {
+    __syncthreads();   // (serial walk) the previous sample's dz2 is consumed
     if (tid < 6) {
         const float v = bn ? dtheta[(size_t)n * 6 + tid] : dtheta[(size_t)n * 6 + tid] * lrelu_grad(theta[(size_t)n * 6 + tid]);
         dz2[tid] = v;
@@ -292,6 +313,7 @@ __global__ void __launch_bounds__(256) theta_bwd1_kernel(const float *__restrict
         const float d1 = bn ? dh : dh * lrelu_grad(hj);
         dz1[(size_t)n * hidden + j] = d1;
         if (!bn) atomicAdd(db_flat + j, d1);
+    }
     }
 }
 
@@ -349,10 +371,11 @@ int field_bwd_gz(const float *resid, const float *g_grid, const float *g_resid, 
     int slices = (2048 + n - 1) / n;
     const int max_slices = (int)(((size_t)h * w + 1023) / 1024);
     if (slices > max_slices) slices = max_slices;
-    if (slices < 1) slices = 1;
+    if (slices < 1 || t_deterministic) slices = 1;   // deterministic: one workgroup (one add to dtheta[n]) per sample
     PWS_REQUIRE(n <= 65535, "pws_field_head_bwd: more than 65535 samples");
     hipLaunchKernelGGL(field_gz_kernel, dim3((unsigned)slices, (unsigned)n), dim3(256), 0, st, resid, g_grid, g_resid, h, w, slices, ac, gz,
-                       db_out, dtheta);
+                       t_deterministic ? (float *)nullptr : db_out, dtheta);
+    if (t_deterministic && db_out) hipLaunchKernelGGL(ordered_sum2_kernel, dim3(1), dim3(256), 0, st, gz, (size_t)n * h * w, db_out);
     return check_launch("field_gz_kernel");
 }
 
@@ -388,6 +411,7 @@ int field_bwd_dx_dw(const float *x, int ld, const float *gz, int n, int h, int w
         const int ntiles = tiles_x * tiles_y * n, cblocks = (c + FB_CH - 1) / FB_CH;
         int gx = (1024 + cblocks - 1) / cblocks;  // ~4 workgroups per CU in total; each walks ntiles / gx tiles
         if (gx > ntiles) gx = ntiles;
+        if (t_deterministic) gx = 1;   // one adding workgroup per channel block
         if (io16)
             hipLaunchKernelGGL(field_dw_kernel<true>, dim3((unsigned)gx, (unsigned)cblocks), dim3(256), 0, st, x, ld, gz, n, h, w, c, dw_out,
                                tiles_x, tiles_y, ntiles);
@@ -401,8 +425,8 @@ int field_bwd_dx_dw(const float *x, int ld, const float *gz, int n, int h, int w
 // theta head, use_BN: dz2 given -> dW2 += h (x) dz2, dh = W2^T dz2 (no activation derivative: the BatchNorm backward of the hidden
 // layer follows);  then, with dz1:  dW1 += v (x) dz1, dv = W1 dz1
 int theta_bwd_bn_lin(const float *dz2, const float *h, int n, int hidden, const float *w_lin, float *dw_lin, float *dh, hipStream_t st) {
-    hipLaunchKernelGGL(theta_bwd1_kernel, dim3(n), dim3(256), 0, st, (const float *)nullptr, dz2, h, hidden, w_lin, dw_lin, (float *)nullptr,
-                       (float *)nullptr, dh, 1);
+    hipLaunchKernelGGL(theta_bwd1_kernel, dim3(t_deterministic ? 1 : n), dim3(256), 0, st, (const float *)nullptr, dz2, h, hidden, w_lin, dw_lin,
+                       (float *)nullptr, (float *)nullptr, dh, 1, t_deterministic ? n : 0);
     return check_launch("theta_bwd1_kernel<bn>");
 }
 int theta_bwd_flat(const float *x, int n, int c, int hidden, const float *w_flat, const float *dz1, float *dw_flat, float *dx,
@@ -453,7 +477,8 @@ extern "C" int pws_theta_head_bwd(const float *x, int n, int c, int hidden, cons
     hipStream_t st = as_stream(stream);
     const int k1 = 4 * c;
     ProfScope prof(KID_THETA_HEAD_BWD, 4.0 * n * (double)k1 * hidden, 4.0 * 3.0 * (double)k1 * hidden, st);
-    hipLaunchKernelGGL(theta_bwd1_kernel, dim3(n), dim3(256), 0, st, theta, dtheta, h_saved, hidden, w_lin, dw_lin, db_lin, db_flat, ws, 0);
+    hipLaunchKernelGGL(theta_bwd1_kernel, dim3(t_deterministic ? 1 : n), dim3(256), 0, st, theta, dtheta, h_saved, hidden, w_lin, dw_lin, db_lin,
+                       db_flat, ws, 0, t_deterministic ? n : 0);
     const size_t e = (size_t)k1 * hidden;
     hipLaunchKernelGGL(theta_bwd2_kernel, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, st, x, ws, n, k1, hidden, dw_flat);
     if (dx) {

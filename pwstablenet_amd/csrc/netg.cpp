@@ -146,6 +146,8 @@ static void fill_pack_layers(const std::vector<Layer> &L, PackLayer *out) {
 struct NetgOpts {
     int math, store;
     bool two_queues;
+    bool deterministic = false;     // PWS_NETG_DETERMINISTIC
+    size_t x_sample_stride = 0;     // floats between samples of the window (0 = dense)
 };
 static NetgOpts opts_defaults() { return NetgOpts{g_math, g_store, g_two_queues}; }
 static int opts_from(const pws_netg_opts *o, NetgOpts *out) {
@@ -156,9 +158,10 @@ static int opts_from(const pws_netg_opts *o, NetgOpts *out) {
     PWS_REQUIRE(o->math == PWS_MATH_FP32 || o->math == PWS_MATH_BF16, "pws_netg_opts: math %d", o->math);
     PWS_REQUIRE(o->store == PWS_STORE_FP32 || o->store == PWS_STORE_BF16, "pws_netg_opts: store %d", o->store);
     PWS_REQUIRE(o->store == PWS_STORE_FP32 || o->math == PWS_MATH_BF16, "pws_netg_opts: PWS_STORE_BF16 needs PWS_MATH_BF16");
-    PWS_REQUIRE(o->two_queues >= -1 && o->two_queues <= 1 && o->reserved == 0, "pws_netg_opts: two_queues %d / reserved %d", o->two_queues,
-                o->reserved);
-    *out = NetgOpts{o->math, o->store, o->two_queues < 0 ? g_two_queues : o->two_queues != 0};
+    PWS_REQUIRE(o->two_queues >= -1 && o->two_queues <= 1 && (o->flags & ~PWS_NETG_DETERMINISTIC) == 0, "pws_netg_opts: two_queues %d / flags %d",
+                o->two_queues, o->flags);
+    *out = NetgOpts{o->math, o->store, o->two_queues < 0 ? g_two_queues : o->two_queues != 0, (o->flags & PWS_NETG_DETERMINISTIC) != 0,
+                    o->x_sample_stride};
     return PWS_OK;
 }
 
@@ -223,7 +226,7 @@ class Exec {
   public:
     Exec(const float *packed, const std::vector<Layer> &layers, int n, char *ws, size_t ws_bytes, hipStream_t st, bool dry,
          bool launch, const NetgOpts &o, const BnCfg *bn = nullptr)
-        : math_(o.math), packed_(packed), L_(layers), n_(n), ws_(ws), cap_(ws_bytes), dry_(dry), launch_(launch && !dry) {
+        : math_(o.math), x_sstride_(o.x_sample_stride), packed_(packed), L_(layers), n_(n), ws_(ws), cap_(ws_bytes), dry_(dry), launch_(launch && !dry) {
         if (bn) {
             bn_on_ = true, bn_ = *bn;
             size_t off = 0;
@@ -322,11 +325,11 @@ class Exec {
         a.kind = l.kind, a.n = n_, a.h = x.h, a.w = x.w;
         if (nchw_c > 0 && math_ == PWS_MATH_BF16 && l.wb_off != (size_t)-1 && x_nhwc_ && nchw_c <= 32) {
             // bf16 first layer: the NCHW window is re-laid once as a 32-channel NHWC source (kept for the weight gradient)
-            rc_ = pws_nchw_to_nhwc_pad_s(nchw_src, x_nhwc_, n_, nchw_c, x.h, x.w, 32, store(), streams_[q_]);
+            rc_ = nchw_to_nhwc_pad_strided(nchw_src, x_sstride_, x_nhwc_, n_, nchw_c, x.h, x.w, 32, store(), streams_[q_]);
             if (rc_ != PWS_OK) return o;
             a.nsrc = 1, a.src[0] = pws_src{x_nhwc_, 32, 32};
         } else if (nchw_c > 0) {
-            a.nsrc = 1, a.src_nchw = 1, a.src[0] = pws_src{nchw_src, nchw_c, 0};
+            a.nsrc = 1, a.src_nchw = 1, a.src[0] = pws_src{nchw_src, nchw_c, (int)x_sstride_};
         } else {
             a.nsrc = x.nseg;
             for (int i = 0; i < x.nseg; ++i) a.src[i] = pws_src{x.seg[i].ptr, x.seg[i].c, x.seg[i].ld};
@@ -449,6 +452,7 @@ class Exec {
     float *bn_ws_[2] = {nullptr, nullptr};
     bool io16_ = false;
     int math_ = PWS_MATH_FP32;
+    size_t x_sstride_ = 0;
     SideStream *side_ = nullptr;
     hipStream_t streams_[2];
     int q_ = 0;
@@ -554,6 +558,7 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
     size_t total = 0;
     const std::vector<Layer> L = build_layers(input_nc, g, &total);
     const NetgOpts mode = opts ? *opts : opts_defaults();
+    DeterministicScope det_scope(mode.deterministic);   // PWS_NETG_DETERMINISTIC: every accumulating launcher of this call
     Exec E(packed, L, n, ws, ws_bytes, st, dry, /*launch=*/false, mode, bn);
     float dummy_thetas = 0.f;  // non-NULL: the training forward is always given a caller-owned thetas buffer
     forward_graph(E, x, n, input_nc, g, 1, ac, nullptr, nullptr, &dummy_thetas);
@@ -737,6 +742,13 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             wa.cout = l.cout, wa.gout = go.g, wa.gout_ld = l.cout, wa.dw_packed = dpacked + l.w_off;
             wa.math = mode.math, wa.store = E.store();
             wa.dbias = !bn && go.preact ? dpacked + l.b_off : nullptr;
+            if (wa.dbias && mode.deterministic) {
+                // the weight-gradient kernels' bias sums arrive per parity class / class pair in any order: an ordered pass instead
+                // (act = NONE: sums only, slab partials + ordered reduction)
+                rc = pws_act_bwd_bias_s(go.g, go.g, pixels, l.cout, PWS_ACT_NONE, dpacked + l.b_off, E.store(), abb_ws, abb_bytes, st);
+                if (rc != PWS_OK) break;
+                wa.dbias = nullptr;
+            }
             rc = pws_conv2d_bwd_weight(&wa, st);
             if (rc != PWS_OK || op.nchw) {
                 g_prof_tag = -1;
@@ -962,6 +974,8 @@ extern "C" int pws_netg_forward_opts(const float *packed, const float *x, int n,
     if (n == 0) return PWS_OK;
     PWS_REQUIRE(packed && x && ws && grids, "pws_netg_forward: NULL pointer");
     PWS_REQUIRE(!is_training || (resid && thetas), "pws_netg_forward: resid and thetas must be given when is_training");
+    PWS_REQUIRE(o.x_sample_stride == 0 || (!is_training && o.x_sample_stride % 4 == 0 && o.x_sample_stride < (1u << 30)),
+                "pws_netg_opts: x_sample_stride %zu: inference forward only, a multiple of 4 floats", o.x_sample_stride);
     PWS_REQUIRE((reinterpret_cast<size_t>(ws) & 255) == 0, "pws_netg_forward: workspace must be 256-byte aligned");
     size_t total = 0;
     const std::vector<Layer> L = build_layers(input_nc, ngf, &total);

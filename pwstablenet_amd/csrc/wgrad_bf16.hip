@@ -392,7 +392,7 @@ static int launch_wb(WgradBfParams &p, int nclasses, hipStream_t st) {
     // all weight-gradient launches of a batch-32 step: 256 / 512 / 768 / 1024 -> 7.7 / 7.2 / 8.5 / 9.1 ms)
     long ps = (512 + other - 1) / other;
     if (ps > p.ntiles) ps = p.ntiles;
-    if (ps < 1) ps = 1;
+    if (ps < 1 || t_deterministic) ps = 1;   // deterministic: one adding workgroup per (channel block, class, tap group)
     dim3 grid((unsigned)ps, (unsigned)(p.ci_blocks * p.co_blocks), (unsigned)(nclasses * C::NGROUPS));
     if (p.io_bf16)
         hipLaunchKernelGGL((wgrad_bf16_kernel<C, true>), grid, dim3(256), C::LDS_BYTES, st, p);

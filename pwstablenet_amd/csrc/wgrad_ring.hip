@@ -301,7 +301,7 @@ static int wrg_launch(WgradRingParams &p, int nclasses, hipStream_t st) {
     // one workgroup per CU and round: the pixel tiles are split over as many workgroups as it takes to give every CU one
     long ps = (ncu + other - 1) / other;
     if (ps > p.ntiles) ps = p.ntiles;
-    if (ps < 1) ps = 1;
+    if (ps < 1 || t_deterministic) ps = 1;
     hipLaunchKernelGGL((wgrad_ring_kernel<C>), dim3((unsigned)ps, (unsigned)(p.ci_blocks * p.co_blocks), (unsigned)nclasses), dim3(C::THREADS), C::LDS_BYTES,
                        st, p);
     return check_launch("wgrad_ring_kernel");

@@ -17,6 +17,8 @@ ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 OPT_TWO_QUEUES = 1
 OPT_MATH, MATH_FP32, MATH_BF16 = 2, 0, 1
 OPT_STORE, STORE_FP32, STORE_BF16 = 3, 0, 1
+ABI_VERSION = 2
+NETG_DETERMINISTIC = 1
 OPT_EXPERIMENT = 100   # measured kernel variants (tools, per-path tests); 0 = product default
 OBJ_SLOTS = 64
 CONV_K3S1, CONV_K3S2, CONV_K5S1, CONVT_K3S1, CONVT_K4S2, CONV_K2S1P0, CONV_K1, CONV_K3S1_OUT = range(8)
@@ -51,11 +53,12 @@ class PwsConvBwdWeightArgs(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("n", ctypes.c_int), ("h", ctypes.c_int), ("w", ctypes.c_int), ("nsrc", ctypes.c_int),
                 ("src", PwsSrc * 4), ("src_nchw", ctypes.c_int), ("cout", ctypes.c_int), ("gout", ctypes.c_void_p),
                 ("gout_ld", ctypes.c_int), ("dw_packed", ctypes.c_void_p), ("math", ctypes.c_int), ("store", ctypes.c_int),
-                ("dbias", ctypes.c_void_p)]
+                ("dbias", ctypes.c_void_p), ("deterministic", ctypes.c_int)]
 
 
 class PwsNetgOpts(ctypes.Structure):
-    _fields_ = [("math", ctypes.c_int), ("store", ctypes.c_int), ("two_queues", ctypes.c_int), ("reserved", ctypes.c_int)]
+    _fields_ = [("math", ctypes.c_int), ("store", ctypes.c_int), ("two_queues", ctypes.c_int), ("flags", ctypes.c_int),
+                ("x_sample_stride", ctypes.c_size_t)]
 
 
 class PwsProfRecord(ctypes.Structure):
@@ -149,6 +152,7 @@ SIGNATURES = {
     "pws_sqdiff_bwd": (_I, [_P, _P, _S, _F, _P, _P, _P]),
     "pws_gray_area_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "pws_area_half_u8": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "pws_area_resize_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "pws_bn_ws_bytes": (_S, [_I]),
     "pws_bn_train_fwd": (_I, [_P, _S, _I, _P, _P, _I, _P, _P, _P, _P, _F, _F, _I, _P, _S, _P]),
     "pws_bn_train_bwd": (_I, [_P, _P, _P, _P, _P, _I, _S, _I, _P, _P, _P, _S, _P]),
@@ -176,7 +180,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.pws_version() != 1:
+        if L.pws_version() != ABI_VERSION:
             raise RuntimeError("pwstablenet_amd: ABI version mismatch (%d)" % L.pws_version())
         _lib = L
     return _lib

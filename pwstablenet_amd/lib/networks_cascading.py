@@ -152,6 +152,9 @@ class UnetGenerator(nn.Module):
         # "pytorch 0.4.0+" expect
         self.align_corners = bool(getattr(opt, "align_corners", 0))
         self.two_queues = None   # None: the process default (PWS_OPT_TWO_QUEUES); True / False: per generator
+        # True: the backward adds every weight / bias gradient element with ONE fp32 atomic per launch (PWS_NETG_DETERMINISTIC):
+        # bit-identical gradients run to run, at the price of the weight-gradient kernels' parallelism over pixels
+        self.deterministic = False
         if getattr(opt, "math", "fp32") == "bf16":
             self.set_math("bf16")
 
@@ -172,12 +175,14 @@ class UnetGenerator(nn.Module):
         self.math, self.store = math, store
         return self
 
-    def _opts(self, math=None, store=None):
+    def _opts(self, math=None, store=None, x_sample_stride=0):
         """The mode of one executor call as the C ABI takes it (pws_netg_opts): carried in the call's arguments, no
         process-wide state is written."""
         math, store = math or self.math, store or self.store
         tq = -1 if self.two_queues is None else int(bool(self.two_queues))
-        return A.PwsNetgOpts(A.MATH_BF16 if math == "bf16" else A.MATH_FP32, A.STORE_BF16 if store == "bf16" else A.STORE_FP32, tq, 0)
+        flags = A.NETG_DETERMINISTIC if self.deterministic else 0
+        return A.PwsNetgOpts(A.MATH_BF16 if math == "bf16" else A.MATH_FP32, A.STORE_BF16 if store == "bf16" else A.STORE_FP32, tq, flags,
+                             int(x_sample_stride))
 
     def enable_graph(self, on=True, alias_output=False):
         """Opt-in hipGraph replay of the inference forward (``netG(x, False)`` under ``no_grad``): the ~75 launches of a
@@ -327,7 +332,16 @@ class UnetGenerator(nn.Module):
     def _run(self, input1, is_training, train_ctx=None, ws=None):
         """train_ctx: dict filled with what backward needs; the arena is then private to this call (the reference's
         training loop runs two forwards before one backward, main_new.py:101,112,214).  ws: caller-owned arena (graph capture)."""
-        x = input1.contiguous()
+        # overlapping sliding windows (stream._windows: an as_strided view whose samples start one plane apart) are read in place
+        # by the first layer -- pws_netg_opts.x_sample_stride -- instead of from a gathered copy (inference only)
+        x, sstride = input1, 0
+        if not x.is_contiguous():
+            st = x.stride()
+            if (train_ctx is None and not is_training and x.dim() == 4 and st[1:] == (256 * 256, 256, 1) and st[0] > 0 and st[0] % 4 == 0
+                    and st[0] < (1 << 30)):
+                sstride = st[0]
+            else:
+                x = x.contiguous()
         n = x.shape[0]
         S = 256
         packed = self.packed_weights()
@@ -343,7 +357,7 @@ class UnetGenerator(nn.Module):
         resid = torch.empty((3, n, S, S, 2), device=x.device, dtype=torch.float32) if is_training else None
         thetas = torch.empty((3, n, 6), device=x.device, dtype=torch.float32)
         ac = int(self.align_corners)
-        opts = self._opts()
+        opts = self._opts(x_sample_stride=sstride)
         A.check(A.lib().pws_netg_forward_opts(A.ptr(packed), A.ptr(x), n, self.input_nc, self.ngf, int(bool(is_training)),
                                               ac, ctypes.c_void_p(ws_ptr), ws_bytes, A.ptr(grids), A.ptr(resid), A.ptr(thetas),
                                               ctypes.byref(opts), A.current_stream()), "pws_netg_forward_opts")

@@ -49,12 +49,26 @@ def area_half(frames_hwc, swap_rb=False):
     return out
 
 
+def area_resize(frames_hwc, size, swap_rb=False):
+    """``cv2.resize(frame, size, interpolation=cv2.INTER_AREA)`` for any down-scaling ratio, ``size`` = (width, height) as cv2 takes
+    it (main_new.py:723: ``cv2.resize(samples, (640, 360), interpolation=cv2.INTER_AREA)``): (T, H, W, 3) uint8 -> (T, height, width, 3)."""
+    A.require_cuda(frames_hwc, dtype=torch.uint8)
+    frames_hwc = frames_hwc.contiguous()
+    t, h, w, _ = frames_hwc.shape
+    ow, oh = int(size[0]), int(size[1])
+    out = torch.empty((t, oh, ow, 3), device=frames_hwc.device, dtype=torch.uint8)
+    A.check(A.lib().pws_area_resize_u8(A.ptr(frames_hwc), A.ptr(out), t, h, w, oh, ow, int(bool(swap_rb)), A.current_stream()),
+            "pws_area_resize_u8")
+    return out
+
+
 def _windows(gray_padded, start, count, period):
-    """(count, period+1, 256, 256) windows: window b covers padded frames [start+b, start+b+period]."""
+    """(count, period+1, 256, 256) windows: window b covers padded frames [start+b, start+b+period].  An OVERLAPPING VIEW of the
+    plane buffer (sample stride = one plane): the generator's first layer reads it in place (pws_netg_opts.x_sample_stride); no
+    31-plane copy per window (65 MB per batch of 8)."""
     h, w = gray_padded.shape[-2:]
-    view = torch.as_strided(gray_padded, (count, period + 1, h, w), (h * w, h * w, w, 1),
+    return torch.as_strided(gray_padded, (count, period + 1, h, w), (h * w, h * w, w, 1),
                             storage_offset=gray_padded.storage_offset() + start * h * w)
-    return view.contiguous()
 
 
 class VideoStabilizer:
@@ -145,7 +159,8 @@ class VideoStabilizer:
         return out
 
     @torch.no_grad()
-    def run_video(self, frames, chunk=64, half_size_output=False, frames_are_rgb=False, halo_left=0, halo_right=0, crop=None):
+    def run_video(self, frames, chunk=64, half_size_output=False, frames_are_rgb=False, halo_left=0, halo_right=0, crop=None,
+                  output_size=None):
         """The whole device side of the reference's ``process()`` loop for one decoded clip: ``frames`` (T, H, W, 3) uint8 as
         cv2 delivers them, in (pinned) host memory or on the device.  Per chunk of ``chunk`` frames: H2D on a side stream,
         gray + INTER_AREA 256x256 window planes computed there from the uploaded frames (so nothing but the uint8 frames
@@ -159,7 +174,9 @@ class VideoStabilizer:
         int(x_end)-threshold]``, applied after the down-scale), sliced on the device so that only the cropped frames cross PCIe;
         the reference's live values (0, 640, 0, 360, threshold 0) are the whole 640x360 frame.  The 3x3 GaussianBlur(sigma=0.2)
         that follows in the reference (:731) is the identity on 8-bit frames and is not run.
-        Returns (T, H, W, 3) -- or (T, H/2, W/2, 3), or the crop window of it -- uint8 on the inputs' side."""
+        output_size = (width, height): the reference's ``cv2.resize(samples, (640, 360), INTER_AREA)`` for ANY source size
+        (main_new.py:723; half_size_output=True is the same thing for a 1280 x 720 source).
+        Returns (T, H, W, 3) -- or (T, H/2, W/2, 3) / (T, height, width, 3), or the crop window of it -- uint8 on the inputs' side."""
         half = self.period // 2
         if not (0 <= halo_left <= half and 0 <= halo_right <= half):
             raise ValueError("halo must be within [0, %d]" % half)
@@ -170,7 +187,14 @@ class VideoStabilizer:
         on_host = not frames.is_cuda
         dev = self.device
         h, w = frames.shape[1], frames.shape[2]
-        oh, ow = (h // 2, w // 2) if half_size_output else (h, w)
+        if output_size is not None and half_size_output:
+            raise ValueError("run_video: give output_size or half_size_output, not both")
+        if output_size is not None:
+            ow, oh = int(output_size[0]), int(output_size[1])
+            if not (0 < ow <= w and 0 < oh <= h):
+                raise ValueError("run_video: output_size %s must not exceed the %d x %d source (INTER_AREA down-scaling)" % (tuple(output_size), w, h))
+        else:
+            oh, ow = (h // 2, w // 2) if half_size_output else (h, w)
         cy0, cy1, cx0, cx1 = 0, oh, 0, ow
         if crop is not None:
             if len(crop) not in (4, 5):
@@ -217,6 +241,8 @@ class VideoStabilizer:
             warped = self.run(gray_all[cs - hl:ce + hr], buf[cs - s:ce - s], halo_left=hl, halo_right=hr)
             if half_size_output:
                 warped = area_half(warped)
+            elif output_size is not None and (oh, ow) != (h, w):
+                warped = area_resize(warped, (ow, oh))
             if crop is not None:
                 warped = warped[:, cy0:cy1, cx0:cx1, :].contiguous()   # packed on the device: only the window crosses PCIe
             s, e = cs - halo_left, ce - halo_left   # position in the output

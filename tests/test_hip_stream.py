@@ -226,3 +226,67 @@ def test_run_video_sharded_with_halos_equals_whole_clip(hip):
     assert d.max() <= 1 and np.mean(d > 0) < 1e-3, (d.max(), float(np.mean(d > 0)))   # batch composition differs: see run_video test
     with pytest.raises(ValueError):
         vs.run_video(frames[:10], halo_left=16)
+
+
+@pytest.mark.parametrize("src,dst", [((1080, 1920), (360, 640)), ((12, 18), (4, 6)), ((480, 854), (360, 640)), ((6, 8), (3, 4)),
+                                      ((7, 9), (7, 9)), ((8, 6), (8, 3)), ((50, 77), (9, 31)), ((720, 1280), (360, 640))])
+@pytest.mark.parametrize("swap", [False, True])
+def test_area_resize_u8_any_ratio_vs_opencv_restatement(hip, src, dst, swap):
+    """cv2.resize(frame, (640, 360), INTER_AREA) from any source size (main_new.py:723): the 2 x 2 SIMD path, the integer-ratio
+    path (1080p: 3 x 3) and the area tables (854 x 480), byte for byte against oracle/frameio_ref.py (cv2 itself is not in the
+    image: parity unpinned)."""
+    from oracle import frameio_ref as R
+    from pwstablenet_amd.stream import area_resize
+    (h, w), (oh, ow) = src, dst
+    rs = np.random.RandomState(h * 7 + ow)
+    clip = rs.randint(0, 256, (2, h, w, 3)).astype(np.uint8)
+    clip[1, : h // 2] = 255          # saturated region: sums at the top of the range
+    got = area_resize(torch.from_numpy(clip).cuda(), (ow, oh), swap_rb=swap).cpu().numpy()
+    want = np.stack([R.resize_area_u8_hwc(f, oh, ow) for f in clip])
+    if swap:
+        want = want[..., ::-1]
+    assert got.shape == want.shape and np.array_equal(got, want), int(np.abs(got.astype(int) - want.astype(int)).max())
+    L = hip.lib()
+    assert L.pws_area_resize_u8(None, None, 1, 100, 100, 200, 100, 0, None) == -22     # up-scaling is refused
+
+
+def test_run_video_output_size_640x360_from_1080p(hip):
+    """The reference writes every output frame at (640, 360) (main_new.py:723): run_video(output_size=(640, 360)) on a 1080p clip =
+    the full-size result resized by the restated cv2 step."""
+    from oracle import frameio_ref as R
+    from pwstablenet_amd.stream import VideoStabilizer
+    net = make_net()
+    T, H, W = 6, 1080, 1920
+    frames = torch.from_numpy(_clip_u8(T, H, W, 3))
+    vs = VideoStabilizer(net, batch=4, swap_rb=True)
+    full = vs.run_video(frames.cuda(), chunk=4).cpu().numpy()
+    got = vs.run_video(frames.pin_memory(), chunk=4, output_size=(640, 360))
+    assert not got.is_cuda and tuple(got.shape) == (T, 360, 640, 3)
+    want = np.stack([R.resize_area_u8_hwc(f, 360, 640) for f in full])
+    assert np.array_equal(got.numpy(), want)
+    with pytest.raises(ValueError):
+        vs.run_video(frames.cuda(), output_size=(4000, 360))
+    with pytest.raises(ValueError):
+        vs.run_video(frames.cuda(), output_size=(640, 360), half_size_output=True)
+
+
+@pytest.mark.parametrize("math", ["fp32", "bf16"])
+def test_generator_reads_overlapping_windows_in_place(hip, math):
+    """the windows of consecutive frames are overlapping views of ONE plane buffer (sample stride = one plane);
+    the first layer reads them in place (pws_netg_opts.x_sample_stride), bit-identical to a gathered copy -- and a view the
+    executor cannot take (another stride pattern) is gathered as before."""
+    from pwstablenet_amd.stream import _windows
+    net = make_net()
+    net.module.set_math(math)
+    planes = torch.from_numpy(synth.make_window(1, 40, 256, seed=21)[0]).cuda()     # 40 planes -> 10 windows
+    view = _windows(planes, 2, 7, 30)
+    assert not view.is_contiguous() and view.stride(0) == 256 * 256 and view.data_ptr() == planes[2].data_ptr()
+    with torch.no_grad():
+        a = net(view, False)
+        b = net(view.contiguous(), False)
+        odd = torch.as_strided(planes, (3, 31, 256, 256), (2 * 256 * 256, 256 * 256, 256, 1))   # windows two frames apart
+        c = net(odd, False)
+        d = net(odd.contiguous(), False)
+        e = net(view.flip(1), False)                                                           # not a window view: gathered
+    assert torch.equal(a, b) and torch.equal(c, d) and torch.isfinite(e).all()
+    assert float((a[0] - a[1]).abs().max()) > 0

@@ -112,3 +112,26 @@ def test_netg_forward(oracle, netg_golden, tag, kind, ngf, n):
     # inference mode returns exactly the stage-3 field (reference :237)
     ri = oracle.netg_forward(params, x, is_training=False, ngf=ngf)
     assert np.array_equal(ri["grids"][0], r["grids"][2])
+
+
+def test_frameio_restatement_area_resize_dispatch():
+    """oracle/frameio_ref.py (restated OpenCV steps; cv2 is not in the image: parity unpinned): the three INTER_AREA paths of
+    cv::resize agree where they must -- a constant frame stays constant on every path, the integer-ratio path is the rounded block
+    mean, the table path on an integer ratio equals it to one gray level (different arithmetic: float weights vs int sum), and the
+    2 x 2 path rounds half up as (a + b + c + d + 2) >> 2 does."""
+    from oracle import frameio_ref as R
+    rs = np.random.RandomState(0)
+    for (h, w), (oh, ow) in (((12, 18), (4, 6)), ((9, 10), (3, 5)), ((11, 13), (5, 6)), ((8, 8), (4, 4))):
+        const = np.full((h, w, 3), 137, np.uint8)
+        assert np.array_equal(R.resize_area_u8_hwc(const, oh, ow), np.full((oh, ow, 3), 137, np.uint8))
+    img = rs.randint(0, 256, (12, 18, 3)).astype(np.uint8)
+    fast = R.resize_area_u8_hwc(img, 4, 6)
+    mean = img.astype(np.float64).reshape(4, 3, 6, 3, 3).mean(axis=(1, 3))
+    assert np.abs(fast.astype(np.float64) - mean).max() <= 0.5 + 1e-6
+    tab = np.stack([R.resize_area_u8(img[..., k], 4, 6) for k in range(3)], -1)
+    assert np.abs(fast.astype(int) - tab.astype(int)).max() <= 1
+    quad = np.array([[[1, 0, 0], [2, 0, 0]], [[1, 0, 0], [2, 0, 0]]], np.uint8)      # mean 1.5 -> 2 (half up), not 2 by half-even luck:
+    assert R.resize_area_u8_hwc(quad, 1, 1)[0, 0, 0] == 2
+    quad[..., 0] = [[0, 1], [0, 1]]                                                    # mean 0.5 -> (2 + 2) >> 2 = 1; half-to-even would give 0
+    assert R.resize_area_u8_hwc(quad, 1, 1)[0, 0, 0] == 1
+    assert R.resize_area_u8_hwc(img, 12, 18).tobytes() == img.tobytes()                # ratio 1: identity
