@@ -351,7 +351,13 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
     // pass to get 8 consecutive channels per lane; tools/ring_timers.py: that epilogue took 3.5 us per unit = 22-36 % of the
     // launch, bound by its ~700 vector instructions per wave and the LDS round trips, plus a workgroup barrier to free the LDS
     // it used.)
-    constexpr int PF = 1;          // data-gradient: store slots whose old value / forward value are requested ahead of their use
+    // data-gradient: store slots whose old value / forward value are requested ahead of their use.  The sub-pixel data gradient
+    // of the stride-2 layers on the 256 x 256 maps is a read-modify-write of 537 MB tensors with 1-4 taps of matrix work per
+    // group: its pace is the number of 16-byte requests a wave keeps in flight (PWS_RING_PF overrides for A/B builds)
+#ifndef PWS_RING_PF
+#define PWS_RING_PF (C::MODE == RM_SP3 ? 2 : 1)
+#endif
+    constexpr int PF = PWS_RING_PF;
     constexpr int NSLOT = 8;       // slot = mt * 4 + q: pixel mt, 8-channel group q of the lane's 32 channels
     // destination of the unit's two 32-channel blocks (block b = channels co0 + 32 b + [0, 32) = store slots q = 2 b, 2 b + 1;
     // data gradient: a block lies in ONE source of the forward layer, sources being multiples of 32 channels): pointers already

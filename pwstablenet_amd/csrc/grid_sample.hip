@@ -94,6 +94,7 @@ struct __attribute__((packed, aligned(4))) F2U {
 struct Taps2 {
     int o0, o1;          // offsets of the two row pairs inside a channel plane
     float a0, b0, a1, b1;  // weights of (pair.x, pair.y) for row 0 and row 1
+    int xs, r0, r1;      // pair start column and the two (clamped) rows: o0 = r0 * W + xs (row-window variant of the u8 kernel)
 };
 
 __device__ __forceinline__ Taps2 make_taps2(float gx, float gy, int H, int W, bool ac) {
@@ -108,7 +109,8 @@ __device__ __forceinline__ Taps2 make_taps2(float gx, float gy, int H, int W, bo
     const float wr = sel == 0 ? (vx1 ? wx1 : 0.f) : (sel == 1 ? (vx0 ? wx0 : 0.f) : 0.f);
     const float r0 = vy0 ? wy0 : 0.f, r1 = vy1 ? wy1 : 0.f;
     Taps2 t;
-    t.o0 = min(max(y0, 0), H - 1) * W + xs, t.o1 = min(max(y1, 0), H - 1) * W + xs;
+    t.xs = xs, t.r0 = min(max(y0, 0), H - 1), t.r1 = min(max(y1, 0), H - 1);
+    t.o0 = t.r0 * W + xs, t.o1 = t.r1 * W + xs;
     t.a0 = wl * r0, t.b0 = wr * r0, t.a1 = wl * r1, t.b1 = wr * r1;
     return t;
 }
@@ -476,7 +478,15 @@ struct __attribute__((packed, aligned(1))) U8x4 {
 struct __attribute__((packed, aligned(1))) U8x2 {
     unsigned short v;
 };
-template <bool NARROW>
+struct __attribute__((packed, aligned(1))) U8x16 {
+    unsigned w[4];
+};
+// ROWWIN (the "wavefront shuffle" variant, measured against the per-tap gathers: DESIGN.md): where a stabiliser's field maps the 4
+// consecutive output pixels of a lane onto at most 5 consecutive pixels of ONE source row pair, the lane fetches each row as ONE
+// unaligned 16-byte window (5.33 RGB pixels) -- plus, for the sixth pixel, the second dword of the NEXT lane's window through a
+// wave shuffle when that lane's window starts exactly 4 pixels further -- instead of 4 x (4 + 2)-byte gathers per row: 2 vector
+// memory instructions per lane instead of 16.  Lanes whose pixels straddle a row or spread wider keep the per-tap gathers.
+template <bool NARROW, bool ROWWIN = false>
 __global__ void __launch_bounds__(256) upsample_grid_sample_u8_kernel(const unsigned char *__restrict__ input,
                                                                       const float *__restrict__ field,
                                                                       unsigned char *__restrict__ out, int H, int W, int fh, int fw,
@@ -484,8 +494,9 @@ __global__ void __launch_bounds__(256) upsample_grid_sample_u8_kernel(const unsi
                                                                       int ac, int swap_rb) {
     constexpr int PPT = 4;
     const unsigned blk = xcd_remap(blockIdx.x, nblocks);
-    const size_t gidx = (size_t)blk * 256 + threadIdx.x;
-    if (gidx >= total_groups) return;
+    const size_t gidx_raw = (size_t)blk * 256 + threadIdx.x;
+    const bool live = gidx_raw < total_groups;   // lanes past the end keep running (on the last group): the wave shuffles below want every lane
+    const size_t gidx = live ? gidx_raw : total_groups - 1;
     const int HW = H * W;
     const size_t p0 = gidx * PPT;
     const int n = (int)(p0 / HW);
@@ -531,23 +542,79 @@ __global__ void __launch_bounds__(256) upsample_grid_sample_u8_kernel(const unsi
     }
     const unsigned char *ip = input + (size_t)n * HW * 3;
     unsigned char res[PPT * 3];
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-        // the two horizontally adjacent source pixels of a row are 6 consecutive bytes: one 4-byte + one 2-byte unaligned load
-        const unsigned char *q0 = ip + (size_t)t[i].o0 * 3, *q1 = ip + (size_t)t[i].o1 * 3;
-        const unsigned long long u = (unsigned long long)reinterpret_cast<const U8x4 *>(q0)->v |
-                                     ((unsigned long long)reinterpret_cast<const U8x2 *>(q0 + 4)->v << 32);
-        const unsigned long long v = (unsigned long long)reinterpret_cast<const U8x4 *>(q1)->v |
-                                     ((unsigned long long)reinterpret_cast<const U8x2 *>(q1 + 4)->v << 32);
+    auto blend = [&](int i, unsigned long long u, unsigned long long v) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int ci = swap_rb ? 2 - c : c;
             const float ux = (float)((u >> (8 * ci)) & 0xff), uy = (float)((u >> (8 * (3 + ci))) & 0xff);
             const float vx = (float)((v >> (8 * ci)) & 0xff), vy = (float)((v >> (8 * (3 + ci))) & 0xff);
-            const float r = ux * t[i].a0 + uy * t[i].b0 + vx * t[i].a1 + vy * t[i].b1;
+            // one explicit fma chain: the same rounding in every instantiation and on both paths (left to the compiler, the
+            // contraction of this sum differed between them -- a byte flips where the blend lands on an integer)
+            const float r = fmaf(vy, t[i].b1, fmaf(vx, t[i].a1, fmaf(uy, t[i].b0, ux * t[i].a0)));
             res[i * 3 + c] = (unsigned char)min(max((int)r, 0), 255);
         }
+    };
+    bool fast = false;
+    if constexpr (ROWWIN) {
+        int lo = t[0].xs, hi_ = t[0].xs;
+        bool same = true;
+#pragma unroll
+        for (int i = 1; i < PPT; ++i) {
+            lo = min(lo, t[i].xs), hi_ = max(hi_, t[i].xs);
+            same = same && t[i].r0 == t[0].r0 && t[i].r1 == t[0].r1;
+        }
+        // the window must not run past the frame buffer: 16 (+4 shuffled) bytes from the window start
+        const size_t row_end = (size_t)HW * 3;
+        const bool in_buf = ((size_t)t[0].r0 * W + lo) * 3 + 16 <= row_end && ((size_t)t[0].r1 * W + lo) * 3 + 16 <= row_end;
+        const int span = hi_ - lo;   // the pair of the last pixel ends at column lo + span + 1: bytes up to 3 (span + 2)
+        // neighbour lane's window: its second dword = bytes 16..19 of this lane's rows when it starts exactly 4 pixels further
+        const int nb_lo = __shfl_down(lo, 1, 64), nb_r0 = __shfl_down(t[0].r0, 1, 64), nb_r1 = __shfl_down(t[0].r1, 1, 64);
+        const bool nb_same = __shfl_down((int)(same && in_buf), 1, 64) != 0;
+        const bool nb_ok = (threadIdx.x & 63) != 63 && nb_same && nb_lo == lo + 4 && nb_r0 == t[0].r0 && nb_r1 == t[0].r1;
+        const bool want = same && in_buf && (span <= 3 || (span == 4 && nb_ok));
+        // every lane that could be a window lane loads (the shuffle needs the neighbour's dwords whatever its own verdict)
+        unsigned w0[5] = {0u, 0u, 0u, 0u, 0u}, w1[5] = {0u, 0u, 0u, 0u, 0u};
+        if (same && in_buf) {
+            const U8x16 a = *reinterpret_cast<const U8x16 *>(ip + ((size_t)t[0].r0 * W + lo) * 3);
+            const U8x16 b = *reinterpret_cast<const U8x16 *>(ip + ((size_t)t[0].r1 * W + lo) * 3);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w0[k] = a.w[k], w1[k] = b.w[k];
+        }
+        w0[4] = __shfl_down(w0[1], 1, 64), w1[4] = __shfl_down(w1[1], 1, 64);
+        fast = want;
+        if (fast) {
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                const int d = (t[i].xs - lo) * 3;        // byte offset of the pixel pair inside the window: 0, 3, .. 12
+                const int k = d >> 2, sh = d & 3;
+                // dwords k, k + 1, k + 2 of the (extended) window, selected without dynamic register indexing
+                const unsigned a0 = k == 0 ? w0[0] : (k == 1 ? w0[1] : (k == 2 ? w0[2] : w0[3]));
+                const unsigned a1 = k == 0 ? w0[1] : (k == 1 ? w0[2] : (k == 2 ? w0[3] : w0[4]));
+                const unsigned a2 = k == 0 ? w0[2] : (k == 1 ? w0[3] : w0[4]);
+                const unsigned b0 = k == 0 ? w1[0] : (k == 1 ? w1[1] : (k == 2 ? w1[2] : w1[3]));
+                const unsigned b1 = k == 0 ? w1[1] : (k == 1 ? w1[2] : (k == 2 ? w1[3] : w1[4]));
+                const unsigned b2 = k == 0 ? w1[2] : (k == 1 ? w1[3] : w1[4]);
+                const unsigned long long u = (unsigned long long)__builtin_amdgcn_alignbyte(a1, a0, sh) |
+                                             ((unsigned long long)__builtin_amdgcn_alignbyte(a2, a1, sh) << 32);
+                const unsigned long long v = (unsigned long long)__builtin_amdgcn_alignbyte(b1, b0, sh) |
+                                             ((unsigned long long)__builtin_amdgcn_alignbyte(b2, b1, sh) << 32);
+                blend(i, u, v);
+            }
+        }
     }
+    if (!fast) {
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            // the two horizontally adjacent source pixels of a row are 6 consecutive bytes: one 4-byte + one 2-byte unaligned load
+            const unsigned char *q0 = ip + (size_t)t[i].o0 * 3, *q1 = ip + (size_t)t[i].o1 * 3;
+            const unsigned long long u = (unsigned long long)reinterpret_cast<const U8x4 *>(q0)->v |
+                                         ((unsigned long long)reinterpret_cast<const U8x2 *>(q0 + 4)->v << 32);
+            const unsigned long long v = (unsigned long long)reinterpret_cast<const U8x4 *>(q1)->v |
+                                         ((unsigned long long)reinterpret_cast<const U8x2 *>(q1 + 4)->v << 32);
+            blend(i, u, v);
+        }
+    }
+    if (!live) return;
     unsigned *op = reinterpret_cast<unsigned *>(out + ((size_t)n * HW + hw) * 3);  // 12 bytes, 4-byte aligned (hw % 4 == 0)
 #pragma unroll
     for (int k = 0; k < 3; ++k)
@@ -731,11 +798,24 @@ extern "C" int pws_upsample_grid_sample_u8(const unsigned char *frame_hwc, const
     const unsigned nb = (unsigned)((groups + 255) / 256);
     ProfScope prof(KID_UPSAMPLE_GRID_SAMPLE_U8, (double)total * (40.0 + 8.0 * 3), (double)total * 6.0 + 8.0 * (double)n * fh * fw,
                    as_stream(stream));
-    if (3.f * rx < 0.999f)
-        hipLaunchKernelGGL(upsample_grid_sample_u8_kernel<true>, dim3(nb), dim3(256), 0, as_stream(stream), frame_hwc, field, out_hwc, h,
+    // PWS_OPT_EXPERIMENT 4: the row-window + wave-shuffle variant, kept for the A/B in DESIGN.md (tools/warp_u8_ab.py).  Measured
+    // on 8 frames of 1280 x 720: 39.0 vs 40.3 us on a pure translation (every lane takes the window), 51.6 vs 41.2 us on a
+    // stabiliser's field, 49.8 vs 41.1 us on the random-weight generator's: 16 -> 2 memory instructions per lane buy nothing,
+    // the kernel is bound by its ~200 vector instructions per pixel (field interpolation, taps, 12 blends, byte packing), and the
+    // lanes whose 4 pixels straddle a source row pay both paths.  The per-tap gathers stay the product path.
+    const bool rowwin = g_experiment == 4;
+    if (3.f * rx < 0.999f) {
+        if (rowwin)
+            hipLaunchKernelGGL((upsample_grid_sample_u8_kernel<true, true>), dim3(nb), dim3(256), 0, as_stream(stream), frame_hwc, field, out_hwc,
+                               h, w, fh, fw, ry, rx, groups, nb, align_corners, swap_rb);
+        else
+            hipLaunchKernelGGL((upsample_grid_sample_u8_kernel<true, false>), dim3(nb), dim3(256), 0, as_stream(stream), frame_hwc, field, out_hwc,
+                               h, w, fh, fw, ry, rx, groups, nb, align_corners, swap_rb);
+    } else if (rowwin)
+        hipLaunchKernelGGL((upsample_grid_sample_u8_kernel<false, true>), dim3(nb), dim3(256), 0, as_stream(stream), frame_hwc, field, out_hwc, h,
                            w, fh, fw, ry, rx, groups, nb, align_corners, swap_rb);
     else
-        hipLaunchKernelGGL(upsample_grid_sample_u8_kernel<false>, dim3(nb), dim3(256), 0, as_stream(stream), frame_hwc, field, out_hwc, h,
+        hipLaunchKernelGGL((upsample_grid_sample_u8_kernel<false, false>), dim3(nb), dim3(256), 0, as_stream(stream), frame_hwc, field, out_hwc, h,
                            w, fh, fw, ry, rx, groups, nb, align_corners, swap_rb);
     return check_launch("upsample_grid_sample_u8_kernel");
 }

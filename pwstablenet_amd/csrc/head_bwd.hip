@@ -265,6 +265,208 @@ __global__ void __launch_bounds__(256) field_dw_kernel(const float *__restrict__
     }
 }
 
+// ---- K2+K3 fused on the bf16 matrix cores (bf16 storage, C == 64): dx AND dW_out from ONE read of the activation.
+// Both are products with the same small matrix G'[q][g] = gz[q - (tap - 1)][o], g = 2 tap + o (18 columns, padded to 32): the 3x3
+// shift lives in the 2-channel gz (a 2.6 KB halo tile), so the 64-channel x tile needs NO halo and every x element is read once:
+//     dx[q][c]       = sum_g G'[q][g] Wm[c][g]                 (K = 32: two k-steps of v_mfma_f32_32x32x16_bf16, weights as A)
+//     dW[tap][c][o] += sum_q x[q][c] G'[q][g]                  (K = pixels: x^T and G' through the transposing LDS read)
+// and act'(x) of the dx epilogue comes from the x tile already in LDS.  The VALU kernels above read the 537 MB activation twice
+// and spend 1152 FMAs per pixel in each of them (343 + 304 us per call at 64 x 256 x 256: 1.57x / 2.2x their algorithmic bytes,
+// 60 % LDS bank conflicts); here the matrix work is 2 MFLOP per 256 pixels and the kernel is a stream of x in, dx out.
+// Precision: gz and W_out enter the products rounded to bf16 (as dy and the weights do in every other bf16 data / weight gradient);
+// fp32 accumulation; dx leaves as bf16.
+// Layouts (copied from wgrad_bf16_kernel, which pins them with tools/probes/tr16_read_probe.hip): x tile = two 32-channel planes of
+// [256 px][64 B] rows, G' = one plane of [256 px][32 g]; an operand with K = pixels is two ds_read_b64_tr_b16.
+constexpr int FQ_T = 16, FQ_PIX = FQ_T * FQ_T, FQ_ROW = 64;
+constexpr int FQ_SX = 0, FQ_SG = 2 * FQ_PIX * FQ_ROW, FQ_SGZ = FQ_SG + FQ_PIX * FQ_ROW;
+constexpr int FQ_HALO = FQ_T + 2;
+constexpr int FQ_LDS = FQ_SGZ + FQ_HALO * FQ_HALO * 8;
+
+__device__ __forceinline__ float fq_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float fq_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+__device__ __forceinline__ bf16x8 fq_tr_pair(const unsigned char *lds, int off0, int off1) {
+    typedef short s16x4_ __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4_ *lptr;
+    const s16x4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + off0));
+    const s16x4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(lds + off1));
+    typedef short s16x8_ __attribute__((ext_vector_type(8)));
+    const s16x8_ v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ void __launch_bounds__(256, 2) field_bwd16_mfma_kernel(const __bf16 *__restrict__ x, int x_ld, const float *__restrict__ gz,
+                                                                   const float *__restrict__ w_out, int N, int H, int W,
+                                                                   __bf16 *__restrict__ dx, int dx_ld, int accumulate, int dx_act,
+                                                                   float *__restrict__ dw, int tiles_x, int tiles_y, int ntiles) {
+    typedef float f32x16_ __attribute__((ext_vector_type(16)));
+    constexpr int C = 64;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FQ_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int li = lane & 15, lg = lane >> 4;
+
+    // ---- the weights as the A operand of the dx product: matrix row i of row tile rt stands for channel
+    // rt * 32 + (r >> 3) * 16 + h * 8 + (r & 7), with h = (i >> 2) & 1 and r = 4 (i >> 3) + (i & 3) -- the result register r of lane
+    // half h -- so that a lane ends up with two groups of 8 consecutive channels per row tile, and the two lane halves' 16-byte
+    // stores of one instruction form whole 32-byte sectors
+    bf16x8 wa[2][2];
+    {
+        const int ih = (l31 >> 2) & 1, ir = 4 * (l31 >> 3) + (l31 & 3);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int ch = rt * 32 + (ir >> 3) * 16 + ih * 8 + (ir & 7);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                unsigned wd[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int g0 = ks * 16 + hi * 8 + 2 * j;   // g = 2 tap + o: (g0, g0 + 1) = both outputs of tap g0 / 2
+                    const float2 v = g0 < 18 ? *reinterpret_cast<const float2 *>(w_out + ((size_t)(g0 >> 1) * C + ch) * 2) : make_float2(0.f, 0.f);
+                    wd[j] = cvt_pk_bf16(v.x, v.y);
+                }
+                const u32x4 u = {wd[0], wd[1], wd[2], wd[3]};
+                wa[rt][ks] = __builtin_bit_cast(bf16x8, u);
+            }
+        }
+    }
+    // ---- dW accumulators: wave = (channel half wv & 1, pixel half wv >> 1); rows = channels, columns = g
+    f32x16_ accw;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[r] = 0.f;
+    const int wci = wv & 1, wph = wv >> 1;
+    const int colb = (16 * (lg & 1) + 4 * (li & 3)) * 2;
+    int a_lane[2], b_lane[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = 8 * (lg >> 1) + 4 * q + (li >> 2);
+        a_lane[q] = FQ_SX + wci * FQ_PIX * FQ_ROW + (wph * 128 + c) * FQ_ROW + colb;
+        b_lane[q] = FQ_SG + (wph * 128 + c) * FQ_ROW + colb;
+    }
+
+    // ---- staging: lane = (pixel tid >> 3 (+ 32 per item), 8-channel piece tid & 7)
+    const int c8 = tid & 7, p0 = tid >> 3;
+    const int xl0 = FQ_SX + (c8 >> 2) * FQ_PIX * FQ_ROW + p0 * FQ_ROW + (c8 & 3) * 16;
+    u32x4 rx[8];
+    float2 rg[2];
+    unsigned okx = 0;
+    int n0 = 0, y0 = 0, x0 = 0;
+    auto locate = [&](int tile) {
+        x0 = (tile % tiles_x) * FQ_T, y0 = ((tile / tiles_x) % tiles_y) * FQ_T, n0 = tile / (tiles_x * tiles_y);
+    };
+    auto issue = [&]() {
+        okx = 0;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int pix = p0 + 32 * it;
+            const int yy = y0 + (pix >> 4), xx = x0 + (pix & 15);
+            const bool ok = yy < H && xx < W;
+            const size_t e = ok ? (((size_t)n0 * H + yy) * W + xx) * x_ld + c8 * 8 : 0;
+            rx[it] = *reinterpret_cast<const u32x4 *>(x + e);
+            okx |= ok ? (1u << it) : 0u;
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int h = tid + 256 * it;
+            const int yy = y0 - 1 + h / FQ_HALO, xx = x0 - 1 + h % FQ_HALO;
+            const bool ok = h < FQ_HALO * FQ_HALO && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const float2 v = *reinterpret_cast<const float2 *>(gz + (ok ? (((size_t)n0 * H + yy) * W + xx) * 2 : 0));
+            rg[it] = ok ? v : make_float2(0.f, 0.f);
+        }
+    };
+    const float sl = dx_act == PWS_ACT_LRELU ? 0.2f : 0.f;
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) locate(tile), issue();
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int ty0 = y0, tx0 = x0, tn0 = n0;
+        __syncthreads();   // the previous tile is consumed
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const bool ok = (okx >> it) & 1u;
+            u32x4 v;
+            v.x = ok ? rx[it].x : 0u, v.y = ok ? rx[it].y : 0u, v.z = ok ? rx[it].z : 0u, v.w = ok ? rx[it].w : 0u;
+            *reinterpret_cast<u32x4 *>(lds + xl0 + it * 32 * FQ_ROW) = v;
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int h = tid + 256 * it;
+            if (h < FQ_HALO * FQ_HALO) *reinterpret_cast<float2 *>(lds + FQ_SGZ + h * 8) = rg[it];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) locate(tile + gridDim.x), issue();   // in flight during everything below
+        {   // ---- G' row of pixel tid: 9 taps x 2 outputs as bf16, 14 zero columns
+            const int py = tid >> 4, px = tid & 15;
+            unsigned wd[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float2 v = *reinterpret_cast<const float2 *>(lds + FQ_SGZ + ((py + 2 - tap / 3) * FQ_HALO + (px + 2 - tap % 3)) * 8);
+                wd[tap] = cvt_pk_bf16(v.x, v.y);
+            }
+            u32x4 *row = reinterpret_cast<u32x4 *>(lds + FQ_SG + tid * FQ_ROW);
+            row[0] = u32x4{wd[0], wd[1], wd[2], wd[3]};
+            row[1] = u32x4{wd[4], wd[5], wd[6], wd[7]};
+            row[2] = u32x4{wd[8], 0u, 0u, 0u};
+            row[3] = u32x4{0u, 0u, 0u, 0u};
+        }
+        __syncthreads();
+        // ---- dx of this wave's 64 pixels: two column tiles of 32 pixels x two row tiles of 32 channels x two k-steps
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int pix = wv * 64 + ct * 32 + l31;
+            bf16x8 bq[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) bq[ks] = *reinterpret_cast<const bf16x8 *>(lds + FQ_SG + pix * FQ_ROW + (ks * 16 + hi * 8) * 2);
+            const int yy = ty0 + (pix >> 4), xx = tx0 + (pix & 15);
+            const bool live = yy < H && xx < W;
+            const size_t gp = live ? ((size_t)tn0 * H + yy) * W + xx : 0;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                f32x16_ d;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[r] = 0.f;
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[rt][0], bq[0], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[rt][1], bq[1], d, 0, 0, 0);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int ch = rt * 32 + h * 16 + hi * 8;   // 8 consecutive channels: registers 8 h .. 8 h + 7
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = d[h * 8 + k];
+                    __bf16 *dptr = dx + gp * dx_ld + ch;
+                    if (accumulate) {
+                        const u32x4 o = *reinterpret_cast<const u32x4 *>(live ? dptr : dx);
+                        v[0] += fq_lo(o.x), v[1] += fq_hi(o.x), v[2] += fq_lo(o.y), v[3] += fq_hi(o.y);
+                        v[4] += fq_lo(o.z), v[5] += fq_hi(o.z), v[6] += fq_lo(o.w), v[7] += fq_hi(o.w);
+                    }
+                    if (dx_act != PWS_ACT_NONE) {   // act'(x) from the tile in LDS
+                        const u32x4 yv = *reinterpret_cast<const u32x4 *>(lds + FQ_SX + (ch >> 5) * FQ_PIX * FQ_ROW + pix * FQ_ROW + (ch & 31) * 2);
+                        v[0] *= fq_lo(yv.x) > 0.f ? 1.f : sl, v[1] *= fq_hi(yv.x) > 0.f ? 1.f : sl;
+                        v[2] *= fq_lo(yv.y) > 0.f ? 1.f : sl, v[3] *= fq_hi(yv.y) > 0.f ? 1.f : sl;
+                        v[4] *= fq_lo(yv.z) > 0.f ? 1.f : sl, v[5] *= fq_hi(yv.z) > 0.f ? 1.f : sl;
+                        v[6] *= fq_lo(yv.w) > 0.f ? 1.f : sl, v[7] *= fq_hi(yv.w) > 0.f ? 1.f : sl;
+                    }
+                    const u32x4 wq = {cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7])};
+                    if (live) *reinterpret_cast<u32x4 *>(dptr) = wq;
+                }
+            }
+        }
+        // ---- dW: this wave's channel half over its 128 pixels (8 k-steps of 16)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bf16x8 a = fq_tr_pair(lds, a_lane[0] + j * 16 * FQ_ROW, a_lane[1] + j * 16 * FQ_ROW);
+            const bf16x8 b = fq_tr_pair(lds, b_lane[0] + j * 16 * FQ_ROW, b_lane[1] + j * 16 * FQ_ROW);
+            accw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, accw, 0, 0, 0);
+        }
+    }
+    // ---- one atomic per (channel, g) and wave: lane column = g = 2 tap + o, register r = channel (r & 3) + 8 (r >> 2) + 4 hi of the half
+    if (l31 < 18) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            atomicAdd(dw + ((size_t)(l31 >> 1) * C + ch) * 2 + (l31 & 1), accw[r]);
+        }
+    }
+}
+
 // Deterministic mode: db_out[k] += sum over all pixels of gz[.][k], ONE workgroup, fixed order (strided partial sums per lane, then
 // a fixed tree) -- the per-sample workgroups of field_gz_kernel would add to db_out in arrival order.
 __global__ void __launch_bounds__(256) ordered_sum2_kernel(const float *__restrict__ gz, size_t pixels, float *__restrict__ db_out) {
@@ -385,6 +587,26 @@ int field_bwd_dx_dw(const float *x, int ld, const float *gz, int n, int h, int w
     PWS_REQUIRE(dx_act == PWS_ACT_NONE || (io16 && dx && (dx_act == PWS_ACT_LRELU || dx_act == PWS_ACT_RELU) && ld % 8 == 0),
                 "pws_field_head_bwd: dx_act needs bf16 storage, dx, PWS_ACT_LRELU / PWS_ACT_RELU and ld %% 8 == 0");
     const size_t total = (size_t)n * h * w;
+    if (io16 && dx && dw_out && c == 64 && ld % 8 == 0 && dx_ld % 8 == 0 && (reinterpret_cast<size_t>(x) & 15) == 0 &&
+        (reinterpret_cast<size_t>(dx) & 15) == 0 && g_experiment != 91) {
+        // dx and dW_out from one read of the activation, on the matrix cores (field_bwd16_mfma_kernel)
+        const int tiles_x = (w + FQ_T - 1) / FQ_T, tiles_y = (h + FQ_T - 1) / FQ_T;
+        const long ntiles = (long)tiles_x * tiles_y * n;
+        PWS_REQUIRE(ntiles < (1L << 30), "pws_field_head_bwd: too many tiles");
+        static PerDeviceInt ncu_dev;
+        int &ncu = ncu_dev.cur();
+        if (ncu == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        }
+        long gx = 3L * ncu;   // three resident workgroups per CU (51 KB of LDS each), each walks ntiles / gx tiles
+        if (gx > ntiles) gx = ntiles;
+        if (t_deterministic) gx = 1;   // one adding workgroup
+        hipLaunchKernelGGL(field_bwd16_mfma_kernel, dim3((unsigned)gx), dim3(256), 0, st, reinterpret_cast<const __bf16 *>(x), ld, gz, w_out, n, h,
+                           w, reinterpret_cast<__bf16 *>(dx), dx_ld, dx_accumulate, dx_act, dw_out, tiles_x, tiles_y, (int)ntiles);
+        return check_launch("field_bwd16_mfma_kernel");
+    }
     if (dx) {
         PWS_REQUIRE(!io16 || (c % 8 == 0 && dx_ld % 8 == 0), "pws_field_head_bwd: bf16 storage needs c and dx_ld to be multiples of 8");
         if (io16) {

@@ -292,14 +292,20 @@ def test_field_head_backward_bf16_storage_and_fused_activation_gradient(hip, act
         torch.cuda.synchronize()
         return dx.float(), dw, db, dth
     ref32 = run(L.pws_field_head_bwd_s, A.STORE_FP32)
-    plain = run(L.pws_field_head_bwd_s, A.STORE_BF16)
+    # c == 64 takes the fused matrix-core kernel (dx and dW from one read of x; gz and W_out enter the products as bf16);
+    # PWS_OPT_EXPERIMENT 91 keeps the VALU kernels (fp32 products), which every other channel count runs anyway
+    L.pws_set_option(A.OPT_EXPERIMENT, 91)
+    try:
+        plain = run(L.pws_field_head_bwd_s, A.STORE_BF16)
+        fused = run(L.pws_field_head_bwd_act, A.STORE_BF16, getattr(A, act)) if act != "ACT_NONE" else None
+    finally:
+        L.pws_set_option(A.OPT_EXPERIMENT, 0)
     assert torch.equal(plain[0], ref32[0].bfloat16().float())       # same fp32 sums, one rounding
     for a_, b_ in zip(ref32[1:], plain[1:]):
         np.testing.assert_allclose(b_.cpu().numpy(), a_.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(a_.abs().max()))
+    slope = 0.2 if act == "ACT_LRELU" else 0.0
+    xv = x.float()
     if act != "ACT_NONE":
-        fused = run(L.pws_field_head_bwd_act, A.STORE_BF16, getattr(A, act))
-        slope = 0.2 if act == "ACT_LRELU" else 0.0
-        xv = x.float()
         want = (plain[0] * torch.where(xv > 0, torch.ones_like(xv), torch.full_like(xv, slope))).bfloat16().float()
         if act == "ACT_RELU":
             assert torch.equal(fused[0], want)
@@ -311,6 +317,34 @@ def test_field_head_backward_bf16_storage_and_fused_activation_gradient(hip, act
         assert L.pws_field_head_bwd_act(A.ptr(xf), c, n, h, w, c, A.ptr(w_out), A.ptr(resid), A.ptr(gg), None, 0, A.ptr(xf.clone()), c, 0,
                                         None, None, None, A.ptr(torch.empty(n * h * w * 2, device="cuda")), A.STORE_FP32, getattr(A, act),
                                         st) == -22
+    if c == 64:
+        # ---- the matrix-core kernel against a float64 model of ITS arithmetic: gz and W_out rounded to bf16, exact products
+        L.pws_prof_enable(1)
+        got = run(L.pws_field_head_bwd_act, A.STORE_BF16, getattr(A, act))
+        L.pws_prof_enable(0)
+        assert [r[0] for r in A.prof_collect()] == ["field_head_bwd_kernels"]
+        ws = torch.empty(n * h * w * 2, device="cuda")     # gz of the same call (the kernel's input), recomputed by the plain call
+        dxs = old.clone()
+        A.check(L.pws_field_head_bwd_s(A.ptr(x), c, n, h, w, c, A.ptr(w_out), A.ptr(resid), A.ptr(gg), None, 0, A.ptr(dxs), c, acc, None, None,
+                                       None, A.ptr(ws), A.STORE_BF16, st), "gz")
+        gz16 = ws.view(n, h, w, 2).bfloat16().double().permute(0, 3, 1, 2)                    # n, 2, h, w
+        w16 = w_out.bfloat16().double()                                                      # [tap][c][o]
+        kern = w16.view(3, 3, c, 2).flip(0, 1).permute(2, 3, 0, 1).contiguous()               # [c][o][ky][kx] = W[(2-ky)*3 + 2-kx][c][o]
+        dxm = torch.nn.functional.conv2d(gz16, kern, padding=1).permute(0, 2, 3, 1)          # n, h, w, c
+        if acc:
+            dxm = dxm + old.double()
+        if act != "ACT_NONE":
+            dxm = dxm * torch.where(xv > 0, torch.ones_like(xv), torch.full_like(xv, slope)).double()
+        err = (got[0].double() - dxm).abs()
+        assert bool((err <= 2.0 ** -7 * dxm.abs() + 1e-5).all()), float((err / (dxm.abs() + 1e-3)).max())    # one bf16 rounding (+ fp32 sum order)
+        xp = torch.nn.functional.pad(xv.double().permute(0, 3, 1, 2), (1, 1, 1, 1))           # n, c, h+2, w+2
+        dwm = torch.stack([torch.einsum("nchw,nohw->co", xp[:, :, ty:ty + h, tx:tx + w], gz16) for ty in range(3) for tx in range(3)])
+        np.testing.assert_allclose(got[1].cpu().numpy(), dwm.cpu().numpy(), rtol=0, atol=2e-5 * float(dwm.abs().max()))
+        # ... and within bf16 accuracy of the fp32-product kernels
+        assert float((got[0] - (fused[0] if fused is not None else plain[0])).abs().max() / plain[0].abs().max()) < 2 ** -6
+        np.testing.assert_allclose(got[1].cpu().numpy(), plain[1].cpu().numpy(), rtol=0, atol=4e-3 * float(plain[1].abs().max()))
+        for a_, b_ in zip(plain[2:], got[2:]):   # bias / theta gradients: the unchanged gz kernel
+            np.testing.assert_allclose(b_.cpu().numpy(), a_.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(a_.abs().max()))
 
 
 DEEP_CASES = [

@@ -79,6 +79,14 @@ def test_u8_hwc_fused_warp(hip, shape, swap):
     d_u8, d_field = u8.cuda(), field.cuda()
     got = PF.upsample_grid_sample_u8(d_u8, d_field, swap_rb=swap).cpu()
     assert got.dtype == torch.uint8 and got.shape == u8.shape
+    # the row-window / wave-shuffle variant (PWS_OPT_EXPERIMENT 4: measured, not faster) and the per-tap gathers blend the
+    # same bytes with the same weights in the same order: byte-identical
+    hip.lib().pws_set_option(hip.OPT_EXPERIMENT, 4)
+    try:
+        taps = PF.upsample_grid_sample_u8(d_u8, d_field, swap_rb=swap).cpu()
+    finally:
+        hip.lib().pws_set_option(hip.OPT_EXPERIMENT, 0)
+    assert torch.equal(got, taps)
     # (a) the float HIP path + truncation: same taps and weights; the 4-term blend may be contracted into FMAs differently
     # by the compiler in the two kernels, so a value within 1e-3 of an integer may truncate to the neighbour
     fl = d_u8.float().permute(0, 3, 1, 2)
