@@ -91,6 +91,9 @@ __global__ void __launch_bounds__(256) grid_sample_fwd_kernel(const float *__res
 struct __attribute__((packed, aligned(4))) F2U {
     float x, y;
 };
+struct __attribute__((packed, aligned(4))) F4U {
+    float x, y, z, w;
+};
 struct Taps2 {
     int o0, o1;          // offsets of the two row pairs inside a channel plane
     float a0, b0, a1, b1;  // weights of (pair.x, pair.y) for row 0 and row 1
@@ -118,14 +121,20 @@ __device__ __forceinline__ Taps2 make_taps2(float gx, float gy, int H, int W, bo
 // NT: streaming (non-temporal) field loads and output stores -- data touched exactly once -- so that L2 / Infinity Cache keep
 // the frame lines that neighbouring rows re-read.  Pays when the launch's traffic exceeds the 256 MB Infinity Cache
 // (N=256: 140 -> 127 us); below that it costs (N=64: 27 -> 34 us), so the entry point picks by size.
-template <int PPT, bool NT>
+// ROWWIN (PWS_OPT_EXPERIMENT 5, measured and NOT taken -- DESIGN.md "wavefront shuffles"): a lane whose 4 pixels read at most 5
+// consecutive columns of ONE source row pair fetches each row of a plane as one 16-byte load and takes the fifth column from the
+// next lane's window through a wave shuffle (when that window starts exactly 4 columns further), instead of 4 paired 8-byte gathers
+// per row: 2 (+ fallback) instead of 8 vector memory instructions per lane and plane.
+template <int PPT, bool NT, bool ROWWIN = false>
 __global__ void __launch_bounds__(256) grid_sample_fwd2_kernel(const float *__restrict__ input,
                                                                const float *__restrict__ grid, float *__restrict__ out,
                                                                int C, int H, int W, int HoWo, size_t total_groups,
                                                                unsigned nblocks, int ac) {
     const unsigned blk = xcd_remap(blockIdx.x, nblocks);
-    const size_t gidx = (size_t)blk * 256 + threadIdx.x;
-    if (gidx >= total_groups) return;
+    const size_t gidx_raw = (size_t)blk * 256 + threadIdx.x;
+    if (!ROWWIN && gidx_raw >= total_groups) return;
+    const bool live = gidx_raw < total_groups;   // ROWWIN: lanes past the end run on the last group (the shuffles want every lane)
+    const size_t gidx = live ? gidx_raw : total_groups - 1;
     const size_t p0 = gidx * PPT;
     const int n = (int)(p0 / HoWo);
     const int hw = (int)(p0 % HoWo);
@@ -148,15 +157,57 @@ __global__ void __launch_bounds__(256) grid_sample_fwd2_kernel(const float *__re
 #pragma unroll
     for (int i = 0; i < PPT; ++i) t[i] = make_taps2(g[2 * i], g[2 * i + 1], H, W, ac != 0);
     const size_t plane = (size_t)H * W;
+    bool fast = false;
+    int lo = 0;
+    bool loads = false;
+    if constexpr (ROWWIN && PPT == 4) {
+        lo = t[0].xs;
+        int hi_ = t[0].xs;
+        bool same = true;
+#pragma unroll
+        for (int i = 1; i < PPT; ++i) {
+            lo = min(lo, t[i].xs), hi_ = max(hi_, t[i].xs);
+            same = same && t[i].r0 == t[0].r0 && t[i].r1 == t[0].r1;
+        }
+        loads = same && (size_t)t[0].r0 * W + lo + 4 <= plane && (size_t)t[0].r1 * W + lo + 4 <= plane;   // the window stays inside the plane
+        const int span = hi_ - lo;   // the last pixel's pair ends at column lo + span + 1
+        const int nb_lo = __shfl_down(lo, 1, 64), nb_r0 = __shfl_down(t[0].r0, 1, 64), nb_r1 = __shfl_down(t[0].r1, 1, 64);
+        const bool nb_loads = __shfl_down((int)loads, 1, 64) != 0;
+        const bool nb_ok = (threadIdx.x & 63) != 63 && nb_loads && nb_lo == lo + 4 && nb_r0 == t[0].r0 && nb_r1 == t[0].r1;
+        fast = loads && (span <= 2 || (span == 3 && nb_ok));
+    }
     for (int c = 0; c < C; ++c) {
         const float *ip = input + ((size_t)n * C + c) * plane;
         float r[PPT];
+        if constexpr (ROWWIN && PPT == 4) {
+            float w0[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, w1[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            if (loads) {
+                const F4U a = *reinterpret_cast<const F4U *>(ip + (size_t)t[0].r0 * W + lo);
+                const F4U b = *reinterpret_cast<const F4U *>(ip + (size_t)t[0].r1 * W + lo);
+                w0[0] = a.x, w0[1] = a.y, w0[2] = a.z, w0[3] = a.w, w1[0] = b.x, w1[1] = b.y, w1[2] = b.z, w1[3] = b.w;
+            }
+            w0[4] = __shfl_down(w0[0], 1, 64), w1[4] = __shfl_down(w1[0], 1, 64);   // the next lane's first column = this lane's fifth
+            if (fast) {
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            const F2U u = *reinterpret_cast<const F2U *>(ip + t[i].o0);
-            const F2U v = *reinterpret_cast<const F2U *>(ip + t[i].o1);
-            r[i] = u.x * t[i].a0 + u.y * t[i].b0 + v.x * t[i].a1 + v.y * t[i].b1;
+                for (int i = 0; i < PPT; ++i) {
+                    const int d = t[i].xs - lo;   // 0 .. 3
+                    const float ux = d == 0 ? w0[0] : (d == 1 ? w0[1] : (d == 2 ? w0[2] : w0[3]));
+                    const float uy = d == 0 ? w0[1] : (d == 1 ? w0[2] : (d == 2 ? w0[3] : w0[4]));
+                    const float vx = d == 0 ? w1[0] : (d == 1 ? w1[1] : (d == 2 ? w1[2] : w1[3]));
+                    const float vy = d == 0 ? w1[1] : (d == 1 ? w1[2] : (d == 2 ? w1[3] : w1[4]));
+                    r[i] = ux * t[i].a0 + uy * t[i].b0 + vx * t[i].a1 + vy * t[i].b1;
+                }
+            }
         }
+        if (!fast) {
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                const F2U u = *reinterpret_cast<const F2U *>(ip + t[i].o0);
+                const F2U v = *reinterpret_cast<const F2U *>(ip + t[i].o1);
+                r[i] = u.x * t[i].a0 + u.y * t[i].b0 + v.x * t[i].a1 + v.y * t[i].b1;
+            }
+        }
+        if (ROWWIN && !live) continue;
         float *op = out + ((size_t)n * C + c) * HoWo + hw;
         if constexpr (PPT == 4) {
             const f32x4 o = {r[0], r[1], r[2], r[3]};
@@ -642,8 +693,14 @@ extern "C" int pws_grid_sample_fwd(const float *input, const float *grid, float 
         const size_t groups = total / 4;
         const unsigned nb = (unsigned)((groups + 255) / 256);
         // streaming hints once the launch no longer fits the 256 MB Infinity Cache (see the kernel's comment)
-        const bool nt = g_experiment == 1 || (g_experiment == 0 && (double)total * (8.0 + 8.0 * c) > 256e6);
-        if (nt)
+        const bool nt = g_experiment == 1 || ((g_experiment == 0 || g_experiment == 5) && (double)total * (8.0 + 8.0 * c) > 256e6);
+        if (g_experiment == 5 && nt)   // row window + wave shuffle (A/B only, tools/gs_shuffle_ab.py)
+            hipLaunchKernelGGL((grid_sample_fwd2_kernel<4, true, true>), dim3(nb), dim3(256), 0, as_stream(stream), input, grid, out, c, h,
+                               w, howo, groups, nb, align_corners);
+        else if (g_experiment == 5)
+            hipLaunchKernelGGL((grid_sample_fwd2_kernel<4, false, true>), dim3(nb), dim3(256), 0, as_stream(stream), input, grid, out, c, h,
+                               w, howo, groups, nb, align_corners);
+        else if (nt)
             hipLaunchKernelGGL((grid_sample_fwd2_kernel<4, true>), dim3(nb), dim3(256), 0, as_stream(stream), input, grid, out, c, h,
                                w, howo, groups, nb, align_corners);
         else

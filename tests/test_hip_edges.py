@@ -78,3 +78,29 @@ def test_netg_odd_batches_match_oracle(hip, oracle, n):
         got = net(torch.from_numpy(xw).cuda(), False).cpu().numpy()
     ref = oracle.netg_forward([v for _, v in weights], xw, is_training=False, ngf=ngf)["grids"][0]
     assert np.abs(got - ref).max() < 5e-4
+
+
+@pytest.mark.parametrize("shape,n", [((64, 64), 3), ((256, 256), 2), ((37, 52), 5)])
+def test_grid_sample_row_window_shuffle_variant_is_bit_identical(hip, shape, n):
+    """north_star's "wavefront shuffles for the bilinear gather": the row-window + wave-shuffle variant of grid_sample forward
+    (PWS_OPT_EXPERIMENT 5; measured in DESIGN.md, not the product default) must give the product kernel's values bit for bit -- on a
+    translation (every lane takes the window), on a rotated / scaled field (mixed waves), on a field that leaves the frame, and on a
+    group count that is not a multiple of the workgroup."""
+    import torch.nn.functional as F
+    from pwstablenet_amd import functional as PF
+    h, w = shape
+    rs = np.random.RandomState(h + n)
+    img = torch.from_numpy(rs.uniform(0, 255, (n, 3, h, w)).astype(np.float32)).cuda()
+    eye = torch.tensor([[1.0, 0, 0], [0, 1.0, 0]])
+    thetas = {"translation": eye + torch.tensor([[0, 0, 0.031], [0, 0, -0.017]]),
+              "rotation+scale": torch.tensor([[1.04, 0.06, 0.01], [-0.05, 0.97, 0.02]]),
+              "leaves the frame": torch.tensor([[1.3, 0.0, 0.4], [0.0, 1.2, -0.5]])}
+    for name, th in thetas.items():
+        grid = F.affine_grid(th.unsqueeze(0).repeat(n, 1, 1), (n, 3, h, w), align_corners=False).cuda()
+        want = PF.grid_sample(img, grid)
+        hip.lib().pws_set_option(hip.OPT_EXPERIMENT, 5)
+        try:
+            got = PF.grid_sample(img, grid)
+        finally:
+            hip.lib().pws_set_option(hip.OPT_EXPERIMENT, 0)
+        assert torch.equal(got, want), name
