@@ -457,8 +457,19 @@ __global__ void __launch_bounds__(256, 2) field_bwd16_mfma_kernel(const __bf16 *
             accw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, accw, 0, 0, 0);
         }
     }
-    // ---- one atomic per (channel, g) and wave: lane column = g = 2 tap + o, register r = channel (r & 3) + 8 (r >> 2) + 4 hi of the half
-    if (l31 < 18) {
+    // ---- the two pixel halves of a channel half meet in LDS (one atomic per address and workgroup: with ONE workgroup --
+    // deterministic mode -- every address gets a single add per launch), then one atomic per (channel, g): lane column = g = 2 tap + o,
+    // register r = channel (r & 3) + 8 (r >> 2) + 4 hi of the half
+    __syncthreads();   // every wave is done with the tiles in LDS
+    float *red = reinterpret_cast<float *>(lds);
+    if (wph == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wci * 16 + r) * 64 + lane] = accw[r];
+    }
+    __syncthreads();
+    if (wph == 0 && l31 < 18) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accw[r] += red[(wci * 16 + r) * 64 + lane];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ch = wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
