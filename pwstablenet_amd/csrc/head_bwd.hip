@@ -278,7 +278,8 @@ __global__ void __launch_bounds__(256) field_dw_kernel(const float *__restrict__
 // Layouts (copied from wgrad_bf16_kernel, which pins them with tools/probes/tr16_read_probe.hip): x tile = two 32-channel planes of
 // [256 px][64 B] rows, G' = one plane of [256 px][32 g]; an operand with K = pixels is two ds_read_b64_tr_b16.
 constexpr int FQ_T = 16, FQ_PIX = FQ_T * FQ_T, FQ_ROW = 64;
-constexpr int FQ_SX = 0, FQ_SG = 2 * FQ_PIX * FQ_ROW, FQ_SGZ = FQ_SG + FQ_PIX * FQ_ROW;
+constexpr int FQ_PLANE = FQ_PIX * FQ_ROW + 128;   // + 128 B: the two channel planes of a pixel (staged by lanes c8 and c8 + 4) on different banks
+constexpr int FQ_SX = 0, FQ_SG = 2 * FQ_PLANE, FQ_SGZ = FQ_SG + FQ_PIX * FQ_ROW;
 constexpr int FQ_HALO = FQ_T + 2;
 constexpr int FQ_LDS = FQ_SGZ + FQ_HALO * FQ_HALO * 8;
 
@@ -333,18 +334,22 @@ __global__ void __launch_bounds__(256, 2) field_bwd16_mfma_kernel(const __bf16 *
 #pragma unroll
     for (int r = 0; r < 16; ++r) accw[r] = 0.f;
     const int wci = wv & 1, wph = wv >> 1;
+    // The four 16-byte slots of a 64-byte row are permuted by XOR with bits 2..3 of the row (pixel) index: the row-strided 16-byte
+    // accesses (G' rows written / read per pixel, act'(x) reads of the dx epilogue) then spread over all banks, and a transposing read
+    // still covers them exactly once (its 4 consecutive rows share the XOR).  Unpermuted: 55 % of the LDS cycles were bank conflicts.
     const int colb = (16 * (lg & 1) + 4 * (li & 3)) * 2;
     int a_lane[2], b_lane[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int c = 8 * (lg >> 1) + 4 * q + (li >> 2);
-        a_lane[q] = FQ_SX + wci * FQ_PIX * FQ_ROW + (wph * 128 + c) * FQ_ROW + colb;
-        b_lane[q] = FQ_SG + (wph * 128 + c) * FQ_ROW + colb;
+        const int cs = colb ^ (((c >> 2) & 3) << 4);
+        a_lane[q] = FQ_SX + wci * FQ_PLANE + (wph * 128 + c) * FQ_ROW + cs;
+        b_lane[q] = FQ_SG + (wph * 128 + c) * FQ_ROW + cs;
     }
 
     // ---- staging: lane = (pixel tid >> 3 (+ 32 per item), 8-channel piece tid & 7)
     const int c8 = tid & 7, p0 = tid >> 3;
-    const int xl0 = FQ_SX + (c8 >> 2) * FQ_PIX * FQ_ROW + p0 * FQ_ROW + (c8 & 3) * 16;
+    const int xl0 = FQ_SX + (c8 >> 2) * FQ_PLANE + p0 * FQ_ROW + (((c8 & 3) ^ ((p0 >> 2) & 3)) << 4);   // (pixel p0 + 32 it: same XOR)
     u32x4 rx[8];
     float2 rg[2];
     unsigned okx = 0;
@@ -402,10 +407,11 @@ __global__ void __launch_bounds__(256, 2) field_bwd16_mfma_kernel(const __bf16 *
                 wd[tap] = cvt_pk_bf16(v.x, v.y);
             }
             u32x4 *row = reinterpret_cast<u32x4 *>(lds + FQ_SG + tid * FQ_ROW);
-            row[0] = u32x4{wd[0], wd[1], wd[2], wd[3]};
-            row[1] = u32x4{wd[4], wd[5], wd[6], wd[7]};
-            row[2] = u32x4{wd[8], 0u, 0u, 0u};
-            row[3] = u32x4{0u, 0u, 0u, 0u};
+            const int sw = (tid >> 2) & 3;
+            row[0 ^ sw] = u32x4{wd[0], wd[1], wd[2], wd[3]};
+            row[1 ^ sw] = u32x4{wd[4], wd[5], wd[6], wd[7]};
+            row[2 ^ sw] = u32x4{wd[8], 0u, 0u, 0u};
+            row[3 ^ sw] = u32x4{0u, 0u, 0u, 0u};
         }
         __syncthreads();
         // ---- dx of this wave's 64 pixels: two column tiles of 32 pixels x two row tiles of 32 channels x two k-steps
@@ -414,7 +420,8 @@ __global__ void __launch_bounds__(256, 2) field_bwd16_mfma_kernel(const __bf16 *
             const int pix = wv * 64 + ct * 32 + l31;
             bf16x8 bq[2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) bq[ks] = *reinterpret_cast<const bf16x8 *>(lds + FQ_SG + pix * FQ_ROW + (ks * 16 + hi * 8) * 2);
+            for (int ks = 0; ks < 2; ++ks)
+                bq[ks] = *reinterpret_cast<const bf16x8 *>(lds + FQ_SG + pix * FQ_ROW + (((ks * 2 + hi) ^ ((pix >> 2) & 3)) << 4));
             const int yy = ty0 + (pix >> 4), xx = tx0 + (pix & 15);
             const bool live = yy < H && xx < W;
             const size_t gp = live ? ((size_t)tn0 * H + yy) * W + xx : 0;
@@ -438,7 +445,8 @@ __global__ void __launch_bounds__(256, 2) field_bwd16_mfma_kernel(const __bf16 *
                         v[4] += fq_lo(o.z), v[5] += fq_hi(o.z), v[6] += fq_lo(o.w), v[7] += fq_hi(o.w);
                     }
                     if (dx_act != PWS_ACT_NONE) {   // act'(x) from the tile in LDS
-                        const u32x4 yv = *reinterpret_cast<const u32x4 *>(lds + FQ_SX + (ch >> 5) * FQ_PIX * FQ_ROW + pix * FQ_ROW + (ch & 31) * 2);
+                        const u32x4 yv = *reinterpret_cast<const u32x4 *>(lds + FQ_SX + (ch >> 5) * FQ_PLANE + pix * FQ_ROW +
+                                                                          ((((ch & 31) >> 3) ^ ((pix >> 2) & 3)) << 4));
                         v[0] *= fq_lo(yv.x) > 0.f ? 1.f : sl, v[1] *= fq_hi(yv.x) > 0.f ? 1.f : sl;
                         v[2] *= fq_lo(yv.y) > 0.f ? 1.f : sl, v[3] *= fq_hi(yv.y) > 0.f ? 1.f : sl;
                         v[4] *= fq_lo(yv.z) > 0.f ? 1.f : sl, v[5] *= fq_hi(yv.z) > 0.f ? 1.f : sl;
