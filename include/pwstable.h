@@ -506,6 +506,16 @@ int pws_netg_forward_bn(const float *packed, const float *bn_params, float *bn_r
 int pws_netg_backward_bn(const float *packed, const float *packed_dgrad, const float *bn_params, float eps, const float *x, int n,
                          int input_nc, int ngf, int align_corners, void *ws, size_t ws_bytes, const float *resid, const float *thetas,
                          const float *g_grids, const float *g_resid, float *dpacked, float *dbn, pws_stream_t stream);
+/* The same two with their mode in the arguments: opts->math = PWS_MATH_BF16 runs the conv contractions (forward, data and weight
+ * gradients) on the bf16 matrix cores -- operands rounded while they are staged, fp32 accumulation; activations, BatchNorm
+ * statistics and gradients stay fp32 (opts->store must be PWS_STORE_FP32).  opts == NULL: fp32. */
+int pws_netg_forward_bn_opts(const float *packed, const float *bn_params, float *bn_running, float momentum, float eps, const float *x,
+                             int n, int input_nc, int ngf, int align_corners, void *ws, size_t ws_bytes, float *grids, float *resid,
+                             float *thetas, const pws_netg_opts *opts, pws_stream_t stream);
+int pws_netg_backward_bn_opts(const float *packed, const float *packed_dgrad, const float *bn_params, float eps, const float *x, int n,
+                              int input_nc, int ngf, int align_corners, void *ws, size_t ws_bytes, const float *resid,
+                              const float *thetas, const float *g_grids, const float *g_resid, float *dpacked, float *dbn,
+                              const pws_netg_opts *opts, pws_stream_t stream);
 /* grads: HOST array of 92 DEVICE pointers (torch layouts, state-dict order), overwritten; a layer whose weight AND bias
  * pointers are NULL is skipped. */
 int pws_netg_unpack_grads(const float *dpacked, float *const *grads, int input_nc, int ngf, pws_stream_t stream);

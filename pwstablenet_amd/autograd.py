@@ -154,9 +154,11 @@ class _NetGTrainBN(torch.autograd.Function):
         resid = torch.empty((3, n, 256, 256, 2), device=dev, dtype=torch.float32)
         thetas = torch.empty((3, n, 6), device=dev, dtype=torch.float32)
         eps, mom = float(bns[0].eps), float(bns[0].momentum if bns[0].momentum is not None else 0.1)
-        A.check(L.pws_netg_forward_bn(A.ptr(packed), A.ptr(bn_params), A.ptr(running), mom, eps, A.ptr(x), n, net.input_nc, net.ngf, int(net.align_corners),
-                                      ctypes.c_void_p(ws_ptr), ws_bytes, A.ptr(grids), A.ptr(resid), A.ptr(thetas), st),
-                "pws_netg_forward_bn")
+        # the BatchNorm path stores fp32 activations whatever set_math's storage says; its conv contractions follow net.math
+        opts = net._opts(net.math, "fp32")
+        A.check(L.pws_netg_forward_bn_opts(A.ptr(packed), A.ptr(bn_params), A.ptr(running), mom, eps, A.ptr(x), n, net.input_nc, net.ngf,
+                                           int(net.align_corners), ctypes.c_void_p(ws_ptr), ws_bytes, A.ptr(grids), A.ptr(resid), A.ptr(thetas),
+                                           ctypes.byref(opts), st), "pws_netg_forward_bn_opts")
         with torch.no_grad():   # running statistics back into the modules (plumbing), call counters as nn.BatchNorm2d keeps them
             off = 0
             for bn, uses in zip(bns, _bn_uses(net)):
@@ -168,7 +170,7 @@ class _NetGTrainBN(torch.autograd.Function):
         net.last_thetas = thetas
         ctx.net_ref = net_ref
         ctx.saved = dict(x=x, ws=ws, ws_ptr=ws_ptr, ws_bytes=ws_bytes, resid=resid, thetas=thetas, packed=packed, bn_params=bn_params,
-                         eps=eps, ac=int(net.align_corners))
+                         eps=eps, ac=int(net.align_corners), math=net.math)
         return (grids[0], grids[1], grids[2], resid[0], resid[1], resid[2])
 
     @staticmethod
@@ -190,9 +192,11 @@ class _NetGTrainBN(torch.autograd.Function):
         packed, packed_dg = sv["packed"], net.packed_dgrad_weights()
         dpacked = torch.empty_like(packed)
         dbn = torch.empty_like(sv["bn_params"])
-        A.check(L.pws_netg_backward_bn(A.ptr(packed), A.ptr(packed_dg), A.ptr(sv["bn_params"]), sv["eps"], A.ptr(sv["x"]), n, net.input_nc,
-                                       net.ngf, sv["ac"], ctypes.c_void_p(sv["ws_ptr"]), sv["ws_bytes"], A.ptr(sv["resid"]), A.ptr(sv["thetas"]),
-                                       A.ptr(g_grids), A.ptr(g_resid), A.ptr(dpacked), A.ptr(dbn), st), "pws_netg_backward_bn")
+        opts = net._opts(sv["math"], "fp32")   # the arena holds what the forward's mode wrote
+        A.check(L.pws_netg_backward_bn_opts(A.ptr(packed), A.ptr(packed_dg), A.ptr(sv["bn_params"]), sv["eps"], A.ptr(sv["x"]), n, net.input_nc,
+                                            net.ngf, sv["ac"], ctypes.c_void_p(sv["ws_ptr"]), sv["ws_bytes"], A.ptr(sv["resid"]),
+                                            A.ptr(sv["thetas"]), A.ptr(g_grids), A.ptr(g_resid), A.ptr(dpacked), A.ptr(dbn), ctypes.byref(opts), st),
+                "pws_netg_backward_bn_opts")
         params = net._ordered_params()
         grads = [torch.empty_like(p) for p in params]
         ptrs = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])

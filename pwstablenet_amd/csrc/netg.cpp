@@ -888,9 +888,29 @@ extern "C" size_t pws_netg_train_workspace_bytes_bn(int n, int input_nc, int ngf
     return used;
 }
 
+// mode of the BatchNorm training path: fp32 storage always (the BatchNorm kernels are fp32); the conv contractions in fp32 or on the
+// bf16 matrix cores (operands rounded while they are staged, fp32 accumulation), as pws_netg_opts.math says
+static int bn_opts_from(const pws_netg_opts *opts, NetgOpts *o) {
+    *o = NetgOpts{PWS_MATH_FP32, PWS_STORE_FP32, g_two_queues};
+    if (!opts) return PWS_OK;
+    NetgOpts u;
+    if (int rc = opts_from(opts, &u)) return rc;
+    PWS_REQUIRE(u.store == PWS_STORE_FP32 && u.x_sample_stride == 0,
+                "pws_netg_*_bn_opts: the BatchNorm training path stores fp32 activations (store must be PWS_STORE_FP32) and reads a dense window");
+    o->math = u.math, o->two_queues = u.two_queues, o->deterministic = u.deterministic;
+    return PWS_OK;
+}
+
 extern "C" int pws_netg_forward_bn(const float *packed, const float *bn_params, float *bn_running, float momentum, float eps,
                                    const float *x, int n, int input_nc, int ngf, int align_corners, void *ws, size_t ws_bytes,
                                    float *grids, float *resid, float *thetas, pws_stream_t stream) {
+    return pws_netg_forward_bn_opts(packed, bn_params, bn_running, momentum, eps, x, n, input_nc, ngf, align_corners, ws, ws_bytes, grids, resid,
+                                    thetas, nullptr, stream);
+}
+
+extern "C" int pws_netg_forward_bn_opts(const float *packed, const float *bn_params, float *bn_running, float momentum, float eps,
+                                        const float *x, int n, int input_nc, int ngf, int align_corners, void *ws, size_t ws_bytes,
+                                        float *grids, float *resid, float *thetas, const pws_netg_opts *opts, pws_stream_t stream) {
     PWS_REQUIRE(n >= 0 && input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_forward_bn: bad n/input_nc/ngf %d/%d/%d", n, input_nc, ngf);
     if (n == 0) return PWS_OK;
     PWS_REQUIRE(n >= 2, "pws_netg_forward_bn: training-mode BatchNorm needs more than 1 value per channel (the theta head has one per "
@@ -901,7 +921,8 @@ extern "C" int pws_netg_forward_bn(const float *packed, const float *bn_params, 
     const std::vector<Layer> L = build_layers(input_nc, ngf, &total);
     BnCfg bn;
     bn.params = bn_params, bn.running = bn_running, bn.momentum = momentum, bn.eps = eps;
-    const NetgOpts o{PWS_MATH_FP32, PWS_STORE_FP32, g_two_queues};   // the BatchNorm training path is fp32 whatever the defaults say
+    NetgOpts o;   // opts == NULL: fp32 whatever the process defaults say
+    if (int rc = bn_opts_from(opts, &o)) return rc;
     Exec E(packed, L, n, static_cast<char *>(ws), ws_bytes, as_stream(stream), false, true, o, &bn);
     forward_graph(E, x, n, input_nc, ngf, 1, align_corners, grids, resid, thetas);
     return E.rc();
@@ -911,13 +932,22 @@ extern "C" int pws_netg_backward_bn(const float *packed, const float *packed_dgr
                                     int n, int input_nc, int ngf, int align_corners, void *ws, size_t ws_bytes, const float *resid,
                                     const float *thetas, const float *g_grids, const float *g_resid, float *dpacked, float *dbn,
                                     pws_stream_t stream) {
+    return pws_netg_backward_bn_opts(packed, packed_dgrad, bn_params, eps, x, n, input_nc, ngf, align_corners, ws, ws_bytes, resid, thetas, g_grids,
+                                     g_resid, dpacked, dbn, nullptr, stream);
+}
+
+extern "C" int pws_netg_backward_bn_opts(const float *packed, const float *packed_dgrad, const float *bn_params, float eps, const float *x,
+                                         int n, int input_nc, int ngf, int align_corners, void *ws, size_t ws_bytes, const float *resid,
+                                         const float *thetas, const float *g_grids, const float *g_resid, float *dpacked, float *dbn,
+                                         const pws_netg_opts *opts, pws_stream_t stream) {
     PWS_REQUIRE(n >= 2 && input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_backward_bn: bad n/input_nc/ngf");
     PWS_REQUIRE(packed && packed_dgrad && bn_params && x && ws && resid && thetas && dpacked && dbn, "pws_netg_backward_bn: NULL pointer");
     PWS_REQUIRE(g_grids || g_resid, "pws_netg_backward_bn: no output gradient given");
     PWS_REQUIRE((reinterpret_cast<size_t>(ws) & 255) == 0, "pws_netg_backward_bn: workspace must be 256-byte aligned");
     BnCfg bn;
     bn.params = bn_params, bn.eps = eps;
-    const NetgOpts o{PWS_MATH_FP32, PWS_STORE_FP32, g_two_queues};
+    NetgOpts o;
+    if (int rc = bn_opts_from(opts, &o)) return rc;
     return run_backward(packed, packed_dgrad, x, n, input_nc, ngf, align_corners, static_cast<char *>(ws), ws_bytes, resid, thetas, g_grids,
                         g_resid, dpacked, as_stream(stream), false, nullptr, 0, 1, nullptr, &bn, dbn, &o);
 }

@@ -112,6 +112,8 @@ SIGNATURES = {
     "pws_netg_train_workspace_bytes_bn": (_S, [_I, _I, _I]),
     "pws_netg_forward_bn": (_I, [_P, _P, _P, _F, _F, _P, _I, _I, _I, _I, _P, _S, _P, _P, _P, _P]),
     "pws_netg_backward_bn": (_I, [_P, _P, _P, _F, _P, _I, _I, _I, _I, _P, _S, _P, _P, _P, _P, _P, _P, _P]),
+    "pws_netg_forward_bn_opts": (_I, [_P, _P, _P, _F, _F, _P, _I, _I, _I, _I, _P, _S, _P, _P, _P, ctypes.POINTER(PwsNetgOpts), _P]),
+    "pws_netg_backward_bn_opts": (_I, [_P, _P, _P, _F, _P, _I, _I, _I, _I, _P, _S, _P, _P, _P, _P, _P, _P, ctypes.POINTER(PwsNetgOpts), _P]),
     "pws_netg_unpack_grads": (_I, [_P, ctypes.POINTER(_P), _I, _I, _P]),
     "pws_theta_head_ws_floats": (_S, [_I, _I, _I]),
     "pws_theta_head_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),

@@ -279,8 +279,8 @@ class UnetGenerator(nn.Module):
         if self.use_BN and self.training:
             # train() mode: batch statistics, running statistics updated, as nn.BatchNorm2d (the reference's forward always
             # returns the six training outputs here; netG(x, False) in train() mode still normalises with batch statistics)
-            if self.math != "fp32":
-                raise NotImplementedError("UnetGenerator(use_BN=True).train(): the BatchNorm training path runs in fp32 (set_math('fp32'))")
+            # (set_math('bf16'): the conv contractions run on the bf16 matrix cores; activations, BatchNorm statistics and gradients
+            # stay fp32 -- the BatchNorm kernels are fp32 -- whatever the storage set_math chose for the BatchNorm-free path)
             from ..autograd import netg_apply_bn
             grids, resid = netg_apply_bn(self, input1)
             return (grids, resid) if is_training else grids[2]
