@@ -439,6 +439,14 @@ __global__ void __launch_bounds__(256) affine_grid_bwd_kernel(const float *__res
     if (threadIdx.x < 6) gtheta[(size_t)n * 6 + threadIdx.x] = (float)red[threadIdx.x][0];
 }
 
+// The field's bilinear interpolation with its roundings spelled out (one fma chain): left as a plain expression, hipcc contracted
+// it differently in different instantiations of the kernels below, and a last-ulp difference of a coordinate flips a byte of the
+// uint8 output where the blend lands on an integer.
+__device__ __forceinline__ float field_lerp(float hy, float ly, float hx, float lx, float a, float b, float c, float d) {
+    const float top = fmaf(lx, b, hx * a), bot = fmaf(lx, d, hx * c);
+    return fmaf(ly, bot, hy * top);
+}
+
 // ---------------------------------------------------------------------------------------------- fused 720p path
 // field [n,fh,fw,2] --(bilinear, align_corners=True, never materialised)--> per-pixel (gx,gy) --> 4-tap gather.
 // NARROW: the PPT pixels of a lane span less than one field cell ((PPT-1)*rx < 1, e.g. 256 -> 1280 columns), so the lane
@@ -479,8 +487,8 @@ __global__ void __launch_bounds__(256) upsample_grid_sample_fwd_kernel(const flo
             const bool second = x0 > cb;  // x0 - cb is 0 or 1; x1 = min(x0 + 1, fw - 1) is column x0 - cb + 1 (clamped loads)
             const float2 a = second ? r0[1] : r0[0], b = second ? r0[2] : r0[1];
             const float2 c = second ? r1[1] : r1[0], d = second ? r1[2] : r1[1];
-            const float gx = hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * d.x);
-            const float gy = hy * (hx * a.y + lx * b.y) + ly * (hx * c.y + lx * d.y);
+            const float gx = field_lerp(hy, ly, hx, lx, a.x, b.x, c.x, d.x);
+            const float gy = field_lerp(hy, ly, hx, lx, a.y, b.y, c.y, d.y);
             t[i] = make_taps2(gx, gy, H, W, ac != 0);
         }
     } else {
@@ -490,8 +498,8 @@ __global__ void __launch_bounds__(256) upsample_grid_sample_fwd_kernel(const flo
             const int x0 = (int)sx, x1 = x0 + (x0 < fw - 1 ? 1 : 0);
             const float lx = sx - x0, hx = 1.f - lx;
             const float2 a = f0[x0], b = f0[x1], c = f1[x0], d = f1[x1];
-            const float gx = hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * d.x);
-            const float gy = hy * (hx * a.y + lx * b.y) + ly * (hx * c.y + lx * d.y);
+            const float gx = field_lerp(hy, ly, hx, lx, a.x, b.x, c.x, d.x);
+            const float gy = field_lerp(hy, ly, hx, lx, a.y, b.y, c.y, d.y);
             t[i] = make_taps2(gx, gy, H, W, ac != 0);
         }
     }
@@ -537,12 +545,15 @@ struct __attribute__((packed, aligned(1))) U8x16 {
 // unaligned 16-byte window (5.33 RGB pixels) -- plus, for the sixth pixel, the second dword of the NEXT lane's window through a
 // wave shuffle when that lane's window starts exactly 4 pixels further -- instead of 4 x (4 + 2)-byte gathers per row: 2 vector
 // memory instructions per lane instead of 16.  Lanes whose pixels straddle a row or spread wider keep the per-tap gathers.
-template <bool NARROW, bool ROWWIN = false>
+// SWAP (R <-> B) is a template parameter and a pixel pair travels as two 32-bit words: every source byte is then a CONSTANT byte of a
+// dword and converts with one v_cvt_f32_ubyteN.  (Round 2 carried the six bytes as a 64-bit value shifted by a run-time amount:
+// 330 of the kernel's 897 vector instructions per lane were 64-bit shifts, masks and u64 -> float conversions.)
+template <bool NARROW, bool ROWWIN, bool SWAP>
 __global__ void __launch_bounds__(256) upsample_grid_sample_u8_kernel(const unsigned char *__restrict__ input,
                                                                       const float *__restrict__ field,
                                                                       unsigned char *__restrict__ out, int H, int W, int fh, int fw,
                                                                       float ry, float rx, size_t total_groups, unsigned nblocks,
-                                                                      int ac, int swap_rb) {
+                                                                      int ac) {
     constexpr int PPT = 4;
     const unsigned blk = xcd_remap(blockIdx.x, nblocks);
     const size_t gidx_raw = (size_t)blk * 256 + threadIdx.x;
@@ -575,8 +586,8 @@ __global__ void __launch_bounds__(256) upsample_grid_sample_u8_kernel(const unsi
             const bool second = x0 > cb;
             const float2 a = second ? r0[1] : r0[0], b = second ? r0[2] : r0[1];
             const float2 c = second ? r1[1] : r1[0], d = second ? r1[2] : r1[1];
-            const float gx = hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * d.x);
-            const float gy = hy * (hx * a.y + lx * b.y) + ly * (hx * c.y + lx * d.y);
+            const float gx = field_lerp(hy, ly, hx, lx, a.x, b.x, c.x, d.x);
+            const float gy = field_lerp(hy, ly, hx, lx, a.y, b.y, c.y, d.y);
             t[i] = make_taps2(gx, gy, H, W, ac != 0);
         }
     } else {
@@ -586,19 +597,21 @@ __global__ void __launch_bounds__(256) upsample_grid_sample_u8_kernel(const unsi
             const int x0 = (int)sx, x1 = x0 + (x0 < fw - 1 ? 1 : 0);
             const float lx = sx - x0, hx = 1.f - lx;
             const float2 a = f0[x0], b = f0[x1], c = f1[x0], d = f1[x1];
-            const float gx = hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * d.x);
-            const float gy = hy * (hx * a.y + lx * b.y) + ly * (hx * c.y + lx * d.y);
+            const float gx = field_lerp(hy, ly, hx, lx, a.x, b.x, c.x, d.x);
+            const float gy = field_lerp(hy, ly, hx, lx, a.y, b.y, c.y, d.y);
             t[i] = make_taps2(gx, gy, H, W, ac != 0);
         }
     }
     const unsigned char *ip = input + (size_t)n * HW * 3;
     unsigned char res[PPT * 3];
-    auto blend = [&](int i, unsigned long long u, unsigned long long v) {
+    // (ulo, uhi): bytes 0..3 and 4..5 of the pixel pair of row 0; (vlo, vhi): row 1.  Pixel x = bytes 0..2, pixel x + 1 = bytes 3..5.
+    auto blend = [&](int i, unsigned ulo, unsigned uhi, unsigned vlo, unsigned vhi) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const int ci = swap_rb ? 2 - c : c;
-            const float ux = (float)((u >> (8 * ci)) & 0xff), uy = (float)((u >> (8 * (3 + ci))) & 0xff);
-            const float vx = (float)((v >> (8 * ci)) & 0xff), vy = (float)((v >> (8 * (3 + ci))) & 0xff);
+            const int ci = SWAP ? 2 - c : c;   // compile-time
+            const float ux = (float)((ulo >> (8 * ci)) & 0xffu), vx = (float)((vlo >> (8 * ci)) & 0xffu);
+            const float uy = ci == 0 ? (float)(ulo >> 24) : (float)((uhi >> (8 * (ci - 1))) & 0xffu);
+            const float vy = ci == 0 ? (float)(vlo >> 24) : (float)((vhi >> (8 * (ci - 1))) & 0xffu);
             // one explicit fma chain: the same rounding in every instantiation and on both paths (left to the compiler, the
             // contraction of this sum differed between them -- a byte flips where the blend lands on an integer)
             const float r = fmaf(vy, t[i].b1, fmaf(vx, t[i].a1, fmaf(uy, t[i].b0, ux * t[i].a0)));
@@ -645,11 +658,8 @@ __global__ void __launch_bounds__(256) upsample_grid_sample_u8_kernel(const unsi
                 const unsigned b0 = k == 0 ? w1[0] : (k == 1 ? w1[1] : (k == 2 ? w1[2] : w1[3]));
                 const unsigned b1 = k == 0 ? w1[1] : (k == 1 ? w1[2] : (k == 2 ? w1[3] : w1[4]));
                 const unsigned b2 = k == 0 ? w1[2] : (k == 1 ? w1[3] : w1[4]);
-                const unsigned long long u = (unsigned long long)__builtin_amdgcn_alignbyte(a1, a0, sh) |
-                                             ((unsigned long long)__builtin_amdgcn_alignbyte(a2, a1, sh) << 32);
-                const unsigned long long v = (unsigned long long)__builtin_amdgcn_alignbyte(b1, b0, sh) |
-                                             ((unsigned long long)__builtin_amdgcn_alignbyte(b2, b1, sh) << 32);
-                blend(i, u, v);
+                blend(i, __builtin_amdgcn_alignbyte(a1, a0, sh), __builtin_amdgcn_alignbyte(a2, a1, sh), __builtin_amdgcn_alignbyte(b1, b0, sh),
+                      __builtin_amdgcn_alignbyte(b2, b1, sh));
             }
         }
     }
@@ -658,11 +668,8 @@ __global__ void __launch_bounds__(256) upsample_grid_sample_u8_kernel(const unsi
         for (int i = 0; i < PPT; ++i) {
             // the two horizontally adjacent source pixels of a row are 6 consecutive bytes: one 4-byte + one 2-byte unaligned load
             const unsigned char *q0 = ip + (size_t)t[i].o0 * 3, *q1 = ip + (size_t)t[i].o1 * 3;
-            const unsigned long long u = (unsigned long long)reinterpret_cast<const U8x4 *>(q0)->v |
-                                         ((unsigned long long)reinterpret_cast<const U8x2 *>(q0 + 4)->v << 32);
-            const unsigned long long v = (unsigned long long)reinterpret_cast<const U8x4 *>(q1)->v |
-                                         ((unsigned long long)reinterpret_cast<const U8x2 *>(q1 + 4)->v << 32);
-            blend(i, u, v);
+            blend(i, reinterpret_cast<const U8x4 *>(q0)->v, reinterpret_cast<const U8x2 *>(q0 + 4)->v, reinterpret_cast<const U8x4 *>(q1)->v,
+                  reinterpret_cast<const U8x2 *>(q1 + 4)->v);
         }
     }
     if (!live) return;
@@ -855,24 +862,29 @@ extern "C" int pws_upsample_grid_sample_u8(const unsigned char *frame_hwc, const
     const unsigned nb = (unsigned)((groups + 255) / 256);
     ProfScope prof(KID_UPSAMPLE_GRID_SAMPLE_U8, (double)total * (40.0 + 8.0 * 3), (double)total * 6.0 + 8.0 * (double)n * fh * fw,
                    as_stream(stream));
-    // PWS_OPT_EXPERIMENT 4: the row-window + wave-shuffle variant, kept for the A/B in DESIGN.md (tools/warp_u8_ab.py).  Measured
-    // on 8 frames of 1280 x 720: 39.0 vs 40.3 us on a pure translation (every lane takes the window), 51.6 vs 41.2 us on a
-    // stabiliser's field, 49.8 vs 41.1 us on the random-weight generator's: 16 -> 2 memory instructions per lane buy nothing,
-    // the kernel is bound by its ~200 vector instructions per pixel (field interpolation, taps, 12 blends, byte packing), and the
-    // lanes whose 4 pixels straddle a source row pay both paths.  The per-tap gathers stay the product path.
+    // PWS_OPT_EXPERIMENT 4: the row-window + wave-shuffle variant, kept for the A/B in DESIGN.md (tools/warp_u8_ab.py).  Measured on 8
+    // frames of 1280 x 720 (after the 32-bit byte handling above): 33.6 vs 27.2 us on a pure translation (every lane takes the
+    // window), 39.2 vs 34.7 us on a stabiliser's field, 42.6 vs 38.9 us on the random-weight generator's: 16 -> 2 memory instructions
+    // per lane buy nothing, the kernel is bound by its vector instructions (613 per lane), the variant's shuffles and selects add to
+    // them, and the lanes whose 4 pixels straddle a source row pay both paths.  The per-tap gathers stay the product path.
     const bool rowwin = g_experiment == 4;
-    if (3.f * rx < 0.999f) {
-        if (rowwin)
-            hipLaunchKernelGGL((upsample_grid_sample_u8_kernel<true, true>), dim3(nb), dim3(256), 0, as_stream(stream), frame_hwc, field, out_hwc,
-                               h, w, fh, fw, ry, rx, groups, nb, align_corners, swap_rb);
-        else
-            hipLaunchKernelGGL((upsample_grid_sample_u8_kernel<true, false>), dim3(nb), dim3(256), 0, as_stream(stream), frame_hwc, field, out_hwc,
-                               h, w, fh, fw, ry, rx, groups, nb, align_corners, swap_rb);
-    } else if (rowwin)
-        hipLaunchKernelGGL((upsample_grid_sample_u8_kernel<false, true>), dim3(nb), dim3(256), 0, as_stream(stream), frame_hwc, field, out_hwc, h,
-                           w, fh, fw, ry, rx, groups, nb, align_corners, swap_rb);
-    else
-        hipLaunchKernelGGL((upsample_grid_sample_u8_kernel<false, false>), dim3(nb), dim3(256), 0, as_stream(stream), frame_hwc, field, out_hwc, h,
-                           w, fh, fw, ry, rx, groups, nb, align_corners, swap_rb);
+    const bool narrow = 3.f * rx < 0.999f;
+#define PWS_U8_LAUNCH(NARROW_, ROWWIN_, SWAP_)                                                                                             \
+    hipLaunchKernelGGL((upsample_grid_sample_u8_kernel<NARROW_, ROWWIN_, SWAP_>), dim3(nb), dim3(256), 0, as_stream(stream), frame_hwc, field, \
+                       out_hwc, h, w, fh, fw, ry, rx, groups, nb, align_corners)
+    if (narrow && !rowwin) {
+        if (swap_rb) PWS_U8_LAUNCH(true, false, true);
+        else PWS_U8_LAUNCH(true, false, false);
+    } else if (narrow) {
+        if (swap_rb) PWS_U8_LAUNCH(true, true, true);
+        else PWS_U8_LAUNCH(true, true, false);
+    } else if (!rowwin) {
+        if (swap_rb) PWS_U8_LAUNCH(false, false, true);
+        else PWS_U8_LAUNCH(false, false, false);
+    } else {
+        if (swap_rb) PWS_U8_LAUNCH(false, true, true);
+        else PWS_U8_LAUNCH(false, true, false);
+    }
+#undef PWS_U8_LAUNCH
     return check_launch("upsample_grid_sample_u8_kernel");
 }

@@ -109,7 +109,10 @@ def test_u8_hwc_fused_warp(hip, shape, swap):
     ref = ref_f.to(torch.uint8)
     diff = (got.int() - ref.int()).abs()
     assert diff.max().item() <= 1
-    near_int = (ref_f - ref_f.round()).abs() < 0.02
+    # one ulp of a normalised coordinate near +-1 is 1.2e-7 * W / 2 = 7.6e-5 pixels at 1280; next to the zero padding (a 0 -> ~250 step
+    # per pixel) that is 0.02 gray levels, and the resized field of two fp32 evaluations (torch's vectorised lerp, this kernel's fma
+    # chain) may differ by two: measured once, 0.035 at a pixel whose right tap is the padding (field 1.00033629 vs 1.00033641)
+    near_int = (ref_f - ref_f.round()).abs() < 0.05
     assert bool(near_int[diff > 0].all())
     # the synthetic frames are smooth AND integer-valued: wherever the 4 taps are equal the blend is exactly v*(1 +- 1ulp),
     # so truncation is a coin flip between any two fp32 evaluations (3.6 % of the values at 720p, 0.3 % at 72x128)
