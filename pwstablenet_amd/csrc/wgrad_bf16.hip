@@ -40,10 +40,16 @@ struct WgradBfParams {
     float *dbias;    // optional: dbias[co] += column sums of dy (pws_conv_bwd_weight_args.dbias)
 };
 
-template <int KS_, int STRIDE_, int PAD_, int SUBPIX_, int TH_, int TW_, int TN_, int TG_, bool CI32_ = false>
+template <int KS_, int STRIDE_, int PAD_, int SUBPIX_, int TH_, int TW_, int TN_, int TG_, bool CI32_ = false, int COW_ = 2>
 struct WbCfg {
     static constexpr int KS = KS_, STRIDE = STRIDE_, PAD = PAD_, SUBPIX = SUBPIX_, TH = TH_, TW = TW_, TN = TN_;
     static constexpr int TG = TG_;  // taps per workgroup
+    // COW: 32-channel output blocks (= waves) per input-channel half.  2: the workgroup owns 64 x 64 channels (4 waves).  4: 64 x 128
+    // (8 waves): the x tile -- the larger operand of the stride-2 kinds (a 17 x 17 halo for 8 x 8 outputs: 37 of the 45 KB a
+    // 64 x 64 workgroup stages per tile) -- is staged once for twice the matrix work.  These kernels are bound by what they stage
+    // (15 % matrix-pipe busy at 80 KB per 8.4 MFLOP for the stride-2 kind, profiles/r02_pmc_train_bf16_table.log), not by the pipe.
+    static constexpr int COW = COW_, THREADS = 64 * 2 * COW, CO_BLK = 32 * COW;
+    static_assert(COW == 2 || (COW == 4 && !CI32_), "output-channel waves");
     // CI32: layers with <= 32 (padded) input channels (the first layer): a workgroup owns 32 input x 64 output channels and its
     // two wave pairs take two consecutive tap groups instead of two input-channel halves (no wave multiplies zeros)
     static constexpr bool CI32 = CI32_;
@@ -54,7 +60,7 @@ struct WbCfg {
     static constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
     static constexpr int PIX = TN * IH * IW;
     static constexpr int ROW = 64;                               // bytes per LDS row: 32 bf16 channels
-    static constexpr int LDS_X = XPL * PIX * ROW, LDS_G = 2 * BM * ROW;
+    static constexpr int LDS_X = XPL * PIX * ROW, LDS_G = COW * BM * ROW;
     static constexpr int LDS_BYTES = LDS_X + LDS_G + 16;         // + sink for staging items past the tile
 };
 
@@ -82,20 +88,20 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char *lds, int off0, in
 }
 
 template <class C, bool IO16>
-__global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradBfParams p) {
+__global__ void __launch_bounds__(C::THREADS, 2) wgrad_bf16_kernel(const WgradBfParams p) {
     static_assert(wb_linear<C>(), "tile shape breaks the k-step address walk");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int li = lane & 15, lg = lane >> 4;
 
     const int cb = blockIdx.y;
-    const int ci0 = (cb / p.co_blocks) * (C::CI32 ? 32 : 64), co0 = (cb % p.co_blocks) * 64;
+    const int ci0 = (cb / p.co_blocks) * (C::CI32 ? 32 : 64), co0 = (cb % p.co_blocks) * C::CO_BLK;
     const int cls = C::SUBPIX ? (int)(blockIdx.z & 3) : 0;
     const int tg = C::SUBPIX ? (int)(blockIdx.z >> 2) : (int)blockIdx.z;
     const int py = cls >> 1, px = cls & 1;
     const int pad_y = C::SUBPIX ? 1 - py : C::PAD, pad_x = C::SUBPIX ? 1 - px : C::PAD;
-    const int wci = C::CI32 ? 0 : wv >> 1, wco = wv & 1;  // this wave's 32 x 32 quadrant
-    const int wtg = C::CI32 ? 2 * tg + (wv >> 1) : tg;     // ... and tap group (wave-uniform)
+    const int wci = C::CI32 ? 0 : wv / C::COW, wco = wv % C::COW;  // this wave's 32 x 32 quadrant
+    const int wtg = C::CI32 ? 2 * tg + (wv >> 1) : tg;             // ... and tap group (wave-uniform)
 
     f32x16 acc[C::TG];
 #pragma unroll
@@ -117,7 +123,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradBfParams 
 
     // bias gradient: the waves of the first wave pair of the workgroups of input-channel block 0 / tap group 0 see every pixel of
     // dy exactly once (tiles partition the pixels, the parity classes the pixels of a tile)
-    const bool do_bias = p.dbias != nullptr && cb / p.co_blocks == 0 && tg == 0 && (wv >> 1) == 0;
+    const bool do_bias = p.dbias != nullptr && cb / p.co_blocks == 0 && tg == 0 && wv / C::COW == 0;
     float bsum = 0.f;
     auto compute = [&]() {
         // ---- K steps of 16 pixels over the whole tile
@@ -150,10 +156,11 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradBfParams 
         // items: source, channel offset and LDS column are tile-invariant, and an item's LDS row is p0 + 32 * it).
         // Before: batches of 4 loads, each batch waited for before its LDS stores -- 7 exposed memory latencies per tile, which
         // was 80 % of the kernel's time (64->64 @256x256 x32: 305 us, 116 us with the loads removed but the rest in place).
-        constexpr int XC = 4 * C::XPL, XPP = 256 / XC;   // 16-byte groups per x pixel, x pixels per pass of the workgroup
-        constexpr int XITS = (C::PIX + XPP - 1) / XPP, GITS = (C::BM * 8 + 255) / 256;
-        static_assert(XITS <= 16 && GITS <= 16, "mask width");
-        const int c8 = tid & 7, p0 = tid >> 3;
+        constexpr int XC = 4 * C::XPL, XPP = C::THREADS / XC;   // 16-byte groups per x pixel, x pixels per pass of the workgroup
+        constexpr int GC = 4 * C::COW;                           // 16-byte groups per dy pixel; C::THREADS / GC = 32 pixels per pass
+        constexpr int XITS = (C::PIX + XPP - 1) / XPP, GITS = (C::BM + 31) / 32;
+        static_assert(XITS <= 16 && GITS <= 16 && C::THREADS / GC == 32, "mask width / dy pass");
+        const int c8 = tid % GC, p0 = tid / GC;
         const int cx = tid % XC, px0 = tid / XC;
         int xch = ci0 + cx * 8, xs = 0;
         const bool xc_ok = xch < p.cin;
@@ -161,7 +168,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradBfParams 
         if (!xc_ok) xs = 0, xch = 0;
         const __bf16 *xsrc = reinterpret_cast<const __bf16 *>(p.src_ptr[xs]) + xch;
         const size_t xld = p.src_ld[xs];
-        const bool gc_ok = co0 + c8 * 8 < p.cout;
+        const bool gc_ok = co0 + c8 * 8 < p.cout;   // (c8 >> 2 = the 32-channel plane of the dy tile)
         const __bf16 *gsrc = reinterpret_cast<const __bf16 *>(p.gout) + (gc_ok ? co0 + c8 * 8 : 0);
         const int xl0 = (cx >> 2) * C::PIX * C::ROW + px0 * C::ROW + (cx & 3) * 16;
         const int gl0 = C::LDS_X + (c8 >> 2) * C::BM * C::ROW + p0 * C::ROW + (c8 & 3) * 16;
@@ -255,7 +262,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradBfParams 
             // ---- x halo tile, channels ci0..ci0+63 of the (virtually concatenated) sources: 8-channel items, loads of a batch
             // issued unconditionally before the first LDS store (masked items read a valid dummy address)
             {
-                constexpr int NIT = C::PIX * 8, ITS = (NIT + 255) / 256, BATCH = 4;
+                constexpr int NIT = C::PIX * 8, ITS = (NIT + C::THREADS - 1) / C::THREADS, BATCH = 4;
     #pragma unroll 1
                 for (int it0 = 0; it0 < ITS; it0 += BATCH) {
                     f32x4 r[BATCH][2];
@@ -264,7 +271,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradBfParams 
                     bool okv[BATCH];
     #pragma unroll
                     for (int k = 0; k < BATCH; ++k) {
-                        const int item = tid + (it0 + k) * 256;
+                        const int item = tid + (it0 + k) * C::THREADS;
                         const int pix = item >> 3, c8 = item & 7;
                         const int lx = pix % C::IW, ly = (pix / C::IW) % C::IH, tn = pix / (C::IW * C::IH);
                         const int n = n0 + tn, iy = iy0 + ly, ix = ix0 + lx;
@@ -298,7 +305,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradBfParams 
             }
             // ---- dy tile, channels co0..co0+63 at the tile's output pixels
             {
-                constexpr int NIT = C::BM * 8, ITS = (NIT + 255) / 256, BATCH = 4;
+                constexpr int GC = 4 * C::COW;
+                constexpr int NIT = C::BM * GC, ITS = (NIT + C::THREADS - 1) / C::THREADS, BATCH = 4;
     #pragma unroll 1
                 for (int it0 = 0; it0 < ITS; it0 += BATCH) {
                     f32x4 r[BATCH][2];
@@ -307,8 +315,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradBfParams 
                     bool okv[BATCH];
     #pragma unroll
                     for (int k = 0; k < BATCH; ++k) {
-                        const int item = tid + (it0 + k) * 256;
-                        const int m = item >> 3, c8 = item & 7;
+                        const int item = tid + (it0 + k) * C::THREADS;
+                        const int m = item / GC, c8 = item % GC;
                         const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
                         const int n = n0 + tn, y = y0 + ty, x = x0 + tx;
                         const int oy = C::SUBPIX ? 2 * y + py : y, ox = C::SUBPIX ? 2 * x + px : x;
@@ -385,19 +393,19 @@ static int launch_wb(WgradBfParams &p, int nclasses, hipStream_t st) {
     }
     p.tiles_x = (p.LW + C::TW - 1) / C::TW, p.tiles_y = (p.LH + C::TH - 1) / C::TH, p.tiles_n = (p.N + C::TN - 1) / C::TN;
     p.ntiles = p.tiles_x * p.tiles_y * p.tiles_n;
-    p.ci_blocks = C::CI32 ? (p.cin_pad + 31) / 32 : (p.cin_pad + 63) / 64, p.co_blocks = (p.cout + 63) / 64;
+    p.ci_blocks = C::CI32 ? (p.cin_pad + 31) / 32 : (p.cin_pad + 63) / 64, p.co_blocks = (p.cout + C::CO_BLK - 1) / C::CO_BLK;
     const long other = (long)p.ci_blocks * p.co_blocks * nclasses * C::NGROUPS;
     // ~2 workgroups per CU overall: every workgroup ends with 64 x 64 x taps fp32 atomics on the same addresses, and with
     // the bf16 MFMA rate that tail is what a 1024-workgroup grid is bound by (64->64 @256x256 x8: 176 us -> 117 us at 512;
     // all weight-gradient launches of a batch-32 step: 256 / 512 / 768 / 1024 -> 7.7 / 7.2 / 8.5 / 9.1 ms)
-    long ps = (512 + other - 1) / other;
+    long ps = ((C::COW == 4 ? 256 : 512) + other - 1) / other;   // (an 8-wave workgroup fills a CU by itself)
     if (ps > p.ntiles) ps = p.ntiles;
     if (ps < 1 || t_deterministic) ps = 1;   // deterministic: one adding workgroup per (channel block, class, tap group)
     dim3 grid((unsigned)ps, (unsigned)(p.ci_blocks * p.co_blocks), (unsigned)(nclasses * C::NGROUPS));
     if (p.io_bf16)
-        hipLaunchKernelGGL((wgrad_bf16_kernel<C, true>), grid, dim3(256), C::LDS_BYTES, st, p);
+        hipLaunchKernelGGL((wgrad_bf16_kernel<C, true>), grid, dim3(C::THREADS), C::LDS_BYTES, st, p);
     else
-        hipLaunchKernelGGL((wgrad_bf16_kernel<C, false>), grid, dim3(256), C::LDS_BYTES, st, p);
+        hipLaunchKernelGGL((wgrad_bf16_kernel<C, false>), grid, dim3(C::THREADS), C::LDS_BYTES, st, p);
     return check_launch("wgrad_bf16_kernel");
 }
 
@@ -415,6 +423,7 @@ using WB_K3S1_T64N16 = WbCfg<3, 1, 1, 0, 2, 2, 16, 9>;
 using WB_K3S2_T64 = WbCfg<3, 2, 1, 0, 8, 8, 1, 9>;
 using WB_K3S2_T64N4 = WbCfg<3, 2, 1, 0, 4, 4, 4, 9>;
 using WB_K3S2_T64N16 = WbCfg<3, 2, 1, 0, 2, 2, 16, 9>;
+using WB_K3S2_T64_W = WbCfg<3, 2, 1, 0, 8, 8, 1, 9, false, 4>;     // 64 x 128 channels, 8 waves
 using WB_K5S1_T128 = WbCfg<5, 1, 2, 0, 8, 16, 1, 5>;   // first layer: one kernel row of taps per workgroup
 using WB_K5S1_T128H = WbCfg<5, 1, 2, 0, 8, 16, 1, 5, true>;    // ... <= 32 input channels: two kernel rows per workgroup (the 16x16
                                                                 // tile of this kind runs out of registers: 272 B of scratch, 3.4x slower)
@@ -426,6 +435,7 @@ using WB_CT4_T64N16 = WbCfg<2, 1, 0, 1, 2, 2, 16, 4>;
 static const WbChoice kWbK3S1[] = {wbchoice<WB_K3S1_T256>(), wbchoice<WB_K3S1_T128>(), wbchoice<WB_K3S1_T64>(), wbchoice<WB_K3S1_T64N4>(),
                                    wbchoice<WB_K3S1_T64N16>()};
 static const WbChoice kWbK3S2[] = {wbchoice<WB_K3S2_T64>(), wbchoice<WB_K3S2_T64N4>(), wbchoice<WB_K3S2_T64N16>()};
+static const WbChoice kWbK3S2W = wbchoice<WB_K3S2_T64_W>();
 static const WbChoice kWbK5[] = {wbchoice<WB_K5S1_T128>(), wbchoice<WB_K5S1_T128H>()};
 static const WbChoice kWbCT4[] = {wbchoice<WB_CT4_T256>(), wbchoice<WB_CT4_T64>(), wbchoice<WB_CT4_T64N4>(),
                                   wbchoice<WB_CT4_T64N16>()};
@@ -482,6 +492,9 @@ int wgrad_bf16_launch(const pws_conv_bwd_weight_args *a, hipStream_t st) {
     case PWS_CONV_K3S2:
         p.OH = p.LH = (a->h - 1) / 2 + 1, p.OW = p.LW = (a->w - 1) / 2 + 1;
         c = &pick(kWbK3S2, 3, p.LH, p.LW, p.N);
+        // >= 128 output channels on maps that whole 8 x 8 tiles cover: 64 x 128 channels per (8-wave) workgroup.  PWS_OPT_EXPERIMENT 83
+        // keeps the 64 x 64 workgroups (A/B)
+        if (c == &kWbK3S2[0] && a->cout % 128 == 0 && p.io_bf16 && g_experiment != 83) c = &kWbK3S2W;
         break;
     case PWS_CONVT_K4S2:
         p.LH = a->h, p.LW = a->w, p.OH = 2 * a->h, p.OW = 2 * a->w, nclasses = 4, k2 = 4;
