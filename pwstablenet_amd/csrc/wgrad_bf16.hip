@@ -499,6 +499,7 @@ int wgrad_bf16_launch(const pws_conv_bwd_weight_args *a, hipStream_t st) {
     case PWS_CONVT_K4S2:
         p.LH = a->h, p.LW = a->w, p.OH = 2 * a->h, p.OW = 2 * a->w, nclasses = 4, k2 = 4;
         c = &pick(kWbCT4, 4, p.LH, p.LW, p.N);
+        // (a 64 x 128-channel variant as for the stride-2 kind was measured on the layers with >= 128 outputs: 33.2 vs 33.2 ms per step)
         break;
     case PWS_CONV_K5S1:
         p.OH = p.LH = a->h, p.OW = p.LW = a->w, k2 = 25;

@@ -35,7 +35,7 @@ CASES = [
     ("CONV_K3S2", (2, 24, 40), [64, 32], 256), ("CONV_K3S2", (1, 16, 16), [32], 128),   # >= 128 outputs: the 64 x 128-channel (8-wave) weight gradient
     ("CONVT_K3S1", (2, 18, 21), [32, 64], 48), ("CONVT_K3S1", (2, 4, 4), [32], 16), ("CONVT_K3S1", (2, 2, 2), [256], 256),
     ("CONVT_K4S2", (2, 17, 19), [32, 32, 64], 64), ("CONVT_K4S2", (2, 8, 8), [32], 32), ("CONVT_K4S2", (3, 4, 4), [32, 32], 16),
-    ("CONVT_K4S2", (20, 2, 2), [32], 64), ("CONVT_K4S2", (1, 32, 32), [128, 64], 64),
+    ("CONVT_K4S2", (20, 2, 2), [32], 64), ("CONVT_K4S2", (1, 32, 32), [128, 64], 64), ("CONVT_K4S2", (2, 16, 24), [64, 32], 128),
     ("CONV_K5S1", (1, 23, 40), [32], 64), ("CONV_K5S1", (2, 16, 16), [32], 64), ("CONV_K5S1", (1, 9, 70), [64], 32),
 ]
 
