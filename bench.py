@@ -711,6 +711,34 @@ def main():
                                                        "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                                        "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_us": round(1e3 * ms, 2),
                                                        "bytes_per_launch": r[0][3]}}
+            # as for the fp32 warp above: the same kernel on the field a stabiliser emits, inputs rotated through 4 buffers (HBM)
+            try:
+                rot8 = [u720] + [torch.randint(0, 256, (B, 720, 1280, 3), device=dev, dtype=torch.uint8) for _ in range(3)]
+                th = torch.tensor([1, 0, 0, 0, 1, 0], device=dev, dtype=torch.float32).repeat(B, 1)
+                ramp = torch.linspace(0, 6.28, 256, device=dev)
+                fsm = PF.affine_grid(th + 0.02 * torch.randn_like(th), (B, 3, 256, 256)) + \
+                    (4.0 / 256) * (torch.sin(3 * ramp).view(1, 256, 1, 1) * torch.cos(2 * ramp).view(1, 1, 256, 1))
+                with torch.no_grad():
+                    for b_ in rot8:
+                        PF.upsample_grid_sample_u8(b_, fsm, swap_rb=True)
+                    torch.cuda.synchronize()
+                    A.lib().pws_prof_enable(1)
+                    for i_ in range(12):
+                        PF.upsample_grid_sample_u8(rot8[i_ % 4], fsm, swap_rb=True)
+                    A.lib().pws_prof_enable(0)
+                r = [x_ for x_ in A.prof_collect() if x_[0] == "upsample_grid_sample_u8_kernel"]
+                ms = sorted(x_[4] for x_ in r)[len(r) // 2]
+                rw = line["value_720p_u8"]["roofline_warp"]
+                rw["achieved_random_weight_field"], rw["frac_random_weight_field"] = rw["achieved"], rw["frac"]
+                rw["avg_launch_us_random_weight_field"] = rw["avg_launch_us"]
+                rw["field"] = "2 % affine + smooth +-2 px residual, inputs rotated through 4 buffers (HBM, not Infinity Cache)"
+                rw["achieved"] = round(r[0][3] / (ms * 1e-3) / 1e9, 1)
+                rw["frac"] = round(r[0][3] / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+                rw["avg_launch_us"] = round(1e3 * ms, 2)
+                rw["bound_note"] = "instruction-bound, not HBM-bound: ~150 vector instructions per pixel (DESIGN.md section 9, item 9)"
+                del rot8, fsm
+            except Exception as e:
+                line["value_720p_u8"]["roofline_warp"]["smooth_field_error"] = str(e)[:200]
             del u720
             # configs[4] shape on one GPU, PCIe inclusive, the whole device side of process(): 192 decoded uint8 720p frames in
             # PINNED HOST memory -> VideoStabilizer.run_video (H2D per 64-frame chunk on a side stream, gray + INTER_AREA window
