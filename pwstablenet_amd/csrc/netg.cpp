@@ -1029,6 +1029,7 @@ extern "C" int pws_netg_backward_opts(const float *packed, const float *packed_d
     PWS_REQUIRE(nparts >= 1 && part >= 0 && part < nparts, "pws_netg_backward: part %d of %d", part, nparts);
     NetgOpts o;
     if (int rc = opts_from(opts, &o)) return rc;
+    PWS_REQUIRE(o.x_sample_stride == 0, "pws_netg_backward: x_sample_stride is an option of the inference forward (the backward reads a dense window)");
     if (n == 0) {
         if (final_mask)
             for (int i = 0; i < L_COUNT; ++i) final_mask[i] = 1;

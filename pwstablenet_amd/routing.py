@@ -2,7 +2,8 @@
 unchanged ``main_new.py`` reaches them (reference main_new.py:9 ``import torch.nn.functional as functional``;
 ``functional.grid_sample`` :106,109,116,118,197,716; ``functional.affine_grid`` :195; ``torch.nn.UpsamplingBilinear2d`` :708).
 
-``install()`` (called when ``dropin/lib/networks_cascading.py`` or ``dropin/lib/cfg.py`` is imported) replaces three module
+``install()`` (called when ``dropin/lib/networks_cascading.py`` is imported -- the driver's first import of the path,
+main_new.py:5) replaces three module
 attributes: ``torch.nn.functional.grid_sample``, ``torch.nn.functional.affine_grid`` and ``torch.nn.UpsamplingBilinear2d``.
 A call is routed when it is what the kernels implement -- float32 device tensors, 4-D, bilinear + zeros padding -- and handed
 to the original torch function UNTOUCHED otherwise (CPU tensors, other dtypes / modes, 5-D volumes): torch code elsewhere in
