@@ -385,6 +385,10 @@ int pws_temporal_l1_fwd(const float *fake1, const float *fake2, const float *the
 /* gfake1 -= c*sign(d) (plain read-modify-write), gfake2 += c*sign(d)*bilinear weights (atomics): both must be initialised */
 int pws_temporal_l1_bwd(const float *fake1, const float *fake2, const float *theta, float c, const float *scale, float *gfake1,
                         float *gfake2, int n, int h, int w, pws_stream_t stream);
+/* The same gradients without atomics: the scatter into gfake2 runs as an ordered gather (one lane per source pixel walks the output
+ * pixels whose taps can hit it), so repeated runs are bit-identical.  scratch: n * 3 * h * w floats.  Slower (deterministic mode). */
+int pws_temporal_l1_bwd_det(const float *fake1, const float *fake2, const float *theta, float c, const float *scale, float *gfake1,
+                            float *gfake2, float *scratch, int n, int h, int w, pws_stream_t stream);
 /* features [m,nf,6] = [stable x,y,1, unstable x,y,1] (lib/utils.py:225); slots += sum_k |unstable_k - grid[stable_k]|^2
  * with the reference's index int((coord+1)*size/2) (lib/utils.py:341-345) */
 int pws_feature_loss_fwd(const float *grid, const float *features, double *slots, int m, int nf, int h, int w,
@@ -392,6 +396,9 @@ int pws_feature_loss_fwd(const float *grid, const float *features, double *slots
 /* ggrid += c * d(sum)/d grid (atomics; ggrid must be initialised) */
 int pws_feature_loss_bwd(const float *grid, const float *features, float c, const float *scale, float *ggrid, int m, int nf,
                          int h, int w, pws_stream_t stream);
+/* The same without atomics: one lane per sample adds its points in order (bit-identical runs; deterministic mode). */
+int pws_feature_loss_bwd_det(const float *grid, const float *features, float c, const float *scale, float *ggrid, int m, int nf,
+                             int h, int w, pws_stream_t stream);
 /* slots_dx += sum|grid[:,:,1:]-grid[:,:,:-1]|, slots_dy likewise along h (lib/utils.py:351-357; reported, not optimised) */
 int pws_field_smoothness(const float *grid, double *slots_dx, double *slots_dy, int m, int h, int w, pws_stream_t stream);
 /* loss_pixel1 (lib/utils.py:405-425): fp64 L1 residual of the least-squares fit of generate_affine_matrix's bilinear

@@ -202,7 +202,7 @@ template <bool BWD>
 __global__ void __launch_bounds__(256) temporal_l1_kernel(const float *__restrict__ fake1, const float *__restrict__ fake2,
                                                           const float *__restrict__ theta, double *__restrict__ slots, float c,
                                                           const float *__restrict__ scale, float *__restrict__ gfake1, float *__restrict__ gfake2, int H, int W,
-                                                          size_t total, unsigned nblocks) {
+                                                          size_t total, unsigned nblocks, float *__restrict__ sbuf = nullptr) {
     const unsigned blk = xcd_remap(blockIdx.x, nblocks);
     const size_t p = (size_t)blk * 256 + threadIdx.x;
     const int HW = H * W;
@@ -225,7 +225,9 @@ __global__ void __launch_bounds__(256) temporal_l1_kernel(const float *__restric
             if constexpr (BWD) {
                 const float s = c * sgn(d);
                 gfake1[pl + hw] -= s;
-                if (s != 0.f) {
+                if (sbuf) {   // deterministic mode: the scatter is done as an ordered gather by temporal_gather_kernel
+                    sbuf[pl + hw] = s;
+                } else if (s != 0.f) {
                     float *gp = gfake2 + pl;
                     if (t.w00 != 0.f) atomicAdd(gp + t.o00, s * t.w00);
                     if (t.w01 != 0.f) atomicAdd(gp + t.o01, s * t.w01);
@@ -241,6 +243,53 @@ __global__ void __launch_bounds__(256) temporal_l1_kernel(const float *__restric
         double *const dst[1] = {slots};
         block_accumulate<1>(acc, dst);
     }
+}
+
+// Deterministic adjoint of the affine warp (pws_temporal_l1_bwd_det): gfake2[q] += sum over the output pixels p one of whose four taps
+// is q of S[p] * w(p -> q), as a GATHER -- one lane per source pixel walks its candidates in row-major order, so every element is
+// written by one lane in a fixed order (the scatter adds with fp32 atomics in arrival order).  The sample coordinate is affine in p:
+// ix = a00 px + a01 py + b0, iy = a10 px + a11 py + b1; p is a candidate of q when |ix - qx| < 1 and |iy - qy| < 1, i.e. inside the
+// parallelogram M^-1 ([-1, 1]^2) round M^-1 (q - b): its bounding box (+ a margin) is walked and every candidate's taps are
+// recomputed with the forward's own arithmetic (make_taps4), so membership and weights are exactly the scatter's.
+__global__ void __launch_bounds__(256) temporal_gather_kernel(const float *__restrict__ sbuf, const float *__restrict__ theta,
+                                                              float *__restrict__ gfake2, int H, int W, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int HW = H * W;
+    const int n = (int)(i / HW), q = (int)(i % HW);
+    const int qy = q / W, qx = q % W;
+    const float *th = theta + (size_t)n * 6;
+    const float a00 = th[0], a01 = th[1] * (float)W / (float)H, a10 = th[3] * (float)H / (float)W, a11 = th[4];
+    const float b0 = th[0] * (0.5f - 0.5f * W) + th[1] * (0.5f * W / H - 0.5f * W) + th[2] * 0.5f * W + 0.5f * (W - 1);
+    const float b1 = th[3] * (0.5f * H / W - 0.5f * H) + th[4] * (0.5f - 0.5f * H) + th[5] * 0.5f * H + 0.5f * (H - 1);
+    const float det = a00 * a11 - a01 * a10;
+    int px_lo = 0, px_hi = W - 1, py_lo = 0, py_hi = H - 1;   // degenerate map: every pixel is a candidate
+    if (fabsf(det) > 1e-6f) {
+        const float rx = (float)qx - b0, ry = (float)qy - b1;
+        const float pcx = (a11 * rx - a01 * ry) / det, pcy = (-a10 * rx + a00 * ry) / det;
+        const float ex = (fabsf(a11) + fabsf(a01)) / fabsf(det) + 1.01f, ey = (fabsf(a10) + fabsf(a00)) / fabsf(det) + 1.01f;
+        px_lo = max(0, (int)ceilf(pcx - ex)), px_hi = min(W - 1, (int)floorf(pcx + ex));
+        py_lo = max(0, (int)ceilf(pcy - ey)), py_hi = min(H - 1, (int)floorf(pcy + ey));
+    }
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int py = py_lo; py <= py_hi; ++py)
+        for (int px = px_lo; px <= px_hi; ++px) {
+            const float bx = base_o(px, W), by = base_o(py, H);
+            const Taps4 t = make_taps4(th[0] * bx + th[1] * by + th[2], th[3] * bx + th[4] * by + th[5], H, W);
+            // the scatter adds tap by tap (o00, o01, o10, o11): clamped taps of a border pixel may coincide, all of them count
+            float wq = 0.f;
+            if (t.o00 == q) wq += t.w00;
+            if (t.o01 == q) wq += t.w01;
+            if (t.o10 == q) wq += t.w10;
+            if (t.o11 == q) wq += t.w11;
+            if (wq != 0.f) {
+                const size_t pp = (size_t)n * 3 * HW + (size_t)py * W + px;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) acc[ch] = fmaf(sbuf[pp + (size_t)ch * HW], wq, acc[ch]);
+            }
+        }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) gfake2[((size_t)n * 3 + ch) * HW + q] += acc[ch];
 }
 
 // ------------------------------------------------------------------------------------------------ feature points
@@ -275,6 +324,24 @@ __global__ void __launch_bounds__(256) feature_loss_kernel(const float *__restri
     if constexpr (!BWD) {
         double *const dst[1] = {slots};
         block_accumulate<1>(acc, dst);
+    }
+}
+
+// Deterministic variant of the backward above: one lane per SAMPLE walks its points in order (plain read-modify-write: several points
+// may share a pixel, and the atomics of the kernel above arrive in any order).
+__global__ void __launch_bounds__(64) feature_loss_bwd_serial_kernel(const float *__restrict__ grid, const float *__restrict__ features, float c,
+                                                                    const float *__restrict__ scale, float *__restrict__ ggrid, int m, int nf,
+                                                                    int H, int W) {
+    const int n = blockIdx.x * 64 + threadIdx.x;
+    if (n >= m) return;
+    if (scale) c *= *scale;
+    for (int k = 0; k < nf; ++k) {
+        const float *f = features + ((size_t)n * nf + k) * 6;
+        const int ix = feat_index(f[0], W), iy = feat_index(f[1], H);
+        const size_t q = (((size_t)n * H + iy) * W + ix) * 2;
+        const float dx = f[3] - grid[q], dy = f[4] - grid[q + 1];
+        ggrid[q] += -2.f * c * dx;
+        ggrid[q + 1] += -2.f * c * dy;
     }
 }
 
@@ -476,6 +543,30 @@ extern "C" int pws_temporal_l1_bwd(const float *fake1, const float *fake2, const
     hipLaunchKernelGGL(temporal_l1_kernel<true>, dim3(nb), dim3(256), 0, as_stream(stream), fake1, fake2, theta,
                        (double *)nullptr, c, scale, gfake1, gfake2, h, w, total, nb);
     return check_launch("temporal_l1_kernel<bwd>");
+}
+
+extern "C" int pws_temporal_l1_bwd_det(const float *fake1, const float *fake2, const float *theta, float c, const float *scale,
+                                       float *gfake1, float *gfake2, float *scratch, int n, int h, int w, pws_stream_t stream) {
+    PWS_REQUIRE(n >= 0 && h > 0 && w > 0, "pws_temporal_l1_bwd_det: bad shape");
+    if (n == 0) return PWS_OK;
+    PWS_REQUIRE(fake1 && fake2 && theta && gfake1 && gfake2 && scratch, "pws_temporal_l1_bwd_det: NULL pointer (scratch: n * 3 * h * w floats)");
+    const size_t total = (size_t)n * h * w;
+    const unsigned nb = (unsigned)((total + 255) / 256);
+    ProfScope prof(KID_OBJECTIVE, 400.0 * total, 120.0 * total, as_stream(stream));
+    hipLaunchKernelGGL(temporal_l1_kernel<true>, dim3(nb), dim3(256), 0, as_stream(stream), fake1, fake2, theta, (double *)nullptr, c, scale,
+                       gfake1, gfake2, h, w, total, nb, scratch);
+    hipLaunchKernelGGL(temporal_gather_kernel, dim3(nb), dim3(256), 0, as_stream(stream), scratch, theta, gfake2, h, w, total);
+    return check_launch("temporal_gather_kernel");
+}
+
+extern "C" int pws_feature_loss_bwd_det(const float *grid, const float *features, float c, const float *scale, float *ggrid, int m,
+                                        int nf, int h, int w, pws_stream_t stream) {
+    PWS_REQUIRE(m >= 0 && nf >= 0 && h > 0 && w > 0, "pws_feature_loss_bwd_det: bad shape");
+    if (m == 0 || nf == 0) return PWS_OK;
+    PWS_REQUIRE(grid && features && ggrid, "pws_feature_loss_bwd_det: NULL pointer");
+    hipLaunchKernelGGL(feature_loss_bwd_serial_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, as_stream(stream), grid, features, c, scale,
+                       ggrid, m, nf, h, w);
+    return check_launch("feature_loss_bwd_serial_kernel");
 }
 
 extern "C" int pws_feature_loss_fwd(const float *grid, const float *features, double *slots, int m, int nf, int h, int w,

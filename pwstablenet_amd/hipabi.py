@@ -140,8 +140,10 @@ SIGNATURES = {
     "pws_warp_norm_bwd": (_I, [_P, _S, _P, _P, _S, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
     "pws_temporal_l1_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "pws_temporal_l1_bwd": (_I, [_P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
+    "pws_temporal_l1_bwd_det": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P]),
     "pws_feature_loss_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "pws_feature_loss_bwd": (_I, [_P, _P, _F, _P, _P, _I, _I, _I, _I, _P]),
+    "pws_feature_loss_bwd_det": (_I, [_P, _P, _F, _P, _P, _I, _I, _I, _I, _P]),
     "pws_field_smoothness": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "pws_shape_loss_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "pws_shape_loss_bwd": (_I, [_P, ctypes.c_double, _P, _P, _I, _I, _I, _P]),

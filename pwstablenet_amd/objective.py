@@ -128,13 +128,19 @@ class _Objective(torch.autograd.Function):
         for nl in range(L_):
             gx = g_fakes[nl]
             gextra = torch.zeros_like(fakes[nl]) if gx is None else gx.contiguous().clone()
-            A.check(lib.pws_temporal_l1_bwd(A.ptr(fakes[nl][:n]), A.ptr(fakes[nl][n:]), A.ptr(theta), c_t, A.ptr(scale),
-                                            A.ptr(gextra[:n]), A.ptr(gextra[n:]), n, h, w, st), "pws_temporal_l1_bwd")
+            if cfg.get("deterministic"):   # ordered gather instead of the atomics' scatter (bit-identical runs)
+                scratch = torch.empty((n, 3, h, w), device=rgb.device, dtype=torch.float32)
+                A.check(lib.pws_temporal_l1_bwd_det(A.ptr(fakes[nl][:n]), A.ptr(fakes[nl][n:]), A.ptr(theta), c_t, A.ptr(scale),
+                                                    A.ptr(gextra[:n]), A.ptr(gextra[n:]), A.ptr(scratch), n, h, w, st), "pws_temporal_l1_bwd_det")
+            else:
+                A.check(lib.pws_temporal_l1_bwd(A.ptr(fakes[nl][:n]), A.ptr(fakes[nl][n:]), A.ptr(theta), c_t, A.ptr(scale),
+                                                A.ptr(gextra[:n]), A.ptr(gextra[n:]), n, h, w, st), "pws_temporal_l1_bwd")
             gg = torch.empty_like(grids[nl])
             A.check(lib.pws_warp_norm_bwd(rgb_p, rgb_s, A.ptr(grids[nl]), stb_p, stb_s, c_l1, A.ptr(scale), A.ptr(gextra),
                                           A.ptr(gg), 0, m, h, w, st), "pws_warp_norm_bwd")
-            A.check(lib.pws_feature_loss_bwd(A.ptr(grids[nl]), A.ptr(features), c_f, A.ptr(scale), A.ptr(gg), m,
-                                             features.shape[1], h, w, st), "pws_feature_loss_bwd")
+            feat_bwd = lib.pws_feature_loss_bwd_det if cfg.get("deterministic") else lib.pws_feature_loss_bwd
+            A.check(feat_bwd(A.ptr(grids[nl]), A.ptr(features), c_f, A.ptr(scale), A.ptr(gg), m, features.shape[1], h, w, st),
+                    "pws_feature_loss_bwd")
             ggrids.append(gg)
         gresid = None
         if cfg["shapeloss"]:
@@ -177,6 +183,10 @@ class StabObjective:
         # sum-type term so that the averaged gradient equals the reference's; the reported loss values stay local
         # (loss_pixel of the job = SUM of the ranks', the other terms = their MEAN).
         self.grad_average_world = kw.get("grad_average_world", None)
+        # True: the two scatter gradients of the objective (the temporal term's warp of fake2, feature points sharing a pixel) run
+        # without atomics (pws_temporal_l1_bwd_det / pws_feature_loss_bwd_det); together with UnetGenerator.deterministic a whole
+        # train_step then gives bit-identical gradients and weights run to run.  train_step sets it from the generator's flag.
+        self.deterministic = bool(kw.get("deterministic", False))
         if self.num_layer != 3:
             raise NotImplementedError("StabObjective: the generator has 3 cascaded stages (num_layer=%d)" % self.num_layer)
         if bool(get("use_gan", False)):
@@ -216,7 +226,8 @@ class StabObjective:
             raise ValueError("StabObjective: feature_adjacent must hold n = %d affine maps, got %s" % (n, tuple(feature_adjacent.shape)))
         cfg = {"size": self.size, "number_feature": self.number_feature, "batch": self.batch, "lamd": self.lamd,
                "shapeloss": self.shapeloss, "shapeloss_weight": self.shapeloss_weight, "block": self.block,
-               "num_layer": self.num_layer, "coef": lambda dev: self._coef_matrix(n, dev), "dp_world": self.grad_average_world}
+               "num_layer": self.num_layer, "coef": lambda dev: self._coef_matrix(n, dev), "dp_world": self.grad_average_world,
+               "deterministic": self.deterministic}
         out = _Objective.apply(cfg, rgb_unstable, image_stable, features.to(dtype=torch.float32).contiguous(), theta,
                                *grids, resid[self.num_layer - 1])
         loss_g, losses, fakes = out[0], out[1], list(out[2:])
@@ -253,6 +264,8 @@ def train_step(netG, optimizerG, batch, objective, perceptual=None, period=30, s
         u8_normalize(img[:, period + 1:], rest[half * n:(half + 1) * n])
     features = torch.cat([features1, features2], 0).to(device=dev, dtype=torch.float32)
     grids, resid = netG(win)
+    if getattr(getattr(netG, "module", netG), "deterministic", False):
+        objective.deterministic = True   # the generator asks for bit-reproducible gradients: so does the objective round it
     out = objective(grids, resid, rest[:, 0:3], rest[:, 3:], features, feature_adjacent.to(dev))
     loss = out.loss_g if perceptual is None else out.loss_g + perceptual(out.fake, rest[:, 3:6])
     optimizerG.zero_grad()
