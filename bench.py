@@ -86,6 +86,7 @@ _PMC_NAMES = {
     "wino_ring_kernel<convT4,F(2x2,2x2)>": ["wino_ring_kernel<convT4"],        # 1 or 2 classes per unit, both geometries
     "conv_bf16_kernel": ["conv_bf16_kernel", "conv_bf16_k5_kernel"],
     "conv_mfma_kernel<k5s1,16x16>": ["k5s1,tile"],
+    "conv_first_kernel": ["conv_first_kernel"],
     "grid_sample_fwd_kernel": ["grid_sample_fwd2_kernel"],
 }
 

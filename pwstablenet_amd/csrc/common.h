@@ -76,7 +76,7 @@ enum KernelId {
     KID_CONV_K3S1_BIG = 0, KID_CONV_K3S1_SMALL, KID_CONV_K3S2_BIG, KID_CONV_K3S2_SMALL, KID_CONV_K5S1, KID_CONVT4_BIG,
     KID_CONVT4_SMALL, KID_THETA_HEAD, KID_FIELD_HEAD, KID_GRID_SAMPLE_FWD, KID_GRID_SAMPLE_BWD, KID_UPSAMPLE_GRID_SAMPLE_FWD,
     KID_UPSAMPLE, KID_AFFINE_GRID, KID_ADAM, KID_PACK, KID_DGRAD_K4S2, KID_DGRAD_SP3, KID_WGRAD, KID_ACT_BWD, KID_FIELD_HEAD_BWD,
-    KID_THETA_HEAD_BWD, KID_CONV_WINO, KID_CONV_BF16, KID_WGRAD_BF16, KID_CONV_WINO_CT4, KID_UPSAMPLE_GRID_SAMPLE_U8, KID_OBJECTIVE, KID_CONV_RING, KID_CONV_RINGF, KID_CONV_WRING, KID_CONV_WRING_CT4, KID_CONV_SKINNY, KID_WGRAD_RING, KID_CONV_SKINNY16, KID_COUNT
+    KID_THETA_HEAD_BWD, KID_CONV_WINO, KID_CONV_BF16, KID_WGRAD_BF16, KID_CONV_WINO_CT4, KID_UPSAMPLE_GRID_SAMPLE_U8, KID_OBJECTIVE, KID_CONV_RING, KID_CONV_RINGF, KID_CONV_WRING, KID_CONV_WRING_CT4, KID_CONV_SKINNY, KID_WGRAD_RING, KID_CONV_SKINNY16, KID_CONV_FIRST, KID_COUNT
 };
 // Deterministic accumulation (PWS_NETG_DETERMINISTIC / pws_conv_bwd_weight_args.deterministic): while set on the calling thread,
 // every launcher that accumulates with fp32 atomics gives each address ONE adding workgroup per launch (no pixel split), the head

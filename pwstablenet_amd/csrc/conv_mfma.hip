@@ -364,6 +364,7 @@ int conv_bf16_fwd(int kind, ConvKParams &kp, int cin_total, float *out, float *w
                   const ProfInfo &pi);  // conv_bf16.hip; 1 = not covered
 int conv_bf16_dgrad(int kind, ConvKParams &kp, int cout_f, float *ws, size_t ws_floats, hipStream_t st, const ProfInfo &pi);
 int conv_ringf_try(int kind, const ConvKParams &kp, hipStream_t st, const ProfInfo &pi);   // conv_ring_f32.hip; 1 = not covered
+int conv_first_try(const ConvKParams &kp, hipStream_t st, const ProfInfo &pi);             // conv_first.hip; 1 = not covered
 int conv_skinny_try(int kind, ConvKParams &kp, float *final_out, float *ws, size_t ws_floats, hipStream_t st, const ProfInfo &pi);  // conv_skinny.hip; 1 = not covered
 
 int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
@@ -472,6 +473,11 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
         kp.OH = kp.LH = a->h, kp.OW = kp.LW = a->w;
         if (bf16) {
             const int rc = conv_bf16_fwd(a->kind, kp, kp.cin_pad, a->out, nullptr, 0, st, info(25, (double)a->n * a->h * a->w));
+            if (rc != 1) return rc;
+        }
+        if (nchw) {   // the persistent planar-LDS kernel where it is covered (the generator's 256 x 256 windows)
+            kp.out = a->out;
+            const int rc = conv_first_try(kp, st, info(25, (double)a->n * a->h * a->w));
             if (rc != 1) return rc;
         }
         return select_and_launch(nchw ? kK5N : kK5, 1, kp, kp.cin_pad, a->out, nullptr, 0, st,

@@ -28,7 +28,7 @@ def nchw(a):
     return np.ascontiguousarray(a.transpose(0, 3, 1, 2))
 
 
-def run_conv(A, kind, srcs_nhwc, w_torch, bias, act, cout, nchw_src=None, ws_mb=0, wino=False):
+def run_conv(A, kind, srcs_nhwc, w_torch, bias, act, cout, nchw_src=None, ws_mb=0, wino=False, nchw_channels=None):
     """srcs_nhwc: list of numpy NHWC arrays (virtual concat) or nchw_src: one NCHW array."""
     L = A.lib()
     st = A.current_stream()
@@ -45,6 +45,8 @@ def run_conv(A, kind, srcs_nhwc, w_torch, bias, act, cout, nchw_src=None, ws_mb=
         n, _, h, w = nchw_src.shape
         args.nsrc, args.src_nchw = 1, 1
         args.src[0].ptr, args.src[0].channels, args.src[0].ld = t.data_ptr(), nchw_src.shape[1], 0
+        if nchw_channels is not None:   # the first `nchw_channels` planes of every sample, read in place (ld = sample stride)
+            args.src[0].channels, args.src[0].ld = nchw_channels, nchw_src.shape[1] * h * w
     else:
         n, h, w, _ = srcs_nhwc[0].shape
         args.nsrc = len(srcs_nhwc)
@@ -358,6 +360,47 @@ def test_conv_first_layer_nchw_31ch(hip, oracle):
     ref = oracle.conv2d(x, wt, b, 1, 2, oracle.ACT_LRELU)
     got = run_conv(A, A.CONV_K5S1, None, wt, b, 1, 64, nchw_src=x)
     np.testing.assert_allclose(nchw(got), ref, rtol=0, atol=5e-5)
+
+
+FIRST_CASES = [   # (n, h, w), cin, cout, planes per sample in memory (None = dense), forced (PWS_OPT_EXPERIMENT 29: small launches)
+    ((1, 256, 256), 31, 64, None, False),    # the generator's window: 256 units, the product dispatch
+    ((2, 128, 256), 31, 64, 34, False),      # the driver's 34-plane item read in place
+    ((2, 16, 32), 31, 64, None, True), ((1, 8, 64), 17, 64, None, True), ((3, 24, 32), 32, 20, None, True),
+    ((1, 40, 96), 31, 128, 36, True), ((5, 8, 32), 20, 4, None, True),
+]
+
+
+@pytest.mark.parametrize("shape,cin,cout,planes,forced", FIRST_CASES)
+@pytest.mark.parametrize("act", [1, 2])
+def test_first_layer_planar_kernel_vs_oracle(hip, oracle, shape, cin, cout, planes, forced, act):
+    """conv_first_kernel (csrc/conv_first.hip: persistent, planar NCHW halo in LDS by LDS-DMA, exact fp32 MFMA) against the C oracle
+    and against conv_mfma_kernel<k5s1, NCHW> (PWS_OPT_EXPERIMENT 25): image borders on every side, the zero padding channel,
+    cout ending inside / spanning 64-channel blocks, samples read in place out of wider items."""
+    A = hip
+    L = A.lib()
+    n, h, w = shape
+    rs = np.random.RandomState(zlib.crc32(repr((shape, cin, cout, planes)).encode()))
+    xfull = rs.standard_normal((n, planes or cin, h, w)).astype(np.float32)
+    x = xfull[:, :cin]
+    wt = (rs.standard_normal((cout, cin, 5, 5)) / np.sqrt(cin * 25)).astype(np.float32)
+    b = rs.standard_normal((cout,)).astype(np.float32)
+    ref = oracle.conv2d(np.ascontiguousarray(x), wt, b, 1, 2, {1: oracle.ACT_LRELU, 2: oracle.ACT_RELU}[act])
+    got = {}
+    try:
+        for exp in ((29 if forced else 0), 25):
+            assert L.pws_set_option(100, exp) == 0
+            L.pws_prof_enable(1)
+            got[exp] = run_conv(A, A.CONV_K5S1, None, wt, b, act, cout, nchw_src=xfull, nchw_channels=cin if planes else None)
+            L.pws_prof_enable(0)
+            names = [r[0] for r in A.prof_collect()]
+            assert names == (["conv_mfma_kernel<k5s1,16x16>"] if exp == 25 else ["conv_first_kernel"]), (exp, names)
+    finally:
+        L.pws_prof_enable(0)
+        L.pws_set_option(100, 0)
+    new = got[29 if forced else 0]
+    assert not np.isnan(new).any(), "kernel left output elements unwritten"
+    np.testing.assert_allclose(nchw(new), ref, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(new, got[25], rtol=0, atol=5e-5)
 
 
 def test_conv_empty_batch_and_bad_args(hip):

@@ -113,8 +113,45 @@ def bench(kname, n, h, w, cin, cout, wino, bf16=False):
         r[0][2] / (ms * 1e-3) / 1e12))
 
 
+def bench_first(n=8, h=256, w=256, cin=31, cout=64):
+    """The generator's first layer on the NCHW window (conv_first_kernel; PWS_EXPERIMENT 25 = conv_mfma_kernel<k5s1, NCHW>)."""
+    L, st = A.lib(), A.current_stream()
+    L.pws_set_option(100, int(os.environ.get("PWS_EXPERIMENT", "0")))
+    wt = torch.randn((cout, cin, 5, 5), device="cuda") / (cin * 25) ** 0.5
+    wp = torch.empty(L.pws_packed_weight_floats(A.CONV_K5S1, cin, cout), device="cuda")
+    A.check(L.pws_pack_conv_weight(A.ptr(wt), A.ptr(wp), A.CONV_K5S1, cin, cout, st), "pack")
+    xs = [torch.randn((n, cin, h, w), device="cuda") for _ in range(3)]
+    outs = [torch.empty((n, h, w, cout), device="cuda") for _ in range(3)]
+    b = torch.randn(cout, device="cuda")
+    a = A.PwsConvArgs()
+    a.kind, a.n, a.h, a.w, a.nsrc, a.cout, a.act, a.src_nchw = A.CONV_K5S1, n, h, w, 1, cout, 1, 1
+    a.src[0].channels, a.src[0].ld = cin, 0
+    a.w_packed, a.bias, a.out_ld = wp.data_ptr(), b.data_ptr(), cout
+
+    def launch(i):
+        a.src[0].ptr, a.out = xs[i % 3].data_ptr(), outs[i % 3].data_ptr()
+        A.check(L.pws_conv2d_fwd(ctypes.byref(a), st), "conv")
+    for i in range(3):
+        launch(i)
+    torch.cuda.synchronize()
+    L.pws_prof_enable(1)
+    for i in range(12):
+        launch(i)
+    L.pws_prof_enable(0)
+    r = A.prof_collect()
+    if not r:   # PWS_EXPERIMENT 1200: the kernel reports its own clock on stderr instead
+        return
+    ms = sorted(x_[4] for x_ in r)[len(r) // 2]
+    print("first layer n=%d %dx%d %d->%d exp=%s %-30s: %8.1f us  %6.1f TFLOP/s (algorithmic)" % (
+        n, h, w, cin, cout, os.environ.get("PWS_EXPERIMENT", "0"), r[0][0], ms * 1e3, r[0][2] / (ms * 1e-3) / 1e12))
+    L.pws_set_option(100, 0)
+
+
 if __name__ == "__main__":
     v = sys.argv[1:]
+    if v and v[0] == "first":
+        bench_first(*[int(t) for t in v[1:]])
+        sys.exit(0)
     if len(v) > 7 and v[7] == "dgrad":
         bench_dgrad(v[0], int(v[1]), int(v[2]), int(v[3]), int(v[4]), int(v[5]))
         sys.exit(0)
