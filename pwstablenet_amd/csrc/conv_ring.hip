@@ -234,6 +234,10 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
         unsigned pu = u_begin;
         int pplane = 0, ps = 0, pc0 = 0, pwrow = 0, pbuf = 0;
         RingUnit PU = ring_unit(p, pu);
+        unsigned loc[C::NL], cv[C::NL];   // cached per-lane source offsets (see stage())
+        int loc_ld = -1;
+#pragma unroll
+        for (int it = 0; it < C::NL; ++it) loc[it] = kRingOob, cv[it] = kRingOob;
         auto stage = [&]() {
             const unsigned d_base = uni((unsigned)(pbuf * C::GROUP_BYTES)) + (unsigned)(lw * 1024);
             pbuf = pbuf + 1 == C::R ? 0 : pbuf + 1;
@@ -275,34 +279,60 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
                 const_cast<char *>(uni(mix_in ? base_in : static_cast<const char *>(p.w_bf))), 0, (int)uni(mix_in ? (unsigned)img : (unsigned)p.w_bytes),
                 0x00020000);
             const unsigned d_smix = uni(mix_in ? d_sin : d_sw);
+            // Per-lane source offsets live in cv[] and are rebuilt only at the first group of a (unit, plane, source): every vector
+            // instruction a loader wave issues takes matrix-pipe cycles from its SIMD (~5 per instruction beside bf16 / fp32 matrix
+            // instructions: conv_first.hip, tools/probes/mfma_f32_probe.hip), and the 32-bit multiplies of the address arithmetic
+            // are quarter rate.  Offsets of a halo that lies inside the image are ONE add: loc[] (the lane's offset from the halo's
+            // first pixel, rebuilt only when the source's row stride changes) + the halo's scalar offset.
+            if (pc0 == 0) {
+                constexpr int S = C::NPLANES == 4 ? 2 : 1;
+                if (ld != loc_ld) {
+                    loc_ld = ld;
+#pragma unroll
+                    for (int it = 0; it < C::NL; ++it) {
+                        if (it * C::LWAVES >= C::IN_WI) continue;
+                        const int tn = ia[it] >> 20, ly = (ia[it] >> 10) & 0x3ff, lx = ia[it] & 0x3ff;
+                        loc[it] = ia[it] >= 0 ? (unsigned)((tn * p.H + S * ly) * p.W + S * lx) * ldb + (unsigned)ib[it] : kRingOob;
+                    }
+                }
+                const int fy = S * oy + (S == 2 ? a : 0), fx = S * ox + (S == 2 ? b : 0);   // image coordinates of the halo's first pixel
+                const unsigned s_halo = uni((unsigned)((fy * p.W + fx) * (int)ldb));
+                const bool interior = fy >= 0 && fy + S * (C::IH - 1) < p.H && fx >= 0 && fx + S * (C::IW - 1) < p.W;   // scalar
+#pragma unroll
+                for (int it = 0; it < C::NL; ++it) {
+                    const bool in_ct = (it + 1) * C::LWAVES <= C::IN_WI, w_ct = it * C::LWAVES >= C::IN_WI;
+                    unsigned v_in = kRingOob, v_w = kRingOob;
+                    if (!w_ct) {
+                        v_in = loc[it] + s_halo;   // (a filler lane stays out of range: ~2^31 + an offset inside one tile's samples)
+                        if (!interior) {
+                            const int ly = (ia[it] >> 10) & 0x3ff, lx = ia[it] & 0x3ff;
+                            const int ry = fy + S * ly, rx = fx + S * lx;
+                            v_in = (ia[it] >= 0 && ry >= 0 && ry < p.H && rx >= 0 && rx < p.W) ? v_in : kRingOob;
+                        }
+                    }
+                    if (!in_ct) {
+                        const int t = ia[it];
+                        int wt = t;   // plane of the packed weights this tap slot reads
+                        bool ok = t >= 0;
+                        const int ty = t >> 1, tx = t & 1;
+                        if constexpr (C::MODE == RM_CT4 || C::MODE == RM_SP3) wt = (PU.py * 2 + PU.px) * 4 + t;
+                        if constexpr (C::MODE == RM_SP3) ok = ok && ty <= PU.py && tx <= PU.px;
+                        if constexpr (C::MODE == RM_K3S2) wt = (a ? 2 * ty : 1) * 3 + (b ? 2 * tx : 1), ok = ok && ty <= a && tx <= b;
+                        if constexpr (C::MODE == RM_K4S2) wt = (2 * ty + 1 - a) * 4 + (2 * tx + 1 - b);
+                        v_w = ok ? (unsigned)wt * wplane + (unsigned)ib[it] : kRingOob;
+                    }
+                    cv[it] = in_ct ? v_in : (w_ct ? v_w : (mix_in ? v_in : v_w));
+                }
+            }
 #pragma unroll
             for (int it = 0; it < C::NL; ++it) {
                 // kind of this wave-instruction: compile-time except for the one `it` that straddles the input / weight boundary
                 const bool in_ct = (it + 1) * C::LWAVES <= C::IN_WI, w_ct = it * C::LWAVES >= C::IN_WI;
-                unsigned v_in = kRingOob, v_w = kRingOob;
-                if (!w_ct) {
-                    const int tn = ia[it] >> 20, ly = (ia[it] >> 10) & 0x3ff, lx = ia[it] & 0x3ff;
-                    int ry = oy + ly, rx = ox + lx;
-                    if constexpr (C::NPLANES == 4) ry = 2 * ry + a, rx = 2 * rx + b;
-                    const bool ok = ia[it] >= 0 && ry >= 0 && ry < p.H && rx >= 0 && rx < p.W;
-                    v_in = ok ? (unsigned)((tn * p.H + ry) * p.W + rx) * ldb + (unsigned)ib[it] : kRingOob;
-                }
-                if (!in_ct) {
-                    const int t = ia[it];
-                    int wt = t;   // plane of the packed weights this tap slot reads
-                    bool ok = t >= 0;
-                    const int ty = t >> 1, tx = t & 1;
-                    if constexpr (C::MODE == RM_CT4 || C::MODE == RM_SP3) wt = (PU.py * 2 + PU.px) * 4 + t;
-                    if constexpr (C::MODE == RM_SP3) ok = ok && ty <= PU.py && tx <= PU.px;
-                    if constexpr (C::MODE == RM_K3S2) wt = (a ? 2 * ty : 1) * 3 + (b ? 2 * tx : 1), ok = ok && ty <= a && tx <= b;
-                    if constexpr (C::MODE == RM_K4S2) wt = (2 * ty + 1 - a) * 4 + (2 * tx + 1 - b);
-                    v_w = ok ? (unsigned)wt * wplane + (unsigned)ib[it] : kRingOob;
-                }
                 const unsigned dst = d_base + (unsigned)(it * C::LWAVES * 1024);
                 if (C::SKIP_FILL && it * C::LWAVES + lw >= C::IN_WI + C::W_WI) continue;   // filler (wave-uniform)
-                if (in_ct) ring_dma16(dst, v_in, d_rin, d_sin);
-                else if (w_ct) ring_dma16(dst, v_w, rsrc_w, d_sw);
-                else ring_dma16(dst, mix_in ? v_in : v_w, d_rmix, d_smix);
+                if (in_ct) ring_dma16(dst, cv[it], d_rin, d_sin);
+                else if (w_ct) ring_dma16(dst, cv[it], rsrc_w, d_sw);
+                else ring_dma16(dst, cv[it], d_rmix, d_smix);
             }
             // advance
             pc0 += C::CKG, pwrow += C::CKG;

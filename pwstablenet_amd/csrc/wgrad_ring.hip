@@ -139,51 +139,81 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
             xs[q] = xok[q] ? s : 0, xch[q] = xok[q] ? ch : 0;
         }
         const bool gok[2] = {co0 < p.cout, co0 + 32 < p.cout};
+        // Per-lane offsets from the tile's first halo pixel (x planes) / first pixel (dy planes): constants of the workgroup, so a tile
+        // inside the image costs a loader ONE vector add per DMA piece (every vector instruction issued beside the matrix
+        // instructions takes matrix-pipe cycles from its SIMD: conv_first.hip; the divisions and 32-bit multiplies that turned a
+        // row number into an address were ~25 instructions per piece and tile).
+        constexpr int S = C::SUBPIX ? 2 : 1;
+        unsigned ldx[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) ldx[q] = (unsigned)wrgsel4(p.src_ld, xs[q]) * 2u;
+        const unsigned ldg = (unsigned)p.gout_ld * 2u;
+        unsigned loc[C::NL];
+        int geo[C::NL];   // row-in-tile << 10 | column-in-tile
+#pragma unroll
+        for (int it = 0; it < C::NL; ++it) {
+            const int pc = it * C::LWAVES + lw;
+            const int row = (desc[it] >> 2) & 0x1ffffff, sp = desc[it] & 3;
+            if (pc < C::XPL * C::XPP) {
+                const int q = pc < C::XPP ? 0 : 1;
+                const int lx = row % C::IW, ly = row / C::IW;
+                loc[it] = (desc[it] >= 0 && xok[q]) ? (unsigned)(ly * p.W + lx) * ldx[q] + (unsigned)(sp * 16) : kWrgOob;
+                geo[it] = ly << 10 | lx;
+            } else {
+                const int q = ((pc - C::XPL * C::XPP) / C::GPP) & 1;
+                const int tx = row % C::TW, ty = row / C::TW;
+                loc[it] = (desc[it] >= 0 && gok[q]) ? (unsigned)(S * ty * p.OW + S * tx) * ldg + (unsigned)(q * 64 + sp * 16) : kWrgOob;
+                geo[it] = ty << 10 | tx;
+            }
+        }
         int tile = blockIdx.x, pbuf = 0;
         auto stage = [&]() {
             const unsigned d_base = uniq((unsigned)(pbuf * C::IMG_BYTES)) + (unsigned)(lw * 1024);
             pbuf ^= 1;
-            const bool live = tile < p.ntiles;
-            const int tt = live ? tile : 0;
+            if (tile >= p.ntiles) return;   // past the last tile: nothing reads that buffer (the waits are vmcnt(0): no piece count to keep)
+            const int tt = tile;
             const int tx_i = tt % p.tiles_x, ty_i = (tt / p.tiles_x) % p.tiles_y, n0 = tt / (p.tiles_x * p.tiles_y);
             const int y0 = ty_i * C::TH, x0 = tx_i * C::TW;
             const int iy0 = y0 - pad_y, ix0 = x0 - pad_x;
             // descriptors: one sample of each tensor (offsets stay below 2^31 whatever the batch)
             __amdgpu_buffer_rsrc_t rx[2];
-            unsigned ldx[2];
+            unsigned sx[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int ld = wrgsel4(p.src_ld, xs[q]);
                 const size_t img = (size_t)p.H * p.W * ld * 2;
                 const char *b = uniq(static_cast<const char *>(wrgsel4(p.src_ptr, xs[q])) + (size_t)n0 * img + (size_t)xch[q] * 2);
                 rx[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(b), 0, (int)uniq((unsigned)(img - (size_t)xch[q] * 2)), 0x00020000);
-                ldx[q] = (unsigned)ld * 2u;
+                sx[q] = uniq((unsigned)((iy0 * p.W + ix0) * (int)ldx[q]));
             }
             const size_t gimg = (size_t)p.OH * p.OW * p.gout_ld * 2;
             const char *gb = uniq(static_cast<const char *>(p.gout) + (size_t)n0 * gimg + (size_t)co0 * 2);
             const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gb), 0, (int)uniq((unsigned)(gimg - (size_t)co0 * 2)), 0x00020000);
-            const unsigned ldg = (unsigned)p.gout_ld * 2u;
+            const bool x_inside = iy0 >= 0 && iy0 + C::IH <= p.H && ix0 >= 0 && ix0 + C::IW <= p.W;   // scalar
 #pragma unroll
             for (int it = 0; it < C::NL; ++it) {
                 const int pc = it * C::LWAVES + lw;   // wave-uniform: the kind of a piece is too
-                const int row = (desc[it] >> 2) & 0x1ffffff, sp = desc[it] & 3;
-                unsigned v = kWrgOob;
                 const unsigned dst = d_base + (unsigned)(it * C::LWAVES * 1024);
                 if (pc < C::XPL * C::XPP) {
                     const int q = pc < C::XPP ? 0 : 1;
-                    const int lx = row % C::IW, ly = row / C::IW;
-                    const int iy = iy0 + ly, ix = ix0 + lx;
-                    const bool ok = live && desc[it] >= 0 && xok[q] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                    if (ok) v = (unsigned)(iy * p.W + ix) * ldx[q] + (unsigned)(sp * 16);
+                    unsigned v = loc[it] + (q ? sx[1] : sx[0]);   // (a filler lane stays out of range: ~2^31 + an offset inside one sample)
+                    if (!x_inside) {
+                        const int iy = iy0 + (geo[it] >> 10), ix = ix0 + (geo[it] & 0x3ff);
+                        v = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? v : kWrgOob;
+                    }
                     wrg_dma16(dst, v, q ? rx[1] : rx[0], 0u);
                 } else {
                     const int g = (pc - C::XPL * C::XPP) / C::GPP;   // dy plane: (class of the pair,) output-channel half
-                    const int q = g & 1, gpx = C::PAIR ? g >> 1 : px;
-                    const int tx = row % C::TW, ty = row / C::TW;
-                    const int y = y0 + ty, x = x0 + tx;
-                    const int oy = C::SUBPIX ? 2 * y + py : y, ox = C::SUBPIX ? 2 * x + gpx : x;
-                    const bool ok = live && desc[it] >= 0 && gok[q] && y < p.LH && x < p.LW && oy < p.OH && ox < p.OW;
-                    if (ok) v = (unsigned)(oy * p.OW + ox) * ldg + (unsigned)(q * 64 + sp * 16);
+                    const int gpx = C::PAIR ? g >> 1 : px;
+                    const int fy = C::SUBPIX ? 2 * y0 + py : y0, fx = C::SUBPIX ? 2 * x0 + gpx : x0;   // dy pixel of the tile's first pixel
+                    const unsigned sg = uniq((unsigned)((fy * p.OW + fx) * (int)ldg));
+                    const bool g_inside = y0 + C::TH <= p.LH && x0 + C::TW <= p.LW && fy + S * (C::TH - 1) < p.OH && fx + S * (C::TW - 1) < p.OW;
+                    unsigned v = loc[it] + sg;
+                    if (!g_inside) {
+                        const int y = y0 + (geo[it] >> 10), x = x0 + (geo[it] & 0x3ff);
+                        const int oy = fy + S * (geo[it] >> 10), ox = fx + S * (geo[it] & 0x3ff);
+                        v = (y < p.LH && x < p.LW && oy < p.OH && ox < p.OW) ? v : kWrgOob;
+                    }
                     wrg_dma16(dst, v, rg, 0u);
                 }
             }
