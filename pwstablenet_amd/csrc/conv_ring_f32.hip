@@ -156,6 +156,10 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ringf_kernel(const RingfPa
         unsigned pu = u_begin;
         int pplane = 0, ps = 0, pc0 = 0, pwrow = 0, pbuf = 0;
         RingfUnit PU = ringf_unit(p, pu);
+        unsigned loc[C::NL], cv[C::NL];   // cached per-lane source offsets (see stage())
+        int loc_ld = -1;
+#pragma unroll
+        for (int it = 0; it < C::NL; ++it) loc[it] = kRingfOob, cv[it] = kRingfOob;
         auto stage = [&]() {
             const unsigned d_base = unif((unsigned)(pbuf * C::GROUP_BYTES)) + (unsigned)(lw * 1024);
             pbuf = pbuf + 1 == C::R ? 0 : pbuf + 1;
@@ -183,30 +187,53 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ringf_kernel(const RingfPa
                 const_cast<char *>(unif(mix_in ? base_in : reinterpret_cast<const char *>(p.w))), 0,
                 (int)unif(mix_in ? (unsigned)img : (unsigned)p.w_bytes), 0x00020000);
             const unsigned d_smix = unif(mix_in ? d_sin : d_sw);
+            // Per-lane source offsets live in cv[] and are rebuilt only at the first group of a (unit, plane, source), as in
+            // conv_ring.hip: a vector instruction issued by a loader wave takes ~5 cycles of fp32 matrix time from its SIMD
+            // (conv_first.hip).  A halo inside the image costs one add per piece: loc[] + the halo's scalar offset.
+            if (pc0 == 0) {
+                constexpr int S = C::NPLANES == 4 ? 2 : 1;
+                if (ld != loc_ld) {
+                    loc_ld = ld;
+#pragma unroll
+                    for (int it = 0; it < C::NL; ++it) {
+                        if (it * C::LWAVES >= C::IN_WI) continue;
+                        const int ly = ia[it] >> 10, lx = ia[it] & 0x3ff;
+                        loc[it] = ia[it] >= 0 ? (unsigned)(S * ly * p.W + S * lx) * ldb + (unsigned)ib[it] : kRingfOob;
+                    }
+                }
+                const int fy = S * oy + (S == 2 ? a : 0), fx = S * ox + (S == 2 ? b : 0);   // image coordinates of the halo's first pixel
+                const unsigned s_halo = unif((unsigned)((fy * p.W + fx) * (int)ldb));
+                const bool interior = fy >= 0 && fy + S * (C::IH - 1) < p.H && fx >= 0 && fx + S * (C::IW - 1) < p.W;   // scalar
+#pragma unroll
+                for (int it = 0; it < C::NL; ++it) {
+                    const bool in_ct = (it + 1) * C::LWAVES <= C::IN_WI, w_ct = it * C::LWAVES >= C::IN_WI;
+                    unsigned v_in = kRingfOob, v_w = kRingfOob;
+                    if (!w_ct) {
+                        v_in = loc[it] + s_halo;
+                        if (!interior) {
+                            const int ry = fy + S * (ia[it] >> 10), rx = fx + S * (ia[it] & 0x3ff);
+                            v_in = (ia[it] >= 0 && ry >= 0 && ry < p.H && rx >= 0 && rx < p.W) ? v_in : kRingfOob;
+                        }
+                    }
+                    if (!in_ct) {
+                        const int t = ia[it] >> 4, k = ia[it] & 15;
+                        int wt = t;   // plane of the packed weights this tap slot reads
+                        bool ok = ia[it] >= 0 && PU.co0 + ib[it] * 4 < p.cout;
+                        const int ty = t >> 1, tx = t & 1;
+                        if constexpr (C::MODE == RF_CT4) wt = (PU.py * 2 + PU.px) * 4 + t;
+                        if constexpr (C::MODE == RF_K3S2) wt = (a ? 2 * ty : 1) * 3 + (b ? 2 * tx : 1), ok = ok && ty <= a && tx <= b;
+                        v_w = ok ? (unsigned)wt * wplane + (unsigned)(k * p.cout + ib[it] * 4) * 4u : kRingfOob;
+                    }
+                    cv[it] = in_ct ? v_in : (w_ct ? v_w : (mix_in ? v_in : v_w));
+                }
+            }
 #pragma unroll
             for (int it = 0; it < C::NL; ++it) {
                 const bool in_ct = (it + 1) * C::LWAVES <= C::IN_WI, w_ct = it * C::LWAVES >= C::IN_WI;
-                unsigned v_in = kRingfOob, v_w = kRingfOob;
-                if (!w_ct) {
-                    const int ly = ia[it] >> 10, lx = ia[it] & 0x3ff;
-                    int ry = oy + ly, rx = ox + lx;
-                    if constexpr (C::NPLANES == 4) ry = 2 * ry + a, rx = 2 * rx + b;
-                    const bool ok = ia[it] >= 0 && ry >= 0 && ry < p.H && rx >= 0 && rx < p.W;
-                    v_in = ok ? (unsigned)(ry * p.W + rx) * ldb + (unsigned)ib[it] : kRingfOob;
-                }
-                if (!in_ct) {
-                    const int t = ia[it] >> 4, k = ia[it] & 15;
-                    int wt = t;   // plane of the packed weights this tap slot reads
-                    bool ok = ia[it] >= 0 && PU.co0 + ib[it] * 4 < p.cout;
-                    const int ty = t >> 1, tx = t & 1;
-                    if constexpr (C::MODE == RF_CT4) wt = (PU.py * 2 + PU.px) * 4 + t;
-                    if constexpr (C::MODE == RF_K3S2) wt = (a ? 2 * ty : 1) * 3 + (b ? 2 * tx : 1), ok = ok && ty <= a && tx <= b;
-                    v_w = ok ? (unsigned)wt * wplane + (unsigned)(k * p.cout + ib[it] * 4) * 4u : kRingfOob;
-                }
                 const unsigned dst = d_base + (unsigned)(it * C::LWAVES * 1024);
-                if (in_ct) ringf_dma16(dst, v_in, d_rin, d_sin);
-                else if (w_ct) ringf_dma16(dst, v_w, rsrc_w, d_sw);
-                else ringf_dma16(dst, mix_in ? v_in : v_w, d_rmix, d_smix);
+                if (in_ct) ringf_dma16(dst, cv[it], d_rin, d_sin);
+                else if (w_ct) ringf_dma16(dst, cv[it], rsrc_w, d_sw);
+                else ringf_dma16(dst, cv[it], d_rmix, d_smix);
             }
             pc0 += C::CKG, pwrow += C::CKG;
             if (pc0 >= selq4(p.src_c, ps)) {
@@ -395,7 +422,9 @@ int conv_ringf_try(int kind, const ConvKParams &kp, hipStream_t st, const ProfIn
     // (stride-2 kind: from one 16 x 32 unit per CU upwards -- 64 -> 64 @256^2 x 8 = 256 units: 113 vs 136 us of conv_mfma_kernel; with
     //  fewer units than CUs the persistent kernel loses: 128 -> 128 @128^2 x 8 = 128 units 188 vs 109 us)
     if (kp.LH % 16 == 0 && (per256 / 2 >= (mode == RF_K3S2 ? 256 : 512) || g_experiment == 24)) th = 16;
-    else if (forced) th = 8;
+    // (stride-2 kind with one 8 x 32 unit per CU, measured after the loader's offsets moved into registers: 128 -> 128 @128^2 x 8
+    //  91 vs 98 us, 64 -> 128 @128^2 52 vs 60 us of conv_mfma_kernel; half a chip of units loses: 256 -> 256 @64^2 158 vs 98 us)
+    else if (forced || (mode == RF_K3S2 && per256 >= 256)) th = 8;
     else return 1;
     if (mode == RF_CT4 && !forced) return 1;
     ProfScope prof(KID_CONV_RINGF, pi.flops, pi.bytes, st);

@@ -27,6 +27,7 @@ def main():
     net.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in synth.make_weights("W1", 123, ngf=64)})
     net = net.cuda()
     net.module.set_math(a.math)
+    A.lib().pws_set_option(A.OPT_EXPERIMENT, int(os.environ.get("PWS_EXPERIMENT", "0")))
     A.lib().pws_set_option(A.OPT_TWO_QUEUES, 0)  # one queue: per-kernel durations are not inflated by overlap
     x = torch.from_numpy(synth.noise_window(a.batch, 31, 256, 123)).cuda()
     names = [ls.name.replace(".0", "").replace(".mpconv", "") for ls in spec.layer_specs()]
