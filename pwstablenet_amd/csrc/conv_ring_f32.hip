@@ -19,6 +19,9 @@
 
 namespace pws {
 
+typedef float rf_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned rf_u32x2 __attribute__((ext_vector_type(2)));
+
 enum RingfMode {
     RF_K3S1 = 0,  // conv k3 s1 p1 (and transposed k3 s1 p1 = flipped taps): dense in, dense out
     RF_CT4 = 1,   // transposed conv k4 s2 p1: 4 output parity classes, each a 2x2 conv of the dense input
@@ -44,9 +47,13 @@ struct RingfParams {
     int gpp;              // K groups per plane = sum(src_c) / 16
 };
 
-template <int MODE_, int TH_, int R_>
+template <int MODE_, int TH_, int R_, int NT_ = 2>
 struct RfCfg {
     static constexpr int MODE = MODE_, TH = TH_, TW = 32, R = R_;
+    // NT: 32-channel output blocks per unit.  2: a matrix wave owns 64 output channels.  1: units of 32 output channels, twice as
+    // many of them -- for launches whose 64-channel units would leave half the chip idle (the stride-2 layers on 64^2 inputs)
+    static constexpr int NT = NT_, CO_UNIT = 32 * NT, WROWB = 128 * NT, WSL = 8 * NT;   // weight row: bytes, 16-byte slots
+    static_assert(NT == 1 || NT == 2, "output-channel blocks");
     static constexpr int KS = MODE == RF_K3S1 ? 3 : 2;
     static constexpr int TAPS = KS * KS;
     static constexpr int NPLANES = MODE == RF_K3S2 ? 4 : 1;   // input parity planes
@@ -62,7 +69,7 @@ struct RfCfg {
     static constexpr int SPP = ROWB / 16;                         // 16-byte slots per input row
     static constexpr int IN_SLOTS = IH * IW * SPP;
     static constexpr int IN_WI = (IN_SLOTS + 63) / 64;            // wave-instructions (64 slots each)
-    static constexpr int W_WI = TAPS * CKG * 256 / 1024;          // TAPS x 16 channel rows x 256 bytes
+    static constexpr int W_WI = TAPS * CKG * WROWB / 1024;        // TAPS x 16 channel rows x 128 NT bytes
     static constexpr int NL = (IN_WI + W_WI + LWAVES - 1) / LWAVES; // DMA instructions per loader wave and group
     static constexpr int GROUP_BYTES = NL * LWAVES * 1024;
     static constexpr int W_OFF = IN_WI * 1024;
@@ -98,14 +105,14 @@ __device__ __forceinline__ T selq4(const T (&a)[4], int i) {
 struct RingfUnit {   // decoded (tile, cout block, class)
     int n0, y0, x0, co0, py, px;
 };
-__device__ __forceinline__ RingfUnit ringf_unit(const RingfParams &p, unsigned u) {
+__device__ __forceinline__ RingfUnit ringf_unit(const RingfParams &p, unsigned u, int co_unit) {
     RingfUnit r;
     const unsigned cls = u % p.ncls, rest = u / p.ncls;
     const unsigned cob = rest % p.ncob, tile = rest / p.ncob;
     const unsigned tx = tile % (unsigned)p.tiles_x, t2 = tile / (unsigned)p.tiles_x;
     const unsigned ty = t2 % (unsigned)p.tiles_y;
     r.n0 = (int)(t2 / (unsigned)p.tiles_y);
-    r.y0 = (int)ty, r.x0 = (int)tx, r.co0 = (int)cob * 64, r.py = (int)(cls >> 1), r.px = (int)(cls & 1);
+    r.y0 = (int)ty, r.x0 = (int)tx, r.co0 = (int)cob * co_unit, r.py = (int)(cls >> 1), r.px = (int)(cls & 1);
     return r;
 }
 
@@ -146,8 +153,8 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ringf_kernel(const RingfPa
                 ib[it] = (sp ^ ((lx >> 2) & 3)) * 16;
             } else if (wi < C::IN_WI + C::W_WI) {
                 const int jj = j - C::IN_WI * 64;
-                ia[it] = jj >> 4;      // tap * 16 + k
-                ib[it] = jj & 15;      // 4-cout slot
+                ia[it] = jj / C::WSL;   // tap * 16 + k
+                ib[it] = jj % C::WSL;   // 4-cout slot
             } else {
                 ia[it] = -1, ib[it] = 0;
             }
@@ -155,7 +162,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ringf_kernel(const RingfPa
         const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, (int)p.w_bytes, 0x00020000);
         unsigned pu = u_begin;
         int pplane = 0, ps = 0, pc0 = 0, pwrow = 0, pbuf = 0;
-        RingfUnit PU = ringf_unit(p, pu);
+        RingfUnit PU = ringf_unit(p, pu, C::CO_UNIT);
         unsigned loc[C::NL], cv[C::NL];   // cached per-lane source offsets (see stage())
         int loc_ld = -1;
 #pragma unroll
@@ -242,7 +249,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ringf_kernel(const RingfPa
                     ps = 0, pwrow = 0, ++pplane;
                     if (pplane == C::NPLANES) {
                         pplane = 0, pu += u_step;
-                        if (pu < u_end) PU = ringf_unit(p, pu);
+                        if (pu < u_end) PU = ringf_unit(p, pu, C::CO_UNIT);
                     }
                 }
             }
@@ -269,12 +276,14 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ringf_kernel(const RingfPa
             a_off[mt][dx] = ((wv * C::MT + mt) * C::IW + lx) * C::ROWB + ((hi ^ ((lx >> 2) & 3)) << 4);
         }
     // B: weight row of channel 4 (2 t + hi) + i, output channel nt * 32 + l31
-    const int b_off = C::W_OFF + hi * 4 * 256 + l31 * 4;
+    // (NT == 2: output channels split even / odd over the two accumulators -- a lane's B operands of both are ONE 8-byte read and its
+    //  results 8-byte stores; every LDS / vector instruction beside the fp32 matrix instructions costs matrix time: conv_first.hip)
+    const int b_off = C::W_OFF + hi * 4 * C::WROWB + l31 * 4 * C::NT;
 
-    f32x16 acc[C::MT][2];
+    f32x16 acc[C::MT][C::NT];
     unsigned cu = u_begin;
     int cg = 0, cplane = 0, cgp = 0, cbuf = 0;
-    RingfUnit CU = ringf_unit(p, cu);
+    RingfUnit CU = ringf_unit(p, cu, C::CO_UNIT);
 
     for (unsigned s = 0; s < total; ++s) {
         asm volatile("" ::: "memory");
@@ -284,7 +293,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ringf_kernel(const RingfPa
 #pragma unroll
             for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
         }
@@ -305,42 +314,54 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ringf_kernel(const RingfPa
                     a4[mt] = *reinterpret_cast<const f32x4 *>(lds + gb + (unsigned)((a_off[mt][tx] ^ (t * 32)) + ty * C::IW * C::ROWB));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float bv[2];
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        bv[nt] = *reinterpret_cast<const float *>(lds + gb + (unsigned)(b_off + (tap * 16 + 8 * t + i) * 256 + nt * 128));
+                    float bv[C::NT];
+                    if constexpr (C::NT == 2) {
+                        const rf_f32x2 b2 = *reinterpret_cast<const rf_f32x2 *>(lds + gb + (unsigned)(b_off + (tap * 16 + 8 * t + i) * C::WROWB));
+                        bv[0] = b2[0], bv[1] = b2[1];
+                    } else {
+                        bv[0] = *reinterpret_cast<const float *>(lds + gb + (unsigned)(b_off + (tap * 16 + 8 * t + i) * C::WROWB));
+                    }
 #pragma unroll
                     for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
+                        for (int nt = 0; nt < C::NT; ++nt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[mt][i], bv[nt], acc[mt][nt], 0, 0, 0);
                 }
             }
         }
 
         if (cg == ngroups - 1) {
-            // ---- epilogue of unit cu: bias + activation on the accumulators; lane (l31, hi) holds channel nt * 32 + l31 of the
-            // pixels (r & 3) + 8 (r >> 2) + 4 hi of its 32-pixel rows: a store instruction writes 2 pixels x 128 bytes
+            // ---- epilogue of unit cu: bias + activation on the accumulators; lane (l31, hi) holds channels NT l31 (+ 1) of the pixels
+            // (r & 3) + 8 (r >> 2) + 4 hi of its 32-pixel rows.  Stores are buffer stores with the pixel as SCALAR offset: the
+            // epilogue's vector work is the bias and the activation alone (NT == 2: 8-byte stores, 256 bytes per pixel and half-wave)
             constexpr int SO = C::NCLS == 4 ? 2 : 1;
+            const int co = CU.co0 + C::NT * l31;
+            const bool co_ok = co < p.cout;
+            float bs[C::NT];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int co = CU.co0 + nt * 32 + l31;
-                const bool co_ok = co < p.cout;
-                const float bs = (p.bias && co_ok) ? p.bias[co] : 0.f;
+            for (int nt = 0; nt < C::NT; ++nt) bs[nt] = (p.bias && co_ok) ? p.bias[co + nt] : 0.f;
+            const size_t oimg = (size_t)p.OH * p.OW * p.out_ld;
+            const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)CU.n0 * oimg, 0, (int)(oimg * 4), 0x00020000);
+            const unsigned pxb = (unsigned)(SO * p.out_ld * 4);   // bytes between consecutive tile pixels in the output
 #pragma unroll
-                for (int mt = 0; mt < C::MT; ++mt) {
-                    const int y = CU.y0 * C::TH + wv * C::MT + mt;
-                    const int oy = SO * y + (C::NCLS == 4 ? CU.py : 0);
+            for (int mt = 0; mt < C::MT; ++mt) {
+                const int y = CU.y0 * C::TH + wv * C::MT + mt;
+                const int oy = SO * y + (C::NCLS == 4 ? CU.py : 0);
+                const int ox0 = SO * (CU.x0 * C::TW + 4 * hi) + (C::NCLS == 4 ? CU.px : 0);
+                const unsigned vo = co_ok ? (unsigned)(((oy * p.OW + ox0) * p.out_ld + co) * 4) : kRingfOob;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int x = CU.x0 * C::TW + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        const int ox = SO * x + (C::NCLS == 4 ? CU.px : 0);
-                        if (co_ok) p.out[((size_t)(CU.n0 * p.OH + oy) * p.OW + ox) * p.out_ld + co] = act_apply(acc[mt][nt][r] + bs, p.act);
+                for (int r = 0; r < 16; ++r) {
+                    const int soff = (int)(((r & 3) + 8 * (r >> 2)) * pxb);
+                    if constexpr (C::NT == 2) {
+                        const rf_f32x2 v = {act_apply(acc[mt][0][r] + bs[0], p.act), act_apply(acc[mt][1][r] + bs[1], p.act)};
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(rf_u32x2, v), rsrc_o, (int)vo, soff, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, act_apply(acc[mt][0][r] + bs[0], p.act)), rsrc_o, (int)vo, soff, 0);
                     }
                 }
             }
             cg = 0, cplane = 0, cgp = 0, cu += u_step;
-            if (cu < u_end) CU = ringf_unit(p, cu);
+            if (cu < u_end) CU = ringf_unit(p, cu, C::CO_UNIT);
         } else {
             ++cg;
             if (++cgp == p.gpp) cgp = 0, ++cplane;
@@ -371,7 +392,7 @@ static int ringf_launch(RingfParams &rp, hipStream_t st) {
         ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
     rp.tiles_x = rp.LW / C::TW, rp.tiles_y = rp.LH / C::TH;   // whole tiles only (conv_ringf_try)
-    rp.ncob = (unsigned)((rp.cout + 63) / 64), rp.ncls = (unsigned)C::NCLS;
+    rp.ncob = (unsigned)((rp.cout + C::CO_UNIT - 1) / C::CO_UNIT), rp.ncls = (unsigned)C::NCLS;
     rp.nunits = (unsigned)(rp.tiles_x * rp.tiles_y) * (unsigned)rp.N * rp.ncob * rp.ncls;
     int cin = 0;
     for (int s = 0; s < rp.nsrc; ++s) cin += rp.src_c[s];
@@ -382,8 +403,11 @@ static int ringf_launch(RingfParams &rp, hipStream_t st) {
 }
 
 template <int MODE>
-static int ringf_launch_tile(int th, RingfParams &rp, hipStream_t st) {
+static int ringf_launch_tile(int th, int nt, RingfParams &rp, hipStream_t st) {
     constexpr int KS2 = MODE != RF_K3S1;
+    if constexpr (MODE == RF_K3S2) {
+        if (th == 8 && nt == 1) return ringf_launch<RfCfg<MODE, 8, 4, 1>>(rp, st);
+    }
     if (th == 16) return ringf_launch<RfCfg<MODE, 16, KS2 ? 3 : 2>>(rp, st);
     return ringf_launch<RfCfg<MODE, 8, KS2 ? 4 : 2>>(rp, st);
 }
@@ -397,6 +421,8 @@ int conv_ringf_try(int kind, const ConvKParams &kp, hipStream_t st, const ProfIn
     for (int s = 0; s < kp.nsrc; ++s)
         if (kp.src_ld[s] == 0 || kp.src_c[s] % 16 != 0 || kp.src_ld[s] % 4 != 0 || (reinterpret_cast<size_t>(kp.src_ptr[s]) & 15)) return 1;
     if (kp.LW % 32 != 0 || kp.LH % 8 != 0 || kp.cout % 4 != 0) return 1;
+    // (8-byte stores of channel pairs through one buffer descriptor per output sample)
+    if (kp.out_ld % 2 != 0 || (reinterpret_cast<size_t>(kp.out) & 7) || (size_t)kp.OH * kp.OW * kp.out_ld * 4 >= (1u << 31)) return 1;
     int mode, planes;
     if (kind == PWS_CONV_K3S1 || kind == PWS_CONVT_K3S1) mode = RF_K3S1, planes = 9;
     else if (kind == PWS_CONV_K3S2) mode = RF_K3S2, planes = 9;
@@ -417,21 +443,25 @@ int conv_ringf_try(int kind, const ConvKParams &kp, hipStream_t st, const ProfIn
     // peak at that clock) -- so this kernel is taken where its missing per-tile prologue / epilogue shows: the stride-2 kind and the
     // direct 3x3 kind on maps large enough for 16 x 32 tiles (256^2 stride-2: 123 -> 114 us, 3x3 128->128 @128^2: 100 -> 88 us);
     // the 8 x 32-tile variant and the transposed kind stay available to the tests (PWS_OPT_EXPERIMENT 23 / 24).
-    int th;
+    const long per256_32 = (long)kp.LW * kp.LH * kp.N / 256 * ((kp.cout + 31) / 32);   // ... with 32 output channels each
+    int th, nt = 2;
     const bool forced = g_experiment == 23 || g_experiment == 24;
     // (stride-2 kind: from one 16 x 32 unit per CU upwards -- 64 -> 64 @256^2 x 8 = 256 units: 113 vs 136 us of conv_mfma_kernel; with
     //  fewer units than CUs the persistent kernel loses: 128 -> 128 @128^2 x 8 = 128 units 188 vs 109 us)
-    if (kp.LH % 16 == 0 && (per256 / 2 >= (mode == RF_K3S2 ? 256 : 512) || g_experiment == 24)) th = 16;
+    if (g_experiment == 27 && mode == RF_K3S2) th = 8, nt = 1;   // (the 32-channel units forced for the tests' small launches)
+    else if (kp.LH % 16 == 0 && (per256 / 2 >= (mode == RF_K3S2 ? 256 : 512) || g_experiment == 24)) th = 16;
     // (stride-2 kind with one 8 x 32 unit per CU, measured after the loader's offsets moved into registers: 128 -> 128 @128^2 x 8
     //  91 vs 98 us, 64 -> 128 @128^2 52 vs 60 us of conv_mfma_kernel; half a chip of units loses: 256 -> 256 @64^2 158 vs 98 us)
     else if (forced || (mode == RF_K3S2 && per256 >= 256)) th = 8;
+    // (units of 32 output channels where 64-channel units fill only half the chip: 256 -> 256 @64^2 x 8 = 256 such units)
+    else if (mode == RF_K3S2 && per256_32 >= 256 && g_experiment != 26) th = 8, nt = 1;
     else return 1;
     if (mode == RF_CT4 && !forced) return 1;
     ProfScope prof(KID_CONV_RINGF, pi.flops, pi.bytes, st);
     switch (mode) {
-    case RF_K3S1: return ringf_launch_tile<RF_K3S1>(th, rp, st);
-    case RF_CT4: return ringf_launch_tile<RF_CT4>(th, rp, st);
-    default: return ringf_launch_tile<RF_K3S2>(th, rp, st);
+    case RF_K3S1: return ringf_launch_tile<RF_K3S1>(th, nt, rp, st);
+    case RF_CT4: return ringf_launch_tile<RF_CT4>(th, nt, rp, st);
+    default: return ringf_launch_tile<RF_K3S2>(th, nt, rp, st);
     }
 }
 

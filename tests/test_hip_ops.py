@@ -170,15 +170,17 @@ RINGF_CASES = [
 ]
 
 
-@pytest.mark.parametrize("force", [23, 24])
+@pytest.mark.parametrize("force", [23, 24, 27])
 @pytest.mark.parametrize("kname,shape,src_c,cout", RINGF_CASES)
 @pytest.mark.parametrize("act", [1, 2])
 def test_fp32_ring_kernel_vs_oracle(hip, oracle, kname, shape, src_c, cout, act, force):
     """conv_ringf_kernel (csrc/conv_ring_f32.hip: persistent LDS-ring, exact fp32 MFMA) forced for small launches with both tile
-    heights (PWS_OPT_EXPERIMENT 23 / 24), against the C oracle and against conv_mfma_kernel (22): 3x3 s1, transposed 3x3 s1,
+    heights (PWS_OPT_EXPERIMENT 23 / 24; 27: the stride-2 kind's units of 32 output channels), against the C oracle and against conv_mfma_kernel (22): 3x3 s1, transposed 3x3 s1,
     3x3 s2 as parity planes, transposed 4x4 s2 as parity classes, virtual concats, cout ending inside a 64-channel block."""
     A = hip
     L = A.lib()
+    if force == 27 and kname != "CONV_K3S2":
+        pytest.skip("32-channel units exist for the stride-2 kind only")
     kind = getattr(A, kname)
     n, h, w = shape
     rs = np.random.RandomState(zlib.crc32(repr((kname, shape, cout, "rf")).encode()))
