@@ -176,9 +176,6 @@ __global__ void __launch_bounds__(256) field_head16_mfma_kernel(const __bf16 *__
     __shared__ float ys[NPIX * YP];
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-    const unsigned tile = xcd_remap(blockIdx.x, ntiles);
-    const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-    const int x0 = tx_i * FH_T, y0 = ty_i * FH_T;
     // B operand: column l31 = (tap, o), this lane's 8 channels of each of the four 16-channel k-steps, split hi + lo
     bf16x8 bh[4], bl[4], bl2[4];
     {
@@ -196,67 +193,89 @@ __global__ void __launch_bounds__(256) field_head16_mfma_kernel(const __bf16 *__
     }
     constexpr int MT = (NPIX + 31) / 32;   // 11 tiles of 32 halo pixels: wave w takes the tiles w, w + 4, w + 8
     constexpr int MTW = (MT + 3) / 4;
-    // all loads of the wave first (12 x 16 bytes per lane in flight), then the matrix instructions
+    // Persistent: a workgroup walks the tiles t = blockIdx.x, + gridDim.x, ... (the grid is a multiple of the XCD count, so all of
+    // them map to its XCD's contiguous chunk), keeps the 96 weight terms of its lanes in registers for all of them and has the next
+    // tile's 12 x 16 bytes per lane in flight during the stencil and the stores of the current one.
     bf16x8 a[MTW][4];
+    auto load_tile = [&](unsigned t) {
+        const unsigned tile = xcd_remap(t, ntiles);
+        const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int x0 = tx_i * FH_T, y0 = ty_i * FH_T;
 #pragma unroll
-    for (int i = 0; i < MTW; ++i) {
-        const int q = (wv + 4 * i) * 32 + l31;
-        const int iy = y0 - 1 + q / FH_I, ix = x0 - 1 + q % FH_I;
-        const bool ok = q < NPIX && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        const __bf16 *px = x + (ok ? ((size_t)(n * H + iy) * W + ix) * ld + hi * 8 : 0);
+        for (int i = 0; i < MTW; ++i) {
+            const int q = (wv + 4 * i) * 32 + l31;
+            const int iy = y0 - 1 + q / FH_I, ix = x0 - 1 + q % FH_I;
+            const bool ok = q < NPIX && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const __bf16 *px = x + (ok ? ((size_t)(n * H + iy) * W + ix) * ld + hi * 8 : 0);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(px + ks * 16);   // unconditional load, masked below
-            a[i][ks] = __builtin_bit_cast(bf16x8, ok ? v : (u32x4){0u, 0u, 0u, 0u});
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < MTW; ++i) {
-        const int mt = wv + 4 * i;
-        if (mt >= MT) break;
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], bh[ks], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], bl[ks], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], bl2[ks], acc, 0, 0, 0);
-        }
-        if (l31 < 18) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qq = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (qq < NPIX) ys[qq * YP + l31] = acc[r];
+            for (int ks = 0; ks < 4; ++ks) {
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(px + ks * 16);   // unconditional load, masked below
+                a[i][ks] = __builtin_bit_cast(bf16x8, ok ? v : (u32x4){0u, 0u, 0u, 0u});
             }
         }
-    }
-    __syncthreads();
-    const int tx = tid & 15, ty = tid >> 4;
-    float acc0 = b_out ? b_out[0] : 0.f, acc1 = b_out ? b_out[1] : 0.f;
+    };
+    unsigned t = blockIdx.x;
+    if (t >= ntiles) return;
+    load_tile(t);
+    const float bias0 = b_out ? b_out[0] : 0.f, bias1 = b_out ? b_out[1] : 0.f;
+    for (;;) {
+        const unsigned tile = xcd_remap(t, ntiles);
+        const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int x0 = tx_i * FH_T, y0 = ty_i * FH_T;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const float2 v = *reinterpret_cast<const float2 *>(ys + ((ty + tap / 3) * FH_I + tx + tap % 3) * YP + tap * 2);
-        acc0 += v.x, acc1 += v.y;
-    }
-    const int y = y0 + ty, xq = x0 + tx;
-    if (y < H && xq < W && raw) {
-        *reinterpret_cast<float2 *>(resid + (((size_t)n * H + y) * W + xq) * 2) = make_float2(acc0, acc1);
-    } else if (y < H && xq < W) {
-        const float r0 = tanhf(tanhf(acc0)), r1 = tanhf(tanhf(acc1));
-        const size_t p = ((size_t)n * H + y) * W + xq;
-        if (resid) *reinterpret_cast<float2 *>(resid + p * 2) = make_float2(r0, r1);
-        if (grid) {
-            float a0 = 0.f, a1 = 0.f;
-            if (theta) {
-                const float *t = theta + (size_t)n * 6;
-                const float bx = ac ? (W > 1 ? (2.f * xq) / (float)(W - 1) - 1.f : 0.f) : (2.f * xq + 1.f) / (float)W - 1.f;
-                const float by = ac ? (H > 1 ? (2.f * y) / (float)(H - 1) - 1.f : 0.f) : (2.f * y + 1.f) / (float)H - 1.f;
-                a0 = t[0] * bx + t[1] * by + t[2];
-                a1 = t[3] * bx + t[4] * by + t[5];
+        for (int i = 0; i < MTW; ++i) {
+            const int mt = wv + 4 * i;
+            if (mt >= MT) break;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], bh[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], bl[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], bl2[ks], acc, 0, 0, 0);
             }
-            *reinterpret_cast<float2 *>(grid + p * 2) = make_float2(r0 + a0, r1 + a1);
+            if (l31 < 18) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qq = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (qq < NPIX) ys[qq * YP + l31] = acc[r];
+                }
+            }
         }
+        const unsigned tn = t + gridDim.x;
+        const bool more = tn < ntiles;
+        if (more) load_tile(tn);
+        __syncthreads();
+        const int tx = tid & 15, ty = tid >> 4;
+        float acc0 = bias0, acc1 = bias1;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float2 v = *reinterpret_cast<const float2 *>(ys + ((ty + tap / 3) * FH_I + tx + tap % 3) * YP + tap * 2);
+            acc0 += v.x, acc1 += v.y;
+        }
+        const int y = y0 + ty, xq = x0 + tx;
+        if (y < H && xq < W && raw) {
+            *reinterpret_cast<float2 *>(resid + (((size_t)n * H + y) * W + xq) * 2) = make_float2(acc0, acc1);
+        } else if (y < H && xq < W) {
+            const float r0 = tanhf(tanhf(acc0)), r1 = tanhf(tanhf(acc1));
+            const size_t p = ((size_t)n * H + y) * W + xq;
+            if (resid) *reinterpret_cast<float2 *>(resid + p * 2) = make_float2(r0, r1);
+            if (grid) {
+                float a0 = 0.f, a1 = 0.f;
+                if (theta) {
+                    const float *th = theta + (size_t)n * 6;
+                    const float bx = ac ? (W > 1 ? (2.f * xq) / (float)(W - 1) - 1.f : 0.f) : (2.f * xq + 1.f) / (float)W - 1.f;
+                    const float by = ac ? (H > 1 ? (2.f * y) / (float)(H - 1) - 1.f : 0.f) : (2.f * y + 1.f) / (float)H - 1.f;
+                    a0 = th[0] * bx + th[1] * by + th[2];
+                    a1 = th[3] * bx + th[4] * by + th[5];
+                }
+                *reinterpret_cast<float2 *>(grid + p * 2) = make_float2(r0 + a0, r1 + a1);
+            }
+        }
+        if (!more) break;
+        __syncthreads();   // everybody is done with this tile's Y before the next tile's products are written
+        t = tn;
     }
 }
 
@@ -271,9 +290,6 @@ __global__ void __launch_bounds__(256) field_head32_mfma_kernel(const float *__r
     __shared__ float ys[NPIX * YP];
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-    const unsigned tile = xcd_remap(blockIdx.x, ntiles);
-    const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-    const int x0 = tx_i * FH_T, y0 = ty_i * FH_T;
     float bw[32];
     {
         const int tap = l31 >> 1, o = l31 & 1;
@@ -281,62 +297,83 @@ __global__ void __launch_bounds__(256) field_head32_mfma_kernel(const float *__r
         for (int j = 0; j < 32; ++j) bw[j] = l31 < 18 ? w_out[((size_t)tap * C + hi * 32 + j) * 2 + o] : 0.f;
     }
     constexpr int MT = (NPIX + 31) / 32, MTW = (MT + 3) / 4;
+    // persistent, as field_head16_mfma_kernel: weights loaded once per workgroup, the next tile's loads under the stencil and the stores
     f32x4 a[MTW][8];
+    auto load_tile = [&](unsigned t) {
+        const unsigned tile = xcd_remap(t, ntiles);
+        const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int x0 = tx_i * FH_T, y0 = ty_i * FH_T;
 #pragma unroll
-    for (int i = 0; i < MTW; ++i) {
-        const int q = (wv + 4 * i) * 32 + l31;
-        const int iy = y0 - 1 + q / FH_I, ix = x0 - 1 + q % FH_I;
-        const bool ok = q < NPIX && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        const float *px = x + (ok ? ((size_t)(n * H + iy) * W + ix) * ld + hi * 32 : 0);
+        for (int i = 0; i < MTW; ++i) {
+            const int q = (wv + 4 * i) * 32 + l31;
+            const int iy = y0 - 1 + q / FH_I, ix = x0 - 1 + q % FH_I;
+            const bool ok = q < NPIX && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const float *px = x + (ok ? ((size_t)(n * H + iy) * W + ix) * ld + hi * 32 : 0);
 #pragma unroll
-        for (int k4 = 0; k4 < 8; ++k4) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(px + k4 * 4);   // unconditional load, masked below
-            a[i][k4] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < MTW; ++i) {
-        const int mt = wv + 4 * i;
-        if (mt >= MT) break;
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 32; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j >> 2][j & 3], bw[j], acc, 0, 0, 0);
-        if (l31 < 18) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qq = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (qq < NPIX) ys[qq * YP + l31] = acc[r];
+            for (int k4 = 0; k4 < 8; ++k4) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(px + k4 * 4);   // unconditional load, masked below
+                a[i][k4] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-    }
-    __syncthreads();
-    const int tx = tid & 15, ty = tid >> 4;
-    float acc0 = b_out ? b_out[0] : 0.f, acc1 = b_out ? b_out[1] : 0.f;
+    };
+    unsigned t = blockIdx.x;
+    if (t >= ntiles) return;
+    load_tile(t);
+    const float bias0 = b_out ? b_out[0] : 0.f, bias1 = b_out ? b_out[1] : 0.f;
+    for (;;) {
+        const unsigned tile = xcd_remap(t, ntiles);
+        const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int x0 = tx_i * FH_T, y0 = ty_i * FH_T;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const float2 v = *reinterpret_cast<const float2 *>(ys + ((ty + tap / 3) * FH_I + tx + tap % 3) * YP + tap * 2);
-        acc0 += v.x, acc1 += v.y;
-    }
-    const int y = y0 + ty, xq = x0 + tx;
-    if (y < H && xq < W && raw) {
-        *reinterpret_cast<float2 *>(resid + (((size_t)n * H + y) * W + xq) * 2) = make_float2(acc0, acc1);
-    } else if (y < H && xq < W) {
-        const float r0 = tanhf(tanhf(acc0)), r1 = tanhf(tanhf(acc1));
-        const size_t p = ((size_t)n * H + y) * W + xq;
-        if (resid) *reinterpret_cast<float2 *>(resid + p * 2) = make_float2(r0, r1);
-        if (grid) {
-            float a0 = 0.f, a1 = 0.f;
-            if (theta) {
-                const float *t = theta + (size_t)n * 6;
-                const float bx = ac ? (W > 1 ? (2.f * xq) / (float)(W - 1) - 1.f : 0.f) : (2.f * xq + 1.f) / (float)W - 1.f;
-                const float by = ac ? (H > 1 ? (2.f * y) / (float)(H - 1) - 1.f : 0.f) : (2.f * y + 1.f) / (float)H - 1.f;
-                a0 = t[0] * bx + t[1] * by + t[2];
-                a1 = t[3] * bx + t[4] * by + t[5];
+        for (int i = 0; i < MTW; ++i) {
+            const int mt = wv + 4 * i;
+            if (mt >= MT) break;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j >> 2][j & 3], bw[j], acc, 0, 0, 0);
+            if (l31 < 18) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qq = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (qq < NPIX) ys[qq * YP + l31] = acc[r];
+                }
             }
-            *reinterpret_cast<float2 *>(grid + p * 2) = make_float2(r0 + a0, r1 + a1);
         }
+        const unsigned tn = t + gridDim.x;
+        const bool more = tn < ntiles;
+        if (more) load_tile(tn);
+        __syncthreads();
+        const int tx = tid & 15, ty = tid >> 4;
+        float acc0 = bias0, acc1 = bias1;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float2 v = *reinterpret_cast<const float2 *>(ys + ((ty + tap / 3) * FH_I + tx + tap % 3) * YP + tap * 2);
+            acc0 += v.x, acc1 += v.y;
+        }
+        const int y = y0 + ty, xq = x0 + tx;
+        if (y < H && xq < W && raw) {
+            *reinterpret_cast<float2 *>(resid + (((size_t)n * H + y) * W + xq) * 2) = make_float2(acc0, acc1);
+        } else if (y < H && xq < W) {
+            const float r0 = tanhf(tanhf(acc0)), r1 = tanhf(tanhf(acc1));
+            const size_t p = ((size_t)n * H + y) * W + xq;
+            if (resid) *reinterpret_cast<float2 *>(resid + p * 2) = make_float2(r0, r1);
+            if (grid) {
+                float a0 = 0.f, a1 = 0.f;
+                if (theta) {
+                    const float *th = theta + (size_t)n * 6;
+                    const float bx = ac ? (W > 1 ? (2.f * xq) / (float)(W - 1) - 1.f : 0.f) : (2.f * xq + 1.f) / (float)W - 1.f;
+                    const float by = ac ? (H > 1 ? (2.f * y) / (float)(H - 1) - 1.f : 0.f) : (2.f * y + 1.f) / (float)H - 1.f;
+                    a0 = th[0] * bx + th[1] * by + th[2];
+                    a1 = th[3] * bx + th[4] * by + th[5];
+                }
+                *reinterpret_cast<float2 *>(grid + p * 2) = make_float2(r0 + a0, r1 + a1);
+            }
+        }
+        if (!more) break;
+        __syncthreads();
+        t = tn;
     }
 }
 
@@ -469,14 +506,28 @@ extern "C" int pws_field_head_fwd_s(const float *x, int ld, int n, int h, int w,
     const unsigned ntiles = (unsigned)tiles_x * tiles_y * n;
     ProfScope prof(KID_FIELD_HEAD, 2.0 * n * h * w * 18.0 * c,
                    (double)n * h * w * (4.0 * c + (resid ? 8.0 : 0.0) + (grid ? 8.0 : 0.0)), as_stream(stream));
+    // the matrix-core kernels are persistent: 3 workgroups per CU (registers), a multiple of the XCD count (see the kernels);
+    // PWS_OPT_EXPERIMENT 92: one tile per workgroup
+    static PerDeviceInt ncu_dev;
+    int &ncu = ncu_dev.cur();
+    if (ncu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    unsigned pgrid = ntiles;
+    if (g_experiment != 92 && ntiles > (unsigned)(ncu * 3)) {   // equal shares: k tiles per workgroup, as few workgroups as that takes
+        const unsigned k = (ntiles + (unsigned)(ncu * 3) - 1) / (unsigned)(ncu * 3);
+        pgrid = ((ntiles + k - 1) / k + kXcds - 1) / kXcds * kXcds;
+    }
     if (store == PWS_STORE_BF16 && c == 64 && ld % 8 == 0 && g_experiment != 90)   // the matrix-core kernel (see its comment)
-        hipLaunchKernelGGL(field_head16_mfma_kernel, dim3(ntiles), dim3(256), 0, as_stream(stream), reinterpret_cast<const __bf16 *>(x), ld, n, h, w,
+        hipLaunchKernelGGL(field_head16_mfma_kernel, dim3(pgrid), dim3(256), 0, as_stream(stream), reinterpret_cast<const __bf16 *>(x), ld, n, h, w,
                            w_out, b_out, theta, align_corners, resid, grid, tiles_x, tiles_y, ntiles, 0);
     else if (store == PWS_STORE_BF16)
         hipLaunchKernelGGL(field_head_kernel<true>, dim3(ntiles), dim3(256), 0, as_stream(stream), x, ld, n, h, w, c, w_out, b_out,
                            theta, align_corners, resid, grid, tiles_x, tiles_y, ntiles, 0);
     else if (c == 64 && g_experiment != 90)
-        hipLaunchKernelGGL(field_head32_mfma_kernel, dim3(ntiles), dim3(256), 0, as_stream(stream), x, ld, n, h, w, w_out, b_out, theta, align_corners,
+        hipLaunchKernelGGL(field_head32_mfma_kernel, dim3(pgrid), dim3(256), 0, as_stream(stream), x, ld, n, h, w, w_out, b_out, theta, align_corners,
                            resid, grid, tiles_x, tiles_y, ntiles, 0);
     else
         hipLaunchKernelGGL(field_head_kernel<false>, dim3(ntiles), dim3(256), 0, as_stream(stream), x, ld, n, h, w, c, w_out, b_out,
