@@ -87,6 +87,8 @@ _PMC_NAMES = {
     "conv_bf16_kernel": ["conv_bf16_kernel", "conv_bf16_k5_kernel"],
     "conv_mfma_kernel<k5s1,16x16>": ["k5s1,tile"],
     "conv_first_kernel": ["conv_first_kernel"],
+    "grid_sample_fwd_kernel@roofline": ["grid_sample_fwd2_kernel<4, true"],   # the 256-frame launch (non-temporal variant: > 256 MB)
+    "upsample_grid_sample_fwd_kernel": ["upsample_grid_sample_fwd_kernel"],
     "grid_sample_fwd_kernel": ["grid_sample_fwd2_kernel"],
 }
 
@@ -552,7 +554,7 @@ def main():
         gbs, ms, by = res_gs["smooth"]
         line["roofline_grid_sample"] = {"kernel": "grid_sample_fwd_kernel", "bound": "hbm", "achieved": round(gbs, 1),
                                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                        "traffic": None, "avg_launch_us": round(1e3 * ms, 2),
+                                        "traffic": pmc_traffic("grid_sample_fwd_kernel@roofline"), "avg_launch_us": round(1e3 * ms, 2),
                                         "bytes_per_launch": by, "frames_per_launch": GB,
                                         "field": "random 5% affine + smooth +-2 px residual",
                                         "achieved_white_noise_field": round(res_gs["noisy"][0], 1),
@@ -653,7 +655,7 @@ def main():
                               "roofline_warp": {"kernel": "upsample_grid_sample_fwd_kernel", "bound": "hbm",
                                                 "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                                 "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_us": round(1e3 * ms, 2),
-                                                "bytes_per_launch": r[0][3]}}
+                                                "bytes_per_launch": r[0][3], "traffic": pmc_traffic("upsample_grid_sample_fwd_kernel")}}
         # the same kernel on the field a stabiliser emits (2 % affine + smooth residual) instead of the random-weight
         # generator's (whose residual jumps by up to ~100 px between neighbouring 256x256 cells), inputs rotated so that
         # they come from HBM, not from the Infinity Cache

@@ -411,6 +411,43 @@ def test_field_head_forward_bf16_storage_matrix_core_kernel(hip, shape):
     assert not np.array_equal(got[0][0], got[90][0]) or n * h * w < 512   # two different kernels ran
 
 
+@pytest.mark.parametrize("store", ["bf16", "fp32"])
+def test_field_head_persistent_walk_equals_one_tile_per_workgroup(hip, oracle, store):
+    """The matrix-core field-head kernels are persistent from 3 workgroups per CU upwards (weights in registers, the next tile loaded
+    under the stencil): 6 x 200 x 250 pixels = 1248 tiles make every workgroup walk two tiles, ragged at the right / bottom border.
+    Bit-identical to one tile per workgroup (PWS_OPT_EXPERIMENT 92) and within the kernels' tolerance of the C oracle."""
+    A = hip
+    L, st = A.lib(), A.current_stream()
+    n, h, w, c = 6, 200, 250, 64
+    rs = np.random.RandomState(92)
+    x = rs.standard_normal((n, c, h, w)).astype(np.float32)
+    if store == "bf16":
+        x = bf16r(torch.from_numpy(x)).numpy()
+    wo = (rs.standard_normal((2, c, 3, 3)) / 12).astype(np.float32)
+    bo = rs.standard_normal(2).astype(np.float32)
+    theta = (np.array([1, 0, 0, 0, 1, 0], np.float32) + 0.1 * rs.standard_normal((n, 6))).astype(np.float32)
+    ref_res = nhwc(torch.from_numpy(np.tanh(oracle.conv2d(x, wo, bo, 1, 1, oracle.ACT_TANH)))).numpy()
+    ref_grid = ref_res + oracle.affine_grid(theta, h, w)
+    po = torch.empty(L.pws_packed_weight_floats(A.CONV_K3S1_OUT, c, 2), device="cuda")
+    d_wo, d_bo, d_th = torch.from_numpy(wo).cuda(), torch.from_numpy(bo).cuda(), torch.from_numpy(theta).cuda()
+    A.check(L.pws_pack_conv_weight(A.ptr(d_wo), A.ptr(po), A.CONV_K3S1_OUT, c, 2, st), "pack")
+    d_x = nhwc(torch.from_numpy(x)).cuda().to(torch.bfloat16 if store == "bf16" else torch.float32)
+    got = {}
+    try:
+        for exp in (0, 92):
+            L.pws_set_option(A.OPT_EXPERIMENT, exp)
+            res = torch.full((n, h, w, 2), float("nan"), device="cuda")
+            grid = torch.full((n, h, w, 2), float("nan"), device="cuda")
+            A.check(L.pws_field_head_fwd_s(A.ptr(d_x), c, n, h, w, c, A.ptr(po), A.ptr(d_bo), A.ptr(d_th), 0, A.ptr(res), A.ptr(grid),
+                                           A.STORE_BF16 if store == "bf16" else A.STORE_FP32, st), "field")
+            got[exp] = (res.cpu().numpy(), grid.cpu().numpy())
+    finally:
+        L.pws_set_option(A.OPT_EXPERIMENT, 0)
+    assert np.array_equal(got[0][0], got[92][0]) and np.array_equal(got[0][1], got[92][1])
+    np.testing.assert_allclose(got[0][0], ref_res, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(got[0][1], ref_grid, rtol=0, atol=5e-5)
+
+
 @pytest.mark.parametrize("store,ld", [("bf16", 96), ("bf16", 72), ("fp32", 80), ("fp32", 68)])
 def test_field_head_c64_with_padded_rows_through_the_c_abi(hip, oracle, store, ld):
     """pws_field_head_fwd_s called directly with c == 64, ld > c and a map that is no multiple of the 16-pixel tile,
