@@ -69,7 +69,8 @@ struct RingParams {
 #ifdef PWS_RING_TIMERS
     unsigned long long *timers;   // [workgroup][matrix wave][8]
 #endif
-    int ablate;           // measurement only (PWS_OPT_EXPERIMENT 41..43): 1 = the DMA pieces fetch nothing after the first groups,
+    int ablate;           // measurement only (PWS_OPT_EXPERIMENT 41..48): 1 = the DMA pieces fetch nothing after the first groups,
+                          // 8 = weight pieces only for a workgroup's first unit (what resident weights would save: 5.5 % at 64 -> 64 @256^2),
                           // 2 = no matrix phase, 4 = no epilogue -- results are meaningless, only the timing is read
 };
 
@@ -330,6 +331,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
                 const bool in_ct = (it + 1) * C::LWAVES <= C::IN_WI, w_ct = it * C::LWAVES >= C::IN_WI;
                 const unsigned dst = d_base + (unsigned)(it * C::LWAVES * 1024);
                 if (C::SKIP_FILL && it * C::LWAVES + lw >= C::IN_WI + C::W_WI) continue;   // filler (wave-uniform)
+                if (C::SKIP_FILL && (p.ablate & 8) && w_ct && pu != u_begin) continue;       // TIMING ONLY: what resident weights would save
                 if (in_ct) ring_dma16(dst, cv[it], d_rin, d_sin);
                 else if (w_ct) ring_dma16(dst, cv[it], rsrc_w, d_sw);
                 else ring_dma16(dst, cv[it], d_rmix, d_smix);
@@ -716,7 +718,7 @@ int conv_ring_try(int kind, bool dgrad, const ConvKParams &kp, hipStream_t st, c
         rp.timers = e ? reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 0)) : nullptr;
     }
 #endif
-    rp.ablate = g_experiment >= 41 && g_experiment <= 47 ? g_experiment - 40 : 0;
+    rp.ablate = g_experiment >= 41 && g_experiment <= 48 ? g_experiment - 40 : 0;   // (48 = mask 8: weight pieces only for a workgroup's first unit)
     if (tw == 8 && mode == RM_K3S1) return 1;
     if (kp.cout > (tw == 16 && mode == RM_K3S1 ? 512 : 1024)) return 1;   // the bias vector's LDS slot (RgCfg::BIAS_FLOATS)
     const long units = (long)kp.LW * kp.LH * kp.N / 512 * ((kp.cout + 63) / 64) * ((mode == RM_CT4 || mode == RM_SP3) ? 4 : 1);
