@@ -424,7 +424,8 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
     auto info = [&](int k2, double out_pix) {
         ProfInfo pi;
         pi.flops = 2.0 * out_pix * a->cout * (double)cin * k2;
-        pi.bytes = 4.0 * ((double)a->n * a->h * a->w * cin + out_pix * a->cout + (double)k2 * cin * a->cout);
+        const double es = a->store == PWS_STORE_BF16 ? 2.0 : 4.0, ws_ = bf16 ? 2.0 : 4.0;   // activation / weight element size
+        pi.bytes = es * ((double)a->n * a->h * a->w * cin + out_pix * a->cout) + ws_ * (double)k2 * cin * a->cout;
         return pi;
     };
     switch (a->kind) {
@@ -485,7 +486,7 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
     case PWS_CONVT_K4S2: {
         kp.LH = a->h, kp.LW = a->w, kp.OH = 2 * a->h, kp.OW = 2 * a->w, kp.nclasses = 4;
         ProfInfo pi = info(4, (double)a->n * kp.OH * kp.OW);  // every output pixel sees 2x2 taps
-        pi.bytes += 4.0 * 12.0 * cin * a->cout;              // all 16 taps of the weight are read
+        pi.bytes += (bf16 ? 2.0 : 4.0) * 12.0 * cin * a->cout;   // all 16 taps of the weight are read
         if (bf16) {
             const int rc = conv_bf16_fwd(a->kind, kp, kp.cin_pad, a->out, ws, ws_floats, st, pi);
             if (rc != 1) return rc;
@@ -555,7 +556,14 @@ int conv2d_bwd_data_impl(const pws_conv_bwd_data_args *a, hipStream_t st) {
     ProfInfo pi;
     const double k2 = a->kind == PWS_CONVT_K4S2 ? 4.0 : 9.0;  // taps per forward OUTPUT pixel
     pi.flops = 2.0 * a->n * oh * ow * (double)a->cout * cin_f * k2;
-    pi.bytes = 4.0 * ((double)a->n * oh * ow * a->cout + (double)a->n * a->h * a->w * cin_f);
+    // algorithmic bytes: dy read once, every destination written once -- plus what the fused epilogue reads: the old gradient of
+    // an accumulating destination and the forward tensor whose act' multiplies the sum (bf16 storage: 2 bytes per element)
+    {
+        const double es = a->store == PWS_STORE_BF16 ? 2.0 : 4.0, in_pix = (double)a->n * a->h * a->w;
+        pi.bytes = es * ((double)a->n * oh * ow * a->cout + in_pix * cin_f);
+        for (int s = 0; s < a->ndst; ++s)
+            pi.bytes += es * in_pix * a->dst[s].channels * ((a->dst[s].accumulate ? 1.0 : 0.0) + (kp.dst_act[s] != PWS_ACT_NONE ? 1.0 : 0.0));
+    }
     if (a->kind == PWS_CONV_K3S2)
         kp.LH = oh, kp.LW = ow, kp.nclasses = 4;
     else

@@ -69,8 +69,8 @@ def main():
         print("  %-40s %-26s %8.1f us %7.1f TF/s" % (name, names[tag] if 0 <= tag < len(names) else "-", ms * 1e3, fl / (ms * 1e-3) / 1e12))
     if a.list:   # every launch, slowest first, with its algorithmic bytes
         for name, tag, fl, by, ms in sorted(recs, key=lambda r: -r[4])[:a.list]:
-            print("  . %-38s %-26s %8.1f us %7.1f TF/s %7.1f GB/s" % (name, names[tag] if 0 <= tag < len(names) else "-", ms * 1e3,
-                                                                fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9))
+            print("  . %-38s %-26s %8.1f us %7.1f TF/s %8.1f MB algorithmic %7.1f GB/s" % (name, names[tag] if 0 <= tag < len(names) else "-", ms * 1e3,
+                                                                                    fl / (ms * 1e-3) / 1e12, by / 1e6, by / (ms * 1e-3) / 1e9))
 
 
 if __name__ == "__main__":
