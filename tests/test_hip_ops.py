@@ -369,6 +369,9 @@ FIRST_CASES = [   # (n, h, w), cin, cout, planes per sample in memory (None = de
     ((2, 128, 256), 31, 64, 34, False),      # the driver's 34-plane item read in place
     ((2, 16, 32), 31, 64, None, True), ((1, 8, 64), 17, 64, None, True), ((3, 24, 32), 32, 20, None, True),
     ((1, 40, 96), 31, 128, 36, True), ((5, 8, 32), 20, 4, None, True),
+    ((1, 8, 32), 31, 64, None, True),        # ONE unit: every image border inside the same halo
+    ((5, 264, 32), 31, 64, None, False),     # one tile column: left and right border in every unit; 165 units on 256 CUs
+    ((9, 64, 96), 32, 64, None, False),      # 216 units: workgroups with and without a next unit to prefetch
 ]
 
 
