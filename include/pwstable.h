@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define PWS_VERSION 2   /* 2: pws_netg_opts carries flags + x_sample_stride (round 3) */
+#define PWS_VERSION 3   /* 2: pws_netg_opts carries flags + x_sample_stride (round 3) */
 
 #define PWS_OK 0
 #define PWS_EINVAL (-22) /* bad argument / unsupported shape */
@@ -173,6 +173,10 @@ typedef struct pws_conv_args {
                          the bf16 kernels cover.  Halves the activation traffic of the bf16 path. */
     const float *w_wring; /* optional: ring-layout Winograd weights from pws_pack_conv_weight_wring (K3S1 / CONVT_K3S1 / CONVT_K4S2,
                          fp32 NHWC sources): tried before w_wino and the direct kernels */
+    void *out_sign;   /* optional, store == PWS_STORE_BF16 and cout % 8 == 0 only: the SIGN BITS of `out`, written beside it -- bit (c & 7)
+                         of byte out_sign[pixel * out_sign_ld + c / 8] = (out[pixel][c] > 0), for the rounded bf16 value.  What the
+                         backward of a LeakyReLU / ReLU block needs of its forward tensor (pws_dst.act_sign): 1/16 of its bytes. */
+    int out_sign_ld;  /* bytes per pixel of out_sign (>= cout / 8) */
 } pws_conv_args;
 
 int pws_conv2d_fwd(const pws_conv_args *args, pws_stream_t stream);
@@ -212,6 +216,11 @@ typedef struct pws_dst {
     const void *act_y;
     int act_y_ld;
     int act;
+    /* Optional beside act_y: its sign bits as written by pws_conv2d_fwd (pws_conv_args.out_sign, same layout, act_sign_ld bytes per
+     * pixel).  A kernel that knows them reads one byte instead of 16 per 8 channels (the persistent ring kernel does when every
+     * destination with an act has them); the others read act_y, which must be given as well.  Same result bit for bit. */
+    const void *act_sign;
+    int act_sign_ld;
 } pws_dst;
 
 typedef struct pws_conv_bwd_data_args {

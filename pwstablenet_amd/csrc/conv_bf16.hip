@@ -711,15 +711,10 @@ int conv_ring_try(int kind, bool dgrad, const ConvKParams &kp, hipStream_t st, c
 int conv_skinny16_try(int kind, bool dgrad, ConvKParams &kp, int kchan, float *final_out, float *ws, size_t ws_floats, hipStream_t st,
                       const ProfInfo &pi);   // conv_skinny16.hip (the deep levels, bf16 storage); 1 = not covered
 
-int conv_bf16_fwd(int kind, ConvKParams &kp, int cin_total, float *out, float *ws, size_t ws_floats, hipStream_t st,
-                  const ProfInfo &pi) {
-    for (int s = 0; s < kp.nsrc; ++s)
-        if (kp.src_c[s] % 32 != 0) return 1;
-    if (kind != PWS_CONV_K5S1) {   // the persistent LDS-ring kernel takes the launches it covers (bf16 storage, maps >= 16 x 32)
-        kp.out = out;
-        int rc = conv_ring_try(kind, false, kp, st, pi);
-        if (rc != 1) return rc;
-        rc = conv_skinny16_try(kind, false, kp, cin_total, out, ws, ws_floats, st, pi);
+static int conv_bf16_fwd_rest(int kind, ConvKParams &kp, int cin_total, float *out, float *ws, size_t ws_floats, hipStream_t st,
+                              const ProfInfo &pi) {
+    if (kind != PWS_CONV_K5S1) {
+        const int rc = conv_skinny16_try(kind, false, kp, cin_total, out, ws, ws_floats, st, pi);
         if (rc != 1) return rc;
     }
     switch (kind) {
@@ -737,6 +732,37 @@ int conv_bf16_fwd(int kind, ConvKParams &kp, int cin_total, float *out, float *w
         return launch_k5(kp, st, pi);
     default: return 1;
     }
+}
+
+// Sign bits of a bf16 NHWC tensor (ConvKParams.out_sign) for the forward kernels that do not write them themselves: one lane per
+// (pixel, 8 channels): a 16-byte load, a byte store.
+__global__ void __launch_bounds__(256) sign_bits_kernel(const __bf16 *__restrict__ y, int ld, size_t pixels, int groups, unsigned char *__restrict__ sign,
+                                                        int sign_ld) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= pixels * (size_t)groups) return;
+    const size_t pix = i / (size_t)groups;
+    const int g = (int)(i - pix * (size_t)groups);
+    const u32x4 v = *reinterpret_cast<const u32x4 *>(y + pix * (size_t)ld + g * 8);
+    const unsigned m = (bf16_lo(v.x) > 0.f ? 1u : 0u) | (bf16_hi(v.x) > 0.f ? 2u : 0u) | (bf16_lo(v.y) > 0.f ? 4u : 0u) | (bf16_hi(v.y) > 0.f ? 8u : 0u) |
+                       (bf16_lo(v.z) > 0.f ? 16u : 0u) | (bf16_hi(v.z) > 0.f ? 32u : 0u) | (bf16_lo(v.w) > 0.f ? 64u : 0u) | (bf16_hi(v.w) > 0.f ? 128u : 0u);
+    sign[pix * (size_t)sign_ld + g] = (unsigned char)m;
+}
+
+int conv_bf16_fwd(int kind, ConvKParams &kp, int cin_total, float *out, float *ws, size_t ws_floats, hipStream_t st,
+                  const ProfInfo &pi) {
+    for (int s = 0; s < kp.nsrc; ++s)
+        if (kp.src_c[s] % 32 != 0) return 1;
+    if (kind != PWS_CONV_K5S1) {   // the persistent LDS-ring kernel takes the launches it covers (bf16 storage, maps >= 16 x 32)
+        kp.out = out;
+        const int rc = conv_ring_try(kind, false, kp, st, pi);   // (writes kp.out_sign itself)
+        if (rc != 1) return rc;
+    }
+    const int rc = conv_bf16_fwd_rest(kind, kp, cin_total, out, ws, ws_floats, st, pi);
+    if (rc != PWS_OK || !kp.out_sign || !kp.io_bf16) return rc;
+    const size_t pixels = (size_t)kp.N * kp.OH * kp.OW, items = pixels * (size_t)(kp.cout / 8);
+    hipLaunchKernelGGL(sign_bits_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const __bf16 *>(out), kp.out_ld, pixels,
+                       kp.cout / 8, static_cast<unsigned char *>(kp.out_sign), kp.out_sign_ld);
+    return check_launch("sign_bits_kernel");
 }
 
 // Data-gradient kinds (kp prepared by conv2d_bwd_data_impl).

@@ -45,6 +45,13 @@ struct ConvKParams {
     // bf16 storage only: the sum is multiplied by act'(dst_y) (the forward tensor this destination is the gradient of)
     const void *dst_y[4];
     int dst_y_ld[4], dst_act[4];
+    // bf16 storage only: sign bits of the forward tensors (pws_conv_args.out_sign / pws_dst.act_sign): bit (c & 7) of byte
+    // [pixel * ld + c / 8] = (tensor[pixel][c] > 0).  out_sign: written by the forward launch beside `out`; dst_sign[s]: read by the
+    // data-gradient epilogue INSTEAD of dst_y[s] (1/16 of its bytes) by the kernels that know it (conv_ring.hip)
+    void *out_sign;
+    int out_sign_ld;
+    const void *dst_sign[4];
+    int dst_sign_ld[4];
 };
 
 // final store of one output element (pixel index `pix` in the output tensor, channel `co`)

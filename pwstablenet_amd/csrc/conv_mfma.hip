@@ -419,6 +419,11 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
         kp.epi16 = a->cout % 8 == 0 && a->out_ld % 8 == 0 && (reinterpret_cast<size_t>(a->out) & 15) == 0;
     }
     kp.w_bf = a->w_bf16, kp.kpad_bf = (kp.cin_pad + 31) / 32 * 32, kp.npad_bf = (a->cout + 63) / 64 * 64;
+    if (a->out_sign) {
+        PWS_REQUIRE(a->store == PWS_STORE_BF16 && a->cout % 8 == 0 && a->out_sign_ld >= a->cout / 8,
+                    "pws_conv2d_fwd: out_sign needs bf16 storage, cout %% 8 == 0 and out_sign_ld >= cout / 8");
+        kp.out_sign = a->out_sign, kp.out_sign_ld = a->out_sign_ld;
+    }
 
     // algorithmic work of this launch (real channels, each tensor touched once)
     auto info = [&](int k2, double out_pix) {
@@ -545,6 +550,10 @@ int conv2d_bwd_data_impl(const pws_conv_bwd_data_args *a, hipStream_t st) {
             PWS_REQUIRE(d.act_y_ld >= d.channels && d.act_y_ld % 2 == 0 && (reinterpret_cast<size_t>(d.act_y) & 3) == 0,
                         "pws_conv2d_bwd_data: bad act_y / act_y_ld of destination %d", s);
             kp.dst_y[s] = d.act_y, kp.dst_y_ld[s] = d.act_y_ld, kp.dst_act[s] = d.act;
+            if (d.act_sign) {
+                PWS_REQUIRE(d.channels % 8 == 0 && d.act_sign_ld >= d.channels / 8, "pws_conv2d_bwd_data: bad act_sign / act_sign_ld of destination %d", s);
+                kp.dst_sign[s] = d.act_sign, kp.dst_sign_ld[s] = d.act_sign_ld;
+            }
         }
         cin_f += d.channels;
     }
@@ -562,7 +571,8 @@ int conv2d_bwd_data_impl(const pws_conv_bwd_data_args *a, hipStream_t st) {
         const double es = a->store == PWS_STORE_BF16 ? 2.0 : 4.0, in_pix = (double)a->n * a->h * a->w;
         pi.bytes = es * ((double)a->n * oh * ow * a->cout + in_pix * cin_f);
         for (int s = 0; s < a->ndst; ++s)
-            pi.bytes += es * in_pix * a->dst[s].channels * ((a->dst[s].accumulate ? 1.0 : 0.0) + (kp.dst_act[s] != PWS_ACT_NONE ? 1.0 : 0.0));
+            pi.bytes += es * in_pix * a->dst[s].channels * (a->dst[s].accumulate ? 1.0 : 0.0) +
+                        (kp.dst_act[s] == PWS_ACT_NONE ? 0.0 : (kp.dst_sign[s] ? in_pix * a->dst[s].channels / 8.0 : es * in_pix * a->dst[s].channels));
     }
     if (a->kind == PWS_CONV_K3S2)
         kp.LH = oh, kp.LW = ow, kp.nclasses = 4;

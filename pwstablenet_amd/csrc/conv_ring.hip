@@ -63,6 +63,10 @@ struct RingParams {
     int dst_c0[4], dst_c1[4], dst_ld[4], dst_acc[4];
     const void *dst_y[4];
     int dst_y_ld[4], dst_act[4];
+    unsigned char *out_sign;            // forward: sign bits of `out` (ConvKParams.out_sign), NULL = none
+    int out_sign_ld;
+    const unsigned char *dst_sign[4];   // data gradient: sign bits of dst_y[s], read instead of it
+    int dst_sign_ld[4];
     int tiles_x, tiles_y, tn;   // tn: samples per tile
     unsigned ncob, ncls, nunits;
     int gpp;              // K groups per plane = sum(src_c) / 32
@@ -164,8 +168,11 @@ __device__ __forceinline__ RingUnit ring_unit(const RingParams &p, unsigned u) {
     return r;
 }
 
-template <class C, bool DG>   // DG: data-gradient epilogue (scatter over the forward layer's sources, accumulate, act')
+// SG (data gradient only): every act' operand is given as SIGN BITS (RingParams.dst_sign): the epilogue loads one byte per slot instead of
+// 16 (a runtime choice would keep both in registers: the data-gradient kernels stand at the 168-register limit)
+template <class C, bool DG, bool SG = false>   // DG: data-gradient epilogue (scatter over the forward layer's sources, accumulate, act')
 __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingParams p) {
+    static_assert(DG || !SG, "sign bits are an operand of the data-gradient epilogue");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -387,7 +394,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
     // of the stride-2 layers on the 256 x 256 maps is a read-modify-write of 537 MB tensors with 1-4 taps of matrix work per
     // group: its pace is the number of 16-byte requests a wave keeps in flight (PWS_RING_PF overrides for A/B builds)
 #ifndef PWS_RING_PF
-#define PWS_RING_PF (C::MODE == RM_SP3 ? 2 : 1)
+#define PWS_RING_PF (SG ? (C::MODE == RM_K4S2 ? 8 : (C::MODE == RM_SP3 ? 4 : 2)) : (C::MODE == RM_SP3 ? 2 : 1))   // (the sign-bit variants have the registers for more slots in flight)
 #endif
     constexpr int PF = PWS_RING_PF;
     constexpr int NSLOT = 8;       // slot = mt * 4 + q: pixel mt, 8-channel group q of the lane's 32 channels
@@ -396,18 +403,27 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
     // at this lane's first group (+ 8 hi channels)
     struct EpiBlock {
         unsigned char *d;
-        const unsigned char *y;
+        const unsigned char *y;   // the forward tensor (16 bytes per slot) or, with `sign`, its sign bits (1 byte per slot)
         unsigned dld2, yld2;   // pixel strides in bytes
+        unsigned yo;           // SG: this lane's byte inside a pixel's sign bytes (y is then the tensor's base: wave-uniform, stays in scalar registers)
         bool ok, acc, hasy;
         float slope;
     } eb[2] = {};
-    u32x4 e_old[DG ? NSLOT : 1], e_y[DG ? NSLOT : 1];
+    u32x4 e_old[DG ? NSLOT : 1], e_y[DG && !SG ? NSLOT : 1];
+    unsigned e_m[SG ? NSLOT : 1];
 
     // The epilogue's loads are unconditional in control flow (a lane without the tensor reads 16 zero bytes instead): a load inside
     // an if leaves a control-flow merge behind, and hipcc waits vmcnt(0) at the first use
     // after every merge -- which serialised the rolling requests and the stores of the data-gradient epilogue.
     auto e_load = [&](const unsigned char *ptr, bool have) {
         return *reinterpret_cast<const u32x4 *>(have ? ptr : reinterpret_cast<const unsigned char *>(&g_ring_zero16));
+    };
+    // act' operand of slot `sl` (channel half sl & 1 of its block) at pixel `pix` into register set `dst`: the 8 bf16 values of the forward
+    // tensor, or -- SG -- ONE byte of sign bits (v > 0 is all the epilogue asks of them)
+    auto e_load_y = [&](const EpiBlock &e, unsigned pix, int sl, bool have, int dst) {
+        const unsigned char *z = reinterpret_cast<const unsigned char *>(&g_ring_zero16);
+        if constexpr (SG) e_m[dst] = *(have ? e.y + (size_t)(pix * e.yld2 + e.yo + (unsigned)((sl & 1) * 2)) : z);
+        else e_y[dst] = *reinterpret_cast<const u32x4 *>(have ? e.y + (size_t)pix * e.yld2 + (sl & 1) * 32 : z);
     };
     constexpr int SO = C::NCLS == 4 ? 2 : 1;   // output stride of the parity classes
     unsigned cu = u_begin;
@@ -465,9 +481,13 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
                             e.d = reinterpret_cast<unsigned char *>(reinterpret_cast<__bf16 *>(p.dst_ptr[s_]) + (co - p.dst_c0[s_]) + hi * 8);
                             e.dld2 = (unsigned)p.dst_ld[s_] * 2u, e.acc = p.dst_acc[s_] != 0, e.ok = true;
                             if (p.dst_act[s_] != PWS_ACT_NONE) {
-                                e.y = reinterpret_cast<const unsigned char *>(static_cast<const __bf16 *>(p.dst_y[s_]) + (co - p.dst_c0[s_]) + hi * 8);
-                                e.yld2 = (unsigned)p.dst_y_ld[s_] * 2u, e.slope = p.dst_act[s_] == PWS_ACT_LRELU ? 0.2f : 0.f;
-                                e.hasy = true;
+                                if constexpr (SG) {
+                                    e.y = p.dst_sign[s_], e.yo = (unsigned)(((co - p.dst_c0[s_]) >> 3) + hi), e.yld2 = (unsigned)p.dst_sign_ld[s_];
+                                } else {
+                                    e.y = reinterpret_cast<const unsigned char *>(static_cast<const __bf16 *>(p.dst_y[s_]) + (co - p.dst_c0[s_]) + hi * 8);
+                                    e.yld2 = (unsigned)p.dst_y_ld[s_] * 2u;
+                                }
+                                e.slope = p.dst_act[s_] == PWS_ACT_LRELU ? 0.2f : 0.f, e.hasy = true;
                             }
                         }
                     }
@@ -480,7 +500,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
                     const unsigned pix = e_pix(slot >> 2);
                     const EpiBlock &e = eb[(slot >> 1) & 1];
                     e_old[slot] = e_load(e.d + (size_t)pix * e.dld2 + (slot & 1) * 32, e.ok && e.acc);
-                    e_y[slot] = e_load(e.y + (size_t)pix * e.yld2 + (slot & 1) * 32, e.ok && e.hasy);
+                    e_load_y(e, pix, slot, e.ok && e.hasy, slot);
                 }
             }
         }
@@ -579,7 +599,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
                                 const unsigned pix2 = e_pix(nx2 >> 2);
                                 const EpiBlock &e2 = eb[(nx2 >> 1) & 1];
                                 e_old[nx2] = e_load(e2.d + (size_t)pix2 * e2.dld2 + (nx2 & 1) * 32, e2.ok && e2.acc);
-                                e_y[nx2] = e_load(e2.y + (size_t)pix2 * e2.yld2 + (nx2 & 1) * 32, e2.ok && e2.hasy);
+                                e_load_y(e2, pix2, nx2, e2.ok && e2.hasy && !(p.ablate & 16), nx2);
                             }
                         }
                         // straight-line on purpose: only the store itself is predicated (a block that short gets no skip branch), so
@@ -598,12 +618,18 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
                             v[0] += bf16_lo(o.x), v[1] += bf16_hi(o.x), v[2] += bf16_lo(o.y), v[3] += bf16_hi(o.y);
                             v[4] += bf16_lo(o.z), v[5] += bf16_hi(o.z), v[6] += bf16_lo(o.w), v[7] += bf16_hi(o.w);
                             // act'(y) of the tensor this destination is the gradient of (no such tensor: slope == 1)
-                            const u32x4 yv = e_y[slot];
                             const float sl = e.slope;
-                            v[0] *= bf16_lo(yv.x) > 0.f ? 1.f : sl, v[1] *= bf16_hi(yv.x) > 0.f ? 1.f : sl;
-                            v[2] *= bf16_lo(yv.y) > 0.f ? 1.f : sl, v[3] *= bf16_hi(yv.y) > 0.f ? 1.f : sl;
-                            v[4] *= bf16_lo(yv.z) > 0.f ? 1.f : sl, v[5] *= bf16_hi(yv.z) > 0.f ? 1.f : sl;
-                            v[6] *= bf16_lo(yv.w) > 0.f ? 1.f : sl, v[7] *= bf16_hi(yv.w) > 0.f ? 1.f : sl;
+                            if constexpr (SG) {
+                                const unsigned m = e_m[slot];
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) v[k] *= (m >> k) & 1u ? 1.f : sl;
+                            } else {
+                                const u32x4 yv = e_y[slot];
+                                v[0] *= bf16_lo(yv.x) > 0.f ? 1.f : sl, v[1] *= bf16_hi(yv.x) > 0.f ? 1.f : sl;
+                                v[2] *= bf16_lo(yv.y) > 0.f ? 1.f : sl, v[3] *= bf16_hi(yv.y) > 0.f ? 1.f : sl;
+                                v[4] *= bf16_lo(yv.z) > 0.f ? 1.f : sl, v[5] *= bf16_hi(yv.z) > 0.f ? 1.f : sl;
+                                v[6] *= bf16_lo(yv.w) > 0.f ? 1.f : sl, v[7] *= bf16_hi(yv.w) > 0.f ? 1.f : sl;
+                            }
                         }
                         u32x4 wq;
                         wq.x = cvt_pk_bf16(v[0], v[1]), wq.y = cvt_pk_bf16(v[2], v[3]);
@@ -616,6 +642,14 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
 #else
                         if (st_ok) *reinterpret_cast<u32x4 *>(dptr) = wq;
 #endif
+                        if constexpr (!DG) {
+                            if (p.out_sign) {   // (uniform) sign bits of the 8 rounded values: what a later act' needs of this tensor
+                                const unsigned m = (bf16_lo(wq.x) > 0.f ? 1u : 0u) | (bf16_hi(wq.x) > 0.f ? 2u : 0u) | (bf16_lo(wq.y) > 0.f ? 4u : 0u) |
+                                                   (bf16_hi(wq.y) > 0.f ? 8u : 0u) | (bf16_lo(wq.z) > 0.f ? 16u : 0u) | (bf16_hi(wq.z) > 0.f ? 32u : 0u) |
+                                                   (bf16_lo(wq.w) > 0.f ? 64u : 0u) | (bf16_hi(wq.w) > 0.f ? 128u : 0u);
+                                if (st_ok) p.out_sign[(size_t)pix * (unsigned)p.out_sign_ld + (unsigned)((CU.co0 + q * 16) >> 3) + (unsigned)hi] = (unsigned char)m;
+                            }
+                        }
                     }
                 }
             }
@@ -639,12 +673,12 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-template <class C, bool DG>
+template <class C, bool DG, bool SG = false>
 static int ring_launch(RingParams &rp, hipStream_t st) {
     static PerDeviceFlag attr_set_dev;
     bool &attr_set = attr_set_dev.cur();   // hipFuncSetAttribute acts on the CURRENT device's function object
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ring_kernel<C, DG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ring_kernel<C, DG, SG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            C::LDS_BYTES);
         if (e != hipSuccess) {
             set_error("hipFuncSetAttribute(conv_ring_kernel, %d B LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
@@ -666,17 +700,17 @@ static int ring_launch(RingParams &rp, hipStream_t st) {
     for (int s = 0; s < rp.nsrc; ++s) cin += rp.src_c[s];
     rp.gpp = cin / C::CKG;
     const unsigned grid = rp.nunits < (unsigned)ncu ? rp.nunits : (unsigned)ncu;   // one persistent workgroup per CU
-    hipLaunchKernelGGL((conv_ring_kernel<C, DG>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, st, rp);
+    hipLaunchKernelGGL((conv_ring_kernel<C, DG, SG>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, st, rp);
     return check_launch("conv_ring_kernel");
 }
 
 // Tile shapes: 16 x 32 pixels of one sample for maps at least 32 wide, 16 x 16 x 2 samples for 16-wide maps, 8 x 8 x 8 samples for
 // 8 x 8 maps (2x2-tap kinds only: the 3x3 kind's group of 8 halo'd samples does not fit two ring buffers).
-template <int MODE, bool DG>
+template <int MODE, bool DG, bool SG = false>
 static int ring_launch_tile(int tw, RingParams &rp, hipStream_t st) {
-    if (tw == 32) return ring_launch<RgCfg<MODE, 16, 32, 1, MODE == RM_K3S1 ? 2 : 3>, DG>(rp, st);
-    if (tw == 16) return ring_launch<RgCfg<MODE, 16, 16, 2, 2>, DG>(rp, st);
-    if constexpr (MODE != RM_K3S1) return ring_launch<RgCfg<MODE, 8, 8, 8, 2>, DG>(rp, st);
+    if (tw == 32) return ring_launch<RgCfg<MODE, 16, 32, 1, MODE == RM_K3S1 ? 2 : 3>, DG, SG>(rp, st);
+    if (tw == 16) return ring_launch<RgCfg<MODE, 16, 16, 2, 2>, DG, SG>(rp, st);
+    if constexpr (MODE != RM_K3S1) return ring_launch<RgCfg<MODE, 8, 8, 8, 2>, DG, SG>(rp, st);
     return 1;
 }
 
@@ -712,24 +746,31 @@ int conv_ring_try(int kind, bool dgrad, const ConvKParams &kp, hipStream_t st, c
     rp.w_bytes = (size_t)planes * kp.npad_bf * kp.kpad_bf * 2;
     if (rp.w_bytes >= (1u << 31)) return 1;
     rp.bias = kp.bias, rp.act = kp.act, rp.out = kp.out, rp.out_ld = kp.out_ld, rp.ndst = kp.ndst;
+    rp.out_sign = dgrad ? nullptr : static_cast<unsigned char *>(kp.out_sign), rp.out_sign_ld = kp.out_sign_ld;
+    for (int s = 0; s < 4; ++s) rp.dst_sign[s] = static_cast<const unsigned char *>(kp.dst_sign[s]), rp.dst_sign_ld[s] = kp.dst_sign_ld[s];
 #ifdef PWS_RING_TIMERS
     {   // tools/ring_timers.py passes the buffer's address through the environment
         const char *e = getenv("PWS_RING_TIMERS_PTR");
         rp.timers = e ? reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 0)) : nullptr;
     }
 #endif
-    rp.ablate = g_experiment >= 41 && g_experiment <= 48 ? g_experiment - 40 : 0;   // (48 = mask 8: weight pieces only for a workgroup's first unit)
+    rp.ablate = g_experiment >= 41 && g_experiment <= 48 ? g_experiment - 40 : (g_experiment == 49 ? 16 : 0);   // (49 = mask 16: no act' loads)   // (48 = mask 8: weight pieces only for a workgroup's first unit)
     if (tw == 8 && mode == RM_K3S1) return 1;
     if (kp.cout > (tw == 16 && mode == RM_K3S1 ? 512 : 1024)) return 1;   // the bias vector's LDS slot (RgCfg::BIAS_FLOATS)
     const long units = (long)kp.LW * kp.LH * kp.N / 512 * ((kp.cout + 63) / 64) * ((mode == RM_CT4 || mode == RM_SP3) ? 4 : 1);
     if (units < 192 && g_experiment != 21) return 1;   // too few units for 256 persistent workgroups: the split-K kernels do better
+    // the sign-bit variant of the data-gradient epilogue: when EVERY destination with an act' has its sign bits (PWS_OPT_EXPERIMENT 12: never)
+    bool sg = dgrad && g_experiment != 12, any_act = false;
+    for (int s = 0; s < kp.ndst; ++s)
+        if (kp.dst_act[s] != PWS_ACT_NONE) any_act = true, sg = sg && kp.dst_sign[s] != nullptr;
+    sg = sg && any_act;
     ProfScope prof(KID_CONV_RING, pi.flops, pi.bytes, st);
     switch (mode) {
-    case RM_K3S1: return dgrad ? ring_launch_tile<RM_K3S1, true>(tw, rp, st) : ring_launch_tile<RM_K3S1, false>(tw, rp, st);
+    case RM_K3S1: return !dgrad ? ring_launch_tile<RM_K3S1, false>(tw, rp, st) : (sg ? ring_launch_tile<RM_K3S1, true, true>(tw, rp, st) : ring_launch_tile<RM_K3S1, true>(tw, rp, st));
     case RM_CT4: return ring_launch_tile<RM_CT4, false>(tw, rp, st);
-    case RM_SP3: return ring_launch_tile<RM_SP3, true>(tw, rp, st);
+    case RM_SP3: return sg ? ring_launch_tile<RM_SP3, true, true>(tw, rp, st) : ring_launch_tile<RM_SP3, true>(tw, rp, st);
     case RM_K3S2: return ring_launch_tile<RM_K3S2, false>(tw, rp, st);
-    default: return ring_launch_tile<RM_K4S2, true>(tw, rp, st);
+    default: return sg ? ring_launch_tile<RM_K4S2, true, true>(tw, rp, st) : ring_launch_tile<RM_K4S2, true>(tw, rp, st);
     }
 }
 

@@ -168,6 +168,7 @@ static int opts_from(const pws_netg_opts *o, NetgOpts *out) {
 struct Seg {
     float *ptr;
     int c, ld;
+    unsigned char *sign = nullptr;   // bf16 training: the tensor's sign bits (pws_conv_args.out_sign), c / 8 bytes per pixel; NULL = none
 };
 struct Tn {  // a (virtually concatenated) NHWC tensor
     Seg seg[4];
@@ -317,6 +318,15 @@ class Exec {
         Tn o{};
         o.nseg = 1, o.h = oh, o.w = ow;
         o.seg[0] = Seg{alloc((size_t)n_ * oh * ow * l.cout), l.cout, l.cout};
+        // bf16 training: the layers whose backward multiplies by act'(this output) read its SIGN BITS instead of the tensor (1/16 of the
+        // bytes: the data-gradient epilogues of the large maps are read-modify-writes waiting on their loads).  Asked of the maps the
+        // ring kernel takes (it writes them in its epilogue; another kernel is followed by a pass over the output), not of the first
+        // layer (5x5 kernel) -- PWS_OPT_EXPERIMENT 12: never.
+        // (The arena holds the bytes in every training layout -- the workspace size does not depend on the storage mode.)
+        if (training_ && !bn_on_ && nchw_c == 0 && act != PWS_ACT_NONE && l.cout % 8 == 0 && ow >= 32) {
+            unsigned char *sg = reinterpret_cast<unsigned char *>(alloc(((size_t)n_ * oh * ow * (l.cout / 8) + 3) / 4));
+            if (io16_ && g_experiment != 12) o.seg[0].sign = sg;
+        }
         Op op{OP_CONV, layer, act, 0, nchw_c > 0, x, o};
         if (bn_on_) op.aux[0] = alloc((size_t)n_ * oh * ow * l.cout), op.aux[1] = alloc(2 * (size_t)l.cout);
         tape_.push_back(op);
@@ -341,6 +351,7 @@ class Exec {
         a.ws = q_ ? splitk_ws2_ : splitk_ws_, a.ws_bytes = splitk_bytes_;
         if (math_ == PWS_MATH_BF16 && l.wb_off != (size_t)-1) a.math = PWS_MATH_BF16, a.w_bf16 = packed_ + l.wb_off;
         a.store = store();
+        a.out_sign = o.seg[0].sign, a.out_sign_ld = l.cout / 8;
         g_prof_tag = layer;
         rc_ = pws_conv2d_fwd(&a, streams_[q_]);
         g_prof_tag = -1;
@@ -426,6 +437,7 @@ class Exec {
     // scratch shared by all layers (launches are stream-ordered): split-K partial tiles, the theta head's partials,
     // and (training) the hidden activations of the three theta heads
     void reserve_scratch(int ngf, bool training) {
+        training_ = training;
         splitk_bytes_ = (size_t)(n_ > 8 ? n_ : 8) * (2u << 20);
         splitk_ws_ = alloc(splitk_bytes_ / sizeof(float));
         splitk_ws2_ = alloc(splitk_bytes_ / sizeof(float));  // one scratch per queue: the two run concurrently
@@ -450,7 +462,7 @@ class Exec {
     BnCfg bn_;
     size_t bn_off_[L_COUNT] = {}, bn_total_ = 0, bn_ws_bytes_ = 0;
     float *bn_ws_[2] = {nullptr, nullptr};
-    bool io16_ = false;
+    bool io16_ = false, training_ = false;
     int math_ = PWS_MATH_FP32;
     size_t x_sstride_ = 0;
     SideStream *side_ = nullptr;
@@ -759,11 +771,12 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             da.w_dgrad = packed_dgrad + l.dg_off, da.ndst = op.in.nseg;
             for (int i = 0; i < op.in.nseg; ++i) {
                 GradBuf &gi = G[op.in.seg[i].ptr];
-                da.dst[i] = pws_dst{gi.g, op.in.seg[i].c, op.in.seg[i].c, gi.written ? 1 : 0, nullptr, 0, PWS_ACT_NONE};
+                da.dst[i] = pws_dst{gi.g, op.in.seg[i].c, op.in.seg[i].c, gi.written ? 1 : 0, nullptr, 0, PWS_ACT_NONE, nullptr, 0};
                 gi.written = true;
                 const int fa = fused_act(ii, op.in.seg[i].ptr);
                 if (fa != PWS_ACT_NONE)
-                    da.dst[i].act_y = op.in.seg[i].ptr, da.dst[i].act_y_ld = op.in.seg[i].ld, da.dst[i].act = fa, gi.preact = true;
+                    da.dst[i].act_y = op.in.seg[i].ptr, da.dst[i].act_y_ld = op.in.seg[i].ld, da.dst[i].act = fa, gi.preact = true,
+                    da.dst[i].act_sign = op.in.seg[i].sign, da.dst[i].act_sign_ld = op.in.seg[i].c / 8;
             }
             da.ws = E.splitk_ws(), da.ws_bytes = E.splitk_bytes();
             if (mode.math == PWS_MATH_BF16 && l.dgb_off != (size_t)-1) da.math = PWS_MATH_BF16, da.w_dgrad_bf16 = packed_dgrad + l.dgb_off;

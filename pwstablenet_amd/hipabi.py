@@ -17,7 +17,7 @@ ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 OPT_TWO_QUEUES = 1
 OPT_MATH, MATH_FP32, MATH_BF16 = 2, 0, 1
 OPT_STORE, STORE_FP32, STORE_BF16 = 3, 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 NETG_DETERMINISTIC = 1
 OPT_EXPERIMENT = 100   # measured kernel variants (tools, per-path tests); 0 = product default
 OBJ_SLOTS = 64
@@ -34,12 +34,13 @@ class PwsConvArgs(ctypes.Structure):
                 ("w_packed", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("act", ctypes.c_int),
                 ("out", ctypes.c_void_p), ("out_ld", ctypes.c_int), ("w_wino", ctypes.c_void_p), ("ws", ctypes.c_void_p),
                 ("ws_bytes", ctypes.c_size_t), ("math", ctypes.c_int), ("w_bf16", ctypes.c_void_p), ("store", ctypes.c_int),
-                ("w_wring", ctypes.c_void_p)]
+                ("w_wring", ctypes.c_void_p), ("out_sign", ctypes.c_void_p), ("out_sign_ld", ctypes.c_int)]
 
 
 class PwsDst(ctypes.Structure):
     _fields_ = [("ptr", ctypes.c_void_p), ("channels", ctypes.c_int), ("ld", ctypes.c_int), ("accumulate", ctypes.c_int),
-                ("act_y", ctypes.c_void_p), ("act_y_ld", ctypes.c_int), ("act", ctypes.c_int)]
+                ("act_y", ctypes.c_void_p), ("act_y_ld", ctypes.c_int), ("act", ctypes.c_int),
+                ("act_sign", ctypes.c_void_p), ("act_sign_ld", ctypes.c_int)]
 
 
 class PwsConvBwdDataArgs(ctypes.Structure):

@@ -742,6 +742,22 @@ def test_netg_bf16_training_step_gradients_vs_fp32(hip, store):
     hip.lib().pws_prof_enable(1)
     l16, g16 = step("bf16")
     hip.lib().pws_prof_enable(0)
+    if store == "bf16":   # the sign-bit epilogues (PWS_OPT_EXPERIMENT 12: off) change which bytes are read, not one result
+        hip.lib().pws_set_option(hip.OPT_EXPERIMENT, 12)
+        try:
+            l12, g12 = step("bf16")
+        finally:
+            hip.lib().pws_set_option(hip.OPT_EXPERIMENT, 0)
+        if not getattr(net.module, "deterministic", False):
+            net.module.deterministic = True   # (atomics' arrival order moves the weight gradients' last bits otherwise)
+            try:
+                ld0, gd0 = step("bf16")
+                hip.lib().pws_set_option(hip.OPT_EXPERIMENT, 12)
+                ld12, gd12 = step("bf16")
+            finally:
+                hip.lib().pws_set_option(hip.OPT_EXPERIMENT, 0)
+                net.module.deterministic = False
+            assert ld0 == ld12 and all(torch.equal(a, b) for a, b in zip(gd0, gd12))
     names = [r[0] for r in hip.prof_collect()]
     net.module.set_math("fp32")
     nconv = sum(names.count(k) for k in BF16_CONV_KERNELS)
@@ -759,6 +775,128 @@ def test_netg_bf16_training_step_gradients_vs_fp32(hip, store):
     for r_, k in sorted(rel)[-6:]:
         print("   %-44s %.4f" % (k, r_))
     assert worst < 0.15, (worst, worst_name)
+
+
+def _sign_bytes(y_nhwc_bf16):
+    """Bit (c & 7) of byte [pixel][c / 8] = (y[pixel][c] > 0): pws_conv_args.out_sign's layout, from the bf16 tensor itself."""
+    pos = (y_nhwc_bf16.float() > 0).to(torch.uint8).cpu().numpy()
+    n, h, w, c = pos.shape
+    return np.packbits(pos.reshape(n, h, w, c // 8, 8), axis=-1, bitorder="little")[..., 0]
+
+
+@pytest.mark.parametrize("kname,shape,src_c,cout,expect", [
+    ("CONV_K3S1", (2, 128, 128), [32, 32], 64, "conv_ring_kernel"),      # the ring kernel writes the bytes in its epilogue
+    ("CONVT_K4S2", (2, 64, 64), [64], 72, "conv_ring_kernel"),           # parity classes, cout ending inside a 64-channel block
+    ("CONV_K3S2", (2, 128, 128), [64], 64, "conv_ring_kernel"),
+    ("CONV_K3S1", (3, 12, 20), [32], 40, "conv_bf16_kernel"),            # another kernel + the pass over its output
+    ("CONVT_K4S2", (2, 4, 4), [64], 64, "conv_skinny16_kernel"),
+])
+def test_forward_sign_bits_equal_the_sign_of_the_stored_output(hip, kname, shape, src_c, cout, expect):
+    """pws_conv_args.out_sign (ABI version 3): the sign bits of the ROUNDED bf16 output, one byte per 8 channels, whichever kernel
+    produced the output; rows of out_sign_ld > cout / 8 bytes keep their padding."""
+    A = hip
+    L, st = A.lib(), A.current_stream()
+    kind = getattr(A, kname)
+    x, wt, b, rs = make_case(kname, shape, src_c, cout, "sg")
+    n, cin, h, w = x.shape
+    wp = torch.empty(L.pws_packed_weight_floats(kind, cin, cout), device="cuda")
+    A.check(L.pws_pack_conv_weight(A.ptr(wt.cuda()), A.ptr(wp), kind, cin, cout, st), "pack")
+    wb = torch.empty(L.pws_packed_bf16_floats(PLANES[kname], (cin + 15) // 16 * 16, cout), device="cuda")
+    A.check(L.pws_pack_weight_bf16(A.ptr(wp), A.ptr(wb), PLANES[kname], (cin + 15) // 16 * 16, cout, st), "pack_bf16")
+    xs = nhwc(x)
+    a = A.PwsConvArgs()
+    a.kind, a.n, a.h, a.w, a.nsrc, a.cout, a.act = kind, n, h, w, len(src_c), cout, A.ACT_LRELU
+    keep, c0 = [], 0
+    for i, c in enumerate(src_c):
+        t = xs[..., c0:c0 + c].contiguous().cuda().bfloat16()
+        keep.append(t)
+        a.src[i].ptr, a.src[i].channels, a.src[i].ld = t.data_ptr(), c, c
+        c0 += c
+    oh, ow = (h, w) if "S1" in kname else (((h - 1) // 2 + 1, (w - 1) // 2 + 1) if kname == "CONV_K3S2" else (2 * h, 2 * w))
+    out = torch.full((n, oh, ow, cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+    sld = cout // 8 + 3
+    sign = torch.full((n, oh, ow, sld), 0xA5, device="cuda", dtype=torch.uint8)
+    d_b = b.cuda()
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    a.store, a.math, a.w_bf16 = A.STORE_BF16, A.MATH_BF16, wb.data_ptr()
+    a.w_packed, a.bias, a.out, a.out_ld, a.ws, a.ws_bytes = wp.data_ptr(), d_b.data_ptr(), out.data_ptr(), cout, ws.data_ptr(), ws.numel()
+    a.out_sign, a.out_sign_ld = sign.data_ptr(), sld
+    L.pws_set_option(A.OPT_EXPERIMENT, 21 if expect == "conv_ring_kernel" else 0)   # (21: the ring kernel also for launches of few units)
+    try:
+        L.pws_prof_enable(1)
+        A.check(L.pws_conv2d_fwd(ctypes.byref(a), st), "conv with sign bits")
+        L.pws_prof_enable(0)
+    finally:
+        L.pws_set_option(A.OPT_EXPERIMENT, 0)
+    assert [r[0] for r in A.prof_collect()] == [expect]
+    torch.cuda.synchronize()
+    assert not torch.isnan(out.float()).any()
+    got = sign.cpu().numpy()
+    assert np.array_equal(got[..., :cout // 8], _sign_bytes(out)) and (got[..., cout // 8:] == 0xA5).all()
+    # fp32 storage has no use for them and says so
+    a.store = A.STORE_FP32
+    assert L.pws_conv2d_fwd(ctypes.byref(a), st) == -22 and b"out_sign" in L.pws_last_error()
+
+
+@pytest.mark.parametrize("kname,shape,src_c,cout", [
+    ("CONVT_K4S2", (4, 128, 128), [64, 64], 64),     # k4 s2 data gradient on the ring (256 units): planes, two destinations
+    ("CONV_K3S2", (4, 128, 128), [64, 32], 64),      # sub-pixel classes
+    ("CONV_K3S1", (6, 128, 128), [32, 64], 64),
+    ("CONV_K3S1", (3, 12, 20), [32], 64),            # not on the ring: act_sign is ignored, act_y read
+])
+@pytest.mark.parametrize("act", ["ACT_LRELU", "ACT_RELU"])
+def test_data_gradient_with_sign_bits_is_bit_identical_to_reading_the_forward_tensor(hip, kname, shape, src_c, cout, act):
+    """pws_dst.act_sign: the ring kernel's sign-bit epilogue (one byte per 8 channels, more requests in flight) gives the same bytes as
+    the epilogue that reads act_y; a destination without act' beside one with it; PWS_OPT_EXPERIMENT 12 = sign bits ignored."""
+    A = hip
+    L, st = A.lib(), A.current_stream()
+    kind = getattr(A, kname)
+    x, wt, b, rs = make_case(kname, shape, src_c, cout, "sgd")
+    n, cin, h, w = x.shape
+    kd, k, s_, p_ = KINDS[kname]
+    oh, ow = (h, w) if s_ == 1 else ((h // 2, w // 2) if kd == "conv" else (2 * h, 2 * w))
+    d_dy = torch.from_numpy(rs.standard_normal((n, oh, ow, cout)).astype(np.float32)).cuda().bfloat16()
+    wdg = torch.empty(L.pws_packed_dgrad_floats(kind, cin, cout), device="cuda")
+    A.check(L.pws_pack_conv_weight_dgrad(A.ptr(wt.cuda()), A.ptr(wdg), kind, cin, cout, st), "pack_dgrad")
+    planes = 9 if "S1" in kname else 16
+    wdb = torch.empty(L.pws_packed_bf16_floats(planes, cout, cin), device="cuda")
+    A.check(L.pws_pack_weight_bf16(A.ptr(wdg), A.ptr(wdb), planes, cout, cin, st), "pack_bf16")
+    ys = [torch.from_numpy(rs.standard_normal((n, h, w, c)).astype(np.float32)).cuda().bfloat16() for c in src_c]
+    signs = [torch.from_numpy(_sign_bytes(y)).cuda() for y in ys]
+    wsb = torch.empty(64 << 20, device="cuda", dtype=torch.uint8)
+
+    def run(with_sign, exp):
+        L.pws_set_option(A.OPT_EXPERIMENT, exp)
+        da = A.PwsConvBwdDataArgs()
+        da.kind, da.n, da.h, da.w, da.cout = kind, n, h, w, cout
+        da.gout, da.gout_ld, da.w_dgrad, da.ndst = d_dy.data_ptr(), cout, wdg.data_ptr(), len(src_c)
+        da.math, da.w_dgrad_bf16, da.store = A.MATH_BF16, wdb.data_ptr(), A.STORE_BF16
+        da.ws, da.ws_bytes = wsb.data_ptr(), wsb.numel()
+        outs = []
+        for i, c in enumerate(src_c):
+            acc = 1 if i == 0 else 0
+            o = torch.full((n, h, w, c), 0.25 if acc else float("nan"), device="cuda", dtype=torch.bfloat16)
+            outs.append(o)
+            da.dst[i].ptr, da.dst[i].channels, da.dst[i].ld, da.dst[i].accumulate = o.data_ptr(), c, c, acc
+            if i == 0:   # the second destination, if any, stays plain
+                da.dst[i].act_y, da.dst[i].act_y_ld, da.dst[i].act = ys[i].data_ptr(), c, getattr(A, act)
+                if with_sign:
+                    da.dst[i].act_sign, da.dst[i].act_sign_ld = signs[i].data_ptr(), c // 8
+        try:
+            L.pws_prof_enable(1)
+            A.check(L.pws_conv2d_bwd_data(ctypes.byref(da), st), "bwd_data")
+            L.pws_prof_enable(0)
+        finally:
+            L.pws_set_option(A.OPT_EXPERIMENT, 0)
+        ran.append([r[0] for r in A.prof_collect()])
+        torch.cuda.synchronize()
+        return [o.float().cpu() for o in outs]
+    ran = []
+    ref, got, off = run(False, 0), run(True, 0), run(True, 12)
+    assert ran[0] == ran[1] == ran[2] and (ran[0] == ["conv_ring_kernel"]) == (shape[1] >= 128), ran
+    for r_, g_, o_ in zip(ref, got, off):
+        assert not torch.isnan(r_).any()
+        assert torch.equal(r_, g_) and torch.equal(r_, o_)
 
 
 def test_nchw_to_nhwc_pad_and_first_layer_bf16(hip):
