@@ -33,11 +33,12 @@ def short(name):
         sub = {"0": "", "1": ",convT4", "2": ",dgrad-subpix", "true": ",convT4", "false": ""}.get(a[3], "," + a[3])
         return "conv_mfma_kernel<k%ss%s%s,tile %sx%sx%s,CK%s%s>" % (
             a[0], a[1], sub, a[6], a[4], a[5], a[7], ",NCHW" if len(a) > 12 and a[12].startswith("t") else "")
-    m = re.match(r"pws::conv_ring_kernel<pws::RgCfg<([^>]*)>,\s*(true|false)\s*>", name)
-    if m:   # persistent LDS-ring bf16 conv (conv_ring.hip): mode, tile, ring depth, epilogue kind
+    m = re.match(r"pws::conv_ring_kernel<pws::RgCfg<([^>]*)>,\s*(true|false)(?:,\s*(true|false))?\s*>", name)
+    if m:   # persistent LDS-ring bf16 conv (conv_ring.hip): mode, tile, ring depth, epilogue kind (+ sign-bit variant of the data gradient)
         a = [x.strip() for x in m.group(1).split(",")]
         mode = {"0": "k3s1", "1": "convT4", "2": "dgrad-subpix k3s2", "3": "k3s2 planes", "4": "dgrad k4s2 planes"}.get(a[0], a[0])
-        return "conv_ring_kernel<%s,tile %sx%sx%s,R%s,%s>" % (mode, a[3], a[1], a[2], a[4], "dgrad" if m.group(2) == "true" else "fwd")
+        return "conv_ring_kernel<%s,tile %sx%sx%s,R%s,%s%s>" % (mode, a[3], a[1], a[2], a[4], "dgrad" if m.group(2) == "true" else "fwd",
+                                                                 ",sign bits" if m.group(3) == "true" else "")
     m = re.match(r"(?:pws::)?wino_ring_kernel<(\d+),\s*(\d+),\s*(\d+)>", name)
     if m:   # persistent LDS-ring Winograd kernel (conv_wring.hip): mode, map geometry, ablation mask (0 in the product)
         return "wino_ring_kernel<%s%s%s>" % ({"0": "F(2x2,3x3)", "1": "convT4,F(2x2,2x2),2 classes per unit", "2": "convT4,F(2x2,2x2),1 class per unit"}[m.group(1)],
