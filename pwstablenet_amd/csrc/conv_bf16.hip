@@ -156,6 +156,13 @@ struct BfCfg {
                     w_.x = cvt_pk_bf16(v_[0], v_[1]), w_.y = cvt_pk_bf16(v_[2], v_[3]);                                    \
                     w_.z = cvt_pk_bf16(v_[4], v_[5]), w_.w = cvt_pk_bf16(v_[6], v_[7]);                                    \
                     *d_ = w_;                                                                                              \
+                    if ((p).ndst == 0 && (p).out_sign) { /* forward: the sign bits of the rounded values (ConvKParams.out_sign) */ \
+                        const unsigned m_ = (bf16_lo(w_.x) > 0.f ? 1u : 0u) | (bf16_hi(w_.x) > 0.f ? 2u : 0u) | (bf16_lo(w_.y) > 0.f ? 4u : 0u) | \
+                                            (bf16_hi(w_.y) > 0.f ? 8u : 0u) | (bf16_lo(w_.z) > 0.f ? 16u : 0u) | (bf16_hi(w_.z) > 0.f ? 32u : 0u) | \
+                                            (bf16_lo(w_.w) > 0.f ? 64u : 0u) | (bf16_hi(w_.w) > 0.f ? 128u : 0u);         \
+                        static_cast<unsigned char *>((p).out_sign)[((size_t)(n * (p).OH + oy) * (p).OW + ox) * (size_t)(p).out_sign_ld + (co_ >> 3)] = \
+                            (unsigned char)m_;                                                                             \
+                    }                                                                                                      \
                 }                                                                                                          \
             }                                                                                                              \
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                         \
@@ -712,11 +719,12 @@ int conv_skinny16_try(int kind, bool dgrad, ConvKParams &kp, int kchan, float *f
                       const ProfInfo &pi);   // conv_skinny16.hip (the deep levels, bf16 storage); 1 = not covered
 
 static int conv_bf16_fwd_rest(int kind, ConvKParams &kp, int cin_total, float *out, float *ws, size_t ws_floats, hipStream_t st,
-                              const ProfInfo &pi) {
+                              const ProfInfo &pi, bool *tiled) {
     if (kind != PWS_CONV_K5S1) {
         const int rc = conv_skinny16_try(kind, false, kp, cin_total, out, ws, ws_floats, st, pi);
         if (rc != 1) return rc;
     }
+    *tiled = true;
     switch (kind) {
     case PWS_CONV_K3S1:
     case PWS_CONVT_K3S1:
@@ -757,8 +765,10 @@ int conv_bf16_fwd(int kind, ConvKParams &kp, int cin_total, float *out, float *w
         const int rc = conv_ring_try(kind, false, kp, st, pi);   // (writes kp.out_sign itself)
         if (rc != 1) return rc;
     }
-    const int rc = conv_bf16_fwd_rest(kind, kp, cin_total, out, ws, ws_floats, st, pi);
+    bool tiled = false;   // conv_bf16_kernel / conv_bf16_k5_kernel ran (not the one-shot kernel)
+    const int rc = conv_bf16_fwd_rest(kind, kp, cin_total, out, ws, ws_floats, st, pi, &tiled);
     if (rc != PWS_OK || !kp.out_sign || !kp.io_bf16) return rc;
+    if (tiled && kp.epi16 && kp.ksplit <= 1) return rc;   // its 16-byte epilogue wrote the sign bytes (no split-K reduce in between)
     const size_t pixels = (size_t)kp.N * kp.OH * kp.OW, items = pixels * (size_t)(kp.cout / 8);
     hipLaunchKernelGGL(sign_bits_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const __bf16 *>(out), kp.out_ld, pixels,
                        kp.cout / 8, static_cast<unsigned char *>(kp.out_sign), kp.out_sign_ld);

@@ -320,10 +320,10 @@ class Exec {
         o.seg[0] = Seg{alloc((size_t)n_ * oh * ow * l.cout), l.cout, l.cout};
         // bf16 training: the layers whose backward multiplies by act'(this output) read its SIGN BITS instead of the tensor (1/16 of the
         // bytes: the data-gradient epilogues of the large maps are read-modify-writes waiting on their loads).  Asked of the maps the
-        // ring kernel takes (it writes them in its epilogue; another kernel is followed by a pass over the output), not of the first
-        // layer (5x5 kernel) -- PWS_OPT_EXPERIMENT 12: never.
+        // ring kernel takes and the first layer (they write them in their epilogues; the one-shot kernel and split-K launches are followed
+        // by a pass over the output) -- PWS_OPT_EXPERIMENT 12: never.
         // (The arena holds the bytes in every training layout -- the workspace size does not depend on the storage mode.)
-        if (training_ && !bn_on_ && nchw_c == 0 && act != PWS_ACT_NONE && l.cout % 8 == 0 && ow >= 32) {
+        if (training_ && !bn_on_ && act != PWS_ACT_NONE && l.cout % 8 == 0 && ow >= 32) {
             unsigned char *sg = reinterpret_cast<unsigned char *>(alloc(((size_t)n_ * oh * ow * (l.cout / 8) + 3) / 4));
             if (io16_ && g_experiment != 12) o.seg[0].sign = sg;
         }
