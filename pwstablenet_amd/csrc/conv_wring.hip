@@ -599,21 +599,36 @@ int wring_try(const pws_conv_args *a, const ProfHint &ph, hipStream_t st) {
     p.ncob = (unsigned)(a->cout / 32), p.ncls = ct4 ? 2u : 1u;
     const unsigned tiles = (unsigned)(p.tiles_x * p.tiles_y) * (unsigned)(g16 ? a->n / 2 : a->n);
     unsigned units1 = tiles * p.ncob * p.ncls;
-    // transposed kind: one class per unit (MODE 2) when the two-class units leave CUs without work (PWS_OPT_EXPERIMENT 59 forces it)
-    const bool mode2 = ct4 && ((units1 < (unsigned)ncu && g_experiment != 60) || g_experiment == 59);
-    if (mode2) p.ncls = 4, units1 *= 2;
     p.nchunks = cin / 16;
-    // K split over units when there are still fewer units than CUs: the smallest divisor of the chunk count that fills the chip (at most
-    // 8 splits, at least 4 chunks per unit), partial sums through the caller's workspace (PWS_OPT_EXPERIMENT 62: never split)
+    // K split over units when there are fewer units than CUs: the smallest divisor of the chunk count that fills the chip (at most 8
+    // splits, at least 4 chunks per unit), partial sums through the caller's workspace (PWS_OPT_EXPERIMENT 62: never split)
     const size_t out_floats = (size_t)a->n * (ct4 ? 4 : 1) * a->h * a->w * a->cout;
-    int ksplit = 1;
-    if (units1 < (unsigned)ncu && a->ws && g_experiment != 62) {
-        for (int k = 2; k <= 8; ++k) {
-            if (p.nchunks % k != 0 || p.nchunks / k < 4 || (size_t)k * out_floats * 4 > a->ws_bytes) continue;
-            ksplit = k;
-            if (units1 * (unsigned)k >= (unsigned)ncu) break;
+    auto split_for = [&](unsigned units) {   // 1 = none needed / none possible
+        int ks = 1;
+        if (units < (unsigned)ncu && a->ws && g_experiment != 62) {
+            for (int k = 2; k <= 8; ++k) {
+                if (p.nchunks % k != 0 || p.nchunks / k < 4 || (size_t)k * out_floats * 4 > a->ws_bytes) continue;
+                ks = k;
+                if (units * (unsigned)k >= (unsigned)ncu) break;
+            }
         }
+        return ks;
+    };
+    // transposed kind with two-class units that leave CUs without work: one class per unit (MODE 2: twice the units, twice the raw-tile
+    // DMA per matrix instruction) or a deeper K split of the two-class units.  Measured at batch 8 (tools/layer_profile.py): the split
+    // wins where MODE 2 would have to split as well (1024 -> 256 @16^2: 115 -> 101 us) or where its units keep >= 32 chunks
+    // (1024 -> 128 @32^2: 187 -> 178 us); MODE 2 without any split wins over a split to 16 chunks (512 -> 128 @32^2: 100 vs 103 us).
+    // (PWS_OPT_EXPERIMENT 59 forces MODE 2, 60 forbids it, 63 = the rule before: MODE 2 whenever the two-class units do not fill the chip)
+    bool mode2 = false;
+    if (ct4 && units1 < (unsigned)ncu) {
+        const int k1 = split_for(units1), k2 = split_for(units1 * 2);
+        const bool split1_fills = units1 * (unsigned)k1 >= (unsigned)ncu;
+        mode2 = g_experiment == 63 || !(split1_fills && (k2 > 1 || p.nchunks / k1 >= 32));
     }
+    if (g_experiment == 60) mode2 = false;
+    if (ct4 && g_experiment == 59) mode2 = true;
+    if (mode2) p.ncls = 4, units1 *= 2;
+    const int ksplit = split_for(units1);
     p.ksplit = ksplit, p.cps = p.nchunks / ksplit, p.split_stride = out_floats;
     p.nunits = units1 * (unsigned)ksplit;
     if (ksplit > 1) p.out = static_cast<float *>(a->ws);

@@ -348,7 +348,7 @@ class Exec {
         a.w_wino = l.ww_off != (size_t)-1 ? packed_ + l.ww_off : nullptr;
         a.w_wring = l.wr_off != (size_t)-1 ? packed_ + l.wr_off : nullptr;
         a.out = bn_on_ ? op.aux[0] : o.seg[0].ptr, a.out_ld = l.cout;
-        a.ws = q_ ? splitk_ws2_ : splitk_ws_, a.ws_bytes = splitk_bytes_;
+        a.ws = q_ ? splitk_ws2_ : splitk_ws_, a.ws_bytes = math_ == PWS_MATH_FP32 ? splitk_big_ : splitk_bytes_;
         if (math_ == PWS_MATH_BF16 && l.wb_off != (size_t)-1) a.math = PWS_MATH_BF16, a.w_bf16 = packed_ + l.wb_off;
         a.store = store();
         a.out_sign = o.seg[0].sign, a.out_sign_ld = l.cout / 8;
@@ -439,11 +439,15 @@ class Exec {
     void reserve_scratch(int ngf, bool training) {
         training_ = training;
         splitk_bytes_ = (size_t)(n_ > 8 ? n_ : 8) * (2u << 20);
-        splitk_ws_ = alloc(splitk_bytes_ / sizeof(float));
-        splitk_ws2_ = alloc(splitk_bytes_ / sizeof(float));  // one scratch per queue: the two run concurrently
+        // fp32 inference: four times that -- the Winograd ring kernel's two-class units of the transposed layers on 16 x 16 / 32 x 32 maps
+        // split K four ways (33 MB of partial sums at batch 8; conv_wring.hip).  The bf16 kernels keep the smaller bound: deeper splits
+        // of their small maps measured slower (configs[2] step +0.17 ms)
+        splitk_big_ = training ? splitk_bytes_ : 4 * splitk_bytes_;
+        splitk_ws_ = alloc(splitk_big_ / sizeof(float));
+        splitk_ws2_ = alloc(splitk_big_ / sizeof(float));  // one scratch per queue: the two run concurrently
         theta_ws_ = alloc(pws_theta_head_ws_floats(n_, 4 * ngf, 8 * ngf));
         theta_ws2_ = alloc(pws_theta_head_ws_floats(n_, 4 * ngf, 8 * ngf));
-        if (!splitk_ws_ || !splitk_ws2_) splitk_bytes_ = 0;
+        if (!splitk_ws_ || !splitk_ws2_) splitk_bytes_ = 0, splitk_big_ = 0;
         for (int s = 0; s < 3; ++s) h_saved_[s] = training ? alloc((size_t)n_ * 8 * ngf) : nullptr;
         x_nhwc_ = alloc((size_t)n_ * 256 * 256 * 32);  // bf16 math: NHWC copy of the window (unused in fp32 math)
         theta_x32_[0] = alloc((size_t)n_ * 16 * ngf), theta_x32_[1] = alloc((size_t)n_ * 16 * ngf);  // bf16 storage: fp32 copy of x_s8
@@ -468,7 +472,7 @@ class Exec {
     SideStream *side_ = nullptr;
     hipStream_t streams_[2];
     int q_ = 0;
-    size_t splitk_bytes_ = 0;
+    size_t splitk_bytes_ = 0, splitk_big_ = 0;
     const float *packed_;
     const std::vector<Layer> &L_;
     int n_;
