@@ -439,10 +439,10 @@ class Exec {
     void reserve_scratch(int ngf, bool training) {
         training_ = training;
         splitk_bytes_ = (size_t)(n_ > 8 ? n_ : 8) * (2u << 20);
-        // fp32 inference: four times that -- the Winograd ring kernel's two-class units of the transposed layers on 16 x 16 / 32 x 32 maps
+        // fp32 math: four times that -- the Winograd ring kernel's two-class units of the transposed layers on 16 x 16 / 32 x 32 maps
         // split K four ways (33 MB of partial sums at batch 8; conv_wring.hip).  The bf16 kernels keep the smaller bound: deeper splits
         // of their small maps measured slower (configs[2] step +0.17 ms)
-        splitk_big_ = training ? splitk_bytes_ : 4 * splitk_bytes_;
+        splitk_big_ = 4 * splitk_bytes_;   // (training forwards in fp32 as well: netG(x, False) stays bit-equal to netG(x)[0][2], reference :237)
         splitk_ws_ = alloc(splitk_big_ / sizeof(float));
         splitk_ws2_ = alloc(splitk_big_ / sizeof(float));  // one scratch per queue: the two run concurrently
         theta_ws_ = alloc(pws_theta_head_ws_floats(n_, 4 * ngf, 8 * ngf));
