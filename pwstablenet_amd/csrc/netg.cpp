@@ -509,12 +509,15 @@ static void forward_graph(Exec &E, const float *x, int n, int input_nc, int g, i
     Tn x23 = E.down_bottom(2, &x22, x12), x24 = E.down_bottom(3, &x23, x13), x25 = E.down_bottom(4, &x24, x14);
     E.use(0);
     Tn x16 = E.down(5, x15), x17 = E.down(6, x16), x18 = E.down(7, x17);
-    if (is_training) E.theta(x18, 0, th1);
     E.order(0, 1);  // x16..x18
+    // (the theta heads are needed by the field heads only: they are issued BEHIND the marks the other queue waits for -- 30 us of
+    //  GEMV launches off the critical path of every stage)
+    if (is_training) E.theta(x18, 0, th1);
     E.use(1);
     Tn x26 = E.down_bottom(5, &x25, x15), x27 = E.down_bottom(6, &x26, x16), x28 = E.down_bottom(7, &x27, x17);
-    if (is_training) E.theta(x28, 1, th2);
     hipEvent_t enc2_done = E.mark(1);
+    if (is_training) E.theta(x28, 1, th2);
+    hipEvent_t th2_done = is_training ? E.mark(1) : nullptr;
     // ---- stage 1 decoder (reference :166-174) on queue 0, beside the stage-2 encoder
     E.use(0);
     Tn x177 = E.up(7, x18, &x17), x166 = E.up(6, x177, &x16), x155 = E.up(5, x166, &x15);
@@ -528,8 +531,9 @@ static void forward_graph(Exec &E, const float *x, int n, int input_nc, int g, i
     const Tn &x32 = x22;
     Tn x33 = E.down_bottom(2, &x32, x22), x34 = E.down_bottom(3, &x33, x23), x35 = E.down_bottom(4, &x34, x24);
     Tn x36 = E.down_bottom(5, &x35, x25), x37 = E.down_bottom(6, &x36, x26), x38 = E.down_bottom(7, &x37, x27);
-    E.theta(x38, 2, th3);
     hipEvent_t enc3_done = E.mark(1);
+    E.theta(x38, 2, th3);
+    hipEvent_t th3_done = E.mark(1);
     // ---- stage 2 decoder (reference :190-198) on queue 0, beside the stage-3 encoder: waits for stage 2's encoder only
     E.wait(0, enc2_done);
     E.use(0);
@@ -538,6 +542,7 @@ static void forward_graph(Exec &E, const float *x, int n, int input_nc, int g, i
     Tn x233 = E.up_bottom(3, x144, x244, &x23), x222 = E.up_bottom(2, x133, x233, &x22);
     if (is_training) {
         Tn x211 = E.up_bottom(1, x122, x222, nullptr);
+        E.wait(0, th2_done);
         E.field(x211, 1, th2, ac, resid ? resid + gsz : nullptr, grids ? grids + gsz : nullptr);
     }
     // ---- stage 3 decoder (reference :212-219): joins queue 1 (nothing is issued there after this point)
@@ -546,6 +551,7 @@ static void forward_graph(Exec &E, const float *x, int n, int input_nc, int g, i
     Tn x355 = E.up_bottom(5, x266, x366, &x35), x344 = E.up_bottom(4, x255, x355, &x34);
     Tn x333 = E.up_bottom(3, x244, x344, &x33), x322 = E.up_bottom(2, x233, x333, &x32);
     Tn x311 = E.up_bottom(1, x222, x322, nullptr);
+    E.wait(0, th3_done);
     if (is_training)
         E.field(x311, 2, th3, ac, resid ? resid + 2 * gsz : nullptr, grids ? grids + 2 * gsz : nullptr);
     else
