@@ -532,23 +532,41 @@ static void forward_graph(Exec &E, const float *x, int n, int input_nc, int g, i
     Tn x33 = E.down_bottom(2, &x32, x22), x34 = E.down_bottom(3, &x33, x23), x35 = E.down_bottom(4, &x34, x24);
     Tn x36 = E.down_bottom(5, &x35, x25), x37 = E.down_bottom(6, &x36, x26), x38 = E.down_bottom(7, &x37, x27);
     hipEvent_t enc3_done = E.mark(1);
-    E.theta(x38, 2, th3);
-    hipEvent_t th3_done = E.mark(1);
     // ---- stage 2 decoder (reference :190-198) on queue 0, beside the stage-3 encoder: waits for stage 2's encoder only
     E.wait(0, enc2_done);
     E.use(0);
     Tn x277 = E.up_bottom(7, x18, x28, &x27), x266 = E.up_bottom(6, x177, x277, &x26);
-    Tn x255 = E.up_bottom(5, x166, x266, &x25), x244 = E.up_bottom(4, x155, x255, &x24);
+    Tn x255 = E.up_bottom(5, x166, x266, &x25);
+    hipEvent_t dec2_deep = E.mark(0);
+    // ---- stage 3 decoder (reference :212-219), deep levels: on queue 1 behind the stage-3 encoder, beside the LARGE levels of the stage-2
+    // decoder on queue 0 (nine latency-bound launches on <= 8 x 8 maps under three chip-filling ones); PWS_OPT_EXPERIMENT 14: on queue 0
+    // after the whole stage-2 decoder, as before
+    const bool deep_on_q1 = g_experiment != 14 && !E.bn_on();
+    Tn x377{}, x366{}, x355{};
+    hipEvent_t dec3_deep = nullptr;
+    if (deep_on_q1) {
+        E.use(1);
+        E.wait(1, dec2_deep);
+        x377 = E.up_bottom(7, x28, x38, &x37), x366 = E.up_bottom(6, x277, x377, &x36), x355 = E.up_bottom(5, x266, x366, &x35);
+        dec3_deep = E.mark(1);
+        E.use(0);
+    }
+    Tn x244 = E.up_bottom(4, x155, x255, &x24);
     Tn x233 = E.up_bottom(3, x144, x244, &x23), x222 = E.up_bottom(2, x133, x233, &x22);
     if (is_training) {
         Tn x211 = E.up_bottom(1, x122, x222, nullptr);
         E.wait(0, th2_done);
         E.field(x211, 1, th2, ac, resid ? resid + gsz : nullptr, grids ? grids + gsz : nullptr);
     }
-    // ---- stage 3 decoder (reference :212-219): joins queue 1 (nothing is issued there after this point)
+    E.use(1);
+    E.theta(x38, 2, th3);   // (behind everything the other queue waits for)
+    hipEvent_t th3_done = E.mark(1);
+    E.use(0);
+    // ---- stage 3 decoder, large levels: joins queue 1 (nothing is issued there after the theta head)
     E.wait(0, enc3_done);
-    Tn x377 = E.up_bottom(7, x28, x38, &x37), x366 = E.up_bottom(6, x277, x377, &x36);
-    Tn x355 = E.up_bottom(5, x266, x366, &x35), x344 = E.up_bottom(4, x255, x355, &x34);
+    if (deep_on_q1) E.wait(0, dec3_deep);
+    else x377 = E.up_bottom(7, x28, x38, &x37), x366 = E.up_bottom(6, x277, x377, &x36), x355 = E.up_bottom(5, x266, x366, &x35);
+    Tn x344 = E.up_bottom(4, x255, x355, &x34);
     Tn x333 = E.up_bottom(3, x244, x344, &x33), x322 = E.up_bottom(2, x233, x333, &x32);
     Tn x311 = E.up_bottom(1, x222, x322, nullptr);
     E.wait(0, th3_done);
