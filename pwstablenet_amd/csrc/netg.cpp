@@ -643,6 +643,26 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
     }
     const size_t T = E.tape().size();
     const size_t r_begin = T * (size_t)part / nparts, r_end = T * (size_t)(part + 1) / nparts;  // reversed positions of this run
+    // Weight gradients are leaves of the backward graph (only the optimizer reads them): they run on the side queue, each behind an
+    // event recorded where its dy is final, while this queue goes on with the data-gradient chain -- whose deep levels are ~100
+    // latency-bound launches that then sit beside chip-filling weight-gradient kernels instead of between them.  The queues join at
+    // the end of the call.  (PWS_OPT_EXPERIMENT 16 or two_queues == 0: one queue, as before.)
+    hipStream_t wst = st;
+    SideStream *wside = nullptr;
+    if (mode.two_queues && g_experiment != 16) {
+        wside = &side_stream();
+        if (wside->init()) wst = wside->stream, wside->next = 0;
+        else wside = nullptr;
+    }
+    auto wgrad_fork = [&]() -> int {   // the side queue waits for everything issued on `st` so far
+        if (wst == st) return PWS_OK;
+        hipEvent_t e = wside->event();
+        if (!e || hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(wst, e, 0) != hipSuccess) {
+            set_error("pws_netg_backward: event record / wait on the weight-gradient queue failed");
+            return PWS_EHIP;
+        }
+        return PWS_OK;
+    };
     if (final_mask) {
         // a layer is final once every op that uses it lies at a reversed position < r_end
         for (int i = 0; i < L_COUNT; ++i) final_mask[i] = 1;
@@ -789,7 +809,8 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
                 if (rc != PWS_OK) break;
                 wa.dbias = nullptr;
             }
-            rc = pws_conv2d_bwd_weight(&wa, st);
+            rc = wgrad_fork();
+            if (rc == PWS_OK) rc = pws_conv2d_bwd_weight(&wa, wst);
             if (rc != PWS_OK || op.nchw) {
                 g_prof_tag = -1;
                 continue;  // the window is data: no gradient wrt the first layer's input
@@ -811,6 +832,12 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             da.store = E.store();
             rc = pws_conv2d_bwd_data(&da, st);
             g_prof_tag = -1;
+        }
+    }
+    if (wst != st) {   // join: whatever follows on `st` (unpack, optimizer, the next part) sees every weight gradient
+        hipEvent_t e = wside->event();
+        if (!e || hipEventRecord(e, wst) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess) {
+            if (rc == PWS_OK) set_error("pws_netg_backward: joining the weight-gradient queue failed"), rc = PWS_EHIP;
         }
     }
     return rc;
