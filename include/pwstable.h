@@ -8,8 +8,9 @@
  * Return value: 0 on success, negative errno-style code otherwise (pws_last_error() has the text).
  * Re-entrant per stream and per thread.  Global mutable state: the thread-local error string, the process-wide DEFAULTS of
  * pws_set_option() (read only by the entry points that take no pws_netg_opts; the *_opts entry points carry math / store / queue
- * mode in their arguments and read no global), the per-(thread, device) side queue of the generator forward and the
- * measurement hooks (pws_prof_*, off by default).
+ * mode in their arguments and read no global), the per-device side queue of the generator forward / backward (one stream per device
+ * and process, shared by the host threads; every thread owns the events it orders it with, and a call that finds the queue inside
+ * another thread's graph capture runs on the caller's stream alone) and the measurement hooks (pws_prof_*, off by default).
  *
  * Reference interfaces replaced (paths relative to the mindazhao/PWStableNet checkout; the reference has
  * no native code -- each entry point replaces the PyTorch/ATen op the reference dispatches at that line):

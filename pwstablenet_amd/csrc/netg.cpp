@@ -15,6 +15,7 @@
 // buffers of the layer's sources (first consumer overwrites, later consumers accumulate -- no zero-fill pass).
 // No allocation, no synchronisation: every launch is ordered after the caller's `stream`; the forward forks an internal
 // second queue by events (stage k+1's encoder beside stage k's decoder) and joins it back before returning.
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 
@@ -197,14 +198,37 @@ struct BnCfg {
 // Second in-order queue for the branch of the forward that does not depend on the current one (stage k+1's encoder
 // runs beside stage k's decoder), plus the events that fork / join it.  Created lazily once per process (the only
 // runtime objects this library owns); ordering against the caller's stream is by events only, never by a sync.
+// The side QUEUE is one per device and process: the runtime deals streams to a few hardware queues round-robin, and a second side
+// stream made late in a process with several streams alive (the backward's, on autograd's thread, in bench.py after its streaming
+// leg) landed on the caller's hardware queue -- the two then serialise, barrier packets on top (configs[2] step 32.3 ms instead of
+// 30.1; tools/_bin-style probe: 5 extra torch streams reproduce it).  So every host thread shares the stream made first; what a
+// thread owns is its EVENT POOL.  A call that finds the queue inside somebody else's graph capture runs on one queue.
+static hipStream_t shared_side_queue(int dev) {
+    static std::mutex m;
+    static std::unordered_map<int, hipStream_t> per_device;
+    std::lock_guard<std::mutex> lock(m);
+    auto it = per_device.find(dev);
+    if (it != per_device.end()) return it->second;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+    per_device[dev] = s;
+    return s;
+}
 struct SideStream {
     hipStream_t stream = nullptr;
     std::vector<hipEvent_t> events;
     size_t next = 0;
     bool ok = false;
+    int dev = 0;
     bool init() {
-        if (!stream) ok = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess;
+        if (!stream) stream = shared_side_queue(dev), ok = stream != nullptr;
         return ok;
+    }
+    // usable beside `st` now: not part of a graph capture that `st` does not belong to
+    bool free_for(hipStream_t st) const {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone, cm = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess || hipStreamIsCapturing(st, &cm) != hipSuccess) return false;
+        return cs == hipStreamCaptureStatusNone || cm != hipStreamCaptureStatusNone;
     }
     hipEvent_t event() {
         if (next == events.size()) {
@@ -215,12 +239,14 @@ struct SideStream {
         return events[next++];
     }
 };
-// one per host thread AND device: a thread that drives two GPUs, or two threads on one GPU, never share a queue or an event pool
+// one event pool per host thread AND device
 static SideStream &side_stream() {
     static thread_local std::unordered_map<int, SideStream> per_device;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    return per_device[dev];
+    SideStream &s = per_device[dev];
+    s.dev = dev;
+    return s;
 }
 
 class Exec {
@@ -239,7 +265,7 @@ class Exec {
         streams_[0] = st, streams_[1] = st;
         if (launch_ && o.two_queues) {
             side_ = &side_stream();
-            if (side_->init()) streams_[1] = side_->stream, side_->next = 0;
+            if (side_->init() && side_->free_for(st)) streams_[1] = side_->stream, side_->next = 0;
         }
     }
 
@@ -651,7 +677,7 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
     SideStream *wside = nullptr;
     if (mode.two_queues && g_experiment != 16) {
         wside = &side_stream();
-        if (wside->init()) wst = wside->stream, wside->next = 0;
+        if (wside->init() && wside->free_for(st)) wst = wside->stream, wside->next = 0;
         else wside = nullptr;
     }
     auto wgrad_fork = [&]() -> int {   // the side queue waits for everything issued on `st` so far
