@@ -467,7 +467,9 @@ int pws_netg_forward(const float *packed, const float *x, int n, int input_nc, i
 typedef struct pws_netg_opts {
     int math;       /* PWS_MATH_FP32 / PWS_MATH_BF16 */
     int store;      /* PWS_STORE_FP32 / PWS_STORE_BF16 (needs PWS_MATH_BF16 and ngf % 32 == 0) */
-    int two_queues; /* 1: fork the internal second queue (stage k+1 encoder beside stage k decoder); 0: caller's stream only;
+    int two_queues; /* 1: fork the internal second queue (forward: stage k+1 encoder and the last stage's deep decoder levels beside
+                       stage k's decoder; backward: every weight gradient beside the data-gradient chain; the queues join before the
+                       call's last launch on the caller's stream / at the end of the call); 0: caller's stream only;
                        -1: the process default (PWS_OPT_TWO_QUEUES) */
     int flags;      /* bit set of PWS_NETG_*; unknown bits are refused */
     size_t x_sample_stride; /* floats between consecutive samples of the window tensor x; 0 = dense (input_nc * 256 * 256).  The
