@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the bf16 inference / training-step legs (extra JSON fields)")
     ap.add_argument("--ddp-items", type=int, default=32, help="item pairs per GPU per step of the N>1 training leg (configs[3]: 32)")
     ap.add_argument("--stream-frames", type=int, default=128, help="720p frames per GPU of the N>1 streaming leg (configs[4])")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="--gpus 1 only: initialise a ONE-rank RCCL group and run the training_ddp leg with its collectives forced "
+                         "(first contact with RCCL on a single GPU; rccl_ranks = 1 in the line)")
     return ap.parse_args()
 
 
@@ -393,6 +396,15 @@ def main():
             return
     else:
         torch.cuda.set_device(0)
+        if a.force_collectives:
+            # a group of ONE rank over RCCL, made exactly as the N > 1 branch makes its group
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29547")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", 0), rank=0, world_size=1)
+            ctl_device = torch.device("cuda", 0)
+            control_plane = "rccl (one-rank group: --force-collectives)"
+    force = bool(a.force_collectives) and world == 1
     dev = torch.device("cuda", torch.cuda.current_device())
 
     from pwstablenet_amd import functional as PF
@@ -487,7 +499,7 @@ def main():
         line = {
             "metric": "stabilized frames/sec at 256x256 (netG %s + grid_sample), whole job" % a.math,
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world,
-            "rccl_ranks": dist.get_world_size() if world > 1 and dist.get_backend() == "nccl" else (1 if world == 1 else 0),
+            "rccl_ranks": dist.get_world_size() if dist.is_initialized() and dist.get_backend() == "nccl" else 0,
             "control_plane": control_plane, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if a.math == "fp32" else "bf16 operands, f32 accumulate", "data": "synthetic",
@@ -788,7 +800,7 @@ def main():
             line["bf16"] = bf16_legs(net, x, frames, out, a, PF, A, synth)
     else:
         line = None
-    if world > 1 and not a.no_extra:
+    if (world > 1 and not a.no_extra) or force:
         # configs[3] on this node: 32 item pairs per GPU per step, replicas + ONE flat-bucket RCCL all-reduce of the 48.5 M
         # gradients per step.  Every rank takes part; a watchdog keeps a stuck collective from costing the headline.
         import threading
@@ -815,6 +827,8 @@ def main():
         # pinned host memory to pinned host memory (VideoStabilizer.run_video: frames up, window planes + generator + fused warp
         # + 2x down-scale on the device, 640x360 frames down); no collective, the host's PCIe / memory system is shared
         try:
+            if world == 1:
+                raise StopIteration   # --force-collectives: the training leg only
             from pwstablenet_amd.stream import VideoStabilizer
             Ts = a.stream_frames
             net.module.enable_graph(False)
@@ -836,60 +850,66 @@ def main():
                                                             "(batch %d), fused u8 warp, 2x INTER_AREA -> pinned host; frame-sharded, no "
                                                             "collective" % (Ts, B)}
             del u8_h, out_h, vs
+        except StopIteration:
+            pass
         except Exception as e:
             if rank == 0:
                 line["value_720p_stream_u8"] = {"error": str(e)[:300]}
         try:
             from pwstablenet_amd import distributed as D
-            nbytes = [0]
-
-            def sync(params):
-                nbytes[0] = sum(p.grad.numel() * 4 for p in params if p.grad is not None)
-                D.allreduce_gradients(params)
             dist.barrier()
             NI = a.ddp_items
-            dt, loss = configs2_step_leg(net, dev, NI, "bf16", 3, sync=sync, seed=500 + rank)
-            t = torch.tensor([dt], device=ctl_device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-            # the same step with the exchange overlapped with backward (distributed.OverlappedGradSync: backward in 4 runs, the
-            # gradients that are final after each run are all-reduced on a second stream while the next run computes)
-            gs = D.enable_overlapped_grad_sync(net, nparts=4)
-            dist.barrier()
-            dt_ov, _ = configs2_step_leg(net, dev, NI, "bf16", 3, sync=None, seed=500 + rank)
-            ncoll = gs.collectives
-            net.module.grad_sync = None
-            t = torch.tensor([dt_ov], device=ctl_device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt_ov = float(t.item())
-            # the collective alone, same buckets, for the xGMI bus-bandwidth figure
-            flat = torch.zeros(nbytes[0] // 4, device=dev)
-            dist.all_reduce(flat)
+            grad_bytes = 4 * A.lib().pws_netg_grad_floats(31, 64)
+
+            def timed(nparts):
+                # the exchange lives in the generator's backward: the gradient SLAB (one flat buffer in the kernels' layout) is
+                # averaged in place -- whole (nparts = 1: after backward) or range by range as the backward's runs finish layers
+                # (nparts = 4: overlapped, on a second stream) -- and unpacked once; no flatten, no copy back
+                gs = D.enable_overlapped_grad_sync(net, nparts=nparts, force=force)
+                dist.barrier()
+                dt_, loss_ = configs2_step_leg(net, dev, NI, "bf16", 3, sync=None, seed=500 + rank)
+                ncoll_, moved_ = gs.collectives, gs.bytes_reduced
+                net.module.grad_sync = None
+                t_ = torch.tensor([dt_], device=ctl_device, dtype=torch.float64)
+                dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+                return float(t_.item()), loss_, ncoll_, moved_
+            dt, loss, ncoll_after, moved = timed(1)
+            dt_ov, _, ncoll, moved_ov = timed(4)
+            assert moved == grad_bytes and moved_ov == grad_bytes, (moved, moved_ov, grad_bytes)
+            # the step WITHOUT any exchange on the same box (what the exchange adds), and the collective alone, same message
+            # sizes, for the xGMI bus-bandwidth figure
+            dt_none, _ = configs2_step_leg(net, dev, NI, "bf16", 3, sync=None, seed=500 + rank)
+            flat = torch.zeros(grad_bytes // 4, device=dev)
+            D.allreduce_slab(flat, [(0, flat.numel())], force=force)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(5):
-                dist.all_reduce(flat)
+                D.allreduce_slab(flat, [(0, flat.numel())], force=force)
             torch.cuda.synchronize()
             ar = (time.perf_counter() - t1) / 5
+            del flat
             if rank == 0:
                 line["training_ddp"] = {
                     "workload": "configs[3]: %d item pairs per GPU per step (%d netG forwards + objective + backward), bf16 math, "
-                                "gradient all-reduce over %s in 64 MB flat buckets, fused Adam; weak scaling"
-                                % (NI, 2 * NI, "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (test hook)"),
-                    "items_per_gpu_per_step": NI,
+                                "the %.1f MB gradient slab averaged IN PLACE over %s (ReduceOp.AVG on views of the slab, 64 MB messages), "
+                                "one unpack, fused Adam; weak scaling"
+                                % (NI, 2 * NI, grad_bytes / 1e6, "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (test hook)"),
+                    "items_per_gpu_per_step": NI, "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
+                    "collectives_forced_in_one_rank_group": force,
                     "items_per_s": round(world * NI / min(dt, dt_ov), 1), "ms_per_step": round(1e3 * min(dt, dt_ov), 2),
-                    "ms_per_step_allreduce_after_backward": round(1e3 * dt, 2),
+                    "ms_per_step_allreduce_after_backward": round(1e3 * dt, 2), "collectives_per_step_after_backward": ncoll_after,
                     "ms_per_step_allreduce_overlapped": round(1e3 * dt_ov, 2), "overlapped_collectives_per_step": ncoll,
+                    "ms_per_step_no_exchange": round(1e3 * dt_none, 2),
                     "tflops_per_gpu": round(2 * NI / min(dt, dt_ov) * GFLOP_PER_SAMPLE_TRAIN / 1e3, 1), "loss_g_rank0": round(loss, 4),
-                    "allreduce_bytes": nbytes[0], "allreduce_alone_ms": round(1e3 * ar, 3),
-                    "allreduce_bus_gb_per_s": round(2.0 * (world - 1) / world * nbytes[0] / ar / 1e9, 1)}
+                    "allreduce_bytes": grad_bytes, "extra_passes_over_the_gradients": 0, "allreduce_alone_ms": round(1e3 * ar, 3),
+                    "allreduce_bus_gb_per_s": round(2.0 * (world - 1) / world * grad_bytes / ar / 1e9, 1)}
         except Exception as e:
             if rank == 0:
                 line["training_ddp"] = {"error": str(e)[:300]}
         done.set()
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

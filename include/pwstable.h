@@ -40,7 +40,8 @@
 extern "C" {
 #endif
 
-#define PWS_VERSION 3   /* 2: pws_netg_opts carries flags + x_sample_stride (round 3) */
+#define PWS_VERSION 4   /* 2: pws_netg_opts carries flags + x_sample_stride (round 3); 4: dpacked is the compact gradient slab
+                          (pws_netg_grad_floats / pws_netg_grad_layout), pws_netg_backward_lists (round 4) */
 
 #define PWS_OK 0
 #define PWS_EINVAL (-22) /* bad argument / unsupported shape */
@@ -486,10 +487,18 @@ int pws_netg_forward_opts(const float *packed, const float *x, int n, int input_
 /* ---- training: backward of the whole generator (is_training=1 forward must have run on the SAME ws, untouched since).
  * Data-gradient weights: a second packed buffer (pws_netg_packed_dgrad_floats) filled by pws_netg_pack_weights_dgrad.
  * g_grids / g_resid: [3][n,256,256,2] each, or NULL as a whole (no gradient wrt that output list).
- * dpacked: gradient of every weight and bias in the layout of `packed` (pws_netg_packed_floats floats), overwritten;
+ * dpacked: the GRADIENT SLAB (pws_netg_grad_floats floats, overwritten): per layer in state-dict order the weight gradient in the
+ * forward packed layout with the bias gradient behind it and nothing else (no Winograd / bf16 copies as in `packed`), so that a
+ * data-parallel host all-reduces the slab -- or the ranges pws_netg_grad_layout reports for the layers a run finished -- IN PLACE
+ * (replaces nn.DataParallel's reduce to GPU 0, lib/networks_cascading.py:51-52) and unpacks once;
  * pws_netg_unpack_grads converts it to 92 torch-layout tensors.  dx (nullable): gradient wrt the input window is not
  * needed by the reference (the window is data) and is not computed. */
 size_t pws_netg_packed_dgrad_floats(int input_nc, int ngf);
+size_t pws_netg_grad_floats(int input_nc, int ngf);
+/* first_float[46], floats[46] (HOST): the contiguous range of the gradient slab that holds layer i's weight + bias gradient (with
+ * its alignment padding, which stays zero); consecutive layers abut, so the layers a backward run reports final merge into a few
+ * large ranges. */
+int pws_netg_grad_layout(int input_nc, int ngf, size_t *first_float, size_t *floats);
 int pws_netg_pack_weights_dgrad(const float *const *params, float *packed_dgrad, int input_nc, int ngf,
                                 pws_stream_t stream);
 size_t pws_netg_train_workspace_bytes(int n, int input_nc, int ngf);
@@ -510,6 +519,13 @@ int pws_netg_backward_opts(const float *packed, const float *packed_dgrad, const
                            int align_corners, void *ws, size_t ws_bytes, const float *resid, const float *thetas,
                            const float *g_grids, const float *g_resid, float *dpacked, int part, int nparts,
                            unsigned char *final_mask, const pws_netg_opts *opts, pws_stream_t stream);
+/* pws_netg_backward_opts with the six upstream gradients as two HOST arrays of 3 DEVICE pointers ([n,256,256,2] each; an entry, or a
+ * whole array, may be NULL: that output has no gradient) -- autograd hands them over as separate tensors (main_new.py:214), so no
+ * stacked copy and no zero-filled stand-ins are needed. */
+int pws_netg_backward_lists(const float *packed, const float *packed_dgrad, const float *x, int n, int input_nc, int ngf,
+                            int align_corners, void *ws, size_t ws_bytes, const float *resid, const float *thetas,
+                            const float *const *g_grids, const float *const *g_resid, float *dpacked, int part, int nparts,
+                            unsigned char *final_mask, const pws_netg_opts *opts, pws_stream_t stream);
 /* ---- use_BN=True training (lib/cfg.py:37; lib/networks_cascading.py:253-341: BatchNorm2d after every conv, batch statistics).
  * bn_params / bn_running / dbn: flat buffers of pws_netg_bn_floats() floats, per layer in state-dict order
  * [gamma(cout) | beta(cout)], [running_mean | running_var], [dgamma | dbeta].  The forward is the is_training one (6 fields) and

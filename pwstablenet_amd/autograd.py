@@ -32,15 +32,18 @@ class _NetGTrain(torch.autograd.Function):
             raise RuntimeError("pwstablenet_amd: backward through the generator twice (the activation arena was released)")
         n = sv["x"].shape[0]
         dev = sv["x"].device
-
-        def stack(gs):
-            if all(g is None for g in gs):
-                return None
-            return torch.stack([g.contiguous() if g is not None else torch.zeros((n, 256, 256, 2), device=dev) for g in gs])
-
-        g_grids, g_resid = stack(gouts[0:3]), stack(gouts[3:6])
-        if g_grids is None and g_resid is None:
+        # the six upstream gradients go over as two lists of pointers (pws_netg_backward_lists): no stacked copy, and an output
+        # nobody differentiated is a NULL entry instead of a zero-filled stand-in
+        keep = [None if g is None else g.contiguous() for g in gouts[:6]]
+        if all(g is None for g in keep):
             return (None, None) + (None,) * 92
+        for g in keep:
+            if g is not None:
+                A.require_cuda(g)
+                if tuple(g.shape) != (n, 256, 256, 2):
+                    raise RuntimeError("pwstablenet_amd: upstream gradient of shape %s for an (%d, 256, 256, 2) field" % (tuple(g.shape), n))
+        g_grids = (ctypes.c_void_p * 3)(*[None if g is None else g.data_ptr() for g in keep[0:3]])
+        g_resid = (ctypes.c_void_p * 3)(*[None if g is None else g.data_ptr() for g in keep[3:6]])
         L = A.lib()
         st = A.current_stream()
         # the packed weights are ONE buffer shared by every forward of this generator and re-packed in place when a parameter
@@ -51,52 +54,66 @@ class _NetGTrain(torch.autograd.Function):
                                "another forward after a change) between netG(x) and its backward; the packed weights of that "
                                "forward are gone -- call backward() before updating the parameters")
         packed, packed_dg = sv["packed"], net.packed_dgrad_weights()
-        dpacked = torch.empty_like(packed)
+        # the gradient slab: weight + bias gradients of the 46 layers in the kernels' layout and nothing else (195 MB at ngf 64);
+        # a data-parallel job all-reduces it IN PLACE and unpacks once
+        dpacked = torch.empty(L.pws_netg_grad_floats(net.input_nc, net.ngf), device=dev, dtype=torch.float32)
         opts = net._opts(sv.get("math", "fp32"), sv.get("store", "fp32"))  # the arena holds what the forward's mode wrote
         ac = sv.get("ac", 0)
         params = net._ordered_params()
         grads = [torch.empty_like(p) for p in params]
         sync = getattr(net, "grad_sync", None)
+
+        def run(part, nparts, mask):
+            A.check(L.pws_netg_backward_lists(A.ptr(packed), A.ptr(packed_dg), A.ptr(sv["x"]), n, net.input_nc, net.ngf, ac,
+                                              ctypes.c_void_p(sv["ws_ptr"]), sv["ws_bytes"], A.ptr(sv["resid"]), A.ptr(sv["thetas"]),
+                                              g_grids, g_resid, A.ptr(dpacked), part, nparts, mask, ctypes.byref(opts), st),
+                    "pws_netg_backward_lists")
+
         if sync is None or sync.nparts == 1:
-            A.check(L.pws_netg_backward_opts(A.ptr(packed), A.ptr(packed_dg), A.ptr(sv["x"]), n, net.input_nc, net.ngf, ac,
-                                             ctypes.c_void_p(sv["ws_ptr"]), sv["ws_bytes"], A.ptr(sv["resid"]), A.ptr(sv["thetas"]),
-                                             A.ptr(g_grids), A.ptr(g_resid), A.ptr(dpacked), 0, 1, None, ctypes.byref(opts), st),
-                    "pws_netg_backward_opts")
-            ptrs = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
-            A.check(L.pws_netg_unpack_grads(A.ptr(dpacked), ptrs, net.input_nc, net.ngf, st), "pws_netg_unpack_grads")
+            run(0, 1, None)
             if sync is not None:
                 sync.collectives = 0
-                sync.allreduce(grads)
+                sync.allreduce_slab(dpacked, [(0, dpacked.numel())])
+            ptrs = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+            A.check(L.pws_netg_unpack_grads(A.ptr(dpacked), ptrs, net.input_nc, net.ngf, st), "pws_netg_unpack_grads")
         else:
-            # overlapped gradient exchange (distributed.OverlappedGradSync): backward in runs; after each run the layers whose
-            # gradients are final are unpacked + all-reduced on the communication stream while the next run computes
+            # overlapped gradient exchange (distributed.OverlappedGradSync): backward in runs; after each run the slab ranges of the
+            # layers whose gradients are final are all-reduced in place and unpacked on the communication stream while the next
+            # run computes
             nl = len(params) // 2
+            first, count = net._grad_layout()
             main, comm = torch.cuda.current_stream(dev), sync.stream(dev)
             mask = (ctypes.c_ubyte * nl)()
             done = [False] * nl
             sync.collectives = 0
             for part in range(sync.nparts):
-                A.check(L.pws_netg_backward_opts(A.ptr(packed), A.ptr(packed_dg), A.ptr(sv["x"]), n, net.input_nc, net.ngf, ac,
-                                                 ctypes.c_void_p(sv["ws_ptr"]), sv["ws_bytes"], A.ptr(sv["resid"]),
-                                                 A.ptr(sv["thetas"]), A.ptr(g_grids), A.ptr(g_resid), A.ptr(dpacked), part,
-                                                 sync.nparts, mask, ctypes.byref(opts), st), "pws_netg_backward_opts")
+                run(part, sync.nparts, mask)
                 newly = [i for i in range(nl) if mask[i] and not done[i]]
                 if not newly:
                     continue
+                ranges = []   # consecutive layers abut in the slab: merge them into a few large messages
+                for i in newly:
+                    if ranges and ranges[-1][1] == first[i]:
+                        ranges[-1][1] = first[i] + count[i]
+                    else:
+                        ranges.append([first[i], first[i] + count[i]])
                 ready = torch.cuda.Event()
                 ready.record(main)
                 with torch.cuda.stream(comm):
                     comm.wait_event(ready)
+                    sync.allreduce_slab(dpacked, ranges)
                     ptrs = (ctypes.c_void_p * len(grads))()
                     for i in newly:
                         ptrs[2 * i], ptrs[2 * i + 1] = grads[2 * i].data_ptr(), grads[2 * i + 1].data_ptr()
                     A.check(L.pws_netg_unpack_grads(A.ptr(dpacked), ptrs, net.input_nc, net.ngf, A.current_stream()),
                             "pws_netg_unpack_grads")
-                    sync.allreduce([grads[k] for i in newly for k in (2 * i, 2 * i + 1)])
                 for i in newly:
                     done[i] = True
             assert all(done), "pws_netg_backward_part: a layer never became final"
             main.wait_stream(comm)
+            dpacked.record_stream(comm)
+            for g in grads:
+                g.record_stream(comm)
         ctx.saved = None  # release the arena
         return (None, None) + tuple(grads)
 
@@ -190,7 +207,7 @@ class _NetGTrainBN(torch.autograd.Function):
             return (None, None) + (None,) * (2 * nconv)
         L, st = A.lib(), A.current_stream()
         packed, packed_dg = sv["packed"], net.packed_dgrad_weights()
-        dpacked = torch.empty_like(packed)
+        dpacked = torch.empty(L.pws_netg_grad_floats(net.input_nc, net.ngf), device=dev, dtype=torch.float32)
         dbn = torch.empty_like(sv["bn_params"])
         opts = net._opts(sv["math"], "fp32")   # the arena holds what the forward's mode wrote
         A.check(L.pws_netg_backward_bn_opts(A.ptr(packed), A.ptr(packed_dg), A.ptr(sv["bn_params"]), sv["eps"], A.ptr(sv["x"]), n, net.input_nc,

@@ -28,7 +28,9 @@ namespace pws {
 
 struct Layer {
     int kind, cin, cout;
-    size_t w_off, b_off;  // float offsets into the packed buffer (and into the packed gradient buffer)
+    size_t w_off, b_off;  // float offsets into the packed buffer
+    size_t gw_off, gb_off;  // float offsets into the GRADIENT slab (pws_netg_grad_floats): weight gradient in the forward packed layout,
+                            // bias gradient right behind it -- the slab holds nothing else, so a data-parallel host all-reduces it in place
     size_t dg_off;        // float offset into the data-gradient weight buffer (or SIZE_MAX)
     size_t ww_off;        // float offset of the Winograd-domain weights inside the packed buffer (or SIZE_MAX)
     size_t wr_off;        // ... of the ring-layout Winograd weights (conv_wring.hip; or SIZE_MAX)
@@ -64,16 +66,20 @@ enum {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Same registration order as the reference's __init__ (lib/networks_cascading.py:112-149) / spec.py.
-static std::vector<Layer> build_layers(int input_nc, int g, size_t *total_floats, size_t *total_dgrad = nullptr) {
+static std::vector<Layer> build_layers(int input_nc, int g, size_t *total_floats, size_t *total_dgrad = nullptr, size_t *total_grad = nullptr) {
     std::vector<Layer> L;
-    size_t off = 0, dg = 0;
+    size_t off = 0, dg = 0, gr = 0;
     // ring: the layer runs on maps of whole 16 x 32 (or, two samples at a time, 16 x 16) units at the reference's 256 x 256 input (conv_wring.hip)
     auto add = [&](int kind, int cin, int cout, bool ring = false) {
-        Layer l{kind, cin, cout, 0, 0, (size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1};
+        Layer l{kind, cin, cout, 0, 0, 0, 0, (size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1, (size_t)-1};
         l.w_off = off;
         off = align_up(off + pws_packed_weight_floats(kind, cin, cout), 64);
         l.b_off = off;
         off = align_up(off + (size_t)cout, 64);
+        l.gw_off = gr;
+        gr = align_up(gr + pws_packed_weight_floats(kind, cin, cout), 64);
+        l.gb_off = gr;
+        gr = align_up(gr + (size_t)cout, 64);
         if (kind == PWS_CONV_K3S1 || kind == PWS_CONVT_K3S1) {
             l.ww_off = off;
             off = align_up(off + pws_packed_wino_floats(cin, cout), 64);
@@ -116,6 +122,7 @@ static std::vector<Layer> build_layers(int input_nc, int g, size_t *total_floats
     add(PWS_CONV_K1, 8 * g, 6);
     if (total_floats) *total_floats = off;
     if (total_dgrad) *total_dgrad = dg;
+    if (total_grad) *total_grad = gr;
     return L;
 }
 
@@ -202,7 +209,7 @@ struct BnCfg {
 // stream made late in a process with several streams alive (the backward's, on autograd's thread, in bench.py after its streaming
 // leg) landed on the caller's hardware queue -- the two then serialise, barrier packets on top (configs[2] step 32.3 ms instead of
 // 30.1; tools/_bin-style probe: 5 extra torch streams reproduce it).  So every host thread shares the stream made first; what a
-// thread owns is its EVENT POOL.  A call that finds the queue inside somebody else's graph capture runs on one queue.
+// thread owns is its EVENT POOL (and a private side stream for calls made inside a graph capture: SideStream::pick).
 static hipStream_t shared_side_queue(int dev) {
     static std::mutex m;
     static std::unordered_map<int, hipStream_t> per_device;
@@ -215,20 +222,27 @@ static hipStream_t shared_side_queue(int dev) {
     return s;
 }
 struct SideStream {
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // the device's shared side queue (eager calls)
+    hipStream_t own = nullptr;       // this thread's private side stream: calls made inside a graph capture fork into it
     std::vector<hipEvent_t> events;
     size_t next = 0;
-    bool ok = false;
     int dev = 0;
-    bool init() {
-        if (!stream) stream = shared_side_queue(dev), ok = stream != nullptr;
-        return ok;
-    }
-    // usable beside `st` now: not part of a graph capture that `st` does not belong to
-    bool free_for(hipStream_t st) const {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone, cm = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(stream, &cs) != hipSuccess || hipStreamIsCapturing(st, &cm) != hipSuccess) return false;
-        return cs == hipStreamCaptureStatusNone || cm != hipStreamCaptureStatusNone;
+    // The side queue to fork into beside `st`, or nullptr (run on one queue).  A call that is being CAPTURED never touches the shared
+    // queue: forking joins the side stream to the caller's capture, and two host threads capturing at once would pull one stream into
+    // two captures (both invalid) -- a captured call forks into the thread's own stream instead (a graph has no hardware queue of its
+    // own to collide with: its nodes are scheduled when it is launched).  An eager call takes the shared queue, which therefore is never
+    // part of anybody's capture; the capture status of `st` is the calling thread's own business, so nothing here is check-then-use
+    // against another thread.
+    hipStream_t pick(hipStream_t st) {
+        hipStreamCaptureStatus cm = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cm) != hipSuccess) return nullptr;
+        if (cm == hipStreamCaptureStatusNone) {
+            if (!stream) stream = shared_side_queue(dev);
+            return stream;
+        }
+        if (cm != hipStreamCaptureStatusActive) return nullptr;
+        if (!own && hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess) own = nullptr;
+        return own;
     }
     hipEvent_t event() {
         if (next == events.size()) {
@@ -265,7 +279,7 @@ class Exec {
         streams_[0] = st, streams_[1] = st;
         if (launch_ && o.two_queues) {
             side_ = &side_stream();
-            if (side_->init() && side_->free_for(st)) streams_[1] = side_->stream, side_->next = 0;
+            if (hipStream_t q = side_->pick(st)) streams_[1] = q, side_->next = 0;
         }
     }
 
@@ -468,7 +482,10 @@ class Exec {
         // fp32 math: four times that -- the Winograd ring kernel's two-class units of the transposed layers on 16 x 16 / 32 x 32 maps
         // split K four ways (33 MB of partial sums at batch 8; conv_wring.hip).  The bf16 kernels keep the smaller bound: deeper splits
         // of their small maps measured slower (configs[2] step +0.17 ms)
-        splitk_big_ = 4 * splitk_bytes_;   // (training forwards in fp32 as well: netG(x, False) stays bit-equal to netG(x)[0][2], reference :237)
+        // (training forwards in fp32 as well: netG(x, False) stays bit-equal to netG(x)[0][2], reference :237).  The deep splits are a
+        // small-batch matter -- from batch 16 on those maps fill the chip without them -- so the extra is capped at the 48 MB batch 8
+        // asks for: 2 x 176 MB of scratch at batch 64 instead of 2 x 512 MB in every arena
+        splitk_big_ = splitk_bytes_ + ((size_t)48 << 20) < 4 * splitk_bytes_ ? splitk_bytes_ + ((size_t)48 << 20) : 4 * splitk_bytes_;
         splitk_ws_ = alloc(splitk_big_ / sizeof(float));
         splitk_ws2_ = alloc(splitk_big_ / sizeof(float));  // one scratch per queue: the two run concurrently
         theta_ws_ = alloc(pws_theta_head_ws_floats(n_, 4 * ngf, 8 * ngf));
@@ -615,14 +632,31 @@ struct GradBuf {
 // bookkeeping of every earlier run is replayed without launching), so that a data-parallel host can all-reduce the weight
 // gradients that are already final while the later runs still compute.  final_mask (nullable, one byte per layer): 1 once no
 // op of a later run contributes to that layer's gradient.
+// upstream gradients of the six fields, one pointer per stage (NULL: that output has no gradient)
+struct UpGrads {
+    const float *grids[3] = {nullptr, nullptr, nullptr}, *resid[3] = {nullptr, nullptr, nullptr};
+    UpGrads() = default;
+    UpGrads(const float *g_grids, const float *g_resid, size_t gsz) {   // the stacked [3][n,256,256,2] form
+        for (int k = 0; k < 3; ++k) grids[k] = g_grids ? g_grids + k * gsz : nullptr, resid[k] = g_resid ? g_resid + k * gsz : nullptr;
+    }
+    UpGrads(const float *const *g_grids, const float *const *g_resid) {   // HOST arrays of 3 device pointers (either may be NULL)
+        for (int k = 0; k < 3; ++k) grids[k] = g_grids ? g_grids[k] : nullptr, resid[k] = g_resid ? g_resid[k] : nullptr;
+    }
+    bool any() const {
+        for (int k = 0; k < 3; ++k)
+            if (grids[k] || resid[k]) return true;
+        return false;
+    }
+};
+
 static int run_backward(const float *packed, const float *packed_dgrad, const float *x, int n, int input_nc, int g, int ac,
-                        char *ws, size_t ws_bytes, const float *resid, const float *thetas, const float *g_grids,
-                        const float *g_resid, float *dpacked, hipStream_t st, bool dry, size_t *used, int part = 0,
+                        char *ws, size_t ws_bytes, const float *resid, const float *thetas, const UpGrads &up, float *dpacked,
+                        hipStream_t st, bool dry, size_t *used, int part = 0,
                         int nparts = 1, unsigned char *final_mask = nullptr, const BnCfg *bn = nullptr, float *dbn = nullptr,
                         const NetgOpts *opts = nullptr) {
     const int S = 256;
-    size_t total = 0;
-    const std::vector<Layer> L = build_layers(input_nc, g, &total);
+    size_t total = 0, total_grad = 0;
+    const std::vector<Layer> L = build_layers(input_nc, g, &total, nullptr, &total_grad);
     const NetgOpts mode = opts ? *opts : opts_defaults();
     DeterministicScope det_scope(mode.deterministic);   // PWS_NETG_DETERMINISTIC: every accumulating launcher of this call
     Exec E(packed, L, n, ws, ws_bytes, st, dry, /*launch=*/false, mode, bn);
@@ -661,7 +695,7 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
         return pws_bn_train_bwd(dy, y, z, stats, E.gamma(layer), act, pixels, c, dg, dg + c, E.bn_ws(0), E.bn_ws_bytes(), st);
     };
     if (part == 0) {
-        hipError_t e = hipMemsetAsync(dpacked, 0, total * sizeof(float), st);
+        hipError_t e = hipMemsetAsync(dpacked, 0, total_grad * sizeof(float), st);
         if (e != hipSuccess) {
             set_error("pws_netg_backward: hipMemsetAsync: %s", hipGetErrorString(e));
             return PWS_EHIP;
@@ -677,7 +711,7 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
     SideStream *wside = nullptr;
     if (mode.two_queues && g_experiment != 16) {
         wside = &side_stream();
-        if (wside->init() && wside->free_for(st)) wst = wside->stream, wside->next = 0;
+        if (hipStream_t q = wside->pick(st)) wst = q, wside->next = 0;
         else wside = nullptr;
     }
     auto wgrad_fork = [&]() -> int {   // the side queue waits for everything issued on `st` so far
@@ -712,7 +746,7 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
         for (size_t ii = T; ii-- > 0;) {
             const Op &op = E.tape()[ii];
             if (op.type == OP_FIELD) {
-                const float *gg = g_grids ? g_grids + op.stage * gsz : nullptr, *gr = g_resid ? g_resid + op.stage * gsz : nullptr;
+                const float *gg = up.grids[op.stage], *gr = up.resid[op.stage];
                 if (!gg && !gr) continue;
                 wr[op.in.seg[0].ptr] = true, last_writer[op.in.seg[0].ptr] = ii, hd[op.stage] = gg != nullptr;
             } else if (op.type == OP_THETA) {
@@ -745,7 +779,7 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
         const bool run = r >= r_begin;  // earlier runs: replay the bookkeeping (written / have_dtheta flags) only
         if (op.type == OP_FIELD) {
             const int k = op.stage;
-            const float *gg = g_grids ? g_grids + k * gsz : nullptr, *gr = g_resid ? g_resid + k * gsz : nullptr;
+            const float *gg = up.grids[k], *gr = up.resid[k];
             if (!gg && !gr) continue;
             const Seg &xs = op.in.seg[0];
             GradBuf &gb = G[xs.ptr];
@@ -755,10 +789,10 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
                 if (rc == PWS_OK) rc = bn_backward(L_OUT, gz_ws, nullptr, op.aux[0], op.aux[1], PWS_ACT_NONE, (size_t)n * op.in.h * op.in.w);
                 if (rc == PWS_OK)
                     rc = field_bwd_dx_dw(xs.ptr, xs.ld, gz_ws, n, op.in.h, op.in.w, xs.c, packed + o.w_off, gb.g, xs.c, gb.written ? 1 : 0,
-                                         dpacked + o.w_off, E.store(), st);
+                                         dpacked + o.gw_off, E.store(), st);
             } else if (run)
                 rc = pws_field_head_bwd_act(xs.ptr, xs.ld, n, op.in.h, op.in.w, xs.c, packed + o.w_off, resid + k * gsz, gg, gr, ac, gb.g,
-                                            xs.c, gb.written ? 1 : 0, dpacked + o.w_off, dpacked + o.b_off,
+                                            xs.c, gb.written ? 1 : 0, dpacked + o.gw_off, dpacked + o.gb_off,
                                             gg ? dtheta + (size_t)k * n * 6 : nullptr, gz_ws, E.store(), fused_act(ii, xs.ptr), st);
             gb.written = true;
             if (fused_act(ii, xs.ptr) != PWS_ACT_NONE) gb.preact = true;
@@ -776,10 +810,10 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             if (bn) {
                 float *dz2 = dtheta + (size_t)k * n * 6;   // overwritten by the BatchNorm backward
                 rc = bn_backward(L_LINEAR, dz2, thetas + (size_t)k * n * 6, op.aux[2], op.aux[3], PWS_ACT_LRELU, (size_t)n);
-                if (rc == PWS_OK) rc = theta_bwd_bn_lin(dz2, E.h_saved(k), n, f.cout, packed + l.w_off, dpacked + l.w_off, th_bwd_ws, st);
+                if (rc == PWS_OK) rc = theta_bwd_bn_lin(dz2, E.h_saved(k), n, f.cout, packed + l.w_off, dpacked + l.gw_off, th_bwd_ws, st);
                 if (rc == PWS_OK) rc = bn_backward(L_FLATTEN, th_bwd_ws, E.h_saved(k), op.aux[0], op.aux[1], PWS_ACT_LRELU, (size_t)n);
                 if (rc == PWS_OK)
-                    rc = theta_bwd_flat(xs.ptr, n, xs.c, f.cout, packed + f.w_off, th_bwd_ws, dpacked + f.w_off, gb.g, gb.written ? 1 : 0, st);
+                    rc = theta_bwd_flat(xs.ptr, n, xs.c, f.cout, packed + f.w_off, th_bwd_ws, dpacked + f.gw_off, gb.g, gb.written ? 1 : 0, st);
                 gb.written = true;
                 continue;
             }
@@ -789,13 +823,13 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
                 rc = pws_cvt_bf16_to_f32(xs.ptr, E.theta_x32(0), cnt, st);
                 if (rc == PWS_OK)
                     rc = pws_theta_head_bwd(E.theta_x32(0), n, xs.c, f.cout, packed + f.w_off, packed + l.w_off, E.h_saved(k),
-                                            thetas + (size_t)k * n * 6, dtheta + (size_t)k * n * 6, dpacked + f.w_off,
-                                            dpacked + f.b_off, dpacked + l.w_off, dpacked + l.b_off, th_dx32, 0, th_bwd_ws, st);
+                                            thetas + (size_t)k * n * 6, dtheta + (size_t)k * n * 6, dpacked + f.gw_off,
+                                            dpacked + f.gb_off, dpacked + l.gw_off, dpacked + l.gb_off, th_dx32, 0, th_bwd_ws, st);
                 if (rc == PWS_OK) rc = pws_cvt_f32_to_bf16(th_dx32, gb.g, cnt, gb.written ? 1 : 0, st);
             } else {
                 rc = pws_theta_head_bwd(xs.ptr, n, xs.c, f.cout, packed + f.w_off, packed + l.w_off, E.h_saved(k),
-                                        thetas + (size_t)k * n * 6, dtheta + (size_t)k * n * 6, dpacked + f.w_off, dpacked + f.b_off,
-                                        dpacked + l.w_off, dpacked + l.b_off, gb.g, gb.written ? 1 : 0, th_bwd_ws, st);
+                                        thetas + (size_t)k * n * 6, dtheta + (size_t)k * n * 6, dpacked + f.gw_off, dpacked + f.gb_off,
+                                        dpacked + l.gw_off, dpacked + l.gb_off, gb.g, gb.written ? 1 : 0, th_bwd_ws, st);
             }
             gb.written = true;
         } else {
@@ -817,7 +851,7 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             if (bn)   // the conv bias gets no gradient: BatchNorm removes any per-channel constant (torch returns rounding noise)
                 rc = bn_backward(op.layer, go.g, o.ptr, op.aux[0], op.aux[1], op.act, pixels);
             else if (!go.preact)   // (a pre-activation gradient needs the bias sum only: the weight-gradient kernel takes it along)
-                rc = pws_act_bwd_bias_s(go.g, o.ptr, pixels, l.cout, op.act, dpacked + l.b_off, E.store(), abb_ws, abb_bytes, st);
+                rc = pws_act_bwd_bias_s(go.g, o.ptr, pixels, l.cout, op.act, dpacked + l.gb_off, E.store(), abb_ws, abb_bytes, st);
             if (rc != PWS_OK) break;
             pws_conv_bwd_weight_args wa{};
             wa.kind = l.kind, wa.n = n, wa.h = op.in.h, wa.w = op.in.w, wa.nsrc = op.in.nseg, wa.src_nchw = op.nchw ? 1 : 0;
@@ -825,13 +859,13 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             if (op.nchw) wa.src[0] = pws_src{x, input_nc, 0};
             if (op.nchw && mode.math == PWS_MATH_BF16 && l.wb_off != (size_t)-1 && E.x_nhwc() && input_nc <= 32)
                 wa.src_nchw = 0, wa.src[0] = pws_src{E.x_nhwc(), 32, 32};  // the forward's NHWC copy
-            wa.cout = l.cout, wa.gout = go.g, wa.gout_ld = l.cout, wa.dw_packed = dpacked + l.w_off;
+            wa.cout = l.cout, wa.gout = go.g, wa.gout_ld = l.cout, wa.dw_packed = dpacked + l.gw_off;
             wa.math = mode.math, wa.store = E.store();
-            wa.dbias = !bn && go.preact ? dpacked + l.b_off : nullptr;
+            wa.dbias = !bn && go.preact ? dpacked + l.gb_off : nullptr;
             if (wa.dbias && mode.deterministic) {
                 // the weight-gradient kernels' bias sums arrive per parity class / class pair in any order: an ordered pass instead
                 // (act = NONE: sums only, slab partials + ordered reduction)
-                rc = pws_act_bwd_bias_s(go.g, go.g, pixels, l.cout, PWS_ACT_NONE, dpacked + l.b_off, E.store(), abb_ws, abb_bytes, st);
+                rc = pws_act_bwd_bias_s(go.g, go.g, pixels, l.cout, PWS_ACT_NONE, dpacked + l.gb_off, E.store(), abb_ws, abb_bytes, st);
                 if (rc != PWS_OK) break;
                 wa.dbias = nullptr;
             }
@@ -977,7 +1011,7 @@ extern "C" size_t pws_netg_train_workspace_bytes_bn(int n, int input_nc, int ngf
     size_t used = 0;
     BnCfg bn;
     const NetgOpts o{PWS_MATH_FP32, PWS_STORE_FP32, false};
-    run_backward(nullptr, nullptr, nullptr, n, input_nc, ngf, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true,
+    run_backward(nullptr, nullptr, nullptr, n, input_nc, ngf, 0, nullptr, 0, nullptr, nullptr, UpGrads(), nullptr, nullptr, true,
                  &used, 0, 1, nullptr, &bn, nullptr, &o);
     return used;
 }
@@ -1042,8 +1076,8 @@ extern "C" int pws_netg_backward_bn_opts(const float *packed, const float *packe
     bn.params = bn_params, bn.eps = eps;
     NetgOpts o;
     if (int rc = bn_opts_from(opts, &o)) return rc;
-    return run_backward(packed, packed_dgrad, x, n, input_nc, ngf, align_corners, static_cast<char *>(ws), ws_bytes, resid, thetas, g_grids,
-                        g_resid, dpacked, as_stream(stream), false, nullptr, 0, 1, nullptr, &bn, dbn, &o);
+    return run_backward(packed, packed_dgrad, x, n, input_nc, ngf, align_corners, static_cast<char *>(ws), ws_bytes, resid, thetas,
+                        UpGrads(g_grids, g_resid, (size_t)n * 256 * 256 * 2), dpacked, as_stream(stream), false, nullptr, 0, 1, nullptr, &bn, dbn, &o);
 }
 
 extern "C" int pws_netg_unpack_grads(const float *dpacked, float *const *grads, int input_nc, int ngf, pws_stream_t stream) {
@@ -1054,6 +1088,7 @@ extern "C" int pws_netg_unpack_grads(const float *dpacked, float *const *grads, 
     UnpackAllArgs a{};
     a.nlayers = L_COUNT;
     fill_pack_layers(L, a.layer);
+    for (int i = 0; i < L_COUNT; ++i) a.layer[i].w_off = off32(L[i].gw_off), a.layer[i].b_off = off32(L[i].gb_off);   // the gradient slab's layout
     unsigned nb = 0;
     for (int i = 0; i < L_COUNT; ++i) {
         // a layer whose two pointers are both NULL is skipped (part-wise unpacking, pws_netg_backward_part)
@@ -1083,7 +1118,7 @@ extern "C" size_t pws_netg_train_workspace_bytes(int n, int input_nc, int ngf) {
     if (n <= 0 || input_nc <= 0 || ngf <= 0 || ngf % 16 != 0) return 0;
     size_t used = 0;
     const NetgOpts o{PWS_MATH_FP32, PWS_STORE_FP32, false};   // the arena layout does not depend on the mode
-    run_backward(nullptr, nullptr, nullptr, n, input_nc, ngf, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+    run_backward(nullptr, nullptr, nullptr, n, input_nc, ngf, 0, nullptr, 0, nullptr, nullptr, UpGrads(), nullptr, nullptr,
                  true, &used, 0, 1, nullptr, nullptr, nullptr, &o);
     return used;
 }
@@ -1115,10 +1150,9 @@ extern "C" int pws_netg_forward(const float *packed, const float *x, int n, int 
                                  stream);
 }
 
-extern "C" int pws_netg_backward_opts(const float *packed, const float *packed_dgrad, const float *x, int n, int input_nc, int ngf,
-                                      int align_corners, void *ws, size_t ws_bytes, const float *resid, const float *thetas,
-                                      const float *g_grids, const float *g_resid, float *dpacked, int part, int nparts,
-                                      unsigned char *final_mask, const pws_netg_opts *opts, pws_stream_t stream) {
+static int backward_entry(const float *packed, const float *packed_dgrad, const float *x, int n, int input_nc, int ngf, int align_corners,
+                          void *ws, size_t ws_bytes, const float *resid, const float *thetas, const UpGrads &up, float *dpacked, int part,
+                          int nparts, unsigned char *final_mask, const pws_netg_opts *opts, pws_stream_t stream) {
     PWS_REQUIRE(n >= 0 && input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_backward: bad n/input_nc/ngf");
     PWS_REQUIRE(nparts >= 1 && part >= 0 && part < nparts, "pws_netg_backward: part %d of %d", part, nparts);
     NetgOpts o;
@@ -1130,10 +1164,45 @@ extern "C" int pws_netg_backward_opts(const float *packed, const float *packed_d
         return PWS_OK;
     }
     PWS_REQUIRE(packed && packed_dgrad && x && ws && resid && thetas && dpacked, "pws_netg_backward: NULL pointer");
-    PWS_REQUIRE(g_grids || g_resid, "pws_netg_backward: no output gradient given");
+    PWS_REQUIRE(up.any(), "pws_netg_backward: no output gradient given");
     PWS_REQUIRE((reinterpret_cast<size_t>(ws) & 255) == 0, "pws_netg_backward: workspace must be 256-byte aligned");
-    return run_backward(packed, packed_dgrad, x, n, input_nc, ngf, align_corners, static_cast<char *>(ws), ws_bytes, resid, thetas,
-                        g_grids, g_resid, dpacked, as_stream(stream), false, nullptr, part, nparts, final_mask, nullptr, nullptr, &o);
+    return run_backward(packed, packed_dgrad, x, n, input_nc, ngf, align_corners, static_cast<char *>(ws), ws_bytes, resid, thetas, up,
+                        dpacked, as_stream(stream), false, nullptr, part, nparts, final_mask, nullptr, nullptr, &o);
+}
+
+extern "C" int pws_netg_backward_opts(const float *packed, const float *packed_dgrad, const float *x, int n, int input_nc, int ngf,
+                                      int align_corners, void *ws, size_t ws_bytes, const float *resid, const float *thetas,
+                                      const float *g_grids, const float *g_resid, float *dpacked, int part, int nparts,
+                                      unsigned char *final_mask, const pws_netg_opts *opts, pws_stream_t stream) {
+    return backward_entry(packed, packed_dgrad, x, n, input_nc, ngf, align_corners, ws, ws_bytes, resid, thetas,
+                          UpGrads(g_grids, g_resid, (size_t)(n > 0 ? n : 0) * 256 * 256 * 2), dpacked, part, nparts, final_mask, opts, stream);
+}
+
+extern "C" int pws_netg_backward_lists(const float *packed, const float *packed_dgrad, const float *x, int n, int input_nc, int ngf,
+                                       int align_corners, void *ws, size_t ws_bytes, const float *resid, const float *thetas,
+                                       const float *const *g_grids, const float *const *g_resid, float *dpacked, int part, int nparts,
+                                       unsigned char *final_mask, const pws_netg_opts *opts, pws_stream_t stream) {
+    return backward_entry(packed, packed_dgrad, x, n, input_nc, ngf, align_corners, ws, ws_bytes, resid, thetas, UpGrads(g_grids, g_resid),
+                          dpacked, part, nparts, final_mask, opts, stream);
+}
+
+extern "C" size_t pws_netg_grad_floats(int input_nc, int ngf) {
+    if (input_nc <= 0 || ngf <= 0 || ngf % 16 != 0) return 0;
+    size_t total = 0, total_grad = 0;
+    build_layers(input_nc, ngf, &total, nullptr, &total_grad);
+    return total_grad;
+}
+
+extern "C" int pws_netg_grad_layout(int input_nc, int ngf, size_t *first_float, size_t *floats) {
+    PWS_REQUIRE(input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_grad_layout: bad ngf %d", ngf);
+    PWS_REQUIRE(first_float && floats, "pws_netg_grad_layout: NULL pointer");
+    size_t total = 0, total_grad = 0;
+    const std::vector<Layer> L = build_layers(input_nc, ngf, &total, nullptr, &total_grad);
+    for (int i = 0; i < L_COUNT; ++i) {
+        first_float[i] = L[i].gw_off;
+        floats[i] = (i + 1 < L_COUNT ? L[i + 1].gw_off : total_grad) - L[i].gw_off;   // weight, bias and their padding: adjacent layers abut
+    }
+    return PWS_OK;
 }
 
 extern "C" int pws_netg_backward(const float *packed, const float *packed_dgrad, const float *x, int n, int input_nc, int ngf,

@@ -17,7 +17,9 @@ def init_from_env(backend=None):
     """Initialises the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun). Returns (rank, world)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # PWS_FORCE_PROCESS_GROUP=1: a group of ONE rank as well (RCCL's communicator, streams and IPC set-up on a single GPU)
+    if (world > 1 or os.environ.get("PWS_FORCE_PROCESS_GROUP") == "1") and not dist.is_initialized():
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
@@ -59,12 +61,39 @@ def max_over_ranks(value, device=None):
     return float(t.item())
 
 
-def allreduce_tensors(tensors, bucket_bytes=64 << 20):
-    """Averages the given fp32 tensors over ranks in place, in flat buckets of ~bucket_bytes, on the CURRENT stream.
-    Returns the number of collectives issued (0 without a process group)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+def _average_in_place(flat):
+    """ONE collective that leaves the mean over ranks in ``flat``.  RCCL averages inside the collective (ReduceOp.AVG: no extra
+    pass over the buffer); gloo (the CPU tests' backend) has no AVG: SUM, then one division."""
+    if dist.get_backend() == "nccl":
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(dist.get_world_size())
+
+
+def allreduce_slab(slab, ranges, bucket_bytes=64 << 20, force=False):
+    """Averages ``slab[a:b]`` for every (a, b) of ``ranges`` over the ranks IN PLACE -- the slab is the generator's flat gradient
+    buffer (``pws_netg_grad_floats``), the collectives run on views of it: no flatten, no copy back (under RCCL the wire is the
+    only traffic besides the collective's own read + write).  Ranges longer than ``bucket_bytes`` go out as several messages
+    (xGMI is point-to-point: a few large messages, pipelined).  On the CURRENT stream.  ``force``: issue the collectives in a
+    group of ONE rank too (first contact with RCCL on a single GPU).  Returns the number of collectives issued."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return 0
-    world = dist.get_world_size()
+    step = max(1, bucket_bytes // slab.element_size())
+    n_coll = 0
+    for a, b in ranges:
+        for lo in range(a, b, step):
+            _average_in_place(slab[lo:min(b, lo + step)])
+            n_coll += 1
+    return n_coll
+
+
+def allreduce_tensors(tensors, bucket_bytes=64 << 20, force=False):
+    """Averages the given fp32 tensors over ranks in place, in flat buckets of ~bucket_bytes, on the CURRENT stream (separate
+    tensors have to be flattened and copied back: the generator's own backward uses ``allreduce_slab`` on its gradient slab
+    instead).  Returns the number of collectives issued (0 without a process group)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
+        return 0
     n_coll, i = 0, 0
     while i < len(tensors):
         j, size = i, 0
@@ -72,8 +101,7 @@ def allreduce_tensors(tensors, bucket_bytes=64 << 20):
             size += tensors[j].numel() * 4
             j += 1
         flat = torch.cat([g.reshape(-1) for g in tensors[i:j]])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.div_(world)
+        _average_in_place(flat)
         off = 0
         for g in tensors[i:j]:
             g.copy_(flat[off:off + g.numel()].view_as(g))
@@ -83,13 +111,15 @@ def allreduce_tensors(tensors, bucket_bytes=64 << 20):
     return n_coll
 
 
-def allreduce_gradients(params, bucket_bytes=64 << 20):
-    """Averages ``p.grad`` over ranks in place, in flat buckets of ~bucket_bytes.
+def allreduce_gradients(params, bucket_bytes=64 << 20, force=False):
+    """Averages ``p.grad`` over ranks in place, in flat buckets of ~bucket_bytes (generic: any parameter list -- it flattens and
+    copies back; for the generator prefer ``enable_overlapped_grad_sync(netG, nparts=1)``, whose backward all-reduces its
+    gradient slab in place before unpacking).
 
     Shared-weight gradients (stages 2 and 3 use the same modules) are already accumulated locally by backward before
     this is called.  Returns the number of collectives issued.
     """
-    return allreduce_tensors([p.grad for p in params if p.grad is not None], bucket_bytes)
+    return allreduce_tensors([p.grad for p in params if p.grad is not None], bucket_bytes, force)
 
 
 def broadcast_parameters(netG, src=0, check=False):
@@ -146,12 +176,14 @@ class OverlappedGradSync:
     on a second stream while the next run computes.  ``p.grad`` arrive averaged: no ``allreduce_gradients`` call after
     ``backward()``.  Without a process group (one GPU) the collectives are skipped, everything else runs the same."""
 
-    def __init__(self, nparts=4, bucket_bytes=64 << 20):
+    def __init__(self, nparts=4, bucket_bytes=64 << 20, force=False):
         if nparts < 1:
             raise ValueError("nparts must be >= 1")
         self.nparts, self.bucket_bytes = int(nparts), int(bucket_bytes)
+        self.force = bool(force)   # issue the collectives in a one-rank group as well (RCCL on a single GPU)
         self._streams = {}
         self.collectives = 0   # issued by the last backward (diagnostics)
+        self.bytes_reduced = 0  # by the last backward
 
     def stream(self, device):
         key = str(device)
@@ -160,15 +192,24 @@ class OverlappedGradSync:
         return self._streams[key]
 
     def allreduce(self, tensors):
-        self.collectives += allreduce_tensors(tensors, self.bucket_bytes)
+        self.collectives += allreduce_tensors(tensors, self.bucket_bytes, self.force)
+
+    def allreduce_slab(self, slab, ranges):
+        """In-place average of the given [a, b) ranges of the gradient slab (see ``allreduce_slab``)."""
+        k = allreduce_slab(slab, ranges, self.bucket_bytes, self.force)
+        if self.collectives == 0:
+            self.bytes_reduced = 0
+        if k:
+            self.bytes_reduced += sum(b - a for a, b in ranges) * slab.element_size()
+        self.collectives += k
 
 
-def enable_overlapped_grad_sync(netG, nparts=4, bucket_bytes=64 << 20, broadcast=True):
+def enable_overlapped_grad_sync(netG, nparts=4, bucket_bytes=64 << 20, broadcast=True, force=False):
     """netG: what ``define_G`` returned (or its ``.module``).  Returns the OverlappedGradSync; ``netG.grad_sync = None`` turns
     it off again.  broadcast: first make every replica equal to rank 0's (``broadcast_parameters`` -- a COLLECTIVE: every
     rank must make this call, after ``netG.cuda()`` under RCCL; pass broadcast=False to attach the exchange without it)."""
     target = getattr(netG, "module", netG)
     if broadcast:
         broadcast_parameters(target, src=0)
-    target.grad_sync = OverlappedGradSync(nparts, bucket_bytes)
+    target.grad_sync = OverlappedGradSync(nparts, bucket_bytes, force)
     return target.grad_sync

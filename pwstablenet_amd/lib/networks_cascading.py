@@ -263,12 +263,27 @@ class UnetGenerator(nn.Module):
             self._packed_dgrad_key = key
         return self._packed_dgrad
 
+    def _grad_layout(self):
+        """(first_float, floats) per layer of the gradient slab the backward fills (pws_netg_grad_layout)."""
+        if getattr(self, "_grad_layout_cache", None) is None:
+            nl = len(self._specs)
+            first, count = (ctypes.c_size_t * nl)(), (ctypes.c_size_t * nl)()
+            A.check(A.lib().pws_netg_grad_layout(self.input_nc, self.ngf, first, count), "pws_netg_grad_layout")
+            self._grad_layout_cache = (list(first), list(count))
+        return self._grad_layout_cache
+
     def _workspace(self, n, is_training, device):
+        """The inference arena of the CURRENT stream: kernels of two streams run concurrently, so host threads that share this
+        generator on their own streams (the reference's nn.DataParallel runs one thread per replica, lib/networks_cascading.py:51-52)
+        must not share an arena.  One arena per stream is kept (a new batch size replaces that stream's arena)."""
+        sid = torch.cuda.current_stream(device).cuda_stream
         k = (n, bool(is_training), device)
-        if k not in self._ws:
+        ent = self._ws.get(sid)
+        if ent is None or ent[0] != k:
             nbytes = A.lib().pws_netg_workspace_bytes(n, self.input_nc, self.ngf, int(is_training))
-            self._ws = {k: torch.empty(nbytes + 256, device=device, dtype=torch.uint8)}  # keep one arena only
-        return self._ws[k]
+            ent = (k, torch.empty(nbytes + 256, device=device, dtype=torch.uint8))
+            self._ws[sid] = ent
+        return ent[1]
 
     def forward(self, input1, is_training=True):
         A.require_cuda(input1)
@@ -295,37 +310,43 @@ class UnetGenerator(nn.Module):
         return self._run(input1, is_training)
 
     def _capture(self, x, key, static_input):
-        """Captures one forward on ``x`` (or on a private copy of it: ``static_input``) with an arena private to the graph."""
-        xg = x.clone() if static_input else x
+        """Captures one forward on ``x`` (or on a private dense copy of it: ``static_input``) with an arena private to the graph.
+        The caller must hold no reference to the previous graph's entry (it is dropped first; its arena is reused when it fits)."""
+        xg = x.clone(memory_format=torch.contiguous_format) if static_input else x
         nbytes = A.lib().pws_netg_workspace_bytes(xg.shape[0], self.input_nc, self.ngf, 0)
-        old, self._graph = self._graph, None   # drop the previous graph first; its arena is reused when it has the right size
+        old, self._graph = self._graph, None
         ws = old["ws"] if old is not None and old["ws"].numel() == nbytes + 256 and old["ws"].device == xg.device else None
-        del old
+        del old   # the previous hipGraphExec, its output and its input buffer go before the new graph is made
         if ws is None:
             ws = torch.empty(nbytes + 256, device=xg.device, dtype=torch.uint8)
         self._run(xg, False, ws=ws)  # eager warm-up: one-time kernel attribute calls must not happen during capture
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: only THIS thread's calls are held to the capture rules -- another host thread (a second replica, a data
+        # loader) may allocate or synchronise while this capture is open without invalidating it
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             out = self._run(xg, False, ws=ws)
         # one graph is kept; it holds its input tensor (address baked in), its arena and its output
         self._graph = dict(key=key, g=g, out=out, x=xg, ws=ws, static=static_input)
         return self._graph
 
     def _run_graph(self, input1):
-        x = input1.contiguous()
+        x = input1   # may be a strided view (the video loop's overlapping windows): copied ONCE, straight into the graph's input
         self.packed_weights()
         # the packed buffer is re-packed IN PLACE at a fixed address when a parameter changes (packed_weights() above, outside the
         # graph), so a weight update needs no re-capture: the key holds the buffer's address, not the parameter versions
         key = (tuple(x.shape), str(x.device), self._packed.data_ptr(), self.math, self.store, self.align_corners, self.two_queues)
         ent = self._graph
         if ent is None or ent["key"] != key:
-            ent = self._capture(x, key, static_input=False)
-        elif x.data_ptr() != ent["x"].data_ptr():
+            ent = None   # (no reference to the old entry while the new graph is captured)
+            ent = self._capture(x, key, static_input=not x.is_contiguous())
+        elif not x.is_contiguous() or x.data_ptr() != ent["x"].data_ptr():
             # a different input buffer: from now on the graph reads a private static buffer that every call copies into
             if not ent["static"]:
-                ent = self._capture(x, key, static_input=True)
-            ent["x"].copy_(x)
+                ent = None
+                ent = self._capture(x, key, static_input=True)   # (the capture's copy of x IS this call's input)
+            else:
+                ent["x"].copy_(x)
         ent["g"].replay()
         return ent["out"] if self._graph_alias else ent["out"].clone()
 

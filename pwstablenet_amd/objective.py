@@ -138,17 +138,15 @@ class _Objective(torch.autograd.Function):
             gg = torch.empty_like(grids[nl])
             A.check(lib.pws_warp_norm_bwd(rgb_p, rgb_s, A.ptr(grids[nl]), stb_p, stb_s, c_l1, A.ptr(scale), A.ptr(gextra),
                                           A.ptr(gg), 0, m, h, w, st), "pws_warp_norm_bwd")
-            feat_bwd = lib.pws_feature_loss_bwd_det if cfg.get("deterministic") else lib.pws_feature_loss_bwd
+            det = bool(cfg.get("deterministic"))
+            feat_bwd = lib.pws_feature_loss_bwd_det if det else lib.pws_feature_loss_bwd
             A.check(feat_bwd(A.ptr(grids[nl]), A.ptr(features), c_f, A.ptr(scale), A.ptr(gg), m, features.shape[1], h, w, st),
-                    "pws_feature_loss_bwd")
+                    "pws_feature_loss_bwd_det" if det else "pws_feature_loss_bwd")
             ggrids.append(gg)
         gresid = None
         if cfg["shapeloss"]:
             gresid = torch.empty_like(resid)
-            dp_world = cfg.get("dp_world")
-            if dp_world is None:
-                import torch.distributed as dist
-                dp_world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+            dp_world = cfg.get("dp_world") or 1
             A.check(lib.pws_shape_loss_bwd(A.ptr(resid), float(cfg["shapeloss_weight"]) * float(dp_world), A.ptr(scale), A.ptr(gresid), m,
                                            cfg["size"], cfg["block"], st), "pws_shape_loss_bwd")
         return (None, None, None, None, None) + tuple(ggrids) + (gresid,)
@@ -179,14 +177,20 @@ class StabObjective:
         # loss_g is a mean over the batch except the shape term, which the reference SUMS over items and pixels
         # (lib/utils.py:421 torch.dist(AB, B, 1)).  The reference's nn.DataParallel evaluates the loss on the gathered outputs of the
         # whole batch, so its gradient of that term is the sum over ALL items; averaging the ranks' gradients would deliver 1/world
-        # of it.  grad_average_world (None: the default process group's size when backward runs) multiplies the GRADIENT of the
-        # sum-type term so that the averaged gradient equals the reference's; the reported loss values stay local
-        # (loss_pixel of the job = SUM of the ranks', the other terms = their MEAN).
+        # of it.  grad_average_world multiplies the GRADIENT of the sum-type term so that the averaged gradient equals the
+        # reference's; the reported loss values stay local (loss_pixel of the job = SUM of the ranks', the other terms = their
+        # MEAN).  It is EXPLICIT: None means 1 here (no scaling) -- ``train_step`` passes the world size for the calls whose
+        # gradients it averages (``sync_gradients`` given, or an exchange attached to the generator); a caller that composes the
+        # step by hand sets it (or passes ``grad_average_world=`` to the call).  A process group that only shards inference, or a
+        # job that SUMS its gradients, therefore never gets the factor; an unset value under an initialised group of several
+        # ranks warns once.
         self.grad_average_world = kw.get("grad_average_world", None)
         # True: the two scatter gradients of the objective (the temporal term's warp of fake2, feature points sharing a pixel) run
         # without atomics (pws_temporal_l1_bwd_det / pws_feature_loss_bwd_det); together with UnetGenerator.deterministic a whole
-        # train_step then gives bit-identical gradients and weights run to run.  train_step sets it from the generator's flag.
+        # train_step then gives bit-identical gradients and weights run to run.  train_step asks for it PER CALL from the
+        # generator's flag (``deterministic=`` of the call); this attribute is the objective's own default and is never written.
         self.deterministic = bool(kw.get("deterministic", False))
+        self._warned_world = False
         if self.num_layer != 3:
             raise NotImplementedError("StabObjective: the generator has 3 cascaded stages (num_layer=%d)" % self.num_layer)
         if bool(get("use_gan", False)):
@@ -211,10 +215,23 @@ class StabObjective:
             self._coef[key] = torch.from_numpy(c).to(device)
         return self._coef[key]
 
-    def __call__(self, grids, resid, rgb_unstable, image_stable, features, feature_adjacent):
+    def __call__(self, grids, resid, rgb_unstable, image_stable, features, feature_adjacent, grad_average_world=None, deterministic=None):
         """grids, resid: the two lists ``netG(x)`` returns (m = 2n samples); rgb_unstable: (m, 3, H, W) view of the
         unstable RGB frames in [-1, 1] (``image_unstable[:, period+1:period+4]``); image_stable: (m, >=3, H, W);
-        features: (m, nf, 6) float32 as the loader collates them; feature_adjacent: (n, 2, 3) / (n, 6)."""
+        features: (m, nf, 6) float32 as the loader collates them; feature_adjacent: (n, 2, 3) / (n, 6).
+        grad_average_world / deterministic: per-call overrides of the attributes of the same name (None: the attribute)."""
+        dp_world = grad_average_world if grad_average_world is not None else self.grad_average_world
+        if dp_world is None:
+            dp_world = 1
+            if self.shapeloss and not self._warned_world:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                    import warnings
+                    warnings.warn("StabObjective: a process group of %d ranks is initialised and grad_average_world is unset: the shape "
+                                  "term's gradient is NOT scaled for gradient averaging (set grad_average_world = world size if the "
+                                  "ranks' gradients are averaged; train_step does)" % dist.get_world_size())
+                    self._warned_world = True
+        det = self.deterministic if deterministic is None else bool(deterministic)
         m = grids[0].shape[0]
         if m % 2 != 0:
             raise ValueError("StabObjective: expects the two branches batched (m = 2n samples), got m = %d" % m)
@@ -226,8 +243,8 @@ class StabObjective:
             raise ValueError("StabObjective: feature_adjacent must hold n = %d affine maps, got %s" % (n, tuple(feature_adjacent.shape)))
         cfg = {"size": self.size, "number_feature": self.number_feature, "batch": self.batch, "lamd": self.lamd,
                "shapeloss": self.shapeloss, "shapeloss_weight": self.shapeloss_weight, "block": self.block,
-               "num_layer": self.num_layer, "coef": lambda dev: self._coef_matrix(n, dev), "dp_world": self.grad_average_world,
-               "deterministic": self.deterministic}
+               "num_layer": self.num_layer, "coef": lambda dev: self._coef_matrix(n, dev), "dp_world": dp_world,
+               "deterministic": det}
         out = _Objective.apply(cfg, rgb_unstable, image_stable, features.to(dtype=torch.float32).contiguous(), theta,
                                *grids, resid[self.num_layer - 1])
         loss_g, losses, fakes = out[0], out[1], list(out[2:])
@@ -264,9 +281,17 @@ def train_step(netG, optimizerG, batch, objective, perceptual=None, period=30, s
         u8_normalize(img[:, period + 1:], rest[half * n:(half + 1) * n])
     features = torch.cat([features1, features2], 0).to(device=dev, dtype=torch.float32)
     grids, resid = netG(win)
-    if getattr(getattr(netG, "module", netG), "deterministic", False):
-        objective.deterministic = True   # the generator asks for bit-reproducible gradients: so does the objective round it
-    out = objective(grids, resid, rest[:, 0:3], rest[:, 3:], features, feature_adjacent.to(dev))
+    target = getattr(netG, "module", netG)
+    # the generator asks for bit-reproducible gradients: so does the objective round it, for THIS call (the objective may be shared)
+    det = bool(getattr(target, "deterministic", False)) or objective.deterministic
+    # gradients averaged over ranks after this backward (by sync_gradients or by the exchange attached to the generator): the
+    # sum-type shape term's gradient is scaled by the world size (StabObjective.grad_average_world)
+    dp_world = objective.grad_average_world
+    if dp_world is None and (sync_gradients is not None or getattr(target, "grad_sync", None) is not None):
+        import torch.distributed as dist
+        dp_world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    out = objective(grids, resid, rest[:, 0:3], rest[:, 3:], features, feature_adjacent.to(dev), grad_average_world=dp_world,
+                    deterministic=det)
     loss = out.loss_g if perceptual is None else out.loss_g + perceptual(out.fake, rest[:, 3:6])
     optimizerG.zero_grad()
     loss.backward()

@@ -50,6 +50,16 @@ def _worker(rank, world, port, q):
     mean = sum(range(1, world + 1)) / world
     for i, p in enumerate(params):
         assert torch.allclose(p.grad, torch.full_like(p, mean * (i + 1)))
+    # the generator's gradient slab: ranges of ONE flat buffer averaged in place (views: no flatten / copy back), the rest untouched
+    slab = torch.arange(100, dtype=torch.float32) * float(rank + 1)
+    keep = slab.clone()
+    ptr = slab.data_ptr()
+    assert D.allreduce_slab(slab, [(0, 10), (40, 90)], bucket_bytes=64) == 1 + 4      # 16 floats per message
+    want = keep.clone()
+    for a, b in ((0, 10), (40, 90)):
+        want[a:b] = torch.arange(a, b, dtype=torch.float32) * mean
+    assert torch.allclose(slab, want) and slab.data_ptr() == ptr
+    assert D.allreduce_slab(torch.zeros(4), []) == 0
     # replicas start equal: parameters + BatchNorm buffers of rank 0 reach every rank as one flat bucket
     torch.manual_seed(100 + rank)   # define_G initialises from the LOCAL torch RNG: the ranks differ before the broadcast
     m = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4))

@@ -182,3 +182,27 @@ def test_generator_loss_and_train_step_hook(hip, ref):
     np.testing.assert_allclose(float(seen["loss"]), float(want), rtol=5e-3)
     diff = max(float((p.grad - g).abs().max()) for p, g in zip(net.parameters(), g0))
     assert diff > 0, "the perceptual term must reach the generator's parameters"
+
+
+def test_features_vs_torchvision_fixture(hip):
+    """pwstablenet_amd.perceptual.VGG16Features on the HIP kernels against torchvision's own ``vgg16().features[:31]`` forward on
+    seeded weights (lib/utils.py:14-15) -- consumed the day tests/golden/vgg.npz exists (tests/golden/make_golden_vgg.py needs
+    torchvision, which this image lacks: until then the stack is pinned to the torch-CPU restatement only)."""
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(here, "golden", "vgg.npz")
+    if not os.path.exists(path):
+        pytest.skip("PARITY UNPINNED: vgg.npz is absent -- torchvision is not installed in this image; run tests/golden/make_golden_vgg.py where it is")
+    g = np.load(path)
+    spec = importlib.util.spec_from_file_location("make_golden_vgg", os.path.join(here, "golden", "make_golden_vgg.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    from pwstablenet_amd.perceptual import VGG16Features
+    net = VGG16Features("fp32")
+    sd = {k: torch.from_numpy(w) for k, w in zip([str(k) for k in g["state_keys"]], mk.seeded_vgg_weights())}
+    net.features.load_state_dict(sd, strict=True)     # torchvision's own key names load
+    net = net.cuda()
+    with torch.no_grad():
+        f = net(torch.from_numpy(mk.images(21)).cuda()).cpu().numpy()
+    assert np.abs(f - g["features_a"]).max() <= 2e-4 * np.abs(g["features_a"]).max()

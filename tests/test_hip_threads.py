@@ -1,0 +1,143 @@
+"""include/pwstable.h:9-14 promises "re-entrant per stream and per thread" with ONE side queue per device shared by the host
+threads (csrc/netg.cpp: shared_side_queue / SideStream::pick).  The reference's ``nn.DataParallel`` runs one Python thread per
+replica inside ``forward`` (lib/networks_cascading.py:51-52), so this is a path its users take.
+
+Two host threads, each on its own torch stream, run concurrently -- eager inference, hipGraph capture + replay, and one whole
+``train_step`` (two batched forwards, objective, backward on autograd's thread with the weight gradients on the shared side queue,
+fused Adam) -- and every result must equal the same work run serially BIT FOR BIT (deterministic mode for the backward; the
+forward is bit-reproducible as it is).  One case shares a single generator between the threads.
+"""
+import threading
+
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from pwstablenet_amd import synth  # noqa: E402
+
+NGF = 32
+
+
+def make_net(kind, seed, ngf=NGF):
+    from pwstablenet_amd.lib.networks_cascading import define_G
+    net = define_G(31, 2, ngf, "normal", 0.02)
+    net.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in synth.make_weights(kind, seed=seed, ngf=ngf)})
+    return net.cuda()
+
+
+def _in_threads(fns):
+    """Runs the callables concurrently, each on its own stream, all released together; returns their results (raises the first error)."""
+    out, err = [None] * len(fns), [None] * len(fns)
+    go = threading.Barrier(len(fns))
+
+    def body(i):
+        try:
+            torch.cuda.set_device(0)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                go.wait()
+                out[i] = fns[i]()
+            s.synchronize()
+        except BaseException as e:   # noqa: BLE001 -- reported on the main thread
+            err[i] = e
+            try:
+                go.abort()
+            except Exception:
+                pass
+    ts = [threading.Thread(target=body, args=(i,)) for i in range(len(fns))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(600)
+        assert not t.is_alive(), "a worker thread hung"
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+def _infer_work(net, x, rounds, graph):
+    def work():
+        res = []
+        with torch.no_grad():
+            if graph:
+                net.module.enable_graph(True)
+            for r in range(rounds):
+                res.append(net(x[r % len(x)], False).clone())
+            if graph:
+                net.module.enable_graph(False)
+        return res
+    return work
+
+
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph"])
+def test_two_threads_two_generators_inference(hip, graph):
+    nets = [make_net("W1", 123), make_net("W2", 7)]
+    xs = [[torch.from_numpy(synth.noise_window(4, 31, 256, seed=50 + 10 * t + r)).cuda() for r in range(3)] for t in range(2)]
+    assert hip.lib().pws_get_option(hip.OPT_TWO_QUEUES) == 1
+    serial = [_infer_work(nets[t], xs[t], 6, graph)() for t in range(2)]
+    torch.cuda.synchronize()
+    for _ in range(3):   # several attempts at an unlucky interleaving
+        got = _in_threads([_infer_work(nets[t], xs[t], 6, graph) for t in range(2)])
+        torch.cuda.synchronize()
+        for t in range(2):
+            for a, b in zip(got[t], serial[t]):
+                assert torch.equal(a, b), (t, float((a - b).abs().max()))
+
+
+def test_two_threads_share_one_generator(hip):
+    """Eager inference of ONE generator from two threads / streams: the packed weights are shared (read-only once packed), the
+    activation arena is per stream (UnetGenerator._workspace)."""
+    net = make_net("W2", 123)
+    xs = [[torch.from_numpy(synth.noise_window(3, 31, 256, seed=90 + 10 * t + r)).cuda() for r in range(2)] for t in range(2)]
+    serial = [_infer_work(net, xs[t], 6, False)() for t in range(2)]   # (also packs the weights before the threads start)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        got = _in_threads([_infer_work(net, xs[t], 6, False) for t in range(2)])
+        torch.cuda.synchronize()
+        for t in range(2):
+            for a, b in zip(got[t], serial[t]):
+                assert torch.equal(a, b), (t, float((a - b).abs().max()))
+    assert len(net.module._ws) >= 2   # one arena per stream
+
+
+def _train_work(kind, seed, math, items):
+    """A fresh generator + optimizer + one deterministic train_step; returns (loss vector, gradients, updated weights)."""
+    from pwstablenet_amd.objective import LOSS_NAMES, StabObjective, train_step
+    from pwstablenet_amd.optim import Adam
+
+    def work():
+        net = make_net(kind, seed)
+        net.module.set_math(math)
+        net.module.deterministic = True
+        batch = [torch.from_numpy(t).cuda() for t in synth.make_train_batch(items, seed=seed)]
+        opt = Adam(net.parameters(), lr=1e-3, betas=(0.5, 0.999))
+        out = train_step(net, opt, batch, StabObjective(batchSize=items))
+        torch.cuda.current_stream().synchronize()
+        return (torch.stack([out[k].detach().reshape(()) for k in LOSS_NAMES]).cpu(), [p.grad.detach().cpu() for p in net.parameters()],
+                [p.detach().cpu() for p in net.parameters()])
+    return work
+
+
+@pytest.mark.parametrize("math", ["fp32", "bf16"])
+def test_train_step_beside_inference_and_another_train_step(hip, math):
+    """Thread A: a whole train_step.  Thread B: another generator's train_step.  Thread C: eager + graph inference of a third
+    generator.  All three fork into the device's ONE shared side queue (the backward's weight gradients, the forward's second
+    branch) at the same time."""
+    works = [_train_work("W1", 11, math, 2), _train_work("W2", 12, math, 2)]
+    infer_net = make_net("W1", 5)
+    x = [torch.from_numpy(synth.noise_window(2, 31, 256, seed=33 + r)).cuda() for r in range(2)]
+    infer = _infer_work(infer_net, x, 8, True)
+    serial = [w() for w in works] + [infer()]
+    torch.cuda.synchronize()
+    got = _in_threads(works + [infer])
+    torch.cuda.synchronize()
+    for t in range(2):
+        assert torch.equal(got[t][0], serial[t][0]), (got[t][0], serial[t][0])
+        for i, (a, b) in enumerate(zip(got[t][1], serial[t][1])):
+            assert torch.equal(a, b), ("gradient", t, i, float((a - b).abs().max()))
+        for i, (a, b) in enumerate(zip(got[t][2], serial[t][2])):
+            assert torch.equal(a, b), ("weight", t, i)
+    for a, b in zip(got[2], serial[2]):
+        assert torch.equal(a, b)

@@ -117,3 +117,33 @@ def test_whole_step_against_reference(og, ref):
             np.testing.assert_allclose(g.reshape(-1)[idx], ref_s, rtol=2e-3, atol=2e-3 * np.abs(ref_s).max())
             cs = og["step_W1_grad_%s_csum" % nm]
             np.testing.assert_allclose(_csum(g)[1], cs[1], rtol=2e-3)
+
+
+def test_vgg_restatement_vs_torchvision_fixture():
+    """oracle/objective_ref.py: vgg16_features / generator_loss against torchvision's own ``vgg16().features[:31]`` (lib/utils.py:14-15)
+    on seeded weights, and the module / key list pwstablenet_amd.perceptual.VGG16Features must mirror: consumed the day
+    tests/golden/vgg.npz exists (tests/golden/make_golden_vgg.py; torchvision is not in this image)."""
+    import importlib.util
+    import os
+    import pytest
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(here, "golden", "vgg.npz")
+    if not os.path.exists(path):
+        pytest.skip("PARITY UNPINNED: vgg.npz is absent -- torchvision is not installed in this image; run tests/golden/make_golden_vgg.py where it is")
+    g = np.load(path)
+    spec = importlib.util.spec_from_file_location("make_golden_vgg", os.path.join(here, "golden", "make_golden_vgg.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    from oracle import objective_ref as R
+    from pwstablenet_amd.perceptual import VGG16Features
+    params = [torch.from_numpy(w) for w in mk.seeded_vgg_weights()]
+    a, b = torch.from_numpy(mk.images(21)), torch.from_numpy(mk.images(22))
+    with torch.no_grad():
+        fa = R.vgg16_features(params, a)
+        loss = float(R.generator_loss(params, a, b))
+    np.testing.assert_allclose(fa.numpy(), g["features_a"], rtol=1e-4, atol=1e-5 * float(np.abs(g["features_a"]).max()))
+    assert abs(loss - float(g["loss_ab"])) <= 1e-4 * abs(float(g["loss_ab"]))
+    mine = VGG16Features("fp32")
+    assert list(mine.features.state_dict().keys()) == [str(k) for k in g["state_keys"]]
+    assert [",".join(map(str, v.shape)) for v in mine.features.state_dict().values()] == [str(s) for s in g["state_shapes"]]
+    assert ["%d:%s" % (i, type(m).__name__) for i, m in enumerate(mine.features)] == [str(m) for m in g["modules"]]

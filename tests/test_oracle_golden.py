@@ -135,3 +135,32 @@ def test_frameio_restatement_area_resize_dispatch():
     quad[..., 0] = [[0, 1], [0, 1]]                                                    # mean 0.5 -> (2 + 2) >> 2 = 1; half-to-even would give 0
     assert R.resize_area_u8_hwc(quad, 1, 1)[0, 0, 0] == 1
     assert R.resize_area_u8_hwc(img, 12, 18).tobytes() == img.tobytes()                # ratio 1: identity
+
+
+def _fixture(name, what):
+    """A fixture only an image with the third-party package can generate (tests/golden/make_golden_cv2.py / make_golden_vgg.py)."""
+    import os
+    import pytest as _pytest
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)
+    if not os.path.exists(path):
+        _pytest.skip("PARITY UNPINNED: %s is absent -- %s is not installed in this image; run tests/golden/make_golden_%s.py where it is"
+                     % (name, what, name.split(".")[0]))
+    return np.load(path)
+
+
+def test_frameio_restatement_vs_cv2_fixture():
+    """oracle/frameio_ref.py against cv2's OWN bytes (main_new.py:639-640,723): consumed the day tests/golden/cv2.npz exists."""
+    g = _fixture("cv2.npz", "cv2")
+    import importlib.util
+    import os
+    from oracle import frameio_ref as R
+    spec = importlib.util.spec_from_file_location("make_golden_cv2", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden_cv2.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    for name, seed in (("720p", 11), ("1080p", 12), ("480p", 13)):
+        fr = mk.frame_u8(name, seed)
+        gray = R.bgr2gray_u8(fr)
+        assert np.array_equal(gray, g["gray_" + name]), name
+        assert np.array_equal(R.resize_area_u8(gray, 256, 256), g["plane256_" + name]), name
+        assert np.array_equal(R.resize_area_u8_hwc(fr, 360, 640), g["out640x360_" + name]), name
+        assert bool(g["blur_is_identity_" + name]), "GaussianBlur((3,3), 0.2) is not the identity at 8 bits: the build skips it"
