@@ -355,6 +355,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries ONE JSON line: native libraries write to file descriptor 1 as well (RCCL prints its version banner there when
+    # the first communicator is made), so descriptor 1 is pointed at stderr for the rest of the process and the line goes out
+    # through a private duplicate of the original stdout
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if world != a.gpus:
         print("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a %d-GPU number as a %d-GPU one" % (a.gpus, world, world, a.gpus),
               file=sys.stderr)
@@ -390,7 +396,7 @@ def main():
                 print(json.dumps({"launch_check": True, "n_gpus": world, "gpus_arg": a.gpus, "max_over_ranks": float(t.item()),
                                   "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
                                   "control_plane": control_plane,
-                                  "self_launched": os.environ.get("PWS_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+                                  "self_launched": os.environ.get("PWS_BENCH_SELF_LAUNCHED") == "1"}), file=json_out, flush=True)
             dist.barrier()
             dist.destroy_process_group()
             return
@@ -818,7 +824,7 @@ def main():
                 if time.time() > deadline[0]:
                     if rank == 0:
                         line["training_ddp"] = {"error": "did not finish within %g s (watchdog; exit code 3)" % limit}
-                        print(json.dumps(line), flush=True)
+                        print(json.dumps(line), file=json_out, flush=True)
                     os._exit(3)
         threading.Thread(target=watchdog, daemon=True).start()
         dist.barrier()
@@ -908,7 +914,7 @@ def main():
                 line["training_ddp"] = {"error": str(e)[:300]}
         done.set()
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=json_out, flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

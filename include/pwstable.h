@@ -9,8 +9,15 @@
  * Re-entrant per stream and per thread.  Global mutable state: the thread-local error string, the process-wide DEFAULTS of
  * pws_set_option() (read only by the entry points that take no pws_netg_opts; the *_opts entry points carry math / store / queue
  * mode in their arguments and read no global), the per-device side queue of the generator forward / backward (one stream per device
- * and process, shared by the host threads; every thread owns the events it orders it with, and a call that finds the queue inside
- * another thread's graph capture runs on the caller's stream alone) and the measurement hooks (pws_prof_*, off by default).
+ * and process, shared by the EAGER calls of all host threads; every thread owns the events it orders it with, and a call made
+ * inside a hipGraph capture forks into a private stream of the calling thread instead, so the shared queue is never part of
+ * anybody's capture) and the measurement hooks (pws_prof_*, off by default).
+ * What is exercised (tests/test_hip_threads.py, results bit-equal to serial execution): concurrent eager forwards of two generators
+ * and of ONE generator from two threads / streams, concurrent replays of graphs, two whole training steps beside graph replays.
+ * Graph CAPTURE is the caller's: capture after one eager call on the same thread (the library makes its private stream then,
+ * not while the capture is open) and while no other host thread issues GPU work -- on ROCm 7.0 captures that overlapped another
+ * thread's capture, device-wide synchronisation or training step ended invalidated, crashed inside the runtime, or (1 run in 12)
+ * perturbed the other thread's gradient sums (gpurun_out/r4c, tools/probes/thread_race_probe.py).
  *
  * Reference interfaces replaced (paths relative to the mindazhao/PWStableNet checkout; the reference has
  * no native code -- each entry point replaces the PyTorch/ATen op the reference dispatches at that line):

@@ -238,11 +238,13 @@ struct SideStream {
         if (hipStreamIsCapturing(st, &cm) != hipSuccess) return nullptr;
         if (cm == hipStreamCaptureStatusNone) {
             if (!stream) stream = shared_side_queue(dev);
+            // the private stream is made HERE, on the thread's first eager call: creating a stream while a capture is open is one of
+            // the calls a capture may not survive (a host captures after an eager warm-up on the same thread)
+            if (!own && hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess) own = nullptr;
             return stream;
         }
         if (cm != hipStreamCaptureStatusActive) return nullptr;
-        if (!own && hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess) own = nullptr;
-        return own;
+        return own;   // nullptr (one queue) when this thread never made an eager call
     }
     hipEvent_t event() {
         if (next == events.size()) {

@@ -15,6 +15,7 @@ without a GPU or without libpwstable_hip.so raises.  Data parallelism is one pro
 ``torch.distributed``), so the wrapper returned by ``define_G`` never scatters over devices.
 """
 import ctypes
+import threading
 
 import torch
 import torch.nn as nn
@@ -311,24 +312,30 @@ class UnetGenerator(nn.Module):
 
     def _capture(self, x, key, static_input):
         """Captures one forward on ``x`` (or on a private dense copy of it: ``static_input``) with an arena private to the graph.
-        The caller must hold no reference to the previous graph's entry (it is dropped first; its arena is reused when it fits)."""
-        xg = x.clone(memory_format=torch.contiguous_format) if static_input else x
-        nbytes = A.lib().pws_netg_workspace_bytes(xg.shape[0], self.input_nc, self.ngf, 0)
-        old, self._graph = self._graph, None
-        ws = old["ws"] if old is not None and old["ws"].numel() == nbytes + 256 and old["ws"].device == xg.device else None
-        del old   # the previous hipGraphExec, its output and its input buffer go before the new graph is made
-        if ws is None:
-            ws = torch.empty(nbytes + 256, device=xg.device, dtype=torch.uint8)
-        self._run(xg, False, ws=ws)  # eager warm-up: one-time kernel attribute calls must not happen during capture
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        # thread_local: only THIS thread's calls are held to the capture rules -- another host thread (a second replica, a data
-        # loader) may allocate or synchronise while this capture is open without invalidating it
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            out = self._run(xg, False, ws=ws)
-        # one graph is kept; it holds its input tensor (address baked in), its arena and its output
-        self._graph = dict(key=key, g=g, out=out, x=xg, ws=ws, static=static_input)
-        return self._graph
+        The caller must hold no reference to the previous graph's entry (it is dropped first; its arena is reused when it fits).
+        Captures of different host threads are serialised, preamble included (_capture_lock): on this runtime a device-wide
+        synchronisation -- the one below, or the one torch.cuda.graph makes on entry -- from a thread that is about to capture
+        invalidates the capture another thread has open (hipErrorStreamCaptureInvalidated / ...Unjoined, seen in
+        tests/test_hip_threads.py), whatever the capture mode.  A capture happens once per (batch, mode); eager launches and
+        stream-level synchronisation of other threads go on beside it."""
+        with _capture_lock:
+            xg = x.clone(memory_format=torch.contiguous_format) if static_input else x
+            nbytes = A.lib().pws_netg_workspace_bytes(xg.shape[0], self.input_nc, self.ngf, 0)
+            old, self._graph = self._graph, None
+            ws = old["ws"] if old is not None and old["ws"].numel() == nbytes + 256 and old["ws"].device == xg.device else None
+            del old   # the previous hipGraphExec, its output and its input buffer go before the new graph is made
+            if ws is None:
+                ws = torch.empty(nbytes + 256, device=xg.device, dtype=torch.uint8)
+            self._run(xg, False, ws=ws)  # eager warm-up: one-time kernel attribute calls must not happen during capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            # thread_local: only THIS thread's calls are held to the capture rules; its own capture stream: torch.cuda.graph's
+            # default one is shared by every capture of the process
+            with torch.cuda.graph(g, stream=_capture_stream(xg.device), capture_error_mode="thread_local"):
+                out = self._run(xg, False, ws=ws)
+            # one graph is kept; it holds its input tensor (address baked in), its arena and its output
+            self._graph = dict(key=key, g=g, out=out, x=xg, ws=ws, static=static_input)
+            return self._graph
 
     def _run_graph(self, input1):
         x = input1   # may be a strided view (the video loop's overlapping windows): copied ONCE, straight into the graph's input
@@ -389,6 +396,21 @@ class UnetGenerator(nn.Module):
         if is_training:
             return [grids[0], grids[1], grids[2]], [resid[0], resid[1], resid[2]]
         return grids[0]
+
+
+_capture_tls = threading.local()
+_capture_lock = threading.Lock()
+
+
+def _capture_stream(device):
+    """One graph-capture stream per host thread and device."""
+    streams = getattr(_capture_tls, "streams", None)
+    if streams is None:
+        streams = _capture_tls.streams = {}
+    key = str(device)
+    if key not in streams:
+        streams[key] = torch.cuda.Stream(device)
+    return streams[key]
 
 
 def _netg_autograd(net, input1, is_training):

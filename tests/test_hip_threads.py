@@ -6,6 +6,13 @@ Two host threads, each on its own torch stream, run concurrently -- eager infere
 ``train_step`` (two batched forwards, objective, backward on autograd's thread with the weight gradients on the shared side queue,
 fused Adam) -- and every result must equal the same work run serially BIT FOR BIT (deterministic mode for the backward; the
 forward is bit-reproducible as it is).  One case shares a single generator between the threads.
+
+What is NOT exercised concurrently, and why: the CAPTURE of a graph.  On this runtime (ROCm 7.0 HIP under torch 2.10) a capture that
+is open while another host thread captures, or while another thread makes a device-wide synchronisation (torch.cuda.graph does
+one on entry), ended in hipErrorStreamCaptureUnjoined / hipErrorStreamCaptureInvalidated or a segmentation fault inside
+hipDeviceSynchronize in 1 of 3 runs (gpurun_out/r4c/threads*.log, round 4), with thread-local capture mode and one capture stream
+per thread.  Captures are therefore made before the threads start (UnetGenerator._capture additionally serialises captures with a
+process-wide lock); the threads REPLAY concurrently, each copying its input into its graph's static buffer.
 """
 import threading
 
@@ -57,18 +64,26 @@ def _in_threads(fns):
     return out
 
 
-def _infer_work(net, x, rounds, graph):
+def _infer_work(net, x, rounds):
+    """Inference calls on rotating inputs; with enable_graph(True) set by the caller (and the static-input graph captured before the
+    threads start) every call is a copy into the graph's input + a replay."""
     def work():
         res = []
         with torch.no_grad():
-            if graph:
-                net.module.enable_graph(True)
             for r in range(rounds):
                 res.append(net(x[r % len(x)], False).clone())
-            if graph:
-                net.module.enable_graph(False)
         return res
     return work
+
+
+def _capture_serially(net, x):
+    """enable_graph + the calls that make the graph with a private static input (a second input address), on the calling thread."""
+    net.module.enable_graph(True)
+    with torch.no_grad():
+        net(x[0], False), net(x[1], False)
+    torch.cuda.synchronize()
+    assert net.module._graph is not None and net.module._graph["static"]
+    return net.module._graph["g"]
 
 
 @pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph"])
@@ -76,14 +91,17 @@ def test_two_threads_two_generators_inference(hip, graph):
     nets = [make_net("W1", 123), make_net("W2", 7)]
     xs = [[torch.from_numpy(synth.noise_window(4, 31, 256, seed=50 + 10 * t + r)).cuda() for r in range(3)] for t in range(2)]
     assert hip.lib().pws_get_option(hip.OPT_TWO_QUEUES) == 1
-    serial = [_infer_work(nets[t], xs[t], 6, graph)() for t in range(2)]
+    serial = [_infer_work(nets[t], xs[t], 6)() for t in range(2)]     # eager
     torch.cuda.synchronize()
+    graphs = [_capture_serially(nets[t], xs[t]) for t in range(2)] if graph else None
     for _ in range(3):   # several attempts at an unlucky interleaving
-        got = _in_threads([_infer_work(nets[t], xs[t], 6, graph) for t in range(2)])
+        got = _in_threads([_infer_work(nets[t], xs[t], 6) for t in range(2)])
         torch.cuda.synchronize()
         for t in range(2):
             for a, b in zip(got[t], serial[t]):
-                assert torch.equal(a, b), (t, float((a - b).abs().max()))
+                assert torch.equal(a, b), (t, float((a - b).abs().max()))   # (graph replay == eager, bit for bit)
+    if graph:
+        assert all(nets[t].module._graph["g"] is graphs[t] for t in range(2)), "a thread re-captured"
 
 
 def test_two_threads_share_one_generator(hip):
@@ -91,10 +109,10 @@ def test_two_threads_share_one_generator(hip):
     activation arena is per stream (UnetGenerator._workspace)."""
     net = make_net("W2", 123)
     xs = [[torch.from_numpy(synth.noise_window(3, 31, 256, seed=90 + 10 * t + r)).cuda() for r in range(2)] for t in range(2)]
-    serial = [_infer_work(net, xs[t], 6, False)() for t in range(2)]   # (also packs the weights before the threads start)
+    serial = [_infer_work(net, xs[t], 6)() for t in range(2)]   # (also packs the weights before the threads start)
     torch.cuda.synchronize()
     for _ in range(3):
-        got = _in_threads([_infer_work(net, xs[t], 6, False) for t in range(2)])
+        got = _in_threads([_infer_work(net, xs[t], 6) for t in range(2)])
         torch.cuda.synchronize()
         for t in range(2):
             for a, b in zip(got[t], serial[t]):
@@ -122,15 +140,16 @@ def _train_work(kind, seed, math, items):
 
 @pytest.mark.parametrize("math", ["fp32", "bf16"])
 def test_train_step_beside_inference_and_another_train_step(hip, math):
-    """Thread A: a whole train_step.  Thread B: another generator's train_step.  Thread C: eager + graph inference of a third
-    generator.  All three fork into the device's ONE shared side queue (the backward's weight gradients, the forward's second
-    branch) at the same time."""
+    """Thread A: a whole train_step.  Thread B: another generator's train_step.  Thread C: graph replays of a third generator
+    (captured before the threads start).  A and B fork into the device's ONE shared side queue (the backward's weight gradients,
+    the forward's second branch) at the same time, beside C's graph launches."""
     works = [_train_work("W1", 11, math, 2), _train_work("W2", 12, math, 2)]
     infer_net = make_net("W1", 5)
     x = [torch.from_numpy(synth.noise_window(2, 31, 256, seed=33 + r)).cuda() for r in range(2)]
-    infer = _infer_work(infer_net, x, 8, True)
+    infer = _infer_work(infer_net, x, 8)
     serial = [w() for w in works] + [infer()]
     torch.cuda.synchronize()
+    _capture_serially(infer_net, x)
     got = _in_threads(works + [infer])
     torch.cuda.synchronize()
     for t in range(2):
