@@ -227,7 +227,7 @@ def cpu_baseline(timed=None):
     return res
 
 
-def configs2_step_leg(net, dev, n_items, math, reps, sync=None, seed=500, perceptual=None):
+def configs2_step_leg(net, dev, n_items, math, reps, sync=None, seed=500, perceptual=None, per_rep=None):
     """BASELINE configs[2] / [3] step, per GPU: n_items item pairs -> 2*n_items generator forwards (is_training), 6 fused
     warp+L1 launches, temporal / feature / smoothness / fp64 shape terms, backward through all of it, [gradient
     all-reduce,] fused Adam (reference main_new.py:84-216 without GAN and without the VGG term, which needs torchvision
@@ -248,6 +248,10 @@ def configs2_step_leg(net, dev, n_items, math, reps, sync=None, seed=500, percep
     t0 = time.perf_counter()
     for _ in range(reps):
         out = train_step(net, opt, batch, obj, sync_gradients=sync, perceptual=perceptual)
+        if per_rep is not None:   # diagnostics (tools/configs2_step.py --per-rep): a host sync per step, host and device time apart
+            th = time.perf_counter()
+            torch.cuda.synchronize()
+            per_rep.append((th, time.perf_counter()))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     loss = float(out.loss_g.detach())
