@@ -62,12 +62,22 @@ struct WbCfg {
     static constexpr int ROW = 64;                               // bytes per LDS row: 32 bf16 channels
     static constexpr int LDS_X = XPL * PIX * ROW, LDS_G = COW * BM * ROW;
     static constexpr int LDS_BYTES = LDS_X + LDS_G + 16;         // + sink for staging items past the tile
+    // Stride 2 (round 4): the pixels of a halo row lie in LDS as [even columns | odd columns].  A k-step's 16 output pixels read the
+    // input columns 2 c + kx -- one parity -- so with the split they are CONSECUTIVE 64-byte rows and the 4 rows x 2 channel halves of
+    // a half-wave's transposing read cover the 64 banks once, as for the stride-1 kinds.  (Dense rows put them 128 bytes apart: two
+    // rows per bank group, 38-43 % of the LDS cycles of the stride-2 kinds were bank conflicts, profiles/r03_pmc_train_bf16_table.log.)
+    static constexpr bool SPLIT = STRIDE_ == 2;
+    static constexpr int HW = (IW + 1) / 2;                      // even columns of a halo row
+    // column of the halo tile whose pixel sits at position q of its LDS row
+    __host__ __device__ static constexpr int col_at(int q) { return SPLIT ? (q < HW ? 2 * q : 2 * (q - HW) + 1) : q; }
+    // LDS row offset (in rows) of filter tap (ky, kx) relative to the k-step's own pixel rows
+    __host__ __device__ static constexpr int tap_rows(int ky, int kx) { return SPLIT ? ky * IW + (kx & 1) * HW + (kx >> 1) : ky * IW + kx; }
 };
 
 // halo-tile pixel of tile-local output pixel p
 template <class C>
 __host__ __device__ constexpr int wb_xoff(int p) {
-    return ((p / (C::TH * C::TW)) * C::IH + ((p % (C::TH * C::TW)) / C::TW) * C::STRIDE) * C::IW + (p % C::TW) * C::STRIDE;
+    return ((p / (C::TH * C::TW)) * C::IH + ((p % (C::TH * C::TW)) / C::TW) * C::STRIDE) * C::IW + (p % C::TW) * (C::SPLIT ? 1 : C::STRIDE);
 }
 // the k-step walk relies on xoff(16 j + c) == xoff(c) + j * xoff(16) for c < 16
 template <class C>
@@ -142,7 +152,7 @@ __global__ void __launch_bounds__(C::THREADS, 2) wgrad_bf16_kernel(const WgradBf
             for (int t = 0; t < C::TG; ++t) {
                 const int tap = (C::NGROUPS == 1 ? 0 : wtg * C::TG) + t;  // wave-uniform
                 if (C::CI32 && tap >= C::TAPS) continue;
-                const int toff = ((tap / C::KS) * C::IW + (tap % C::KS)) * C::ROW;
+                const int toff = C::tap_rows(tap / C::KS, tap % C::KS) * C::ROW;
                 const int joff = j * wb_xoff<C>(16) * C::ROW + toff;
                 const bf16x8 a = tr_pair(lds, a_lane[0] + joff, a_lane[1] + joff);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
@@ -186,7 +196,7 @@ __global__ void __launch_bounds__(C::THREADS, 2) wgrad_bf16_kernel(const WgradBf
 #pragma unroll
             for (int it = B.value; it < E.value; ++it) {
                 const int pix = px0 + XPP * it;
-                const int lx = pix % C::IW, ly = (pix / C::IW) % C::IH, tn = pix / (C::IW * C::IH);
+                const int lx = C::col_at(pix % C::IW), ly = (pix / C::IW) % C::IH, tn = pix / (C::IW * C::IH);
                 const int n = n0 + tn, iy = iy0 + ly, ix = ix0 + lx;
                 const bool ok = pix < C::PIX && xc_ok && n < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
                 const size_t e = ok ? (size_t)((n * p.H + iy) * p.W + ix) * xld : 0;
@@ -273,7 +283,7 @@ __global__ void __launch_bounds__(C::THREADS, 2) wgrad_bf16_kernel(const WgradBf
                     for (int k = 0; k < BATCH; ++k) {
                         const int item = tid + (it0 + k) * C::THREADS;
                         const int pix = item >> 3, c8 = item & 7;
-                        const int lx = pix % C::IW, ly = (pix / C::IW) % C::IH, tn = pix / (C::IW * C::IH);
+                        const int lx = C::col_at(pix % C::IW), ly = (pix / C::IW) % C::IH, tn = pix / (C::IW * C::IH);
                         const int n = n0 + tn, iy = iy0 + ly, ix = ix0 + lx;
                         int ch = ci0 + c8 * 8;
                         const bool ok = item < NIT && ch < p.cin && n < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;

@@ -37,10 +37,12 @@ struct WgradRingParams {
     int tiles_x, tiles_y, ntiles;
     int ci_blocks, co_blocks;
     float *dbias;
+    int xcd_groups;   // 0: 3-D grid; else the number of pixel splits of the XCD-grouped 1-D grid (a multiple of 8)
 };
 
-template <int KS_, int PAD_, int SUBPIX_, bool CI32_ = false>
+template <int KS_, int PAD_, int SUBPIX_, bool CI32_ = false, bool WIDE_ = false, int ABL_ = 0>
 struct WrgCfg {
+    static constexpr int ABL = ABL_;   // timing-only ablations (tools/wgrad_wide_ab.sh; results are wrong): 1 no DMA, 2 no operand reads, 4 no matrix instructions, 8 one atomic per accumulator instead of 16
     static constexpr int KS = KS_, PAD = PAD_, SUBPIX = SUBPIX_;
     // SUBPIX: 0 = dense kinds; 1 = one parity class of the transposed k4 s2 layers per workgroup (2x2 taps: a wave's dy fragment
     // feeds only two matrix instructions -- measured slower than wgrad_bf16_kernel); 2 = the class PAIR (py, 0) and (py, 1) per
@@ -53,7 +55,19 @@ struct WrgCfg {
     // channels x all 25 taps, matrix wave = (output-channel half, tap quarter): 7 / 7 / 7 / 4 accumulators.  (wgrad_bf16_kernel
     // walked the tensors three times, once per group of 10 taps: 2.7 GB of HBM traffic for 0.8 GB of operands.)
     static constexpr bool CI32 = CI32_;
-    static constexpr int XPL = CI32 ? 1 : 2;              // 32-channel planes of the x tile
+    // WIDE (round 4, the class pairs of the transposed layers with cin % 128 == 0): a workgroup = 128 input x 64 output channels x the
+    // 8 taps of a class pair, matrix wave = (32-channel plane of x, class) x BOTH output-channel halves x the 4 taps of its class:
+    // 8 accumulators.  Why: (a) the dy tile is staged once for twice the matrix work (18 instead of 26 bytes per clock and CU through
+    // the LDS-DMA path, which delivers ~20); (b) operand reads: a k-step of a wave is 4 x + 2 dy fragments for 8 matrix instructions
+    // (0.75 fragments each) where the 64 x 64 workgroup's waves read 4 + 1 for 4 (1.25: 160 bytes per clock and CU at full matrix
+    // rate against the LDS's 128); (c) the four workgroups that read the same tiles (2 channel blocks x 2 class rows at 256 input
+    // channels) are issued next to each other on ONE XCD (wrg_launch), so that the re-reads are L2 hits instead of HBM traffic --
+    // x and dy of the largest layer are 537 MB each, twice the Infinity Cache.
+    static constexpr bool WIDE = WIDE_;
+    static_assert(!WIDE || (SUBPIX_ == 2 && !CI32_), "WIDE: class pairs only");
+    static constexpr int XPL = CI32 ? 1 : (WIDE ? 4 : 2); // 32-channel planes of the x tile
+    static constexpr int NCO = WIDE ? 2 : 1;              // output-channel halves of a matrix wave
+    static constexpr int CIB = 32 * XPL;                  // input channels of a workgroup
     static constexpr int NTG = CI32 ? 4 : (PAIR ? 1 : 2); // tap groups: matrix wave = (32 x 32 quadrant, tap group [or class of the pair])
     static constexpr int NG = PAIR ? 4 : 2;               // 32-channel planes of dy: (class of the pair,) output-channel half
     static constexpr int TAPS = KS * KS;
@@ -104,13 +118,21 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5, li = lane & 15, lg = lane >> 4;
 
-    const int cb = blockIdx.y;
-    const int ci0 = (cb / p.co_blocks) * 64, co0 = (cb % p.co_blocks) * 64;
-    // blockIdx.z: the parity class (SUBPIX 1) or py of the class pair (SUBPIX 2: px is the matrix wave's / the dy plane's)
-    const int cls = C::SUBPIX == 1 ? (int)blockIdx.z : 0;
-    const int py = C::PAIR ? (int)blockIdx.z : cls >> 1, px = cls & 1;
+    // (pixel split, channel block, class [row]) of this workgroup.  Plain grids: blockIdx = (split, block, class).  p.xcd_groups: a
+    // 1-D grid in which the `members` = blocks x class rows workgroups that walk the SAME tiles sit next to each other on one XCD
+    // (consecutive workgroup ids go round the 8 XCDs): id = 8 * (group-in-XCD * members + member) + XCD, split = group-in-XCD * 8 + XCD
+    int bx = blockIdx.x, cb = blockIdx.y, bz = blockIdx.z, nsplit = gridDim.x;
+    if (p.xcd_groups) {
+        const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+        const int members = p.ci_blocks * p.co_blocks * 2, member = slot % members;
+        bx = (slot / members) * 8 + xcd, cb = member >> 1, bz = member & 1, nsplit = p.xcd_groups;
+    }
+    const int ci0 = (cb / p.co_blocks) * C::CIB, co0 = (cb % p.co_blocks) * 64;
+    // bz: the parity class (SUBPIX 1) or py of the class pair (SUBPIX 2: px is the matrix wave's / the dy plane's)
+    const int cls = C::SUBPIX == 1 ? bz : 0;
+    const int py = C::PAIR ? bz : cls >> 1, px = cls & 1;
     const int pad_y = C::SUBPIX ? 1 - py : C::PAD, pad_x = C::PAIR ? 1 : (C::SUBPIX ? 1 - px : C::PAD);
-    const int my_tiles = ((int)blockIdx.x < p.ntiles) ? (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int my_tiles = (bx < p.ntiles) ? (p.ntiles - bx + nsplit - 1) / nsplit : 0;
 
     if (wv >= C::MWAVES) {
         // =========================================================================================== loader waves
@@ -122,17 +144,17 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
             const int pc = it * C::LWAVES + lw;
             int kind, pl0;
             if (pc < C::XPL * C::XPP) kind = pc / C::XPP, pl0 = kind * C::XPP;
-            else kind = 2 + (pc - C::XPL * C::XPP) / C::GPP, pl0 = C::XPL * C::XPP + (kind - 2) * C::GPP;   // dy plane kind - 2
+            else kind = C::XPL + (pc - C::XPL * C::XPP) / C::GPP, pl0 = C::XPL * C::XPP + (kind - C::XPL) * C::GPP;   // dy plane kind - XPL
             const int j = (pc - pl0) * 64 + lane;
             const int row = j >> 2, sp = j & 3;
-            const bool ok = pc < C::PIECES && row < (kind < 2 ? C::PIX : C::BM);
+            const bool ok = pc < C::PIECES && row < (kind < C::XPL ? C::PIX : C::BM);
             desc[it] = ok ? (kind << 27 | row << 2 | sp) : -1;
         }
         // channel block of the x planes inside the virtual concat (sources are multiples of 32 channels: a plane lies in one source)
-        int xs[2], xch[2];
-        bool xok[2];
+        int xs[4], xch[4];
+        bool xok[4];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < 4; ++q) {
             int ch = ci0 + q * 32, s = 0;
             xok[q] = q < C::XPL && ch < p.cin;
             while (s < p.nsrc - 1 && ch >= wrgsel4(p.src_c, s)) ch -= wrgsel4(p.src_c, s), ++s;
@@ -144,9 +166,9 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
         // instructions takes matrix-pipe cycles from its SIMD: conv_first.hip; the divisions and 32-bit multiplies that turned a
         // row number into an address were ~25 instructions per piece and tile).
         constexpr int S = C::SUBPIX ? 2 : 1;
-        unsigned ldx[2];
+        unsigned ldx[4];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) ldx[q] = (unsigned)wrgsel4(p.src_ld, xs[q]) * 2u;
+        for (int q = 0; q < 4; ++q) ldx[q] = (unsigned)wrgsel4(p.src_ld, xs[q]) * 2u;
         const unsigned ldg = (unsigned)p.gout_ld * 2u;
         unsigned loc[C::NL];
         int geo[C::NL];   // row-in-tile << 10 | column-in-tile
@@ -155,9 +177,9 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
             const int pc = it * C::LWAVES + lw;
             const int row = (desc[it] >> 2) & 0x1ffffff, sp = desc[it] & 3;
             if (pc < C::XPL * C::XPP) {
-                const int q = pc < C::XPP ? 0 : 1;
+                const int q = pc / C::XPP;
                 const int lx = row % C::IW, ly = row / C::IW;
-                loc[it] = (desc[it] >= 0 && xok[q]) ? (unsigned)(ly * p.W + lx) * ldx[q] + (unsigned)(sp * 16) : kWrgOob;
+                loc[it] = (desc[it] >= 0 && wrgsel4(xok, q)) ? (unsigned)(ly * p.W + lx) * wrgsel4(ldx, q) + (unsigned)(sp * 16) : kWrgOob;
                 geo[it] = ly << 10 | lx;
             } else {
                 const int q = ((pc - C::XPL * C::XPP) / C::GPP) & 1;
@@ -166,20 +188,20 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
                 geo[it] = ty << 10 | tx;
             }
         }
-        int tile = blockIdx.x, pbuf = 0;
+        int tile = bx, pbuf = 0;
         auto stage = [&]() {
             const unsigned d_base = uniq((unsigned)(pbuf * C::IMG_BYTES)) + (unsigned)(lw * 1024);
             pbuf ^= 1;
-            if (tile >= p.ntiles) return;   // past the last tile: nothing reads that buffer (the waits are vmcnt(0): no piece count to keep)
+            if (tile >= p.ntiles || (C::ABL & 1)) return;   // past the last tile: nothing reads that buffer (the waits are vmcnt(0): no piece count to keep)
             const int tt = tile;
             const int tx_i = tt % p.tiles_x, ty_i = (tt / p.tiles_x) % p.tiles_y, n0 = tt / (p.tiles_x * p.tiles_y);
             const int y0 = ty_i * C::TH, x0 = tx_i * C::TW;
             const int iy0 = y0 - pad_y, ix0 = x0 - pad_x;
             // descriptors: one sample of each tensor (offsets stay below 2^31 whatever the batch)
-            __amdgpu_buffer_rsrc_t rx[2];
-            unsigned sx[2];
+            __amdgpu_buffer_rsrc_t rx[4];
+            unsigned sx[4];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < C::XPL; ++q) {
                 const int ld = wrgsel4(p.src_ld, xs[q]);
                 const size_t img = (size_t)p.H * p.W * ld * 2;
                 const char *b = uniq(static_cast<const char *>(wrgsel4(p.src_ptr, xs[q])) + (size_t)n0 * img + (size_t)xch[q] * 2);
@@ -195,13 +217,13 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
                 const int pc = it * C::LWAVES + lw;   // wave-uniform: the kind of a piece is too
                 const unsigned dst = d_base + (unsigned)(it * C::LWAVES * 1024);
                 if (pc < C::XPL * C::XPP) {
-                    const int q = pc < C::XPP ? 0 : 1;
-                    unsigned v = loc[it] + (q ? sx[1] : sx[0]);   // (a filler lane stays out of range: ~2^31 + an offset inside one sample)
+                    const int q = pc / C::XPP;   // wave-uniform
+                    unsigned v = loc[it] + (C::XPL == 1 ? sx[0] : (C::XPL == 2 ? (q ? sx[1] : sx[0]) : (q < 2 ? (q ? sx[1] : sx[0]) : (q == 2 ? sx[2] : sx[3]))));   // (a filler lane stays out of range: ~2^31 + an offset inside one sample)
                     if (!x_inside) {
                         const int iy = iy0 + (geo[it] >> 10), ix = ix0 + (geo[it] & 0x3ff);
                         v = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? v : kWrgOob;
                     }
-                    wrg_dma16(dst, v, q ? rx[1] : rx[0], 0u);
+                    wrg_dma16(dst, v, C::XPL == 1 ? rx[0] : (C::XPL == 2 ? (q ? rx[1] : rx[0]) : (q < 2 ? (q ? rx[1] : rx[0]) : (q == 2 ? rx[2] : rx[3]))), 0u);
                 } else {
                     const int g = (pc - C::XPL * C::XPP) / C::GPP;   // dy plane: (class of the pair,) output-channel half
                     const int gpx = C::PAIR ? g >> 1 : px;
@@ -217,7 +239,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
                     wrg_dma16(dst, v, rg, 0u);
                 }
             }
-            tile += gridDim.x;
+            tile += nsplit;
         };
         stage();
         for (int s = 0; s < my_tiles; ++s) {
@@ -231,12 +253,13 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
 
     // =============================================================================================== matrix waves
     const int quad = C::CI32 ? (wv & 1) : (wv & 3), th = C::CI32 ? (wv >> 1) : (wv >> 2);   // quadrant, tap group (PAIR: class px)
-    const int wci = C::CI32 ? 0 : quad >> 1, wco = C::CI32 ? quad : quad & 1;
+    // WIDE: wave = (x plane wv & 3, class wv >> 2), both output-channel halves
+    const int wci = C::CI32 ? 0 : (C::WIDE ? quad : quad >> 1), wco = C::CI32 ? quad : (C::WIDE ? 0 : quad & 1);
     const int t0 = C::PAIR ? 0 : th * C::NT0, nt = C::TAPS - t0 < C::NT0 ? C::TAPS - t0 : C::NT0;   // wave-uniform
     const int wpx = C::PAIR ? th : 0;   // this wave's class of the pair: its x columns start one to the right for px = 1
-    wr_f32x16 acc[C::NT0];
+    wr_f32x16 acc[C::NT0 * C::NCO];
 #pragma unroll
-    for (int t = 0; t < C::NT0; ++t)
+    for (int t = 0; t < C::NT0 * C::NCO; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -251,7 +274,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
         b_lane[q] = C::G_OFF + (wpx * 2 + wco) * C::GP_BYTES + c * C::ROW + colb;
     }
     const bool do_bias = p.dbias != nullptr && cb / p.co_blocks == 0 && (C::PAIR || th == 0) && wci == 0;   // PAIR: both classes' dy
-    float bsum = 0.f;
+    float bsum = 0.f, bsum1 = 0.f;
 
     int cbuf = 0;
     for (int s = 0; s < my_tiles; ++s) {
@@ -259,16 +282,40 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
         __builtin_amdgcn_s_barrier();   // B_s
         asm volatile("" ::: "memory");
         const unsigned char *img = lds + (unsigned)(cbuf * C::IMG_BYTES);
-        constexpr int UNR = C::CI32 ? 2 : C::KSTEPS;   // (7 accumulators: fully unrolled, hipcc hoists operand reads until it spills)
+        constexpr int UNR = C::CI32 || C::WIDE ? 2 : C::KSTEPS;   // (7 / 8 accumulators: fully unrolled, hipcc hoists operand reads until it spills)
 #pragma unroll UNR
         for (int j = 0; j < C::KSTEPS; ++j) {   // k-step j = the 16 pixels of tile row j
+            if (C::WIDE && (C::ABL & 6)) {   // timing only
+                bf16x8 z = {};
+                if (!(C::ABL & 2)) z = wrg_tr_pair(img, b_lane[0] + j * 16 * C::ROW, b_lane[1] + j * 16 * C::ROW);
+                if (!(C::ABL & 4)) {
+#pragma unroll
+                    for (int t = 0; t < C::NT0 * C::NCO; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(z, z, acc[t], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < C::NT0; ++t) {
+                        const int joff = j * C::IW * C::ROW + (((t / C::KS) * C::IW + (t % C::KS) + wpx) * C::ROW);
+                        const bf16x8 a = wrg_tr_pair(img, a_lane[0] + joff, a_lane[1] + joff);
+                        acc[t][0] += (float)a[0] + (float)z[0];
+                    }
+                }
+                continue;
+            }
             const bf16x8 b = wrg_tr_pair(img, b_lane[0] + j * 16 * C::ROW, b_lane[1] + j * 16 * C::ROW);
+            bf16x8 b1 = b;
+            if (C::WIDE) b1 = wrg_tr_pair(img, b_lane[0] + C::GP_BYTES + j * 16 * C::ROW, b_lane[1] + C::GP_BYTES + j * 16 * C::ROW);
             if (do_bias) {   // wave-uniform: this lane holds 8 pixels of dy column l31 (masked pixels are zeros)
                 const bf16x2 one2 = {(__bf16)1.0f, (__bf16)1.0f};
                 bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(b, b, 0, 1), one2, bsum, false);
                 bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(b, b, 2, 3), one2, bsum, false);
                 bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(b, b, 4, 5), one2, bsum, false);
                 bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(b, b, 6, 7), one2, bsum, false);
+                if (C::WIDE) {
+                    bsum1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(b1, b1, 0, 1), one2, bsum1, false);
+                    bsum1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(b1, b1, 2, 3), one2, bsum1, false);
+                    bsum1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(b1, b1, 4, 5), one2, bsum1, false);
+                    bsum1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(b1, b1, 6, 7), one2, bsum1, false);
+                }
             }
 #pragma unroll
             for (int t = 0; t < C::NT0; ++t) {
@@ -277,7 +324,8 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
                     const int toff = ((tap / C::KS) * C::IW + (tap % C::KS) + wpx) * C::ROW;
                     const int joff = j * C::IW * C::ROW + toff;
                     const bf16x8 a = wrg_tr_pair(img, a_lane[0] + joff, a_lane[1] + joff);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+                    acc[t * C::NCO] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t * C::NCO], 0, 0, 0);
+                    if (C::WIDE) acc[t * C::NCO + C::NCO - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[t * C::NCO + C::NCO - 1], 0, 0, 0);
                 }
             }
         }
@@ -285,20 +333,26 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
     }
 
     // ---- one atomic per element: rows = input channels of this wave's quadrant, 32 lanes = 32 consecutive output channels
-    const int co = co0 + wco * 32 + l31;
-    if (do_bias) {
-        bsum += __shfl_xor(bsum, 32, 64);   // the two k halves
-        if (hi == 0 && co < p.cout) atomicAdd(p.dbias + co, bsum);
-    }
 #pragma unroll
-    for (int t = 0; t < C::NT0; ++t) {
-        if (t < nt) {
-            const int tap = t0 + t;
+    for (int h = 0; h < C::NCO; ++h) {
+        const int co = co0 + (C::WIDE ? h : wco) * 32 + l31;
+        if (do_bias) {
+            float bs = h ? bsum1 : bsum;
+            bs += __shfl_xor(bs, 32, 64);   // the two k halves
+            if (hi == 0 && co < p.cout) atomicAdd(p.dbias + co, bs);
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ci = ci0 + wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int ocls = C::PAIR ? py * 2 + wpx : cls;
-                if (ci < p.cin_pad && co < p.cout) atomicAdd(p.dw + ((size_t)(ocls * C::TAPS + tap) * p.cin_pad + ci) * p.cout + co, acc[t][r]);
+        for (int t = 0; t < C::NT0; ++t) {
+            if (t < nt) {
+                const int tap = t0 + t;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = ci0 + wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int ocls = C::PAIR ? py * 2 + wpx : cls;
+                    if ((C::ABL & 8) && r) continue;
+                    if (ci < p.cin_pad && co < p.cout)
+                        atomicAdd(p.dw + ((size_t)(ocls * C::TAPS + tap) * p.cin_pad + ci) * p.cout + co, acc[t * C::NCO + h][r]);
+                }
             }
         }
     }
@@ -325,13 +379,21 @@ static int wrg_launch(WgradRingParams &p, int nclasses, hipStream_t st) {
     }
     p.tiles_x = (p.LW + C::TW - 1) / C::TW, p.tiles_y = (p.LH + C::TH - 1) / C::TH;
     p.ntiles = p.tiles_x * p.tiles_y * p.N;
-    p.ci_blocks = (p.cin_pad + 63) / 64, p.co_blocks = (p.cout + 63) / 64;
+    p.ci_blocks = (p.cin_pad + C::CIB - 1) / C::CIB, p.co_blocks = (p.cout + 63) / 64;
     if (C::PAIR) nclasses = 2;   // grid.z = py: a workgroup takes the classes (py, 0) and (py, 1)
     const long other = (long)p.ci_blocks * p.co_blocks * nclasses;
     // one workgroup per CU and round: the pixel tiles are split over as many workgroups as it takes to give every CU one
     long ps = (ncu + other - 1) / other;
     if (ps > p.ntiles) ps = p.ntiles;
     if (ps < 1 || t_deterministic) ps = 1;
+    p.xcd_groups = 0;
+    if (C::WIDE && ps >= 8 && g_experiment != 84) {
+        // the workgroups that walk the same tiles next to each other on one XCD: a multiple of 8 pixel splits, 1-D grid (kernel head)
+        ps = ps / 8 * 8;
+        p.xcd_groups = (int)ps;
+        hipLaunchKernelGGL((wgrad_ring_kernel<C>), dim3((unsigned)(ps * other)), dim3(C::THREADS), C::LDS_BYTES, st, p);
+        return check_launch("wgrad_ring_kernel");
+    }
     hipLaunchKernelGGL((wgrad_ring_kernel<C>), dim3((unsigned)ps, (unsigned)(p.ci_blocks * p.co_blocks), (unsigned)nclasses), dim3(C::THREADS), C::LDS_BYTES,
                        st, p);
     return check_launch("wgrad_ring_kernel");
@@ -340,7 +402,7 @@ static int wrg_launch(WgradRingParams &p, int nclasses, hipStream_t st) {
 // Called by wgrad_bf16_launch (wgrad_bf16.hip) with its checked arguments for the stride-1 kinds with bf16 storage.  Returns 1 when
 // not covered: fewer than 64 (padded) input channels, maps that 16 x 16 tiles cover badly, too few tiles for a stream.
 int wgrad_ring_try(const pws_conv_bwd_weight_args *a, int cin, hipStream_t st) {
-    if (a->store != PWS_STORE_BF16 || g_experiment == 80) return 1;
+    if (a->store != PWS_STORE_BF16 || g_experiment == 80) return 1;   // 80: never (A/B, tests)
     if (a->kind != PWS_CONV_K3S1 && a->kind != PWS_CONVT_K3S1 && a->kind != PWS_CONVT_K4S2 && a->kind != PWS_CONV_K5S1) return 1;
     const bool first = a->kind == PWS_CONV_K5S1;   // the first layer: one source of 32 (31 + padding) channels
     if (first && (cin != 32 || a->nsrc != 1)) return 1;
@@ -354,7 +416,13 @@ int wgrad_ring_try(const pws_conv_bwd_weight_args *a, int cin, hipStream_t st) {
     // The transposed kind as class pairs (SUBPIX 2): 780 / 416 / 421 / 217 us on the four decoder shapes against 807 / 436 / 423 / 207 us
     // of wgrad_bf16_kernel (one class per workgroup, SUBPIX 1: 910 / 488 / 485 / 248): 54 KB staged per 2 x 1024 matrix cycles is
     // more than the LDS-DMA delivers -- not taken either (81 takes the pairs, 82 the single classes).
-    if (!first && (ct4 || cin < 128) && g_experiment != 81 && g_experiment != 82) return 1;
+    // Round 4: the class pairs on 128 x 64-channel workgroups (WrgCfg<..., WIDE>: dy staged once for twice the matrix work, 0.75 operand
+    // fragments per matrix instruction, the workgroups that share tiles grouped on one XCD) -- taken for cin % 128 == 0;
+    // PWS_OPT_EXPERIMENT 85: never (the previous selection).
+    // (86: every covered launch as 81, but the 64 x 64 pairs)
+    const bool wide = ct4 && cin % 128 == 0 && g_experiment != 85 && g_experiment != 86;   // (1300 + mask: timing-only ablations of the wide kernel)
+    const bool force = g_experiment == 81 || g_experiment == 86;
+    if (!first && ((ct4 && !wide) || cin < 128) && !force && g_experiment != 82) return 1;
     for (int s = 0; s < a->nsrc; ++s)
         if ((size_t)a->h * a->w * a->src[s].ld * 2 >= (1u << 31) || (reinterpret_cast<size_t>(a->src[s].ptr) & 15) || a->src[s].ld % 8 != 0) return 1;
     const int oh = a->kind == PWS_CONVT_K4S2 ? 2 * a->h : a->h, ow = a->kind == PWS_CONVT_K4S2 ? 2 * a->w : a->w;
@@ -367,14 +435,27 @@ int wgrad_ring_try(const pws_conv_bwd_weight_args *a, int cin, hipStream_t st) {
     p.gout = a->gout, p.gout_ld = a->gout_ld, p.dw = a->dw_packed, p.dbias = a->dbias;
     const int nclasses = a->kind == PWS_CONVT_K4S2 ? 4 : 1;
     const long tiles = (long)(a->h / (ct4 ? 8 : 16)) * (a->w / 16) * a->n;
-    const long other = (long)((p.cin_pad + 63) / 64) * ((a->cout + 63) / 64) * (ct4 ? 2 : 1);
+    const long other = (long)((p.cin_pad + (wide ? 127 : 63)) / (wide ? 128 : 64)) * ((a->cout + 63) / 64) * (ct4 ? 2 : 1);
     // a workgroup should stream at least a few tiles (its prologue is one exposed tile load, its tail the atomics)
-    if (tiles * other < 256 * 4 && g_experiment != 81) return 1;
+    if (tiles * other < 256 * 4 && !force) return 1;
     const double k2 = a->kind == PWS_CONVT_K4S2 ? 4 : (first ? 25 : 9);
     const double out_pix = (double)a->n * oh * ow;
     ProfScope prof(KID_WGRAD_RING, 2.0 * out_pix * a->cout * cin * k2,
                    4.0 * ((double)a->n * a->h * a->w * cin + out_pix * a->cout + k2 * cin * a->cout * (nclasses == 4 ? 4 : 1)), st);
     if (ct4 && g_experiment == 82) return (a->h % 16 == 0) ? wrg_launch<WrgCfg<2, 0, 1>>(p, nclasses, st) : 1;   // one class per workgroup (A/B)
+    if (ct4 && wide) {
+        switch (g_experiment) {   // 1300 + mask: timing-only ablations
+        case 1301: return wrg_launch<WrgCfg<2, 0, 2, false, true, 1>>(p, nclasses, st);
+        case 1302: return wrg_launch<WrgCfg<2, 0, 2, false, true, 2>>(p, nclasses, st);
+        case 1303: return wrg_launch<WrgCfg<2, 0, 2, false, true, 3>>(p, nclasses, st);
+        case 1304: return wrg_launch<WrgCfg<2, 0, 2, false, true, 4>>(p, nclasses, st);
+        case 1305: return wrg_launch<WrgCfg<2, 0, 2, false, true, 5>>(p, nclasses, st);
+        case 1307: return wrg_launch<WrgCfg<2, 0, 2, false, true, 7>>(p, nclasses, st);
+        case 1308: return wrg_launch<WrgCfg<2, 0, 2, false, true, 8>>(p, nclasses, st);
+        case 1315: return wrg_launch<WrgCfg<2, 0, 2, false, true, 15>>(p, nclasses, st);
+        default: return wrg_launch<WrgCfg<2, 0, 2, false, true>>(p, nclasses, st);
+        }
+    }
     if (ct4) return wrg_launch<WrgCfg<2, 0, 2>>(p, nclasses, st);
     if (first) return wrg_launch<WrgCfg<5, 2, 0, true>>(p, nclasses, st);
     return wrg_launch<WrgCfg<3, 1, 0>>(p, nclasses, st);

@@ -596,6 +596,11 @@ def test_bf16_one_shot_kernel_forward(hip, kname, shape, src_c, cout):
     ("CONVT_K4S2", (3, 24, 48), [64], 96),         # class pairs per workgroup on 8 x 16 tiles: 24 rows = 3 tiles; cout 96
     ("CONV_K5S1", (2, 32, 48), [32], 64),          # the first layer's shape: one 32-channel plane, 25 taps over 4 tap groups (7 / 7 / 7 / 4)
     ("CONV_K5S1", (1, 16, 16), [32], 96),          # one tile; cout 96: the second output block has one dy plane
+    # round 4: class pairs on 128 x 64-channel workgroups (WrgCfg<..., WIDE>): matrix wave = (32-channel plane, class) x both output halves
+    ("CONVT_K4S2", (2, 16, 32), [128], 64),        # one channel block, 2 class rows: few workgroups, plain 3-D grid
+    ("CONVT_K4S2", (3, 24, 48), [128, 128], 96),   # two channel blocks over a virtual concat; cout 96: the second block has one dy plane
+    ("CONVT_K4S2", (16, 32, 32), [256], 64),       # 256 tiles: XCD-grouped 1-D grid (64 pixel splits x 4 workgroups sharing tiles)
+    ("CONVT_K4S2", (5, 40, 16), [128], 32),        # 32 output channels: the second dy half is masked; 5 tile rows per sample
 ])
 def test_bf16_weight_gradient_ring(hip, kname, shape, src_c, cout):
     """The persistent LDS-ring weight-gradient kernel (csrc/wgrad_ring.hip: bf16 storage, LDS-DMA tile stream; PWS_OPT_EXPERIMENT 81
