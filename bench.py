@@ -772,23 +772,46 @@ def main():
             try:
                 from pwstablenet_amd.stream import VideoStabilizer
                 T = 192
+                SB = 32   # windows per generator call: tools/stream_sweep.py, round 4 -- fp32 8 / 16 / 32: 1611 / 1751 / 1803 f/s, bf16 4501 / 5818 / 6595
                 u8_h = torch.randint(0, 256, (T, 720, 1280, 3), dtype=torch.uint8).pin_memory()
-                vs = VideoStabilizer(net, batch=B, swap_rb=True)
-                vs.run_video(u8_h[:4 * B], chunk=2 * B, half_size_output=True)
+                vs = VideoStabilizer(net, batch=SB, swap_rb=True)
+                vs.run_video(u8_h[:2 * SB], chunk=SB, half_size_output=True)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 out_h = vs.run_video(u8_h, chunk=64, half_size_output=True)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t1
+                # the three activities ALONE on the same clip (upload, the device side with resident frames, download): what the
+                # pipelined run hides.  overlap = slowest alone / pipelined wall (1.0 = the other two fully hidden)
+                u8_d = u8_h.to(dev)
+                small_d = torch.empty((T, 360, 640, 3), dtype=torch.uint8, device=dev)
+
+                def alone(fn):
+                    fn()
+                    torch.cuda.synchronize()
+                    t_ = time.perf_counter()
+                    fn()
+                    torch.cuda.synchronize()
+                    return time.perf_counter() - t_
+                t_up = alone(lambda: u8_d.copy_(u8_h, non_blocking=True))
+                t_down = alone(lambda: out_h.copy_(small_d, non_blocking=True))
+                t_comp = alone(lambda: vs.run_video(u8_d, chunk=64, half_size_output=True))
                 line["value_720p_stream_u8"] = {"value": round(T / dt, 1), "unit": "frames/s", "n_gpus": 1,
                                                 "workload": "%d uint8 1280x720 frames, pinned host -> device (2.76 MB per frame) -> gray+"
                                                             "INTER_AREA window planes on the device -> batch %d windows per netG call -> "
-                                                            "fused u8 warp -> 2x INTER_AREA -> pinned host (0.69 MB per frame)" % (T, B),
-                                                "pcie_h2d_gb_per_s": round(T * 2.7648e-3 / dt, 2)}
+                                                            "fused u8 warp -> 2x INTER_AREA -> pinned host (0.69 MB per frame)" % (T, SB),
+                                                "pcie_h2d_gb_per_s": round(T * 2.7648e-3 / dt, 2), "pcie_d2h_gb_per_s": round(T * 0.6912e-3 / dt, 2),
+                                                "alone_ms": {"upload": round(1e3 * t_up, 1), "device_side_frames_resident": round(1e3 * t_comp, 1),
+                                                             "download": round(1e3 * t_down, 1)},
+                                                "pcie_alone_gb_per_s": {"h2d": round(T * 2.7648e-3 / t_up, 1), "d2h": round(T * 0.6912e-3 / t_down, 1)},
+                                                "pipelined_ms": round(1e3 * dt, 1), "overlap": round(max(t_up, t_comp, t_down) / dt, 3),
+                                                "bound": "the fp32 generator (device side alone = %.0f %% of the pipelined wall); PCIe alone would carry %.0f frames/s"
+                                                         % (100 * t_comp / dt, T / max(t_up, t_down))}
+                del u8_d, small_d
                 assert not out_h.is_cuda and tuple(out_h.shape) == (T, 360, 640, 3)
                 if a.math == "fp32":   # the same clip with the generator on the bf16 matrix cores (an extra, never `value`)
                     net.module.set_math("bf16")
-                    vs.run_video(u8_h[:4 * B], chunk=2 * B, half_size_output=True)
+                    vs.run_video(u8_h[:2 * SB], chunk=SB, half_size_output=True)
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
                     out_b = vs.run_video(u8_h, chunk=64, half_size_output=True)
@@ -844,8 +867,9 @@ def main():
             net.module.enable_graph(False)
             net.module.set_math("fp32")
             u8_h = torch.randint(0, 256, (Ts, 720, 1280, 3), dtype=torch.uint8).pin_memory()
-            vs = VideoStabilizer(net, batch=B, swap_rb=True)
-            vs.run_video(u8_h[:4 * B], chunk=2 * B, half_size_output=True)
+            SB = min(32, Ts)   # windows per generator call (tools/stream_sweep.py: 32 is the fastest of 8 / 16 / 32)
+            vs = VideoStabilizer(net, batch=SB, swap_rb=True)
+            vs.run_video(u8_h[:min(Ts, 2 * SB)], chunk=SB, half_size_output=True)
             barrier()
             t1 = time.perf_counter()
             out_h = vs.run_video(u8_h, chunk=64, half_size_output=True)
@@ -858,7 +882,7 @@ def main():
                 line["value_720p_stream_u8"] = {"value": round(world * Ts / float(t.item()), 1), "unit": "frames/s", "n_gpus": world,
                                                 "workload": "%d uint8 1280x720 frames per GPU, pinned host -> device -> window planes, netG fp32 "
                                                             "(batch %d), fused u8 warp, 2x INTER_AREA -> pinned host; frame-sharded, no "
-                                                            "collective" % (Ts, B)}
+                                                            "collective" % (Ts, SB)}
             del u8_h, out_h, vs
         except StopIteration:
             pass

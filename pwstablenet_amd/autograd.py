@@ -114,7 +114,10 @@ class _NetGTrain(torch.autograd.Function):
             dpacked.record_stream(comm)
             for g in grads:
                 g.record_stream(comm)
-        ctx.saved = None  # release the arena
+        ctx.saved = None  # release the arena: back to the generator for the next forward on this stream (UnetGenerator._take_train_arena)
+        ws = sv.pop("ws", None)
+        del sv
+        net._give_train_arena(ws)
         return (None, None) + tuple(grads)
 
 

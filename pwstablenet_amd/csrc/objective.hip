@@ -448,6 +448,91 @@ __global__ void __launch_bounds__(1024) shape_loss_kernel(const float *__restric
     }
 }
 
+// bs == 16 (the reference's configuration: 256 x 256 fields in 16 x 16 blocks), round 4: ONE WAVE per block, 4 pixels of a row per
+// lane (a 32-byte load), the eight sums of A^T val by a 6-step butterfly over the wave -- no shared memory, no workgroup barrier.  The
+// kernel above spends its time in two (backward: four) workgroup reductions of 8 doubles per 256 pixels: 633 us per backward at
+// 64 x 256 x 256 (422 GB/s) for 67 MB of traffic.  Same arithmetic in double; the summation ORDER differs (last bits of the doubles).
+template <bool BWD>
+__global__ void __launch_bounds__(256) shape_loss16_kernel(const float *__restrict__ resid, double *__restrict__ slots, double c,
+                                                           const float *__restrict__ scale, float *__restrict__ gresid, int size, int nblk, unsigned nblocks,
+                                                           double gi00, double gi01, double gi11) {
+    const int lane = threadIdx.x & 63;
+    const unsigned b = blockIdx.x * 4u + (threadIdx.x >> 6);   // (sample, block row, block col)
+    if (b >= nblocks) return;   // whole waves leave together
+    const int n = (int)(b / (unsigned)(nblk * nblk)), by = (int)((b / (unsigned)nblk) % (unsigned)nblk), bx = (int)(b % (unsigned)nblk);
+    const int py = lane >> 2, px0 = (lane & 3) * 4;
+    const double L = 15.0;
+    const double ay[2] = {(L - py) / L, py / L};
+    double ax[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ax[i][0] = (L - (px0 + i)) / L, ax[i][1] = (px0 + i) / L;
+    const size_t q = (((size_t)n * size + (size_t)by * 16 + py) * size + (size_t)bx * 16 + px0) * 2;
+    const float4 v0 = *reinterpret_cast<const float4 *>(resid + q), v1 = *reinterpret_cast<const float4 *>(resid + q + 4);
+    const double bxy[4][2] = {{v0.x, v0.y}, {v0.z, v0.w}, {v1.x, v1.y}, {v1.z, v1.w}};
+    const double gi[2][2] = {{gi00, gi01}, {gi01, gi11}};
+    // out[i] = (A (A^T A)^-1 A^T val)[pixel i of this lane]
+    auto project = [&](const double (&val)[4][2], double (&out)[4][2]) {
+        double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // t[2 k + comp], k = 2 * (y basis) + (x basis): Q11, Q21, Q12, Q22 (lib/utils.py:438-441)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double a = ay[k >> 1] * ax[i][k & 1];
+                t[2 * k] += a * val[i][0], t[2 * k + 1] += a * val[i][1];
+            }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) t[k] += __shfl_xor(t[k], off, 64);
+        double cx[4], cy[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            cx[k] = cy[k] = 0.0;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const double g = gi[k >> 1][l >> 1] * gi[k & 1][l & 1];
+                cx[k] += g * t[2 * l], cy[k] += g * t[2 * l + 1];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            out[i][0] = out[i][1] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double a = ay[k >> 1] * ax[i][k & 1];
+                out[i][0] += a * cx[k], out[i][1] += a * cy[k];
+            }
+        }
+    };
+    double proj[4][2];
+    project(bxy, proj);
+    if constexpr (!BWD) {
+        double l1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) l1 += fabs(proj[i][0] - bxy[i][0]) + fabs(proj[i][1] - bxy[i][1]);   // AB - B, as torch.dist(AB, B, 1)
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) l1 += __shfl_xor(l1, off, 64);
+        if (lane == 0) unsafeAtomicAdd(slots + (b % kSlots), l1);
+    } else {
+        // d sum|PB - B| / dB = (P - I)^T s = P s - s   (P symmetric), s = sign(PB - B)
+        double sg[4][2], ps[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const double r = proj[i][k] - bxy[i][k];
+                sg[i][k] = r > 0 ? 1.0 : (r < 0 ? -1.0 : 0.0);
+            }
+        project(sg, ps);
+        if (scale) c *= (double)*scale;
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[2 * i] = (float)(c * (ps[i][0] - sg[i][0])), o[2 * i + 1] = (float)(c * (ps[i][1] - sg[i][1]));
+        *reinterpret_cast<float4 *>(gresid + q) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4 *>(gresid + q + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ finalize
 __global__ void objective_finalize_kernel(const double *__restrict__ slots, int nq, const double *__restrict__ coef,
                                           int nout, float *__restrict__ out) {
@@ -630,6 +715,12 @@ extern "C" int pws_shape_loss_fwd(const float *resid, double *slots, int m, int 
     PWS_REQUIRE(resid && slots, "pws_shape_loss_fwd: NULL pointer");
     const int threads = ((bs * bs + 63) / 64) * 64;
     ProfScope prof(KID_OBJECTIVE, 120.0 * m * size * size, 8.0 * m * size * size, as_stream(stream));
+    if (bs == 16 && al16(resid) && g_experiment != 90) {   // one wave per block (90: the general kernel, A/B and tests)
+        const unsigned nb = (unsigned)(m * block * block);
+        hipLaunchKernelGGL(shape_loss16_kernel<false>, dim3((nb + 3) / 4), dim3(256), 0, as_stream(stream), resid, slots, 0.0, (const float *)nullptr,
+                           (float *)nullptr, size, block, nb, gi[0], gi[1], gi[2]);
+        return check_launch("shape_loss16_kernel<fwd>");
+    }
     hipLaunchKernelGGL(shape_loss_kernel<false>, dim3((unsigned)(m * block * block)), dim3(threads), 0, as_stream(stream), resid,
                        slots, 0.0, (const float *)nullptr, (float *)nullptr, size, block, bs, gi[0], gi[1], gi[2]);
     return check_launch("shape_loss_kernel<fwd>");
@@ -645,6 +736,12 @@ extern "C" int pws_shape_loss_bwd(const float *resid, double c, const float *sca
     PWS_REQUIRE(resid && gresid, "pws_shape_loss_bwd: NULL pointer");
     const int threads = ((bs * bs + 63) / 64) * 64;
     ProfScope prof(KID_OBJECTIVE, 240.0 * m * size * size, 16.0 * m * size * size, as_stream(stream));
+    if (bs == 16 && al16(resid) && al16(gresid) && g_experiment != 90) {
+        const unsigned nb = (unsigned)(m * block * block);
+        hipLaunchKernelGGL(shape_loss16_kernel<true>, dim3((nb + 3) / 4), dim3(256), 0, as_stream(stream), resid, (double *)nullptr, c, scale, gresid, size,
+                           block, nb, gi[0], gi[1], gi[2]);
+        return check_launch("shape_loss16_kernel<bwd>");
+    }
     hipLaunchKernelGGL(shape_loss_kernel<true>, dim3((unsigned)(m * block * block)), dim3(threads), 0, as_stream(stream), resid,
                        (double *)nullptr, c, scale, gresid, size, block, bs, gi[0], gi[1], gi[2]);
     return check_launch("shape_loss_kernel<bwd>");

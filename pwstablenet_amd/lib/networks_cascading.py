@@ -144,6 +144,7 @@ class UnetGenerator(nn.Module):
         self._packed_dgrad = None
         self._packed_dgrad_key = None
         self._ws = {}
+        self._train_ws = {}
         self._graph_mode = False
         self._graph_alias = False
         self._graph = None
@@ -286,6 +287,33 @@ class UnetGenerator(nn.Module):
             self._ws[sid] = ent
         return ent[1]
 
+    # The training arena (activations + their gradients: 23 GB at 64 samples) is private to a forward until its backward has run.
+    # It is handed back to the GENERATOR, not to torch's caching allocator: there a freed 23 GB block is the best fit for whatever
+    # is allocated next while it lies free (the optimizer's state on the first step did exactly that), the next forward then finds
+    # it split and allocates a second one -- 23 GB more reserved, and a hipMalloc of that size inside a step (1 ms, but 0.5 s when
+    # the driver is still reclaiming a previous process's memory: configs[2] timed 110 ms per step instead of 29 in one process of
+    # six, round 4).  One arena per stream is kept (work on a stream is ordered, so the next forward there may overwrite it);
+    # eval() / release_training_arena() drop it.
+    def _take_train_arena(self, nbytes, device):
+        sid = torch.cuda.current_stream(device).cuda_stream
+        ws = self._train_ws.pop(sid, None)
+        if ws is not None and ws.numel() == nbytes and ws.device == device:
+            return ws
+        del ws
+        return torch.empty(nbytes, device=device, dtype=torch.uint8)
+
+    def _give_train_arena(self, ws):
+        if ws is not None and self.training:
+            self._train_ws[torch.cuda.current_stream(ws.device).cuda_stream] = ws
+
+    def release_training_arena(self):
+        self._train_ws.clear()
+
+    def train(self, mode=True):
+        if not mode:
+            self._train_ws.clear()
+        return super().train(mode)
+
     def forward(self, input1, is_training=True):
         A.require_cuda(input1)
         if input1.dim() != 4 or input1.shape[1] != self.input_nc or input1.shape[2] != 256 or input1.shape[3] != 256:
@@ -374,8 +402,7 @@ class UnetGenerator(nn.Module):
         S = 256
         packed = self.packed_weights()
         if train_ctx is not None:
-            nbytes = A.lib().pws_netg_train_workspace_bytes(n, self.input_nc, self.ngf)
-            ws = torch.empty(nbytes + 256, device=x.device, dtype=torch.uint8)
+            ws = self._take_train_arena(A.lib().pws_netg_train_workspace_bytes(n, self.input_nc, self.ngf) + 256, x.device)
         elif ws is None:
             ws = self._workspace(n, is_training, x.device)
         ws_ptr = (ws.data_ptr() + 255) // 256 * 256

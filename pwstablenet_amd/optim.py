@@ -14,6 +14,11 @@ class Adam:
         self.lr, self.betas, self.eps = lr, betas, eps
         self.state = {}
         self.step_count = 0
+        # the moments of parameters that already sit on the device are made NOW (torch makes them on the first step: there they
+        # would be carved out of whatever large block the first backward has just freed -- see UnetGenerator._take_train_arena)
+        for p in self.params:
+            if p.is_cuda and p.requires_grad:
+                self.state[p] = (torch.zeros_like(p), torch.zeros_like(p))
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:

@@ -72,7 +72,7 @@ def _windows(gray_padded, start, count, period):
 
 
 class VideoStabilizer:
-    def __init__(self, netG, batch=8, period=30, device=None, swap_rb=False):
+    def __init__(self, netG, batch=32, period=30, device=None, swap_rb=False):
         self.net = netG
         self.swap_rb = bool(swap_rb)   # uint8 frames only: BGR (cv2) in, RGB out, as main_new.py:679
         self.batch = int(batch)

@@ -199,6 +199,18 @@ def test_shape_loss_fwd_bwd_vs_reference_function(hip, ref, size, block):
     want = r.grad.numpy()
     np.testing.assert_allclose(gr.cpu().numpy(), want, atol=1e-5)
     assert L.pws_shape_loss_fwd(hip.ptr(d), hip.ptr(slots), 3, size, block * 2, st()) == -22   # size != block^2: refused
+    if block == 16:
+        # 16 x 16 blocks run one WAVE per block (shape_loss16_kernel); PWS_OPT_EXPERIMENT 90 takes the general one-workgroup-per-block
+        # kernel: same doubles up to the summation order
+        try:
+            L.pws_set_option(100, 90)
+            slots2, gr2 = _slots("cuda"), torch.empty_like(d)
+            hip.check(L.pws_shape_loss_fwd(hip.ptr(d), hip.ptr(slots2), 3, size, block, st()), "shape")
+            hip.check(L.pws_shape_loss_bwd(hip.ptr(d), 0.5, None, hip.ptr(gr2), 3, size, block, st()), "shapeb")
+        finally:
+            L.pws_set_option(100, 0)
+        np.testing.assert_allclose(slots2.sum().item(), slots.sum().item(), rtol=1e-12)
+        np.testing.assert_allclose(gr2.cpu().numpy(), gr.cpu().numpy(), atol=1e-7)
 
 
 def test_components_vs_reference_goldens(hip, og):

@@ -39,7 +39,10 @@ def main():
             start = last if last is not None else None
             print("   host %s  device %s" % ("%.1f" % (1e3 * (th - start)) if start else "?", "%.1f" % (1e3 * (td - start)) if start else "?"))
             last = td
-    print("configs[2] step (%d item pairs, %s): %.2f ms, loss_g %.4f" % (a.items, a.math, 1e3 * dt, loss))
+    st = torch.cuda.memory_stats()
+    print("configs[2] step (%d item pairs, %s): %.2f ms, loss_g %.4f   [hipMalloc calls %d, hipFree calls %d, reserved %.1f GB, peak allocated %.1f GB]"
+          % (a.items, a.math, 1e3 * dt, loss, st.get("num_device_alloc", -1), st.get("num_device_free", -1), st["reserved_bytes.all.current"] / 1e9,
+             st["allocated_bytes.all.peak"] / 1e9))
 
 
 if __name__ == "__main__":
