@@ -245,6 +245,119 @@ __global__ void __launch_bounds__(256) temporal_l1_kernel(const float *__restric
     }
 }
 
+// Backward of the temporal term on 32 x 32-pixel tiles (round 4).  The warp is AFFINE, so the four taps of a tile's pixels fall into
+// the bounding box of the tile's image (+ 1 pixel): the workgroup scatters into an LDS copy of that box (ds_add_f32) and adds every
+// box cell to gfake2 ONCE.  temporal_l1_kernel<true> sends 12 fp32 atomics per pixel to memory (25 M per launch at 32 x 256 x 256:
+// 135 us, 3 launches per training step); here it is ~3.4 per pixel (a 34 x 34 box x 3 planes per 1024 pixels).  A tile whose box
+// does not fit the LDS (strong zoom-out / shear in feature_adjacent) takes the per-pixel global atomics -- block-uniform.
+constexpr int kTT = 32;                 // tile edge
+constexpr int kTBoxCells = 56 * 56;     // LDS box: 3 planes x 3136 floats = 37.6 KB
+__global__ void __launch_bounds__(256) temporal_l1_bwd_tiled_kernel(const float *__restrict__ fake1, const float *__restrict__ fake2,
+                                                                    const float *__restrict__ theta, float c, const float *__restrict__ scale,
+                                                                    float *__restrict__ gfake1, float *__restrict__ gfake2, int H, int W, int tiles_x,
+                                                                    int tiles_y) {
+    __shared__ float box[3][kTBoxCells];
+    const int tile = blockIdx.x % (tiles_x * tiles_y), n = blockIdx.x / (tiles_x * tiles_y);
+    const int px0 = (tile % tiles_x) * kTT, py0 = (tile / tiles_x) * kTT;
+    const int HW = H * W;
+    if (scale) c *= *scale;
+    const float *th = theta + (size_t)n * 6;
+    // bounding box (in clamped source pixels) of the taps of this tile: the sample coordinate is affine in the pixel, so its extremes
+    // over the tile are at the tile's corners; taps are floor(.) and floor(.) + 1, clamped to the image as make_taps4 clamps them
+    float ixmin = 3.0e38f, ixmax = -3.0e38f, iymin = 3.0e38f, iymax = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int cx = min(px0 + ((k & 1) ? kTT - 1 : 0), W - 1), cy = min(py0 + ((k & 2) ? kTT - 1 : 0), H - 1);
+        const float bx = base_o(cx, W), by = base_o(cy, H);
+        const float ix = unnorm_o(th[0] * bx + th[1] * by + th[2], W), iy = unnorm_o(th[3] * bx + th[4] * by + th[5], H);
+        ixmin = fminf(ixmin, ix), ixmax = fmaxf(ixmax, ix), iymin = fminf(iymin, iy), iymax = fmaxf(iymax, iy);
+    }
+    // (one pixel of slack either side: the corner values and the per-pixel values round differently)
+    const bool finite = ixmin > -1.0e9f && ixmax < 1.0e9f && iymin > -1.0e9f && iymax < 1.0e9f;   // (NaN compares false)
+    const int x_lo = finite ? min(max((int)floorf(ixmin) - 1, 0), W - 1) : 0, x_hi = finite ? min(max((int)floorf(ixmax) + 2, 0), W - 1) : W - 1;
+    const int y_lo = finite ? min(max((int)floorf(iymin) - 1, 0), H - 1) : 0, y_hi = finite ? min(max((int)floorf(iymax) + 2, 0), H - 1) : H - 1;
+    const int bw = x_hi - x_lo + 1, bh = y_hi - y_lo + 1;
+    const bool in_lds = finite && bw * bh <= kTBoxCells;   // block-uniform
+    if (in_lds) {
+        for (int i = threadIdx.x; i < bw * bh; i += 256) box[0][i] = 0.f, box[1][i] = 0.f, box[2][i] = 0.f;
+        __syncthreads();
+    }
+    // thread t: row t / 8 of the tile, 4 consecutive pixels
+    const int y_ = py0 + (int)(threadIdx.x >> 3), xq = px0 + (int)(threadIdx.x & 7) * 4;
+    if (y_ < H && xq < W) {
+        const bool vec = xq + 3 < W && (W & 3) == 0;
+        float f1[3][4], g1[3][4];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const size_t o = ((size_t)n * 3 + ch) * HW + (size_t)y_ * W + xq;
+            if (vec) {
+                const float4 a = *reinterpret_cast<const float4 *>(fake1 + o), b = *reinterpret_cast<const float4 *>(gfake1 + o);
+                f1[ch][0] = a.x, f1[ch][1] = a.y, f1[ch][2] = a.z, f1[ch][3] = a.w, g1[ch][0] = b.x, g1[ch][1] = b.y, g1[ch][2] = b.z, g1[ch][3] = b.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) f1[ch][i] = xq + i < W ? fake1[o + i] : 0.f, g1[ch][i] = xq + i < W ? gfake1[o + i] : 0.f;
+            }
+        }
+        const float by = base_o(y_, H);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (xq + i >= W) continue;
+            const float bx = base_o(xq + i, W);
+            const Taps4 t = make_taps4(th[0] * bx + th[1] * by + th[2], th[3] * bx + th[4] * by + th[5], H, W);
+            // the taps' cells inside the box (in_lds: the box holds them by construction; the clamp only guards the slack reasoning)
+            int c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+            if (in_lds) {
+                const int r0 = t.o00 / W, q0 = t.o00 % W, r1 = t.o11 / W, q1 = t.o11 % W;   // (cy0, cx0), (cy1, cx1)
+                const int a0 = min(max(r0 - y_lo, 0), bh - 1), a1 = min(max(r1 - y_lo, 0), bh - 1);
+                const int b0 = min(max(q0 - x_lo, 0), bw - 1), b1 = min(max(q1 - x_lo, 0), bw - 1);
+                c00 = a0 * bw + b0, c01 = a0 * bw + b1, c10 = a1 * bw + b0, c11 = a1 * bw + b1;
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float *ip = fake2 + ((size_t)n * 3 + ch) * HW;
+                const float o21 = ip[t.o00] * t.w00 + ip[t.o01] * t.w01 + ip[t.o10] * t.w10 + ip[t.o11] * t.w11;
+                const float sg = c * sgn(o21 - f1[ch][i]);
+                g1[ch][i] -= sg;
+                if (sg == 0.f) continue;
+                if (in_lds) {
+                    if (t.w00 != 0.f) atomicAdd(&box[ch][c00], sg * t.w00);
+                    if (t.w01 != 0.f) atomicAdd(&box[ch][c01], sg * t.w01);
+                    if (t.w10 != 0.f) atomicAdd(&box[ch][c10], sg * t.w10);
+                    if (t.w11 != 0.f) atomicAdd(&box[ch][c11], sg * t.w11);
+                } else {
+                    float *gp = gfake2 + ((size_t)n * 3 + ch) * HW;
+                    if (t.w00 != 0.f) atomicAdd(gp + t.o00, sg * t.w00);
+                    if (t.w01 != 0.f) atomicAdd(gp + t.o01, sg * t.w01);
+                    if (t.w10 != 0.f) atomicAdd(gp + t.o10, sg * t.w10);
+                    if (t.w11 != 0.f) atomicAdd(gp + t.o11, sg * t.w11);
+                }
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const size_t o = ((size_t)n * 3 + ch) * HW + (size_t)y_ * W + xq;
+            if (vec) {
+                *reinterpret_cast<float4 *>(gfake1 + o) = make_float4(g1[ch][0], g1[ch][1], g1[ch][2], g1[ch][3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (xq + i < W) gfake1[o + i] = g1[ch][i];
+            }
+        }
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < bw * bh; i += 256) {
+            const size_t q = (size_t)(y_lo + i / bw) * W + (x_lo + i % bw);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float v = box[ch][i];
+                if (v != 0.f) atomicAdd(gfake2 + ((size_t)n * 3 + ch) * HW + q, v);
+            }
+        }
+    }
+}
+
 // Deterministic adjoint of the affine warp (pws_temporal_l1_bwd_det): gfake2[q] += sum over the output pixels p one of whose four taps
 // is q of S[p] * w(p -> q), as a GATHER -- one lane per source pixel walks its candidates in row-major order, so every element is
 // written by one lane in a fixed order (the scatter adds with fp32 atomics in arrival order).  The sample coordinate is affine in p:
@@ -625,6 +738,12 @@ extern "C" int pws_temporal_l1_bwd(const float *fake1, const float *fake2, const
     const size_t total = (size_t)n * h * w;
     const unsigned nb = (unsigned)((total + 255) / 256);
     ProfScope prof(KID_OBJECTIVE, 110.0 * total, 72.0 * total, as_stream(stream));
+    if (g_experiment != 91) {   // tiles with the scatter in LDS (91: one lane per pixel, atomics to memory -- A/B and tests)
+        const int tx = (w + kTT - 1) / kTT, ty = (h + kTT - 1) / kTT;
+        hipLaunchKernelGGL(temporal_l1_bwd_tiled_kernel, dim3((unsigned)(n * tx * ty)), dim3(256), 0, as_stream(stream), fake1, fake2, theta, c, scale,
+                           gfake1, gfake2, h, w, tx, ty);
+        return check_launch("temporal_l1_bwd_tiled_kernel");
+    }
     hipLaunchKernelGGL(temporal_l1_kernel<true>, dim3(nb), dim3(256), 0, as_stream(stream), fake1, fake2, theta,
                        (double *)nullptr, c, scale, gfake1, gfake2, h, w, total, nb);
     return check_launch("temporal_l1_kernel<bwd>");

@@ -409,7 +409,14 @@ def test_temporal_l1_backward_without_atomics_equals_the_scatter(hip, kind):
             hip.check(L.pws_temporal_l1_bwd(hip.ptr(f1), hip.ptr(f2), hip.ptr(th), c, hip.ptr(two), hip.ptr(g1), hip.ptr(g2), n, hw, hw, st()), "atomics")
         torch.cuda.synchronize()
         return g1, g2
-    a1, a2 = run(False)
+    a1, a2 = run(False)     # tiles with the scatter in LDS (temporal_l1_bwd_tiled_kernel; a box that does not fit scatters to memory)
+    try:
+        L.pws_set_option(100, 91)   # one lane per pixel, atomics to memory
+        p1, p2 = run(False)
+    finally:
+        L.pws_set_option(100, 0)
+    assert torch.equal(a1, p1)
+    assert float((a2 - p2).abs().max()) <= 2e-5 * max(1.0, float(a2.abs().max())), float((a2 - p2).abs().max())
     d1, d2 = run(True)
     e1, e2 = run(True)
     assert torch.equal(d1, e1) and torch.equal(d2, e2)
