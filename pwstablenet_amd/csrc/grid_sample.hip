@@ -700,7 +700,8 @@ extern "C" int pws_grid_sample_fwd(const float *input, const float *grid, float 
         const size_t groups = total / 4;
         const unsigned nb = (unsigned)((groups + 255) / 256);
         // streaming hints once the launch no longer fits the 256 MB Infinity Cache (see the kernel's comment)
-        const bool nt = g_experiment == 1 || ((g_experiment == 0 || g_experiment == 5) && (double)total * (8.0 + 8.0 * c) > 256e6);
+        // (experiments 2..4 are this file's A/B switches: 2 / 3 = never non-temporal; every OTHER value -- other kernels' A/B numbers -- keeps the product rule)
+        const bool nt = g_experiment == 1 || (!(g_experiment >= 2 && g_experiment <= 4) && (double)total * (8.0 + 8.0 * c) > 256e6);
         if (g_experiment == 5 && nt)   // row window + wave shuffle (A/B only, tools/gs_shuffle_ab.py)
             hipLaunchKernelGGL((grid_sample_fwd2_kernel<4, true, true>), dim3(nb), dim3(256), 0, as_stream(stream), input, grid, out, c, h,
                                w, howo, groups, nb, align_corners);
@@ -831,7 +832,7 @@ extern "C" int pws_upsample_grid_sample_fwd(const float *input, const float *fie
     if (w % 4 == 0 && aligned16(out)) {
         const size_t groups = total / 4;
         const unsigned nb = (unsigned)((groups + 255) / 256);
-        const bool nt = g_experiment == 1 || (g_experiment == 0 && (double)total * 8.0 * c > 256e6);
+        const bool nt = g_experiment == 1 || (!(g_experiment >= 2 && g_experiment <= 5) && (double)total * 8.0 * c > 256e6);
         if (3.f * rx < 0.999f && nt)
             hipLaunchKernelGGL((upsample_grid_sample_fwd_kernel<4, true, true>), dim3(nb), dim3(256), 0, as_stream(stream), input,
                                field, out, c, h, w, fh, fw, ry, rx, groups, nb, align_corners);

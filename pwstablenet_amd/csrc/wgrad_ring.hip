@@ -40,7 +40,7 @@ struct WgradRingParams {
     int xcd_groups;   // 0: 3-D grid; else the number of pixel splits of the XCD-grouped 1-D grid (a multiple of 8)
 };
 
-template <int KS_, int PAD_, int SUBPIX_, bool CI32_ = false, bool WIDE_ = false, int ABL_ = 0>
+template <int KS_, int PAD_, int SUBPIX_, bool CI32_ = false, bool WIDE_ = false, int ABL_ = 0, bool S2_ = false, int TH_ = 0, int R_ = 0>
 struct WrgCfg {
     static constexpr int ABL = ABL_;   // timing-only ablations (tools/wgrad_wide_ab.sh; results are wrong): 1 no DMA, 2 no operand reads, 4 no matrix instructions, 8 one atomic per accumulator instead of 16
     static constexpr int KS = KS_, PAD = PAD_, SUBPIX = SUBPIX_;
@@ -50,7 +50,15 @@ struct WrgCfg {
     // its class, so a dy fragment feeds four matrix instructions and the x tile is staged once for eight taps.  The pair's tiles are
     // 8 x 16 pixels (x 9 x 18 + dy 2 x 8 x 16 pixels x 64 channels: 56 KB per tile, two in the ring).
     static constexpr bool PAIR = SUBPIX == 2;
-    static constexpr int TH = PAIR ? 8 : 16, TW = 16;     // stride 1 kinds, tiles of one sample
+    // S2 (round 4): the 3x3 STRIDE-2 layers (conv k3 s2 p1).  Tiles of 4 x 16 OUTPUT pixels; the x tile is the 9 x 33 input pixels under
+    // them, each halo row stored as [17 even columns | 16 odd columns]: a k-step's 16 output pixels read the input columns 2 c + kx --
+    // one parity -- i.e. 16 CONSECUTIVE 64-byte rows, as in the stride-1 kinds (tap (ky, kx) = row offset ky * 33 + (kx & 1) * 17 +
+    // (kx >> 1)); tile row j sits 2 halo rows further.  wgrad_bf16_kernel stages this kind through registers without prefetch (its
+    // 17 x 17 halo leaves no registers): 14 % matrix-pipe busy, 1.8 TB/s (profiles/r03_pmc_train_bf16_table.log).
+    static constexpr bool S2 = S2_;
+    static_assert(!S2 || (KS_ == 3 && PAD_ == 1 && SUBPIX_ == 0 && !CI32_ && !WIDE_), "S2: conv k3 s2 p1");
+    // (TH_ / R_: shorter tiles in a deeper ring -- the tile stream is bound by the bytes IN FLIGHT per tile latency, not by the LDS-DMA rate)
+    static constexpr int TH = TH_ ? TH_ : (S2 ? 4 : (PAIR ? 8 : 16)), TW = 16;     // tiles of one sample
     // CI32: the first layer (5x5, 31 -> 32 padded input channels): ONE 32-channel plane of x, a workgroup = 32 input x 64 output
     // channels x all 25 taps, matrix wave = (output-channel half, tap quarter): 7 / 7 / 7 / 4 accumulators.  (wgrad_bf16_kernel
     // walked the tensors three times, once per group of 10 taps: 2.7 GB of HBM traffic for 0.8 GB of operands.)
@@ -73,7 +81,12 @@ struct WrgCfg {
     static constexpr int TAPS = KS * KS;
     static constexpr int NT0 = (TAPS + NTG - 1) / NTG;    // taps of a wave (the last group takes the rest)
     static constexpr int BM = TH * TW, KSTEPS = BM / 16;
-    static constexpr int IH = TH + KS - 1, IW = TW + KS - 1 + (PAIR ? 1 : 0), PIX = IH * IW;
+    static constexpr int IH = S2 ? 2 * TH + 1 : TH + KS - 1, IW = S2 ? 2 * TW + 1 : TW + KS - 1 + (PAIR ? 1 : 0), PIX = IH * IW;
+    static constexpr int EW = (IW + 1) / 2;               // S2: even columns of a halo row
+    // column of the halo tile at position q of its LDS row; LDS row offset of a tap; LDS rows between consecutive tile rows
+    __host__ __device__ static constexpr int col_at(int q) { return S2 ? (q < EW ? 2 * q : 2 * (q - EW) + 1) : q; }
+    __host__ __device__ static constexpr int tap_rows(int tap) { return S2 ? (tap / KS) * IW + ((tap % KS) & 1) * EW + ((tap % KS) >> 1) : (tap / KS) * IW + (tap % KS); }
+    static constexpr int JROWS = S2 ? 2 * IW : IW;
     static constexpr int ROW = 64;                        // bytes per LDS row: 32 bf16 channels
     static constexpr int XPP = (PIX * 4 + 63) / 64;       // DMA pieces (1 KB) per 32-channel plane of the x tile
     static constexpr int GPP = BM * 4 / 64;               // ... of the dy tile
@@ -82,8 +95,11 @@ struct WrgCfg {
     static constexpr int MWAVES = 8, LWAVES = 4, THREADS = 64 * (MWAVES + LWAVES);
     static constexpr int NL = (PIECES + LWAVES - 1) / LWAVES;
     static constexpr int IMG_BYTES = NL * LWAVES * 1024;
-    static constexpr int R = 2, LDS_BYTES = R * IMG_BYTES;
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    // ring depth: 3 for the S2 kind -- its tiles are short (4 k-steps, 46 KB): with one tile in flight per tile latency (~2.7 us under load)
+    // the stream delivered 8 bytes per clock and CU; two in flight (counted vmcnt) double that
+    static constexpr int R = R_ ? R_ : (S2 ? 3 : 2), LDS_BYTES = R * IMG_BYTES;
+    static_assert((R - 2) * NL <= 63, "vmcnt immediate");
+    static_assert(LDS_BYTES <= 160 * 1024 && R <= 4, "LDS");
 };
 
 __device__ __forceinline__ void wrg_dma16(unsigned lds_addr, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned soff) {
@@ -178,7 +194,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
             const int row = (desc[it] >> 2) & 0x1ffffff, sp = desc[it] & 3;
             if (pc < C::XPL * C::XPP) {
                 const int q = pc / C::XPP;
-                const int lx = row % C::IW, ly = row / C::IW;
+                const int lx = C::col_at(row % C::IW), ly = row / C::IW;
                 loc[it] = (desc[it] >= 0 && wrgsel4(xok, q)) ? (unsigned)(ly * p.W + lx) * wrgsel4(ldx, q) + (unsigned)(sp * 16) : kWrgOob;
                 geo[it] = ly << 10 | lx;
             } else {
@@ -191,12 +207,12 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
         int tile = bx, pbuf = 0;
         auto stage = [&]() {
             const unsigned d_base = uniq((unsigned)(pbuf * C::IMG_BYTES)) + (unsigned)(lw * 1024);
-            pbuf ^= 1;
+            pbuf = pbuf + 1 == C::R ? 0 : pbuf + 1;
             if (tile >= p.ntiles || (C::ABL & 1)) return;   // past the last tile: nothing reads that buffer (the waits are vmcnt(0): no piece count to keep)
             const int tt = tile;
             const int tx_i = tt % p.tiles_x, ty_i = (tt / p.tiles_x) % p.tiles_y, n0 = tt / (p.tiles_x * p.tiles_y);
             const int y0 = ty_i * C::TH, x0 = tx_i * C::TW;
-            const int iy0 = y0 - pad_y, ix0 = x0 - pad_x;
+            const int iy0 = C::S2 ? 2 * y0 - 1 : y0 - pad_y, ix0 = C::S2 ? 2 * x0 - 1 : x0 - pad_x;
             // descriptors: one sample of each tensor (offsets stay below 2^31 whatever the batch)
             __amdgpu_buffer_rsrc_t rx[4];
             unsigned sx[4];
@@ -242,10 +258,17 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
             tile += nsplit;
         };
         stage();
+#pragma unroll
+        for (int k = 2; k < C::R; ++k) stage();
         for (int s = 0; s < my_tiles; ++s) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile s have landed
+            // this wave's pieces of tile s have landed; a ring of R keeps the pieces of tiles s + 1 .. s + R - 2 in flight (in-order
+            // return counting: NL per tile) -- as far as those tiles exist (stage() issues nothing past the end: the count is shorter)
+            const int ahead = my_tiles - 1 - s < C::R - 2 ? my_tiles - 1 - s : C::R - 2;   // wave-uniform
+            if (C::R >= 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * C::NL) : "memory");
+            else if (C::R >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                       // B_s: everybody's have; the matrix waves are done with tile s - 1
-            stage();                                            // tile s + 1 into the buffer tile s - 1 occupied (fillers past the end)
+            stage();                                            // tile s + R - 1 into the buffer tile s - 1 occupied (nothing past the end)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the filler pieces still target this workgroup's LDS
         return;
@@ -321,15 +344,15 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
             for (int t = 0; t < C::NT0; ++t) {
                 if (t < nt) {
                     const int tap = t0 + t;   // wave-uniform
-                    const int toff = ((tap / C::KS) * C::IW + (tap % C::KS) + wpx) * C::ROW;
-                    const int joff = j * C::IW * C::ROW + toff;
+                    const int toff = (C::tap_rows(tap) + wpx) * C::ROW;
+                    const int joff = j * C::JROWS * C::ROW + toff;
                     const bf16x8 a = wrg_tr_pair(img, a_lane[0] + joff, a_lane[1] + joff);
                     acc[t * C::NCO] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t * C::NCO], 0, 0, 0);
                     if (C::WIDE) acc[t * C::NCO + C::NCO - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[t * C::NCO + C::NCO - 1], 0, 0, 0);
                 }
             }
         }
-        cbuf ^= 1;
+        cbuf = cbuf + 1 == C::R ? 0 : cbuf + 1;
     }
 
     // ---- one atomic per element: rows = input channels of this wave's quadrant, 32 lanes = 32 consecutive output channels
@@ -403,11 +426,14 @@ static int wrg_launch(WgradRingParams &p, int nclasses, hipStream_t st) {
 // not covered: fewer than 64 (padded) input channels, maps that 16 x 16 tiles cover badly, too few tiles for a stream.
 int wgrad_ring_try(const pws_conv_bwd_weight_args *a, int cin, hipStream_t st) {
     if (a->store != PWS_STORE_BF16 || g_experiment == 80) return 1;   // 80: never (A/B, tests)
-    if (a->kind != PWS_CONV_K3S1 && a->kind != PWS_CONVT_K3S1 && a->kind != PWS_CONVT_K4S2 && a->kind != PWS_CONV_K5S1) return 1;
+    if (a->kind != PWS_CONV_K3S1 && a->kind != PWS_CONVT_K3S1 && a->kind != PWS_CONVT_K4S2 && a->kind != PWS_CONV_K5S1 && a->kind != PWS_CONV_K3S2) return 1;
     const bool first = a->kind == PWS_CONV_K5S1;   // the first layer: one source of 32 (31 + padding) channels
     if (first && (cin != 32 || a->nsrc != 1)) return 1;
     const bool ct4 = a->kind == PWS_CONVT_K4S2;
-    if ((!first && cin < 64) || a->cout < 32 || a->h % (ct4 ? 8 : 16) != 0 || a->w % 16 != 0) return 1;
+    const bool s2 = a->kind == PWS_CONV_K3S2;      // round 4: tiles of 4 x 16 output pixels (PWS_OPT_EXPERIMENT 87: never)
+    if (s2 && (g_experiment == 87 || a->h % 8 != 0 || a->w % 32 != 0 || cin < 64)) return 1;
+    if (!s2 && ((!first && cin < 64) || a->h % (ct4 ? 8 : 16) != 0 || a->w % 16 != 0)) return 1;
+    if (a->cout < 32) return 1;
     // Measured (tools/wgrad_ring_bench.sh, batch 64, bf16 storage): the first layer (5x5, 32 -> 64 @256^2) 480 us against 1110 us;
     // 3x3 layers of >= 128 channels 329-343 us against 341-358 us of
     // wgrad_bf16_kernel (+4-5 %); 64 -> 64 @256^2 397 vs 372 us and the transposed kind 464-874 vs 410-767 us (its two-tap waves read
@@ -422,19 +448,19 @@ int wgrad_ring_try(const pws_conv_bwd_weight_args *a, int cin, hipStream_t st) {
     // (86: every covered launch as 81, but the 64 x 64 pairs)
     const bool wide = ct4 && cin % 128 == 0 && g_experiment != 85 && g_experiment != 86;   // (1300 + mask: timing-only ablations of the wide kernel)
     const bool force = g_experiment == 81 || g_experiment == 86;
-    if (!first && ((ct4 && !wide) || cin < 128) && !force && g_experiment != 82) return 1;
+    if (!first && !s2 && ((ct4 && !wide) || cin < 128) && !force && g_experiment != 82) return 1;
     for (int s = 0; s < a->nsrc; ++s)
         if ((size_t)a->h * a->w * a->src[s].ld * 2 >= (1u << 31) || (reinterpret_cast<size_t>(a->src[s].ptr) & 15) || a->src[s].ld % 8 != 0) return 1;
-    const int oh = a->kind == PWS_CONVT_K4S2 ? 2 * a->h : a->h, ow = a->kind == PWS_CONVT_K4S2 ? 2 * a->w : a->w;
+    const int oh = ct4 ? 2 * a->h : (s2 ? a->h / 2 : a->h), ow = ct4 ? 2 * a->w : (s2 ? a->w / 2 : a->w);
     if ((size_t)oh * ow * a->gout_ld * 2 >= (1u << 31) || (reinterpret_cast<size_t>(a->gout) & 15) || a->gout_ld % 8 != 0) return 1;
     WgradRingParams p{};
     p.nsrc = a->nsrc;
     for (int s = 0; s < a->nsrc; ++s) p.src_ptr[s] = a->src[s].ptr, p.src_c[s] = a->src[s].channels, p.src_ld[s] = a->src[s].ld;
     p.cin = cin, p.cin_pad = (cin + 15) / 16 * 16, p.cout = a->cout;
-    p.N = a->n, p.H = a->h, p.W = a->w, p.LH = a->h, p.LW = a->w, p.OH = oh, p.OW = ow;
+    p.N = a->n, p.H = a->h, p.W = a->w, p.LH = s2 ? oh : a->h, p.LW = s2 ? ow : a->w, p.OH = oh, p.OW = ow;
     p.gout = a->gout, p.gout_ld = a->gout_ld, p.dw = a->dw_packed, p.dbias = a->dbias;
     const int nclasses = a->kind == PWS_CONVT_K4S2 ? 4 : 1;
-    const long tiles = (long)(a->h / (ct4 ? 8 : 16)) * (a->w / 16) * a->n;
+    const long tiles = s2 ? (long)(oh / 4) * (ow / 16) * a->n : (long)(a->h / (ct4 ? 8 : 16)) * (a->w / 16) * a->n;
     const long other = (long)((p.cin_pad + (wide ? 127 : 63)) / (wide ? 128 : 64)) * ((a->cout + 63) / 64) * (ct4 ? 2 : 1);
     // a workgroup should stream at least a few tiles (its prologue is one exposed tile load, its tail the atomics)
     if (tiles * other < 256 * 4 && !force) return 1;
@@ -453,11 +479,16 @@ int wgrad_ring_try(const pws_conv_bwd_weight_args *a, int cin, hipStream_t st) {
         case 1307: return wrg_launch<WrgCfg<2, 0, 2, false, true, 7>>(p, nclasses, st);
         case 1308: return wrg_launch<WrgCfg<2, 0, 2, false, true, 8>>(p, nclasses, st);
         case 1315: return wrg_launch<WrgCfg<2, 0, 2, false, true, 15>>(p, nclasses, st);
+        // (4 x 16 tiles in a ring of 4 -- 120 instead of 76 KB in flight -- measured SLOWER on all six decoder shapes, 5-11 %: tools/wgrad_ring_ab2.sh)
+        case 88: return wrg_launch<WrgCfg<2, 0, 2, false, true, 0, false, 4, 4>>(p, nclasses, st);
         default: return wrg_launch<WrgCfg<2, 0, 2, false, true>>(p, nclasses, st);
         }
     }
     if (ct4) return wrg_launch<WrgCfg<2, 0, 2>>(p, nclasses, st);
     if (first) return wrg_launch<WrgCfg<5, 2, 0, true>>(p, nclasses, st);
+    if (s2) return wrg_launch<WrgCfg<3, 1, 0, false, false, 0, true>>(p, nclasses, st);
+    // (8 x 16 tiles in a ring of 4: within +-3 % of the 16 x 16 tiles in a ring of 2 on five layer shapes, tools/wgrad_ring_ab2.sh: kept for A/B)
+    if (g_experiment == 88) return wrg_launch<WrgCfg<3, 1, 0, false, false, 0, false, 8, 4>>(p, nclasses, st);
     return wrg_launch<WrgCfg<3, 1, 0>>(p, nclasses, st);
 }
 

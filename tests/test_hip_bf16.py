@@ -601,6 +601,11 @@ def test_bf16_one_shot_kernel_forward(hip, kname, shape, src_c, cout):
     ("CONVT_K4S2", (3, 24, 48), [128, 128], 96),   # two channel blocks over a virtual concat; cout 96: the second block has one dy plane
     ("CONVT_K4S2", (16, 32, 32), [256], 64),       # 256 tiles: XCD-grouped 1-D grid (64 pixel splits x 4 workgroups sharing tiles)
     ("CONVT_K4S2", (5, 40, 16), [128], 32),        # 32 output channels: the second dy half is masked; 5 tile rows per sample
+    # round 4: the stride-2 kind on the ring (WrgCfg<..., S2>): 4 x 16 output tiles, halo rows stored [even | odd columns]
+    ("CONV_K3S2", (2, 32, 64), [64], 64),          # 16 x 32 outputs: 4 x 2 tiles per sample; left / top padding, right / bottom edge inside
+    ("CONV_K3S2", (3, 16, 32), [64, 64], 96),      # two input blocks over a virtual concat; cout 96: the second block has one dy plane
+    ("CONV_K3S2", (8, 64, 64), [128], 128),        # 4 channel blocks, pixel split over workgroups
+    ("CONV_K3S2", (1, 8, 32), [96], 32),           # ONE tile per sample (the whole map), 96 input channels, one dy plane
 ])
 def test_bf16_weight_gradient_ring(hip, kname, shape, src_c, cout):
     """The persistent LDS-ring weight-gradient kernel (csrc/wgrad_ring.hip: bf16 storage, LDS-DMA tile stream; PWS_OPT_EXPERIMENT 81
