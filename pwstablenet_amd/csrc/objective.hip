@@ -250,8 +250,9 @@ __global__ void __launch_bounds__(256) temporal_l1_kernel(const float *__restric
 // box cell to gfake2 ONCE.  temporal_l1_kernel<true> sends 12 fp32 atomics per pixel to memory (25 M per launch at 32 x 256 x 256:
 // 135 us, 3 launches per training step); here it is ~3.4 per pixel (a 34 x 34 box x 3 planes per 1024 pixels).  A tile whose box
 // does not fit the LDS (strong zoom-out / shear in feature_adjacent) takes the per-pixel global atomics -- block-uniform.
+// MEASURED SLOWER than temporal_l1_kernel<true> and not taken by the product (see pws_temporal_l1_bwd); kept for the A/B.
 constexpr int kTT = 32;                 // tile edge
-constexpr int kTBoxCells = 56 * 56;     // LDS box: 3 planes x 3136 floats = 37.6 KB
+constexpr int kTBoxCells = 44 * 44;     // LDS box: 3 planes x 1936 floats = 23 KB (a near-identity map needs 35 x 35): 6 workgroups per CU
 __global__ void __launch_bounds__(256) temporal_l1_bwd_tiled_kernel(const float *__restrict__ fake1, const float *__restrict__ fake2,
                                                                     const float *__restrict__ theta, float c, const float *__restrict__ scale,
                                                                     float *__restrict__ gfake1, float *__restrict__ gfake2, int H, int W, int tiles_x,
@@ -299,33 +300,47 @@ __global__ void __launch_bounds__(256) temporal_l1_bwd_tiled_kernel(const float 
             }
         }
         const float by = base_o(y_, H);
+        // the four pixels' taps first, then all 48 gathers of fake2 back to back (one lane's loads are independent: the kernel is
+        // bound by their latency, not by bytes), then the scatter
+        Taps4 tp[4];
+        int cell[4][4];
+        bool live[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (xq + i >= W) continue;
-            const float bx = base_o(xq + i, W);
-            const Taps4 t = make_taps4(th[0] * bx + th[1] * by + th[2], th[3] * bx + th[4] * by + th[5], H, W);
-            // the taps' cells inside the box (in_lds: the box holds them by construction; the clamp only guards the slack reasoning)
-            int c00 = 0, c01 = 0, c10 = 0, c11 = 0;
-            if (in_lds) {
-                const int r0 = t.o00 / W, q0 = t.o00 % W, r1 = t.o11 / W, q1 = t.o11 % W;   // (cy0, cx0), (cy1, cx1)
+            live[i] = xq + i < W;
+            const float bx = base_o(min(xq + i, W - 1), W);
+            tp[i] = make_taps4(th[0] * bx + th[1] * by + th[2], th[3] * bx + th[4] * by + th[5], H, W);
+            cell[i][0] = cell[i][1] = cell[i][2] = cell[i][3] = 0;
+            if (in_lds) {   // the taps' cells inside the box (it holds them by construction; the clamps only guard that reasoning)
+                const int r0 = tp[i].o00 / W, q0 = tp[i].o00 - r0 * W, r1 = tp[i].o11 / W, q1 = tp[i].o11 - r1 * W;   // (cy0, cx0), (cy1, cx1)
                 const int a0 = min(max(r0 - y_lo, 0), bh - 1), a1 = min(max(r1 - y_lo, 0), bh - 1);
                 const int b0 = min(max(q0 - x_lo, 0), bw - 1), b1 = min(max(q1 - x_lo, 0), bw - 1);
-                c00 = a0 * bw + b0, c01 = a0 * bw + b1, c10 = a1 * bw + b0, c11 = a1 * bw + b1;
+                cell[i][0] = a0 * bw + b0, cell[i][1] = a0 * bw + b1, cell[i][2] = a1 * bw + b0, cell[i][3] = a1 * bw + b1;
             }
+        }
+        float v[3][4][4];
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const float *ip = fake2 + ((size_t)n * 3 + ch) * HW;
-                const float o21 = ip[t.o00] * t.w00 + ip[t.o01] * t.w01 + ip[t.o10] * t.w10 + ip[t.o11] * t.w11;
-                const float sg = c * sgn(o21 - f1[ch][i]);
+        for (int ch = 0; ch < 3; ++ch) {
+            const float *ip = fake2 + ((size_t)n * 3 + ch) * HW;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[ch][i][0] = ip[tp[i].o00], v[ch][i][1] = ip[tp[i].o01], v[ch][i][2] = ip[tp[i].o10], v[ch][i][3] = ip[tp[i].o11];
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float *gp = gfake2 + ((size_t)n * 3 + ch) * HW;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const Taps4 &t = tp[i];
+                const float o21 = v[ch][i][0] * t.w00 + v[ch][i][1] * t.w01 + v[ch][i][2] * t.w10 + v[ch][i][3] * t.w11;
+                const float sg = live[i] ? c * sgn(o21 - f1[ch][i]) : 0.f;
                 g1[ch][i] -= sg;
                 if (sg == 0.f) continue;
                 if (in_lds) {
-                    if (t.w00 != 0.f) atomicAdd(&box[ch][c00], sg * t.w00);
-                    if (t.w01 != 0.f) atomicAdd(&box[ch][c01], sg * t.w01);
-                    if (t.w10 != 0.f) atomicAdd(&box[ch][c10], sg * t.w10);
-                    if (t.w11 != 0.f) atomicAdd(&box[ch][c11], sg * t.w11);
+                    if (t.w00 != 0.f) atomicAdd(&box[ch][cell[i][0]], sg * t.w00);
+                    if (t.w01 != 0.f) atomicAdd(&box[ch][cell[i][1]], sg * t.w01);
+                    if (t.w10 != 0.f) atomicAdd(&box[ch][cell[i][2]], sg * t.w10);
+                    if (t.w11 != 0.f) atomicAdd(&box[ch][cell[i][3]], sg * t.w11);
                 } else {
-                    float *gp = gfake2 + ((size_t)n * 3 + ch) * HW;
                     if (t.w00 != 0.f) atomicAdd(gp + t.o00, sg * t.w00);
                     if (t.w01 != 0.f) atomicAdd(gp + t.o01, sg * t.w01);
                     if (t.w10 != 0.f) atomicAdd(gp + t.o10, sg * t.w10);
@@ -738,7 +753,10 @@ extern "C" int pws_temporal_l1_bwd(const float *fake1, const float *fake2, const
     const size_t total = (size_t)n * h * w;
     const unsigned nb = (unsigned)((total + 255) / 256);
     ProfScope prof(KID_OBJECTIVE, 110.0 * total, 72.0 * total, as_stream(stream));
-    if (g_experiment != 91) {   // tiles with the scatter in LDS (91: one lane per pixel, atomics to memory -- A/B and tests)
+    // Measured (tools/temporal_ab.py, random frames): 108 / 416 us per launch at 32 / 128 samples for one lane per pixel with 12 memory
+    // atomics, 156 / 598 us for the tiles with the scatter in LDS -- the L2 retires fp32 atomics at ~230 G/s, the tiled kernel's two
+    // barriers, box zeroing / flush and 186 registers cost more than the atomics it saves.  NOT taken (PWS_OPT_EXPERIMENT 98 takes it).
+    if (g_experiment == 98) {
         const int tx = (w + kTT - 1) / kTT, ty = (h + kTT - 1) / kTT;
         hipLaunchKernelGGL(temporal_l1_bwd_tiled_kernel, dim3((unsigned)(n * tx * ty)), dim3(256), 0, as_stream(stream), fake1, fake2, theta, c, scale,
                            gfake1, gfake2, h, w, tx, ty);
@@ -834,7 +852,7 @@ extern "C" int pws_shape_loss_fwd(const float *resid, double *slots, int m, int 
     PWS_REQUIRE(resid && slots, "pws_shape_loss_fwd: NULL pointer");
     const int threads = ((bs * bs + 63) / 64) * 64;
     ProfScope prof(KID_OBJECTIVE, 120.0 * m * size * size, 8.0 * m * size * size, as_stream(stream));
-    if (bs == 16 && al16(resid) && g_experiment != 90) {   // one wave per block (90: the general kernel, A/B and tests)
+    if (bs == 16 && al16(resid) && g_experiment != 97) {   // one wave per block (97: the general kernel, A/B and tests)
         const unsigned nb = (unsigned)(m * block * block);
         hipLaunchKernelGGL(shape_loss16_kernel<false>, dim3((nb + 3) / 4), dim3(256), 0, as_stream(stream), resid, slots, 0.0, (const float *)nullptr,
                            (float *)nullptr, size, block, nb, gi[0], gi[1], gi[2]);
@@ -855,7 +873,7 @@ extern "C" int pws_shape_loss_bwd(const float *resid, double c, const float *sca
     PWS_REQUIRE(resid && gresid, "pws_shape_loss_bwd: NULL pointer");
     const int threads = ((bs * bs + 63) / 64) * 64;
     ProfScope prof(KID_OBJECTIVE, 240.0 * m * size * size, 16.0 * m * size * size, as_stream(stream));
-    if (bs == 16 && al16(resid) && al16(gresid) && g_experiment != 90) {
+    if (bs == 16 && al16(resid) && al16(gresid) && g_experiment != 97) {
         const unsigned nb = (unsigned)(m * block * block);
         hipLaunchKernelGGL(shape_loss16_kernel<true>, dim3((nb + 3) / 4), dim3(256), 0, as_stream(stream), resid, (double *)nullptr, c, scale, gresid, size,
                            block, nb, gi[0], gi[1], gi[2]);
