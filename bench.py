@@ -772,13 +772,13 @@ def main():
             try:
                 from pwstablenet_amd.stream import VideoStabilizer
                 T = 192
-                SB = 32   # windows per generator call: tools/stream_sweep.py, round 4 -- fp32 8 / 16 / 32: 1611 / 1751 / 1803 f/s, bf16 4501 / 5818 / 6595
+                SB = 32   # windows per generator call = frames per uploaded chunk: tools/stream_sweep.py, round 4 -- fp32 batch 8 / 16 / 32: 1611 / 1751 / 1803 f/s, bf16 4501 / 5818 / 6595 (chunk 64); chunk 16 / 32 / 64 at batch 32: fp32 1834 / 1848 / 1795, bf16 6455 / 7160 / 6365
                 u8_h = torch.randint(0, 256, (T, 720, 1280, 3), dtype=torch.uint8).pin_memory()
                 vs = VideoStabilizer(net, batch=SB, swap_rb=True)
                 vs.run_video(u8_h[:2 * SB], chunk=SB, half_size_output=True)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                out_h = vs.run_video(u8_h, chunk=64, half_size_output=True)
+                out_h = vs.run_video(u8_h, chunk=32, half_size_output=True)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t1
                 # the three activities ALONE on the same clip (upload, the device side with resident frames, download): what the
@@ -796,7 +796,7 @@ def main():
                     return time.perf_counter() - t_
                 t_up = alone(lambda: u8_d.copy_(u8_h, non_blocking=True))
                 t_down = alone(lambda: down_h.copy_(small_d, non_blocking=True))
-                t_comp = alone(lambda: vs.run_video(u8_d, chunk=64, half_size_output=True))
+                t_comp = alone(lambda: vs.run_video(u8_d, chunk=32, half_size_output=True))
                 line["value_720p_stream_u8"] = {"value": round(T / dt, 1), "unit": "frames/s", "n_gpus": 1,
                                                 "workload": "%d uint8 1280x720 frames, pinned host -> device (2.76 MB per frame) -> gray+"
                                                             "INTER_AREA window planes on the device -> batch %d windows per netG call -> "
@@ -815,7 +815,7 @@ def main():
                     vs.run_video(u8_h[:2 * SB], chunk=SB, half_size_output=True)
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
-                    out_b = vs.run_video(u8_h, chunk=64, half_size_output=True)
+                    out_b = vs.run_video(u8_h, chunk=32, half_size_output=True)
                     torch.cuda.synchronize()
                     dtb = time.perf_counter() - t1
                     net.module.set_math("fp32")
@@ -873,7 +873,7 @@ def main():
             vs.run_video(u8_h[:min(Ts, 2 * SB)], chunk=SB, half_size_output=True)
             barrier()
             t1 = time.perf_counter()
-            out_h = vs.run_video(u8_h, chunk=64, half_size_output=True)
+            out_h = vs.run_video(u8_h, chunk=32, half_size_output=True)
             torch.cuda.synchronize()
             dts = time.perf_counter() - t1
             barrier()

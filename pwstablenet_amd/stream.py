@@ -159,7 +159,7 @@ class VideoStabilizer:
         return out
 
     @torch.no_grad()
-    def run_video(self, frames, chunk=64, half_size_output=False, frames_are_rgb=False, halo_left=0, halo_right=0, crop=None,
+    def run_video(self, frames, chunk=32, half_size_output=False, frames_are_rgb=False, halo_left=0, halo_right=0, crop=None,
                   output_size=None):
         """The whole device side of the reference's ``process()`` loop for one decoded clip: ``frames`` (T, H, W, 3) uint8 as
         cv2 delivers them, in (pinned) host memory or on the device.  Per chunk of ``chunk`` frames: H2D on a side stream,
