@@ -267,6 +267,13 @@ typedef struct pws_conv_bwd_weight_args {
                           (pws_dst.act_y) this replaces the pws_act_bwd_bias pass */
     int deterministic; /* 1: no pixel split -- every element of dw_packed / dbias receives exactly one fp32 atomic add from this
                           launch, so repeated runs are bit-identical (slower: one workgroup per channel block) */
+    /* Optional SECOND operand pair of the same geometry (n, h, w, channels, strides as src[] / gout; ABI version 4): stages 2 and 3 of the
+     * generator run the same modules (lib/networks_cascading.py:178-214), so a shared layer's weight gradient is the sum of two
+     * contributions -- given both, the ring kernels walk the two tensors' tiles in ONE launch (one prologue, one set of epilogue
+     * atomics: 5-11 % less than two launches on the decoder shapes); kinds the ring does not cover run as two launches.
+     * gout2 == NULL: none. */
+    const void *src2_ptr[4];
+    const float *gout2;
 } pws_conv_bwd_weight_args;
 int pws_conv2d_bwd_weight(const pws_conv_bwd_weight_args *args, pws_stream_t stream);
 

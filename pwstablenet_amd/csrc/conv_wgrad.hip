@@ -272,6 +272,8 @@ static const WgChoice &pick(const WgChoice *c, int n, int LH, int LW, int N) {
 
 int wgrad_bf16_launch(const pws_conv_bwd_weight_args *a, hipStream_t st);  // wgrad_bf16.hip
 
+int wgrad_ring_try_pair(const pws_conv_bwd_weight_args *a, hipStream_t st);   // wgrad_ring.hip: both operand pairs in one launch; 1 = not covered
+
 int conv2d_bwd_weight_impl(const pws_conv_bwd_weight_args *a, hipStream_t st) {
     PWS_REQUIRE(a != nullptr, "pws_conv2d_bwd_weight: args is NULL");
     PWS_REQUIRE(a->n >= 0 && a->h > 0 && a->w > 0 && a->cout > 0 && a->cout % 4 == 0, "pws_conv2d_bwd_weight: bad shape");
@@ -279,6 +281,23 @@ int conv2d_bwd_weight_impl(const pws_conv_bwd_weight_args *a, hipStream_t st) {
                     (reinterpret_cast<size_t>(a->gout) & 15) == 0,
                 "pws_conv2d_bwd_weight: bad sources / gout / dw");
     if (a->n == 0) return PWS_OK;
+    if (a->gout2) {
+        // two operand pairs (a layer shared by stages 2 and 3): one launch where the ring kernel covers the layer, else one after the other
+        for (int s = 0; s < a->nsrc; ++s) PWS_REQUIRE(a->src2_ptr[s] != nullptr, "pws_conv2d_bwd_weight: gout2 without src2_ptr[%d]", s);
+        PWS_REQUIRE((reinterpret_cast<size_t>(a->gout2) & 15) == 0, "pws_conv2d_bwd_weight: gout2 alignment");
+        if (a->math == PWS_MATH_BF16 && a->store == PWS_STORE_BF16 && !a->src_nchw && !(t_deterministic && a->dbias)) {
+            const int rc = wgrad_ring_try_pair(a, st);   // 1: not covered
+            if (rc != 1) return rc;
+        }
+        pws_conv_bwd_weight_args b = *a;
+        b.gout2 = nullptr;
+        for (int s = 0; s < 4; ++s) b.src2_ptr[s] = nullptr;
+        int rc = conv2d_bwd_weight_impl(&b, st);
+        if (rc != PWS_OK) return rc;
+        b.gout = a->gout2;
+        for (int s = 0; s < a->nsrc; ++s) b.src[s].ptr = static_cast<const float *>(a->src2_ptr[s]);
+        return conv2d_bwd_weight_impl(&b, st);
+    }
     PWS_REQUIRE(!(t_deterministic && a->dbias),
                 "pws_conv2d_bwd_weight: deterministic with dbias: the parity classes / the scratch-less bias pass add in arrival order -- pass "
                 "dbias = NULL and sum the bias with pws_act_bwd_bias_s(act = PWS_ACT_NONE) and a workspace (ordered slab sums)");

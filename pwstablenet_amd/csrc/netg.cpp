@@ -774,6 +774,10 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
     };
     bool have_dtheta[3] = {false, false, false};
     int rc = PWS_OK;
+    int layer_uses[L_COUNT] = {};
+    for (size_t ii = 0; ii < T; ++ii)
+        if (E.tape()[ii].type == OP_CONV) ++layer_uses[E.tape()[ii].layer];
+    std::unordered_map<int, pws_conv_bwd_weight_args> pending;   // first weight-gradient operand pair of a layer used twice (below)
     for (size_t ii = T; ii-- > 0 && rc == PWS_OK;) {
         const Op &op = E.tape()[ii];
         const size_t r = T - 1 - ii;
@@ -840,6 +844,46 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             GradBuf &go = G[o.ptr];
             if (!go.written) continue;  // nothing downstream asked for a gradient
             const size_t pixels = (size_t)n * op.out.h * op.out.w;
+            // the weight-gradient call of this op (pointers only: built the same way whether this run launches it or replays it)
+            auto make_wa = [&]() {
+                pws_conv_bwd_weight_args wa{};
+                wa.kind = l.kind, wa.n = n, wa.h = op.in.h, wa.w = op.in.w, wa.nsrc = op.in.nseg, wa.src_nchw = op.nchw ? 1 : 0;
+                for (int i = 0; i < op.in.nseg; ++i) wa.src[i] = pws_src{op.in.seg[i].ptr, op.in.seg[i].c, op.in.seg[i].ld};
+                if (op.nchw) wa.src[0] = pws_src{x, input_nc, 0};
+                if (op.nchw && mode.math == PWS_MATH_BF16 && l.wb_off != (size_t)-1 && E.x_nhwc() && input_nc <= 32)
+                    wa.src_nchw = 0, wa.src[0] = pws_src{E.x_nhwc(), 32, 32};  // the forward's NHWC copy
+                wa.cout = l.cout, wa.gout = go.g, wa.gout_ld = l.cout, wa.dw_packed = dpacked + l.gw_off;
+                wa.math = mode.math, wa.store = E.store();
+                // (deterministic: the bias sum is an ordered pass of its own on `st`, below)
+                wa.dbias = !bn && go.preact && !mode.deterministic ? dpacked + l.gb_off : nullptr;
+                return wa;
+            };
+            // A layer that stages 2 AND 3 run (down_bottom2..7, up_bottom7..1: the same modules, reference :178-214) comes by twice: its
+            // first weight gradient (stage 3, earlier in the reversed tape) waits in `pending` and goes out WITH the second one as ONE
+            // launch over both operand pairs (pws_conv_bwd_weight_args.gout2: one prologue, one set of epilogue atomics -- 5-11 % less
+            // than two launches; the first pair's buffers stay untouched until then: a gradient buffer is final once its producer has
+            // been processed).  Returns the call to launch now (nsrc == 0: nothing -- deferred).  PWS_OPT_EXPERIMENT 89 and the kinds
+            // the ring kernels do not cover run the pair as two launches inside pws_conv2d_bwd_weight.
+            const bool shared = !bn && !op.nchw && layer_uses[op.layer] == 2;
+            pws_conv_bwd_weight_args extra{};   // an unmergeable first pair that has to go out by itself (nsrc == 0: none)
+            auto pair_up = [&](pws_conv_bwd_weight_args wa) {
+                if (!shared) return wa;
+                auto mine = pending.find(op.layer);
+                if (mine == pending.end()) {
+                    pending.emplace(op.layer, wa);
+                    wa.nsrc = 0;
+                    return wa;
+                }
+                const pws_conv_bwd_weight_args first = mine->second;
+                pending.erase(mine);
+                if ((first.dbias != nullptr) != (wa.dbias != nullptr)) {   // one pair's bias sum is already in: no merged bias pass
+                    extra = first;
+                    return wa;
+                }
+                for (int i = 0; i < wa.nsrc; ++i) wa.src2_ptr[i] = first.src[i].ptr;
+                wa.gout2 = first.gout;
+                return wa;
+            };
             if (!run) {
                 if (!op.nchw)
                     for (int i = 0; i < op.in.nseg; ++i) {
@@ -847,6 +891,7 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
                         gi.written = true;
                         if (fused_act(ii, op.in.seg[i].ptr) != PWS_ACT_NONE) gi.preact = true;
                     }
+                (void)pair_up(make_wa());   // an earlier run launched (or deferred) it: keep `pending` as that run left it
                 continue;
             }
             g_prof_tag = op.layer;
@@ -854,25 +899,17 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
                 rc = bn_backward(op.layer, go.g, o.ptr, op.aux[0], op.aux[1], op.act, pixels);
             else if (!go.preact)   // (a pre-activation gradient needs the bias sum only: the weight-gradient kernel takes it along)
                 rc = pws_act_bwd_bias_s(go.g, o.ptr, pixels, l.cout, op.act, dpacked + l.gb_off, E.store(), abb_ws, abb_bytes, st);
-            if (rc != PWS_OK) break;
-            pws_conv_bwd_weight_args wa{};
-            wa.kind = l.kind, wa.n = n, wa.h = op.in.h, wa.w = op.in.w, wa.nsrc = op.in.nseg, wa.src_nchw = op.nchw ? 1 : 0;
-            for (int i = 0; i < op.in.nseg; ++i) wa.src[i] = pws_src{op.in.seg[i].ptr, op.in.seg[i].c, op.in.seg[i].ld};
-            if (op.nchw) wa.src[0] = pws_src{x, input_nc, 0};
-            if (op.nchw && mode.math == PWS_MATH_BF16 && l.wb_off != (size_t)-1 && E.x_nhwc() && input_nc <= 32)
-                wa.src_nchw = 0, wa.src[0] = pws_src{E.x_nhwc(), 32, 32};  // the forward's NHWC copy
-            wa.cout = l.cout, wa.gout = go.g, wa.gout_ld = l.cout, wa.dw_packed = dpacked + l.gw_off;
-            wa.math = mode.math, wa.store = E.store();
-            wa.dbias = !bn && go.preact ? dpacked + l.gb_off : nullptr;
-            if (wa.dbias && mode.deterministic) {
+            else if (mode.deterministic)
                 // the weight-gradient kernels' bias sums arrive per parity class / class pair in any order: an ordered pass instead
                 // (act = NONE: sums only, slab partials + ordered reduction)
                 rc = pws_act_bwd_bias_s(go.g, go.g, pixels, l.cout, PWS_ACT_NONE, dpacked + l.gb_off, E.store(), abb_ws, abb_bytes, st);
-                if (rc != PWS_OK) break;
-                wa.dbias = nullptr;
+            if (rc != PWS_OK) break;
+            const pws_conv_bwd_weight_args wa = pair_up(make_wa());
+            if (wa.nsrc > 0 || extra.nsrc > 0) {
+                rc = wgrad_fork();
+                if (rc == PWS_OK && extra.nsrc > 0) rc = pws_conv2d_bwd_weight(&extra, wst);
+                if (rc == PWS_OK && wa.nsrc > 0) rc = pws_conv2d_bwd_weight(&wa, wst);
             }
-            rc = wgrad_fork();
-            if (rc == PWS_OK) rc = pws_conv2d_bwd_weight(&wa, wst);
             if (rc != PWS_OK || op.nchw) {
                 g_prof_tag = -1;
                 continue;  // the window is data: no gradient wrt the first layer's input
@@ -894,6 +931,18 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
             da.store = E.store();
             rc = pws_conv2d_bwd_data(&da, st);
             g_prof_tag = -1;
+        }
+    }
+    // a deferred first pair whose partner never came (its output got no gradient): it goes out in the run that holds the layer's last op
+    if (rc == PWS_OK && !pending.empty()) {
+        for (auto &kv : pending) {
+            size_t last_r = 0;
+            for (size_t ii = 0; ii < T; ++ii)
+                if (E.tape()[ii].type == OP_CONV && E.tape()[ii].layer == kv.first) { last_r = T - 1 - ii; break; }
+            if (last_r < r_begin || last_r >= r_end) continue;
+            rc = wgrad_fork();
+            if (rc == PWS_OK) rc = pws_conv2d_bwd_weight(&kv.second, wst);
+            if (rc != PWS_OK) break;
         }
     }
     if (wst != st) {   // join: whatever follows on `st` (unpack, optimizer, the next part) sees every weight gradient

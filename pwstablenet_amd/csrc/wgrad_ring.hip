@@ -38,6 +38,10 @@ struct WgradRingParams {
     int ci_blocks, co_blocks;
     float *dbias;
     int xcd_groups;   // 0: 3-D grid; else the number of pixel splits of the XCD-grouped 1-D grid (a multiple of 8)
+    // second operand pair (pws_conv_bwd_weight_args.gout2): samples N1 .. N - 1 of the tile walk read these tensors (same geometry)
+    const void *src_ptr2[4];
+    const void *gout2;
+    int N1;           // samples of the first pair (== N without a second one)
 };
 
 template <int KS_, int PAD_, int SUBPIX_, bool CI32_ = false, bool WIDE_ = false, int ABL_ = 0, bool S2_ = false, int TH_ = 0, int R_ = 0>
@@ -210,7 +214,9 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
             pbuf = pbuf + 1 == C::R ? 0 : pbuf + 1;
             if (tile >= p.ntiles || (C::ABL & 1)) return;   // past the last tile: nothing reads that buffer (the waits are vmcnt(0): no piece count to keep)
             const int tt = tile;
-            const int tx_i = tt % p.tiles_x, ty_i = (tt / p.tiles_x) % p.tiles_y, n0 = tt / (p.tiles_x * p.tiles_y);
+            const int tx_i = tt % p.tiles_x, ty_i = (tt / p.tiles_x) % p.tiles_y, nn = tt / (p.tiles_x * p.tiles_y);
+            const bool second = nn >= p.N1;            // (scalar) the tile belongs to the second operand pair
+            const int n0 = second ? nn - p.N1 : nn;
             const int y0 = ty_i * C::TH, x0 = tx_i * C::TW;
             const int iy0 = C::S2 ? 2 * y0 - 1 : y0 - pad_y, ix0 = C::S2 ? 2 * x0 - 1 : x0 - pad_x;
             // descriptors: one sample of each tensor (offsets stay below 2^31 whatever the batch)
@@ -220,12 +226,12 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
             for (int q = 0; q < C::XPL; ++q) {
                 const int ld = wrgsel4(p.src_ld, xs[q]);
                 const size_t img = (size_t)p.H * p.W * ld * 2;
-                const char *b = uniq(static_cast<const char *>(wrgsel4(p.src_ptr, xs[q])) + (size_t)n0 * img + (size_t)xch[q] * 2);
+                const char *b = uniq(static_cast<const char *>(second ? wrgsel4(p.src_ptr2, xs[q]) : wrgsel4(p.src_ptr, xs[q])) + (size_t)n0 * img + (size_t)xch[q] * 2);
                 rx[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(b), 0, (int)uniq((unsigned)(img - (size_t)xch[q] * 2)), 0x00020000);
                 sx[q] = uniq((unsigned)((iy0 * p.W + ix0) * (int)ldx[q]));
             }
             const size_t gimg = (size_t)p.OH * p.OW * p.gout_ld * 2;
-            const char *gb = uniq(static_cast<const char *>(p.gout) + (size_t)n0 * gimg + (size_t)co0 * 2);
+            const char *gb = uniq(static_cast<const char *>(second ? p.gout2 : p.gout) + (size_t)n0 * gimg + (size_t)co0 * 2);
             const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gb), 0, (int)uniq((unsigned)(gimg - (size_t)co0 * 2)), 0x00020000);
             const bool x_inside = iy0 >= 0 && iy0 + C::IH <= p.H && ix0 >= 0 && ix0 + C::IW <= p.W;   // scalar
 #pragma unroll
@@ -424,7 +430,20 @@ static int wrg_launch(WgradRingParams &p, int nclasses, hipStream_t st) {
 
 // Called by wgrad_bf16_launch (wgrad_bf16.hip) with its checked arguments for the stride-1 kinds with bf16 storage.  Returns 1 when
 // not covered: fewer than 64 (padded) input channels, maps that 16 x 16 tiles cover badly, too few tiles for a stream.
-int wgrad_ring_try(const pws_conv_bwd_weight_args *a, int cin, hipStream_t st) {
+static int wgrad_ring_try_impl(const pws_conv_bwd_weight_args *a, int cin, hipStream_t st, bool pair);
+int wgrad_ring_try(const pws_conv_bwd_weight_args *a, int cin, hipStream_t st) { return wgrad_ring_try_impl(a, cin, st, false); }
+// both operand pairs of a->gout2 in one launch (conv2d_bwd_weight_impl); 1 = not covered (the caller then launches them one after the other)
+int wgrad_ring_try_pair(const pws_conv_bwd_weight_args *a, hipStream_t st) {
+    if (g_experiment == 89) return 1;   // A/B: never merge
+    int cin = 0;
+    for (int s = 0; s < a->nsrc; ++s) {
+        if (a->src[s].channels % 32 != 0 || a->src[s].ld % 8 != 0 || (reinterpret_cast<size_t>(a->src2_ptr[s]) & 15)) return 1;
+        cin += a->src[s].channels;
+    }
+    if (a->cout % 8 != 0 || a->gout_ld % 8 != 0) return 1;
+    return wgrad_ring_try_impl(a, cin, st, true);
+}
+static int wgrad_ring_try_impl(const pws_conv_bwd_weight_args *a, int cin, hipStream_t st, bool pair) {
     if (a->store != PWS_STORE_BF16 || g_experiment == 80) return 1;   // 80: never (A/B, tests)
     if (a->kind != PWS_CONV_K3S1 && a->kind != PWS_CONVT_K3S1 && a->kind != PWS_CONVT_K4S2 && a->kind != PWS_CONV_K5S1 && a->kind != PWS_CONV_K3S2) return 1;
     const bool first = a->kind == PWS_CONV_K5S1;   // the first layer: one source of 32 (31 + padding) channels
@@ -457,17 +476,21 @@ int wgrad_ring_try(const pws_conv_bwd_weight_args *a, int cin, hipStream_t st) {
     p.nsrc = a->nsrc;
     for (int s = 0; s < a->nsrc; ++s) p.src_ptr[s] = a->src[s].ptr, p.src_c[s] = a->src[s].channels, p.src_ld[s] = a->src[s].ld;
     p.cin = cin, p.cin_pad = (cin + 15) / 16 * 16, p.cout = a->cout;
-    p.N = a->n, p.H = a->h, p.W = a->w, p.LH = s2 ? oh : a->h, p.LW = s2 ? ow : a->w, p.OH = oh, p.OW = ow;
+    p.N = pair ? 2 * a->n : a->n, p.N1 = a->n, p.H = a->h, p.W = a->w, p.LH = s2 ? oh : a->h, p.LW = s2 ? ow : a->w, p.OH = oh, p.OW = ow;
+    if (pair) {
+        for (int s = 0; s < a->nsrc; ++s) p.src_ptr2[s] = a->src2_ptr[s];
+        p.gout2 = a->gout2;
+    }
     p.gout = a->gout, p.gout_ld = a->gout_ld, p.dw = a->dw_packed, p.dbias = a->dbias;
     const int nclasses = a->kind == PWS_CONVT_K4S2 ? 4 : 1;
-    const long tiles = s2 ? (long)(oh / 4) * (ow / 16) * a->n : (long)(a->h / (ct4 ? 8 : 16)) * (a->w / 16) * a->n;
+    const long tiles = (s2 ? (long)(oh / 4) * (ow / 16) * a->n : (long)(a->h / (ct4 ? 8 : 16)) * (a->w / 16) * a->n) * (pair ? 2 : 1);
     const long other = (long)((p.cin_pad + (wide ? 127 : 63)) / (wide ? 128 : 64)) * ((a->cout + 63) / 64) * (ct4 ? 2 : 1);
     // a workgroup should stream at least a few tiles (its prologue is one exposed tile load, its tail the atomics)
     if (tiles * other < 256 * 4 && !force) return 1;
     const double k2 = a->kind == PWS_CONVT_K4S2 ? 4 : (first ? 25 : 9);
-    const double out_pix = (double)a->n * oh * ow;
+    const double out_pix = (double)p.N * oh * ow;
     ProfScope prof(KID_WGRAD_RING, 2.0 * out_pix * a->cout * cin * k2,
-                   4.0 * ((double)a->n * a->h * a->w * cin + out_pix * a->cout + k2 * cin * a->cout * (nclasses == 4 ? 4 : 1)), st);
+                   4.0 * ((double)p.N * a->h * a->w * cin + out_pix * a->cout + k2 * cin * a->cout * (nclasses == 4 ? 4 : 1)), st);
     if (ct4 && g_experiment == 82) return (a->h % 16 == 0) ? wrg_launch<WrgCfg<2, 0, 1>>(p, nclasses, st) : 1;   // one class per workgroup (A/B)
     if (ct4 && wide) {
         switch (g_experiment) {   // 1300 + mask: timing-only ablations

@@ -54,7 +54,7 @@ class PwsConvBwdWeightArgs(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("n", ctypes.c_int), ("h", ctypes.c_int), ("w", ctypes.c_int), ("nsrc", ctypes.c_int),
                 ("src", PwsSrc * 4), ("src_nchw", ctypes.c_int), ("cout", ctypes.c_int), ("gout", ctypes.c_void_p),
                 ("gout_ld", ctypes.c_int), ("dw_packed", ctypes.c_void_p), ("math", ctypes.c_int), ("store", ctypes.c_int),
-                ("dbias", ctypes.c_void_p), ("deterministic", ctypes.c_int)]
+                ("dbias", ctypes.c_void_p), ("deterministic", ctypes.c_int), ("src2_ptr", ctypes.c_void_p * 4), ("gout2", ctypes.c_void_p)]
 
 
 class PwsNetgOpts(ctypes.Structure):

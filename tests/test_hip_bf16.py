@@ -928,3 +928,83 @@ def test_nchw_to_nhwc_pad_and_first_layer_bf16(hip):
     y = hip_fwd(A, "CONV_K5S1", bf16r(x32), w32, b, 1, [32], 64, 0).numpy()
     want = nhwc(torch_layer("CONV_K5S1", bf16r(x), bf16r(wt), b, 1)).numpy()
     assert relerr(y, want) < TIGHT
+
+
+@pytest.mark.parametrize("kname,shape,src_c,cout,force", [
+    ("CONVT_K4S2", (2, 16, 32), [128], 64, 81),        # class pairs on 128 x 64-channel workgroups: both operand pairs in one ring launch
+    ("CONV_K3S1", (3, 16, 32), [64, 64], 96, 81),      # 3x3 on the ring, virtual concat, cout 96
+    ("CONV_K3S2", (2, 32, 64), [64], 64, 81),          # stride-2 kind on the ring (ring of 3: the tile walk crosses from pair 1 to pair 2)
+    ("CONV_K5S1", (2, 32, 48), [32], 64, 81),          # the first layer's shape on the ring
+    ("CONV_K3S1", (2, 16, 16), [32], 32, 0),           # not covered by the ring (32 input channels): two launches inside the call
+    ("CONVT_K4S2", (2, 8, 8), [64], 32, 80),           # ring switched off: two launches of wgrad_bf16_kernel
+])
+def test_bf16_weight_gradient_of_a_layer_used_twice(hip, kname, shape, src_c, cout, force):
+    """pws_conv_bwd_weight_args.gout2 / src2_ptr (round 4): stages 2 and 3 of the generator run the same modules, so a shared layer's weight
+    gradient is the sum over TWO operand pairs of the same geometry; given both, the ring kernels walk both tensors' tiles in one
+    launch.  Against the sum of two single-pair calls (same products, fp32 summation order) and PyTorch-CPU autograd; dbias over both."""
+    A = hip
+    L, st = A.lib(), A.current_stream()
+    kind = getattr(A, kname)
+    kd, k, s_, p_ = KINDS[kname]
+    pairs = []
+    for tag in ("p1", "p2"):
+        x, wt, b, rs = make_case(kname, shape, src_c, cout, tag)
+        xr = bf16r(x)
+        wg = wt.clone().requires_grad_(True)
+        y = (F.conv2d if kd == "conv" else F.conv_transpose2d)(xr, wg, None, stride=s_, padding=p_)
+        dy = bf16r(torch.from_numpy(rs.standard_normal(tuple(y.shape)).astype(np.float32)))
+        y.backward(dy)
+        pairs.append((x, dy, wg.grad.numpy(), wt))
+    n, cin, h, w = pairs[0][0].shape
+    want_dw = pairs[0][2] + pairs[1][2]
+    want_db = (pairs[0][1].double().sum(dim=(0, 2, 3)) + pairs[1][1].double().sum(dim=(0, 2, 3))).numpy()
+
+    def args(pair, second=None):
+        wa = A.PwsConvBwdWeightArgs()
+        wa.kind, wa.n, wa.h, wa.w, wa.nsrc, wa.cout, wa.math, wa.store = kind, n, h, w, len(src_c), cout, A.MATH_BF16, A.STORE_BF16
+        keep, c0 = [], 0
+        xs = nhwc(pair[0])
+        xs2 = nhwc(second[0]) if second is not None else None
+        for i, c in enumerate(src_c):
+            t = xs[..., c0:c0 + c].contiguous().cuda().bfloat16()
+            keep.append(t)
+            wa.src[i].ptr, wa.src[i].channels, wa.src[i].ld = t.data_ptr(), c, c
+            if xs2 is not None:
+                t2 = xs2[..., c0:c0 + c].contiguous().cuda().bfloat16()
+                keep.append(t2)
+                wa.src2_ptr[i] = t2.data_ptr()
+            c0 += c
+        g = nhwc(pair[1]).cuda().bfloat16()
+        keep.append(g)
+        wa.gout, wa.gout_ld = g.data_ptr(), cout
+        if second is not None:
+            g2 = nhwc(second[1]).cuda().bfloat16()
+            keep.append(g2)
+            wa.gout2 = g2.data_ptr()
+        return wa, keep
+
+    def run(calls):
+        dwp = torch.zeros(L.pws_packed_weight_floats(kind, cin, cout), device="cuda")
+        db = torch.zeros(cout, device="cuda")
+        names = []
+        for wa, _keep in calls:
+            wa.dw_packed, wa.dbias = dwp.data_ptr(), db.data_ptr()
+            L.pws_prof_enable(1)
+            A.check(L.pws_conv2d_bwd_weight(ctypes.byref(wa), st), "bwd_weight pair")
+            L.pws_prof_enable(0)
+            names += [r[0] for r in A.prof_collect()]
+        dw = torch.empty(tuple(pairs[0][3].shape), device="cuda")
+        A.check(L.pws_unpack_conv_weight(A.ptr(dwp), A.ptr(dw), kind, cin, cout, st), "unpack")
+        return dw.cpu().numpy(), db.cpu().numpy(), names
+    try:
+        L.pws_set_option(100, force)
+        both, db_both, names = run([args(pairs[0], pairs[1])])
+        two, db_two, _ = run([args(pairs[0]), args(pairs[1])])
+    finally:
+        L.pws_prof_enable(0)
+        L.pws_set_option(100, 0)
+    assert names == (["wgrad_ring_kernel"] if force == 81 else ["wgrad_bf16_kernel"] * 2), names
+    assert relerr(both, want_dw) < 1e-4 and relerr(both, two) < 2e-5
+    tol = 2e-5 * (np.abs(pairs[0][1].numpy()).sum(axis=(0, 2, 3)).max() + np.abs(pairs[1][1].numpy()).sum(axis=(0, 2, 3)).max())
+    np.testing.assert_allclose(db_both, want_db, rtol=0, atol=tol)
+    np.testing.assert_allclose(db_two, want_db, rtol=0, atol=tol)
