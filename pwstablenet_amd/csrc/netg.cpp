@@ -352,11 +352,15 @@ class Exec {
         return o;
     }
 
+    static void out_extent(int kind, const Tn &x, int *oh, int *ow) {
+        *oh = x.h, *ow = x.w;
+        if (kind == PWS_CONV_K3S2) *oh = (x.h - 1) / 2 + 1, *ow = (x.w - 1) / 2 + 1;
+        if (kind == PWS_CONVT_K4S2) *oh = 2 * x.h, *ow = 2 * x.w;
+    }
     Tn conv(int layer, const Tn &x, int act, const float *nchw_src = nullptr, int nchw_c = 0) {
         const Layer &l = L_[layer];
-        int oh = x.h, ow = x.w;
-        if (l.kind == PWS_CONV_K3S2) oh = (x.h - 1) / 2 + 1, ow = (x.w - 1) / 2 + 1;
-        if (l.kind == PWS_CONVT_K4S2) oh = 2 * x.h, ow = 2 * x.w;
+        int oh, ow;
+        out_extent(l.kind, x, &oh, &ow);
         Tn o{};
         o.nseg = 1, o.h = oh, o.w = ow;
         o.seg[0] = Seg{alloc((size_t)n_ * oh * ow * l.cout), l.cout, l.cout};
@@ -365,16 +369,67 @@ class Exec {
         // ring kernel takes and the first layer (they write them in their epilogues; the one-shot kernel and split-K launches are followed
         // by a pass over the output) -- PWS_OPT_EXPERIMENT 12: never.
         // (The arena holds the bytes in every training layout -- the workspace size does not depend on the storage mode.)
-        if (training_ && !bn_on_ && act != PWS_ACT_NONE && l.cout % 8 == 0 && ow >= 32) {
+        if (wants_sign(act, l.cout, ow)) {
             unsigned char *sg = reinterpret_cast<unsigned char *>(alloc(((size_t)n_ * oh * ow * (l.cout / 8) + 3) / 4));
             if (io16_ && g_experiment != 12) o.seg[0].sign = sg;
         }
+        return run_conv(layer, x, act, o, 1, nchw_src, nchw_c);
+    }
+    bool wants_sign(int act, int cout, int ow) const { return training_ && !bn_on_ && act != PWS_ACT_NONE && cout % 8 == 0 && ow >= 32; }
+
+    // ---- stages 2 and 3 in LOCKSTEP (round 4).  They run the same modules (reference :178-214) on different inputs, and every input of
+    // stage 3 at a level is an output of stage 2 at that level's predecessor -- so with the three stages' tensors of a level laid out as
+    // sample GROUPS of one buffer [stage 1 | stage 2 | stage 3] (each n samples), "what stages 2 and 3 read" are the two batch-2n views
+    // groups (0, 1) and groups (1, 2) of it, and ONE launch of batch 2n computes both stages' outputs into groups (1, 2) of the next
+    // buffer.  23 of the 68 launches of an inference forward go; what is left of the deep levels runs on twice the pixels per launch.
+    // The tape still holds one op per stage (the backward is per stage, as before).
+    struct Groups {   // a [groups][n][h][w][c] buffer
+        float *ptr = nullptr;
+        unsigned char *sign = nullptr;
+        int c = 0, h = 0, w = 0;
+    };
+    size_t esz() const { return io16_ ? 2 : 4; }
+    Groups alloc_groups(int ngroups, int h, int w, int c, int act) {
+        Groups t;
+        t.c = c, t.h = h, t.w = w;
+        t.ptr = alloc((size_t)ngroups * n_ * h * w * c);
+        if (wants_sign(act, c, w)) {
+            unsigned char *sg = reinterpret_cast<unsigned char *>(alloc(((size_t)ngroups * n_ * h * w * (c / 8) + 3) / 4));
+            if (io16_ && g_experiment != 12) t.sign = sg;
+        }
+        return t;
+    }
+    Tn group(const Groups &t, int g0) const {   // group g0 (read as batch 2n: groups g0 and g0 + 1)
+        Tn o{};
+        o.nseg = 1, o.h = t.h, o.w = t.w;
+        float *p = t.ptr ? reinterpret_cast<float *>(reinterpret_cast<char *>(t.ptr) + (size_t)g0 * n_ * t.h * t.w * t.c * esz()) : nullptr;
+        o.seg[0] = Seg{p, t.c, t.c, t.sign ? t.sign + (size_t)g0 * n_ * t.h * t.w * (t.c / 8) : nullptr};
+        return o;
+    }
+    Tn shifted(const Tn &x, int k) const {   // the same (virtually concatenated) tensor k groups further
+        Tn o = x;
+        for (int i = 0; i < o.nseg; ++i) {
+            Seg &sg = o.seg[i];
+            if (sg.ptr) sg.ptr = reinterpret_cast<float *>(reinterpret_cast<char *>(sg.ptr) + (size_t)k * n_ * x.h * x.w * sg.ld * esz());
+            if (sg.sign) sg.sign += (size_t)k * n_ * x.h * x.w * (sg.c / 8);
+        }
+        return o;
+    }
+    // layer on `ngroups` consecutive groups of x (batch ngroups * n) into group g0.. of dst; returns group g0's output
+    Tn conv_groups(int layer, const Tn &x, int act, int ngroups, const Groups &dst, int g0) {
+        return run_conv(layer, x, act, group(dst, g0), ngroups, nullptr, 0);
+    }
+
+    Tn run_conv(int layer, const Tn &x, int act, const Tn &o, int ngroups, const float *nchw_src, int nchw_c) {
+        const Layer &l = L_[layer];
+        const int oh = o.h, ow = o.w;
         Op op{OP_CONV, layer, act, 0, nchw_c > 0, x, o};
         if (bn_on_) op.aux[0] = alloc((size_t)n_ * oh * ow * l.cout), op.aux[1] = alloc(2 * (size_t)l.cout);
         tape_.push_back(op);
+        for (int k = 1; k < ngroups; ++k) tape_.push_back(Op{OP_CONV, layer, act, 0, false, shifted(x, k), shifted(o, k)});
         if (!launch_ || rc_ != PWS_OK) return o;
         pws_conv_args a{};
-        a.kind = l.kind, a.n = n_, a.h = x.h, a.w = x.w;
+        a.kind = l.kind, a.n = ngroups * n_, a.h = x.h, a.w = x.w;
         if (nchw_c > 0 && math_ == PWS_MATH_BF16 && l.wb_off != (size_t)-1 && x_nhwc_ && nchw_c <= 32) {
             // bf16 first layer: the NCHW window is re-laid once as a 32-channel NHWC source (kept for the weight gradient)
             rc_ = nchw_to_nhwc_pad_strided(nchw_src, x_sstride_, x_nhwc_, n_, nchw_c, x.h, x.w, 32, store(), streams_[q_]);
@@ -480,7 +535,7 @@ class Exec {
     // and (training) the hidden activations of the three theta heads
     void reserve_scratch(int ngf, bool training) {
         training_ = training;
-        splitk_bytes_ = (size_t)(n_ > 8 ? n_ : 8) * (2u << 20);
+        splitk_bytes_ = (size_t)(2 * n_ > 8 ? 2 * n_ : 8) * (2u << 20);   // (2 n: stages 2 and 3 run as one launch of twice the batch)
         // fp32 math: four times that -- the Winograd ring kernel's two-class units of the transposed layers on 16 x 16 / 32 x 32 maps
         // split K four ways (33 MB of partial sums at batch 8; conv_wring.hip).  The bf16 kernels keep the smaller bound: deeper splits
         // of their small maps measured slower (configs[2] step +0.17 ms)
@@ -528,6 +583,103 @@ class Exec {
     std::vector<Op> tape_;
 };
 
+// The forward with stages 2 and 3 in lockstep (Exec::Groups): every level's tensors of the three stages are the sample groups of ONE
+// buffer, the layers stages 2 and 3 share run as one launch of batch 2n wherever both stages' inputs are such views.
+//   encoder level k (k = 2 .. 8, maps 128 .. 1):  Ek = [x1k | x2k | x3k]   (x32 == x22: the reference computes it twice, :178,:200)
+//       x2k, x3k = mpconv_{k-1}(cat(x_left, conv_same_{k-1}(x_up))),  x_up = (x1,k-1 | x2,k-1) = groups (0, 1) of E_{k-1},
+//                                                                  x_left = (x2,k-1 | x3,k-1) = groups (1, 2)
+//       conv_same merges from k = 3, mpconv from k = 4 (at k = 3 x_left would be (x22 | x32) = the same tensor twice)
+//   decoder level l (l = 7 .. 1):  d_s(l) = cat(V_l[s], x_sl),  V_l = [u1l | v2l | v3l];  d_s(8) = x_s8
+//       v_sl = mpconv_l(cat(conv_same_l(x_up), x_left)),  x_up = (d1 | d2)(l+1), x_left = (d2 | d3)(l+1): merged for l = 7 .. 2
+//       (level 1 exists for stage 3 only at inference; in training its inputs d_s(2) hold x22 twice: separate launches)
+// Queues: 0 = stage-1 encoder, stage-1 decoder, then the large merged decoder levels and the heads; 1 = the stage-2/3 encoder beside the
+// stage-1 decoder, then the deep merged decoder levels.
+static void forward_lockstep(Exec &E, const Tn &in, const float *x, int n, int input_nc, int g, int is_training, int ac, float *grids, float *resid,
+                             float *th1, float *th2, float *th3) {
+    const int S = 256;
+    const size_t gsz = (size_t)n * S * S * 2;
+    const int enc_c[9] = {0, g, g, 2 * g, 4 * g, 4 * g, 4 * g, 4 * g, 4 * g};        // channels of x_sk, k = 1 .. 8
+    const int dec_c[8] = {0, g, g, 2 * g, 4 * g, 4 * g, 4 * g, 4 * g};               // channels of v_sl, l = 1 .. 7
+    auto side = [&](int k) { return S >> (k - 1); };                                // map edge at level k
+    // ---- buffers
+    Exec::Groups Ek[9], Ck[9], Vl[8], Gl[8];
+    for (int k = 2; k <= 8; ++k) Ek[k] = E.alloc_groups(k == 2 ? 2 : 3, side(k), side(k), enc_c[k], PWS_ACT_LRELU);   // (x32 == x22: E2 has no third group)
+    for (int k = 3; k <= 8; ++k) Ck[k] = E.alloc_groups(2, side(k - 1), side(k - 1), enc_c[k - 1], PWS_ACT_LRELU);   // conv_same_{k-1}: level k-1 in, same size out
+    for (int l = 7; l >= 2; --l) {
+        Vl[l] = E.alloc_groups(3, side(l), side(l), dec_c[l], PWS_ACT_RELU);
+        // conv_same of up_bottom level l: input x_up at level l + 1 (channels of d(l+1): v + skip, or the bottom x_s8), same size out
+        const int cin = l == 7 ? enc_c[8] : dec_c[l + 1] + enc_c[l + 1];
+        Gl[l] = E.alloc_groups(2, side(l + 1), side(l + 1), cin, PWS_ACT_RELU);
+    }
+    auto enc = [&](int k, int s) { return E.group(Ek[k], s - 1); };                 // x_sk
+    auto dec = [&](int l, int s) {                                                   // d_s(l), l = 8 .. 2
+        if (l == 8) return enc(8, s);
+        Tn skip = s == 3 && l == 2 ? enc(2, 2) : enc(l, s);                          // x32 == x22
+        return Exec::cat(E.group(Vl[l], s - 1), skip);
+    };
+    // ---- stage 1 encoder (reference :153-160) on queue 0; x22 and level 3 of stages 2 / 3 beside its deep levels on queue 1
+    E.use(0);
+    Tn x11 = E.conv(L_TRANSFER, in, PWS_ACT_LRELU, x, input_nc);
+    for (int k = 2; k <= 5; ++k) E.conv_groups(L_DOWN1 + (k - 2), k == 2 ? x11 : enc(k - 1, 1), PWS_ACT_LRELU, 1, Ek[k], 0);
+    E.order(0, 1);
+    E.use(1);
+    {   // down_bottom1 (:178 == :200): once, into group 1 of E2
+        Tn c = E.conv(L_DB1_CS, x11, PWS_ACT_LRELU);
+        E.conv_groups(L_DB1_CS + 1, c, PWS_ACT_LRELU, 1, Ek[2], 1);
+    }
+    {   // level 3: conv_same_2 on (x12 | x22) in one launch; the two mpconvs apart (both read x22 as x_left)
+        E.conv_groups(L_DB1_CS + 2, enc(2, 1), PWS_ACT_LRELU, 2, Ck[3], 0);
+        E.conv_groups(L_DB1_CS + 3, Exec::cat(enc(2, 2), E.group(Ck[3], 0)), PWS_ACT_LRELU, 1, Ek[3], 1);
+        E.conv_groups(L_DB1_CS + 3, Exec::cat(enc(2, 2), E.group(Ck[3], 1)), PWS_ACT_LRELU, 1, Ek[3], 2);
+    }
+    E.use(0);
+    for (int k = 6; k <= 8; ++k) E.conv_groups(L_DOWN1 + (k - 2), enc(k - 1, 1), PWS_ACT_LRELU, 1, Ek[k], 0);
+    E.order(0, 1);
+    if (is_training) E.theta(enc(8, 1), 0, th1);
+    // ---- stages 2 / 3 encoder, levels 4 .. 8 (reference :179-184, :201-206), merged, on queue 1
+    E.use(1);
+    for (int k = 4; k <= 8; ++k) {
+        const int db = k - 1;   // down_bottom index
+        E.conv_groups(L_DB1_CS + 2 * (db - 1), enc(k - 1, 1), PWS_ACT_LRELU, 2, Ck[k], 0);
+        E.conv_groups(L_DB1_CS + 2 * (db - 1) + 1, Exec::cat(enc(k - 1, 2), E.group(Ck[k], 0)), PWS_ACT_LRELU, 2, Ek[k], 1);
+    }
+    if (is_training) E.theta(enc(8, 2), 1, th2);
+    E.theta(enc(8, 3), 2, th3);
+    hipEvent_t th_done = E.mark(1);
+    // ---- stage 1 decoder (reference :166-174) on queue 0
+    E.use(0);
+    for (int l = 7; l >= 2; --l) {
+        E.conv_groups(L_UP7 + (7 - l), dec(l + 1, 1), PWS_ACT_RELU, 1, Vl[l], 0);
+        if (l == 6) E.order(0, 1);   // u17, u16: what the deep merged levels (7 .. 5, queue 1) read of stage 1
+    }
+    if (is_training) {
+        Tn x111 = E.up(1, dec(2, 1), nullptr);
+        E.field(x111, 0, th1, ac, resid, grids);
+    }
+    // ---- stages 2 / 3 decoder (reference :190-198, :212-219): levels 7 .. 5 on queue 1 (behind the encoder, beside the large levels of the
+    // stage-1 decoder), levels 4 .. 2 on queue 0
+    auto merged_level = [&](int l) {
+        E.conv_groups(L_UB7_MP + 2 * (7 - l) + 1, dec(l + 1, 1), PWS_ACT_RELU, 2, Gl[l], 0);
+        E.conv_groups(L_UB7_MP + 2 * (7 - l), Exec::cat(E.group(Gl[l], 0), dec(l + 1, 2)), PWS_ACT_RELU, 2, Vl[l], 1);
+    };
+    E.use(1);
+    for (int l = 7; l >= 5; --l) merged_level(l);
+    E.order(1, 0);
+    E.use(0);
+    for (int l = 4; l >= 2; --l) merged_level(l);
+    // ---- level 1 and the field heads
+    E.wait(0, th_done);
+    if (is_training) {
+        Tn x211 = E.up_bottom(1, dec(2, 1), dec(2, 2), nullptr);
+        E.field(x211, 1, th2, ac, resid ? resid + gsz : nullptr, grids ? grids + gsz : nullptr);
+    }
+    Tn x311 = E.up_bottom(1, dec(2, 2), dec(2, 3), nullptr);
+    if (is_training)
+        E.field(x311, 2, th3, ac, resid ? resid + 2 * gsz : nullptr, grids ? grids + 2 * gsz : nullptr);
+    else
+        E.field(x311, 2, th3, ac, nullptr, grids);
+}
+
 // Runs (or only plans) the forward over the arena of E.  thetas may be NULL (then they live in the arena).
 static void forward_graph(Exec &E, const float *x, int n, int input_nc, int g, int is_training, int ac, float *grids,
                           float *resid, float *thetas) {
@@ -539,6 +691,10 @@ static void forward_graph(Exec &E, const float *x, int n, int input_nc, int g, i
 
     Tn in{};
     in.nseg = 1, in.h = S, in.w = S, in.seg[0] = Seg{nullptr, input_nc, 0};
+    if (!E.bn_on() && g_experiment != 15) {   // (15: the per-stage schedule below, A/B; the BatchNorm path keeps it: statistics are per call)
+        forward_lockstep(E, in, x, n, input_nc, g, is_training, ac, grids, resid, th1, th2, th3);
+        return;
+    }
     // Queue 0 (the caller's stream): stage-1 encoder, then the three decoders.  Queue 1: the stage-2 and stage-3 encoders,
     // which only need the previous stage's ENCODER outputs -- so stage 1's latency-bound deep layers and its decoder
     // overlap with stage 2's big conv_same layers, and stage 2's decoder overlaps with stage 3's encoder.
