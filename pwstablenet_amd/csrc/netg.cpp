@@ -617,32 +617,67 @@ static void forward_lockstep(Exec &E, const Tn &in, const float *x, int n, int i
         Tn skip = s == 3 && l == 2 ? enc(2, 2) : enc(l, s);                          // x32 == x22
         return Exec::cat(E.group(Vl[l], s - 1), skip);
     };
-    // ---- stage 1 encoder (reference :153-160) on queue 0; x22 and level 3 of stages 2 / 3 beside its deep levels on queue 1
-    E.use(0);
-    Tn x11 = E.conv(L_TRANSFER, in, PWS_ACT_LRELU, x, input_nc);
-    for (int k = 2; k <= 5; ++k) E.conv_groups(L_DOWN1 + (k - 2), k == 2 ? x11 : enc(k - 1, 1), PWS_ACT_LRELU, 1, Ek[k], 0);
-    E.order(0, 1);
-    E.use(1);
-    {   // down_bottom1 (:178 == :200): once, into group 1 of E2
+    // ---- encoders.  sched (PWS_OPT_EXPERIMENT 150 + v, measured in tools/lockstep_sched.sh): how queue 1 follows queue 0
+    const int sched = g_experiment >= 150 && g_experiment < 160 ? g_experiment - 150 : 0;
+    auto db1 = [&](const Tn &x11) {   // down_bottom1 (:178 == :200): once, into group 1 of E2
         Tn c = E.conv(L_DB1_CS, x11, PWS_ACT_LRELU);
         E.conv_groups(L_DB1_CS + 1, c, PWS_ACT_LRELU, 1, Ek[2], 1);
-    }
-    {   // level 3: conv_same_2 on (x12 | x22) in one launch; the two mpconvs apart (both read x22 as x_left)
+    };
+    auto level3 = [&]() {   // conv_same_2 on (x12 | x22) in one launch; the two mpconvs apart (both read x22 as x_left)
         E.conv_groups(L_DB1_CS + 2, enc(2, 1), PWS_ACT_LRELU, 2, Ck[3], 0);
         E.conv_groups(L_DB1_CS + 3, Exec::cat(enc(2, 2), E.group(Ck[3], 0)), PWS_ACT_LRELU, 1, Ek[3], 1);
         E.conv_groups(L_DB1_CS + 3, Exec::cat(enc(2, 2), E.group(Ck[3], 1)), PWS_ACT_LRELU, 1, Ek[3], 2);
-    }
+    };
+    auto enc1 = [&](int k, const Tn &x11) { E.conv_groups(L_DOWN1 + (k - 2), k == 2 ? x11 : enc(k - 1, 1), PWS_ACT_LRELU, 1, Ek[k], 0); };
     E.use(0);
-    for (int k = 6; k <= 8; ++k) E.conv_groups(L_DOWN1 + (k - 2), enc(k - 1, 1), PWS_ACT_LRELU, 1, Ek[k], 0);
-    E.order(0, 1);
-    if (is_training) E.theta(enc(8, 1), 0, th1);
-    // ---- stages 2 / 3 encoder, levels 4 .. 8 (reference :179-184, :201-206), merged, on queue 1
-    E.use(1);
-    for (int k = 4; k <= 8; ++k) {
+    Tn x11 = E.conv(L_TRANSFER, in, PWS_ACT_LRELU, x, input_nc);
+    hipEvent_t lvl[9] = {};
+    if (sched == 4) {   // an event behind every level of stage 1: queue 1 follows level by level
+        lvl[1] = E.mark(0);
+        for (int k = 2; k <= 8; ++k) enc1(k, x11), lvl[k] = E.mark(0);
+        E.use(1);
+        E.wait(1, lvl[1]);
+        db1(x11);
+        E.wait(1, lvl[2]);
+        level3();
+    } else if (sched == 2) {   // the large early layers of stages 2 / 3 on queue 0 itself, queue 1 gets the merged levels only
+        enc1(2, x11);
+        db1(x11);
+        level3();
+        for (int k = 3; k <= 5; ++k) enc1(k, x11);
+        E.order(0, 1);
+        for (int k = 6; k <= 8; ++k) enc1(k, x11);
+        E.order(0, 1);
+        E.use(1);
+    } else if (sched == 1) {   // queue 1 starts behind the whole stage-1 encoder
+        for (int k = 2; k <= 8; ++k) enc1(k, x11);
+        E.order(0, 1);
+        E.use(1);
+        db1(x11);
+        level3();
+    } else {   // 0 / 3: queue 1 starts behind x15 (its large layers beside the deep levels of stage 1), the merged levels behind x18
+        for (int k = 2; k <= 5; ++k) enc1(k, x11);
+        E.order(0, 1);
+        E.use(1);
+        db1(x11);
+        level3();
+        E.use(0);
+        for (int k = 6; k <= 8; ++k) enc1(k, x11);
+        E.order(0, 1);
+        E.use(1);
+    }
+    if (is_training) {
+        E.use(0);
+        E.theta(enc(8, 1), 0, th1);
+        E.use(1);
+    }
+    for (int k = 4; k <= 8; ++k) {   // levels 4 .. 8, merged, on queue 1
         const int db = k - 1;   // down_bottom index
+        if (sched == 4) E.wait(1, lvl[k - 1]);
         E.conv_groups(L_DB1_CS + 2 * (db - 1), enc(k - 1, 1), PWS_ACT_LRELU, 2, Ck[k], 0);
         E.conv_groups(L_DB1_CS + 2 * (db - 1) + 1, Exec::cat(enc(k - 1, 2), E.group(Ck[k], 0)), PWS_ACT_LRELU, 2, Ek[k], 1);
     }
+    if (sched == 4) E.wait(1, lvl[8]);   // (the bottom of stage 1: x_up of the deepest decoder level)
     if (is_training) E.theta(enc(8, 2), 1, th2);
     E.theta(enc(8, 3), 2, th3);
     hipEvent_t th_done = E.mark(1);
@@ -662,10 +697,16 @@ static void forward_lockstep(Exec &E, const Tn &in, const float *x, int n, int i
         E.conv_groups(L_UB7_MP + 2 * (7 - l) + 1, dec(l + 1, 1), PWS_ACT_RELU, 2, Gl[l], 0);
         E.conv_groups(L_UB7_MP + 2 * (7 - l), Exec::cat(E.group(Gl[l], 0), dec(l + 1, 2)), PWS_ACT_RELU, 2, Vl[l], 1);
     };
-    E.use(1);
-    for (int l = 7; l >= 5; --l) merged_level(l);
-    E.order(1, 0);
-    E.use(0);
+    if (sched == 3) {   // everything of the decoders on queue 0
+        E.order(1, 0);
+        E.use(0);
+        for (int l = 7; l >= 5; --l) merged_level(l);
+    } else {
+        E.use(1);
+        for (int l = 7; l >= 5; --l) merged_level(l);
+        E.order(1, 0);
+        E.use(0);
+    }
     for (int l = 4; l >= 2; --l) merged_level(l);
     // ---- level 1 and the field heads
     E.wait(0, th_done);
