@@ -50,6 +50,28 @@ __device__ __forceinline__ void block_accumulate(const float (&v)[NV], double *c
     }
 }
 
+// the same for per-lane DOUBLES (kernels whose workgroups walk several blocks: fp32 per block, f64 across blocks)
+template <int NV>
+__device__ __forceinline__ void block_accumulate_d(const double (&v)[NV], double *const (&dst)[NV]) {
+    __shared__ double red[NV][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double d = v[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off, 64);
+        if (lane == 0) red[k][wave] = d;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        const int nw = (blockDim.x + 63) >> 6;
+        double s = 0.0;
+        for (int w = 0; w < nw; ++w) s += red[threadIdx.x][w];
+        unsafeAtomicAdd(dst[threadIdx.x] + (blockIdx.x % kSlots), s);
+    }
+}
+constexpr unsigned kLossGrid = 2048;   // workgroups of a capped loss launch (8 per CU): 2048 f64 atomics per quantity instead of one per 256 lanes
+
 // ------------------------------------------------------------------------------------------------ pre-processing
 __global__ void __launch_bounds__(256) u8_normalize_kernel(const unsigned char *__restrict__ src, size_t src_nstride,
                                                            float *__restrict__ dst, size_t dst_nstride, size_t per4) {
@@ -92,11 +114,15 @@ __global__ void __launch_bounds__(256) warp_norm_fwd_kernel(const float *__restr
                                                             const float *__restrict__ target, size_t tgt_nstride,
                                                             double *__restrict__ l1_slots, int H, int W, size_t total_groups,
                                                             unsigned nblocks) {
-    const unsigned blk = xcd_remap(blockIdx.x, nblocks);
-    const size_t gidx = (size_t)blk * 256 + threadIdx.x;
     const int HW = H * W;
-    float acc[1] = {0.f};
-    if (gidx < total_groups) {
+    double sum[1] = {0.0};
+    // (a workgroup walks several blocks of 256 lanes when the grid is capped -- kLossGrid -- so that the f64 atomics on the 64 slots stay few:
+    //  at 256 samples one atomic per 256-lane block was 65 536 atomics on four cache lines and cost more than the kernel's own traffic)
+    for (unsigned b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const unsigned blk = xcd_remap(b, nblocks);
+        const size_t gidx = (size_t)blk * 256 + threadIdx.x;
+        if (gidx >= total_groups) continue;
+        float acc[1] = {0.f};
         const size_t p0 = gidx * 4;
         const int n = (int)(p0 / HW), hw = (int)(p0 % HW);
         const float4 ga = *reinterpret_cast<const float4 *>(grid + p0 * 2);
@@ -121,10 +147,11 @@ __global__ void __launch_bounds__(256) warp_norm_fwd_kernel(const float *__restr
                 acc[0] += fabsf(tg.x - r[0]) + fabsf(tg.y - r[1]) + fabsf(tg.z - r[2]) + fabsf(tg.w - r[3]);
             }
         }
+        sum[0] += (double)acc[0];
     }
     if (l1_slots) {
         double *const dst[1] = {l1_slots};
-        block_accumulate<1>(acc, dst);
+        block_accumulate_d<1>(sum, dst);
     }
 }
 
@@ -203,14 +230,16 @@ __global__ void __launch_bounds__(256) temporal_l1_kernel(const float *__restric
                                                           const float *__restrict__ theta, double *__restrict__ slots, float c,
                                                           const float *__restrict__ scale, float *__restrict__ gfake1, float *__restrict__ gfake2, int H, int W,
                                                           size_t total, unsigned nblocks, float *__restrict__ sbuf = nullptr) {
-    const unsigned blk = xcd_remap(blockIdx.x, nblocks);
-    const size_t p = (size_t)blk * 256 + threadIdx.x;
     const int HW = H * W;
-    float acc[1] = {0.f};
+    double sum[1] = {0.0};
     if constexpr (BWD) {
         if (scale) c *= *scale;
     }
-    if (p < total) {
+    for (unsigned b = blockIdx.x; b < nblocks; b += gridDim.x) {   // (forward: capped grid, see warp_norm_fwd_kernel)
+        const unsigned blk = xcd_remap(b, nblocks);
+        const size_t p = (size_t)blk * 256 + threadIdx.x;
+        if (p >= total) continue;
+        float acc[1] = {0.f};
         const int n = (int)(p / HW), hw = (int)(p % HW);
         const int y_ = hw / W, x_ = hw % W;
         const float *th = theta + (size_t)n * 6;
@@ -238,10 +267,11 @@ __global__ void __launch_bounds__(256) temporal_l1_kernel(const float *__restric
                 acc[0] += fabsf(d);
             }
         }
+        sum[0] += (double)acc[0];
     }
     if constexpr (!BWD) {
         double *const dst[1] = {slots};
-        block_accumulate<1>(acc, dst);
+        block_accumulate_d<1>(sum, dst);
     }
 }
 
@@ -477,24 +507,25 @@ __global__ void __launch_bounds__(64) feature_loss_bwd_serial_kernel(const float
 __global__ void __launch_bounds__(256) field_smoothness_kernel(const float *__restrict__ grid, double *__restrict__ slots_dx,
                                                                double *__restrict__ slots_dy, int H, int W, size_t total,
                                                                unsigned nblocks) {
-    const unsigned blk = xcd_remap(blockIdx.x, nblocks);
-    const size_t p = (size_t)blk * 256 + threadIdx.x;
-    float acc[2] = {0.f, 0.f};
-    if (p < total) {
+    double sum[2] = {0.0, 0.0};
+    for (unsigned b = blockIdx.x; b < nblocks; b += gridDim.x) {   // (capped grid, see warp_norm_fwd_kernel)
+        const unsigned blk = xcd_remap(b, nblocks);
+        const size_t p = (size_t)blk * 256 + threadIdx.x;
+        if (p >= total) continue;
         const int hw = (int)(p % ((size_t)H * W));
         const int y_ = hw / W, x_ = hw % W;
         const float2 g = *reinterpret_cast<const float2 *>(grid + p * 2);
         if (x_ + 1 < W) {
             const float2 r = *reinterpret_cast<const float2 *>(grid + (p + 1) * 2);
-            acc[0] = fabsf(g.x - r.x) + fabsf(g.y - r.y);
+            sum[0] += (double)(fabsf(g.x - r.x) + fabsf(g.y - r.y));
         }
         if (y_ + 1 < H) {
             const float2 d = *reinterpret_cast<const float2 *>(grid + (p + W) * 2);
-            acc[1] = fabsf(g.x - d.x) + fabsf(g.y - d.y);
+            sum[1] += (double)(fabsf(g.x - d.x) + fabsf(g.y - d.y));
         }
     }
     double *const dst[2] = {slots_dx, slots_dy};
-    block_accumulate<2>(acc, dst);
+    block_accumulate_d<2>(sum, dst);
 }
 
 // ------------------------------------------------------------------------------------------------ shape loss (fp64)
@@ -585,8 +616,8 @@ __global__ void __launch_bounds__(256) shape_loss16_kernel(const float *__restri
                                                            const float *__restrict__ scale, float *__restrict__ gresid, int size, int nblk, unsigned nblocks,
                                                            double gi00, double gi01, double gi11) {
     const int lane = threadIdx.x & 63;
-    const unsigned b = blockIdx.x * 4u + (threadIdx.x >> 6);   // (sample, block row, block col)
-    if (b >= nblocks) return;   // whole waves leave together
+    double l1_total = 0.0;   // forward: this lane's share over every block its wave walks (capped grid: few f64 atomics on the 64 slots)
+    for (unsigned b = blockIdx.x * 4u + (threadIdx.x >> 6); b < nblocks; b += gridDim.x * 4u) {   // (sample, block row, block col); whole waves
     const int n = (int)(b / (unsigned)(nblk * nblk)), by = (int)((b / (unsigned)nblk) % (unsigned)nblk), bx = (int)(b % (unsigned)nblk);
     const int py = lane >> 2, px0 = (lane & 3) * 4;
     const double L = 15.0;
@@ -635,12 +666,8 @@ __global__ void __launch_bounds__(256) shape_loss16_kernel(const float *__restri
     double proj[4][2];
     project(bxy, proj);
     if constexpr (!BWD) {
-        double l1 = 0.0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) l1 += fabs(proj[i][0] - bxy[i][0]) + fabs(proj[i][1] - bxy[i][1]);   // AB - B, as torch.dist(AB, B, 1)
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) l1 += __shfl_xor(l1, off, 64);
-        if (lane == 0) unsafeAtomicAdd(slots + (b % kSlots), l1);
+        for (int i = 0; i < 4; ++i) l1_total += fabs(proj[i][0] - bxy[i][0]) + fabs(proj[i][1] - bxy[i][1]);   // AB - B, as torch.dist(AB, B, 1)
     } else {
         // d sum|PB - B| / dB = (P - I)^T s = P s - s   (P symmetric), s = sign(PB - B)
         double sg[4][2], ps[4][2];
@@ -658,6 +685,12 @@ __global__ void __launch_bounds__(256) shape_loss16_kernel(const float *__restri
         for (int i = 0; i < 4; ++i) o[2 * i] = (float)(c * (ps[i][0] - sg[i][0])), o[2 * i + 1] = (float)(c * (ps[i][1] - sg[i][1]));
         *reinterpret_cast<float4 *>(gresid + q) = make_float4(o[0], o[1], o[2], o[3]);
         *reinterpret_cast<float4 *>(gresid + q + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+    }   // blocks of this wave
+    if constexpr (!BWD) {
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) l1_total += __shfl_xor(l1_total, off, 64);
+        if (lane == 0) unsafeAtomicAdd(slots + ((blockIdx.x * 4u + (threadIdx.x >> 6)) % kSlots), l1_total);
     }
 }
 
@@ -711,7 +744,7 @@ extern "C" int pws_warp_norm_fwd(const float *src, size_t src_nstride, const flo
     const size_t groups = (size_t)m * h * w / 4;
     const unsigned nb = (unsigned)((groups + 255) / 256);
     ProfScope prof(KID_OBJECTIVE, 120.0 * m * h * w, (double)m * h * w * (8.0 + 12.0 + 12.0 + (target ? 12.0 : 0.0)), as_stream(stream));
-    hipLaunchKernelGGL(warp_norm_fwd_kernel, dim3(nb), dim3(256), 0, as_stream(stream), src, src_nstride, grid, fake, target,
+    hipLaunchKernelGGL(warp_norm_fwd_kernel, dim3(target && l1_slots && nb > kLossGrid ? kLossGrid : nb), dim3(256), 0, as_stream(stream), src, src_nstride, grid, fake, target,
                        tgt_nstride, l1_slots, h, w, groups, nb);
     return check_launch("warp_norm_fwd_kernel");
 }
@@ -740,7 +773,7 @@ extern "C" int pws_temporal_l1_fwd(const float *fake1, const float *fake2, const
     const size_t total = (size_t)n * h * w;
     const unsigned nb = (unsigned)((total + 255) / 256);
     ProfScope prof(KID_OBJECTIVE, 90.0 * total, 24.0 * total, as_stream(stream));
-    hipLaunchKernelGGL(temporal_l1_kernel<false>, dim3(nb), dim3(256), 0, as_stream(stream), fake1, fake2, theta, slots, 0.f,
+    hipLaunchKernelGGL(temporal_l1_kernel<false>, dim3(nb > kLossGrid ? kLossGrid : nb), dim3(256), 0, as_stream(stream), fake1, fake2, theta, slots, 0.f,
                        (const float *)nullptr, (float *)nullptr, (float *)nullptr, h, w, total, nb);
     return check_launch("temporal_l1_kernel<fwd>");
 }
@@ -821,7 +854,7 @@ extern "C" int pws_field_smoothness(const float *grid, double *slots_dx, double 
     const size_t total = (size_t)m * h * w;
     const unsigned nb = (unsigned)((total + 255) / 256);
     ProfScope prof(KID_OBJECTIVE, 10.0 * total, 8.0 * total, as_stream(stream));
-    hipLaunchKernelGGL(field_smoothness_kernel, dim3(nb), dim3(256), 0, as_stream(stream), grid, slots_dx, slots_dy, h, w, total, nb);
+    hipLaunchKernelGGL(field_smoothness_kernel, dim3(nb > kLossGrid ? kLossGrid : nb), dim3(256), 0, as_stream(stream), grid, slots_dx, slots_dy, h, w, total, nb);
     return check_launch("field_smoothness_kernel");
 }
 
@@ -854,7 +887,7 @@ extern "C" int pws_shape_loss_fwd(const float *resid, double *slots, int m, int 
     ProfScope prof(KID_OBJECTIVE, 120.0 * m * size * size, 8.0 * m * size * size, as_stream(stream));
     if (bs == 16 && al16(resid) && g_experiment != 97) {   // one wave per block (97: the general kernel, A/B and tests)
         const unsigned nb = (unsigned)(m * block * block);
-        hipLaunchKernelGGL(shape_loss16_kernel<false>, dim3((nb + 3) / 4), dim3(256), 0, as_stream(stream), resid, slots, 0.0, (const float *)nullptr,
+        hipLaunchKernelGGL(shape_loss16_kernel<false>, dim3((nb + 3) / 4 > kLossGrid ? kLossGrid : (nb + 3) / 4), dim3(256), 0, as_stream(stream), resid, slots, 0.0, (const float *)nullptr,
                            (float *)nullptr, size, block, nb, gi[0], gi[1], gi[2]);
         return check_launch("shape_loss16_kernel<fwd>");
     }
