@@ -122,3 +122,49 @@ def test_use_bn_eval_inference_vs_reference_golden(hip):
     assert np.abs(field2 - field).max() > 1e-4
     with pytest.raises(ValueError):      # train() mode runs BatchNorm with batch statistics (tests/test_hip_bn.py); batch 1 is refused as by torch
         net.train()(x)
+
+
+@pytest.mark.parametrize("math", ["fp32", "bf16"])
+def test_lockstep_schedule_equals_the_per_stage_schedule(hip, math):
+    """Round 4: stages 2 and 3 run in lockstep -- the 23 layers they share go out as ONE launch of batch 2n on sample-group views of
+    shared buffers (csrc/netg.cpp forward_lockstep; reference lib/networks_cascading.py:178-219 runs them one after the other).
+    PWS_OPT_EXPERIMENT 15 keeps the per-stage schedule: same layers on the same inputs, so the six training fields and the inference
+    field agree to rounding (a launch of twice the batch may split K differently: fp32 summation order), and so does one backward
+    (the tape holds one op per stage in either schedule)."""
+    L = hip.lib()
+    x = torch.from_numpy(synth.make_window(3, 31, 256, seed=77)).cuda()   # odd batch: group offsets that are no multiple of anything
+    up = [torch.from_numpy(np.random.RandomState(5 + k).standard_normal((3, 256, 256, 2)).astype(np.float32)).cuda() for k in range(3)]
+    out = {}
+    try:
+        for e in (15, 0):
+            L.pws_set_option(100, e)
+            net = make_net("W2", 32)          # a fresh generator per schedule: arenas are sized by the schedule in force
+            net.module.set_math(math)
+            net.module.deterministic = True   # (no atomics noise in the gradients: what is left is the K-split / summation order)
+            with torch.no_grad():
+                inf = net(x, False).clone()
+            grids, resid = net(x)
+            assert torch.equal(inf, grids[2].detach())
+            loss = sum((g * u).sum() for g, u in zip(grids, up)) + (resid[2] ** 2).sum()
+            loss.backward()
+            out[e] = ([g.detach().clone() for g in grids] + [r.detach().clone() for r in resid], [p.grad.clone() for p in net.parameters()])
+    finally:
+        L.pws_set_option(100, 0)
+    ftol = 2e-5 if math == "fp32" else 3e-2
+    for a, b in zip(out[15][0], out[0][0]):
+        assert float((a - b).abs().max()) < ftol, float((a - b).abs().max())
+    if math == "bf16":
+        # bf16 storage: a 1e-2 difference in the forward flips LeakyReLU masks of the theta heads' six values per sample (slope 1 <-> 0.2), so
+        # single tensors of the heads move by tens of per cent between equally valid evaluations; judged over ALL 48.5 M... (12 M here) entries
+        fa = torch.cat([t.double().reshape(-1) for t in out[15][1]])
+        fb = torch.cat([t.double().reshape(-1) for t in out[0][1]])
+        assert float((fa @ fb) / (fa.norm() * fb.norm())) > 0.999
+        return
+    for i, (a, b) in enumerate(zip(out[15][1], out[0][1])):
+        scale = float(a.abs().max()) + 1e-20
+        # (measured 2.0e-4 .. 5.2e-4 of a tensor's maximum on deep layers: the loss weights the fields with white noise and W2 saturates
+        #  the tanh heads, so these gradients are strongly cancelling sums, and a 1e-6 difference in the forward moves LeakyReLU / ReLU
+        #  masks of activations near zero; tests/test_hip_ddp.py sees 1.5e-4 between one launch of 32 items and two of 16)
+        assert float((a - b).abs().max()) / scale < 2e-3, (i, float((a - b).abs().max()) / scale)
+        cos = float((a.double().reshape(-1) @ b.double().reshape(-1)) / (a.double().norm() * b.double().norm() + 1e-300))
+        assert cos > 0.999999, (i, cos)
