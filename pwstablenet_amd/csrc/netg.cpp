@@ -678,9 +678,8 @@ static void forward_lockstep(Exec &E, const Tn &in, const float *x, int n, int i
         E.conv_groups(L_DB1_CS + 2 * (db - 1) + 1, Exec::cat(enc(k - 1, 2), E.group(Ck[k], 0)), PWS_ACT_LRELU, 2, Ek[k], 1);
     }
     if (sched == 4) E.wait(1, lvl[8]);   // (the bottom of stage 1: x_up of the deepest decoder level)
-    if (is_training) E.theta(enc(8, 2), 1, th2);
-    E.theta(enc(8, 3), 2, th3);
-    hipEvent_t th_done = E.mark(1);
+    // (the theta heads of stages 2 / 3 -- 30 us of GEMV launches the field heads need at the very end -- are issued on queue 1 BEHIND the deep
+    //  decoder levels, where that queue has nothing else to do: in front of them they sat on the critical path)
     // ---- stage 1 decoder (reference :166-174) on queue 0
     E.use(0);
     for (int l = 7; l >= 2; --l) {
@@ -705,8 +704,12 @@ static void forward_lockstep(Exec &E, const Tn &in, const float *x, int n, int i
         E.use(1);
         for (int l = 7; l >= 5; --l) merged_level(l);
         E.order(1, 0);
-        E.use(0);
     }
+    E.use(1);
+    if (is_training) E.theta(enc(8, 2), 1, th2);
+    E.theta(enc(8, 3), 2, th3);
+    hipEvent_t th_done = E.mark(1);
+    E.use(0);
     for (int l = 4; l >= 2; --l) merged_level(l);
     // ---- level 1 and the field heads
     E.wait(0, th_done);
