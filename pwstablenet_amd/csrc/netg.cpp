@@ -655,14 +655,15 @@ static void forward_lockstep(Exec &E, const Tn &in, const float *x, int n, int i
         E.use(1);
         db1(x11);
         level3();
-    } else {   // 0 / 3: queue 1 starts behind x15 (its large layers beside the deep levels of stage 1), the merged levels behind x18
-        for (int k = 2; k <= 5; ++k) enc1(k, x11);
+    } else {   // 0 / 3: queue 1 starts behind x14 (its large layers beside the deeper levels of stage 1), the merged levels behind x18
+        const int first = sched == 5 ? 3 : (sched == 6 ? 5 : 4);   // (5 / 6: behind x13 / x15 instead -- fp32 1815 / 1826 against 1840 f/s, bf16 6238 / 6150 against 6252)
+        for (int k = 2; k <= first; ++k) enc1(k, x11);
         E.order(0, 1);
         E.use(1);
         db1(x11);
         level3();
         E.use(0);
-        for (int k = 6; k <= 8; ++k) enc1(k, x11);
+        for (int k = first + 1; k <= 8; ++k) enc1(k, x11);
         E.order(0, 1);
         E.use(1);
     }
