@@ -229,7 +229,7 @@ template <bool BWD>
 __global__ void __launch_bounds__(256) temporal_l1_kernel(const float *__restrict__ fake1, const float *__restrict__ fake2,
                                                           const float *__restrict__ theta, double *__restrict__ slots, float c,
                                                           const float *__restrict__ scale, float *__restrict__ gfake1, float *__restrict__ gfake2, int H, int W,
-                                                          size_t total, unsigned nblocks, float *__restrict__ sbuf = nullptr) {
+                                                          size_t total, unsigned nblocks, float *__restrict__ sbuf = nullptr, int g_pair = 0) {
     const int HW = H * W;
     double sum[1] = {0.0};
     if constexpr (BWD) {
@@ -256,6 +256,28 @@ __global__ void __launch_bounds__(256) temporal_l1_kernel(const float *__restric
                 gfake1[pl + hw] -= s;
                 if (sbuf) {   // deterministic mode: the scatter is done as an ordered gather by temporal_gather_kernel
                     sbuf[pl + hw] = s;
+                } else if (g_pair) {
+                    // (round 4) the kernel runs at the L2's atomic rate (12 per pixel: ~230 G/s), and for an affine map close to the identity
+                    // the RIGHT taps of a pixel are the LEFT taps of its right-hand neighbour = the next lane: a lane whose neighbour has
+                    // the same addresses hands its two right-tap values over (wave shuffle) and the neighbour adds them to its own -- 4
+                    // atomics per pixel and plane become ~2.  Every lane of the wave takes part in the shuffles (no divergence here).
+                    const float v00 = s * t.w00, v01 = s * t.w01, v10 = s * t.w10, v11 = s * t.w11;
+                    const int lane = threadIdx.x & 63;
+                    // (g_pair is only set when total % 256 == 0: every lane of every wave is here)
+                    constexpr bool live = true;
+                    const bool nxt_same = lane < 63 && __shfl_down(t.o00, 1, 64) == t.o01 && __shfl_down(t.o10, 1, 64) == t.o11;   // my right taps == the next lane's left taps
+                    const bool prv_same = __shfl_up(nxt_same ? 1 : 0, 1, 64) == 1 && lane > 0;
+                    const float a01 = __shfl_up(v01, 1, 64), a11 = __shfl_up(v11, 1, 64);
+                    if (live) {
+                        float *gp = gfake2 + pl;
+                        const float u00 = v00 + (prv_same ? a01 : 0.f), u10 = v10 + (prv_same ? a11 : 0.f);
+                        if (u00 != 0.f) atomicAdd(gp + t.o00, u00);
+                        if (u10 != 0.f) atomicAdd(gp + t.o10, u10);
+                        if (!nxt_same) {
+                            if (v01 != 0.f) atomicAdd(gp + t.o01, v01);
+                            if (v11 != 0.f) atomicAdd(gp + t.o11, v11);
+                        }
+                    }
                 } else if (s != 0.f) {
                     float *gp = gfake2 + pl;
                     if (t.w00 != 0.f) atomicAdd(gp + t.o00, s * t.w00);
@@ -387,6 +409,83 @@ __global__ void __launch_bounds__(256) temporal_l1_bwd_tiled_kernel(const float 
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (xq + i < W) gfake1[o + i] = g1[ch][i];
+            }
+        }
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < bw * bh; i += 256) {
+            const size_t q = (size_t)(y_lo + i / bw) * W + (x_lo + i % bw);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float v = box[ch][i];
+                if (v != 0.f) atomicAdd(gfake2 + ((size_t)n * 3 + ch) * HW + q, v);
+            }
+        }
+    }
+}
+
+// The lean form of the tiled variant: 16 x 16 pixels per workgroup, ONE pixel per lane (few registers, a 7 KB box: many workgroups per
+// CU).  PWS_OPT_EXPERIMENT 99 (A/B, tools/temporal_ab.py).
+constexpr int kT16Box = 24 * 24;
+__global__ void __launch_bounds__(256) temporal_l1_bwd_tile16_kernel(const float *__restrict__ fake1, const float *__restrict__ fake2,
+                                                                     const float *__restrict__ theta, float c, const float *__restrict__ scale,
+                                                                     float *__restrict__ gfake1, float *__restrict__ gfake2, int H, int W, int tiles_x,
+                                                                     int tiles_y) {
+    __shared__ float box[3][kT16Box];
+    const int tile = blockIdx.x % (tiles_x * tiles_y), n = blockIdx.x / (tiles_x * tiles_y);
+    const int px0 = (tile % tiles_x) * 16, py0 = (tile / tiles_x) * 16;
+    const int HW = H * W;
+    if (scale) c *= *scale;
+    const float *th = theta + (size_t)n * 6;
+    float ixmin = 3.0e38f, ixmax = -3.0e38f, iymin = 3.0e38f, iymax = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int cx = min(px0 + ((k & 1) ? 15 : 0), W - 1), cy = min(py0 + ((k & 2) ? 15 : 0), H - 1);
+        const float bx = base_o(cx, W), by = base_o(cy, H);
+        const float ix = unnorm_o(th[0] * bx + th[1] * by + th[2], W), iy = unnorm_o(th[3] * bx + th[4] * by + th[5], H);
+        ixmin = fminf(ixmin, ix), ixmax = fmaxf(ixmax, ix), iymin = fminf(iymin, iy), iymax = fmaxf(iymax, iy);
+    }
+    const bool finite = ixmin > -1.0e9f && ixmax < 1.0e9f && iymin > -1.0e9f && iymax < 1.0e9f;
+    const int x_lo = finite ? min(max((int)floorf(ixmin) - 1, 0), W - 1) : 0, x_hi = finite ? min(max((int)floorf(ixmax) + 2, 0), W - 1) : W - 1;
+    const int y_lo = finite ? min(max((int)floorf(iymin) - 1, 0), H - 1) : 0, y_hi = finite ? min(max((int)floorf(iymax) + 2, 0), H - 1) : H - 1;
+    const int bw = x_hi - x_lo + 1, bh = y_hi - y_lo + 1;
+    const bool in_lds = finite && bw * bh <= kT16Box;   // block-uniform
+    if (in_lds) {
+        for (int i = threadIdx.x; i < bw * bh; i += 256) box[0][i] = 0.f, box[1][i] = 0.f, box[2][i] = 0.f;
+        __syncthreads();
+    }
+    const int y_ = py0 + (int)(threadIdx.x >> 4), x_ = px0 + (int)(threadIdx.x & 15);
+    if (y_ < H && x_ < W) {
+        const float bx = base_o(x_, W), by = base_o(y_, H);
+        const Taps4 t = make_taps4(th[0] * bx + th[1] * by + th[2], th[3] * bx + th[4] * by + th[5], H, W);
+        int c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+        if (in_lds) {
+            const int r0 = t.o00 / W, q0 = t.o00 - r0 * W, r1 = t.o11 / W, q1 = t.o11 - r1 * W;
+            const int a0 = min(max(r0 - y_lo, 0), bh - 1), a1 = min(max(r1 - y_lo, 0), bh - 1);
+            const int b0 = min(max(q0 - x_lo, 0), bw - 1), b1 = min(max(q1 - x_lo, 0), bw - 1);
+            c00 = a0 * bw + b0, c01 = a0 * bw + b1, c10 = a1 * bw + b0, c11 = a1 * bw + b1;
+        }
+        const int hw = y_ * W + x_;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const size_t pl = ((size_t)n * 3 + ch) * HW;
+            const float *ip = fake2 + pl;
+            const float o21 = ip[t.o00] * t.w00 + ip[t.o01] * t.w01 + ip[t.o10] * t.w10 + ip[t.o11] * t.w11;
+            const float sg = c * sgn(o21 - fake1[pl + hw]);
+            gfake1[pl + hw] -= sg;
+            if (sg == 0.f) continue;
+            if (in_lds) {
+                if (t.w00 != 0.f) atomicAdd(&box[ch][c00], sg * t.w00);
+                if (t.w01 != 0.f) atomicAdd(&box[ch][c01], sg * t.w01);
+                if (t.w10 != 0.f) atomicAdd(&box[ch][c10], sg * t.w10);
+                if (t.w11 != 0.f) atomicAdd(&box[ch][c11], sg * t.w11);
+            } else {
+                float *gp = gfake2 + pl;
+                if (t.w00 != 0.f) atomicAdd(gp + t.o00, sg * t.w00);
+                if (t.w01 != 0.f) atomicAdd(gp + t.o01, sg * t.w01);
+                if (t.w10 != 0.f) atomicAdd(gp + t.o10, sg * t.w10);
+                if (t.w11 != 0.f) atomicAdd(gp + t.o11, sg * t.w11);
             }
         }
     }
@@ -789,14 +888,21 @@ extern "C" int pws_temporal_l1_bwd(const float *fake1, const float *fake2, const
     // Measured (tools/temporal_ab.py, random frames): 108 / 416 us per launch at 32 / 128 samples for one lane per pixel with 12 memory
     // atomics, 156 / 598 us for the tiles with the scatter in LDS -- the L2 retires fp32 atomics at ~230 G/s, the tiled kernel's two
     // barriers, box zeroing / flush and 186 registers cost more than the atomics it saves.  NOT taken (PWS_OPT_EXPERIMENT 98 takes it).
+    if (g_experiment == 99) {
+        const int tx = (w + 15) / 16, ty = (h + 15) / 16;
+        hipLaunchKernelGGL(temporal_l1_bwd_tile16_kernel, dim3((unsigned)(n * tx * ty)), dim3(256), 0, as_stream(stream), fake1, fake2, theta, c, scale,
+                           gfake1, gfake2, h, w, tx, ty);
+        return check_launch("temporal_l1_bwd_tile16_kernel");
+    }
     if (g_experiment == 98) {
         const int tx = (w + kTT - 1) / kTT, ty = (h + kTT - 1) / kTT;
         hipLaunchKernelGGL(temporal_l1_bwd_tiled_kernel, dim3((unsigned)(n * tx * ty)), dim3(256), 0, as_stream(stream), fake1, fake2, theta, c, scale,
                            gfake1, gfake2, h, w, tx, ty);
         return check_launch("temporal_l1_bwd_tiled_kernel");
     }
+    // neighbouring lanes merge the atomics of the taps they share (PWS_OPT_EXPERIMENT 93: never)
     hipLaunchKernelGGL(temporal_l1_kernel<true>, dim3(nb), dim3(256), 0, as_stream(stream), fake1, fake2, theta,
-                       (double *)nullptr, c, scale, gfake1, gfake2, h, w, total, nb);
+                       (double *)nullptr, c, scale, gfake1, gfake2, h, w, total, nb, (float *)nullptr, (total % 256 == 0 && g_experiment != 93) ? 1 : 0);
     return check_launch("temporal_l1_kernel<bwd>");
 }
 
