@@ -516,7 +516,7 @@ def main():
             "config": {"workload": "configs[1]: batch=8 256x256 inference per GPU, fp32 HIP conv + grid_sample; "
                                    "frame-sharded, no collective", "frames_per_gpu_per_step": B,
                        "launch": ("eager" if a.no_graph else "hipGraph replay of the forward + 1 grid_sample launch") +
-                                 (", single queue" if a.serial else ", two queues (stage k+1 encoder beside stage k decoder)"),
+                                 (", single queue" if a.serial else ", two queues; stages 2 and 3 in lockstep (their shared layers as one launch of batch 2n: 45 launches per forward)"),
                        "window": "31x256x256", "frame": "3x256x256", "weights": "synthetic W1 (pwstablenet_amd.synth)"},
             "netg_tflops_per_gpu": round(fps / world * GFLOP_PER_FRAME_INFER / 1e3, 2),
             "netg_frac_fp32_peak": round(fps / world * GFLOP_PER_FRAME_INFER / 1e3 / PEAK_FP32_TFLOPS, 4),

@@ -482,8 +482,9 @@ int pws_netg_forward(const float *packed, const float *x, int n, int input_nc, i
 typedef struct pws_netg_opts {
     int math;       /* PWS_MATH_FP32 / PWS_MATH_BF16 */
     int store;      /* PWS_STORE_FP32 / PWS_STORE_BF16 (needs PWS_MATH_BF16 and ngf % 32 == 0) */
-    int two_queues; /* 1: fork the internal second queue (forward: stage k+1 encoder and the last stage's deep decoder levels beside
-                       stage k's decoder; backward: every weight gradient beside the data-gradient chain; the queues join before the
+    int two_queues; /* 1: fork the internal second queue (forward: the stage-2/3 encoder -- stages 2 and 3 run in lockstep, their shared
+                       layers as one launch of batch 2n -- and the deep decoder levels beside stage 1's encoder / decoder;
+                       backward: every weight gradient beside the data-gradient chain; the queues join before the
                        call's last launch on the caller's stream / at the end of the call); 0: caller's stream only;
                        -1: the process default (PWS_OPT_TWO_QUEUES) */
     int flags;      /* bit set of PWS_NETG_*; unknown bits are refused */
