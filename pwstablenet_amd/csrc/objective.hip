@@ -203,6 +203,72 @@ __global__ void __launch_bounds__(256) warp_norm_bwd_kernel(const float *__restr
     *q = o;
 }
 
+// 4 pixels per lane (round 4): float4 reads of the field / the upstream gradient / the target planes, a float4 read-modify-write of the result,
+// the two taps of a source row as ONE unaligned 8-byte load (as warp_norm_fwd_kernel) -- 24 loads of 8 bytes per lane where the kernel above
+// issues 48 scalar gathers, a third of its streaming instructions.  Same arithmetic per pixel.
+__global__ void __launch_bounds__(256) warp_norm_bwd4_kernel(const float *__restrict__ src, size_t src_nstride, const float *__restrict__ grid,
+                                                             const float *__restrict__ target, size_t tgt_nstride, float c_l1,
+                                                             const float *__restrict__ scale, const float *__restrict__ gextra,
+                                                             float *__restrict__ ggrid, int accumulate, int H, int W, size_t total_groups,
+                                                             unsigned nblocks) {
+    const unsigned blk = xcd_remap(blockIdx.x, nblocks);
+    const size_t gidx = (size_t)blk * 256 + threadIdx.x;
+    if (gidx >= total_groups) return;
+    const int HW = H * W;
+    const size_t p0 = gidx * 4;
+    const int n = (int)(p0 / HW), hw = (int)(p0 % HW);
+    if (scale) c_l1 *= *scale;
+    const float4 ga = *reinterpret_cast<const float4 *>(grid + p0 * 2), gb = *reinterpret_cast<const float4 *>(grid + p0 * 2 + 4);
+    const float gxy[4][2] = {{ga.x, ga.y}, {ga.z, ga.w}, {gb.x, gb.y}, {gb.z, gb.w}};
+    int o0[4], o1[4], sel[4];
+    float wx0[4], wx1[4], wy0[4], wy1[4];
+    bool vx0[4], vx1[4], vy0[4], vy1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float ix = unnorm_o(gxy[i][0], W), iy = unnorm_o(gxy[i][1], H);
+        const float fx = floorf(ix), fy = floorf(iy);
+        const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+        wx1[i] = ix - fx, wx0[i] = 1.f - wx1[i], wy1[i] = iy - fy, wy0[i] = 1.f - wy1[i];
+        vx0[i] = x0 >= 0 && x0 < W, vx1[i] = x1 >= 0 && x1 < W, vy0[i] = y0 >= 0 && y0 < H, vy1[i] = y1 >= 0 && y1 < H;
+        const int xs = min(max(x0, 0), W - 2);   // the pair (xs, xs + 1) holds whichever of x0 / x1 lie inside the row
+        sel[i] = x0 - xs;                        // 0: (x0, x1) = the pair; -1: x1 = pair.x (x0 = -1); 1: x0 = pair.y (x1 = W); else both outside
+        o0[i] = min(max(y0, 0), H - 1) * W + xs, o1[i] = min(max(y1, 0), H - 1) * W + xs;
+    }
+    float gix[4] = {0.f, 0.f, 0.f, 0.f}, giy[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float *ip = src + (size_t)n * src_nstride + (size_t)c * HW;
+        float4 ge = make_float4(0.f, 0.f, 0.f, 0.f), tg = ge;
+        if (gextra) ge = *reinterpret_cast<const float4 *>(gextra + ((size_t)n * 3 + c) * HW + hw);
+        if (target) tg = *reinterpret_cast<const float4 *>(target + (size_t)n * tgt_nstride + (size_t)c * HW + hw);
+        const float gev[4] = {ge.x, ge.y, ge.z, ge.w}, tgv[4] = {tg.x, tg.y, tg.z, tg.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const F2Uo u = *reinterpret_cast<const F2Uo *>(ip + o0[i]);
+            const F2Uo v = *reinterpret_cast<const F2Uo *>(ip + o1[i]);
+            const float l0 = sel[i] == 0 ? u.x : (sel[i] == 1 ? u.y : 0.f), r0 = sel[i] == 0 ? u.y : (sel[i] == -1 ? u.x : 0.f);
+            const float l1 = sel[i] == 0 ? v.x : (sel[i] == 1 ? v.y : 0.f), r1 = sel[i] == 0 ? v.y : (sel[i] == -1 ? v.x : 0.f);
+            const float v00 = (vy0[i] && vx0[i]) ? (l0 + 1.f) * 127.5f : 0.f, v01 = (vy0[i] && vx1[i]) ? (r0 + 1.f) * 127.5f : 0.f;
+            const float v10 = (vy1[i] && vx0[i]) ? (l1 + 1.f) * 127.5f : 0.f, v11 = (vy1[i] && vx1[i]) ? (r1 + 1.f) * 127.5f : 0.f;
+            float gf = gev[i];
+            if (target) {
+                const float fk = (v00 * (wx0[i] * wy0[i]) + v01 * (wx1[i] * wy0[i]) + v10 * (wx0[i] * wy1[i]) + v11 * (wx1[i] * wy1[i])) / 127.5f - 1.f;
+                gf += c_l1 * sgn(fk - tgv[i]);
+            }
+            gix[i] += gf * ((v01 - v00) * wy0[i] + (v11 - v10) * wy1[i]);
+            giy[i] += gf * ((v10 - v00) * wx0[i] + (v11 - v01) * wx1[i]);
+        }
+    }
+    const float sx = 0.5f * (float)W / 127.5f, sy = 0.5f * (float)H / 127.5f;
+    float4 oa = make_float4(gix[0] * sx, giy[0] * sy, gix[1] * sx, giy[1] * sy), ob = make_float4(gix[2] * sx, giy[2] * sy, gix[3] * sx, giy[3] * sy);
+    float4 *q = reinterpret_cast<float4 *>(ggrid + p0 * 2);
+    if (accumulate) {
+        const float4 a = q[0], b = q[1];
+        oa.x += a.x, oa.y += a.y, oa.z += a.z, oa.w += a.w, ob.x += b.x, ob.y += b.y, ob.z += b.z, ob.w += b.w;
+    }
+    q[0] = oa, q[1] = ob;
+}
+
 // ------------------------------------------------------------------------------------------------ temporal consistency
 __device__ __forceinline__ float base_o(int j, int size) { return (2.f * j + 1.f) / (float)size - 1.f; }
 
@@ -237,7 +303,14 @@ __global__ void __launch_bounds__(256) temporal_l1_kernel(const float *__restric
     }
     for (unsigned b = blockIdx.x; b < nblocks; b += gridDim.x) {   // (forward: capped grid, see warp_norm_fwd_kernel)
         const unsigned blk = xcd_remap(b, nblocks);
-        const size_t p = (size_t)blk * 256 + threadIdx.x;
+        size_t p = (size_t)blk * 256 + threadIdx.x;
+        if (BWD && g_pair == 2) {
+            // a workgroup = 128 columns x 2 rows, a wave = 32 columns x 2 rows (lanes l and l + 32 are vertical neighbours)
+            const unsigned tiles_x = (unsigned)W / 128u, per_sample = tiles_x * ((unsigned)H / 2u);
+            const unsigned ns = blk / per_sample, tb = blk % per_sample;
+            const unsigned row = (tb / tiles_x) * 2u + ((threadIdx.x >> 5) & 1u), col = (tb % tiles_x) * 128u + (threadIdx.x >> 6) * 32u + (threadIdx.x & 31u);
+            p = (size_t)ns * HW + (size_t)row * W + col;
+        }
         if (p >= total) continue;
         float acc[1] = {0.f};
         const int n = (int)(p / HW), hw = (int)(p % HW);
@@ -264,19 +337,27 @@ __global__ void __launch_bounds__(256) temporal_l1_kernel(const float *__restric
                     const float v00 = s * t.w00, v01 = s * t.w01, v10 = s * t.w10, v11 = s * t.w11;
                     const int lane = threadIdx.x & 63;
                     // (g_pair is only set when total % 256 == 0: every lane of every wave is here)
-                    constexpr bool live = true;
-                    const bool nxt_same = lane < 63 && __shfl_down(t.o00, 1, 64) == t.o01 && __shfl_down(t.o10, 1, 64) == t.o11;   // my right taps == the next lane's left taps
-                    const bool prv_same = __shfl_up(nxt_same ? 1 : 0, 1, 64) == 1 && lane > 0;
+                    const int rowlen = g_pair == 2 ? 32 : 64, li = lane & (rowlen - 1);   // lanes of one image row inside the wave
+                    const bool nxt_same = li < rowlen - 1 && __shfl_down(t.o00, 1, 64) == t.o01 && __shfl_down(t.o10, 1, 64) == t.o11;   // my right taps == the next lane's left taps
+                    const bool prv_same = __shfl_up(nxt_same ? 1 : 0, 1, 64) == 1 && li > 0;
                     const float a01 = __shfl_up(v01, 1, 64), a11 = __shfl_up(v11, 1, 64);
-                    if (live) {
-                        float *gp = gfake2 + pl;
-                        const float u00 = v00 + (prv_same ? a01 : 0.f), u10 = v10 + (prv_same ? a11 : 0.f);
-                        if (u00 != 0.f) atomicAdd(gp + t.o00, u00);
+                    float u00 = v00 + (prv_same ? a01 : 0.f), u10 = v10 + (prv_same ? a11 : 0.f);   // left taps, the previous lane's right taps folded in
+                    float r01 = nxt_same ? 0.f : v01, r11 = nxt_same ? 0.f : v11;                    // right taps, unless the next lane takes them
+                    bool lower_out = true;   // this lane issues its bottom-row taps itself
+                    if (g_pair == 2) {
+                        // ... and the BOTTOM taps of a pixel are the TOP taps of the pixel below = lane + 32
+                        const bool ver_same = lane < 32 && __shfl_down(t.o00, 32, 64) == t.o10 && __shfl_down(t.o01, 32, 64) == t.o11;
+                        const bool from_up = __shfl_up(ver_same ? 1 : 0, 32, 64) == 1 && lane >= 32;
+                        const float c_in = __shfl_up(u10, 32, 64), d_in = __shfl_up(r11, 32, 64);
+                        if (from_up) u00 += c_in, r01 += d_in;
+                        lower_out = !ver_same;
+                    }
+                    float *gp = gfake2 + pl;
+                    if (u00 != 0.f) atomicAdd(gp + t.o00, u00);
+                    if (r01 != 0.f) atomicAdd(gp + t.o01, r01);
+                    if (lower_out) {
                         if (u10 != 0.f) atomicAdd(gp + t.o10, u10);
-                        if (!nxt_same) {
-                            if (v01 != 0.f) atomicAdd(gp + t.o01, v01);
-                            if (v11 != 0.f) atomicAdd(gp + t.o11, v11);
-                        }
+                        if (r11 != 0.f) atomicAdd(gp + t.o11, r11);
                     }
                 } else if (s != 0.f) {
                     float *gp = gfake2 + pl;
@@ -859,6 +940,14 @@ extern "C" int pws_warp_norm_bwd(const float *src, size_t src_nstride, const flo
     const unsigned nb = (unsigned)((total + 255) / 256);
     ProfScope prof(KID_OBJECTIVE, 150.0 * total, (double)total * (8.0 + 12.0 + 8.0 + (target ? 12.0 : 0.0) + (gextra ? 12.0 : 0.0)),
                    as_stream(stream));
+    if (((size_t)h * w) % 4 == 0 && w >= 2 && al16(grid) && al16(ggrid) && (!gextra || al16(gextra)) && (!target || (al16(target) && tgt_nstride % 4 == 0)) &&
+        g_experiment != 94) {   // 4 pixels per lane (94: one pixel per lane, A/B and tests)
+        const size_t groups = total / 4;
+        const unsigned nb4 = (unsigned)((groups + 255) / 256);
+        hipLaunchKernelGGL(warp_norm_bwd4_kernel, dim3(nb4), dim3(256), 0, as_stream(stream), src, src_nstride, grid, target, tgt_nstride, c_l1, scale,
+                           gextra, ggrid, accumulate, h, w, groups, nb4);
+        return check_launch("warp_norm_bwd4_kernel");
+    }
     hipLaunchKernelGGL(warp_norm_bwd_kernel, dim3(nb), dim3(256), 0, as_stream(stream), src, src_nstride, grid, target,
                        tgt_nstride, c_l1, scale, gextra, ggrid, accumulate, h, w, total, nb);
     return check_launch("warp_norm_bwd_kernel");
@@ -900,9 +989,11 @@ extern "C" int pws_temporal_l1_bwd(const float *fake1, const float *fake2, const
                            gfake1, gfake2, h, w, tx, ty);
         return check_launch("temporal_l1_bwd_tiled_kernel");
     }
-    // neighbouring lanes merge the atomics of the taps they share (PWS_OPT_EXPERIMENT 93: never)
+    // neighbouring lanes merge the atomics of the taps they share (PWS_OPT_EXPERIMENT 93: never; 101: vertical neighbours as well -- a wave as
+    // 32 columns x 2 rows: 1.5 instead of 2 atomics per pixel and plane, measured SLOWER, 91 vs 72 us: the narrower rows and the extra shuffles cost more)
     hipLaunchKernelGGL(temporal_l1_kernel<true>, dim3(nb), dim3(256), 0, as_stream(stream), fake1, fake2, theta,
-                       (double *)nullptr, c, scale, gfake1, gfake2, h, w, total, nb, (float *)nullptr, (total % 256 == 0 && g_experiment != 93) ? 1 : 0);
+                       (double *)nullptr, c, scale, gfake1, gfake2, h, w, total, nb, (float *)nullptr,
+                       (total % 256 != 0 || g_experiment == 93) ? 0 : ((w % 128 == 0 && h % 2 == 0 && g_experiment == 101) ? 2 : 1));
     return check_launch("temporal_l1_kernel<bwd>");
 }
 

@@ -14,7 +14,7 @@ for n in (32, 128):
     f2 = torch.rand((n, 3, 256, 256), device="cuda") * 2 - 1
     th = torch.tensor([1, 0, 0, 0, 1, 0], device="cuda", dtype=torch.float32).repeat(n, 1) + 0.01 * torch.randn((n, 6), device="cuda")
     g1, g2 = torch.zeros_like(f1), torch.zeros_like(f2)
-    for e in (93, 0, 98, 99):
+    for e in (93, 101, 0, 98, 99):
         L.pws_set_option(100, e)
         for _ in range(3):
             A.check(L.pws_temporal_l1_bwd(A.ptr(f1), A.ptr(f2), A.ptr(th), 0.1, None, A.ptr(g1), A.ptr(g2), n, 256, 256, st()), "t")
