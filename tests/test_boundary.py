@@ -195,3 +195,32 @@ def test_checkpoint_files_in_the_reference_format(tmp_path):
     torch.save({"net": broken, "epoch": 1}, bare)
     with pytest.raises(RuntimeError):
         load_checkpoint(net, str(bare))
+
+
+def test_gradient_slab_layout_is_consistent():
+    """pws_netg_grad_floats / pws_netg_grad_layout (ABI 4, host-side functions: no GPU needed): the 46 layers' ranges abut, cover the slab,
+    and each holds its weight gradient in the forward packed layout + its bias gradient; the slab is the 48.5 M gradients plus alignment
+    only (what a data-parallel host all-reduces in place instead of nn.DataParallel's reduce, lib/networks_cascading.py:51-52)."""
+    import ctypes
+    from pwstablenet_amd import hipabi as A
+    from pwstablenet_amd.spec import layer_specs
+    L = A.lib()
+    for ngf in (16, 64):
+        specs = layer_specs(31, 2, ngf)
+        nl = len(specs)
+        assert nl == 46
+        first, count = (ctypes.c_size_t * nl)(), (ctypes.c_size_t * nl)()
+        assert L.pws_netg_grad_layout(31, ngf, first, count) == 0
+        total = L.pws_netg_grad_floats(31, ngf)
+        assert first[0] == 0 and first[nl - 1] + count[nl - 1] == total
+        nparam = 0
+        for i, ls in enumerate(specs):
+            if i + 1 < nl:
+                assert first[i] + count[i] == first[i + 1]        # consecutive layers abut: finished layers merge into few large messages
+            w = ls.cin * ls.cout * ls.k * ls.k
+            assert count[i] >= w + ls.cout and count[i] % 64 == 0  # (input channels padded to 16, 64-float alignment)
+            nparam += w + ls.cout
+        assert nparam <= total <= nparam * 1.02 + 64 * 2 * nl
+        assert total < L.pws_netg_packed_floats(31, ngf)            # (the weight buffer also holds the Winograd / bf16 copies)
+    assert L.pws_netg_grad_floats(31, 60) == 0                      # ngf must be a multiple of 16
+    assert L.pws_netg_grad_layout(31, 64, None, None) == -22
