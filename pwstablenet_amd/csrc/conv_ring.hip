@@ -78,9 +78,16 @@ struct RingParams {
                           // 2 = no matrix phase, 4 = no epilogue -- results are meaningless, only the timing is read
 };
 
-template <int MODE_, int TH_, int TW_, int TN_, int R_>
+// MT_: 32-pixel operand rows per matrix wave.  2: eight matrix waves (two per SIMD), each 64 pixels x 64 channels -- every matrix instruction
+// reads 1 KB of operands from LDS, and at 128 B per clock the CU's LDS delivers exactly the 8 waves x 4 KB a step of 4 x 8 matrix
+// instructions (256 cycles per SIMD) consumes: the matrix phase cannot run faster than the LDS reads (measured: 55-60 % of the peak
+// with the DMA and the epilogue switched off).  4 ("tall", 32-wide tiles): FOUR matrix waves (one per SIMD), each 4 tile rows x 64
+// channels in 8 accumulators; the 6 halo rows a wave's 4 rows see through the 3 vertical taps are read ONCE per (tap column, channel
+// half) and feed 24 matrix instructions with 6 weight reads: 0.5 KB per matrix instruction.
+template <int MODE_, int TH_, int TW_, int TN_, int R_, int MT_ = 2>
 struct RgCfg {
-    static constexpr int MODE = MODE_, TH = TH_, TW = TW_, TN = TN_, R = R_;
+    static constexpr int MODE = MODE_, TH = TH_, TW = TW_, TN = TN_, R = R_, MT = MT_;
+    static_assert(MT == 2 || (MT == 4 && TW == 32 && TN == 1), "tall matrix waves: consecutive operand rows = consecutive tile rows");
     static constexpr int KS = MODE == RM_K3S1 ? 3 : 2;
     static constexpr int TAPS = KS * KS;
     static constexpr int NPLANES = MODE >= RM_K3S2 ? 4 : 1;   // input parity planes
@@ -89,7 +96,7 @@ struct RgCfg {
     // the LDS-DMA pieces: a DMA piece blocks its wave for the ~30-70 cycles the texture addresser takes per piece, 75 pieces per
     // group -- issued by the matrix waves themselves that time ADDS to the matrix phase (measured: DMA-only, MFMA-only and
     // epilogue-only timings of the one-role kernel summed to its run time), issued by waves of their own it hides under it
-    static constexpr int MWAVES = 8, LWAVES = 4, THREADS = 64 * (MWAVES + LWAVES);
+    static constexpr int MWAVES = 16 / MT, LWAVES = 4, THREADS = 64 * (MWAVES + LWAVES);
     // 512 pixels per tile = TN samples x TH x TW; a matrix wave's operand is 32 consecutive tile pixels = 32 / TW tile rows
     static_assert(TH * TW * TN == 512 && (TW == 32 || TW == 16 || TW == 8) && (TH & (TH - 1)) == 0, "tile");
     static constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
@@ -171,7 +178,7 @@ __device__ __forceinline__ RingUnit ring_unit(const RingParams &p, unsigned u) {
 // SG (data gradient only): every act' operand is given as SIGN BITS (RingParams.dst_sign): the epilogue loads one byte per slot instead of
 // 16 (a runtime choice would keep both in registers: the data-gradient kernels stand at the 168-register limit)
 template <class C, bool DG, bool SG = false>   // DG: data-gradient epilogue (scatter over the forward layer's sources, accumulate, act')
-__global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingParams p) {
+__global__ void __launch_bounds__(C::THREADS, C::MT == 4 ? 2 : 3) conv_ring_kernel(const RingParams p) {
     static_assert(DG || !SG, "sign bits are an operand of the data-gradient epilogue");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -370,19 +377,20 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
     // =============================================================================================== matrix waves
     // operand read offsets inside a group image (bytes): lane (l31, hi) reads k-slot 2 ks + hi of its row
     // (the second 16-channel half, ks = 1, is the same address with bit 5 flipped: the slot index is (2 ks + hi) ^ f)
-    int a_off[2][C::KS];
+    constexpr int MT = C::MT;
+    int a_off[MT][C::KS];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int dx = 0; dx < C::KS; ++dx) {
-            const int m = (wv * 2 + mt) * 32 + l31;   // tile pixel of this lane's operand row
+            const int m = (wv * MT + mt) * 32 + l31;   // tile pixel of this lane's operand row
             const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
             const int lx = tx + dx;
             a_off[mt][dx] = ((tn * C::IH + ty) * C::IW + lx) * C::ROWB + ((hi ^ ((lx >> 2) & 3)) << 4);
         }
     const int b_off = C::W_OFF + l31 * C::ROWB + ((hi ^ ((l31 >> 2) & 3)) << 4);
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][2];
 
     // epilogue state.  The matrix instructions run transposed (weights as the A operand, pixels as B): lane (l31, hi) holds, for
     // each of its two pixels (mt), the 32 channels co0 + 32 hi + [0, 32) in acc[mt][0..1][0..15] -- four 16-byte stores per pixel
@@ -394,10 +402,16 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
     // of the stride-2 layers on the 256 x 256 maps is a read-modify-write of 537 MB tensors with 1-4 taps of matrix work per
     // group: its pace is the number of 16-byte requests a wave keeps in flight (PWS_RING_PF overrides for A/B builds)
 #ifndef PWS_RING_PF
-#define PWS_RING_PF (SG ? (C::MODE == RM_K4S2 ? 8 : (C::MODE == RM_SP3 ? 4 : 2)) : (C::MODE == RM_SP3 ? 2 : 1))   // (the sign-bit variants have the registers for more slots in flight)
+#define PWS_RING_PF (SG ? (C::MODE == RM_K4S2 ? (C::MT == 4 ? 4 : 8) : (C::MODE == RM_SP3 ? 4 : 2)) : (C::MODE == RM_SP3 ? 2 : 1))   // (the sign-bit variants have the registers for more slots in flight)
 #endif
     constexpr int PF = PWS_RING_PF;
-    constexpr int NSLOT = 8;       // slot = mt * 4 + q: pixel mt, 8-channel group q of the lane's 32 channels
+    // tall waves: half as many waves issue the epilogue's requests, and the 96 operand registers of the matrix phase are free once it is over:
+    // the requests of slots PF .. PFR - 1 go out right behind the last matrix instruction, and the rolling distance is PFR
+#ifndef PWS_RING_PFR
+#define PWS_RING_PFR (MT == 4 ? (SG ? 10 : 6) : PF)
+#endif
+    constexpr int PFR = PWS_RING_PFR < PF ? PF : PWS_RING_PFR;
+    constexpr int NSLOT = MT * 4;  // slot = mt * 4 + q: pixel mt, 8-channel group q of the lane's 32 channels
     // destination of the unit's two 32-channel blocks (block b = channels co0 + 32 b + [0, 32) = store slots q = 2 b, 2 b + 1;
     // data gradient: a block lies in ONE source of the forward layer, sources being multiples of 32 channels): pointers already
     // at this lane's first group (+ 8 hi channels)
@@ -431,7 +445,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
     RingUnit CU = ring_unit(p, cu);
     // output pixel index of this lane's pixel mt of unit CU: tile pixel m = (2 wv + mt) * 32 + l31
     auto e_pix = [&](int mt) {
-        const int m = (wv * 2 + mt) * 32 + l31;
+        const int m = (wv * MT + mt) * 32 + l31;
         const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
         const int y = CU.y0 * C::TH + ty, x = CU.x0 * C::TW + tx;
         const int oy = SO * y + (C::NCLS == 4 ? CU.py : 0), ox = SO * x + (C::NCLS == 4 ? CU.px : 0);
@@ -507,7 +521,7 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
 
         if (cg == 0) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -522,7 +536,48 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
         if constexpr (C::MODE == RM_K3S2) tapmask = (cplane >> 1) ? ((cplane & 1) ? 0xfu : 0x5u) : ((cplane & 1) ? 0x3u : 0x1u);
         const unsigned gb = (unsigned)(cbuf * C::GROUP_BYTES);
         if (!(p.ablate & 2)) {
-            if constexpr (C::MODE != RM_K3S1) {
+            if constexpr (MT == 4) {
+                // tall waves: step = (channel half ks, tap column tx).  The wave's 4 tile rows see MT + KS - 1 halo rows through the KS vertical
+                // taps: each is read once per step; the operands of step + 1 are requested under the matrix instructions of the step, one
+                // ds_read_b128 after every second matrix instruction (one wave per SIMD: nobody else fills a bubble in the matrix pipe)
+                static_assert(C::MODE == RM_K3S1 || C::MODE == RM_CT4 || C::MODE == RM_K4S2, "tall waves: the kinds without a tap mask");
+                constexpr int NST = 2 * C::KS, NA = MT + C::KS - 1, NRD = NA + 2 * C::KS, NMM = C::KS * MT * 2;
+                bf16x8 av[2][NA], bv[2][C::KS][2];
+                auto rd = [&](int slot, int st) {
+                    const int ks = st / C::KS, tx = st % C::KS;
+#pragma unroll
+                    for (int j = 0; j < NA; ++j)
+                        av[slot][j] = *reinterpret_cast<const bf16x8 *>(lds + gb + (unsigned)((a_off[0][tx] ^ (ks * 32)) + j * C::IW * C::ROWB));
+#pragma unroll
+                    for (int ty = 0; ty < C::KS; ++ty)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            bv[slot][ty][nt] = *reinterpret_cast<const bf16x8 *>(lds + gb + (unsigned)((b_off ^ (ks * 32)) + ((ty * C::KS + tx) * 64 + nt * 32) * C::ROWB));
+                };
+                rd(0, 0);
+#pragma unroll
+                for (int st = 0; st < NST; ++st) {
+                    const int cur = st & 1;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (st + 1 < NST) rd(cur ^ 1, st + 1);
+#pragma unroll
+                    for (int ty = 0; ty < C::KS; ++ty)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[cur][ty][nt], av[cur][mt + ty], acc[mt][nt], 0, 0, 0);
+                    if (st + 1 < NST) {
+                        if constexpr (NRD > NMM / 2) __builtin_amdgcn_sched_group_barrier(0x100, NRD - NMM / 2, 0);
+#pragma unroll
+                        for (int i = 0; i < (NRD < NMM / 2 ? NRD : NMM / 2); ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if constexpr (C::MODE != RM_K3S1) {
                 // sub-pixel / stride-2 kinds take 1, 2 or 4 of the taps by class / plane (wave-uniform mask); the k4s2 kinds measured
                 // 1-2 % slower with the pipelined loop below: plain loop
 #pragma unroll
@@ -586,15 +641,24 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ring_kernel(const RingPara
             // ---- epilogue of unit cu, straight from the accumulators: slot (mt, q) = channels co0 + 32 hi + 8 q + [0, 8) of pixel mt
             // = acc[mt][q / 2][8 (q % 2) + k].  No LDS, no barrier: the waves run into the next unit's first group on their own.
             if (!(p.ablate & 4)) {
+                if constexpr (DG && PFR > PF) {
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
+                    for (int slot = PF; slot < PFR && slot < NSLOT; ++slot) {
+                        const unsigned pix2 = e_pix(slot >> 2);
+                        const EpiBlock &e2 = eb[(slot >> 1) & 1];
+                        e_old[slot] = e_load(e2.d + (size_t)pix2 * e2.dld2 + (slot & 1) * 32, e2.ok && e2.acc);
+                        e_load_y(e2, pix2, slot, e2.ok && e2.hasy && !(p.ablate & 16), slot);
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
                     const unsigned pix = e_pix(mt);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int slot = mt * 4 + q;
                         const EpiBlock &e = eb[q >> 1];
                         if constexpr (DG) {   // rolling request, PF slots ahead
-                            const int nx2 = slot + PF;
+                            const int nx2 = slot + PFR;
                             if (nx2 < NSLOT) {
                                 const unsigned pix2 = e_pix(nx2 >> 2);
                                 const EpiBlock &e2 = eb[(nx2 >> 1) & 1];
@@ -708,6 +772,8 @@ static int ring_launch(RingParams &rp, hipStream_t st) {
 // 8 x 8 maps (2x2-tap kinds only: the 3x3 kind's group of 8 halo'd samples does not fit two ring buffers).
 template <int MODE, bool DG, bool SG = false>
 static int ring_launch_tile(int tw, RingParams &rp, hipStream_t st) {
+    if constexpr (MODE == RM_K3S1 || MODE == RM_CT4 || MODE == RM_K4S2)
+        if (tw == 32 && g_experiment != 105 && !(g_experiment == 106 && DG) && !(g_experiment == 107 && !DG)) return ring_launch<RgCfg<MODE, 16, 32, 1, MODE == RM_K3S1 ? 2 : 3, 4>, DG, SG>(rp, st);   // (A/B: 105 = the 8-wave kernel, 106 / 107 = for the data gradients / the forwards only)
     if (tw == 32) return ring_launch<RgCfg<MODE, 16, 32, 1, MODE == RM_K3S1 ? 2 : 3>, DG, SG>(rp, st);
     if (tw == 16) return ring_launch<RgCfg<MODE, 16, 16, 2, 2>, DG, SG>(rp, st);
     if constexpr (MODE != RM_K3S1) return ring_launch<RgCfg<MODE, 8, 8, 8, 2>, DG, SG>(rp, st);

@@ -907,6 +907,14 @@ def test_data_gradient_with_sign_bits_is_bit_identical_to_reading_the_forward_te
     for r_, g_, o_ in zip(ref, got, off):
         assert not torch.isnan(r_).any()
         assert torch.equal(r_, g_) and torch.equal(r_, o_)
+    if ran[0] == ["conv_ring_kernel"]:
+        # round 4: on 32-wide tiles the kinds without a tap mask run FOUR matrix waves of 4 tile rows (RgCfg<..., MT = 4>); PWS_OPT_EXPERIMENT 105
+        # = the eight-wave kernel.  Same products, another fp32 summation order, one rounding to bf16
+        for exp, with_sign in ((105, True), (105, False)):
+            eight = run(with_sign, exp)
+            assert ran[-1] == ["conv_ring_kernel"]
+            for r_, e_ in zip(ref, eight):
+                assert relerr(e_.numpy(), r_.numpy()) < 2.0 ** -7   # of the largest value: at most one bf16 ulp apart
 
 
 def test_nchw_to_nhwc_pad_and_first_layer_bf16(hip):

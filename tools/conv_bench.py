@@ -111,6 +111,41 @@ def bench(kname, n, h, w, cin, cout, wino, bf16=False):
     print("%-11s n=%d %dx%d %d->%d %-5s exp=%s %-18s: %8.1f us  %6.1f TFLOP/s (algorithmic)" % (
         kname, n, h, w, cin, cout, "bf16" if bf16 else ("wino" if wino else "direct"), os.environ.get("PWS_EXPERIMENT", "0"), r[0][0], ms * 1e3,
         r[0][2] / (ms * 1e-3) / 1e12))
+    secs = float(os.environ.get("CONV_BENCH_SECONDS", "0"))
+    if secs > 0:
+        # sustained: the same launch back to back for `secs` seconds, the engine clock and the socket power sampled beside it
+        # (a 12-launch measurement is over before the power management has settled)
+        import re
+        import subprocess
+        import threading
+        import time
+        stop, samples = threading.Event(), []
+
+        def sampler():
+            while not stop.is_set():
+                o = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True).stdout
+                c = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", o)
+                pw = re.search(r"Power \(W\): ([0-9.]+)", o)
+                samples.append((int(c.group(1)) if c else -1, float(pw.group(1)) if pw else -1.0))
+                time.sleep(0.3)
+        th = threading.Thread(target=sampler)
+        th.start()
+        t_end, per = time.perf_counter() + secs, []
+        i = 0
+        while time.perf_counter() < t_end:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(300):
+                launch(i)
+                i += 1
+            e1.record()
+            e1.synchronize()
+            per.append(e0.elapsed_time(e1) / 300 * 1e3)
+        stop.set()
+        th.join()
+        tail = samples[len(samples) // 2:]
+        print("   sustained %.0f s: %.1f us per launch at the start, %.1f at the end (%.1f TFLOP/s); sclk %s MHz, power %s W (second half of the samples)" % (
+            secs, per[0], per[-1], r[0][2] / (per[-1] * 1e-6) / 1e12, sorted(set(c for c, _ in tail)), sorted(set(round(q) for _, q in tail))[::max(1, len(tail) // 6)]))
 
 
 def bench_first(n=8, h=256, w=256, cin=31, cout=64):
