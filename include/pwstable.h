@@ -9,11 +9,16 @@
  * Re-entrant per stream and per thread.  Global mutable state: the thread-local error string, the process-wide DEFAULTS of
  * pws_set_option() (read only by the entry points that take no pws_netg_opts; the *_opts entry points carry math / store / queue
  * mode in their arguments and read no global), the per-device side queue of the generator forward / backward (one stream per device
- * and process, shared by the EAGER calls of all host threads; every thread owns the events it orders it with, and a call made
- * inside a hipGraph capture forks into a private stream of the calling thread instead, so the shared queue is never part of
- * anybody's capture) and the measurement hooks (pws_prof_*, off by default).
+ * and process, shared by the EAGER calls of all host threads; every thread owns the events it orders it with -- one pool per CALLER
+ * STREAM, so that calls a thread makes for different streams, as autograd's worker thread does, never re-record each other's events --
+ * and a call made inside a hipGraph capture forks into a private stream of the calling thread instead, so the shared queue is never
+ * part of anybody's capture) and the measurement hooks (pws_prof_*, off by default).
  * What is exercised (tests/test_hip_threads.py, results bit-equal to serial execution): concurrent eager forwards of two generators
- * and of ONE generator from two threads / streams, concurrent replays of graphs, two whole training steps beside graph replays.
+ * and of ONE generator from two threads / streams, concurrent replays of graphs, two whole fp32 training steps beside graph replays.
+ * NOT bit-reproducible: bf16-math work of one stream beside other GPU work.  While conv_bf16_kernel runs, kernels of other streams --
+ * of other PROCESSES too -- that keep many registers live over long gather sequences compute other values in a few lanes (measured
+ * with one kernel per stream: profiles/r04_cross_stream_interference.txt; cause not found, not host-side).  One training process per
+ * GPU, the deployment this library is built for, never overlaps the two.
  * Graph CAPTURE is the caller's: capture after one eager call on the same thread (the library makes its private stream then,
  * not while the capture is open) and while no other host thread issues GPU work -- on ROCm 7.0 captures that overlapped another
  * thread's capture, device-wide synchronisation or training step ended invalidated, crashed inside the runtime, or (1 run in 12)
@@ -470,6 +475,12 @@ size_t pws_netg_packed_floats(int input_nc, int ngf);
 /* params: HOST array of 92 DEVICE pointers in state-dict order (weight, bias per layer; torch layouts). */
 int pws_netg_pack_weights(const float *const *params, float *packed, int input_nc, int ngf,
                           pws_stream_t stream);
+/* The same for a buffer that will serve forwards of ONE math mode only (a training loop re-packs after every optimizer step): `math`
+ * PWS_MATH_BF16 leaves out the Winograd-domain copies of the layers that have bf16 weights (those layers never read them in that mode),
+ * PWS_MATH_FP32 leaves out the bf16 copies; anything else packs everything (= pws_netg_pack_weights).  Running a forward of the other
+ * mode on such a buffer reads stale copies: re-pack when the mode changes. */
+int pws_netg_pack_weights_for(const float *const *params, float *packed, int input_nc, int ngf, int math,
+                              pws_stream_t stream);
 size_t pws_netg_workspace_bytes(int n, int input_nc, int ngf, int is_training);
 /* x: [n,input_nc,256,256] NCHW.  grids: is_training ? [3][n,256,256,2] : [n,256,256,2] (stage 3).
  * resid: is_training ? [3][n,256,256,2] : ignored (may be NULL).  thetas (nullable): [3][n,6]. */

@@ -224,9 +224,20 @@ static hipStream_t shared_side_queue(int dev) {
 struct SideStream {
     hipStream_t stream = nullptr;    // the device's shared side queue (eager calls)
     hipStream_t own = nullptr;       // this thread's private side stream: calls made inside a graph capture fork into it
-    std::vector<hipEvent_t> events;
-    size_t next = 0;
+    // Event pools, one per CALLER STREAM: a call re-records the pool's events from the first one on.  Waits made by an earlier call may
+    // still be queued then -- harmless while the new record lands on the same queues as the old one (it is later in their order: the
+    // queued wait can only become stricter).  With ONE pool per thread, a second call on ANOTHER stream re-recorded events that waits
+    // of the first call had not consumed yet: autograd runs the backwards of all host threads on one worker thread per device, so two
+    // training threads shared a pool, a weight-gradient launch of one waited for the other's stream and read its dy early (gradients
+    // off by 1e-4..1e-1 of their size in 1 run of 10 of tests/test_hip_threads.py, tools/probes/thread_grad_probe.py, round 4).
+    struct Pool {
+        std::vector<hipEvent_t> events;
+        size_t next = 0;
+    };
+    std::unordered_map<hipStream_t, Pool> pools;
+    Pool *cur = nullptr;
     int dev = 0;
+    void begin(hipStream_t st) { cur = &pools[st], cur->next = 0; }   // (references into an unordered_map survive a rehash)
     // The side queue to fork into beside `st`, or nullptr (run on one queue).  A call that is being CAPTURED never touches the shared
     // queue: forking joins the side stream to the caller's capture, and two host threads capturing at once would pull one stream into
     // two captures (both invalid) -- a captured call forks into the thread's own stream instead (a graph has no hardware queue of its
@@ -247,12 +258,13 @@ struct SideStream {
         return own;   // nullptr (one queue) when this thread never made an eager call
     }
     hipEvent_t event() {
-        if (next == events.size()) {
+        if (!cur) return nullptr;
+        if (cur->next == cur->events.size()) {
             hipEvent_t e = nullptr;
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-            events.push_back(e);
+            cur->events.push_back(e);
         }
-        return events[next++];
+        return cur->events[cur->next++];
     }
 };
 // one event pool per host thread AND device
@@ -281,7 +293,7 @@ class Exec {
         streams_[0] = st, streams_[1] = st;
         if (launch_ && o.two_queues) {
             side_ = &side_stream();
-            if (hipStream_t q = side_->pick(st)) streams_[1] = q, side_->next = 0;
+            if (hipStream_t q = side_->pick(st)) streams_[1] = q, side_->begin(st);
         }
     }
 
@@ -914,7 +926,7 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
     SideStream *wside = nullptr;
     if (mode.two_queues && g_experiment != 16) {
         wside = &side_stream();
-        if (hipStream_t q = wside->pick(st)) wst = q, wside->next = 0;
+        if (hipStream_t q = wside->pick(st)) wst = q, wside->begin(st);
         else wside = nullptr;
     }
     auto wgrad_fork = [&]() -> int {   // the side queue waits for everything issued on `st` so far
@@ -1174,6 +1186,10 @@ extern "C" size_t pws_netg_packed_dgrad_floats(int input_nc, int ngf) {
 }
 
 extern "C" int pws_netg_pack_weights(const float *const *params, float *packed, int input_nc, int ngf, pws_stream_t stream) {
+    return pws_netg_pack_weights_for(params, packed, input_nc, ngf, -1, stream);
+}
+
+extern "C" int pws_netg_pack_weights_for(const float *const *params, float *packed, int input_nc, int ngf, int math, pws_stream_t stream) {
     PWS_REQUIRE(params && packed, "pws_netg_pack_weights: NULL pointer");
     PWS_REQUIRE(input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_pack_weights: ngf must be a positive multiple of 16 (got %d)",
                 ngf);
@@ -1195,16 +1211,18 @@ extern "C" int pws_netg_pack_weights(const float *const *params, float *packed, 
         if (pack_tiled(p.kind)) nb += pack_tiles(p.kind, p.cin_pad, p.cout, p.k) + (unsigned)((p.cout + 255) / 256);   // tiles + bias blocks
         else nb += (unsigned)(((size_t)p.planes * p.cin_pad * p.cout + p.cout + 255) / 256);
         a.first_block_wino[i] = nbw;
-        if (p.ww_off != kNoOff || p.wr_off != kNoOff) nbw += (unsigned)(((size_t)p.cin_pad * p.cout + 255) / 256);
+        // (math == bf16: a layer with bf16 weights runs on them -- run_conv sets a.math whenever wb_off exists -- and never reads its Winograd copies)
+        const bool skip_wino = math == PWS_MATH_BF16 && L[i].wb_off != (size_t)-1;
+        if ((p.ww_off != kNoOff || p.wr_off != kNoOff) && !skip_wino) nbw += (unsigned)(((size_t)p.cin_pad * p.cout + 255) / 256);
         Bf16Layer &q = b.layer[i];
         q.planes = p.planes, q.krows = p.cin_pad, q.ncols = p.cout, q.kpad = (p.cin_pad + 31) / 32 * 32, q.npad = (p.cout + 63) / 64 * 64;
         q.src_off = p.w_off, q.dst_off = off32(L[i].wb_off);
         b.first_block[i] = nbb;
-        if (q.dst_off != kNoOff) nbb += (unsigned)(q.planes * (q.kpad / 32) * (q.npad / 64));
+        if (q.dst_off != kNoOff && math != PWS_MATH_FP32) nbb += (unsigned)(q.planes * (q.kpad / 32) * (q.npad / 64));
     }
     a.total_blocks = nb, a.total_blocks_wino = nbw, b.total_blocks = nbb;
     int rc = launch_pack_all(a, packed, as_stream(stream));
-    if (rc == PWS_OK) rc = launch_bf16_all(b, packed, packed, as_stream(stream));
+    if (rc == PWS_OK && nbb) rc = launch_bf16_all(b, packed, packed, as_stream(stream));
     return rc;
 }
 

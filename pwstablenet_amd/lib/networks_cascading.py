@@ -235,6 +235,9 @@ class UnetGenerator(nn.Module):
         """Device buffer with every layer in the kernels' layout; re-packed when a parameter changed.  raw: the conv weights as
         they are (training-mode BatchNorm normalises with batch statistics), not folded with the running statistics."""
         key = (("raw",) + tuple((p.data_ptr(), p._version) for p in self._ordered_params())) if raw else (("eff",) + self._weights_key())
+        # the buffer serves ONE math mode (pws_netg_pack_weights_for: a bf16 training loop does not re-make the Winograd copies after
+        # every optimizer step, an fp32 one not the bf16 copies); set_math() to the other mode re-packs
+        key = (self.math,) + key
         params = None
         if self._packed is None or key != self._packed_key:
             params = self._ordered_params() if raw else self._effective_params()
@@ -245,8 +248,9 @@ class UnetGenerator(nn.Module):
             if self._packed is None or self._packed.numel() != nfl or self._packed.device != dev:
                 self._packed = torch.empty(nfl, device=dev, dtype=torch.float32)
             ptrs = (ctypes.c_void_p * len(params))(*[p.data_ptr() for p in params])
-            A.check(A.lib().pws_netg_pack_weights(ptrs, A.ptr(self._packed), self.input_nc, self.ngf, A.current_stream()),
-                    "pws_netg_pack_weights")
+            A.check(A.lib().pws_netg_pack_weights_for(ptrs, A.ptr(self._packed), self.input_nc, self.ngf,
+                                                      A.MATH_BF16 if self.math == "bf16" else A.MATH_FP32, A.current_stream()),
+                    "pws_netg_pack_weights_for")
             self._packed_key = key
         return self._packed
 

@@ -87,6 +87,51 @@ def test_netg_batch_invariance_and_repack(hip):
     assert (after - before).abs().max().item() > 1e-3
 
 
+@pytest.mark.parametrize("ngf", [32, 16])
+def test_pack_for_one_math_mode(hip, ngf):
+    """pws_netg_pack_weights_for (round 4): math = -1 is pws_netg_pack_weights bit for bit; PWS_MATH_BF16 / PWS_MATH_FP32 write a subset
+    of the same values and leave the rest of the buffer alone (checked on a NaN-filled buffer: every written float equals the full
+    pack's) -- and a forward of that mode on such a buffer equals the forward on the full pack bit for bit, while the generator
+    re-packs when set_math changes the mode.  ngf 16: the shallow layers (16 / 48 input channels) have no bf16 weights and run fp32
+    Winograd in bf16 mode too -- their Winograd copies must be kept."""
+    import ctypes
+    A = hip
+    L, st = A.lib(), A.current_stream()
+    net = make_net("W2", ngf)
+    g = net.module
+    params = g._effective_params()
+    ptrs = (ctypes.c_void_p * len(params))(*[p_.data_ptr() for p_ in params])
+    nfl = L.pws_netg_packed_floats(31, ngf)
+    full = torch.full((nfl,), float("nan"), device="cuda")
+    A.check(L.pws_netg_pack_weights(ptrs, A.ptr(full), 31, ngf, st), "pack")
+    written = {}
+    for math in (-1, A.MATH_BF16, A.MATH_FP32):
+        buf = torch.full((nfl,), float("nan"), device="cuda")
+        A.check(L.pws_netg_pack_weights_for(ptrs, A.ptr(buf), 31, ngf, math, st), "pack_for")
+        # (bf16 pairs read as fp32 may BE NaN patterns: compare bit patterns against the fill)
+        w = buf.view(torch.int32) != torch.full((1,), float("nan"), device="cuda").view(torch.int32)
+        assert torch.equal(buf.view(torch.int32)[w], full.view(torch.int32)[w]), math
+        written[math] = int(w.sum())
+    full_w = int((full.view(torch.int32) != torch.full((1,), float("nan"), device="cuda").view(torch.int32)).sum())
+    assert written[-1] == full_w
+    assert written[A.MATH_FP32] < full_w    # the bf16 copies are left out
+    assert written[A.MATH_BF16] < full_w    # the Winograd copies of the layers that run on bf16 weights are left out
+    x = torch.from_numpy(synth.make_window(2, 31, 256, seed=3)).cuda()
+    outs = {}
+    with torch.no_grad():
+        for math in ("fp32", "bf16", "fp32"):
+            g.set_math(math)
+            out = net(x, False).clone()
+            assert g._packed_key[0] == math
+            # the same forward on a full pack of the same weights
+            keep_key = g._packed_key
+            A.check(L.pws_netg_pack_weights(ptrs, A.ptr(g._packed), 31, ngf, st), "pack")
+            assert torch.equal(net(x, False), out), math
+            assert g._packed_key == keep_key
+            outs.setdefault(math, out)
+            assert torch.equal(outs[math], out)   # fp32 again after bf16: re-packed, same result
+
+
 def test_inference_with_grad_mode_on_and_errors(hip):
     """The reference's video loop calls netG(images, False) without no_grad (main_new.py:697)."""
     net = make_net("W1", 16)
