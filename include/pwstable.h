@@ -15,10 +15,11 @@
  * part of anybody's capture) and the measurement hooks (pws_prof_*, off by default).
  * What is exercised (tests/test_hip_threads.py, results bit-equal to serial execution): concurrent eager forwards of two generators
  * and of ONE generator from two threads / streams, concurrent replays of graphs, two whole fp32 training steps beside graph replays.
- * NOT bit-reproducible: bf16-math work of one stream beside other GPU work.  While conv_bf16_kernel runs, kernels of other streams --
- * of other PROCESSES too -- that keep many registers live over long gather sequences compute other values in a few lanes (measured
- * with one kernel per stream: profiles/r04_cross_stream_interference.txt; cause not found, not host-side).  One training process per
- * GPU, the deployment this library is built for, never overlaps the two.
+ * NOT bit-reproducible: bf16-math work of one stream beside other GPU work.  While a kernel that leaves room on its CUs executes
+ * v_mfma_f32_32x32x16_bf16 (conv_bf16_kernel above all), kernels of other streams -- of other PROCESSES too -- that keep many registers
+ * live over long gather sequences compute other values in a few lanes (measured down to that one instruction:
+ * profiles/r04_cross_stream_interference.txt; below this library's level, not host-side).  One training process per GPU, the deployment
+ * this library is built for, never overlaps the two.
  * Graph CAPTURE is the caller's: capture after one eager call on the same thread (the library makes its private stream then,
  * not while the capture is open) and while no other host thread issues GPU work -- on ROCm 7.0 captures that overlapped another
  * thread's capture, device-wide synchronisation or training step ended invalidated, crashed inside the runtime, or (1 run in 12)

@@ -175,7 +175,12 @@ struct BfCfg {
 // destination is not 16-byte aligned and for split-K partials).  For that the 64 output channels of a workgroup are dealt to
 // the lanes as (2 l, 2 l + 1) -> (nt 0, nt 1) instead of (l, l + 32): the weight rows are permuted while they are staged
 // (LDS row (nn & 1) * 32 + (nn >> 1) holds output channel nn), the MFMA side is unchanged.  Requires NT == 2.
-template <class C, bool IO16>
+// ABL (interference probe, tools/probes/kernel_victim_probe.py; PWS_OPT_EXPERIMENT 2100 + ABL, one tile shape only): while this kernel
+// runs, kernels of OTHER streams and processes that share its CUs compute wrong values in a few lanes.  Variants to find out what in it does that:
+// 1 no matrix instructions, 2 no LDS operand reads, 4 no LDS stores, 8 no global loads (results meaningless), 16 the gfx90a instruction
+// v_mfma_f32_32x32x8_bf16_1k twice in place of v_mfma_f32_32x32x16_bf16 (same results up to the summation order).  Measured: 1 -> clean; 14 (the x16
+// matrix instructions and nothing else) -> as bad as the complete kernel; 16 and 30 -> clean, at +29 % of the launch time on the 128 -> 128 @128^2 layer.
+template <class C, bool IO16, int ABL = 0>
 __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_kernel(const ConvKParams p) {
     static_assert(!IO16 || (C::NT == 2 && C::WN == 1), "bf16 storage pairs the two 32-channel blocks of a wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -293,14 +298,20 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_kernel(const ConvKPar
     const int ch_end = min(total_chunks, ch_begin + p.chunks_per_split);
     int s = 0, c0 = ch_begin * C::CK, wrow = ch_begin * C::CK;
     while (s < p.nsrc - 1 && c0 >= p.src_c[s]) c0 -= p.src_c[s], ++s;
-    if (ch_begin < ch_end) load_chunk(s, c0, wrow);
+    if constexpr (ABL & 8) {
+#pragma unroll
+        for (int it = 0; it < C::ITEMS_W; ++it) r_w[it] = u32x4{1u, 2u, 3u, 4u};
+#pragma unroll
+        for (int it = 0; it < (IO16 ? C::ITEMS_IN : 1); ++it) r_in16[it] = u32x4{5u, 6u, 7u, 8u};
+    }
+    if (ch_begin < ch_end && !(ABL & 8)) load_chunk(s, c0, wrow);
     for (int ch = ch_begin; ch < ch_end; ++ch) {
         __syncthreads();  // everyone finished reading the previous chunk from LDS
-        store_chunk();
+        if (!(ABL & 4)) store_chunk();
         __syncthreads();
         c0 += C::CK, wrow += C::CK;
         if (c0 >= p.src_c[s]) ++s, c0 = 0;
-        if (ch + 1 < ch_end) load_chunk(s, c0, wrow);
+        if (ch + 1 < ch_end && !(ABL & 8)) load_chunk(s, c0, wrow);
 
 #pragma unroll
         for (int tap = 0; tap < C::TAPS; ++tap) {
@@ -310,15 +321,28 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_kernel(const ConvKPar
             for (int ks = 0; ks < C::CK / 16; ++ks) {
                 bf16x8 a[C::MT], b[C::NT];
 #pragma unroll
-                for (int mt = 0; mt < C::MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8 *>(lds_in + a_base[mt] + toff + ks * 32);
+                for (int mt = 0; mt < C::MT; ++mt) {
+                    if (ABL & 2) a[mt] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)(tap + ch), 1u, 2u, (unsigned)lane});
+                    else a[mt] = *reinterpret_cast<const bf16x8 *>(lds_in + a_base[mt] + toff + ks * 32);
+                }
 #pragma unroll
-                for (int nt = 0; nt < C::NT; ++nt)
-                    b[nt] = *reinterpret_cast<const bf16x8 *>(lds_w + b_base + (tap * C::BN + nt * 32) * C::PITCH + ks * 32);
+                for (int nt = 0; nt < C::NT; ++nt) {
+                    if (ABL & 2) b[nt] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)(tap + ch), 3u, 4u, (unsigned)lane});
+                    else b[nt] = *reinterpret_cast<const bf16x8 *>(lds_w + b_base + (tap * C::BN + nt * 32) * C::PITCH + ks * 32);
+                }
 #pragma unroll
                 for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < C::NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < C::NT; ++nt) {
+                        if (ABL & 1) acc[mt][nt][0] += (float)a[mt][0] * (float)b[nt][1];
+                        else if (ABL & 16) {   // the gfx90a instruction, twice: k {0..3, 8..11} then {4..7, 12..15} (a lane's 8 values = its k half)
+                            typedef short s16x4_ __attribute__((ext_vector_type(4)));
+                            typedef short s16x8_ __attribute__((ext_vector_type(8)));
+                            const s16x8_ av = __builtin_bit_cast(s16x8_, a[mt]), bv = __builtin_bit_cast(s16x8_, b[nt]);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_shufflevector(av, av, 0, 1, 2, 3), __builtin_shufflevector(bv, bv, 0, 1, 2, 3), acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_shufflevector(av, av, 4, 5, 6, 7), __builtin_shufflevector(bv, bv, 4, 5, 6, 7), acc[mt][nt], 0, 0, 0);
+                        } else acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                    }
             }
         }
     }
@@ -576,6 +600,13 @@ static int launch_bf_io(ConvKParams &kp, hipStream_t st) {
         attr_set = true;
     }
     const dim3 grid = conv_grid(kp, C::BN);
+    if constexpr (IO16 && C::KS == 3 && C::TH == 16 && C::TW == 16 && C::STRIDE == 1 && C::SUBPIX == 0) {   // the probe variants of this one tile (see conv_bf16_kernel)
+        switch (g_experiment) {
+#define PWS_BF_ABL_CASE(k) case 2100 + k: (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_kernel<C, IO16, k>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES); hipLaunchKernelGGL((conv_bf16_kernel<C, IO16, k>), grid, dim3(C::THREADS), C::LDS_BYTES, st, kp); return check_launch("conv_bf16_kernel");
+            PWS_BF_ABL_CASE(1) PWS_BF_ABL_CASE(14) PWS_BF_ABL_CASE(16) PWS_BF_ABL_CASE(30)
+        default: break;
+        }
+    }
     hipLaunchKernelGGL((conv_bf16_kernel<C, IO16>), grid, dim3(C::THREADS), C::LDS_BYTES, st, kp);
     return check_launch("conv_bf16_kernel");
 }

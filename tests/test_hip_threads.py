@@ -162,10 +162,11 @@ def test_train_step_beside_inference_and_another_train_step(hip, math):
             for i, (a, b) in enumerate(zip(got[t][2], serial[t][2])):
                 assert torch.equal(a, b), ("weight", t, i)
         else:
-            # bf16: NOT bit for bit.  While conv_bf16_kernel of one thread runs, a few lanes of kernels of OTHER streams (even of other
-            # processes) that hold many registers over long gather sequences -- the objective's backward here -- compute other values, in
-            # 1 run of 10 of this test (profiles/r04_cross_stream_interference.txt, tools/probes/kernel_victim_probe.py: reproduced with ONE
-            # kernel per stream and with the two in separate processes; cause not found, not in this library's host code).  What a host-side
+            # bf16: NOT bit for bit.  While conv_bf16_kernel of one thread executes v_mfma_f32_32x32x16_bf16, a few lanes of kernels of OTHER
+            # streams (even of other processes) that hold many registers over long gather sequences -- the objective's backward here --
+            # compute other values, in 1 run of 10 of this test (profiles/r04_cross_stream_interference.txt, tools/probes/kernel_victim_probe.py:
+            # reproduced with ONE kernel per stream, with the two in separate processes, and down to that one instruction; below this
+            # library's level, not in its host code).  What a host-side
             # mix-up -- another thread's stream, arena, event or weights -- would give is garbage, so the check that remains is: the
             # objective's terms to 1e-3, all gradients together and all updated weights together to a cosine of 0.9999.
             assert torch.allclose(got[t][0], serial[t][0], rtol=1e-3, atol=1e-6), (got[t][0], serial[t][0])
