@@ -18,8 +18,10 @@
  * NOT bit-reproducible: bf16-math work of one stream beside other GPU work.  While a kernel that leaves room on its CUs executes
  * v_mfma_f32_32x32x16_bf16 (conv_bf16_kernel above all), kernels of other streams -- of other PROCESSES too -- that keep many registers
  * live over long gather sequences compute other values in a few lanes (measured down to that one instruction:
- * profiles/r04_cross_stream_interference.txt; below this library's level, not host-side).  One training process per GPU, the deployment
- * this library is built for, never overlaps the two.
+ * profiles/r04_cross_stream_interference.txt; below this library's level, not host-side).  The effect is local to a compute unit: tenants
+ * whose streams own DISJOINT CUs (hipExtStreamCreateWithCUMask; the generator on one queue, pws_netg_opts.two_queues = 0, since the side
+ * queue is not masked) are bit-reproducible again -- 0 of 150 three-thread rounds against 1 in 10.  One training process per GPU, the
+ * deployment this library is built for, never overlaps the two kinds of kernel in the first place.
  * Graph CAPTURE is the caller's: capture after one eager call on the same thread (the library makes its private stream then,
  * not while the capture is open) and while no other host thread issues GPU work -- on ROCm 7.0 captures that overlapped another
  * thread's capture, device-wide synchronisation or training step ended invalidated, crashed inside the runtime, or (1 run in 12)

@@ -206,6 +206,42 @@ def current_stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def cu_masked_streams(shares, device=None):
+    """torch streams that may only use DISJOINT sets of the device's compute units: ``shares`` = CUs per stream, dealt in order
+    (``hipExtStreamCreateWithCUMask``).  For work of several tenants on one GPU: while a kernel that leaves room on its CUs executes
+    ``v_mfma_f32_32x32x16_bf16`` (the first-generation bf16 kernels of this library), kernels of OTHER streams on the SAME CUs compute
+    other values in a few lanes; on disjoint CUs they do not (tools/probes/kernel_victim_probe.py PROBE_CU_MASK).
+    A generator run on such a stream should keep to it: ``net.module.two_queues = False`` (the side queue is not masked).
+    The streams live until the process ends (torch.cuda.ExternalStream does not own them), and every one of them takes a hardware queue
+    of its own: the same ``shares`` give the same streams again (a few hundred of them made in a loop crashed the runtime)."""
+    import torch
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    key = (dev, tuple(int(n) for n in shares))
+    if key in _cu_streams:
+        return list(_cu_streams[key])
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    if sum(shares) > ncu or min(shares) < 1:
+        raise ValueError("cu_masked_streams: %r does not fit %d compute units" % (list(shares), ncu))
+    hip = ctypes.CDLL("libamdhip64.so")
+    words = (ncu + 31) // 32
+    out, first = [], 0
+    with torch.cuda.device(dev):
+        for n in shares:
+            bits = ((1 << n) - 1) << first
+            mask = (ctypes.c_uint32 * words)(*[(bits >> (32 * w)) & 0xffffffff for w in range(words)])
+            st = ctypes.c_void_p()
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
+            if rc != 0 or not st.value:
+                raise RuntimeError("hipExtStreamCreateWithCUMask failed (rc=%d)" % rc)
+            out.append(torch.cuda.ExternalStream(st.value, device=dev))
+            first += n
+    _cu_streams[key] = tuple(out)
+    return out
+
+
+_cu_streams = {}
+
+
 def require_cuda(*tensors, dtype=None):
     """The hot path runs on the GPU only; refuse anything else loudly.  dtype: expected dtype (default torch.float32)."""
     import torch

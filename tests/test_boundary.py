@@ -123,7 +123,8 @@ def test_torch_ref_matches_reference_golden(netg_golden):
         grids, resid = torch_ref.netg_forward(params, x, True)
         g_inf = torch_ref.netg_forward(params, x, False)
     assert torch.equal(g_inf, grids[2])
-    np.testing.assert_allclose(g_inf.numpy(), netg_golden["W2_g16_grid2_full"], rtol=0, atol=1e-6)
+    # (1e-5: the goldens were made in the build container; another host CPU's oneDNN sums in another order -- 1.7e-6 on an EPYC 9575F)
+    np.testing.assert_allclose(g_inf.numpy(), netg_golden["W2_g16_grid2_full"], rtol=0, atol=1e-5)
 
 
 def test_no_kernel_spills_to_scratch():

@@ -35,6 +35,23 @@ scale = torch.ones(1, device="cuda")
 stop, started = threading.Event(), threading.Event()
 
 
+def masked_stream(which):
+    """PROBE_CU_MASK=1: victim and aggressor on DISJOINT halves of the chip's CUs (hipExtStreamCreateWithCUMask): is the effect local to a CU?
+    PROBE_CU_MASK=2: both on the SAME half (control)."""
+    mode = os.environ.get("PROBE_CU_MASK")
+    if not mode:
+        return torch.cuda.Stream()
+    hip = ctypes.CDLL("libamdhip64.so")
+    words = 8   # 256 CUs
+    lo = (ctypes.c_uint32 * words)(*([0xffffffff] * 4 + [0] * 4))
+    hi = (ctypes.c_uint32 * words)(*([0] * 4 + [0xffffffff] * 4))
+    mask = lo if (which == "victim" or mode == "2") else hi
+    st = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
+    assert rc == 0 and st.value, rc
+    return torch.cuda.ExternalStream(st.value)
+
+
 def cand_warp(st):
     gg = torch.empty_like(grid)
     A.check(L.pws_warp_norm_bwd(A.ptr(rgb), 3 * h * w, A.ptr(grid), A.ptr(stable), 3 * h * w, 1e-6, A.ptr(scale), A.ptr(gextra0), A.ptr(gg), 0, m, h, w, st), "w")
@@ -97,7 +114,7 @@ CLEAN = {}
 
 def victim():
     torch.cuda.set_device(0)
-    s = torch.cuda.Stream()
+    s = masked_stream("victim")
     with torch.cuda.stream(s):
         s.wait_stream(torch.cuda.default_stream())
         if os.environ.get("PROBE_DETAIL") == "1":
@@ -141,7 +158,7 @@ def victim():
 
 def aggressor():
     torch.cuda.set_device(0)
-    s = torch.cuda.Stream()
+    s = masked_stream("aggressor")
     if amath.startswith("gemm"):   # NOT this library: torch matmuls (hipBLASLt / rocBLAS) in bf16 or fp32, back to back
         dt = torch.bfloat16 if amath == "gemm_bf16" else torch.float32
         with torch.cuda.stream(s):

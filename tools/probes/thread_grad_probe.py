@@ -93,7 +93,8 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 math = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 variant = sys.argv[3] if len(sys.argv) > 3 else "all"
 A.lib().pws_set_option(100, int(os.environ.get("PWS_EXPERIMENT", "0")))
-works = [T._train_work("W1", 11, math, 2), T._train_work("W2", 12, math, 2)]
+_tq = False if os.environ.get("PROBE_CU_MASK") == "1" else None
+works = [T._train_work("W1", 11, math, 2, two_queues=_tq), T._train_work("W2", 12, math, 2, two_queues=_tq)]
 infer_net = T.make_net("W1", 5)
 x = [torch.from_numpy(synth.noise_window(2, 31, 256, seed=33 + r)).cuda() for r in range(2)]
 infer = T._infer_work(infer_net, x, 8)
@@ -135,7 +136,10 @@ for r in range(rounds):
         return None
     third = {"all": infer, "dummy": dummy_gpu, "copy": dummy_copy, "host": dummy_host}.get(variant)
     fns = works + [third] if third is not None else (works if variant == "noinfer" else [works[1], infer])
-    got = T._in_threads(fns)
+    streams = None
+    if os.environ.get("PROBE_CU_MASK") == "1":   # every thread on its own share of the compute units (and one queue per call: see below)
+        streams = A.cu_masked_streams([96, 96, 64][:len(fns)])
+    got = T._in_threads(fns, streams=streams)
     torch.cuda.synchronize()
     idx = [0, 1] if variant != "one" else [1]
     for j, t in enumerate(idx):
