@@ -9,7 +9,8 @@
 // phase ahead of their use (hipcc's vmcnt(0) at the register hand-off drains any deeper prefetch), and every 256-pixel tile pays
 // its own prologue (first-chunk latency) and epilogue (store burst) with nothing else to run on the CU but one more workgroup in
 // the same state.  Here:
-//   * a workgroup (8 waves, one per CU) walks a contiguous range of (tile, 64-channel block, parity class) units; the K groups
+//   * a workgroup (one per CU: 8 matrix waves -- 4 TALL ones on 32-wide tiles since round 4, RgCfg::MT -- plus 4 loader waves) walks a contiguous range of
+//     (tile, 64-channel block, parity class) units; the K groups
 //     of consecutive units form ONE stream, so the DMAs of the next unit's first groups are in flight under the last matrix
 //     phases and the epilogue stores of the current unit -- no per-tile prologue, and the store burst overlaps loads;
 //   * a K group = 32 input channels, staged as [pixel][32 ch] rows of 64 bytes (+ the weight rows of the same 32 channels): a
