@@ -98,6 +98,20 @@ def cand_feature(st):
     return gg
 
 
+from pwstablenet_amd import functional as PF  # noqa: E402
+frames256 = torch.rand(8, 3, 256, 256, device="cuda", generator=g) * 2 - 1
+grid8 = (base[None] + 0.05 * torch.randn(8, h, w, 2, device="cuda", generator=g)).contiguous()
+frames720 = torch.randint(0, 256, (4, 720, 1280, 3), device="cuda", dtype=torch.uint8, generator=g)
+
+
+def cand_grid_sample(st):   # the inference output: F.grid_sample of 256 x 256 frames
+    return PF.grid_sample(frames256, grid8)
+
+
+def cand_warp720_u8(st):    # ... and the fused 720p uint8 warp of the video loop
+    return PF.upsample_grid_sample_u8(frames720, grid8[:4])
+
+
 def cand_clone(st):
     return (grid.clone() * 1.5).contiguous()
 
@@ -142,7 +156,8 @@ def victim():
         started.wait(120)
         for name, fn in (("warp_norm_bwd", cand_warp), ("warp_norm_bwd, scale NULL", cand_warp_noscale), ("warp_norm_bwd, scale in 4 MB", cand_warp_bigscale),
                          ("warp_norm_bwd, no gextra", cand_warp_noextra), ("warp_norm_bwd, no target", cand_warp_notarget), ("temporal_l1_bwd_det", cand_temporal), ("feature_loss_bwd_det", cand_feature),
-                         ("warp_norm_fwd + slots", cand_warp_fwd), ("torch clone * 1.5", cand_clone)):
+                         ("warp_norm_fwd + slots", cand_warp_fwd), ("grid_sample 256^2 (inference output)", cand_grid_sample),
+                         ("upsample_grid_sample_u8 720p", cand_warp720_u8), ("torch clone * 1.5", cand_clone)):
             ref = fn(A.current_stream()).clone()
             s.synchronize()
             t_end, it, bad, worst = time.perf_counter() + secs, 0, 0, 0
@@ -152,7 +167,7 @@ def victim():
                     bad += 1
                     worst = max(worst, int((cur != ref).sum()))
                 it += 1
-            print("%-30s %5d of %6d launches differ from the first (at most %d elements)" % (name, bad, it, worst), flush=True)
+            print("%-38s %5d of %6d launches differ from the first (at most %d elements)" % (name, bad, it, worst), flush=True)
     stop.set()
 
 
