@@ -180,6 +180,7 @@ struct BfCfg {
 // 1 no matrix instructions, 2 no LDS operand reads, 4 no LDS stores, 8 no global loads (results meaningless), 16 the gfx90a instruction
 // v_mfma_f32_32x32x8_bf16_1k twice in place of v_mfma_f32_32x32x16_bf16 (same results up to the summation order).  Measured: 1 -> clean; 14 (the x16
 // matrix instructions and nothing else) -> as bad as the complete kernel; 16 and 30 -> clean, at +29 % of the launch time on the 128 -> 128 @128^2 layer.
+// 32: four v_mfma_f32_16x16x32_bf16 (the other gfx950 bf16 shape; results meaningless) per product: as bad as the complete kernel -- but 46 (those and nothing else) clean.
 template <class C, bool IO16, int ABL = 0>
 __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_kernel(const ConvKParams p) {
     static_assert(!IO16 || (C::NT == 2 && C::WN == 1), "bf16 storage pairs the two 32-channel blocks of a wave");
@@ -334,7 +335,15 @@ __global__ void __launch_bounds__(C::THREADS, 2) conv_bf16_kernel(const ConvKPar
                 for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < C::NT; ++nt) {
-                        if (ABL & 1) acc[mt][nt][0] += (float)a[mt][0] * (float)b[nt][1];
+                        if (ABL & 32) {   // PROBE ONLY (results meaningless): the other gfx950 bf16 shape, v_mfma_f32_16x16x32_bf16, four per 32 x 32 x 16 product
+                            typedef float f32x4_ __attribute__((ext_vector_type(4)));
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; ++q4) {
+                                f32x4_ c4 = {acc[mt][nt][4 * q4], acc[mt][nt][4 * q4 + 1], acc[mt][nt][4 * q4 + 2], acc[mt][nt][4 * q4 + 3]};
+                                c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[nt], c4, 0, 0, 0);
+                                acc[mt][nt][4 * q4] = c4[0], acc[mt][nt][4 * q4 + 1] = c4[1], acc[mt][nt][4 * q4 + 2] = c4[2], acc[mt][nt][4 * q4 + 3] = c4[3];
+                            }
+                        } else if (ABL & 1) acc[mt][nt][0] += (float)a[mt][0] * (float)b[nt][1];
                         else if (ABL & 16) {   // the gfx90a instruction, twice: k {0..3, 8..11} then {4..7, 12..15} (a lane's 8 values = its k half)
                             typedef short s16x4_ __attribute__((ext_vector_type(4)));
                             typedef short s16x8_ __attribute__((ext_vector_type(8)));
@@ -603,7 +612,7 @@ static int launch_bf_io(ConvKParams &kp, hipStream_t st) {
     if constexpr (IO16 && C::KS == 3 && C::TH == 16 && C::TW == 16 && C::STRIDE == 1 && C::SUBPIX == 0) {   // the probe variants of this one tile (see conv_bf16_kernel)
         switch (g_experiment) {
 #define PWS_BF_ABL_CASE(k) case 2100 + k: (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_kernel<C, IO16, k>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES); hipLaunchKernelGGL((conv_bf16_kernel<C, IO16, k>), grid, dim3(C::THREADS), C::LDS_BYTES, st, kp); return check_launch("conv_bf16_kernel");
-            PWS_BF_ABL_CASE(1) PWS_BF_ABL_CASE(14) PWS_BF_ABL_CASE(16) PWS_BF_ABL_CASE(30)
+            PWS_BF_ABL_CASE(1) PWS_BF_ABL_CASE(14) PWS_BF_ABL_CASE(16) PWS_BF_ABL_CASE(30) PWS_BF_ABL_CASE(32) PWS_BF_ABL_CASE(46)
         default: break;
         }
     }
