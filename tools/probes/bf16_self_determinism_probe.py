@@ -25,7 +25,12 @@ for ngf, n in ((32, 4), (64, 8)):
             ref = net(x, False).clone()
             bad = sum(0 if torch.equal(net(x, False), ref) else 1 for _ in range(iters))
         print("bf16 forward ngf %d batch %d, two queues %s: %d of %d runs differ from the first" % (ngf, n, tq, bad, iters))
-work = T._train_work("W2", 12, "bf16", 2)
+if os.environ.get("PROBE_FULL") == "1":   # BASELINE configs[2] scale: ngf 64, 32 item pairs (the two queues overlap chip-filling launches)
+    _mk = T.make_net
+    T.make_net = lambda kind, seed, ngf=64: _mk(kind, seed, ngf)
+    work = T._train_work("W2", 12, "bf16", 32)
+else:
+    work = T._train_work("W2", 12, "bf16", 2)
 ref = work()
 bad = 0
 for _ in range(max(10, iters // 10)):
