@@ -164,6 +164,29 @@ def test_feature_and_smoothness_vs_reference_functions(hip, ref):
     s = slots.sum(1).cpu().numpy()
     np.testing.assert_allclose(s[0] / (nf * m), feat.item(), rtol=1e-5)
     np.testing.assert_allclose((s[1] / (m * 256 * 255 * 2) + s[2] / (m * 255 * 256 * 2)) / 2, delta.item(), rtol=1e-5)
+    # (round 4) four pixels per lane (field_smoothness4_kernel); PWS_OPT_EXPERIMENT 110 = the one-pixel kernel: the same sums up to the fp32 partial sums
+    # of a lane's eight terms; a field whose width is not a multiple of 4 takes the one-pixel kernel by itself
+    L.pws_set_option(100, 110)
+    try:
+        slots1 = _slots("cuda", 3)
+        q1 = [ctypes.c_void_p(slots1.data_ptr() + k * 64 * 8) for k in range(3)]
+        hip.check(L.pws_field_smoothness(hip.ptr(g), q1[1], q1[2], m, 256, 256, st()), "smooth1")
+    finally:
+        L.pws_set_option(100, 0)
+    s1 = slots1.sum(1).cpu().numpy()
+    np.testing.assert_allclose(s[1:3], s1[1:3], rtol=1e-7)
+    g_odd = g[:, :250, :254].contiguous()   # 254 columns
+    want_dx = float((g_odd[:, :, 1:] - g_odd[:, :, :-1]).abs().double().sum()), float((g_odd[:, 1:] - g_odd[:, :-1]).abs().double().sum())
+    slots2 = _slots("cuda", 3)
+    q2 = [ctypes.c_void_p(slots2.data_ptr() + k * 64 * 8) for k in range(3)]
+    hip.check(L.pws_field_smoothness(hip.ptr(g_odd), q2[1], q2[2], m, 250, 254, st()), "smooth odd")
+    np.testing.assert_allclose(slots2.sum(1).cpu().numpy()[1:3], want_dx, rtol=1e-6)
+    g4 = g[:, :250, :252].contiguous()      # 252 columns: the four-pixel kernel on rows that are not a power of two
+    want4 = float((g4[:, :, 1:] - g4[:, :, :-1]).abs().double().sum()), float((g4[:, 1:] - g4[:, :-1]).abs().double().sum())
+    slots3 = _slots("cuda", 3)
+    q3 = [ctypes.c_void_p(slots3.data_ptr() + k * 64 * 8) for k in range(3)]
+    hip.check(L.pws_field_smoothness(hip.ptr(g4), q3[1], q3[2], m, 250, 252, st()), "smooth 252")
+    np.testing.assert_allclose(slots3.sum(1).cpu().numpy()[1:3], want4, rtol=1e-6)
     gg = torch.zeros_like(g)
     hip.check(L.pws_feature_loss_bwd(hip.ptr(g), hip.ptr(f), 1.0 / (nf * m), None, hip.ptr(gg), m, nf, 256, 256, st()), "featb")
     np.testing.assert_allclose(gg.cpu().numpy(), gridr.grad.numpy(), atol=1e-8)

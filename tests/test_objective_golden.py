@@ -62,8 +62,10 @@ def test_loss_calculate_values_and_gradients(og, ref):
     np.testing.assert_allclose([mse.item(), delta.item(), feat.item()], og["lc_values"], rtol=2e-6)
     np.testing.assert_allclose(fake.detach().numpy()[:, :, ::8, ::8], og["lc_fake_sub"], atol=1e-6)
     np.testing.assert_allclose(grid.grad.numpy()[:, ::8, ::8], og["lc_ggrid_sub"], atol=1e-7)
-    np.testing.assert_allclose(_csum(grid.grad.numpy()), og["lc_ggrid_csum"], rtol=1e-5)
-    np.testing.assert_allclose(_csum(fake.grad.numpy()), og["lc_gfake_csum"], rtol=1e-5)
+    # (the checksums add signed values of an L1 term's gradient: one pixel whose |difference| is at rounding level flips its sign with the host CPU's
+    #  summation order -- 2e-5 absolute on an EPYC 9575F against the goldens made in the build container; the sub-sampled values above stay at 1e-7)
+    np.testing.assert_allclose(_csum(grid.grad.numpy()), og["lc_ggrid_csum"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(_csum(fake.grad.numpy()), og["lc_gfake_csum"], rtol=1e-5, atol=1e-4)
 
 
 def test_shape_basis_and_loss(og, ref):
