@@ -227,7 +227,47 @@ def cpu_baseline(timed=None):
     return res
 
 
-def configs2_step_leg(net, dev, n_items, math, reps, sync=None, seed=500, perceptual=None, per_rep=None):
+def sample_clock_and_power(run_once, seconds=1.5):
+    """Engine clock (MHz) and socket power (W) from rocm-smi while ``run_once`` is repeated for ``seconds`` -- OUTSIDE any timed region.
+    The bf16 matrix kernels pull the chip to its power cap (1.4 kW on MI355X): the dense peak that applies inside them is the spec peak
+    times clock / 2400 (tools/clock_probe.sh).  Returns {} when rocm-smi is not there or says nothing."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    if shutil.which("rocm-smi") is None:
+        return {}
+    stop, samples = threading.Event(), []
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                o = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=5).stdout
+            except Exception:
+                return
+            c = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", o)
+            pw = re.search(r"Power \(W\): ([0-9.]+)", o)
+            if c and pw:
+                samples.append((int(c.group(1)), float(pw.group(1))))
+            time.sleep(0.15)
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    import torch
+    t_end = time.perf_counter() + seconds
+    while time.perf_counter() < t_end:
+        run_once()
+        torch.cuda.synchronize()
+    stop.set()
+    th.join(6)
+    samples = samples[1:] if len(samples) > 2 else samples   # the first sample may predate the load
+    if not samples:
+        return {}
+    clk = sorted(c for c, _ in samples)[len(samples) // 2]
+    pw = sorted(p_ for _, p_ in samples)[len(samples) // 2]
+    return {"sclk_mhz_median": clk, "socket_power_w_median": round(pw), "samples": len(samples)}
+
+
+def configs2_step_leg(net, dev, n_items, math, reps, sync=None, seed=500, perceptual=None, per_rep=None, clock=None):
     """BASELINE configs[2] / [3] step, per GPU: n_items item pairs -> 2*n_items generator forwards (is_training), 6 fused
     warp+L1 launches, temporal / feature / smoothness / fp64 shape terms, backward through all of it, [gradient
     all-reduce,] fused Adam (reference main_new.py:84-216 without GAN and without the VGG term, which needs torchvision
@@ -256,6 +296,11 @@ def configs2_step_leg(net, dev, n_items, math, reps, sync=None, seed=500, percep
     dt = (time.perf_counter() - t0) / reps
     loss = float(out.loss_g.detach())
     assert loss == loss and abs(loss) != float("inf"), loss
+    if clock is not None:   # after the timed steps: what clock / power the chip holds under this step
+        try:
+            clock.update(sample_clock_and_power(lambda: train_step(net, opt, batch, obj, sync_gradients=sync, perceptual=perceptual)))
+        except Exception as e:  # never at the cost of the leg
+            clock["error"] = str(e)[:120]
     del opt, batch
     net.zero_grad(set_to_none=True)
     return dt, loss
@@ -321,13 +366,19 @@ def bf16_legs(net, x, frames, out_fp32, a, PF, A, synth):
         del opt
     # configs[2] itself: batch=32 ITEM PAIRS per step = 64 generator forwards + the objective, bf16 math
     try:
-        dt, loss = configs2_step_leg(net, x.device, 32, "bf16", 3)
+        clk = {}
+        dt, loss = configs2_step_leg(net, x.device, 32, "bf16", 3, clock=clk)
         train["configs2_bf16_batch32"] = {
             "workload": "configs[2]: 32 item pairs per step = 64 netG forwards (is_training) + fused warp/L1 x6, temporal, feature, "
                         "smoothness, fp64 shape terms + backward + fused Adam (train() of main_new.py:84-216, no GAN, no VGG term)",
             "items_per_s": round(32 / dt, 1), "forwards_per_s": round(64 / dt, 1), "ms_per_step": round(1e3 * dt, 2),
             "tflops": round(64 / dt * GFLOP_PER_SAMPLE_TRAIN / 1e3, 1),
             "frac_bf16_peak": round(64 / dt * GFLOP_PER_SAMPLE_TRAIN / 1e3 / PEAK_BF16_TFLOPS, 4), "loss_g": round(loss, 4)}
+        if clk.get("sclk_mhz_median"):
+            # the step runs at the socket's power cap: the peak the matrix cores can reach at the clock the chip holds (spec peak x clock / 2400 MHz)
+            c2 = train["configs2_bf16_batch32"]
+            c2["under_this_step"] = clk
+            c2["frac_bf16_peak_at_held_clock"] = round(c2["frac_bf16_peak"] * 2400.0 / clk["sclk_mhz_median"], 4)
     except Exception as e:  # an extra leg must never cost the headline line
         train["configs2_bf16_batch32"] = {"error": str(e)[:200]}
     # the same step with the VGG-16 perceptual term of train() (main_new.py:191-192) on top: 4 x 64 VGG forwards (3 stages of
