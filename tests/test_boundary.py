@@ -127,6 +127,28 @@ def test_torch_ref_matches_reference_golden(netg_golden):
     np.testing.assert_allclose(g_inf.numpy(), netg_golden["W2_g16_grid2_full"], rtol=0, atol=1e-5)
 
 
+def test_no_tracked_binaries_in_the_package():
+    """History stays source-only: no tracked file under pwstablenet_amd/ (or anywhere else but the .npz fixtures) is an ELF
+    object, an offload bundle or an extracted code object (44 of those once slipped past the *.so rule)."""
+    try:
+        tracked = subprocess.check_output(["git", "ls-files"], cwd=ROOT, stderr=subprocess.DEVNULL).decode().split("\n")
+    except (subprocess.CalledProcessError, FileNotFoundError):
+        pytest.skip("not a git checkout")
+    bad = []
+    for rel in filter(None, tracked):
+        p = os.path.join(ROOT, rel)
+        if not os.path.isfile(p):
+            continue
+        if "hipv4" in rel or ".host-x86_64" in rel or re.search(r"\.(so|o|a|hsaco|co)(\.\d+)*$", rel):
+            bad.append(rel)
+            continue
+        with open(p, "rb") as fh:
+            head = fh.read(24)
+        if head[:4] == b"\x7fELF" or head.startswith(b"__CLANG_OFFLOAD_BUNDLE__"):
+            bad.append(rel)
+    assert not bad, bad
+
+
 def test_no_kernel_spills_to_scratch():
     """hipcc's per-kernel resource report (written by pwstablenet_amd.build): accumulators or prefetch registers that end
     up in scratch make a kernel several times slower without failing any numerical test (seen once: a by-reference
