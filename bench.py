@@ -168,6 +168,41 @@ def usable_cores():
     return n
 
 
+def cpu_provenance():
+    """Why `cores` is what it is, so that the baseline compares across boxes: logical CPUs of the host, the affinity mask this process
+    was given, the cgroup CPU quota (v2 cpu.max / v1 cfs quota) in CPUs, what limits, and the load average when the baseline started."""
+    out = {"logical_cpus": os.cpu_count()}
+    try:
+        out["affinity_mask_cpus"] = len(os.sched_getaffinity(0))
+    except Exception:
+        out["affinity_mask_cpus"] = None
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        quota = None if q == "max" else round(int(q) / int(per), 2)
+        out["cgroup"] = "v2 cpu.max = %s %s" % (q, per)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            quota = None if q <= 0 else round(q / per, 2)
+            out["cgroup"] = "v1 cfs_quota_us / cfs_period_us = %d / %d" % (q, per)
+        except Exception:
+            out["cgroup"] = "no cpu controller visible"
+    out["cgroup_quota_cpus"] = quota
+    aff = out["affinity_mask_cpus"] or out["logical_cpus"] or 1
+    out["limited_by"] = ("cgroup quota" if quota is not None and quota < aff else
+                         "affinity mask" if aff < (out["logical_cpus"] or aff) else "nothing (all logical CPUs)")
+    try:
+        out["loadavg_1m"] = round(os.getloadavg()[0], 2)
+    except Exception:
+        pass
+    return out
+
+
 def cpu_baseline(timed=None):
     """Hot path on the host cores: netG(window, False) + grid_sample, N=1, min over a bounded number of runs.
     timed = (x, frames, field, warped) as CPU tensors: the inputs of the TIMED region (batch 8) and what its launch path --
@@ -175,6 +210,7 @@ def cpu_baseline(timed=None):
     import torch
     from oracle import torch_ref
     from pwstablenet_amd import synth
+    prov = cpu_provenance()
     cores = min(usable_cores(), 64)  # oneDNN convs of one 256x256 frame stop scaling long before 64 threads
     torch.set_num_threads(cores)
     params = [torch.from_numpy(v) for _, v in synth.make_weights("W1", seed=123, ngf=64)]
@@ -188,6 +224,7 @@ def cpu_baseline(timed=None):
         best = min(best, time.time() - t0)
         runs += 1
     res = {"value": round(1.0 / best, 3), "unit": "frames/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
+           "provenance": dict(prov, torch_num_threads=torch.get_num_threads(), torch_num_interop_threads=torch.get_num_interop_threads()),
            "sample": "N=1 frame: PyTorch-CPU restatement of netG(x,False)+grid_sample (oracle/torch_ref.py), "
                      "min of %d runs after 1 warm-up, %d torch threads" % (runs, torch.get_num_threads()),
            # the reference's own Python cannot travel to this box: its numbers measured in the build container
@@ -267,7 +304,7 @@ def sample_clock_and_power(run_once, seconds=1.5):
     return {"sclk_mhz_median": clk, "socket_power_w_median": round(pw), "samples": len(samples)}
 
 
-def configs2_step_leg(net, dev, n_items, math, reps, sync=None, seed=500, perceptual=None, per_rep=None, clock=None):
+def configs2_step_leg(net, dev, n_items, math, reps, sync=None, seed=500, perceptual=None, per_rep=None, clock=None, warmup=1):
     """BASELINE configs[2] / [3] step, per GPU: n_items item pairs -> 2*n_items generator forwards (is_training), 6 fused
     warp+L1 launches, temporal / feature / smoothness / fp64 shape terms, backward through all of it, [gradient
     all-reduce,] fused Adam (reference main_new.py:84-216 without GAN and without the VGG term, which needs torchvision
@@ -283,7 +320,8 @@ def configs2_step_leg(net, dev, n_items, math, reps, sync=None, seed=500, percep
     batch = [torch.from_numpy(t).repeat((rep,) + (1,) * (t.ndim - 1))[:n_items].to(dev) for t in small]
     obj = StabObjective(batchSize=n_items)
     opt = Adam(net.parameters(), lr=1e-6, betas=(0.5, 0.999))
-    out = train_step(net, opt, batch, obj, sync_gradients=sync, perceptual=perceptual)   # warm-up (allocations, weight re-pack)
+    for _ in range(max(1, warmup)):   # warm-up (allocations, weight re-pack; at the power cap the first steps run at a higher clock)
+        out = train_step(net, opt, batch, obj, sync_gradients=sync, perceptual=perceptual)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -946,6 +984,7 @@ def main():
             dist.barrier()
             NI = a.ddp_items
             grad_bytes = 4 * A.lib().pws_netg_grad_floats(31, 64)
+            DDP_REPS, DDP_WARMUP = 10, 3   # per mode: the driver's one 8-GPU run is this leg's only measurement
 
             def timed(nparts):
                 # the exchange lives in the generator's backward: the gradient SLAB (one flat buffer in the kernels' layout) is
@@ -953,7 +992,7 @@ def main():
                 # (nparts = 4: overlapped, on a second stream) -- and unpacked once; no flatten, no copy back
                 gs = D.enable_overlapped_grad_sync(net, nparts=nparts, force=force)
                 dist.barrier()
-                dt_, loss_ = configs2_step_leg(net, dev, NI, "bf16", 3, sync=None, seed=500 + rank)
+                dt_, loss_ = configs2_step_leg(net, dev, NI, "bf16", DDP_REPS, sync=None, seed=500 + rank, warmup=DDP_WARMUP)
                 ncoll_, moved_ = gs.collectives, gs.bytes_reduced
                 net.module.grad_sync = None
                 t_ = torch.tensor([dt_], device=ctl_device, dtype=torch.float64)
@@ -964,7 +1003,7 @@ def main():
             assert moved == grad_bytes and moved_ov == grad_bytes, (moved, moved_ov, grad_bytes)
             # the step WITHOUT any exchange on the same box (what the exchange adds), and the collective alone, same message
             # sizes, for the xGMI bus-bandwidth figure
-            dt_none, _ = configs2_step_leg(net, dev, NI, "bf16", 3, sync=None, seed=500 + rank)
+            dt_none, _ = configs2_step_leg(net, dev, NI, "bf16", DDP_REPS, sync=None, seed=500 + rank, warmup=DDP_WARMUP)
             flat = torch.zeros(grad_bytes // 4, device=dev)
             D.allreduce_slab(flat, [(0, flat.numel())], force=force)
             torch.cuda.synchronize()
@@ -980,7 +1019,7 @@ def main():
                                 "the %.1f MB gradient slab averaged IN PLACE over %s (ReduceOp.AVG on views of the slab, 64 MB messages), "
                                 "one unpack, fused Adam; weak scaling"
                                 % (NI, 2 * NI, grad_bytes / 1e6, "RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (test hook)"),
-                    "items_per_gpu_per_step": NI, "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
+                    "items_per_gpu_per_step": NI, "reps": DDP_REPS, "warmup": DDP_WARMUP, "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
                     "collectives_forced_in_one_rank_group": force,
                     "items_per_s": round(world * NI / min(dt, dt_ov), 1), "ms_per_step": round(1e3 * min(dt, dt_ov), 2),
                     "ms_per_step_allreduce_after_backward": round(1e3 * dt, 2), "collectives_per_step_after_backward": ncoll_after,

@@ -55,8 +55,9 @@
 extern "C" {
 #endif
 
-#define PWS_VERSION 4   /* 2: pws_netg_opts carries flags + x_sample_stride (round 3); 4: dpacked is the compact gradient slab
-                          (pws_netg_grad_floats / pws_netg_grad_layout), pws_netg_backward_lists (round 4) */
+#define PWS_VERSION 5   /* 2: pws_netg_opts carries flags + x_sample_stride (round 3); 4: dpacked is the compact gradient slab
+                          (pws_netg_grad_floats / pws_netg_grad_layout), pws_netg_backward_lists (round 4); 5: pws_netg_backward_plan
+                          (round 5; additions only) */
 
 #define PWS_OK 0
 #define PWS_EINVAL (-22) /* bad argument / unsupported shape */
@@ -528,6 +529,10 @@ size_t pws_netg_grad_floats(int input_nc, int ngf);
  * its alignment padding, which stays zero); consecutive layers abut, so the layers a backward run reports final merge into a few
  * large ranges. */
 int pws_netg_grad_layout(int input_nc, int ngf, size_t *first_float, size_t *floats);
+/* final_part[46] (HOST; no GPU call): the run of an nparts-run backward (pws_netg_backward_opts / _lists with part = 0 .. nparts-1)
+ * after which layer i's range of the slab is final, i.e. the run whose final_mask first reports it -- lets a data-parallel host
+ * plan its messages (and a CPU rehearsal replay them) without a device. */
+int pws_netg_backward_plan(int input_nc, int ngf, int nparts, unsigned char *final_part);
 int pws_netg_pack_weights_dgrad(const float *const *params, float *packed_dgrad, int input_nc, int ngf,
                                 pws_stream_t stream);
 size_t pws_netg_train_workspace_bytes(int n, int input_nc, int ngf);

@@ -458,7 +458,14 @@ class Exec {
         a.w_wring = l.wr_off != (size_t)-1 ? packed_ + l.wr_off : nullptr;
         a.out = bn_on_ ? op.aux[0] : o.seg[0].ptr, a.out_ld = l.cout;
         a.ws = q_ ? splitk_ws2_ : splitk_ws_, a.ws_bytes = math_ == PWS_MATH_FP32 ? splitk_big_ : splitk_bytes_;
-        if (math_ == PWS_MATH_BF16 && l.wb_off != (size_t)-1) a.math = PWS_MATH_BF16, a.w_bf16 = packed_ + l.wb_off;
+        if (math_ == PWS_MATH_BF16 && l.wb_off != (size_t)-1) {
+            a.math = PWS_MATH_BF16, a.w_bf16 = packed_ + l.wb_off;
+            // pws_netg_pack_weights_for(math = bf16) leaves this layer's Winograd copies out.  The bf16 kernels decline a call
+            // with a source of channels % 32 != 0 (wb_off only needs the TOTAL cin % 32 == 0: ngf 16 / 48 in up_bottom1.conv_same);
+            // pws_conv2d_fwd then falls through to the fp32 kernels, which must not find the stale Winograd pointers: the direct
+            // kernel on w_packed (always packed) takes it.
+            a.w_wino = a.w_wring = nullptr;
+        }
         a.store = store();
         a.out_sign = o.seg[0].sign, a.out_sign_ld = l.cout / 8;
         g_prof_tag = layer;
@@ -1382,6 +1389,36 @@ extern "C" size_t pws_netg_workspace_bytes(int n, int input_nc, int ngf, int is_
     Exec E(nullptr, L, n, nullptr, 0, nullptr, /*dry=*/true, false, NetgOpts{PWS_MATH_FP32, PWS_STORE_FP32, false});   // the arena layout does not depend on the mode
     forward_graph(E, nullptr, n, input_nc, ngf, is_training, 0, nullptr, nullptr, nullptr);
     return E.used();
+}
+
+// HOST only (no GPU call): the run of an nparts-run backward after which layer i's gradient is final -- the same rule
+// run_backward applies to its final_mask (a layer is final once every tape op that uses it lies at a reversed position < r_end).
+extern "C" int pws_netg_backward_plan(int input_nc, int ngf, int nparts, unsigned char *final_part) {
+    PWS_REQUIRE(input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_backward_plan: bad input_nc / ngf %d / %d", input_nc, ngf);
+    PWS_REQUIRE(nparts >= 1 && nparts <= 255 && final_part, "pws_netg_backward_plan: nparts %d (1..255) / NULL pointer", nparts);
+    size_t total = 0;
+    const std::vector<Layer> L = build_layers(input_nc, ngf, &total);
+    Exec E(nullptr, L, 1, nullptr, 0, nullptr, /*dry=*/true, false, NetgOpts{PWS_MATH_FP32, PWS_STORE_FP32, false});
+    float dummy_thetas = 0.f;
+    forward_graph(E, nullptr, 1, input_nc, ngf, 1, 0, nullptr, nullptr, &dummy_thetas);
+    const size_t T = E.tape().size();
+    size_t last[L_COUNT];   // largest reversed position of an op that uses the layer
+    bool used[L_COUNT];
+    for (int i = 0; i < L_COUNT; ++i) last[i] = 0, used[i] = false;
+    auto touch = [&](int layer, size_t rpos) { last[layer] = used[layer] ? std::max(last[layer], rpos) : rpos, used[layer] = true; };
+    for (size_t ii = 0; ii < T; ++ii) {
+        const Op &op = E.tape()[ii];
+        const size_t rpos = T - 1 - ii;
+        if (op.type == OP_FIELD) touch(L_OUT, rpos);
+        else if (op.type == OP_THETA) touch(L_FLATTEN, rpos), touch(L_LINEAR, rpos);
+        else touch(op.layer, rpos);
+    }
+    for (int i = 0; i < L_COUNT; ++i) {
+        int part = 0;
+        while (used[i] && part < nparts - 1 && !(last[i] < T * (size_t)(part + 1) / nparts)) ++part;
+        final_part[i] = (unsigned char)part;
+    }
+    return PWS_OK;
 }
 
 extern "C" size_t pws_netg_train_workspace_bytes(int n, int input_nc, int ngf) {

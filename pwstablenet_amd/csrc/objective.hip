@@ -1022,11 +1022,12 @@ extern "C" int pws_temporal_l1_bwd(const float *fake1, const float *fake2, const
                            gfake1, gfake2, h, w, tx, ty);
         return check_launch("temporal_l1_bwd_tiled_kernel");
     }
-    // neighbouring lanes merge the atomics of the taps they share (PWS_OPT_EXPERIMENT 93: never; 101: vertical neighbours as well -- a wave as
+    // neighbouring lanes merge the atomics of the taps they share -- only when a wave never straddles two samples (h * w % 64 == 0: the
+    // hand-over compares plane-relative offsets, and two samples have different theta) (PWS_OPT_EXPERIMENT 93: never; 101: vertical neighbours as well -- a wave as
     // 32 columns x 2 rows: 1.5 instead of 2 atomics per pixel and plane, measured SLOWER, 91 vs 72 us: the narrower rows and the extra shuffles cost more)
     hipLaunchKernelGGL(temporal_l1_kernel<true>, dim3(nb), dim3(256), 0, as_stream(stream), fake1, fake2, theta,
                        (double *)nullptr, c, scale, gfake1, gfake2, h, w, total, nb, (float *)nullptr,
-                       (total % 256 != 0 || g_experiment == 93) ? 0 : ((w % 128 == 0 && h % 2 == 0 && g_experiment == 101) ? 2 : 1));
+                       (total % 256 != 0 || ((size_t)h * w) % 64 != 0 || g_experiment == 93) ? 0 : ((w % 128 == 0 && h % 2 == 0 && g_experiment == 101) ? 2 : 1));
     return check_launch("temporal_l1_kernel<bwd>");
 }
 

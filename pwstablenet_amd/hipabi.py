@@ -17,7 +17,7 @@ ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 OPT_TWO_QUEUES = 1
 OPT_MATH, MATH_FP32, MATH_BF16 = 2, 0, 1
 OPT_STORE, STORE_FP32, STORE_BF16 = 3, 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 NETG_DETERMINISTIC = 1
 OPT_EXPERIMENT = 100   # measured kernel variants (tools, per-path tests); 0 = product default
 OBJ_SLOTS = 64
@@ -141,6 +141,7 @@ SIGNATURES = {
                                      ctypes.POINTER(PwsNetgOpts), _P]),
     "pws_netg_grad_floats": (_S, [_I, _I]),
     "pws_netg_grad_layout": (_I, [_I, _I, ctypes.POINTER(_S), ctypes.POINTER(_S)]),
+    "pws_netg_backward_plan": (_I, [_I, _I, _I, ctypes.POINTER(ctypes.c_ubyte)]),
     "pws_u8_normalize": (_I, [_P, _S, _P, _S, _I, _S, _P]),
     "pws_warp_norm_fwd": (_I, [_P, _S, _P, _P, _P, _S, _P, _I, _I, _I, _P]),
     "pws_warp_norm_bwd": (_I, [_P, _S, _P, _P, _S, _F, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -223,14 +223,15 @@ class StabObjective:
         dp_world = grad_average_world if grad_average_world is not None else self.grad_average_world
         if dp_world is None:
             dp_world = 1
-            if self.shapeloss and not self._warned_world:
+            if self.shapeloss:
                 import torch.distributed as dist
                 if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                    import warnings
-                    warnings.warn("StabObjective: a process group of %d ranks is initialised and grad_average_world is unset: the shape "
-                                  "term's gradient is NOT scaled for gradient averaging (set grad_average_world = world size if the "
-                                  "ranks' gradients are averaged; train_step does)" % dist.get_world_size())
-                    self._warned_world = True
+                    # the shape term is a SUM over the batch in the reference (DataParallel adds the replicas' gradients), every
+                    # other term a mean: whether this rank's share must be scaled by the world size depends on whether the caller
+                    # averages or sums the ranks' gradients, and a silent default is a silent numerical change -- say which
+                    raise ValueError("StabObjective: a process group of %d ranks is initialised, shapeloss is on and grad_average_world is "
+                                     "unset: pass grad_average_world = world size if the ranks' gradients are AVERAGED (train_step does), "
+                                     "or grad_average_world = 1 if they are summed / not exchanged" % dist.get_world_size())
         det = self.deterministic if deterministic is None else bool(deterministic)
         m = grids[0].shape[0]
         if m % 2 != 0:

@@ -9,11 +9,18 @@ from . import hipabi as A
 
 
 def _bump_versions(tensors):
+    """The packed-weight cache of the generator is keyed on the parameters' version counters: the fused kernel writes through raw
+    pointers, so the counters are advanced here.  torch 2.10: the private setter takes (list, list) on the host; earlier releases
+    expose the same name as (Tensor, int) or not at all -- any failure falls back to a no-op in-place add (three multi-tensor
+    launches), which bumps them the documented way."""
     setter = getattr(torch._C._autograd, "_unsafe_set_version_counter", None)
-    if setter is None:
-        torch._foreach_add_(tensors, 0.0)
-        return
-    setter(tensors, [t._version + 1 for t in tensors])
+    if setter is not None:
+        try:
+            setter(tensors, [t._version + 1 for t in tensors])
+            return
+        except TypeError:
+            pass
+    torch._foreach_add_(tensors, 0.0)
 
 
 class Adam:

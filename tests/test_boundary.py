@@ -95,7 +95,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), "missing export " + name
     assert declared == set(hipabi.SIGNATURES), declared ^ set(hipabi.SIGNATURES)
-    assert L.pws_version() == 4
+    assert L.pws_version() == 5
     assert L.pws_netg_packed_floats(31, 64) >= 48535944
     assert L.pws_netg_workspace_bytes(8, 31, 64, 0) > 10 ** 9
     assert L.pws_packed_weight_floats(hipabi.CONVT_K4S2, 1024, 256) == 16 * 1024 * 256

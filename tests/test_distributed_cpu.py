@@ -1,4 +1,4 @@
-"""world_size-2 tests of the multi-GPU host logic on CPU (gloo): frame sharding with window halos (no collective on
+"""world_size-2 and world_size-8 tests of the multi-GPU host logic on CPU (gloo): frame sharding with window halos (no collective on
 the data path), MAX-over-ranks timing, flat-bucket gradient averaging."""
 import os
 import socket
@@ -60,6 +60,45 @@ def _worker(rank, world, port, q):
         want[a:b] = torch.arange(a, b, dtype=torch.float32) * mean
     assert torch.allclose(slab, want) and slab.data_ptr() == ptr
     assert D.allreduce_slab(torch.zeros(4), []) == 0
+    # the REAL gradient slab of the reference-size generator (ngf 64: 46 layers = 92 tensors, 194 MB), exchanged as the overlapped
+    # backward does at nparts = 4: after each run the ranges of the layers pws_netg_backward_plan reports final, merged where they
+    # abut (autograd._NetGTrain.backward), in 64 MB messages -- every float of every layer averaged exactly once, the padding and
+    # the message count as on the GPU
+    from pwstablenet_amd import hipabi as A
+    import ctypes
+    L = A.lib()
+    nl, nparts = 46, 4
+    first, count = (ctypes.c_size_t * nl)(), (ctypes.c_size_t * nl)()
+    assert L.pws_netg_grad_layout(31, 64, first, count) == 0
+    plan = (ctypes.c_ubyte * nl)()
+    assert L.pws_netg_backward_plan(31, 64, nparts, plan) == 0
+    nfl = L.pws_netg_grad_floats(31, 64)
+    assert nfl >= 48535944 and sum(count) == nfl and all(first[i] + count[i] == first[i + 1] for i in range(nl - 1))
+    assert set(plan) == set(range(nparts)) and plan[0] == nparts - 1   # `transfer` (first op of the forward) is final in the last run
+    one = (ctypes.c_ubyte * nl)()
+    assert L.pws_netg_backward_plan(31, 64, 1, one) == 0 and not any(one)
+    pattern = (torch.arange(nfl, dtype=torch.float32) % 1021.0) - 510.0
+    gslab = pattern * float(rank + 1)
+    n_msgs, seen = 0, torch.zeros(nl, dtype=torch.int32)
+    for part in range(nparts):
+        newly = [i for i in range(nl) if plan[i] == part]
+        ranges = []
+        for i in newly:
+            if ranges and ranges[-1][1] == first[i]:
+                ranges[-1][1] = first[i] + count[i]
+            else:
+                ranges.append([first[i], first[i] + count[i]])
+        n_msgs += D.allreduce_slab(gslab, ranges)
+        seen[newly] += 1
+    assert bool((seen == 1).all())
+    assert torch.allclose(gslab, pattern * mean, rtol=1e-6, atol=1e-4)
+    assert 4 <= n_msgs <= 16, n_msgs            # a few large messages (GPU: 9 at nparts 4), never one per tensor
+    # configs[4]: a 1 001-frame clip sharded over the ranks, 15-frame halos, every frame owned once
+    s, e, rs, re_ = D.shard_frames(1001, rank, world, halo=15)
+    own = torch.zeros(1001)
+    own[s:e] = 1
+    dist.all_reduce(own)
+    assert torch.equal(own, torch.ones(1001)) and rs == max(0, s - 15) and re_ == min(1001, e + 15)
     # replicas start equal: parameters + BatchNorm buffers of rank 0 reach every rank as one flat bucket
     torch.manual_seed(100 + rank)   # define_G initialises from the LOCAL torch RNG: the ranks differ before the broadcast
     m = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4))
@@ -88,21 +127,25 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_gloo():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_gloo(world):
+    """world 2 and world 8 (BASELINE configs[3] / [4] name 8 GPUs: the control plane -- rendezvous, slab exchange plan, frame
+    shards, broadcast, MAX timing -- rehearsed at that size on CPU; the data plane is RCCL's)."""
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(300)
         assert p.exitcode == 0
     got = sorted(q.get(timeout=5) for _ in range(world))
-    assert [g[0] for g in got] == [0, 1] and all(g[1] >= 2 for g in got)
+    assert [g[0] for g in got] == list(range(world)) and all(g[1] >= 2 for g in got)
 
 
-def test_bench_launches_its_own_ranks_and_refuses_a_world_size_mismatch():
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_launches_its_own_ranks_and_refuses_a_world_size_mismatch(world):
     """`python bench.py --gpus N` without a launcher must start N ranks itself: here with the control-plane
     check hook (no GPU work) over gloo.  A WORLD_SIZE that contradicts --gpus is an error, not a warning."""
     import json
@@ -112,12 +155,12 @@ def test_bench_launches_its_own_ranks_and_refuses_a_world_size_mismatch():
     bench = os.path.join(root, "bench.py")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     env.update(PWS_BENCH_LAUNCH_CHECK="1", PWS_BENCH_BACKEND="gloo")
-    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True,
-                       timeout=300)
+    r = subprocess.run([sys.executable, bench, "--gpus", str(world), "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True,
+                       timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line == {"launch_check": True, "n_gpus": 2, "gpus_arg": 2, "max_over_ranks": 2.0, "rccl_ranks": 0,
+    assert line == {"launch_check": True, "n_gpus": world, "gpus_arg": world, "max_over_ranks": float(world), "rccl_ranks": 0,
                     "control_plane": "gloo (PWS_BENCH_BACKEND test hook: RCCL not exercised)", "self_launched": True}
     env2 = dict(env, WORLD_SIZE="1", RANK="0")
-    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=120)
+    r = subprocess.run([sys.executable, bench, "--gpus", str(world)], env=env2, capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and "refusing" in r.stderr

@@ -730,6 +730,32 @@ def test_netg_bf16_inference_vs_fp32(hip, kind, store):
     assert w_int.max().item() <= tol_int and w_brd.max().item() <= tol_brd
 
 
+@pytest.mark.parametrize("ngf,n", [(16, 32), (48, 16)])
+def test_netg_bf16_math_with_sources_off_the_32_channel_grid_never_reads_the_winograd_copies(hip, ngf, n):
+    """ngf 16 / 48: up_bottom1.conv_same reads cat(ngf, ngf) -- cin % 32 == 0, so the layer has bf16 weights and the bf16-mode
+    pack leaves its Winograd copies out, but the bf16 kernels decline sources of channels % 32 != 0 and pws_conv2d_fwd falls through
+    to the fp32 kernels: from wblocks >= 2048 that used to be the Winograd kernel on weights nobody packed.  The packed buffer is
+    poisoned with NaN before the bf16-mode pack, and the weights are changed once (a stale copy of the fp32-mode pack would pass
+    otherwise)."""
+    from pwstablenet_amd import synth
+    net = _make_net("W1", ngf)
+    x = torch.from_numpy(synth.make_window(n, 31, seed=11)).cuda()
+    with torch.no_grad():
+        net(x[:2], False)                                   # fp32-mode pack (Winograd copies of the OLD weights)
+        for p in net.parameters():
+            if p.dim() == 4:
+                p.mul_(1.25)
+        f32 = net(x, False).clone()
+        net.module.set_math("bf16", store="fp32")
+        nfl = hip.lib().pws_netg_packed_floats(31, ngf)
+        net.module._packed = torch.full((nfl,), float("nan"), device="cuda")
+        net.module._packed_key = None
+        f16 = net(x, False).clone()
+    assert bool(torch.isfinite(f16).all())
+    err = (f16 - f32).abs().max().item()
+    assert err < FIELD_TOL["W1"], err
+
+
 @pytest.mark.parametrize("store", ["bf16", "fp32"])
 def test_netg_bf16_training_step_gradients_vs_fp32(hip, store):
     """One training forward + backward (smooth field loss) in bf16 math: loss within 1 % of fp32, cosine similarity > 0.995 over
