@@ -291,6 +291,8 @@ def train_step(netG, optimizerG, batch, objective, perceptual=None, period=30, s
     if dp_world is None and (sync_gradients is not None or getattr(target, "grad_sync", None) is not None):
         import torch.distributed as dist
         dp_world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    elif dp_world is None:
+        dp_world = 1   # this step composes everything itself and exchanges nothing: the gradients stay this rank's own
     out = objective(grids, resid, rest[:, 0:3], rest[:, 3:], features, feature_adjacent.to(dev), grad_average_world=dp_world,
                     deterministic=det)
     loss = out.loss_g if perceptual is None else out.loss_g + perceptual(out.fake, rest[:, 3:6])

@@ -174,6 +174,34 @@ def victim():
 def aggressor():
     torch.cuda.set_device(0)
     s = masked_stream("aggressor")
+    if amath.startswith("poison"):
+        # round 5: NO matrix instruction, NO memory traffic -- waves that fill their registers (512 per lane: "poison"; 128: "poison128";
+        # "poisonlds": + 64 KB of LDS; "poisonhold": sleep a while first) with a NaN pattern and exit, back to back.  A victim that reads a
+        # register / LDS word it never wrote now reads NaN.  tools/probes/reg_poison.hip, built into tools/_bin/reg_poison.so.
+        so = os.path.join(ROOT, "tools", "_bin", "reg_poison.so")
+        if not os.path.exists(so):
+            import subprocess
+            os.makedirs(os.path.dirname(so), exist_ok=True)
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC",
+                                   os.path.join(ROOT, "tools", "probes", "reg_poison.hip"), "-o", so])
+        P = ctypes.CDLL(so)
+        P.reg_poison_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        lds_too = 128 if amath == "poison128" else (1 if amath == "poisonlds" else 0)
+        hold = 64 if amath in ("poisonhold", "poison128") else 0
+        nblk = int(os.environ.get("PROBE_POISON_BLOCKS", "1024"))
+        with torch.cuda.stream(s):
+            stq = A.current_stream()
+            k = 0
+            while not stop.is_set():
+                rc = P.reg_poison_launch(stq, nblk, lds_too, hold)
+                assert rc == 0, rc
+                k += 1
+                if k == 4:
+                    started.set()
+                if k % 64 == 0:
+                    s.synchronize()
+        print("poison launches:", k, flush=True)
+        return
     if amath.startswith("gemm"):   # NOT this library: torch matmuls (hipBLASLt / rocBLAS) in bf16 or fp32, back to back
         dt = torch.bfloat16 if amath == "gemm_bf16" else torch.float32
         with torch.cuda.stream(s):
