@@ -140,6 +140,10 @@ __device__ __forceinline__ void ring_dma16(unsigned lds_addr, unsigned voff, __a
     // fenced barriers that order it against every LDS access to its destination), while hipcc stays free to schedule the
     // matrix phase's ds_reads and MFMAs around it
 }
+// the same inside a bracket that saved M0 and restores it (one save / restore per group instead of per piece)
+__device__ __forceinline__ void ring_dma16_m0(unsigned lds_addr, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff));
+}
 template <int N>
 __device__ __forceinline__ void ring_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -246,132 +250,126 @@ __global__ void __launch_bounds__(C::THREADS, C::MT == 4 ? 2 : 3) conv_ring_kern
             }
         }
         const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w_bf), 0, (int)p.w_bytes, 0x00020000);
-        // cursor: (unit, plane, source, channel) of the next group to stage
-        unsigned pu = u_begin;
-        int pplane = 0, ps = 0, pc0 = 0, pwrow = 0, pbuf = 0;
-        RingUnit PU = ring_unit(p, pu);
-        unsigned loc[C::NL], cv[C::NL];   // cached per-lane source offsets (see stage())
+        // The groups are walked by NESTED LOOPS (unit, plane, source, 32-channel group) -- round 5.  (Rounds 2-4 kept a cursor
+        // (unit, plane, source, channel) that a stage() call advanced: hipcc turned its selects and nested ifs into ~900 lines of
+        // branchy scalar code per group, and a loader wave spent ~0.6 us per group on that bookkeeping before its first DMA piece
+        // (timing-only ablation "nothing but the loops": 163-193 us of the 440-710 us of the 2x2-tap kinds) -- for the stride-2 kinds,
+        // whose matrix phase is 0.7-0.8 us per group, the loaders were the critical path: matrix waves 35-47 % of their life at B.)
+        // Everything that depends on (unit, plane, source) -- descriptor, halo offset, per-lane offsets cv[] -- is set up once per
+        // source; the innermost loop over a source's groups only bumps two scalar offsets by 64 bytes.  Protocol unchanged: group g
+        // is issued behind barrier B_(g - R + 1); the loop's first R - 1 groups go out at once, R - 1 barriers remain at the end.
+        unsigned loc[C::NL], cv[C::NL];   // cached per-lane source offsets
         int loc_ld = -1;
 #pragma unroll
         for (int it = 0; it < C::NL; ++it) loc[it] = kRingOob, cv[it] = kRingOob;
-        auto stage = [&]() {
-            const unsigned d_base = uni((unsigned)(pbuf * C::GROUP_BYTES)) + (unsigned)(lw * 1024);
-            pbuf = pbuf + 1 == C::R ? 0 : pbuf + 1;
-            if (pu >= u_end || ((p.ablate & 1) && pu != u_begin)) {
-                if ((p.ablate & 1) && pu < u_end) {   // keep the cursor moving
-                    pc0 += C::CKG;
-                    if (pc0 >= sel4(p.src_c, ps)) {
-                        pc0 = 0, ++ps;
-                        if (ps == p.nsrc) {
-                            ps = 0, ++pplane;
-                            if (pplane == C::NPLANES) pplane = 0, pu += u_step;
+        unsigned issued = 0;   // groups staged so far
+        unsigned dslot = 0;    // ring slot of the next group
+        const bool mix_in = C::MIX_IT >= 0 && C::MIX_IT * C::LWAVES + lw < C::IN_WI;   // the straddling wave-instruction: input piece on this wave?
+        for (unsigned pu = u_begin; pu < u_end; pu += u_step) {
+            const RingUnit PU = ring_unit(p, pu);
+            const bool dry = (p.ablate & 1) && pu != u_begin;     // TIMING ONLY: the pieces fetch nothing
+            const bool no_w = C::SKIP_FILL && (p.ablate & 8) && pu != u_begin;   // TIMING ONLY: what resident weights would save
+            for (int pplane = 0; pplane < C::NPLANES; ++pplane) {
+                const int a = pplane >> 1, b = pplane & 1;
+                int oy, ox;   // view coordinates of the halo's first pixel
+                if constexpr (C::MODE == RM_K3S1) oy = PU.y0 * C::TH - 1, ox = PU.x0 * C::TW - 1;
+                else if constexpr (C::MODE == RM_CT4) oy = PU.y0 * C::TH - (1 - PU.py), ox = PU.x0 * C::TW - (1 - PU.px);
+                else if constexpr (C::MODE == RM_SP3) oy = PU.y0 * C::TH, ox = PU.x0 * C::TW;
+                else oy = PU.y0 * C::TH - a, ox = PU.x0 * C::TW - b;
+                unsigned d_sw = uni((unsigned)((size_t)PU.co0 * p.kpad * 2));   // the unit's weight rows; + 64 bytes per group of the plane
+                const unsigned wplane = (unsigned)(p.npad * p.kpad * 2);
+                for (int ps = 0; ps < p.nsrc; ++ps) {
+                    const int ld = sel4(p.src_ld, ps), srcc = sel4(p.src_c, ps);
+                    const size_t img1 = (size_t)p.H * p.W * ld * 2;   // bytes of one sample
+                    const size_t img = img1 * C::TN;                   // ... of the samples of a tile (N % TN == 0: conv_ring_try)
+                    const char *base_in = uni(static_cast<const char *>(sel4(p.src_ptr, ps)) + (size_t)PU.n0 * img1);
+                    const __amdgpu_buffer_rsrc_t d_rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base_in), 0, (int)uni((unsigned)img), 0x00020000);
+                    const unsigned ldb = (unsigned)ld * 2u;
+                    // descriptor of the straddling wave-instruction (wave-uniform selects)
+                    const __amdgpu_buffer_rsrc_t d_rmix = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<char *>(uni(mix_in ? base_in : static_cast<const char *>(p.w_bf))), 0, (int)uni(mix_in ? (unsigned)img : (unsigned)p.w_bytes),
+                        0x00020000);
+                    // Per-lane source offsets: every vector instruction a loader wave issues takes matrix-pipe cycles from its SIMD (~5 per
+                    // instruction beside bf16 / fp32 matrix instructions: conv_first.hip, tools/probes/mfma_f32_probe.hip), and the 32-bit
+                    // multiplies of the address arithmetic are quarter rate.  Offsets of a halo that lies inside the image are ONE add:
+                    // loc[] (the lane's offset from the halo's first pixel, rebuilt only when the source's row stride changes) + the
+                    // halo's scalar offset.
+                    constexpr int S = C::NPLANES == 4 ? 2 : 1;
+                    if (ld != loc_ld) {
+                        loc_ld = ld;
+#pragma unroll
+                        for (int it = 0; it < C::NL; ++it) {
+                            if (it * C::LWAVES >= C::IN_WI) continue;
+                            const int tn = ia[it] >> 20, ly = (ia[it] >> 10) & 0x3ff, lx = ia[it] & 0x3ff;
+                            loc[it] = ia[it] >= 0 ? (unsigned)((tn * p.H + S * ly) * p.W + S * lx) * ldb + (unsigned)ib[it] : kRingOob;
                         }
                     }
-                }
-                // past the last group: filler pieces keep every loader's DMA count per group constant (the counted waits)
-                if constexpr (C::SKIP_FILL) return;
-#pragma unroll
-                for (int it = 0; it < C::NL; ++it) ring_dma16(d_base + (unsigned)(it * C::LWAVES * 1024), kRingOob, rsrc_w, 0u);
-                return;
-            }
-            const int a = pplane >> 1, b = pplane & 1;
-            int oy, ox;   // view coordinates of the halo's first pixel
-            if constexpr (C::MODE == RM_K3S1) oy = PU.y0 * C::TH - 1, ox = PU.x0 * C::TW - 1;
-            else if constexpr (C::MODE == RM_CT4) oy = PU.y0 * C::TH - (1 - PU.py), ox = PU.x0 * C::TW - (1 - PU.px);
-            else if constexpr (C::MODE == RM_SP3) oy = PU.y0 * C::TH, ox = PU.x0 * C::TW;
-            else oy = PU.y0 * C::TH - a, ox = PU.x0 * C::TW - b;
-            const int ld = sel4(p.src_ld, ps);
-            const size_t img1 = (size_t)p.H * p.W * ld * 2;   // bytes of one sample
-            const size_t img = img1 * C::TN;                   // ... of the samples of a tile (N % TN == 0: conv_ring_try)
-            const char *base_in = uni(static_cast<const char *>(sel4(p.src_ptr, ps)) + (size_t)PU.n0 * img1);
-            const __amdgpu_buffer_rsrc_t d_rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base_in), 0, (int)uni((unsigned)img), 0x00020000);
-            const unsigned ldb = (unsigned)ld * 2u;
-            const unsigned d_sin = uni((unsigned)(pc0 * 2));
-            const unsigned d_sw = uni((unsigned)(((size_t)PU.co0 * p.kpad + pwrow) * 2));
-            const unsigned wplane = (unsigned)(p.npad * p.kpad * 2);
-            // descriptor / scalar offset of the straddling wave-instruction (wave-uniform selects)
-            const bool mix_in = C::MIX_IT >= 0 && C::MIX_IT * C::LWAVES + lw < C::IN_WI;
-            const __amdgpu_buffer_rsrc_t d_rmix = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<char *>(uni(mix_in ? base_in : static_cast<const char *>(p.w_bf))), 0, (int)uni(mix_in ? (unsigned)img : (unsigned)p.w_bytes),
-                0x00020000);
-            const unsigned d_smix = uni(mix_in ? d_sin : d_sw);
-            // Per-lane source offsets live in cv[] and are rebuilt only at the first group of a (unit, plane, source): every vector
-            // instruction a loader wave issues takes matrix-pipe cycles from its SIMD (~5 per instruction beside bf16 / fp32 matrix
-            // instructions: conv_first.hip, tools/probes/mfma_f32_probe.hip), and the 32-bit multiplies of the address arithmetic
-            // are quarter rate.  Offsets of a halo that lies inside the image are ONE add: loc[] (the lane's offset from the halo's
-            // first pixel, rebuilt only when the source's row stride changes) + the halo's scalar offset.
-            if (pc0 == 0) {
-                constexpr int S = C::NPLANES == 4 ? 2 : 1;
-                if (ld != loc_ld) {
-                    loc_ld = ld;
+                    const int fy = S * oy + (S == 2 ? a : 0), fx = S * ox + (S == 2 ? b : 0);   // image coordinates of the halo's first pixel
+                    const unsigned s_halo = uni((unsigned)((fy * p.W + fx) * (int)ldb));
+                    const bool interior = fy >= 0 && fy + S * (C::IH - 1) < p.H && fx >= 0 && fx + S * (C::IW - 1) < p.W;   // scalar
 #pragma unroll
                     for (int it = 0; it < C::NL; ++it) {
-                        if (it * C::LWAVES >= C::IN_WI) continue;
-                        const int tn = ia[it] >> 20, ly = (ia[it] >> 10) & 0x3ff, lx = ia[it] & 0x3ff;
-                        loc[it] = ia[it] >= 0 ? (unsigned)((tn * p.H + S * ly) * p.W + S * lx) * ldb + (unsigned)ib[it] : kRingOob;
-                    }
-                }
-                const int fy = S * oy + (S == 2 ? a : 0), fx = S * ox + (S == 2 ? b : 0);   // image coordinates of the halo's first pixel
-                const unsigned s_halo = uni((unsigned)((fy * p.W + fx) * (int)ldb));
-                const bool interior = fy >= 0 && fy + S * (C::IH - 1) < p.H && fx >= 0 && fx + S * (C::IW - 1) < p.W;   // scalar
-#pragma unroll
-                for (int it = 0; it < C::NL; ++it) {
-                    const bool in_ct = (it + 1) * C::LWAVES <= C::IN_WI, w_ct = it * C::LWAVES >= C::IN_WI;
-                    unsigned v_in = kRingOob, v_w = kRingOob;
-                    if (!w_ct) {
-                        v_in = loc[it] + s_halo;   // (a filler lane stays out of range: ~2^31 + an offset inside one tile's samples)
-                        if (!interior) {
-                            const int ly = (ia[it] >> 10) & 0x3ff, lx = ia[it] & 0x3ff;
-                            const int ry = fy + S * ly, rx = fx + S * lx;
-                            v_in = (ia[it] >= 0 && ry >= 0 && ry < p.H && rx >= 0 && rx < p.W) ? v_in : kRingOob;
+                        const bool in_ct = (it + 1) * C::LWAVES <= C::IN_WI, w_ct = it * C::LWAVES >= C::IN_WI;
+                        unsigned v_in = kRingOob, v_w = kRingOob;
+                        if (!w_ct) {
+                            v_in = loc[it] + s_halo;   // (a filler lane stays out of range: ~2^31 + an offset inside one tile's samples)
+                            if (!interior) {
+                                const int ly = (ia[it] >> 10) & 0x3ff, lx = ia[it] & 0x3ff;
+                                const int ry = fy + S * ly, rx = fx + S * lx;
+                                v_in = (ia[it] >= 0 && ry >= 0 && ry < p.H && rx >= 0 && rx < p.W) ? v_in : kRingOob;
+                            }
                         }
+                        if (!in_ct) {
+                            const int t = ia[it];
+                            int wt = t;   // plane of the packed weights this tap slot reads
+                            bool ok = t >= 0;
+                            const int ty = t >> 1, tx = t & 1;
+                            if constexpr (C::MODE == RM_CT4 || C::MODE == RM_SP3) wt = (PU.py * 2 + PU.px) * 4 + t;
+                            if constexpr (C::MODE == RM_SP3) ok = ok && ty <= PU.py && tx <= PU.px;
+                            if constexpr (C::MODE == RM_K3S2) wt = (a ? 2 * ty : 1) * 3 + (b ? 2 * tx : 1), ok = ok && ty <= a && tx <= b;
+                            if constexpr (C::MODE == RM_K4S2) wt = (2 * ty + 1 - a) * 4 + (2 * tx + 1 - b);
+                            v_w = ok ? (unsigned)wt * wplane + (unsigned)ib[it] : kRingOob;
+                        }
+                        cv[it] = dry ? kRingOob : (in_ct ? v_in : (w_ct ? v_w : (mix_in ? v_in : v_w)));
                     }
-                    if (!in_ct) {
-                        const int t = ia[it];
-                        int wt = t;   // plane of the packed weights this tap slot reads
-                        bool ok = t >= 0;
-                        const int ty = t >> 1, tx = t & 1;
-                        if constexpr (C::MODE == RM_CT4 || C::MODE == RM_SP3) wt = (PU.py * 2 + PU.px) * 4 + t;
-                        if constexpr (C::MODE == RM_SP3) ok = ok && ty <= PU.py && tx <= PU.px;
-                        if constexpr (C::MODE == RM_K3S2) wt = (a ? 2 * ty : 1) * 3 + (b ? 2 * tx : 1), ok = ok && ty <= a && tx <= b;
-                        if constexpr (C::MODE == RM_K4S2) wt = (2 * ty + 1 - a) * 4 + (2 * tx + 1 - b);
-                        v_w = ok ? (unsigned)wt * wplane + (unsigned)ib[it] : kRingOob;
+                    unsigned d_sin = 0;   // byte offset of the group's 32 channels inside a pixel of this source
+                    for (int pc0 = 0; pc0 < srcc; pc0 += C::CKG) {
+                        if (issued >= (unsigned)(C::R - 1)) {
+                            ring_wait_vmcnt<(C::R - 2) * C::NL>();   // this wave's pieces of group issued - R + 1 have landed (R > 2: younger groups may still fly)
+                            __builtin_amdgcn_s_barrier();            // B_(issued - R + 1): ... and nobody reads the slot this group goes to any more
+                        }
+                        const unsigned d_base = uni(dslot * (unsigned)C::GROUP_BYTES + (unsigned)(lw * 1024));
+                        const unsigned d_smix = mix_in ? d_sin : d_sw;
+                        unsigned keep;
+                        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0" : "=s"(keep));   // (the s_nop covers descriptor / offset SGPRs fresh from a v_readfirstlane)
+#pragma unroll
+                        for (int it = 0; it < C::NL; ++it) {
+                            // kind of this wave-instruction: compile-time except for the one `it` that straddles the input / weight boundary
+                            const bool in_ct = (it + 1) * C::LWAVES <= C::IN_WI, w_ct = it * C::LWAVES >= C::IN_WI;
+                            const unsigned dst = d_base + (unsigned)(it * C::LWAVES * 1024);
+                            if (C::SKIP_FILL && it * C::LWAVES + lw >= C::IN_WI + C::W_WI) continue;   // filler (wave-uniform)
+                            if (no_w && w_ct) continue;
+                            if (in_ct) ring_dma16_m0(dst, cv[it], d_rin, d_sin);
+                            else if (w_ct) ring_dma16_m0(dst, cv[it], rsrc_w, d_sw);
+                            else ring_dma16_m0(dst, cv[it], d_rmix, d_smix);
+                        }
+                        asm volatile("s_mov_b32 m0, %0" ::"s"(keep));
+                        d_sin += (unsigned)(C::CKG * 2), d_sw += (unsigned)(C::CKG * 2);
+                        ++issued;
+                        dslot = dslot + 1 == (unsigned)C::R ? 0u : dslot + 1;
                     }
-                    cv[it] = in_ct ? v_in : (w_ct ? v_w : (mix_in ? v_in : v_w));
                 }
             }
-#pragma unroll
-            for (int it = 0; it < C::NL; ++it) {
-                // kind of this wave-instruction: compile-time except for the one `it` that straddles the input / weight boundary
-                const bool in_ct = (it + 1) * C::LWAVES <= C::IN_WI, w_ct = it * C::LWAVES >= C::IN_WI;
-                const unsigned dst = d_base + (unsigned)(it * C::LWAVES * 1024);
-                if (C::SKIP_FILL && it * C::LWAVES + lw >= C::IN_WI + C::W_WI) continue;   // filler (wave-uniform)
-                if (C::SKIP_FILL && (p.ablate & 8) && w_ct && pu != u_begin) continue;       // TIMING ONLY: what resident weights would save
-                if (in_ct) ring_dma16(dst, cv[it], d_rin, d_sin);
-                else if (w_ct) ring_dma16(dst, cv[it], rsrc_w, d_sw);
-                else ring_dma16(dst, cv[it], d_rmix, d_smix);
-            }
-            // advance
-            pc0 += C::CKG, pwrow += C::CKG;
-            if (pc0 >= sel4(p.src_c, ps)) {
-                pc0 = 0, ++ps;
-                if (ps == p.nsrc) {
-                    ps = 0, pwrow = 0, ++pplane;
-                    if (pplane == C::NPLANES) {
-                        pplane = 0, pu += u_step;
-                        if (pu < u_end) PU = ring_unit(p, pu);
-                    }
-                }
-            }
-        };
-#pragma unroll
-        for (int i = 0; i < C::R - 1; ++i) stage();
-        for (unsigned s = 0; s < total; ++s) {
-            ring_wait_vmcnt<(C::R - 2) * C::NL>();   // this wave's pieces of group s have landed (R > 2: younger groups may still fly)
-            __builtin_amdgcn_s_barrier();            // B_s
-            stage();                                 // group s + R - 1 into the buffer group s - 1 occupied
         }
-        ring_wait_vmcnt<0>();   // the filler pieces still target this workgroup's LDS
+        // the last min(total, R - 1) barriers: the groups still in flight land one by one (exact counts: no filler groups)
+        const unsigned rem = issued < (unsigned)(C::R - 1) ? issued : (unsigned)(C::R - 1);
+        for (unsigned j = 0; j < rem; ++j) {
+            const unsigned left = rem - 1 - j;   // groups that may still fly behind the one this barrier publishes
+            if (left >= 2) ring_wait_vmcnt<(C::R >= 4 ? 2 : 0) * C::NL>();
+            else if (left == 1) ring_wait_vmcnt<(C::R >= 3 ? 1 : 0) * C::NL>();
+            else ring_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+        }
         return;
     }
 

@@ -131,6 +131,47 @@ def victim():
     s = masked_stream("victim")
     with torch.cuda.stream(s):
         s.wait_stream(torch.cuda.default_stream())
+        if os.environ.get("PROBE_DETAIL") == "2":
+            # round 5: WHICH of the deterministic temporal backward's three outputs differs (gfake1 and the staged s values are written by
+            # temporal_l1_kernel<true>, gfake2 by temporal_gather_kernel from the staged values), does a second read of the same memory
+            # still differ (wrong data vs a wrong read), and what do the wrong values look like
+            def run_t():
+                ge = gextra0.clone()
+                scratch = torch.full((n, 3, h, w), float("nan"), device="cuda")
+                A.check(L.pws_temporal_l1_bwd_det(A.ptr(fake[:n]), A.ptr(fake[n:]), A.ptr(theta), 1e-5, A.ptr(scale), A.ptr(ge[:n]), A.ptr(ge[n:]),
+                                                  A.ptr(scratch), n, h, w, A.current_stream()), "t")
+                return ge, scratch
+            ref_ge, ref_sc = run_t()
+            ref_ge, ref_sc = ref_ge.clone(), ref_sc.clone()
+            s.synchronize()
+            started.wait(120)
+            shown = tot = 0
+            kinds = {"gfake1": 0, "staged": 0, "gfake2": 0, "second read equal": 0}
+            for it in range(int(os.environ.get("PROBE_LAUNCHES", "20000"))):
+                ge, sc = run_t()
+                d1, ds, d2 = (ge[:n] != ref_ge[:n]), (sc != ref_sc), (ge[n:] != ref_ge[n:])
+                n1, ns, n2 = int(d1.sum()), int(ds.sum()), int(d2.sum())
+                if n1 or ns or n2:
+                    tot += 1
+                    kinds["gfake1"] += 1 if n1 else 0
+                    kinds["staged"] += 1 if ns else 0
+                    kinds["gfake2"] += 1 if n2 else 0
+                    s.synchronize()
+                    again = int((ge != ref_ge).sum()) + int((sc != ref_sc).sum())
+                    kinds["second read equal"] += 1 if again == 0 else 0
+                    if shown < 8:
+                        shown += 1
+                        which = d2 if n2 else (ds if ns else d1)
+                        cur = ge[n:] if n2 else (sc if ns else ge[:n])
+                        ref = ref_ge[n:] if n2 else (ref_sc if ns else ref_ge[:n])
+                        idx = which.reshape(-1).nonzero().reshape(-1)
+                        rows = torch.unique((idx % (h * w)) // w)
+                        print("launch %d: gfake1 %d, staged %d, gfake2 %d elements differ (second read: %d); rows %s; got %s want %s" % (
+                            it, n1, ns, n2, again, rows[:8].tolist(), ["%.6g" % v for v in cur.reshape(-1)[idx[:5]].tolist()],
+                            ["%.6g" % v for v in ref.reshape(-1)[idx[:5]].tolist()]), flush=True)
+            print("temporal_l1_bwd_det: %d launches with wrong elements: %s" % (tot, kinds), flush=True)
+            stop.set()
+            return
         if os.environ.get("PROBE_DETAIL") == "1":
             clean = cand_warp(A.current_stream()).clone()   # before the aggressor starts
             s.synchronize()
