@@ -70,6 +70,7 @@ struct RingParams {
     int dst_sign_ld[4];
     int tiles_x, tiles_y, tn;   // tn: samples per tile
     unsigned ncob, ncls, nunits;
+    unsigned m_cls, m_cob, m_tx, m_ty;   // ceil(2^32 / d) of the four divisors of ring_unit (0: d == 1): u / d = umulhi(u, m), exact for u * d < 2^32 (ring_launch checks)
     int gpp;              // K groups per plane = sum(src_c) / 32
 #ifdef PWS_RING_TIMERS
     unsigned long long *timers;   // [workgroup][matrix wave][8]
@@ -169,13 +170,17 @@ __device__ __forceinline__ T sel4(const T (&a)[4], int i) {
 struct RingUnit {   // decoded (tile, cout block, class)
     int n0, y0, x0, co0, py, px;
 };
+// (divisions by multiply-high with host-made reciprocals: scalar instructions.  hipcc's own expansion of a 32-bit division goes through
+//  v_rcp_iflag_f32 -- vector registers holding wave-uniform reciprocals, hoisted in front of the role split and, in the 256-register
+//  kernels, spilled round the matrix waves' whole loop)
+__device__ __forceinline__ unsigned ring_div(unsigned u, unsigned m) { return m ? __umulhi(u, m) : u; }
 __device__ __forceinline__ RingUnit ring_unit(const RingParams &p, unsigned u) {
     RingUnit r;
-    const unsigned cls = u % p.ncls, rest = u / p.ncls;
-    const unsigned cob = rest % p.ncob, tile = rest / p.ncob;
-    const unsigned tx = tile % (unsigned)p.tiles_x, t2 = tile / (unsigned)p.tiles_x;
-    const unsigned ty = t2 % (unsigned)p.tiles_y;
-    r.n0 = (int)(t2 / (unsigned)p.tiles_y) * p.tn;
+    const unsigned rest = ring_div(u, p.m_cls), cls = u - rest * p.ncls;
+    const unsigned tile = ring_div(rest, p.m_cob), cob = rest - tile * p.ncob;
+    const unsigned t2 = ring_div(tile, p.m_tx), tx = tile - t2 * (unsigned)p.tiles_x;
+    const unsigned t3 = ring_div(t2, p.m_ty), ty = t2 - t3 * (unsigned)p.tiles_y;
+    r.n0 = (int)t3 * p.tn;
     r.y0 = (int)ty, r.x0 = (int)tx, r.co0 = (int)cob * 64, r.py = (int)(cls >> 1), r.px = (int)(cls & 1);
     return r;
 }
@@ -198,8 +203,9 @@ __global__ void __launch_bounds__(C::THREADS, C::MT == 4 ? 2 : 3) conv_ring_kern
     const unsigned nxc = G < (unsigned)kXcds ? G : (unsigned)kXcds;
     const unsigned xcd = blockIdx.x % nxc, slot = blockIdx.x / nxc;
     const unsigned nx = G / nxc + (xcd < G % nxc ? 1u : 0u);   // workgroups on this XCD
-    const unsigned c_begin = (unsigned)((unsigned long long)xcd * p.nunits / nxc);
-    const unsigned c_end = (unsigned)((unsigned long long)(xcd + 1) * p.nunits / nxc);
+    // (32-bit: nunits < 2^28, conv_ring_try; through uni(): both roles use these, they belong in scalar registers)
+    const unsigned c_begin = uni(xcd * p.nunits / nxc);
+    const unsigned c_end = uni((xcd + 1) * p.nunits / nxc);
     if (c_begin + slot >= c_end) return;
     const unsigned u_begin = c_begin + slot, u_end = c_end, u_step = nx;
     const unsigned my_units = (u_end - u_begin + u_step - 1) / u_step;
@@ -519,12 +525,37 @@ __global__ void __launch_bounds__(C::THREADS, C::MT == 4 ? 2 : 3) conv_ring_kern
         }
 
         if (cg == 0) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            if constexpr (!DG) {
+                // the accumulators start at the BIAS (round 5): acc[mt][nt][r] is channel co0 + 32 nt + 16 (r / 8) + 8 hi + r % 8 of pixel mt, so a
+                // lane's 32 bias values are eight 16-byte LDS reads per unit -- instead of two reads and eight adds in each of the 4 MT store
+                // slots of the epilogue, which is bound by the instructions ONE wave per SIMD can issue (tools/probes/r5d_epilogue.sh: the
+                // epilogue takes 3.5 us per unit with or without its stores)
+                float bz[2][16];
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+                    for (int h = 0; h < 2; ++h) {
+                        const float4 b0 = *reinterpret_cast<const float4 *>(lds_bias + CU.co0 + nt * 32 + h * 16 + hi * 8);
+                        const float4 b1 = *reinterpret_cast<const float4 *>(lds_bias + CU.co0 + nt * 32 + h * 16 + hi * 8 + 4);
+                        bz[nt][h * 8 + 0] = b0.x, bz[nt][h * 8 + 1] = b0.y, bz[nt][h * 8 + 2] = b0.z, bz[nt][h * 8 + 3] = b0.w;
+                        bz[nt][h * 8 + 4] = b1.x, bz[nt][h * 8 + 5] = b1.y, bz[nt][h * 8 + 6] = b1.z, bz[nt][h * 8 + 7] = b1.w;
+                    }
+                // (one opaque v_mov per element: with plain copies -- element by element or acc[mt] = acc[0] -- hipcc gave the loop-carried
+                //  accumulators other registers than the initialised ones and copied 96 registers in EVERY group: +6 ... +13 % on the tall kernels)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) asm("v_mov_b32 %0, %1" : "=v"(acc[mt][nt][r]) : "v"(bz[nt][r]));   // (opaque: a plain copy is not coalesced with the loop-carried registers)
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+            }
         }
 #ifdef PWS_RING_TIMERS
         const unsigned long long t2 = PWS_RT();
@@ -671,11 +702,20 @@ __global__ void __launch_bounds__(C::THREADS, C::MT == 4 ? 2 : 3) conv_ring_kern
 #pragma unroll
                         for (int k = 0; k < 8; ++k) v[k] = acc[mt][q >> 1][(q & 1) * 8 + k];
                         if constexpr (!DG) {
-                            const float4 b0 = *reinterpret_cast<const float4 *>(lds_bias + CU.co0 + q * 16 + hi * 8);
-                            const float4 b1 = *reinterpret_cast<const float4 *>(lds_bias + CU.co0 + q * 16 + hi * 8 + 4);
-                            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                            // (the bias is in the accumulators already.)  LReLU / none: max(v, slope v) -- the multiplies pack two to an
+                            // instruction; ReLU: max(v, +0) (slope v would leave -0 behind).  One scalar branch per slot.
+                            if (p.act == PWS_ACT_RELU) {
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) v[k] = act_apply(v[k] + bb[k], p.act);
+                                for (int k = 0; k < 8; ++k) asm("v_max_f32 %0, 0, %1" : "=v"(v[k]) : "v"(v[k]));
+                            } else {
+                                const float slope = p.act == PWS_ACT_LRELU ? 0.2f : 1.f;
+#pragma unroll
+                                for (int k = 0; k < 8; k += 2) {
+                                    const f32x2 t = (f32x2){v[k], v[k + 1]} * (f32x2){slope, slope};   // v_pk_mul_f32
+                                    asm("v_max_f32 %0, %1, %2" : "=v"(v[k]) : "v"(v[k]), "v"(t.x));   // (the builtin would canonicalise first)
+                                    asm("v_max_f32 %0, %1, %2" : "=v"(v[k + 1]) : "v"(v[k + 1]), "v"(t.y));
+                                }
+                            }
                         } else {
                             const u32x4 o = e_old[slot];   // zeros when this destination is overwritten
                             v[0] += bf16_lo(o.x), v[1] += bf16_hi(o.x), v[2] += bf16_lo(o.y), v[3] += bf16_hi(o.y);
@@ -683,9 +723,15 @@ __global__ void __launch_bounds__(C::THREADS, C::MT == 4 ? 2 : 3) conv_ring_kern
                             // act'(y) of the tensor this destination is the gradient of (no such tensor: slope == 1)
                             const float sl = e.slope;
                             if constexpr (SG) {
+                                // bit k of the mask set: v stays, else slope v -- as a bit select (v_bfe_i32 makes 0 / ~0 of the bit, v_bfi_b32
+                                // picks v or slope v): 2.5 instructions per value instead of 4 (bit test, compare, select, multiply)
                                 const unsigned m = e_m[slot];
 #pragma unroll
-                                for (int k = 0; k < 8; ++k) v[k] *= (m >> k) & 1u ? 1.f : sl;
+                                for (int k = 0; k < 8; ++k) {
+                                    const unsigned keepv = (unsigned)__builtin_amdgcn_sbfe((int)m, (unsigned)k, 1u);
+                                    const unsigned a_ = __builtin_bit_cast(unsigned, v[k]), b_ = __builtin_bit_cast(unsigned, v[k] * sl);
+                                    v[k] = __builtin_bit_cast(float, (a_ & keepv) | (b_ & ~keepv));
+                                }
                             } else {
                                 const u32x4 yv = e_y[slot];
                                 v[0] *= bf16_lo(yv.x) > 0.f ? 1.f : sl, v[1] *= bf16_hi(yv.x) > 0.f ? 1.f : sl;
@@ -707,10 +753,18 @@ __global__ void __launch_bounds__(C::THREADS, C::MT == 4 ? 2 : 3) conv_ring_kern
 #endif
                         if constexpr (!DG) {
                             if (p.out_sign) {   // (uniform) sign bits of the 8 rounded values: what a later act' needs of this tensor
-                                const unsigned m = (bf16_lo(wq.x) > 0.f ? 1u : 0u) | (bf16_hi(wq.x) > 0.f ? 2u : 0u) | (bf16_lo(wq.y) > 0.f ? 4u : 0u) |
-                                                   (bf16_hi(wq.y) > 0.f ? 8u : 0u) | (bf16_lo(wq.z) > 0.f ? 16u : 0u) | (bf16_hi(wq.z) > 0.f ? 32u : 0u) |
-                                                   (bf16_lo(wq.w) > 0.f ? 64u : 0u) | (bf16_hi(wq.w) > 0.f ? 128u : 0u);
-                                if (st_ok) p.out_sign[(size_t)pix * (unsigned)p.out_sign_ld + (unsigned)((CU.co0 + q * 16) >> 3) + (unsigned)hi] = (unsigned char)m;
+                                // a bf16 is > 0 exactly when its bit pattern, read as a SIGNED 16-bit integer, is > 0 (a NaN with a clear sign bit
+                                // counts as positive here; the float compare of rounds 2-4 said no): min(max(x, 0), 1) on both halves of a word
+                                // at once (v_pk_max_i16 / v_pk_min_i16) leaves the two answers at bits 0 and 16 -- 13 instructions per slot
+                                // instead of 35 (8 x unpack, compare, select, or)
+                                const unsigned one2 = 0x00010001u;
+                                auto pos2 = [&](unsigned w) {   // (asm: hipcc turns the elementwise min / max into two compares, two selects and a permute)
+                                    unsigned r;
+                                    asm("v_pk_max_i16 %0, %1, 0\n\tv_pk_min_i16 %0, %0, %2" : "=v"(r) : "v"(w), "s"(one2));
+                                    return r;
+                                };
+                                const unsigned x = pos2(wq.x) | (pos2(wq.y) << 2) | (pos2(wq.z) << 4) | (pos2(wq.w) << 6);   // values 0, 2, 4, 6 at bits 0, 2, 4, 6; 1, 3, 5, 7 at 16, 18, 20, 22
+                                if (st_ok) p.out_sign[(size_t)pix * (unsigned)p.out_sign_ld + (unsigned)((CU.co0 + q * 16) >> 3) + (unsigned)hi] = (unsigned char)(x | (x >> 15));
                             }
                         }
                     }
@@ -759,6 +813,13 @@ static int ring_launch(RingParams &rp, hipStream_t st) {
     rp.tiles_x = rp.LW / C::TW, rp.tiles_y = rp.LH / C::TH, rp.tn = C::TN;   // whole tiles only (conv_ring_try)
     rp.ncob = (unsigned)((rp.cout + 63) / 64), rp.ncls = (unsigned)C::NCLS;
     rp.nunits = (unsigned)(rp.tiles_x * rp.tiles_y) * (unsigned)(rp.N / C::TN) * rp.ncob * rp.ncls;
+    {
+        auto magic = [](unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); };
+        unsigned dmax = rp.ncls > rp.ncob ? rp.ncls : rp.ncob;
+        dmax = dmax > (unsigned)rp.tiles_x ? dmax : (unsigned)rp.tiles_x, dmax = dmax > (unsigned)rp.tiles_y ? dmax : (unsigned)rp.tiles_y;
+        if ((unsigned long long)rp.nunits * dmax >= 0x100000000ull) return 1;   // (never at this generator's sizes) the multiply-high division would not be exact
+        rp.m_cls = magic(rp.ncls), rp.m_cob = magic(rp.ncob), rp.m_tx = magic((unsigned)rp.tiles_x), rp.m_ty = magic((unsigned)rp.tiles_y);
+    }
     int cin = 0;
     for (int s = 0; s < rp.nsrc; ++s) cin += rp.src_c[s];
     rp.gpp = cin / C::CKG;
@@ -823,7 +884,8 @@ int conv_ring_try(int kind, bool dgrad, const ConvKParams &kp, hipStream_t st, c
     if (tw == 8 && mode == RM_K3S1) return 1;
     if (kp.cout > (tw == 16 && mode == RM_K3S1 ? 512 : 1024)) return 1;   // the bias vector's LDS slot (RgCfg::BIAS_FLOATS)
     const long units = (long)kp.LW * kp.LH * kp.N / 512 * ((kp.cout + 63) / 64) * ((mode == RM_CT4 || mode == RM_SP3) ? 4 : 1);
-    if (units < 192 && g_experiment != 21) return 1;   // too few units for 256 persistent workgroups: the split-K kernels do better
+    if (units < 192 && g_experiment != 21) return 1;
+    if (units >= (1l << 28)) return 1;   // 32-bit unit arithmetic in the kernel   // too few units for 256 persistent workgroups: the split-K kernels do better
     // the sign-bit variant of the data-gradient epilogue: when EVERY destination with an act' has its sign bits (PWS_OPT_EXPERIMENT 12: never)
     bool sg = dgrad && g_experiment != 12, any_act = false;
     for (int s = 0; s < kp.ndst; ++s)
