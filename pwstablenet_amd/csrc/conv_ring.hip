@@ -434,15 +434,19 @@ __global__ void __launch_bounds__(C::THREADS, C::MT == 4 ? 2 : 3) conv_ring_kern
     // The epilogue's loads are unconditional in control flow (a lane without the tensor reads 16 zero bytes instead): a load inside
     // an if leaves a control-flow merge behind, and hipcc waits vmcnt(0) at the first use
     // after every merge -- which serialised the rolling requests and the stores of the data-gradient epilogue.
+    // (address space 1 spelled out: through a generic pointer these were flat_load instructions, which count on lgkmcnt as well as vmcnt and so sat
+    //  in the way of the matrix phase's LDS reads)
+    typedef const __attribute__((address_space(1))) u32x4 *gptr16;
+    typedef const __attribute__((address_space(1))) unsigned char *gptr1;
     auto e_load = [&](const unsigned char *ptr, bool have) {
-        return *reinterpret_cast<const u32x4 *>(have ? ptr : reinterpret_cast<const unsigned char *>(&g_ring_zero16));
+        return *(gptr16)(have ? ptr : reinterpret_cast<const unsigned char *>(&g_ring_zero16));
     };
     // act' operand of slot `sl` (channel half sl & 1 of its block) at pixel `pix` into register set `dst`: the 8 bf16 values of the forward
     // tensor, or -- SG -- ONE byte of sign bits (v > 0 is all the epilogue asks of them)
     auto e_load_y = [&](const EpiBlock &e, unsigned pix, int sl, bool have, int dst) {
         const unsigned char *z = reinterpret_cast<const unsigned char *>(&g_ring_zero16);
-        if constexpr (SG) e_m[dst] = *(have ? e.y + (size_t)(pix * e.yld2 + e.yo + (unsigned)((sl & 1) * 2)) : z);
-        else e_y[dst] = *reinterpret_cast<const u32x4 *>(have ? e.y + (size_t)pix * e.yld2 + (sl & 1) * 32 : z);
+        if constexpr (SG) e_m[dst] = *(gptr1)(have ? e.y + (size_t)(pix * e.yld2 + e.yo + (unsigned)((sl & 1) * 2)) : z);
+        else e_y[dst] = *(gptr16)(have ? e.y + (size_t)pix * e.yld2 + (sl & 1) * 32 : z);
     };
     constexpr int SO = C::NCLS == 4 ? 2 : 1;   // output stride of the parity classes
     unsigned cu = u_begin;
@@ -729,8 +733,8 @@ __global__ void __launch_bounds__(C::THREADS, C::MT == 4 ? 2 : 3) conv_ring_kern
 #pragma unroll
                                 for (int k = 0; k < 8; ++k) {
                                     const unsigned keepv = (unsigned)__builtin_amdgcn_sbfe((int)m, (unsigned)k, 1u);
-                                    const unsigned a_ = __builtin_bit_cast(unsigned, v[k]), b_ = __builtin_bit_cast(unsigned, v[k] * sl);
-                                    v[k] = __builtin_bit_cast(float, (a_ & keepv) | (b_ & ~keepv));
+                                    const float vs = v[k] * sl;
+                                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(v[k]) : "v"(keepv), "v"(v[k]), "v"(vs));   // (keepv & v) | (~keepv & slope v); hipcc's own lowering of that expression is six instructions
                                 }
                             } else {
                                 const u32x4 yv = e_y[slot];
