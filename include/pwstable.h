@@ -56,8 +56,8 @@ extern "C" {
 #endif
 
 #define PWS_VERSION 5   /* 2: pws_netg_opts carries flags + x_sample_stride (round 3); 4: dpacked is the compact gradient slab
-                          (pws_netg_grad_floats / pws_netg_grad_layout), pws_netg_backward_lists (round 4); 5: pws_netg_backward_plan
-                          (round 5; additions only) */
+                          (pws_netg_grad_floats / pws_netg_grad_layout), pws_netg_backward_lists (round 4); 5: pws_netg_backward_plan,
+                          pws_netg_pack_weights_train (round 5; additions only) */
 
 #define PWS_OK 0
 #define PWS_EINVAL (-22) /* bad argument / unsupported shape */
@@ -534,6 +534,11 @@ int pws_netg_grad_layout(int input_nc, int ngf, size_t *first_float, size_t *flo
  * plan its messages (and a CPU rehearsal replay them) without a device. */
 int pws_netg_backward_plan(int input_nc, int ngf, int nparts, unsigned char *final_part);
 int pws_netg_pack_weights_dgrad(const float *const *params, float *packed_dgrad, int input_nc, int ngf,
+                                pws_stream_t stream);
+/* Both buffers of a training step at once (ABI 5).  math == PWS_MATH_BF16 and ngf % 64 == 0: the conv layers go torch layout -> bf16
+ * forward copy + bf16 data-gradient copy in ONE pass, without the fp32 packed copies nothing reads in that mode (so the buffers then
+ * serve bf16-math calls only, as pws_netg_pack_weights_for(.., PWS_MATH_BF16, ..) already implies); otherwise the two calls above. */
+int pws_netg_pack_weights_train(const float *const *params, float *packed, float *packed_dgrad, int input_nc, int ngf, int math,
                                 pws_stream_t stream);
 size_t pws_netg_train_workspace_bytes(int n, int input_nc, int ngf);
 int pws_netg_backward(const float *packed, const float *packed_dgrad, const float *x, int n, int input_nc, int ngf,

@@ -1196,7 +1196,8 @@ extern "C" int pws_netg_pack_weights(const float *const *params, float *packed, 
     return pws_netg_pack_weights_for(params, packed, input_nc, ngf, -1, stream);
 }
 
-extern "C" int pws_netg_pack_weights_for(const float *const *params, float *packed, int input_nc, int ngf, int math, pws_stream_t stream) {
+// skip (nullable, one flag per layer): layers another launch packs (pws_netg_pack_weights_train's one-pass kernel) get no blocks here
+static int pack_weights_impl(const float *const *params, float *packed, int input_nc, int ngf, int math, pws_stream_t stream, const bool *skip) {
     PWS_REQUIRE(params && packed, "pws_netg_pack_weights: NULL pointer");
     PWS_REQUIRE(input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_pack_weights: ngf must be a positive multiple of 16 (got %d)",
                 ngf);
@@ -1214,16 +1215,18 @@ extern "C" int pws_netg_pack_weights_for(const float *const *params, float *pack
         PWS_REQUIRE(params[2 * i] && params[2 * i + 1], "pws_netg_pack_weights: params[%d] is NULL", 2 * i);
         a.params[2 * i] = params[2 * i], a.params[2 * i + 1] = params[2 * i + 1];
         const PackLayer &p = a.layer[i];
+        const bool sk = skip && skip[i];
         a.first_block[i] = nb;
-        if (pack_tiled(p.kind)) nb += pack_tiles(p.kind, p.cin_pad, p.cout, p.k) + (unsigned)((p.cout + 255) / 256);   // tiles + bias blocks
+        if (sk) ;
+        else if (pack_tiled(p.kind)) nb += pack_tiles(p.kind, p.cin_pad, p.cout, p.k) + (unsigned)((p.cout + 255) / 256);   // tiles + bias blocks
         else nb += (unsigned)(((size_t)p.planes * p.cin_pad * p.cout + p.cout + 255) / 256);
         a.first_block_wino[i] = nbw;
         // (math == bf16: a layer with bf16 weights runs on them -- run_conv sets a.math whenever wb_off exists -- and never reads its Winograd copies)
-        const bool skip_wino = math == PWS_MATH_BF16 && L[i].wb_off != (size_t)-1;
+        const bool skip_wino = sk || (math == PWS_MATH_BF16 && L[i].wb_off != (size_t)-1);
         if ((p.ww_off != kNoOff || p.wr_off != kNoOff) && !skip_wino) nbw += (unsigned)(((size_t)p.cin_pad * p.cout + 255) / 256);
         Bf16Layer &q = b.layer[i];
         q.planes = p.planes, q.krows = p.cin_pad, q.ncols = p.cout, q.kpad = (p.cin_pad + 31) / 32 * 32, q.npad = (p.cout + 63) / 64 * 64;
-        q.src_off = p.w_off, q.dst_off = off32(L[i].wb_off);
+        q.src_off = p.w_off, q.dst_off = sk ? kNoOff : off32(L[i].wb_off);
         b.first_block[i] = nbb;
         if (q.dst_off != kNoOff && math != PWS_MATH_FP32) nbb += (unsigned)(q.planes * (q.kpad / 32) * (q.npad / 64));
     }
@@ -1233,8 +1236,11 @@ extern "C" int pws_netg_pack_weights_for(const float *const *params, float *pack
     return rc;
 }
 
-extern "C" int pws_netg_pack_weights_dgrad(const float *const *params, float *packed_dgrad, int input_nc, int ngf,
-                                           pws_stream_t stream) {
+extern "C" int pws_netg_pack_weights_for(const float *const *params, float *packed, int input_nc, int ngf, int math, pws_stream_t stream) {
+    return pack_weights_impl(params, packed, input_nc, ngf, math, stream, nullptr);
+}
+
+static int pack_weights_dgrad_impl(const float *const *params, float *packed_dgrad, int input_nc, int ngf, pws_stream_t stream, const bool *skip) {
     PWS_REQUIRE(params && packed_dgrad, "pws_netg_pack_weights_dgrad: NULL pointer");
     PWS_REQUIRE(input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_pack_weights_dgrad: bad ngf %d", ngf);
     size_t total = 0, dg = 0;
@@ -1253,7 +1259,7 @@ extern "C" int pws_netg_pack_weights_dgrad(const float *const *params, float *pa
         q = Bf16Layer{};
         q.dst_off = kNoOff;
         b.first_block[i] = nbb;
-        if (p.dg_off == kNoOff) continue;
+        if (p.dg_off == kNoOff || (skip && skip[i])) continue;
         PWS_REQUIRE(params[2 * i], "pws_netg_pack_weights_dgrad: params[%d] is NULL", 2 * i);
         if (pack_tiled(p.kind)) nb += pack_tiles(p.kind, p.cin, p.cout, p.k);
         else nb += (unsigned)(((size_t)p.dg_taps * p.cin * p.cout + 255) / 256);
@@ -1262,8 +1268,55 @@ extern "C" int pws_netg_pack_weights_dgrad(const float *const *params, float *pa
         if (q.dst_off != kNoOff) nbb += (unsigned)(q.planes * (q.kpad / 32) * (q.npad / 64));
     }
     a.total_blocks_dgrad = nb, b.total_blocks = nbb;
-    int rc = launch_dgrad_all(a, packed_dgrad, as_stream(stream));
+    int rc = nb ? launch_dgrad_all(a, packed_dgrad, as_stream(stream)) : PWS_OK;
     if (rc == PWS_OK) rc = launch_bf16_all(b, packed_dgrad, packed_dgrad, as_stream(stream));
+    return rc;
+}
+
+extern "C" int pws_netg_pack_weights_dgrad(const float *const *params, float *packed_dgrad, int input_nc, int ngf,
+                                           pws_stream_t stream) {
+    return pack_weights_dgrad_impl(params, packed_dgrad, input_nc, ngf, stream, nullptr);
+}
+
+// Both buffers of a TRAINING step at once.  math == PWS_MATH_BF16: the conv layers whose padded extents are the real ones (every one of them
+// at ngf % 64 == 0) go torch layout -> bf16 forward copy + bf16 data-gradient copy in ONE pass (pack16_all_kernel: one read of the 194 MB,
+// no fp32 packed copies -- nothing reads them in this mode: run_conv and the data-gradient calls take the bf16 copies whenever they
+// exist, and at these channel counts the bf16 kernels never decline); the heads' small tensors and any layer that does not qualify take
+// the ordinary path.  Otherwise: pws_netg_pack_weights_for + pws_netg_pack_weights_dgrad.
+extern "C" int pws_netg_pack_weights_train(const float *const *params, float *packed, float *packed_dgrad, int input_nc, int ngf, int math,
+                                           pws_stream_t stream) {
+    PWS_REQUIRE(params && packed && packed_dgrad, "pws_netg_pack_weights_train: NULL pointer");
+    PWS_REQUIRE(input_nc > 0 && ngf > 0 && ngf % 16 == 0, "pws_netg_pack_weights_train: ngf must be a positive multiple of 16 (got %d)", ngf);
+    bool fused[L_COUNT] = {};
+    int nfused = 0;
+    size_t total = 0, dg = 0;
+    const std::vector<Layer> L = build_layers(input_nc, ngf, &total, &dg);
+    PWS_REQUIRE(total < 0xffffffffu && dg < 0xffffffffu, "pws_netg_pack_weights_train: buffers too large for 32-bit offsets");
+    Pack16Args f{};
+    f.nlayers = L_COUNT;
+    fill_pack_layers(L, f.layer);
+    unsigned nb = 0;
+    for (int i = 0; i < L_COUNT; ++i) {
+        PWS_REQUIRE(params[2 * i] && params[2 * i + 1], "pws_netg_pack_weights_train: params[%d] is NULL", 2 * i);
+        f.params[2 * i] = params[2 * i], f.params[2 * i + 1] = params[2 * i + 1];
+        const PackLayer &p = f.layer[i];
+        const Layer &l = L[i];
+        const bool has_dg = l.dg_off != (size_t)-1;
+        bool ok = math == PWS_MATH_BF16 && g_experiment != 120 && pack_tiled(p.kind) && l.wb_off != (size_t)-1 && p.cout % 64 == 0 && p.cin_pad % 32 == 0;
+        if (ok && has_dg) ok = l.dgb_off != (size_t)-1 && p.cin % 64 == 0;   // (cout % 64 == 0 covers the data-gradient copy's k padding)
+        // every source of the layer must be a multiple of 32 channels, or the bf16 kernels decline and fall back to the fp32 copies:
+        // sources are sums of ngf multiples, ngf % 32 == 0 settles it
+        ok = ok && ngf % 32 == 0;
+        fused[i] = ok, nfused += ok ? 1 : 0;
+        f.first_block[i] = nb;
+        f.wb_off[i] = ok ? off32(l.wb_off) : kNoOff;
+        f.dgb_off[i] = ok && has_dg ? off32(l.dgb_off) : kNoOff;
+        if (ok) nb += pack_tiles(p.kind, p.cin_pad, p.cout, p.k) + (unsigned)((p.cout + 255) / 256);
+    }
+    f.total_blocks = nb;
+    int rc = nfused ? launch_pack16_all(f, packed, packed_dgrad, as_stream(stream)) : PWS_OK;
+    if (rc == PWS_OK) rc = pack_weights_impl(params, packed, input_nc, ngf, math, stream, nfused ? fused : nullptr);
+    if (rc == PWS_OK) rc = pack_weights_dgrad_impl(params, packed_dgrad, input_nc, ngf, stream, nfused ? fused : nullptr);
     return rc;
 }
 

@@ -60,6 +60,18 @@ PWS_PACK_HD static inline unsigned pack_tiles(int kind, int cin_rows, int cout, 
     return (unsigned)(((A + ta - 1) / ta) * ((B + 31) / 32));
 }
 
+// One-pass pack of a bf16 training step (round 5): torch layouts -> the bf16 forward copy AND the bf16 data-gradient copy (+ bias), one
+// read of the weights, no fp32 packed copies in between (those exist only to feed bf16_all_kernel in this mode).
+struct Pack16Args {
+    int nlayers;
+    unsigned total_blocks;
+    unsigned first_block[kPackMaxLayers];
+    unsigned wb_off[kPackMaxLayers], dgb_off[kPackMaxLayers];   // float offsets of the bf16 copies in packed / packed_dgrad (kNoOff: layer not taken / no data-gradient copy)
+    PackLayer layer[kPackMaxLayers];
+    const float *params[2 * kPackMaxLayers];
+};
+static_assert(sizeof(Pack16Args) <= 4096, "kernel argument blocks are limited to 4 KB");
+
 static_assert(sizeof(PackAllArgs) <= 4096 && sizeof(UnpackAllArgs) <= 4096 && sizeof(Bf16AllArgs) <= 4096,
               "kernel argument blocks are limited to 4 KB");
 
@@ -67,5 +79,6 @@ int launch_pack_all(const PackAllArgs &a, float *packed, hipStream_t st);
 int launch_dgrad_all(const PackAllArgs &a, float *packed_dgrad, hipStream_t st);
 int launch_bf16_all(const Bf16AllArgs &a, const float *src_base, float *dst_base, hipStream_t st);
 int launch_unpack_all(const UnpackAllArgs &a, const float *dpacked, hipStream_t st);
+int launch_pack16_all(const Pack16Args &a, float *packed, float *packed_dgrad, hipStream_t st);
 
 }  // namespace pws

@@ -317,6 +317,62 @@ __global__ void __launch_bounds__(256) unpack_all_kernel(const UnpackAllArgs a, 
     }
 }
 
+// ---- one pass for a bf16 training step: torch tensor tile -> LDS -> bf16 forward layout [plane][cout][cin_pad] AND bf16 data-gradient
+// layout [plane][cin][cout] (both k-contiguous, as bf16_all_kernel writes them), + the bias.  Only for layers whose padded extents are
+// the real ones (netg.cpp: cout % 64 == 0, cin_pad % 32 == 0; with a data-gradient copy cin % 64 == 0 too), so the tiles cover every
+// element of both destinations and nothing is left to zero-fill.  Per step and generator: 194 MB read + 2 x 97 MB written, against
+// 194 + 194 (pack) + 194 + 97 (bf16) + 194 + 194 (data-gradient pack) + 194 + 97 (bf16) with the four launches it replaces.
+__global__ void __launch_bounds__(256) pack16_all_kernel(const Pack16Args a, float *__restrict__ packed, float *__restrict__ packed_dgrad) {
+    __shared__ float lds[kPackTileFloats];
+    const int l = find_layer(a.first_block, a.nlayers, blockIdx.x);
+    const PackLayer &L = a.layer[l];
+    const unsigned b = blockIdx.x - a.first_block[l];
+    const unsigned ntiles = pack_tiles(L.kind, L.cin_pad, L.cout, L.k);
+    if (b >= ntiles) {   // the bias blocks behind the tiles
+        const unsigned i = (b - ntiles) * 256 + threadIdx.x;
+        if (i < (unsigned)L.cout) packed[L.b_off + i] = a.params[2 * l + 1][i];
+        return;
+    }
+    const PackTile t = pack_tile_of(L, b, L.cin_pad);
+    pack_tile_load(t, a.params[2 * l], t.iohw ? L.cin : L.cout, t.iohw ? L.cout : L.cin, lds);
+    __syncthreads();
+    const int nci = t.iohw ? t.TA : 32, nco = t.iohw ? 32 : t.TA;   // extents of the tile in ci / co
+    const int ci0 = t.iohw ? t.a0 : t.b0, co0 = t.iohw ? t.b0 : t.a0;
+    const int sci = t.iohw ? t.PA : t.PB, sco = t.iohw ? t.PB : t.PA;   // LDS strides of ci / co
+    {   // forward: [plane][co][ci], ci pairs per dword
+        unsigned *dst = reinterpret_cast<unsigned *>(packed) + a.wb_off[l];
+        const int kpad = L.cin_pad, half = nci / 2;
+        const int n = L.planes * nco * half;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int k2 = i % half, r = i / half;
+            const int co_l = r % nco, pl = r / nco;
+            const int q = pack_fwd_tap(L.kind, L.k, pl);
+            const float *src = lds + (2 * k2) * sci + co_l * sco + q;
+            const int ci = ci0 + 2 * k2, co = co0 + co_l;
+            if (ci < kpad && co < L.cout) dst[(((size_t)pl * L.cout + co) * kpad + ci) >> 1] = cvt_pk_bf16(src[0], src[sci]);
+        }
+    }
+    if (a.dgb_off[l] != kNoOff) {   // data gradient: [plane][ci][co], co pairs per dword; a plane element without a tap is zero
+        unsigned *dst = reinterpret_cast<unsigned *>(packed_dgrad) + a.dgb_off[l];
+        const int kpad = L.cout, half = nco / 2;
+        const int n = L.dg_taps * nci * half;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int k2 = i % half, r = i / half;
+            const int ci_l = r % nci, pl = r / nci;
+            const int q = pack_dgrad_tap(L.kind, pl);
+            const float *src = lds + ci_l * sci + (2 * k2) * sco + (q >= 0 ? q : 0);
+            const int ci = ci0 + ci_l, co = co0 + 2 * k2;
+            if (ci < L.cin && co < kpad) dst[(((size_t)pl * L.cin + ci) * kpad + co) >> 1] = q >= 0 ? cvt_pk_bf16(src[0], src[sco]) : 0u;
+        }
+    }
+}
+
+int launch_pack16_all(const Pack16Args &a, float *packed, float *packed_dgrad, hipStream_t st) {
+    if (!a.total_blocks) return PWS_OK;
+    hipLaunchKernelGGL(pack16_all_kernel, dim3(a.total_blocks), dim3(256), 0, st, a, packed, packed_dgrad);
+    return check_launch("pack16_all_kernel");
+}
+
 int launch_pack_all(const PackAllArgs &a, float *packed, hipStream_t st) {
     hipLaunchKernelGGL(pack_all_kernel, dim3(a.total_blocks), dim3(256), 0, st, a, packed);
     if (a.total_blocks_wino) hipLaunchKernelGGL(wino_all_kernel, dim3(a.total_blocks_wino), dim3(256), 0, st, a, packed);

@@ -133,6 +133,7 @@ SIGNATURES = {
     "pws_netg_packed_floats": (_S, [_I, _I]),
     "pws_netg_pack_weights": (_I, [ctypes.POINTER(_P), _P, _I, _I, _P]),
     "pws_netg_pack_weights_for": (_I, [ctypes.POINTER(_P), _P, _I, _I, _I, _P]),
+    "pws_netg_pack_weights_train": (_I, [ctypes.POINTER(_P), _P, _P, _I, _I, _I, _P]),
     "pws_netg_workspace_bytes": (_S, [_I, _I, _I, _I]),
     "pws_netg_forward": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _S, _P, _P, _P, _P]),
     "pws_netg_forward_opts": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _S, _P, _P, _P, ctypes.POINTER(PwsNetgOpts), _P]),

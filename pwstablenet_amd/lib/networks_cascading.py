@@ -231,9 +231,11 @@ class UnetGenerator(nn.Module):
                 ts += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
         return tuple((p.data_ptr(), p._version) for p in ts)
 
-    def packed_weights(self, raw=False):
+    def packed_weights(self, raw=False, train=False):
         """Device buffer with every layer in the kernels' layout; re-packed when a parameter changed.  raw: the conv weights as
-        they are (training-mode BatchNorm normalises with batch statistics), not folded with the running statistics."""
+        they are (training-mode BatchNorm normalises with batch statistics), not folded with the running statistics.
+        train: a backward will follow -- the data-gradient buffer is packed in the same go (pws_netg_pack_weights_train: in bf16 mode
+        ONE pass over the weights makes both bf16 copies and skips the fp32 packed copies nobody reads there)."""
         key = (("raw",) + tuple((p.data_ptr(), p._version) for p in self._ordered_params())) if raw else (("eff",) + self._weights_key())
         # the buffer serves ONE math mode (pws_netg_pack_weights_for: a bf16 training loop does not re-make the Winograd copies after
         # every optimizer step, an fp32 one not the bf16 copies); set_math() to the other mode re-packs
@@ -248,9 +250,18 @@ class UnetGenerator(nn.Module):
             if self._packed is None or self._packed.numel() != nfl or self._packed.device != dev:
                 self._packed = torch.empty(nfl, device=dev, dtype=torch.float32)
             ptrs = (ctypes.c_void_p * len(params))(*[p.data_ptr() for p in params])
-            A.check(A.lib().pws_netg_pack_weights_for(ptrs, A.ptr(self._packed), self.input_nc, self.ngf,
-                                                      A.MATH_BF16 if self.math == "bf16" else A.MATH_FP32, A.current_stream()),
-                    "pws_netg_pack_weights_for")
+            math = A.MATH_BF16 if self.math == "bf16" else A.MATH_FP32
+            if train and self.math == "bf16" and not self.use_BN:
+                dkey = tuple((p.data_ptr(), p._version) for p in params)
+                nfd = A.lib().pws_netg_packed_dgrad_floats(self.input_nc, self.ngf)
+                if self._packed_dgrad is None or self._packed_dgrad.numel() != nfd or self._packed_dgrad.device != dev:
+                    self._packed_dgrad = torch.empty(nfd, device=dev, dtype=torch.float32)
+                A.check(A.lib().pws_netg_pack_weights_train(ptrs, A.ptr(self._packed), A.ptr(self._packed_dgrad), self.input_nc, self.ngf, math,
+                                                            A.current_stream()), "pws_netg_pack_weights_train")
+                self._packed_dgrad_key = dkey
+            else:
+                A.check(A.lib().pws_netg_pack_weights_for(ptrs, A.ptr(self._packed), self.input_nc, self.ngf, math, A.current_stream()),
+                        "pws_netg_pack_weights_for")
             self._packed_key = key
         return self._packed
 
@@ -404,7 +415,7 @@ class UnetGenerator(nn.Module):
                 x = x.contiguous()
         n = x.shape[0]
         S = 256
-        packed = self.packed_weights()
+        packed = self.packed_weights(train=train_ctx is not None)
         if train_ctx is not None:
             ws = self._take_train_arena(A.lib().pws_netg_train_workspace_bytes(n, self.input_nc, self.ngf) + 256, x.device)
         elif ws is None:

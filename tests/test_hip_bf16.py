@@ -813,6 +813,52 @@ def test_netg_bf16_training_step_gradients_vs_fp32(hip, store):
     assert worst < 0.15, (worst, worst_name)
 
 
+@pytest.mark.parametrize("ngf", [64, 32])
+def test_one_pass_training_pack_gives_the_bits_of_the_four_pass_pack(hip, ngf):
+    """pws_netg_pack_weights_train (bf16 math): torch layouts -> bf16 forward + bf16 data-gradient copies in one pass, no fp32 packed
+    copies of the conv layers.  A deterministic training step on it must give the fields, the loss and all 92 gradients BIT FOR BIT as on
+    the buffers the separate calls pack (PWS_OPT_EXPERIMENT 120 switches the one-pass kernel off); both packed buffers are poisoned with
+    NaN first, so a read of a copy the one-pass kernel does not make would show.  ngf 32: layers of 32 output channels do not qualify
+    (padded to 64 in the bf16 layout) and take the ordinary path next to the ones that do."""
+    from pwstablenet_amd import synth
+    net = _make_net("W1", ngf)
+    net.module.set_math("bf16")
+    net.module.deterministic = True
+    x = torch.from_numpy(synth.make_window(2, 31, seed=21)).cuda()
+    tgt = torch.from_numpy(np.random.RandomState(6).standard_normal((2, 256, 256, 2)).astype(np.float32) * 0.1).cuda()
+    L = hip.lib()
+
+    def step(exp):
+        L.pws_set_option(hip.OPT_EXPERIMENT, exp)
+        try:
+            m = net.module
+            m._packed = torch.full((L.pws_netg_packed_floats(31, ngf),), float("nan"), device="cuda")
+            m._packed_dgrad = torch.full((L.pws_netg_packed_dgrad_floats(31, ngf),), float("nan"), device="cuda")
+            m._packed_key = m._packed_dgrad_key = None
+            net.zero_grad(set_to_none=True)
+            L.pws_prof_enable(1)
+            grids, resid = net(x)
+            loss = sum(((g - tgt) ** 2).mean() for g in grids) + sum((r ** 2).mean() for r in resid)
+            loss.backward()
+            L.pws_prof_enable(0)
+            names = [r[0] for r in hip.prof_collect()]
+            return [g.detach().clone() for g in grids], loss.item(), [p.grad.clone() for p in net.parameters()], names
+        finally:
+            L.pws_set_option(hip.OPT_EXPERIMENT, 0)
+
+    g1, l1, d1, _ = step(0)
+    g0, l0, d0, _ = step(120)
+    assert np.isfinite(l1) and l1 == l0
+    assert all(torch.equal(a, b) for a, b in zip(g1, g0))
+    assert all(torch.equal(a, b) for a, b in zip(d1, d0))
+    # and the inference path on the one-pass buffers (same weights version: no re-pack)
+    with torch.no_grad():
+        f_train_pack = net(x, False).clone()
+        net.module._packed_key = None
+        f_own_pack = net(x, False)
+    assert torch.equal(f_train_pack, f_own_pack)
+
+
 def _sign_bytes(y_nhwc_bf16):
     """Bit (c & 7) of byte [pixel][c / 8] = (y[pixel][c] > 0): pws_conv_args.out_sign's layout, from the bf16 tensor itself."""
     pos = (y_nhwc_bf16.float() > 0).to(torch.uint8).cpu().numpy()
