@@ -175,7 +175,7 @@ struct BfCfg {
 // destination is not 16-byte aligned and for split-K partials).  For that the 64 output channels of a workgroup are dealt to
 // the lanes as (2 l, 2 l + 1) -> (nt 0, nt 1) instead of (l, l + 32): the weight rows are permuted while they are staged
 // (LDS row (nn & 1) * 32 + (nn >> 1) holds output channel nn), the MFMA side is unchanged.  Requires NT == 2.
-// ABL (interference probe, tools/probes/kernel_victim_probe.py; PWS_OPT_EXPERIMENT 2100 + ABL, one tile shape only): while this kernel
+// ABL (interference probe, tools/probes/kernel_victim_probe.py; -DPWS_INTERFERENCE_PROBE builds only: PWS_OPT_EXPERIMENT 2100 + ABL, one tile shape only): while this kernel
 // runs, kernels of OTHER streams and processes that share its CUs compute wrong values in a few lanes.  Variants to find out what in it does that:
 // 1 no matrix instructions, 2 no LDS operand reads, 4 no LDS stores, 8 no global loads (results meaningless), 16 the gfx90a instruction
 // v_mfma_f32_32x32x8_bf16_1k twice in place of v_mfma_f32_32x32x16_bf16 (same results up to the summation order).  Measured: 1 -> clean; 14 (the x16
@@ -609,6 +609,7 @@ static int launch_bf_io(ConvKParams &kp, hipStream_t st) {
         attr_set = true;
     }
     const dim3 grid = conv_grid(kp, C::BN);
+#ifdef PWS_INTERFERENCE_PROBE   // diagnostic build only (round 5: the six probe instantiations are no longer part of the shipped library; -DPWS_INTERFERENCE_PROBE brings them back for tools/probes/kernel_victim_probe.py)
     if constexpr (IO16 && C::KS == 3 && C::TH == 16 && C::TW == 16 && C::STRIDE == 1 && C::SUBPIX == 0) {   // the probe variants of this one tile (see conv_bf16_kernel)
         switch (g_experiment) {
 #define PWS_BF_ABL_CASE(k) case 2100 + k: (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_kernel<C, IO16, k>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES); hipLaunchKernelGGL((conv_bf16_kernel<C, IO16, k>), grid, dim3(C::THREADS), C::LDS_BYTES, st, kp); return check_launch("conv_bf16_kernel");
@@ -616,6 +617,7 @@ static int launch_bf_io(ConvKParams &kp, hipStream_t st) {
         default: break;
         }
     }
+#endif
     hipLaunchKernelGGL((conv_bf16_kernel<C, IO16>), grid, dim3(C::THREADS), C::LDS_BYTES, st, kp);
     return check_launch("conv_bf16_kernel");
 }

@@ -848,7 +848,10 @@ static int ring_launch_tile(int tw, RingParams &rp, hipStream_t st) {
 // is covered: bf16 storage with 16-byte epilogue stores, every source a multiple of 32 channels, a logical map of at least
 // 16 x 32 pixels and enough units to give every CU one.  Returns 1 when not covered (the caller runs conv_bf16_kernel).
 int conv_ring_try(int kind, bool dgrad, const ConvKParams &kp, hipStream_t st, const ProfInfo &pi) {
-    if (!kp.io_bf16 || !kp.epi16 || g_experiment == 20 || (g_experiment >= 2100 && g_experiment < 2140)) return 1;   // (2100 ..: the probe variants of conv_bf16_kernel)
+    if (!kp.io_bf16 || !kp.epi16 || g_experiment == 20) return 1;
+#ifdef PWS_INTERFERENCE_PROBE
+    if (g_experiment >= 2100 && g_experiment < 2140) return 1;   // (2100 ..: the probe variants of conv_bf16_kernel)
+#endif
     for (int s = 0; s < kp.nsrc; ++s)
         if (kp.src_c[s] % 32 != 0 || kp.src_ld[s] % 8 != 0 || (reinterpret_cast<size_t>(kp.src_ptr[s]) & 15)) return 1;
     int tw;   // tile shape by map size: whole tiles only
