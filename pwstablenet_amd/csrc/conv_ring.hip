@@ -143,7 +143,9 @@ __device__ __forceinline__ void ring_dma16(unsigned lds_addr, unsigned voff, __a
 }
 // the same inside a bracket that saved M0 and restores it (one save / restore per group instead of per piece)
 __device__ __forceinline__ void ring_dma16_m0(unsigned lds_addr, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff));
+    // (s_nop 3 + the two instructions behind it = the 5 wait states between a VALU write of an SGPR -- v_readfirstlane, or hipcc reloading a spilled
+    //  scalar with v_readlane right in front of this statement -- and a VMEM instruction that reads it as descriptor / offset: hipcc pads nothing for inline asm)
+    asm volatile("s_nop 3\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff));
 }
 template <int N>
 __device__ __forceinline__ void ring_wait_vmcnt() {

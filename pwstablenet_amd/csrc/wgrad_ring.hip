@@ -112,6 +112,12 @@ __device__ __forceinline__ void wrg_dma16(unsigned lds_addr, unsigned voff, __am
                  : "=&s"(keep)
                  : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff));
 }
+// the same inside a bracket that saved M0 and restores it (once per tile instead of per piece)
+__device__ __forceinline__ void wrg_dma16_m0(unsigned lds_addr, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned soff) {
+    // (s_nop 3 + the two instructions behind it = the 5 wait states between a VALU write of an SGPR -- v_readfirstlane, or hipcc reloading a spilled
+    //  scalar with v_readlane right in front of this statement -- and a VMEM instruction that reads it as descriptor / offset: hipcc pads nothing for inline asm)
+    asm volatile("s_nop 3\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff));
+}
 constexpr unsigned kWrgOob = 0x7ffffff0u;
 __device__ __forceinline__ unsigned uniq(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ const char *uniq(const char *ptr) {
@@ -156,7 +162,10 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
 
     if (wv >= C::MWAVES) {
         // =========================================================================================== loader waves
-        const int lw = wv - C::MWAVES;
+        // the loader's code is instantiated once per loader wave (lw a compile-time constant): which plane / descriptor a DMA piece uses is then
+        // known per piece -- with a run-time lw every piece chose its descriptor by chains of scalar selects (16 per piece)
+        auto loader = [&](auto LWC) {
+        constexpr int lw = decltype(LWC)::value;
         // piece pc = it * 4 + lw of a tile image: [x plane 0 | x plane 1 | dy plane 0 | dy plane 1], a plane = rows of 64 bytes (4 lanes)
         int desc[C::NL];   // kind << 28 | row-in-plane << 2 | 16-byte slot, or -1 (filler / past the plane)
 #pragma unroll
@@ -208,60 +217,106 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
                 geo[it] = ty << 10 | tx;
             }
         }
+        // ---- per-tile work of a loader (round 5).  Rounds 2-4 decoded the tile index with three integer divisions, rebuilt five buffer
+        // descriptors from 64-bit pointer arithmetic and took every scalar through v_readfirstlane, per tile: ~2 600 lines of ISA per tile
+        // with ~480 v_readlane / v_writelane of spilled scalar registers, while a tile is only 4 096 cycles of matrix instructions -- the
+        // LOADERS' instruction stream, not the tile stream's bandwidth, is what the matrix waves waited for (57-63 % of their life at the
+        // barrier).  Now: the tile coordinates advance by constant increments with carries; a descriptor = the tensor's base + the
+        // sample's offset (two scalar adds per tensor and tile; num_records = ONE sample's extent: the out-of-range lanes' zero fill), nothing
+        // goes through v_readfirstlane; M0 is saved / restored once per tile.
+        const int tpx = p.tiles_x, tpy = p.tiles_y;
+        int t_tx = bx % tpx, t_ty = (bx / tpx) % tpy, t_nn = bx / (tpx * tpy);
+        const int d_tx = nsplit % tpx, d_ty = (nsplit / tpx) % tpy, d_nn = nsplit / (tpx * tpy);
+        const char *xb1[4], *xb2[4];
+        unsigned ximg[4], xrec[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ld = wrgsel4(p.src_ld, xs[q]);
+            ximg[q] = (unsigned)((size_t)p.H * p.W * ld * 2);                 // bytes of one sample (< 2^31: wgrad_ring_try)
+            xrec[q] = ximg[q] - (unsigned)xch[q] * 2u;
+            xb1[q] = static_cast<const char *>(wrgsel4(p.src_ptr, xs[q])) + (size_t)xch[q] * 2;
+            xb2[q] = p.N1 < p.N ? static_cast<const char *>(wrgsel4(p.src_ptr2, xs[q])) + (size_t)xch[q] * 2 : xb1[q];
+        }
+        const unsigned gimg = (unsigned)((size_t)p.OH * p.OW * p.gout_ld * 2), grec = gimg - (unsigned)co0 * 2u;
+        const char *gb1 = static_cast<const char *>(p.gout) + (size_t)co0 * 2;
+        const char *gb2 = p.N1 < p.N ? static_cast<const char *>(p.gout2) + (size_t)co0 * 2 : gb1;
         int tile = bx, pbuf = 0;
         auto stage = [&]() {
-            const unsigned d_base = uniq((unsigned)(pbuf * C::IMG_BYTES)) + (unsigned)(lw * 1024);
+            const unsigned d_base = (unsigned)(pbuf * C::IMG_BYTES) + (unsigned)(lw * 1024);
             pbuf = pbuf + 1 == C::R ? 0 : pbuf + 1;
             if (tile >= p.ntiles || (C::ABL & 1)) return;   // past the last tile: nothing reads that buffer (the waits are vmcnt(0): no piece count to keep)
-            const int tt = tile;
-            const int tx_i = tt % p.tiles_x, ty_i = (tt / p.tiles_x) % p.tiles_y, nn = tt / (p.tiles_x * p.tiles_y);
-            const bool second = nn >= p.N1;            // (scalar) the tile belongs to the second operand pair
-            const int n0 = second ? nn - p.N1 : nn;
-            const int y0 = ty_i * C::TH, x0 = tx_i * C::TW;
+            const bool second = t_nn >= p.N1;            // (scalar) the tile belongs to the second operand pair
+            const unsigned n0 = (unsigned)(second ? t_nn - p.N1 : t_nn);
+            const int y0 = t_ty * C::TH, x0 = t_tx * C::TW;
             const int iy0 = C::S2 ? 2 * y0 - 1 : y0 - pad_y, ix0 = C::S2 ? 2 * x0 - 1 : x0 - pad_x;
-            // descriptors: one sample of each tensor (offsets stay below 2^31 whatever the batch)
             __amdgpu_buffer_rsrc_t rx[4];
-            unsigned sx[4];
+            unsigned sxs[4], sxv[4];   // sample offset (the instruction's scalar offset) / offset of the tile's first halo pixel inside the sample (added to the lanes' offsets: may be negative at the border)
 #pragma unroll
             for (int q = 0; q < C::XPL; ++q) {
-                const int ld = wrgsel4(p.src_ld, xs[q]);
-                const size_t img = (size_t)p.H * p.W * ld * 2;
-                const char *b = uniq(static_cast<const char *>(second ? wrgsel4(p.src_ptr2, xs[q]) : wrgsel4(p.src_ptr, xs[q])) + (size_t)n0 * img + (size_t)xch[q] * 2);
-                rx[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(b), 0, (int)uniq((unsigned)(img - (size_t)xch[q] * 2)), 0x00020000);
-                sx[q] = uniq((unsigned)((iy0 * p.W + ix0) * (int)ldx[q]));
+                // (the sample goes into the descriptor's BASE -- two scalar adds -- not into the instruction's scalar offset: that offset takes part
+                //  in the range check against num_records, which is ONE sample's extent here; measured: every sample but the first read zeros)
+                rx[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>((second ? xb2[q] : xb1[q]) + (size_t)n0 * ximg[q]), 0, (int)xrec[q], 0x00020000);
+                sxs[q] = 0u;
+                sxv[q] = (unsigned)((iy0 * p.W + ix0) * (int)ldx[q]);
             }
-            const size_t gimg = (size_t)p.OH * p.OW * p.gout_ld * 2;
-            const char *gb = uniq(static_cast<const char *>(second ? p.gout2 : p.gout) + (size_t)n0 * gimg + (size_t)co0 * 2);
-            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gb), 0, (int)uniq((unsigned)(gimg - (size_t)co0 * 2)), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>((second ? gb2 : gb1) + (size_t)n0 * gimg), 0, (int)grec, 0x00020000);
+            const unsigned sgs = 0u;
             const bool x_inside = iy0 >= 0 && iy0 + C::IH <= p.H && ix0 >= 0 && ix0 + C::IW <= p.W;   // scalar
+            // dy: first pixel of the tile per class of the pair (px = 0 / 1), and whether the whole tile (both classes) lies inside
+            const int fy = C::SUBPIX ? 2 * y0 + py : y0;
+            const int fx0 = C::SUBPIX ? 2 * x0 + (C::PAIR ? 0 : px) : x0;
+            const unsigned sgv0 = (unsigned)((fy * p.OW + fx0) * (int)ldg), sgv1 = sgv0 + ldg;   // (PAIR: class px = 1 starts one dy pixel to the right)
+            const bool g_inside = y0 + C::TH <= p.LH && x0 + C::TW <= p.LW && fy + S * (C::TH - 1) < p.OH && fx0 + (C::PAIR ? 1 : 0) + S * (C::TW - 1) < p.OW;
+            unsigned keep;
+            asm volatile("s_nop 4\n\ts_mov_b32 %0, m0" : "=s"(keep));
+            if (x_inside && g_inside) {
+                // ---- a tile inside the image (all but the border tiles): ONE vector add per piece, no predicate
 #pragma unroll
-            for (int it = 0; it < C::NL; ++it) {
-                const int pc = it * C::LWAVES + lw;   // wave-uniform: the kind of a piece is too
-                const unsigned dst = d_base + (unsigned)(it * C::LWAVES * 1024);
-                if (pc < C::XPL * C::XPP) {
-                    const int q = pc / C::XPP;   // wave-uniform
-                    unsigned v = loc[it] + (C::XPL == 1 ? sx[0] : (C::XPL == 2 ? (q ? sx[1] : sx[0]) : (q < 2 ? (q ? sx[1] : sx[0]) : (q == 2 ? sx[2] : sx[3]))));   // (a filler lane stays out of range: ~2^31 + an offset inside one sample)
-                    if (!x_inside) {
+                for (int it = 0; it < C::NL; ++it) {
+                    const int pc = it * C::LWAVES + lw;   // wave-uniform: the kind of a piece is too
+                    const unsigned dst = d_base + (unsigned)(it * C::LWAVES * 1024);
+                    if (pc < C::XPL * C::XPP) {
+                        const int q = pc / C::XPP;   // wave-uniform
+                        const unsigned v = loc[it] + (C::XPL == 1 ? sxv[0] : (C::XPL == 2 ? (q ? sxv[1] : sxv[0]) : (q < 2 ? (q ? sxv[1] : sxv[0]) : (q == 2 ? sxv[2] : sxv[3]))));   // (a filler lane stays out of range: ~2^31 + an offset inside one sample)
+                        wrg_dma16_m0(dst, v, C::XPL == 1 ? rx[0] : (C::XPL == 2 ? (q ? rx[1] : rx[0]) : (q < 2 ? (q ? rx[1] : rx[0]) : (q == 2 ? rx[2] : rx[3]))),
+                                     C::XPL == 1 ? sxs[0] : (C::XPL == 2 ? (q ? sxs[1] : sxs[0]) : (q < 2 ? (q ? sxs[1] : sxs[0]) : (q == 2 ? sxs[2] : sxs[3]))));
+                    } else {
+                        const int g = (pc - C::XPL * C::XPP) / C::GPP;   // dy plane: (class of the pair,) output-channel half
+                        wrg_dma16_m0(dst, loc[it] + ((C::PAIR && (g >> 1)) ? sgv1 : sgv0), rg, sgs);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < C::NL; ++it) {
+                    const int pc = it * C::LWAVES + lw;
+                    const unsigned dst = d_base + (unsigned)(it * C::LWAVES * 1024);
+                    if (pc < C::XPL * C::XPP) {
+                        const int q = pc / C::XPP;
+                        unsigned v = loc[it] + (C::XPL == 1 ? sxv[0] : (C::XPL == 2 ? (q ? sxv[1] : sxv[0]) : (q < 2 ? (q ? sxv[1] : sxv[0]) : (q == 2 ? sxv[2] : sxv[3]))));
                         const int iy = iy0 + (geo[it] >> 10), ix = ix0 + (geo[it] & 0x3ff);
                         v = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? v : kWrgOob;
-                    }
-                    wrg_dma16(dst, v, C::XPL == 1 ? rx[0] : (C::XPL == 2 ? (q ? rx[1] : rx[0]) : (q < 2 ? (q ? rx[1] : rx[0]) : (q == 2 ? rx[2] : rx[3]))), 0u);
-                } else {
-                    const int g = (pc - C::XPL * C::XPP) / C::GPP;   // dy plane: (class of the pair,) output-channel half
-                    const int gpx = C::PAIR ? g >> 1 : px;
-                    const int fy = C::SUBPIX ? 2 * y0 + py : y0, fx = C::SUBPIX ? 2 * x0 + gpx : x0;   // dy pixel of the tile's first pixel
-                    const unsigned sg = uniq((unsigned)((fy * p.OW + fx) * (int)ldg));
-                    const bool g_inside = y0 + C::TH <= p.LH && x0 + C::TW <= p.LW && fy + S * (C::TH - 1) < p.OH && fx + S * (C::TW - 1) < p.OW;
-                    unsigned v = loc[it] + sg;
-                    if (!g_inside) {
+                        wrg_dma16_m0(dst, v, C::XPL == 1 ? rx[0] : (C::XPL == 2 ? (q ? rx[1] : rx[0]) : (q < 2 ? (q ? rx[1] : rx[0]) : (q == 2 ? rx[2] : rx[3]))),
+                                     C::XPL == 1 ? sxs[0] : (C::XPL == 2 ? (q ? sxs[1] : sxs[0]) : (q < 2 ? (q ? sxs[1] : sxs[0]) : (q == 2 ? sxs[2] : sxs[3]))));
+                    } else {
+                        const int g = (pc - C::XPL * C::XPP) / C::GPP;
+                        const int gpx = C::PAIR ? g >> 1 : 0;
+                        const int fx = fx0 + gpx;
+                        unsigned v = loc[it] + (gpx ? sgv1 : sgv0);
                         const int y = y0 + (geo[it] >> 10), x = x0 + (geo[it] & 0x3ff);
                         const int oy = fy + S * (geo[it] >> 10), ox = fx + S * (geo[it] & 0x3ff);
                         v = (y < p.LH && x < p.LW && oy < p.OH && ox < p.OW) ? v : kWrgOob;
+                        wrg_dma16_m0(dst, v, rg, sgs);
                     }
-                    wrg_dma16(dst, v, rg, 0u);
                 }
             }
+            asm volatile("s_mov_b32 m0, %0" ::"s"(keep));
+            // next tile of this workgroup: + nsplit, as increments of (column, row, sample) with carries
             tile += nsplit;
+            t_tx += d_tx;
+            const int cx = t_tx >= tpx ? 1 : 0;
+            t_tx -= cx ? tpx : 0, t_ty += d_ty + cx;
+            const int cy = t_ty >= tpy ? 1 : 0;
+            t_ty -= cy ? tpy : 0, t_nn += d_nn + cy;
         };
         stage();
 #pragma unroll
@@ -277,6 +332,12 @@ __global__ void __launch_bounds__(C::THREADS, 3) wgrad_ring_kernel(const WgradRi
             stage();                                            // tile s + R - 1 into the buffer tile s - 1 occupied (nothing past the end)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the filler pieces still target this workgroup's LDS
+        };
+        const int lw_rt = wv - C::MWAVES;
+        if (lw_rt == 0) loader(std::integral_constant<int, 0>{});
+        else if (lw_rt == 1) loader(std::integral_constant<int, 1>{});
+        else if (lw_rt == 2) loader(std::integral_constant<int, 2>{});
+        else loader(std::integral_constant<int, 3>{});
         return;
     }
 
