@@ -87,6 +87,11 @@ __device__ __forceinline__ void ringf_dma16(unsigned lds_addr, unsigned voff, __
                  : "=&s"(keep)
                  : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff));
 }
+// the same inside a bracket that saved M0 and restores it; s_nop 3 + the two instructions behind it = the 5 wait states a VALU-written
+// SGPR needs before a VMEM instruction reads it (conv_ring.hip)
+__device__ __forceinline__ void ringf_dma16_m0(unsigned lds_addr, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned soff) {
+    asm volatile("s_nop 3\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff));
+}
 template <int N>
 __device__ __forceinline__ void ringf_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -160,108 +165,106 @@ __global__ void __launch_bounds__(C::THREADS, 3) conv_ringf_kernel(const RingfPa
             }
         }
         const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, (int)p.w_bytes, 0x00020000);
-        unsigned pu = u_begin;
-        int pplane = 0, ps = 0, pc0 = 0, pwrow = 0, pbuf = 0;
-        RingfUnit PU = ringf_unit(p, pu, C::CO_UNIT);
-        unsigned loc[C::NL], cv[C::NL];   // cached per-lane source offsets (see stage())
+        // The groups are walked by nested loops (unit, plane, source, 16-channel group), as in conv_ring.hip since round 5: what depends on
+        // (unit, plane, source) -- descriptor, halo offset, per-lane offsets cv[] -- is set up once per source, the innermost loop bumps two
+        // scalar offsets.  (The cursor + stage() form of rounds 2-4 compiled to several hundred scalar instructions per group.)  Protocol
+        // unchanged: group g is issued behind barrier B_(g - R + 1); R - 1 barriers remain at the end.
+        unsigned loc[C::NL], cv[C::NL];   // cached per-lane source offsets
         int loc_ld = -1;
 #pragma unroll
         for (int it = 0; it < C::NL; ++it) loc[it] = kRingfOob, cv[it] = kRingfOob;
-        auto stage = [&]() {
-            const unsigned d_base = unif((unsigned)(pbuf * C::GROUP_BYTES)) + (unsigned)(lw * 1024);
-            pbuf = pbuf + 1 == C::R ? 0 : pbuf + 1;
-            if (pu >= u_end) {
-                // past the last group: filler pieces keep every loader's DMA count per group constant (the counted waits)
+        unsigned issued = 0, dslot = 0;
+        const bool mix_in = C::MIX_IT >= 0 && C::MIX_IT * C::LWAVES + lw < C::IN_WI;
+        for (unsigned pu = u_begin; pu < u_end; pu += u_step) {
+            const RingfUnit PU = ringf_unit(p, pu, C::CO_UNIT);
+            for (int pplane = 0; pplane < C::NPLANES; ++pplane) {
+                const int a = pplane >> 1, b = pplane & 1;
+                int oy, ox;   // view coordinates of the halo's first pixel
+                if constexpr (C::MODE == RF_K3S1) oy = PU.y0 * C::TH - 1, ox = PU.x0 * C::TW - 1;
+                else if constexpr (C::MODE == RF_CT4) oy = PU.y0 * C::TH - (1 - PU.py), ox = PU.x0 * C::TW - (1 - PU.px);
+                else oy = PU.y0 * C::TH - a, ox = PU.x0 * C::TW - b;
+                unsigned d_sw = unif((unsigned)((size_t)PU.co0 * 4));   // + 16 channel rows of cout floats per group of the plane
+                const unsigned wplane = (unsigned)(p.cin_pad * p.cout * 4);
+                const unsigned wstep = (unsigned)(C::CKG * p.cout * 4);
+                for (int ps = 0; ps < p.nsrc; ++ps) {
+                    const int ld = selq4(p.src_ld, ps), srcc = selq4(p.src_c, ps);
+                    const size_t img = (size_t)p.H * p.W * ld * 4;   // bytes of one sample
+                    const char *base_in = unif(reinterpret_cast<const char *>(selq4(p.src_ptr, ps)) + (size_t)PU.n0 * img);
+                    const __amdgpu_buffer_rsrc_t d_rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base_in), 0, (int)unif((unsigned)img), 0x00020000);
+                    const unsigned ldb = (unsigned)ld * 4u;
+                    const __amdgpu_buffer_rsrc_t d_rmix = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<char *>(unif(mix_in ? base_in : reinterpret_cast<const char *>(p.w))), 0,
+                        (int)unif(mix_in ? (unsigned)img : (unsigned)p.w_bytes), 0x00020000);
+                    constexpr int S = C::NPLANES == 4 ? 2 : 1;
+                    if (ld != loc_ld) {
+                        loc_ld = ld;
 #pragma unroll
-                for (int it = 0; it < C::NL; ++it) ringf_dma16(d_base + (unsigned)(it * C::LWAVES * 1024), kRingfOob, rsrc_w, 0u);
-                return;
-            }
-            const int a = pplane >> 1, b = pplane & 1;
-            int oy, ox;   // view coordinates of the halo's first pixel
-            if constexpr (C::MODE == RF_K3S1) oy = PU.y0 * C::TH - 1, ox = PU.x0 * C::TW - 1;
-            else if constexpr (C::MODE == RF_CT4) oy = PU.y0 * C::TH - (1 - PU.py), ox = PU.x0 * C::TW - (1 - PU.px);
-            else oy = PU.y0 * C::TH - a, ox = PU.x0 * C::TW - b;
-            const int ld = selq4(p.src_ld, ps);
-            const size_t img = (size_t)p.H * p.W * ld * 4;   // bytes of one sample
-            const char *base_in = unif(reinterpret_cast<const char *>(selq4(p.src_ptr, ps)) + (size_t)PU.n0 * img);
-            const __amdgpu_buffer_rsrc_t d_rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base_in), 0, (int)unif((unsigned)img), 0x00020000);
-            const unsigned ldb = (unsigned)ld * 4u;
-            const unsigned d_sin = unif((unsigned)(pc0 * 4));
-            const unsigned d_sw = unif((unsigned)(((size_t)pwrow * p.cout + PU.co0) * 4));
-            const unsigned wplane = (unsigned)(p.cin_pad * p.cout * 4);
-            const bool mix_in = C::MIX_IT >= 0 && C::MIX_IT * C::LWAVES + lw < C::IN_WI;
-            const __amdgpu_buffer_rsrc_t d_rmix = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<char *>(unif(mix_in ? base_in : reinterpret_cast<const char *>(p.w))), 0,
-                (int)unif(mix_in ? (unsigned)img : (unsigned)p.w_bytes), 0x00020000);
-            const unsigned d_smix = unif(mix_in ? d_sin : d_sw);
-            // Per-lane source offsets live in cv[] and are rebuilt only at the first group of a (unit, plane, source), as in
-            // conv_ring.hip: a vector instruction issued by a loader wave takes ~5 cycles of fp32 matrix time from its SIMD
-            // (conv_first.hip).  A halo inside the image costs one add per piece: loc[] + the halo's scalar offset.
-            if (pc0 == 0) {
-                constexpr int S = C::NPLANES == 4 ? 2 : 1;
-                if (ld != loc_ld) {
-                    loc_ld = ld;
-#pragma unroll
-                    for (int it = 0; it < C::NL; ++it) {
-                        if (it * C::LWAVES >= C::IN_WI) continue;
-                        const int ly = ia[it] >> 10, lx = ia[it] & 0x3ff;
-                        loc[it] = ia[it] >= 0 ? (unsigned)(S * ly * p.W + S * lx) * ldb + (unsigned)ib[it] : kRingfOob;
-                    }
-                }
-                const int fy = S * oy + (S == 2 ? a : 0), fx = S * ox + (S == 2 ? b : 0);   // image coordinates of the halo's first pixel
-                const unsigned s_halo = unif((unsigned)((fy * p.W + fx) * (int)ldb));
-                const bool interior = fy >= 0 && fy + S * (C::IH - 1) < p.H && fx >= 0 && fx + S * (C::IW - 1) < p.W;   // scalar
-#pragma unroll
-                for (int it = 0; it < C::NL; ++it) {
-                    const bool in_ct = (it + 1) * C::LWAVES <= C::IN_WI, w_ct = it * C::LWAVES >= C::IN_WI;
-                    unsigned v_in = kRingfOob, v_w = kRingfOob;
-                    if (!w_ct) {
-                        v_in = loc[it] + s_halo;
-                        if (!interior) {
-                            const int ry = fy + S * (ia[it] >> 10), rx = fx + S * (ia[it] & 0x3ff);
-                            v_in = (ia[it] >= 0 && ry >= 0 && ry < p.H && rx >= 0 && rx < p.W) ? v_in : kRingfOob;
+                        for (int it = 0; it < C::NL; ++it) {
+                            if (it * C::LWAVES >= C::IN_WI) continue;
+                            const int ly = ia[it] >> 10, lx = ia[it] & 0x3ff;
+                            loc[it] = ia[it] >= 0 ? (unsigned)(S * ly * p.W + S * lx) * ldb + (unsigned)ib[it] : kRingfOob;
                         }
                     }
-                    if (!in_ct) {
-                        const int t = ia[it] >> 4, k = ia[it] & 15;
-                        int wt = t;   // plane of the packed weights this tap slot reads
-                        bool ok = ia[it] >= 0 && PU.co0 + ib[it] * 4 < p.cout;
-                        const int ty = t >> 1, tx = t & 1;
-                        if constexpr (C::MODE == RF_CT4) wt = (PU.py * 2 + PU.px) * 4 + t;
-                        if constexpr (C::MODE == RF_K3S2) wt = (a ? 2 * ty : 1) * 3 + (b ? 2 * tx : 1), ok = ok && ty <= a && tx <= b;
-                        v_w = ok ? (unsigned)wt * wplane + (unsigned)(k * p.cout + ib[it] * 4) * 4u : kRingfOob;
+                    const int fy = S * oy + (S == 2 ? a : 0), fx = S * ox + (S == 2 ? b : 0);   // image coordinates of the halo's first pixel
+                    const unsigned s_halo = unif((unsigned)((fy * p.W + fx) * (int)ldb));
+                    const bool interior = fy >= 0 && fy + S * (C::IH - 1) < p.H && fx >= 0 && fx + S * (C::IW - 1) < p.W;   // scalar
+#pragma unroll
+                    for (int it = 0; it < C::NL; ++it) {
+                        const bool in_ct = (it + 1) * C::LWAVES <= C::IN_WI, w_ct = it * C::LWAVES >= C::IN_WI;
+                        unsigned v_in = kRingfOob, v_w = kRingfOob;
+                        if (!w_ct) {
+                            v_in = loc[it] + s_halo;
+                            if (!interior) {
+                                const int ry = fy + S * (ia[it] >> 10), rx = fx + S * (ia[it] & 0x3ff);
+                                v_in = (ia[it] >= 0 && ry >= 0 && ry < p.H && rx >= 0 && rx < p.W) ? v_in : kRingfOob;
+                            }
+                        }
+                        if (!in_ct) {
+                            const int t = ia[it] >> 4, k = ia[it] & 15;
+                            int wt = t;   // plane of the packed weights this tap slot reads
+                            bool ok = ia[it] >= 0 && PU.co0 + ib[it] * 4 < p.cout;
+                            const int ty = t >> 1, tx = t & 1;
+                            if constexpr (C::MODE == RF_CT4) wt = (PU.py * 2 + PU.px) * 4 + t;
+                            if constexpr (C::MODE == RF_K3S2) wt = (a ? 2 * ty : 1) * 3 + (b ? 2 * tx : 1), ok = ok && ty <= a && tx <= b;
+                            v_w = ok ? (unsigned)wt * wplane + (unsigned)(k * p.cout + ib[it] * 4) * 4u : kRingfOob;
+                        }
+                        cv[it] = in_ct ? v_in : (w_ct ? v_w : (mix_in ? v_in : v_w));
                     }
-                    cv[it] = in_ct ? v_in : (w_ct ? v_w : (mix_in ? v_in : v_w));
+                    unsigned d_sin = 0;   // byte offset of the group's 16 channels inside a pixel of this source
+                    for (int pc0 = 0; pc0 < srcc; pc0 += C::CKG) {
+                        if (issued >= (unsigned)(C::R - 1)) {
+                            ringf_wait_vmcnt<(C::R - 2) * C::NL>();   // this wave's pieces of group issued - R + 1 have landed
+                            __builtin_amdgcn_s_barrier();             // B_(issued - R + 1)
+                        }
+                        const unsigned d_base = unif(dslot * (unsigned)C::GROUP_BYTES + (unsigned)(lw * 1024));
+                        const unsigned d_smix = mix_in ? d_sin : d_sw;
+                        unsigned keep;
+                        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0" : "=s"(keep));
+#pragma unroll
+                        for (int it = 0; it < C::NL; ++it) {
+                            const bool in_ct = (it + 1) * C::LWAVES <= C::IN_WI, w_ct = it * C::LWAVES >= C::IN_WI;
+                            const unsigned dst = d_base + (unsigned)(it * C::LWAVES * 1024);
+                            if (in_ct) ringf_dma16_m0(dst, cv[it], d_rin, d_sin);
+                            else if (w_ct) ringf_dma16_m0(dst, cv[it], rsrc_w, d_sw);
+                            else ringf_dma16_m0(dst, cv[it], d_rmix, d_smix);
+                        }
+                        asm volatile("s_mov_b32 m0, %0" ::"s"(keep));
+                        d_sin += (unsigned)(C::CKG * 4), d_sw += wstep;
+                        ++issued;
+                        dslot = dslot + 1 == (unsigned)C::R ? 0u : dslot + 1;
+                    }
                 }
             }
-#pragma unroll
-            for (int it = 0; it < C::NL; ++it) {
-                const bool in_ct = (it + 1) * C::LWAVES <= C::IN_WI, w_ct = it * C::LWAVES >= C::IN_WI;
-                const unsigned dst = d_base + (unsigned)(it * C::LWAVES * 1024);
-                if (in_ct) ringf_dma16(dst, cv[it], d_rin, d_sin);
-                else if (w_ct) ringf_dma16(dst, cv[it], rsrc_w, d_sw);
-                else ringf_dma16(dst, cv[it], d_rmix, d_smix);
-            }
-            pc0 += C::CKG, pwrow += C::CKG;
-            if (pc0 >= selq4(p.src_c, ps)) {
-                pc0 = 0, ++ps;
-                if (ps == p.nsrc) {
-                    ps = 0, pwrow = 0, ++pplane;
-                    if (pplane == C::NPLANES) {
-                        pplane = 0, pu += u_step;
-                        if (pu < u_end) PU = ringf_unit(p, pu, C::CO_UNIT);
-                    }
-                }
-            }
-        };
-#pragma unroll
-        for (int i = 0; i < C::R - 1; ++i) stage();
-        for (unsigned s = 0; s < total; ++s) {
-            ringf_wait_vmcnt<(C::R - 2) * C::NL>();   // this wave's pieces of group s have landed
-            __builtin_amdgcn_s_barrier();             // B_s
-            stage();                                  // group s + R - 1 into the buffer group s - 1 occupied
         }
-        ringf_wait_vmcnt<0>();
+        // the last min(total, R - 1) barriers: the groups still in flight land one by one (exact counts: no filler groups)
+        const unsigned rem = issued < (unsigned)(C::R - 1) ? issued : (unsigned)(C::R - 1);
+        for (unsigned j = 0; j < rem; ++j) {
+            const unsigned left = rem - 1 - j;
+            if (left >= 2) ringf_wait_vmcnt<(C::R >= 4 ? 2 : 0) * C::NL>();
+            else if (left == 1) ringf_wait_vmcnt<(C::R >= 3 ? 1 : 0) * C::NL>();
+            else ringf_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+        }
         return;
     }
 
