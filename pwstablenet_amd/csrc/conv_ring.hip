@@ -724,8 +724,14 @@ __global__ void __launch_bounds__(C::THREADS, C::MT == 4 ? 2 : 3) conv_ring_kern
                             }
                         } else {
                             const u32x4 o = e_old[slot];   // zeros when this destination is overwritten
-                            v[0] += bf16_lo(o.x), v[1] += bf16_hi(o.x), v[2] += bf16_lo(o.y), v[3] += bf16_hi(o.y);
-                            v[4] += bf16_lo(o.z), v[5] += bf16_hi(o.z), v[6] += bf16_lo(o.w), v[7] += bf16_hi(o.w);
+                            {   // (two values per instruction: v_pk_add_f32 -- written out, hipcc does not pair them across the asm statements below)
+                                const unsigned ow[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    const f32x2 t = (f32x2){v[2 * k], v[2 * k + 1]} + (f32x2){bf16_lo(ow[k]), bf16_hi(ow[k])};
+                                    v[2 * k] = t.x, v[2 * k + 1] = t.y;
+                                }
+                            }
                             // act'(y) of the tensor this destination is the gradient of (no such tensor: slope == 1)
                             const float sl = e.slope;
                             if constexpr (SG) {
@@ -733,10 +739,11 @@ __global__ void __launch_bounds__(C::THREADS, C::MT == 4 ? 2 : 3) conv_ring_kern
                                 // picks v or slope v): 2.5 instructions per value instead of 4 (bit test, compare, select, multiply)
                                 const unsigned m = e_m[slot];
 #pragma unroll
-                                for (int k = 0; k < 8; ++k) {
-                                    const unsigned keepv = (unsigned)__builtin_amdgcn_sbfe((int)m, (unsigned)k, 1u);
-                                    const float vs = v[k] * sl;
-                                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(v[k]) : "v"(keepv), "v"(v[k]), "v"(vs));   // (keepv & v) | (~keepv & slope v); hipcc's own lowering of that expression is six instructions
+                                for (int k = 0; k < 8; k += 2) {
+                                    const f32x2 vs = (f32x2){v[k], v[k + 1]} * (f32x2){sl, sl};   // v_pk_mul_f32
+                                    const unsigned keep0 = (unsigned)__builtin_amdgcn_sbfe((int)m, (unsigned)k, 1u), keep1 = (unsigned)__builtin_amdgcn_sbfe((int)m, (unsigned)(k + 1), 1u);
+                                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(v[k]) : "v"(keep0), "v"(v[k]), "v"(vs.x));   // (keep & v) | (~keep & slope v); hipcc's own lowering of that expression is six instructions
+                                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(v[k + 1]) : "v"(keep1), "v"(v[k + 1]), "v"(vs.y));
                                 }
                             } else {
                                 const u32x4 yv = e_y[slot];
