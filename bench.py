@@ -90,6 +90,7 @@ _PMC_NAMES = {
     "conv_bf16_kernel": ["conv_bf16_kernel", "conv_bf16_k5_kernel"],
     "conv_mfma_kernel<k5s1,16x16>": ["k5s1,tile"],
     "conv_first_kernel": ["conv_first_kernel"],
+    "wino5_first_kernel": ["wino5_first_kernel"],
     "grid_sample_fwd_kernel@roofline": ["grid_sample_fwd2_kernel<4, true"],   # the 256-frame launch (non-temporal variant: > 256 MB)
     "upsample_grid_sample_fwd_kernel": ["upsample_grid_sample_fwd_kernel"],
     "grid_sample_fwd_kernel": ["grid_sample_fwd2_kernel"],
@@ -98,7 +99,7 @@ _PMC_NAMES = {
 
 # multiplies of the direct convolution per multiply the Winograd kernels execute (conv_wino.hip / conv_wring.hip)
 WINOGRAD_REDUCTION = {"wino_k3s1_kernel<F(2x2,3x3)>": 2.25, "wino_ct4_kernel<F(3x3,2x2)>": 2.25, "wino_ring_kernel<F(2x2,3x3)>": 2.25,
-                      "wino_ring_kernel<convT4,F(2x2,2x2)>": 16.0 / 9.0}
+                      "wino_ring_kernel<convT4,F(2x2,2x2)>": 16.0 / 9.0, "wino5_first_kernel": 100.0 / 36.0}
 
 
 def pmc_traffic(kernel):

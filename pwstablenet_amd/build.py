@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libpwstable_hip.so")
-SOURCES = ["abi.cpp", "netg.cpp", "netg_pack.hip", "pack.hip", "conv_mfma.hip", "conv_bf16.hip", "conv_ring.hip", "conv_ring_f32.hip", "conv_first.hip", "conv_wgrad.hip", "wgrad_bf16.hip", "wgrad_ring.hip", "conv_wino.hip", "conv_wring.hip", "conv_skinny.hip", "conv_skinny16.hip", "head.hip", "head_bwd.hip", "grid_sample.hip",
+SOURCES = ["abi.cpp", "netg.cpp", "netg_pack.hip", "pack.hip", "conv_mfma.hip", "conv_bf16.hip", "conv_ring.hip", "conv_ring_f32.hip", "conv_first.hip", "conv_first_wino.hip", "conv_wgrad.hip", "wgrad_bf16.hip", "wgrad_ring.hip", "conv_wino.hip", "conv_wring.hip", "conv_skinny.hip", "conv_skinny16.hip", "head.hip", "head_bwd.hip", "grid_sample.hip",
            "adam.hip", "objective.hip", "pool.hip", "frameio.hip", "bnorm.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

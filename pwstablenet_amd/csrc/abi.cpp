@@ -38,7 +38,7 @@ const char *const kKernelNames[KID_COUNT] = {
     "wgrad_mfma_kernel", "act_bwd_bias_kernel", "field_head_bwd_kernels", "theta_head_bwd_kernels",
     "wino_k3s1_kernel<F(2x2,3x3)>", "conv_bf16_kernel", "wgrad_bf16_kernel",
     "wino_ct4_kernel<F(3x3,2x2)>", "upsample_grid_sample_u8_kernel", "objective_kernels", "conv_ring_kernel", "conv_ringf_kernel",
-    "wino_ring_kernel<F(2x2,3x3)>", "wino_ring_kernel<convT4,F(2x2,2x2)>", "conv_skinny_kernel", "wgrad_ring_kernel", "conv_skinny16_kernel", "conv_first_kernel"};
+    "wino_ring_kernel<F(2x2,3x3)>", "wino_ring_kernel<convT4,F(2x2,2x2)>", "conv_skinny_kernel", "wgrad_ring_kernel", "conv_skinny16_kernel", "conv_first_kernel", "wino5_first_kernel"};
 }  // namespace
 
 void prof_begin(int kernel_id, double flops, double bytes, hipStream_t st) {

@@ -76,7 +76,7 @@ enum KernelId {
     KID_CONV_K3S1_BIG = 0, KID_CONV_K3S1_SMALL, KID_CONV_K3S2_BIG, KID_CONV_K3S2_SMALL, KID_CONV_K5S1, KID_CONVT4_BIG,
     KID_CONVT4_SMALL, KID_THETA_HEAD, KID_FIELD_HEAD, KID_GRID_SAMPLE_FWD, KID_GRID_SAMPLE_BWD, KID_UPSAMPLE_GRID_SAMPLE_FWD,
     KID_UPSAMPLE, KID_AFFINE_GRID, KID_ADAM, KID_PACK, KID_DGRAD_K4S2, KID_DGRAD_SP3, KID_WGRAD, KID_ACT_BWD, KID_FIELD_HEAD_BWD,
-    KID_THETA_HEAD_BWD, KID_CONV_WINO, KID_CONV_BF16, KID_WGRAD_BF16, KID_CONV_WINO_CT4, KID_UPSAMPLE_GRID_SAMPLE_U8, KID_OBJECTIVE, KID_CONV_RING, KID_CONV_RINGF, KID_CONV_WRING, KID_CONV_WRING_CT4, KID_CONV_SKINNY, KID_WGRAD_RING, KID_CONV_SKINNY16, KID_CONV_FIRST, KID_COUNT
+    KID_THETA_HEAD_BWD, KID_CONV_WINO, KID_CONV_BF16, KID_WGRAD_BF16, KID_CONV_WINO_CT4, KID_UPSAMPLE_GRID_SAMPLE_U8, KID_OBJECTIVE, KID_CONV_RING, KID_CONV_RINGF, KID_CONV_WRING, KID_CONV_WRING_CT4, KID_CONV_SKINNY, KID_WGRAD_RING, KID_CONV_SKINNY16, KID_CONV_FIRST, KID_CONV_FIRST_WINO, KID_COUNT
 };
 // Deterministic accumulation (PWS_NETG_DETERMINISTIC / pws_conv_bwd_weight_args.deterministic): while set on the calling thread,
 // every launcher that accumulates with fp32 atomics gives each address ONE adding workgroup per launch (no pixel split), the head
@@ -160,6 +160,27 @@ __device__ inline void wring_pack_element(const float *__restrict__ pk, float *_
             ur[wring_index(16, r * 4 + 2, ci, co, nch)] = 0.5f * (u[r][0] - u[r][1] + u[r][2]);
             ur[wring_index(16, r * 4 + 3, ci, co, nch)] = u[r][2];
         }
+    } else if (ct4 == 2) {   // F(2x2,5x5) of the first layer (conv_first_wino.hip), points {0, 1, -1, 2, -2, inf}: U = G g G^T in double, rounded once;
+        // layout [k-step = ci / 4][component i * 6 + j][channel block co / 16][kq = ci % 4][co % 16]: a k-step is 36 KB of lane-linear A operands
+        const double G[6][5] = {{0.25, 0, 0, 0, 0},
+                                {-1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6},
+                                {-1.0 / 6, 1.0 / 6, -1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                {1.0 / 24, 1.0 / 12, 1.0 / 6, 1.0 / 3, 2.0 / 3},
+                                {1.0 / 24, -1.0 / 12, 1.0 / 6, -1.0 / 3, 2.0 / 3},
+                                {0, 0, 0, 0, 1}};
+        double t[6][5];
+        for (int r = 0; r < 6; ++r)
+            for (int v = 0; v < 5; ++v) {
+                double a = 0;
+                for (int q = 0; q < 5; ++q) a += G[r][q] * (double)pk[(size_t)(q * 5 + v) * plane + i];
+                t[r][v] = a;
+            }
+        for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c) {
+                double a = 0;
+                for (int v = 0; v < 5; ++v) a += t[r][v] * G[c][v];
+                ur[(((size_t)((ci >> 2) * 36 + r * 6 + c) * (cout / 16) + (co >> 4)) * 4 + (ci & 3)) * 16 + (co & 15)] = (float)a;
+            }
     } else {      // F(2x2,2x2) per parity class: G = [[1,0],[1,1],[0,1]]; [py][... 18 components = (px, i, j) ...]
 #pragma unroll
         for (int py = 0; py < 2; ++py)

@@ -365,6 +365,7 @@ int conv_bf16_fwd(int kind, ConvKParams &kp, int cin_total, float *out, float *w
 int conv_bf16_dgrad(int kind, ConvKParams &kp, int cout_f, float *ws, size_t ws_floats, hipStream_t st, const ProfInfo &pi);
 int conv_ringf_try(int kind, const ConvKParams &kp, hipStream_t st, const ProfInfo &pi);   // conv_ring_f32.hip; 1 = not covered
 int conv_first_try(const ConvKParams &kp, hipStream_t st, const ProfInfo &pi);             // conv_first.hip; 1 = not covered
+int wino5_first_try(const ConvKParams &kp, const float *u, hipStream_t st, const ProfInfo &pi);   // conv_first_wino.hip; 1 = not covered
 int conv_skinny_try(int kind, ConvKParams &kp, float *final_out, float *ws, size_t ws_floats, hipStream_t st, const ProfInfo &pi);  // conv_skinny.hip; 1 = not covered
 
 int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
@@ -483,6 +484,10 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
         }
         if (nchw) {   // the persistent planar-LDS kernel where it is covered (the generator's 256 x 256 windows)
             kp.out = a->out;
+            if (a->w_wring) {   // Winograd F(2x2,5x5) where the transformed weights are given and whole 8 x 16 units fill the chip
+                const int rcw = wino5_first_try(kp, static_cast<const float *>(a->w_wring), st, info(25, (double)a->n * a->h * a->w));
+                if (rcw != 1) return rcw;
+            }
             const int rc = conv_first_try(kp, st, info(25, (double)a->n * a->h * a->w));
             if (rc != 1) return rc;
         }

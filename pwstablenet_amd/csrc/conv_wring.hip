@@ -680,11 +680,12 @@ extern "C" size_t pws_packed_wring_floats(int kind, int cin, int cout) {
     const size_t plane = (size_t)((cin + 15) / 16 * 16) * cout;
     if (kind == PWS_CONV_K3S1 || kind == PWS_CONVT_K3S1) return 16 * plane;
     if (kind == PWS_CONVT_K4S2) return 36 * plane;
+    if (kind == PWS_CONV_K5S1 && cin <= 32 && cin > 16 && cout == 64) return 36 * plane;   // F(2x2,5x5) of the first layer (conv_first_wino.hip)
     return 0;
 }
 
 extern "C" int pws_pack_conv_weight_wring(const float *w_packed, float *w_wring, int kind, int cin, int cout, pws_stream_t stream) {
     PWS_REQUIRE(w_packed && w_wring && pws_packed_wring_floats(kind, cin, cout) > 0, "pws_pack_conv_weight_wring: bad arguments (kind %d, cout %d)", kind,
                 cout);
-    return pws::wring_pack(w_packed, w_wring, (cin + 15) / 16 * 16, cout, kind == PWS_CONVT_K4S2 ? 1 : 0, pws::as_stream(stream));
+    return pws::wring_pack(w_packed, w_wring, (cin + 15) / 16 * 16, cout, kind == PWS_CONVT_K4S2 ? 1 : (kind == PWS_CONV_K5S1 ? 2 : 0), pws::as_stream(stream));
 }

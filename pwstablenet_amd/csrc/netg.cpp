@@ -103,7 +103,7 @@ static std::vector<Layer> build_layers(int input_nc, int g, size_t *total_floats
         L.push_back(l);
     };
     const int enc[7][2] = {{g, g}, {g, 2 * g}, {2 * g, 4 * g}, {4 * g, 4 * g}, {4 * g, 4 * g}, {4 * g, 4 * g}, {4 * g, 4 * g}};
-    add(PWS_CONV_K5S1, input_nc, g);
+    add(PWS_CONV_K5S1, input_nc, g, true);   // (ring: the F(2x2,5x5) weights of conv_first_wino.hip, where pws_packed_wring_floats covers the shape)
     for (int i = 0; i < 7; ++i) add(PWS_CONV_K3S2, enc[i][0], enc[i][1]);
     const int dec[7][2] = {{4 * g, 4 * g}, {8 * g, 4 * g}, {8 * g, 4 * g}, {8 * g, 4 * g}, {8 * g, 2 * g}, {4 * g, g}, {2 * g, g}};
     for (int j = 0; j < 7; ++j) add(PWS_CONVT_K4S2, dec[j][0], dec[j][1], j >= 3);  // up7..up1 (up4..up1: inputs of 16^2..128^2)

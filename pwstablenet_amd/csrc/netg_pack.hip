@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256) wino_all_kernel(const PackAllArgs a, floa
     const size_t i = (size_t)(blockIdx.x - a.first_block_wino[l]) * 256 + threadIdx.x;
     if (i >= plane) return;
     const float *pk = packed + L.w_off;
-    if (L.wr_off != kNoOff) wring_pack_element(pk, packed + L.wr_off, plane, i, L.cin_pad, L.cout, L.kind == PWS_CONVT_K4S2 ? 1 : 0);
+    if (L.wr_off != kNoOff) wring_pack_element(pk, packed + L.wr_off, plane, i, L.cin_pad, L.cout, L.kind == PWS_CONVT_K4S2 ? 1 : (L.kind == PWS_CONV_K5S1 ? 2 : 0));
     if (L.ww_off == kNoOff) return;
     float *uw = packed + L.ww_off;
     float g[3][3];

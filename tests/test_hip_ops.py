@@ -64,7 +64,9 @@ def run_conv(A, kind, srcs_nhwc, w_torch, bias, act, cout, nchw_src=None, ws_mb=
     b = dev(bias) if bias is not None else None
     args.cout, args.w_packed, args.bias, args.act = cout, wp.data_ptr(), (b.data_ptr() if b is not None else None), act
     args.out, args.out_ld = out.data_ptr(), cout
-    if wino and kind == A.CONVT_K4S2:
+    if wino and kind == A.CONV_K5S1:
+        pass   # (only the ring-layout F(2x2,5x5) weights below)
+    elif wino and kind == A.CONVT_K4S2:
         ww = torch.empty(L.pws_packed_wino_ct4_floats(cin, cout), device="cuda", dtype=torch.float32)
         A.check(L.pws_pack_conv_weight_wino_ct4(A.ptr(wp), A.ptr(ww), cin, cout, st), "pack_wino_ct4")
         args.w_wino = ww.data_ptr()
@@ -406,6 +408,54 @@ def test_first_layer_planar_kernel_vs_oracle(hip, oracle, shape, cin, cout, plan
     assert not np.isnan(new).any(), "kernel left output elements unwritten"
     np.testing.assert_allclose(nchw(new), ref, rtol=0, atol=5e-5)
     np.testing.assert_allclose(new, got[25], rtol=0, atol=5e-5)
+
+
+WINO5_CASES = [   # (n, h, w), cin, planes per sample in memory (None = dense), forced (PWS_OPT_EXPERIMENT 30: launches of fewer than 2 units per CU)
+    ((8, 256, 256), 31, None, False),     # BASELINE configs[1]'s batch: 4 096 units, the product dispatch
+    ((2, 256, 256), 31, 34, False),       # the driver's 34-plane item read in place: 1 024 units
+    ((1, 8, 16), 31, None, True),         # ONE unit: every image border inside the same halo, one k-step sequence
+    ((1, 16, 48), 17, None, True), ((3, 24, 32), 32, None, True), ((2, 40, 96), 20, 36, True),
+    ((5, 264, 16), 31, None, True),       # one unit column: left and right border in every unit; workgroups with 1 and 2 units
+    ((1, 64, 64), 31, None, True),        # 32 units on 256 CUs: most workgroups idle
+]
+
+
+@pytest.mark.parametrize("shape,cin,planes,forced", WINO5_CASES)
+@pytest.mark.parametrize("act", [1, 2])
+def test_first_layer_winograd_kernel_vs_oracle(hip, oracle, shape, cin, planes, forced, act):
+    """wino5_first_kernel (csrc/conv_first_wino.hip: F(2x2,5x5) in exact fp32, transformed input shared through LDS, 36 component accumulators
+    per wave) against the C oracle and against conv_first_kernel (PWS_OPT_EXPERIMENT 26): image borders on every side, the zero padding
+    channels, samples read in place out of wider items, launches of one unit and of several units per workgroup."""
+    A = hip
+    L = A.lib()
+    n, h, w = shape
+    rs = np.random.RandomState(zlib.crc32(repr((shape, cin, planes, "w5")).encode()))
+    xfull = rs.standard_normal((n, planes or cin, h, w)).astype(np.float32)
+    x = xfull[:, :cin]
+    wt = (rs.standard_normal((64, cin, 5, 5)) / np.sqrt(cin * 25)).astype(np.float32)
+    b = rs.standard_normal((64,)).astype(np.float32)
+    small = n * h * w <= 2 * 256 * 256
+    ref = oracle.conv2d(np.ascontiguousarray(x), wt, b, 1, 2, {1: oracle.ACT_LRELU, 2: oracle.ACT_RELU}[act]) if small else None
+    got = {}
+    try:
+        for exp in ((30 if forced else 0), 26):
+            assert L.pws_set_option(100, exp) == 0
+            L.pws_prof_enable(1)
+            got[exp] = run_conv(A, A.CONV_K5S1, None, wt, b, act, 64, nchw_src=xfull, nchw_channels=cin if planes else None, wino=True)
+            L.pws_prof_enable(0)
+            names = [r[0] for r in A.prof_collect()]
+            if exp != 26:
+                assert names == ["wino5_first_kernel"], (exp, names)
+            else:
+                assert names[0] in ("conv_first_kernel", "conv_mfma_kernel<k5s1,16x16>"), names
+    finally:
+        L.pws_prof_enable(0)
+        L.pws_set_option(100, 0)
+    new = got[30 if forced else 0]
+    assert not np.isnan(new).any(), "kernel left output elements unwritten"
+    if ref is not None:
+        np.testing.assert_allclose(nchw(new), ref, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(new, got[26], rtol=0, atol=5e-5)
 
 
 def test_conv_empty_batch_and_bad_args(hip):

@@ -162,6 +162,10 @@ def bench_first(n=8, h=256, w=256, cin=31, cout=64):
     a.kind, a.n, a.h, a.w, a.nsrc, a.cout, a.act, a.src_nchw = A.CONV_K5S1, n, h, w, 1, cout, 1, 1
     a.src[0].channels, a.src[0].ld = cin, 0
     a.w_packed, a.bias, a.out_ld = wp.data_ptr(), b.data_ptr(), cout
+    if L.pws_packed_wring_floats(A.CONV_K5S1, cin, cout):   # F(2x2,5x5) weights: wino5_first_kernel (PWS_EXPERIMENT 26 = conv_first_kernel)
+        wr = torch.empty(L.pws_packed_wring_floats(A.CONV_K5S1, cin, cout), device="cuda")
+        A.check(L.pws_pack_conv_weight_wring(A.ptr(wp), A.ptr(wr), A.CONV_K5S1, cin, cout, st), "pack_wring")
+        a.w_wring = wr.data_ptr()
 
     def launch(i):
         a.src[0].ptr, a.out = xs[i % 3].data_ptr(), outs[i % 3].data_ptr()
