@@ -161,7 +161,7 @@ __device__ inline void wring_pack_element(const float *__restrict__ pk, float *_
             ur[wring_index(16, r * 4 + 3, ci, co, nch)] = u[r][2];
         }
     } else if (ct4 == 2) {   // F(2x2,5x5) of the first layer (conv_first_wino.hip), points {0, 1, -1, 2, -2, inf}: U = G g G^T in double, rounded once;
-        // layout [k-step = ci / 4][component i * 6 + j][channel block co / 16][kq = ci % 4][co % 16]: a k-step is 36 KB of lane-linear A operands
+        // layout [k-step = ci / 4][component / 4][channel block co / 16][kq = ci % 4][co % 16][component % 4]: a k-step is 36 KB, a lane's A operands of four components 16 bytes
         const double G[6][5] = {{0.25, 0, 0, 0, 0},
                                 {-1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6},
                                 {-1.0 / 6, 1.0 / 6, -1.0 / 6, 1.0 / 6, -1.0 / 6},
@@ -179,7 +179,7 @@ __device__ inline void wring_pack_element(const float *__restrict__ pk, float *_
             for (int c = 0; c < 6; ++c) {
                 double a = 0;
                 for (int v = 0; v < 5; ++v) a += t[r][v] * G[c][v];
-                ur[(((size_t)((ci >> 2) * 36 + r * 6 + c) * (cout / 16) + (co >> 4)) * 4 + (ci & 3)) * 16 + (co & 15)] = (float)a;
+                ur[((((size_t)((ci >> 2) * 9 + ((r * 6 + c) >> 2)) * (cout / 16) + (co >> 4)) * 4 + (ci & 3)) * 16 + (co & 15)) * 4 + ((r * 6 + c) & 3)] = (float)a;
             }
     } else {      // F(2x2,2x2) per parity class: G = [[1,0],[1,1],[0,1]]; [py][... 18 components = (px, i, j) ...]
 #pragma unroll

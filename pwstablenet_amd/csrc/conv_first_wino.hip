@@ -13,7 +13,7 @@
 //     transforms them back in registers at the end: no second trip through LDS;
 //   * unit = 4 x 8 tiles (8 x 16 output pixels) x 64 channels: 8 matrix waves (4 channel blocks x 2 tile blocks); per k-step the
 //     helper waves copy the next raw planes (LDS-DMA, 4 channels x 12 x 24 floats, zero padding by out-of-range offsets) and the next
-//     36 KB of transformed weights U (packed [k-step][component][channel block][kq][16] = lane-linear A operands), and transform
+//     36 KB of transformed weights U (packed [k-step][4 components][channel block][lane][4]: a lane's A operands of four matrix instructions are one 16-byte LDS read), and transform
 //     the planes that landed one step earlier: 6 x 6 -> rows i of B^T d B split over two lanes' waves (rows 0-2 / 3-5);
 //   * one s_barrier per k-step; rings: raw planes 3 deep, V (transformed input) 2 deep, U 3 deep = 159 KB of LDS.
 // Numerics: exact fp32 products, fp32 sums in Winograd order (not the direct kernel's bits; same tolerance in the tests).
@@ -25,14 +25,14 @@ struct Wino5Params {
     const float *src;      // NCHW
     size_t sstride;        // floats between samples
     int C, N, H, W;
-    const float *u;        // [8 k-steps][36][4 channel blocks][4 kq][16] fp32 (wring_pack_element, mode 2)
+    const float *u;        // [8 k-steps][9 groups of 4 components][4 channel blocks][kq * 16 + channel % 16][4] fp32 (wring_pack_element, mode 2)
     const float *bias;
     int act;
     float *out;
     int out_ld;
     int tiles_x, tiles_y;
     unsigned nunits;
-    int ablate;            // timing-only (PWS_OPT_EXPERIMENT 1300 + mask): 1 no matrix phase, 2 no transform, 4 no DMA, 8 no epilogue
+    int ablate;            // timing-only (PWS_OPT_EXPERIMENT 1300 + mask): 1 no matrix phase, 2 no transform, 4 no DMA, 8 no epilogue; 16 (not timing-only): every wave in the same order
 };
 
 namespace {
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(W5_THREADS, 2) wino5_first_kernel(const Wino5P
     // tile = lane & 15 of the block: 2 tile rows x 8).  Rows 3 half .. 3 half + 2 of B^T d B, all 6 columns.
     const int tt = (wv & 3) >> 1, half = wv & 1;
     const unsigned t_rd = (unsigned)((lane >> 4) * W5_PLANE * 4 + ((2 * (2 * tt + ((lane & 15) >> 3)) + half) * W5_IW + 2 + 2 * (lane & 7)) * 4);
-    const unsigned t_wr = (unsigned)(W5_V_OFF + (half * 18) * 512 + tt * 256 + lane * 4);
+    const unsigned t_wr = (unsigned)(W5_V_OFF + tt * 1024 + lane * 16);
     auto transform = [&](unsigned rslot, unsigned vslot) {
         if (no_tf) return;
         const unsigned char *src = lds + rslot * W5_RAW_SLOT + t_rd;
@@ -194,45 +194,56 @@ __global__ void __launch_bounds__(W5_THREADS, 2) wino5_first_kernel(const Wino5P
                 t[2][jj] = 4.f * d[0][jj] + (d[4][jj] - 5.f * d[2][jj]);
             }
         }
-        float *dst = reinterpret_cast<float *>(lds + t_wr + vslot * W5_V_BYTES);
+        float v[18];   // components 18 half .. 18 half + 17
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const float c[6] = {t[i][0].x, t[i][0].y, t[i][1].x, t[i][1].y, t[i][2].x, t[i][2].y};
-            float v[6];
-            w5_bt6(c, v);
+            w5_bt6(c, v + i * 6);
+        }
+        // V[group of 4 components][tile block][lane][4]: a lane's operands of four matrix instructions are ONE 16-byte read; this wave's 18
+        // components are four whole groups and half of group 4 (components 16, 17 from the rows 0-2 wave, 18, 19 from the rows 3-5 wave)
+        unsigned char *dst = lds + t_wr + vslot * W5_V_BYTES;
+        if (half == 0) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) dst[(i * 6 + j) * 128] = v[j];
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4 *>(dst + g * 2048) = (f32x4){v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+            *reinterpret_cast<f32x2 *>(dst + 4 * 2048) = (f32x2){v[16], v[17]};
+        } else {
+            *reinterpret_cast<f32x2 *>(dst + 4 * 2048 + 8) = (f32x2){v[0], v[1]};
+#pragma unroll
+            for (int g = 5; g < 9; ++g) *reinterpret_cast<f32x4 *>(dst + g * 2048) = (f32x4){v[4 * g - 18], v[4 * g - 17], v[4 * g - 16], v[4 * g - 15]};
         }
     };
 
     // ---- matrix phase: wave wv = (channel block cb = wv & 3, tile block tb = wv >> 2): A = U[component][cb][kq][16 channels],
     // B = V[component][tb][kq][16 tiles], both lane-linear; acc[component][r] = channel cb * 16 + 4 (lane >> 4) + r of tile tb * 16 + (lane & 15)
     const int cb = wv & 3, tb = wv >> 2;
-    const unsigned a_lane = (unsigned)(W5_U_OFF + cb * 256 + lane * 4), b_lane = (unsigned)(W5_V_OFF + tb * 256 + lane * 4);
+    const unsigned a_lane = (unsigned)(W5_U_OFF + cb * 1024 + lane * 16), b_lane = (unsigned)(W5_V_OFF + tb * 1024 + lane * 16);
     f32x4 acc[36];
     auto phase = [&](auto FIRST_, unsigned s3, unsigned s2) {
         constexpr bool FIRST = decltype(FIRST_)::value;
         const unsigned char *ua = lds + a_lane + s3 * W5_U_BYTES, *vb = lds + b_lane + s2 * W5_V_BYTES;
-        constexpr int NP = 18, PD = 3;   // component pairs; pairs requested ahead of their matrix instructions
-        float au[36], bv[36];
-        auto rd = [&](int pp) {
-            au[2 * pp] = *reinterpret_cast<const float *>(ua + (2 * pp) * 1024), au[2 * pp + 1] = *reinterpret_cast<const float *>(ua + (2 * pp + 1) * 1024);
-            bv[2 * pp] = *reinterpret_cast<const float *>(vb + (2 * pp) * 512), bv[2 * pp + 1] = *reinterpret_cast<const float *>(vb + (2 * pp + 1) * 512);
+        constexpr int NG = 9, PD = 2;   // groups of 4 components; groups requested ahead of their matrix instructions
+        f32x4 au[NG], bv[NG];
+        auto rd = [&](int g) {
+            au[g] = *reinterpret_cast<const f32x4 *>(ua + g * 4096);
+            bv[g] = *reinterpret_cast<const f32x4 *>(vb + g * 2048);
         };
 #pragma unroll
-        for (int pp = 0; pp < PD; ++pp) rd(pp);
+        for (int g = 0; g < PD; ++g) rd(g);
+        if (p.ablate & 32) __builtin_amdgcn_s_setprio(2);   // (A/B: the multiplying wave first at its SIMD's issue port)
 #pragma unroll
-        for (int pp = 0; pp < NP; ++pp) {
-            if (pp + PD < NP) rd(pp + PD);
+        for (int g = 0; g < NG; ++g) {
+            if (g + PD < NG) rd(g + PD);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int c = 2 * pp + e;
-                if constexpr (FIRST) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(au[c], bv[c], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                else acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(au[c], bv[c], acc[c], 0, 0, 0);
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * g + e;
+                if constexpr (FIRST) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(au[g][e], bv[g][e], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                else acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(au[g][e], bv[g][e], acc[c], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (p.ablate & 32) __builtin_amdgcn_s_setprio(0);
     };
 
     unsigned keep;
@@ -252,69 +263,85 @@ __global__ void __launch_bounds__(W5_THREADS, 2) wino5_first_kernel(const Wino5P
     __builtin_amdgcn_s_barrier();   // B_0
     asm volatile("" ::: "memory");
 
-    unsigned cu = u_begin;
-    unsigned s = 0, s3 = 0;         // k-step, s % 3  (s % 2 = k % 2, s % 8 = k: 8 k-steps per unit)
-    // one k-step: k is a compile-time constant, so a unit is straight-line code -- the first step's matrix instructions (C = 0) define the
-    // accumulators, the other seven update them, nothing merges two forms of the 36 accumulators at a control-flow join
-    auto step = [&](auto KC) {
-        constexpr int k = decltype(KC)::value;
-        const unsigned sp1_3 = s3 == 2 ? 0u : s3 + 1, sp2_3 = sp1_3 == 2 ? 0u : sp1_3 + 1;
-        asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
-        if (s + 2 < total) issue_u(sp2_3, (k + 2) & 7);
-        if (s + 3 < total) issue_raw(s3);
-        asm volatile("s_mov_b32 m0, %0" ::"s"(keep));
-        if (s + 1 < total && (wv >> 2) == (k & 1)) transform(sp1_3, (unsigned)((k & 1) ^ 1));
-        if (!(p.ablate & 1)) phase(std::integral_constant<bool, k == 0>{}, s3, (unsigned)(k & 1));
-        if (s + 1 < total) {
-            // own pieces of U_(s+1) / raw_(s+2) have landed: at most this interval's pieces still fly (loads return in order; the epilogue's
-            // stores, if they still fly, only make this wait longer)
-            if (s + 3 < total && !no_dma) {
-                if (wv == 7) w5_wait_vmcnt<6>();
-                else w5_wait_vmcnt<5>();
-            } else {
-                w5_wait_vmcnt<0>();
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();   // B_(s+1)
-            asm volatile("" ::: "memory");
-        }
-        ++s, s3 = sp1_3;
-    };
-    for (; cu < u_end; cu += u_step) {
-        step(std::integral_constant<int, 0>{}), step(std::integral_constant<int, 1>{}), step(std::integral_constant<int, 2>{}), step(std::integral_constant<int, 3>{});
-        step(std::integral_constant<int, 4>{}), step(std::integral_constant<int, 5>{}), step(std::integral_constant<int, 6>{}), step(std::integral_constant<int, 7>{});
-        if (!(p.ablate & 8)) {
-            const W5Unit CU = w5_unit(p, cu);
-            // ---- Y = A^T M A, A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,1]]: rows first (over j), then columns (over i)
-            f32x4 z[6][2];
+    // ---- the unit loop.  The two waves of a SIMD run the SAME k-step in OPPOSITE order (round 5, second cut): waves 0-3 multiply first and do
+    // everything else -- epilogue, DMA issue, their turn at the transform -- behind it; waves 4-7 do all that first and multiply last.  One of
+    // the two is in its matrix phase at any time.  (First cut, both in the same order: the timing-only ablations ADDED UP -- 123 us of matrix
+    // instructions + 55 DMA issue + 31 transform + 33 epilogue + 52 barriers and waits = the 288 us measured.)
+    // k is a compile-time constant and the two orders are two separate loops: a unit is straight-line code -- the first step's matrix
+    // instructions (C = 0) define the accumulators, the other seven update them, nothing merges two forms of them at a control-flow join (merged,
+    // hipcc spilled ~250 registers or moved all 144 through copies at every loop edge).
+    auto run = [&](auto MF_) {
+        constexpr bool MF = decltype(MF_)::value;   // matrix phase first
+        unsigned s = 0, s3 = 0;                     // k-step, s % 3  (s % 2 = k % 2, s % 8 = k: 8 k-steps per unit)
+        for (unsigned cu = u_begin; cu < u_end; cu += u_step) {
+            auto epilogue = [&]() {
+                if (p.ablate & 8) return;
+                const W5Unit CU = w5_unit(p, cu);
+                // ---- Y = A^T M A, A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,1]]: rows first (over j), then columns (over i)
+                f32x4 z[6][2];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const f32x4 *m = acc + i * 6;
-                z[i][0] = ((m[0] + m[1]) + (m[2] + m[3])) + m[4];
-                z[i][1] = ((m[1] - m[2]) + 2.f * (m[3] - m[4])) + m[5];
-            }
-            f32x4 y[2][2];
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                y[0][b] = ((z[0][b] + z[1][b]) + (z[2][b] + z[3][b])) + z[4][b];
-                y[1][b] = ((z[1][b] - z[2][b]) + 2.f * (z[3][b] - z[4][b])) + z[5][b];
-            }
-            const int co = cb * 16 + 4 * (lane >> 4);
-            f32x4 bs = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) bs = *reinterpret_cast<const f32x4 *>(p.bias + co);
-            const int t16 = lane & 15;
-            const int oy = CU.y0 + 2 * (2 * tb + (t16 >> 3)), ox = CU.x0 + 2 * (t16 & 7);
-            float *o = p.out + ((size_t)(CU.n * p.H + oy) * p.W + ox) * p.out_ld + co;
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
+                for (int i = 0; i < 6; ++i) {
+                    const f32x4 *m = acc + i * 6;
+                    z[i][0] = ((m[0] + m[1]) + (m[2] + m[3])) + m[4];
+                    z[i][1] = ((m[1] - m[2]) + 2.f * (m[3] - m[4])) + m[5];
+                }
+                f32x4 y[2][2];
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    f32x4 v = y[a][b] + bs;
-                    v.x = act_apply(v.x, p.act), v.y = act_apply(v.y, p.act), v.z = act_apply(v.z, p.act), v.w = act_apply(v.w, p.act);
-                    *reinterpret_cast<f32x4 *>(o + ((size_t)a * p.W + b) * p.out_ld) = v;
+                    y[0][b] = ((z[0][b] + z[1][b]) + (z[2][b] + z[3][b])) + z[4][b];
+                    y[1][b] = ((z[1][b] - z[2][b]) + 2.f * (z[3][b] - z[4][b])) + z[5][b];
                 }
+                const int co = cb * 16 + 4 * (lane >> 4);
+                f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) bs = *reinterpret_cast<const f32x4 *>(p.bias + co);
+                const int t16 = lane & 15;
+                const int oy = CU.y0 + 2 * (2 * tb + (t16 >> 3)), ox = CU.x0 + 2 * (t16 & 7);
+                float *o = p.out + ((size_t)(CU.n * p.H + oy) * p.W + ox) * p.out_ld + co;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        f32x4 v = y[a][b] + bs;
+                        v.x = act_apply(v.x, p.act), v.y = act_apply(v.y, p.act), v.z = act_apply(v.z, p.act), v.w = act_apply(v.w, p.act);
+                        *reinterpret_cast<f32x4 *>(o + ((size_t)a * p.W + b) * p.out_ld) = v;
+                    }
+            };
+            auto step = [&](auto KC) {
+                constexpr int k = decltype(KC)::value;
+                const unsigned sp1_3 = s3 == 2 ? 0u : s3 + 1, sp2_3 = sp1_3 == 2 ? 0u : sp1_3 + 1;
+                if constexpr (MF) {
+                    if (!(p.ablate & 1)) phase(std::integral_constant<bool, k == 0>{}, s3, (unsigned)(k & 1));
+                    if constexpr (k == W5_NK - 1) epilogue();
+                }
+                asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
+                if (s + 2 < total) issue_u(sp2_3, (k + 2) & 7);
+                if (s + 3 < total) issue_raw(s3);
+                asm volatile("s_mov_b32 m0, %0" ::"s"(keep));
+                if (s + 1 < total && (wv >> 2) == (k & 1)) transform(sp1_3, (unsigned)((k & 1) ^ 1));
+                if constexpr (!MF)
+                    if (!(p.ablate & 1)) phase(std::integral_constant<bool, k == 0>{}, s3, (unsigned)(k & 1));
+                if (s + 1 < total) {
+                    // own pieces of U_(s+1) / raw_(s+2) have landed: at most this interval's pieces still fly (loads return in order; the
+                    // epilogue's stores, if they still fly, only make this wait longer)
+                    if (s + 3 < total && !no_dma) {
+                        if (wv == 7) w5_wait_vmcnt<6>();
+                        else w5_wait_vmcnt<5>();
+                    } else {
+                        w5_wait_vmcnt<0>();
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();   // B_(s+1)
+                    asm volatile("" ::: "memory");
+                }
+                ++s, s3 = sp1_3;
+            };
+            step(std::integral_constant<int, 0>{}), step(std::integral_constant<int, 1>{}), step(std::integral_constant<int, 2>{}), step(std::integral_constant<int, 3>{});
+            step(std::integral_constant<int, 4>{}), step(std::integral_constant<int, 5>{}), step(std::integral_constant<int, 6>{}), step(std::integral_constant<int, 7>{});
+            if constexpr (!MF) epilogue();   // (behind the barrier: beside the other waves' first matrix phase of the next unit)
         }
-    }
+    };
+    if (wv < 4 && !(p.ablate & 16)) run(std::true_type{});
+    else run(std::false_type{});
 }
 
 // Runs the first-layer launch described by kp on the Winograd kernel when it is covered: fp32, NCHW source of 17 .. 32 channels with
@@ -333,7 +360,7 @@ int wino5_first_try(const ConvKParams &kp, const float *u, hipStream_t st, const
     p.u = u, p.bias = kp.bias, p.act = kp.act, p.out = static_cast<float *>(kp.out), p.out_ld = kp.out_ld;
     p.tiles_x = kp.W / (2 * W5_TC), p.tiles_y = kp.H / (2 * W5_TR);
     p.nunits = (unsigned)(p.tiles_x * p.tiles_y) * (unsigned)kp.N;
-    p.ablate = g_experiment >= 1300 && g_experiment < 1316 ? g_experiment - 1300 : 0;
+    p.ablate = g_experiment >= 1300 && g_experiment < 1364 ? g_experiment - 1300 : 0;
     static PerDeviceInt ncu_dev;
     int &ncu = ncu_dev.cur();
     if (ncu == 0) {
