@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(W5_THREADS, 2) wino5_first_kernel(const Wino5P
         };
 #pragma unroll
         for (int g = 0; g < PD; ++g) rd(g);
-        if (p.ablate & 32) __builtin_amdgcn_s_setprio(2);   // (A/B: the multiplying wave first at its SIMD's issue port)
+        if (!(p.ablate & 32)) __builtin_amdgcn_s_setprio(2);   // the multiplying wave first at its SIMD's issue port (287 -> 279 us; PWS_OPT_EXPERIMENT 1332: without)
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (g + PD < NG) rd(g + PD);
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(W5_THREADS, 2) wino5_first_kernel(const Wino5P
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (p.ablate & 32) __builtin_amdgcn_s_setprio(0);
+        if (!(p.ablate & 32)) __builtin_amdgcn_s_setprio(0);
     };
 
     unsigned keep;
