@@ -160,13 +160,13 @@ __device__ inline void wring_pack_element(const float *__restrict__ pk, float *_
             ur[wring_index(16, r * 4 + 2, ci, co, nch)] = 0.5f * (u[r][0] - u[r][1] + u[r][2]);
             ur[wring_index(16, r * 4 + 3, ci, co, nch)] = u[r][2];
         }
-    } else if (ct4 == 2) {   // F(2x2,5x5) of the first layer (conv_first_wino.hip), points {0, 1, -1, 2, -2, inf}: U = G g G^T in double, rounded once;
+    } else if (ct4 == 2) {   // F(2x2,5x5) of the first layer (conv_first_wino.hip), points {0, 1, -1, 2, -1/2, inf}: U = G g G^T in double, rounded once;
         // layout [k-step = ci / 4][component / 4][channel block co / 16][kq = ci % 4][co % 16][component % 4]: a k-step is 36 KB, a lane's A operands of four components 16 bytes
-        const double G[6][5] = {{0.25, 0, 0, 0, 0},
-                                {-1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6},
-                                {-1.0 / 6, 1.0 / 6, -1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                {1.0 / 24, 1.0 / 12, 1.0 / 6, 1.0 / 3, 2.0 / 3},
-                                {1.0 / 24, -1.0 / 12, 1.0 / 6, -1.0 / 3, 2.0 / 3},
+        const double G[6][5] = {{1, 0, 0, 0, 0},
+                                {-1.0 / 3, -1.0 / 3, -1.0 / 3, -1.0 / 3, -1.0 / 3},
+                                {1.0 / 3, -1.0 / 3, 1.0 / 3, -1.0 / 3, 1.0 / 3},
+                                {1.0 / 15, 2.0 / 15, 4.0 / 15, 8.0 / 15, 16.0 / 15},
+                                {-16.0 / 15, 8.0 / 15, -4.0 / 15, 2.0 / 15, -1.0 / 15},
                                 {0, 0, 0, 0, 1}};
         double t[6][5];
         for (int r = 0; r < 6; ++r)
