@@ -136,7 +136,10 @@ int pws_pack_conv_weight_wino_ct4(const float *w_packed, float *w_wino, int cin,
 /* Winograd weights in the layout of the persistent LDS-ring kernel (second generation, taken when the map consists of whole
  * 16 x 32-pixel units and fills the chip): F(2x2,3x3) for K3S1 / CONVT_K3S1 (16 components), F(2x2,2x2) per output parity class
  * for CONVT_K4S2 (2 x 18 components), from the PACKED weights.  Needs cout % 32 == 0 (pws_packed_wring_floats returns 0
- * otherwise: leave pws_conv_args.w_wring NULL). */
+ * otherwise: leave pws_conv_args.w_wring NULL).
+ * Round 5: also K5S1 with 17..32 input channels and exactly 64 output channels -- the generator's first layer (reference
+ * lib/networks_cascading.py:21-23) as Winograd F(2x2,5x5), 36 components on the points {0, 1, -1, 2, -1/2, inf}, for fp32 NCHW
+ * sources (pws_conv_args.src_nchw) whose maps are whole 8 x 16-pixel units, at least two per compute unit. */
 size_t pws_packed_wring_floats(int kind, int cin, int cout);
 int pws_pack_conv_weight_wring(const float *w_packed, float *w_wring, int kind, int cin, int cout, pws_stream_t stream);
 
@@ -190,7 +193,7 @@ typedef struct pws_conv_args {
                          ld / out_ld still count ELEMENTS; ld % 8 == 0, out_ld even).  Needs math == PWS_MATH_BF16 and a kind
                          the bf16 kernels cover.  Halves the activation traffic of the bf16 path. */
     const float *w_wring; /* optional: ring-layout Winograd weights from pws_pack_conv_weight_wring (K3S1 / CONVT_K3S1 / CONVT_K4S2,
-                         fp32 NHWC sources): tried before w_wino and the direct kernels */
+                         fp32 NHWC sources; K5S1 of the first layer, fp32 NCHW source): tried before w_wino and the direct kernels */
     void *out_sign;   /* optional, store == PWS_STORE_BF16 and cout % 8 == 0 only: the SIGN BITS of `out`, written beside it -- bit (c & 7)
                          of byte out_sign[pixel * out_sign_ld + c / 8] = (out[pixel][c] > 0), for the rounded bf16 value.  What the
                          backward of a LeakyReLU / ReLU block needs of its forward tensor (pws_dst.act_sign): 1/16 of its bytes. */

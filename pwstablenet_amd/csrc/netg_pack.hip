@@ -343,9 +343,10 @@ __global__ void __launch_bounds__(256) pack16_all_kernel(const Pack16Args a, flo
         unsigned *dst = reinterpret_cast<unsigned *>(packed) + a.wb_off[l];
         const int kpad = L.cin_pad, half = nci / 2;
         const int n = L.planes * nco * half;
+        const int lh = 31 - __builtin_clz((unsigned)half), lc = 31 - __builtin_clz((unsigned)nco);   // (tile extents are powers of two: shifts, not divisions)
         for (int i = threadIdx.x; i < n; i += 256) {
-            const int k2 = i % half, r = i / half;
-            const int co_l = r % nco, pl = r / nco;
+            const int k2 = i & (half - 1), r = i >> lh;
+            const int co_l = r & (nco - 1), pl = r >> lc;
             const int q = pack_fwd_tap(L.kind, L.k, pl);
             const float *src = lds + (2 * k2) * sci + co_l * sco + q;
             const int ci = ci0 + 2 * k2, co = co0 + co_l;
@@ -356,9 +357,10 @@ __global__ void __launch_bounds__(256) pack16_all_kernel(const Pack16Args a, flo
         unsigned *dst = reinterpret_cast<unsigned *>(packed_dgrad) + a.dgb_off[l];
         const int kpad = L.cout, half = nco / 2;
         const int n = L.dg_taps * nci * half;
+        const int lh = 31 - __builtin_clz((unsigned)half), lc = 31 - __builtin_clz((unsigned)nci);
         for (int i = threadIdx.x; i < n; i += 256) {
-            const int k2 = i % half, r = i / half;
-            const int ci_l = r % nci, pl = r / nci;
+            const int k2 = i & (half - 1), r = i >> lh;
+            const int ci_l = r & (nci - 1), pl = r >> lc;
             const int q = pack_dgrad_tap(L.kind, pl);
             const float *src = lds + ci_l * sci + (2 * k2) * sco + (q >= 0 ? q : 0);
             const int ci = ci0 + ci_l, co = co0 + 2 * k2;
