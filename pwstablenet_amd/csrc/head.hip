@@ -6,6 +6,8 @@
 //  * field head  (reference :128,174,198,219,235-237): conv3x3 (C->2) + bias, tanh, tanh again, NCHW->NHWC
 //    permute, + F.affine_grid(theta) -- fused into one pass that reads the C-channel feature map once
 //    (HBM-bound: C*4 B/pixel in, 8-16 B/pixel out) and writes the final N,H,W,2 field.
+#include <type_traits>
+
 #include "common.h"
 
 namespace pws {
@@ -279,6 +281,194 @@ __global__ void __launch_bounds__(256) field_head16_mfma_kernel(const __bf16 *__
     }
 }
 
+// Second cut of the kernel above (round 5).  profiles/r05_pmc_train_bf16_table.log: 189 us per dispatch of 64 samples = 3.3 TB/s on 630 MB, 15 %
+// matrix-pipe busy, 35 % of the cycles spent issuing vector instructions -- its main loop is 430 vector + 490 scalar instructions per 256-pixel
+// tile and lane, the memory side waits for them.  Same arithmetic (the three-term weights, fp32 sums, tanh(tanh(.)), the stencil's order of
+// additions), fewer instructions per pixel:
+//   * tile 16 x 32 (halo 18 x 34 = 612 pixels = 20 blocks of 32, five per wave): 1.20 halo pixels per output pixel instead of 1.27, two output
+//     pixels per lane in the stencil phase;
+//   * the matrix instruction transposed: the weights are the A operand, a block of 32 halo pixels the B operand, so a lane ends up with
+//     (tap, o) rows m = 4 hi + {0..3, 8..11, 16..19} of ITS pixel -- three (two) 16-byte LDS writes per block instead of sixteen 4-byte ones;
+//   * the pixels of block g + 2 (fp32: g + 1) are requested while block g is multiplied, through three (two) register sets that rotate with the
+//     block index (the tile loop is unrolled three (two) times so that every index is a constant): 48 KB in flight per workgroup where the
+//     first cut had one tile's loads issued behind its last matrix instruction;
+//   * a block's tile offsets are computed once per kernel, an interior tile adds one scalar to them.
+__device__ const u32x4 g_head_zero128[8] = {};   // what the masked lanes of field_head_v2_kernel load
+namespace {
+constexpr int F2_TH = 16, F2_TW = 32, F2_IH = F2_TH + 2, F2_IW = F2_TW + 2, F2_NPIX = F2_IH * F2_IW, F2_BPW = 5, F2_YP = 20;
+static_assert(F2_BPW * 4 * 32 >= F2_NPIX, "five blocks of 32 halo pixels per wave");
+struct F2Tile {
+    int n, y0, x0;
+};
+}  // namespace
+// F32: fp32 storage on v_mfma_f32_32x32x2_f32 (k-step j of lane half `hi` = channel 32 hi + j: a lane's 32 consecutive channels, exact fp32
+// weights), else bf16 storage on v_mfma_f32_32x32x16_bf16 with the three-term weights.  NSET register sets of one block of pixels each.
+template <bool F32, int NSET>
+__global__ void __launch_bounds__(256, 3) field_head_v2_kernel(const void *__restrict__ x_, int ld, int N, int H, int W,
+                                                               const float *__restrict__ w_out, const float *__restrict__ b_out,
+                                                               const float *__restrict__ theta, int ac, float *__restrict__ resid,
+                                                               float *__restrict__ grid, int tiles_x, int tiles_y, unsigned ntiles, int raw) {
+    constexpr int C = 64;
+    constexpr int EB = F32 ? 4 : 2;                // bytes per element
+    constexpr int NV = F32 ? 8 : 4;                // 16-byte loads per lane and block: its 32 (fp32) / 4 x 8 (bf16) channels
+    __shared__ __attribute__((aligned(16))) float ys[F2_NPIX * F2_YP];   // Y[halo pixel][(tap, o) 0 .. 17 (+2)]: 48 KB
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    const unsigned char *x = static_cast<const unsigned char *>(x_);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    // A operand: row l31 = (tap, o).  bf16: this lane's 8 channels of each of the four 16-channel k-steps, as three bf16 terms; fp32: its 32 channels
+    bf16x8 wh[F32 ? 1 : 4], wm[F32 ? 1 : 4], wl[F32 ? 1 : 4];
+    float w32[F32 ? 32 : 1];
+    {
+        const int tap = l31 >> 1, o = l31 & 1;
+        if constexpr (F32) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) w32[j] = l31 < 18 ? w_out[((size_t)tap * C + hi * 32 + j) * 2 + o] : 0.f;
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float w = l31 < 18 ? w_out[((size_t)tap * C + ks * 16 + hi * 8 + i) * 2 + o] : 0.f;
+                    const __bf16 h = (__bf16)w;
+                    const float r1 = w - (float)h;
+                    const __bf16 m = (__bf16)r1;
+                    wh[ks][i] = h, wm[ks][i] = m, wl[ks][i] = (__bf16)(r1 - (float)m);
+                }
+        }
+    }
+    // this lane's halo pixel of each of its wave's five blocks: row | column << 8, and its byte offset from the halo's first pixel
+    int geo[F2_BPW];
+    unsigned rel[F2_BPW];
+#pragma unroll
+    for (int j = 0; j < F2_BPW; ++j) {
+        const int q = (wv + 4 * j) * 32 + l31;
+        const int row = q / F2_IW, col = q - row * F2_IW;
+        geo[j] = q < F2_NPIX ? (row | col << 8) : -1;
+        rel[j] = (unsigned)(((row * W + col) * ld + hi * (F32 ? 32 : 8)) * EB);
+    }
+    auto decode = [&](unsigned t) {
+        const unsigned tile = xcd_remap(t, ntiles);
+        F2Tile r;
+        r.x0 = (int)(tile % (unsigned)tiles_x) * F2_TW;
+        r.y0 = (int)((tile / (unsigned)tiles_x) % (unsigned)tiles_y) * F2_TH;
+        r.n = (int)(tile / (unsigned)(tiles_x * tiles_y));
+        return r;
+    };
+    auto issue = [&](const F2Tile &T, int j, u32x4 (&dst)[NV]) {   // block j of tile T into a register set
+        const int oy = T.y0 - 1, ox = T.x0 - 1;
+        const bool interior = oy >= 0 && oy + F2_IH <= H && ox >= 0 && ox + F2_IW <= W;   // scalar
+        bool ok = geo[j] >= 0;
+        if (!interior) {
+            const int iy = oy + (geo[j] & 0xff), ix = ox + (geo[j] >> 8);
+            ok = ok && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        }
+        const long long base = ((long long)(T.n * H + oy) * W + ox) * ld * EB;   // scalar; may be negative at the border
+        // a lane outside the image (or past the halo) reads 128 bytes of zeros instead: ONE select on the address, none on the loaded words
+        const unsigned char *px = ok ? x + (base + (long long)rel[j]) : reinterpret_cast<const unsigned char *>(g_head_zero128);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) dst[v] = *reinterpret_cast<const u32x4 *>(px + (F32 ? v * 16 : v * 32));   // (bf16: k-step v = channels 16 v + 8 hi ..)
+    };
+    unsigned t = blockIdx.x;
+    if (t >= ntiles) return;
+    F2Tile T = decode(t);
+    unsigned tn = t + gridDim.x;
+    bool more = tn < ntiles;
+    F2Tile TN = more ? decode(tn) : T;
+    const float bias0 = b_out ? b_out[0] : 0.f, bias1 = b_out ? b_out[1] : 0.f;
+    u32x4 xb[NSET][NV];
+    constexpr int D = NSET - 1;   // blocks requested ahead
+#pragma unroll
+    for (int j = 0; j < D; ++j) issue(T, j, xb[j]);
+    auto do_tile = [&](auto R_) {
+        constexpr int R = decltype(R_)::value;   // register set of this tile's block 0
+#pragma unroll
+        for (int j = 0; j < F2_BPW; ++j) {
+            if (j + D < F2_BPW) issue(T, j + D, xb[(j + D + R) % NSET]);
+            else if (more) issue(TN, j + D - F2_BPW, xb[(j + D + R) % NSET]);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            if constexpr (F32) {
+#pragma unroll
+                for (int k4 = 0; k4 < 8; ++k4) {
+                    const f32x4 xv = __builtin_bit_cast(f32x4, xb[(j + R) % NSET][k4]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w32[4 * k4], xv[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w32[4 * k4 + 1], xv[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w32[4 * k4 + 2], xv[2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w32[4 * k4 + 3], xv[3], acc, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 xv = __builtin_bit_cast(bf16x8, xb[(j + R) % NSET][ks]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], xv, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm[ks], xv, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks], xv, acc, 0, 0, 0);
+                }
+            }
+            // this lane's pixel (column l31 of the block), rows m = 4 hi + {0..3, 8..11, 16..19}
+            const int q = (wv + 4 * j) * 32 + l31;
+            if (q < F2_NPIX) {
+                float *yq = ys + q * F2_YP + 4 * hi;
+                *reinterpret_cast<f32x4 *>(yq) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+                *reinterpret_cast<f32x4 *>(yq + 8) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
+                if (hi == 0) *reinterpret_cast<f32x4 *>(yq + 16) = (f32x4){acc[8], acc[9], acc[10], acc[11]};
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int idx = tid + h2 * 256;
+            const int ty = idx >> 5, tx = idx & 31;
+            float acc0 = bias0, acc1 = bias1;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float2 v = *reinterpret_cast<const float2 *>(ys + ((ty + tap / 3) * F2_IW + tx + tap % 3) * F2_YP + tap * 2);
+                acc0 += v.x, acc1 += v.y;
+            }
+            const int y = T.y0 + ty, xq = T.x0 + tx;
+            if (y < H && xq < W && raw) {
+                *reinterpret_cast<float2 *>(resid + (((size_t)T.n * H + y) * W + xq) * 2) = make_float2(acc0, acc1);
+            } else if (y < H && xq < W) {
+                const float r0 = tanhf(tanhf(acc0)), r1 = tanhf(tanhf(acc1));
+                const size_t pp = ((size_t)T.n * H + y) * W + xq;
+                if (resid) *reinterpret_cast<float2 *>(resid + pp * 2) = make_float2(r0, r1);
+                if (grid) {
+                    float a0 = 0.f, a1 = 0.f;
+                    if (theta) {
+                        const float *th = theta + (size_t)T.n * 6;
+                        const float bx = ac ? (W > 1 ? (2.f * xq) / (float)(W - 1) - 1.f : 0.f) : (2.f * xq + 1.f) / (float)W - 1.f;
+                        const float by = ac ? (H > 1 ? (2.f * y) / (float)(H - 1) - 1.f : 0.f) : (2.f * y + 1.f) / (float)H - 1.f;
+                        a0 = th[0] * bx + th[1] * by + th[2];
+                        a1 = th[3] * bx + th[4] * by + th[5];
+                    }
+                    *reinterpret_cast<float2 *>(grid + pp * 2) = make_float2(r0 + a0, r1 + a1);
+                }
+            }
+        }
+        __syncthreads();   // everybody is done with this tile's Y before the next tile's products are written
+    };
+    auto advance = [&]() {
+        T = TN, t = tn, tn += gridDim.x;
+        more = tn < ntiles;
+        if (more) TN = decode(tn);
+    };
+    // the register set of a tile's block 0 moves by F2_BPW % NSET from tile to tile: NSET tiles unrolled, every index a constant
+    for (;;) {
+        do_tile(std::integral_constant<int, 0>{});
+        if (!more) break;
+        advance();
+        do_tile(std::integral_constant<int, F2_BPW % NSET>{});
+        if (!more) break;
+        advance();
+        if constexpr (NSET == 3) {
+            do_tile(std::integral_constant<int, (2 * F2_BPW) % NSET>{});
+            if (!more) break;
+            advance();
+        }
+    }
+}
+
 // The same formulation in exact fp32 (BASELINE configs[1]: fp32 storage, 64 channels) on v_mfma_f32_32x32x2_f32: k-step j of lane
 // half `hi` is channel 32 hi + j, so a lane reads the 32 consecutive channels of its pixel (8 x 16 bytes) and holds the matching 32
 // weights of its column (tap, o).  Products and sums are fp32 as in the VALU kernel (the summation order differs).
@@ -520,7 +710,23 @@ extern "C" int pws_field_head_fwd_s(const float *x, int ld, int n, int h, int w,
         const unsigned k = (ntiles + (unsigned)(ncu * 3) - 1) / (unsigned)(ncu * 3);
         pgrid = ((ntiles + k - 1) / k + kXcds - 1) / kXcds * kXcds;
     }
-    if (store == PWS_STORE_BF16 && c == 64 && ld % 8 == 0 && g_experiment != 90)   // the matrix-core kernel (see its comment)
+    const bool v2_16 = store == PWS_STORE_BF16 && ld % 8 == 0, v2_32 = store != PWS_STORE_BF16;
+    if (c == 64 && (v2_16 || v2_32) && g_experiment != 90 && g_experiment != 35 && w >= F2_TW && h >= F2_TH && (long long)h * w * ld * 4 < (1ll << 31)) {
+        // the second cut (16 x 32 tiles; PWS_OPT_EXPERIMENT 35: the first cut below)
+        const int tx2 = (w + F2_TW - 1) / F2_TW, ty2 = (h + F2_TH - 1) / F2_TH;
+        const unsigned nt2 = (unsigned)tx2 * ty2 * n;
+        unsigned pg2 = nt2;
+        if (g_experiment != 92 && nt2 > (unsigned)(ncu * 3)) {
+            const unsigned k = (nt2 + (unsigned)(ncu * 3) - 1) / (unsigned)(ncu * 3);
+            pg2 = ((nt2 + k - 1) / k + kXcds - 1) / kXcds * kXcds;
+        }
+        if (v2_16)
+            hipLaunchKernelGGL((field_head_v2_kernel<false, 3>), dim3(pg2), dim3(256), 0, as_stream(stream), x, ld, n, h, w, w_out, b_out, theta, align_corners, resid,
+                               grid, tx2, ty2, nt2, 0);
+        else
+            hipLaunchKernelGGL((field_head_v2_kernel<true, 2>), dim3(pg2), dim3(256), 0, as_stream(stream), x, ld, n, h, w, w_out, b_out, theta, align_corners, resid,
+                               grid, tx2, ty2, nt2, 0);
+    } else if (store == PWS_STORE_BF16 && c == 64 && ld % 8 == 0 && g_experiment != 90)   // the matrix-core kernel (see its comment)
         hipLaunchKernelGGL(field_head16_mfma_kernel, dim3(pgrid), dim3(256), 0, as_stream(stream), reinterpret_cast<const __bf16 *>(x), ld, n, h, w,
                            w_out, b_out, theta, align_corners, resid, grid, tiles_x, tiles_y, ntiles, 0);
     else if (store == PWS_STORE_BF16)

@@ -448,6 +448,40 @@ def test_field_head_persistent_walk_equals_one_tile_per_workgroup(hip, oracle, s
     np.testing.assert_allclose(got[0][1], ref_grid, rtol=0, atol=5e-5)
 
 
+@pytest.mark.parametrize("store", ["bf16", "fp32"])
+@pytest.mark.parametrize("shape", [(1, 16, 32), (2, 37, 45), (1, 256, 256), (7, 200, 250), (24, 256, 256)])
+def test_field_head_second_cut_gives_the_bits_of_the_first(hip, store, shape):
+    """Round 5: field_head_v2_kernel (csrc/head.hip: 16 x 32 tiles, the matrix instruction transposed -- weights as the A operand --, three / two
+    rotating register sets of pixel blocks requested ahead, tile loop unrolled so that every register index is a constant) against the first cut
+    (PWS_OPT_EXPERIMENT 35): same products, same sums in the same order -- bit for bit, on one tile, ragged borders, workgroups that walk 1, 2
+    and 5 tiles (the register sets rotate through every phase), with and without theta / resid."""
+    A = hip
+    L, st = A.lib(), A.current_stream()
+    n, h, w = shape
+    c = 64
+    g = torch.Generator(device="cuda").manual_seed(n * 1000 + h)
+    x = (torch.randn((n, h, w, c), device="cuda", generator=g) * 0.5).to(torch.bfloat16 if store == "bf16" else torch.float32)
+    wout = torch.randn((9, c, 2), device="cuda", generator=g) * 0.05
+    bout = torch.randn(2, device="cuda", generator=g) * 0.1
+    theta = torch.randn((n, 6), device="cuda", generator=g) * 0.1
+    out = {}
+    try:
+        for e in (0, 35):
+            L.pws_set_option(A.OPT_EXPERIMENT, e)
+            res = torch.full((n, h, w, 2), float("nan"), device="cuda")
+            grid = torch.full((n, h, w, 2), float("nan"), device="cuda")
+            A.check(L.pws_field_head_fwd_s(ctypes.c_void_p(x.data_ptr()), c, n, h, w, c, A.ptr(wout), A.ptr(bout), A.ptr(theta), 0, A.ptr(res), A.ptr(grid),
+                                           A.STORE_BF16 if store == "bf16" else A.STORE_FP32, st), "field head")
+            only = torch.full((n, h, w, 2), float("nan"), device="cuda")
+            A.check(L.pws_field_head_fwd_s(ctypes.c_void_p(x.data_ptr()), c, n, h, w, c, A.ptr(wout), None, None, 1, None, A.ptr(only),
+                                           A.STORE_BF16 if store == "bf16" else A.STORE_FP32, st), "field head")
+            out[e] = (res.clone(), grid.clone(), only.clone())
+    finally:
+        L.pws_set_option(A.OPT_EXPERIMENT, 0)
+    for a, b in zip(out[0], out[35]):
+        assert not torch.isnan(a).any() and torch.equal(a, b)
+
+
 @pytest.mark.parametrize("store,ld", [("bf16", 96), ("bf16", 72), ("fp32", 80), ("fp32", 68)])
 def test_field_head_c64_with_padded_rows_through_the_c_abi(hip, oracle, store, ld):
     """pws_field_head_fwd_s called directly with c == 64, ld > c and a map that is no multiple of the 16-pixel tile,
