@@ -293,10 +293,10 @@ __global__ void __launch_bounds__(256) field_head16_mfma_kernel(const __bf16 *__
 //     block index (the tile loop is unrolled three (two) times so that every index is a constant): 48 KB in flight per workgroup where the
 //     first cut had one tile's loads issued behind its last matrix instruction;
 //   * a block's tile offsets are computed once per kernel, an interior tile adds one scalar to them.
-__device__ const u32x4 g_head_zero128[8] = {};   // what the masked lanes of field_head_v2_kernel load
 namespace {
 constexpr int F2_TH = 16, F2_TW = 32, F2_IH = F2_TH + 2, F2_IW = F2_TW + 2, F2_NPIX = F2_IH * F2_IW, F2_BPW = 5, F2_YP = 20;
 static_assert(F2_BPW * 4 * 32 >= F2_NPIX, "five blocks of 32 halo pixels per wave");
+constexpr unsigned kF2Oob = 0x7ffffff0u;   // a byte offset no sample reaches (the launch rejects samples of 2^30 bytes and more)
 struct F2Tile {
     int n, y0, x0;
 };
@@ -314,6 +314,7 @@ __global__ void __launch_bounds__(256, 3) field_head_v2_kernel(const void *__res
     __shared__ __attribute__((aligned(16))) float ys[F2_NPIX * F2_YP];   // Y[halo pixel][(tap, o) 0 .. 17 (+2)]: 48 KB
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     const unsigned char *x = static_cast<const unsigned char *>(x_);
+    const unsigned img_bytes = (unsigned)H * W * ld * EB;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     // A operand: row l31 = (tap, o).  bf16: this lane's 8 channels of each of the four 16-channel k-steps, as three bf16 terms; fp32: its 32 channels
     bf16x8 wh[F32 ? 1 : 4], wm[F32 ? 1 : 4], wl[F32 ? 1 : 4];
@@ -344,7 +345,7 @@ __global__ void __launch_bounds__(256, 3) field_head_v2_kernel(const void *__res
         const int q = (wv + 4 * j) * 32 + l31;
         const int row = q / F2_IW, col = q - row * F2_IW;
         geo[j] = q < F2_NPIX ? (row | col << 8) : -1;
-        rel[j] = (unsigned)(((row * W + col) * ld + hi * (F32 ? 32 : 8)) * EB);
+        rel[j] = q < F2_NPIX ? (unsigned)(((row * W + col) * ld + hi * (F32 ? 32 : 8)) * EB) : kF2Oob;
     }
     auto decode = [&](unsigned t) {
         const unsigned tile = xcd_remap(t, ntiles);
@@ -354,19 +355,25 @@ __global__ void __launch_bounds__(256, 3) field_head_v2_kernel(const void *__res
         r.n = (int)(tile / (unsigned)(tiles_x * tiles_y));
         return r;
     };
-    auto issue = [&](const F2Tile &T, int j, u32x4 (&dst)[NV]) {   // block j of tile T into a register set
+    // Block j of tile T into a register set, through a buffer descriptor of T's sample: a lane outside the image (or past the halo) carries an
+    // offset beyond the descriptor's records and is handed zeros by the address unit -- no select on the loaded words, no 64-bit lane addresses.
+    auto issue = [&](const F2Tile &T, int j, u32x4 (&dst)[NV]) {
         const int oy = T.y0 - 1, ox = T.x0 - 1;
         const bool interior = oy >= 0 && oy + F2_IH <= H && ox >= 0 && ox + F2_IW <= W;   // scalar
-        bool ok = geo[j] >= 0;
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(x) + (size_t)T.n * img_bytes, 0, (int)img_bytes, 0x00020000);
+        const int toff = (oy * W + ox) * ld * EB;   // scalar; negative at the top / left border (only for lanes the test below rejects)
+        unsigned voff = rel[j];   // kF2Oob already where the lane is past the halo
+        int soff = toff;
         if (!interior) {
             const int iy = oy + (geo[j] & 0xff), ix = ox + (geo[j] >> 8);
-            ok = ok && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const bool ok = geo[j] >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            voff = ok ? rel[j] + (unsigned)toff : kF2Oob;
+            soff = 0;
         }
-        const long long base = ((long long)(T.n * H + oy) * W + ox) * ld * EB;   // scalar; may be negative at the border
-        // a lane outside the image (or past the halo) reads 128 bytes of zeros instead: ONE select on the address, none on the loaded words
-        const unsigned char *px = ok ? x + (base + (long long)rel[j]) : reinterpret_cast<const unsigned char *>(g_head_zero128);
 #pragma unroll
-        for (int v = 0; v < NV; ++v) dst[v] = *reinterpret_cast<const u32x4 *>(px + (F32 ? v * 16 : v * 32));   // (bf16: k-step v = channels 16 v + 8 hi ..)
+        for (int v = 0; v < NV; ++v)   // (bf16: k-step v = channels 16 v + 8 hi ..)
+            dst[v] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff + (F32 ? v * 16 : v * 32), soff, 0));
     };
     unsigned t = blockIdx.x;
     if (t >= ntiles) return;
@@ -375,6 +382,8 @@ __global__ void __launch_bounds__(256, 3) field_head_v2_kernel(const void *__res
     bool more = tn < ntiles;
     F2Tile TN = more ? decode(tn) : T;
     const float bias0 = b_out ? b_out[0] : 0.f, bias1 = b_out ? b_out[1] : 0.f;
+    float *const yq0 = ys + (wv * 32 + l31) * F2_YP + 4 * hi;            // where this lane's products of block 0 go
+    const float *const ysr = ys + ((tid >> 5) * F2_IW + (tid & 31)) * F2_YP;   // this lane's first stencil pixel (the second is 8 rows down)
     u32x4 xb[NSET][NV];
     constexpr int D = NSET - 1;   // blocks requested ahead
 #pragma unroll
@@ -409,7 +418,7 @@ __global__ void __launch_bounds__(256, 3) field_head_v2_kernel(const void *__res
             // this lane's pixel (column l31 of the block), rows m = 4 hi + {0..3, 8..11, 16..19}
             const int q = (wv + 4 * j) * 32 + l31;
             if (q < F2_NPIX) {
-                float *yq = ys + q * F2_YP + 4 * hi;
+                float *yq = yq0 + j * (128 * F2_YP);   // one lane address, the block a constant offset
                 *reinterpret_cast<f32x4 *>(yq) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
                 *reinterpret_cast<f32x4 *>(yq + 8) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
                 if (hi == 0) *reinterpret_cast<f32x4 *>(yq + 16) = (f32x4){acc[8], acc[9], acc[10], acc[11]};
@@ -423,7 +432,7 @@ __global__ void __launch_bounds__(256, 3) field_head_v2_kernel(const void *__res
             float acc0 = bias0, acc1 = bias1;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                const float2 v = *reinterpret_cast<const float2 *>(ys + ((ty + tap / 3) * F2_IW + tx + tap % 3) * F2_YP + tap * 2);
+                const float2 v = *reinterpret_cast<const float2 *>(ysr + (h2 * 8 * F2_IW + (tap / 3) * F2_IW + tap % 3) * F2_YP + tap * 2);
                 acc0 += v.x, acc1 += v.y;
             }
             const int y = T.y0 + ty, xq = T.x0 + tx;
@@ -437,8 +446,9 @@ __global__ void __launch_bounds__(256, 3) field_head_v2_kernel(const void *__res
                     float a0 = 0.f, a1 = 0.f;
                     if (theta) {
                         const float *th = theta + (size_t)T.n * 6;
-                        const float bx = ac ? (W > 1 ? (2.f * xq) / (float)(W - 1) - 1.f : 0.f) : (2.f * xq + 1.f) / (float)W - 1.f;
-                        const float by = ac ? (H > 1 ? (2.f * y) / (float)(H - 1) - 1.f : 0.f) : (2.f * y + 1.f) / (float)H - 1.f;
+                        // (2 x + 1) / W - 1, or 2 x / (W - 1) - 1 with align_corners: the numerators are exact integers either way, one quotient each
+                        const float bx = (ac && W <= 1) ? 0.f : (float)(2 * xq + 1 - ac) / (float)(W - ac) - 1.f;
+                        const float by = (ac && H <= 1) ? 0.f : (float)(2 * y + 1 - ac) / (float)(H - ac) - 1.f;
                         a0 = th[0] * bx + th[1] * by + th[2];
                         a1 = th[3] * bx + th[4] * by + th[5];
                     }
@@ -711,7 +721,7 @@ extern "C" int pws_field_head_fwd_s(const float *x, int ld, int n, int h, int w,
         pgrid = ((ntiles + k - 1) / k + kXcds - 1) / kXcds * kXcds;
     }
     const bool v2_16 = store == PWS_STORE_BF16 && ld % 8 == 0, v2_32 = store != PWS_STORE_BF16;
-    if (c == 64 && (v2_16 || v2_32) && g_experiment != 90 && g_experiment != 35 && w >= F2_TW && h >= F2_TH && (long long)h * w * ld * 4 < (1ll << 31)) {
+    if (c == 64 && (v2_16 || v2_32) && g_experiment != 90 && g_experiment != 35 && w >= F2_TW && h >= F2_TH && (long long)h * w * ld * 4 < (1ll << 30)) {
         // the second cut (16 x 32 tiles; PWS_OPT_EXPERIMENT 35: the first cut below)
         const int tx2 = (w + F2_TW - 1) / F2_TW, ty2 = (h + F2_TH - 1) / F2_TH;
         const unsigned nt2 = (unsigned)tx2 * ty2 * n;

@@ -1307,6 +1307,9 @@ extern "C" int pws_netg_pack_weights_train(const float *const *params, float *pa
         // every source of the layer must be a multiple of 32 channels, or the bf16 kernels decline and fall back to the fp32 copies:
         // sources are sums of ngf multiples, ngf % 32 == 0 settles it
         ok = ok && ngf % 32 == 0;
+        // the first layer reads the caller's NCHW window: run_conv takes its bf16 kernel only for windows of <= 32 channels (the NHWC-32 copy);
+        // a wider window goes to the fp32 first-layer kernels, which read the fp32 packed copy -- so that copy must exist
+        if (i == L_TRANSFER) ok = ok && input_nc <= 32;
         fused[i] = ok, nfused += ok ? 1 : 0;
         f.first_block[i] = nb;
         f.wb_off[i] = ok ? off32(l.wb_off) : kNoOff;
