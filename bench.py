@@ -319,7 +319,10 @@ def configs2_step_leg(net, dev, n_items, math, reps, sync=None, seed=500, percep
     small = synth.make_train_batch(4, seed=seed)     # 4 distinct items tiled to n_items (host-side synthesis is slow)
     rep = (n_items + 3) // 4
     batch = [torch.from_numpy(t).repeat((rep,) + (1,) * (t.ndim - 1))[:n_items].to(dev) for t in small]
-    obj = StabObjective(batchSize=n_items)
+    # a leg without an exchange (no sync_gradients, no grad_sync on the generator) says so: its gradients stay this rank's own, whatever
+    # process group the bench has initialised (train_step refuses to guess in a multi-rank group)
+    exchanged = sync is not None or getattr(net.module, "grad_sync", None) is not None
+    obj = StabObjective(batchSize=n_items, grad_average_world=None if exchanged else 1)
     opt = Adam(net.parameters(), lr=1e-6, betas=(0.5, 0.999))
     for _ in range(max(1, warmup)):   # warm-up (allocations, weight re-pack; at the power cap the first steps run at a higher clock)
         out = train_step(net, opt, batch, obj, sync_gradients=sync, perceptual=perceptual)

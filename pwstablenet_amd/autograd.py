@@ -86,6 +86,7 @@ class _NetGTrain(torch.autograd.Function):
             mask = (ctypes.c_ubyte * nl)()
             done = [False] * nl
             sync.collectives = 0
+            sync.final_part = [None] * nl   # the run after which the C side reported each layer final (tests: equals pws_netg_backward_plan)
             for part in range(sync.nparts):
                 run(part, sync.nparts, mask)
                 newly = [i for i in range(nl) if mask[i] and not done[i]]
@@ -109,6 +110,7 @@ class _NetGTrain(torch.autograd.Function):
                             "pws_netg_unpack_grads")
                 for i in newly:
                     done[i] = True
+                    sync.final_part[i] = part
             assert all(done), "pws_netg_backward_part: a layer never became final"
             main.wait_stream(comm)
             dpacked.record_stream(comm)

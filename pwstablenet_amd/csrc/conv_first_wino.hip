@@ -357,7 +357,7 @@ int wino5_first_try(const ConvKParams &kp, const float *u, hipStream_t st, const
     if ((reinterpret_cast<size_t>(kp.src_ptr[0]) & 15) || sstride % 4 != 0 || (reinterpret_cast<size_t>(kp.out) & 15) ||
         (kp.bias && (reinterpret_cast<size_t>(kp.bias) & 15)) || (reinterpret_cast<size_t>(u) & 15))
         return 1;
-    if ((size_t)kp.src_c[0] * kp.H * kp.W * 4 >= (1u << 31)) return 1;
+    if ((size_t)kp.src_c[0] * kp.H * kp.W * 4 >= (1u << 30)) return 1;   // kW5Oob (+ a unit's scalar offset) must stay beyond the descriptor's records and below 2^32
     Wino5Params p{};
     p.src = static_cast<const float *>(kp.src_ptr[0]), p.C = kp.src_c[0], p.N = kp.N, p.H = kp.H, p.W = kp.W, p.sstride = sstride;
     p.u = u, p.bias = kp.bias, p.act = kp.act, p.out = static_cast<float *>(kp.out), p.out_ld = kp.out_ld;

@@ -363,6 +363,11 @@ static const TileChoice kK5N[] = {choice<K5S1_T256_NCHW, KID_CONV_K5S1>()};
 int conv_bf16_fwd(int kind, ConvKParams &kp, int cin_total, float *out, float *ws, size_t ws_floats, hipStream_t st,
                   const ProfInfo &pi);  // conv_bf16.hip; 1 = not covered
 int conv_bf16_dgrad(int kind, ConvKParams &kp, int cout_f, float *ws, size_t ws_floats, hipStream_t st, const ProfInfo &pi);
+// Parity ledger (tools/parity_budget.py): PWS_OPT_EXPERIMENT 3000 + mask takes ONE kernel family of the fp32 forward at a time back to the plain
+// direct fp32 kernel (conv_mfma_kernel), so that the whole-network error can be attributed family by family.  Bits: 1 = first layer (no
+// F(2x2,5x5), no planar-LDS kernel), 2 = the 3x3 stride-1 Winograd kernels, 4 = the transposed layers' F(2x2,2x2), 8 = conv_ringf_kernel,
+// 16 = conv_skinny_kernel.  Measurement only: nothing in the product sets it.
+static inline bool ledger_direct(int bit) { return g_experiment >= 3000 && g_experiment < 3032 && ((g_experiment - 3000) & bit) != 0; }
 int conv_ringf_try(int kind, const ConvKParams &kp, hipStream_t st, const ProfInfo &pi);   // conv_ring_f32.hip; 1 = not covered
 int conv_first_try(const ConvKParams &kp, hipStream_t st, const ProfInfo &pi);             // conv_first.hip; 1 = not covered
 int wino5_first_try(const ConvKParams &kp, const float *u, hipStream_t st, const ProfInfo &pi);   // conv_first_wino.hip; 1 = not covered
@@ -445,19 +450,19 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
         }
         // Winograd F(2x2,3x3) when there is enough of the map to fill the chip (measured cross-over, tools/conv_bench.py:
         // 256->256 @32x32 x8: 104 -> 79 us; 512->512 @16x16 x8: 106 -> 138 us); the deep maps stay direct + split-K
-        if (a->w_wring && !nchw && !bf16) {   // second-generation Winograd (persistent LDS ring) where whole 16 x 32 units fill the chip
+        if (a->w_wring && !nchw && !bf16 && !ledger_direct(2)) {   // second-generation Winograd (persistent LDS ring) where whole 16 x 32 units fill the chip
             const int rc = wring_try(a, ProfHint{pi.flops, pi.bytes}, st);
             if (rc != 1) return rc;
         }
         const long wblocks = cdiv(a->w, 16) * cdiv(a->h, 16) * a->n * cdiv(a->cout, 64);
         // (measured: with <= 64 input channels the per-workgroup prologue/epilogue outweighs the saving unless the map is huge)
-        if (a->w_wino && !nchw && a->h >= 16 && a->w >= 16 && wblocks >= 128 && (cin >= 128 || wblocks >= 2048))
+        if (a->w_wino && !nchw && a->h >= 16 && a->w >= 16 && wblocks >= 128 && (cin >= 128 || wblocks >= 2048) && !ledger_direct(2))
             return wino_k3s1_launch(a, ProfHint{pi.flops, pi.bytes}, st);
         if (!bf16 && !nchw) {   // the persistent LDS-ring kernel (exact fp32) where it is covered
             kp.out = a->out;
-            int rc = conv_ringf_try(a->kind, kp, st, pi);
+            int rc = ledger_direct(8) ? 1 : conv_ringf_try(a->kind, kp, st, pi);
             if (rc != 1) return rc;
-            rc = conv_skinny_try(a->kind, kp, a->out, ws, ws_floats, st, pi);   // the deep levels: one-shot weight fetch
+            rc = ledger_direct(16) ? 1 : conv_skinny_try(a->kind, kp, a->out, ws, ws_floats, st, pi);   // the deep levels: one-shot weight fetch
             if (rc != 1) return rc;
         }
         return select_and_launch(kK3S1, 5, kp, kp.cin_pad, a->out, ws, ws_floats, st, pi);
@@ -470,9 +475,9 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
         }
         if (!bf16 && !nchw) {
             kp.out = a->out;
-            int rc = conv_ringf_try(a->kind, kp, st, info(9, (double)a->n * kp.OH * kp.OW));
+            int rc = ledger_direct(8) ? 1 : conv_ringf_try(a->kind, kp, st, info(9, (double)a->n * kp.OH * kp.OW));
             if (rc != 1) return rc;
-            rc = conv_skinny_try(a->kind, kp, a->out, ws, ws_floats, st, info(9, (double)a->n * kp.OH * kp.OW));
+            rc = ledger_direct(16) ? 1 : conv_skinny_try(a->kind, kp, a->out, ws, ws_floats, st, info(9, (double)a->n * kp.OH * kp.OW));
             if (rc != 1) return rc;
         }
         return select_and_launch(kK3S2, 5, kp, kp.cin_pad, a->out, ws, ws_floats, st, info(9, (double)a->n * kp.OH * kp.OW));
@@ -482,7 +487,7 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
             const int rc = conv_bf16_fwd(a->kind, kp, kp.cin_pad, a->out, nullptr, 0, st, info(25, (double)a->n * a->h * a->w));
             if (rc != 1) return rc;
         }
-        if (nchw) {   // the persistent planar-LDS kernel where it is covered (the generator's 256 x 256 windows)
+        if (nchw && !ledger_direct(1)) {   // the persistent planar-LDS kernel where it is covered (the generator's 256 x 256 windows)
             kp.out = a->out;
             if (a->w_wring) {   // Winograd F(2x2,5x5) where the transformed weights are given and whole 8 x 16 units fill the chip
                 const int rcw = wino5_first_try(kp, static_cast<const float *>(a->w_wring), st, info(25, (double)a->n * a->h * a->w));
@@ -505,17 +510,17 @@ int conv2d_fwd_impl(const pws_conv_args *a, hipStream_t st) {
         // Measured (tools/conv_bench.py, N=8): 256->64 @128x128 646 vs 661 us direct, but 512->64 @64x64 473 vs 333 us -- the
         // 3-pixel tiles waste 21-41 % of a 64/32-pixel map and the 9-output epilogue is 2.25x the F(2x2,3x3) one -- so the
         // generator's executor does not pack these weights; the path stays available for large maps.
-        if (a->w_wring && !nchw && !bf16) {   // Winograd F(2x2,2x2) per parity class on the LDS ring (whole 16 x 32 input units)
+        if (a->w_wring && !nchw && !bf16 && !ledger_direct(4)) {   // Winograd F(2x2,2x2) per parity class on the LDS ring (whole 16 x 32 input units)
             const int rc = wring_try(a, ProfHint{pi.flops, pi.bytes}, st);
             if (rc != 1) return rc;
         }
         const long wb = cdiv(a->w, 24) * cdiv(a->h, 12) * a->n * cdiv(a->cout, 64) * 4;
-        if (a->w_wino && a->h >= 24 && a->w >= 24 && wb >= 256) return wino_k3s1_launch(a, ProfHint{pi.flops, pi.bytes}, st);
+        if (a->w_wino && a->h >= 24 && a->w >= 24 && wb >= 256 && !ledger_direct(4)) return wino_k3s1_launch(a, ProfHint{pi.flops, pi.bytes}, st);
         if (!bf16 && !nchw) {
             kp.out = a->out;
-            int rc = conv_ringf_try(a->kind, kp, st, pi);
+            int rc = ledger_direct(8) ? 1 : conv_ringf_try(a->kind, kp, st, pi);
             if (rc != 1) return rc;
-            rc = conv_skinny_try(a->kind, kp, a->out, ws, ws_floats, st, pi);
+            rc = ledger_direct(16) ? 1 : conv_skinny_try(a->kind, kp, a->out, ws, ws_floats, st, pi);
             if (rc != 1) return rc;
         }
         return select_and_launch(kCT4, 5, kp, kp.cin_pad, a->out, ws, ws_floats, st, pi);

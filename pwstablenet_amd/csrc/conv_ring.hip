@@ -90,6 +90,13 @@ template <int MODE_, int TH_, int TW_, int TN_, int R_, int MT_ = 2>
 struct RgCfg {
     static constexpr int MODE = MODE_, TH = TH_, TW = TW_, TN = TN_, R = R_, MT = MT_;
     static_assert(MT == 2 || (MT == 4 && TW == 32 && TN == 1), "tall matrix waves: consecutive operand rows = consecutive tile rows");
+    // Pixels per unit.  512 is the unit the large maps run on: a weight row staged for a group feeds 512 pixels, and the matrix phase of a group is
+    // as long as the DMA of the next.  Round 6: units of 256 and 128 pixels for the maps that give fewer than ~200 units of 512 (the 32 x 32 ... 8 x 8
+    // levels of a training batch, the 64 x 64 ... 16 x 16 levels of batch-8 inference): those launches left half the chip idle or fell back to
+    // conv_bf16_kernel's single-buffered chunk pipeline (16-19 % of the bf16 peak, profiles/r05_train_launches_bf16_b64.txt).  A small unit is
+    // DMA-bound by construction (the 36 KB of a 3x3 group's weights feed 128-256 pixels instead of 512), so fewer matrix waves do: PIX / 64.
+    static constexpr int PIX = TH * TW * TN;
+    static_assert(PIX == 512 || PIX == 256 || PIX == 128, "pixels per unit");
     static constexpr int KS = MODE == RM_K3S1 ? 3 : 2;
     static constexpr int TAPS = KS * KS;
     static constexpr int NPLANES = MODE >= RM_K3S2 ? 4 : 1;   // input parity planes
@@ -98,9 +105,10 @@ struct RgCfg {
     // the LDS-DMA pieces: a DMA piece blocks its wave for the ~30-70 cycles the texture addresser takes per piece, 75 pieces per
     // group -- issued by the matrix waves themselves that time ADDS to the matrix phase (measured: DMA-only, MFMA-only and
     // epilogue-only timings of the one-role kernel summed to its run time), issued by waves of their own it hides under it
-    static constexpr int MWAVES = 16 / MT, LWAVES = 4, THREADS = 64 * (MWAVES + LWAVES);
-    // 512 pixels per tile = TN samples x TH x TW; a matrix wave's operand is 32 consecutive tile pixels = 32 / TW tile rows
-    static_assert(TH * TW * TN == 512 && (TW == 32 || TW == 16 || TW == 8) && (TH & (TH - 1)) == 0, "tile");
+    static constexpr int MWAVES = PIX / 32 / MT, LWAVES = 4, THREADS = 64 * (MWAVES + LWAVES);
+    static constexpr int WAVES_PER_SIMD = (MWAVES + LWAVES + 3) / 4;   // what __launch_bounds__ promises: 3 -> 168 registers, 2 -> 256
+    // PIX pixels per tile = TN samples x TH x TW; a matrix wave's operand is 32 consecutive tile pixels = 32 / TW tile rows
+    static_assert((TW == 32 || TW == 16 || TW == 8 || TW == 4) && (TH & (TH - 1)) == 0 && MWAVES >= 1, "tile");
     static constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
     static constexpr int CKG = 32;                                // input channels per K group
     static constexpr int ROWB = CKG * 2;                          // bytes per LDS row (pixel / weight row): one 64-byte L2 request
@@ -141,7 +149,10 @@ __device__ __forceinline__ void ring_dma16(unsigned lds_addr, unsigned voff, __a
     // fenced barriers that order it against every LDS access to its destination), while hipcc stays free to schedule the
     // matrix phase's ds_reads and MFMAs around it
 }
-// the same inside a bracket that saved M0 and restores it (one save / restore per group instead of per piece)
+// the same inside a bracket that saved M0 and restores it (one save / restore per group instead of per piece).  Between the statements of a bracket
+// M0 holds the last piece's LDS address while hipcc believes it unchanged; it cannot be told ("m0" on a clobber list is rejected as a reserved
+// register), so the contract is the loaders' own: nothing M0-dependent (no s_movrel / s_sendmsg / GWS / v_readlane through m0, no LDS-direct) is
+// ever emitted between save and restore -- true of everything a loader wave does (scalar adds, v_add offsets, the DMA instructions).
 __device__ __forceinline__ void ring_dma16_m0(unsigned lds_addr, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned soff) {
     // (s_nop 3 + the two instructions behind it = the 5 wait states between a VALU write of an SGPR -- v_readfirstlane, or hipcc reloading a spilled
     //  scalar with v_readlane right in front of this statement -- and a VMEM instruction that reads it as descriptor / offset: hipcc pads nothing for inline asm)
@@ -190,7 +201,7 @@ __device__ __forceinline__ RingUnit ring_unit(const RingParams &p, unsigned u) {
 // SG (data gradient only): every act' operand is given as SIGN BITS (RingParams.dst_sign): the epilogue loads one byte per slot instead of
 // 16 (a runtime choice would keep both in registers: the data-gradient kernels stand at the 168-register limit)
 template <class C, bool DG, bool SG = false>   // DG: data-gradient epilogue (scatter over the forward layer's sources, accumulate, act')
-__global__ void __launch_bounds__(C::THREADS, C::MT == 4 ? 2 : 3) conv_ring_kernel(const RingParams p) {
+__global__ void __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) conv_ring_kernel(const RingParams p) {
     static_assert(DG || !SG, "sign bits are an operand of the data-gradient epilogue");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -468,6 +479,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MT == 4 ? 2 : 3) conv_ring_kern
     if constexpr (!DG) {
         float *wb = reinterpret_cast<float *>(lds + C::BIAS_OFF);
         for (int c = tid; c < C::BIAS_FLOATS; c += C::MWAVES * 64) wb[c] = (p.bias && c < p.cout) ? p.bias[c] : 0.f;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the writes have landed before this wave reaches B_0 (hipcc puts no wait in front of a bare s_barrier)
     }
 
 #ifdef PWS_RING_TIMERS   // diagnostic build (tools/ring_timers.sh): where a matrix wave's time goes, in s_memrealtime ticks (10 ns)
@@ -841,10 +853,28 @@ static int ring_launch(RingParams &rp, hipStream_t st) {
     return check_launch("conv_ring_kernel");
 }
 
-// Tile shapes: 16 x 32 pixels of one sample for maps at least 32 wide, 16 x 16 x 2 samples for 16-wide maps, 8 x 8 x 8 samples for
-// 8 x 8 maps (2x2-tap kinds only: the 3x3 kind's group of 8 halo'd samples does not fit two ring buffers).
+// Tile shapes.  Units of 512 pixels: 16 x 32 pixels of one sample for maps at least 32 wide, 16 x 16 x 2 samples for 16-wide maps, 8 x 8 x 8 samples for
+// 8 x 8 maps (2x2-tap kinds only: the 3x3 kind's group of 8 halo'd samples does not fit two ring buffers).  Units of 256 pixels (round 6): 16 x 16 of
+// one sample, 8 x 8 x 4 samples; of 128 pixels: 8 x 8 x 2 samples, 4 x 4 x 8 samples.
 template <int MODE, bool DG, bool SG = false>
-static int ring_launch_tile(int tw, RingParams &rp, hipStream_t st) {
+static int ring_launch_tile(int pix, int tw, RingParams &rp, hipStream_t st) {
+    constexpr int RS = MODE == RM_K3S1 ? 2 : 3;   // ring depth of the small units (the 3x3 kind's 36 KB of weights per group leave room for two)
+    if (pix == 256) {
+        using C16 = RgCfg<MODE, 16, 16, 1, RS>;
+        using C8 = RgCfg<MODE, 8, 8, 4, RS>;
+        static_assert(C16::BIAS_FLOATS == 1024 && C8::BIAS_FLOATS == 1024, "conv_ring_try's bias-slot check");
+        if (tw == 16) return ring_launch<C16, DG, SG>(rp, st);
+        if (tw == 8) return ring_launch<C8, DG, SG>(rp, st);
+        return 1;
+    }
+    if (pix == 128) {
+        using C8 = RgCfg<MODE, 8, 8, 2, RS>;
+        using C4 = RgCfg<MODE, 4, 4, 8, RS>;
+        static_assert(C8::BIAS_FLOATS == 1024 && C4::BIAS_FLOATS == 1024, "conv_ring_try's bias-slot check");
+        if (tw == 8) return ring_launch<C8, DG, SG>(rp, st);
+        if (tw == 4) return ring_launch<C4, DG, SG>(rp, st);
+        return 1;
+    }
     if constexpr (MODE == RM_K3S1 || MODE == RM_CT4 || MODE == RM_K4S2)
         if (tw == 32 && g_experiment != 105 && !(g_experiment == 106 && DG) && !(g_experiment == 107 && !DG)) return ring_launch<RgCfg<MODE, 16, 32, 1, MODE == RM_K3S1 ? 2 : 3, 4>, DG, SG>(rp, st);   // (A/B: 105 = the 8-wave kernel, 106 / 107 = for the data gradients / the forwards only)
     if (tw == 32) return ring_launch<RgCfg<MODE, 16, 32, 1, MODE == RM_K3S1 ? 2 : 3>, DG, SG>(rp, st);
@@ -863,11 +893,6 @@ int conv_ring_try(int kind, bool dgrad, const ConvKParams &kp, hipStream_t st, c
 #endif
     for (int s = 0; s < kp.nsrc; ++s)
         if (kp.src_c[s] % 32 != 0 || kp.src_ld[s] % 8 != 0 || (reinterpret_cast<size_t>(kp.src_ptr[s]) & 15)) return 1;
-    int tw;   // tile shape by map size: whole tiles only
-    if (kp.LW % 32 == 0 && kp.LH % 16 == 0) tw = 32;
-    else if (kp.LW % 16 == 0 && kp.LH % 16 == 0 && kp.N % 2 == 0) tw = 16;
-    else if (kp.LW % 8 == 0 && kp.LH % 8 == 0 && kp.N % 8 == 0) tw = 8;
-    else return 1;
     int mode;
     int planes;
     if (kind == PWS_CONV_K3S1 || kind == PWS_CONVT_K3S1) mode = RM_K3S1, planes = 9;
@@ -897,11 +922,36 @@ int conv_ring_try(int kind, bool dgrad, const ConvKParams &kp, hipStream_t st, c
     }
 #endif
     rp.ablate = g_experiment >= 41 && g_experiment <= 48 ? g_experiment - 40 : (g_experiment == 49 ? 16 : 0);   // (49 = mask 16: no act' loads)   // (48 = mask 8: weight pieces only for a workgroup's first unit)
-    if (tw == 8 && mode == RM_K3S1) return 1;
-    if (kp.cout > (tw == 16 && mode == RM_K3S1 ? 512 : 1024)) return 1;   // the bias vector's LDS slot (RgCfg::BIAS_FLOATS)
-    const long units = (long)kp.LW * kp.LH * kp.N / 512 * ((kp.cout + 63) / 64) * ((mode == RM_CT4 || mode == RM_SP3) ? 4 : 1);
-    if (units < 192 && g_experiment != 21) return 1;
-    if (units >= (1l << 28)) return 1;   // 32-bit unit arithmetic in the kernel   // too few units for 256 persistent workgroups: the split-K kernels do better
+    // Unit size and tile shape: whole tiles only.  512-pixel units when they give every CU (most of) one; else 256, else 128 -- a smaller unit stages
+    // the same weight rows for fewer pixels, so it is taken only where the large one would leave the chip idle.  Below `min_small` units of 128 pixels
+    // the launch is the split-K / one-shot kernels' (PWS_OPT_EXPERIMENT 181 .. 184: min_small 64 / 96 / 192 / 256; 185: no small units, rounds 2-5; 186 / 187: units of 256 / 128 pixels whatever the count).
+    const long per_px = (long)((kp.cout + 63) / 64) * ((mode == RM_CT4 || mode == RM_SP3) ? 4 : 1);
+    const long px = (long)kp.LW * kp.LH * kp.N;
+    int pix = 0, tw = 0;
+    {
+        int tw512 = 0;
+        if (kp.LW % 32 == 0 && kp.LH % 16 == 0) tw512 = 32;
+        else if (kp.LW % 16 == 0 && kp.LH % 16 == 0 && kp.N % 2 == 0) tw512 = 16;
+        else if (kp.LW % 8 == 0 && kp.LH % 8 == 0 && kp.N % 8 == 0 && mode != RM_K3S1) tw512 = 8;
+        int tw256 = 0;
+        if (kp.LW % 16 == 0 && kp.LH % 16 == 0) tw256 = 16;
+        else if (kp.LW % 8 == 0 && kp.LH % 8 == 0 && kp.N % 4 == 0) tw256 = 8;
+        int tw128 = 0;
+        if (kp.LW % 8 == 0 && kp.LH % 8 == 0 && kp.N % 2 == 0) tw128 = 8;
+        else if (kp.LW % 4 == 0 && kp.LH % 4 == 0 && kp.N % 8 == 0) tw128 = 4;
+        const bool small_ok = g_experiment != 185;
+        const long min_small = g_experiment == 181 ? 64 : (g_experiment == 182 ? 96 : (g_experiment == 183 ? 192 : (g_experiment == 184 ? 256 : 128)));
+        const int force_pix = g_experiment == 186 ? 256 : (g_experiment == 187 ? 128 : 0);   // tests: that unit size or nothing
+        if (force_pix == 256 && tw256) pix = 256, tw = tw256;
+        else if (force_pix == 128 && tw128) pix = 128, tw = tw128;
+        else if (force_pix) return 1;
+        else if (tw512 && (px / 512 * per_px >= 192 || g_experiment == 21)) pix = 512, tw = tw512;
+        else if (small_ok && tw256 && px / 256 * per_px >= 192) pix = 256, tw = tw256;
+        else if (small_ok && tw128 && px / 128 * per_px >= min_small) pix = 128, tw = tw128;
+        else return 1;   // too few units for 256 persistent workgroups: the split-K kernels do better
+    }
+    if (kp.cout > (pix == 512 && tw == 16 && mode == RM_K3S1 ? 512 : 1024)) return 1;   // the bias vector's LDS slot (RgCfg::BIAS_FLOATS)
+    if (px / pix * per_px >= (1l << 28)) return 1;   // 32-bit unit arithmetic in the kernel
     // the sign-bit variant of the data-gradient epilogue: when EVERY destination with an act' has its sign bits (PWS_OPT_EXPERIMENT 12: never)
     bool sg = dgrad && g_experiment != 12, any_act = false;
     for (int s = 0; s < kp.ndst; ++s)
@@ -909,11 +959,11 @@ int conv_ring_try(int kind, bool dgrad, const ConvKParams &kp, hipStream_t st, c
     sg = sg && any_act;
     ProfScope prof(KID_CONV_RING, pi.flops, pi.bytes, st);
     switch (mode) {
-    case RM_K3S1: return !dgrad ? ring_launch_tile<RM_K3S1, false>(tw, rp, st) : (sg ? ring_launch_tile<RM_K3S1, true, true>(tw, rp, st) : ring_launch_tile<RM_K3S1, true>(tw, rp, st));
-    case RM_CT4: return ring_launch_tile<RM_CT4, false>(tw, rp, st);
-    case RM_SP3: return sg ? ring_launch_tile<RM_SP3, true, true>(tw, rp, st) : ring_launch_tile<RM_SP3, true>(tw, rp, st);
-    case RM_K3S2: return ring_launch_tile<RM_K3S2, false>(tw, rp, st);
-    default: return sg ? ring_launch_tile<RM_K4S2, true, true>(tw, rp, st) : ring_launch_tile<RM_K4S2, true>(tw, rp, st);
+    case RM_K3S1: return !dgrad ? ring_launch_tile<RM_K3S1, false>(pix, tw, rp, st) : (sg ? ring_launch_tile<RM_K3S1, true, true>(pix, tw, rp, st) : ring_launch_tile<RM_K3S1, true>(pix, tw, rp, st));
+    case RM_CT4: return ring_launch_tile<RM_CT4, false>(pix, tw, rp, st);
+    case RM_SP3: return sg ? ring_launch_tile<RM_SP3, true, true>(pix, tw, rp, st) : ring_launch_tile<RM_SP3, true>(pix, tw, rp, st);
+    case RM_K3S2: return ring_launch_tile<RM_K3S2, false>(pix, tw, rp, st);
+    default: return sg ? ring_launch_tile<RM_K4S2, true, true>(pix, tw, rp, st) : ring_launch_tile<RM_K4S2, true>(pix, tw, rp, st);
     }
 }
 

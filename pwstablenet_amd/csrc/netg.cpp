@@ -745,12 +745,13 @@ static void forward_lockstep(Exec &E, const Tn &in, const float *x, int n, int i
 }
 
 // Runs (or only plans) the forward over the arena of E.  thetas may be NULL (then they live in the arena).
+// caller_thetas: the caller owns the thetas buffer even when `thetas` is NULL (a planning replay of the training forward: no arena space for them)
 static void forward_graph(Exec &E, const float *x, int n, int input_nc, int g, int is_training, int ac, float *grids,
-                          float *resid, float *thetas) {
+                          float *resid, float *thetas, bool caller_thetas = false) {
     const int S = 256;
     E.reserve_scratch(g, is_training != 0);
     const size_t gsz = (size_t)n * S * S * 2;
-    float *th = thetas ? thetas : E.alloc((size_t)3 * n * 6);
+    float *th = (thetas || caller_thetas) ? thetas : E.alloc((size_t)3 * n * 6);
     float *th1 = th, *th2 = th ? th + (size_t)n * 6 : nullptr, *th3 = th ? th + (size_t)2 * n * 6 : nullptr;
 
     Tn in{};
@@ -882,8 +883,8 @@ static int run_backward(const float *packed, const float *packed_dgrad, const fl
     const NetgOpts mode = opts ? *opts : opts_defaults();
     DeterministicScope det_scope(mode.deterministic);   // PWS_NETG_DETERMINISTIC: every accumulating launcher of this call
     Exec E(packed, L, n, ws, ws_bytes, st, dry, /*launch=*/false, mode, bn);
-    float dummy_thetas = 0.f;  // non-NULL: the training forward is always given a caller-owned thetas buffer
-    forward_graph(E, x, n, input_nc, g, 1, ac, nullptr, nullptr, &dummy_thetas);
+    // (the training forward is always given a caller-owned thetas buffer: the replay must not reserve arena space for them either)
+    forward_graph(E, x, n, input_nc, g, 1, ac, nullptr, nullptr, nullptr, /*caller_thetas=*/true);
     // gradient buffers, one per produced tensor, after the forward region of the arena
     std::unordered_map<const float *, GradBuf> G;
     for (size_t i = 0; i < E.tape().size(); ++i) {
@@ -1455,8 +1456,7 @@ extern "C" int pws_netg_backward_plan(int input_nc, int ngf, int nparts, unsigne
     size_t total = 0;
     const std::vector<Layer> L = build_layers(input_nc, ngf, &total);
     Exec E(nullptr, L, 1, nullptr, 0, nullptr, /*dry=*/true, false, NetgOpts{PWS_MATH_FP32, PWS_STORE_FP32, false});
-    float dummy_thetas = 0.f;
-    forward_graph(E, nullptr, 1, input_nc, ngf, 1, 0, nullptr, nullptr, &dummy_thetas);
+    forward_graph(E, nullptr, 1, input_nc, ngf, 1, 0, nullptr, nullptr, nullptr, /*caller_thetas=*/true);
     const size_t T = E.tape().size();
     size_t last[L_COUNT];   // largest reversed position of an op that uses the layer
     bool used[L_COUNT];

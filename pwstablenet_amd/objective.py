@@ -263,6 +263,29 @@ def check_features_host(features, size=256):
         raise IndexError("feature coordinates index the %dx%d field out of bounds" % (size, size))
 
 
+def _dist_world():
+    """World size of the initialised default process group, or None without one."""
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else None
+
+
+def resolve_grad_world(netG, objective_world, sync_gradients, dist_world):
+    """Over how many ranks the gradients of a ``train_step`` are AVERAGED after its backward (StabObjective.grad_average_world: the
+    sum-type shape term's gradient is scaled by it).  The objective's own setting wins; an exchange this step knows of
+    (``sync_gradients``, a ``grad_sync`` attached to the generator, torch's DistributedDataParallel round it) averages over the group;
+    no group, or a group of one: 1.  A multi-rank group and NO known exchange returns None, so that the objective refuses to guess
+    (somebody else -- a wrapper this step cannot see -- may be averaging)."""
+    if objective_world is not None:
+        return objective_world
+    world = dist_world if dist_world is not None else 1
+    target = getattr(netG, "module", netG)
+    if sync_gradients is not None or getattr(target, "grad_sync", None) is not None:
+        return world
+    if isinstance(netG, torch.nn.parallel.DistributedDataParallel):
+        return world
+    return 1 if world <= 1 else None
+
+
 def train_step(netG, optimizerG, batch, objective, perceptual=None, period=30, sync_gradients=None):
     """One generator step of the reference's ``train()`` (main_new.py:84-118,184-216) on device tensors.
 
@@ -287,12 +310,7 @@ def train_step(netG, optimizerG, batch, objective, perceptual=None, period=30, s
     det = bool(getattr(target, "deterministic", False)) or objective.deterministic
     # gradients averaged over ranks after this backward (by sync_gradients or by the exchange attached to the generator): the
     # sum-type shape term's gradient is scaled by the world size (StabObjective.grad_average_world)
-    dp_world = objective.grad_average_world
-    if dp_world is None and (sync_gradients is not None or getattr(target, "grad_sync", None) is not None):
-        import torch.distributed as dist
-        dp_world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-    elif dp_world is None:
-        dp_world = 1   # this step composes everything itself and exchanges nothing: the gradients stay this rank's own
+    dp_world = resolve_grad_world(netG, objective.grad_average_world, sync_gradients, _dist_world())
     out = objective(grids, resid, rest[:, 0:3], rest[:, 3:], features, feature_adjacent.to(dev), grad_average_world=dp_world,
                     deterministic=det)
     loss = out.loss_g if perceptual is None else out.loss_g + perceptual(out.fake, rest[:, 3:6])

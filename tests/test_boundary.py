@@ -247,3 +247,33 @@ def test_gradient_slab_layout_is_consistent():
         assert total < L.pws_netg_packed_floats(31, ngf)            # (the weight buffer also holds the Winograd / bf16 copies)
     assert L.pws_netg_grad_floats(31, 60) == 0                      # ngf must be a multiple of 16
     assert L.pws_netg_grad_layout(31, 64, None, None) == -22
+
+
+def test_train_step_never_guesses_the_gradient_world_in_a_multi_rank_group():
+    """objective.resolve_grad_world (round-5 review): the sum-type shape term's gradient is scaled by the number of ranks the gradients are
+    AVERAGED over.  A step that knows its exchange takes the group's size; no group means 1; a multi-rank group with NO exchange this step
+    can see (a wrapper averaging behind its back) must come out as None, so that StabObjective raises instead of scaling for a world of one."""
+    import torch
+
+    from pwstablenet_amd.objective import resolve_grad_world
+
+    class Net(torch.nn.Module):
+        grad_sync = None
+
+    class Wrapped(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.module = m
+
+    plain, hooked = Net(), Net()
+    hooked.grad_sync = object()
+    sync = lambda params: None  # noqa: E731
+    assert resolve_grad_world(plain, None, None, None) == 1            # no process group
+    assert resolve_grad_world(plain, None, None, 1) == 1               # a group of one
+    assert resolve_grad_world(plain, None, None, 8) is None            # eight ranks, nothing known to exchange: refuse to guess
+    assert resolve_grad_world(Wrapped(plain), None, None, 8) is None   # ... also behind a DataParallel-style wrapper
+    assert resolve_grad_world(plain, None, sync, 8) == 8               # train_step's own sync_gradients averages over the group
+    assert resolve_grad_world(Wrapped(hooked), None, None, 8) == 8     # the overlapped exchange attached to the generator
+    assert resolve_grad_world(plain, None, sync, None) == 1
+    assert resolve_grad_world(plain, 4, None, 8) == 4                  # the objective's own setting wins
+    assert resolve_grad_world(plain, 1, None, 8) == 1

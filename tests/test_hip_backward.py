@@ -413,8 +413,13 @@ def test_backward_in_parts_with_overlapped_grad_sync(hip, nparts, math, det):
         rms = float((a - b).double().pow(2).mean().sqrt()) / (float(b.double().pow(2).mean().sqrt()) + 1e-20)
         assert rms < (1e-4 if math == "fp32" else 6e-3), rms
     net.module.grad_sync = None
-    # the C side's final-layer report: monotone, complete after the last run
     L = hip.lib()
+    # the host-only plan (pws_netg_backward_plan: what a rank's control plane schedules its messages by) is the order the runs
+    # themselves reported: it replays the fp32 non-BN tape, the runs here are fp32 or bf16 -- same tape
+    plan = (ctypes.c_ubyte * 46)()
+    assert L.pws_netg_backward_plan(31, net.module.ngf, nparts, plan) == 0
+    assert list(plan) == list(sync.final_part), (list(plan), sync.final_part)
+    # the C side's final-layer report: monotone, complete after the last run
     seen = None
     for part in range(nparts):
         mask = (ctypes.c_ubyte * 46)()

@@ -893,6 +893,40 @@ def test_one_pass_training_pack_gives_the_bits_of_the_four_pass_pack(hip, ngf):
     assert torch.equal(f_train_pack, f_own_pack)
 
 
+def test_training_pack_keeps_the_fp32_first_layer_for_wide_windows(hip):
+    """input_nc = 64 (cin_pad % 32 == 0, so the first layer has bf16 weights), bf16 math, fp32 storage, training: run_conv takes the bf16
+    first-layer kernel only for windows of <= 32 channels (the NHWC-32 copy), so this window goes to the fp32 first-layer kernels -- which
+    read the fp32 packed copy.  pws_netg_pack_weights_train must therefore not treat layer 0 as bf16-only (round-5 review: it did, and the
+    forward read whatever torch.empty had left there).  Both packed buffers are poisoned with NaN first."""
+    from pwstablenet_amd import synth
+    from pwstablenet_amd.lib.networks_cascading import define_G
+    ngf, nc = 32, 64
+    net = define_G(nc, 2, ngf, "normal", 0.02).cuda()
+    net.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in synth.make_weights("W1", ngf=ngf, input_nc=nc)})
+    x = torch.from_numpy(synth.make_window(2, nc, seed=31)).cuda()
+    tgt = torch.from_numpy(np.random.RandomState(7).standard_normal((2, 256, 256, 2)).astype(np.float32) * 0.1).cuda()
+    L = hip.lib()
+
+    def step(math):
+        m = net.module
+        m.set_math(math, store="fp32" if math == "bf16" else None)
+        m._packed = torch.full((L.pws_netg_packed_floats(nc, ngf),), float("nan"), device="cuda")
+        m._packed_dgrad = torch.full((L.pws_netg_packed_dgrad_floats(nc, ngf),), float("nan"), device="cuda")
+        m._packed_key = m._packed_dgrad_key = None
+        net.zero_grad(set_to_none=True)
+        grids, resid = net(x)
+        loss = sum(((g - tgt) ** 2).mean() for g in grids) + sum((r ** 2).mean() for r in resid)
+        loss.backward()
+        return [g.detach().clone() for g in grids], loss.item(), [p.grad.clone() for p in net.parameters()]
+
+    g32, l32, d32 = step("fp32")
+    g16, l16, d16 = step("bf16")
+    net.module.set_math("fp32")
+    assert np.isfinite(l16) and all(bool(torch.isfinite(g).all()) for g in g16) and all(bool(torch.isfinite(d).all()) for d in d16)
+    assert abs(l16 - l32) < 1e-2 * abs(l32), (l16, l32)
+    assert max((a - b).abs().max().item() for a, b in zip(g16, g32)) < FIELD_TOL["W1"]
+
+
 def _sign_bytes(y_nhwc_bf16):
     """Bit (c & 7) of byte [pixel][c / 8] = (y[pixel][c] > 0): pws_conv_args.out_sign's layout, from the bf16 tensor itself."""
     pos = (y_nhwc_bf16.float() > 0).to(torch.uint8).cpu().numpy()

@@ -38,6 +38,27 @@ BWD = [
     ("CONVT_K4S2", (8, 8, 8), [64], 64), ("CONV_K3S2", (8, 16, 16), [64], 32),
 ]
 
+# Round 6: units of 256 pixels (tiles 16 x 16, 8 x 8 x 4 samples) and 128 pixels (8 x 8 x 2 samples, 4 x 4 x 8 samples) for the maps that give too few
+# units of 512.  PWS_OPT_EXPERIMENT 186 / 187 force that unit size; shapes chosen so that exactly that tile shape applies (several tiles per map,
+# cout ending inside a 64-channel block, virtual concats).
+FWD_SMALL = [
+    ("CONV_K3S1", (1, 16, 32), [32], 64, 186), ("CONVT_K3S1", (3, 16, 16), [64], 128, 186), ("CONVT_K4S2", (1, 16, 16), [64, 32], 72, 186),
+    ("CONV_K3S2", (1, 32, 64), [32, 32], 64, 186),
+    ("CONV_K3S1", (4, 8, 8), [64], 64, 186), ("CONV_K3S1", (8, 8, 24), [32], 40, 186), ("CONVT_K4S2", (4, 8, 8), [32, 32], 96, 186),
+    ("CONV_K3S2", (4, 16, 16), [64], 64, 186),
+    ("CONV_K3S1", (2, 8, 8), [64, 32], 64, 187), ("CONVT_K3S1", (6, 8, 16), [32], 72, 187), ("CONVT_K4S2", (2, 8, 8), [64], 64, 187),
+    ("CONV_K3S2", (2, 16, 16), [32, 32], 128, 187),
+    ("CONV_K3S1", (8, 4, 4), [64], 64, 187), ("CONVT_K3S1", (16, 4, 12), [32], 64, 187), ("CONVT_K4S2", (8, 4, 4), [32, 64], 64, 187),
+    ("CONV_K3S2", (8, 8, 8), [64], 96, 187),
+]
+BWD_SMALL = [
+    ("CONV_K3S1", (1, 16, 32), [64], 64, 186), ("CONVT_K3S1", (3, 16, 16), [32, 64, 32], 64, 186), ("CONV_K3S2", (1, 32, 64), [32, 32], 64, 186),
+    ("CONVT_K4S2", (1, 16, 16), [64, 64], 32, 186),
+    ("CONV_K3S1", (4, 8, 8), [64], 96, 186), ("CONV_K3S2", (4, 16, 16), [64], 32, 186), ("CONVT_K4S2", (4, 8, 8), [32, 64], 64, 186),
+    ("CONV_K3S1", (2, 8, 8), [64, 32], 64, 187), ("CONV_K3S2", (2, 16, 16), [32, 32], 64, 187), ("CONVT_K4S2", (2, 8, 8), [64], 64, 187),
+    ("CONV_K3S1", (8, 4, 4), [64], 64, 187), ("CONV_K3S2", (8, 8, 8), [128], 96, 187), ("CONVT_K4S2", (8, 4, 4), [32, 64], 64, 187),
+]
+
 
 @pytest.fixture()
 def force(hip):
@@ -86,17 +107,17 @@ def _fwd(A, kname, x, wt, b, act, src_c, cout):
 
 
 @pytest.mark.parametrize("act", [1, 2])
-@pytest.mark.parametrize("kname,shape,src_c,cout", FWD)
-def test_ring_forward(hip, force, kname, shape, src_c, cout, act):
+@pytest.mark.parametrize("kname,shape,src_c,cout,unit", [c + (21,) for c in FWD] + FWD_SMALL)
+def test_ring_forward(hip, force, kname, shape, src_c, cout, unit, act):
     x, wt, b, _ = make_case(kname, shape, src_c, cout, "ring")
     xr, wr = bf16r(x), bf16r(wt)
     want = nhwc(torch_layer(kname, xr, wr, b, act)).numpy()
-    force(21)
+    force(unit)
     got, names = _fwd(hip, kname, xr, wt, b, act, src_c, cout)
     assert names == ["conv_ring_kernel"], names
     force(20)
     old, names = _fwd(hip, kname, xr, wt, b, act, src_c, cout)
-    assert names == ["conv_bf16_kernel"], names
+    assert names == ["conv_bf16_kernel"] or (unit != 21 and "conv_ring_kernel" not in names), names   # (the smallest maps are the one-shot kernel's)
     got, old = got.numpy(), old.numpy()
     assert not np.isnan(got).any()
     e_ref, e_old = relerr(got, want), relerr(got, old)
@@ -138,8 +159,8 @@ def _bwd(A, kname, d_dy, wt, shape, src_c, cout, ys, act, stale):
 
 
 @pytest.mark.parametrize("act", [0, 1, 2])
-@pytest.mark.parametrize("kname,shape,src_c,cout", BWD)
-def test_ring_data_gradient(hip, force, kname, shape, src_c, cout, act):
+@pytest.mark.parametrize("kname,shape,src_c,cout,unit", [c + (21,) for c in BWD] + BWD_SMALL)
+def test_ring_data_gradient(hip, force, kname, shape, src_c, cout, unit, act):
     x, wt, b, rs = make_case(kname, shape, src_c, cout, "ringd")
     n, cin, h, w = x.shape
     wr = bf16r(wt)
@@ -153,12 +174,12 @@ def test_ring_data_gradient(hip, force, kname, shape, src_c, cout, act):
     d_dy[..., :cout] = nhwc(dy).cuda().bfloat16()
     ys = [torch.from_numpy(rs.standard_normal((n, h, w, c + 8)).astype(np.float32)).cuda().bfloat16() for c in src_c]
     stale = [torch.from_numpy(rs.standard_normal((n, h, w, c)).astype(np.float32)).cuda().bfloat16() for c in src_c]
-    force(21)
+    force(unit)
     got, names = _bwd(hip, kname, d_dy, wt, shape, src_c, cout, ys, act, stale)
     assert names == ["conv_ring_kernel"], names
     force(20)
     old, names = _bwd(hip, kname, d_dy, wt, shape, src_c, cout, ys, act, stale)
-    assert names == ["conv_bf16_kernel"], names
+    assert names == ["conv_bf16_kernel"] or (unit != 21 and "conv_ring_kernel" not in names), names
     slope = {0: 1.0, 1: 0.2, 2: 0.0}[act]
     c0 = 0
     for i, c in enumerate(src_c):
