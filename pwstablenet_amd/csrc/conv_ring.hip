@@ -940,7 +940,10 @@ int conv_ring_try(int kind, bool dgrad, const ConvKParams &kp, hipStream_t st, c
         if (kp.LW % 8 == 0 && kp.LH % 8 == 0 && kp.N % 2 == 0) tw128 = 8;
         else if (kp.LW % 4 == 0 && kp.LH % 4 == 0 && kp.N % 8 == 0) tw128 = 4;
         const bool small_ok = g_experiment != 185;
-        const long min_small = g_experiment == 181 ? 64 : (g_experiment == 182 ? 96 : (g_experiment == 183 ? 192 : (g_experiment == 184 ? 256 : 128)));
+        // (measured, tools/probes/r6c / r6d: batch-8 inference 6471 -> 6600 f/s with 64 instead of 128 -- its alternatives are launch-latency-bound split-K
+        //  pairs; the batch-64 training step 25.88 -> 25.94 ms -- there the alternative is a conv_bf16_kernel launch that fills the chip: by batch)
+        const long min_dflt = kp.N <= 16 ? 64 : 128;
+        const long min_small = g_experiment == 181 ? 64 : (g_experiment == 182 ? 96 : (g_experiment == 183 ? 192 : (g_experiment == 184 ? 256 : min_dflt)));
         const int force_pix = g_experiment == 186 ? 256 : (g_experiment == 187 ? 128 : 0);   // tests: that unit size or nothing
         if (force_pix == 256 && tw256) pix = 256, tw = tw256;
         else if (force_pix == 128 && tw128) pix = 128, tw = tw128;

@@ -273,6 +273,7 @@ static const WgChoice &pick(const WgChoice *c, int n, int LH, int LW, int N) {
 int wgrad_bf16_launch(const pws_conv_bwd_weight_args *a, hipStream_t st);  // wgrad_bf16.hip
 
 int wgrad_ring_try_pair(const pws_conv_bwd_weight_args *a, hipStream_t st);   // wgrad_ring.hip: both operand pairs in one launch; 1 = not covered
+int wgrad_bf16_launch_pair(const pws_conv_bwd_weight_args *a, hipStream_t st);   // wgrad_bf16.hip: the same on wgrad_bf16_kernel; 1 = not covered
 
 int conv2d_bwd_weight_impl(const pws_conv_bwd_weight_args *a, hipStream_t st) {
     PWS_REQUIRE(a != nullptr, "pws_conv2d_bwd_weight: args is NULL");
@@ -286,7 +287,9 @@ int conv2d_bwd_weight_impl(const pws_conv_bwd_weight_args *a, hipStream_t st) {
         for (int s = 0; s < a->nsrc; ++s) PWS_REQUIRE(a->src2_ptr[s] != nullptr, "pws_conv2d_bwd_weight: gout2 without src2_ptr[%d]", s);
         PWS_REQUIRE((reinterpret_cast<size_t>(a->gout2) & 15) == 0, "pws_conv2d_bwd_weight: gout2 alignment");
         if (a->math == PWS_MATH_BF16 && a->store == PWS_STORE_BF16 && !a->src_nchw && !(t_deterministic && a->dbias)) {
-            const int rc = wgrad_ring_try_pair(a, st);   // 1: not covered
+            int rc = wgrad_ring_try_pair(a, st);   // 1: not covered
+            if (rc != 1) return rc;
+            rc = wgrad_bf16_launch_pair(a, st);          // the deep levels (maps below 16 x 16, short tile streams)
             if (rc != 1) return rc;
         }
         pws_conv_bwd_weight_args b = *a;

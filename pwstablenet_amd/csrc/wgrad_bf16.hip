@@ -38,6 +38,12 @@ struct WgradBfParams {
     int ntiles;
     int ci_blocks, co_blocks;  // of 64 channels
     float *dbias;    // optional: dbias[co] += column sums of dy (pws_conv_bwd_weight_args.dbias)
+    // second operand pair (pws_conv_bwd_weight_args.gout2; bf16 storage only): samples N1 .. N - 1 of the tile walk are samples 0 .. N - N1 - 1 of
+    // these tensors (same geometry).  A layer shared by stages 2 and 3 then takes ONE launch: one prologue, one set of epilogue atomics on dW
+    // (the deep levels' launches are bound by exactly those: 4.7-16.8 MB of fp32 atomics behind 4-16 tiles).  N1 % TN == 0 (wgrad_bf16_launch).
+    const float *src_ptr2[4];
+    const float *gout2;
+    int N1;          // samples of the first pair (== N without a second one)
 };
 
 template <int KS_, int STRIDE_, int PAD_, int SUBPIX_, int TH_, int TW_, int TN_, int TG_, bool CI32_ = false, int COW_ = 2>
@@ -97,8 +103,11 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char *lds, int off0, in
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <class C, bool IO16>
+// PAIR: the tile walk covers two operand pairs (WgradBfParams.src_ptr2 / gout2); instantiated for the 64-pixel tiles only -- the deep levels, where
+// a launch is its prologue and its atomics -- so that the large tiles' kernels keep their registers (the 16 x 16 tile's prefetch sets fill all 256)
+template <class C, bool IO16, bool PAIR = false>
 __global__ void __launch_bounds__(C::THREADS, 2) wgrad_bf16_kernel(const WgradBfParams p) {
+    static_assert(!PAIR || (IO16 && C::BM <= 64 && !(C::STRIDE == 2 && C::TN == 4)), "operand pairs: bf16 storage, 64-pixel tiles");
     static_assert(wb_linear<C>(), "tile shape breaks the k-step address walk");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -176,10 +185,14 @@ __global__ void __launch_bounds__(C::THREADS, 2) wgrad_bf16_kernel(const WgradBf
         const bool xc_ok = xch < p.cin;
         while (xs < p.nsrc - 1 && xch >= p.src_c[xs]) xch -= p.src_c[xs], ++xs;
         if (!xc_ok) xs = 0, xch = 0;
-        const __bf16 *xsrc = reinterpret_cast<const __bf16 *>(p.src_ptr[xs]) + xch;
+        const __bf16 *const xsrc1 = reinterpret_cast<const __bf16 *>(p.src_ptr[xs]) + xch;
+        const __bf16 *const xsrc2 = PAIR ? reinterpret_cast<const __bf16 *>(p.src_ptr2[xs]) + xch : xsrc1;
         const size_t xld = p.src_ld[xs];
         const bool gc_ok = co0 + c8 * 8 < p.cout;   // (c8 >> 2 = the 32-channel plane of the dy tile)
-        const __bf16 *gsrc = reinterpret_cast<const __bf16 *>(p.gout) + (gc_ok ? co0 + c8 * 8 : 0);
+        const __bf16 *const gsrc1 = reinterpret_cast<const __bf16 *>(p.gout) + (gc_ok ? co0 + c8 * 8 : 0);
+        const __bf16 *const gsrc2 = PAIR ? reinterpret_cast<const __bf16 *>(p.gout2) + (gc_ok ? co0 + c8 * 8 : 0) : gsrc1;
+        bool second = false;   // (tile-uniform) the tile being requested belongs to the second operand pair (locate)
+        int nlim = p.N1;       // ... and that pair's sample count
         const int xl0 = (cx >> 2) * C::PIX * C::ROW + px0 * C::ROW + (cx & 3) * 16;
         const int gl0 = C::LDS_X + (c8 >> 2) * C::BM * C::ROW + p0 * C::ROW + (c8 & 3) * 16;
         u32x4 rx[XITS], rg[GITS];
@@ -189,6 +202,10 @@ __global__ void __launch_bounds__(C::THREADS, 2) wgrad_bf16_kernel(const WgradBf
         auto locate = [&](int tile) {
             const int tx_i = tile % p.tiles_x, ty_i = (tile / p.tiles_x) % p.tiles_y, tn_i = tile / (p.tiles_x * p.tiles_y);
             n0 = tn_i * C::TN, y0 = ty_i * C::TH, x0 = tx_i * C::TW;
+            if constexpr (PAIR) {
+                second = n0 >= p.N1;   // (N1 % TN == 0: a tile never straddles the pairs)
+                n0 -= second ? p.N1 : 0, nlim = second ? p.N - p.N1 : p.N1;
+            }
         };
         auto issue_x = [&](auto B, auto E) {   // items [B, E); all loads unconditional (masked items read a valid dummy address)
             const int iy0 = y0 * C::STRIDE - pad_y, ix0 = x0 * C::STRIDE - pad_x;
@@ -198,9 +215,9 @@ __global__ void __launch_bounds__(C::THREADS, 2) wgrad_bf16_kernel(const WgradBf
                 const int pix = px0 + XPP * it;
                 const int lx = C::col_at(pix % C::IW), ly = (pix / C::IW) % C::IH, tn = pix / (C::IW * C::IH);
                 const int n = n0 + tn, iy = iy0 + ly, ix = ix0 + lx;
-                const bool ok = pix < C::PIX && xc_ok && n < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                const bool ok = pix < C::PIX && xc_ok && n < nlim && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
                 const size_t e = ok ? (size_t)((n * p.H + iy) * p.W + ix) * xld : 0;
-                rx[it] = *reinterpret_cast<const u32x4 *>(xsrc + e);
+                rx[it] = *reinterpret_cast<const u32x4 *>((PAIR && second ? xsrc2 : xsrc1) + e);
                 okx |= ok ? (1u << it) : 0u;
             }
         };
@@ -212,9 +229,9 @@ __global__ void __launch_bounds__(C::THREADS, 2) wgrad_bf16_kernel(const WgradBf
                 const int tx = m % C::TW, ty = (m / C::TW) % C::TH, tn = m / (C::TW * C::TH);
                 const int n = n0 + tn, y = y0 + ty, x = x0 + tx;
                 const int oy = C::SUBPIX ? 2 * y + py : y, ox = C::SUBPIX ? 2 * x + px : x;
-                const bool ok = m < C::BM && gc_ok && n < p.N && y < p.LH && x < p.LW && oy < p.OH && ox < p.OW;
+                const bool ok = m < C::BM && gc_ok && n < nlim && y < p.LH && x < p.LW && oy < p.OH && ox < p.OW;
                 const size_t e = ok ? (size_t)((n * p.OH + oy) * p.OW + ox) * p.gout_ld : 0;
-                rg[it] = *reinterpret_cast<const u32x4 *>(gsrc + e);
+                rg[it] = *reinterpret_cast<const u32x4 *>((PAIR && second ? gsrc2 : gsrc1) + e);
                 okg |= ok ? (1u << it) : 0u;
             }
         };
@@ -401,6 +418,8 @@ static int launch_wb(WgradBfParams &p, int nclasses, hipStream_t st) {
         }
         attr_set = true;
     }
+    constexpr bool kPairCfg = C::BM <= 64 && !(C::STRIDE == 2 && C::TN == 4);   // (the stride-2 4 x 4 x 4-sample tile is 2 registers short of carrying a second pair)
+    if (p.N1 < p.N && (!kPairCfg || !p.io_bf16 || p.N1 % C::TN != 0 || p.N != 2 * p.N1)) return 1;   // the pair's tiles must not straddle the operand pairs
     p.tiles_x = (p.LW + C::TW - 1) / C::TW, p.tiles_y = (p.LH + C::TH - 1) / C::TH, p.tiles_n = (p.N + C::TN - 1) / C::TN;
     p.ntiles = p.tiles_x * p.tiles_y * p.tiles_n;
     p.ci_blocks = C::CI32 ? (p.cin_pad + 31) / 32 : (p.cin_pad + 63) / 64, p.co_blocks = (p.cout + C::CO_BLK - 1) / C::CO_BLK;
@@ -409,9 +428,30 @@ static int launch_wb(WgradBfParams &p, int nclasses, hipStream_t st) {
     // the bf16 MFMA rate that tail is what a 1024-workgroup grid is bound by (64->64 @256x256 x8: 176 us -> 117 us at 512;
     // all weight-gradient launches of a batch-32 step: 256 / 512 / 768 / 1024 -> 7.7 / 7.2 / 8.5 / 9.1 ms)
     long ps = ((C::COW == 4 ? 256 : 512) + other - 1) / other;   // (an 8-wave workgroup fills a CU by itself)
+    // The deep levels (few tiles, 2.4-16.8 MB of weights): every pixel split ends with 64 x 64 x taps atomics on the SAME addresses, so with 1-2 tiles
+    // per workgroup the launch is the atomics (down_bottom6.conv_same at batch 64: 64 tiles over 32 splits = 18.9 M atomics for 0.6 M weights, 73 us at
+    // 65 TFLOP/s).  At least `mint` tiles per workgroup (PWS_OPT_EXPERIMENT 190 + k: mint = k, 190 = no floor as in rounds 1-5).
+    const long mint = g_experiment >= 190 && g_experiment < 200 ? g_experiment - 190 : 6;   // (tools/probes/r6e_wgrad.sh: 256 -> 256 @8x8 x 64: 71 / 45 / 39 / 41 us at 0 / 4 / 6 / 8)
+    if (mint > 0 && ps > p.ntiles / mint) ps = p.ntiles / mint;
     if (ps > p.ntiles) ps = p.ntiles;
     if (ps < 1 || t_deterministic) ps = 1;   // deterministic: one adding workgroup per (channel block, class, tap group)
     dim3 grid((unsigned)ps, (unsigned)(p.ci_blocks * p.co_blocks), (unsigned)(nclasses * C::NGROUPS));
+    if constexpr (kPairCfg) {
+        if (p.N1 < p.N) {
+            static PerDeviceFlag attr_pair_dev;
+            bool &attr_pair = attr_pair_dev.cur();
+            if (!attr_pair) {
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_bf16_kernel<C, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+                if (e != hipSuccess) {
+                    set_error("hipFuncSetAttribute(wgrad_bf16_kernel<pair>, %d B LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
+                    return PWS_EHIP;
+                }
+                attr_pair = true;
+            }
+            hipLaunchKernelGGL((wgrad_bf16_kernel<C, true, true>), grid, dim3(C::THREADS), C::LDS_BYTES, st, p);
+            return check_launch("wgrad_bf16_kernel");
+        }
+    }
     if (p.io_bf16)
         hipLaunchKernelGGL((wgrad_bf16_kernel<C, true>), grid, dim3(C::THREADS), C::LDS_BYTES, st, p);
     else
@@ -463,7 +503,18 @@ static const WbChoice &pick(const WbChoice *c, int n, int LH, int LW, int N) {
 // NCHW window, sources that are not multiples of 32 channels): the caller then runs the fp32 kernel.
 int wgrad_ring_try(const pws_conv_bwd_weight_args *a, int cin, hipStream_t st);   // wgrad_ring.hip; 1 = not covered
 
-int wgrad_bf16_launch(const pws_conv_bwd_weight_args *a, hipStream_t st) {
+static int wgrad_bf16_launch_impl(const pws_conv_bwd_weight_args *a, hipStream_t st, bool pair);
+int wgrad_bf16_launch(const pws_conv_bwd_weight_args *a, hipStream_t st) { return wgrad_bf16_launch_impl(a, st, false); }
+// both operand pairs of a->gout2 in ONE launch of wgrad_bf16_kernel (bf16 storage; called by conv2d_bwd_weight_impl after wgrad_ring_try_pair
+// declined); 1 = not covered (tile shapes that would straddle the pairs, fp32 storage): the caller launches the pairs one after the other.
+// PWS_OPT_EXPERIMENT 188: never (A/B).
+int wgrad_bf16_launch_pair(const pws_conv_bwd_weight_args *a, hipStream_t st) {
+    if (g_experiment == 188 || a->store != PWS_STORE_BF16 || !a->gout2) return 1;
+    for (int s = 0; s < a->nsrc; ++s)
+        if (!a->src2_ptr[s] || (reinterpret_cast<size_t>(a->src2_ptr[s]) & 15)) return 1;
+    return wgrad_bf16_launch_impl(a, st, true);
+}
+static int wgrad_bf16_launch_impl(const pws_conv_bwd_weight_args *a, hipStream_t st, bool pair) {
     if (a->src_nchw) return 1;
     WgradBfParams p{};
     p.nsrc = a->nsrc;
@@ -483,12 +534,17 @@ int wgrad_bf16_launch(const pws_conv_bwd_weight_args *a, hipStream_t st) {
             return PWS_EINVAL;
         }
     }
-    if (p.io_bf16) {   // the persistent LDS-ring kernel where it is covered (stride-1 kinds, whole 16 x 16 tiles, long tile streams)
+    if (p.io_bf16 && !pair) {   // the persistent LDS-ring kernel where it is covered (stride-1 kinds, whole 16 x 16 tiles, long tile streams)
         const int rc = wgrad_ring_try(a, cin, st);
         if (rc != 1) return rc;
     }
     p.cin = cin, p.cin_pad = (cin + 15) / 16 * 16, p.cout = a->cout;
-    p.N = a->n, p.H = a->h, p.W = a->w;
+    p.N = pair ? 2 * a->n : a->n, p.N1 = a->n, p.H = a->h, p.W = a->w;
+    if (pair) {
+        if (a->kind == PWS_CONV_K5S1) return 1;
+        for (int s = 0; s < a->nsrc; ++s) p.src_ptr2[s] = static_cast<const float *>(a->src2_ptr[s]);
+        p.gout2 = a->gout2;
+    }
     p.gout = a->gout, p.gout_ld = a->gout_ld, p.dw = a->dw_packed, p.dbias = a->dbias;
     double k2 = 9;
     int nclasses = 1;
@@ -497,18 +553,18 @@ int wgrad_bf16_launch(const pws_conv_bwd_weight_args *a, hipStream_t st) {
     case PWS_CONV_K3S1:
     case PWS_CONVT_K3S1:
         p.OH = p.LH = a->h, p.OW = p.LW = a->w;
-        c = &pick(kWbK3S1, 5, p.LH, p.LW, p.N);
+        c = &pick(kWbK3S1, 5, p.LH, p.LW, a->n);
         break;
     case PWS_CONV_K3S2:
         p.OH = p.LH = (a->h - 1) / 2 + 1, p.OW = p.LW = (a->w - 1) / 2 + 1;
-        c = &pick(kWbK3S2, 3, p.LH, p.LW, p.N);
+        c = &pick(kWbK3S2, 3, p.LH, p.LW, a->n);
         // >= 128 output channels on maps that whole 8 x 8 tiles cover: 64 x 128 channels per (8-wave) workgroup.  PWS_OPT_EXPERIMENT 83
         // keeps the 64 x 64 workgroups (A/B)
         if (c == &kWbK3S2[0] && a->cout % 128 == 0 && p.io_bf16 && g_experiment != 83) c = &kWbK3S2W;
         break;
     case PWS_CONVT_K4S2:
         p.LH = a->h, p.LW = a->w, p.OH = 2 * a->h, p.OW = 2 * a->w, nclasses = 4, k2 = 4;
-        c = &pick(kWbCT4, 4, p.LH, p.LW, p.N);
+        c = &pick(kWbCT4, 4, p.LH, p.LW, a->n);
         // (a 64 x 128-channel variant as for the stride-2 kind was measured on the layers with >= 128 outputs: 33.2 vs 33.2 ms per step)
         break;
     case PWS_CONV_K5S1:
@@ -517,9 +573,10 @@ int wgrad_bf16_launch(const pws_conv_bwd_weight_args *a, hipStream_t st) {
         break;
     default: return 1;
     }
-    const double out_pix = (double)a->n * p.OH * p.OW;
+    if (pair && (a->n % c->tn != 0 || c->th * c->tw * c->tn > 64 || (a->kind == PWS_CONV_K3S2 && c->tn == 4))) return 1;   // (before the profiler scope opens) a tile would straddle the operand pairs / large tiles: no pair kernel
+    const double out_pix = (double)p.N * p.OH * p.OW;
     ProfScope prof(KID_WGRAD_BF16, 2.0 * out_pix * a->cout * cin * k2,
-                   4.0 * ((double)a->n * a->h * a->w * cin + out_pix * a->cout + k2 * cin * a->cout * (nclasses == 4 ? 4 : 1)), st);
+                   4.0 * ((double)p.N * a->h * a->w * cin + out_pix * a->cout + k2 * cin * a->cout * (nclasses == 4 ? 4 : 1)), st);
     return c->launch(p, nclasses, st);
 }
 

@@ -1083,8 +1083,13 @@ def test_nchw_to_nhwc_pad_and_first_layer_bf16(hip):
     ("CONV_K3S1", (3, 16, 32), [64, 64], 96, 81),      # 3x3 on the ring, virtual concat, cout 96
     ("CONV_K3S2", (2, 32, 64), [64], 64, 81),          # stride-2 kind on the ring (ring of 3: the tile walk crosses from pair 1 to pair 2)
     ("CONV_K5S1", (2, 32, 48), [32], 64, 81),          # the first layer's shape on the ring
-    ("CONV_K3S1", (2, 16, 16), [32], 32, 0),           # not covered by the ring (32 input channels): two launches inside the call
-    ("CONVT_K4S2", (2, 8, 8), [64], 32, 80),           # ring switched off: two launches of wgrad_bf16_kernel
+    ("CONV_K3S1", (2, 16, 16), [32], 32, 0),           # not covered by the ring (32 input channels), 16 x 16 tiles: two launches inside the call
+    ("CONVT_K4S2", (2, 8, 8), [64], 32, 80),           # ring switched off, 8 x 8 tiles: ONE launch of wgrad_bf16_kernel over both pairs (round 6)
+    ("CONV_K3S1", (3, 8, 8), [64, 32], 72, 0),         # the same on the 3x3 kind, virtual concat, cout ending inside a block
+    ("CONVT_K4S2", (4, 4, 4), [64], 64, 0),            # 4 x 4 maps: tiles of 4 samples, a pair of 4 + 4 samples = two whole tiles
+    ("CONVT_K3S1", (16, 2, 2), [64, 32], 64, 0),       # 2 x 2 maps: tiles of 16 samples
+    ("CONVT_K4S2", (6, 4, 4), [64], 64, 0),            # 6 samples in tiles of 4: a tile would straddle the pairs -> two launches
+    ("CONV_K3S1", (2, 8, 8), [64], 64, 188),           # merged launch switched off: two launches inside the call
 ])
 def test_bf16_weight_gradient_of_a_layer_used_twice(hip, kname, shape, src_c, cout, force):
     """pws_conv_bwd_weight_args.gout2 / src2_ptr (round 4): stages 2 and 3 of the generator run the same modules, so a shared layer's weight
@@ -1151,7 +1156,8 @@ def test_bf16_weight_gradient_of_a_layer_used_twice(hip, kname, shape, src_c, co
     finally:
         L.pws_prof_enable(0)
         L.pws_set_option(100, 0)
-    assert names == (["wgrad_ring_kernel"] if force == 81 else ["wgrad_bf16_kernel"] * 2), names
+    two_launches = force == 188 or (kname, shape) in (("CONVT_K4S2", (6, 4, 4)), ("CONV_K3S1", (2, 16, 16)))
+    assert names == (["wgrad_ring_kernel"] if force == 81 else ["wgrad_bf16_kernel"] * (2 if two_launches else 1)), names
     assert relerr(both, want_dw) < 1e-4 and relerr(both, two) < 2e-5
     tol = 2e-5 * (np.abs(pairs[0][1].numpy()).sum(axis=(0, 2, 3)).max() + np.abs(pairs[1][1].numpy()).sum(axis=(0, 2, 3)).max())
     np.testing.assert_allclose(db_both, want_db, rtol=0, atol=tol)

@@ -1,12 +1,12 @@
 """A bare inference loop for timelines: the bench's configs[1] forward (batch 8, graph replay, two queues) N times.
-usage: python3 tools/probes/infer_loop.py [--math bf16] [--reps 20] [--batch 8]"""
+usage: python3 tools/infer_loop.py [--math bf16] [--reps 20] [--batch 8]"""
 import argparse
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from pwstablenet_amd import functional as PF, hipabi as A, synth  # noqa: E402
 from pwstablenet_amd.lib.networks_cascading import define_G  # noqa: E402
 
