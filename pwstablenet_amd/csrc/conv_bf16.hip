@@ -802,7 +802,7 @@ int conv_bf16_fwd(int kind, ConvKParams &kp, int cin_total, float *out, float *w
                   const ProfInfo &pi) {
     for (int s = 0; s < kp.nsrc; ++s)
         if (kp.src_c[s] % 32 != 0) return 1;
-    if (kind != PWS_CONV_K5S1) {   // the persistent LDS-ring kernel takes the launches it covers (bf16 storage, maps >= 16 x 32)
+    {   // the persistent LDS-ring kernel takes the launches it covers (bf16 storage, maps >= 16 x 32; round 6: the first layer too)
         kp.out = out;
         const int rc = conv_ring_try(kind, false, kp, st, pi);   // (writes kp.out_sign itself)
         if (rc != 1) return rc;

@@ -42,7 +42,9 @@ enum RingMode {
     RM_CT4 = 1,   // transposed conv k4 s2 p1 forward: 4 output parity classes, each a 2x2 conv of the dense input
     RM_SP3 = 2,   // data gradient of conv k3 s2 p1: 4 output parity classes of 1/2/2/4 taps over the dense dy
     RM_K3S2 = 3,  // conv k3 s2 p1 forward: sum over the 4 input parity planes of 2x2 convs with 4/2/2/1 taps
-    RM_K4S2 = 4   // data gradient of transposed conv k4 s2 p1 (= conv k4 s2 p1 over dy): 4 input parity planes x 2x2 taps
+    RM_K4S2 = 4,  // data gradient of transposed conv k4 s2 p1 (= conv k4 s2 p1 over dy): 4 input parity planes x 2x2 taps
+    RM_K5 = 5     // round 6: the first layer (conv k5 s1 p2 on the NHWC-32 copy of the window, 32 -> 64 channels), forward only: ONE K group per
+                  // unit, the 25 x 64 weight rows (100 KB) RESIDENT in LDS for the workgroup's whole life, the ring carries input tiles only
 };
 
 struct RingParams {
@@ -97,9 +99,12 @@ struct RgCfg {
     // DMA-bound by construction (the 36 KB of a 3x3 group's weights feed 128-256 pixels instead of 512), so fewer matrix waves do: PIX / 64.
     static constexpr int PIX = TH * TW * TN;
     static_assert(PIX == 512 || PIX == 256 || PIX == 128, "pixels per unit");
-    static constexpr int KS = MODE == RM_K3S1 ? 3 : 2;
+    static constexpr int KS = MODE == RM_K3S1 ? 3 : (MODE == RM_K5 ? 5 : 2);
     static constexpr int TAPS = KS * KS;
-    static constexpr int NPLANES = MODE >= RM_K3S2 ? 4 : 1;   // input parity planes
+    static constexpr bool WRES = MODE == RM_K5;          // weights resident behind the ring (one 64-channel block, one K group: every unit multiplies the same rows)
+    static constexpr bool TALL = MT == 4 || MODE == RM_K5;   // matrix phase by tile rows (halo rows read once per tap column and channel half, reused over the vertical taps)
+    static_assert(MODE != RM_K5 || (TW == 32 && TN == 1 && R_ == 2), "first layer: 32-wide tiles of one sample");
+    static constexpr int NPLANES = (MODE == RM_K3S2 || MODE == RM_K4S2) ? 4 : 1;   // input parity planes
     static constexpr int NCLS = (MODE == RM_CT4 || MODE == RM_SP3) ? 4 : 1;   // output parity classes
     // 8 matrix waves (two per SIMD, each 2 tile rows x 64 channels) + 4 loader waves (one per SIMD) that do nothing but issue
     // the LDS-DMA pieces: a DMA piece blocks its wave for the ~30-70 cycles the texture addresser takes per piece, 75 pieces per
@@ -115,26 +120,30 @@ struct RgCfg {
     static constexpr int SPP = ROWB / 16;                         // 16-byte slots per row
     static constexpr int IN_SLOTS = TN * IH * IW * SPP;           // 16-byte slots of the input image of one group
     static constexpr int IN_WI = (IN_SLOTS + 63) / 64;            // wave-instructions (64 slots each)
-    static constexpr int W_WI = TAPS * 64 * SPP / 64;             // TAPS x 64 rows x SPP slots
+    static constexpr int WRES_WI = WRES ? TAPS * 64 * SPP / 64 : 0;   // resident weights: wave-instructions of the one-time preload
+    static constexpr int WRES_BYTES = WRES_WI * 1024;
+    static constexpr int W_WI = WRES ? 0 : TAPS * 64 * SPP / 64;  // TAPS x 64 rows x SPP slots
     static constexpr int NL = (IN_WI + W_WI + LWAVES - 1) / LWAVES; // DMA instructions per loader wave and group
     static constexpr int GROUP_BYTES = NL * LWAVES * 1024;
     static constexpr int W_OFF = IN_WI * 1024;
     static constexpr int LDS_RING_BYTES = R * GROUP_BYTES;
+    static constexpr int W_RES_OFF = LDS_RING_BYTES;              // WRES: the resident weight rows
     // the layer's bias vector (conv_ring_try: cout <= BIAS_FLOATS) sits behind the ring -- or, where the ring fills the LDS (the
     // 3x3 kind on 16-wide maps: 2 x 80 KB), in the filler tail of the last ring buffer, which a ring of depth 2 need not write
     // (its waits are vmcnt(0): no piece count to keep constant)
     static constexpr int FILL_BYTES = (NL * LWAVES - IN_WI - W_WI) * 1024;
-    static constexpr bool BIAS_IN_FILL = LDS_RING_BYTES + 4096 > 160 * 1024;
+    static constexpr bool BIAS_IN_FILL = LDS_RING_BYTES + WRES_BYTES + 4096 > 160 * 1024;
     static constexpr int BIAS_FLOATS = BIAS_IN_FILL ? 512 : 1024;
-    static constexpr int BIAS_OFF = BIAS_IN_FILL ? LDS_RING_BYTES - BIAS_FLOATS * 4 : LDS_RING_BYTES;
-    static constexpr int LDS_BYTES = BIAS_IN_FILL ? LDS_RING_BYTES : LDS_RING_BYTES + BIAS_FLOATS * 4;
+    static constexpr int BIAS_OFF = BIAS_IN_FILL ? LDS_RING_BYTES - BIAS_FLOATS * 4 : LDS_RING_BYTES + WRES_BYTES;
+    static constexpr int LDS_BYTES = BIAS_IN_FILL ? LDS_RING_BYTES : LDS_RING_BYTES + WRES_BYTES + BIAS_FLOATS * 4;
+    static_assert(!(WRES && BIAS_IN_FILL), "resident weights: the bias slot sits behind them");
     static constexpr bool SKIP_FILL = R == 2;
     static_assert(!BIAS_IN_FILL || (SKIP_FILL && FILL_BYTES >= BIAS_FLOATS * 4), "bias slot");
     // the `it` whose 4 wave-instructions hold input pieces on the first loader waves and weight pieces on the others (-1: none)
     static constexpr int MIX_IT = IN_WI % LWAVES == 0 ? -1 : IN_WI / LWAVES;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert(R >= 2 && R <= 4, "ring depth");
-    static_assert((R - 2) * NL <= 63, "vmcnt is 6 bits");
+    static_assert((R - 2) * NL + WRES_WI / LWAVES <= 63, "vmcnt is 6 bits");
 };
 
 // one LDS-DMA: 64 lanes x 16 bytes, lane l lands at lds_addr + 16 l; source = rsrc base + soff + voff (lanes beyond
@@ -284,6 +293,25 @@ __global__ void __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) conv_ring_kerne
         unsigned issued = 0;   // groups staged so far
         unsigned dslot = 0;    // ring slot of the next group
         const bool mix_in = C::MIX_IT >= 0 && C::MIX_IT * C::LWAVES + lw < C::IN_WI;   // the straddling wave-instruction: input piece on this wave?
+        if constexpr (C::WRES) {
+            // the resident weight rows, once: TAPS x 64 rows in the order and slot permutation of a group's weight rows (see the table above); they are
+            // OLDER than every piece of group 0, so the counted wait in front of B_0 covers them
+            unsigned keep0;
+            asm volatile("s_nop 4\n\ts_mov_b32 %0, m0" : "=s"(keep0));
+#pragma unroll
+            for (int i = 0; i < C::WRES_WI / C::LWAVES; ++i) {
+                const int wi = i * C::LWAVES + lw;
+                const int jj = wi * 64 + lane;
+                const int row = jj / C::SPP, sp = jj % C::SPP;
+                const int t = row >> 6, rr = row & 63;
+                const int ri = rr & 31;
+                const int rreg = (ri >> 3) * 4 + (ri & 3), rhalf = (ri >> 2) & 1, rnt = rr >> 5;
+                const int nn = (rnt * 2 + (rreg >> 3)) * 16 + rhalf * 8 + (rreg & 7);
+                const unsigned voff = (unsigned)t * (unsigned)(p.npad * p.kpad * 2) + (unsigned)(nn * p.kpad * 2 + (sp ^ ((rr >> 2) & 3)) * 16);
+                ring_dma16_m0(uni((unsigned)(C::W_RES_OFF + wi * 1024)), voff, rsrc_w, 0u);
+            }
+            asm volatile("s_mov_b32 m0, %0" ::"s"(keep0));
+        }
         for (unsigned pu = u_begin; pu < u_end; pu += u_step) {
             const RingUnit PU = ring_unit(p, pu);
             const bool dry = (p.ablate & 1) && pu != u_begin;     // TIMING ONLY: the pieces fetch nothing
@@ -292,6 +320,7 @@ __global__ void __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) conv_ring_kerne
                 const int a = pplane >> 1, b = pplane & 1;
                 int oy, ox;   // view coordinates of the halo's first pixel
                 if constexpr (C::MODE == RM_K3S1) oy = PU.y0 * C::TH - 1, ox = PU.x0 * C::TW - 1;
+                else if constexpr (C::MODE == RM_K5) oy = PU.y0 * C::TH - 2, ox = PU.x0 * C::TW - 2;
                 else if constexpr (C::MODE == RM_CT4) oy = PU.y0 * C::TH - (1 - PU.py), ox = PU.x0 * C::TW - (1 - PU.px);
                 else if constexpr (C::MODE == RM_SP3) oy = PU.y0 * C::TH, ox = PU.x0 * C::TW;
                 else oy = PU.y0 * C::TH - a, ox = PU.x0 * C::TW - b;
@@ -406,7 +435,7 @@ __global__ void __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) conv_ring_kerne
             const int lx = tx + dx;
             a_off[mt][dx] = ((tn * C::IH + ty) * C::IW + lx) * C::ROWB + ((hi ^ ((lx >> 2) & 3)) << 4);
         }
-    const int b_off = C::W_OFF + l31 * C::ROWB + ((hi ^ ((l31 >> 2) & 3)) << 4);
+    const int b_off = l31 * C::ROWB + ((hi ^ ((l31 >> 2) & 3)) << 4);   // inside the weight rows (wb below: a group's, or the resident ones)
 
     f32x16 acc[MT][2];
 
@@ -426,7 +455,7 @@ __global__ void __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) conv_ring_kerne
     // tall waves: half as many waves issue the epilogue's requests, and the 96 operand registers of the matrix phase are free once it is over:
     // the requests of slots PF .. PFR - 1 go out right behind the last matrix instruction, and the rolling distance is PFR
 #ifndef PWS_RING_PFR
-#define PWS_RING_PFR (MT == 4 ? (SG ? 10 : 6) : PF)
+#define PWS_RING_PFR (C::TALL && MT == 4 ? (SG ? 10 : 6) : PF)
 #endif
     constexpr int PFR = PWS_RING_PFR < PF ? PF : PWS_RING_PFR;
     constexpr int NSLOT = MT * 4;  // slot = mt * 4 + q: pixel mt, 8-channel group q of the lane's 32 channels
@@ -583,12 +612,13 @@ __global__ void __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) conv_ring_kerne
         if constexpr (C::MODE == RM_SP3) tapmask = CU.py ? (CU.px ? 0xfu : 0x5u) : (CU.px ? 0x3u : 0x1u);
         if constexpr (C::MODE == RM_K3S2) tapmask = (cplane >> 1) ? ((cplane & 1) ? 0xfu : 0x5u) : ((cplane & 1) ? 0x3u : 0x1u);
         const unsigned gb = (unsigned)(cbuf * C::GROUP_BYTES);
+        const unsigned wb = C::WRES ? (unsigned)C::W_RES_OFF : gb + (unsigned)C::W_OFF;
         if (!(p.ablate & 2)) {
-            if constexpr (MT == 4) {
+            if constexpr (C::TALL) {
                 // tall waves: step = (channel half ks, tap column tx).  The wave's 4 tile rows see MT + KS - 1 halo rows through the KS vertical
                 // taps: each is read once per step; the operands of step + 1 are requested under the matrix instructions of the step, one
                 // ds_read_b128 after every second matrix instruction (one wave per SIMD: nobody else fills a bubble in the matrix pipe)
-                static_assert(C::MODE == RM_K3S1 || C::MODE == RM_CT4 || C::MODE == RM_K4S2, "tall waves: the kinds without a tap mask");
+                static_assert(C::MODE == RM_K3S1 || C::MODE == RM_CT4 || C::MODE == RM_K4S2 || C::MODE == RM_K5, "tall waves: the kinds without a tap mask");
                 constexpr int NST = 2 * C::KS, NA = MT + C::KS - 1, NRD = NA + 2 * C::KS, NMM = C::KS * MT * 2;
                 bf16x8 av[2][NA], bv[2][C::KS][2];
                 auto rd = [&](int slot, int st) {
@@ -600,7 +630,7 @@ __global__ void __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) conv_ring_kerne
                     for (int ty = 0; ty < C::KS; ++ty)
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
-                            bv[slot][ty][nt] = *reinterpret_cast<const bf16x8 *>(lds + gb + (unsigned)((b_off ^ (ks * 32)) + ((ty * C::KS + tx) * 64 + nt * 32) * C::ROWB));
+                            bv[slot][ty][nt] = *reinterpret_cast<const bf16x8 *>(lds + wb + (unsigned)((b_off ^ (ks * 32)) + ((ty * C::KS + tx) * 64 + nt * 32) * C::ROWB));
                 };
                 rd(0, 0);
 #pragma unroll
@@ -640,7 +670,7 @@ __global__ void __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) conv_ring_kerne
                             av[mt] = *reinterpret_cast<const bf16x8 *>(lds + gb + (unsigned)((a_off[mt][tx] ^ (ks * 32)) + ty * C::IW * C::ROWB));
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
-                            bv[nt] = *reinterpret_cast<const bf16x8 *>(lds + gb + (unsigned)((b_off ^ (ks * 32)) + (tap * 64 + nt * 32) * C::ROWB));
+                            bv[nt] = *reinterpret_cast<const bf16x8 *>(lds + wb + (unsigned)((b_off ^ (ks * 32)) + (tap * 64 + nt * 32) * C::ROWB));
 #pragma unroll
                         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -661,7 +691,7 @@ __global__ void __launch_bounds__(C::THREADS, C::WAVES_PER_SIMD) conv_ring_kerne
                         av[slot][mt] = *reinterpret_cast<const bf16x8 *>(lds + gb + (unsigned)((a_off[mt][tx] ^ (ks * 32)) + ty * C::IW * C::ROWB));
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
-                        bv[slot][nt] = *reinterpret_cast<const bf16x8 *>(lds + gb + (unsigned)((b_off ^ (ks * 32)) + (tap * 64 + nt * 32) * C::ROWB));
+                        bv[slot][nt] = *reinterpret_cast<const bf16x8 *>(lds + wb + (unsigned)((b_off ^ (ks * 32)) + (tap * 64 + nt * 32) * C::ROWB));
                 };
 #pragma unroll
                 for (int st = 0; st < PD; ++st) rd(st, st);
@@ -898,7 +928,11 @@ int conv_ring_try(int kind, bool dgrad, const ConvKParams &kp, hipStream_t st, c
     if (kind == PWS_CONV_K3S1 || kind == PWS_CONVT_K3S1) mode = RM_K3S1, planes = 9;
     else if (kind == PWS_CONV_K3S2) mode = dgrad ? RM_SP3 : RM_K3S2, planes = dgrad ? 16 : 9;
     else if (kind == PWS_CONVT_K4S2) mode = dgrad ? RM_K4S2 : RM_CT4, planes = 16;
+    else if (kind == PWS_CONV_K5S1 && !dgrad) mode = RM_K5, planes = 25;
     else return 1;
+    // the first layer (round 6): ONE source of 32 channels (the NHWC-32 copy of the window), ONE 64-channel output block -- what makes its weights resident;
+    // 8 x 32 tiles (PWS_OPT_EXPERIMENT 189: never -- conv_bf16_k5_kernel as in rounds 1-5)
+    if (mode == RM_K5 && (g_experiment == 189 || kp.nsrc != 1 || kp.src_c[0] != 32 || kp.cout > 64 || kp.kpad_bf != 32 || kp.LW % 32 != 0 || kp.LH % 8 != 0)) return 1;
     const size_t sample_bytes = (size_t)kp.H * kp.W * 2;
     for (int s = 0; s < kp.nsrc; ++s)
         if (sample_bytes * kp.src_ld[s] >= (1u << 31)) return 1;
@@ -928,7 +962,10 @@ int conv_ring_try(int kind, bool dgrad, const ConvKParams &kp, hipStream_t st, c
     const long per_px = (long)((kp.cout + 63) / 64) * ((mode == RM_CT4 || mode == RM_SP3) ? 4 : 1);
     const long px = (long)kp.LW * kp.LH * kp.N;
     int pix = 0, tw = 0;
-    {
+    if (mode == RM_K5) {
+        pix = 256, tw = 32;
+        if (px / 256 < 192 && g_experiment != 21) return 1;
+    } else {
         int tw512 = 0;
         if (kp.LW % 32 == 0 && kp.LH % 16 == 0) tw512 = 32;
         else if (kp.LW % 16 == 0 && kp.LH % 16 == 0 && kp.N % 2 == 0) tw512 = 16;
@@ -962,6 +999,7 @@ int conv_ring_try(int kind, bool dgrad, const ConvKParams &kp, hipStream_t st, c
     sg = sg && any_act;
     ProfScope prof(KID_CONV_RING, pi.flops, pi.bytes, st);
     switch (mode) {
+    case RM_K5: return ring_launch<RgCfg<RM_K5, 8, 32, 1, 2, 2>, false, false>(rp, st);
     case RM_K3S1: return !dgrad ? ring_launch_tile<RM_K3S1, false>(pix, tw, rp, st) : (sg ? ring_launch_tile<RM_K3S1, true, true>(pix, tw, rp, st) : ring_launch_tile<RM_K3S1, true>(pix, tw, rp, st));
     case RM_CT4: return ring_launch_tile<RM_CT4, false>(pix, tw, rp, st);
     case RM_SP3: return sg ? ring_launch_tile<RM_SP3, true, true>(pix, tw, rp, st) : ring_launch_tile<RM_SP3, true>(pix, tw, rp, st);

@@ -107,7 +107,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char *lds, int off0, in
 // a launch is its prologue and its atomics -- so that the large tiles' kernels keep their registers (the 16 x 16 tile's prefetch sets fill all 256)
 template <class C, bool IO16, bool PAIR = false>
 __global__ void __launch_bounds__(C::THREADS, 2) wgrad_bf16_kernel(const WgradBfParams p) {
-    static_assert(!PAIR || (IO16 && C::BM <= 64 && !(C::STRIDE == 2 && C::TN == 4)), "operand pairs: bf16 storage, 64-pixel tiles");
+    static_assert(!PAIR || (IO16 && C::BM <= 128 && !(C::STRIDE == 2 && C::TN == 4)), "operand pairs: bf16 storage, tiles of at most 128 pixels");
     static_assert(wb_linear<C>(), "tile shape breaks the k-step address walk");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -418,7 +418,7 @@ static int launch_wb(WgradBfParams &p, int nclasses, hipStream_t st) {
         }
         attr_set = true;
     }
-    constexpr bool kPairCfg = C::BM <= 64 && !(C::STRIDE == 2 && C::TN == 4);   // (the stride-2 4 x 4 x 4-sample tile is 2 registers short of carrying a second pair)
+    constexpr bool kPairCfg = C::BM <= 128 && !(C::STRIDE == 2 && C::TN == 4);   // (the stride-2 4 x 4 x 4-sample tile is 2 registers short of carrying a second pair)
     if (p.N1 < p.N && (!kPairCfg || !p.io_bf16 || p.N1 % C::TN != 0 || p.N != 2 * p.N1)) return 1;   // the pair's tiles must not straddle the operand pairs
     p.tiles_x = (p.LW + C::TW - 1) / C::TW, p.tiles_y = (p.LH + C::TH - 1) / C::TH, p.tiles_n = (p.N + C::TN - 1) / C::TN;
     p.ntiles = p.tiles_x * p.tiles_y * p.tiles_n;
@@ -573,7 +573,7 @@ static int wgrad_bf16_launch_impl(const pws_conv_bwd_weight_args *a, hipStream_t
         break;
     default: return 1;
     }
-    if (pair && (a->n % c->tn != 0 || c->th * c->tw * c->tn > 64 || (a->kind == PWS_CONV_K3S2 && c->tn == 4))) return 1;   // (before the profiler scope opens) a tile would straddle the operand pairs / large tiles: no pair kernel
+    if (pair && (a->n % c->tn != 0 || c->th * c->tw * c->tn > 128 || (a->kind == PWS_CONV_K3S2 && c->tn == 4))) return 1;   // (before the profiler scope opens) a tile would straddle the operand pairs / large tiles: no pair kernel
     const double out_pix = (double)p.N * p.OH * p.OW;
     ProfScope prof(KID_WGRAD_BF16, 2.0 * out_pix * a->cout * cin * k2,
                    4.0 * ((double)p.N * a->h * a->w * cin + out_pix * a->cout + k2 * cin * a->cout * (nclasses == 4 ? 4 : 1)), st);

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 from test_hip_bf16 import KINDS, STORE_TOL, bf16r, make_case, nhwc, relerr, torch_layer  # noqa: E402
 
-PLANES = {"CONV_K3S1": 9, "CONV_K3S2": 9, "CONVT_K3S1": 9, "CONVT_K4S2": 16}
+PLANES = {"CONV_K3S1": 9, "CONV_K3S2": 9, "CONVT_K3S1": 9, "CONVT_K4S2": 16, "CONV_K5S1": 25}
 # (kind, (n, h, w) of the layer INPUT, sources, cout): the logical map (output, or the class / plane grid) is a multiple of 16 x 32
 FWD = [
     ("CONV_K3S1", (2, 16, 32), [32], 64), ("CONV_K3S1", (1, 32, 64), [64, 32], 96), ("CONV_K3S1", (3, 16, 64), [32, 64, 32, 32], 128),
@@ -28,6 +28,9 @@ FWD = [
     # 16-wide maps: tiles of 16 x 16 x 2 samples; 8 x 8 maps: tiles of 8 x 8 x 8 samples (2x2-tap kinds)
     ("CONV_K3S1", (2, 16, 16), [64], 64), ("CONVT_K3S1", (4, 32, 16), [32, 32], 72), ("CONVT_K4S2", (4, 16, 16), [32, 32], 96),
     ("CONV_K3S2", (2, 32, 32), [64], 64), ("CONVT_K4S2", (8, 8, 8), [64], 64), ("CONV_K3S2", (8, 16, 16), [32], 64),
+    # round 6: the first layer's kind (5x5 on a 32-channel NHWC source, weights resident in LDS, 8 x 32 tiles): borders on every side, several tiles per
+    # workgroup, cout ending inside the block
+    ("CONV_K5S1", (2, 16, 64), [32], 64), ("CONV_K5S1", (1, 24, 32), [32], 64), ("CONV_K5S1", (3, 8, 96), [32], 40), ("CONV_K5S1", (5, 64, 64), [32], 64),
 ]
 # data gradients: (kind, (n, h, w) of the forward INPUT = extent of dx, forward sources = destinations, forward cout)
 BWD = [
