@@ -999,7 +999,8 @@ int conv_ring_try(int kind, bool dgrad, const ConvKParams &kp, hipStream_t st, c
     sg = sg && any_act;
     ProfScope prof(KID_CONV_RING, pi.flops, pi.bytes, st);
     switch (mode) {
-    case RM_K5: return ring_launch<RgCfg<RM_K5, 8, 32, 1, 2, 2>, false, false>(rp, st);
+    case RM_K5:   // (one tile row per wave on 8 matrix waves -- the epilogue of one wave under the matrix phase of the other -- measured the same: 480-510 against 490 us)
+        return ring_launch<RgCfg<RM_K5, 8, 32, 1, 2, 2>, false, false>(rp, st);
     case RM_K3S1: return !dgrad ? ring_launch_tile<RM_K3S1, false>(pix, tw, rp, st) : (sg ? ring_launch_tile<RM_K3S1, true, true>(pix, tw, rp, st) : ring_launch_tile<RM_K3S1, true>(pix, tw, rp, st));
     case RM_CT4: return ring_launch_tile<RM_CT4, false>(pix, tw, rp, st);
     case RM_SP3: return sg ? ring_launch_tile<RM_SP3, true, true>(pix, tw, rp, st) : ring_launch_tile<RM_SP3, true>(pix, tw, rp, st);
