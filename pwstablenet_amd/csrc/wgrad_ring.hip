@@ -528,7 +528,10 @@ static int wgrad_ring_try_impl(const pws_conv_bwd_weight_args *a, int cin, hipSt
     // (86: every covered launch as 81, but the 64 x 64 pairs)
     const bool wide = ct4 && cin % 128 == 0 && g_experiment != 85 && g_experiment != 86;   // (1300 + mask: timing-only ablations of the wide kernel)
     const bool force = g_experiment == 81 || g_experiment == 86;
-    if (!first && !s2 && ((ct4 && !wide) || cin < 128) && !force && g_experiment != 82) return 1;
+    // Round 6: the 64-channel 3x3 layers too (after round 5's loader rewrite the ring wins there: 64 -> 64 @256^2 x 64 377 -> 348 us, @128^2 135 -> 104 us,
+    // tools/probes/r6l_wgrad64.sh; PWS_OPT_EXPERIMENT 176: from 128 channels as in rounds 2-5)
+    const int ring_min_cin = g_experiment == 176 ? 128 : 64;
+    if (!first && !s2 && ((ct4 && !wide) || cin < ring_min_cin) && !force && g_experiment != 82) return 1;
     for (int s = 0; s < a->nsrc; ++s)
         if ((size_t)a->h * a->w * a->src[s].ld * 2 >= (1u << 31) || (reinterpret_cast<size_t>(a->src[s].ptr) & 15) || a->src[s].ld % 8 != 0) return 1;
     const int oh = ct4 ? 2 * a->h : (s2 ? a->h / 2 : a->h), ow = ct4 ? 2 * a->w : (s2 ? a->w / 2 : a->w);

@@ -2,7 +2,7 @@
 drawn around the selectors' thresholds (ring kernel / one-shot kernel / tiled kernel; whole and ragged tiles; 1..4 sources of the
 virtual concat; cout ending inside a 64-channel block), forward, data gradient (with accumulation into a destination; act'
 of a forward tensor is covered by tests/test_hip_bf16.py) and weight gradient.  Every result is checked against PyTorch on the same rounded operands, and the
-second-generation kernels against the first-generation ones (PWS_OPT_EXPERIMENT 20 / 71 / 80 switch them off, 21 / 81 take the ring kernels wherever they are covered)."""
+second-generation kernels against the first-generation ones (PWS_OPT_EXPERIMENT 20 / 71 / 80 switch them off, 21 / 81 take the ring kernels wherever they are covered, 186 / 187 the ring kernel's small units)."""
 import ctypes
 import zlib
 
@@ -136,9 +136,11 @@ def test_bf16_storage_dispatch_sweep(hip, kname, shape, src_c, cout):
     try:
         # product dispatch; first-generation conv kernel; ring kernel for every launch it covers (not only the long ones); no one-shot
         # kernel; no ring weight gradient; ring weight gradient for every launch it covers
-        for e in (0, 20, 21, 71, 80, 81):
+        # (round 6) 186 / 187: the ring kernel's units of 256 / 128 pixels wherever a tile shape of that size divides the map (else the launch falls through
+        # to the other kernels, which is the dispatch being swept too); 188: a shared layer's operand pairs as two weight-gradient launches
+        for e in (0, 20, 21, 186, 187, 71, 80, 81):
             L.pws_set_option(100, e)
-            res[e] = (forward(), dgrad(), wgrad()) if e in (0, 20) else (forward(), dgrad(), None) if e in (21, 71) else (None, None, wgrad())
+            res[e] = (forward(), dgrad(), wgrad()) if e in (0, 20) else (forward(), dgrad(), None) if e in (21, 186, 187, 71) else (None, None, wgrad())
     finally:
         L.pws_set_option(100, 0)
     torch.cuda.synchronize()

@@ -36,7 +36,7 @@ def short(name):
     m = re.match(r"pws::conv_ring_kernel<pws::RgCfg<([^>]*)>,\s*(true|false)(?:,\s*(true|false))?\s*>", name)
     if m:   # persistent LDS-ring bf16 conv (conv_ring.hip): mode, tile, ring depth, epilogue kind (+ sign-bit variant of the data gradient)
         a = [x.strip() for x in m.group(1).split(",")]
-        mode = {"0": "k3s1", "1": "convT4", "2": "dgrad-subpix k3s2", "3": "k3s2 planes", "4": "dgrad k4s2 planes"}.get(a[0], a[0])
+        mode = {"0": "k3s1", "1": "convT4", "2": "dgrad-subpix k3s2", "3": "k3s2 planes", "4": "dgrad k4s2 planes", "5": "k5s1 first layer, weights resident"}.get(a[0], a[0])
         return "conv_ring_kernel<%s,tile %sx%sx%s,R%s,%s%s>" % (mode, a[3], a[1], a[2], a[4], "dgrad" if m.group(2) == "true" else "fwd",
                                                                  ",sign bits" if m.group(3) == "true" else "")
     m = re.match(r"(?:pws::)?wino_ring_kernel<(\d+),\s*(\d+),\s*(\d+)>", name)
