@@ -277,3 +277,19 @@ def test_train_step_never_guesses_the_gradient_world_in_a_multi_rank_group():
     assert resolve_grad_world(plain, None, sync, None) == 1
     assert resolve_grad_world(plain, 4, None, 8) == 4                  # the objective's own setting wins
     assert resolve_grad_world(plain, 1, None, 8) == 1
+
+
+def test_documents_cite_files_that_exist():
+    """DESIGN.md, README.md, INTEGRATION.md and profiles/README.md name tools, tests, sources and profile files in backticks; a file that a clean-up
+    removed must not stay cited (round 6 removed 27 probe scripts).  docs/ROUNDS.md is history ("as written at the time") and is not checked."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    missing = []
+    for doc in ("DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("profiles", "README.md")):
+        with open(os.path.join(root, doc)) as fh:
+            txt = fh.read()
+        for ref in set(re.findall(r"`((?:tools|tests|pwstablenet_amd|oracle|profiles|include|dropin|docs)/[A-Za-z0-9_./\-]+)`", txt)):
+            ref = ref.rstrip(".,")
+            if not os.path.exists(os.path.join(root, ref)):
+                missing.append((doc, ref))
+    assert not missing, missing
