@@ -33,7 +33,13 @@ else:
         field = net(x, False).clone()
     d = (field[:, :, 1:, 0] - field[:, :, :-1, 0]).abs() * 640
     print("generator field: |d source x / d cell| mean %.1f px, max %.1f px" % (float(d.mean()), float(d.max())), file=sys.stderr)
+u8 = os.environ.get("PWS_WARP_U8", "0") == "1"   # the uint8 HWC variant (what VideoStabilizer runs)
+if u8:
+    rot = [torch.randint(0, 256, (B, 720, 1280, 3), device=dev, dtype=torch.uint8) for _ in range(4)]
 with torch.no_grad():
     for i in range(8):
-        PF.upsample_grid_sample(rot[i % 4], field)
+        if u8:
+            PF.upsample_grid_sample_u8(rot[i % 4], field, swap_rb=True)
+        else:
+            PF.upsample_grid_sample(rot[i % 4], field)
 torch.cuda.synchronize()
