@@ -853,7 +853,8 @@ def main():
                 rw["achieved"] = round(r[0][3] / (ms * 1e-3) / 1e9, 1)
                 rw["frac"] = round(r[0][3] / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
                 rw["avg_launch_us"] = round(1e3 * ms, 2)
-                rw["bound_note"] = "instruction-bound, not HBM-bound: ~150 vector instructions per pixel (DESIGN.md section 9, item 9)"
+                rw["bound_note"] = ("vector-instruction-bound, not HBM-bound: 140 vector instructions per pixel, vector pipes >= 78 % occupied "
+                                    "(profiles/r06_warp_u8_issue_slots.txt, DESIGN.md section 8)")
                 del rot8, fsm
             except Exception as e:
                 line["value_720p_u8"]["roofline_warp"]["smooth_field_error"] = str(e)[:200]
