@@ -505,36 +505,63 @@ __global__ void __launch_bounds__(256) ordered_sum2_kernel(const float *__restri
 }
 
 // ---- theta head backward
-// T1: one workgroup per sample (serial_n > 0: ONE workgroup walks the samples 0 .. serial_n-1 in order -- deterministic mode: every
-// address then receives its adds from one lane in a fixed order): dz2, dW2 += h (x) dz2, db2 += dz2, dz1 = (W2^T dz2) * L'(h) -> ws, db1 += dz1
+// T1: dz2 = dtheta * L'(theta), dW2 += h (x) dz2, db2 += dz2, dz1 = (W2^T dz2) * L'(h) -> ws, db1 += dz1.
+// A lane owns ONE hidden unit j and walks the samples of its workgroup's slice in order, so its seven sums (dW2[j][0..5], db1[j]) stay in registers and reach
+// memory once.  (Rounds 1-5: one workgroup per SAMPLE, seven atomics per hidden unit each -- at 64 samples 64-way contention on 3 584 addresses, 100 us for a
+// 512 x 6 matrix, three times per training step.)  nslices > 1: the samples are dealt to nslices workgroups per block of 256 hidden units and the sums meet by
+// atomics (<= 8 per address); nslices == 1 (deterministic mode, small batches): plain stream-ordered adds in sample order -- every address gets its adds from one
+// lane in a fixed order.
 __global__ void __launch_bounds__(256) theta_bwd1_kernel(const float *__restrict__ theta, const float *__restrict__ dtheta,
                                                          const float *__restrict__ h, int hidden, const float *__restrict__ w_lin,
                                                          float *__restrict__ dw_lin, float *__restrict__ db_lin,
-                                                         float *__restrict__ db_flat, float *__restrict__ dz1, int bn, int serial_n) {
+                                                         float *__restrict__ db_flat, float *__restrict__ dz1, int bn, int n, int nslices) {
     // bn (use_BN training): `dtheta` already IS dz2 (BatchNorm backward ran on it) and the output is dh, the gradient wrt the
     // BatchNorm output of the hidden layer (its own BatchNorm backward follows); the conv biases get no gradient (BN removes it)
-    __shared__ float dz2[6];
+    extern __shared__ float dz2s[];   // [samples of this slice][6]
     const int tid = threadIdx.x;
-    for (int n = serial_n > 0 ? 0 : (int)blockIdx.x; n < (serial_n > 0 ? serial_n : (int)blockIdx.x + 1); ++n) {
-    __syncthreads();   // (serial walk) the previous sample's dz2 is consumed
-    if (tid < 6) {
-        const float v = bn ? dtheta[(size_t)n * 6 + tid] : dtheta[(size_t)n * 6 + tid] * lrelu_grad(theta[(size_t)n * 6 + tid]);
-        dz2[tid] = v;
-        if (!bn) atomicAdd(db_lin + tid, v);
+    const int jblocks = (hidden + 255) / 256;
+    const int jb = (int)blockIdx.x % jblocks, sl = (int)blockIdx.x / jblocks;
+    const int cnt = sl < n ? (n - sl + nslices - 1) / nslices : 0;   // samples sl, sl + nslices, ...
+    for (int t = tid; t < cnt * 6; t += 256) {
+        const size_t e = (size_t)(sl + (t / 6) * nslices) * 6 + (t % 6);
+        dz2s[t] = bn ? dtheta[e] : dtheta[e] * lrelu_grad(theta[e]);
     }
     __syncthreads();
-    for (int j = tid; j < hidden; j += 256) {
-        const float hj = h[(size_t)n * hidden + j];
-        float dh = 0.f;
+    const bool atomic = nslices > 1;
+    const int j = jb * 256 + tid;
+    if (j < hidden) {
+        float w[6], acc[6], bsum = 0.f;
+#pragma unroll
+        for (int o = 0; o < 6; ++o) w[o] = w_lin[(size_t)j * 6 + o], acc[o] = 0.f;
+        for (int c = 0; c < cnt; ++c) {
+            const size_t i = (size_t)(sl + c * nslices);
+            const float hj = h[i * hidden + j];
+            float dh = 0.f;
+#pragma unroll
+            for (int o = 0; o < 6; ++o) {
+                const float z = dz2s[c * 6 + o];
+                acc[o] = fmaf(hj, z, acc[o]);
+                dh = fmaf(w[o], z, dh);
+            }
+            const float d1 = bn ? dh : dh * lrelu_grad(hj);
+            dz1[i * hidden + j] = d1;
+            bsum += d1;
+        }
 #pragma unroll
         for (int o = 0; o < 6; ++o) {
-            atomicAdd(dw_lin + (size_t)j * 6 + o, hj * dz2[o]);
-            dh = fmaf(w_lin[(size_t)j * 6 + o], dz2[o], dh);
+            if (atomic) atomicAdd(dw_lin + (size_t)j * 6 + o, acc[o]);
+            else dw_lin[(size_t)j * 6 + o] += acc[o];
         }
-        const float d1 = bn ? dh : dh * lrelu_grad(hj);
-        dz1[(size_t)n * hidden + j] = d1;
-        if (!bn) atomicAdd(db_flat + j, d1);
+        if (!bn) {
+            if (atomic) atomicAdd(db_flat + j, bsum);
+            else db_flat[j] += bsum;
+        }
     }
+    if (!bn && jb == 0 && tid < 6) {
+        float sz = 0.f;
+        for (int c = 0; c < cnt; ++c) sz += dz2s[c * 6 + tid];
+        if (atomic) atomicAdd(db_lin + tid, sz);
+        else db_lin[tid] += sz;
     }
 }
 
@@ -665,9 +692,16 @@ int field_bwd_dx_dw(const float *x, int ld, const float *gz, int n, int h, int w
 
 // theta head, use_BN: dz2 given -> dW2 += h (x) dz2, dh = W2^T dz2 (no activation derivative: the BatchNorm backward of the hidden
 // layer follows);  then, with dz1:  dW1 += v (x) dz1, dv = W1 dz1
+// sample slices of theta_bwd1_kernel: one in deterministic mode (a fixed order of additions), else up to 8 of at least 8 samples each
+static int theta_bwd1_slices(int n) {
+    if (t_deterministic || n < 16) return 1;
+    return n / 8 < 8 ? n / 8 : 8;
+}
+static size_t theta_bwd1_lds(int n, int nslices) { return (size_t)((n + nslices - 1) / nslices) * 6 * sizeof(float); }
 int theta_bwd_bn_lin(const float *dz2, const float *h, int n, int hidden, const float *w_lin, float *dw_lin, float *dh, hipStream_t st) {
-    hipLaunchKernelGGL(theta_bwd1_kernel, dim3(t_deterministic ? 1 : n), dim3(256), 0, st, (const float *)nullptr, dz2, h, hidden, w_lin, dw_lin,
-                       (float *)nullptr, (float *)nullptr, dh, 1, t_deterministic ? n : 0);
+    const int nslices = theta_bwd1_slices(n);
+    hipLaunchKernelGGL(theta_bwd1_kernel, dim3((unsigned)(((hidden + 255) / 256) * nslices)), dim3(256), theta_bwd1_lds(n, nslices), st, (const float *)nullptr, dz2, h,
+                       hidden, w_lin, dw_lin, (float *)nullptr, (float *)nullptr, dh, 1, n, nslices);
     return check_launch("theta_bwd1_kernel<bn>");
 }
 int theta_bwd_flat(const float *x, int n, int c, int hidden, const float *w_flat, const float *dz1, float *dw_flat, float *dx,
@@ -718,8 +752,10 @@ extern "C" int pws_theta_head_bwd(const float *x, int n, int c, int hidden, cons
     hipStream_t st = as_stream(stream);
     const int k1 = 4 * c;
     ProfScope prof(KID_THETA_HEAD_BWD, 4.0 * n * (double)k1 * hidden, 4.0 * 3.0 * (double)k1 * hidden, st);
-    hipLaunchKernelGGL(theta_bwd1_kernel, dim3(t_deterministic ? 1 : n), dim3(256), 0, st, theta, dtheta, h_saved, hidden, w_lin, dw_lin, db_lin,
-                       db_flat, ws, 0, t_deterministic ? n : 0);
+    const int nslices = theta_bwd1_slices(n);
+    PWS_REQUIRE(theta_bwd1_lds(n, nslices) <= 64 * 1024, "pws_theta_head_bwd: n = %d samples exceed the kernel's LDS staging", n);
+    hipLaunchKernelGGL(theta_bwd1_kernel, dim3((unsigned)(((hidden + 255) / 256) * nslices)), dim3(256), theta_bwd1_lds(n, nslices), st, theta, dtheta, h_saved, hidden,
+                       w_lin, dw_lin, db_lin, db_flat, ws, 0, n, nslices);
     const size_t e = (size_t)k1 * hidden;
     hipLaunchKernelGGL(theta_bwd2_kernel, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, st, x, ws, n, k1, hidden, dw_flat);
     if (dx) {
