@@ -30,6 +30,9 @@
 //     no 4x larger halo per matrix instruction, no strided (bank-conflicted) operand reads.
 // Arithmetic is that of conv_bf16_kernel: bf16 x bf16 products exact in fp32, fp32 accumulation (v_mfma_f32_32x32x16_bf16), the
 // K order differs (plane-major for the stride-2 kinds), one rounding to bf16 in the epilogue.
+// Round 6: (a) units of 256 and 128 pixels (RgCfg::PIX) for the launches that give fewer than ~200 units of 512 -- the 32 x 32 ... 8 x 8 levels of a training
+// batch, the 64 x 64 ... 16 x 16 levels of batch-8 inference -- which used to fall back to conv_bf16_kernel or leave half the chip idle (conv_ring_try picks the
+// unit); (b) the first layer (RM_K5: 5x5 on the NHWC-32 copy of the window) with its 25 x 64 weight rows RESIDENT in LDS and input tiles only in the ring.
 #include <cstdlib>
 #include <type_traits>
 
