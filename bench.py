@@ -548,6 +548,27 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
+    # NOT the headline: the same step with the one dead layer of the inference forward pruned (UnetGenerator.prune_dead /
+    # PWS_NETG_PRUNE_DEAD: stage 1's up2, whose output the reference reads only under `if is_training`, lib/networks_cascading.py:171,173,196).
+    # Same field bit for bit (tests/test_hip_netg.py); the headline keeps the layer because the reference executes it.
+    pruned_fps = None
+    if rank == 0 and world == 1 and not a.no_extra:
+        try:
+            net.module.prune_dead = True
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            for _ in range(a.steps):
+                step()
+            torch.cuda.synchronize()
+            pruned_fps = B * a.steps / (time.perf_counter() - tp)
+        except Exception:
+            pruned_fps = None
+        finally:
+            net.module.prune_dead = False
+            step()   # (the default path's graph again, for everything below)
+            torch.cuda.synchronize()
     # what the timed launch path produced for its inputs (one more replay of the same path), for parity_vs_cpu_path
     timed_pair = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -612,6 +633,10 @@ def main():
                                  (", single queue" if a.serial else ", two queues; stages 2 and 3 in lockstep (their shared layers as one launch of batch 2n: 45 launches per forward)"),
                        "window": "31x256x256", "frame": "3x256x256", "weights": "synthetic W1 (pwstablenet_amd.synth)"},
             "netg_tflops_per_gpu": round(fps / world * GFLOP_PER_FRAME_INFER / 1e3, 2),
+            **({"value_dead_layer_pruned": {
+                "value": round(pruned_fps, 2), "unit": "frames/s", "what": "NOT the headline: the same step with stage 1's up2 pruned from the inference forward "
+                "(pws_netg_opts.flags PWS_NETG_PRUNE_DEAD): its output x122 is read only under `if is_training` in the reference (lib/networks_cascading.py:171,173,196), "
+                "so the returned field is bit-identical; 92.33 instead of 94.48 GFLOP per frame"}} if pruned_fps else {}),
             "netg_frac_fp32_peak": round(fps / world * GFLOP_PER_FRAME_INFER / 1e3 / PEAK_FP32_TFLOPS, 4),
         }
         if recs:

@@ -513,6 +513,10 @@ typedef struct pws_netg_opts {
 } pws_netg_opts;
 #define PWS_NETG_DETERMINISTIC 1   /* backward: every weight / bias gradient element receives exactly ONE fp32 atomic add per
                                       launch (no pixel split across workgroups), so two runs give bit-identical gradients; slower */
+#define PWS_NETG_PRUNE_DEAD 2      /* inference forward (is_training = 0) only: do not compute stage 1's `up2` (x122, reference
+                                      lib/networks_cascading.py:171): its only consumers are `up1` (:173) and stage 2's `up_bottom1`
+                                      (:196), both under `if is_training` -- the returned field is bit-identical, 2.147 of the 94.48 GFLOP
+                                      per frame are not spent.  Off by default: the reference executes the layer. */
 int pws_netg_forward_opts(const float *packed, const float *x, int n, int input_nc, int ngf, int is_training, int align_corners,
                           void *ws, size_t ws_bytes, float *grids, float *resid, float *thetas, const pws_netg_opts *opts,
                           pws_stream_t stream);

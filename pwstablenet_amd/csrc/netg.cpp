@@ -156,6 +156,7 @@ struct NetgOpts {
     bool two_queues;
     bool deterministic = false;     // PWS_NETG_DETERMINISTIC
     size_t x_sample_stride = 0;     // floats between samples of the window (0 = dense)
+    bool prune_dead = false;        // PWS_NETG_PRUNE_DEAD
 };
 static NetgOpts opts_defaults() { return NetgOpts{g_math, g_store, g_two_queues}; }
 static int opts_from(const pws_netg_opts *o, NetgOpts *out) {
@@ -166,10 +167,10 @@ static int opts_from(const pws_netg_opts *o, NetgOpts *out) {
     PWS_REQUIRE(o->math == PWS_MATH_FP32 || o->math == PWS_MATH_BF16, "pws_netg_opts: math %d", o->math);
     PWS_REQUIRE(o->store == PWS_STORE_FP32 || o->store == PWS_STORE_BF16, "pws_netg_opts: store %d", o->store);
     PWS_REQUIRE(o->store == PWS_STORE_FP32 || o->math == PWS_MATH_BF16, "pws_netg_opts: PWS_STORE_BF16 needs PWS_MATH_BF16");
-    PWS_REQUIRE(o->two_queues >= -1 && o->two_queues <= 1 && (o->flags & ~PWS_NETG_DETERMINISTIC) == 0, "pws_netg_opts: two_queues %d / flags %d",
+    PWS_REQUIRE(o->two_queues >= -1 && o->two_queues <= 1 && (o->flags & ~(PWS_NETG_DETERMINISTIC | PWS_NETG_PRUNE_DEAD)) == 0, "pws_netg_opts: two_queues %d / flags %d",
                 o->two_queues, o->flags);
     *out = NetgOpts{o->math, o->store, o->two_queues < 0 ? g_two_queues : o->two_queues != 0, (o->flags & PWS_NETG_DETERMINISTIC) != 0,
-                    o->x_sample_stride};
+                    o->x_sample_stride, (o->flags & PWS_NETG_PRUNE_DEAD) != 0};
     return PWS_OK;
 }
 
@@ -281,7 +282,7 @@ class Exec {
   public:
     Exec(const float *packed, const std::vector<Layer> &layers, int n, char *ws, size_t ws_bytes, hipStream_t st, bool dry,
          bool launch, const NetgOpts &o, const BnCfg *bn = nullptr)
-        : math_(o.math), x_sstride_(o.x_sample_stride), packed_(packed), L_(layers), n_(n), ws_(ws), cap_(ws_bytes), dry_(dry), launch_(launch && !dry) {
+        : math_(o.math), x_sstride_(o.x_sample_stride), prune_dead_(o.prune_dead), packed_(packed), L_(layers), n_(n), ws_(ws), cap_(ws_bytes), dry_(dry), launch_(launch && !dry) {
         if (bn) {
             bn_on_ = true, bn_ = *bn;
             size_t off = 0;
@@ -323,6 +324,7 @@ class Exec {
     float *splitk_ws() const { return splitk_ws_; }
     float *x_nhwc() const { return x_nhwc_; }
     bool io16() const { return io16_; }
+    bool prune_dead() const { return prune_dead_; }
     int math() const { return math_; }
     int store() const { return io16_ ? PWS_STORE_BF16 : PWS_STORE_FP32; }
     float *theta_x32(int q) const { return theta_x32_[q]; }
@@ -588,6 +590,7 @@ class Exec {
     bool io16_ = false, training_ = false;
     int math_ = PWS_MATH_FP32;
     size_t x_sstride_ = 0;
+    bool prune_dead_ = false;
     SideStream *side_ = nullptr;
     hipStream_t streams_[2];
     int q_ = 0;
@@ -702,7 +705,9 @@ static void forward_lockstep(Exec &E, const Tn &in, const float *x, int n, int i
     //  decoder levels, where that queue has nothing else to do: in front of them they sat on the critical path)
     // ---- stage 1 decoder (reference :166-174) on queue 0
     E.use(0);
-    for (int l = 7; l >= 2; --l) {
+    // (PWS_NETG_PRUNE_DEAD, inference: u12 = up2's output is read by up1 and stage 2's up_bottom1 only, reference :173,:196 -- both `if is_training`)
+    const int l_last = (!is_training && E.prune_dead()) ? 3 : 2;
+    for (int l = 7; l >= l_last; --l) {
         E.conv_groups(L_UP7 + (7 - l), dec(l + 1, 1), PWS_ACT_RELU, 1, Vl[l], 0);
         if (l == 6) E.order(0, 1);   // u17, u16: what the deep merged levels (7 .. 5, queue 1) read of stage 1
     }

@@ -19,6 +19,7 @@ OPT_MATH, MATH_FP32, MATH_BF16 = 2, 0, 1
 OPT_STORE, STORE_FP32, STORE_BF16 = 3, 0, 1
 ABI_VERSION = 5
 NETG_DETERMINISTIC = 1
+NETG_PRUNE_DEAD = 2
 OPT_EXPERIMENT = 100   # measured kernel variants (tools, per-path tests); 0 = product default
 OBJ_SLOTS = 64
 CONV_K3S1, CONV_K3S2, CONV_K5S1, CONVT_K3S1, CONVT_K4S2, CONV_K2S1P0, CONV_K1, CONV_K3S1_OUT = range(8)

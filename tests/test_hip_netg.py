@@ -213,3 +213,45 @@ def test_lockstep_schedule_equals_the_per_stage_schedule(hip, math):
         assert float((a - b).abs().max()) / scale < 2e-3, (i, float((a - b).abs().max()) / scale)
         cos = float((a.double().reshape(-1) @ b.double().reshape(-1)) / (a.double().norm() * b.double().norm() + 1e-300))
         assert cos > 0.999999, (i, cos)
+
+
+@pytest.mark.parametrize("math", ["fp32", "bf16"])
+def test_prune_dead_gives_the_same_field_bit_for_bit(hip, math):
+    """PWS_NETG_PRUNE_DEAD (UnetGenerator.prune_dead): the inference forward without stage 1's up2 -- its output x122 (reference
+    lib/networks_cascading.py:171) is read only under `if is_training` (:173, :196) -- returns the SAME field, eagerly and from a replayed graph,
+    with one launch less; the training forward ignores the flag (it needs x122)."""
+    from pwstablenet_amd import synth
+    from pwstablenet_amd.lib.networks_cascading import define_G
+    net = define_G(31, 2, 64, "normal", 0.02)
+    net.load_state_dict({"module." + k: torch.from_numpy(v) for k, v in synth.make_weights("W2", seed=123, ngf=64)})
+    net = net.cuda()
+    net.module.set_math(math)
+    x = torch.from_numpy(synth.make_window(4, 31, 256, seed=17)).cuda()
+    L = hip.lib()
+
+    def run(prune, graph):
+        net.module.prune_dead = prune
+        net.module.enable_graph(graph)
+        with torch.no_grad():
+            if graph:
+                net(x, False)
+            L.pws_prof_enable(0 if graph else 1)
+            f = net(x, False).clone()
+            L.pws_prof_enable(0)
+        return f, (0 if graph else len(hip.prof_collect()))
+    try:
+        f0, n0 = run(False, False)
+        f1, n1 = run(True, False)
+        g1, _ = run(True, True)
+        assert torch.equal(f0, f1) and torch.equal(f0, g1)
+        assert n1 == n0 - 1, (n0, n1)   # exactly the one launch of up2 (profiler scopes: one per conv launch)
+        net.module.enable_graph(False)
+        with torch.no_grad():
+            a = net(x)
+            net.module.prune_dead = False
+            b = net(x)
+        assert all(torch.equal(p, q) for p, q in zip(a[0] + a[1], b[0] + b[1]))
+    finally:
+        net.module.prune_dead = False
+        net.module.enable_graph(False)
+        net.module.set_math("fp32")
