@@ -31,7 +31,7 @@ def bench_dgrad(kname, n, h, w, cin, cout):
     da.kind, da.n, da.h, da.w, da.cout = kind, n, h, w, cout
     da.gout_ld, da.w_dgrad, da.ndst = cout, wdg.data_ptr(), 1
     da.math, da.w_dgrad_bf16, da.store = A.MATH_BF16, wdb.data_ptr(), A.STORE_BF16
-    da.dst[0].channels, da.dst[0].ld, da.dst[0].accumulate = cin, cin, 0
+    da.dst[0].channels, da.dst[0].ld, da.dst[0].accumulate = cin, cin, int(os.environ.get("CONV_BENCH_ACC", "0"))   # 1: read-modify-write of dx (a second consumer's gradient)
     da.ws, da.ws_bytes = ws.data_ptr(), ws.numel()
 
     def launch(i):
