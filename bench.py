@@ -72,6 +72,10 @@ def parse():
                     help="conv arithmetic of the TIMED region (default fp32 = configs[1], the headline); bf16 is for profiling the "
                          "bf16 path: metric/dtype fields say so and vs_baseline stays null")
     ap.add_argument("--no-extra", action="store_true", help="skip the bf16 inference / training-step legs (extra JSON fields)")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="batches in flight in the inference legs: consecutive steps alternate over this many streams (one hipGraph + arena per stream, one "
+                         "queue per forward), so that one batch's large layers fill the CUs the other batch's chain of short launches leaves idle; "
+                         "1 = one step at a time on two queues (rounds 1-5; always with --serial)")
     ap.add_argument("--ddp-items", type=int, default=32, help="item pairs per GPU per step of the N>1 training leg (configs[3]: 32)")
     ap.add_argument("--stream-frames", type=int, default=128, help="720p frames per GPU of the N>1 streaming leg (configs[4])")
     ap.add_argument("--force-collectives", action="store_true",
@@ -365,6 +369,8 @@ def bf16_legs(net, x, frames, out_fp32, a, PF, A, synth):
 
         def step():
             return PF.grid_sample(frames, net(x, False))
+        # one step at a time on two queues (rounds 1-5), then D batches in flight as the headline leg (see there)
+        D = 1 if a.serial else max(1, a.in_flight)
         for _ in range(max(a.warmup, 2)):
             o = step()
         torch.cuda.synchronize()
@@ -372,9 +378,30 @@ def bf16_legs(net, x, frames, out_fp32, a, PF, A, synth):
         for _ in range(a.steps):
             o = step()
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        dt = dt_one = time.perf_counter() - t0
+        if D > 1:
+            lanes = [torch.cuda.Stream(x.device) for _ in range(D)]
+            net.module.two_queues = False
+            net.module.enable_graph(not a.no_graph, per_stream=True)
+            try:
+                def step_on(i):
+                    with torch.cuda.stream(lanes[i % D]):
+                        return step()
+                for i in range(max(a.warmup, 2 * D)):
+                    o = step_on(i)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(a.steps):
+                    o = step_on(i)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            finally:
+                net.module.two_queues = None
+                net.module.enable_graph(not a.no_graph)
+                torch.cuda.synchronize()
     res["inference"] = {"value": round(B * a.steps / dt, 2), "unit": "frames/s", "n_gpus": 1, "dtype": "bf16 operands + activation storage, f32 accumulate",
-                        "ms_per_step": round(1e3 * dt / a.steps, 4),
+                        "ms_per_step": round(1e3 * dt / a.steps, 4), "batches_in_flight": D,
+                        "value_one_in_flight": round(B * a.steps / dt_one, 2),
                         "field_max_abs_err_vs_fp32": float((f16 - f32).abs().max()),
                         "warped_max_abs_err_vs_fp32_over_255": float((o - out_fp32).abs().max() / 255.0),
                         "netg_tflops": round(B * a.steps / dt * GFLOP_PER_FRAME_INFER / 1e3, 1),
@@ -539,12 +566,51 @@ def main():
     if a.serial:
         A.lib().pws_set_option(A.OPT_TWO_QUEUES, 0)
     net.module.enable_graph(not a.no_graph)  # the ~75 launches of a forward replay as one hipGraph launch
-    for _ in range(a.warmup):
-        step()
+    # Batches in flight (round 6): the K steps are independent batches, so step i is issued on stream i % D without waiting for step i - 1
+    # (one graph + arena per stream: UnetGenerator keeps them per stream; one queue per forward -- two forwards that both fork into the
+    # device's side queue do not overlap).  While one batch walks the chain of its <= 8x8 levels (one 5-25 us launch at a time, most CUs
+    # idle), the other batch's large layers run.  D = 1: one step at a time on two queues, as rounds 1-5 timed it (value_one_in_flight).
+    D = 1 if a.serial else max(1, a.in_flight)
+    one_fps = None
+    lanes = None
+    if D > 1:
+        if rank == 0 and world == 1 and not a.no_extra:
+            for _ in range(a.warmup):
+                step()
+            torch.cuda.synchronize()
+            t1f = time.perf_counter()
+            for _ in range(a.steps):
+                step()
+            torch.cuda.synchronize()
+            one_fps = B * a.steps / (time.perf_counter() - t1f)
+        lanes = [torch.cuda.Stream(dev) for _ in range(D)]
+
+    def set_in_flight(on):
+        """D > 1: one queue per forward and one graph + arena per stream while steps alternate over the lanes; off: the process defaults again."""
+        if lanes is None:
+            return
+        torch.cuda.synchronize()
+        net.module.two_queues = False if on else None
+        net.module.enable_graph(not a.no_graph, per_stream=bool(on))
+        if not on:
+            step()   # (switching drops the graphs: capture the default one here, not inside a later instrumented loop)
+            torch.cuda.synchronize()
+
+    def on_lane(i, fn):
+        if lanes is None:
+            return fn()
+        with torch.cuda.stream(lanes[i % D]):
+            return fn()
+
+    def step_on(i):
+        return on_lane(i, step)
+    set_in_flight(True)
+    for i in range(max(a.warmup, 2 * D)):
+        step_on(i)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
+    for i in range(a.steps):
+        out = step_on(i)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
@@ -555,25 +621,28 @@ def main():
     if rank == 0 and world == 1 and not a.no_extra:
         try:
             net.module.prune_dead = True
-            for _ in range(2):
-                step()
+            for i in range(2 * D):
+                step_on(i)
             torch.cuda.synchronize()
             tp = time.perf_counter()
-            for _ in range(a.steps):
-                step()
+            for i in range(a.steps):
+                step_on(i)
             torch.cuda.synchronize()
             pruned_fps = B * a.steps / (time.perf_counter() - tp)
         except Exception:
             pruned_fps = None
         finally:
             net.module.prune_dead = False
-            step()   # (the default path's graph again, for everything below)
+            for i in range(D):
+                step_on(i)   # (the default path's graphs again, for everything below)
             torch.cuda.synchronize()
     # what the timed launch path produced for its inputs (one more replay of the same path), for parity_vs_cpu_path
     timed_pair = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        with torch.no_grad():
-            timed_pair = (net(x, False).cpu(), step().cpu())
+        with torch.no_grad(), torch.cuda.stream(lanes[0] if lanes else torch.cuda.current_stream()):
+            tp_field, tp_warp = net(x, False), step()
+        torch.cuda.synchronize()
+        timed_pair = (tp_field.cpu(), tp_warp.cpu())
     # 720p leg of the metric on EVERY rank (configs[4] shape, frame-sharded, no collective): netG on 256x256 windows + fused
     # field-resize+warp of 1280x720 RGB frames (reference main_new.py:697-716), frames resident in HBM
     f720 = torch.rand((B, 3, 720, 1280), device=dev) * 255
@@ -581,17 +650,18 @@ def main():
     def step720():
         with torch.no_grad():
             return PF.upsample_grid_sample(f720, net(x, False))
-    for _ in range(2):
-        step720()
+    for i in range(2 * D):
+        on_lane(i, step720)
     barrier()
     t1 = time.perf_counter()
-    for _ in range(a.steps):
-        o720 = step720()
+    for i in range(a.steps):
+        o720 = on_lane(i, step720)
     torch.cuda.synchronize()
     dt720 = time.perf_counter() - t1
     barrier()
     assert torch.isfinite(o720).all()
     del o720
+    set_in_flight(False)   # the legs below run one step at a time: the process default (two queues, one graph) again
     if world > 1:
         t = torch.tensor([dt720], device=ctl_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -630,9 +700,13 @@ def main():
             "config": {"workload": "configs[1]: batch=8 256x256 inference per GPU, fp32 HIP conv + grid_sample; "
                                    "frame-sharded, no collective", "frames_per_gpu_per_step": B,
                        "launch": ("eager" if a.no_graph else "hipGraph replay of the forward + 1 grid_sample launch") +
-                                 (", single queue" if a.serial else ", two queues; stages 2 and 3 in lockstep (their shared layers as one launch of batch 2n: 45 launches per forward)"),
+                                 (", single queue" if a.serial else (", two queues" if D == 1 else ", %d batches in flight (step i on stream i %% %d: one graph + arena per stream, one queue per forward)" % (D, D)) +
+                                  "; stages 2 and 3 in lockstep (their shared layers as one launch of batch 2n: 45 launches per forward)"),
+                       "batches_in_flight": D,
                        "window": "31x256x256", "frame": "3x256x256", "weights": "synthetic W1 (pwstablenet_amd.synth)"},
             "netg_tflops_per_gpu": round(fps / world * GFLOP_PER_FRAME_INFER / 1e3, 2),
+            **({"value_one_in_flight": {"value": round(one_fps, 2), "unit": "frames/s",
+                                        "what": "the same K steps one at a time (each step waits for the one before), two queues: how rounds 1-5 timed `value`"}} if one_fps else {}),
             **({"value_dead_layer_pruned": {
                 "value": round(pruned_fps, 2), "unit": "frames/s", "what": "NOT the headline: the same step with stage 1's up2 pruned from the inference forward "
                 "(pws_netg_opts.flags PWS_NETG_PRUNE_DEAD): its output x122 is read only under `if is_training` in the reference (lib/networks_cascading.py:171,173,196), "
@@ -791,7 +865,7 @@ def main():
         gbs = r[0][3] / (ms * 1e-3) / 1e9
         line["value_720p"] = {"value": round(world * B * a.steps / dt720, 2), "unit": "frames/s", "n_gpus": world,
                               "workload": "batch=%d per GPU: netG(31x256x256 window, fp32) + fused upsample(256^2 field)+grid_sample "
-                                          "of 3x720x1280 fp32 frames; frame-sharded, no collective" % B,
+                                          "of 3x720x1280 fp32 frames; frame-sharded, no collective; %d batches in flight" % (B, D),
                               "roofline_warp": {"kernel": "upsample_grid_sample_fwd_kernel", "bound": "hbm",
                                                 "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                                 "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_us": round(1e3 * ms, 2),
@@ -833,14 +907,18 @@ def main():
             with torch.no_grad():
                 def step720u8():
                     return PF.upsample_grid_sample_u8(u720, net(x, False), swap_rb=True)
-                for _ in range(2):
-                    step720u8()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(a.steps):
-                    step720u8()
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t1
+                set_in_flight(True)
+                try:
+                    for i in range(2 * D):
+                        on_lane(i, step720u8)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for i in range(a.steps):
+                        on_lane(i, step720u8)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t1
+                finally:
+                    set_in_flight(False)
                 A.lib().pws_prof_enable(1)
                 for _ in range(5):
                     step720u8()

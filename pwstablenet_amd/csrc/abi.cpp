@@ -41,10 +41,14 @@ const char *const kKernelNames[KID_COUNT] = {
     "wino_ring_kernel<F(2x2,3x3)>", "wino_ring_kernel<convT4,F(2x2,2x2)>", "conv_skinny_kernel", "wgrad_ring_kernel", "conv_skinny16_kernel", "conv_first_kernel", "wino5_first_kernel"};
 }  // namespace
 
-void prof_begin(int kernel_id, double flops, double bytes, hipStream_t st) {
+bool prof_begin(int kernel_id, double flops, double bytes, hipStream_t st) {
+    // an event recorded while the stream is captured becomes a graph node, not a timestamp (hipEventElapsedTime: invalid resource handle)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
     ProfEntry e{prof_event(), prof_event(), kernel_id, g_prof_tag, flops, bytes};
     (void)hipEventRecord(e.a, st);
     g_prof_log.push_back(e);
+    return true;
 }
 void prof_end(hipStream_t st) {
     if (!g_prof_log.empty()) (void)hipEventRecord(g_prof_log.back().b, st);
@@ -90,20 +94,22 @@ extern "C" int pws_prof_enable(int on) {
 
 extern "C" int pws_prof_collect(pws_prof_record *out, int max_records) {
     const int n = (int)pws::g_prof_log.size();
+    hipError_t bad = hipSuccess;
     for (int i = 0; i < n; ++i) {
         pws::ProfEntry &e = pws::g_prof_log[i];
         float ms = 0.f;
         hipError_t err = hipEventSynchronize(e.b);
         if (err == hipSuccess) err = hipEventElapsedTime(&ms, e.a, e.b);
-        if (err != hipSuccess) {
-            pws::set_error("pws_prof_collect: %s", hipGetErrorString(err));
-            return PWS_EHIP;
-        }
-        if (out && i < max_records) out[i] = pws_prof_record{e.kernel_id, e.tag, e.flops, e.bytes, ms};
+        if (err != hipSuccess && bad == hipSuccess) bad = err;
+        if (err == hipSuccess && out && i < max_records) out[i] = pws_prof_record{e.kernel_id, e.tag, e.flops, e.bytes, ms};
         pws::g_prof_pool.push_back(e.a);
         pws::g_prof_pool.push_back(e.b);
     }
-    pws::g_prof_log.clear();
+    pws::g_prof_log.clear();   // (also after an error: the next collection starts clean)
+    if (bad != hipSuccess) {
+        pws::set_error("pws_prof_collect: %s", hipGetErrorString(bad));
+        return PWS_EHIP;
+    }
     return n;
 }
 

@@ -93,13 +93,13 @@ extern int g_store;  // PWS_OPT_STORE (effective only with PWS_MATH_BF16)
 extern int g_experiment;  // PWS_OPT_EXPERIMENT: selects measured kernel variants (tools/*_bench.py); 0 = product default
 extern bool g_prof_on;
 extern thread_local int g_prof_tag;  // the layer a launch belongs to, per calling thread
-void prof_begin(int kernel_id, double flops, double bytes, hipStream_t st);
+bool prof_begin(int kernel_id, double flops, double bytes, hipStream_t st);  // false: nothing recorded (the stream is being captured)
 void prof_end(hipStream_t st);
 struct ProfScope {  // brackets one launch with events when profiling is enabled; free otherwise
     hipStream_t st;
     bool on;
     ProfScope(int kernel_id, double flops, double bytes, hipStream_t s) : st(s), on(g_prof_on) {
-        if (on) prof_begin(kernel_id, flops, bytes, st);
+        if (on) on = prof_begin(kernel_id, flops, bytes, st);
     }
     ~ProfScope() {
         if (on) prof_end(st);

@@ -147,7 +147,8 @@ class UnetGenerator(nn.Module):
         self._train_ws = {}
         self._graph_mode = False
         self._graph_alias = False
-        self._graph = None
+        self._graph = None     # the graph entry of the stream the last call ran on (tests read it)
+        self._graphs = {}      # one graph + arena per STREAM (hip stream handle -> entry): two batches in flight on two streams (bench.py --in-flight 2)
         self.math, self.store = "fp32", "fp32"
         # coordinate convention of the fused affine_grid (and of the functional.grid_sample default the drivers should pass):
         # False = torch >= 1.3 defaults (goldens); True = torch < 1.3, what checkpoints trained on the reference's pinned
@@ -177,7 +178,7 @@ class UnetGenerator(nn.Module):
         if store not in ("fp32", "bf16") or (store == "bf16" and (math != "bf16" or self.ngf % 32 != 0)):
             raise ValueError("UnetGenerator.set_math: store=%r needs math='bf16' and ngf %% 32 == 0" % (store,))
         if (math, store) != (self.math, self.store):
-            self._graph = None
+            self._graph, self._graphs = None, {}
         self.math, self.store = math, store
         return self
 
@@ -190,15 +191,21 @@ class UnetGenerator(nn.Module):
         return A.PwsNetgOpts(A.MATH_BF16 if math == "bf16" else A.MATH_FP32, A.STORE_BF16 if store == "bf16" else A.STORE_FP32, tq, flags,
                              int(x_sample_stride))
 
-    def enable_graph(self, on=True, alias_output=False):
+    def enable_graph(self, on=True, alias_output=False, per_stream=False):
         """Opt-in hipGraph replay of the inference forward (``netG(x, False)`` under ``no_grad``): the ~75 launches of a
         forward are captured once per (batch, weight version, mode) and replayed as one graph launch.  The graph owns its
         activation arena and its output buffer; every call returns a fresh tensor (a 0.5 MB/frame device copy) unless
         ``alias_output=True``, in which case the returned field is the graph's own buffer and is OVERWRITTEN by the next call."""
+        if bool(per_stream) != getattr(self, "_graph_per_stream", False):
+            self._graph, self._graphs = None, {}
         self._graph_mode = bool(on)
         self._graph_alias = bool(alias_output)
+        # per_stream: one graph + arena per calling STREAM instead of one in all, for callers that keep several batches in flight by issuing
+        # consecutive calls on different streams (bench.py --in-flight 2).  Default: one graph, replayed on whatever stream the caller is on --
+        # safe as long as the caller's calls are ordered (one stream, or streams that wait for each other).
+        self._graph_per_stream = bool(per_stream)
         if not on:
-            self._graph = None
+            self._graph, self._graphs = None, {}
 
     # -- parameters in state-dict order: (weight, bias) per layer
     def _ordered_params(self):
@@ -368,7 +375,8 @@ class UnetGenerator(nn.Module):
         with _capture_lock:
             xg = x.clone(memory_format=torch.contiguous_format) if static_input else x
             nbytes = A.lib().pws_netg_workspace_bytes(xg.shape[0], self.input_nc, self.ngf, 0)
-            old, self._graph = self._graph, None
+            sid = self._graph_slot(xg.device)
+            old, self._graph = self._graphs.pop(sid, None), None
             ws = old["ws"] if old is not None and old["ws"].numel() == nbytes + 256 and old["ws"].device == xg.device else None
             del old   # the previous hipGraphExec, its output and its input buffer go before the new graph is made
             if ws is None:
@@ -381,8 +389,13 @@ class UnetGenerator(nn.Module):
             with torch.cuda.graph(g, stream=_capture_stream(xg.device), capture_error_mode="thread_local"):
                 out = self._run(xg, False, ws=ws)
             # one graph is kept; it holds its input tensor (address baked in), its arena and its output
-            self._graph = dict(key=key, g=g, out=out, x=xg, ws=ws, static=static_input)
+            self._graph = self._graphs[sid] = dict(key=key, g=g, out=out, x=xg, ws=ws, static=static_input)
+            if len(self._graphs) > 8:   # (streams come and go: keep the most recent few)
+                self._graphs.pop(next(iter(self._graphs)))
             return self._graph
+
+    def _graph_slot(self, device):
+        return torch.cuda.current_stream(device).cuda_stream if getattr(self, "_graph_per_stream", False) else 0
 
     def _run_graph(self, input1):
         x = input1   # may be a strided view (the video loop's overlapping windows): copied ONCE, straight into the graph's input
@@ -390,7 +403,8 @@ class UnetGenerator(nn.Module):
         # the packed buffer is re-packed IN PLACE at a fixed address when a parameter changes (packed_weights() above, outside the
         # graph), so a weight update needs no re-capture: the key holds the buffer's address, not the parameter versions
         key = (tuple(x.shape), str(x.device), self._packed.data_ptr(), self.math, self.store, self.align_corners, self.two_queues, bool(self.prune_dead))
-        ent = self._graph
+        # one graph (and arena) per stream: a forward replayed on stream B while the previous one still runs on stream A must not share its arena
+        ent = self._graphs.get(self._graph_slot(x.device))
         if ent is None or ent["key"] != key:
             ent = None   # (no reference to the old entry while the new graph is captured)
             ent = self._capture(x, key, static_input=not x.is_contiguous())
@@ -401,6 +415,7 @@ class UnetGenerator(nn.Module):
                 ent = self._capture(x, key, static_input=True)   # (the capture's copy of x IS this call's input)
             else:
                 ent["x"].copy_(x)
+        self._graph = ent
         ent["g"].replay()
         return ent["out"] if self._graph_alias else ent["out"].clone()
 

@@ -304,3 +304,71 @@ def test_bench_watchdog_exits_non_zero(hip):
     assert r.returncode != 0
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["value"] > 0 and "watchdog" in line["training_ddp"]["error"]
+
+
+@pytest.mark.parametrize("math", ["fp32", "bf16"])
+def test_two_batches_in_flight_on_two_streams(hip, math):
+    """bench.py --in-flight 2 (the headline's launch path since round 6): consecutive steps alternate over two streams without waiting for each
+    other.  The generator keeps one graph + arena per STREAM, so the two forwards in flight do not share activations: every step returns the bits
+    of the one-at-a-time forward of its own input, no stream re-captures after its first call, and eager launches behave the same."""
+    from pwstablenet_amd import functional as PF
+    net = make_net("W2")
+    net.module.set_math(math)
+    xs = [torch.from_numpy(synth.noise_window(8, 31, 256, seed=40 + i)).cuda() for i in range(2)]
+    fr = torch.from_numpy(synth.make_frames(8, 3, 256, 256, seed=7)).cuda()
+    with torch.no_grad():
+        want = [net(x, False).clone() for x in xs]
+        want_w = [PF.grid_sample(fr, w) for w in want]
+    torch.cuda.synchronize()
+    lanes = [torch.cuda.Stream(), torch.cuda.Stream()]
+    net.module.two_queues = False   # one queue per forward: two forwards forking into the device's one side queue would serialise
+    try:
+        for graph in (True, False):
+            net.module.enable_graph(graph, per_stream=True)
+            outs, graphs = [], {}
+            with torch.no_grad():
+                for i in range(8):
+                    with torch.cuda.stream(lanes[i % 2]):
+                        f = net(xs[i % 2], False)
+                        outs.append((i % 2, f, PF.grid_sample(fr, f)))
+                    if graph:
+                        g = net.module._graph["g"]
+                        assert graphs.setdefault(i % 2, g) is g, "a stream re-captured its graph"
+            torch.cuda.synchronize()
+            if graph:
+                assert len(net.module._graphs) == 2 and graphs[0] is not graphs[1]
+            for k, f, w in outs:
+                assert torch.equal(f, want[k]) and torch.equal(w, want_w[k]), (graph, k)
+    finally:
+        net.module.two_queues = None
+        net.module.enable_graph(False)
+        net.module.set_math("fp32")
+
+
+def test_kernel_events_enabled_across_a_graph_capture(hip):
+    """pws_prof_enable(1) while a forward is CAPTURED (bench.py --no-prof used to reach this on its first 720p step after leaving the
+    in-flight mode): the captured launches record nothing (an event recorded into a capture is a graph node, not a timestamp), the launches
+    outside the graph are timed as before, and the collection does not fail -- nor would a failed one poison the next."""
+    from pwstablenet_amd import functional as PF, hipabi as A
+    net = make_net("W1")
+    x = torch.from_numpy(synth.noise_window(2, 31, 256, seed=3)).cuda()
+    fr = torch.from_numpy(synth.make_frames(2, 3, 256, 256, seed=4)).cuda()
+    with torch.no_grad():
+        want = net(x, False).clone()
+        net.module.enable_graph(True)
+        try:
+            A.lib().pws_prof_enable(1)
+            got = [PF.grid_sample(fr, net(x, False)) for _ in range(3)]   # capture, replay, replay
+            torch.cuda.synchronize()
+            A.lib().pws_prof_enable(0)
+            recs = A.prof_collect()
+            # (the capture's eager warm-up forward is timed like any eager launch; the captured and the replayed launches are not)
+            assert sum(r[0] == "grid_sample_fwd_kernel" for r in recs) == 3 and all(r[4] > 0 for r in recs)
+            eager_forward = len(recs) - 3
+            assert 0 < eager_forward < 120, eager_forward
+            assert torch.equal(net(x, False), want)
+            assert all(torch.equal(g, got[0]) for g in got)
+            assert A.prof_collect() == []
+        finally:
+            A.lib().pws_prof_enable(0)
+            net.module.enable_graph(False)
