@@ -956,8 +956,9 @@ def main():
                 rw["achieved"] = round(r[0][3] / (ms * 1e-3) / 1e9, 1)
                 rw["frac"] = round(r[0][3] / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
                 rw["avg_launch_us"] = round(1e3 * ms, 2)
-                rw["bound_note"] = ("vector-instruction-bound, not HBM-bound: 140 vector instructions per pixel, vector pipes >= 78 % occupied "
-                                    "(profiles/r06_warp_u8_issue_slots.txt, DESIGN.md section 8)")
+                rw["bound_note"] = ("not HBM-bound at 6 B/pixel: bound by the NUMBER and alignment of its vector memory instructions (23 -> 11 per lane "
+                                    "of 4 pixels in round 6: 35 -> 22 us), then by the vector ALU (conversions and VOP3 forms issue in ~4.5 cycles); "
+                                    "profiles/r06_warp_u8_rewrite.txt, DESIGN.md section 8")
                 del rot8, fsm
             except Exception as e:
                 line["value_720p_u8"]["roofline_warp"]["smooth_field_error"] = str(e)[:200]

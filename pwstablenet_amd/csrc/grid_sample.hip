@@ -531,152 +531,253 @@ __global__ void __launch_bounds__(256) upsample_grid_sample_fwd_kernel(const flo
 // frame moves 3 + 3 bytes per pixel instead of 12 + 12.  Field interpolation and tap weights are the float kernel's, the blend
 // is evaluated in the same order on the same fp32 values, then truncated like numpy's astype(uint8) (values are in [0, 255]).
 // swap_rb: output channel c = input channel 2 - c (the reference's COLOR_BGR2RGB before the warp).
+//
+// What bounds this kernel (round 6, 8 frames of 1280 x 720, profiles/r06_warp_u8_rewrite.txt): NOT its 6 bytes per pixel, and not the count of its
+// vector-ALU instructions either (the round-5 cut ran 35 us with 613 of them per lane and 35 us with 309) but, in this order,
+//   1. the NUMBER of vector memory instructions (a CU's address unit spends ~16-30 cycles per wave instruction whatever its width) and their
+//      ALIGNMENT (a byte-aligned dword / 8-byte load costs about twice an aligned one): 23 per lane (per tap row a 4- and a 2-byte
+//      unaligned load, 6 field loads, a store) -> 11 (per tap row ONE aligned 12-byte load + two v_alignbyte; the field's row pair fetched
+//      once per wave, one column per lane, and handed round with ds_bpermute; a 12-byte store): 35 -> 22 us;
+//   2. then the vector ALU (tools/probes/valu_rate_probe.hip: conversions, VOP3 forms and packed fp32 issue in ~4.5 cycles, plain
+//      fp32 / moves / logic in ~2.5): a WAVE owns 256 consecutive pixels of ONE output row, so sample, row, the field's row pair, its vertical
+//      weights and every base address are wave-uniform (scalar registers, no per-lane division, loads and stores are base + 32-bit offset);
+//      a lane's 4 pixels run as two PAIRS through packed fp32 (the same IEEE roundings as the scalar forms: field interpolation,
+//      un-normalisation, tap weights and the 4-term blend are the float kernel's operations in the float kernel's order); the border logic
+//      runs only in waves that have a tap outside the frame (wave-uniform branch); float -> byte is one SDWA convert per byte.
 struct __attribute__((packed, aligned(1))) U8x4 {
     unsigned v;
 };
 struct __attribute__((packed, aligned(1))) U8x2 {
     unsigned short v;
 };
-struct __attribute__((packed, aligned(1))) U8x16 {
-    unsigned w[4];
+struct __attribute__((aligned(4))) U32x3 {
+    unsigned x, y, z;
 };
-// ROWWIN (the "wavefront shuffle" variant, measured against the per-tap gathers: DESIGN.md): where a stabiliser's field maps the 4
-// consecutive output pixels of a lane onto at most 5 consecutive pixels of ONE source row pair, the lane fetches each row as ONE
-// unaligned 16-byte window (5.33 RGB pixels) -- plus, for the sixth pixel, the second dword of the NEXT lane's window through a
-// wave shuffle when that lane's window starts exactly 4 pixels further -- instead of 4 x (4 + 2)-byte gathers per row: 2 vector
-// memory instructions per lane instead of 16.  Lanes whose pixels straddle a row or spread wider keep the per-tap gathers.
-// SWAP (R <-> B) is a template parameter and a pixel pair travels as two 32-bit words: every source byte is then a CONSTANT byte of a
-// dword and converts with one v_cvt_f32_ubyteN.  (Round 2 carried the six bytes as a 64-bit value shifted by a run-time amount:
-// 330 of the kernel's 897 vector instructions per lane were 64-bit shifts, masks and u64 -> float conversions.)
-template <bool NARROW, bool ROWWIN, bool SWAP>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_splat(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 pk_floor(f32x2 v) { return f32x2{floorf(v.x), floorf(v.y)}; }
+__device__ __forceinline__ f32x2 pk_mul_rounded(f32x2 a, f32x2 b) {   // (mul_rounded of common.h, two at a time)
+    f32x2 p = a * b;
+    asm volatile("" : "+v"(p));
+    return p;
+}
+__device__ __forceinline__ f32x2 pk_field_lerp(f32x2 hy, f32x2 ly, f32x2 hx, f32x2 lx, f32x2 a, f32x2 b, f32x2 c, f32x2 d) {
+    const f32x2 top = pk_fma(lx, b, hx * a), bot = pk_fma(lx, d, hx * c);   // field_lerp above, per component
+    return pk_fma(ly, bot, hy * top);
+}
+// float -> byte B of `word`, truncating like astype(uint8) (the blend is in [0, 255.0001]; v_cvt_u32_f32 truncates and saturates at 0): one
+// SDWA instruction converts and writes the byte in place.  (v_cvt_pk_u8_f32 rounds to NEAREST -- measured -- and would need a floor in front.)
+__device__ __forceinline__ void cvt_u8_into(int B, unsigned &word, float v) {   // (B: a constant once the caller's loops are unrolled)
+    if (B == 0) asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(word) : "v"(v));
+    if (B == 1) asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(word) : "v"(v));
+    if (B == 2) asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(word) : "v"(v));
+    if (B == 3) asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(word) : "v"(v));
+}
+struct TapsU8 {   // one pixel's source: byte offsets of its two row pairs inside the sample, weights of (left, right) per row
+    unsigned o0, o1;
+    float wl, wr, r0, r1;
+};
+__device__ __forceinline__ int med3_i32(int x, int hi) {   // clamp to [0, hi], hi >= 0 and wave-uniform: one instruction (hipcc emits max + min)
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
+    return r;
+}
+// make_taps2's values (same operations on ix / iy), border cases decided on the integer column / row
+__device__ __forceinline__ TapsU8 make_taps_u8(float wx0, float wx1, float fx, float wy0, float wy1, float fy, int H, int W, unsigned W3) {
+    const int x0 = (int)fx, y0 = (int)fy, y1 = y0 + 1;
+    const bool in = (unsigned)x0 <= (unsigned)(W - 2), m1 = x0 == -1, p1 = x0 == W - 1;
+    TapsU8 t;
+    t.wl = in ? wx0 : (m1 ? wx1 : 0.f), t.wr = in ? wx1 : (p1 ? wx0 : 0.f);
+    t.r0 = (unsigned)y0 < (unsigned)H ? wy0 : 0.f, t.r1 = (unsigned)y1 < (unsigned)H ? wy1 : 0.f;
+    const unsigned xs = (unsigned)med3_i32(x0, W - 2), xs3 = xs + 2u * xs;
+    t.o0 = __umul24((unsigned)med3_i32(y0, H - 1), W3) + xs3, t.o1 = __umul24((unsigned)med3_i32(y1, H - 1), W3) + xs3;   // (rows, 3 W < 2^24)
+    return t;
+}
+template <int FMODE, bool SWAP, bool PKU8>   // FMODE: how a lane gets its field values -- 0 four corners per pixel, 1 a 3-column window per lane, 2 the window through the wave
 __global__ void __launch_bounds__(256) upsample_grid_sample_u8_kernel(const unsigned char *__restrict__ input,
                                                                       const float *__restrict__ field,
                                                                       unsigned char *__restrict__ out, int H, int W, int fh, int fw,
-                                                                      float ry, float rx, size_t total_groups, unsigned nblocks,
-                                                                      int ac) {
-    constexpr int PPT = 4;
-    const unsigned blk = xcd_remap(blockIdx.x, nblocks);
-    const size_t gidx_raw = (size_t)blk * 256 + threadIdx.x;
-    const bool live = gidx_raw < total_groups;   // lanes past the end keep running (on the last group): the wave shuffles below want every lane
-    const size_t gidx = live ? gidx_raw : total_groups - 1;
-    const int HW = H * W;
-    const size_t p0 = gidx * PPT;
-    const int n = (int)(p0 / HW);
-    const int hw = (int)(p0 % HW);
-    const int oy = hw / W, ox0 = hw % W;  // W % 4 == 0: the group stays inside one row
+                                                                      float ry, float rx, unsigned nrg, float kx, float kx1, float ky, float ky1) {
+    // grid = (row groups padded to a multiple of 8, 256-pixel chunks of a row, samples): the XCD of a workgroup is blockIdx.x % 8 whatever
+    // y and z are, so xcd_remap on x alone keeps consecutive row groups (shared source rows) on one L2.  A wave = one output row's chunk:
+    // sample, row, the field's row pair and its vertical weights are wave-uniform -- no division anywhere, scalar base addresses.
+    // (Several rows per wave, one after the other or as a software pipeline over the rows, bought nothing: measured, docs/ROUNDS.md.)
+    const unsigned rg = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned oy = __builtin_amdgcn_readfirstlane(rg * 4u + (threadIdx.x >> 6));
+    const unsigned n = blockIdx.z;
+    if (rg >= nrg || oy >= (unsigned)H) return;
+    const int ox0 = (int)(blockIdx.y * 256u + (threadIdx.x & 63u) * 4u);
+    if (FMODE != 2 && ox0 >= W) return;   // (FMODE 2: every lane fetches and serves field columns first)
+    const unsigned row = n * (unsigned)H + oy;
     const float sy = mul_rounded(ry, (float)oy);
-    const int y0 = (int)sy, y1 = y0 + (y0 < fh - 1 ? 1 : 0);
-    const float ly = sy - y0, hy = 1.f - ly;
+    const int y0 = __builtin_amdgcn_readfirstlane((int)sy), y1 = y0 + (y0 < fh - 1 ? 1 : 0);
+    const float ly = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sy - (float)y0))), hy = 1.f - ly;
     const float2 *f0 = reinterpret_cast<const float2 *>(field) + ((size_t)n * fh + y0) * fw;
     const float2 *f1 = reinterpret_cast<const float2 *>(field) + ((size_t)n * fh + y1) * fw;
-    Taps2 t[PPT];
-    if constexpr (NARROW) {
-        const int cb = (int)mul_rounded(rx, (float)ox0);
-        float2 r0[3], r1[3];
+    const f32x2 ly2 = pk_splat(ly), hy2 = pk_splat(hy), one2 = pk_splat(1.f);
+    const float oxf = (float)ox0;   // (exact, and so are oxf + 1 .. 3: W < 2^24)
+    f32x2 gx[2], gy[2];
+    if constexpr (FMODE != 0) {
+        f32x2 sx[2], fl[2];
+        sx[0] = pk_mul_rounded(pk_splat(rx), f32x2{oxf, oxf + 1.f}), sx[1] = pk_mul_rounded(pk_splat(rx), f32x2{oxf + 2.f, oxf + 3.f});
+        fl[0] = pk_floor(sx[0]), fl[1] = pk_floor(sx[1]);   // sx >= 0: floor == the float kernel's (float)(int)sx
+        const unsigned cb = (unsigned)(int)fl[0].x;         // first field column this lane can touch; it needs cb .. cb + 2 at most
+        if constexpr (FMODE == 2) {
+            // the wave's 256 pixels span <= 62 field columns: lane L fetches column c0 + L of the row pair (2 memory instructions instead
+            // of 6 -- the launch is bound by their number, see the gathers below) and every pixel takes its four corners from the lanes that
+            // hold them (lane (x0 - c0) holds column x0, lane (x0 - c0 + 1) column min(x0 + 1, fw - 1): the values the per-lane loads return)
+            const unsigned c0 = __builtin_amdgcn_readfirstlane(cb);   // (lane 0 has the wave's smallest column)
+            const unsigned mine = min(c0 + (threadIdx.x & 63u), (unsigned)(fw - 1));
+            const float2 w0 = f0[mine], w1 = f1[mine];
+            const int w0x = __builtin_bit_cast(int, w0.x), w0y = __builtin_bit_cast(int, w0.y), w1x = __builtin_bit_cast(int, w1.x), w1y = __builtin_bit_cast(int, w1.y);
+            auto take = [](int addr, int v) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, v)); };
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int col = min(cb + k, fw - 1);
-            r0[k] = f0[col], r1[k] = f1[col];
-        }
+            for (int q = 0; q < 2; ++q) {
+                const f32x2 lx = sx[q] - fl[q], hx = one2 - lx;
+                const int j0 = ((int)fl[q].x - (int)c0) * 4, j1 = ((int)fl[q].y - (int)c0) * 4;
+                gx[q] = pk_field_lerp(hy2, ly2, hx, lx, f32x2{take(j0, w0x), take(j1, w0x)}, f32x2{take(j0 + 4, w0x), take(j1 + 4, w0x)},
+                                      f32x2{take(j0, w1x), take(j1, w1x)}, f32x2{take(j0 + 4, w1x), take(j1 + 4, w1x)});
+                gy[q] = pk_field_lerp(hy2, ly2, hx, lx, f32x2{take(j0, w0y), take(j1, w0y)}, f32x2{take(j0 + 4, w0y), take(j1 + 4, w0y)},
+                                      f32x2{take(j0, w1y), take(j1, w1y)}, f32x2{take(j0 + 4, w1y), take(j1 + 4, w1y)});
+            }
+            if (ox0 >= W) return;
+        } else {
+            float2 r0[3], r1[3];
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            const float sx = mul_rounded(rx, (float)(ox0 + i));
-            const int x0 = (int)sx;
-            const float lx = sx - x0, hx = 1.f - lx;
-            const bool second = x0 > cb;
-            const float2 a = second ? r0[1] : r0[0], b = second ? r0[2] : r0[1];
-            const float2 c = second ? r1[1] : r1[0], d = second ? r1[2] : r1[1];
-            const float gx = field_lerp(hy, ly, hx, lx, a.x, b.x, c.x, d.x);
-            const float gy = field_lerp(hy, ly, hx, lx, a.y, b.y, c.y, d.y);
-            t[i] = make_taps2(gx, gy, H, W, ac != 0);
+            for (int k = 0; k < 3; ++k) {
+                const unsigned col = min(cb + (unsigned)k, (unsigned)(fw - 1));
+                r0[k] = f0[col], r1[k] = f1[col];
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const f32x2 lx = sx[q] - fl[q], hx = one2 - lx;
+                // a pixel whose cell is the lane's second one reads columns (1, 2) of the window (pixel 0 never is)
+                const bool s0 = q == 0 ? false : fl[q].x > fl[0].x, s1 = fl[q].y > fl[0].x;
+                const float2 a0 = s0 ? r0[1] : r0[0], b0 = s0 ? r0[2] : r0[1], c0 = s0 ? r1[1] : r1[0], d0 = s0 ? r1[2] : r1[1];
+                const float2 a1 = s1 ? r0[1] : r0[0], b1 = s1 ? r0[2] : r0[1], c1 = s1 ? r1[1] : r1[0], d1 = s1 ? r1[2] : r1[1];
+                gx[q] = pk_field_lerp(hy2, ly2, hx, lx, f32x2{a0.x, a1.x}, f32x2{b0.x, b1.x}, f32x2{c0.x, c1.x}, f32x2{d0.x, d1.x});
+                gy[q] = pk_field_lerp(hy2, ly2, hx, lx, f32x2{a0.y, a1.y}, f32x2{b0.y, b1.y}, f32x2{c0.y, c1.y}, f32x2{d0.y, d1.y});
+            }
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            const float sx = mul_rounded(rx, (float)(ox0 + i));
-            const int x0 = (int)sx, x1 = x0 + (x0 < fw - 1 ? 1 : 0);
-            const float lx = sx - x0, hx = 1.f - lx;
-            const float2 a = f0[x0], b = f0[x1], c = f1[x0], d = f1[x1];
-            const float gx = field_lerp(hy, ly, hx, lx, a.x, b.x, c.x, d.x);
-            const float gy = field_lerp(hy, ly, hx, lx, a.y, b.y, c.y, d.y);
-            t[i] = make_taps2(gx, gy, H, W, ac != 0);
+        for (int q = 0; q < 2; ++q) {
+            const f32x2 sx = pk_mul_rounded(pk_splat(rx), f32x2{oxf + (float)(2 * q), oxf + (float)(2 * q + 1)});
+            const f32x2 fl = pk_floor(sx), lx = sx - fl, hx = one2 - lx;
+            const unsigned xa = (unsigned)(int)fl.x, xb = (unsigned)(int)fl.y;
+            const unsigned xa1 = xa + ((int)xa < fw - 1 ? 1u : 0u), xb1 = xb + ((int)xb < fw - 1 ? 1u : 0u);
+            const float2 a0 = f0[xa], b0 = f0[xa1], c0 = f1[xa], d0 = f1[xa1];
+            const float2 a1 = f0[xb], b1 = f0[xb1], c1 = f1[xb], d1 = f1[xb1];
+            gx[q] = pk_field_lerp(hy2, ly2, hx, lx, f32x2{a0.x, a1.x}, f32x2{b0.x, b1.x}, f32x2{c0.x, c1.x}, f32x2{d0.x, d1.x});
+            gy[q] = pk_field_lerp(hy2, ly2, hx, lx, f32x2{a0.y, a1.y}, f32x2{b0.y, b1.y}, f32x2{c0.y, c1.y}, f32x2{d0.y, d1.y});
         }
     }
-    const unsigned char *ip = input + (size_t)n * HW * 3;
-    unsigned char res[PPT * 3];
-    // (ulo, uhi): bytes 0..3 and 4..5 of the pixel pair of row 0; (vlo, vhi): row 1.  Pixel x = bytes 0..2, pixel x + 1 = bytes 3..5.
-    auto blend = [&](int i, unsigned ulo, unsigned uhi, unsigned vlo, unsigned vhi) {
+    // un-normalisation (unnormalize above: one fma) and the tap weights, a pixel pair at a time
+    // (kx, kx1, ky, ky1: unnormalize()'s constants 0.5 * size or 0.5 * (size - 1), the same fp32 products formed by the launcher)
+    const unsigned W3 = 3u * (unsigned)W;
+    const unsigned char *ip = input + (size_t)n * H * W3;
+    unsigned ulo[4], uhi[4], vlo[4], vhi[4], off[2][4];
+    f32x2 wa0[2], wb0[2], wa1[2], wb1[2];
+    f32x2 fx[2], fy[2], wx0[2], wx1[2], wy0[2], wy1[2];
+    int x0[4], y0i[4];
+    bool inner = true;   // this lane's 4 pixels have all four taps inside the frame
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const f32x2 ix = pk_fma(gx[q], pk_splat(kx), pk_splat(kx1)), iy = pk_fma(gy[q], pk_splat(ky), pk_splat(ky1));
+        fx[q] = pk_floor(ix), fy[q] = pk_floor(iy);
+        wx1[q] = ix - fx[q], wx0[q] = one2 - wx1[q], wy1[q] = iy - fy[q], wy0[q] = one2 - wy1[q];
+        x0[2 * q] = (int)fx[q].x, x0[2 * q + 1] = (int)fx[q].y, y0i[2 * q] = (int)fy[q].x, y0i[2 * q + 1] = (int)fy[q].y;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            inner = inner && (unsigned)x0[2 * q + e] <= (unsigned)(W - 2) && (unsigned)y0i[2 * q + e] <= (unsigned)(H - 2);
+    }
+    // Border logic only where a wave needs it (wave-uniform branch): with every tap of every lane inside the frame the weights are the plain
+    // products and the offsets need no clamps -- the same values make_taps_u8 returns for such pixels, 12 instructions per pixel fewer.
+    if (H >= 2 && __builtin_amdgcn_ballot_w64(!inner) == 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            wa0[q] = wx0[q] * wy0[q], wb0[q] = wx1[q] * wy0[q], wa1[q] = wx0[q] * wy1[q], wb1[q] = wx1[q] * wy1[q];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const unsigned x = (unsigned)x0[2 * q + e];
+                off[0][2 * q + e] = __umul24((unsigned)y0i[2 * q + e], W3) + (x + 2u * x);
+                off[1][2 * q + e] = off[0][2 * q + e] + W3;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const TapsU8 ta = make_taps_u8(wx0[q].x, wx1[q].x, fx[q].x, wy0[q].x, wy1[q].x, fy[q].x, H, W, W3);
+            const TapsU8 tb = make_taps_u8(wx0[q].y, wx1[q].y, fx[q].y, wy0[q].y, wy1[q].y, fy[q].y, H, W, W3);
+            off[0][2 * q] = ta.o0, off[1][2 * q] = ta.o1, off[0][2 * q + 1] = tb.o0, off[1][2 * q + 1] = tb.o1;
+            const f32x2 wl = {ta.wl, tb.wl}, wr = {ta.wr, tb.wr}, r0 = {ta.r0, tb.r0}, r1 = {ta.r1, tb.r1};
+            wa0[q] = wl * r0, wb0[q] = wr * r0, wa1[q] = wl * r1, wb1[q] = wr * r1;
+        }
+    }
+    // The two horizontally adjacent source pixels of a row are 6 consecutive bytes at any byte offset: ONE aligned 12-byte load (the dword the
+    // pair starts in and the two behind it) + two v_alignbyte.  The launch is bound by its vector MEMORY instructions, not by bytes: a
+    // 4-byte + a 2-byte unaligned load per pair (23 memory instructions per lane) ran 35 us whether the arithmetic took 613 or 309
+    // instructions; one unaligned 8-byte load per pair 27 us; aligned loads cost about half an unaligned one (timing-only ablation: -5 us).
+    // Up to 8 bytes behind the pair are read and not used: only for the last THREE pixel pairs of the last row of the LAST sample are they
+    // outside the caller's buffer, so a wave of that sample in which some lane reads there takes exact 4 + 2-byte loads instead
+    // (wave-uniform branch; the other samples' waves do not even test).
+    bool exact = false;
+    if (n + 1 == gridDim.z) {
+        unsigned m = off[1][0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) m = max(m, off[1][i]);   // (row 1 of a pixel is never above its row 0)
+        exact = __builtin_amdgcn_ballot_w64((m & ~3u) + 12u > (unsigned)H * W3) != 0;
+    }
+    if (!exact) {
+        unsigned a[2][4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const U32x3 t = *reinterpret_cast<const U32x3 *>(ip + (off[r][i] & ~3u));
+                a[r][i][0] = t.x, a[r][i][1] = t.y, a[r][i][2] = t.z;
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // (v_alignbyte shifts by the low two bits of its third operand)
+            ulo[i] = __builtin_amdgcn_alignbyte(a[0][i][1], a[0][i][0], off[0][i]), uhi[i] = __builtin_amdgcn_alignbyte(a[0][i][2], a[0][i][1], off[0][i]);
+            vlo[i] = __builtin_amdgcn_alignbyte(a[1][i][1], a[1][i][0], off[1][i]), vhi[i] = __builtin_amdgcn_alignbyte(a[1][i][2], a[1][i][1], off[1][i]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ulo[i] = reinterpret_cast<const U8x4 *>(ip + off[0][i])->v, uhi[i] = reinterpret_cast<const U8x2 *>(ip + off[0][i] + 4)->v;
+            vlo[i] = reinterpret_cast<const U8x4 *>(ip + off[1][i])->v, vhi[i] = reinterpret_cast<const U8x2 *>(ip + off[1][i] + 4)->v;
+        }
+    }
+    // blend: (ulo, uhi) = bytes 0..3 and 4..5 of the pixel pair of row 0, (vlo, vhi) of row 1; source pixel x = bytes 0..2, x + 1 = bytes 3..5.
+    // One explicit fma chain per value: the same rounding in every instantiation and in the float kernel (a byte flips where the blend lands
+    // on an integer).
+    unsigned ow[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int ci = SWAP ? 2 - c : c;   // compile-time
-            const float ux = (float)((ulo >> (8 * ci)) & 0xffu), vx = (float)((vlo >> (8 * ci)) & 0xffu);
-            const float uy = ci == 0 ? (float)(ulo >> 24) : (float)((uhi >> (8 * (ci - 1))) & 0xffu);
-            const float vy = ci == 0 ? (float)(vlo >> 24) : (float)((vhi >> (8 * (ci - 1))) & 0xffu);
-            // one explicit fma chain: the same rounding in every instantiation and on both paths (left to the compiler, the
-            // contraction of this sum differed between them -- a byte flips where the blend lands on an integer)
-            const float r = fmaf(vy, t[i].b1, fmaf(vx, t[i].a1, fmaf(uy, t[i].b0, ux * t[i].a0)));
-            res[i * 3 + c] = (unsigned char)min(max((int)r, 0), 255);
-        }
-    };
-    bool fast = false;
-    if constexpr (ROWWIN) {
-        int lo = t[0].xs, hi_ = t[0].xs;
-        bool same = true;
-#pragma unroll
-        for (int i = 1; i < PPT; ++i) {
-            lo = min(lo, t[i].xs), hi_ = max(hi_, t[i].xs);
-            same = same && t[i].r0 == t[0].r0 && t[i].r1 == t[0].r1;
-        }
-        // the window must not run past the frame buffer: 16 (+4 shuffled) bytes from the window start
-        const size_t row_end = (size_t)HW * 3;
-        const bool in_buf = ((size_t)t[0].r0 * W + lo) * 3 + 16 <= row_end && ((size_t)t[0].r1 * W + lo) * 3 + 16 <= row_end;
-        const int span = hi_ - lo;   // the pair of the last pixel ends at column lo + span + 1: bytes up to 3 (span + 2)
-        // neighbour lane's window: its second dword = bytes 16..19 of this lane's rows when it starts exactly 4 pixels further
-        const int nb_lo = __shfl_down(lo, 1, 64), nb_r0 = __shfl_down(t[0].r0, 1, 64), nb_r1 = __shfl_down(t[0].r1, 1, 64);
-        const bool nb_same = __shfl_down((int)(same && in_buf), 1, 64) != 0;
-        const bool nb_ok = (threadIdx.x & 63) != 63 && nb_same && nb_lo == lo + 4 && nb_r0 == t[0].r0 && nb_r1 == t[0].r1;
-        const bool want = same && in_buf && (span <= 3 || (span == 4 && nb_ok));
-        // every lane that could be a window lane loads (the shuffle needs the neighbour's dwords whatever its own verdict)
-        unsigned w0[5] = {0u, 0u, 0u, 0u, 0u}, w1[5] = {0u, 0u, 0u, 0u, 0u};
-        if (same && in_buf) {
-            const U8x16 a = *reinterpret_cast<const U8x16 *>(ip + ((size_t)t[0].r0 * W + lo) * 3);
-            const U8x16 b = *reinterpret_cast<const U8x16 *>(ip + ((size_t)t[0].r1 * W + lo) * 3);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) w0[k] = a.w[k], w1[k] = b.w[k];
-        }
-        w0[4] = __shfl_down(w0[1], 1, 64), w1[4] = __shfl_down(w1[1], 1, 64);
-        fast = want;
-        if (fast) {
-#pragma unroll
-            for (int i = 0; i < PPT; ++i) {
-                const int d = (t[i].xs - lo) * 3;        // byte offset of the pixel pair inside the window: 0, 3, .. 12
-                const int k = d >> 2, sh = d & 3;
-                // dwords k, k + 1, k + 2 of the (extended) window, selected without dynamic register indexing
-                const unsigned a0 = k == 0 ? w0[0] : (k == 1 ? w0[1] : (k == 2 ? w0[2] : w0[3]));
-                const unsigned a1 = k == 0 ? w0[1] : (k == 1 ? w0[2] : (k == 2 ? w0[3] : w0[4]));
-                const unsigned a2 = k == 0 ? w0[2] : (k == 1 ? w0[3] : w0[4]);
-                const unsigned b0 = k == 0 ? w1[0] : (k == 1 ? w1[1] : (k == 2 ? w1[2] : w1[3]));
-                const unsigned b1 = k == 0 ? w1[1] : (k == 1 ? w1[2] : (k == 2 ? w1[3] : w1[4]));
-                const unsigned b2 = k == 0 ? w1[2] : (k == 1 ? w1[3] : w1[4]);
-                blend(i, __builtin_amdgcn_alignbyte(a1, a0, sh), __builtin_amdgcn_alignbyte(a2, a1, sh), __builtin_amdgcn_alignbyte(b1, b0, sh),
-                      __builtin_amdgcn_alignbyte(b2, b1, sh));
+            const int i = 2 * q, j = 2 * q + 1;
+            const f32x2 ux = {(float)((ulo[i] >> (8 * ci)) & 0xffu), (float)((ulo[j] >> (8 * ci)) & 0xffu)};
+            const f32x2 vx = {(float)((vlo[i] >> (8 * ci)) & 0xffu), (float)((vlo[j] >> (8 * ci)) & 0xffu)};
+            const f32x2 uy = {ci == 0 ? (float)(ulo[i] >> 24) : (float)((uhi[i] >> (8 * (ci - 1))) & 0xffu),
+                              ci == 0 ? (float)(ulo[j] >> 24) : (float)((uhi[j] >> (8 * (ci - 1))) & 0xffu)};
+            const f32x2 vy = {ci == 0 ? (float)(vlo[i] >> 24) : (float)((vhi[i] >> (8 * (ci - 1))) & 0xffu),
+                              ci == 0 ? (float)(vlo[j] >> 24) : (float)((vhi[j] >> (8 * (ci - 1))) & 0xffu)};
+            const f32x2 r = pk_fma(vy, wb1[q], pk_fma(vx, wa1[q], pk_fma(uy, wb0[q], ux * wa0[q])));
+            const int bi = i * 3 + c, bj = j * 3 + c;   // byte positions inside the lane's 12 output bytes (compile-time)
+            if constexpr (PKU8) {
+                cvt_u8_into(bi & 3, ow[bi >> 2], r.x), cvt_u8_into(bj & 3, ow[bj >> 2], r.y);
+            } else {
+                ow[bi >> 2] |= (unsigned)min(max((int)r.x, 0), 255) << (8 * (bi & 3));
+                ow[bj >> 2] |= (unsigned)min(max((int)r.y, 0), 255) << (8 * (bj & 3));
             }
         }
     }
-    if (!fast) {
-#pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            // the two horizontally adjacent source pixels of a row are 6 consecutive bytes: one 4-byte + one 2-byte unaligned load
-            const unsigned char *q0 = ip + (size_t)t[i].o0 * 3, *q1 = ip + (size_t)t[i].o1 * 3;
-            blend(i, reinterpret_cast<const U8x4 *>(q0)->v, reinterpret_cast<const U8x2 *>(q0 + 4)->v, reinterpret_cast<const U8x4 *>(q1)->v,
-                  reinterpret_cast<const U8x2 *>(q1 + 4)->v);
-        }
-    }
-    if (!live) return;
-    unsigned *op = reinterpret_cast<unsigned *>(out + ((size_t)n * HW + hw) * 3);  // 12 bytes, 4-byte aligned (hw % 4 == 0)
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-        op[k] = (unsigned)res[4 * k] | ((unsigned)res[4 * k + 1] << 8) | ((unsigned)res[4 * k + 2] << 16) | ((unsigned)res[4 * k + 3] << 24);
+    unsigned *op = reinterpret_cast<unsigned *>(out + ((size_t)row * W) * 3) + 3u * ((unsigned)ox0 >> 2);  // 12 bytes, 4-byte aligned (W % 4 == 0)
+    op[0] = ow[0], op[1] = ow[1], op[2] = ow[2];
 }
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
@@ -859,33 +960,40 @@ extern "C" int pws_upsample_grid_sample_u8(const unsigned char *frame_hwc, const
     PWS_REQUIRE((reinterpret_cast<size_t>(out_hwc) & 3) == 0, "pws_upsample_grid_sample_u8: out must be 4-byte aligned");
     const float ry = h > 1 ? (float)(fh - 1) / (float)(h - 1) : 0.f;
     const float rx = w > 1 ? (float)(fw - 1) / (float)(w - 1) : 0.f;
-    const size_t total = (size_t)n * h * w, groups = total / 4;
-    const unsigned nb = (unsigned)((groups + 255) / 256);
+    const size_t total = (size_t)n * h * w;
+    const unsigned cpr = (unsigned)((w + 255) / 256);                      // 256-pixel chunks per output row: one wave each
+    const unsigned nrg = (unsigned)((h + 3) / 4), gx = (nrg + 7u) & ~7u;   // row groups of 4 (one row per wave), padded: see the kernel
+    PWS_REQUIRE(n < 65536 && cpr < 65536 && (size_t)w * 3 < (1u << 24) && h < (1 << 24), "pws_upsample_grid_sample_u8: frame or batch too large");
     ProfScope prof(KID_UPSAMPLE_GRID_SAMPLE_U8, (double)total * (40.0 + 8.0 * 3), (double)total * 6.0 + 8.0 * (double)n * fh * fw,
                    as_stream(stream));
-    // PWS_OPT_EXPERIMENT 4: the row-window + wave-shuffle variant, kept for the A/B in DESIGN.md (tools/warp_u8_ab.py).  Measured on 8
-    // frames of 1280 x 720 (after the 32-bit byte handling above): 33.6 vs 27.2 us on a pure translation (every lane takes the
-    // window), 39.2 vs 34.7 us on a stabiliser's field, 42.6 vs 38.9 us on the random-weight generator's: 16 -> 2 memory instructions
-    // per lane buy nothing, the kernel is bound by its vector instructions (613 per lane), the variant's shuffles and selects add to
-    // them, and the lanes whose 4 pixels straddle a source row pay both paths.  The per-tap gathers stay the product path.
-    const bool rowwin = g_experiment == 4;
+    // PWS_OPT_EXPERIMENT 4: float -> byte through (int) + clamp + shift/or instead of v_cvt_pk_u8_f32 (A/B and the equality test).
+    // (Rounds 2-5 kept a row-window + wave-shuffle variant here, north_star's "wavefront shuffles for the bilinear gather": 16 -> 2 memory
+    // instructions per lane bought nothing, 33.6 vs 27.2 us on a pure translation -- the kernel is bound by its vector instructions;
+    // docs/ROUNDS.md.  The float kernel's variant stays: grid_sample_fwd2_kernel<.., ROWWIN>, tools/gs_shuffle_ab.py.)
+    const bool pku8 = g_experiment != 4;
+    const float kx = align_corners ? 0.5f * (float)(w - 1) : 0.5f * (float)w, kx1 = 0.5f * (float)(w - 1);
+    const float ky = align_corners ? 0.5f * (float)(h - 1) : 0.5f * (float)h, ky1 = 0.5f * (float)(h - 1);
     const bool narrow = 3.f * rx < 0.999f;
-#define PWS_U8_LAUNCH(NARROW_, ROWWIN_, SWAP_)                                                                                             \
-    hipLaunchKernelGGL((upsample_grid_sample_u8_kernel<NARROW_, ROWWIN_, SWAP_>), dim3(nb), dim3(256), 0, as_stream(stream), frame_hwc, field, \
-                       out_hwc, h, w, fh, fw, ry, rx, groups, nb, align_corners)
-    if (narrow && !rowwin) {
-        if (swap_rb) PWS_U8_LAUNCH(true, false, true);
-        else PWS_U8_LAUNCH(true, false, false);
-    } else if (narrow) {
-        if (swap_rb) PWS_U8_LAUNCH(true, true, true);
-        else PWS_U8_LAUNCH(true, true, false);
-    } else if (!rowwin) {
-        if (swap_rb) PWS_U8_LAUNCH(false, false, true);
-        else PWS_U8_LAUNCH(false, false, false);
+    // field access (the kernel's FMODE): 3 * rx < 1 -> a lane's 4 pixels touch <= 3 field columns; 255 * rx + 3 <= 63 -> a wave's 256 pixels touch
+    // <= 63: the wave fetches them once (1280 from 256 columns: rx = 0.199).  PWS_OPT_EXPERIMENT 49: per-lane windows (A/B)
+    const int fmode = !narrow ? 0 : (255.f * rx + 3.f <= 63.f && g_experiment != 49 ? 2 : 1);
+#define PWS_U8_LAUNCH_F(FMODE_, SWAP_, PK_)                                                                                             \
+    hipLaunchKernelGGL((upsample_grid_sample_u8_kernel<FMODE_, SWAP_, PK_>), dim3(gx, cpr, (unsigned)n), dim3(256), 0, as_stream(stream), \
+                       frame_hwc, field, out_hwc, h, w, fh, fw, ry, rx, nrg, kx, kx1, ky, ky1)
+#define PWS_U8_LAUNCH(SWAP_, PK_)                                                                                                       \
+    do {                                                                                                                                \
+        if (fmode == 2) PWS_U8_LAUNCH_F(2, SWAP_, PK_);                                                                                 \
+        else if (fmode == 1) PWS_U8_LAUNCH_F(1, SWAP_, PK_);                                                                            \
+        else PWS_U8_LAUNCH_F(0, SWAP_, PK_);                                                                                            \
+    } while (0)
+    if (pku8) {
+        if (swap_rb) PWS_U8_LAUNCH(true, true);
+        else PWS_U8_LAUNCH(false, true);
     } else {
-        if (swap_rb) PWS_U8_LAUNCH(false, true, true);
-        else PWS_U8_LAUNCH(false, true, false);
+        if (swap_rb) PWS_U8_LAUNCH(true, false);
+        else PWS_U8_LAUNCH(false, false);
     }
+#undef PWS_U8_LAUNCH_F
 #undef PWS_U8_LAUNCH
     return check_launch("upsample_grid_sample_u8_kernel");
 }

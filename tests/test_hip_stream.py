@@ -79,8 +79,8 @@ def test_u8_hwc_fused_warp(hip, shape, swap):
     d_u8, d_field = u8.cuda(), field.cuda()
     got = PF.upsample_grid_sample_u8(d_u8, d_field, swap_rb=swap).cpu()
     assert got.dtype == torch.uint8 and got.shape == u8.shape
-    # the row-window / wave-shuffle variant (PWS_OPT_EXPERIMENT 4: measured, not faster) and the per-tap gathers blend the
-    # same bytes with the same weights in the same order: byte-identical
+    # float -> byte through v_cvt_pk_u8_f32 (product) and through (int) + clamp + shift (PWS_OPT_EXPERIMENT 4): the instruction truncates
+    # and saturates like astype(uint8) of a value in [0, 255] -- byte-identical
     hip.lib().pws_set_option(hip.OPT_EXPERIMENT, 4)
     try:
         taps = PF.upsample_grid_sample_u8(d_u8, d_field, swap_rb=swap).cpu()

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""A/B of the fused 720p uint8 resize+warp (north_star: "wavefront shuffles for the bilinear gather"): the row-window variant -- one
-unaligned 16-byte load per source row and lane + the next lane's dword through a wave shuffle -- against the per-tap gathers
-(the product path; the variant is PWS_OPT_EXPERIMENT 4), on the field a stabiliser emits and on the random-weight generator's field.  Prints microseconds per
-launch of 8 frames (hipEvents through pws_prof_*), inputs rotated through 4 buffers so that they come from HBM."""
+"""The fused 720p uint8 resize+warp (upsample_grid_sample_u8_kernel) on the field a stabiliser emits, on a pure translation and on the
+random-weight generator's field: microseconds per launch of 8 frames (hipEvents through pws_prof_*), inputs rotated through 4 buffers
+so that they come from HBM.  A/B: the product path (v_cvt_pk_u8_f32 for float -> byte) against PWS_OPT_EXPERIMENT 4 ((int) + clamp +
+shift/or).  (Rounds 2-5 compared a row-window + wave-shuffle variant here -- north_star's "wavefront shuffles for the bilinear gather";
+it lost 33.6 vs 27.2 us on a pure translation and was removed with the round-6 rewrite: docs/ROUNDS.md.)"""
 import contextlib
 import os
 import sys
@@ -33,7 +34,7 @@ with torch.no_grad():
 L = A.lib()
 for name, field in fields.items():
     res = {}
-    for exp, tag in ((0, "per-tap gathers"), (4, "row window + shuffle")):
+    for exp, tag in ((0, "product"), (4, "clamp + shift")):
         L.pws_set_option(A.OPT_EXPERIMENT, exp)
         with torch.no_grad():
             for i in range(8):
