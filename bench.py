@@ -593,7 +593,7 @@ def main():
         net.module.two_queues = False if on else None
         net.module.enable_graph(not a.no_graph, per_stream=bool(on))
         if not on:
-            step()   # (switching drops the graphs: capture the default one here, not inside a later instrumented loop)
+            step()   # (the default graph is captured here, if it was not yet, and not inside a later instrumented loop)
             torch.cuda.synchronize()
 
     def on_lane(i, fn):
@@ -976,9 +976,17 @@ def main():
                 vs.run_video(u8_h[:2 * SB], chunk=SB, half_size_output=True)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                out_h = vs.run_video(u8_h, chunk=32, half_size_output=True)
+                out_1 = vs.run_video(u8_h, chunk=32, half_size_output=True)
+                torch.cuda.synchronize()
+                dt_one = time.perf_counter() - t1   # one chunk at a time (rounds 1-5; D = 1: the run below repeats it)
+                vs.run_video(u8_h[:4 * SB], chunk=SB, half_size_output=True, in_flight=D)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                out_h = vs.run_video(u8_h, chunk=32, half_size_output=True, in_flight=D)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t1
+                assert torch.equal(out_1, out_h), "chunks in flight changed the frames"
+                del out_1
                 # the three activities ALONE on the same clip (upload, the device side with resident frames, download): what the
                 # pipelined run hides.  overlap = slowest alone / pipelined wall (1.0 = the other two fully hidden)
                 u8_d = u8_h.to(dev)
@@ -994,8 +1002,9 @@ def main():
                     return time.perf_counter() - t_
                 t_up = alone(lambda: u8_d.copy_(u8_h, non_blocking=True))
                 t_down = alone(lambda: down_h.copy_(small_d, non_blocking=True))
-                t_comp = alone(lambda: vs.run_video(u8_d, chunk=32, half_size_output=True))
-                line["value_720p_stream_u8"] = {"value": round(T / dt, 1), "unit": "frames/s", "n_gpus": 1,
+                t_comp = alone(lambda: vs.run_video(u8_d, chunk=32, half_size_output=True, in_flight=D))
+                line["value_720p_stream_u8"] = {"value": round(T / dt, 1), "unit": "frames/s", "n_gpus": 1, "chunks_in_flight": D,
+                                                "value_one_in_flight": round(T / dt_one, 1),
                                                 "workload": "%d uint8 1280x720 frames, pinned host -> device (2.76 MB per frame) -> gray+"
                                                             "INTER_AREA window planes on the device -> batch %d windows per netG call -> "
                                                             "fused u8 warp -> 2x INTER_AREA -> pinned host (0.69 MB per frame)" % (T, SB),
@@ -1010,10 +1019,10 @@ def main():
                 assert not out_h.is_cuda and tuple(out_h.shape) == (T, 360, 640, 3)
                 if a.math == "fp32":   # the same clip with the generator on the bf16 matrix cores (an extra, never `value`)
                     net.module.set_math("bf16")
-                    vs.run_video(u8_h[:2 * SB], chunk=SB, half_size_output=True)
+                    vs.run_video(u8_h[:4 * SB], chunk=SB, half_size_output=True, in_flight=D)
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
-                    out_b = vs.run_video(u8_h, chunk=32, half_size_output=True)
+                    out_b = vs.run_video(u8_h, chunk=32, half_size_output=True, in_flight=D)
                     torch.cuda.synchronize()
                     dtb = time.perf_counter() - t1
                     net.module.set_math("fp32")
@@ -1068,10 +1077,10 @@ def main():
             u8_h = torch.randint(0, 256, (Ts, 720, 1280, 3), dtype=torch.uint8).pin_memory()
             SB = min(32, Ts)   # windows per generator call (tools/stream_sweep.py: 32 is the fastest of 8 / 16 / 32)
             vs = VideoStabilizer(net, batch=SB, swap_rb=True)
-            vs.run_video(u8_h[:min(Ts, 2 * SB)], chunk=SB, half_size_output=True)
+            vs.run_video(u8_h[:min(Ts, 4 * SB)], chunk=SB, half_size_output=True, in_flight=D)
             barrier()
             t1 = time.perf_counter()
-            out_h = vs.run_video(u8_h, chunk=32, half_size_output=True)
+            out_h = vs.run_video(u8_h, chunk=32, half_size_output=True, in_flight=D)
             torch.cuda.synchronize()
             dts = time.perf_counter() - t1
             barrier()
@@ -1080,8 +1089,8 @@ def main():
             if rank == 0:
                 line["value_720p_stream_u8"] = {"value": round(world * Ts / float(t.item()), 1), "unit": "frames/s", "n_gpus": world,
                                                 "workload": "%d uint8 1280x720 frames per GPU, pinned host -> device -> window planes, netG fp32 "
-                                                            "(batch %d), fused u8 warp, 2x INTER_AREA -> pinned host; frame-sharded, no "
-                                                            "collective" % (Ts, SB)}
+                                                            "(batch %d, %d chunks in flight), fused u8 warp, 2x INTER_AREA -> pinned host; "
+                                                            "frame-sharded, no collective" % (Ts, SB, D)}
             del u8_h, out_h, vs
         except StopIteration:
             pass

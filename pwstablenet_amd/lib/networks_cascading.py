@@ -196,13 +196,12 @@ class UnetGenerator(nn.Module):
         forward are captured once per (batch, weight version, mode) and replayed as one graph launch.  The graph owns its
         activation arena and its output buffer; every call returns a fresh tensor (a 0.5 MB/frame device copy) unless
         ``alias_output=True``, in which case the returned field is the graph's own buffer and is OVERWRITTEN by the next call."""
-        if bool(per_stream) != getattr(self, "_graph_per_stream", False):
-            self._graph, self._graphs = None, {}
         self._graph_mode = bool(on)
         self._graph_alias = bool(alias_output)
         # per_stream: one graph + arena per calling STREAM instead of one in all, for callers that keep several batches in flight by issuing
         # consecutive calls on different streams (bench.py --in-flight 2).  Default: one graph, replayed on whatever stream the caller is on --
-        # safe as long as the caller's calls are ordered (one stream, or streams that wait for each other).
+        # safe as long as the caller's calls are ordered (one stream, or streams that wait for each other).  Switching between the two keeps what
+        # was captured (the shared graph lives in slot 0, a stream's graph in the slot of its handle: separate arenas).
         self._graph_per_stream = bool(per_stream)
         if not on:
             self._graph, self._graphs = None, {}

@@ -81,6 +81,7 @@ class VideoStabilizer:
         # grid_sample follows the generator's coordinate convention (UnetGenerator.align_corners: torch >= 1.3 default False;
         # True for checkpoints trained under the reference's pinned torch 0.4)
         self.align_corners = bool(getattr(getattr(netG, "module", netG), "align_corners", False))
+        self._lanes = []   # compute streams of run_video(in_flight > 1)
 
     def _pad(self, gray, halo_left, halo_right):
         """Replicates the first / last available frame so that every frame owns a full window (reference :627-633)."""
@@ -160,7 +161,7 @@ class VideoStabilizer:
 
     @torch.no_grad()
     def run_video(self, frames, chunk=32, half_size_output=False, frames_are_rgb=False, halo_left=0, halo_right=0, crop=None,
-                  output_size=None):
+                  output_size=None, in_flight=1):
         """The whole device side of the reference's ``process()`` loop for one decoded clip: ``frames`` (T, H, W, 3) uint8 as
         cv2 delivers them, in (pinned) host memory or on the device.  Per chunk of ``chunk`` frames: H2D on a side stream,
         gray + INTER_AREA 256x256 window planes computed there from the uploaded frames (so nothing but the uint8 frames
@@ -176,6 +177,9 @@ class VideoStabilizer:
         that follows in the reference (:731) is the identity on 8-bit frames and is not run.
         output_size = (width, height): the reference's ``cv2.resize(samples, (640, 360), INTER_AREA)`` for ANY source size
         (main_new.py:723; half_size_output=True is the same thing for a 1280 x 720 source).
+        in_flight = 2: consecutive chunks compute on two streams without waiting for each other (one chunk walks the generator's chain of
+        small levels while the other's large layers fill the chip: DESIGN.md section 8); for the duration of the call the generator runs one
+        queue per forward and, in graph mode, keeps one graph + arena per stream.  Same frames bit for bit as in_flight = 1.
         Returns (T, H, W, 3) -- or (T, H/2, W/2, 3) / (T, height, width, 3), or the crop window of it -- uint8 on the inputs' side."""
         half = self.period // 2
         if not (0 <= halo_left <= half and 0 <= halo_right <= half):
@@ -209,6 +213,22 @@ class VideoStabilizer:
             return out
         compute = torch.cuda.current_stream(dev)
         up, down = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        in_flight = max(1, int(in_flight))
+        # (the lanes live as long as this object: the generator keeps an arena / a graph per STREAM, and torch's allocator a pool per stream)
+        # The caller's stream is lane 0: the runtime deals streams to a handful of hardware queues, and a lane that shares its queue with
+        # the upload or the download stream waits behind their copies (two NEW lanes beside up / down: 1 744 -> 1 291 frames/s).
+        while len(self._lanes) < in_flight - 1:
+            self._lanes.append(torch.cuda.Stream(dev))
+        lanes = [compute] + self._lanes[:in_flight - 1]
+        mod = getattr(self.net, "module", self.net)
+        restore = None
+        if in_flight > 1:
+            restore = (mod._graph_mode, mod._graph_alias, getattr(mod, "_graph_per_stream", False), mod.two_queues)
+            mod.two_queues = False   # two forwards that both fork into the device's one side queue would serialise there
+            if mod._graph_mode:
+                mod.enable_graph(True, mod._graph_alias, per_stream=True)
+            for lane in lanes[1:]:
+                lane.wait_stream(compute)
         gray_all = torch.empty((n_all, 256, 256), device=dev, dtype=torch.float32)
         # chunk bounds in the index space of `frames`: the first / last chunk carry the halo frames with them
         chunks = [(s if s > halo_left else 0, min(halo_left + T, s + chunk) if s + chunk < halo_left + T else n_all)
@@ -224,38 +244,48 @@ class VideoStabilizer:
                 ev.record(up)
             return buf, ev
         staged, uploaded = {}, 0
-        for c, (s, e) in enumerate(chunks):
-            # a chunk's windows reach `half` frames past its end: every chunk that holds one of those frames must be on the
-            # device (and its planes computed) first; one chunk further ahead keeps the upload stream busy during this compute
-            need = min(n_all, e + half)
-            while uploaded < len(chunks) and (chunks[uploaded][0] < need or uploaded <= c + 1):
-                staged[uploaded] = upload(uploaded)
-                uploaded += 1
-            for k in range(c, uploaded):
-                if chunks[k][0] < need:
-                    compute.wait_event(staged[k][1])
-            buf, ev = staged.pop(c)
-            # core frames of this chunk (the halo frames at the clip's ends are uploaded with it but not stabilised)
-            cs, ce = max(s, halo_left), min(e, halo_left + T)
-            hl, hr = min(half, cs), min(half, n_all - ce)
-            warped = self.run(gray_all[cs - hl:ce + hr], buf[cs - s:ce - s], halo_left=hl, halo_right=hr)
-            if half_size_output:
-                warped = area_half(warped)
-            elif output_size is not None and (oh, ow) != (h, w):
-                warped = area_resize(warped, (ow, oh))
-            if crop is not None:
-                warped = warped[:, cy0:cy1, cx0:cx1, :].contiguous()   # packed on the device: only the window crosses PCIe
-            s, e = cs - halo_left, ce - halo_left   # position in the output
-            if on_host:
-                buf.record_stream(compute)
-                done = torch.cuda.Event()
-                done.record(compute)
-                with torch.cuda.stream(down):
-                    down.wait_event(done)
-                    out[s:e].copy_(warped, non_blocking=True)
-                warped.record_stream(down)
-            else:
-                out[s:e].copy_(warped)
+        try:
+            for c, (s, e) in enumerate(chunks):
+                lane = lanes[c % len(lanes)]
+                # a chunk's windows reach `half` frames past its end: every chunk that holds one of those frames must be on the
+                # device (and its planes computed) first; one chunk further ahead keeps the upload stream busy during this compute
+                need = min(n_all, e + half)
+                while uploaded < len(chunks) and (chunks[uploaded][0] < need or uploaded <= c + 1):
+                    staged[uploaded] = upload(uploaded)
+                    uploaded += 1
+                for k in range(c, uploaded):
+                    if chunks[k][0] < need:
+                        lane.wait_event(staged[k][1])
+                # (planes of EARLIER chunks that this one's windows reach back into were produced before staged[c]'s event on the same stream)
+                buf, ev = staged.pop(c)
+                # core frames of this chunk (the halo frames at the clip's ends are uploaded with it but not stabilised)
+                cs, ce = max(s, halo_left), min(e, halo_left + T)
+                hl, hr = min(half, cs), min(half, n_all - ce)
+                with torch.cuda.stream(lane):
+                    warped = self.run(gray_all[cs - hl:ce + hr], buf[cs - s:ce - s], halo_left=hl, halo_right=hr)
+                    if half_size_output:
+                        warped = area_half(warped)
+                    elif output_size is not None and (oh, ow) != (h, w):
+                        warped = area_resize(warped, (ow, oh))
+                    if crop is not None:
+                        warped = warped[:, cy0:cy1, cx0:cx1, :].contiguous()   # packed on the device: only the window crosses PCIe
+                    s, e = cs - halo_left, ce - halo_left   # position in the output
+                    if on_host:
+                        buf.record_stream(lane)
+                        done = torch.cuda.Event()
+                        done.record(lane)
+                        with torch.cuda.stream(down):
+                            down.wait_event(done)
+                            out[s:e].copy_(warped, non_blocking=True)
+                        warped.record_stream(down)
+                    else:
+                        out[s:e].copy_(warped)
+        finally:
+            if restore is not None:
+                for lane in lanes[1:]:
+                    compute.wait_stream(lane)   # the caller's stream sees every chunk; gray_all and the outputs may be freed behind it
+                mod.two_queues = restore[3]
+                mod.enable_graph(restore[0], restore[1], per_stream=restore[2])
         if on_host:
             down.synchronize()
         return out

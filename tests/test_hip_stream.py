@@ -193,6 +193,29 @@ def test_run_video_equals_run_on_host_prepared_planes(hip, on_host, half_out):
     assert d.max() <= 1 and np.mean(d > 0) < 1e-3, (d.max(), float(np.mean(d > 0)))
 
 
+@pytest.mark.parametrize("on_host,graph", [(True, True), (False, True), (True, False)])
+def test_run_video_two_chunks_in_flight(hip, on_host, graph):
+    """run_video(in_flight=2): consecutive chunks compute on two streams (one queue per forward, one graph + arena per stream for the call's
+    duration) -- the same frames bit for bit as one chunk at a time, ragged last chunk included; the generator's settings are restored."""
+    from pwstablenet_amd.stream import VideoStabilizer
+    net = make_net()
+    T, H, W = 45, 288, 320
+    frames = torch.from_numpy(_clip_u8(T, H, W, 13))
+    src = frames.pin_memory() if on_host else frames.cuda()
+    vs = VideoStabilizer(net, batch=8, swap_rb=True)
+    net.module.enable_graph(graph)
+    try:
+        want = vs.run_video(src, chunk=8, half_size_output=True)
+        for k in (2, 3):
+            got = vs.run_video(src, chunk=8, half_size_output=True, in_flight=k)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), k
+            assert net.module.two_queues is None and net.module._graph_mode == graph and not net.module._graph_per_stream
+        assert torch.equal(vs.run_video(src, chunk=8, half_size_output=True), want)
+    finally:
+        net.module.enable_graph(False)
+
+
 def test_run_video_crop_window(hip):
     """The reference's crop of the output frame (main_new.py:607-610,729-730) as an argument of run_video: sliced on the device
     before the copy back; the live values of the reference (the whole 640x360 frame, threshold 0) change nothing."""
