@@ -72,6 +72,7 @@ def parse():
                     help="conv arithmetic of the TIMED region (default fp32 = configs[1], the headline); bf16 is for profiling the "
                          "bf16 path: metric/dtype fields say so and vs_baseline stays null")
     ap.add_argument("--no-extra", action="store_true", help="skip the bf16 inference / training-step legs (extra JSON fields)")
+    ap.add_argument("--experiment", type=int, default=0, help="PWS_OPT_EXPERIMENT for the whole run (A/B switches of the library; 0 = product)")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="batches in flight in the inference legs: consecutive steps alternate over this many streams (one hipGraph + arena per stream, one "
                          "queue per forward), so that one batch's large layers fill the CUs the other batch's chain of short launches leaves idle; "
@@ -565,6 +566,8 @@ def main():
 
     if a.serial:
         A.lib().pws_set_option(A.OPT_TWO_QUEUES, 0)
+    if a.experiment:
+        A.lib().pws_set_option(A.OPT_EXPERIMENT, a.experiment)   # (captured graphs keep the kernel selection of their capture)
     net.module.enable_graph(not a.no_graph)  # the ~75 launches of a forward replay as one hipGraph launch
     # Batches in flight (round 6): the K steps are independent batches, so step i is issued on stream i % D without waiting for step i - 1
     # (one graph + arena per stream: UnetGenerator keeps them per stream; one queue per forward -- two forwards that both fork into the
