@@ -59,7 +59,8 @@ def test_stream_equals_per_frame_loop(hip):
     assert one.shape == frames[:1].shape
 
 
-@pytest.mark.parametrize("shape", [(2, 72, 128), (1, 720, 1280), (3, 37, 52)])
+# (field access of the kernel by the frame width: 128 and 52 columns -> four corners per pixel; 896 -> a 3-column window per lane; 1280 -> the wave's shared row pair)
+@pytest.mark.parametrize("shape", [(2, 72, 128), (1, 720, 1280), (3, 37, 52), (2, 90, 896)])
 @pytest.mark.parametrize("swap", [False, True])
 def test_u8_hwc_fused_warp(hip, shape, swap):
     """uint8 HWC frames (what cv2 hands over, main_new.py:679-721): [BGR->RGB] -> float CHW -> grid_sample(resized field) ->
@@ -87,6 +88,13 @@ def test_u8_hwc_fused_warp(hip, shape, swap):
     finally:
         hip.lib().pws_set_option(hip.OPT_EXPERIMENT, 0)
     assert torch.equal(got, taps)
+    # per-lane field windows (PWS_OPT_EXPERIMENT 49) instead of the wave's shared row pair: the same field values, the same bytes
+    hip.lib().pws_set_option(hip.OPT_EXPERIMENT, 49)
+    try:
+        lanes = PF.upsample_grid_sample_u8(d_u8, d_field, swap_rb=swap).cpu()
+    finally:
+        hip.lib().pws_set_option(hip.OPT_EXPERIMENT, 0)
+    assert torch.equal(got, lanes)
     # (a) the float HIP path + truncation: same taps and weights; the 4-term blend may be contracted into FMAs differently
     # by the compiler in the two kernels, so a value within 1e-3 of an integer may truncate to the neighbour
     fl = d_u8.float().permute(0, 3, 1, 2)
